@@ -1,0 +1,211 @@
+/* metacache_amd.h -- C ABI of the MI355X-native MetaCache query hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch types.
+ * Every entry point names the reference interface (file:line under muellan/metacache src/) it
+ * replaces.  The library behind it is hand-written HIP for gfx950; there is NO CPU fallback: every
+ * call that needs the GPU fails with MC_ERR_HIP if no device is usable.
+ *
+ * Pipeline per batch of queries (a query = one read or one read pair):
+ *   sketch_probe kernel : windows -> 2-bit/LDS -> canonical k-mers -> min-hash sketch -> bucket probe
+ *   scan                : per-query hit counts -> segment offsets
+ *   sort_candidates     : gather location lists -> sort (tgt,win) -> contiguous-window-range
+ *                         candidates -> top-K                (semantics = reference CPU classifier)
+ *
+ * Threading: one mc_ctx per (process, device).  mc_batch_* calls are thread-safe for DISTINCT slots
+ * (one slot per host thread, like one query_handler / query_host_data per thread in the reference,
+ * database_query.hpp:204-205, query_batch.cuh:369-371); mc_batch_submit is serialised internally.
+ */
+#ifndef METACACHE_AMD_H_
+#define METACACHE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes: 0 ok, >0 recoverable, <0 fatal; nothing throws or exits across this ABI
+ * (reference: C++ exceptions main.cpp:65-77, CUERR exit(1) cuda_helpers.cuh:18-26) */
+#define MC_OK               0
+#define MC_BATCH_FULL       1   /* mc_batch_add: query does not fit, submit first (query_batch.cuh:126-132) */
+#define MC_ERR_INVALID     -1
+#define MC_ERR_HIP         -2
+#define MC_ERR_NOMEM       -3
+#define MC_ERR_IO          -4
+#define MC_ERR_UNSUPPORTED -5
+#define MC_ERR_STATE       -6
+
+#define MC_NUM_RANKS 21          /* taxonomy.hpp:103 */
+#define MC_MAX_SKETCH 32         /* features per window handled on device */
+#define MC_MAX_WINLEN 1024       /* characters per window handled on device */
+
+typedef struct mc_ctx mc_ctx;
+
+/* One top candidate = match_candidate minus the host pointer (candidate_structs.hpp:80-104).
+ * Unused trailing entries of a query have hits == 0 (consumers stop at hits > 0, printing.cpp:291). */
+typedef struct {
+    uint32_t tgt;   /* target id                         */
+    uint32_t hits;  /* number of location hits in range  */
+    uint32_t beg;   /* first window of the range         */
+    uint32_t end;   /* last window of the range (incl.)  */
+} mc_candidate;
+
+/* One location = database::location (database.hpp:136-166), always widened to 2 x u32 on device;
+ * as a little-endian u64 it reads (tgt << 32) | win, i.e. location::operator< is integer <. */
+typedef struct {
+    uint32_t win;
+    uint32_t tgt;
+} mc_location;
+
+typedef struct {
+    int32_t  device;                 /* HIP device ordinal */
+    /* query sketching (sketching_options, hash_dna.hpp:99-163); kmerlen must equal the DB's */
+    uint32_t kmerlen;                /* <= 16 */
+    uint32_t sketchlen;              /* <= MC_MAX_SKETCH */
+    uint32_t winlen;                 /* <= MC_MAX_WINLEN */
+    uint32_t winstride;
+    /* candidate generation (candidate_structs.hpp:113-125) */
+    uint32_t max_candidates;         /* K: output stride per query; '-maxcand 0' => caller passes a cap */
+    /* table loading */
+    uint32_t target_id_bytes;        /* 2 or 4: width of target_id in mc_load_batch values (config.hpp:56-62) */
+    uint32_t num_parts;              /* database parts to be loaded (1 for now) */
+    uint32_t max_locations_per_feature; /* load-time truncation to the first n values (host_hashmap.hpp:454-466); 0 = keep */
+    uint32_t remove_overpopulated;   /* load-time: empty buckets with more than n values (host_hashmap.hpp:480-495); 0 = off */
+    float    max_load_factor;        /* hash table load factor (-max-load-fac, mode_query.cpp:49-55); 0 = default 0.8 */
+    /* host batch slots (query_batch ctor, database_query.hpp:192-202) */
+    uint32_t num_slots;
+    uint32_t slot_max_queries;
+    uint32_t slot_max_chars;
+    uint32_t copy_allhits;           /* 1: sorted location lists are copied back too (-allhits) */
+} mc_config;
+
+void mc_config_default(mc_config* cfg);
+
+/* lifetime ---------------------------------------------------------------------------------- */
+int  mc_create(const mc_config* cfg, mc_ctx** out);
+void mc_destroy(mc_ctx* ctx);
+const char* mc_last_error(const mc_ctx* ctx);   /* ctx may be NULL: error of the last failed mc_create */
+
+/* table loading: mirrors read_binary(is, featureStore_, partId, progress) (database.cpp:167-179)
+ * = hash_multimap::deserialize (hash_multimap.hpp:970-1030), batch structure as in the file
+ * (:1037-1082): per batch keys[n] (u32), sizes[n] (u8), values[sum sizes] packed
+ * {window_id win (u32); target_id tgt (u16|u32)}. */
+int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues);
+int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_t* sizes,
+                  const void* values, uint64_t nkeys_in_batch);
+int mc_load_end(mc_ctx* ctx, uint32_t part);
+
+/* convenience: database::read (database.cpp:183-242) -- reads <name>.meta (header, sketching,
+ * taxonomy -> lineages) and every <name>.cache<p>, creates the context with the DB's sketching
+ * parameters (cfg->kmerlen.. == 0 => take from DB) and loads all parts. */
+int mc_open_database(const char* name, const mc_config* cfg, mc_ctx** out);
+
+/* target lineage table (ranked_lineages_of_targets, taxonomy.hpp:919-1030; uploaded like
+ * copy_target_lineages_to_gpus gpu_hashmap.cu:1383-1396): lin[tgt*21 + rank] = taxon index + 1,
+ * 0 = none.  Needed only for lowest_rank > 0 (taxon merging, candidate_generation.hpp:203-228). */
+int mc_set_lineages(mc_ctx* ctx, const uint32_t* lin, uint64_t num_targets);
+
+/* database facts after loading: info[0..7] = k, s, w, stride (target sketching), maxLocsPerFeature,
+ * targetCount, partCount, locationCount (as stored on device) */
+int mc_db_info(const mc_ctx* ctx, uint64_t info[8]);
+
+/* taxonomy block of the .meta file as read by mc_open_database (taxonomy.hpp:702-728): taxa in file
+ * order; 'taxon index' everywhere in this ABI = position in this list.  Targets are the taxa with
+ * negative ids, id = -(target)-1 (taxonomy.hpp:930). */
+int mc_db_num_taxa(const mc_ctx* ctx, uint64_t* n);
+int mc_db_taxon(const mc_ctx* ctx, uint64_t index, int64_t* id, int64_t* parent, uint32_t* rank, const char** name);
+int mc_db_lineages(const mc_ctx* ctx, const uint32_t** lin, uint64_t* num_targets);
+
+/* host batch slots: query_batch::add_paired_read (query_batch.cuh:85-186), database::query_gpu_async
+ * (database.hpp:386-397), host_data.wait_for_results / allhits(i) / top_candidates(i) / clear
+ * (query_batch.cuh:212-259); caller code database_query.hpp:87-124 */
+int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* seq1, uint32_t len1, const char* seq2, uint32_t len2,
+                 uint32_t max_windows_in_range);
+int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowest_rank);
+
+typedef struct {
+    uint32_t num_queries;
+    uint32_t max_candidates;          /* stride of cands */
+    const mc_candidate* cands;        /* [num_queries * max_candidates], slot-owned pinned memory */
+    const uint64_t* hit_offsets;      /* [num_queries + 1] (NULL unless copy_allhits) */
+    const mc_location* hits;          /* sorted (tgt,win) lists, query i = [hit_offsets[i], hit_offsets[i+1]) */
+    const uint32_t* hit_counts;       /* [num_queries] number of location hits per query */
+} mc_results;
+
+int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out);  /* valid until mc_batch_clear(slot) */
+int mc_batch_clear(mc_ctx* ctx, uint32_t slot);
+
+/* device-resident entry point (what the slots call after their H2D copy; also used when reads are
+ * already in HBM).  All pointers are DEVICE pointers.
+ *   seq     : characters; every sequence starts 4-byte aligned; 8 readable slack bytes at the end
+ *   qinfo   : [n][4] = {offset1, len1, offset2, len2} (offsets into seq; len2 = 0 for single reads)
+ *   max_win : [n] maxWindowsInRange per query (candidate_structs.hpp:143-145), or NULL with
+ *             max_win_uniform > 0
+ * Results stay on device inside ctx-owned buffers (valid until the next call on this ctx):
+ *   cands [n * max_candidates], hit_counts [n], and -- if want_allhits -- hit_offsets [n+1] / hits.
+ * 'stream' is a hipStream_t (NULL = the context's own stream); the call is asynchronous. */
+typedef struct {
+    const uint8_t*  seq;
+    const uint32_t* qinfo;
+    const uint32_t* max_win;
+    uint32_t        max_win_uniform;
+    uint32_t        num_queries;
+    uint64_t        num_chars;        /* bytes in seq actually used (for checks) */
+} mc_device_batch;
+
+typedef struct {
+    const mc_candidate* cands;
+    const uint32_t*     hit_counts;
+    const uint64_t*     hit_offsets;
+    const mc_location*  hits;
+    const uint32_t*     features;     /* [total_windows * sketchlen] window sketches, 0xFFFFFFFF padded */
+    const uint32_t*     win_offsets;  /* [n+1] first window index of each query */
+} mc_device_results;
+
+int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int want_allhits,
+                    mc_device_results* out, void* stream);
+int mc_synchronize(mc_ctx* ctx);
+
+/* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
+ * names: "sketch_probe", "scan", "sort_candidates", "plan".  Returns accumulated milliseconds and
+ * launch counts since the last reset. */
+int mc_timing_enable(mc_ctx* ctx, int on);
+int mc_timing_reset(mc_ctx* ctx);
+int mc_timing_get(mc_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+
+/* workload statistics of the LAST mc_query_device call (device reductions, synchronises):
+ * stats[0] = total windows, [1] = valid features probed (F), [2] = locations returned (H),
+ * [3] = features found in table, [4] = probe steps (bucket groups read) */
+int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8]);
+
+/* ---- minimal database builder ------------------------------------------
+ * Needed so that synthetic databases can be produced on the GPU box itself; it re-uses the
+ * parity-proven sketch kernel.  Mirrors database::add_target (database.cpp:34-81) +
+ * host_hashmap::add_target (host_hashmap.hpp:570-589) for a SINGLE-threaded build: target ids in
+ * call order, window ids = running index of windows with >= k characters, buckets hold the first
+ * max_locations_per_feature locations in (target, window) order (host_hashmap.hpp:593-605), and
+ * database::write (database.cpp:247-325) for the file format.  cfg fields used: device, kmerlen,
+ * sketchlen, winlen, winstride, target_id_bytes, max_locations_per_feature (0 => 254). */
+typedef struct mc_builder mc_builder;
+typedef struct {
+    int64_t  id;
+    int64_t  parent;
+    uint32_t rank;          /* taxonomy::rank as integer (taxonomy.hpp:68-91), 21 = none */
+    const char* name;
+} mc_taxon_rec;
+
+int  mc_build_begin(const mc_config* cfg, mc_builder** out);
+int  mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parent_taxid,
+                         const char* source_filename);
+/* sorts + bucketises everything added so far; if out_ctx != NULL also loads the table into a fresh
+ * query context created from the builder's config merged with qcfg (may be NULL). */
+int  mc_build_finish(mc_builder* b, mc_ctx** out_ctx);
+/* writes <name>.meta and <name>.cache0 in the reference's format (after mc_build_finish) */
+int  mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa);
+void mc_build_free(mc_builder* b);
+const char* mc_build_last_error(const mc_builder* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METACACHE_AMD_H_ */

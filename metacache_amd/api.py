@@ -1,0 +1,243 @@
+"""ctypes binding of the C ABI in include/metacache_amd.h (the product's only entry points).
+
+There is deliberately no CPU path here: if libmetacache_amd.so cannot be built / loaded, or no GPU
+is usable, every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MC_OK, MC_BATCH_FULL = 0, 1
+NUM_RANKS = 21
+
+cand_dtype = np.dtype([("tgt", "<u4"), ("hits", "<u4"), ("beg", "<u4"), ("end", "<u4")])
+loc_dtype = np.dtype([("win", "<u4"), ("tgt", "<u4")])
+qstat_dtype = np.dtype([("hits", "<u4"), ("nfeat", "<u4"), ("nfound", "<u4"), ("nsteps", "<u4")])
+
+
+class McConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("kmerlen", C.c_uint32), ("sketchlen", C.c_uint32), ("winlen", C.c_uint32),
+                ("winstride", C.c_uint32), ("max_candidates", C.c_uint32), ("target_id_bytes", C.c_uint32),
+                ("num_parts", C.c_uint32), ("max_locations_per_feature", C.c_uint32), ("remove_overpopulated", C.c_uint32),
+                ("max_load_factor", C.c_float), ("num_slots", C.c_uint32), ("slot_max_queries", C.c_uint32),
+                ("slot_max_chars", C.c_uint32), ("copy_allhits", C.c_uint32)]
+
+
+class McResults(C.Structure):
+    _fields_ = [("num_queries", C.c_uint32), ("max_candidates", C.c_uint32), ("cands", C.c_void_p),
+                ("hit_offsets", C.c_void_p), ("hits", C.c_void_p), ("hit_counts", C.c_void_p)]
+
+
+class McDeviceBatch(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("qinfo", C.c_void_p), ("max_win", C.c_void_p), ("max_win_uniform", C.c_uint32),
+                ("num_queries", C.c_uint32), ("num_chars", C.c_uint64)]
+
+
+class McDeviceResults(C.Structure):
+    _fields_ = [("cands", C.c_void_p), ("hit_counts", C.c_void_p), ("hit_offsets", C.c_void_p), ("hits", C.c_void_p),
+                ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
+
+
+EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end",
+           "mc_open_database", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_lineages",
+           "mc_batch_add", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
+           "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
+           "mc_build_begin", "mc_build_add_target", "mc_build_finish", "mc_build_write", "mc_build_free", "mc_build_last_error"]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads (building first if needed) libmetacache_amd.so.  Raises if that is impossible."""
+    global _lib
+    if _lib is None:
+        path = _build.build_library()
+        L = C.CDLL(path)
+        L.mc_last_error.restype = C.c_char_p
+        L.mc_last_error.argtypes = [C.c_void_p]
+        L.mc_create.argtypes = [C.POINTER(McConfig), C.POINTER(C.c_void_p)]
+        L.mc_destroy.argtypes = [C.c_void_p]
+        L.mc_destroy.restype = None
+        L.mc_open_database.argtypes = [C.c_char_p, C.POINTER(McConfig), C.POINTER(C.c_void_p)]
+        L.mc_load_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
+        L.mc_load_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_load_end.argtypes = [C.c_void_p, C.c_uint32]
+        L.mc_set_lineages.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mc_db_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.mc_db_num_taxa.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.mc_db_taxon.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_char_p)]
+        L.mc_db_lineages.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.mc_batch_add.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32]
+        L.mc_batch_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.mc_batch_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(McResults)]
+        L.mc_batch_clear.argtypes = [C.c_void_p, C.c_uint32]
+        L.mc_query_device.argtypes = [C.c_void_p, C.POINTER(McDeviceBatch), C.c_int, C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
+        L.mc_synchronize.argtypes = [C.c_void_p]
+        L.mc_timing_enable.argtypes = [C.c_void_p, C.c_int]
+        L.mc_timing_reset.argtypes = [C.c_void_p]
+        L.mc_timing_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mc_last_batch_stats.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "mc_build_begin"):
+            L.mc_build_begin.argtypes = [C.POINTER(McConfig), C.POINTER(C.c_void_p)]
+            L.mc_build_add_target.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int64, C.c_char_p]
+            L.mc_build_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+            L.mc_build_write.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+            L.mc_build_free.argtypes = [C.c_void_p]
+            L.mc_build_free.restype = None
+        _lib = L
+    return _lib
+
+
+class McError(RuntimeError):
+    pass
+
+
+def default_config(**kw) -> McConfig:
+    cfg = McConfig()
+    lib().mc_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _view(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Database:
+    """Host-side mirror of what the reference's `database` gives the query layer
+    (database.hpp:386-408): open files, run batches, read results."""
+
+    def __init__(self, handle, cfg: McConfig):
+        self.h = C.c_void_p(handle)
+        self.cfg = cfg
+        info = np.zeros(8, dtype=np.uint64)
+        self._check(lib().mc_db_info(self.h, info.ctypes.data_as(C.c_void_p)))
+        (self.k, self.s, self.w, self.stride, self.max_locs, self.n_targets, self.n_parts, self.n_locations) = map(int, info)
+
+    # ---- construction ----------------------------------------------------------------------
+    @classmethod
+    def open(cls, name: str, **kw) -> "Database":
+        kw.setdefault("kmerlen", 0); kw.setdefault("sketchlen", 0); kw.setdefault("winlen", 0); kw.setdefault("winstride", 0)
+        cfg = default_config(**kw)
+        h = C.c_void_p()
+        rc = lib().mc_open_database(name.encode(), C.byref(cfg), C.byref(h))
+        if rc != MC_OK:
+            raise McError(f"mc_open_database({name}) -> {rc}: {lib().mc_last_error(None).decode()}")
+        return cls(h.value, cfg)
+
+    @classmethod
+    def from_handle(cls, handle, cfg) -> "Database":
+        return cls(handle, cfg)
+
+    def close(self):
+        if self.h:
+            lib().mc_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc < 0:
+            raise McError(f"metacache_amd error {rc}: {lib().mc_last_error(self.h).decode()}")
+        return rc
+
+    def info(self):
+        info = np.zeros(8, dtype=np.uint64)
+        self._check(lib().mc_db_info(self.h, info.ctypes.data_as(C.c_void_p)))
+        return list(map(int, info))
+
+    # ---- taxonomy --------------------------------------------------------------------------
+    def taxa(self):
+        n = C.c_uint64()
+        self._check(lib().mc_db_num_taxa(self.h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            tid, par, rk, nm = C.c_int64(), C.c_int64(), C.c_uint32(), C.c_char_p()
+            self._check(lib().mc_db_taxon(self.h, i, C.byref(tid), C.byref(par), C.byref(rk), C.byref(nm)))
+            out.append((tid.value, par.value, rk.value, nm.value.decode()))
+        return out
+
+    def lineages(self) -> np.ndarray:
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(lib().mc_db_lineages(self.h, C.byref(p), C.byref(n)))
+        return _view(p.value, n.value * NUM_RANKS, np.dtype("<u4")).reshape(n.value, NUM_RANKS).copy()
+
+    def max_windows_in_range(self, l1: int, l2: int = 0, insert_max: int = 0) -> int:
+        """candidate_structs.hpp:143-145 (stride = the database's window stride)"""
+        return (2 + max(l1 + l2, insert_max) // self.stride) & 0xFFFFFFFF
+
+    # ---- host slot path ---------------------------------------------------------------------
+    def query(self, reads, mates=None, lowest: int = 0, insert_max: int = 0, slot: int = 0):
+        """Runs all reads (bytes) through slot batches.
+        -> (cands[n, K] cand_dtype, hit_counts[n], allhits list or None)"""
+        L = lib()
+        n = len(reads)
+        K = self.cfg.max_candidates
+        cands = np.zeros((n, K), dtype=cand_dtype)
+        counts = np.zeros(n, dtype=np.uint32)
+        allhits = [None] * n if self.cfg.copy_allhits else None
+        start = 0
+
+        def flush(upto):
+            nonlocal start
+            self._check(L.mc_batch_submit(self.h, slot, lowest))
+            res = McResults()
+            self._check(L.mc_batch_wait(self.h, slot, C.byref(res)))
+            m = res.num_queries
+            assert m == upto - start
+            cands[start:upto] = _view(res.cands, m * K, cand_dtype).reshape(m, K)
+            counts[start:upto] = _view(res.hit_counts, m, np.dtype("<u4"))
+            if allhits is not None:
+                off = _view(res.hit_offsets, m + 1, np.dtype("<u8"))
+                hits = _view(res.hits, int(off[m]), loc_dtype)
+                for i in range(m):
+                    allhits[start + i] = hits[int(off[i]):int(off[i + 1])].copy()
+            self._check(L.mc_batch_clear(self.h, slot))
+            start = upto
+
+        for i in range(n):
+            a = bytes(reads[i]); b = bytes(mates[i]) if mates is not None else b""
+            mw = self.max_windows_in_range(len(a), len(b), insert_max)
+            rc = self._check(L.mc_batch_add(self.h, slot, a, len(a), b, len(b), mw))
+            if rc == MC_BATCH_FULL:
+                flush(i)
+                rc = self._check(L.mc_batch_add(self.h, slot, a, len(a), b, len(b), mw))
+                if rc != MC_OK:
+                    raise McError("query does not fit an empty slot")
+        flush(n)
+        return cands, counts, allhits
+
+    # ---- device path (pointers are device addresses, e.g. torch tensors' data_ptr()) ----------
+    def query_device(self, seq_ptr: int, qinfo_ptr: int, n: int, num_chars: int, max_win_ptr: int = 0, max_win_uniform: int = 0,
+                     lowest: int = 0, want_allhits: bool = False, stream: int = 0) -> McDeviceResults:
+        b = McDeviceBatch(seq_ptr, qinfo_ptr, max_win_ptr or None, max_win_uniform, n, num_chars)
+        r = McDeviceResults()
+        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits), C.byref(r), stream or None))
+        return r
+
+    def synchronize(self):
+        self._check(lib().mc_synchronize(self.h))
+
+    def timing(self, on: bool):
+        self._check(lib().mc_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._check(lib().mc_timing_reset(self.h))
+
+    def timing_get(self, kernel: str):
+        ms, cnt = C.c_double(), C.c_uint64()
+        self._check(lib().mc_timing_get(self.h, kernel.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def last_batch_stats(self):
+        st = np.zeros(8, dtype=np.uint64)
+        self._check(lib().mc_last_batch_stats(self.h, st.ctypes.data_as(C.c_void_p)))
+        return dict(windows=int(st[0]), features=int(st[1]), locations=int(st[2]), found=int(st[3]), probe_steps=int(st[4]))

@@ -1,0 +1,67 @@
+"""Builds the in-tree native libraries.
+
+    libmetacache_amd.so   the product: HIP kernels (gfx950) + C-ABI host code   [hipcc]
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container and on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libmetacache_amd.so")
+SOURCES = ["kernels.hip", "context.cpp", "dbfile.cpp", "builder.hip"]
+HEADERS = ["kernels.h", "context.h", os.path.join(ROOT, "include", "metacache_amd.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    hipcc = _hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", os.path.join(ROOT, "include"),
+             "-Wno-unused-result"]
+    procs = []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s).rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            if verbose:
+                print("+", " ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("compile failed: " + " ".join(cmd))
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,354 @@
+// metacache_amd/csrc/builder.hip -- minimal GPU database builder.
+// Target sequences are cut into window-aligned chunks, sketched by the same sketch kernel the query
+// path uses (probe disabled), turned into (feature, location) pairs, sorted by feature with a stable
+// device radix sort (insertion order = (target, window) order survives inside a bucket) and cut to
+// the first max_locations_per_feature locations per feature.
+#include <cstring>
+#include <string.h>
+
+#include "context.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mcamd;
+
+struct TargetRec { std::string name, filename; int64_t parent; uint64_t windows; };
+
+struct mc_builder {
+    mc_config cfg{};
+    SketchParams sp{};
+    uint32_t maxLocs = 254;
+    hipStream_t st = nullptr;
+    std::string err;
+    std::vector<TargetRec> targets;
+    // staged chunks (host)
+    std::vector<uint8_t> hseq;
+    std::vector<uint32_t> hqinfo, hqtgt, hqfirst;
+    // all pairs so far (device, grow-only)
+    uint32_t* dkeys = nullptr; uint64_t* dvals = nullptr; uint64_t npairs = 0, cap = 0;
+    // result (host)
+    bool finished = false;
+    std::vector<uint32_t> keys; std::vector<uint8_t> sizes; std::vector<uint64_t> values;   // values = (tgt<<32)|win
+};
+
+namespace {
+
+constexpr uint32_t kChunkWindows = 256;
+constexpr uint64_t kFlushChars = 96ull << 20;
+
+#define B_TRY(b, expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) { (b)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return MC_ERR_HIP; } \
+    } while (0)
+
+// one thread per window: pairs[(w*s + j)] = (feature, (tgt << 32) | window id)
+__global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ features, const uint32_t* __restrict__ winOff,
+                                                         const uint32_t* __restrict__ qtgt, const uint32_t* __restrict__ qfirst,
+                                                         uint32_t nq, uint32_t s, uint32_t* __restrict__ keys, uint64_t* __restrict__ vals)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const uint32_t w0 = winOff[q], w1 = winOff[q + 1];
+    const uint64_t tgt = qtgt[q];
+    const uint32_t first = qfirst[q];
+    const uint32_t total = (w1 - w0) * s;
+    for (uint32_t i = lane; i < total; i += 64) {
+        const uint32_t w = i / s;
+        const size_t idx = (size_t)w0 * s + i;
+        keys[idx] = features[idx];
+        vals[idx] = (tgt << 32) | (first + w);
+    }
+}
+
+int grow_pairs(mc_builder* b, uint64_t need)
+{
+    if (need <= b->cap) return MC_OK;
+    uint64_t ncap = std::max<uint64_t>(need + need / 2, 1u << 20);
+    uint32_t* nk = nullptr; uint64_t* nv = nullptr;
+    B_TRY(b, hipMalloc((void**)&nk, ncap * 4));
+    B_TRY(b, hipMalloc((void**)&nv, ncap * 8));
+    if (b->npairs) {
+        B_TRY(b, hipMemcpyAsync(nk, b->dkeys, b->npairs * 4, hipMemcpyDeviceToDevice, b->st));
+        B_TRY(b, hipMemcpyAsync(nv, b->dvals, b->npairs * 8, hipMemcpyDeviceToDevice, b->st));
+        B_TRY(b, hipStreamSynchronize(b->st));
+    }
+    if (b->dkeys) (void)hipFree(b->dkeys);
+    if (b->dvals) (void)hipFree(b->dvals);
+    b->dkeys = nk; b->dvals = nv; b->cap = ncap;
+    return MC_OK;
+}
+
+int flush(mc_builder* b)
+{
+    const uint32_t nq = (uint32_t)(b->hqinfo.size() / 4);
+    if (nq == 0) return MC_OK;
+    const uint64_t nchars = b->hseq.size();
+    const SketchParams sp = b->sp;
+    const uint64_t maxWindows = nchars / sp.stride + 4ull * nq + 1;
+    uint8_t* dseq = nullptr; uint32_t *dq = nullptr, *dtgt = nullptr, *dfirst = nullptr, *dwc = nullptr, *dwo = nullptr, *dfeat = nullptr;
+    uint32_t* dhs = nullptr; QueryStat* dqs = nullptr; void* dscan = nullptr;
+    B_TRY(b, hipMalloc((void**)&dseq, nchars + 16));
+    B_TRY(b, hipMalloc((void**)&dq, (size_t)nq * 16));
+    B_TRY(b, hipMalloc((void**)&dtgt, (size_t)nq * 4));
+    B_TRY(b, hipMalloc((void**)&dfirst, (size_t)nq * 4));
+    B_TRY(b, hipMalloc((void**)&dwc, (size_t)(nq + 1) * 4));
+    B_TRY(b, hipMalloc((void**)&dwo, (size_t)(nq + 2) * 4));
+    B_TRY(b, hipMalloc((void**)&dfeat, (size_t)maxWindows * sp.s * 4));
+    B_TRY(b, hipMalloc((void**)&dhs, (size_t)(nq + 1) * 4));
+    B_TRY(b, hipMalloc((void**)&dqs, (size_t)(nq + 1) * sizeof(QueryStat)));
+    B_TRY(b, hipMalloc(&dscan, scan_tmp_bytes(nq + 1)));
+    B_TRY(b, hipMemsetAsync(dseq + nchars, 0, 16, b->st));
+    B_TRY(b, hipMemcpyAsync(dseq, b->hseq.data(), nchars, hipMemcpyHostToDevice, b->st));
+    B_TRY(b, hipMemcpyAsync(dq, b->hqinfo.data(), (size_t)nq * 16, hipMemcpyHostToDevice, b->st));
+    B_TRY(b, hipMemcpyAsync(dtgt, b->hqtgt.data(), (size_t)nq * 4, hipMemcpyHostToDevice, b->st));
+    B_TRY(b, hipMemcpyAsync(dfirst, b->hqfirst.data(), (size_t)nq * 4, hipMemcpyHostToDevice, b->st));
+
+    BatchView bv{dseq, dq, nullptr, 1, nq};
+    Workspace ws{};
+    ws.winCount = dwc; ws.winOff = dwo; ws.features = dfeat; ws.qstat = dqs; ws.hitScan = dhs; ws.scanTmp = dscan;
+    DeviceTable tab{nullptr, nullptr, 1, 0};
+    launch_plan(bv, sp, dwc, b->st);
+    launch_scan_u32(dwc, 1, nq, dwo, nullptr, dscan, b->st);
+    launch_sketch_probe(bv, sp, tab, false, false, ws, b->st);
+    uint32_t W = 0;
+    B_TRY(b, hipMemcpyAsync(&W, dwo + nq, 4, hipMemcpyDeviceToHost, b->st));
+    B_TRY(b, hipStreamSynchronize(b->st));
+    int rc = grow_pairs(b, b->npairs + (uint64_t)W * sp.s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s,
+                       b->dkeys + b->npairs, b->dvals + b->npairs);
+    B_TRY(b, hipGetLastError());
+    B_TRY(b, hipStreamSynchronize(b->st));
+    b->npairs += (uint64_t)W * sp.s;
+    for (void* p : {(void*)dseq, (void*)dq, (void*)dtgt, (void*)dfirst, (void*)dwc, (void*)dwo, (void*)dfeat, (void*)dhs, (void*)dqs, dscan})
+        (void)hipFree(p);
+    b->hseq.clear(); b->hqinfo.clear(); b->hqtgt.clear(); b->hqfirst.clear();
+    return MC_OK;
+}
+
+void wr(FILE* f, const void* p, size_t n) { std::fwrite(p, 1, n, f); }
+void wr_str(FILE* f, const std::string& s) { uint64_t n = s.size(); wr(f, &n, 8); if (n) wr(f, s.data(), n); }
+
+}  // namespace
+
+extern "C" {
+
+int mc_build_begin(const mc_config* cfg, mc_builder** out)
+{
+    if (!cfg || !out) return MC_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->kmerlen < 1 || cfg->kmerlen > 16 || cfg->sketchlen < 1 || cfg->sketchlen > kMaxSketch || cfg->winlen < cfg->kmerlen ||
+        cfg->winlen > kMaxWinLen || cfg->winstride < 1 || (cfg->target_id_bytes != 2 && cfg->target_id_bytes != 4)) {
+        set_global_error("mc_build_begin: unsupported sketching parameters");
+        return MC_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
+        set_global_error("no usable HIP device (this library has no CPU fallback)");
+        return MC_ERR_HIP;
+    }
+    auto* b = new mc_builder;
+    b->cfg = *cfg;
+    b->sp = SketchParams{cfg->kmerlen, cfg->sketchlen, cfg->winlen, cfg->winstride};
+    b->maxLocs = cfg->max_locations_per_feature ? std::min<uint32_t>(cfg->max_locations_per_feature, 254) : 254;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) {
+        delete b;
+        set_global_error("cannot create HIP stream");
+        return MC_ERR_HIP;
+    }
+    *out = b;
+    return MC_OK;
+}
+
+int mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parentTaxid, const char* filename)
+{
+    if (!b || (!seq && len)) return MC_ERR_INVALID;
+    if (b->finished) { b->err = "builder already finished"; return MC_ERR_STATE; }
+    const uint64_t maxTargets = b->cfg.target_id_bytes == 2 ? 0xFFFFull : 0xFFFFFFFFull;   // database.hpp:340-343
+    if (b->targets.size() >= maxTargets) { b->err = "target count limit exceeded"; return MC_ERR_UNSUPPORTED; }
+    if (len >= (1ull << 32) - 16) { b->err = "target sequence too long for one call"; return MC_ERR_UNSUPPORTED; }
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    const SketchParams sp = b->sp;
+    const uint32_t tgt = (uint32_t)b->targets.size();
+    const uint32_t L = (uint32_t)len;
+    const uint32_t total = windows_of_host(L, sp);
+    // window-aligned chunks: all but the last consist of full windows only (tail suppressed)
+    uint32_t firstWin = 0;
+    uint64_t pos = 0;
+    const uint32_t fullWins = L > sp.w ? (L - sp.w) / sp.stride + 1 : 0;
+    while (true) {
+        const bool last = fullWins <= firstWin + kChunkWindows;
+        uint32_t clen;
+        if (last) clen = (uint32_t)(L - pos);
+        else clen = (kChunkWindows - 1) * sp.stride + sp.w;
+        const uint64_t off = b->hseq.size();
+        if (off + clen + 8 > 0xFFFFFFF0ull) { int rc = flush(b); if (rc) return rc; continue; }
+        b->hseq.insert(b->hseq.end(), (const uint8_t*)seq + pos, (const uint8_t*)seq + pos + clen);
+        b->hseq.resize((b->hseq.size() + 3) / 4 * 4, 0);
+        b->hqinfo.push_back((uint32_t)off); b->hqinfo.push_back(clen); b->hqinfo.push_back((uint32_t)off);
+        b->hqinfo.push_back(last ? 0u : kNoTail);
+        b->hqtgt.push_back(tgt); b->hqfirst.push_back(firstWin);
+        if (b->hseq.size() >= kFlushChars) { int rc = flush(b); if (rc) return rc; }
+        if (last) break;
+        firstWin += kChunkWindows;
+        pos += (uint64_t)kChunkWindows * sp.stride;
+    }
+    TargetRec r;
+    r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid; r.windows = total;
+    b->targets.push_back(std::move(r));
+    return MC_OK;
+}
+
+int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
+{
+    if (!b) return MC_ERR_INVALID;
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    if (!b->finished) {
+        int rc = flush(b);
+        if (rc) return rc;
+        const uint64_t n = b->npairs;
+        std::vector<uint32_t> hk(n);
+        std::vector<uint64_t> hv(n);
+        if (n) {
+            uint32_t* k2 = nullptr; uint64_t* v2 = nullptr; void* tmp = nullptr; size_t tmpBytes = 0;
+            B_TRY(b, hipMalloc((void**)&k2, n * 4));
+            B_TRY(b, hipMalloc((void**)&v2, n * 8));
+            B_TRY(b, rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, b->st));
+            B_TRY(b, hipMalloc(&tmp, tmpBytes + 16));
+            B_TRY(b, rocprim::radix_sort_pairs(tmp, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, b->st));
+            B_TRY(b, hipMemcpyAsync(hk.data(), k2, n * 4, hipMemcpyDeviceToHost, b->st));
+            B_TRY(b, hipMemcpyAsync(hv.data(), v2, n * 8, hipMemcpyDeviceToHost, b->st));
+            B_TRY(b, hipStreamSynchronize(b->st));
+            (void)hipFree(k2); (void)hipFree(v2); (void)hipFree(tmp);
+        }
+        (void)hipFree(b->dkeys); (void)hipFree(b->dvals);
+        b->dkeys = nullptr; b->dvals = nullptr; b->cap = 0;
+        // run-length encode; features == 0xFFFFFFFF are padding and sort last
+        b->keys.clear(); b->sizes.clear(); b->values.clear();
+        for (uint64_t i = 0; i < n;) {
+            const uint32_t key = hk[i];
+            if (key == 0xFFFFFFFFu) break;
+            uint64_t j = i;
+            while (j < n && hk[j] == key) ++j;
+            const uint64_t keep = std::min<uint64_t>(j - i, b->maxLocs);   // first maxLocs in insertion order
+            b->keys.push_back(key);
+            b->sizes.push_back((uint8_t)keep);
+            b->values.insert(b->values.end(), hv.begin() + i, hv.begin() + i + keep);
+            i = j;
+        }
+        b->finished = true;
+    }
+    if (outCtx) {
+        *outCtx = nullptr;
+        mc_config qc = b->cfg;
+        qc.max_locations_per_feature = 0; qc.remove_overpopulated = 0; qc.num_parts = 1;
+        qc.target_id_bytes = 4;                                    // values are handed over as {u32 win, u32 tgt}
+        mc_ctx* ctx = nullptr;
+        int rc = mc_create(&qc, &ctx);
+        if (rc) { b->err = mc_last_error(nullptr); return rc; }
+        ctx->targetCount = b->targets.size();
+        ctx->maxLocs = b->maxLocs;
+        rc = mc_load_begin(ctx, 0, b->keys.size(), b->values.size());
+        const uint64_t batch = 1ull << 20;
+        uint64_t voff = 0;
+        for (uint64_t i = 0; !rc && i < b->keys.size(); i += batch) {
+            const uint64_t nb = std::min<uint64_t>(batch, b->keys.size() - i);
+            uint64_t bv = 0;
+            for (uint64_t t = 0; t < nb; ++t) bv += b->sizes[i + t];
+            // (tgt<<32)|win little-endian == {u32 win; u32 tgt}
+            rc = mc_load_batch(ctx, 0, b->keys.data() + i, b->sizes.data() + i, b->values.data() + voff, nb);
+            voff += bv;
+        }
+        if (!rc) rc = mc_load_end(ctx, 0);
+        if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
+        *outCtx = ctx;
+    }
+    return MC_OK;
+}
+
+int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa)
+{
+    if (!b || !name) return MC_ERR_INVALID;
+    if (!b->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
+    const uint32_t tb = b->cfg.target_id_bytes;
+    {   // .meta  (database.cpp:247-290)
+        FILE* f = std::fopen((std::string(name) + ".meta").c_str(), "wb");
+        if (!f) { b->err = "cannot write .meta"; return MC_ERR_IO; }
+        const uint64_t ver = 20200820ull;
+        wr(f, &ver, 8);
+        const uint8_t wd[7] = {4, (uint8_t)tb, 4, 1, 4, 8, MC_NUM_RANKS};
+        wr(f, wd, 7);
+        const uint64_t sk[4] = {b->sp.k, b->sp.s, b->sp.w, b->sp.stride};
+        wr(f, sk, 32); wr(f, sk, 32);
+        const uint64_t ml = b->maxLocs;
+        wr(f, &ml, 8);
+        if (tb == 2) { uint16_t t = (uint16_t)b->targets.size(); wr(f, &t, 2); } else { uint32_t t = (uint32_t)b->targets.size(); wr(f, &t, 4); }
+        const uint32_t parts = 1;
+        wr(f, &parts, 4);
+        const uint64_t nt = ntaxa + b->targets.size();
+        wr(f, &nt, 8);
+        for (uint64_t i = 0; i < ntaxa; ++i) {
+            wr(f, &taxa[i].id, 8); wr(f, &taxa[i].parent, 8);
+            const uint8_t rk = (uint8_t)taxa[i].rank; wr(f, &rk, 1);
+            wr_str(f, taxa[i].name ? taxa[i].name : ""); wr_str(f, "");
+            const uint64_t z = 0; wr(f, &z, 8); wr(f, &z, 8);
+        }
+        for (uint64_t t = 0; t < b->targets.size(); ++t) {
+            const int64_t id = -(int64_t)t - 1;
+            wr(f, &id, 8); wr(f, &b->targets[t].parent, 8);
+            const uint8_t rk = 0; wr(f, &rk, 1);                       // rank::Sequence (taxonomy.hpp:453)
+            wr_str(f, b->targets[t].name); wr_str(f, b->targets[t].filename);
+            const uint64_t idx = 0; wr(f, &idx, 8); wr(f, &b->targets[t].windows, 8);
+        }
+        std::fclose(f);
+    }
+    {   // .cache0  (hash_multimap.hpp:1037-1082)
+        FILE* f = std::fopen((std::string(name) + ".cache0").c_str(), "wb");
+        if (!f) { b->err = "cannot write .cache0"; return MC_ERR_IO; }
+        const uint64_t nk = b->keys.size(), nv = b->values.size(), batch = 1ull << 20;
+        wr(f, &nk, 8); wr(f, &nv, 8); wr(f, &batch, 8);
+        std::vector<uint8_t> packed;
+        uint64_t voff = 0;
+        for (uint64_t i = 0; i < nk; i += batch) {
+            const uint64_t nb = std::min<uint64_t>(batch, nk - i);
+            wr(f, b->keys.data() + i, nb * 4);
+            wr(f, b->sizes.data() + i, nb);
+            uint64_t bv = 0;
+            for (uint64_t t = 0; t < nb; ++t) bv += b->sizes[i + t];
+            packed.resize(bv * (4 + tb));
+            for (uint64_t t = 0; t < bv; ++t) {
+                const uint64_t v = b->values[voff + t];
+                const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
+                std::memcpy(&packed[t * (4 + tb)], &win, 4);
+                if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(&packed[t * 6 + 4], &t16, 2); }
+                else std::memcpy(&packed[t * 8 + 4], &tgt, 4);
+            }
+            wr(f, packed.data(), packed.size());
+            voff += bv;
+        }
+        std::fclose(f);
+    }
+    return MC_OK;
+}
+
+void mc_build_free(mc_builder* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->cfg.device);
+    if (b->dkeys) (void)hipFree(b->dkeys);
+    if (b->dvals) (void)hipFree(b->dvals);
+    if (b->st) (void)hipStreamDestroy(b->st);
+    delete b;
+}
+
+const char* mc_build_last_error(const mc_builder* b) { return b ? b->err.c_str() : mc_last_error(nullptr); }
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+// metacache_amd/csrc/context.cpp -- host side of the C ABI: context, table loading, the per-batch
+// pipeline, host slots, timing.  (Compiled with hipcc; the kernels live in kernels.hip.)
+#include "context.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+using namespace mcamd;
+
+namespace {
+
+thread_local std::string g_createError;
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return MC_ERR_HIP;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+int fail(mc_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg; else g_createError = msg;
+    return code;
+}
+
+int ensure(mc_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return MC_OK;
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;                 // head-room: fewer re-allocations
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return MC_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------
+hipEvent_t get_event(mc_ctx* ctx)
+{
+    if (!ctx->eventPool.empty()) { hipEvent_t e = ctx->eventPool.back(); ctx->eventPool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {
+    mc_ctx* ctx; const char* name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(mc_ctx* c, const char* n, hipStream_t s) : ctx(c), name(n), st(s)
+    {
+        if (ctx->timing) { a = get_event(ctx); b = get_event(ctx); (void)hipEventRecord(a, st); }
+    }
+    ~ScopedTimer()
+    {
+        if (a) { (void)hipEventRecord(b, st); ctx->timers[name].pending.emplace_back(a, b); }
+    }
+};
+
+void collect_timers(mc_ctx* ctx)
+{
+    for (auto& kv : ctx->timers) {
+        for (auto& pr : kv.second.pending) {
+            (void)hipEventSynchronize(pr.second);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches++; }
+            ctx->eventPool.push_back(pr.first); ctx->eventPool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+}  // namespace
+
+void mcamd::set_global_error(const std::string& msg) { g_createError = msg; }
+
+extern "C" {
+
+void mc_config_default(mc_config* c)
+{
+    std::memset(c, 0, sizeof(*c));
+    c->device = 0;
+    c->kmerlen = 16; c->sketchlen = 16; c->winlen = 127; c->winstride = 112;   // options.hpp:102, options.cpp:625
+    c->max_candidates = 2;                                                      // options.hpp:257
+    c->target_id_bytes = 4;
+    c->num_parts = 1;
+    c->max_locations_per_feature = 0;
+    c->remove_overpopulated = 0;
+    c->max_load_factor = 0.8f;                                                  // host_hashmap.hpp:159-161
+    c->num_slots = 1;
+    c->slot_max_queries = 1u << 16;
+    c->slot_max_chars = 1u << 24;
+    c->copy_allhits = 0;
+}
+
+const char* mc_last_error(const mc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int mc_create(const mc_config* cfg, mc_ctx** out)
+{
+    if (!cfg || !out) return fail(nullptr, MC_ERR_INVALID, "mc_create: null argument");
+    *out = nullptr;
+    if (cfg->kmerlen < 1 || cfg->kmerlen > 16) return fail(nullptr, MC_ERR_UNSUPPORTED, "kmerlen must be 1..16 (kmer_type = uint32_t)");
+    if (cfg->sketchlen < 1 || cfg->sketchlen > kMaxSketch) return fail(nullptr, MC_ERR_UNSUPPORTED, "sketchlen must be 1..32");
+    if (cfg->winlen < cfg->kmerlen || cfg->winlen > kMaxWinLen) return fail(nullptr, MC_ERR_UNSUPPORTED, "winlen must be kmerlen..1024");
+    if (cfg->winstride < 1) return fail(nullptr, MC_ERR_INVALID, "winstride must be >= 1");
+    if (cfg->target_id_bytes != 2 && cfg->target_id_bytes != 4) return fail(nullptr, MC_ERR_INVALID, "target_id_bytes must be 2 or 4");
+    if (cfg->num_parts != 1) return fail(nullptr, MC_ERR_UNSUPPORTED, "exactly one database part per context for now");
+    if (cfg->max_candidates < 1) return fail(nullptr, MC_ERR_INVALID, "max_candidates must be >= 1");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return fail(nullptr, MC_ERR_HIP, "no usable HIP device (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MC_ERR_INVALID, "device ordinal out of range");
+
+    auto* ctx = new mc_ctx;
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device;
+    ctx->querySketch = SketchParams{cfg->kmerlen, cfg->sketchlen, cfg->winlen, cfg->winstride};
+    ctx->targetSketch = ctx->querySketch;
+    ctx->loadFactor = (cfg->max_load_factor > 0.05f && cfg->max_load_factor <= 0.99f) ? cfg->max_load_factor : 0.8f;
+    ctx->parts.resize(cfg->num_parts);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream");
+    }
+    // host slots
+    ctx->slots.resize(cfg->num_slots);
+    const size_t K = cfg->max_candidates;
+    for (auto& s : ctx->slots) {
+        const size_t nq = cfg->slot_max_queries, nc = (size_t)cfg->slot_max_chars + 16;
+        bool ok = hipHostMalloc((void**)&s.hseq, nc) == hipSuccess && hipHostMalloc((void**)&s.hqinfo, nq * 16) == hipSuccess &&
+                  hipHostMalloc((void**)&s.hmaxwin, nq * 4) == hipSuccess && hipMalloc((void**)&s.dseq, nc) == hipSuccess &&
+                  hipMalloc((void**)&s.dqinfo, nq * 16) == hipSuccess && hipMalloc((void**)&s.dmaxwin, nq * 4) == hipSuccess &&
+                  hipHostMalloc((void**)&s.hcands, nq * K * sizeof(mc_candidate)) == hipSuccess &&
+                  hipHostMalloc((void**)&s.hqstat, nq * sizeof(QueryStat)) == hipSuccess &&
+                  hipHostMalloc((void**)&s.hhitcounts, nq * 4) == hipSuccess &&
+                  hipHostMalloc((void**)&s.hhitoff, (nq + 1) * 8) == hipSuccess && hipEventCreate(&s.done) == hipSuccess;
+        if (!ok) { mc_destroy(ctx); return fail(nullptr, MC_ERR_NOMEM, "cannot allocate slot buffers"); }
+    }
+    *out = ctx;
+    return MC_OK;
+}
+
+void mc_destroy(mc_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->parts) { if (p.dslots) (void)hipFree(p.dslots); if (p.dvalues) (void)hipFree(p.dvalues); }
+    for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
+    DevBuf* bufs[] = {&ctx->bWinCount, &ctx->bWinOff, &ctx->bFeatures, &ctx->bPsize, &ctx->bPpay, &ctx->bQstat, &ctx->bHitOff,
+                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn};
+    for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& s : ctx->slots) {
+        if (s.hseq) (void)hipHostFree(s.hseq); if (s.hqinfo) (void)hipHostFree(s.hqinfo); if (s.hmaxwin) (void)hipHostFree(s.hmaxwin);
+        if (s.dseq) (void)hipFree(s.dseq); if (s.dqinfo) (void)hipFree(s.dqinfo); if (s.dmaxwin) (void)hipFree(s.dmaxwin);
+        if (s.hcands) (void)hipHostFree(s.hcands); if (s.hqstat) (void)hipHostFree(s.hqstat);
+        if (s.hhitcounts) (void)hipHostFree(s.hhitcounts); if (s.hhitoff) (void)hipHostFree(s.hhitoff);
+        if (s.hhits) (void)hipHostFree(s.hhits); if (s.done) (void)hipEventDestroy(s.done);
+    }
+    collect_timers(ctx);
+    for (auto e : ctx->eventPool) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// table loading
+// ------------------------------------------------------------------------------------------------
+int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    if (part >= ctx->parts.size()) return fail(ctx, MC_ERR_INVALID, "mc_load_begin: part out of range");
+    Part& P = ctx->parts[part];
+    if (P.loading || P.ready) return fail(ctx, MC_ERR_STATE, "mc_load_begin: part already loaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t ng = (uint64_t)((double)nkeys / (kSlotsPerGroup * (double)ctx->loadFactor)) + 1;
+    if (ng > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit group index");
+    P.ngroups = (uint32_t)ng;
+    P.expectKeys = nkeys; P.expectValues = nvalues;
+    P.hslots.assign((size_t)ng * kSlotsPerGroup, TableSlot{0, 0, 0});
+    P.dvaluesCap = nvalues + 1;
+    HIP_TRY(ctx, hipMalloc((void**)&P.dvalues, P.dvaluesCap * sizeof(uint64_t)));
+    P.loading = true;
+    return MC_OK;
+}
+
+int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_t* sizes, const void* values, uint64_t n)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    if (part >= ctx->parts.size() || !ctx->parts[part].loading) return fail(ctx, MC_ERR_STATE, "mc_load_batch: call mc_load_begin first");
+    Part& P = ctx->parts[part];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t tb = ctx->cfg.target_id_bytes, vb = 4 + tb;
+    const uint32_t maxLocs = ctx->cfg.max_locations_per_feature;
+    const uint32_t rmOver = ctx->cfg.remove_overpopulated;
+    const uint8_t* vp = static_cast<const uint8_t*>(values);
+    std::vector<uint64_t> stage;
+    stage.reserve(n * 2);
+    auto decode = [&](const uint8_t* p) -> uint64_t {
+        uint32_t win; std::memcpy(&win, p, 4);
+        uint32_t tgt = 0;
+        if (tb == 2) { uint16_t t; std::memcpy(&t, p + 4, 2); tgt = t; } else std::memcpy(&tgt, p + 4, 4);
+        return ((uint64_t)tgt << 32) | win;
+    };
+    if (P.keysLoaded + n > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t fileSize = sizes[i];
+        uint32_t size = fileSize;
+        if (rmOver && size > rmOver) size = 0;                 // bucket emptied, key kept without values = never matches
+        if (maxLocs && size > maxLocs) size = maxLocs;         // keep the FIRST n values
+        if (size > 0) {
+            // place the key: first group along the chain with a free slot
+            const uint32_t key = keys[i];
+            uint32_t g = (uint32_t)(((uint64_t)mix32(key) * P.ngroups) >> 32);
+            uint32_t probe = 1;
+            TableSlot* dst = nullptr;
+            for (;; ++probe) {
+                TableSlot* grp = &P.hslots[(size_t)g * kSlotsPerGroup];
+                for (uint32_t j = 0; j < kSlotsPerGroup; ++j)
+                    if (!(grp[j].meta >> 31)) { dst = &grp[j]; break; }
+                if (dst) break;
+                g = (g + 1 == P.ngroups) ? 0 : g + 1;
+                if (probe > P.ngroups) return fail(ctx, MC_ERR_NOMEM, "hash table full");
+            }
+            if (probe > P.maxProbe) P.maxProbe = probe;
+            dst->key = key;
+            dst->meta = 0x80000000u | size;
+            if (size == 1) dst->payload = decode(vp);
+            else {
+                dst->payload = P.valuesStored + stage.size();
+                for (uint32_t t = 0; t < size; ++t) stage.push_back(decode(vp + (size_t)t * vb));
+            }
+            P.locations += size;
+            P.keysStored++;
+        }
+        vp += (size_t)fileSize * vb;
+    }
+    if (!stage.empty()) {
+        if (P.valuesStored + stage.size() > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
+        HIP_TRY(ctx, hipMemcpy(P.dvalues + P.valuesStored, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
+        P.valuesStored += stage.size();
+    }
+    P.keysLoaded += n;
+    return MC_OK;
+}
+
+int mc_load_end(mc_ctx* ctx, uint32_t part)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    if (part >= ctx->parts.size() || !ctx->parts[part].loading) return fail(ctx, MC_ERR_STATE, "mc_load_end: nothing being loaded");
+    Part& P = ctx->parts[part];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = P.hslots.size() * sizeof(TableSlot);
+    HIP_TRY(ctx, hipMalloc((void**)&P.dslots, bytes));
+    HIP_TRY(ctx, hipMemcpy(P.dslots, P.hslots.data(), bytes, hipMemcpyHostToDevice));
+    std::vector<TableSlot>().swap(P.hslots);
+    P.loading = false; P.ready = true;
+    return MC_OK;
+}
+
+int mc_set_lineages(mc_ctx* ctx, const uint32_t* lin, uint64_t numTargets)
+{
+    if (!ctx || !lin) return MC_ERR_INVALID;
+    for (uint64_t i = 0; i < numTargets * MC_NUM_RANKS; ++i)
+        if (lin[i] >= (1u << 24)) return fail(ctx, MC_ERR_UNSUPPORTED, "taxon index does not fit 24 bits");
+    ctx->lineages.assign(lin, lin + numTargets * MC_NUM_RANKS);
+    if (ctx->targetCount < numTargets) ctx->targetCount = numTargets;
+    for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
+    ctx->taxkeyDev.clear();
+    return MC_OK;
+}
+
+int mc_db_info(const mc_ctx* ctx, uint64_t info[8])
+{
+    if (!ctx) return MC_ERR_INVALID;
+    info[0] = ctx->targetSketch.k; info[1] = ctx->targetSketch.s; info[2] = ctx->targetSketch.w; info[3] = ctx->targetSketch.stride;
+    info[4] = ctx->maxLocs; info[5] = ctx->targetCount; info[6] = ctx->parts.size();
+    uint64_t loc = 0;
+    for (auto& p : ctx->parts) loc += p.locations;
+    info[7] = loc;
+    return MC_OK;
+}
+
+// taxkey[tgt] = lowest_ranked_ancestor(tgt, rank) as taxon index + 1 (taxonomy.hpp:1260-1267)
+static int taxkey_for_rank(mc_ctx* ctx, int rank, const uint32_t** out)
+{
+    *out = nullptr;
+    if (rank <= 0) return MC_OK;
+    if (rank >= MC_NUM_RANKS) return fail(ctx, MC_ERR_INVALID, "lowest_rank out of range");
+    auto it = ctx->taxkeyDev.find(rank);
+    if (it != ctx->taxkeyDev.end()) { *out = it->second; return MC_OK; }
+    if (ctx->lineages.empty()) return fail(ctx, MC_ERR_STATE, "lowest_rank > sequence needs mc_set_lineages first");
+    const uint64_t nt = ctx->lineages.size() / MC_NUM_RANKS;
+    std::vector<uint32_t> tk(nt, 0);
+    for (uint64_t t = 0; t < nt; ++t)
+        for (int r = rank; r < MC_NUM_RANKS; ++r)
+            if (ctx->lineages[t * MC_NUM_RANKS + r]) { tk[t] = ctx->lineages[t * MC_NUM_RANKS + r]; break; }
+    uint32_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, std::max<uint64_t>(nt, 1) * 4));
+    HIP_TRY(ctx, hipMemcpy(d, tk.data(), nt * 4, hipMemcpyHostToDevice));
+    ctx->taxkeyDev[rank] = d;
+    *out = d;
+    return MC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the per-batch pipeline
+// ------------------------------------------------------------------------------------------------
+int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int wantAllhits, mc_device_results* out, void* streamv)
+{
+    if (!ctx || !in || !out) return MC_ERR_INVALID;
+    if (ctx->parts.empty() || !ctx->parts[0].ready) return fail(ctx, MC_ERR_STATE, "no database loaded");
+    if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    const uint32_t n = in->num_queries;
+    const SketchParams sp = ctx->querySketch;
+    const uint32_t K = ctx->cfg.max_candidates;
+    const uint32_t* taxkey = nullptr;
+    int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
+    if (rc) return rc;
+
+    // windows <= chars/stride + 2 per sequence (row 1), so the sketch buffers can be sized without a sync
+    const uint64_t maxWindows = in->num_chars / sp.stride + 4ull * n + 1;
+    if (maxWindows * sp.s > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "batch too large (feature index exceeds 32 bits)");
+    const size_t nfeat = (size_t)maxWindows * sp.s;
+    if ((rc = ensure(ctx, ctx->bWinCount, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bWinOff, (size_t)(n + 2) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bPsize, nfeat * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bPpay, nfeat * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
+    if ((rc = ensure(ctx, ctx->bScanIn, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->bScan, scan_tmp_bytes(n + 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->bStats, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
+
+    Workspace ws{};
+    ws.winCount = (uint32_t*)ctx->bWinCount.p; ws.winOff = (uint32_t*)ctx->bWinOff.p;
+    ws.features = (uint32_t*)ctx->bFeatures.p; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
+    ws.qstat = (QueryStat*)ctx->bQstat.p; ws.hitScan = (uint32_t*)ctx->bScanIn.p; ws.hitOff = (uint64_t*)ctx->bHitOff.p;
+    ws.scanTmp = ctx->bScan.p; ws.stats = (uint64_t*)ctx->bStats.p;
+
+    BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
+    const Part& P = ctx->parts[0];
+    DeviceTable tab{P.dslots, P.dvalues, P.ngroups, P.maxProbe};
+
+    {
+        ScopedTimer t(ctx, "plan", st);
+        launch_plan(b, sp, ws.winCount, st);
+        launch_scan_u32(ws.winCount, 1, n, ws.winOff, nullptr, ws.scanTmp, st);
+    }
+    {
+        ScopedTimer t(ctx, "sketch_probe", st);
+        launch_sketch_probe(b, sp, tab, true, wantAllhits != 0, ws, st);
+    }
+    {
+        ScopedTimer t(ctx, "scan", st);
+        launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
+    }
+    // the only host round trip of a batch: how many locations need a segment in HBM
+    uint64_t totalHits = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&totalHits, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const size_t hb = (size_t)(totalHits + 1) * 8;
+    if ((rc = ensure(ctx, ctx->bHits, hb))) return rc;
+    if ((rc = ensure(ctx, ctx->bCscr, hb))) return rc;
+    if (taxkey && (rc = ensure(ctx, ctx->bCscr2, hb))) return rc;
+    ws.hits = (uint64_t*)ctx->bHits.p; ws.cscr = (uint64_t*)ctx->bCscr.p; ws.cscr2 = (uint64_t*)ctx->bCscr2.p;
+    {
+        ScopedTimer t(ctx, "sort_candidates", st);
+        launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits != 0, ctx->bCands.p, st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->lastN = n;
+    out->cands = (const mc_candidate*)ctx->bCands.p;
+    out->hit_counts = (const uint32_t*)ctx->bQstat.p;       // QueryStat.hits: stride 4 words
+    out->hit_offsets = wantAllhits ? ws.hitOff : nullptr;
+    out->hits = wantAllhits ? (const mc_location*)ws.hits : nullptr;
+    out->features = ws.features;
+    out->win_offsets = ws.winOff;
+    return MC_OK;
+}
+
+int mc_synchronize(mc_ctx* ctx)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
+{
+    if (!ctx) return MC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::memset(stats, 0, 64);
+    if (!ctx->bStats.p || !ctx->bQstat.p) return MC_OK;
+    Workspace ws{};
+    ws.qstat = (QueryStat*)ctx->bQstat.p; ws.winOff = (uint32_t*)ctx->bWinOff.p; ws.stats = (uint64_t*)ctx->bStats.p;
+    launch_batch_stats(ws, ctx->lastN, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(stats, ws.stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MC_OK;
+}
+
+int mc_timing_enable(mc_ctx* ctx, int on) { if (!ctx) return MC_ERR_INVALID; ctx->timing = on != 0; return MC_OK; }
+int mc_timing_reset(mc_ctx* ctx)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    collect_timers(ctx);
+    for (auto& kv : ctx->timers) { kv.second.ms = 0; kv.second.launches = 0; }
+    return MC_OK;
+}
+int mc_timing_get(mc_ctx* ctx, const char* kernel, double* ms, uint64_t* launches)
+{
+    if (!ctx || !kernel) return MC_ERR_INVALID;
+    collect_timers(ctx);
+    auto it = ctx->timers.find(kernel);
+    if (ms) *ms = it == ctx->timers.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.launches;
+    return MC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host batch slots
+// ------------------------------------------------------------------------------------------------
+int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* s1, uint32_t l1, const char* s2, uint32_t l2, uint32_t maxWin)
+{
+    if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
+    Slot& S = ctx->slots[slot];
+    if (S.submitted) return fail(ctx, MC_ERR_STATE, "mc_batch_add: slot is in flight, call mc_batch_wait + mc_batch_clear");
+    if (l2 == kNoTail) return fail(ctx, MC_ERR_INVALID, "sequence too long");
+    const uint64_t need = ((uint64_t)l1 + 3) / 4 * 4 + ((uint64_t)l2 + 3) / 4 * 4;
+    if (need > ctx->cfg.slot_max_chars) return fail(ctx, MC_ERR_INVALID, "query longer than the slot's character capacity");
+    if (S.nq >= ctx->cfg.slot_max_queries || S.nchars + need > ctx->cfg.slot_max_chars) return MC_BATCH_FULL;
+    uint32_t* qi = S.hqinfo + (size_t)S.nq * 4;
+    qi[0] = (uint32_t)S.nchars; qi[1] = l1;
+    if (l1) std::memcpy(S.hseq + S.nchars, s1, l1);
+    S.nchars += ((uint64_t)l1 + 3) / 4 * 4;
+    qi[2] = (uint32_t)S.nchars; qi[3] = l2;
+    if (l2) std::memcpy(S.hseq + S.nchars, s2, l2);
+    S.nchars += ((uint64_t)l2 + 3) / 4 * 4;
+    S.hmaxwin[S.nq] = maxWin;
+    S.nq++;
+    return MC_OK;
+}
+
+int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
+{
+    if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
+    Slot& S = ctx->slots[slot];
+    if (S.submitted) return fail(ctx, MC_ERR_STATE, "mc_batch_submit: slot already submitted");
+    std::lock_guard<std::mutex> lock(ctx->submitMtx);     // ordered submission (database_query.hpp:110-113)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n = S.nq;
+    S.submittedQueries = n;
+    if (n == 0) { HIP_TRY(ctx, hipEventRecord(S.done, st)); S.submitted = true; return MC_OK; }
+    HIP_TRY(ctx, hipMemcpyAsync(S.dseq, S.hseq, S.nchars + 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.dqinfo, S.hqinfo, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.dmaxwin, S.hmaxwin, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    mc_device_batch in{S.dseq, S.dqinfo, S.dmaxwin, 0, n, S.nchars};
+    mc_device_results res{};
+    const int wantAll = ctx->cfg.copy_allhits ? 1 : 0;
+    int rc = mc_query_device(ctx, &in, lowestRank, wantAll, &res, st);
+    if (rc) return rc;
+    const size_t K = ctx->cfg.max_candidates;
+    HIP_TRY(ctx, hipMemcpyAsync(S.hcands, res.cands, (size_t)n * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.hqstat, ctx->bQstat.p, (size_t)n * sizeof(QueryStat), hipMemcpyDeviceToHost, st));
+    if (wantAll) {
+        HIP_TRY(ctx, hipMemcpyAsync(S.hhitoff, res.hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint64_t total = S.hhitoff[n];
+        if (total > S.hhitsCap) {
+            if (S.hhits) HIP_TRY(ctx, hipHostFree(S.hhits));
+            S.hhits = nullptr; S.hhitsCap = 0;
+            HIP_TRY(ctx, hipHostMalloc((void**)&S.hhits, (total + total / 4 + 64) * sizeof(mc_location)));
+            S.hhitsCap = total + total / 4 + 64;
+        }
+        if (total) HIP_TRY(ctx, hipMemcpyAsync(S.hhits, res.hits, total * sizeof(mc_location), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipEventRecord(S.done, st));
+    S.submitted = true;
+    return MC_OK;
+}
+
+int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
+{
+    if (!ctx || slot >= ctx->slots.size() || !out) return MC_ERR_INVALID;
+    Slot& S = ctx->slots[slot];
+    if (!S.submitted) return fail(ctx, MC_ERR_STATE, "mc_batch_wait: slot not submitted");
+    HIP_TRY(ctx, hipEventSynchronize(S.done));
+    const uint32_t n = S.submittedQueries;
+    int status = MC_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        S.hhitcounts[i] = S.hqstat[i].hits;
+        if (S.hqstat[i].hits > kMaxHitsPerQuery) status = MC_ERR_UNSUPPORTED;
+    }
+    out->num_queries = n;
+    out->max_candidates = ctx->cfg.max_candidates;
+    out->cands = S.hcands;
+    out->hit_counts = S.hhitcounts;
+    out->hit_offsets = ctx->cfg.copy_allhits ? S.hhitoff : nullptr;
+    out->hits = ctx->cfg.copy_allhits ? S.hhits : nullptr;
+    if (status) return fail(ctx, status, "a query produced more than 2^20-1 location hits (unsupported)");
+    return MC_OK;
+}
+
+int mc_batch_clear(mc_ctx* ctx, uint32_t slot)
+{
+    if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
+    Slot& S = ctx->slots[slot];
+    if (S.submitted) (void)hipEventSynchronize(S.done);
+    S.submitted = false; S.nq = 0; S.nchars = 0;
+    return MC_OK;
+}
+
+}  // extern "C"

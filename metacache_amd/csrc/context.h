@@ -1,0 +1,92 @@
+// metacache_amd/csrc/context.h -- the object behind mc_ctx (internal).
+#pragma once
+
+#include "../../include/metacache_amd.h"
+#include "kernels.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace mcamd {
+
+struct DevBuf {                 // grow-only device allocation
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Part {
+    // host-side build state (freed by mc_load_end)
+    std::vector<TableSlot> hslots;
+    uint64_t expectKeys = 0, expectValues = 0;
+    uint64_t keysLoaded = 0;
+    uint64_t valuesStored = 0;      // entries written to dvalues (buckets of size > 1 only)
+    uint64_t locations = 0;         // all locations kept (incl. inline singletons)
+    uint64_t keysStored = 0;
+    uint32_t ngroups = 0, maxProbe = 1;
+    bool loading = false, ready = false;
+    TableSlot* dslots = nullptr;
+    uint64_t* dvalues = nullptr;
+    uint64_t dvaluesCap = 0;
+};
+
+struct Taxon {
+    int64_t id, parent;
+    uint8_t rank;
+    std::string name, filename;
+    uint64_t index, windows;
+};
+
+struct Slot {
+    // pinned host staging
+    uint8_t* hseq = nullptr; uint32_t* hqinfo = nullptr; uint32_t* hmaxwin = nullptr;
+    uint32_t nq = 0; uint64_t nchars = 0;
+    // device input
+    uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;
+    // pinned results
+    mc_candidate* hcands = nullptr; QueryStat* hqstat = nullptr; uint32_t* hhitcounts = nullptr;
+    uint64_t* hhitoff = nullptr; mc_location* hhits = nullptr; size_t hhitsCap = 0;
+    hipEvent_t done = nullptr;
+    bool submitted = false;
+    uint32_t submittedQueries = 0;
+};
+
+// error text for failures that have no context yet (mc_last_error(NULL))
+void set_global_error(const std::string& msg);
+
+struct TimedKernel { double ms = 0; uint64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+
+}  // namespace mcamd
+
+struct mc_ctx {
+    mc_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    mcamd::SketchParams querySketch{};     // used for queries
+    mcamd::SketchParams targetSketch{};    // the database's own (window stride feeds maxWindowsInRange)
+    uint64_t maxLocs = 254, targetCount = 0;
+    std::vector<mcamd::Part> parts;
+    float loadFactor = 0.8f;
+
+    // taxonomy / lineages (host) + per-rank taxon keys (device)
+    std::vector<mcamd::Taxon> taxa;
+    std::vector<uint32_t> lineages;        // [targets * 21], taxon index + 1
+    std::map<int, uint32_t*> taxkeyDev;    // lowest_rank -> device array [targets]
+
+    // workspace
+    mcamd::DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
+        bCands, bScanIn;
+    uint32_t lastN = 0;
+
+    // timing
+    bool timing = false;
+    std::map<std::string, mcamd::TimedKernel> timers;
+    std::vector<hipEvent_t> eventPool;
+
+    // slots
+    std::vector<mcamd::Slot> slots;
+    std::mutex submitMtx;
+};

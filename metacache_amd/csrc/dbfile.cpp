@@ -1,0 +1,188 @@
+// metacache_amd/csrc/dbfile.cpp -- reads the reference's database files (<name>.meta + <name>.cache<p>)
+// and feeds them through the loading ABI.  File layout: SURVEY.md §8a row 11
+//   .meta  : database.cpp:247-290 (write) / :87-163 (read); taxonomy block taxonomy.hpp:702-728, :322-341
+//   .cache : hash_multimap.hpp:1037-1082 (serialize) / :970-1030 (deserialize)
+#include "context.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+
+using namespace mcamd;
+
+namespace {
+
+struct File {
+    FILE* f = nullptr;
+    explicit File(const std::string& n) : f(std::fopen(n.c_str(), "rb")) {}
+    ~File() { if (f) std::fclose(f); }
+    bool rd(void* p, size_t n) { return std::fread(p, 1, n, f) == n; }
+    bool str(std::string& s)
+    {
+        uint64_t n = 0;
+        if (!rd(&n, 8) || n > (1ull << 30)) return false;
+        s.resize(n);
+        return n == 0 || rd(&s[0], n);
+    }
+};
+
+struct Meta {
+    uint32_t k, s, w, stride;
+    uint64_t maxLocs, targetCount;
+    uint32_t numParts, targetBytes;
+    std::vector<Taxon> taxa;
+};
+
+int read_meta(const std::string& name, Meta& m, std::string& err)
+{
+    File f(name + ".meta");
+    if (!f.f) { err = "Could not read database metadata file '" + name + ".meta'"; return MC_ERR_IO; }
+    uint64_t ver = 0;
+    uint8_t wd[7];
+    if (!f.rd(&ver, 8) || !f.rd(wd, 7)) { err = "truncated .meta"; return MC_ERR_IO; }
+    if (ver != 20200820ull) { err = "database version " + std::to_string(ver) + " is incompatible (need 20200820)"; return MC_ERR_UNSUPPORTED; }
+    // sizeof{feature, target_id, window_id, bucket_size, part_id, taxon_id}, num_ranks (database.cpp:110-137)
+    if (wd[0] != 4 || (wd[1] != 2 && wd[1] != 4) || wd[2] != 4 || wd[3] != 1 || wd[4] != 4 || wd[5] != 8 || wd[6] != MC_NUM_RANKS) {
+        err = "database uses data type sizes this build does not support";
+        return MC_ERR_UNSUPPORTED;
+    }
+    m.targetBytes = wd[1];
+    uint64_t sk[8];
+    if (!f.rd(sk, 64)) { err = "truncated .meta"; return MC_ERR_IO; }     // sketching options are stored twice
+    m.k = (uint32_t)std::min<uint64_t>(sk[4], 16); m.s = (uint32_t)sk[5]; m.w = (uint32_t)sk[6]; m.stride = (uint32_t)sk[7];
+    if (!f.rd(&m.maxLocs, 8)) { err = "truncated .meta"; return MC_ERR_IO; }
+    m.maxLocs = std::min<uint64_t>(std::max<uint64_t>(m.maxLocs, 1), 254);   // host_hashmap.hpp:454-466
+    if (m.targetBytes == 2) { uint16_t t; if (!f.rd(&t, 2)) return MC_ERR_IO; m.targetCount = t; }
+    else { uint32_t t; if (!f.rd(&t, 4)) return MC_ERR_IO; m.targetCount = t; }
+    if (!f.rd(&m.numParts, 4)) { err = "truncated .meta"; return MC_ERR_IO; }
+    uint64_t nt = 0;
+    if (!f.rd(&nt, 8)) { err = "truncated .meta"; return MC_ERR_IO; }
+    m.taxa.resize(nt);
+    for (auto& t : m.taxa) {
+        if (!f.rd(&t.id, 8) || !f.rd(&t.parent, 8) || !f.rd(&t.rank, 1) || !f.str(t.name) || !f.str(t.filename) ||
+            !f.rd(&t.index, 8) || !f.rd(&t.windows, 8)) { err = "truncated taxonomy block"; return MC_ERR_IO; }
+    }
+    return MC_OK;
+}
+
+// ranked lineage of every target as taxon index + 1 (taxonomy.hpp:576-597, :919-1030)
+void make_lineages(const Meta& m, std::vector<uint32_t>& lin)
+{
+    std::unordered_map<int64_t, uint32_t> byId;
+    byId.reserve(m.taxa.size() * 2);
+    for (uint32_t i = 0; i < m.taxa.size(); ++i) byId.emplace(m.taxa[i].id, i);
+    lin.assign(m.targetCount * MC_NUM_RANKS, 0);
+    for (uint64_t t = 0; t < m.targetCount; ++t) {
+        auto it = byId.find(-(int64_t)t - 1);
+        if (it == byId.end()) continue;
+        uint32_t* L = &lin[t * MC_NUM_RANKS];
+        const Taxon& tx = m.taxa[it->second];
+        if (tx.rank < MC_NUM_RANKS) L[tx.rank] = it->second + 1;
+        int64_t id = tx.parent;
+        while (id > 0) {                                   // parents live among the non-target taxa
+            auto p = byId.find(id);
+            if (p == byId.end()) break;
+            const Taxon& px = m.taxa[p->second];
+            if (px.rank < MC_NUM_RANKS) L[px.rank] = p->second + 1;
+            if (px.parent == id) break;
+            id = px.parent;
+        }
+    }
+}
+
+int load_part(mc_ctx* ctx, uint32_t part, const std::string& fname, uint32_t targetBytes)
+{
+    File f(fname);
+    if (!f.f) { ctx->err = "Could not read database file '" + fname + "'"; return MC_ERR_IO; }
+    uint64_t nkeys = 0, nvalues = 0, batch = 0;
+    if (!f.rd(&nkeys, 8) || !f.rd(&nvalues, 8) || !f.rd(&batch, 8)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+    int rc = mc_load_begin(ctx, part, nkeys, nvalues);
+    if (rc) return rc;
+    const size_t vb = 4 + targetBytes;
+    std::vector<uint32_t> keys(std::min<uint64_t>(batch, nkeys));
+    std::vector<uint8_t> sizes(keys.size());
+    std::vector<uint8_t> vals;
+    for (uint64_t done = 0; done < nkeys;) {
+        const uint64_t nb = std::min<uint64_t>(batch, nkeys - done);
+        if (!f.rd(keys.data(), nb * 4) || !f.rd(sizes.data(), nb)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+        uint64_t bv = 0;
+        for (uint64_t i = 0; i < nb; ++i) bv += sizes[i];
+        vals.resize(bv * vb + 8);
+        if (bv && !f.rd(vals.data(), bv * vb)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+        if ((rc = mc_load_batch(ctx, part, keys.data(), sizes.data(), vals.data(), nb))) return rc;
+        done += nb;
+    }
+    return mc_load_end(ctx, part);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
+{
+    if (!name || !cfgIn || !out) return MC_ERR_INVALID;
+    *out = nullptr;
+    Meta m{};
+    std::string err;
+    int rc = read_meta(name, m, err);
+    if (rc) { set_global_error(err); return rc; }
+    mc_config cfg = *cfgIn;
+    cfg.kmerlen = m.k;                                      // k always comes from the DB (querying.cpp:232-243)
+    if (!cfg.sketchlen) cfg.sketchlen = m.s;
+    if (!cfg.winlen) cfg.winlen = m.w;
+    if (!cfg.winstride) cfg.winstride = m.stride;
+    cfg.target_id_bytes = m.targetBytes;
+    if (m.numParts != 1) { set_global_error("databases with more than one part are not supported yet"); return MC_ERR_UNSUPPORTED; }
+    cfg.num_parts = 1;
+    mc_ctx* ctx = nullptr;
+    if ((rc = mc_create(&cfg, &ctx))) return rc;
+    ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
+    ctx->targetCount = m.targetCount;
+    ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
+    ctx->taxa = std::move(m.taxa);
+    m.taxa.clear();
+    for (uint32_t p = 0; p < cfg.num_parts; ++p) {
+        if ((rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(p), m.targetBytes))) {
+            set_global_error(ctx->err);
+            mc_destroy(ctx);
+            return rc;
+        }
+    }
+    Meta tmp{}; tmp.targetCount = ctx->targetCount; tmp.taxa = ctx->taxa;
+    std::vector<uint32_t> lin;
+    make_lineages(tmp, lin);
+    if ((rc = mc_set_lineages(ctx, lin.data(), ctx->targetCount))) { set_global_error(ctx->err); mc_destroy(ctx); return rc; }
+    *out = ctx;
+    return MC_OK;
+}
+
+int mc_db_num_taxa(const mc_ctx* ctx, uint64_t* n)
+{
+    if (!ctx || !n) return MC_ERR_INVALID;
+    *n = ctx->taxa.size();
+    return MC_OK;
+}
+
+int mc_db_taxon(const mc_ctx* ctx, uint64_t i, int64_t* id, int64_t* parent, uint32_t* rank, const char** name)
+{
+    if (!ctx || i >= ctx->taxa.size()) return MC_ERR_INVALID;
+    const Taxon& t = ctx->taxa[i];
+    if (id) *id = t.id;
+    if (parent) *parent = t.parent;
+    if (rank) *rank = t.rank;
+    if (name) *name = t.name.c_str();
+    return MC_OK;
+}
+
+int mc_db_lineages(const mc_ctx* ctx, const uint32_t** lin, uint64_t* nt)
+{
+    if (!ctx || !lin || !nt) return MC_ERR_INVALID;
+    *lin = ctx->lineages.data();
+    *nt = ctx->lineages.size() / MC_NUM_RANKS;
+    return MC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// metacache_amd/csrc/kernels.h -- internal interface between the host pipeline (context.cpp) and
+// the gfx950 kernels (kernels.hip).  Not part of the public ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mcamd {
+
+constexpr uint32_t kWave = 64;
+constexpr uint32_t kMaxSketch = 32;       // MC_MAX_SKETCH
+constexpr uint32_t kMaxWinLen = 1024;     // MC_MAX_WINLEN
+constexpr uint32_t kSlotsPerGroup = 8;    // 8 x 16 B = one 128-B line per probe
+constexpr uint32_t kNoTail = 0xFFFFFFFFu; // qinfo[3] marker: single sequence, tail window suppressed
+constexpr uint32_t kMaxHitsPerQuery = (1u << 20) - 1;  // packed candidate fields are 20 bits wide
+
+// One hash table slot (16 B).  meta: bit 31 = occupied, low 16 bits = bucket size.
+// size == 1: payload = the location itself ((tgt << 32) | win), no second access needed;
+// size  > 1: payload = index of the first location in DeviceTable::values.
+struct __attribute__((aligned(16))) TableSlot {
+    uint32_t key;
+    uint32_t meta;
+    uint64_t payload;
+};
+
+// table hash: features are the SMALLEST hash values of a window, i.e. far from uniform in their
+// high bits, so they are mixed again (murmur3 fmix32) before the multiply-shift range reduction
+// group = (mix32(key) * ngroups) >> 32.
+__host__ __device__ inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+
+struct DeviceTable {
+    const TableSlot* slots;   // [ngroups * 8]
+    const uint64_t*  values;  // location lists, (tgt << 32) | win, each bucket sorted ascending
+    uint32_t ngroups;
+    uint32_t maxProbe;        // longest probe sequence (in groups) needed by any stored key
+};
+
+struct SketchParams { uint32_t k, s, w, stride; };
+
+// per-query result of the sketch_probe kernel
+struct __attribute__((aligned(16))) QueryStat {
+    uint32_t hits;      // sum of bucket sizes found (H)
+    uint32_t nfeat;     // valid features probed (F)
+    uint32_t nfound;    // features present in the table
+    uint32_t nsteps;    // bucket groups read
+};
+
+// row 1: number of windows with >= k characters (hash_dna.hpp:54-75 + :222)
+__host__ __device__ inline uint32_t windows_of(uint32_t L, const SketchParams& sp, bool noTail)
+{
+    if (L <= sp.w) return L >= sp.k ? 1u : 0u;
+    uint32_t nf = (L - sp.w) / sp.stride + 1;
+    uint64_t first = (uint64_t)nf * sp.stride;      // may exceed L for stride > w
+    if (!noTail && first < L && L - first >= sp.k) return nf + 1;
+    return nf;
+}
+inline uint32_t windows_of_host(uint32_t L, const SketchParams& sp) { return windows_of(L, sp, false); }
+
+struct BatchView {           // device pointers describing one batch
+    const uint8_t*  seq;
+    const uint32_t* qinfo;   // [n][4]
+    const uint32_t* maxWin;  // [n] or nullptr
+    uint32_t maxWinUniform;
+    uint32_t n;
+};
+
+struct Workspace {           // device buffers sized by the host for this batch
+    uint32_t* winCount;      // [n]
+    uint32_t* winOff;        // [n+1]      exclusive scan of winCount
+    uint32_t* features;      // [W*s]      window sketches (0xFFFFFFFF padded)
+    uint32_t* psize;         // [W*s]      bucket size per feature (0 = not found / no feature)
+    uint64_t* ppay;          // [W*s]      payload per feature
+    QueryStat* qstat;        // [n]
+    uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
+    uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
+    uint64_t* hits;          // [H]        gathered + sorted locations
+    uint64_t* cscr;          // [H]        candidate scratch (large queries)
+    uint64_t* cscr2;         // [H]        second scratch (taxon merging, large queries)
+    void*     scanTmp;       // block sums for the scans
+    uint64_t* stats;         // [8]        batch statistics (on demand)
+};
+
+// launchers (all asynchronous on 'st')
+void launch_plan(const BatchView& b, const SketchParams& sp, uint32_t* winCount, hipStream_t st);
+void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64,
+                     void* tmp, hipStream_t st);
+size_t scan_tmp_bytes(uint32_t n);
+void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool doProbe,
+                         bool wantAllhits, const Workspace& ws, hipStream_t st);
+constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS
+void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws,
+                            const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits,
+                            void* cands, hipStream_t st);
+void launch_batch_stats(const Workspace& ws, uint32_t n, hipStream_t st);
+
+}  // namespace mcamd

@@ -1,0 +1,712 @@
+// metacache_amd/csrc/kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the MetaCache
+// query hot path.  Semantics follow the reference's CPU classifier (file:line cite muellan/metacache
+// src/); the structure is our own: one 64-lane wavefront per query, windows staged 2-bit packed
+// through LDS, ballot/DPP based min-hash selection, 8-lane cooperative probing of 128-byte bucket
+// groups, in-LDS (or in-HBM for huge lists) bitonic sorting and a segmented-scan candidate search.
+//
+// No MFMA anywhere: this is integer hashing and gathering; the bound is HBM/L2 random access.
+#include "kernels.h"
+
+namespace mcamd {
+
+// ================================================================================================
+// wave64 primitives
+// ================================================================================================
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// DPP controls: quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l)
+{
+    return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+
+// all 64 lanes must be active
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dpp_mov<0xB1>(v));
+    v = min(v, dpp_mov<0x4E>(v));
+    v = min(v, dpp_mov<0x141>(v));
+    v = min(v, dpp_mov<0x140>(v));
+    return min(min(rdlane(v, 0), rdlane(v, 16)), min(rdlane(v, 32), rdlane(v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+// orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote)
+__device__ __forceinline__ void wave_mem_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ================================================================================================
+// rows 3-4: canonical k-mer + hash   (dna_encoding.hpp:168-177, :215-226; hash_int.hpp:41-48)
+// ================================================================================================
+__device__ __forceinline__ uint32_t tm_hash(uint32_t x)
+{
+    x = ((x >> 16) ^ x) * 0x45d9f3bu;
+    x = ((x >> 16) ^ x) * 0x45d9f3bu;
+    x = ((x >> 16) ^ x);
+    return x;
+}
+// kmer holds the k-mer in its low 2k bits
+__device__ __forceinline__ uint32_t canonical_hash(uint32_t kmer, uint32_t k)
+{
+    uint32_t r = __brev(kmer);                                     // reverses bit pairs AND the bits inside a pair
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);       // undo the swap inside each pair
+    r = (~r) >> (32u - 2u * k);                                    // complement, keep low 2k bits
+    return tm_hash(kmer < r ? kmer : r);
+}
+__device__ __forceinline__ uint32_t home_group(uint32_t key, uint32_t ngroups)
+{
+    return (uint32_t)(((uint64_t)mix32(key) * ngroups) >> 32);
+}
+
+// ================================================================================================
+// row 1: window arithmetic (hash_dna.hpp:54-75 + :222)
+// ================================================================================================
+__global__ __launch_bounds__(256) void plan_kernel(BatchView b, SketchParams sp, uint32_t* __restrict__ winCount)
+{
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b.n) return;
+    uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+    bool noTail = qi.w == kNoTail;
+    uint32_t c = windows_of(qi.y, sp, noTail);
+    if (!noTail) c += windows_of(qi.w, sp, false);
+    winCount[q] = c;
+}
+
+void launch_plan(const BatchView& b, const SketchParams& sp, uint32_t* winCount, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(plan_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, winCount);
+}
+
+// ================================================================================================
+// exclusive scan of u32 counts (element i at in[i*stride]) -> out32[n+1] and/or out64[n+1]
+// three small kernels: block sums, scan of block sums (one block), block scan + offset
+// ================================================================================================
+constexpr uint32_t kScanBlock = 256;
+constexpr uint32_t kScanItems = 8;
+constexpr uint32_t kScanTile = kScanBlock * kScanItems;   // 2048 elements per block
+
+__device__ __forceinline__ uint64_t block_reduce_u64(uint64_t v, uint64_t* sh)
+{
+    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < blockDim.x / 64; ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums(const uint32_t* __restrict__ in, uint32_t stride, uint32_t n,
+                                                              uint64_t* __restrict__ blockSums)
+{
+    __shared__ uint64_t sh[kScanBlock / 64];
+    uint32_t base = blockIdx.x * kScanTile;
+    uint64_t s = 0;
+    for (uint32_t i = threadIdx.x; i < kScanTile; i += kScanBlock) {
+        uint32_t idx = base + i;
+        if (idx < n) s += in[(size_t)idx * stride];
+    }
+    s = block_reduce_u64(s, sh);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_of_sums(uint64_t* __restrict__ blockSums, uint32_t nblocks)
+{
+    // single block, sequential over tiles of 256 block sums with a running carry
+    __shared__ uint64_t sh[kScanBlock];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += kScanBlock) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t v = i < nblocks ? blockSums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < kScanBlock; d <<= 1) {
+            uint64_t o = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += o;
+            __syncthreads();
+        }
+        uint64_t incl = sh[threadIdx.x];
+        uint64_t c = carry;
+        if (i < nblocks) blockSums[i] = c + incl - v;   // exclusive
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockSums[nblocks] = carry;    // grand total
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_apply(const uint32_t* __restrict__ in, uint32_t stride, uint32_t n,
+                                                         const uint64_t* __restrict__ blockSums, uint32_t nblocks,
+                                                         uint32_t* __restrict__ out32, uint64_t* __restrict__ out64)
+{
+    __shared__ uint64_t sh[kScanBlock];
+    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint64_t local = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanItems; ++j) {
+        uint32_t idx = base + j;
+        v[j] = idx < n ? in[(size_t)idx * stride] : 0;
+        local += v[j];
+    }
+    sh[threadIdx.x] = local;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanBlock; d <<= 1) {
+        uint64_t o = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint64_t run = blockSums[blockIdx.x] + sh[threadIdx.x] - local;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanItems; ++j) {
+        uint32_t idx = base + j;
+        if (idx < n) {
+            if (out32) out32[idx] = (uint32_t)run;
+            if (out64) out64[idx] = run;
+        }
+        run += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t total = blockSums[nblocks];
+        if (out32) out32[n] = (uint32_t)total;
+        if (out64) out64[n] = total;
+    }
+}
+
+size_t scan_tmp_bytes(uint32_t n) { return ((size_t)(n + kScanTile - 1) / kScanTile + 2) * sizeof(uint64_t); }
+
+void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64, void* tmp, hipStream_t st)
+{
+    uint32_t nblocks = (n + kScanTile - 1) / kScanTile;
+    if (nblocks == 0) nblocks = 1;
+    uint64_t* sums = (uint64_t*)tmp;
+    hipLaunchKernelGGL(scan_block_sums, dim3(nblocks), dim3(kScanBlock), 0, st, in, stride, n, sums);
+    hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(kScanBlock), 0, st, sums, nblocks);
+    hipLaunchKernelGGL(scan_apply, dim3(nblocks), dim3(kScanBlock), 0, st, in, stride, n, sums, nblocks, out32, out64);
+}
+
+// ================================================================================================
+// sketch_probe: one wave per query.
+//   rows 1-5 (hash_dna.hpp:54-75, :208-255; dna_encoding.hpp:270-316) then row 6-7 lookups
+//   (host_hashmap.hpp:646-651) against OUR table layout.
+// ================================================================================================
+constexpr uint32_t kCodeWords = kMaxWinLen / 16 + 2;   // 2 bits / base, MSB first inside a word
+constexpr uint32_t kAmbWords  = kMaxWinLen / 32 + 2;   // 1 bit / base, LSB first
+
+// A/a=0 C/c=1 G/g=2 T/t/U/u=3 (dna_encoding.hpp:297-304); returns code | (ambiguous << 2)
+__device__ __forceinline__ uint32_t encode_base(uint32_t c)
+{
+    uint32_t x = (c >> 1) & 3u;
+    uint32_t code = x ^ (x >> 1);                 // A0 C1 G3 T2 -> 0 1 2 3 ; U (0x55) -> 3 as well
+    uint32_t u = (c & 0xDFu) - 0x41u;             // upper-cased letter index, 'A' = 0
+    // valid letters: A(0) C(2) G(6) T(19) U(20)
+    bool ok = u < 32u && ((0x00180045u >> u) & 1u);
+    return ok ? code : 4u;
+}
+
+struct WaveLds {
+    uint32_t code[kCodeWords];
+    uint32_t amb[kAmbWords];
+};
+
+// Stage window [p, p+n) of the sequence as packed 2-bit codes + ambiguity bits into this wave's LDS.
+__device__ __forceinline__ void stage_window(const uint8_t* __restrict__ seq, uint64_t start, uint32_t n, WaveLds& L, uint32_t lane)
+{
+    uint8_t* codeB = reinterpret_cast<uint8_t*>(L.code);
+    uint8_t* ambB = reinterpret_cast<uint8_t*>(L.amb);
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) {           // 64 lanes x 4 characters per pass
+        uint32_t c = c0 + lane * 4;
+        uint32_t chars = 0x4E4E4E4Eu;                      // 'N'
+        if (c < n) {
+            // unaligned 4-byte read through two aligned dwords (8 slack bytes behind the buffer)
+            uint64_t a = start + c;
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(seq + (a & ~(uint64_t)3));
+            uint32_t lo = w[0], hi = w[1];
+            chars = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
+        }
+        uint32_t code = 0, amb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t e = encode_base((chars >> (8 * j)) & 0xFFu);
+            bool bad = (e & 4u) || (c + j >= n);
+            code = (code << 2) | (bad ? 0u : e);
+            amb |= (bad ? 1u : 0u) << j;
+        }
+        uint32_t ci = c >> 2;                              // index of this 4-base group
+        codeB[ci ^ 3u] = (uint8_t)code;                    // big-endian inside each 32-bit word
+        uint32_t other = dpp_mov<0xB1>(amb);               // neighbour lane's nibble
+        if ((lane & 1u) == 0) ambB[ci >> 1] = (uint8_t)(amb | (other << 4));
+    }
+}
+
+template <bool PROBE>
+__global__ __launch_bounds__(256) void sketch_probe_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, int wantAllhits)
+{
+    __shared__ WaveLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4 + wave;
+    if (q >= b.n) return;                                 // whole wave leaves together
+    WaveLds& L = lds[wave];
+
+    const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+    const bool noTail = qi.w == kNoTail;
+    uint32_t widx = ws.winOff[q];                         // global index of this query's next window
+    const uint32_t k = sp.k, s = sp.s;
+    const uint32_t kbits = 0xFFFFu >> (16u - k);          // k ambiguity bits
+
+    uint32_t myHits = 0, nfeat = 0, nfound = 0, nsteps = 0;
+
+    for (uint32_t mate = 0; mate < 2; ++mate) {
+        const uint32_t off = mate ? qi.z : qi.x;
+        const uint32_t len = mate ? (noTail ? 0u : qi.w) : qi.y;
+        const uint32_t nwin = windows_of(len, sp, mate == 0 && noTail);
+        for (uint32_t wi = 0; wi < nwin; ++wi, ++widx) {
+            const uint32_t first = (len <= sp.w) ? 0u : wi * sp.stride;
+            const uint32_t n = min(sp.w, len - first);
+            stage_window(b.seq, (uint64_t)off + first, n, L, lane);
+            wave_mem_sync();
+
+            // ---- min-hash sketch: the sl smallest distinct hashes, ascending (hash_dna.hpp:224-251)
+            const uint32_t nk = n - k + 1;
+            const uint32_t sl = min(s, nk);
+            uint32_t sk = 0xFFFFFFFFu;                    // lane j holds sketch element j
+            for (uint32_t base = 0; base < nk; base += 64) {
+                const uint32_t p = base + lane;
+                uint32_t h = 0xFFFFFFFFu;
+                if (p < nk) {
+                    const uint32_t wq = p >> 4, sh = (p & 15u) * 2u;
+                    const uint32_t kmer = __funnelshift_l(L.code[wq + 1], L.code[wq], sh) >> (32u - 2u * k);
+                    const uint32_t aw = p >> 5;
+                    const uint32_t am = __funnelshift_r(L.amb[aw], L.amb[aw + 1], p & 31u) & kbits;
+                    if (am == 0) h = canonical_hash(kmer, k);   // dna_encoding.hpp:438-441
+                }
+                const uint32_t thr = rdlane(sk, sl - 1);
+                if (__any(h < thr)) {
+                    // merge: new sketch = sl smallest distinct of {old sketch} U {this chunk}
+                    uint32_t nsk = 0xFFFFFFFFu, lb = 0;
+                    for (uint32_t t = 0; t < sl; ++t) {
+                        uint32_t cand = min(h >= lb ? h : 0xFFFFFFFFu, sk >= lb ? sk : 0xFFFFFFFFu);
+                        uint32_t m = wave_min_u32(cand);
+                        if (m == 0xFFFFFFFFu) break;      // value ~0 can never enter (hash_dna.hpp:233)
+                        if (lane == t) nsk = m;
+                        lb = m + 1;
+                    }
+                    sk = nsk;
+                }
+            }
+            const uint32_t fbase = widx * s;
+            if (lane < s) ws.features[fbase + lane] = sk;
+            nfeat += (lane < s && sk != 0xFFFFFFFFu) ? 1u : 0u;
+
+            if (PROBE) {
+                // ---- 8 lanes x 16 B read one 128-byte bucket group per feature
+                const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
+                for (uint32_t r = 0; r * 8 < s; ++r) {
+                    const uint32_t fi = r * 8 + grp;
+                    const uint32_t f = __shfl(sk, fi);
+                    bool active = fi < s && f != 0xFFFFFFFFu;
+                    uint32_t g = home_group(f, tab.ngroups);
+                    uint32_t rsize = 0; uint64_t rpay = 0;
+                    bool wrote = false;
+                    for (uint32_t step = 0; step < tab.maxProbe; ++step) {
+                        uint4 sl4 = make_uint4(0, 0, 0, 0);
+                        if (active) sl4 = reinterpret_cast<const uint4*>(tab.slots)[(size_t)g * kSlotsPerGroup + sub];
+                        const bool occ = active && (sl4.y >> 31);
+                        const bool hit = occ && sl4.x == f;
+                        const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
+                        const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
+                        if (hit) { rsize = sl4.y & 0xFFFFu; rpay = ((uint64_t)sl4.w << 32) | sl4.z; wrote = true; }
+                        nsteps += (active && sub == 0) ? 1u : 0u;
+                        // finished when found, or when the group has a free slot (insertion fills the
+                        // first group with room, so the key cannot live further along the chain)
+                        if (ghit != 0 || gocc != 0xFFu) active = false;
+                        if (!__any(active)) break;
+                        g = (g + 1 == tab.ngroups) ? 0u : g + 1;
+                    }
+                    if (fi < s) {
+                        // exactly one lane per feature writes: the hit lane, else sub-lane 0
+                        const uint32_t anyhit = (uint32_t)(__ballot(wrote) >> gshift) & 0xFFu;
+                        if (wrote || (anyhit == 0 && sub == 0)) {
+                            ws.psize[fbase + fi] = rsize;
+                            ws.ppay[fbase + fi] = rpay;
+                        }
+                    }
+                    myHits += rsize;
+                    nfound += wrote ? 1u : 0u;
+                }
+            }
+            wave_mem_sync();                              // LDS is re-staged by the next window
+        }
+    }
+    const uint32_t H = wave_sum_u32(myHits);
+    const uint32_t F = wave_sum_u32(nfeat);
+    const uint32_t Fo = wave_sum_u32(nfound);
+    const uint32_t St = wave_sum_u32(nsteps);
+    if (lane == 0) {
+        QueryStat qs; qs.hits = H; qs.nfeat = F; qs.nfound = Fo; qs.nsteps = St;
+        ws.qstat[q] = qs;
+        ws.hitScan[q] = (H <= kMaxHitsPerQuery && (wantAllhits || H > kLdsCap)) ? H : 0u;
+    }
+}
+
+void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool doProbe,
+                         bool wantAllhits, const Workspace& ws, hipStream_t st)
+{
+    if (b.n == 0) return;
+    dim3 grid((b.n + 3) / 4), block(256);
+    if (doProbe) hipLaunchKernelGGL(sketch_probe_kernel<true>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0);
+    else         hipLaunchKernelGGL(sketch_probe_kernel<false>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0);
+}
+
+// ================================================================================================
+// sort_candidates: one wave per query.
+//   row 7-8: gather the location lists and sort them by (tgt, win)   (host_hashmap.hpp:646-651,
+//            query_handler.hpp:75-101 -- for a single part the merge result == full sort)
+//   row 9  : best contiguous window range per target                   (candidate_generation.hpp:47-108)
+//   row 10 : top-K list, ties keep arrival order, optional taxon merge (candidate_generation.hpp:172-231)
+// Lists of up to kLdsCap locations live in LDS; longer ones are processed in place in HBM.
+// ================================================================================================
+
+__device__ __forceinline__ void cmpxchg(uint64_t* buf, uint32_t i, uint32_t p)
+{
+    uint64_t a = buf[i], c = buf[p];
+    if (c < a) { buf[i] = c; buf[p] = a; }
+}
+
+// ascending bitonic sort of buf[0..n) by one wave; indices >= n behave as +infinity
+__device__ __forceinline__ void wave_sort_u64(uint64_t* buf, uint32_t n, uint32_t lane)
+{
+    if (n < 2) return;
+    uint32_t npow = 2;
+    while (npow < n) npow <<= 1;
+    const uint32_t half = npow >> 1;
+    for (uint32_t k = 2; k <= npow; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = lane; t < half; t += 64) {       // flip: i <-> mirror inside blocks of k
+            const uint32_t blk = t / hk, r = t & (hk - 1);
+            const uint32_t i = blk * k + r, p = blk * k + (k - 1 - r);
+            if (p < n) cmpxchg(buf, i, p);
+        }
+        wave_mem_sync();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < half; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                if (p < n) cmpxchg(buf, i, p);
+            }
+            wave_mem_sync();
+        }
+    }
+}
+
+// n <= 64: sort in registers with lane shuffles, one key per lane (padding = ~0)
+__device__ __forceinline__ uint64_t wave_sort64_reg(uint64_t key, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1) {
+        {
+            uint64_t o = __shfl(key, lane ^ (k - 1));
+            bool lower = (lane & (k >> 1)) == 0;
+            key = lower ? (o < key ? o : key) : (o > key ? o : key);
+        }
+#pragma unroll
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            uint64_t o = __shfl(key, lane ^ j);
+            bool lower = (lane & j) == 0;
+            key = lower ? (o < key ? o : key) : (o > key ? o : key);
+        }
+    }
+    return key;
+}
+
+__device__ __forceinline__ void sort_list(uint64_t* buf, uint32_t n, uint32_t lane)
+{
+    if (n <= 64) {
+        uint64_t key = lane < n ? buf[lane] : ~0ull;
+        key = wave_sort64_reg(key, lane);
+        if (lane < n) buf[lane] = key;
+        wave_mem_sync();
+    } else {
+        wave_sort_u64(buf, n, lane);
+    }
+}
+
+// first index in [0, hi] whose key >= lb (buf[hi] >= lb is guaranteed by the caller)
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t* buf, uint32_t hi, uint64_t lb)
+{
+    uint32_t lo = 0;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (buf[mid] < lb) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// left end of the sliding window range that ends at list position i (candidate_generation.hpp:79-85)
+__device__ __forceinline__ uint32_t range_first(const uint64_t* buf, uint32_t i, uint64_t key, uint32_t maxWin)
+{
+    const uint32_t win = (uint32_t)key;
+    const uint32_t lowWin = win >= maxWin - 1 ? win - (maxWin - 1) : 0u;
+    return lower_bound_u64(buf, i, (key & 0xFFFFFFFF00000000ull) | lowWin);
+}
+
+// packed candidate: hits(20) | ~ord(20) | position of the range end in the sorted list(20)
+// -> unsigned descending order == (hits desc, arrival order asc)  (candidate_generation.hpp:189-201)
+__device__ __forceinline__ uint64_t pack_cand(uint32_t hits, uint32_t ord, uint32_t besti)
+{
+    return ((uint64_t)hits << 40) | ((uint64_t)((~ord) & 0xFFFFFu) << 20) | besti;
+}
+
+struct mc_candidate_dev { uint32_t tgt, hits, beg, end; };
+
+__device__ __forceinline__ void emit_empty(mc_candidate_dev* out, uint32_t from, uint32_t K, uint32_t lane)
+{
+    for (uint32_t r = from + lane; r < K; r += 64) {
+        mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+        out[r] = e;
+    }
+}
+
+// buf[0..H) sorted.  Builds the per-target candidates in C (C2 = scratch for taxon merging) and
+// writes the top K to out.
+__device__ __forceinline__ void candidates_from_sorted(
+    const uint64_t* buf, uint64_t* C, uint64_t* C2, const uint32_t H, const uint32_t maxWin, const uint32_t K,
+    const uint32_t* __restrict__ taxkey, mc_candidate_dev* out, uint32_t lane)
+{
+    // ---- row 9: one candidate per maximal run of equal tgt
+    uint32_t ncand = 0;
+    uint64_t carryVal = 0;
+    uint32_t carryTgt = 0;
+    for (uint32_t c0 = 0; c0 < H; c0 += 64) {
+        const uint32_t i = c0 + lane;
+        const bool valid = i < H;
+        const uint64_t key = valid ? buf[i] : 0;
+        const uint32_t tgt = (uint32_t)(key >> 32);
+        uint32_t prevTgt = __shfl_up(tgt, 1);
+        if (lane == 0) prevTgt = carryTgt;
+        const bool head = valid && (i == 0 || tgt != prevTgt);
+        uint32_t nextTgt = __shfl_down(tgt, 1);
+        bool nextValid = i + 1 < H;
+        if (lane == 63 && nextValid) nextTgt = (uint32_t)(buf[i + 1] >> 32);
+        const bool tail = valid && (!nextValid || nextTgt != tgt);
+
+        uint64_t val = 0;
+        if (valid) {
+            const uint32_t fst = range_first(buf, i, key, maxWin);
+            val = ((uint64_t)(i - fst + 1) << 32) | (0xFFFFFFFFu - i);   // max => most hits, then earliest end
+        }
+        // segmented inclusive max-scan over the runs inside this chunk
+        bool f = head;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t o = __shfl_up(val, d);
+            int of = __shfl_up((int)f, d);
+            if (lane >= (uint32_t)d) {
+                if (!f && o > val) val = o;
+                f = f || of;
+            }
+        }
+        if (valid && !f && carryVal > val) val = carryVal;              // run continues from the previous chunk
+        const uint64_t tailMask = __ballot(tail);
+        if (tail) {
+            const uint32_t ord = ncand + __popcll(tailMask & ((1ull << lane) - 1ull));
+            C[ord] = pack_cand((uint32_t)(val >> 32), ord, 0xFFFFFFFFu - (uint32_t)val);
+        }
+        ncand += __popcll(tailMask);
+        carryVal = rdlane64(val, 63);
+        carryTgt = rdlane(tgt, 63);
+    }
+    wave_mem_sync();
+
+    // ---- row 10: order candidates
+    uint64_t* S = C;       // list that ends up sorted ascending by ~packed
+    if (taxkey) {
+        // at most one entry per taxon: keep the one with most hits, earliest arrival (:205-216)
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+            const uint32_t j = c0 + lane;
+            if (j < ncand) {
+                const uint64_t ck = C[j];
+                const uint32_t besti = (uint32_t)(ck & 0xFFFFFu);
+                const uint32_t tgt = (uint32_t)(buf[besti] >> 32);
+                const uint32_t tax = taxkey[tgt];                         // 0 = no taxon -> dropped (:187)
+                const uint32_t hits = (uint32_t)(ck >> 40);
+                C2[j] = tax ? (((uint64_t)tax << 40) | ((uint64_t)((~hits) & 0xFFFFFu) << 20) | j) : ~0ull;
+            }
+        }
+        wave_mem_sync();
+        sort_list(C2, ncand, lane);
+        uint32_t carryTax = 0;
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+            const uint32_t j = c0 + lane;
+            const uint64_t k1 = j < ncand ? C2[j] : ~0ull;
+            const uint32_t tax = (uint32_t)(k1 >> 40);
+            uint32_t prevTax = __shfl_up(tax, 1);
+            if (lane == 0) prevTax = carryTax;
+            const bool winner = k1 != ~0ull && (j == 0 || tax != prevTax);
+            uint64_t nv = ~0ull;
+            if (winner) nv = ~C[(uint32_t)(k1 & 0xFFFFFu)];
+            carryTax = rdlane(tax, 63);
+            wave_mem_sync();
+            if (j < ncand) C2[j] = nv;
+        }
+        wave_mem_sync();
+        S = C2;
+    } else {
+        for (uint32_t j = lane; j < ncand; j += 64) C[j] = ~C[j];
+        wave_mem_sync();
+    }
+    sort_list(S, ncand, lane);
+
+    // ---- emit the first K
+    const uint32_t nout = min(K, ncand);
+    uint32_t written = 0;
+    for (uint32_t r0 = 0; r0 < nout; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const uint64_t x = r < nout ? ~S[r] : 0;
+        const bool ok = x != 0;                                           // 0 = non-winner / dropped
+        if (ok) {
+            const uint32_t besti = (uint32_t)(x & 0xFFFFFu);
+            const uint64_t key = buf[besti];
+            const uint32_t fst = range_first(buf, besti, key, maxWin);
+            mc_candidate_dev e;
+            e.tgt = (uint32_t)(key >> 32);
+            e.hits = (uint32_t)(x >> 40);
+            e.beg = (uint32_t)buf[fst];
+            e.end = (uint32_t)key;
+            out[r] = e;
+        }
+        written += __popcll(__ballot(ok));                                // valid entries are a prefix
+    }
+    emit_empty(out, written, K, lane);
+}
+
+// row 7 + 8: gather the location lists of this query's features (window / feature order; singletons
+// are inline in the payload) into buf and sort them
+__device__ __forceinline__ void gather_and_sort(uint64_t* buf, const Workspace& ws, const DeviceTable& tab,
+                                                uint32_t fbeg, uint32_t nf, uint32_t H, uint32_t lane)
+{
+    uint32_t base = 0;
+    for (uint32_t e0 = 0; e0 < nf; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const uint32_t sz = e < nf ? ws.psize[fbeg + e] : 0u;
+        const uint64_t pay = e < nf ? ws.ppay[fbeg + e] : 0ull;
+        const uint32_t incl = wave_incl_scan_u32(sz, lane);
+        const uint32_t dst = base + incl - sz;
+        if (sz == 1) buf[dst] = pay;
+        uint64_t multi = __ballot(sz > 1);
+        while (multi) {                                                   // wave-uniform loop over big buckets
+            const uint32_t j = __ffsll((unsigned long long)multi) - 1;
+            multi &= multi - 1;
+            const uint32_t nj = rdlane(sz, j), dj = rdlane(dst, j);
+            const uint64_t src = rdlane64(pay, j);
+            for (uint32_t t = lane; t < nj; t += 64) buf[dj + t] = tab.values[src + t];   // coalesced copy
+        }
+        base += rdlane(incl, 63);
+    }
+    wave_mem_sync();
+    sort_list(buf, H, lane);
+}
+
+struct SortLds {
+    uint64_t buf[kLdsCap];
+    uint64_t c[kLdsCap];
+    uint64_t c2[kLdsCap];
+};
+
+__global__ __launch_bounds__(256) void sort_candidates_kernel(
+    BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, const uint32_t* __restrict__ taxkey,
+    uint32_t K, int wantAllhits, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ SortLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4 + wave;
+    if (q >= b.n) return;
+    mc_candidate_dev* out = cands + (size_t)q * K;
+    const uint32_t H = ws.qstat[q].hits;
+    if (H == 0 || H > kMaxHitsPerQuery) { emit_empty(out, 0, K, lane); return; }
+
+    const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+    const uint64_t hoff = ws.hitOff[q];
+    const uint32_t fbeg = ws.winOff[q] * sp.s;
+    const uint32_t nf = (ws.winOff[q + 1] - ws.winOff[q]) * sp.s;
+    // two instantiations so that the LDS flavour compiles to ds_* instructions
+    if (H <= kLdsCap) {
+        gather_and_sort(lds[wave].buf, ws, tab, fbeg, nf, H, lane);
+        if (wantAllhits)
+            for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = lds[wave].buf[i];
+        candidates_from_sorted(lds[wave].buf, lds[wave].c, lds[wave].c2, H, maxWin, K, taxkey, out, lane);
+    } else {
+        gather_and_sort(ws.hits + hoff, ws, tab, fbeg, nf, H, lane);
+        candidates_from_sorted(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, out, lane);
+    }
+}
+
+void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws,
+                            const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits, void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(sort_candidates_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, tab, ws, taxkey, maxCand,
+                       wantAllhits ? 1 : 0, (mc_candidate_dev*)cands);
+}
+
+// ================================================================================================
+// batch statistics (on demand, not on the timed path)
+// ================================================================================================
+__global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __restrict__ qs, const uint32_t* __restrict__ winOff,
+                                                          uint32_t n, uint64_t* __restrict__ stats)
+{
+    __shared__ uint64_t sh[4];
+    uint64_t h = 0, f = 0, fo = 0, st = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        QueryStat s = qs[i];
+        h += s.hits; f += s.nfeat; fo += s.nfound; st += s.nsteps;
+    }
+    h = block_reduce_u64(h, sh); f = block_reduce_u64(f, sh); fo = block_reduce_u64(fo, sh); st = block_reduce_u64(st, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long*)&stats[1], (unsigned long long)f);
+        atomicAdd((unsigned long long*)&stats[2], (unsigned long long)h);
+        atomicAdd((unsigned long long*)&stats[3], (unsigned long long)fo);
+        atomicAdd((unsigned long long*)&stats[4], (unsigned long long)st);
+        if (blockIdx.x == 0) stats[0] = winOff[n];
+    }
+}
+
+void launch_batch_stats(const Workspace& ws, uint32_t n, hipStream_t st)
+{
+    (void)hipMemsetAsync(ws.stats, 0, 8 * sizeof(uint64_t), st);
+    if (n == 0) return;
+    uint32_t blocks = min((n + 255u) / 256u, 1024u);
+    hipLaunchKernelGGL(batch_stats_kernel, dim3(blocks), dim3(256), 0, st, ws.qstat, ws.winOff, n, ws.stats);
+}
+
+}  // namespace mcamd

@@ -1,0 +1,150 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors of the reference and against the
+C oracle on the same seeded inputs.  Bit-exact: every field of every candidate and every location."""
+import numpy as np
+import pytest
+
+import cpuref
+from golden.make_golden import SINGLE_RULES, PAIR_RULES
+from metacache_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def cands_equal(dev_row, exp):
+    """dev_row: [K] cand_dtype (unused = hits 0); exp: reference candidates of one query"""
+    n = len(exp)
+    used = int((dev_row["hits"] > 0).sum())
+    if used != n:
+        return False
+    d = dev_row[:n]
+    return (np.array_equal(d["tgt"], exp["tgt"]) and np.array_equal(d["hits"], exp["hits"]) and
+            np.array_equal(d["beg"], exp["beg"]) and np.array_equal(d["end"], exp["end"]))
+
+
+def taxid_of(db_taxa, lin, tgt, lowest):
+    if lowest == 0:
+        return -int(tgt) - 1
+    for r in range(lowest, api.NUM_RANKS):
+        if lin[tgt, r]:
+            return db_taxa[lin[tgt, r] - 1][0]
+    return 0
+
+
+@pytest.mark.parametrize("name", ["toy32", "toy16"])
+def test_golden_single_and_pairs(golden, name):
+    single, p1, p2 = golden.reads()
+    exp_hits = golden.expected(name, "single_allhits")
+    for rname, mc, low, ins in SINGLE_RULES:
+        K = mc if mc else 64
+        db = api.Database.open(golden.db_path(name), max_candidates=K, copy_allhits=1, slot_max_queries=700, slot_max_chars=1 << 18)
+        cands, counts, allhits = db.query(single, lowest=low, insert_max=ins)
+        exp = golden.expected(name, "single_" + rname)
+        taxa, lin = db.taxa(), db.lineages()
+        for i in range(len(single)):
+            assert counts[i] == len(exp_hits[i]), (rname, i)
+            assert np.array_equal(allhits[i]["win"], exp_hits[i]["win"]) and np.array_equal(allhits[i]["tgt"], exp_hits[i]["tgt"]), (rname, i)
+            e = exp[i][:K]
+            assert cands_equal(cands[i], e), (rname, i, cands[i], e)
+            for c in e:
+                assert taxid_of(taxa, lin, c["tgt"], low) == c["taxid"]
+        db.close()
+    exp_hits = golden.expected(name, "pair_allhits")
+    for rname, mc, low, ins in PAIR_RULES:
+        db = api.Database.open(golden.db_path(name), max_candidates=mc, copy_allhits=1)
+        cands, counts, allhits = db.query(p1, p2, lowest=low, insert_max=ins)
+        exp = golden.expected(name, "pair_" + rname)
+        for i in range(len(p1)):
+            assert np.array_equal(allhits[i]["win"], exp_hits[i]["win"]) and np.array_equal(allhits[i]["tgt"], exp_hits[i]["tgt"]), (rname, i)
+            assert cands_equal(cands[i], exp[i]), (rname, i, cands[i], exp[i])
+        db.close()
+
+
+@pytest.mark.parametrize("name", ["toy32", "toy16"])
+def test_golden_load_time_modifiers(golden, name):
+    single, _, _ = golden.reads()
+    z = golden.npz(name + "_expected")
+    idx = z["maxloc2_idx"]
+    sub = [single[i] for i in idx]
+    for key, kw in (("maxloc2", dict(max_locations_per_feature=2)), ("rmover", dict(remove_overpopulated=3))):
+        db = api.Database.open(golden.db_path(name), max_candidates=2, copy_allhits=1, **kw)
+        cands, counts, allhits = db.query(sub)
+        eh, ec = golden.expected(name, key + "_allhits"), golden.expected(name, key + "_c2_seq")
+        for j in range(len(sub)):
+            assert np.array_equal(allhits[j]["win"], eh[j]["win"]) and np.array_equal(allhits[j]["tgt"], eh[j]["tgt"]), (key, j)
+            assert cands_equal(cands[j], ec[j]), (key, j)
+        db.close()
+
+
+def test_candidates_without_allhits_and_small_slots(golden):
+    """allhits off (location lists stay in LDS), tiny slots (many batches), odd K."""
+    single, _, _ = golden.reads()
+    db = api.Database.open(golden.db_path("toy32"), max_candidates=3, copy_allhits=0, slot_max_queries=37, slot_max_chars=1 << 14)
+    cands, counts, _ = db.query(single[:600], lowest=4)
+    exp = golden.expected("toy32", "single_c3_species")
+    eh = golden.expected("toy32", "single_allhits")
+    for i in range(600):
+        assert counts[i] == len(eh[i])
+        assert cands_equal(cands[i], exp[i]), i
+    db.close()
+
+
+def test_random_reads_against_oracle(golden):
+    """fresh seeded reads incl. odd query sketching parameters: HIP path vs the C oracle"""
+    rng = np.random.default_rng(11)
+    orc = cpuref.oracle()
+    odb = orc.open(golden.db_path("toy32"))
+    single, _, _ = golden.reads()
+    pool = b"".join(single[:500])
+    for (s, w, st) in ((16, 127, 112), (8, 64, 49), (32, 300, 290), (16, 127, 40), (16, 100, 130)):
+        reads = []
+        for _ in range(400):
+            L = int(rng.integers(0, 900))
+            o = int(rng.integers(0, len(pool) - L))
+            r = bytearray(pool[o:o + L])
+            for _ in range(int(rng.integers(0, 3))):
+                if L:
+                    r[int(rng.integers(0, L))] = int(rng.choice(list(b"NnRx-acgu")))
+            reads.append(bytes(r))
+        db = api.Database.open(golden.db_path("toy32"), max_candidates=4, copy_allhits=1, sketchlen=s, winlen=w, winstride=st)
+        cands, counts, allhits = db.query(reads, lowest=0, insert_max=0)
+        for i, r in enumerate(reads):
+            h, c = odb.query(r, b"", 4, 0, 0, sketchlen=s, winlen=w, winstride=st)
+            assert np.array_equal(allhits[i]["win"], h["win"]) and np.array_equal(allhits[i]["tgt"], h["tgt"]), (s, w, st, i)
+            assert cands_equal(cands[i], c), (s, w, st, i)
+        db.close()
+    odb.close()
+
+
+def test_device_path_features_match_oracle(golden):
+    """window sketches straight from the device buffers vs the oracle's sketcher"""
+    import torch
+    single, _, _ = golden.reads()
+    reads = single[1590:1700]
+    orc = cpuref.oracle()
+    db = api.Database.open(golden.db_path("toy32"), max_candidates=2)
+    offs, chunks, pos = [], [], 0
+    for r in reads:
+        offs.append((pos, len(r), pos, 0))
+        pad = (-len(r)) % 4
+        chunks.append(r + b"\0" * pad)
+        pos += len(r) + pad
+    buf = np.frombuffer(b"".join(chunks) + b"\0" * 16, dtype=np.uint8)
+    dseq = torch.from_numpy(buf.copy()).cuda()
+    dq = torch.from_numpy(np.array(offs, dtype=np.uint32).view(np.int32).reshape(-1)).cuda()
+    res = db.query_device(dseq.data_ptr(), dq.data_ptr(), len(reads), pos, max_win_uniform=3)
+    db.synchronize()
+    n = len(reads)
+    import ctypes as C
+    winoff = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(winoff.data_ptr()), C.c_void_p(res.win_offsets), (n + 1) * 4, 3)
+    wo = winoff.cpu().numpy().astype(np.int64)
+    feats = torch.empty(int(wo[-1]) * 16, dtype=torch.int32, device="cuda")
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(feats.data_ptr()), C.c_void_p(res.features), int(wo[-1]) * 64, 3)
+    f = feats.cpu().numpy().view(np.uint32).reshape(-1, 16)
+    for i, r in enumerate(reads):
+        ef, ec = orc.sketch(r, 16, 16, 127, 112)
+        assert wo[i + 1] - wo[i] == len(ec), i
+        assert np.array_equal(f[wo[i]:wo[i + 1]], ef), i
+    st = db.last_batch_stats()
+    assert st["windows"] == wo[-1]
+    db.close()
