@@ -165,6 +165,9 @@ typedef struct {
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int want_allhits,
                     mc_device_results* out, void* stream);
 int mc_synchronize(mc_ctx* ctx);
+/* copies out of the ctx-owned result buffers, asynchronous on the context's stream
+ * (kind: 0 = device -> device, 1 = device -> host) */
+int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "sketch_probe", "scan", "sort_candidates", "plan".  Returns accumulated milliseconds and
@@ -198,8 +201,10 @@ int  mc_build_begin(const mc_config* cfg, mc_builder** out);
 int  mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parent_taxid,
                          const char* source_filename);
 /* sorts + bucketises everything added so far; if out_ctx != NULL also loads the table into a fresh
- * query context created from the builder's config merged with qcfg (may be NULL). */
+ * query context (see mc_build_set_query_config). */
 int  mc_build_finish(mc_builder* b, mc_ctx** out_ctx);
+/* fields of the query context mc_build_finish creates (max_candidates, slots, copy_allhits, load factor) */
+int  mc_build_set_query_config(mc_builder* b, const mc_config* qcfg);
 /* writes <name>.meta and <name>.cache0 in the reference's format (after mc_build_finish) */
 int  mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa);
 void mc_build_free(mc_builder* b);

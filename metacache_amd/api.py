@@ -46,8 +46,10 @@ class McDeviceResults(C.Structure):
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end",
            "mc_open_database", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_lineages",
            "mc_batch_add", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
+           "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
-           "mc_build_begin", "mc_build_add_target", "mc_build_finish", "mc_build_write", "mc_build_free", "mc_build_last_error"]
+           "mc_build_begin", "mc_build_add_target", "mc_build_finish", "mc_build_write", "mc_build_free", "mc_build_last_error",
+           "mc_build_set_query_config"]
 
 _lib = None
 
@@ -56,6 +58,13 @@ def lib() -> C.CDLL:
     """Loads (building first if needed) libmetacache_amd.so.  Raises if that is impossible."""
     global _lib
     if _lib is None:
+        # PyTorch's wheel bundles its own libamdhip64 / libhsa-runtime64.  Two HSA runtimes in one
+        # process do not both see the GPU, so when torch is present it is imported FIRST and our
+        # library then binds (by SONAME libamdhip64.so.7) to the runtime that is already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = _build.build_library()
         L = C.CDLL(path)
         L.mc_last_error.restype = C.c_char_p
@@ -79,6 +88,7 @@ def lib() -> C.CDLL:
         L.mc_batch_clear.argtypes = [C.c_void_p, C.c_uint32]
         L.mc_query_device.argtypes = [C.c_void_p, C.POINTER(McDeviceBatch), C.c_int, C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
         L.mc_synchronize.argtypes = [C.c_void_p]
+        L.mc_copy_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.mc_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mc_timing_reset.argtypes = [C.c_void_p]
         L.mc_timing_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -223,6 +233,9 @@ class Database:
         self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits), C.byref(r), stream or None))
         return r
 
+    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False):
+        self._check(lib().mc_copy_results(self.h, dst_ptr, src_ptr, nbytes, 1 if to_host else 0))
+
     def synchronize(self):
         self._check(lib().mc_synchronize(self.h))
 
@@ -241,3 +254,57 @@ class Database:
         st = np.zeros(8, dtype=np.uint64)
         self._check(lib().mc_last_batch_stats(self.h, st.ctypes.data_as(C.c_void_p)))
         return dict(windows=int(st[0]), features=int(st[1]), locations=int(st[2]), found=int(st[3]), probe_steps=int(st[4]))
+
+
+class Builder:
+    """Minimal database builder (mc_build_*): sketches targets on the GPU, writes reference-format files."""
+
+    def __init__(self, **kw):
+        self.cfg = default_config(**kw)
+        self.h = C.c_void_p()
+        rc = lib().mc_build_begin(C.byref(self.cfg), C.byref(self.h))
+        if rc != MC_OK:
+            raise McError(f"mc_build_begin -> {rc}: {lib().mc_last_error(None).decode()}")
+        lib().mc_build_last_error.restype = C.c_char_p
+        lib().mc_build_last_error.argtypes = [C.c_void_p]
+
+    def _check(self, rc):
+        if rc < 0:
+            raise McError(f"builder error {rc}: {lib().mc_build_last_error(self.h).decode()}")
+
+    def add_target(self, seq: np.ndarray | bytes, name: str, parent_taxid: int = 0, filename: str = ""):
+        a = np.frombuffer(seq, dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(seq, dtype=np.uint8)
+        self._check(lib().mc_build_add_target(self.h, a.ctypes.data_as(C.c_void_p), a.size, name.encode(), parent_taxid, filename.encode()))
+
+    def finish(self, load: bool = True, **query_kw) -> "Database | None":
+        """Sort + bucketise.  load=True also returns a query Database holding the table."""
+        if not load:
+            self._check(lib().mc_build_finish(self.h, None))
+            return None
+        for k, v in query_kw.items():
+            setattr(self.cfg, k, v)
+        # the builder creates the query context from ITS config; update it first
+        out = C.c_void_p()
+        self._sync_cfg()
+        self._check(lib().mc_build_finish(self.h, C.byref(out)))
+        return Database.from_handle(out.value, self.cfg)
+
+    def _sync_cfg(self):
+        lib().mc_build_set_query_config.argtypes = [C.c_void_p, C.POINTER(McConfig)]
+        lib().mc_build_set_query_config(self.h, C.byref(self.cfg))
+
+    def write(self, name: str, taxa: list[tuple[int, int, int, str]]):
+        """taxa: (id, parent, rank, name) of the non-target taxa"""
+        class Rec(C.Structure):
+            _fields_ = [("id", C.c_int64), ("parent", C.c_int64), ("rank", C.c_uint32), ("name", C.c_char_p)]
+        arr = (Rec * max(len(taxa), 1))()
+        keep = []
+        for i, (tid, par, rk, nm) in enumerate(taxa):
+            b = nm.encode(); keep.append(b)
+            arr[i] = Rec(tid, par, rk, b)
+        self._check(lib().mc_build_write(self.h, name.encode(), C.cast(arr, C.c_void_p), len(taxa)))
+
+    def free(self):
+        if self.h:
+            lib().mc_build_free(self.h)
+            self.h = None

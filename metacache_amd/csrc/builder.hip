@@ -274,6 +274,15 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
     return MC_OK;
 }
 
+int mc_build_set_query_config(mc_builder* b, const mc_config* q)
+{
+    if (!b || !q) return MC_ERR_INVALID;
+    b->cfg.max_candidates = q->max_candidates; b->cfg.max_load_factor = q->max_load_factor;
+    b->cfg.num_slots = q->num_slots; b->cfg.slot_max_queries = q->slot_max_queries; b->cfg.slot_max_chars = q->slot_max_chars;
+    b->cfg.copy_allhits = q->copy_allhits;
+    return MC_OK;
+}
+
 int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa)
 {
     if (!b || !name) return MC_ERR_INVALID;

@@ -394,6 +394,14 @@ int mc_synchronize(mc_ctx* ctx)
     return MC_OK;
 }
 
+int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind)
+{
+    if (!ctx || !dst || !src) return MC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return MC_OK;
+}
+
 int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
 {
     if (!ctx) return MC_ERR_INVALID;

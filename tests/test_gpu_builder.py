@@ -1,0 +1,89 @@
+"""GPU: the minimal database builder (mc_build_*): bucket contents against an independent construction
+from the oracle's sketcher, the written files against the oracle's (and, if present, the reference's)
+reader, and queries on the directly-loaded table against queries on the files."""
+import os
+
+import numpy as np
+import pytest
+
+import cpuref
+from metacache_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_genomes(rng, n=20, length=10000, copies=16):
+    repeat = synth.random_genome(rng, 448)
+    gs = []
+    for _ in range(n):
+        g = synth.random_genome(rng, length + int(rng.integers(0, 200)))
+        for slot in rng.choice(np.arange(1, length // 112 - 5), size=copies, replace=False):
+            p = int(slot) * 112
+            g[p:p + 448] = repeat
+        gs.append(g)
+    gs.append(synth.random_genome(rng, 100))      # shorter than one window
+    gs.append(synth.random_genome(rng, 127))      # exactly one window
+    gs.append(synth.random_genome(rng, 10))       # shorter than k: no windows at all
+    gs.append(np.frombuffer(b"N" * 300, dtype=np.uint8).copy())   # windows without features still count
+    gs.append(synth.random_genome(rng, 112 * 300 + 127))          # > 256 windows: crosses a builder chunk boundary
+    return gs
+
+
+@pytest.mark.parametrize("tb", [4, 2])
+def test_builder_buckets_files_and_queries(tmp_path, tb):
+    rng = np.random.default_rng(5 + tb)
+    orc = cpuref.oracle()
+    genomes = make_genomes(rng)
+    bld = api.Builder(target_id_bytes=tb, max_candidates=2, copy_allhits=1)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"SYN_{i:05d}.1", parent_taxid=1000 + i % 5, filename=f"f{i}.fa")
+    db = bld.finish(load=True)
+    name = str(tmp_path / "built")
+    taxa = [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"species {i}") for i in range(5)]
+    bld.write(name, taxa)
+    bld.free()
+
+    # independent expectation: feature -> first 254 (tgt, win) in insertion order
+    expect = {}
+    for t, g in enumerate(genomes):
+        feats, counts = orc.sketch(g.tobytes(), 16, 16, 127, 112)
+        for w in range(len(counts)):
+            for f in feats[w, :counts[w]]:
+                expect.setdefault(int(f), []).append((t << 32) | w)
+    odb = orc.open(name)
+    assert odb.ref.lib.mco_db_target_id_bytes(odb.h) == tb
+    assert odb.n_targets == len(genomes)
+    nloc = 0
+    for f, locs in expect.items():
+        got = odb.lookup(f)
+        want = np.array(locs[:254], dtype=np.uint64)
+        assert np.array_equal(got, want), f
+        nloc += len(want)
+    assert odb.n_locations == nloc == db.n_locations
+    assert max(len(v) for v in expect.values()) > 254          # the cap was exercised
+
+    # queries: table loaded straight from the builder == table loaded from the files == oracle on the files
+    reads, _, _ = synth.sample_reads(rng, [g for g in genomes if g.size > 200], 600, 150, 0.01, 0.002)
+    reads = [bytes(r) for r in reads]
+    c1, n1, h1 = db.query(reads)
+    db2 = api.Database.open(name, max_candidates=2, copy_allhits=1)
+    c2, n2, h2 = db2.query(reads)
+    assert np.array_equal(c1, c2) and np.array_equal(n1, n2)
+    have_ref = cpuref.have_reference(tb)
+    rdb = cpuref.reference(tb).open(name) if have_ref else None
+    for i, r in enumerate(reads):
+        h, c = odb.query(r, b"", 2, 0, 0)
+        assert np.array_equal(h1[i]["win"], h["win"]) and np.array_equal(h1[i]["tgt"], h["tgt"]), i
+        assert np.array_equal(h2[i]["win"], h["win"]) and np.array_equal(h2[i]["tgt"], h["tgt"]), i
+        k = len(c)
+        assert int((c1[i]["hits"] > 0).sum()) == k
+        for f in ("tgt", "hits", "beg", "end"):
+            assert np.array_equal(c1[i][:k][f], c[f]), (i, f)
+        if rdb is not None:                                   # the real reference reads OUR files
+            hr, cr = rdb.query(r, b"", 2, 0, 0)
+            assert np.array_equal(hr, h) and np.array_equal(cr, c), i
+    if rdb is not None:
+        assert rdb.info()[:7] == odb.info()[:7]
+        assert np.array_equal(rdb.lineages(), odb.lineages())
+        rdb.close()
+    odb.close(); db.close(); db2.close()
