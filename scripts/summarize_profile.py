@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag>/ directory (scripts/profile.sh) into profiles/<tag>_*.{csv,md}."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(k):
+    if "sketch_probe_kernel<true>" in k: return "sketch_probe<probe>"
+    if "sketch_probe_kernel<false>" in k: return "sketch_probe<sketch-only>"
+    if "fused_query" in k: return "fused_query"
+    for n in ("sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs"):
+        if n in k: return n
+    return None
+
+
+# 1. rocprofv3 --kernel-trace --stats summary, our kernels only (torch's synthetic-data kernels dropped)
+rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        if "mcamd" in r["Name"]:
+            w.writerow([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+# 2. PMC counters per kernel (mean per dispatch over the dispatches of each separate --pmc pass)
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for fn in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(fn)):
+        s = short(r["Kernel_Name"])
+        if s:
+            res[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+    for k in sorted(res):
+        for c in sorted(res[k]):
+            v = res[k][c]
+            w.writerow([k, c, len(v), f"{sum(v) / len(v):.6g}"])
+print("wrote", dst)

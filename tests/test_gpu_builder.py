@@ -12,7 +12,7 @@ from metacache_amd import api, synth
 pytestmark = pytest.mark.gpu
 
 
-def make_genomes(rng, n=20, length=10000, copies=16):
+def make_genomes(rng, n=20, length=10000, copies=26):
     repeat = synth.random_genome(rng, 448)
     gs = []
     for _ in range(n):
