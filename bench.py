@@ -32,6 +32,7 @@ import torch  # noqa: E402  (plumbing: device memory, streams, torch.distributed
 import torch.distributed as dist  # noqa: E402
 
 from metacache_amd import api, synth  # noqa: E402
+from metacache_amd.distributed import gather_candidates  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
@@ -165,7 +166,6 @@ def main():
     batches = [torch.cat([b, slack]) for b in batches]
     max_win = db.max_windows_in_range(READ_LEN)              # = 3 for 150 bp
     out_cands = torch.zeros((B, K, 4), dtype=torch.int32, device=dev)
-    gathered = [torch.zeros_like(out_cands) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
     def step(i: int):
@@ -174,7 +174,7 @@ def main():
         db.copy_results(out_cands.data_ptr(), res.cands, B * K * 16)
         db.synchronize()
         if world > 1:                                        # per-rank hit lists -> rank 0 (RCCL over xGMI)
-            dist.gather(out_cands, gathered, dst=0)
+            gather_candidates(out_cands, dst=0)
         return res
 
     for i in range(args.warmup):

@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the N>1 driver logic (read sharding + gather of per-rank candidate lists).
+The per-rank compute is stood in for by the C oracle (the HIP path needs a GPU); what is under test is
+metacache_amd/distributed.py, which bench.py and multi-GPU callers use unchanged with RCCL."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from metacache_amd.distributed import shard_bounds
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, K, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import cpuref
+    from metacache_amd.distributed import classify_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gold = os.path.join(here, "golden")
+    z = np.load(os.path.join(gold, "toy_reads.npz"))
+    off = z["single_off"]
+    reads = [z["single"][int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+    db = cpuref.oracle().open(os.path.join(gold, "toy32"))
+
+    def classify(lo, hi):
+        out = torch.zeros((hi - lo, K, 4), dtype=torch.int32)
+        for i in range(lo, hi):
+            _, c = db.query(reads[i], b"", K, 0, 0)
+            for j in range(len(c)):
+                out[i - lo, j] = torch.tensor([int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], dtype=torch.int64).to(torch.int32)
+        return out
+
+    res = classify_sharded(n, classify)
+    if rank == 0:
+        q.put(res.numpy())
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100, 101):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_two_ranks_gloo_gather_matches_single_process(golden):
+    import cpuref
+    n, K, world = 101, 2, 2          # odd count: shards of different size
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, _, _ = golden.reads()
+    db = cpuref.oracle().open(golden.db_path("toy32"))
+    assert got.shape == (n, K, 4)
+    for i in range(n):
+        _, c = db.query(single[i], b"", K, 0, 0)
+        for j in range(K):
+            if j < len(c):
+                assert [int(x) for x in got[i, j].view(np.uint32)] == [int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])]
+            else:
+                assert got[i, j, 1] == 0
+    db.close()
