@@ -142,7 +142,8 @@ int mc_batch_clear(mc_ctx* ctx, uint32_t slot);
  *   max_win : [n] maxWindowsInRange per query (candidate_structs.hpp:143-145), or NULL with
  *             max_win_uniform > 0
  * Results stay on device inside ctx-owned buffers (valid until the next call on this ctx):
- *   cands [n * max_candidates], hit_counts [n], and -- if want_allhits -- hit_offsets [n+1] / hits.
+ *   cands [n * max_candidates], hit_counts [n] (stride 4 words: {hits, features, found, probe steps}), and -- per
+ *   flags -- hit_offsets [n+1] / hits, features.
  * 'stream' is a hipStream_t (NULL = the context's own stream); the call is asynchronous. */
 typedef struct {
     const uint8_t*  seq;
@@ -162,7 +163,9 @@ typedef struct {
     const uint32_t*     win_offsets;  /* [n+1] first window index of each query */
 } mc_device_results;
 
-int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int want_allhits,
+#define MC_WANT_ALLHITS  1   /* keep the sorted location lists (hit_offsets / hits) */
+#define MC_WANT_FEATURES 2   /* keep the window sketches (features) */
+int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);
 int mc_synchronize(mc_ctx* ctx);
 /* copies out of the ctx-owned result buffers, asynchronous on the context's stream

@@ -309,8 +309,10 @@ static int taxkey_for_rank(mc_ctx* ctx, int rank, const uint32_t** out)
 // ------------------------------------------------------------------------------------------------
 // the per-batch pipeline
 // ------------------------------------------------------------------------------------------------
-int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int wantAllhits, mc_device_results* out, void* streamv)
+int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
 {
+    const int wantAllhits = flags & MC_WANT_ALLHITS;
+    const bool wantFeatures = (flags & MC_WANT_FEATURES) != 0;
     if (!ctx || !in || !out) return MC_ERR_INVALID;
     if (ctx->parts.empty() || !ctx->parts[0].ready) return fail(ctx, MC_ERR_STATE, "no database loaded");
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
@@ -329,7 +331,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     const size_t nfeat = (size_t)maxWindows * sp.s;
     if ((rc = ensure(ctx, ctx->bWinCount, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bWinOff, (size_t)(n + 2) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
+    if (wantFeatures && (rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bPsize, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bPpay, nfeat * 8))) return rc;
     if ((rc = ensure(ctx, ctx->bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
@@ -341,7 +343,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
 
     Workspace ws{};
     ws.winCount = (uint32_t*)ctx->bWinCount.p; ws.winOff = (uint32_t*)ctx->bWinOff.p;
-    ws.features = (uint32_t*)ctx->bFeatures.p; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
+    ws.features = wantFeatures ? (uint32_t*)ctx->bFeatures.p : nullptr; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
     ws.qstat = (QueryStat*)ctx->bQstat.p; ws.hitScan = (uint32_t*)ctx->bScanIn.p; ws.hitOff = (uint64_t*)ctx->bHitOff.p;
     ws.scanTmp = ctx->bScan.p; ws.stats = (uint64_t*)ctx->bStats.p;
 

@@ -52,10 +52,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane
     }
     return v;
 }
-// orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote)
+// orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote).
+// Heavy: waits for every outstanding global load AND store of the wave.
 __device__ __forceinline__ void wave_mem_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// LDS-only flavour: DS operations of one wave execute in issue order, so all that is needed is that
+// the compiler keeps the order and earlier DS results have landed; outstanding global stores are NOT
+// drained (an s_waitcnt vmcnt(0) per window exposed the full HBM write latency).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -238,6 +247,9 @@ __device__ __forceinline__ uint32_t encode_base(uint32_t c)
 struct WaveLds {
     uint32_t code[kCodeWords];
     uint32_t amb[kAmbWords];
+    uint32_t cand[64];      // compacted candidates of the min-hash selection
+    uint32_t sk[64];        // current sketch during selection
+    uint32_t fbuf[64];      // features of the current group of windows (slot = window-in-group * s + j)
 };
 
 // Stage window [p, p+n) of the sequence as packed 2-bit codes + ambiguity bits into this wave's LDS.
@@ -270,6 +282,170 @@ __device__ __forceinline__ void stage_window(const uint8_t* __restrict__ seq, ui
     }
 }
 
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ascending bitonic sort of one u32 per lane (64 lanes), duplicates allowed
+__device__ __forceinline__ uint32_t wave_sort32_reg(uint32_t key, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1) {
+        {
+            uint32_t o = __shfl(key, lane ^ (k - 1));
+            key = ((lane & (k >> 1)) == 0) ? min(key, o) : max(key, o);
+        }
+#pragma unroll
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            uint32_t o = __shfl(key, lane ^ j);
+            key = ((lane & j) == 0) ? min(key, o) : max(key, o);
+        }
+    }
+    return key;
+}
+
+// hash of the k-mer starting at window position p, or ~0 if it is out of range / ambiguous
+__device__ __forceinline__ uint32_t kmer_hash_at(const WaveLds& L, uint32_t p, uint32_t nk, uint32_t k, uint32_t kbits)
+{
+    uint32_t h = 0xFFFFFFFFu;
+    if (p < nk) {
+        const uint32_t wq = p >> 4, sh = (p & 15u) * 2u;
+        const uint32_t kmer = __funnelshift_l(L.code[wq + 1], L.code[wq], sh) >> (32u - 2u * k);
+        const uint32_t aw = p >> 5;
+        const uint32_t am = __funnelshift_r(L.amb[aw], L.amb[aw + 1], p & 31u) & kbits;
+        if (am == 0) h = canonical_hash(kmer, k);              // dna_encoding.hpp:438-441
+    }
+    return h;
+}
+
+// Min-hash sketch of the staged window (hash_dna.hpp:224-251): the sl smallest DISTINCT hashes,
+// ascending; returns it one element per lane (lane j < count holds element j, others ~0).
+//
+// Instead of sl serial minimum extractions, hashes below a threshold T (chosen so that ~1.75 sl of
+// the uniformly distributed hashes pass) are compacted with ballot/mbcnt, sorted with a 64-lane
+// register bitonic network and made unique.  Exact: if at least sl distinct values are < T they are
+// the sl smallest overall; otherwise T is raised and the window redone (rare).  More than 64
+// candidates (degenerate input) fall back to serial extraction.
+__device__ __forceinline__ uint32_t sketch_staged_window(WaveLds& L, uint32_t n, uint32_t k, uint32_t s, uint32_t lane, uint32_t& countOut)
+{
+    const uint32_t kbits = 0xFFFFu >> (16u - k);
+    const uint32_t nk = n - k + 1;
+    const uint32_t sl = min(s, nk);
+    uint64_t t64 = (((uint64_t)7 * sl) << 32) / ((uint64_t)4 * nk);
+    uint32_t T = t64 >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t64;
+    uint32_t sk, cnt;
+    for (;;) {
+        sk = 0xFFFFFFFFu; cnt = 0;
+        for (uint32_t base = 0; base < nk; base += 128) {       // two k-mers per lane per round
+            const uint32_t h0 = kmer_hash_at(L, base + lane, nk, k, kbits);
+            const uint32_t h1 = kmer_hash_at(L, base + 64 + lane, nk, k, kbits);
+            const bool p0 = h0 < T, p1 = h1 < T;
+            const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+            const uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
+            const uint32_t nc = cnt + n0 + n1;
+            if (nc == cnt) continue;
+            if (nc <= 64) {
+                if (lane < cnt) L.cand[lane] = sk;
+                if (p0) L.cand[cnt + mbcnt(m0)] = h0;
+                if (p1) L.cand[cnt + n0 + mbcnt(m1)] = h1;
+                wave_lds_sync();
+                uint32_t v = lane < nc ? L.cand[lane] : 0xFFFFFFFFu;
+                v = wave_sort32_reg(v, lane);
+                uint32_t prev = __shfl_up(v, 1);
+                const bool uniq = lane < nc && (lane == 0 || v != prev);
+                const uint64_t um = __ballot(uniq);
+                const uint32_t upos = mbcnt(um);
+                if (uniq && upos < sl) L.sk[upos] = v;
+                cnt = min(sl, (uint32_t)__popcll(um));
+                wave_lds_sync();
+                sk = lane < cnt ? L.sk[lane] : 0xFFFFFFFFu;
+                wave_lds_sync();
+            } else {
+                // serial extraction over {old sketch, h0, h1} restricted to values < T
+                uint32_t nsk = 0xFFFFFFFFu, lb = 0, c = 0;
+                const uint32_t a0 = p0 ? h0 : 0xFFFFFFFFu, a1 = p1 ? h1 : 0xFFFFFFFFu;
+                for (uint32_t t = 0; t < sl; ++t) {
+                    uint32_t cand = min(min(a0 >= lb ? a0 : 0xFFFFFFFFu, a1 >= lb ? a1 : 0xFFFFFFFFu), sk >= lb ? sk : 0xFFFFFFFFu);
+                    uint32_t m = wave_min_u32(cand);
+                    if (m == 0xFFFFFFFFu) break;
+                    if (lane == t) nsk = m;
+                    lb = m + 1; ++c;
+                }
+                sk = nsk; cnt = c;
+            }
+        }
+        if (cnt >= sl || T == 0xFFFFFFFFu) break;
+        T = T >= 0x40000000u ? 0xFFFFFFFFu : T << 2;
+    }
+    countOut = cnt;
+    return sk;
+}
+
+constexpr uint32_t kProbeRounds = 4;                    // 4 x 8 = 32 feature slots per probe group
+constexpr uint32_t kGroupSlots = kProbeRounds * 8;
+
+// Probe the features held in L.fbuf[0 .. nslots) (slot j -> global feature index fbase + j):
+// 8 lanes x 16 B read one 128-byte bucket group per feature; the first-step loads of all (up to 4)
+// rounds are issued before any result is used.
+__device__ __forceinline__ void probe_group(const WaveLds& L, uint32_t nslots, uint32_t fbase, const DeviceTable& tab, const Workspace& ws,
+                                            uint32_t lane, uint32_t& myHits, uint32_t& nfound, uint32_t& nsteps)
+{
+    const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
+    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
+    uint32_t f[kProbeRounds], g[kProbeRounds];
+    uint4 sl4[kProbeRounds];
+    const uint32_t rounds = (nslots + 7) >> 3;
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        f[r] = 0xFFFFFFFFu; sl4[r] = make_uint4(0, 0, 0, 0); g[r] = 0;
+        if (r < rounds) {
+            const uint32_t fi = r * 8 + grp;
+            f[r] = fi < nslots ? L.fbuf[fi] : 0xFFFFFFFFu;
+            if (f[r] != 0xFFFFFFFFu) {
+                g[r] = home_group(f[r], tab.ngroups);
+                sl4[r] = slots[(size_t)g[r] * kSlotsPerGroup + sub];
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        if (r < rounds) {                                       // wave-uniform
+            const uint32_t fi = r * 8 + grp;
+            bool active = f[r] != 0xFFFFFFFFu;
+            uint4 cur = sl4[r];
+            uint32_t gg = g[r];
+            uint32_t rsize = 0; uint64_t rpay = 0;
+            bool wrote = false;
+            for (uint32_t step = 0;; ++step) {
+                const bool occ = active && (cur.y >> 31);
+                const bool hit = occ && cur.x == f[r];
+                const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
+                const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
+                if (hit) { rsize = cur.y & 0xFFFFu; rpay = ((uint64_t)cur.w << 32) | cur.z; wrote = true; }
+                nsteps += (active && sub == 0) ? 1u : 0u;
+                // finished when found, or when the group has a free slot (insertion fills the first
+                // group with room, so the key cannot live further along the chain)
+                if (ghit != 0 || gocc != 0xFFu) active = false;
+                if (!__any(active) || step + 1 >= tab.maxProbe) break;
+                gg = (gg + 1 == tab.ngroups) ? 0u : gg + 1;
+                cur = make_uint4(0, 0, 0, 0);
+                if (active) cur = slots[(size_t)gg * kSlotsPerGroup + sub];
+            }
+            if (fi < nslots) {
+                // exactly one lane per feature writes: the hit lane, else sub-lane 0
+                const uint32_t anyhit = (uint32_t)(__ballot(wrote) >> gshift) & 0xFFu;
+                if (wrote || (anyhit == 0 && sub == 0)) {
+                    ws.psize[fbase + fi] = rsize;
+                    ws.ppay[fbase + fi] = rpay;
+                }
+            }
+            myHits += rsize;
+            nfound += wrote ? 1u : 0u;
+        }
+    }
+}
+
 template <bool PROBE>
 __global__ __launch_bounds__(256) void sketch_probe_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, int wantAllhits)
 {
@@ -283,9 +459,11 @@ __global__ __launch_bounds__(256) void sketch_probe_kernel(BatchView b, SketchPa
     const bool noTail = qi.w == kNoTail;
     uint32_t widx = ws.winOff[q];                         // global index of this query's next window
     const uint32_t k = sp.k, s = sp.s;
-    const uint32_t kbits = 0xFFFFu >> (16u - k);          // k ambiguity bits
+    const uint32_t winsPerGroup = kGroupSlots / s;        // feature slots of one probe group = winsPerGroup * s <= 32
 
     uint32_t myHits = 0, nfeat = 0, nfound = 0, nsteps = 0;
+    uint32_t gslot = 0;                                   // windows already in the current group
+    uint32_t gfirst = widx;                               // global window index of the group's first window
 
     for (uint32_t mate = 0; mate < 2; ++mate) {
         const uint32_t off = mate ? qi.z : qi.x;
@@ -295,80 +473,25 @@ __global__ __launch_bounds__(256) void sketch_probe_kernel(BatchView b, SketchPa
             const uint32_t first = (len <= sp.w) ? 0u : wi * sp.stride;
             const uint32_t n = min(sp.w, len - first);
             stage_window(b.seq, (uint64_t)off + first, n, L, lane);
-            wave_mem_sync();
-
-            // ---- min-hash sketch: the sl smallest distinct hashes, ascending (hash_dna.hpp:224-251)
-            const uint32_t nk = n - k + 1;
-            const uint32_t sl = min(s, nk);
-            uint32_t sk = 0xFFFFFFFFu;                    // lane j holds sketch element j
-            for (uint32_t base = 0; base < nk; base += 64) {
-                const uint32_t p = base + lane;
-                uint32_t h = 0xFFFFFFFFu;
-                if (p < nk) {
-                    const uint32_t wq = p >> 4, sh = (p & 15u) * 2u;
-                    const uint32_t kmer = __funnelshift_l(L.code[wq + 1], L.code[wq], sh) >> (32u - 2u * k);
-                    const uint32_t aw = p >> 5;
-                    const uint32_t am = __funnelshift_r(L.amb[aw], L.amb[aw + 1], p & 31u) & kbits;
-                    if (am == 0) h = canonical_hash(kmer, k);   // dna_encoding.hpp:438-441
-                }
-                const uint32_t thr = rdlane(sk, sl - 1);
-                if (__any(h < thr)) {
-                    // merge: new sketch = sl smallest distinct of {old sketch} U {this chunk}
-                    uint32_t nsk = 0xFFFFFFFFu, lb = 0;
-                    for (uint32_t t = 0; t < sl; ++t) {
-                        uint32_t cand = min(h >= lb ? h : 0xFFFFFFFFu, sk >= lb ? sk : 0xFFFFFFFFu);
-                        uint32_t m = wave_min_u32(cand);
-                        if (m == 0xFFFFFFFFu) break;      // value ~0 can never enter (hash_dna.hpp:233)
-                        if (lane == t) nsk = m;
-                        lb = m + 1;
-                    }
-                    sk = nsk;
-                }
+            wave_lds_sync();
+            uint32_t cnt;
+            const uint32_t sk = sketch_staged_window(L, n, k, s, lane, cnt);
+            if (lane < s) {
+                if (ws.features) ws.features[widx * s + lane] = sk;
+                L.fbuf[gslot * s + lane] = sk;
             }
-            const uint32_t fbase = widx * s;
-            if (lane < s) ws.features[fbase + lane] = sk;
-            nfeat += (lane < s && sk != 0xFFFFFFFFu) ? 1u : 0u;
-
-            if (PROBE) {
-                // ---- 8 lanes x 16 B read one 128-byte bucket group per feature
-                const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
-                for (uint32_t r = 0; r * 8 < s; ++r) {
-                    const uint32_t fi = r * 8 + grp;
-                    const uint32_t f = __shfl(sk, fi);
-                    bool active = fi < s && f != 0xFFFFFFFFu;
-                    uint32_t g = home_group(f, tab.ngroups);
-                    uint32_t rsize = 0; uint64_t rpay = 0;
-                    bool wrote = false;
-                    for (uint32_t step = 0; step < tab.maxProbe; ++step) {
-                        uint4 sl4 = make_uint4(0, 0, 0, 0);
-                        if (active) sl4 = reinterpret_cast<const uint4*>(tab.slots)[(size_t)g * kSlotsPerGroup + sub];
-                        const bool occ = active && (sl4.y >> 31);
-                        const bool hit = occ && sl4.x == f;
-                        const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
-                        const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
-                        if (hit) { rsize = sl4.y & 0xFFFFu; rpay = ((uint64_t)sl4.w << 32) | sl4.z; wrote = true; }
-                        nsteps += (active && sub == 0) ? 1u : 0u;
-                        // finished when found, or when the group has a free slot (insertion fills the
-                        // first group with room, so the key cannot live further along the chain)
-                        if (ghit != 0 || gocc != 0xFFu) active = false;
-                        if (!__any(active)) break;
-                        g = (g + 1 == tab.ngroups) ? 0u : g + 1;
-                    }
-                    if (fi < s) {
-                        // exactly one lane per feature writes: the hit lane, else sub-lane 0
-                        const uint32_t anyhit = (uint32_t)(__ballot(wrote) >> gshift) & 0xFFu;
-                        if (wrote || (anyhit == 0 && sub == 0)) {
-                            ws.psize[fbase + fi] = rsize;
-                            ws.ppay[fbase + fi] = rpay;
-                        }
-                    }
-                    myHits += rsize;
-                    nfound += wrote ? 1u : 0u;
-                }
+            nfeat += lane < cnt ? 1u : 0u;
+            ++gslot;
+            wave_lds_sync();
+            if (gslot == winsPerGroup) {
+                if (PROBE) probe_group(L, gslot * s, gfirst * s, tab, ws, lane, myHits, nfound, nsteps);
+                gslot = 0; gfirst = widx + 1;
+                wave_lds_sync();
             }
-            wave_mem_sync();                              // LDS is re-staged by the next window
         }
     }
+    if (PROBE && gslot) probe_group(L, gslot * s, gfirst * s, tab, ws, lane, myHits, nfound, nsteps);
+
     const uint32_t H = wave_sum_u32(myHits);
     const uint32_t F = wave_sum_u32(nfeat);
     const uint32_t Fo = wave_sum_u32(nfound);
@@ -398,6 +521,9 @@ void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const Devic
 // Lists of up to kLdsCap locations live in LDS; longer ones are processed in place in HBM.
 // ================================================================================================
 
+template <bool LDS>
+__device__ __forceinline__ void wsync() { if (LDS) wave_lds_sync(); else wave_mem_sync(); }
+
 __device__ __forceinline__ void cmpxchg(uint64_t* buf, uint32_t i, uint32_t p)
 {
     uint64_t a = buf[i], c = buf[p];
@@ -405,6 +531,7 @@ __device__ __forceinline__ void cmpxchg(uint64_t* buf, uint32_t i, uint32_t p)
 }
 
 // ascending bitonic sort of buf[0..n) by one wave; indices >= n behave as +infinity
+template <bool LDS>
 __device__ __forceinline__ void wave_sort_u64(uint64_t* buf, uint32_t n, uint32_t lane)
 {
     if (n < 2) return;
@@ -418,13 +545,13 @@ __device__ __forceinline__ void wave_sort_u64(uint64_t* buf, uint32_t n, uint32_
             const uint32_t i = blk * k + r, p = blk * k + (k - 1 - r);
             if (p < n) cmpxchg(buf, i, p);
         }
-        wave_mem_sync();
+        wsync<LDS>();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < half; t += 64) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
                 if (p < n) cmpxchg(buf, i, p);
             }
-            wave_mem_sync();
+            wsync<LDS>();
         }
     }
 }
@@ -449,15 +576,16 @@ __device__ __forceinline__ uint64_t wave_sort64_reg(uint64_t key, uint32_t lane)
     return key;
 }
 
+template <bool LDS>
 __device__ __forceinline__ void sort_list(uint64_t* buf, uint32_t n, uint32_t lane)
 {
     if (n <= 64) {
         uint64_t key = lane < n ? buf[lane] : ~0ull;
         key = wave_sort64_reg(key, lane);
         if (lane < n) buf[lane] = key;
-        wave_mem_sync();
+        wsync<LDS>();
     } else {
-        wave_sort_u64(buf, n, lane);
+        wave_sort_u64<LDS>(buf, n, lane);
     }
 }
 
@@ -499,6 +627,7 @@ __device__ __forceinline__ void emit_empty(mc_candidate_dev* out, uint32_t from,
 
 // buf[0..H) sorted.  Builds the per-target candidates in C (C2 = scratch for taxon merging) and
 // writes the top K to out.
+template <bool LDS>
 __device__ __forceinline__ void candidates_from_sorted(
     const uint64_t* buf, uint64_t* C, uint64_t* C2, const uint32_t H, const uint32_t maxWin, const uint32_t K,
     const uint32_t* __restrict__ taxkey, mc_candidate_dev* out, uint32_t lane)
@@ -546,7 +675,7 @@ __device__ __forceinline__ void candidates_from_sorted(
         carryVal = rdlane64(val, 63);
         carryTgt = rdlane(tgt, 63);
     }
-    wave_mem_sync();
+    wsync<LDS>();
 
     // ---- row 10: order candidates
     uint64_t* S = C;       // list that ends up sorted ascending by ~packed
@@ -563,8 +692,8 @@ __device__ __forceinline__ void candidates_from_sorted(
                 C2[j] = tax ? (((uint64_t)tax << 40) | ((uint64_t)((~hits) & 0xFFFFFu) << 20) | j) : ~0ull;
             }
         }
-        wave_mem_sync();
-        sort_list(C2, ncand, lane);
+        wsync<LDS>();
+        sort_list<LDS>(C2, ncand, lane);
         uint32_t carryTax = 0;
         for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
             const uint32_t j = c0 + lane;
@@ -576,16 +705,16 @@ __device__ __forceinline__ void candidates_from_sorted(
             uint64_t nv = ~0ull;
             if (winner) nv = ~C[(uint32_t)(k1 & 0xFFFFFu)];
             carryTax = rdlane(tax, 63);
-            wave_mem_sync();
+            wsync<LDS>();
             if (j < ncand) C2[j] = nv;
         }
-        wave_mem_sync();
+        wsync<LDS>();
         S = C2;
     } else {
         for (uint32_t j = lane; j < ncand; j += 64) C[j] = ~C[j];
-        wave_mem_sync();
+        wsync<LDS>();
     }
-    sort_list(S, ncand, lane);
+    sort_list<LDS>(S, ncand, lane);
 
     // ---- emit the first K
     const uint32_t nout = min(K, ncand);
@@ -612,6 +741,7 @@ __device__ __forceinline__ void candidates_from_sorted(
 
 // row 7 + 8: gather the location lists of this query's features (window / feature order; singletons
 // are inline in the payload) into buf and sort them
+template <bool LDS>
 __device__ __forceinline__ void gather_and_sort(uint64_t* buf, const Workspace& ws, const DeviceTable& tab,
                                                 uint32_t fbeg, uint32_t nf, uint32_t H, uint32_t lane)
 {
@@ -633,8 +763,8 @@ __device__ __forceinline__ void gather_and_sort(uint64_t* buf, const Workspace& 
         }
         base += rdlane(incl, 63);
     }
-    wave_mem_sync();
-    sort_list(buf, H, lane);
+    wsync<LDS>();
+    sort_list<LDS>(buf, H, lane);
 }
 
 struct SortLds {
@@ -661,13 +791,13 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(
     const uint32_t nf = (ws.winOff[q + 1] - ws.winOff[q]) * sp.s;
     // two instantiations so that the LDS flavour compiles to ds_* instructions
     if (H <= kLdsCap) {
-        gather_and_sort(lds[wave].buf, ws, tab, fbeg, nf, H, lane);
+        gather_and_sort<true>(lds[wave].buf, ws, tab, fbeg, nf, H, lane);
         if (wantAllhits)
             for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = lds[wave].buf[i];
-        candidates_from_sorted(lds[wave].buf, lds[wave].c, lds[wave].c2, H, maxWin, K, taxkey, out, lane);
+        candidates_from_sorted<true>(lds[wave].buf, lds[wave].c, lds[wave].c2, H, maxWin, K, taxkey, out, lane);
     } else {
-        gather_and_sort(ws.hits + hoff, ws, tab, fbeg, nf, H, lane);
-        candidates_from_sorted(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, out, lane);
+        gather_and_sort<false>(ws.hits + hoff, ws, tab, fbeg, nf, H, lane);
+        candidates_from_sorted<false>(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, out, lane);
     }
 }
 

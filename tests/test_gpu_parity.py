@@ -131,7 +131,7 @@ def test_device_path_features_match_oracle(golden):
     buf = np.frombuffer(b"".join(chunks) + b"\0" * 16, dtype=np.uint8)
     dseq = torch.from_numpy(buf.copy()).cuda()
     dq = torch.from_numpy(np.array(offs, dtype=np.uint32).view(np.int32).reshape(-1)).cuda()
-    res = db.query_device(dseq.data_ptr(), dq.data_ptr(), len(reads), pos, max_win_uniform=3)
+    res = db.query_device(dseq.data_ptr(), dq.data_ptr(), len(reads), pos, max_win_uniform=3, want_features=True)
     db.synchronize()
     n = len(reads)
     import ctypes as C
