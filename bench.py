@@ -71,6 +71,23 @@ def synth_reads_gpu(gcat: torch.Tensor, goff: torch.Tensor, glen: int, n: int, s
     return padded
 
 
+def measured_traffic(kernel_timer_name: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
+    workload (profiles/*_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes; no
+    x2 FETCH_SIZE correction for this access pattern).  None if absent."""
+    import csv, glob
+    names = {"sketch_probe": ("query_kernel<fused>", "sketch_probe<probe>"), "sort_candidates": ("sort_candidates",)}[kernel_timer_name]
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), reverse=True):
+        vals = {}
+        for r in csv.DictReader(open(fn)):
+            if r["kernel"] in names and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
+        for k in names:
+            if k in vals and len(vals[k]) == 2:
+                return (vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
+    return None, None
+
+
 def algorithmic_bytes_per_read(F: float, H: float, K: int, V: int) -> float:
     """ceil(L/4) + ceil(L/8) + 12 F + V H + 16 K"""
     return (READ_LEN + 3) // 4 + (READ_LEN + 7) // 8 + 12.0 * F + V * H + 16.0 * K
@@ -209,6 +226,7 @@ def main():
         dom = max(("sketch_probe", "sort_candidates"), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * B / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(dom) if B == 1_000_000 else (None, None)
         total_reads = world * args.steps * B
         value = total_reads / elapsed * 60.0 / 1e6
         result = {
@@ -221,7 +239,8 @@ def main():
                        "db_locations": db_info[7], "db_build_s": round(build_s, 2), "load_factor": args.load_factor,
                        "parallelism": f"replicated DB x{world}, reads sharded, RCCL gather of top candidates"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(bytes_per_read * B),
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3),
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }

@@ -357,8 +357,9 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
         launch_scan_u32(ws.winCount, 1, n, ws.winOff, nullptr, ws.scanTmp, st);
     }
     {
+        // fused fast path unless the caller needs the sorted lists or taxon merging
         ScopedTimer t(ctx, "sketch_probe", st);
-        launch_sketch_probe(b, sp, tab, true, wantAllhits != 0, ws, st);
+        launch_query(b, sp, tab, !wantAllhits && !taxkey, wantAllhits != 0, ws, K, ctx->bCands.p, st);
     }
     {
         ScopedTimer t(ctx, "scan", st);

@@ -91,6 +91,8 @@ void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* 
 size_t scan_tmp_bytes(uint32_t n);
 void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool doProbe,
                          bool wantAllhits, const Workspace& ws, hipStream_t st);
+void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
+                  const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS
 void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws,
                             const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits,

@@ -782,7 +782,9 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(
     const uint32_t q = blockIdx.x * 4 + wave;
     if (q >= b.n) return;
     mc_candidate_dev* out = cands + (size_t)q * K;
-    const uint32_t H = ws.qstat[q].hits;
+    const QueryStat qs = ws.qstat[q];
+    if (qs.nsteps & 0x80000000u) return;                  // finished by query_kernel's fused path
+    const uint32_t H = qs.hits;
     if (H == 0 || H > kMaxHitsPerQuery) { emit_empty(out, 0, K, lane); return; }
 
     const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
@@ -810,6 +812,367 @@ void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const De
 }
 
 // ================================================================================================
+// query_kernel: the fused fast path.  One wave per query:
+//   stage the read ONCE as 2-bit codes (all windows of a <= 1024-character segment share it),
+//   sketch every window (threshold filter + ballot compaction + rank sort + unique),
+//   probe up to 32 features with all loads in flight,
+//   and -- when the query has a single probe group, at most kFuseCap location hits, no taxon merging
+//   and no -allhits -- finish rows 7-10 in registers with an all-pairs readlane pass (no sort, no
+//   LDS lists, no second kernel).  Everything else is handed to sort_candidates_kernel exactly like
+//   sketch_probe_kernel does.
+// ================================================================================================
+constexpr uint32_t kFuseCap = 32;
+constexpr uint32_t kDoneFlag = 0x80000000u;     // QueryStat.nsteps bit: candidates already written
+
+struct FusedLds {
+    uint32_t code[kCodeWords];
+    uint32_t amb[kAmbWords];
+    uint32_t cand[128];      // [0,64) compaction target, [64,128) dump slots for masked-off lanes
+    uint32_t srt[128];
+    uint32_t sk[128];
+    uint32_t fbuf[kGroupSlots + 64];
+    uint64_t sbuf[kFuseCap + 32];
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_mov<0xB1>(v));
+    v = max(v, dpp_mov<0x4E>(v));
+    v = max(v, dpp_mov<0x141>(v));
+    v = max(v, dpp_mov<0x140>(v));
+    return max(max(rdlane(v, 0), rdlane(v, 16)), max(rdlane(v, 32), rdlane(v, 48)));
+}
+
+// Stage 'n' characters starting at seq[start] (n <= kMaxWinLen); branch-free per lane.
+template <class LDS>
+__device__ __forceinline__ void stage_segment(const uint8_t* __restrict__ seq, uint64_t start, uint32_t n, LDS& L, uint32_t lane)
+{
+    uint8_t* codeB = reinterpret_cast<uint8_t*>(L.code);
+    uint8_t* ambB = reinterpret_cast<uint8_t*>(L.amb);
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) {            // 64 lanes x 4 characters per pass
+        const uint32_t c = c0 + lane * 4;
+        // clamp the address so that every lane may load (8 slack bytes follow the buffer)
+        const uint64_t a = start + (c < n ? c : 0u);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(seq + (a & ~(uint64_t)3));
+        const uint32_t chars = __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3));
+        uint32_t code = 0, amb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t e = encode_base((chars >> (8 * j)) & 0xFFu);
+            const bool bad = (e & 4u) || (c + j >= n);
+            code = (code << 2) | (bad ? 0u : (e & 3u));
+            amb |= (bad ? 1u : 0u) << j;
+        }
+        const uint32_t ci = c >> 2;
+        codeB[ci ^ 3u] = (uint8_t)code;                     // big-endian inside each 32-bit word
+        const uint32_t other = dpp_mov<0xB1>(amb);          // neighbour lane's nibble
+        ambB[(lane & 1u) ? (kAmbWords * 4 - 1) : (ci >> 1)] = (uint8_t)(amb | (other << 4));   // odd lanes: dump byte
+    }
+}
+
+// hash of the k-mer at window position p (window starts at segment offset wo); ~0 if invalid
+template <class LDS>
+__device__ __forceinline__ uint32_t seg_hash_at(const LDS& L, uint32_t wo, uint32_t p, uint32_t nk, uint32_t k, uint32_t kbits)
+{
+    const bool ok = p < nk;
+    const uint32_t a = wo + (ok ? p : 0u);
+    const uint32_t wq = a >> 4, sh = (a & 15u) * 2u;
+    const uint32_t kmer = __funnelshift_l(L.code[wq + 1], L.code[wq], sh) >> (32u - 2u * k);
+    const uint32_t aw = a >> 5;
+    const uint32_t am = __funnelshift_r(L.amb[aw], L.amb[aw + 1], a & 31u) & kbits;
+    const uint32_t h = canonical_hash(kmer, k);
+    return (ok && am == 0) ? h : 0xFFFFFFFFu;
+}
+
+// min-hash sketch of window [wo, wo+n) of the staged segment -> L.fbuf[slotBase .. slotBase+s)
+// (ascending, ~0 padded); returns the number of valid features.
+__device__ __forceinline__ uint32_t sketch_window_v3(FusedLds& L, uint32_t wo, uint32_t n, uint32_t k, uint32_t s, uint32_t slotBase, uint32_t lane)
+{
+    const uint32_t kbits = 0xFFFFu >> (16u - k);
+    const uint32_t nk = n - k + 1;
+    const uint32_t sl = min(s, nk);
+    const uint64_t t64 = (((uint64_t)7 * sl) << 32) / ((uint64_t)4 * nk);
+    uint32_t T = t64 >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t64;
+    uint32_t cnt;
+    for (;;) {
+        cnt = 0;
+        for (uint32_t base = 0; base < nk; base += 128) {
+            const uint32_t h0 = seg_hash_at(L, wo, base + lane, nk, k, kbits);
+            const uint32_t h1 = seg_hash_at(L, wo, base + 64 + lane, nk, k, kbits);
+            const bool b0 = h0 < T, b1 = h1 < T;
+            const uint64_t m0 = __ballot(b0), m1 = __ballot(b1);
+            const uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
+            const uint32_t nc = cnt + n0 + n1;
+            if (nc == cnt) continue;
+            if (nc <= 64) {
+                if (cnt) {                                   // carried sketch of earlier rounds (windows > 143 chars)
+                    const uint32_t old = L.sk[lane];
+                    wave_lds_sync();
+                    L.cand[lane < cnt ? lane : 64 + lane] = old;
+                }
+                L.cand[b0 ? cnt + mbcnt(m0) : 64 + lane] = h0;
+                L.cand[b1 ? cnt + n0 + mbcnt(m1) : 64 + lane] = h1;
+                wave_lds_sync();
+                uint32_t v = L.cand[lane];
+                v = lane < nc ? v : 0xFFFFFFFFu;
+                // rank sort: position = number of smaller (value, lane) pairs
+                const uint64_t key = ((uint64_t)v << 32) | lane;
+                uint32_t rank = 0;
+#pragma unroll 4
+                for (uint32_t j = 0; j < nc; ++j) {
+                    const uint64_t kj = ((uint64_t)rdlane(v, j) << 32) | j;
+                    rank += kj < key ? 1u : 0u;
+                }
+                L.srt[lane < nc ? rank : 64 + lane] = v;
+                wave_lds_sync();
+                const uint32_t x = L.srt[lane], prev = L.srt[(lane + 63u) & 63u];
+                const bool uniq = lane < nc && (lane == 0 || x != prev);
+                const uint64_t um = __ballot(uniq);
+                const uint32_t upos = mbcnt(um);
+                L.sk[(uniq && upos < sl) ? upos : 64 + lane] = x;
+                cnt = min(sl, (uint32_t)__popcll(um));
+                wave_lds_sync();
+            } else {
+                // degenerate input (> 64 candidates): serial minimum extraction, still exact
+                const uint32_t a0 = b0 ? h0 : 0xFFFFFFFFu, a1 = b1 ? h1 : 0xFFFFFFFFu;
+                uint32_t skv = L.sk[lane];
+                skv = lane < cnt ? skv : 0xFFFFFFFFu;
+                uint32_t nsk = 0xFFFFFFFFu, lb = 0, c = 0;
+                for (uint32_t t = 0; t < sl; ++t) {
+                    const uint32_t cand = min(min(a0 >= lb ? a0 : 0xFFFFFFFFu, a1 >= lb ? a1 : 0xFFFFFFFFu), skv >= lb ? skv : 0xFFFFFFFFu);
+                    const uint32_t m = wave_min_u32(cand);
+                    if (m == 0xFFFFFFFFu) break;
+                    if (lane == t) nsk = m;
+                    lb = m + 1; ++c;
+                }
+                wave_lds_sync();
+                L.sk[lane] = nsk;
+                cnt = c;
+                wave_lds_sync();
+            }
+        }
+        if (cnt >= sl || T == 0xFFFFFFFFu) break;
+        T = T >= 0x40000000u ? 0xFFFFFFFFu : T << 2;
+    }
+    const uint32_t fin = L.sk[lane];
+    L.fbuf[lane < s ? slotBase + lane : kGroupSlots + lane] = lane < cnt ? fin : 0xFFFFFFFFu;
+    return cnt;
+}
+
+struct ProbeResult {             // per lane: what this lane found in each of the 4 rounds
+    uint32_t size[kProbeRounds];
+    uint64_t pay[kProbeRounds];
+    bool wrote[kProbeRounds];
+};
+
+__device__ __forceinline__ void probe_group_v3(const FusedLds& L, uint32_t nslots, const DeviceTable& tab, uint32_t lane,
+                                               ProbeResult& R, uint32_t& nsteps)
+{
+    const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
+    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
+    uint32_t f[kProbeRounds], g[kProbeRounds];
+    uint4 sl4[kProbeRounds];
+    const uint32_t rounds = (nslots + 7) >> 3;
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        const uint32_t fi = r * 8 + grp;
+        const uint32_t fv = L.fbuf[fi];
+        f[r] = (r < rounds && fi < nslots) ? fv : 0xFFFFFFFFu;
+        g[r] = home_group(f[r], tab.ngroups);
+        sl4[r] = make_uint4(0, 0, 0, 0);
+        if (f[r] != 0xFFFFFFFFu) sl4[r] = slots[(size_t)g[r] * kSlotsPerGroup + sub];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        R.size[r] = 0; R.pay[r] = 0; R.wrote[r] = false;
+        if (r < rounds) {                                       // wave-uniform
+            bool active = f[r] != 0xFFFFFFFFu;
+            uint4 cur = sl4[r];
+            uint32_t gg = g[r];
+            for (uint32_t step = 0;; ++step) {
+                const bool occ = active && (cur.y >> 31);
+                const bool hit = occ && cur.x == f[r];
+                const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
+                const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
+                if (hit) { R.size[r] = cur.y & 0xFFFFu; R.pay[r] = ((uint64_t)cur.w << 32) | cur.z; R.wrote[r] = true; }
+                nsteps += (active && sub == 0) ? 1u : 0u;
+                if (ghit != 0 || gocc != 0xFFu) active = false;
+                if (!__any(active) || step + 1 >= tab.maxProbe) break;
+                gg = (gg + 1 == tab.ngroups) ? 0u : gg + 1;
+                cur = make_uint4(0, 0, 0, 0);
+                if (active) cur = slots[(size_t)gg * kSlotsPerGroup + sub];
+            }
+        }
+    }
+}
+
+// hand the group's probe results to sort_candidates_kernel (same layout sketch_probe_kernel writes)
+__device__ __forceinline__ void store_probe_results(const ProbeResult& R, uint32_t nslots, uint32_t fbase, const Workspace& ws, uint32_t lane)
+{
+    const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        const uint32_t fi = r * 8 + grp;
+        const uint32_t anyhit = (uint32_t)(__ballot(R.wrote[r]) >> gshift) & 0xFFu;
+        if (fi < nslots && (R.wrote[r] || (anyhit == 0 && sub == 0))) {
+            ws.psize[fbase + fi] = R.size[r];
+            ws.ppay[fbase + fi] = R.pay[r];
+        }
+    }
+}
+
+// rows 7-10 for at most kFuseCap location hits, entirely in registers (sequence-level candidates)
+__device__ __forceinline__ void fused_candidates(FusedLds& L, const ProbeResult& R, const DeviceTable& tab, uint32_t H, uint32_t maxWin,
+                                                 uint32_t K, mc_candidate_dev* out, uint32_t lane)
+{
+    // compact the hit locations into lanes 0..H-1 (their order is irrelevant: ranks are computed below)
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        const bool single = R.wrote[r] && R.size[r] == 1;
+        const uint64_t m = __ballot(single);
+        if (single) L.sbuf[base + mbcnt(m)] = R.pay[r];
+        base += __popcll(m);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        uint64_t mm = __ballot(R.wrote[r] && R.size[r] > 1);
+        while (mm) {
+            const uint32_t j = __ffsll((unsigned long long)mm) - 1;
+            mm &= mm - 1;
+            const uint32_t nj = rdlane(R.size[r], j);
+            const uint64_t src = rdlane64(R.pay[r], j);
+            if (lane < nj) L.sbuf[base + lane] = tab.values[src + lane];    // nj <= H <= 32 < 64
+            base += nj;
+        }
+    }
+    wave_lds_sync();
+    const uint64_t key = L.sbuf[lane < H ? lane : 0];
+    const uint32_t tgt = (uint32_t)(key >> 32), win = (uint32_t)key;
+    uint32_t rank = 0, hits = 0, beg = win;
+    for (uint32_t j = 0; j < H; ++j) {
+        const uint32_t tj = rdlane(tgt, j), wj = rdlane(win, j);
+        const uint64_t kj = ((uint64_t)tj << 32) | wj;
+        const bool lt = kj < key || (kj == key && j < lane);      // position of j before this lane's element in sorted order
+        const bool le = lt || j == lane;
+        rank += lt ? 1u : 0u;
+        const bool inr = le && tj == tgt && (win - wj) < maxWin;   // j lies in the window range that ends here (:79-85)
+        hits += inr ? 1u : 0u;
+        beg = inr ? min(beg, wj) : beg;
+    }
+    // top-K: most hits first, ties by list position (= target order, then window order) (:189-201, :87-91)
+    uint64_t ckey = lane < H ? (((uint64_t)hits << 32) | (0xFFFFFFFFu - rank)) : 0ull;
+    uint32_t nout = 0;
+    for (; nout < K; ++nout) {
+        const uint32_t mh = wave_max_u32((uint32_t)(ckey >> 32));
+        if (mh == 0) break;
+        const uint32_t ml = wave_max_u32((uint32_t)(ckey >> 32) == mh ? (uint32_t)ckey : 0u);
+        const bool winner = ckey == (((uint64_t)mh << 32) | ml);
+        const uint32_t wl = __ffsll((unsigned long long)__ballot(winner)) - 1;
+        const uint32_t wt = rdlane(tgt, wl);
+        if (winner) {
+            mc_candidate_dev e; e.tgt = tgt; e.hits = hits; e.beg = beg; e.end = win;
+            out[nout] = e;
+        }
+        ckey = tgt == wt ? 0ull : ckey;                          // one candidate per target
+    }
+    emit_empty(out, nout, K, lane);
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void query_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, int wantAllhits,
+                                                    uint32_t K, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ FusedLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (q >= b.n) return;
+    FusedLds& L = lds[wave];
+
+    const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+    const bool noTail = qi.w == kNoTail;
+    const uint32_t widx0 = ws.winOff[q];
+    const uint32_t nwinTotal = ws.winOff[q + 1] - widx0;
+    const uint32_t k = sp.k, s = sp.s;
+    const uint32_t winsPerGroup = kGroupSlots / s;
+    const bool single = nwinTotal <= winsPerGroup;          // the whole query is one probe group
+
+    uint32_t widx = widx0;
+    uint32_t myHits = 0, nfeat = 0, nfound = 0, nsteps = 0;
+    uint32_t gslot = 0, gfirst = widx;
+    ProbeResult R;
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) { R.size[r] = 0; R.pay[r] = 0; R.wrote[r] = false; }
+
+    for (uint32_t mate = 0; mate < 2; ++mate) {
+        const uint32_t off = mate ? qi.z : qi.x;
+        const uint32_t len = mate ? (noTail ? 0u : qi.w) : qi.y;
+        const uint32_t nwin = windows_of(len, sp, mate == 0 && noTail);
+        uint32_t wi = 0;
+        while (wi < nwin) {
+            const uint32_t segFirst = (len <= sp.w) ? 0u : wi * sp.stride;
+            const uint32_t segChars = min(len - segFirst, kMaxWinLen);
+            stage_segment(b.seq, (uint64_t)off + segFirst, segChars, L, lane);
+            wave_lds_sync();
+            for (; wi < nwin; ++wi, ++widx) {
+                const uint32_t first = (len <= sp.w) ? 0u : wi * sp.stride;
+                const uint32_t n = min(sp.w, len - first);
+                const uint32_t wo = first - segFirst;
+                if (wo + n > segChars) break;                // continues in the next segment
+                const uint32_t cnt = sketch_window_v3(L, wo, n, k, s, gslot * s, lane);
+                nfeat += lane < cnt ? 1u : 0u;
+                wave_lds_sync();
+                if (ws.features && lane < s) ws.features[widx * s + lane] = L.fbuf[gslot * s + lane];
+                ++gslot;
+                if (gslot == winsPerGroup) {
+                    probe_group_v3(L, gslot * s, tab, lane, R, nsteps);
+                    if (!(FUSE && single)) store_probe_results(R, gslot * s, gfirst * s, ws, lane);
+#pragma unroll
+                    for (uint32_t r = 0; r < kProbeRounds; ++r) { myHits += R.size[r]; nfound += R.wrote[r] ? 1u : 0u; }
+                    if (!single) { gslot = 0; gfirst = widx + 1; }
+                }
+            }
+        }
+    }
+    const bool pending = single ? (gslot > 0 && gslot < winsPerGroup) : gslot > 0;
+    if (pending) {
+        probe_group_v3(L, gslot * s, tab, lane, R, nsteps);
+        if (!(FUSE && single)) store_probe_results(R, gslot * s, gfirst * s, ws, lane);
+#pragma unroll
+        for (uint32_t r = 0; r < kProbeRounds; ++r) { myHits += R.size[r]; nfound += R.wrote[r] ? 1u : 0u; }
+    }
+
+    const uint32_t H = wave_sum_u32(myHits);
+    const uint32_t F = wave_sum_u32(nfeat);
+    const uint32_t Fo = wave_sum_u32(nfound);
+    uint32_t St = wave_sum_u32(nsteps);
+    bool done = false;
+    if (FUSE && single) {
+        if (H <= kFuseCap) {
+            const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+            fused_candidates(L, R, tab, H, maxWin, K, cands + (size_t)q * K, lane);
+            done = true;
+        } else {
+            store_probe_results(R, gslot * s, gfirst * s, ws, lane);
+        }
+    }
+    if (lane == 0) {
+        QueryStat qs; qs.hits = H; qs.nfeat = F; qs.nfound = Fo; qs.nsteps = St | (done ? kDoneFlag : 0u);
+        ws.qstat[q] = qs;
+        ws.hitScan[q] = (!done && H <= kMaxHitsPerQuery && (wantAllhits || H > kLdsCap)) ? H : 0u;
+    }
+}
+
+void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
+                  const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    dim3 grid((b.n + 3) / 4), block(256);
+    if (fuse) hipLaunchKernelGGL(query_kernel<true>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0, maxCand, (mc_candidate_dev*)cands);
+    else      hipLaunchKernelGGL(query_kernel<false>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0, maxCand, (mc_candidate_dev*)cands);
+}
+
+// ================================================================================================
 // batch statistics (on demand, not on the timed path)
 // ================================================================================================
 __global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __restrict__ qs, const uint32_t* __restrict__ winOff,
@@ -819,7 +1182,7 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __res
     uint64_t h = 0, f = 0, fo = 0, st = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         QueryStat s = qs[i];
-        h += s.hits; f += s.nfeat; fo += s.nfound; st += s.nsteps;
+        h += s.hits; f += s.nfeat; fo += s.nfound; st += (s.nsteps & 0x7FFFFFFFu);
     }
     h = block_reduce_u64(h, sh); f = block_reduce_u64(f, sh); fo = block_reduce_u64(fo, sh); st = block_reduce_u64(st, sh);
     if (threadIdx.x == 0) {

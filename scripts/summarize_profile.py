@@ -16,7 +16,8 @@ os.makedirs(dst, exist_ok=True)
 def short(k):
     if "sketch_probe_kernel<true>" in k: return "sketch_probe<probe>"
     if "sketch_probe_kernel<false>" in k: return "sketch_probe<sketch-only>"
-    if "fused_query" in k: return "fused_query"
+    if "query_kernel<true>" in k: return "query_kernel<fused>"
+    if "query_kernel<false>" in k: return "query_kernel<unfused>"
     for n in ("sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs"):
         if n in k: return n
     return None
