@@ -76,7 +76,8 @@ def measured_traffic(kernel_timer_name: str):
     workload (profiles/*_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes; no
     x2 FETCH_SIZE correction for this access pattern).  None if absent."""
     import csv, glob
-    names = {"sketch_probe": ("query_kernel<fused>", "sketch_probe<probe>"), "sort_candidates": ("sort_candidates",)}[kernel_timer_name]
+    names = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",),
+             "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",)}[kernel_timer_name]
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), reverse=True):
         vals = {}
         for r in csv.DictReader(open(fn)):
@@ -134,7 +135,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--maxcand", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--load-factor", type=float, default=0.8)
+    ap.add_argument("--load-factor", type=float, default=0.5)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,12 +219,12 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "scan", "sort_candidates")}
+        kt = {k: db.timing_get(k) for k in ("plan", "sketch_lane", "probe_cands", "query_wave", "scan", "sort_candidates")}
         st = db.last_batch_stats()                            # of the last timed batch
         F, H = st["features"] / B, st["locations"] / B
         V = 6                                                 # uint16 target ids: 6-byte locations in the file format
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
-        dom = max(("sketch_probe", "sort_candidates"), key=lambda k: kt[k][0])
+        dom = max(("sketch_lane", "probe_cands", "query_wave", "sort_candidates"), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * B / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom) if B == 1_000_000 else (None, None)

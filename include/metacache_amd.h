@@ -71,7 +71,7 @@ typedef struct {
     uint32_t num_parts;              /* database parts to be loaded (1 for now) */
     uint32_t max_locations_per_feature; /* load-time truncation to the first n values (host_hashmap.hpp:454-466); 0 = keep */
     uint32_t remove_overpopulated;   /* load-time: empty buckets with more than n values (host_hashmap.hpp:480-495); 0 = off */
-    float    max_load_factor;        /* hash table load factor (-max-load-fac, mode_query.cpp:49-55); 0 = default 0.8 */
+    float    max_load_factor;        /* hash table load factor (-max-load-fac, mode_query.cpp:49-55); 0 = default 0.5 */
     /* host batch slots (query_batch ctor, database_query.hpp:192-202) */
     uint32_t num_slots;
     uint32_t slot_max_queries;
@@ -137,7 +137,7 @@ int mc_batch_clear(mc_ctx* ctx, uint32_t slot);
 
 /* device-resident entry point (what the slots call after their H2D copy; also used when reads are
  * already in HBM).  All pointers are DEVICE pointers.
- *   seq     : characters; every sequence starts 4-byte aligned; 8 readable slack bytes at the end
+ *   seq     : characters; every sequence starts 4-byte aligned; 16 readable slack bytes at the end
  *   qinfo   : [n][4] = {offset1, len1, offset2, len2} (offsets into seq; len2 = 0 for single reads)
  *   max_win : [n] maxWindowsInRange per query (candidate_structs.hpp:143-145), or NULL with
  *             max_win_uniform > 0
@@ -173,7 +173,7 @@ int mc_synchronize(mc_ctx* ctx);
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
- * names: "sketch_probe", "scan", "sort_candidates", "plan".  Returns accumulated milliseconds and
+ * names: "plan", "sketch_lane", "probe_cands", "query_wave", "scan", "sort_candidates".  Returns accumulated milliseconds and
  * launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);
 int mc_timing_reset(mc_ctx* ctx);

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace mcamd;
@@ -88,7 +89,8 @@ void mc_config_default(mc_config* c)
     c->num_parts = 1;
     c->max_locations_per_feature = 0;
     c->remove_overpopulated = 0;
-    c->max_load_factor = 0.8f;                                                  // host_hashmap.hpp:159-161
+    c->max_load_factor = 0.5f;   // our bucket-group table: few full groups => unsuccessful lookups end after one line
+                                 // (the reference CPU map uses 0.8, host_hashmap.hpp:159-161; -max-load-fac overrides)
     c->num_slots = 1;
     c->slot_max_queries = 1u << 16;
     c->slot_max_chars = 1u << 24;
@@ -119,8 +121,9 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->device = cfg->device;
     ctx->querySketch = SketchParams{cfg->kmerlen, cfg->sketchlen, cfg->winlen, cfg->winstride};
     ctx->targetSketch = ctx->querySketch;
-    ctx->loadFactor = (cfg->max_load_factor > 0.05f && cfg->max_load_factor <= 0.99f) ? cfg->max_load_factor : 0.8f;
+    ctx->loadFactor = (cfg->max_load_factor > 0.05f && cfg->max_load_factor <= 0.99f) ? cfg->max_load_factor : 0.5f;
     ctx->parts.resize(cfg->num_parts);
+    if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream");
@@ -151,7 +154,7 @@ void mc_destroy(mc_ctx* ctx)
     for (auto& p : ctx->parts) { if (p.dslots) (void)hipFree(p.dslots); if (p.dvalues) (void)hipFree(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     DevBuf* bufs[] = {&ctx->bWinCount, &ctx->bWinOff, &ctx->bFeatures, &ctx->bPsize, &ctx->bPpay, &ctx->bQstat, &ctx->bHitOff,
-                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn};
+                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& s : ctx->slots) {
         if (s.hseq) (void)hipHostFree(s.hseq); if (s.hqinfo) (void)hipHostFree(s.hqinfo); if (s.hmaxwin) (void)hipHostFree(s.hmaxwin);
@@ -331,11 +334,15 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     const size_t nfeat = (size_t)maxWindows * sp.s;
     if ((rc = ensure(ctx, ctx->bWinCount, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bWinOff, (size_t)(n + 2) * 4))) return rc;
-    if (wantFeatures && (rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
+    // the lane path delivers top candidates only: -allhits, taxon merging and K > 4 go through the wave kernels
+    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAllhits && lowestRank <= 0 && lane_candidates_supported(K);
+    if ((wantFeatures || lanePath) && (rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bPsize, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bPpay, nfeat * 8))) return rc;
     if ((rc = ensure(ctx, ctx->bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, ctx->bScanIn, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bQflag, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bHitlist, 64))) return rc;
     if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->bScan, scan_tmp_bytes(n + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->bStats, 64))) return rc;
@@ -343,8 +350,8 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
 
     Workspace ws{};
     ws.winCount = (uint32_t*)ctx->bWinCount.p; ws.winOff = (uint32_t*)ctx->bWinOff.p;
-    ws.features = wantFeatures ? (uint32_t*)ctx->bFeatures.p : nullptr; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
-    ws.qstat = (QueryStat*)ctx->bQstat.p; ws.hitScan = (uint32_t*)ctx->bScanIn.p; ws.hitOff = (uint64_t*)ctx->bHitOff.p;
+    ws.features = (wantFeatures || lanePath) ? (uint32_t*)ctx->bFeatures.p : nullptr; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
+    ws.qstat = (QueryStat*)ctx->bQstat.p; ws.hitScan = (uint32_t*)ctx->bScanIn.p; ws.qflag = (uint32_t*)ctx->bQflag.p; ws.counter = (uint32_t*)ctx->bHitlist.p; ws.hitOff = (uint64_t*)ctx->bHitOff.p;
     ws.scanTmp = ctx->bScan.p; ws.stats = (uint64_t*)ctx->bStats.p;
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
@@ -356,10 +363,18 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
         launch_plan(b, sp, ws.winCount, st);
         launch_scan_u32(ws.winCount, 1, n, ws.winOff, nullptr, ws.scanTmp, st);
     }
+    const bool fuse = !wantAllhits && !taxkey;
+    if (lanePath) {
+        // short reads: one lane per query for sketching and candidates, cooperative probing in between
+        { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
+        { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, ctx->bCands.p, st); }
+    } else {
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
+    }
     {
-        // fused fast path unless the caller needs the sorted lists or taxon merging
-        ScopedTimer t(ctx, "sketch_probe", st);
-        launch_query(b, sp, tab, !wantAllhits && !taxkey, wantAllhits != 0, ws, K, ctx->bCands.p, st);
+        // wave-per-query kernel for whatever the lane path did not take (long reads, duplicate hashes, ...)
+        ScopedTimer t(ctx, "query_wave", st);
+        launch_query(b, sp, tab, fuse, wantAllhits != 0, ws, K, ctx->bCands.p, st);
     }
     {
         ScopedTimer t(ctx, "scan", st);
@@ -472,7 +487,7 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     const uint32_t n = S.nq;
     S.submittedQueries = n;
     if (n == 0) { HIP_TRY(ctx, hipEventRecord(S.done, st)); S.submitted = true; return MC_OK; }
-    HIP_TRY(ctx, hipMemcpyAsync(S.dseq, S.hseq, S.nchars + 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.dseq, S.hseq, S.nchars + 16, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(S.dqinfo, S.hqinfo, (size_t)n * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(S.dmaxwin, S.hmaxwin, (size_t)n * 4, hipMemcpyHostToDevice, st));
     mc_device_batch in{S.dseq, S.dqinfo, S.dmaxwin, 0, n, S.nchars};

@@ -78,7 +78,8 @@ struct mc_ctx {
 
     // workspace
     mcamd::DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
-        bCands, bScanIn;
+        bCands, bScanIn, bQflag, bHitlist;
+    bool useLanePath = true;               // lane-parallel fast path for short reads (off: wave kernels only)
     uint32_t lastN = 0;
 
     // timing

@@ -75,6 +75,9 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint32_t* psize;         // [W*s]      bucket size per feature (0 = not found / no feature)
     uint64_t* ppay;          // [W*s]      payload per feature
     QueryStat* qstat;        // [n]
+    uint32_t* qflag;         // [n]        0 = done, 1 = needs sketch+probe (wave), 2 = needs candidates (wave),
+                             //            4 = sketched by a lane (probe_cands_kernel takes it from there)
+    uint32_t* counter;       // [1]        dynamic chunk counter of probe_cands_kernel
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations
@@ -93,6 +96,11 @@ void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const Devic
                          bool wantAllhits, const Workspace& ws, hipStream_t st);
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
+void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
+void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, void* cands,
+                        hipStream_t st);
+bool lane_path_supported(const SketchParams& sp);
+bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS
 void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws,
                             const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits,

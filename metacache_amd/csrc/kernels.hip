@@ -9,6 +9,9 @@
 
 namespace mcamd {
 
+// per-query state: what is still to be done (Workspace::qflag)
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagLaneCands = 3, kFlagProbe = 4;
+
 // ================================================================================================
 // wave64 primitives
 // ================================================================================================
@@ -748,7 +751,7 @@ __device__ __forceinline__ void gather_and_sort(uint64_t* buf, const Workspace& 
     uint32_t base = 0;
     for (uint32_t e0 = 0; e0 < nf; e0 += 64) {
         const uint32_t e = e0 + lane;
-        const uint32_t sz = e < nf ? ws.psize[fbeg + e] : 0u;
+        const uint32_t sz = e < nf ? (ws.psize[fbeg + e] & 0xFFFFu) : 0u;
         const uint64_t pay = e < nf ? ws.ppay[fbeg + e] : 0ull;
         const uint32_t incl = wave_incl_scan_u32(sz, lane);
         const uint32_t dst = base + incl - sz;
@@ -773,18 +776,12 @@ struct SortLds {
     uint64_t c2[kLdsCap];
 };
 
-__global__ __launch_bounds__(256) void sort_candidates_kernel(
-    BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, const uint32_t* __restrict__ taxkey,
-    uint32_t K, int wantAllhits, mc_candidate_dev* __restrict__ cands)
+__device__ __forceinline__ void sort_candidates_one(
+    const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, const uint32_t* __restrict__ taxkey,
+    uint32_t K, int wantAllhits, mc_candidate_dev* __restrict__ cands, SortLds& L, uint32_t q, uint32_t lane)
 {
-    __shared__ SortLds lds[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t q = blockIdx.x * 4 + wave;
-    if (q >= b.n) return;
     mc_candidate_dev* out = cands + (size_t)q * K;
-    const QueryStat qs = ws.qstat[q];
-    if (qs.nsteps & 0x80000000u) return;                  // finished by query_kernel's fused path
-    const uint32_t H = qs.hits;
+    const uint32_t H = ws.qstat[q].hits;
     if (H == 0 || H > kMaxHitsPerQuery) { emit_empty(out, 0, K, lane); return; }
 
     const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
@@ -793,13 +790,33 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(
     const uint32_t nf = (ws.winOff[q + 1] - ws.winOff[q]) * sp.s;
     // two instantiations so that the LDS flavour compiles to ds_* instructions
     if (H <= kLdsCap) {
-        gather_and_sort<true>(lds[wave].buf, ws, tab, fbeg, nf, H, lane);
+        gather_and_sort<true>(L.buf, ws, tab, fbeg, nf, H, lane);
         if (wantAllhits)
-            for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = lds[wave].buf[i];
-        candidates_from_sorted<true>(lds[wave].buf, lds[wave].c, lds[wave].c2, H, maxWin, K, taxkey, out, lane);
+            for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = L.buf[i];
+        candidates_from_sorted<true>(L.buf, L.c, L.c2, H, maxWin, K, taxkey, out, lane);
     } else {
         gather_and_sort<false>(ws.hits + hoff, ws, tab, fbeg, nf, H, lane);
         candidates_from_sorted<false>(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, out, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void sort_candidates_kernel(
+    BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, const uint32_t* __restrict__ taxkey,
+    uint32_t K, int wantAllhits, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ SortLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + wave;
+    for (uint32_t base = waveId * 64; base < b.n; base += nWaves * 64) {
+        const uint32_t qq = base + lane;
+        const uint32_t fl = qq < b.n ? ws.qflag[qq] : kFlagDone;
+        uint64_t m = __ballot(fl == kFlagCands);
+        while (m) {
+            const uint32_t j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            sort_candidates_one(b, sp, tab, ws, taxkey, K, wantAllhits, cands, lds[wave], base + j, lane);
+            wave_lds_sync();
+        }
     }
 }
 
@@ -807,7 +824,7 @@ void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const De
                             const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(sort_candidates_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, tab, ws, taxkey, maxCand,
+    hipLaunchKernelGGL(sort_candidates_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, tab, ws, taxkey, maxCand,
                        wantAllhits ? 1 : 0, (mc_candidate_dev*)cands);
 }
 
@@ -822,7 +839,6 @@ void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const De
 //   sketch_probe_kernel does.
 // ================================================================================================
 constexpr uint32_t kFuseCap = 32;
-constexpr uint32_t kDoneFlag = 0x80000000u;     // QueryStat.nsteps bit: candidates already written
 
 struct FusedLds {
     uint32_t code[kCodeWords];
@@ -965,45 +981,84 @@ struct ProbeResult {             // per lane: what this lane found in each of th
     bool wrote[kProbeRounds];
 };
 
-__device__ __forceinline__ void probe_group_v3(const FusedLds& L, uint32_t nslots, const DeviceTable& tab, uint32_t lane,
+// Probing up to 4 x 8 features (f[r] = the feature this lane's 8-lane group handles in round r, ~0 = none)
+// is split in two so that callers can keep the loads of the NEXT query in flight while they resolve the
+// current one:
+//   probe_issue  : home groups + first-step loads of all rounds (8 lanes x 16 B = one 128-byte group each)
+//   probe_resolve: ballot per 8-lane group; groups that are full without a match continue along their
+//                  chain, all rounds together per step (unsuccessful lookups must not serialise).
+struct ProbeState {
+    uint32_t g[kProbeRounds];
+    uint4 cur[kProbeRounds];
+};
+
+__device__ __forceinline__ void probe_issue(const uint32_t (&f)[kProbeRounds], const DeviceTable& tab, uint32_t lane, ProbeState& P)
+{
+    const uint32_t sub = lane & 7u;
+    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) {
+        P.g[r] = home_group(f[r], tab.ngroups);
+        P.cur[r] = make_uint4(0, 0, 0, 0);
+        if (f[r] != 0xFFFFFFFFu) P.cur[r] = slots[(size_t)P.g[r] * kSlotsPerGroup + sub];
+    }
+}
+
+__device__ __forceinline__ void probe_resolve(const uint32_t (&f)[kProbeRounds], ProbeState& P, const DeviceTable& tab, uint32_t lane,
+                                              ProbeResult& R, uint32_t& nsteps)
+{
+    const uint32_t sub = lane & 7u, gshift = lane & ~7u;
+    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
+    bool active[kProbeRounds];
+#pragma unroll
+    for (uint32_t r = 0; r < kProbeRounds; ++r) { active[r] = f[r] != 0xFFFFFFFFu; R.size[r] = 0; R.pay[r] = 0; R.wrote[r] = false; }
+    for (uint32_t step = 0;; ++step) {
+        bool more = false;
+#pragma unroll
+        for (uint32_t r = 0; r < kProbeRounds; ++r) {
+            const bool occ = active[r] && (P.cur[r].y >> 31);
+            const bool hit = occ && P.cur[r].x == f[r];
+            const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
+            const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
+            if (hit) { R.size[r] = P.cur[r].y & 0xFFFFu; R.pay[r] = ((uint64_t)P.cur[r].w << 32) | P.cur[r].z; R.wrote[r] = true; }
+            nsteps += __popcll(__ballot(active[r] && sub == 0));
+            // finished when found, or when the group has a free slot (insertion fills the first group
+            // with room, so the key cannot live further along the chain)
+            if (ghit != 0 || gocc != 0xFFu) active[r] = false;
+            more = more || active[r];
+        }
+        if (!__any(more) || step + 1 >= tab.maxProbe) break;
+#pragma unroll
+        for (uint32_t r = 0; r < kProbeRounds; ++r) {
+            P.g[r] = (P.g[r] + 1 == tab.ngroups) ? 0u : P.g[r] + 1;
+            P.cur[r] = make_uint4(0, 0, 0, 0);
+            if (active[r]) P.cur[r] = slots[(size_t)P.g[r] * kSlotsPerGroup + sub];
+        }
+    }
+}
+
+__device__ __forceinline__ void probe_features(const uint32_t (&f)[kProbeRounds], const DeviceTable& tab, uint32_t lane,
                                                ProbeResult& R, uint32_t& nsteps)
 {
-    const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
-    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
-    uint32_t f[kProbeRounds], g[kProbeRounds];
-    uint4 sl4[kProbeRounds];
-    const uint32_t rounds = (nslots + 7) >> 3;
+    ProbeState P;
+    probe_issue(f, tab, lane, P);
+    probe_resolve(f, P, tab, lane, R, nsteps);
+}
+
+__device__ __forceinline__ void probe_group_v3(const FusedLds& L, uint32_t nslots, const DeviceTable& tab, uint32_t lane,
+                                               ProbeResult& R, uint32_t& nstepsLane)
+{
+    const uint32_t grp = lane >> 3;
+    uint32_t f[kProbeRounds];
 #pragma unroll
     for (uint32_t r = 0; r < kProbeRounds; ++r) {
         const uint32_t fi = r * 8 + grp;
         const uint32_t fv = L.fbuf[fi];
-        f[r] = (r < rounds && fi < nslots) ? fv : 0xFFFFFFFFu;
-        g[r] = home_group(f[r], tab.ngroups);
-        sl4[r] = make_uint4(0, 0, 0, 0);
-        if (f[r] != 0xFFFFFFFFu) sl4[r] = slots[(size_t)g[r] * kSlotsPerGroup + sub];
+        f[r] = fi < nslots ? fv : 0xFFFFFFFFu;
     }
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        R.size[r] = 0; R.pay[r] = 0; R.wrote[r] = false;
-        if (r < rounds) {                                       // wave-uniform
-            bool active = f[r] != 0xFFFFFFFFu;
-            uint4 cur = sl4[r];
-            uint32_t gg = g[r];
-            for (uint32_t step = 0;; ++step) {
-                const bool occ = active && (cur.y >> 31);
-                const bool hit = occ && cur.x == f[r];
-                const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
-                const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
-                if (hit) { R.size[r] = cur.y & 0xFFFFu; R.pay[r] = ((uint64_t)cur.w << 32) | cur.z; R.wrote[r] = true; }
-                nsteps += (active && sub == 0) ? 1u : 0u;
-                if (ghit != 0 || gocc != 0xFFu) active = false;
-                if (!__any(active) || step + 1 >= tab.maxProbe) break;
-                gg = (gg + 1 == tab.ngroups) ? 0u : gg + 1;
-                cur = make_uint4(0, 0, 0, 0);
-                if (active) cur = slots[(size_t)gg * kSlotsPerGroup + sub];
-            }
-        }
-    }
+    uint32_t st = 0;
+    probe_features(f, tab, lane, R, st);
+    nstepsLane += lane == 0 ? st : 0u;                       // callers wave-sum this
 }
 
 // hand the group's probe results to sort_candidates_kernel (same layout sketch_probe_kernel writes)
@@ -1080,14 +1135,9 @@ __device__ __forceinline__ void fused_candidates(FusedLds& L, const ProbeResult&
 }
 
 template <bool FUSE>
-__global__ __launch_bounds__(256) void query_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, int wantAllhits,
-                                                    uint32_t K, mc_candidate_dev* __restrict__ cands)
+__device__ __forceinline__ void query_one(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int wantAllhits,
+                                          uint32_t K, mc_candidate_dev* __restrict__ cands, FusedLds& L, uint32_t q, uint32_t lane)
 {
-    __shared__ FusedLds lds[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
-    if (q >= b.n) return;
-    FusedLds& L = lds[wave];
 
     const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
     const bool noTail = qi.w == kNoTail;
@@ -1157,9 +1207,31 @@ __global__ __launch_bounds__(256) void query_kernel(BatchView b, SketchParams sp
         }
     }
     if (lane == 0) {
-        QueryStat qs; qs.hits = H; qs.nfeat = F; qs.nfound = Fo; qs.nsteps = St | (done ? kDoneFlag : 0u);
+        QueryStat qs; qs.hits = H; qs.nfeat = F; qs.nfound = Fo; qs.nsteps = St;
         ws.qstat[q] = qs;
         ws.hitScan[q] = (!done && H <= kMaxHitsPerQuery && (wantAllhits || H > kLdsCap)) ? H : 0u;
+        ws.qflag[q] = done ? kFlagDone : kFlagCands;
+    }
+}
+
+// Every wave scans 64 query flags at a time and processes the queries that still need sketching.
+template <bool FUSE>
+__global__ __launch_bounds__(256) void query_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, int wantAllhits,
+                                                    uint32_t K, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ FusedLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + wave;
+    for (uint32_t base = waveId * 64; base < b.n; base += nWaves * 64) {
+        const uint32_t qq = base + lane;
+        const uint32_t fl = qq < b.n ? ws.qflag[qq] : kFlagDone;
+        uint64_t m = __ballot(fl == kFlagSketch);
+        while (m) {
+            const uint32_t j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            query_one<FUSE>(b, sp, tab, ws, wantAllhits, K, cands, lds[wave], base + j, lane);
+            wave_lds_sync();
+        }
     }
 }
 
@@ -1167,10 +1239,311 @@ void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable&
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
-    dim3 grid((b.n + 3) / 4), block(256);
+    dim3 grid((b.n + 255) / 256), block(256);               // one wave per 64 query flags
     if (fuse) hipLaunchKernelGGL(query_kernel<true>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0, maxCand, (mc_candidate_dev*)cands);
     else      hipLaunchKernelGGL(query_kernel<false>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0, maxCand, (mc_candidate_dev*)cands);
 }
+
+// ================================================================================================
+// Lane-parallel fast path for short reads (the common case: 100-300 bp reads, small hit lists).
+//
+// Wave-per-query kernels spend most of their instructions on cross-lane bookkeeping that serves ONE
+// query.  Short reads are better served by giving every lane its own query for the irregular parts and
+// keeping only the memory-bound part cooperative:
+//   sketch_lane_kernel     one lane per query : rolling canonical k-mers straight from the characters,
+//                                                16-entry min/max insertion chain = the sketch
+//   probe_flat_kernel      8 lanes per feature: one 128-byte bucket group per load, several in flight
+//   candidates_lane_kernel one lane per query : the CPU algorithm verbatim on <= 32 locations
+// Queries that do not qualify (long reads, windows that do not partition the k-mers, duplicate
+// hashes inside a sketch, long hit lists, taxon merging, -allhits, K > 4) keep qflag != 0 and are
+// finished by the wave-per-query kernels (query_kernel / sort_candidates_kernel), which skip the rest.
+// ================================================================================================
+constexpr uint32_t kLaneMaxLen = 512;     // longest mate handled by one lane
+constexpr uint32_t kLaneS = 16;           // sketch entries held in registers
+constexpr uint32_t kLaneHits = 32;        // longest location list handled by one lane
+constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
+
+__device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
+{
+    // 4 characters -> 4 x 2-bit codes (byte j of 'codes' holds base j) and 4 ambiguity bits
+    const uint32_t x = (w >> 1) & 0x03030303u;
+    codes = x ^ ((x >> 1) & 0x01010101u);
+    ambs = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t u = (((w >> (8 * j)) & 0xDFu) - 0x41u);
+        const bool ok = u < 32u && ((0x00180045u >> u) & 1u);
+        ambs |= ok ? 0u : (1u << j);
+    }
+}
+
+__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, const uint32_t* __restrict__ winOff,
+                                                          uint32_t* __restrict__ features, uint32_t* __restrict__ qflag)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= b.n) return;
+    const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+    const uint32_t k = sp.k, s = sp.s, stride = sp.stride;
+    const bool noTail = qi.w == kNoTail;
+    const uint32_t widx0 = winOff[q];
+    if (noTail || qi.y > kLaneMaxLen || qi.w > kLaneMaxLen) {
+        const uint32_t nw = winOff[q + 1] - widx0;
+        for (uint32_t i = 0; i < nw * s; ++i) features[(size_t)widx0 * s + i] = 0xFFFFFFFFu;   // nothing to probe here
+        qflag[q] = kFlagSketch;
+        return;
+    }
+    const uint32_t kmask = 0xFFFFFFFFu >> (32u - 2u * k);
+    const uint32_t rcshift = 2u * k - 2u;
+    bool dup = false;
+    uint32_t wcount = 0;
+    for (uint32_t mate = 0; mate < 2; ++mate) {
+        const uint32_t off = mate ? qi.z : qi.x;
+        const uint32_t len = mate ? qi.w : qi.y;
+        if (len < k) continue;
+        uint32_t sk[kLaneS];
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneS; ++i) sk[i] = 0xFFFFFFFFu;
+        uint32_t fwd = 0, rc = 0, since = 0, wpos = 0;
+        const uint4* src = reinterpret_cast<const uint4*>(b.seq + off);       // sequences start 4-byte aligned
+        uint4 nxt = src[0];
+        for (uint32_t j0 = 0; j0 < len; j0 += 16) {
+            const uint4 cur = nxt;
+            if (j0 + 16 < len) nxt = src[(j0 >> 4) + 1];
+            const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (uint32_t d = 0; d < 4; ++d) {
+                uint32_t codes, ambs;
+                lane_encode4(wd[d], codes, ambs);
+#pragma unroll
+                for (uint32_t t = 0; t < 4; ++t) {
+                    const uint32_t j = j0 + d * 4 + t;
+                    if (j < len) {
+                        const uint32_t c = (codes >> (8 * t)) & 3u;
+                        const bool a = (ambs >> t) & 1u;
+                        fwd = ((fwd << 2) | c) & kmask;
+                        rc = (rc >> 2) | ((3u - c) << rcshift);
+                        since = a ? 0u : since + 1u;
+                        if (j + 1 >= k) {
+                            uint32_t h = 0xFFFFFFFFu;
+                            if (since >= k) h = tm_hash(fwd < rc ? fwd : rc);
+                            // insertion chain: sk stays sorted ascending, the largest value falls out
+#pragma unroll
+                            for (uint32_t i = 0; i < kLaneS; ++i) {
+                                const uint32_t lo = min(sk[i], h);
+                                h = max(sk[i], h);
+                                sk[i] = lo;
+                            }
+                            ++wpos;
+                            if (wpos == stride || j + 1 == len) {              // window complete (row 1: k-mers partition)
+                                uint32_t* out = features + (size_t)(widx0 + wcount) * s;
+#pragma unroll
+                                for (uint32_t i = 0; i < kLaneS; ++i) {
+                                    if (i < s) out[i] = sk[i];
+                                    if (i + 1 < s) dup = dup || (sk[i] == sk[i + 1] && sk[i] != 0xFFFFFFFFu);
+                                    sk[i] = 0xFFFFFFFFu;
+                                }
+                                ++wcount; wpos = 0;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    qflag[q] = dup ? kFlagSketch : kFlagProbe;
+}
+
+// probe_cands_kernel: every wave repeatedly grabs a chunk of 64 queries (dynamic counter), loads their
+// flags and window offsets with ONE coalesced access and then
+//   (1) walks through the queries the lane sketcher finished: 32 features per pass (one coalesced load,
+//       prefetched a query ahead, distributed with ds_bpermute), 8 lanes per feature, one 128-byte
+//       bucket group per load, all loads of a pass in flight; hits are compacted with ballot/mbcnt into
+//       the query's row of an LDS list (<= kLaneHits locations);
+//   (2) switches to ONE LANE PER QUERY for rows 8-10: insertion sort of the row, the CPU's sequential
+//       window-range scan and top-K insertion -- tiny, irregular work that a whole wave would waste.
+// Per-query results (stats, flags) are kept in the owning lane and written coalesced once per chunk.
+struct LaneCand { uint32_t tgt, hits, beg, end; };
+constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in u64): conflict-free lane-private rows
+
+__global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+                                                          mc_candidate_dev* __restrict__ cands, uint32_t* __restrict__ chunkCounter)
+{
+    __shared__ uint64_t lst[4][64 * kLaneRow];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & 7u, grp = lane >> 3;
+    const uint32_t n = b.n;
+    uint64_t* rows = lst[wave];
+    const uint32_t* __restrict__ features = ws.features;
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(chunkCounter, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        const uint32_t base = chunk * 64;
+        if (base >= n) break;
+        const uint32_t qq = base + lane;
+        const uint32_t fl = qq < n ? ws.qflag[qq] : kFlagDone;
+        const uint32_t wlo = qq < n ? ws.winOff[qq] : 0u, whi = qq < n ? ws.winOff[qq + 1] : 0u;
+        uint64_t m = __ballot(fl == kFlagProbe);
+        // what this lane's query ends up with
+        uint32_t myH = 0, myNfeat = 0, myNfound = 0, myNsteps = 0, myFlag = fl, myScan = 0;
+        // software pipeline over the chunk's queries: while query j is resolved, the bucket-group loads of
+        // query j+1 and the feature load of query j+2 are in flight
+        auto load_feats = [&](uint32_t jq) -> uint32_t {
+            const uint32_t fb = rdlane(wlo, jq) * s, nfq = (rdlane(whi, jq) - rdlane(wlo, jq)) * s;
+            return lane < min(nfq, kGroupSlots) ? features[fb + lane] : 0xFFFFFFFFu;
+        };
+        uint32_t fNext[kProbeRounds];
+        ProbeState pNext;
+        uint32_t nfeatNext = 0, featAfter = 0xFFFFFFFFu;
+        if (m) {
+            const uint32_t j0 = __ffsll((unsigned long long)m) - 1;
+            const uint32_t feat0 = load_feats(j0);
+            const uint64_t rest = m & (m - 1);
+            if (rest) featAfter = load_feats(__ffsll((unsigned long long)rest) - 1);
+            nfeatNext = __popcll(__ballot(feat0 != 0xFFFFFFFFu));
+#pragma unroll
+            for (uint32_t r = 0; r < kProbeRounds; ++r) fNext[r] = __shfl(feat0, r * 8 + grp);
+            probe_issue(fNext, tab, lane, pNext);
+        }
+        while (m) {
+            const uint32_t j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t fbase = rdlane(wlo, j) * s, nf = (rdlane(whi, j) - rdlane(wlo, j)) * s;
+            uint32_t fCur[kProbeRounds];
+            ProbeState pCur = pNext;
+#pragma unroll
+            for (uint32_t r = 0; r < kProbeRounds; ++r) fCur[r] = fNext[r];
+            uint32_t nfeat = nfeatNext;
+            if (m) {                                           // issue the next query's probes before resolving this one
+                const uint32_t featN = featAfter;
+                const uint64_t rest = m & (m - 1);
+                if (rest) featAfter = load_feats(__ffsll((unsigned long long)rest) - 1);
+                nfeatNext = __popcll(__ballot(featN != 0xFFFFFFFFu));
+#pragma unroll
+                for (uint32_t r = 0; r < kProbeRounds; ++r) fNext[r] = __shfl(featN, r * 8 + grp);
+                probe_issue(fNext, tab, lane, pNext);
+            }
+            uint64_t* row = rows + j * kLaneRow;
+            uint32_t H = 0, stored = 0, nfound = 0, nsteps = 0;     // wave-uniform
+            ProbeResult R;
+            for (uint32_t c0 = 0; c0 < nf; c0 += kGroupSlots) {
+                if (c0) {                                      // further passes of queries with > 32 features: not pipelined
+                    const uint32_t feat = (c0 + lane < nf && lane < kGroupSlots) ? features[fbase + c0 + lane] : 0xFFFFFFFFu;
+                    nfeat += __popcll(__ballot(feat != 0xFFFFFFFFu));
+#pragma unroll
+                    for (uint32_t r = 0; r < kProbeRounds; ++r) fCur[r] = __shfl(feat, r * 8 + grp);
+                    probe_issue(fCur, tab, lane, pCur);
+                }
+                probe_resolve(fCur, pCur, tab, lane, R, nsteps);
+#pragma unroll
+                for (uint32_t r = 0; r < kProbeRounds; ++r) {
+                    const bool single = R.wrote[r] && R.size[r] == 1;
+                    const uint64_t ms = __ballot(single);
+                    const uint32_t pos = stored + mbcnt(ms);
+                    if (single && pos < kLaneHits) row[pos] = R.pay[r];
+                    stored += __popcll(ms); H += __popcll(ms);
+                    nfound += __popcll(__ballot(R.wrote[r]));
+                    uint64_t mm = __ballot(R.wrote[r] && R.size[r] > 1);
+                    while (mm) {
+                        const uint32_t jj = __ffsll((unsigned long long)mm) - 1;
+                        mm &= mm - 1;
+                        const uint32_t nj = rdlane(R.size[r], jj);
+                        const uint64_t src = rdlane64(R.pay[r], jj);
+                        if (stored + nj <= kLaneHits && lane < nj) row[stored + lane] = tab.values[src + lane];   // nj <= 32
+                        stored += nj; H += nj;
+                    }
+                }
+            }
+            uint32_t flag = kFlagLaneCands, scan = 0;
+            if (H > kLaneHits) {
+                if (nf <= kGroupSlots) {                           // results still in registers: hand them to sort_candidates
+                    store_probe_results(R, nf, fbase, ws, lane);
+                    flag = kFlagCands;
+                    scan = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
+                } else flag = kFlagSketch;                         // several passes: let the wave kernel redo it
+            }
+            if (lane == j) { myH = H; myNfeat = nfeat; myNfound = nfound; myNsteps = nsteps; myFlag = flag; myScan = scan; }
+        }
+        wave_lds_sync();
+        // ---- one lane per query: rows 8-10 as on the CPU (candidate_generation.hpp:47-108, :172-201)
+        if (myFlag == kFlagLaneCands) {
+            uint64_t* L = rows + lane * kLaneRow;
+            const uint32_t cnt = myH;
+            for (uint32_t t = 1; t < cnt; ++t) {                  // insertion sort by (tgt, win)
+                const uint64_t x = L[t];
+                uint32_t jj = t;
+                while (jj > 0 && L[jj - 1] > x) { L[jj] = L[jj - 1]; --jj; }
+                L[jj] = x;
+            }
+            LaneCand top[kLaneK];
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; }
+            const uint32_t maxWin = b.maxWin ? b.maxWin[qq] : b.maxWinUniform;
+            auto insert = [&](LaneCand c) {
+                // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
+                bool moving = false;
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) {
+                    if (i < K && (moving || c.hits > top[i].hits)) { const LaneCand t = top[i]; top[i] = c; c = t; moving = true; }
+                }
+            };
+            if (cnt > 0) {
+                uint32_t fst = 0, hits = 1;
+                LaneCand best; best.tgt = (uint32_t)(L[0] >> 32); best.hits = 1; best.beg = best.end = (uint32_t)L[0];
+                for (uint32_t i = 1; i < cnt; ++i) {
+                    const uint64_t key = L[i];
+                    const uint32_t tgt = (uint32_t)(key >> 32), win = (uint32_t)key;
+                    if (tgt == best.tgt) {
+                        ++hits;
+                        while (fst != i && (win - (uint32_t)L[fst]) >= maxWin) { --hits; ++fst; }
+                        if (hits > best.hits) { best.hits = hits; best.beg = (uint32_t)L[fst]; best.end = win; }
+                    } else {
+                        insert(best);
+                        fst = i; hits = 1;
+                        best.tgt = tgt; best.hits = 1; best.beg = best.end = win;
+                    }
+                }
+                insert(best);
+            }
+            mc_candidate_dev* out = cands + (size_t)qq * K;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i)
+                if (i < K) { mc_candidate_dev e; e.tgt = top[i].tgt; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end; out[i] = e; }
+            myFlag = kFlagDone;
+        }
+        if (qq < n && fl == kFlagProbe) {
+            QueryStat qs; qs.hits = myH; qs.nfeat = myNfeat; qs.nfound = myNfound; qs.nsteps = myNsteps;
+            ws.qstat[qq] = qs;
+            ws.hitScan[qq] = myScan;
+            ws.qflag[qq] = myFlag;
+        }
+        wave_lds_sync();
+    }
+}
+
+void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(sketch_lane_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, ws.winOff, ws.features, ws.qflag);
+}
+void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, void* cands,
+                        hipStream_t st)
+{
+    if (b.n == 0) return;
+    static int blocksPerCU = 0, numCU = 0;
+    if (!blocksPerCU) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, dev);
+        numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, probe_cands_kernel, 256, 0) != hipSuccess || blocksPerCU < 1) blocksPerCU = 2;
+    }
+    const uint32_t chunks = (b.n + 63u) / 64u;
+    const uint32_t blocks = min((chunks + 3u) / 4u, (uint32_t)(numCU * blocksPerCU));
+    (void)hipMemsetAsync(ws.counter, 0, sizeof(uint32_t), st);
+    hipLaunchKernelGGL(probe_cands_kernel, dim3(blocks), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, (mc_candidate_dev*)cands, ws.counter);
+}
+bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
+bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }
 
 // ================================================================================================
 // batch statistics (on demand, not on the timed path)
@@ -1182,7 +1555,7 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __res
     uint64_t h = 0, f = 0, fo = 0, st = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         QueryStat s = qs[i];
-        h += s.hits; f += s.nfeat; fo += s.nfound; st += (s.nsteps & 0x7FFFFFFFu);
+        h += s.hits; f += s.nfeat; fo += s.nfound; st += s.nsteps;
     }
     h = block_reduce_u64(h, sh); f = block_reduce_u64(f, sh); fo = block_reduce_u64(fo, sh); st = block_reduce_u64(st, sh);
     if (threadIdx.x == 0) {

@@ -148,3 +148,41 @@ def test_device_path_features_match_oracle(golden):
     st = db.last_batch_stats()
     assert st["windows"] == wo[-1]
     db.close()
+
+
+def test_many_reads_random_db_lane_and_wave_paths_against_oracle(tmp_path):
+    """A database of unrelated random genomes produces spurious single hits on other targets, i.e. many
+    equal-hit ties in the top-2 list -- the situation in which candidate ordering bugs show.  Both the
+    lane-parallel short-read path and the wave-per-query path must agree with the oracle."""
+    import os
+    from metacache_amd import synth
+    rng = np.random.default_rng(99)
+    genomes = [synth.random_genome(rng, 300_000) for _ in range(16)]
+    bld = api.Builder(target_id_bytes=4, max_candidates=2)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"R{i:04d}.1", parent_taxid=1000 + i)
+    name = str(tmp_path / "rand16")
+    bld.finish(load=False)
+    bld.write(name, [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"sp{i}") for i in range(16)])
+    bld.free()
+    reads, _, _ = synth.sample_reads(rng, genomes, 30000, 150, 0.01, 0.002)
+    reads = [bytes(r) for r in reads]
+    odb = cpuref.oracle().open(name)
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
+    _, exp = odb.query_many(seqs, offs, max_cand=2)
+    odb.close()
+    ties = int(((exp["hits"][:, 0] > 1) & (exp["hits"][:, 1] == 1)).sum())
+    assert ties > 50                                   # the interesting situation really occurs
+    for env in ("0", "1"):
+        os.environ["MC_NO_LANE_PATH"] = env
+        try:
+            db = api.Database.open(name, max_candidates=2, slot_max_queries=1 << 15, slot_max_chars=1 << 23)
+            cands, counts, _ = db.query(reads)
+            db.close()
+        finally:
+            os.environ.pop("MC_NO_LANE_PATH", None)
+        for f in ("hits", "beg", "end"):
+            assert np.array_equal(cands[f], exp[f]), (env, f)
+        used = exp["hits"] > 0
+        assert np.array_equal(cands["tgt"][used], exp["tgt"][used]), env
