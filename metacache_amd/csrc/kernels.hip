@@ -1364,11 +1364,12 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
 // Per-query results (stats, flags) are kept in the owning lane and written coalesced once per chunk.
 struct LaneCand { uint32_t tgt, hits, beg, end; };
 constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in u64): conflict-free lane-private rows
+constexpr uint32_t kChunk = 32;                               // queries per wave pass: 8.4 KB of LDS rows per wave
 
 __global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                           mc_candidate_dev* __restrict__ cands, uint32_t* __restrict__ chunkCounter)
 {
-    __shared__ uint64_t lst[4][64 * kLaneRow];
+    __shared__ uint64_t lst[4][kChunk * kLaneRow];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t sub = lane & 7u, grp = lane >> 3;
     const uint32_t n = b.n;
@@ -1378,11 +1379,12 @@ __global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t 
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(chunkCounter, 1u);
         chunk = __builtin_amdgcn_readfirstlane(chunk);
-        const uint32_t base = chunk * 64;
+        const uint32_t base = chunk * kChunk;
         if (base >= n) break;
         const uint32_t qq = base + lane;
-        const uint32_t fl = qq < n ? ws.qflag[qq] : kFlagDone;
-        const uint32_t wlo = qq < n ? ws.winOff[qq] : 0u, whi = qq < n ? ws.winOff[qq + 1] : 0u;
+        const bool mine = lane < kChunk && qq < n;                 // lanes >= kChunk idle in the per-query stage
+        const uint32_t fl = mine ? ws.qflag[qq] : kFlagDone;
+        const uint32_t wlo = mine ? ws.winOff[qq] : 0u, whi = mine ? ws.winOff[qq + 1] : 0u;
         uint64_t m = __ballot(fl == kFlagProbe);
         // what this lane's query ends up with
         uint32_t myH = 0, myNfeat = 0, myNfound = 0, myNsteps = 0, myFlag = fl, myScan = 0;
@@ -1392,36 +1394,35 @@ __global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t 
             const uint32_t fb = rdlane(wlo, jq) * s, nfq = (rdlane(whi, jq) - rdlane(wlo, jq)) * s;
             return lane < min(nfq, kGroupSlots) ? features[fb + lane] : 0xFFFFFFFFu;
         };
-        uint32_t fNext[kProbeRounds];
-        ProbeState pNext;
-        uint32_t nfeatNext = 0, featAfter = 0xFFFFFFFFu;
+        // two buffers that swap roles every query (no register copies): {features, probe state, #features}
+        uint32_t fA[kProbeRounds], fB[kProbeRounds];
+        ProbeState pA, pB;
+        uint32_t nfA = 0, nfB = 0, featAfter = 0xFFFFFFFFu;
         if (m) {
             const uint32_t j0 = __ffsll((unsigned long long)m) - 1;
             const uint32_t feat0 = load_feats(j0);
             const uint64_t rest = m & (m - 1);
             if (rest) featAfter = load_feats(__ffsll((unsigned long long)rest) - 1);
-            nfeatNext = __popcll(__ballot(feat0 != 0xFFFFFFFFu));
+            nfA = __popcll(__ballot(feat0 != 0xFFFFFFFFu));
 #pragma unroll
-            for (uint32_t r = 0; r < kProbeRounds; ++r) fNext[r] = __shfl(feat0, r * 8 + grp);
-            probe_issue(fNext, tab, lane, pNext);
+            for (uint32_t r = 0; r < kProbeRounds; ++r) fA[r] = __shfl(feat0, r * 8 + grp);
+            probe_issue(fA, tab, lane, pA);
         }
-        while (m) {
+        // resolves the query whose loads are in (fCur, pCur) after issuing the next one's into (fNxt, pNxt)
+        auto process = [&](uint32_t (&fCur)[kProbeRounds], ProbeState& pCur, uint32_t nfeatCur,
+                           uint32_t (&fNxt)[kProbeRounds], ProbeState& pNxt, uint32_t& nfeatNxt) {
             const uint32_t j = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const uint32_t fbase = rdlane(wlo, j) * s, nf = (rdlane(whi, j) - rdlane(wlo, j)) * s;
-            uint32_t fCur[kProbeRounds];
-            ProbeState pCur = pNext;
-#pragma unroll
-            for (uint32_t r = 0; r < kProbeRounds; ++r) fCur[r] = fNext[r];
-            uint32_t nfeat = nfeatNext;
+            uint32_t nfeat = nfeatCur;
             if (m) {                                           // issue the next query's probes before resolving this one
                 const uint32_t featN = featAfter;
                 const uint64_t rest = m & (m - 1);
                 if (rest) featAfter = load_feats(__ffsll((unsigned long long)rest) - 1);
-                nfeatNext = __popcll(__ballot(featN != 0xFFFFFFFFu));
+                nfeatNxt = __popcll(__ballot(featN != 0xFFFFFFFFu));
 #pragma unroll
-                for (uint32_t r = 0; r < kProbeRounds; ++r) fNext[r] = __shfl(featN, r * 8 + grp);
-                probe_issue(fNext, tab, lane, pNext);
+                for (uint32_t r = 0; r < kProbeRounds; ++r) fNxt[r] = __shfl(featN, r * 8 + grp);
+                probe_issue(fNxt, tab, lane, pNxt);
             }
             uint64_t* row = rows + j * kLaneRow;
             uint32_t H = 0, stored = 0, nfound = 0, nsteps = 0;     // wave-uniform
@@ -1463,6 +1464,11 @@ __global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t 
                 } else flag = kFlagSketch;                         // several passes: let the wave kernel redo it
             }
             if (lane == j) { myH = H; myNfeat = nfeat; myNfound = nfound; myNsteps = nsteps; myFlag = flag; myScan = scan; }
+        };
+        while (m) {
+            process(fA, pA, nfA, fB, pB, nfB);
+            if (!m) break;
+            process(fB, pB, nfB, fA, pA, nfA);
         }
         wave_lds_sync();
         // ---- one lane per query: rows 8-10 as on the CPU (candidate_generation.hpp:47-108, :172-201)
@@ -1511,7 +1517,7 @@ __global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t 
                 if (i < K) { mc_candidate_dev e; e.tgt = top[i].tgt; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end; out[i] = e; }
             myFlag = kFlagDone;
         }
-        if (qq < n && fl == kFlagProbe) {
+        if (mine && fl == kFlagProbe) {
             QueryStat qs; qs.hits = myH; qs.nfeat = myNfeat; qs.nfound = myNfound; qs.nsteps = myNsteps;
             ws.qstat[qq] = qs;
             ws.hitScan[qq] = myScan;
@@ -1537,7 +1543,7 @@ void launch_probe_cands(const BatchView& b, const SketchParams& sp, const Device
         numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, probe_cands_kernel, 256, 0) != hipSuccess || blocksPerCU < 1) blocksPerCU = 2;
     }
-    const uint32_t chunks = (b.n + 63u) / 64u;
+    const uint32_t chunks = (b.n + kChunk - 1) / kChunk;
     const uint32_t blocks = min((chunks + 3u) / 4u, (uint32_t)(numCU * blocksPerCU));
     (void)hipMemsetAsync(ws.counter, 0, sizeof(uint32_t), st);
     hipLaunchKernelGGL(probe_cands_kernel, dim3(blocks), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, (mc_candidate_dev*)cands, ws.counter);
