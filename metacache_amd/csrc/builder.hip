@@ -114,10 +114,9 @@ int flush(mc_builder* b)
     BatchView bv{dseq, dq, nullptr, 1, nq};
     Workspace ws{};
     ws.winCount = dwc; ws.winOff = dwo; ws.features = dfeat; ws.qstat = dqs; ws.hitScan = dhs; ws.scanTmp = dscan;
-    DeviceTable tab{nullptr, nullptr, 1, 0};
     launch_plan(bv, sp, dwc, b->st);
     launch_scan_u32(dwc, 1, nq, dwo, nullptr, dscan, b->st);
-    launch_sketch_probe(bv, sp, tab, false, false, ws, b->st);
+    launch_sketch_only(bv, sp, ws, b->st);
     uint32_t W = 0;
     B_TRY(b, hipMemcpyAsync(&W, dwo + nq, 4, hipMemcpyDeviceToHost, b->st));
     B_TRY(b, hipStreamSynchronize(b->st));

@@ -151,7 +151,7 @@ void mc_destroy(mc_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto& p : ctx->parts) { if (p.dslots) (void)hipFree(p.dslots); if (p.dvalues) (void)hipFree(p.dvalues); }
+    for (auto& p : ctx->parts) { if (p.dbuckets) (void)hipFree(p.dbuckets); if (p.dvalues) (void)hipFree(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     DevBuf* bufs[] = {&ctx->bWinCount, &ctx->bWinOff, &ctx->bFeatures, &ctx->bPsize, &ctx->bPpay, &ctx->bQstat, &ctx->bHitOff,
                       &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist};
@@ -179,11 +179,12 @@ int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues)
     Part& P = ctx->parts[part];
     if (P.loading || P.ready) return fail(ctx, MC_ERR_STATE, "mc_load_begin: part already loaded");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint64_t ng = (uint64_t)((double)nkeys / (kSlotsPerGroup * (double)ctx->loadFactor)) + 1;
-    if (ng > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit group index");
-    P.ngroups = (uint32_t)ng;
+    uint64_t nb = (uint64_t)((double)nkeys / (kSlotsPerBucket * (double)ctx->loadFactor)) + 2;
+    nb += nb & 1;                                            // two buckets per line
+    if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
+    P.nbuckets = (uint32_t)nb;
     P.expectKeys = nkeys; P.expectValues = nvalues;
-    P.hslots.assign((size_t)ng * kSlotsPerGroup, TableSlot{0, 0, 0});
+    P.hbuckets.assign((size_t)nb, TableBucket{});
     P.dvaluesCap = nvalues + 1;
     HIP_TRY(ctx, hipMalloc((void**)&P.dvalues, P.dvaluesCap * sizeof(uint64_t)));
     P.loading = true;
@@ -217,23 +218,23 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
         if (size > 0) {
             // place the key: first group along the chain with a free slot
             const uint32_t key = keys[i];
-            uint32_t g = (uint32_t)(((uint64_t)mix32(key) * P.ngroups) >> 32);
-            uint32_t probe = 1;
-            TableSlot* dst = nullptr;
+            const uint32_t home = (uint32_t)(((uint64_t)mix32(key) * P.nbuckets) >> 32);
+            uint32_t cur = home, probe = 1;
+            TableBucket* grp = nullptr;
+            uint32_t slot = 0;
             for (;; ++probe) {
-                TableSlot* grp = &P.hslots[(size_t)g * kSlotsPerGroup];
-                for (uint32_t j = 0; j < kSlotsPerGroup; ++j)
-                    if (!(grp[j].meta >> 31)) { dst = &grp[j]; break; }
-                if (dst) break;
-                g = (g + 1 == P.ngroups) ? 0 : g + 1;
-                if (probe > P.ngroups) return fail(ctx, MC_ERR_NOMEM, "hash table full");
+                grp = &P.hbuckets[cur];
+                for (slot = 0; slot < kSlotsPerBucket && grp->size[slot]; ++slot) {}
+                if (slot < kSlotsPerBucket) break;
+                if (probe > P.nbuckets) return fail(ctx, MC_ERR_NOMEM, "hash table full");
+                cur = next_bucket(home, cur, probe, P.nbuckets);
             }
             if (probe > P.maxProbe) P.maxProbe = probe;
-            dst->key = key;
-            dst->meta = 0x80000000u | size;
-            if (size == 1) dst->payload = decode(vp);
+            grp->key[slot] = key;
+            grp->size[slot] = (uint16_t)size;
+            if (size == 1) grp->payload[slot] = decode(vp);
             else {
-                dst->payload = P.valuesStored + stage.size();
+                grp->payload[slot] = P.valuesStored + stage.size();
                 for (uint32_t t = 0; t < size; ++t) stage.push_back(decode(vp + (size_t)t * vb));
             }
             P.locations += size;
@@ -256,10 +257,10 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
     if (part >= ctx->parts.size() || !ctx->parts[part].loading) return fail(ctx, MC_ERR_STATE, "mc_load_end: nothing being loaded");
     Part& P = ctx->parts[part];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = P.hslots.size() * sizeof(TableSlot);
-    HIP_TRY(ctx, hipMalloc((void**)&P.dslots, bytes));
-    HIP_TRY(ctx, hipMemcpy(P.dslots, P.hslots.data(), bytes, hipMemcpyHostToDevice));
-    std::vector<TableSlot>().swap(P.hslots);
+    const size_t bytes = P.hbuckets.size() * sizeof(TableBucket);
+    HIP_TRY(ctx, hipMalloc((void**)&P.dbuckets, bytes));
+    HIP_TRY(ctx, hipMemcpy(P.dbuckets, P.hbuckets.data(), bytes, hipMemcpyHostToDevice));
+    std::vector<TableBucket>().swap(P.hbuckets);
     P.loading = false; P.ready = true;
     return MC_OK;
 }
@@ -356,7 +357,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
     const Part& P = ctx->parts[0];
-    DeviceTable tab{P.dslots, P.dvalues, P.ngroups, P.maxProbe};
+    DeviceTable tab{P.dbuckets, P.dvalues, P.nbuckets, P.maxProbe};
 
     {
         ScopedTimer t(ctx, "plan", st);

@@ -18,15 +18,15 @@ struct DevBuf {                 // grow-only device allocation
 
 struct Part {
     // host-side build state (freed by mc_load_end)
-    std::vector<TableSlot> hslots;
+    std::vector<TableBucket> hbuckets;
     uint64_t expectKeys = 0, expectValues = 0;
     uint64_t keysLoaded = 0;
     uint64_t valuesStored = 0;      // entries written to dvalues (buckets of size > 1 only)
     uint64_t locations = 0;         // all locations kept (incl. inline singletons)
     uint64_t keysStored = 0;
-    uint32_t ngroups = 0, maxProbe = 1;
+    uint32_t nbuckets = 0, maxProbe = 1;
     bool loading = false, ready = false;
-    TableSlot* dslots = nullptr;
+    TableBucket* dbuckets = nullptr;
     uint64_t* dvalues = nullptr;
     uint64_t dvaluesCap = 0;
 };

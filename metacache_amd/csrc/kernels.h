@@ -10,22 +10,40 @@ namespace mcamd {
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kMaxSketch = 32;       // MC_MAX_SKETCH
 constexpr uint32_t kMaxWinLen = 1024;     // MC_MAX_WINLEN
-constexpr uint32_t kSlotsPerGroup = 8;    // 8 x 16 B = one 128-B line per probe
 constexpr uint32_t kNoTail = 0xFFFFFFFFu; // qinfo[3] marker: single sequence, tail window suppressed
 constexpr uint32_t kMaxHitsPerQuery = (1u << 20) - 1;  // packed candidate fields are 20 bits wide
 
-// One hash table slot (16 B).  meta: bit 31 = occupied, low 16 bits = bucket size.
-// size == 1: payload = the location itself ((tgt << 32) | win), no second access needed;
-// size  > 1: payload = index of the first location in DeviceTable::values.
-struct __attribute__((aligned(16))) TableSlot {
-    uint32_t key;
-    uint32_t meta;
-    uint64_t payload;
+// Table layout: an array of 64-byte BUCKETS of 4 slots, two per 128-byte line, structure-of-arrays so
+// that a single LANE looks a feature up with four 16-byte loads of ONE half line and has key, size and
+// payload of the match in registers -- no second, dependent access (a separate payload load re-fetched
+// the line from L2 because thousands of lines are in flight per CU and the L1 holds 256):
+//   key[4]     the features
+//   size[4]    bucket sizes (u16), 0 = free slot
+//   payload[4] size == 1: the location itself ((tgt << 32) | win);
+//              size  > 1: index of the first location in DeviceTable::values
+// Probe sequence of a key: its home bucket, the sibling bucket in the same line, then the following
+// buckets linearly.  Insertion uses the first bucket of that sequence with a free slot, so a lookup
+// ends at the first bucket that holds the key or has a free slot.
+struct __attribute__((aligned(64))) TableBucket {
+    uint32_t key[4];
+    uint16_t size[4];
+    uint32_t spare[2];
+    uint64_t payload[4];
 };
+static_assert(sizeof(TableBucket) == 64, "two buckets per 128-byte line");
+constexpr uint32_t kSlotsPerBucket = 4;
+
+__host__ __device__ inline uint32_t next_bucket(uint32_t home, uint32_t cur, uint32_t step, uint32_t nbuckets)
+{
+    // step = number of buckets already visited (>= 1)
+    if (step == 1) return home ^ 1u;                          // sibling half of the same line
+    const uint32_t nx = (step == 2 ? (home | 1u) : cur) + 1u;
+    return nx >= nbuckets ? 0u : nx;
+}
 
 // table hash: features are the SMALLEST hash values of a window, i.e. far from uniform in their
 // high bits, so they are mixed again (murmur3 fmix32) before the multiply-shift range reduction
-// group = (mix32(key) * ngroups) >> 32.
+// bucket = (mix32(key) * nbuckets) >> 32.
 __host__ __device__ inline uint32_t mix32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
@@ -33,9 +51,9 @@ __host__ __device__ inline uint32_t mix32(uint32_t x)
 }
 
 struct DeviceTable {
-    const TableSlot* slots;   // [ngroups * 8]
+    const TableBucket* buckets; // [nbuckets], nbuckets even
     const uint64_t*  values;  // location lists, (tgt << 32) | win, each bucket sorted ascending
-    uint32_t ngroups;
+    uint32_t nbuckets;
     uint32_t maxProbe;        // longest probe sequence (in groups) needed by any stored key
 };
 
@@ -92,8 +110,7 @@ void launch_plan(const BatchView& b, const SketchParams& sp, uint32_t* winCount,
 void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64,
                      void* tmp, hipStream_t st);
 size_t scan_tmp_bytes(uint32_t n);
-void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool doProbe,
-                         bool wantAllhits, const Workspace& ws, hipStream_t st);
+void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);

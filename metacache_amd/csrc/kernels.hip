@@ -89,9 +89,9 @@ __device__ __forceinline__ uint32_t canonical_hash(uint32_t kmer, uint32_t k)
     r = (~r) >> (32u - 2u * k);                                    // complement, keep low 2k bits
     return tm_hash(kmer < r ? kmer : r);
 }
-__device__ __forceinline__ uint32_t home_group(uint32_t key, uint32_t ngroups)
+__device__ __forceinline__ uint32_t home_group(uint32_t key, uint32_t nbuckets)
 {
-    return (uint32_t)(((uint64_t)mix32(key) * ngroups) >> 32);
+    return (uint32_t)(((uint64_t)mix32(key) * nbuckets) >> 32);
 }
 
 // ================================================================================================
@@ -247,272 +247,53 @@ __device__ __forceinline__ uint32_t encode_base(uint32_t c)
     return ok ? code : 4u;
 }
 
-struct WaveLds {
-    uint32_t code[kCodeWords];
-    uint32_t amb[kAmbWords];
-    uint32_t cand[64];      // compacted candidates of the min-hash selection
-    uint32_t sk[64];        // current sketch during selection
-    uint32_t fbuf[64];      // features of the current group of windows (slot = window-in-group * s + j)
-};
-
-// Stage window [p, p+n) of the sequence as packed 2-bit codes + ambiguity bits into this wave's LDS.
-__device__ __forceinline__ void stage_window(const uint8_t* __restrict__ seq, uint64_t start, uint32_t n, WaveLds& L, uint32_t lane)
-{
-    uint8_t* codeB = reinterpret_cast<uint8_t*>(L.code);
-    uint8_t* ambB = reinterpret_cast<uint8_t*>(L.amb);
-    for (uint32_t c0 = 0; c0 < n; c0 += 256) {           // 64 lanes x 4 characters per pass
-        uint32_t c = c0 + lane * 4;
-        uint32_t chars = 0x4E4E4E4Eu;                      // 'N'
-        if (c < n) {
-            // unaligned 4-byte read through two aligned dwords (8 slack bytes behind the buffer)
-            uint64_t a = start + c;
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(seq + (a & ~(uint64_t)3));
-            uint32_t lo = w[0], hi = w[1];
-            chars = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
-        }
-        uint32_t code = 0, amb = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t e = encode_base((chars >> (8 * j)) & 0xFFu);
-            bool bad = (e & 4u) || (c + j >= n);
-            code = (code << 2) | (bad ? 0u : e);
-            amb |= (bad ? 1u : 0u) << j;
-        }
-        uint32_t ci = c >> 2;                              // index of this 4-base group
-        codeB[ci ^ 3u] = (uint8_t)code;                    // big-endian inside each 32-bit word
-        uint32_t other = dpp_mov<0xB1>(amb);               // neighbour lane's nibble
-        if ((lane & 1u) == 0) ambB[ci >> 1] = (uint8_t)(amb | (other << 4));
-    }
-}
-
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// ascending bitonic sort of one u32 per lane (64 lanes), duplicates allowed
-__device__ __forceinline__ uint32_t wave_sort32_reg(uint32_t key, uint32_t lane)
+// ================================================================================================
+// lane-private table lookup: ONE lane looks one feature up with four 16-byte loads of one 64-byte bucket
+// (keys, sizes, payloads).  Split in two so that callers can have several lookups in flight per lane.
+// ================================================================================================
+struct BucketRegs { uint4 k, sz, p0, p1; };      // key[0..3] | size[0..3] (4 x u16) + spare | payload[0..1] | payload[2..3]
+
+__device__ __forceinline__ BucketRegs load_bucket(const DeviceTable& tab, uint32_t bi)
 {
+    const uint4* p = reinterpret_cast<const uint4*>(tab.buckets + bi);
+    BucketRegs r; r.k = p[0]; r.sz = p[1]; r.p0 = p[2]; r.p1 = p[3];
+    return r;
+}
+__device__ __forceinline__ void probe_start(const DeviceTable& tab, uint32_t f, uint32_t& home, BucketRegs& r)
+{
+    home = home_group(f, tab.nbuckets);
+    r.k = r.sz = r.p0 = r.p1 = make_uint4(0, 0, 0, 0);
+    if (f != 0xFFFFFFFFu) r = load_bucket(tab, home);
+}
+// f == ~0 (no feature) yields size 0.  'steps' counts the buckets read.
+__device__ __forceinline__ void probe_finish(const DeviceTable& tab, uint32_t f, uint32_t home, BucketRegs r, uint32_t& size, uint64_t& pay, uint32_t& steps)
+{
+    size = 0; pay = 0;
+    if (f == 0xFFFFFFFFu) return;
+    uint32_t cur = home;
+    for (uint32_t step = 1;; ++step) {
+        ++steps;
+        const uint32_t keys[4] = {r.k.x, r.k.y, r.k.z, r.k.w};
+        const uint32_t s01 = r.sz.x, s23 = r.sz.y;
+        const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
+        const uint64_t pl[4] = {((uint64_t)r.p0.y << 32) | r.p0.x, ((uint64_t)r.p0.w << 32) | r.p0.z,
+                                ((uint64_t)r.p1.y << 32) | r.p1.x, ((uint64_t)r.p1.w << 32) | r.p1.z};
+        bool anyFree = false;
 #pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1) {
-        {
-            uint32_t o = __shfl(key, lane ^ (k - 1));
-            key = ((lane & (k >> 1)) == 0) ? min(key, o) : max(key, o);
+        for (uint32_t i = 0; i < 4; ++i) {
+            anyFree = anyFree || sz[i] == 0;
+            if (sz[i] != 0 && keys[i] == f) { size = sz[i]; pay = pl[i]; }
         }
-#pragma unroll
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            uint32_t o = __shfl(key, lane ^ j);
-            key = ((lane & j) == 0) ? min(key, o) : max(key, o);
-        }
+        // found, or a bucket with a free slot ends the chain (insertion fills the first bucket with room)
+        if (size != 0 || anyFree || step >= tab.maxProbe) return;
+        cur = next_bucket(home, cur, step, tab.nbuckets);
+        r = load_bucket(tab, cur);
     }
-    return key;
-}
-
-// hash of the k-mer starting at window position p, or ~0 if it is out of range / ambiguous
-__device__ __forceinline__ uint32_t kmer_hash_at(const WaveLds& L, uint32_t p, uint32_t nk, uint32_t k, uint32_t kbits)
-{
-    uint32_t h = 0xFFFFFFFFu;
-    if (p < nk) {
-        const uint32_t wq = p >> 4, sh = (p & 15u) * 2u;
-        const uint32_t kmer = __funnelshift_l(L.code[wq + 1], L.code[wq], sh) >> (32u - 2u * k);
-        const uint32_t aw = p >> 5;
-        const uint32_t am = __funnelshift_r(L.amb[aw], L.amb[aw + 1], p & 31u) & kbits;
-        if (am == 0) h = canonical_hash(kmer, k);              // dna_encoding.hpp:438-441
-    }
-    return h;
-}
-
-// Min-hash sketch of the staged window (hash_dna.hpp:224-251): the sl smallest DISTINCT hashes,
-// ascending; returns it one element per lane (lane j < count holds element j, others ~0).
-//
-// Instead of sl serial minimum extractions, hashes below a threshold T (chosen so that ~1.75 sl of
-// the uniformly distributed hashes pass) are compacted with ballot/mbcnt, sorted with a 64-lane
-// register bitonic network and made unique.  Exact: if at least sl distinct values are < T they are
-// the sl smallest overall; otherwise T is raised and the window redone (rare).  More than 64
-// candidates (degenerate input) fall back to serial extraction.
-__device__ __forceinline__ uint32_t sketch_staged_window(WaveLds& L, uint32_t n, uint32_t k, uint32_t s, uint32_t lane, uint32_t& countOut)
-{
-    const uint32_t kbits = 0xFFFFu >> (16u - k);
-    const uint32_t nk = n - k + 1;
-    const uint32_t sl = min(s, nk);
-    uint64_t t64 = (((uint64_t)7 * sl) << 32) / ((uint64_t)4 * nk);
-    uint32_t T = t64 >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t64;
-    uint32_t sk, cnt;
-    for (;;) {
-        sk = 0xFFFFFFFFu; cnt = 0;
-        for (uint32_t base = 0; base < nk; base += 128) {       // two k-mers per lane per round
-            const uint32_t h0 = kmer_hash_at(L, base + lane, nk, k, kbits);
-            const uint32_t h1 = kmer_hash_at(L, base + 64 + lane, nk, k, kbits);
-            const bool p0 = h0 < T, p1 = h1 < T;
-            const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-            const uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
-            const uint32_t nc = cnt + n0 + n1;
-            if (nc == cnt) continue;
-            if (nc <= 64) {
-                if (lane < cnt) L.cand[lane] = sk;
-                if (p0) L.cand[cnt + mbcnt(m0)] = h0;
-                if (p1) L.cand[cnt + n0 + mbcnt(m1)] = h1;
-                wave_lds_sync();
-                uint32_t v = lane < nc ? L.cand[lane] : 0xFFFFFFFFu;
-                v = wave_sort32_reg(v, lane);
-                uint32_t prev = __shfl_up(v, 1);
-                const bool uniq = lane < nc && (lane == 0 || v != prev);
-                const uint64_t um = __ballot(uniq);
-                const uint32_t upos = mbcnt(um);
-                if (uniq && upos < sl) L.sk[upos] = v;
-                cnt = min(sl, (uint32_t)__popcll(um));
-                wave_lds_sync();
-                sk = lane < cnt ? L.sk[lane] : 0xFFFFFFFFu;
-                wave_lds_sync();
-            } else {
-                // serial extraction over {old sketch, h0, h1} restricted to values < T
-                uint32_t nsk = 0xFFFFFFFFu, lb = 0, c = 0;
-                const uint32_t a0 = p0 ? h0 : 0xFFFFFFFFu, a1 = p1 ? h1 : 0xFFFFFFFFu;
-                for (uint32_t t = 0; t < sl; ++t) {
-                    uint32_t cand = min(min(a0 >= lb ? a0 : 0xFFFFFFFFu, a1 >= lb ? a1 : 0xFFFFFFFFu), sk >= lb ? sk : 0xFFFFFFFFu);
-                    uint32_t m = wave_min_u32(cand);
-                    if (m == 0xFFFFFFFFu) break;
-                    if (lane == t) nsk = m;
-                    lb = m + 1; ++c;
-                }
-                sk = nsk; cnt = c;
-            }
-        }
-        if (cnt >= sl || T == 0xFFFFFFFFu) break;
-        T = T >= 0x40000000u ? 0xFFFFFFFFu : T << 2;
-    }
-    countOut = cnt;
-    return sk;
-}
-
-constexpr uint32_t kProbeRounds = 4;                    // 4 x 8 = 32 feature slots per probe group
-constexpr uint32_t kGroupSlots = kProbeRounds * 8;
-
-// Probe the features held in L.fbuf[0 .. nslots) (slot j -> global feature index fbase + j):
-// 8 lanes x 16 B read one 128-byte bucket group per feature; the first-step loads of all (up to 4)
-// rounds are issued before any result is used.
-__device__ __forceinline__ void probe_group(const WaveLds& L, uint32_t nslots, uint32_t fbase, const DeviceTable& tab, const Workspace& ws,
-                                            uint32_t lane, uint32_t& myHits, uint32_t& nfound, uint32_t& nsteps)
-{
-    const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
-    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
-    uint32_t f[kProbeRounds], g[kProbeRounds];
-    uint4 sl4[kProbeRounds];
-    const uint32_t rounds = (nslots + 7) >> 3;
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        f[r] = 0xFFFFFFFFu; sl4[r] = make_uint4(0, 0, 0, 0); g[r] = 0;
-        if (r < rounds) {
-            const uint32_t fi = r * 8 + grp;
-            f[r] = fi < nslots ? L.fbuf[fi] : 0xFFFFFFFFu;
-            if (f[r] != 0xFFFFFFFFu) {
-                g[r] = home_group(f[r], tab.ngroups);
-                sl4[r] = slots[(size_t)g[r] * kSlotsPerGroup + sub];
-            }
-        }
-    }
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        if (r < rounds) {                                       // wave-uniform
-            const uint32_t fi = r * 8 + grp;
-            bool active = f[r] != 0xFFFFFFFFu;
-            uint4 cur = sl4[r];
-            uint32_t gg = g[r];
-            uint32_t rsize = 0; uint64_t rpay = 0;
-            bool wrote = false;
-            for (uint32_t step = 0;; ++step) {
-                const bool occ = active && (cur.y >> 31);
-                const bool hit = occ && cur.x == f[r];
-                const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
-                const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
-                if (hit) { rsize = cur.y & 0xFFFFu; rpay = ((uint64_t)cur.w << 32) | cur.z; wrote = true; }
-                nsteps += (active && sub == 0) ? 1u : 0u;
-                // finished when found, or when the group has a free slot (insertion fills the first
-                // group with room, so the key cannot live further along the chain)
-                if (ghit != 0 || gocc != 0xFFu) active = false;
-                if (!__any(active) || step + 1 >= tab.maxProbe) break;
-                gg = (gg + 1 == tab.ngroups) ? 0u : gg + 1;
-                cur = make_uint4(0, 0, 0, 0);
-                if (active) cur = slots[(size_t)gg * kSlotsPerGroup + sub];
-            }
-            if (fi < nslots) {
-                // exactly one lane per feature writes: the hit lane, else sub-lane 0
-                const uint32_t anyhit = (uint32_t)(__ballot(wrote) >> gshift) & 0xFFu;
-                if (wrote || (anyhit == 0 && sub == 0)) {
-                    ws.psize[fbase + fi] = rsize;
-                    ws.ppay[fbase + fi] = rpay;
-                }
-            }
-            myHits += rsize;
-            nfound += wrote ? 1u : 0u;
-        }
-    }
-}
-
-template <bool PROBE>
-__global__ __launch_bounds__(256) void sketch_probe_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, int wantAllhits)
-{
-    __shared__ WaveLds lds[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t q = blockIdx.x * 4 + wave;
-    if (q >= b.n) return;                                 // whole wave leaves together
-    WaveLds& L = lds[wave];
-
-    const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
-    const bool noTail = qi.w == kNoTail;
-    uint32_t widx = ws.winOff[q];                         // global index of this query's next window
-    const uint32_t k = sp.k, s = sp.s;
-    const uint32_t winsPerGroup = kGroupSlots / s;        // feature slots of one probe group = winsPerGroup * s <= 32
-
-    uint32_t myHits = 0, nfeat = 0, nfound = 0, nsteps = 0;
-    uint32_t gslot = 0;                                   // windows already in the current group
-    uint32_t gfirst = widx;                               // global window index of the group's first window
-
-    for (uint32_t mate = 0; mate < 2; ++mate) {
-        const uint32_t off = mate ? qi.z : qi.x;
-        const uint32_t len = mate ? (noTail ? 0u : qi.w) : qi.y;
-        const uint32_t nwin = windows_of(len, sp, mate == 0 && noTail);
-        for (uint32_t wi = 0; wi < nwin; ++wi, ++widx) {
-            const uint32_t first = (len <= sp.w) ? 0u : wi * sp.stride;
-            const uint32_t n = min(sp.w, len - first);
-            stage_window(b.seq, (uint64_t)off + first, n, L, lane);
-            wave_lds_sync();
-            uint32_t cnt;
-            const uint32_t sk = sketch_staged_window(L, n, k, s, lane, cnt);
-            if (lane < s) {
-                if (ws.features) ws.features[widx * s + lane] = sk;
-                L.fbuf[gslot * s + lane] = sk;
-            }
-            nfeat += lane < cnt ? 1u : 0u;
-            ++gslot;
-            wave_lds_sync();
-            if (gslot == winsPerGroup) {
-                if (PROBE) probe_group(L, gslot * s, gfirst * s, tab, ws, lane, myHits, nfound, nsteps);
-                gslot = 0; gfirst = widx + 1;
-                wave_lds_sync();
-            }
-        }
-    }
-    if (PROBE && gslot) probe_group(L, gslot * s, gfirst * s, tab, ws, lane, myHits, nfound, nsteps);
-
-    const uint32_t H = wave_sum_u32(myHits);
-    const uint32_t F = wave_sum_u32(nfeat);
-    const uint32_t Fo = wave_sum_u32(nfound);
-    const uint32_t St = wave_sum_u32(nsteps);
-    if (lane == 0) {
-        QueryStat qs; qs.hits = H; qs.nfeat = F; qs.nfound = Fo; qs.nsteps = St;
-        ws.qstat[q] = qs;
-        ws.hitScan[q] = (H <= kMaxHitsPerQuery && (wantAllhits || H > kLdsCap)) ? H : 0u;
-    }
-}
-
-void launch_sketch_probe(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool doProbe,
-                         bool wantAllhits, const Workspace& ws, hipStream_t st)
-{
-    if (b.n == 0) return;
-    dim3 grid((b.n + 3) / 4), block(256);
-    if (doProbe) hipLaunchKernelGGL(sketch_probe_kernel<true>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0);
-    else         hipLaunchKernelGGL(sketch_probe_kernel<false>, grid, block, 0, st, b, sp, tab, ws, wantAllhits ? 1 : 0);
 }
 
 // ================================================================================================
@@ -839,6 +620,7 @@ void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const De
 //   sketch_probe_kernel does.
 // ================================================================================================
 constexpr uint32_t kFuseCap = 32;
+constexpr uint32_t kGroupSlots = 64;                    // features probed together by one wave (one lane each)
 
 struct FusedLds {
     uint32_t code[kCodeWords];
@@ -846,7 +628,7 @@ struct FusedLds {
     uint32_t cand[128];      // [0,64) compaction target, [64,128) dump slots for masked-off lanes
     uint32_t srt[128];
     uint32_t sk[128];
-    uint32_t fbuf[kGroupSlots + 64];
+    uint32_t fbuf[kGroupSlots + 64];   // features of the current probe group (+ dump slots)
     uint64_t sbuf[kFuseCap + 32];
 };
 
@@ -975,131 +757,27 @@ __device__ __forceinline__ uint32_t sketch_window_v3(FusedLds& L, uint32_t wo, u
     return cnt;
 }
 
-struct ProbeResult {             // per lane: what this lane found in each of the 4 rounds
-    uint32_t size[kProbeRounds];
-    uint64_t pay[kProbeRounds];
-    bool wrote[kProbeRounds];
-};
-
-// Probing up to 4 x 8 features (f[r] = the feature this lane's 8-lane group handles in round r, ~0 = none)
-// is split in two so that callers can keep the loads of the NEXT query in flight while they resolve the
-// current one:
-//   probe_issue  : home groups + first-step loads of all rounds (8 lanes x 16 B = one 128-byte group each)
-//   probe_resolve: ballot per 8-lane group; groups that are full without a match continue along their
-//                  chain, all rounds together per step (unsuccessful lookups must not serialise).
-struct ProbeState {
-    uint32_t g[kProbeRounds];
-    uint4 cur[kProbeRounds];
-};
-
-__device__ __forceinline__ void probe_issue(const uint32_t (&f)[kProbeRounds], const DeviceTable& tab, uint32_t lane, ProbeState& P)
-{
-    const uint32_t sub = lane & 7u;
-    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        P.g[r] = home_group(f[r], tab.ngroups);
-        P.cur[r] = make_uint4(0, 0, 0, 0);
-        if (f[r] != 0xFFFFFFFFu) P.cur[r] = slots[(size_t)P.g[r] * kSlotsPerGroup + sub];
-    }
-}
-
-__device__ __forceinline__ void probe_resolve(const uint32_t (&f)[kProbeRounds], ProbeState& P, const DeviceTable& tab, uint32_t lane,
-                                              ProbeResult& R, uint32_t& nsteps)
-{
-    const uint32_t sub = lane & 7u, gshift = lane & ~7u;
-    const uint4* slots = reinterpret_cast<const uint4*>(tab.slots);
-    bool active[kProbeRounds];
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) { active[r] = f[r] != 0xFFFFFFFFu; R.size[r] = 0; R.pay[r] = 0; R.wrote[r] = false; }
-    for (uint32_t step = 0;; ++step) {
-        bool more = false;
-#pragma unroll
-        for (uint32_t r = 0; r < kProbeRounds; ++r) {
-            const bool occ = active[r] && (P.cur[r].y >> 31);
-            const bool hit = occ && P.cur[r].x == f[r];
-            const uint32_t ghit = (uint32_t)(__ballot(hit) >> gshift) & 0xFFu;
-            const uint32_t gocc = (uint32_t)(__ballot(occ) >> gshift) & 0xFFu;
-            if (hit) { R.size[r] = P.cur[r].y & 0xFFFFu; R.pay[r] = ((uint64_t)P.cur[r].w << 32) | P.cur[r].z; R.wrote[r] = true; }
-            nsteps += __popcll(__ballot(active[r] && sub == 0));
-            // finished when found, or when the group has a free slot (insertion fills the first group
-            // with room, so the key cannot live further along the chain)
-            if (ghit != 0 || gocc != 0xFFu) active[r] = false;
-            more = more || active[r];
-        }
-        if (!__any(more) || step + 1 >= tab.maxProbe) break;
-#pragma unroll
-        for (uint32_t r = 0; r < kProbeRounds; ++r) {
-            P.g[r] = (P.g[r] + 1 == tab.ngroups) ? 0u : P.g[r] + 1;
-            P.cur[r] = make_uint4(0, 0, 0, 0);
-            if (active[r]) P.cur[r] = slots[(size_t)P.g[r] * kSlotsPerGroup + sub];
-        }
-    }
-}
-
-__device__ __forceinline__ void probe_features(const uint32_t (&f)[kProbeRounds], const DeviceTable& tab, uint32_t lane,
-                                               ProbeResult& R, uint32_t& nsteps)
-{
-    ProbeState P;
-    probe_issue(f, tab, lane, P);
-    probe_resolve(f, P, tab, lane, R, nsteps);
-}
-
-__device__ __forceinline__ void probe_group_v3(const FusedLds& L, uint32_t nslots, const DeviceTable& tab, uint32_t lane,
-                                               ProbeResult& R, uint32_t& nstepsLane)
-{
-    const uint32_t grp = lane >> 3;
-    uint32_t f[kProbeRounds];
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        const uint32_t fi = r * 8 + grp;
-        const uint32_t fv = L.fbuf[fi];
-        f[r] = fi < nslots ? fv : 0xFFFFFFFFu;
-    }
-    uint32_t st = 0;
-    probe_features(f, tab, lane, R, st);
-    nstepsLane += lane == 0 ? st : 0u;                       // callers wave-sum this
-}
-
-// hand the group's probe results to sort_candidates_kernel (same layout sketch_probe_kernel writes)
-__device__ __forceinline__ void store_probe_results(const ProbeResult& R, uint32_t nslots, uint32_t fbase, const Workspace& ws, uint32_t lane)
-{
-    const uint32_t sub = lane & 7u, grp = lane >> 3, gshift = lane & ~7u;
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        const uint32_t fi = r * 8 + grp;
-        const uint32_t anyhit = (uint32_t)(__ballot(R.wrote[r]) >> gshift) & 0xFFu;
-        if (fi < nslots && (R.wrote[r] || (anyhit == 0 && sub == 0))) {
-            ws.psize[fbase + fi] = R.size[r];
-            ws.ppay[fbase + fi] = R.pay[r];
-        }
-    }
-}
-
-// rows 7-10 for at most kFuseCap location hits, entirely in registers (sequence-level candidates)
-__device__ __forceinline__ void fused_candidates(FusedLds& L, const ProbeResult& R, const DeviceTable& tab, uint32_t H, uint32_t maxWin,
+// rows 7-10 for at most kFuseCap location hits, entirely in registers (sequence-level candidates).
+// Every lane looked ONE feature of the group up: (size, pay) is its result (size 0 = nothing).
+__device__ __forceinline__ void fused_candidates(FusedLds& L, uint32_t size, uint64_t pay, const DeviceTable& tab, uint32_t H, uint32_t maxWin,
                                                  uint32_t K, mc_candidate_dev* out, uint32_t lane)
 {
     // compact the hit locations into lanes 0..H-1 (their order is irrelevant: ranks are computed below)
     uint32_t base = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        const bool single = R.wrote[r] && R.size[r] == 1;
+    {
+        const bool single = size == 1;
         const uint64_t m = __ballot(single);
-        if (single) L.sbuf[base + mbcnt(m)] = R.pay[r];
-        base += __popcll(m);
+        if (single) L.sbuf[mbcnt(m)] = pay;
+        base = __popcll(m);
     }
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) {
-        uint64_t mm = __ballot(R.wrote[r] && R.size[r] > 1);
-        while (mm) {
-            const uint32_t j = __ffsll((unsigned long long)mm) - 1;
-            mm &= mm - 1;
-            const uint32_t nj = rdlane(R.size[r], j);
-            const uint64_t src = rdlane64(R.pay[r], j);
-            if (lane < nj) L.sbuf[base + lane] = tab.values[src + lane];    // nj <= H <= 32 < 64
-            base += nj;
-        }
+    uint64_t mm = __ballot(size > 1);
+    while (mm) {
+        const uint32_t j = __ffsll((unsigned long long)mm) - 1;
+        mm &= mm - 1;
+        const uint32_t nj = rdlane(size, j);
+        const uint64_t src = rdlane64(pay, j);
+        if (lane < nj) L.sbuf[base + lane] = tab.values[src + lane];    // nj <= H <= 32 < 64
+        base += nj;
     }
     wave_lds_sync();
     const uint64_t key = L.sbuf[lane < H ? lane : 0];
@@ -1138,7 +816,6 @@ template <bool FUSE>
 __device__ __forceinline__ void query_one(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int wantAllhits,
                                           uint32_t K, mc_candidate_dev* __restrict__ cands, FusedLds& L, uint32_t q, uint32_t lane)
 {
-
     const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
     const bool noTail = qi.w == kNoTail;
     const uint32_t widx0 = ws.winOff[q];
@@ -1148,11 +825,22 @@ __device__ __forceinline__ void query_one(const BatchView& b, const SketchParams
     const bool single = nwinTotal <= winsPerGroup;          // the whole query is one probe group
 
     uint32_t widx = widx0;
-    uint32_t myHits = 0, nfeat = 0, nfound = 0, nsteps = 0;
+    uint32_t myHits = 0, nfeat = 0, nfound = 0, nsteps = 0;  // nfeat is wave-uniform, the others per lane
     uint32_t gslot = 0, gfirst = widx;
-    ProbeResult R;
-#pragma unroll
-    for (uint32_t r = 0; r < kProbeRounds; ++r) { R.size[r] = 0; R.pay[r] = 0; R.wrote[r] = false; }
+    uint32_t rsize = 0; uint64_t rpay = 0;                   // this lane's lookup result of the current group
+
+    // one lane per feature of the group: all lookups of the group are in flight together
+    auto probe_group = [&]() {
+        const uint32_t nslots = gslot * s;
+        const uint32_t fv = L.fbuf[lane];
+        const uint32_t f = lane < nslots ? fv : 0xFFFFFFFFu;
+        uint32_t g; BucketRegs h;
+        probe_start(tab, f, g, h);
+        probe_finish(tab, f, g, h, rsize, rpay, nsteps);
+        myHits += rsize;
+        nfound += rsize ? 1u : 0u;
+        if (!(FUSE && single) && lane < nslots) { ws.psize[gfirst * s + lane] = rsize; ws.ppay[gfirst * s + lane] = rpay; }
+    };
 
     for (uint32_t mate = 0; mate < 2; ++mate) {
         const uint32_t off = mate ? qi.z : qi.x;
@@ -1169,45 +857,36 @@ __device__ __forceinline__ void query_one(const BatchView& b, const SketchParams
                 const uint32_t n = min(sp.w, len - first);
                 const uint32_t wo = first - segFirst;
                 if (wo + n > segChars) break;                // continues in the next segment
-                const uint32_t cnt = sketch_window_v3(L, wo, n, k, s, gslot * s, lane);
-                nfeat += lane < cnt ? 1u : 0u;
+                nfeat += sketch_window_v3(L, wo, n, k, s, gslot * s, lane);
                 wave_lds_sync();
                 if (ws.features && lane < s) ws.features[widx * s + lane] = L.fbuf[gslot * s + lane];
                 ++gslot;
                 if (gslot == winsPerGroup) {
-                    probe_group_v3(L, gslot * s, tab, lane, R, nsteps);
-                    if (!(FUSE && single)) store_probe_results(R, gslot * s, gfirst * s, ws, lane);
-#pragma unroll
-                    for (uint32_t r = 0; r < kProbeRounds; ++r) { myHits += R.size[r]; nfound += R.wrote[r] ? 1u : 0u; }
+                    if (ws.psize) probe_group();
                     if (!single) { gslot = 0; gfirst = widx + 1; }
                 }
             }
         }
     }
     const bool pending = single ? (gslot > 0 && gslot < winsPerGroup) : gslot > 0;
-    if (pending) {
-        probe_group_v3(L, gslot * s, tab, lane, R, nsteps);
-        if (!(FUSE && single)) store_probe_results(R, gslot * s, gfirst * s, ws, lane);
-#pragma unroll
-        for (uint32_t r = 0; r < kProbeRounds; ++r) { myHits += R.size[r]; nfound += R.wrote[r] ? 1u : 0u; }
-    }
+    if (pending && ws.psize) probe_group();
+    if (!ws.psize) return;                                   // sketch-only use (database builder)
 
     const uint32_t H = wave_sum_u32(myHits);
-    const uint32_t F = wave_sum_u32(nfeat);
     const uint32_t Fo = wave_sum_u32(nfound);
-    uint32_t St = wave_sum_u32(nsteps);
+    const uint32_t St = wave_sum_u32(nsteps);
     bool done = false;
     if (FUSE && single) {
         if (H <= kFuseCap) {
             const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-            fused_candidates(L, R, tab, H, maxWin, K, cands + (size_t)q * K, lane);
+            fused_candidates(L, rsize, rpay, tab, H, maxWin, K, cands + (size_t)q * K, lane);
             done = true;
-        } else {
-            store_probe_results(R, gslot * s, gfirst * s, ws, lane);
+        } else if (lane < gslot * s) {                       // too many hits for the register path: hand over
+            ws.psize[gfirst * s + lane] = rsize; ws.ppay[gfirst * s + lane] = rpay;
         }
     }
     if (lane == 0) {
-        QueryStat qs; qs.hits = H; qs.nfeat = F; qs.nfound = Fo; qs.nsteps = St;
+        QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = Fo; qs.nsteps = St;
         ws.qstat[q] = qs;
         ws.hitScan[q] = (!done && H <= kMaxHitsPerQuery && (wantAllhits || H > kLdsCap)) ? H : 0u;
         ws.qflag[q] = done ? kFlagDone : kFlagCands;
@@ -1233,6 +912,25 @@ __global__ __launch_bounds__(256) void query_kernel(BatchView b, SketchParams sp
             wave_lds_sync();
         }
     }
+}
+
+// sketch-only use of the wave path (database builder): windows -> features, nothing else
+__global__ __launch_bounds__(256) void sketch_only_kernel(BatchView b, SketchParams sp, Workspace ws)
+{
+    __shared__ FusedLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (q >= b.n) return;
+    DeviceTable none{};
+    Workspace w = ws;
+    w.psize = nullptr;
+    query_one<false>(b, sp, none, w, 0, 0, nullptr, lds[wave], q, lane);
+}
+
+void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(sketch_only_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, ws);
 }
 
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
@@ -1353,178 +1051,115 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
     qflag[q] = dup ? kFlagSketch : kFlagProbe;
 }
 
-// probe_cands_kernel: every wave repeatedly grabs a chunk of 64 queries (dynamic counter), loads their
-// flags and window offsets with ONE coalesced access and then
-//   (1) walks through the queries the lane sketcher finished: 32 features per pass (one coalesced load,
-//       prefetched a query ahead, distributed with ds_bpermute), 8 lanes per feature, one 128-byte
-//       bucket group per load, all loads of a pass in flight; hits are compacted with ballot/mbcnt into
-//       the query's row of an LDS list (<= kLaneHits locations);
-//   (2) switches to ONE LANE PER QUERY for rows 8-10: insertion sort of the row, the CPU's sequential
-//       window-range scan and top-K insertion -- tiny, irregular work that a whole wave would waste.
-// Per-query results (stats, flags) are kept in the owning lane and written coalesced once per chunk.
+// probe_cands_kernel: ONE LANE PER QUERY for rows 6-10.
+//   rows 6-7: the lane walks through its features (16-byte loads of its own 128-byte feature block), kLaneU
+//             lookups in flight (probe_start / probe_finish: three 16-byte loads of the bucket group's line,
+//             8-byte payload on a hit); hits go to the lane's private LDS row (<= kLaneHits locations);
+//   row 8   : insertion sort of the row;
+//   rows 9-10: the CPU's sequential window-range scan and a shifting top-K insert -- verbatim, so the tie
+//             behaviour is identical by construction.
+// Why not 8 lanes per bucket group (the first version of this kernel): lane-private lookups reach the same
+// random-line rate (tools/gather_bench3.hip: 57 G lines/s vs 55 G lines/s cooperative) with a tenth of the
+// instructions -- no ballots, no cross-lane compaction, no per-query serial section.
+// Lists longer than kLaneHits: second pass that stores (size, payload) per feature for sort_candidates_kernel.
 struct LaneCand { uint32_t tgt, hits, beg, end; };
 constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in u64): conflict-free lane-private rows
-constexpr uint32_t kChunk = 32;                               // queries per wave pass: 8.4 KB of LDS rows per wave
+constexpr uint32_t kLaneU = 4;                                // lookups in flight per lane
+constexpr uint32_t kLaneBlock = 128;
 
-__global__ __launch_bounds__(256) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
-                                                          mc_candidate_dev* __restrict__ cands, uint32_t* __restrict__ chunkCounter)
+__global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+                                                                 mc_candidate_dev* __restrict__ cands)
 {
-    __shared__ uint64_t lst[4][kChunk * kLaneRow];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t sub = lane & 7u, grp = lane >> 3;
-    const uint32_t n = b.n;
-    uint64_t* rows = lst[wave];
-    const uint32_t* __restrict__ features = ws.features;
-    for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(chunkCounter, 1u);
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
-        const uint32_t base = chunk * kChunk;
-        if (base >= n) break;
-        const uint32_t qq = base + lane;
-        const bool mine = lane < kChunk && qq < n;                 // lanes >= kChunk idle in the per-query stage
-        const uint32_t fl = mine ? ws.qflag[qq] : kFlagDone;
-        const uint32_t wlo = mine ? ws.winOff[qq] : 0u, whi = mine ? ws.winOff[qq + 1] : 0u;
-        uint64_t m = __ballot(fl == kFlagProbe);
-        // what this lane's query ends up with
-        uint32_t myH = 0, myNfeat = 0, myNfound = 0, myNsteps = 0, myFlag = fl, myScan = 0;
-        // software pipeline over the chunk's queries: while query j is resolved, the bucket-group loads of
-        // query j+1 and the feature load of query j+2 are in flight
-        auto load_feats = [&](uint32_t jq) -> uint32_t {
-            const uint32_t fb = rdlane(wlo, jq) * s, nfq = (rdlane(whi, jq) - rdlane(wlo, jq)) * s;
-            return lane < min(nfq, kGroupSlots) ? features[fb + lane] : 0xFFFFFFFFu;
-        };
-        // two buffers that swap roles every query (no register copies): {features, probe state, #features}
-        uint32_t fA[kProbeRounds], fB[kProbeRounds];
-        ProbeState pA, pB;
-        uint32_t nfA = 0, nfB = 0, featAfter = 0xFFFFFFFFu;
-        if (m) {
-            const uint32_t j0 = __ffsll((unsigned long long)m) - 1;
-            const uint32_t feat0 = load_feats(j0);
-            const uint64_t rest = m & (m - 1);
-            if (rest) featAfter = load_feats(__ffsll((unsigned long long)rest) - 1);
-            nfA = __popcll(__ballot(feat0 != 0xFFFFFFFFu));
+    __shared__ uint64_t lst[kLaneBlock * kLaneRow];
+    const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
+    if (q >= b.n) return;
+    if (ws.qflag[q] != kFlagProbe) return;
+    uint64_t* L = lst + threadIdx.x * kLaneRow;
+    const uint32_t fbase = ws.winOff[q] * s, nf = (ws.winOff[q + 1] - ws.winOff[q]) * s;
+    const uint32_t* __restrict__ feats = ws.features + fbase;
+
+    uint32_t H = 0, n = 0, nfeat = 0, nfound = 0, nsteps = 0;
+    for (uint32_t e0 = 0; e0 < nf; e0 += kLaneU) {
+        uint32_t f[kLaneU], g[kLaneU];
+        BucketRegs h[kLaneU];
 #pragma unroll
-            for (uint32_t r = 0; r < kProbeRounds; ++r) fA[r] = __shfl(feat0, r * 8 + grp);
-            probe_issue(fA, tab, lane, pA);
+        for (uint32_t u = 0; u < kLaneU; ++u) {
+            f[u] = e0 + u < nf ? feats[e0 + u] : 0xFFFFFFFFu;
+            probe_start(tab, f[u], g[u], h[u]);
         }
-        // resolves the query whose loads are in (fCur, pCur) after issuing the next one's into (fNxt, pNxt)
-        auto process = [&](uint32_t (&fCur)[kProbeRounds], ProbeState& pCur, uint32_t nfeatCur,
-                           uint32_t (&fNxt)[kProbeRounds], ProbeState& pNxt, uint32_t& nfeatNxt) {
-            const uint32_t j = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1;
-            const uint32_t fbase = rdlane(wlo, j) * s, nf = (rdlane(whi, j) - rdlane(wlo, j)) * s;
-            uint32_t nfeat = nfeatCur;
-            if (m) {                                           // issue the next query's probes before resolving this one
-                const uint32_t featN = featAfter;
-                const uint64_t rest = m & (m - 1);
-                if (rest) featAfter = load_feats(__ffsll((unsigned long long)rest) - 1);
-                nfeatNxt = __popcll(__ballot(featN != 0xFFFFFFFFu));
 #pragma unroll
-                for (uint32_t r = 0; r < kProbeRounds; ++r) fNxt[r] = __shfl(featN, r * 8 + grp);
-                probe_issue(fNxt, tab, lane, pNxt);
-            }
-            uint64_t* row = rows + j * kLaneRow;
-            uint32_t H = 0, stored = 0, nfound = 0, nsteps = 0;     // wave-uniform
-            ProbeResult R;
-            for (uint32_t c0 = 0; c0 < nf; c0 += kGroupSlots) {
-                if (c0) {                                      // further passes of queries with > 32 features: not pipelined
-                    const uint32_t feat = (c0 + lane < nf && lane < kGroupSlots) ? features[fbase + c0 + lane] : 0xFFFFFFFFu;
-                    nfeat += __popcll(__ballot(feat != 0xFFFFFFFFu));
-#pragma unroll
-                    for (uint32_t r = 0; r < kProbeRounds; ++r) fCur[r] = __shfl(feat, r * 8 + grp);
-                    probe_issue(fCur, tab, lane, pCur);
-                }
-                probe_resolve(fCur, pCur, tab, lane, R, nsteps);
-#pragma unroll
-                for (uint32_t r = 0; r < kProbeRounds; ++r) {
-                    const bool single = R.wrote[r] && R.size[r] == 1;
-                    const uint64_t ms = __ballot(single);
-                    const uint32_t pos = stored + mbcnt(ms);
-                    if (single && pos < kLaneHits) row[pos] = R.pay[r];
-                    stored += __popcll(ms); H += __popcll(ms);
-                    nfound += __popcll(__ballot(R.wrote[r]));
-                    uint64_t mm = __ballot(R.wrote[r] && R.size[r] > 1);
-                    while (mm) {
-                        const uint32_t jj = __ffsll((unsigned long long)mm) - 1;
-                        mm &= mm - 1;
-                        const uint32_t nj = rdlane(R.size[r], jj);
-                        const uint64_t src = rdlane64(R.pay[r], jj);
-                        if (stored + nj <= kLaneHits && lane < nj) row[stored + lane] = tab.values[src + lane];   // nj <= 32
-                        stored += nj; H += nj;
-                    }
+        for (uint32_t u = 0; u < kLaneU; ++u) {
+            uint32_t sz; uint64_t pay;
+            probe_finish(tab, f[u], g[u], h[u], sz, pay, nsteps);
+            nfeat += f[u] != 0xFFFFFFFFu ? 1u : 0u;
+            if (sz) {
+                ++nfound;
+                H += sz;
+                if (H <= kLaneHits) {
+                    if (sz == 1) L[n++] = pay;
+                    else for (uint32_t t = 0; t < sz; ++t) L[n++] = tab.values[pay + t];
                 }
             }
-            uint32_t flag = kFlagLaneCands, scan = 0;
-            if (H > kLaneHits) {
-                if (nf <= kGroupSlots) {                           // results still in registers: hand them to sort_candidates
-                    store_probe_results(R, nf, fbase, ws, lane);
-                    flag = kFlagCands;
-                    scan = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
-                } else flag = kFlagSketch;                         // several passes: let the wave kernel redo it
-            }
-            if (lane == j) { myH = H; myNfeat = nfeat; myNfound = nfound; myNsteps = nsteps; myFlag = flag; myScan = scan; }
-        };
-        while (m) {
-            process(fA, pA, nfA, fB, pB, nfB);
-            if (!m) break;
-            process(fB, pB, nfB, fA, pA, nfA);
         }
-        wave_lds_sync();
-        // ---- one lane per query: rows 8-10 as on the CPU (candidate_generation.hpp:47-108, :172-201)
-        if (myFlag == kFlagLaneCands) {
-            uint64_t* L = rows + lane * kLaneRow;
-            const uint32_t cnt = myH;
-            for (uint32_t t = 1; t < cnt; ++t) {                  // insertion sort by (tgt, win)
-                const uint64_t x = L[t];
-                uint32_t jj = t;
-                while (jj > 0 && L[jj - 1] > x) { L[jj] = L[jj - 1]; --jj; }
-                L[jj] = x;
-            }
-            LaneCand top[kLaneK];
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; }
-            const uint32_t maxWin = b.maxWin ? b.maxWin[qq] : b.maxWinUniform;
-            auto insert = [&](LaneCand c) {
-                // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
-                bool moving = false;
-#pragma unroll
-                for (uint32_t i = 0; i < kLaneK; ++i) {
-                    if (i < K && (moving || c.hits > top[i].hits)) { const LaneCand t = top[i]; top[i] = c; c = t; moving = true; }
-                }
-            };
-            if (cnt > 0) {
-                uint32_t fst = 0, hits = 1;
-                LaneCand best; best.tgt = (uint32_t)(L[0] >> 32); best.hits = 1; best.beg = best.end = (uint32_t)L[0];
-                for (uint32_t i = 1; i < cnt; ++i) {
-                    const uint64_t key = L[i];
-                    const uint32_t tgt = (uint32_t)(key >> 32), win = (uint32_t)key;
-                    if (tgt == best.tgt) {
-                        ++hits;
-                        while (fst != i && (win - (uint32_t)L[fst]) >= maxWin) { --hits; ++fst; }
-                        if (hits > best.hits) { best.hits = hits; best.beg = (uint32_t)L[fst]; best.end = win; }
-                    } else {
-                        insert(best);
-                        fst = i; hits = 1;
-                        best.tgt = tgt; best.hits = 1; best.beg = best.end = win;
-                    }
-                }
-                insert(best);
-            }
-            mc_candidate_dev* out = cands + (size_t)qq * K;
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i)
-                if (i < K) { mc_candidate_dev e; e.tgt = top[i].tgt; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end; out[i] = e; }
-            myFlag = kFlagDone;
-        }
-        if (mine && fl == kFlagProbe) {
-            QueryStat qs; qs.hits = myH; qs.nfeat = myNfeat; qs.nfound = myNfound; qs.nsteps = myNsteps;
-            ws.qstat[qq] = qs;
-            ws.hitScan[qq] = myScan;
-            ws.qflag[qq] = myFlag;
-        }
-        wave_lds_sync();
     }
+    QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps;
+    ws.qstat[q] = qs;
+    if (H > kLaneHits) {
+        // too long for a lane: leave (size, payload) per feature for the wave kernel
+        for (uint32_t e = 0; e < nf; ++e) {
+            uint32_t g, sz, st = 0; uint64_t pay; BucketRegs h;
+            const uint32_t f = feats[e];
+            probe_start(tab, f, g, h);
+            probe_finish(tab, f, g, h, sz, pay, st);
+            ws.psize[fbase + e] = sz; ws.ppay[fbase + e] = pay;
+        }
+        ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
+        ws.qflag[q] = kFlagCands;
+        return;
+    }
+    ws.hitScan[q] = 0;
+    for (uint32_t t = 1; t < n; ++t) {                            // row 8: insertion sort by (tgt, win)
+        const uint64_t x = L[t];
+        uint32_t j = t;
+        while (j > 0 && L[j - 1] > x) { L[j] = L[j - 1]; --j; }
+        L[j] = x;
+    }
+    // rows 9-10, sequentially as on the CPU (candidate_generation.hpp:47-108, :172-201)
+    LaneCand top[kLaneK];
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; }
+    const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+    auto insert = [&](LaneCand c) {
+        // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
+        bool moving = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) {
+            if (i < K && (moving || c.hits > top[i].hits)) { const LaneCand t = top[i]; top[i] = c; c = t; moving = true; }
+        }
+    };
+    if (n > 0) {
+        uint32_t fst = 0, hits = 1;
+        LaneCand best; best.tgt = (uint32_t)(L[0] >> 32); best.hits = 1; best.beg = best.end = (uint32_t)L[0];
+        for (uint32_t i = 1; i < n; ++i) {
+            const uint64_t key = L[i];
+            const uint32_t tgt = (uint32_t)(key >> 32), win = (uint32_t)key;
+            if (tgt == best.tgt) {
+                ++hits;
+                while (fst != i && (win - (uint32_t)L[fst]) >= maxWin) { --hits; ++fst; }
+                if (hits > best.hits) { best.hits = hits; best.beg = (uint32_t)L[fst]; best.end = win; }
+            } else {
+                insert(best);
+                fst = i; hits = 1;
+                best.tgt = tgt; best.hits = 1; best.beg = best.end = win;
+            }
+        }
+        insert(best);
+    }
+    mc_candidate_dev* out = cands + (size_t)q * K;
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i)
+        if (i < K) { mc_candidate_dev e; e.tgt = top[i].tgt; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end; out[i] = e; }
+    ws.qflag[q] = kFlagDone;
 }
 
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
@@ -1536,17 +1171,8 @@ void launch_probe_cands(const BatchView& b, const SketchParams& sp, const Device
                         hipStream_t st)
 {
     if (b.n == 0) return;
-    static int blocksPerCU = 0, numCU = 0;
-    if (!blocksPerCU) {
-        int dev = 0; (void)hipGetDevice(&dev);
-        hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, dev);
-        numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, probe_cands_kernel, 256, 0) != hipSuccess || blocksPerCU < 1) blocksPerCU = 2;
-    }
-    const uint32_t chunks = (b.n + kChunk - 1) / kChunk;
-    const uint32_t blocks = min((chunks + 3u) / 4u, (uint32_t)(numCU * blocksPerCU));
-    (void)hipMemsetAsync(ws.counter, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(probe_cands_kernel, dim3(blocks), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, (mc_candidate_dev*)cands, ws.counter);
+    hipLaunchKernelGGL(probe_cands_kernel, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
+                       (mc_candidate_dev*)cands);
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }
