@@ -1078,26 +1078,66 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
     const uint32_t fbase = ws.winOff[q] * s, nf = (ws.winOff[q + 1] - ws.winOff[q]) * s;
     const uint32_t* __restrict__ feats = ws.features + fbase;
 
+    // kLaneU lookup slots per lane, each a little state machine: a slot takes the lane's next feature and
+    // issues the load of its home bucket; when the bucket arrives the lookup either ends (found / free slot
+    // seen) or issues the load of the next bucket of its chain and stays pending.  One memory round trip per
+    // loop iteration, no inner waits: a long chain delays only its own slot, not the wave.
+    // (Measured alternatives at the same 1.2 ms: 8 lanes per 128-byte group with ballots; cooperative 4-lane
+    // fetch of the bucket handed to its owner through LDS.)
     uint32_t H = 0, n = 0, nfeat = 0, nfound = 0, nsteps = 0;
-    for (uint32_t e0 = 0; e0 < nf; e0 += kLaneU) {
-        uint32_t f[kLaneU], g[kLaneU];
-        BucketRegs h[kLaneU];
+    uint32_t e = 0;                                              // next feature of this lane
+    uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
+    BucketRegs r[kLaneU];
+    bool busy[kLaneU];
+#pragma unroll
+    for (uint32_t u = 0; u < kLaneU; ++u) busy[u] = false;
+    for (;;) {
+        bool any = false;
 #pragma unroll
         for (uint32_t u = 0; u < kLaneU; ++u) {
-            f[u] = e0 + u < nf ? feats[e0 + u] : 0xFFFFFFFFu;
-            probe_start(tab, f[u], g[u], h[u]);
+            if (!busy[u] && e < nf) {
+                f[u] = feats[e++];
+                if (f[u] != 0xFFFFFFFFu) {
+                    ++nfeat;
+                    home[u] = home_group(f[u], tab.nbuckets);
+                    cur[u] = home[u]; step[u] = 1;
+                    r[u] = load_bucket(tab, cur[u]);
+                    busy[u] = true;
+                }
+            }
+            any = any || busy[u];
         }
+        if (!any && e >= nf) break;
 #pragma unroll
         for (uint32_t u = 0; u < kLaneU; ++u) {
-            uint32_t sz; uint64_t pay;
-            probe_finish(tab, f[u], g[u], h[u], sz, pay, nsteps);
-            nfeat += f[u] != 0xFFFFFFFFu ? 1u : 0u;
-            if (sz) {
-                ++nfound;
-                H += sz;
-                if (H <= kLaneHits) {
-                    if (sz == 1) L[n++] = pay;
-                    else for (uint32_t t = 0; t < sz; ++t) L[n++] = tab.values[pay + t];
+            if (busy[u]) {
+                ++nsteps;
+                const uint32_t keys[4] = {r[u].k.x, r[u].k.y, r[u].k.z, r[u].k.w};
+                const uint32_t s01 = r[u].sz.x, s23 = r[u].sz.y;
+                const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
+                const uint64_t pl[4] = {((uint64_t)r[u].p0.y << 32) | r[u].p0.x, ((uint64_t)r[u].p0.w << 32) | r[u].p0.z,
+                                        ((uint64_t)r[u].p1.y << 32) | r[u].p1.x, ((uint64_t)r[u].p1.w << 32) | r[u].p1.z};
+                uint32_t size = 0; uint64_t pay = 0;
+                bool anyFree = false;
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    anyFree = anyFree || sz[i] == 0;
+                    if (sz[i] != 0 && keys[i] == f[u]) { size = sz[i]; pay = pl[i]; }
+                }
+                if (size) {
+                    ++nfound;
+                    H += size;
+                    if (H <= kLaneHits) {
+                        if (size == 1) L[n++] = pay;
+                        else for (uint32_t t = 0; t < size; ++t) L[n++] = tab.values[pay + t];
+                    }
+                    busy[u] = false;
+                } else if (anyFree || step[u] >= tab.maxProbe) {
+                    busy[u] = false;                               // a bucket with a free slot ends the chain
+                } else {
+                    cur[u] = next_bucket(home[u], cur[u], step[u], tab.nbuckets);
+                    ++step[u];
+                    r[u] = load_bucket(tab, cur[u]);               // stays pending; resolved in the next iteration
                 }
             }
         }
