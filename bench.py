@@ -74,9 +74,9 @@ def synth_reads_gpu(gcat: torch.Tensor, goff: torch.Tensor, glen: int, n: int, s
 def measured_traffic(kernel_timer_name: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
     workload (profiles/*_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes).
-    gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE tallies every 128-byte line request as 64 B, so
-    it is doubled (calibrated on this kernel: probe steps x 128 B = 2 x FETCH_SIZE).
-    None if no summary is committed."""
+    gfx950 caveat of MI355X_MICROARCH.md (FETCH_SIZE tallies every request at 64 B) calibrated for this
+    kernel's access pattern in profiles/r01_fetch_calibration.md: probe_cands reads 64-byte buckets = 64-byte
+    sector requests, which are counted at their true size, so no doubling here.  None if no summary exists."""
     import csv, glob
     names = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",),
              "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",)}[kernel_timer_name]
@@ -87,7 +87,7 @@ def measured_traffic(kernel_timer_name: str):
                 vals.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
         for k in names:
             if k in vals and len(vals[k]) == 2:
-                return (2.0 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
+                return (vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
     return None, None
 
 
