@@ -68,7 +68,8 @@ typedef struct {
     uint32_t max_candidates;         /* K: output stride per query; '-maxcand 0' => caller passes a cap */
     /* table loading */
     uint32_t target_id_bytes;        /* 2 or 4: width of target_id in mc_load_batch values (config.hpp:56-62) */
-    uint32_t num_parts;              /* database parts to be loaded (1 for now) */
+    uint32_t num_parts;              /* database parts to be loaded (1..255; > 1: every part must be announced with
+                                        mc_load_begin before the first mc_load_batch; target ids < 2^24) */
     uint32_t max_locations_per_feature; /* load-time truncation to the first n values (host_hashmap.hpp:454-466); 0 = keep */
     uint32_t remove_overpopulated;   /* load-time: empty buckets with more than n values (host_hashmap.hpp:480-495); 0 = off */
     float    max_load_factor;        /* hash table load factor (-max-load-fac, mode_query.cpp:49-55); 0 = default 0.5 */

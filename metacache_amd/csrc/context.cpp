@@ -108,7 +108,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (cfg->winlen < cfg->kmerlen || cfg->winlen > kMaxWinLen) return fail(nullptr, MC_ERR_UNSUPPORTED, "winlen must be kmerlen..1024");
     if (cfg->winstride < 1) return fail(nullptr, MC_ERR_INVALID, "winstride must be >= 1");
     if (cfg->target_id_bytes != 2 && cfg->target_id_bytes != 4) return fail(nullptr, MC_ERR_INVALID, "target_id_bytes must be 2 or 4");
-    if (cfg->num_parts != 1) return fail(nullptr, MC_ERR_UNSUPPORTED, "exactly one database part per context for now");
+    if (cfg->num_parts < 1 || cfg->num_parts > 255) return fail(nullptr, MC_ERR_UNSUPPORTED, "num_parts must be 1..255");
     if (cfg->max_candidates < 1) return fail(nullptr, MC_ERR_INVALID, "max_candidates must be >= 1");
 
     int ndev = 0;
@@ -172,22 +172,37 @@ void mc_destroy(mc_ctx* ctx)
 // ------------------------------------------------------------------------------------------------
 // table loading
 // ------------------------------------------------------------------------------------------------
+// All parts of a database share ONE device table (state kept in parts[0]): a feature that occurs in several
+// parts gets the concatenation of its per-part buckets, with the part number folded into the target id
+// ((part << 24) | target), so that sorting by the stored key yields "per-part sorted lists concatenated in
+// part order" -- the intended result of host_hashmap.hpp:695-723 -- with a single lookup per feature.
+static int allocate_table(mc_ctx* ctx)
+{
+    Part& T = ctx->parts[0];
+    uint64_t nkeys = 0, nvalues = 0;
+    for (auto& p : ctx->parts) { nkeys += p.expectKeys; nvalues += p.expectValues; }
+    uint64_t nb = (uint64_t)((double)nkeys / (kSlotsPerBucket * (double)ctx->loadFactor)) + 2;
+    nb += nb & 1;                                            // two buckets per line
+    if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
+    T.nbuckets = (uint32_t)nb;
+    T.hbuckets.assign((size_t)nb, TableBucket{});
+    if (ctx->parts.size() == 1) {
+        T.dvaluesCap = nvalues + 1;
+        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, T.dvaluesCap * sizeof(uint64_t)));
+    }
+    return MC_OK;
+}
+
 int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues)
 {
     if (!ctx) return MC_ERR_INVALID;
     if (part >= ctx->parts.size()) return fail(ctx, MC_ERR_INVALID, "mc_load_begin: part out of range");
     Part& P = ctx->parts[part];
-    if (P.loading || P.ready) return fail(ctx, MC_ERR_STATE, "mc_load_begin: part already loaded");
+    if (P.announced) return fail(ctx, MC_ERR_STATE, "mc_load_begin: part already announced");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint64_t nb = (uint64_t)((double)nkeys / (kSlotsPerBucket * (double)ctx->loadFactor)) + 2;
-    nb += nb & 1;                                            // two buckets per line
-    if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
-    P.nbuckets = (uint32_t)nb;
     P.expectKeys = nkeys; P.expectValues = nvalues;
-    P.hbuckets.assign((size_t)nb, TableBucket{});
-    P.dvaluesCap = nvalues + 1;
-    HIP_TRY(ctx, hipMalloc((void**)&P.dvalues, P.dvaluesCap * sizeof(uint64_t)));
-    P.loading = true;
+    P.announced = true; P.loading = true;
+    if (ctx->parts.size() == 1) return allocate_table(ctx);
     return MC_OK;
 }
 
@@ -196,17 +211,28 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
     if (!ctx) return MC_ERR_INVALID;
     if (part >= ctx->parts.size() || !ctx->parts[part].loading) return fail(ctx, MC_ERR_STATE, "mc_load_batch: call mc_load_begin first");
     Part& P = ctx->parts[part];
+    Part& T = ctx->parts[0];
+    const bool multi = ctx->parts.size() > 1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (multi && T.hbuckets.empty()) {
+        for (auto& q : ctx->parts)
+            if (!q.announced) return fail(ctx, MC_ERR_STATE, "multi-part load: call mc_load_begin for EVERY part before the first mc_load_batch");
+        int rc = allocate_table(ctx);
+        if (rc) return rc;
+    }
     const uint32_t tb = ctx->cfg.target_id_bytes, vb = 4 + tb;
     const uint32_t maxLocs = ctx->cfg.max_locations_per_feature;
     const uint32_t rmOver = ctx->cfg.remove_overpopulated;
     const uint8_t* vp = static_cast<const uint8_t*>(values);
-    std::vector<uint64_t> stage;
-    stage.reserve(n * 2);
+    std::vector<uint64_t> stage;                               // single part: values of this batch, uploaded below
+    std::vector<uint64_t>& store = multi ? ctx->hvalues : stage;
+    const uint64_t storeBase = multi ? 0 : T.valuesStored;
+    bool badTarget = false;
     auto decode = [&](const uint8_t* p) -> uint64_t {
         uint32_t win; std::memcpy(&win, p, 4);
         uint32_t tgt = 0;
         if (tb == 2) { uint16_t t; std::memcpy(&t, p + 4, 2); tgt = t; } else std::memcpy(&tgt, p + 4, 4);
+        if (multi) { badTarget = badTarget || tgt >= (1u << 24); tgt |= part << 24; }
         return ((uint64_t)tgt << 32) | win;
     };
     if (P.keysLoaded + n > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
@@ -216,36 +242,58 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
         if (rmOver && size > rmOver) size = 0;                 // bucket emptied, key kept without values = never matches
         if (maxLocs && size > maxLocs) size = maxLocs;         // keep the FIRST n values
         if (size > 0) {
-            // place the key: first group along the chain with a free slot
+            // walk the key's probe sequence: an earlier part may already hold the key; otherwise it goes into
+            // the first bucket with a free slot
             const uint32_t key = keys[i];
-            const uint32_t home = (uint32_t)(((uint64_t)mix32(key) * P.nbuckets) >> 32);
+            const uint32_t home = (uint32_t)(((uint64_t)mix32(key) * T.nbuckets) >> 32);
             uint32_t cur = home, probe = 1;
             TableBucket* grp = nullptr;
-            uint32_t slot = 0;
+            uint32_t slot = kSlotsPerBucket;
+            bool found = false;
             for (;; ++probe) {
-                grp = &P.hbuckets[cur];
-                for (slot = 0; slot < kSlotsPerBucket && grp->size[slot]; ++slot) {}
-                if (slot < kSlotsPerBucket) break;
-                if (probe > P.nbuckets) return fail(ctx, MC_ERR_NOMEM, "hash table full");
-                cur = next_bucket(home, cur, probe, P.nbuckets);
+                grp = &T.hbuckets[cur];
+                uint32_t freeSlot = kSlotsPerBucket;
+                for (uint32_t j = 0; j < kSlotsPerBucket; ++j) {
+                    if (!grp->size[j]) { if (freeSlot == kSlotsPerBucket) freeSlot = j; }
+                    else if (multi && grp->key[j] == key) { slot = j; found = true; break; }
+                }
+                if (found) break;
+                if (freeSlot < kSlotsPerBucket) { slot = freeSlot; break; }
+                if (probe > T.nbuckets) return fail(ctx, MC_ERR_NOMEM, "hash table full");
+                cur = next_bucket(home, cur, probe, T.nbuckets);
             }
-            if (probe > P.maxProbe) P.maxProbe = probe;
-            grp->key[slot] = key;
-            grp->size[slot] = (uint16_t)size;
-            if (size == 1) grp->payload[slot] = decode(vp);
-            else {
-                grp->payload[slot] = P.valuesStored + stage.size();
-                for (uint32_t t = 0; t < size; ++t) stage.push_back(decode(vp + (size_t)t * vb));
+            if (probe > T.maxProbe) T.maxProbe = probe;
+            if (!found) {
+                grp->key[slot] = key;
+                grp->size[slot] = (uint16_t)size;
+                if (size == 1) grp->payload[slot] = decode(vp);
+                else {
+                    grp->payload[slot] = storeBase + store.size();
+                    for (uint32_t t = 0; t < size; ++t) store.push_back(decode(vp + (size_t)t * vb));
+                }
+            } else {
+                // same feature in an earlier part: new bucket = old locations followed by this part's
+                const uint32_t s0 = grp->size[slot];
+                if (s0 + size > 0xFFFFu) return fail(ctx, MC_ERR_UNSUPPORTED, "merged bucket exceeds 65535 locations");
+                const uint64_t p0 = grp->payload[slot];
+                const uint64_t off = store.size();
+                if (s0 == 1) store.push_back(p0);
+                else for (uint32_t t = 0; t < s0; ++t) { const uint64_t v = store[p0 + t]; store.push_back(v); }
+                for (uint32_t t = 0; t < size; ++t) store.push_back(decode(vp + (size_t)t * vb));
+                grp->size[slot] = (uint16_t)(s0 + size);
+                grp->payload[slot] = off;
+                T.keysStored--;                                   // counted again below
             }
             P.locations += size;
-            P.keysStored++;
+            T.keysStored++;
         }
         vp += (size_t)fileSize * vb;
     }
-    if (!stage.empty()) {
-        if (P.valuesStored + stage.size() > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
-        HIP_TRY(ctx, hipMemcpy(P.dvalues + P.valuesStored, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
-        P.valuesStored += stage.size();
+    if (badTarget) return fail(ctx, MC_ERR_UNSUPPORTED, "multi-part databases need target ids < 2^24");
+    if (!multi && !stage.empty()) {
+        if (T.valuesStored + stage.size() > T.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
+        HIP_TRY(ctx, hipMemcpy(T.dvalues + T.valuesStored, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
+        T.valuesStored += stage.size();
     }
     P.keysLoaded += n;
     return MC_OK;
@@ -256,12 +304,24 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
     if (!ctx) return MC_ERR_INVALID;
     if (part >= ctx->parts.size() || !ctx->parts[part].loading) return fail(ctx, MC_ERR_STATE, "mc_load_end: nothing being loaded");
     Part& P = ctx->parts[part];
+    Part& T = ctx->parts[0];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = P.hbuckets.size() * sizeof(TableBucket);
-    HIP_TRY(ctx, hipMalloc((void**)&P.dbuckets, bytes));
-    HIP_TRY(ctx, hipMemcpy(P.dbuckets, P.hbuckets.data(), bytes, hipMemcpyHostToDevice));
-    std::vector<TableBucket>().swap(P.hbuckets);
     P.loading = false; P.ready = true;
+    for (auto& q : ctx->parts) if (!q.ready) return MC_OK;     // the table goes to the device when the last part is in
+    if (T.hbuckets.empty()) { int rc = allocate_table(ctx); if (rc) return rc; }
+    if (ctx->parts.size() > 1) {
+        T.dvaluesCap = ctx->hvalues.size() + 1;
+        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, T.dvaluesCap * sizeof(uint64_t)));
+        if (!ctx->hvalues.empty())
+            HIP_TRY(ctx, hipMemcpy(T.dvalues, ctx->hvalues.data(), ctx->hvalues.size() * 8, hipMemcpyHostToDevice));
+        T.valuesStored = ctx->hvalues.size();
+        std::vector<uint64_t>().swap(ctx->hvalues);
+    }
+    const size_t bytes = T.hbuckets.size() * sizeof(TableBucket);
+    HIP_TRY(ctx, hipMalloc((void**)&T.dbuckets, bytes));
+    HIP_TRY(ctx, hipMemcpy(T.dbuckets, T.hbuckets.data(), bytes, hipMemcpyHostToDevice));
+    std::vector<TableBucket>().swap(T.hbuckets);
+    ctx->tableReady = true;
     return MC_OK;
 }
 
@@ -318,7 +378,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     const int wantAllhits = flags & MC_WANT_ALLHITS;
     const bool wantFeatures = (flags & MC_WANT_FEATURES) != 0;
     if (!ctx || !in || !out) return MC_ERR_INVALID;
-    if (ctx->parts.empty() || !ctx->parts[0].ready) return fail(ctx, MC_ERR_STATE, "no database loaded");
+    if (!ctx->tableReady) return fail(ctx, MC_ERR_STATE, "no database loaded (every part needs mc_load_begin .. mc_load_end)");
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
@@ -357,7 +417,8 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
     const Part& P = ctx->parts[0];
-    DeviceTable tab{P.dbuckets, P.dvalues, P.nbuckets, P.maxProbe};
+    const bool multiPart = ctx->parts.size() > 1;
+    DeviceTable tab{P.dbuckets, P.dvalues, P.nbuckets, multiPart ? 0x00FFFFFFu : 0xFFFFFFFFu, P.maxProbe};
 
     {
         ScopedTimer t(ctx, "plan", st);

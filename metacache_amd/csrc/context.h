@@ -25,7 +25,7 @@ struct Part {
     uint64_t locations = 0;         // all locations kept (incl. inline singletons)
     uint64_t keysStored = 0;
     uint32_t nbuckets = 0, maxProbe = 1;
-    bool loading = false, ready = false;
+    bool loading = false, ready = false, announced = false;
     TableBucket* dbuckets = nullptr;
     uint64_t* dvalues = nullptr;
     uint64_t dvaluesCap = 0;
@@ -69,7 +69,9 @@ struct mc_ctx {
     mcamd::SketchParams targetSketch{};    // the database's own (window stride feeds maxWindowsInRange)
     uint64_t maxLocs = 254, targetCount = 0;
     std::vector<mcamd::Part> parts;
-    float loadFactor = 0.8f;
+    float loadFactor = 0.5f;
+    bool tableReady = false;
+    std::vector<uint64_t> hvalues;          // multi-part load: all location lists on the host until the last part is in
 
     // taxonomy / lineages (host) + per-rank taxon keys (device)
     std::vector<mcamd::Taxon> taxa;

@@ -92,14 +92,23 @@ void make_lineages(const Meta& m, std::vector<uint32_t>& lin)
     }
 }
 
+struct PartHeader { uint64_t nkeys = 0, nvalues = 0, batch = 0; };
+
+int read_part_header(mc_ctx* ctx, const std::string& fname, PartHeader& h)
+{
+    File f(fname);
+    if (!f.f) { ctx->err = "Could not read database file '" + fname + "'"; return MC_ERR_IO; }
+    if (!f.rd(&h.nkeys, 8) || !f.rd(&h.nvalues, 8) || !f.rd(&h.batch, 8)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+    return MC_OK;
+}
+
 int load_part(mc_ctx* ctx, uint32_t part, const std::string& fname, uint32_t targetBytes)
 {
     File f(fname);
     if (!f.f) { ctx->err = "Could not read database file '" + fname + "'"; return MC_ERR_IO; }
     uint64_t nkeys = 0, nvalues = 0, batch = 0;
     if (!f.rd(&nkeys, 8) || !f.rd(&nvalues, 8) || !f.rd(&batch, 8)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
-    int rc = mc_load_begin(ctx, part, nkeys, nvalues);
-    if (rc) return rc;
+    int rc;
     const size_t vb = 4 + targetBytes;
     std::vector<uint32_t> keys(std::min<uint64_t>(batch, nkeys));
     std::vector<uint8_t> sizes(keys.size());
@@ -135,8 +144,8 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     if (!cfg.winlen) cfg.winlen = m.w;
     if (!cfg.winstride) cfg.winstride = m.stride;
     cfg.target_id_bytes = m.targetBytes;
-    if (m.numParts != 1) { set_global_error("databases with more than one part are not supported yet"); return MC_ERR_UNSUPPORTED; }
-    cfg.num_parts = 1;
+    if (m.numParts < 1 || m.numParts > 255) { set_global_error("unsupported number of database parts"); return MC_ERR_UNSUPPORTED; }
+    cfg.num_parts = m.numParts;
     mc_ctx* ctx = nullptr;
     if ((rc = mc_create(&cfg, &ctx))) return rc;
     ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
@@ -144,12 +153,18 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
     ctx->taxa = std::move(m.taxa);
     m.taxa.clear();
-    for (uint32_t p = 0; p < cfg.num_parts; ++p) {
-        if ((rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(p), m.targetBytes))) {
-            set_global_error(ctx->err);
-            mc_destroy(ctx);
-            return rc;
-        }
+    // every part is announced first (the merged table is sized for all of them), then loaded in part order
+    for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
+        PartHeader h;
+        rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(p), h);
+        if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
+    }
+    for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
+        rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(p), m.targetBytes);
+    if (rc) {
+        set_global_error(ctx->err);
+        mc_destroy(ctx);
+        return rc;
     }
     Meta tmp{}; tmp.targetCount = ctx->targetCount; tmp.taxa = ctx->taxa;
     std::vector<uint32_t> lin;

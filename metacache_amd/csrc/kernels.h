@@ -54,6 +54,7 @@ struct DeviceTable {
     const TableBucket* buckets; // [nbuckets], nbuckets even
     const uint64_t*  values;  // location lists, (tgt << 32) | win, each bucket sorted ascending
     uint32_t nbuckets;
+    uint32_t tgtMask;         // multi-part tables store (part << 24 | target) as target: mask to get the real id
     uint32_t maxProbe;        // longest probe sequence (in groups) needed by any stored key
 };
 

@@ -414,7 +414,7 @@ __device__ __forceinline__ void emit_empty(mc_candidate_dev* out, uint32_t from,
 template <bool LDS>
 __device__ __forceinline__ void candidates_from_sorted(
     const uint64_t* buf, uint64_t* C, uint64_t* C2, const uint32_t H, const uint32_t maxWin, const uint32_t K,
-    const uint32_t* __restrict__ taxkey, mc_candidate_dev* out, uint32_t lane)
+    const uint32_t* __restrict__ taxkey, const uint32_t tgtMask, mc_candidate_dev* out, uint32_t lane)
 {
     // ---- row 9: one candidate per maximal run of equal tgt
     uint32_t ncand = 0;
@@ -471,7 +471,7 @@ __device__ __forceinline__ void candidates_from_sorted(
                 const uint64_t ck = C[j];
                 const uint32_t besti = (uint32_t)(ck & 0xFFFFFu);
                 const uint32_t tgt = (uint32_t)(buf[besti] >> 32);
-                const uint32_t tax = taxkey[tgt];                         // 0 = no taxon -> dropped (:187)
+                const uint32_t tax = taxkey[tgt & tgtMask];               // 0 = no taxon -> dropped (:187)
                 const uint32_t hits = (uint32_t)(ck >> 40);
                 C2[j] = tax ? (((uint64_t)tax << 40) | ((uint64_t)((~hits) & 0xFFFFFu) << 20) | j) : ~0ull;
             }
@@ -512,7 +512,7 @@ __device__ __forceinline__ void candidates_from_sorted(
             const uint64_t key = buf[besti];
             const uint32_t fst = range_first(buf, besti, key, maxWin);
             mc_candidate_dev e;
-            e.tgt = (uint32_t)(key >> 32);
+            e.tgt = (uint32_t)(key >> 32) & tgtMask;
             e.hits = (uint32_t)(x >> 40);
             e.beg = (uint32_t)buf[fst];
             e.end = (uint32_t)key;
@@ -569,15 +569,18 @@ __device__ __forceinline__ void sort_candidates_one(
     const uint64_t hoff = ws.hitOff[q];
     const uint32_t fbeg = ws.winOff[q] * sp.s;
     const uint32_t nf = (ws.winOff[q + 1] - ws.winOff[q]) * sp.s;
+    const uint64_t m64 = ((uint64_t)tab.tgtMask << 32) | 0xFFFFFFFFull;   // multi-part tables: strip the part number from targets
     // two instantiations so that the LDS flavour compiles to ds_* instructions
     if (H <= kLdsCap) {
         gather_and_sort<true>(L.buf, ws, tab, fbeg, nf, H, lane);
         if (wantAllhits)
-            for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = L.buf[i];
-        candidates_from_sorted<true>(L.buf, L.c, L.c2, H, maxWin, K, taxkey, out, lane);
+            for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = L.buf[i] & m64;
+        candidates_from_sorted<true>(L.buf, L.c, L.c2, H, maxWin, K, taxkey, tab.tgtMask, out, lane);
     } else {
         gather_and_sort<false>(ws.hits + hoff, ws, tab, fbeg, nf, H, lane);
-        candidates_from_sorted<false>(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, out, lane);
+        candidates_from_sorted<false>(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, tab.tgtMask, out, lane);
+        if (wantAllhits && tab.tgtMask != 0xFFFFFFFFu)
+            for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] &= m64;
     }
 }
 
@@ -804,7 +807,7 @@ __device__ __forceinline__ void fused_candidates(FusedLds& L, uint32_t size, uin
         const uint32_t wl = __ffsll((unsigned long long)__ballot(winner)) - 1;
         const uint32_t wt = rdlane(tgt, wl);
         if (winner) {
-            mc_candidate_dev e; e.tgt = tgt; e.hits = hits; e.beg = beg; e.end = win;
+            mc_candidate_dev e; e.tgt = tgt & tab.tgtMask; e.hits = hits; e.beg = beg; e.end = win;
             out[nout] = e;
         }
         ckey = tgt == wt ? 0ull : ckey;                          // one candidate per target
@@ -1198,7 +1201,10 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
     mc_candidate_dev* out = cands + (size_t)q * K;
 #pragma unroll
     for (uint32_t i = 0; i < kLaneK; ++i)
-        if (i < K) { mc_candidate_dev e; e.tgt = top[i].tgt; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end; out[i] = e; }
+        if (i < K) {
+            mc_candidate_dev e; e.tgt = top[i].hits ? (top[i].tgt & tab.tgtMask) : 0xFFFFFFFFu; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end;
+            out[i] = e;
+        }
     ws.qflag[q] = kFlagDone;
 }
 

@@ -186,3 +186,28 @@ def test_many_reads_random_db_lane_and_wave_paths_against_oracle(tmp_path):
             assert np.array_equal(cands[f], exp[f]), (env, f)
         used = exp["hits"] > 0
         assert np.array_equal(cands["tgt"][used], exp["tgt"][used]), env
+
+
+@pytest.mark.parametrize("lowest,K", [(0, 2), (4, 3)])
+def test_two_part_database_intended_semantics(golden, lowest, K):
+    """Database written by the reference with -parts 2: all parts live in ONE device table, results are the
+    intended 'per-part sorted lists concatenated in part order' (oracle mode 1; the in-process reference
+    itself is history dependent for P > 1)."""
+    single, p1, p2 = golden.reads()
+    odb = cpuref.oracle().open(golden.db_path("toy32p2"))
+    for allhits_flag in (1, 0):
+        db = api.Database.open(golden.db_path("toy32p2"), max_candidates=K, copy_allhits=allhits_flag)
+        assert db.n_parts == 2 and db.n_locations == odb.n_locations
+        cands, counts, allhits = db.query(single, lowest=lowest)
+        for i, s in enumerate(single):
+            h, c = odb.query(s, b"", K, lowest, 0, mode=1)
+            assert counts[i] == len(h), i
+            if allhits_flag:
+                assert np.array_equal(allhits[i]["win"], h["win"]) and np.array_equal(allhits[i]["tgt"], h["tgt"]), i
+            assert cands_equal(cands[i], c), (i, cands[i], c)
+        cands, counts, allhits = db.query(p1, p2, lowest=lowest)
+        for i, (a, b) in enumerate(zip(p1, p2)):
+            h, c = odb.query(a, b, K, lowest, 0, mode=1)
+            assert cands_equal(cands[i], c), i
+        db.close()
+    odb.close()
