@@ -395,8 +395,8 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     const size_t nfeat = (size_t)maxWindows * sp.s;
     if ((rc = ensure(ctx, ctx->bWinCount, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bWinOff, (size_t)(n + 2) * 4))) return rc;
-    // the lane path delivers top candidates only: -allhits, taxon merging and K > 4 go through the wave kernels
-    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAllhits && lowestRank <= 0 && lane_candidates_supported(K);
+    // the lane path delivers top candidates only: -allhits and K > 4 go through the wave kernels
+    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAllhits && lane_candidates_supported(K);
     if ((wantFeatures || lanePath) && (rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bPsize, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bPpay, nfeat * 8))) return rc;
@@ -429,7 +429,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
         { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
-        { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, ctx->bCands.p, st); }
+        { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }

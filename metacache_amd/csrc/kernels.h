@@ -115,8 +115,8 @@ void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Worksp
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
-void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, void* cands,
-                        hipStream_t st);
+void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                        const uint32_t* taxkey, void* cands, hipStream_t st);
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS

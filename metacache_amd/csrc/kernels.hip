@@ -1071,7 +1071,7 @@ constexpr uint32_t kLaneU = 4;                                // lookups in flig
 constexpr uint32_t kLaneBlock = 128;
 
 __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
-                                                                 mc_candidate_dev* __restrict__ cands)
+                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
@@ -1169,15 +1169,50 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
     }
     // rows 9-10, sequentially as on the CPU (candidate_generation.hpp:47-108, :172-201)
     LaneCand top[kLaneK];
+    uint32_t toptax[kLaneK];                                      // taxon of each entry (taxon merging only)
 #pragma unroll
-    for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; }
+    for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
     const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
     auto insert = [&](LaneCand c) {
-        // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
+        uint32_t ctax = 0;
         bool moving = false;
+        if (taxkey) {
+            // candidate_generation.hpp:178-216: full list and not better than its last entry -> ignored;
+            // no taxon -> skipped; taxon already listed -> replaced only by more hits, then moved up behind
+            // the entries with >= hits (std::sort on <= 16 elements = insertion sort)
+            uint32_t lastHits = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
+            if (lastHits > 0 && lastHits >= c.hits) return;
+            ctax = taxkey[c.tgt & tab.tgtMask];
+            if (ctax == 0) return;
+            bool found = false;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) {
+                if (i < K && !found && top[i].hits > 0 && toptax[i] == ctax) {
+                    found = true;
+                    if (c.hits > top[i].hits) {
+                        top[i] = c;
+#pragma unroll
+                        for (uint32_t j = kLaneK - 1; j > 0; --j) {       // bubble up while strictly more hits
+                            if (j <= i && top[j].hits > top[j - 1].hits) {
+                                const LaneCand t = top[j]; top[j] = top[j - 1]; top[j - 1] = t;
+                                const uint32_t tt = toptax[j]; toptax[j] = toptax[j - 1]; toptax[j - 1] = tt;
+                            }
+                        }
+                    }
+                }
+            }
+            if (found) return;
+        }
+        // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
 #pragma unroll
         for (uint32_t i = 0; i < kLaneK; ++i) {
-            if (i < K && (moving || c.hits > top[i].hits)) { const LaneCand t = top[i]; top[i] = c; c = t; moving = true; }
+            if (i < K && (moving || c.hits > top[i].hits)) {
+                const LaneCand t = top[i]; top[i] = c; c = t;
+                const uint32_t tt = toptax[i]; toptax[i] = ctax; ctax = tt;
+                moving = true;
+            }
         }
     };
     if (n > 0) {
@@ -1213,12 +1248,12 @@ void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Worksp
     if (b.n == 0) return;
     hipLaunchKernelGGL(sketch_lane_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, ws.winOff, ws.features, ws.qflag);
 }
-void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, void* cands,
-                        hipStream_t st)
+void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                        const uint32_t* taxkey, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
     hipLaunchKernelGGL(probe_cands_kernel, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
-                       (mc_candidate_dev*)cands);
+                       taxkey, (mc_candidate_dev*)cands);
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }
