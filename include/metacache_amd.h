@@ -78,6 +78,8 @@ typedef struct {
     uint32_t slot_max_queries;
     uint32_t slot_max_chars;
     uint32_t copy_allhits;           /* 1: sorted location lists are copied back too (-allhits) */
+    int32_t  single_part;            /* mc_open_database: -1 = load every part; p >= 0 = only <name>.cache<p>, as one part
+                                        (database::read singlePartId, database.cpp:196-205) -- one part per GPU */
 } mc_config;
 
 void mc_config_default(mc_config* cfg);

@@ -25,7 +25,7 @@ class McConfig(C.Structure):
                 ("winstride", C.c_uint32), ("max_candidates", C.c_uint32), ("target_id_bytes", C.c_uint32),
                 ("num_parts", C.c_uint32), ("max_locations_per_feature", C.c_uint32), ("remove_overpopulated", C.c_uint32),
                 ("max_load_factor", C.c_float), ("num_slots", C.c_uint32), ("slot_max_queries", C.c_uint32),
-                ("slot_max_chars", C.c_uint32), ("copy_allhits", C.c_uint32)]
+                ("slot_max_chars", C.c_uint32), ("copy_allhits", C.c_uint32), ("single_part", C.c_int32)]
 
 
 class McResults(C.Structure):

@@ -95,6 +95,7 @@ void mc_config_default(mc_config* c)
     c->slot_max_queries = 1u << 16;
     c->slot_max_chars = 1u << 24;
     c->copy_allhits = 0;
+    c->single_part = -1;
 }
 
 const char* mc_last_error(const mc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }

@@ -146,6 +146,11 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     cfg.target_id_bytes = m.targetBytes;
     if (m.numParts < 1 || m.numParts > 255) { set_global_error("unsupported number of database parts"); return MC_ERR_UNSUPPORTED; }
     cfg.num_parts = m.numParts;
+    uint32_t firstPart = 0;
+    if (cfg.single_part >= 0) {
+        if ((uint32_t)cfg.single_part >= m.numParts) { set_global_error("database part is not available"); return MC_ERR_INVALID; }
+        firstPart = (uint32_t)cfg.single_part; cfg.num_parts = 1;
+    }
     mc_ctx* ctx = nullptr;
     if ((rc = mc_create(&cfg, &ctx))) return rc;
     ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
@@ -156,11 +161,11 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     // every part is announced first (the merged table is sized for all of them), then loaded in part order
     for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
         PartHeader h;
-        rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(p), h);
+        rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(firstPart + p), h);
         if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
     }
     for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
-        rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(p), m.targetBytes);
+        rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
     if (rc) {
         set_global_error(ctx->err);
         mc_destroy(ctx);

@@ -50,3 +50,38 @@ def classify_sharded(num_queries: int, classify_fn, dst: int = 0, group=None):
         return local
     parts = gather_candidates(local, dst=dst, group=group)
     return torch.cat(parts, dim=0) if parts is not None else None
+
+
+# ------------------------------------------------------------------------------------------------------
+# Mode P: a partitioned database, ONE PART PER GPU (mc_config.single_part = rank).
+# Every rank runs the hot path on the same batch of reads against its own part; a read's final top-K
+# list is the stable merge, by hits descending, of the per-part top-K lists taken in part order --
+# exactly what feeding the parts' candidates one after the other into the reference's sorted insert
+# (candidate_generation.hpp:193-201) gives at sequence level.  Communication: one all-gather of
+# [n, K, 4] int32 per batch (RCCL over xGMI); nothing else of the path crosses GPUs.
+# ------------------------------------------------------------------------------------------------------
+def merge_part_candidates(per_part: list[torch.Tensor]) -> torch.Tensor:
+    """per_part[p]: int32 [n, K, 4] = (tgt, hits, beg, end) of part p, unused entries hits == 0.
+    Returns the merged [n, K, 4]."""
+    K = per_part[0].shape[1]
+    allc = torch.cat(per_part, dim=1)                                     # [n, P*K, 4] in part order
+    hits = allc[:, :, 1].to(torch.int64)
+    order = torch.sort(hits, dim=1, descending=True, stable=True).indices[:, :K]
+    out = torch.gather(allc, 1, order[:, :, None].expand(-1, -1, 4))
+    empty = out[:, :, 1] == 0
+    out = out.clone()
+    out[:, :, 0][empty] = -1                                              # unused entries: tgt = 0xFFFFFFFF
+    out[:, :, 2][empty] = 0
+    out[:, :, 3][empty] = 0
+    return out
+
+
+def classify_partitioned(local: torch.Tensor, group=None) -> torch.Tensor:
+    """local: this rank's (= this part's) candidates [n, K, 4] for the WHOLE batch.  Every rank returns the
+    merged result (all-gather)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    bufs = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(bufs, local.contiguous(), group=group)
+    return merge_part_candidates(bufs)

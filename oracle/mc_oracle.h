@@ -19,6 +19,7 @@ int64_t mco_sketch(const char* seq, uint64_t len, uint32_t k, uint32_t s, uint32
 
 /* row 11-13: database files */
 void* mco_db_open(const char* name);
+void* mco_db_open_part(const char* name, int part);
 void  mco_db_close(void* db);
 void  mco_db_info(void* db, uint64_t* info8);
 int   mco_db_target_id_bytes(void* db);

@@ -92,6 +92,15 @@ class CpuRef:
             raise RuntimeError(f"cannot open database {name}")
         return CpuDb(self, h)
 
+    def open_part(self, name: str, part: int) -> "CpuDb":
+        assert self.is_oracle
+        self.lib.mco_db_open_part.restype = C.c_void_p
+        self.lib.mco_db_open_part.argtypes = [C.c_char_p, C.c_int]
+        h = self.lib.mco_db_open_part(name.encode(), part)
+        if not h:
+            raise RuntimeError(f"cannot open part {part} of {name}")
+        return CpuDb(self, h)
+
     def candidates(self, locs_u64: np.ndarray, max_win: int, max_cand: int, taxkey: np.ndarray | None = None,
                    merge: bool = False) -> np.ndarray:
         assert self.is_oracle

@@ -80,3 +80,57 @@ def test_two_ranks_gloo_gather_matches_single_process(golden):
             else:
                 assert got[i, j, 1] == 0
     db.close()
+
+
+def _worker_parts(rank, world, port, n, K, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import cpuref
+    from metacache_amd.distributed import classify_partitioned
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gold = os.path.join(here, "golden")
+    z = np.load(os.path.join(gold, "toy_reads.npz"))
+    off = z["single_off"]
+    reads = [z["single"][int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+    db = cpuref.oracle().open_part(os.path.join(gold, "toy32p2"), rank)          # this rank's part only
+    local = torch.zeros((n, K, 4), dtype=torch.int32)
+    for i, r in enumerate(reads):
+        _, c = db.query(r, b"", K, 0, 0)
+        for j in range(len(c)):
+            local[i, j] = torch.tensor([int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], dtype=torch.int64).to(torch.int32)
+        for j in range(len(c), K):
+            local[i, j, 0] = -1
+    merged = classify_partitioned(local)
+    if rank == 0:
+        q.put(merged.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mode_p_one_part_per_rank_matches_intended_multipart(golden):
+    """Mode P: rank r holds part r of the 2-part reference DB; merged per-part top-K == the oracle's intended
+    multi-part result on the whole database."""
+    import cpuref
+    n, K, world = 300, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_parts, args=(r, world, port, n, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, _, _ = golden.reads()
+    db = cpuref.oracle().open(golden.db_path("toy32p2"))
+    for i in range(n):
+        _, c = db.query(single[i], b"", K, 0, 0, mode=1)
+        for j in range(K):
+            if j < len(c):
+                assert [int(x) for x in got[i, j].view(np.uint32)] == [int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], (i, j)
+            else:
+                assert got[i, j, 1] == 0
+    db.close()

@@ -211,3 +211,26 @@ def test_two_part_database_intended_semantics(golden, lowest, K):
             assert cands_equal(cands[i], c), i
         db.close()
     odb.close()
+
+
+def test_mode_p_single_parts_merge_equals_whole_database(golden):
+    """one part per context (what one GPU holds in Mode P) + merge_part_candidates == all parts in one context"""
+    import torch
+    from metacache_amd.distributed import merge_part_candidates
+    single, _, _ = golden.reads()
+    reads = single[:700]
+    K = 2
+    whole = api.Database.open(golden.db_path("toy32p2"), max_candidates=K)
+    cw, _, _ = whole.query(reads)
+    whole.close()
+    per_part = []
+    for p in range(2):
+        db = api.Database.open(golden.db_path("toy32p2"), max_candidates=K, single_part=p)
+        assert db.n_parts == 1
+        c, _, _ = db.query(reads)
+        db.close()
+        t = np.stack([c["tgt"], c["hits"], c["beg"], c["end"]], axis=-1).astype(np.uint32).view(np.int32)
+        per_part.append(torch.from_numpy(t.copy()))
+    merged = merge_part_candidates(per_part).numpy().view(np.uint32)
+    for f, j in (("tgt", 0), ("hits", 1), ("beg", 2), ("end", 3)):
+        assert np.array_equal(merged[:, :, j], cw[f]), f
