@@ -124,6 +124,10 @@ int mc_db_lineages(const mc_ctx* ctx, const uint32_t** lin, uint64_t* num_target
  * (query_batch.cuh:212-259); caller code database_query.hpp:87-124 */
 int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* seq1, uint32_t len1, const char* seq2, uint32_t len2,
                  uint32_t max_windows_in_range);
+/* many single-end queries at once: read i = seqs[offsets[i] .. offsets[i+1]); maxWindowsInRange is derived per read
+ * from the database's window stride (candidate_structs.hpp:143-145) and insert_size_max.  Returns the number of reads
+ * added (< n when the slot is full: submit, wait, clear, continue with the rest) or a negative error. */
+int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const uint64_t* offsets, uint64_t n, uint64_t insert_size_max);
 int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowest_rank);
 
 typedef struct {

@@ -45,7 +45,7 @@ class McDeviceResults(C.Structure):
 
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end",
            "mc_open_database", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_lineages",
-           "mc_batch_add", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
+           "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
            "mc_build_begin", "mc_build_add_target", "mc_build_finish", "mc_build_write", "mc_build_free", "mc_build_last_error",
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
                                   C.POINTER(C.c_char_p)]
         L.mc_db_lineages.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.mc_batch_add.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32]
+        L.mc_batch_add_bulk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.mc_batch_add_bulk.restype = C.c_int64
         L.mc_batch_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.mc_batch_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(McResults)]
         L.mc_batch_clear.argtypes = [C.c_void_p, C.c_uint32]
@@ -224,6 +226,28 @@ class Database:
                     raise McError("query does not fit an empty slot")
         flush(n)
         return cands, counts, allhits
+
+    def query_bulk(self, seqs: np.ndarray, offs: np.ndarray, lowest: int = 0, insert_max: int = 0, slot: int = 0) -> np.ndarray:
+        """single-end reads given as one byte array + offsets; host slot path (H2D of the characters, D2H of the
+        candidates) -> cands[n, K]"""
+        L = lib()
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8); offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        K = self.cfg.max_candidates
+        out = np.zeros((n, K), dtype=cand_dtype)
+        done = 0
+        while done < n:
+            added = L.mc_batch_add_bulk(self.h, slot, seqs.ctypes.data_as(C.c_void_p), offs[done:].ctypes.data_as(C.c_void_p), n - done, insert_max)
+            self._check(added)
+            if added == 0:
+                raise McError("query does not fit an empty slot")
+            self._check(L.mc_batch_submit(self.h, slot, lowest))
+            res = McResults()
+            self._check(L.mc_batch_wait(self.h, slot, C.byref(res)))
+            out[done:done + added] = _view(res.cands, added * K, cand_dtype).reshape(added, K)
+            self._check(L.mc_batch_clear(self.h, slot))
+            done += added
+        return out
 
     # ---- device path (pointers are device addresses, e.g. torch tensors' data_ptr()) ----------
     def query_device(self, seq_ptr: int, qinfo_ptr: int, n: int, num_chars: int, max_win_ptr: int = 0, max_win_uniform: int = 0,

@@ -539,6 +539,22 @@ int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* s1, uint32_t l1, const 
     return MC_OK;
 }
 
+int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const uint64_t* offs, uint64_t n, uint64_t insertMax)
+{
+    if (!ctx || slot >= ctx->slots.size() || !seqs || !offs) return MC_ERR_INVALID;
+    const uint64_t stride = ctx->targetSketch.stride ? ctx->targetSketch.stride : 1;
+    uint64_t i = 0;
+    for (; i < n; ++i) {
+        const uint64_t len = offs[i + 1] - offs[i];
+        if (len >= 0xFFFFFFF0ull) return fail(ctx, MC_ERR_INVALID, "sequence too long");
+        const uint32_t maxWin = (uint32_t)(2 + std::max<uint64_t>(len, insertMax) / stride);
+        const int rc = mc_batch_add(ctx, slot, seqs + offs[i], (uint32_t)len, nullptr, 0, maxWin);
+        if (rc == MC_BATCH_FULL) break;
+        if (rc < 0) return rc;
+    }
+    return (int64_t)i;
+}
+
 int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
 {
     if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
