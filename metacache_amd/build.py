@@ -1,6 +1,7 @@
 """Builds the in-tree native libraries.
 
     libmetacache_amd.so   the product: HIP kernels (gfx950) + C-ABI host code   [hipcc]
+    bin/mcq               `metacache query` command line above the C ABI         [g++]
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container and on the GPU box.
 """
@@ -19,6 +20,8 @@ LIB = os.path.join(LIBDIR, "libmetacache_amd.so")
 SOURCES = ["kernels.hip", "context.cpp", "dbfile.cpp", "builder.hip"]
 HEADERS = ["kernels.h", "context.h", os.path.join(ROOT, "include", "metacache_amd.h")]
 ARCH = "gfx950"
+BINDIR = os.path.join(PKG, "bin")
+MCQ = os.path.join(BINDIR, "mcq")
 
 
 def _hipcc() -> str:
@@ -60,7 +63,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_cli(force=force, verbose=verbose)
     return LIB
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """mcq: plain host C++14 linked against the C ABI only (rpath to the in-tree library)."""
+    os.makedirs(BINDIR, exist_ok=True)
+    src = os.path.join(CSRC, "mcq_main.cpp")
+    if force or _stale(MCQ, [src, LIB, os.path.join(ROOT, "include", "metacache_amd.h")]):
+        cmd = ["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", MCQ,
+               "-L", LIBDIR, "-lmetacache_amd", "-Wl,-rpath,$ORIGIN/../lib", "-pthread"]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return MCQ
 
 
 if __name__ == "__main__":

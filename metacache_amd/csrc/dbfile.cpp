@@ -146,6 +146,8 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     cfg.target_id_bytes = m.targetBytes;
     if (m.numParts < 1 || m.numParts > 255) { set_global_error("unsupported number of database parts"); return MC_ERR_UNSUPPORTED; }
     cfg.num_parts = m.numParts;
+    // read_database (mode_query.cpp:69-76): the removal limit never exceeds (the DB's own bucket cap - 1)
+    if (cfg.remove_overpopulated && m.maxLocs > 1) cfg.remove_overpopulated = std::min<uint32_t>(cfg.remove_overpopulated, (uint32_t)m.maxLocs - 1);
     uint32_t firstPart = 0;
     if (cfg.single_part >= 0) {
         if ((uint32_t)cfg.single_part >= m.numParts) { set_global_error("database part is not available"); return MC_ERR_INVALID; }

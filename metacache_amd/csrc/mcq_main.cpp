@@ -1,0 +1,458 @@
+// mcq -- `metacache query` on MI355X: the reference's query command line for the per-read mapping output
+// (SURVEY.md §8f rank 2), host C++ above the C ABI.  Mirrors, for the supported options,
+//   option handling      options.cpp:860-1430 (query subset), querying.cpp:225-269 (adapt_options_to_database)
+//   read ingest          sequence_io.cpp (FASTA / FASTQ, -pairfiles / -pairseq), database_query.hpp:258-284
+//   classification       classification.cpp:146-189 (classify: ranked-LCA vote over the top candidates)
+//   output lines         classification.cpp:470-526 (show_query_mapping), printing.cpp:160-365
+// Not offered (later rows): -precision/-ground-truth, -hits-per-ref, -abundances, -align, gzip input, summary block.
+//
+//   mcq query <database> <reads.fa|fq>... [-out file] [-lowest rank] [-highest rank] [-hitmin n] [-hitdiff f]
+//       [-maxcand n] [-tophits] [-allhits] [-queryids] [-mapped-only] [-no-map] [-taxids] [-taxids-only] [-omit-ranks]
+//       [-separate-cols] [-separator s] [-lineage] [-pairfiles | -pairseq] [-insertsize n] [-sketchlen s] [-winlen w]
+//       [-winstride l] [-max-locations-per-feature n] [-remove-overpopulated-features] [-max-load-fac f]
+//       [-no-query-params] [-no-summary] [-threads n (accepted, ignored)] [-batch-size n]
+#include "metacache_amd.h"
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr int kNumRanks = MC_NUM_RANKS;      // 21, index 21 = none
+const char* const kRankNames[] = {"sequence", "form", "variety", "subspecies", "species", "subgenus", "genus", "subtribe", "tribe",
+                                  "subfamily", "family", "suborder", "order", "subclass", "class", "subphylum", "phylum",
+                                  "subkingdom", "kingdom", "domain", "root", "none"};
+
+int rank_from_name(std::string n)                    // taxonomy.hpp:174-214
+{
+    std::transform(n.begin(), n.end(), n.begin(), ::tolower);
+    for (int i = 0; i <= kNumRanks; ++i) if (n == kRankNames[i]) return i;
+    if (n == "genome") return 0;
+    return -1;
+}
+
+struct Taxon { int64_t id = 0, parent = 0; int rank = kNumRanks; std::string name; };
+using Lineage = std::array<uint32_t, kNumRanks>;     // taxon index + 1, 0 = none
+
+struct Taxonomy {
+    std::vector<Taxon> taxa;
+    std::unordered_map<int64_t, uint32_t> byId;
+    const uint32_t* targetLineages = nullptr;        // [targets * 21]
+    uint64_t numTargets = 0;
+
+    const Taxon* taxon(uint32_t idxPlus1) const { return idxPlus1 ? &taxa[idxPlus1 - 1] : nullptr; }
+    Lineage target_ranks(uint32_t tgt) const
+    {
+        Lineage l{};
+        if (tgt < numTargets) std::copy(targetLineages + (size_t)tgt * kNumRanks, targetLineages + (size_t)(tgt + 1) * kNumRanks, l.begin());
+        return l;
+    }
+    // taxonomy::make_ranks (taxonomy.hpp:576-597)
+    Lineage ranks_of(uint32_t idxPlus1) const
+    {
+        Lineage l{};
+        const Taxon* t = taxon(idxPlus1);
+        if (!t) return l;
+        if (t->rank < kNumRanks) l[t->rank] = idxPlus1;
+        int64_t id = t->parent;
+        while (id != 0) {
+            auto it = byId.find(id);
+            if (it == byId.end()) break;
+            const Taxon& p = taxa[it->second];
+            if (p.rank < kNumRanks) l[p.rank] = it->second + 1;
+            if (p.parent == id) break;
+            id = p.parent;
+        }
+        return l;
+    }
+};
+
+struct Options {
+    std::string db, outfile;
+    std::vector<std::string> infiles;
+    int lowest = 0, highest = 19;                    // sequence .. domain (options.hpp:246-260)
+    int hitsMin = 0; float hitsDiff = 1.0f;
+    uint64_t maxCand = 2, insertMax = 0;
+    enum Pairing { unpaired, files, sequences } pairing = unpaired;
+    bool tophits = false, allhits = false, queryIds = false, lineage = false, separateCols = false;
+    bool showName = true, showRank = true, showId = false;
+    enum MapView { mv_none, mv_mapped, mv_all } mapView = mv_all;
+    bool collapseUnclassified = true;
+    std::string comment = "# ", none = "--", column = "\t|\t", taxSep = ",", rankSuffix = ":", idPrefix = "(", idSuffix = ")";
+    bool showQueryParams = true, showSummary = true;
+    uint32_t sketchlen = 0, winlen = 0, winstride = 0, batchSize = 1u << 16;
+    int maxLocs = -1, threads = 0;
+    bool removeOverpopulated = false; float maxLoadFac = 0;
+};
+
+std::string sanitize_special_chars(const std::string& s)   // cmdline_utility: "\t" etc. typed literally
+{
+    std::string r;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (s[i] == '\\' && i + 1 < s.size()) {
+            const char c = s[i + 1];
+            if (c == 't') { r += '\t'; ++i; continue; }
+            if (c == 'n') { r += '\n'; ++i; continue; }
+        }
+        r += s[i];
+    }
+    return r;
+}
+
+Options parse(int argc, char** argv)
+{
+    Options o;
+    if (argc < 4 || std::string(argv[1]) != "query") throw std::runtime_error("usage: mcq query <database> <sequence files>... [options]");
+    o.db = argv[2];
+    auto need = [&](int& i) -> std::string { if (i + 1 >= argc) throw std::runtime_error(std::string("value missing after '") + argv[i] + "'"); return argv[++i]; };
+    for (int i = 3; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a.empty()) continue;
+        if (a[0] != '-') { o.infiles.push_back(a); continue; }
+        if (a == "-out") o.outfile = need(i);
+        else if (a == "-lowest") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); o.lowest = r; }
+        else if (a == "-highest") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); o.highest = r; }
+        else if (a == "-hitmin" || a == "-hit-min" || a == "-hits-min" || a == "-hitsmin") o.hitsMin = std::stoi(need(i));
+        else if (a == "-hitdiff" || a == "-hit-diff" || a == "-hitsdiff" || a == "-hits-diff") o.hitsDiff = std::stof(need(i));
+        else if (a == "-maxcand" || a == "-max-cand") o.maxCand = std::stoull(need(i));
+        else if (a == "-tophits" || a == "-top-hits") o.tophits = true;
+        else if (a == "-allhits" || a == "-all-hits") o.allhits = true;
+        else if (a == "-queryids" || a == "-query-ids") o.queryIds = true;
+        else if (a == "-mapped-only" || a == "-mappedonly") o.mapView = Options::mv_mapped;
+        else if (a == "-no-map" || a == "-nomap") o.mapView = Options::mv_none;
+        else if (a == "-taxids" || a == "-taxid") o.showId = true;
+        else if (a == "-taxids-only" || a == "-taxidsonly") { o.showId = true; o.showName = false; }
+        else if (a == "-omit-ranks" || a == "-omitranks") o.showRank = false;
+        else if (a == "-separate-cols" || a == "-separatecols") o.separateCols = true;
+        else if (a == "-separator") o.column = sanitize_special_chars(need(i));
+        else if (a == "-lineage" || a == "-lineages") o.lineage = true;
+        else if (a == "-pairfiles" || a == "-pair-files" || a == "-paired-files") o.pairing = Options::files;
+        else if (a == "-pairseq" || a == "-pair-seq" || a == "-paired-seq") o.pairing = Options::sequences;
+        else if (a == "-insertsize" || a == "-insert-size") o.insertMax = std::stoull(need(i));
+        else if (a == "-sketchlen") o.sketchlen = (uint32_t)std::stoul(need(i));
+        else if (a == "-winlen") o.winlen = (uint32_t)std::stoul(need(i));
+        else if (a == "-winstride") o.winstride = (uint32_t)std::stoul(need(i));
+        else if (a == "-max-locations-per-feature") o.maxLocs = std::stoi(need(i));
+        else if (a == "-remove-overpopulated-features") o.removeOverpopulated = true;
+        else if (a == "-max-load-fac" || a == "-max-load-factor") o.maxLoadFac = std::stof(need(i));
+        else if (a == "-no-query-params" || a == "-no-queryparams") o.showQueryParams = false;
+        else if (a == "-no-summary" || a == "-nosummary") o.showSummary = false;
+        else if (a == "-threads") o.threads = std::stoi(need(i));
+        else if (a == "-batch-size" || a == "-batchsize") o.batchSize = (uint32_t)std::stoul(need(i));
+        else throw std::runtime_error("unknown option '" + a + "'");
+    }
+    // process_query_options (options.cpp:1297-1366)
+    if (o.pairing == Options::files) { if (o.infiles.size() > 1) std::sort(o.infiles.begin(), o.infiles.end()); else o.pairing = Options::unpaired; }
+    if (o.hitsDiff > 1) o.hitsDiff *= 0.01;       // double factor, as options.cpp:1312
+    if (o.lowest > o.highest) o.lowest = o.highest;
+    if (o.separateCols) { o.collapseUnclassified = false; o.taxSep = o.column; o.rankSuffix = o.column; o.idPrefix = o.column; o.idSuffix = ""; }
+    if (o.mapView == Options::mv_none && o.tophits) o.mapView = Options::mv_mapped;
+    else if (o.allhits) o.mapView = Options::mv_all;
+    return o;
+}
+
+// ---- sequence files (uncompressed FASTA / FASTQ) --------------------------------------------------------------------
+struct Record { std::string header, seq; };
+
+// sequence_reader::read_next (sequence_io.cpp:160-228): a record starts at a line beginning with '>' or '@' (other lines
+// are skipped), sequence lines run up to the next line beginning with '>' or '+'; after a '+' line one quality line follows.
+class Reader {
+public:
+    explicit Reader(const std::string& fn) : is_(fn)
+    {
+        if (!is_.good()) throw std::runtime_error("file '" + fn + "' could not be opened");
+        advance();
+    }
+    bool has_next()
+    {
+        while (have_ && (line_.empty() || (line_[0] != '>' && line_[0] != '@'))) advance();
+        return have_;
+    }
+    bool next(Record& r)
+    {
+        r.header.clear(); r.seq.clear();
+        if (!has_next()) return false;
+        r.header = line_.substr(1);
+        for (advance(); have_ && (line_.empty() || (line_[0] != '>' && line_[0] != '+')); advance()) r.seq += line_;
+        if (have_ && line_[0] == '+') { advance(); advance(); }      // '+' line, quality line
+        return true;
+    }
+private:
+    void advance()
+    {
+        have_ = bool(std::getline(is_, line_));
+        if (!have_) line_.clear();
+        while (!line_.empty() && (line_.back() == '\r' || line_.back() == '\n')) line_.pop_back();
+    }
+    std::ifstream is_;
+    std::string line_;
+    bool have_ = false;
+};
+
+struct Query { uint64_t id; std::string header, seq1, seq2; };
+
+// ---- output (printing.cpp:160-365) ----------------------------------------------------------------------------------
+void print_taxon(std::ostream& os, const Options& o, const std::string& name, int64_t id, int rank)
+{
+    if (o.showRank) os << (rank == kNumRanks ? o.none : std::string(kRankNames[rank])) << o.rankSuffix;
+    if (o.showName) { os << name; if (o.showId) os << o.idPrefix << id << o.idSuffix; }
+    else if (o.showId) os << id;
+}
+
+void show_lineage(std::ostream& os, const Options& o, const Taxonomy& tx, const Lineage& lin, int lowest, int highest)
+{
+    if (lowest == kNumRanks) return;
+    if (highest == kNumRanks) highest = kNumRanks - 1;
+    for (int r = lowest; r <= highest; ++r) {
+        const Taxon* t = tx.taxon(lin[r]);
+        if (t) print_taxon(os, o, t->name, t->id, t->rank); else print_taxon(os, o, o.none, 0, r);
+        if (r < highest) os << o.taxSep;
+    }
+}
+
+void show_taxon(std::ostream& os, const Options& o, const Taxonomy& tx, uint32_t best /* idx+1 */, bool bestIsTarget, uint32_t bestTgt)
+{
+    const Taxon* t = tx.taxon(best);
+    if (!t || t->rank > o.highest) {
+        if (o.collapseUnclassified) {
+            if (o.showId && !o.showName && !o.showRank) os << 0; else os << o.none;
+        } else {
+            const int rmax = o.lineage ? o.highest : o.lowest;
+            for (int r = o.lowest; r <= rmax; ++r) { print_taxon(os, o, o.none, 0, kNumRanks); if (r < rmax) os << o.taxSep; }
+        }
+    } else {
+        const int rmin = o.lowest < t->rank ? t->rank : o.lowest;
+        const int rmax = o.lineage ? o.highest : rmin;
+        const Lineage lin = bestIsTarget ? tx.target_ranks(bestTgt) : tx.ranks_of(best);
+        show_lineage(os, o, tx, lin, rmin, rmax);
+    }
+}
+
+struct Cand { uint32_t tgt, hits, beg, end; uint32_t tax; /* idx+1 */ };
+
+void show_candidates(std::ostream& os, const Options& o, const Taxonomy& tx, const std::vector<Cand>& c)
+{
+    for (size_t i = 0; i < c.size() && c[i].hits > 0; ++i) {
+        if (i > 0) os << ',';
+        const Taxon* t = tx.taxon(c[i].tax);
+        if (o.lowest == 0) { if (t) os << t->name << ':' << c[i].hits; }
+        else {
+            const Taxon* a = t;
+            if (t && t->rank < o.lowest) a = tx.taxon(tx.target_ranks(c[i].tgt)[o.lowest]);
+            if (a) os << a->id; else os << t->name;
+            os << ':' << c[i].hits;
+        }
+    }
+}
+
+void show_matches(std::ostream& os, const Options& o, const Taxonomy& tx, const mc_location* hits, uint64_t n)
+{
+    if (n == 0) return;
+    auto emit = [&](const mc_location& cur, int count) {
+        const Lineage lin = tx.target_ranks(cur.tgt);
+        if (o.lowest == 0) { const Taxon* t = tx.taxon(lin[0]); if (t) os << t->name << '/' << int(cur.win) << ':' << count << ','; }
+        else { const Taxon* t = tx.taxon(lin[o.lowest]); if (!t) t = tx.taxon(lin[0]); os << t->name << ':' << count << ','; }
+    };
+    uint64_t cur = 0; int count = 1;
+    for (uint64_t i = 1; i < n; ++i) {
+        if (hits[cur].tgt == hits[i].tgt && hits[cur].win == hits[i].win) ++count;
+        else { emit(hits[cur], count); cur = i; count = 1; }
+    }
+    emit(hits[cur], count);
+}
+
+// classification.cpp:146-189
+uint32_t classify(const Options& o, const Taxonomy& tx, const std::vector<Cand>& cand, bool& isTarget, uint32_t& tgt)
+{
+    isTarget = false; tgt = 0;
+    if (cand.empty() || cand[0].hits == 0 || !cand[0].tax) return 0;
+    if (cand[0].hits < (uint32_t)o.hitsMin) return 0;
+    uint32_t lca = cand[0].tax;
+    const float threshold = cand[0].hits > (uint32_t)o.hitsMin ? (cand[0].hits - o.hitsMin) * o.hitsDiff : 0;
+    const Lineage top = tx.target_ranks(cand[0].tgt);
+    for (size_t i = 1; i < cand.size() && cand[i].hits > 0; ++i) {
+        if (cand[i].hits > threshold) {
+            const Lineage cr = tx.target_ranks(cand[i].tgt);
+            const int from = tx.taxon(lca)->rank;
+            uint32_t l = 0;
+            for (int r = from; r <= kNumRanks - 1; ++r) if (top[r] && top[r] == cr[r]) { l = top[r]; break; }   // ranked_lca
+            lca = l;
+            if (!lca || tx.taxon(lca)->rank > o.highest) return 0;
+        } else break;
+    }
+    if (!lca || tx.taxon(lca)->rank > o.highest) return 0;
+    if (lca == cand[0].tax && tx.taxon(lca)->rank == 0) { isTarget = true; tgt = cand[0].tgt; }
+    return lca;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    try {
+        Options o = parse(argc, argv);
+        if (o.infiles.empty()) throw std::runtime_error("no sequence files given");
+
+        mc_config cfg; mc_config_default(&cfg);
+        cfg.kmerlen = 0; cfg.sketchlen = o.sketchlen; cfg.winlen = o.winlen; cfg.winstride = o.winstride;
+        const bool unlimited = o.maxCand < 1;
+        cfg.max_candidates = unlimited ? 256 : (uint32_t)std::min<uint64_t>(o.maxCand, 4096);
+        cfg.copy_allhits = o.allhits ? 1 : 0;
+        cfg.slot_max_queries = o.batchSize;
+        cfg.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
+        cfg.max_load_factor = o.maxLoadFac;
+        if (o.removeOverpopulated) {                                            // read_database, mode_query.cpp:69-92
+            int maxlpf = o.maxLocs - 1;
+            if (maxlpf < 0 || maxlpf >= 254) maxlpf = 253;
+            cfg.remove_overpopulated = (uint32_t)maxlpf;                           // clamped to the DB's cap - 1 by mc_open_database
+            cfg.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
+        } else if (o.maxLocs > 1) cfg.max_locations_per_feature = (uint32_t)o.maxLocs;
+        mc_ctx* ctx = nullptr;
+        if (mc_open_database(o.db.c_str(), &cfg, &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+        uint64_t info[8]; mc_db_info(ctx, info);
+        const uint32_t dbStride = (uint32_t)info[3], dbSketch = (uint32_t)info[1];
+        if (o.hitsMin < 1) o.hitsMin = dbSketch >= 6 ? int(dbSketch / 3.0) : (dbSketch >= 4 ? 2 : 1);        // querying.cpp:257-268
+
+        Taxonomy tx;
+        { uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
+          for (uint64_t i = 0; i < nt; ++i) { uint32_t rk; const char* nm; mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm); tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm; tx.byId.emplace(tx.taxa[i].id, (uint32_t)i); }
+          mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets); }
+
+        std::ofstream fout;
+        if (!o.outfile.empty()) { fout.open(o.outfile); if (!fout.good()) throw std::runtime_error("could not write to file " + o.outfile); }
+        std::ostream& os = o.outfile.empty() ? std::cout : fout;
+
+        if (o.showQueryParams) {                                                 // printing.cpp:47-131
+            if (o.mapView != Options::mv_none) {
+                os << o.comment << "Reporting per-read mappings (non-mapping lines start with '" << o.comment << "').\n";
+                os << o.comment << (o.lineage ? "The complete lineage will be reported starting with the lowest match.\n" : "Only the lowest matching rank will be reported.\n");
+            } else os << o.comment << "Per-Read mappings will not be shown.\n";
+            os << o.comment << "Classification will be constrained to ranks from '" << kRankNames[o.lowest] << "' to '" << kRankNames[o.highest] << "'.\n";
+            os << o.comment << "Classification hit threshold is " << o.hitsMin << " per query\n";
+            os << o.comment << "At maximum " << (unlimited ? std::numeric_limits<size_t>::max() : o.maxCand) << " classification candidates will be considered per query.\n";
+            if (o.pairing == Options::files) os << o.comment << "File based paired-end mode:\n" << o.comment << "  Reads from two consecutive files will be interleaved.\n" << o.comment << "  Max insert size considered " << o.insertMax << ".\n";
+            else if (o.pairing == Options::sequences) os << o.comment << "Per file paired-end mode:\n" << o.comment << "  Reads from two consecutive sequences in each file will be paired up.\n" << o.comment << "  Max insert size considered " << o.insertMax << ".\n";
+            os << o.comment << "Using " << (o.threads > 0 ? o.threads : 1) << " threads\n";
+        }
+        if (o.mapView != Options::mv_none) {                                     // show_query_mapping_header, classification.cpp:432-460
+            os << o.comment << "TABLE_LAYOUT: ";
+            if (o.queryIds) os << "query_id" << o.column;
+            os << "query_header" << o.column;
+            if (o.allhits) os << "all_hits" << o.column;
+            if (o.tophits) os << "top_hits" << o.column;
+            const int rmax = o.lineage ? o.highest : o.lowest;
+            auto hdr = [&](int r, bool named) {
+                if (o.showRank) os << (named ? kRankNames[r] : "rank") << o.rankSuffix;
+                if (o.showName) { os << "taxname"; if (o.showId) os << o.idPrefix << "taxid" << o.idSuffix; } else if (o.showId) os << "taxid";
+            };
+            if (o.lowest == rmax) hdr(o.lowest, false);
+            else for (int r = o.lowest; r <= rmax; ++r) { hdr(r, true); if (r < rmax) os << o.taxSep; }
+            os << '\n';
+        }
+
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t idOffset = 0;
+        uint64_t assigned[kNumRanks + 1] = {};                                   // classification_statistics::assign
+        std::vector<Query> batch;
+        auto flush = [&]() {
+            if (batch.empty()) return;
+            if (mc_batch_submit(ctx, 0, o.lowest) != MC_OK) throw std::runtime_error(mc_last_error(ctx));
+            mc_results r;
+            if (mc_batch_wait(ctx, 0, &r) != MC_OK) throw std::runtime_error(mc_last_error(ctx));
+            for (uint32_t i = 0; i < r.num_queries; ++i) {
+                std::vector<Cand> cands;
+                for (uint32_t j = 0; j < r.max_candidates; ++j) {
+                    const mc_candidate& c = r.cands[(size_t)i * r.max_candidates + j];
+                    if (c.hits == 0) break;
+                    Cand x{c.tgt, c.hits, c.beg, c.end, 0};
+                    const Lineage lin = tx.target_ranks(c.tgt);
+                    if (o.lowest > 0) { for (int rk = o.lowest; rk < kNumRanks; ++rk) if (lin[rk]) { x.tax = lin[rk]; break; } }   // lowest_ranked_ancestor
+                    else x.tax = lin[0];
+                    cands.push_back(x);
+                }
+                const Query& q = batch[i];
+                if (q.header.empty() || q.seq1.empty()) continue;                 // processQuery, classification.cpp:780
+                bool isTarget; uint32_t tgt;
+                const uint32_t best = classify(o, tx, cands, isTarget, tgt);
+                ++assigned[best ? tx.taxon(best)->rank : kNumRanks];
+                if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) continue;
+                if (o.queryIds) os << q.id << o.column;
+                const auto sp = q.header.find(' ');
+                os << (sp == std::string::npos ? q.header : q.header.substr(0, sp)) << o.column;
+                if (o.allhits) { show_matches(os, o, tx, r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i]); os << o.column; }
+                if (o.tophits) { show_candidates(os, o, tx, cands); os << o.column; }
+                show_taxon(os, o, tx, best, isTarget, tgt);
+                os << '\n';
+            }
+            mc_batch_clear(ctx, 0);
+            batch.clear();
+        };
+        auto add = [&](Query&& q) {
+            const uint32_t maxWin = (uint32_t)(2 + std::max<uint64_t>(q.seq1.size() + q.seq2.size(), o.insertMax) / dbStride);
+            int rc = mc_batch_add(ctx, 0, q.seq1.data(), (uint32_t)q.seq1.size(), q.seq2.data(), (uint32_t)q.seq2.size(), maxWin);
+            if (rc == MC_BATCH_FULL) { flush(); rc = mc_batch_add(ctx, 0, q.seq1.data(), (uint32_t)q.seq1.size(), q.seq2.data(), (uint32_t)q.seq2.size(), maxWin); }
+            if (rc == MC_BATCH_FULL) { std::cerr << "query batch is too small for a single read!\n"; return; }
+            if (rc < 0) throw std::runtime_error(mc_last_error(ctx));
+            batch.push_back(std::move(q));
+        };
+
+        const size_t stride = o.pairing == Options::files ? 2 : 1;
+        for (size_t fi = 0; fi < o.infiles.size(); fi += stride) {
+            if (o.pairing == Options::files && fi + 1 >= o.infiles.size()) break;
+            flush();
+            os << o.comment << o.infiles[fi];                                   // appendToOutput, classification.cpp:825-827
+            if (o.pairing == Options::files) os << " + " << o.infiles[fi + 1];
+            os << '\n';
+            Reader r1(o.infiles[fi]);
+            Record a, b;
+            if (o.pairing == Options::files) {
+                Reader r2(o.infiles[fi + 1]);
+                while (r1.has_next() && r2.has_next()) { r1.next(a); r2.next(b); add(Query{++idOffset, a.header, a.seq, b.seq}); }
+            } else if (o.pairing == Options::sequences) {
+                while (r1.has_next()) { r1.next(a); b.seq.clear(); if (r1.has_next()) r1.next(b); add(Query{++idOffset, a.header, a.seq, b.seq}); }
+            } else {
+                while (r1.next(a)) add(Query{++idOffset, a.header, a.seq, ""});
+            }
+        }
+        flush();
+        if (o.showSummary) {                                                     // show_summary, printing.cpp:601-620
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            uint64_t nassigned = 0;
+            for (int r = 0; r < kNumRanks; ++r) nassigned += assigned[r];
+            const uint64_t unassigned = assigned[kNumRanks], total = nassigned + unassigned;
+            const uint64_t nq = o.pairing == Options::unpaired ? total : 2 * total;
+            os << o.comment << "queries: " << nq << '\n' << o.comment << "time:    " << (long long)(s * 1000) << " ms\n"
+               << o.comment << "speed:   " << nq / (s / 60.0) << " queries/min\n";
+            if (total > 0) {                                                     // show_taxon_statistics, printing.cpp:502-535
+                if (nassigned < 1) os << "None of the input sequences could be classified.\n";
+                else {
+                    if (unassigned > 0) os << o.comment << "unclassified: " << (100 * (unassigned / double(total))) << "% (" << unassigned << ")\n";
+                    os << o.comment << "classified:\n";
+                    const int shown[] = {0, 3, 4, 6, 10, 12, 14, 16, 18, 19, 20};
+                    for (int r : shown) {
+                        uint64_t upto = 0;
+                        for (int x = 0; x <= r; ++x) upto += assigned[x];
+                        if (upto > 0) { std::string rn = kRankNames[r]; rn.resize(11, ' '); os << o.comment << "  " << rn << (100 * (upto / double(total))) << "% (" << upto << ")\n"; }
+                    }
+                }
+            } else std::cerr << o.comment << "No valid query sequences found.\n";
+        }
+        mc_destroy(ctx);
+    } catch (std::exception& e) {
+        std::cerr << "ABORT: " << e.what() << "!" << std::endl;                  // main.cpp:65-68
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Golden vectors for the command line: read files + the reference CLI's own output for them.
+
+Runs only in the build container (needs oracle/_ref/metacache_u32 = the reference compiled from
+/root/reference by `make -C oracle ref`, and the toy32 database written by make_golden.py).  Writes data only:
+
+  cli_reads.fa                  400 single-end reads (multi-line FASTA, headers with descriptions, edge cases)
+  cli_pairs.fq                  120 pairs, interleaved FASTQ (for -pairseq)
+  cli_p1.fa / cli_p2.fa         the same pairs as two FASTA files (for -pairfiles)
+  cli_expected.json.gz           {case: {"args": [...], "files": [...], "lines": [...]}}: the complete output file the
+                                reference's `metacache query toy32 <files> <args> -threads 1` wrote (-out)
+
+Usage:  python tests/golden/make_golden_cli.py
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "metacache_u32")
+
+# name -> (input files, options)
+CASES = {
+    "default": (["cli_reads.fa"], []),
+    "everything_species": (["cli_reads.fa"], ["-queryids", "-tophits", "-allhits", "-lineage", "-taxids", "-lowest", "species"]),
+    "allhits_sequence": (["cli_reads.fa"], ["-allhits", "-tophits", "-maxcand", "3"]),
+    "genus_family_idsonly": (["cli_reads.fa"], ["-lowest", "genus", "-highest", "family", "-taxids-only", "-omit-ranks"]),
+    "separate_cols": (["cli_reads.fa"], ["-separate-cols", "-lineage", "-lowest", "species", "-highest", "order", "-taxids"]),
+    "mapped_only_vote": (["cli_reads.fa"], ["-mapped-only", "-hitmin", "5", "-hitdiff", "0.5", "-maxcand", "4", "-tophits"]),
+    "hitdiff_percent": (["cli_reads.fa"], ["-hitdiff", "80", "-maxcand", "3", "-lowest", "species", "-tophits", "-queryids"]),
+    "maxcand_unlimited": (["cli_reads.fa"], ["-maxcand", "0", "-tophits", "-lowest", "subspecies"]),
+    "separator": (["cli_reads.fa"], ["-separator", ";", "-taxids", "-lineage", "-highest", "genus"]),
+    "pairseq": (["cli_pairs.fq"], ["-pairseq", "-tophits", "-queryids"]),
+    "pairseq_insert": (["cli_pairs.fq"], ["-pairseq", "-insertsize", "700", "-tophits", "-lowest", "species"]),
+    "pairfiles": (["cli_p2.fa", "cli_p1.fa"], ["-pairfiles", "-tophits", "-allhits", "-queryids"]),
+    "two_files": (["cli_reads.fa", "cli_pairs.fq"], ["-queryids", "-taxids"]),
+    "sketch_params": (["cli_reads.fa"], ["-sketchlen", "12", "-winlen", "100", "-winstride", "80", "-tophits"]),
+    "max_locations": (["cli_reads.fa"], ["-max-locations-per-feature", "4", "-tophits"]),
+    "remove_overpopulated": (["cli_reads.fa"], ["-remove-overpopulated-features", "-max-locations-per-feature", "20", "-tophits"]),
+}
+
+
+def wrap(seq: bytes, width: int) -> str:
+    s = seq.decode()
+    return "\n".join(s[i:i + width] for i in range(0, len(s), width)) if s else ""
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref missing: run `make -C oracle ref` first")
+    z = np.load(os.path.join(HERE, "toy_reads.npz"))
+
+    def unpack(b, o):
+        return [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
+    single, p1, p2 = unpack(z["single"], z["single_off"]), unpack(z["p1"], z["p1_off"]), unpack(z["p2"], z["p2_off"])
+    pick = list(range(0, 240)) + list(range(1500, 1640)) + list(range(1640, 1660))     # sampled, random, edge cases, long
+    with open(os.path.join(HERE, "cli_reads.fa"), "w") as f:
+        for n, i in enumerate(pick):
+            hdr = f"read{n:04d}" if n % 3 else f"read{n:04d} source=toy idx={i}"
+            f.write(f">{hdr}\n")
+            body = wrap(single[i], 60 if n % 2 else 100000)
+            if body:
+                f.write(body + "\n")
+            if n % 50 == 7:
+                f.write("\n")                                                           # blank lines are skipped
+    with open(os.path.join(HERE, "cli_pairs.fq"), "w") as f:
+        for n in range(120):
+            for m, s in ((1, p1[n]), (2, p2[n])):
+                f.write(f"@pair{n:03d}/{m} len={len(s)}\n{s.decode()}\n+\n{'I' * len(s)}\n")
+    for name, mates in (("cli_p1.fa", p1), ("cli_p2.fa", p2)):
+        with open(os.path.join(HERE, name), "w") as f:
+            for n in range(120):
+                f.write(f">pair{n:03d}\n{mates[n].decode()}\n")
+
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (files, args) in CASES.items():
+            res = os.path.join(tmp, name + ".txt")
+            cmd = [REF, "query", "toy32"] + files + args + ["-threads", "1", "-out", res]
+            print("+", " ".join(cmd))
+            subprocess.check_call(cmd, cwd=HERE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(res) as f:
+                out[name] = {"files": files, "args": args, "lines": f.read().split("\n")}
+    with gzip.open(os.path.join(HERE, "cli_expected.json.gz"), "wt") as f:
+        json.dump(out, f)
+    print("wrote", len(out), "cases")
+
+
+if __name__ == "__main__":
+    main()

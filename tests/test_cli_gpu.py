@@ -1,0 +1,68 @@
+"""`mcq query` (metacache_amd/csrc/mcq_main.cpp) against the output files the reference's own command line wrote for the
+same read files and options (tests/golden/cli_expected.json.gz, made by tests/golden/make_golden_cli.py from
+oracle/_ref/metacache_u32).  Every line must be identical except the two wall-clock lines of the summary."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+from metacache_amd import build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _cases():
+    with gzip.open(os.path.join(GOLD, "cli_expected.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+CASES = _cases()
+
+
+def _volatile(line: str) -> bool:
+    return line.startswith("# time:") or line.startswith("# speed:")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_cli_matches_reference_output(case, tmp_path):
+    build.build_library()
+    c = CASES[case]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-threads", "1", "-out", str(out)]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = out.read_text().split("\n")
+    exp = c["lines"]
+    assert len(got) == len(exp), (case, len(got), len(exp))
+    for i, (g, e) in enumerate(zip(got, exp)):
+        if _volatile(e):
+            assert _volatile(g)
+            continue
+        assert g == e, (case, i, g[:300], e[:300])
+
+
+@pytest.mark.gpu
+def test_cli_small_batches_same_output(tmp_path):
+    """-batch-size only changes how reads are grouped into device batches."""
+    build.build_library()
+    c = CASES["everything_species"]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-threads", "1", "-batch-size", "37", "-out", str(out)]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in out.read_text().split("\n") if not _volatile(l)]
+    exp = [l for l in c["lines"] if not _volatile(l)]
+    assert got == exp
+
+
+def test_cli_fails_loudly_without_gpu_or_db(tmp_path):
+    """No GPU here / no database: the tool reports 'ABORT' and a non-zero exit code, never an empty result file."""
+    build.build_library()
+    r = subprocess.run([build.MCQ, "query", str(tmp_path / "nodb"), os.path.join(GOLD, "cli_reads.fa")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "ABORT" in r.stderr
+    r = subprocess.run([build.MCQ, "query", "toy32", "cli_reads.fa", "-bogus"], cwd=GOLD, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "unknown option" in r.stderr
