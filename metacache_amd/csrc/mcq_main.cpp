@@ -1,7 +1,10 @@
 // mcq -- `metacache query` on MI355X: the reference's query command line for the per-read mapping output
 // (SURVEY.md §8f rank 2), host C++ above the C ABI.  Mirrors, for the supported options,
 //   option handling      options.cpp:860-1430 (query subset), querying.cpp:225-269 (adapt_options_to_database)
-//   read ingest          sequence_io.cpp (FASTA / FASTQ, -pairfiles / -pairseq), database_query.hpp:258-284
+//   read ingest          sequence_io.cpp:160-228, :293-322 (FASTA / FASTQ, -pairfiles / -pairseq), database_query.hpp:258-284;
+//                        files are memory-mapped, record starts are indexed by all threads in parallel
+//                        (query ids = record order, as reader.index()), and every worker thread drives one batch slot:
+//                        parse -> mc_batch_add -> submit -> wait -> classify + format; output is written in file order
 //   classification       classification.cpp:146-189 (classify: ranked-LCA vote over the top candidates)
 //   output lines         classification.cpp:470-526 (show_query_mapping), printing.cpp:160-365
 // Not offered (later rows): -precision/-ground-truth, -hits-per-ref, -abundances, -align, gzip input, summary block.
@@ -13,15 +16,26 @@
 //       [-no-query-params] [-no-summary] [-threads n (accepted, ignored)] [-batch-size n]
 #include "metacache_amd.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -163,45 +177,104 @@ Options parse(int argc, char** argv)
     return o;
 }
 
-// ---- sequence files (uncompressed FASTA / FASTQ) --------------------------------------------------------------------
-struct Record { std::string header, seq; };
+// ---- sequence files (uncompressed FASTA / 4-line FASTQ), memory-mapped ---------------------------------------------
+struct View { const char* p = nullptr; size_t n = 0; bool empty() const { return n == 0; } };
 
-// sequence_reader::read_next (sequence_io.cpp:160-228): a record starts at a line beginning with '>' or '@' (other lines
-// are skipped), sequence lines run up to the next line beginning with '>' or '+'; after a '+' line one quality line follows.
-class Reader {
+class SeqFile {
 public:
-    explicit Reader(const std::string& fn) : is_(fn)
+    explicit SeqFile(const std::string& fn)
     {
-        if (!is_.good()) throw std::runtime_error("file '" + fn + "' could not be opened");
-        advance();
+        fd_ = ::open(fn.c_str(), O_RDONLY);
+        struct stat st;
+        if (fd_ < 0 || fstat(fd_, &st) != 0) throw std::runtime_error("file '" + fn + "' could not be opened");
+        size_ = (size_t)st.st_size;
+        if (size_) {
+            void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+            if (m == MAP_FAILED) throw std::runtime_error("file '" + fn + "' could not be mapped");
+            data_ = (const char*)m;
+            madvise(m, size_, MADV_SEQUENTIAL);
+        }
     }
-    bool has_next()
-    {
-        while (have_ && (line_.empty() || (line_[0] != '>' && line_[0] != '@'))) advance();
-        return have_;
-    }
-    bool next(Record& r)
-    {
-        r.header.clear(); r.seq.clear();
-        if (!has_next()) return false;
-        r.header = line_.substr(1);
-        for (advance(); have_ && (line_.empty() || (line_[0] != '>' && line_[0] != '+')); advance()) r.seq += line_;
-        if (have_ && line_[0] == '+') { advance(); advance(); }      // '+' line, quality line
-        return true;
-    }
-private:
-    void advance()
-    {
-        have_ = bool(std::getline(is_, line_));
-        if (!have_) line_.clear();
-        while (!line_.empty() && (line_.back() == '\r' || line_.back() == '\n')) line_.pop_back();
-    }
-    std::ifstream is_;
-    std::string line_;
-    bool have_ = false;
-};
+    ~SeqFile() { if (data_) munmap((void*)data_, size_); if (fd_ >= 0) ::close(fd_); }
+    SeqFile(const SeqFile&) = delete;
 
-struct Query { uint64_t id; std::string header, seq1, seq2; };
+    // record starts = lines beginning with '>' (FASTA) or '@' header lines of 4-line FASTQ records; found by all threads
+    void index(unsigned threads)
+    {
+        size_t first = 0;                                                         // sequence_io.cpp:168-173: skip to the first '>' / '@' line
+        while (first < size_ && data_[first] != '>' && data_[first] != '@') first = next_line(first);
+        if (first >= size_) return;
+        fastq_ = data_[first] == '@';
+        threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, size_ / (1u << 22) + 1));
+        std::vector<std::vector<uint64_t>> found(threads);
+        std::vector<std::thread> pool;
+        const size_t span = (size_ - first + threads - 1) / threads;
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] { scan(first + t * span, std::min(size_, first + (t + 1) * span), found[t]); });
+        for (auto& th : pool) th.join();
+        for (auto& v : found) starts_.insert(starts_.end(), v.begin(), v.end());
+    }
+    size_t records() const { return starts_.size(); }
+
+    // sequence_reader::read_next: header without the marker, sequence lines joined ('scratch' only for multi-line records)
+    void record(size_t i, View& header, View& seq, std::string& scratch) const
+    {
+        const size_t b = starts_[i], e = i + 1 < starts_.size() ? starts_[i + 1] : size_;
+        size_t eol = line_end(b, e);
+        header = trimmed(b + 1, eol);
+        size_t p = std::min(eol + 1, e);
+        if (fastq_) { seq = trimmed(p, line_end(p, e)); return; }
+        seq = View{};
+        bool multi = false;
+        while (p < e) {
+            eol = line_end(p, e);
+            const View l = trimmed(p, eol);
+            if (l.n) {
+                if (seq.n == 0 && !multi) seq = l;
+                else { if (!multi) { scratch.assign(seq.p, seq.n); multi = true; } scratch.append(l.p, l.n); }
+            }
+            p = eol + 1;
+        }
+        if (multi) seq = View{scratch.data(), scratch.size()};
+    }
+
+private:
+    size_t next_line(size_t p) const { const void* nl = memchr(data_ + p, '\n', size_ - p); return nl ? (size_t)((const char*)nl - data_) + 1 : size_; }
+    size_t line_end(size_t p, size_t e) const { if (p >= e) return e; const void* nl = memchr(data_ + p, '\n', e - p); return nl ? (size_t)((const char*)nl - data_) : e; }
+    View trimmed(size_t b, size_t e) const { while (e > b && (data_[e - 1] == '\r' || data_[e - 1] == '\n')) --e; return View{data_ + b, e > b ? e - b : 0}; }
+    bool fastq_header_at(size_t p) const
+    {
+        if (p >= size_ || data_[p] != '@') return false;
+        const size_t l2 = next_line(next_line(p));
+        return l2 < size_ && data_[l2] == '+';
+    }
+    void scan(size_t lo, size_t hi, std::vector<uint64_t>& out) const
+    {
+        if (!fastq_) {
+            for (size_t p = lo; p < hi;) {
+                const void* g = memchr(data_ + p, '>', hi - p);
+                if (!g) break;
+                const size_t q = (size_t)((const char*)g - data_);
+                if (q == 0 || data_[q - 1] == '\n') out.push_back(q);
+                p = q + 1;
+            }
+            return;
+        }
+        size_t p = lo;
+        if (p > 0 && data_[p - 1] != '\n') p = next_line(p);
+        while (p < hi && !fastq_header_at(p)) p = next_line(p);                   // an '@' line whose line+2 starts with '+' is a header
+        while (p < hi) {
+            out.push_back(p);
+            p = next_line(next_line(next_line(next_line(p))));
+            while (p < size_ && data_[p] != '@') p = next_line(p);                // blank lines between records
+        }
+    }
+    int fd_ = -1;
+    const char* data_ = nullptr;
+    size_t size_ = 0;
+    bool fastq_ = false;
+    std::vector<uint64_t> starts_;
+};
 
 // ---- output (printing.cpp:160-365) ----------------------------------------------------------------------------------
 void print_taxon(std::ostream& os, const Options& o, const std::string& name, int64_t id, int rank)
@@ -310,6 +383,10 @@ int main(int argc, char** argv)
         const bool unlimited = o.maxCand < 1;
         cfg.max_candidates = unlimited ? 256 : (uint32_t)std::min<uint64_t>(o.maxCand, 4096);
         cfg.copy_allhits = o.allhits ? 1 : 0;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned threads = o.threads > 0 ? (unsigned)o.threads : hw;      // options.hpp: numThreads defaults to all hardware threads
+        const unsigned workers = std::min(threads, 48u);                        // one batch slot (pinned staging) per worker
+        cfg.num_slots = workers;
         cfg.slot_max_queries = o.batchSize;
         cfg.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
         cfg.max_load_factor = o.maxLoadFac;
@@ -344,7 +421,7 @@ int main(int argc, char** argv)
             os << o.comment << "At maximum " << (unlimited ? std::numeric_limits<size_t>::max() : o.maxCand) << " classification candidates will be considered per query.\n";
             if (o.pairing == Options::files) os << o.comment << "File based paired-end mode:\n" << o.comment << "  Reads from two consecutive files will be interleaved.\n" << o.comment << "  Max insert size considered " << o.insertMax << ".\n";
             else if (o.pairing == Options::sequences) os << o.comment << "Per file paired-end mode:\n" << o.comment << "  Reads from two consecutive sequences in each file will be paired up.\n" << o.comment << "  Max insert size considered " << o.insertMax << ".\n";
-            os << o.comment << "Using " << (o.threads > 0 ? o.threads : 1) << " threads\n";
+            os << o.comment << "Using " << threads << " threads\n";
         }
         if (o.mapView != Options::mv_none) {                                     // show_query_mapping_header, classification.cpp:432-460
             os << o.comment << "TABLE_LAYOUT: ";
@@ -363,70 +440,135 @@ int main(int argc, char** argv)
         }
 
         const auto t0 = std::chrono::steady_clock::now();
-        uint64_t idOffset = 0;
         uint64_t assigned[kNumRanks + 1] = {};                                   // classification_statistics::assign
-        std::vector<Query> batch;
-        auto flush = [&]() {
-            if (batch.empty()) return;
-            if (mc_batch_submit(ctx, 0, o.lowest) != MC_OK) throw std::runtime_error(mc_last_error(ctx));
-            mc_results r;
-            if (mc_batch_wait(ctx, 0, &r) != MC_OK) throw std::runtime_error(mc_last_error(ctx));
-            for (uint32_t i = 0; i < r.num_queries; ++i) {
-                std::vector<Cand> cands;
-                for (uint32_t j = 0; j < r.max_candidates; ++j) {
-                    const mc_candidate& c = r.cands[(size_t)i * r.max_candidates + j];
-                    if (c.hits == 0) break;
-                    Cand x{c.tgt, c.hits, c.beg, c.end, 0};
-                    const Lineage lin = tx.target_ranks(c.tgt);
-                    if (o.lowest > 0) { for (int rk = o.lowest; rk < kNumRanks; ++rk) if (lin[rk]) { x.tax = lin[rk]; break; } }   // lowest_ranked_ancestor
-                    else x.tax = lin[0];
-                    cands.push_back(x);
-                }
-                const Query& q = batch[i];
-                if (q.header.empty() || q.seq1.empty()) continue;                 // processQuery, classification.cpp:780
-                bool isTarget; uint32_t tgt;
-                const uint32_t best = classify(o, tx, cands, isTarget, tgt);
-                ++assigned[best ? tx.taxon(best)->rank : kNumRanks];
-                if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) continue;
-                if (o.queryIds) os << q.id << o.column;
-                const auto sp = q.header.find(' ');
-                os << (sp == std::string::npos ? q.header : q.header.substr(0, sp)) << o.column;
-                if (o.allhits) { show_matches(os, o, tx, r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i]); os << o.column; }
-                if (o.tophits) { show_candidates(os, o, tx, cands); os << o.column; }
-                show_taxon(os, o, tx, best, isTarget, tgt);
-                os << '\n';
-            }
-            mc_batch_clear(ctx, 0);
-            batch.clear();
-        };
-        auto add = [&](Query&& q) {
-            const uint32_t maxWin = (uint32_t)(2 + std::max<uint64_t>(q.seq1.size() + q.seq2.size(), o.insertMax) / dbStride);
-            int rc = mc_batch_add(ctx, 0, q.seq1.data(), (uint32_t)q.seq1.size(), q.seq2.data(), (uint32_t)q.seq2.size(), maxWin);
-            if (rc == MC_BATCH_FULL) { flush(); rc = mc_batch_add(ctx, 0, q.seq1.data(), (uint32_t)q.seq1.size(), q.seq2.data(), (uint32_t)q.seq2.size(), maxWin); }
-            if (rc == MC_BATCH_FULL) { std::cerr << "query batch is too small for a single read!\n"; return; }
-            if (rc < 0) throw std::runtime_error(mc_last_error(ctx));
-            batch.push_back(std::move(q));
-        };
 
-        const size_t stride = o.pairing == Options::files ? 2 : 1;
-        for (size_t fi = 0; fi < o.infiles.size(); fi += stride) {
-            if (o.pairing == Options::files && fi + 1 >= o.infiles.size()) break;
-            flush();
-            os << o.comment << o.infiles[fi];                                   // appendToOutput, classification.cpp:825-827
-            if (o.pairing == Options::files) os << " + " << o.infiles[fi + 1];
-            os << '\n';
-            Reader r1(o.infiles[fi]);
-            Record a, b;
-            if (o.pairing == Options::files) {
-                Reader r2(o.infiles[fi + 1]);
-                while (r1.has_next() && r2.has_next()) { r1.next(a); r2.next(b); add(Query{++idOffset, a.header, a.seq, b.seq}); }
-            } else if (o.pairing == Options::sequences) {
-                while (r1.has_next()) { r1.next(a); b.seq.clear(); if (r1.has_next()) r1.next(b); add(Query{++idOffset, a.header, a.seq, b.seq}); }
-            } else {
-                while (r1.next(a)) add(Query{++idOffset, a.header, a.seq, ""});
+        // ---- all inputs are indexed first: batches = runs of consecutive queries, ids continue across files -------------
+        struct Batch { size_t f1, f2; size_t qBeg, qEnd; uint64_t firstId; std::string prefix; };
+        std::vector<std::unique_ptr<SeqFile>> files;
+        std::vector<Batch> batches;
+        {
+            uint64_t idOffset = 0;
+            const size_t stride = o.pairing == Options::files ? 2 : 1;
+            for (size_t fi = 0; fi < o.infiles.size(); fi += stride) {
+                if (o.pairing == Options::files && fi + 1 >= o.infiles.size()) break;
+                std::string prefix = o.comment + o.infiles[fi];                  // appendToOutput, classification.cpp:825-827
+                if (o.pairing == Options::files) prefix += " + " + o.infiles[fi + 1];
+                prefix += '\n';
+                size_t nq = 0, f1 = files.size(), f2 = files.size();
+                try {
+                    files.emplace_back(new SeqFile(o.infiles[fi]));
+                    files.back()->index(workers);
+                    nq = files.back()->records();
+                    if (o.pairing == Options::sequences) nq = (nq + 1) / 2;
+                    if (o.pairing == Options::files) {
+                        f2 = files.size();
+                        files.emplace_back(new SeqFile(o.infiles[fi + 1]));
+                        files.back()->index(workers);
+                        nq = std::min(nq, files.back()->records());
+                    }
+                } catch (std::exception& e) { std::cerr << "FAIL: " << e.what() << '\n'; nq = 0; }   // database_query.hpp:397-399
+                for (size_t q = 0; q == 0 || q < nq; q += o.batchSize) {
+                    batches.push_back(Batch{f1, f2, q, std::min<size_t>(nq, q + o.batchSize), idOffset + q, q == 0 ? prefix : std::string()});
+                    if (nq == 0) break;
+                }
+                idOffset += nq;
             }
         }
-        flush();
+
+        // ---- workers: one batch slot each; output delivered in batch order -------------------------------------------------
+        std::atomic<size_t> nextBatch{0};
+        std::mutex outMtx, errMtx;
+        std::map<size_t, std::string> finished;
+        size_t nextToWrite = 0;
+        std::string firstError;
+        std::atomic<bool> failed{false};
+        auto deliver = [&](size_t b, std::string&& text) {
+            std::lock_guard<std::mutex> lock(outMtx);
+            finished.emplace(b, std::move(text));
+            for (auto it = finished.begin(); it != finished.end() && it->first == nextToWrite; it = finished.erase(it), ++nextToWrite)
+                os.write(it->second.data(), (std::streamsize)it->second.size());
+        };
+        auto work = [&](unsigned slot) {
+            struct Meta { uint64_t id; View header; bool empty; };
+            std::vector<Meta> metas;
+            std::vector<Cand> cands;
+            std::string scratch1, scratch2;
+            std::ostringstream out;
+            uint64_t mine[kNumRanks + 1] = {};
+            auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = m; };
+            for (size_t b; !failed && (b = nextBatch++) < batches.size();) {
+                const Batch& B = batches[b];
+                out.str(std::string());
+                out << B.prefix;
+                size_t q = B.qBeg;
+                while (q < B.qEnd && !failed) {
+                    metas.clear();
+                    for (; q < B.qEnd; ++q) {
+                        View h1, s1, h2, s2;
+                        if (o.pairing == Options::sequences) {
+                            files[B.f1]->record(2 * q, h1, s1, scratch1);
+                            if (2 * q + 1 < files[B.f1]->records()) files[B.f1]->record(2 * q + 1, h2, s2, scratch2);
+                        } else {
+                            files[B.f1]->record(q, h1, s1, scratch1);
+                            if (o.pairing == Options::files) files[B.f2]->record(q, h2, s2, scratch2);
+                        }
+                        if (std::max(s1.n, s2.n) >= 0xFFFFFFF0ull) { fail("sequence too long"); break; }
+                        const uint32_t maxWin = (uint32_t)(2 + std::max<uint64_t>(s1.n + s2.n, o.insertMax) / dbStride);   // candidate_structs.hpp:143-145
+                        const bool tooBig = s1.n + s2.n + 8 > cfg.slot_max_chars;
+                        const int rc = tooBig ? MC_BATCH_FULL : mc_batch_add(ctx, slot, s1.p, (uint32_t)s1.n, s2.p, (uint32_t)s2.n, maxWin);
+                        if (rc == MC_BATCH_FULL) {
+                            if (!tooBig && !metas.empty()) break;                 // submit what is there, then retry this query
+                            std::cerr << "query batch is too small for a single read!\n";                                    // database_query.hpp:103
+                            continue;
+                        }
+                        if (rc < 0) { fail(mc_last_error(ctx)); break; }
+                        metas.push_back(Meta{B.firstId + (q - B.qBeg) + 1, h1, h1.empty() || s1.empty()});
+                    }
+                    if (failed) break;
+                    mc_results r;
+                    if (mc_batch_submit(ctx, slot, o.lowest) != MC_OK || mc_batch_wait(ctx, slot, &r) != MC_OK) { fail(mc_last_error(ctx)); break; }
+                    for (uint32_t i = 0; i < r.num_queries; ++i) {
+                        const Meta& m = metas[i];
+                        if (m.empty) continue;                                    // processQuery, classification.cpp:780
+                        cands.clear();
+                        for (uint32_t j = 0; j < r.max_candidates; ++j) {
+                            const mc_candidate& c = r.cands[(size_t)i * r.max_candidates + j];
+                            if (c.hits == 0) break;
+                            Cand x{c.tgt, c.hits, c.beg, c.end, 0};
+                            if (c.tgt < tx.numTargets) {
+                                const uint32_t* lin = tx.targetLineages + (size_t)c.tgt * kNumRanks;
+                                if (o.lowest > 0) { for (int rk = o.lowest; rk < kNumRanks; ++rk) if (lin[rk]) { x.tax = lin[rk]; break; } }   // lowest_ranked_ancestor
+                                else x.tax = lin[0];
+                            }
+                            cands.push_back(x);
+                        }
+                        bool isTarget; uint32_t tgt;
+                        const uint32_t best = classify(o, tx, cands, isTarget, tgt);
+                        ++mine[best ? tx.taxon(best)->rank : kNumRanks];
+                        if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) continue;
+                        if (o.queryIds) out << m.id << o.column;
+                        const void* sp = memchr(m.header.p, ' ', m.header.n);
+                        out.write(m.header.p, sp ? (const char*)sp - m.header.p : (std::streamsize)m.header.n);
+                        out << o.column;
+                        if (o.allhits) { show_matches(out, o, tx, r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i]); out << o.column; }
+                        if (o.tophits) { show_candidates(out, o, tx, cands); out << o.column; }
+                        show_taxon(out, o, tx, best, isTarget, tgt);
+                        out << '\n';
+                    }
+                    mc_batch_clear(ctx, slot);
+                }
+                deliver(b, out.str());
+            }
+            std::lock_guard<std::mutex> l(errMtx);
+            for (int r = 0; r <= kNumRanks; ++r) assigned[r] += mine[r];
+        };
+        {
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work, w);
+            work(0);
+            for (auto& t : pool) t.join();
+        }
+        if (failed) throw std::runtime_error(firstError);
         if (o.showSummary) {                                                     // show_summary, printing.cpp:601-620
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             uint64_t nassigned = 0;
