@@ -155,7 +155,9 @@ void mc_destroy(mc_ctx* ctx)
     for (auto& p : ctx->parts) { if (p.dbuckets) (void)hipFree(p.dbuckets); if (p.dvalues) (void)hipFree(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     DevBuf* bufs[] = {&ctx->bWinCount, &ctx->bWinOff, &ctx->bFeatures, &ctx->bPsize, &ctx->bPpay, &ctx->bQstat, &ctx->bHitOff,
-                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist};
+                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist,
+                      &ctx->bLdKeys, &ctx->bLdSizes, &ctx->bLdVals, &ctx->bLdFileSz, &ctx->bLdStoreSz, &ctx->bLdFileOff, &ctx->bLdStoreOff,
+                      &ctx->bLdScan, &ctx->bLdCounters};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& s : ctx->slots) {
         if (s.hseq) (void)hipHostFree(s.hseq); if (s.hqinfo) (void)hipHostFree(s.hqinfo); if (s.hmaxwin) (void)hipHostFree(s.hmaxwin);
@@ -186,11 +188,64 @@ static int allocate_table(mc_ctx* ctx)
     nb += nb & 1;                                            // two buckets per line
     if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
     T.nbuckets = (uint32_t)nb;
-    T.hbuckets.assign((size_t)nb, TableBucket{});
     if (ctx->parts.size() == 1) {
+        // one part: the table is built on the device, batch by batch (table_build.hip)
         T.dvaluesCap = nvalues + 1;
         HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, T.dvaluesCap * sizeof(uint64_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
+        HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
+        int rc = ensure(ctx, ctx->bLdCounters, 4 * sizeof(unsigned long long));
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->bLdCounters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    } else {
+        T.hbuckets.assign((size_t)nb, TableBucket{});
     }
+    return MC_OK;
+}
+
+// One batch of a single-part database, inserted on the device.  counters: [0] keys stored, [1] locations kept,
+// [2] (as two u32) longest probe sequence | table-full flag.
+static int load_batch_device(mc_ctx* ctx, const uint32_t* keys, const uint8_t* sizes, const uint8_t* values, uint64_t n)
+{
+    Part& P = ctx->parts[0];
+    const uint32_t tb = ctx->cfg.target_id_bytes, vb = 4 + tb;
+    const uint32_t maxLocs = ctx->cfg.max_locations_per_feature, rmOver = ctx->cfg.remove_overpopulated;
+    hipStream_t st = ctx->stream;
+    const uint64_t kChunk = 1ull << 22;                       // keys per launch: file values of a chunk stay below 2^32
+    for (uint64_t done = 0; done < n;) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(kChunk, n - done);
+        uint64_t fileVals = 0;
+        for (uint32_t i = 0; i < nb; ++i) fileVals += sizes[done + i];
+        int rc = 0;
+        if ((rc = ensure(ctx, ctx->bLdKeys, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdSizes, nb)) ||
+            (rc = ensure(ctx, ctx->bLdVals, fileVals * vb + 16)) || (rc = ensure(ctx, ctx->bLdFileSz, (size_t)nb * 4)) ||
+            (rc = ensure(ctx, ctx->bLdStoreSz, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdFileOff, (size_t)(nb + 2) * 4)) ||
+            (rc = ensure(ctx, ctx->bLdStoreOff, (size_t)(nb + 2) * 4)) || (rc = ensure(ctx, ctx->bLdScan, scan_tmp_bytes(nb + 1))))
+            return rc;
+        auto* dkeys = (uint32_t*)ctx->bLdKeys.p; auto* dsizes = (uint8_t*)ctx->bLdSizes.p; auto* dvals = (uint8_t*)ctx->bLdVals.p;
+        auto* fileSz = (uint32_t*)ctx->bLdFileSz.p; auto* storeSz = (uint32_t*)ctx->bLdStoreSz.p;
+        auto* fileOff = (uint32_t*)ctx->bLdFileOff.p; auto* storeOff = (uint32_t*)ctx->bLdStoreOff.p;
+        auto* counters = (unsigned long long*)ctx->bLdCounters.p;
+        HIP_TRY(ctx, hipMemcpyAsync(dkeys, keys + done, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dsizes, sizes + done, nb, hipMemcpyHostToDevice, st));
+        if (fileVals) HIP_TRY(ctx, hipMemcpyAsync(dvals, values, fileVals * vb, hipMemcpyHostToDevice, st));
+        launch_table_prep(dsizes, nb, maxLocs, rmOver, fileSz, storeSz, counters, st);
+        launch_scan_u32(fileSz, 1, nb, fileOff, nullptr, ctx->bLdScan.p, st);
+        launch_scan_u32(storeSz, 1, nb, storeOff, nullptr, ctx->bLdScan.p, st);
+        uint32_t stored = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));               // also: the pageable source buffers are free again
+        if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
+        launch_table_insert(dkeys, dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
+                            (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st);
+        launch_table_values(dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(st));               // staging buffers are reused by the next chunk
+        P.valuesStored += stored;
+        values += fileVals * vb;
+        done += nb;
+    }
+    P.keysLoaded += n;
     return MC_OK;
 }
 
@@ -221,13 +276,15 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
         int rc = allocate_table(ctx);
         if (rc) return rc;
     }
+    if (P.keysLoaded + n > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
+    if (!multi) return load_batch_device(ctx, keys, sizes, static_cast<const uint8_t*>(values), n);
     const uint32_t tb = ctx->cfg.target_id_bytes, vb = 4 + tb;
     const uint32_t maxLocs = ctx->cfg.max_locations_per_feature;
     const uint32_t rmOver = ctx->cfg.remove_overpopulated;
     const uint8_t* vp = static_cast<const uint8_t*>(values);
-    std::vector<uint64_t> stage;                               // single part: values of this batch, uploaded below
-    std::vector<uint64_t>& store = multi ? ctx->hvalues : stage;
-    const uint64_t storeBase = multi ? 0 : T.valuesStored;
+    // several parts: buckets of one feature are merged across parts on the host, the table goes up in mc_load_end
+    std::vector<uint64_t>& store = ctx->hvalues;
+    const uint64_t storeBase = 0;
     bool badTarget = false;
     auto decode = [&](const uint8_t* p) -> uint64_t {
         uint32_t win; std::memcpy(&win, p, 4);
@@ -291,11 +348,6 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
         vp += (size_t)fileSize * vb;
     }
     if (badTarget) return fail(ctx, MC_ERR_UNSUPPORTED, "multi-part databases need target ids < 2^24");
-    if (!multi && !stage.empty()) {
-        if (T.valuesStored + stage.size() > T.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
-        HIP_TRY(ctx, hipMemcpy(T.dvalues + T.valuesStored, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
-        T.valuesStored += stage.size();
-    }
     P.keysLoaded += n;
     return MC_OK;
 }
@@ -309,6 +361,19 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     P.loading = false; P.ready = true;
     for (auto& q : ctx->parts) if (!q.ready) return MC_OK;     // the table goes to the device when the last part is in
+    if (ctx->parts.size() == 1) {                              // built on the device: fetch the counters, drop the staging
+        unsigned long long c[4] = {0, 0, 0, 0};
+        HIP_TRY(ctx, hipMemcpy(c, ctx->bLdCounters.p, sizeof(c), hipMemcpyDeviceToHost));
+        T.keysStored = c[0]; P.locations = c[1];
+        T.maxProbe = std::max<uint32_t>(1u, (uint32_t)(c[2] & 0xFFFFFFFFull));
+        const bool full = (c[2] >> 32) != 0;
+        DevBuf* st[] = {&ctx->bLdKeys, &ctx->bLdSizes, &ctx->bLdVals, &ctx->bLdFileSz, &ctx->bLdStoreSz, &ctx->bLdFileOff, &ctx->bLdStoreOff,
+                        &ctx->bLdScan};
+        for (auto* b : st) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+        if (full) return fail(ctx, MC_ERR_NOMEM, "hash table full");
+        ctx->tableReady = true;
+        return MC_OK;
+    }
     if (T.hbuckets.empty()) { int rc = allocate_table(ctx); if (rc) return rc; }
     if (ctx->parts.size() > 1) {
         T.dvaluesCap = ctx->hvalues.size() + 1;

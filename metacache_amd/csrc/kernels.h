@@ -117,6 +117,14 @@ void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable&
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                         const uint32_t* taxkey, void* cands, hipStream_t st);
+// table_build.hip: GPU-side table construction from the file's batch stream
+void launch_table_prep(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, uint32_t* fileSz, uint32_t* storeSz,
+                       unsigned long long* counters, hipStream_t st);
+void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff,
+                         const uint32_t* storeOff, const uint8_t* vals, uint32_t tb, uint64_t storeBase, TableBucket* buckets,
+                         uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
+void launch_table_values(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff, const uint32_t* storeOff,
+                         const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS
