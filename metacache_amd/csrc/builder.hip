@@ -2,13 +2,16 @@
 // Target sequences are cut into window-aligned chunks, sketched by the same sketch kernel the query
 // path uses (probe disabled), turned into (feature, location) pairs, sorted by feature with a stable
 // device radix sort (insertion order = (target, window) order survives inside a bucket) and cut to
-// the first max_locations_per_feature locations per feature.
+// the first max_locations_per_feature locations per feature.  Run-length encoding, truncation and -- for
+// mc_build_finish(load) -- the query table itself (table_build.hip) stay on the device; the host copy of the
+// file arrays is made only by mc_build_write.
 #include <cstring>
 #include <string.h>
 
 #include "context.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -32,9 +35,13 @@ struct mc_builder {
     std::vector<uint32_t> hqinfo, hqtgt, hqfirst;
     // all pairs so far (device, grow-only)
     uint32_t* dkeys = nullptr; uint64_t* dvals = nullptr; uint64_t npairs = 0, cap = 0;
-    // result (host)
+    // result: the file's arrays -- keys, bucket sizes, location lists ((tgt << 32) | win = {u32 win; u32 tgt}) -- on the device
     bool finished = false;
-    std::vector<uint32_t> keys; std::vector<uint8_t> sizes; std::vector<uint64_t> values;   // values = (tgt<<32)|win
+    uint32_t* rK = nullptr; uint8_t* rS = nullptr; uint64_t* rV = nullptr; uint64_t* rVoff = nullptr;   // rVoff[nkeys + 1]
+    uint64_t nkeys = 0, nvals = 0;
+    // ... and on the host once mc_build_write needs them
+    bool onHost = false;
+    std::vector<uint32_t> keys; std::vector<uint8_t> sizes; std::vector<uint64_t> values;
 };
 
 namespace {
@@ -66,6 +73,28 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
         keys[idx] = features[idx];
         vals[idx] = (tgt << 32) | (first + w);
     }
+}
+
+// per run (= feature): kept size and its u32 copy for the scan
+__global__ __launch_bounds__(256) void keep_sizes_kernel(const uint32_t* __restrict__ counts, uint32_t nruns, uint32_t maxLocs,
+                                                         uint8_t* __restrict__ sizes, uint32_t* __restrict__ keep32)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nruns) return;
+    const uint32_t k = counts[r] < maxLocs ? counts[r] : maxLocs;
+    sizes[r] = (uint8_t)k; keep32[r] = k;
+}
+
+// per run: the FIRST 'keep' locations in insertion order (host_hashmap.hpp:593-605) move to their place in the file's value array
+__global__ __launch_bounds__(256) void compact_values_kernel(const uint64_t* __restrict__ sorted, const uint64_t* __restrict__ runOff,
+                                                             const uint64_t* __restrict__ keepOff, const uint8_t* __restrict__ sizes,
+                                                             uint32_t nruns, uint64_t* __restrict__ out)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nruns) return;
+    const uint64_t src = runOff[r], dst = keepOff[r];
+    const uint32_t k = sizes[r];
+    for (uint32_t t = 0; t < k; ++t) out[dst + t] = sorted[src + t];
 }
 
 int grow_pairs(mc_builder* b, uint64_t need)
@@ -214,34 +243,54 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
         int rc = flush(b);
         if (rc) return rc;
         const uint64_t n = b->npairs;
-        std::vector<uint32_t> hk(n);
-        std::vector<uint64_t> hv(n);
+        if (n >= 0xFFFFFFF0ull) { b->err = "more than 2^32 (feature, location) pairs in one builder"; return MC_ERR_UNSUPPORTED; }
         if (n) {
+            hipStream_t st = b->st;
             uint32_t* k2 = nullptr; uint64_t* v2 = nullptr; void* tmp = nullptr; size_t tmpBytes = 0;
             B_TRY(b, hipMalloc((void**)&k2, n * 4));
             B_TRY(b, hipMalloc((void**)&v2, n * 8));
-            B_TRY(b, rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, b->st));
+            B_TRY(b, rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
             B_TRY(b, hipMalloc(&tmp, tmpBytes + 16));
-            B_TRY(b, rocprim::radix_sort_pairs(tmp, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, b->st));
-            B_TRY(b, hipMemcpyAsync(hk.data(), k2, n * 4, hipMemcpyDeviceToHost, b->st));
-            B_TRY(b, hipMemcpyAsync(hv.data(), v2, n * 8, hipMemcpyDeviceToHost, b->st));
-            B_TRY(b, hipStreamSynchronize(b->st));
-            (void)hipFree(k2); (void)hipFree(v2); (void)hipFree(tmp);
-        }
-        (void)hipFree(b->dkeys); (void)hipFree(b->dvals);
-        b->dkeys = nullptr; b->dvals = nullptr; b->cap = 0;
-        // run-length encode; features == 0xFFFFFFFF are padding and sort last
-        b->keys.clear(); b->sizes.clear(); b->values.clear();
-        for (uint64_t i = 0; i < n;) {
-            const uint32_t key = hk[i];
-            if (key == 0xFFFFFFFFu) break;
-            uint64_t j = i;
-            while (j < n && hk[j] == key) ++j;
-            const uint64_t keep = std::min<uint64_t>(j - i, b->maxLocs);   // first maxLocs in insertion order
-            b->keys.push_back(key);
-            b->sizes.push_back((uint8_t)keep);
-            b->values.insert(b->values.end(), hv.begin() + i, hv.begin() + i + keep);
-            i = j;
+            B_TRY(b, rocprim::radix_sort_pairs(tmp, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
+            B_TRY(b, hipStreamSynchronize(st));
+            (void)hipFree(tmp); tmp = nullptr;
+            (void)hipFree(b->dkeys); (void)hipFree(b->dvals);
+            b->dkeys = nullptr; b->dvals = nullptr; b->cap = 0;
+            // runs of equal features; the padding feature 0xFFFFFFFF sorts last and is dropped
+            uint32_t *uniq = nullptr, *counts = nullptr, *dnruns = nullptr;
+            B_TRY(b, hipMalloc((void**)&uniq, n * 4));
+            B_TRY(b, hipMalloc((void**)&counts, n * 4));
+            B_TRY(b, hipMalloc((void**)&dnruns, 16));
+            B_TRY(b, rocprim::run_length_encode(nullptr, tmpBytes, k2, (unsigned int)n, uniq, counts, dnruns, st));
+            B_TRY(b, hipMalloc(&tmp, tmpBytes + 16));
+            B_TRY(b, rocprim::run_length_encode(tmp, tmpBytes, k2, (unsigned int)n, uniq, counts, dnruns, st));
+            uint32_t nruns = 0, lastKey = 0;
+            B_TRY(b, hipMemcpyAsync(&nruns, dnruns, 4, hipMemcpyDeviceToHost, st));
+            B_TRY(b, hipStreamSynchronize(st));
+            if (nruns) B_TRY(b, hipMemcpy(&lastKey, uniq + nruns - 1, 4, hipMemcpyDeviceToHost));
+            if (nruns && lastKey == 0xFFFFFFFFu) --nruns;
+            (void)hipFree(tmp); (void)hipFree(k2); (void)hipFree(dnruns);
+            uint32_t* keep32 = nullptr; uint64_t *runOff = nullptr; void* scanTmp = nullptr;
+            B_TRY(b, hipMalloc((void**)&b->rS, (size_t)nruns + 16));
+            B_TRY(b, hipMalloc((void**)&keep32, ((size_t)nruns + 1) * 4));
+            B_TRY(b, hipMalloc((void**)&runOff, ((size_t)nruns + 2) * 8));
+            B_TRY(b, hipMalloc((void**)&b->rVoff, ((size_t)nruns + 2) * 8));
+            B_TRY(b, hipMalloc(&scanTmp, scan_tmp_bytes(nruns + 1)));
+            if (nruns) hipLaunchKernelGGL(keep_sizes_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, counts, nruns, b->maxLocs, b->rS, keep32);
+            launch_scan_u32(counts, 1, nruns, nullptr, runOff, scanTmp, st);
+            launch_scan_u32(keep32, 1, nruns, nullptr, b->rVoff, scanTmp, st);
+            uint64_t nvals = 0;
+            B_TRY(b, hipMemcpyAsync(&nvals, b->rVoff + nruns, 8, hipMemcpyDeviceToHost, st));
+            B_TRY(b, hipStreamSynchronize(st));
+            B_TRY(b, hipMalloc((void**)&b->rV, (nvals + 2) * 8));
+            if (nruns) hipLaunchKernelGGL(compact_values_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, v2, runOff, b->rVoff, b->rS, nruns, b->rV);
+            B_TRY(b, hipGetLastError());
+            B_TRY(b, hipStreamSynchronize(st));
+            // keys: shrink the allocation to the number of runs
+            B_TRY(b, hipMalloc((void**)&b->rK, ((size_t)nruns + 1) * 4));
+            B_TRY(b, hipMemcpy(b->rK, uniq, (size_t)nruns * 4, hipMemcpyDeviceToDevice));
+            (void)hipFree(uniq); (void)hipFree(counts); (void)hipFree(keep32); (void)hipFree(runOff); (void)hipFree(scanTmp); (void)hipFree(v2);
+            b->nkeys = nruns; b->nvals = nvals;
         }
         b->finished = true;
     }
@@ -255,16 +304,16 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
         if (rc) { b->err = mc_last_error(nullptr); return rc; }
         ctx->targetCount = b->targets.size();
         ctx->maxLocs = b->maxLocs;
-        rc = mc_load_begin(ctx, 0, b->keys.size(), b->values.size());
-        const uint64_t batch = 1ull << 20;
-        uint64_t voff = 0;
-        for (uint64_t i = 0; !rc && i < b->keys.size(); i += batch) {
-            const uint64_t nb = std::min<uint64_t>(batch, b->keys.size() - i);
-            uint64_t bv = 0;
-            for (uint64_t t = 0; t < nb; ++t) bv += b->sizes[i + t];
-            // (tgt<<32)|win little-endian == {u32 win; u32 tgt}
-            rc = mc_load_batch(ctx, 0, b->keys.data() + i, b->sizes.data() + i, b->values.data() + voff, nb);
-            voff += bv;
+        rc = mc_load_begin(ctx, 0, b->nkeys, b->nvals);
+        // device arrays go straight into the table builder, in chunks whose value count stays below 2^32
+        const uint64_t chunk = 1ull << 22;
+        uint64_t vbeg = 0;
+        for (uint64_t i = 0; !rc && i < b->nkeys; i += chunk) {
+            const uint64_t nb = std::min<uint64_t>(chunk, b->nkeys - i);
+            uint64_t vend = 0;
+            if (hipMemcpy(&vend, b->rVoff + i + nb, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = MC_ERR_HIP; break; }
+            rc = load_chunk_device(ctx, b->rK + i, b->rS + i, reinterpret_cast<const uint8_t*>(b->rV + vbeg), (uint32_t)nb, vend - vbeg);
+            vbeg = vend;
         }
         if (!rc) rc = mc_load_end(ctx, 0);
         if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
@@ -287,6 +336,16 @@ int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, ui
     if (!b || !name) return MC_ERR_INVALID;
     if (!b->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
     const uint32_t tb = b->cfg.target_id_bytes;
+    if (!b->onHost) {
+        B_TRY(b, hipSetDevice(b->cfg.device));
+        b->keys.resize(b->nkeys); b->sizes.resize(b->nkeys); b->values.resize(b->nvals);
+        if (b->nkeys) {
+            B_TRY(b, hipMemcpy(b->keys.data(), b->rK, b->nkeys * 4, hipMemcpyDeviceToHost));
+            B_TRY(b, hipMemcpy(b->sizes.data(), b->rS, b->nkeys, hipMemcpyDeviceToHost));
+        }
+        if (b->nvals) B_TRY(b, hipMemcpy(b->values.data(), b->rV, b->nvals * 8, hipMemcpyDeviceToHost));
+        b->onHost = true;
+    }
     {   // .meta  (database.cpp:247-290)
         FILE* f = std::fopen((std::string(name) + ".meta").c_str(), "wb");
         if (!f) { b->err = "cannot write .meta"; return MC_ERR_IO; }
@@ -353,6 +412,7 @@ void mc_build_free(mc_builder* b)
     (void)hipSetDevice(b->cfg.device);
     if (b->dkeys) (void)hipFree(b->dkeys);
     if (b->dvals) (void)hipFree(b->dvals);
+    for (void* p : {(void*)b->rK, (void*)b->rS, (void*)b->rV, (void*)b->rVoff}) if (p) (void)hipFree(p);
     if (b->st) (void)hipStreamDestroy(b->st);
     delete b;
 }

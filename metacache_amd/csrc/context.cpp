@@ -77,6 +77,42 @@ void collect_timers(mc_ctx* ctx)
 
 void mcamd::set_global_error(const std::string& msg) { g_createError = msg; }
 
+// One chunk of a single-part database whose batch arrays are already in device memory (keys u32 | sizes u8 | packed values).
+// counters: [0] keys stored, [1] locations kept, [2] (as two u32) longest probe sequence | table-full flag.
+int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nb, uint64_t fileVals)
+{
+    if (!ctx || ctx->parts.size() != 1 || !ctx->parts[0].loading) return fail(ctx, MC_ERR_STATE, "load_chunk_device: single-part load only");
+    Part& P = ctx->parts[0];
+    if (P.keysLoaded + nb > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
+    if (fileVals >= (1ull << 32)) return fail(ctx, MC_ERR_INVALID, "load_chunk_device: chunk too large");
+    const uint32_t tb = ctx->cfg.target_id_bytes;
+    const uint32_t maxLocs = ctx->cfg.max_locations_per_feature, rmOver = ctx->cfg.remove_overpopulated;
+    hipStream_t st = ctx->stream;
+    int rc = 0;
+    if ((rc = ensure(ctx, ctx->bLdFileSz, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdStoreSz, (size_t)nb * 4)) ||
+        (rc = ensure(ctx, ctx->bLdFileOff, (size_t)(nb + 2) * 4)) || (rc = ensure(ctx, ctx->bLdStoreOff, (size_t)(nb + 2) * 4)) ||
+        (rc = ensure(ctx, ctx->bLdScan, scan_tmp_bytes(nb + 1))))
+        return rc;
+    auto* fileSz = (uint32_t*)ctx->bLdFileSz.p; auto* storeSz = (uint32_t*)ctx->bLdStoreSz.p;
+    auto* fileOff = (uint32_t*)ctx->bLdFileOff.p; auto* storeOff = (uint32_t*)ctx->bLdStoreOff.p;
+    auto* counters = (unsigned long long*)ctx->bLdCounters.p;
+    launch_table_prep(dsizes, nb, maxLocs, rmOver, fileSz, storeSz, counters, st);
+    launch_scan_u32(fileSz, 1, nb, fileOff, nullptr, ctx->bLdScan.p, st);
+    launch_scan_u32(storeSz, 1, nb, storeOff, nullptr, ctx->bLdScan.p, st);
+    uint32_t stored = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
+    launch_table_insert(dkeys, dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
+                        (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st);
+    launch_table_values(dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));                   // staging buffers are reused by the next chunk
+    P.valuesStored += stored;
+    P.keysLoaded += nb;
+    return MC_OK;
+}
+
 extern "C" {
 
 void mc_config_default(mc_config* c)
@@ -203,13 +239,10 @@ static int allocate_table(mc_ctx* ctx)
     return MC_OK;
 }
 
-// One batch of a single-part database, inserted on the device.  counters: [0] keys stored, [1] locations kept,
-// [2] (as two u32) longest probe sequence | table-full flag.
+// One batch of the file (host memory): upload in chunks, insert on the device.
 static int load_batch_device(mc_ctx* ctx, const uint32_t* keys, const uint8_t* sizes, const uint8_t* values, uint64_t n)
 {
-    Part& P = ctx->parts[0];
-    const uint32_t tb = ctx->cfg.target_id_bytes, vb = 4 + tb;
-    const uint32_t maxLocs = ctx->cfg.max_locations_per_feature, rmOver = ctx->cfg.remove_overpopulated;
+    const uint32_t vb = 4 + ctx->cfg.target_id_bytes;
     hipStream_t st = ctx->stream;
     const uint64_t kChunk = 1ull << 22;                       // keys per launch: file values of a chunk stay below 2^32
     for (uint64_t done = 0; done < n;) {
@@ -218,34 +251,16 @@ static int load_batch_device(mc_ctx* ctx, const uint32_t* keys, const uint8_t* s
         for (uint32_t i = 0; i < nb; ++i) fileVals += sizes[done + i];
         int rc = 0;
         if ((rc = ensure(ctx, ctx->bLdKeys, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdSizes, nb)) ||
-            (rc = ensure(ctx, ctx->bLdVals, fileVals * vb + 16)) || (rc = ensure(ctx, ctx->bLdFileSz, (size_t)nb * 4)) ||
-            (rc = ensure(ctx, ctx->bLdStoreSz, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdFileOff, (size_t)(nb + 2) * 4)) ||
-            (rc = ensure(ctx, ctx->bLdStoreOff, (size_t)(nb + 2) * 4)) || (rc = ensure(ctx, ctx->bLdScan, scan_tmp_bytes(nb + 1))))
+            (rc = ensure(ctx, ctx->bLdVals, fileVals * vb + 16)))
             return rc;
-        auto* dkeys = (uint32_t*)ctx->bLdKeys.p; auto* dsizes = (uint8_t*)ctx->bLdSizes.p; auto* dvals = (uint8_t*)ctx->bLdVals.p;
-        auto* fileSz = (uint32_t*)ctx->bLdFileSz.p; auto* storeSz = (uint32_t*)ctx->bLdStoreSz.p;
-        auto* fileOff = (uint32_t*)ctx->bLdFileOff.p; auto* storeOff = (uint32_t*)ctx->bLdStoreOff.p;
-        auto* counters = (unsigned long long*)ctx->bLdCounters.p;
-        HIP_TRY(ctx, hipMemcpyAsync(dkeys, keys + done, (size_t)nb * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dsizes, sizes + done, nb, hipMemcpyHostToDevice, st));
-        if (fileVals) HIP_TRY(ctx, hipMemcpyAsync(dvals, values, fileVals * vb, hipMemcpyHostToDevice, st));
-        launch_table_prep(dsizes, nb, maxLocs, rmOver, fileSz, storeSz, counters, st);
-        launch_scan_u32(fileSz, 1, nb, fileOff, nullptr, ctx->bLdScan.p, st);
-        launch_scan_u32(storeSz, 1, nb, storeOff, nullptr, ctx->bLdScan.p, st);
-        uint32_t stored = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));               // also: the pageable source buffers are free again
-        if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
-        launch_table_insert(dkeys, dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
-                            (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st);
-        launch_table_values(dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(st));               // staging buffers are reused by the next chunk
-        P.valuesStored += stored;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bLdKeys.p, keys + done, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bLdSizes.p, sizes + done, nb, hipMemcpyHostToDevice, st));
+        if (fileVals) HIP_TRY(ctx, hipMemcpyAsync(ctx->bLdVals.p, values, fileVals * vb, hipMemcpyHostToDevice, st));
+        rc = load_chunk_device(ctx, (const uint32_t*)ctx->bLdKeys.p, (const uint8_t*)ctx->bLdSizes.p, (const uint8_t*)ctx->bLdVals.p, nb, fileVals);
+        if (rc) return rc;
         values += fileVals * vb;
         done += nb;
     }
-    P.keysLoaded += n;
     return MC_OK;
 }
 

@@ -52,6 +52,10 @@ struct Slot {
     uint32_t submittedQueries = 0;
 };
 
+// table_build: insert one chunk of a single-part database whose batch arrays already live in device memory
+// (between mc_load_begin and mc_load_end; used by mc_load_batch after its upload and by the builder directly)
+int load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals);
+
 // error text for failures that have no context yet (mc_last_error(NULL))
 void set_global_error(const std::string& msg);
 
