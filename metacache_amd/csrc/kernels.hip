@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
     // loop iteration, no inner waits: a long chain delays only its own slot, not the wave.
     // (Measured alternatives at the same 1.2 ms: 8 lanes per 128-byte group with ballots; cooperative 4-lane
     // fetch of the bucket handed to its owner through LDS.)
-    uint32_t H = 0, n = 0, nfeat = 0, nfound = 0, nsteps = 0;
+    uint32_t H = 0, n = 0, m = 0, nfeat = 0, nfound = 0, nsteps = 0;
+    bool spill = false;
     uint32_t e = 0;                                              // next feature of this lane
     uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
     BucketRegs r[kLaneU];
@@ -1130,10 +1131,11 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
                 if (size) {
                     ++nfound;
                     H += size;
-                    if (H <= kLaneHits) {
-                        if (size == 1) L[n++] = pay;
-                        else for (uint32_t t = 0; t < size; ++t) L[n++] = tab.values[pay + t];
-                    }
+                    // singletons are the location itself; longer lists are only noted here (descriptor = first index |
+                    // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
+                    if (n + m >= kLaneHits) spill = true;                      // > 32 found features (pairs only)
+                    else if (size == 1) L[n++] = pay;
+                    else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
                     busy[u] = false;
                 } else if (anyFree || step[u] >= tab.maxProbe) {
                     busy[u] = false;                               // a bucket with a free slot ends the chain
@@ -1147,18 +1149,36 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
     }
     QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps;
     ws.qstat[q] = qs;
-    if (H > kLaneHits) {
-        // too long for a lane: leave (size, payload) per feature for the wave kernel
-        for (uint32_t e = 0; e < nf; ++e) {
-            uint32_t g, sz, st = 0; uint64_t pay; BucketRegs h;
-            const uint32_t f = feats[e];
-            probe_start(tab, f, g, h);
-            probe_finish(tab, f, g, h, sz, pay, st);
-            ws.psize[fbase + e] = sz; ws.ppay[fbase + e] = pay;
+    if (H > kLaneHits || spill) {
+        // too long for a lane: leave (size, payload) per found feature for the wave kernel -- straight from the row when
+        // everything was recorded (no second round of lookups), found features first, unused slots zeroed
+        if (!spill) {
+            for (uint32_t j = 0; j < n; ++j) { ws.psize[fbase + j] = 1u; ws.ppay[fbase + j] = L[j]; }
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint64_t d = L[kLaneHits - i];
+                ws.psize[fbase + n + i] = (uint32_t)(d >> 48); ws.ppay[fbase + n + i] = d & 0xFFFFFFFFFFFFull;
+            }
+            for (uint32_t j = n + m; j < nf; ++j) ws.psize[fbase + j] = 0u;
+        } else {
+            for (uint32_t e = 0; e < nf; ++e) {
+                uint32_t g, sz, st = 0; uint64_t pay; BucketRegs h;
+                const uint32_t f = feats[e];
+                probe_start(tab, f, g, h);
+                probe_finish(tab, f, g, h, sz, pay, st);
+                ws.psize[fbase + e] = sz; ws.ppay[fbase + e] = pay;
+            }
         }
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
         ws.qflag[q] = kFlagCands;
         return;
+    }
+    // fetch the noted lists, lowest row position first: the slot of a consumed descriptor is free before the hits reach it
+    // (every descriptor still waiting stands for >= 2 of the <= 32 hits)
+    for (uint32_t i = 0; i < m; ++i) {
+        const uint64_t d = L[kLaneHits - m + 1 + i];
+        const uint32_t size = (uint32_t)(d >> 48);
+        const uint64_t* __restrict__ src = tab.values + (d & 0xFFFFFFFFFFFFull);
+        for (uint32_t t = 0; t < size; ++t) L[n++] = src[t];
     }
     ws.hitScan[q] = 0;
     for (uint32_t t = 1; t < n; ++t) {                            // row 8: insertion sort by (tgt, win)
