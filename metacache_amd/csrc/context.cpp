@@ -191,7 +191,7 @@ void mc_destroy(mc_ctx* ctx)
     for (auto& p : ctx->parts) { if (p.dbuckets) (void)hipFree(p.dbuckets); if (p.dvalues) (void)hipFree(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     DevBuf* bufs[] = {&ctx->bWinCount, &ctx->bWinOff, &ctx->bFeatures, &ctx->bPsize, &ctx->bPpay, &ctx->bQstat, &ctx->bHitOff,
-                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist,
+                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist, &ctx->bMid,
                       &ctx->bLdKeys, &ctx->bLdSizes, &ctx->bLdVals, &ctx->bLdFileSz, &ctx->bLdStoreSz, &ctx->bLdFileOff, &ctx->bLdStoreOff,
                       &ctx->bLdScan, &ctx->bLdCounters};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -485,6 +485,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     if ((rc = ensure(ctx, ctx->bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bQflag, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bHitlist, 64))) return rc;
+    if (lanePath && (rc = ensure(ctx, ctx->bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->bScan, scan_tmp_bytes(n + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->bStats, 64))) return rc;
@@ -495,6 +496,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)ctx->bFeatures.p : nullptr; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
     ws.qstat = (QueryStat*)ctx->bQstat.p; ws.hitScan = (uint32_t*)ctx->bScanIn.p; ws.qflag = (uint32_t*)ctx->bQflag.p; ws.counter = (uint32_t*)ctx->bHitlist.p; ws.hitOff = (uint64_t*)ctx->bHitOff.p;
     ws.scanTmp = ctx->bScan.p; ws.stats = (uint64_t*)ctx->bStats.p;
+    if (lanePath) { ws.midCount = (uint32_t*)ctx->bMid.p; ws.midList = ws.midCount + 4; }
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
     const Part& P = ctx->parts[0];
@@ -510,7 +512,9 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
         { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
+        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 16, st));
         { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands", st); launch_mid_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }

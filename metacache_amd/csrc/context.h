@@ -84,7 +84,7 @@ struct mc_ctx {
 
     // workspace
     mcamd::DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
-        bCands, bScanIn, bQflag, bHitlist;
+        bCands, bScanIn, bQflag, bHitlist, bMid;
     // single-part tables are built on the device (table_build.hip): staging for one batch of the file
     mcamd::DevBuf bLdKeys, bLdSizes, bLdVals, bLdFileSz, bLdStoreSz, bLdFileOff, bLdStoreOff, bLdScan, bLdCounters;
     bool useLanePath = true;               // lane-parallel fast path for short reads (off: wave kernels only)

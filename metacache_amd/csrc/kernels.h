@@ -95,8 +95,10 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint64_t* ppay;          // [W*s]      payload per feature
     QueryStat* qstat;        // [n]
     uint32_t* qflag;         // [n]        0 = done, 1 = needs sketch+probe (wave), 2 = needs candidates (wave),
-                             //            4 = sketched by a lane (probe_cands_kernel takes it from there)
-    uint32_t* counter;       // [1]        dynamic chunk counter of probe_cands_kernel
+                             //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel
+    uint32_t* counter;       // [1]        (unused)
+    uint32_t* midCount;      // [4]        lengths of the three work lists of mid_cands_kernel (zeroed per batch)
+    uint32_t* midList;       // [3][n]     queries with 33..64 / 65..128 / 129..256 locations
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations
@@ -125,6 +127,8 @@ void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
 void launch_table_values(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
+void launch_mid_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                      const uint32_t* taxkey, void* cands, hipStream_t st);
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS

@@ -7,10 +7,12 @@
 // No MFMA anywhere: this is integer hashing and gathering; the bound is HBM/L2 random access.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace mcamd {
 
 // per-query state: what is still to be done (Workspace::qflag)
-constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagLaneCands = 3, kFlagProbe = 4;
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagLaneCands = 3, kFlagProbe = 4, kFlagMid = 5;
 
 // ================================================================================================
 // wave64 primitives
@@ -1069,6 +1071,53 @@ struct LaneCand { uint32_t tgt, hits, beg, end; };
 constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in u64): conflict-free lane-private rows
 constexpr uint32_t kLaneU = 4;                                // lookups in flight per lane
 constexpr uint32_t kLaneBlock = 128;
+constexpr uint32_t kMidMax = 256;                             // longest list taken by mid_cands_kernel
+
+// rows 10: one candidate enters the lane's top list exactly as on the CPU (candidate_generation.hpp:172-231)
+__device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK], LaneCand c, const uint32_t K,
+                                           const uint32_t* __restrict__ taxkey, const uint32_t tgtMask)
+{
+    uint32_t ctax = 0;
+    bool moving = false;
+    if (taxkey) {
+        // candidate_generation.hpp:178-216: full list and not better than its last entry -> ignored;
+        // no taxon -> skipped; taxon already listed -> replaced only by more hits, then moved up behind
+        // the entries with >= hits (std::sort on <= 16 elements = insertion sort)
+        uint32_t lastHits = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
+        if (lastHits > 0 && lastHits >= c.hits) return;
+        ctax = taxkey[c.tgt & tgtMask];
+        if (ctax == 0) return;
+        bool found = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) {
+            if (i < K && !found && top[i].hits > 0 && toptax[i] == ctax) {
+                found = true;
+                if (c.hits > top[i].hits) {
+                    top[i] = c;
+#pragma unroll
+                    for (uint32_t j = kLaneK - 1; j > 0; --j) {       // bubble up while strictly more hits
+                        if (j <= i && top[j].hits > top[j - 1].hits) {
+                            const LaneCand t = top[j]; top[j] = top[j - 1]; top[j - 1] = t;
+                            const uint32_t tt = toptax[j]; toptax[j] = toptax[j - 1]; toptax[j - 1] = tt;
+                        }
+                    }
+                }
+            }
+        }
+        if (found) return;
+    }
+    // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i) {
+        if (i < K && (moving || c.hits > top[i].hits)) {
+            const LaneCand t = top[i]; top[i] = c; c = t;
+            const uint32_t tt = toptax[i]; toptax[i] = ctax; ctax = tt;
+            moving = true;
+        }
+    }
+}
 
 __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                  const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
@@ -1169,7 +1218,21 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
             }
         }
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
-        ws.qflag[q] = kFlagCands;
+        // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
+        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : 3u;
+        ws.qflag[q] = cls < 3 ? kFlagMid : kFlagCands;
+        const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) {
+            const uint64_t mask = __ballot(cls == c);
+            if (cls == c) {
+                const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&ws.midCount[c], (uint32_t)__popcll(mask));
+                base = __shfl(base, leader);
+                ws.midList[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = q;
+            }
+        }
         return;
     }
     // fetch the noted lists, lowest row position first: the slot of a consumed descriptor is free before the hits reach it
@@ -1193,48 +1256,7 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
 #pragma unroll
     for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
     const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-    auto insert = [&](LaneCand c) {
-        uint32_t ctax = 0;
-        bool moving = false;
-        if (taxkey) {
-            // candidate_generation.hpp:178-216: full list and not better than its last entry -> ignored;
-            // no taxon -> skipped; taxon already listed -> replaced only by more hits, then moved up behind
-            // the entries with >= hits (std::sort on <= 16 elements = insertion sort)
-            uint32_t lastHits = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
-            if (lastHits > 0 && lastHits >= c.hits) return;
-            ctax = taxkey[c.tgt & tab.tgtMask];
-            if (ctax == 0) return;
-            bool found = false;
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) {
-                if (i < K && !found && top[i].hits > 0 && toptax[i] == ctax) {
-                    found = true;
-                    if (c.hits > top[i].hits) {
-                        top[i] = c;
-#pragma unroll
-                        for (uint32_t j = kLaneK - 1; j > 0; --j) {       // bubble up while strictly more hits
-                            if (j <= i && top[j].hits > top[j - 1].hits) {
-                                const LaneCand t = top[j]; top[j] = top[j - 1]; top[j - 1] = t;
-                                const uint32_t tt = toptax[j]; toptax[j] = toptax[j - 1]; toptax[j - 1] = tt;
-                            }
-                        }
-                    }
-                }
-            }
-            if (found) return;
-        }
-        // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
-#pragma unroll
-        for (uint32_t i = 0; i < kLaneK; ++i) {
-            if (i < K && (moving || c.hits > top[i].hits)) {
-                const LaneCand t = top[i]; top[i] = c; c = t;
-                const uint32_t tt = toptax[i]; toptax[i] = ctax; ctax = tt;
-                moving = true;
-            }
-        }
-    };
+    auto insert = [&](LaneCand c) { top_insert(top, toptax, c, K, taxkey, tab.tgtMask); };
     if (n > 0) {
         uint32_t fst = 0, hits = 1;
         LaneCand best; best.tgt = (uint32_t)(L[0] >> 32); best.hits = 1; best.beg = best.end = (uint32_t)L[0];
@@ -1274,6 +1296,208 @@ void launch_probe_cands(const BatchView& b, const SketchParams& sp, const Device
     if (b.n == 0) return;
     hipLaunchKernelGGL(probe_cands_kernel, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
                        taxkey, (mc_candidate_dev*)cands);
+}
+// ================================================================================================
+// mid_cands_kernel<G>: location lists of 33 .. 16*G entries (G = 4, 8, 16 lanes per query; 64/G queries per wave).
+// A whole wave per query (sort_candidates_kernel) spends ~10 k issue cycles on such a list, most of it waiting for
+// LDS round trips of a 64-lane bitonic sort.  Here every lane keeps 16 keys in REGISTERS (blocked layout: element
+// i of a query lives in lane i/16, register i%16), so 22 of the 28 compare-exchange stages of a 128-key sort are
+// register-to-register; only the stages with distance >= 16 cross lanes (one 64-bit shuffle per key).
+//   row 7    : gather through a small LDS list (row stride 17 u64: conflict-free for lane-private rows)
+//   row 8    : bitonic sort in registers, written back to LDS
+//   row 9    : every lane runs the CPU's sliding-window scan (candidate_generation.hpp:47-108) over its 16 keys; the
+//              left end of the first range comes from one binary search; per target run it emits (best end, hits)
+//   row 10   : lane 0 of the group walks the emitted segments in order, joins the pieces of runs that span lanes
+//              (strictly more hits wins = earliest best kept) and feeds top_insert -- the same code as the lane path
+// ================================================================================================
+constexpr uint32_t kMidR = 16;                                // keys per lane
+__device__ __forceinline__ uint32_t mid_ix(uint32_t i) { return i + (i >> 4); }   // list index -> padded LDS index
+
+__device__ __forceinline__ void ce64(uint64_t& a, uint64_t& b)              // ascending compare-exchange
+{
+    const bool sw = b < a;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+
+template <uint32_t G>
+__global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+                                                        const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, uint32_t cls)
+{
+    constexpr uint32_t QPW = 64 / G, N = G * kMidR, ROW = kMidR + 1;
+    __shared__ uint64_t listS[4][64 * ROW];
+    __shared__ uint32_t segS[4][64 * ROW];
+    __shared__ uint32_t cntS[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lg = lane % G, qi = lane / G;
+    uint64_t* buf = listS[wave] + qi * (G * ROW);            // this query's list, padded: element i at mid_ix(i)
+    uint32_t* segs = segS[wave] + lane * ROW;
+    const uint32_t total = ws.midCount[cls];
+    const uint32_t nWaves = gridDim.x * 4;
+    for (uint32_t w = blockIdx.x * 4 + wave; w * QPW < total; w += nWaves) {
+        const uint32_t slot = w * QPW + qi;
+        const bool act = slot < total;
+        const uint32_t q = act ? ws.midList[(size_t)cls * b.n + slot] : 0u;
+        uint32_t H = 0, maxWin = 1;
+        uint64_t key[kMidR];
+        if (act) {
+            H = ws.qstat[q].hits;
+            maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+            const uint32_t fbase = ws.winOff[q] * s, nf = (ws.winOff[q + 1] - ws.winOff[q]) * s;
+            // ---- row 7: (size, payload) entries -> list; G entries per round, exclusive offsets by a scan over the group
+            uint32_t base = 0;
+            for (uint32_t e0 = 0; e0 < nf; e0 += G) {
+                const uint32_t e = e0 + lg;
+                const uint32_t sz = e < nf ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
+                const uint64_t pay = e < nf ? ws.ppay[fbase + e] : 0ull;
+                uint32_t incl = sz;
+#pragma unroll
+                for (uint32_t d = 1; d < G; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d, G);
+                    if (lg >= d) incl += o;
+                }
+                uint32_t dst = base + incl - sz;
+                if (sz == 1) { if (dst < N) buf[mid_ix(dst)] = pay; }
+                else {
+                    const uint64_t* __restrict__ src = tab.values + pay;
+                    for (uint32_t t = 0; t < sz && dst + t < N; ++t) buf[mid_ix(dst + t)] = src[t];
+                }
+                base += __shfl(incl, G - 1, G);
+            }
+            for (uint32_t i = H + lg; i < N; i += G) buf[mid_ix(i)] = ~0ull;
+        }
+        wave_lds_sync();
+        if (act) {
+#pragma unroll
+            for (uint32_t r = 0; r < kMidR; ++r) key[r] = buf[lg * ROW + r];
+            // ---- row 8: bitonic sort, "flip" formulation (every merge ascending: the lower index keeps the minimum)
+#pragma unroll
+            for (uint32_t k = 2; k <= kMidR; k <<= 1) {
+#pragma unroll
+                for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ (k - 1); if (p > r) ce64(key[r], key[p]); }
+#pragma unroll
+                for (uint32_t j = k >> 2; j > 0; j >>= 1)
+#pragma unroll
+                    for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ j; if (p > r) ce64(key[r], key[p]); }
+            }
+#pragma unroll
+            for (uint32_t k = 2 * kMidR; k <= N; k <<= 1) {
+                {   // flip: partner element i ^ (k-1) = lane ^ (k/16 - 1), register 15 - r
+                    const uint32_t lm = k / kMidR - 1;
+                    const bool lower = (lg & (k / (2 * kMidR))) == 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < kMidR / 2; ++r) {
+                        const uint64_t o1 = __shfl_xor(key[kMidR - 1 - r], lm), o2 = __shfl_xor(key[r], lm);
+                        const uint64_t a = key[r], c = key[kMidR - 1 - r];
+                        key[r] = lower ? (o1 < a ? o1 : a) : (o1 > a ? o1 : a);
+                        key[kMidR - 1 - r] = lower ? (o2 < c ? o2 : c) : (o2 > c ? o2 : c);
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = k >> 2; j >= kMidR; j >>= 1) {
+                    const bool lower = (lg & (j / kMidR)) == 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < kMidR; ++r) {
+                        const uint64_t o = __shfl_xor(key[r], j / kMidR), a = key[r];
+                        key[r] = lower ? (o < a ? o : a) : (o > a ? o : a);
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = kMidR / 2; j > 0; j >>= 1)
+#pragma unroll
+                    for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ j; if (p > r) ce64(key[r], key[p]); }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kMidR; ++r) buf[lg * ROW + r] = key[r];
+        }
+        wave_lds_sync();
+        if (act) {
+            // ---- row 9: the CPU's scan over this lane's keys; list positions are < 256, hits <= 256
+            uint32_t nseg = 0;
+            const uint32_t i0 = lg * kMidR;
+            if (i0 < H) {
+                uint32_t curTgt = (uint32_t)(key[0] >> 32), fst = i0, hits = 1;
+                if (lg > 0 && (uint32_t)(buf[mid_ix(i0 - 1)] >> 32) == curTgt) {
+                    // the run began in an earlier lane: left end of the range that ends here (candidate_generation.hpp:79-85)
+                    const uint32_t win = (uint32_t)key[0];
+                    const uint32_t lowWin = win >= maxWin - 1 ? win - (maxWin - 1) : 0u;
+                    const uint64_t lb = (key[0] & 0xFFFFFFFF00000000ull) | lowWin;
+                    uint32_t lo = 0, hi = i0;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (buf[mid_ix(mid)] < lb) lo = mid + 1; else hi = mid; }
+                    fst = lo; hits = i0 - fst + 1;
+                }
+                uint32_t bestHits = hits, bestPos = i0;
+#pragma unroll
+                for (uint32_t r = 1; r < kMidR; ++r) {
+                    const uint32_t i = i0 + r;
+                    if (i < H) {
+                        const uint32_t tgt = (uint32_t)(key[r] >> 32), win = (uint32_t)key[r];
+                        if (tgt == curTgt) {
+                            ++hits;
+                            while (fst != i && (win - (uint32_t)buf[mid_ix(fst)]) >= maxWin) { --hits; ++fst; }
+                            if (hits > bestHits) { bestHits = hits; bestPos = i; }
+                        } else {
+                            segs[nseg++] = bestPos | (bestHits << 16);
+                            curTgt = tgt; fst = i; hits = 1; bestHits = 1; bestPos = i;
+                        }
+                    }
+                }
+                segs[nseg++] = bestPos | (bestHits << 16);
+            }
+            cntS[wave][lane] = nseg;
+        }
+        wave_lds_sync();
+        if (act && lg == 0) {
+            // ---- row 10: segments in list order; pieces of one target's run are adjacent
+            LaneCand top[kLaneK];
+            uint32_t toptax[kLaneK];
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
+            uint32_t pTgt = 0, pHits = 0, pPos = 0;
+            for (uint32_t l = 0; l < G; ++l) {
+                const uint32_t c = cntS[wave][lane + l];
+                const uint32_t* sg = segS[wave] + (lane + l) * ROW;
+                for (uint32_t j = 0; j < c; ++j) {
+                    const uint32_t sv = sg[j], pos = sv & 0xFFFFu, h = sv >> 16;
+                    const uint32_t tgt = (uint32_t)(buf[mid_ix(pos)] >> 32);
+                    if (pHits && tgt == pTgt) { if (h > pHits) { pHits = h; pPos = pos; } }
+                    else {
+                        if (pHits) { LaneCand x; x.tgt = pTgt; x.hits = pHits; x.beg = pPos; x.end = 0; top_insert(top, toptax, x, K, taxkey, tab.tgtMask); }
+                        pTgt = tgt; pHits = h; pPos = pos;
+                    }
+                }
+            }
+            if (pHits) { LaneCand x; x.tgt = pTgt; x.hits = pHits; x.beg = pPos; x.end = 0; top_insert(top, toptax, x, K, taxkey, tab.tgtMask); }
+            mc_candidate_dev* out = cands + (size_t)q * K;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i)
+                if (i < K) {
+                    mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+                    if (top[i].hits) {
+                        const uint32_t pos = top[i].beg;
+                        e.tgt = top[i].tgt & tab.tgtMask; e.hits = top[i].hits;
+                        e.end = (uint32_t)buf[mid_ix(pos)]; e.beg = (uint32_t)buf[mid_ix(pos + 1 - top[i].hits)];
+                    }
+                    out[i] = e;
+                }
+            ws.qflag[q] = kFlagDone;
+        }
+        wave_lds_sync();
+    }
+}
+
+void launch_mid_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                      const uint32_t* taxkey, void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    // persistent grids: the work lists are usually short (their lengths stay on the device)
+    const uint32_t blocks = 256 * 3;
+    hipLaunchKernelGGL(mid_cands_kernel<4>, dim3(std::min<uint32_t>(blocks, (b.n + 63) / 64)), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey,
+                       (mc_candidate_dev*)cands, 0u);
+    hipLaunchKernelGGL(mid_cands_kernel<8>, dim3(std::min<uint32_t>(blocks, (b.n + 31) / 32)), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey,
+                       (mc_candidate_dev*)cands, 1u);
+    hipLaunchKernelGGL(mid_cands_kernel<16>, dim3(std::min<uint32_t>(blocks, (b.n + 15) / 16)), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey,
+                       (mc_candidate_dev*)cands, 2u);
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }

@@ -234,3 +234,50 @@ def test_mode_p_single_parts_merge_equals_whole_database(golden):
     merged = merge_part_candidates(per_part).numpy().view(np.uint32)
     for f, j in (("tgt", 0), ("hits", 1), ("beg", 2), ("end", 3)):
         assert np.array_equal(merged[:, :, j], cw[f]), f
+
+
+@pytest.mark.parametrize("lowest,K", [(0, 2), (0, 4), (4, 2), (4, 3)])
+def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K):
+    """5 species x 8 strains (0.5 % divergence): a 150 bp read collects 50..250 locations over up to 8 targets, pairs more --
+    the list lengths handled by mid_cands_kernel (4 / 8 / 16 lanes per query, register bitonic sort), sequence level and
+    merged at species level, against the oracle."""
+    from metacache_amd import synth
+    rng = np.random.default_rng(4242 + lowest + K)
+    genomes, parents = [], []
+    for sp in range(5):
+        base = synth.random_genome(rng, 60_000)
+        for st in range(8):
+            genomes.append(synth.mutate(rng, base, 0.005) if st else base)
+            parents.append(1000 + sp)
+    bld = api.Builder(target_id_bytes=4, max_candidates=K)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"S{i:04d}.1", parent_taxid=parents[i])
+    name = str(tmp_path / "strains")
+    bld.finish(load=False)
+    bld.write(name, [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"sp{i}") for i in range(5)])
+    bld.free()
+    reads, _, _ = synth.sample_reads(rng, genomes, 6000, 150, 0.01, 0.002)
+    reads = [bytes(r) for r in reads]
+    mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:120] for r in reads[:1500]]
+    odb = cpuref.oracle().open(name)
+    db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 12, slot_max_chars=1 << 21)
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    pc, pcounts, _ = db.query(reads[:1500], mates, lowest=lowest, insert_max=400)
+    db.close()
+    assert 0.5 < np.mean((counts > 32) & (counts <= 256))          # most reads take the mid path
+    assert np.any((counts > 32) & (counts <= 64)) and np.any((counts > 64) & (counts <= 128)) and np.any(counts > 128)
+
+    def check(got, i, a, b, ins):
+        _, e = odb.query(a, b, K, lowest, ins)
+        e = e[:K]
+        for j in range(K):
+            if j < len(e):
+                assert (got[i, j]["tgt"], got[i, j]["hits"], got[i, j]["beg"], got[i, j]["end"]) == \
+                       (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]), (i, j, got[i], e)
+            else:
+                assert got[i, j]["hits"] == 0, (i, j, got[i], e)
+    for i in range(len(reads)):
+        check(cands, i, reads[i], b"", 0)
+    for i in range(1500):
+        check(pc, i, reads[i], mates[i], 400)
+    odb.close()
