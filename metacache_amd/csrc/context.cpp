@@ -485,7 +485,7 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     if ((rc = ensure(ctx, ctx->bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bQflag, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bHitlist, 64))) return rc;
-    if (lanePath && (rc = ensure(ctx, ctx->bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 4))) return rc;
+    if (lanePath && (rc = ensure(ctx, ctx->bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 16))) return rc;
     if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->bScan, scan_tmp_bytes(n + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->bStats, 64))) return rc;
@@ -514,7 +514,9 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
         { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
         HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 16, st));
         { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
-        { ScopedTimer t(ctx, "mid_cands", st); launch_mid_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }

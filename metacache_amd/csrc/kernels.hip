@@ -8,6 +8,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace mcamd {
 
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(&ws.midCount[c], (uint32_t)__popcll(mask));
                 base = __shfl(base, leader);
-                ws.midList[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = q;
+                reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nf, H);
             }
         }
         return;
@@ -1321,55 +1322,78 @@ __device__ __forceinline__ void ce64(uint64_t& a, uint64_t& b)              // a
 }
 
 template <uint32_t G>
-__global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+__global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
                                                         const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, uint32_t cls)
 {
-    constexpr uint32_t QPW = 64 / G, N = G * kMidR, ROW = kMidR + 1;
+    constexpr uint32_t QPW = 64 / G, N = G * kMidR, ROW = kMidR + 1, kRounds = 4;
     __shared__ uint64_t listS[4][64 * ROW];
     __shared__ uint32_t segS[4][64 * ROW];
-    __shared__ uint32_t cntS[4][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t lg = lane % G, qi = lane / G;
     uint64_t* buf = listS[wave] + qi * (G * ROW);            // this query's list, padded: element i at mid_ix(i)
-    uint32_t* segs = segS[wave] + lane * ROW;
+    uint32_t* sg = segS[wave] + qi * (G * ROW);              // entry offsets while gathering, then the query's segments
     const uint32_t total = ws.midCount[cls];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)cls * b.n;
     const uint32_t nWaves = gridDim.x * 4;
     for (uint32_t w = blockIdx.x * 4 + wave; w * QPW < total; w += nWaves) {
         const uint32_t slot = w * QPW + qi;
         const bool act = slot < total;
-        const uint32_t q = act ? ws.midList[(size_t)cls * b.n + slot] : 0u;
-        uint32_t H = 0, maxWin = 1;
+        uint32_t q = 0, H = 0, maxWin = 1, nent = 0;
         uint64_t key[kMidR];
         if (act) {
-            H = ws.qstat[q].hits;
+            const uint4 rec = work[slot];                        // {query, first feature slot, feature slots, locations}
+            q = rec.x; H = rec.w;
+            const uint32_t fbase = rec.y, nf = rec.z;
             maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-            const uint32_t fbase = ws.winOff[q] * s, nf = (ws.winOff[q + 1] - ws.winOff[q]) * s;
-            // ---- row 7: (size, payload) entries -> list; G entries per round, exclusive offsets by a scan over the group
+            // ---- row 7a: (size, payload) entries -> table of the FOUND entries in LDS (payload in the list area, start offset in
+            //      the segment area; at most one entry per location, so they always fit).  kRounds x G entries are loaded before
+            //      the first of them is used; slot index and start offset come from ONE scan over (size | found << 16).
             uint32_t base = 0;
-            for (uint32_t e0 = 0; e0 < nf; e0 += G) {
-                const uint32_t e = e0 + lg;
-                const uint32_t sz = e < nf ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
-                const uint64_t pay = e < nf ? ws.ppay[fbase + e] : 0ull;
-                uint32_t incl = sz;
+            for (uint32_t e0 = 0; e0 < nf; e0 += kRounds * G) {
+                uint32_t sz[kRounds]; uint64_t pay[kRounds];
 #pragma unroll
-                for (uint32_t d = 1; d < G; d <<= 1) {
-                    const uint32_t o = __shfl_up(incl, d, G);
-                    if (lg >= d) incl += o;
+                for (uint32_t u = 0; u < kRounds; ++u) {
+                    const uint32_t e = e0 + u * G + lg;
+                    sz[u] = e < nf ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
+                    pay[u] = e < nf ? ws.ppay[fbase + e] : 0ull;
                 }
-                uint32_t dst = base + incl - sz;
-                if (sz == 1) { if (dst < N) buf[mid_ix(dst)] = pay; }
-                else {
-                    const uint64_t* __restrict__ src = tab.values + pay;
-                    for (uint32_t t = 0; t < sz && dst + t < N; ++t) buf[mid_ix(dst + t)] = src[t];
+#pragma unroll
+                for (uint32_t u = 0; u < kRounds; ++u) {
+                    const uint32_t v = sz[u] | (sz[u] ? 1u << 16 : 0u);
+                    uint32_t incl = v;
+#pragma unroll
+                    for (uint32_t d = 1; d < G; d <<= 1) {
+                        const uint32_t o = __shfl_up(incl, d, G);
+                        if (lg >= d) incl += o;
+                    }
+                    const uint32_t ex = base + incl - v;
+                    if (sz[u]) { buf[ex >> 16] = pay[u]; sg[ex >> 16] = ex & 0xFFFFu; }
+                    base += __shfl(incl, G - 1, G);
                 }
-                base += __shfl(incl, G - 1, G);
             }
-            for (uint32_t i = H + lg; i < N; i += G) buf[mid_ix(i)] = ~0ull;
+            nent = base >> 16;
+            if (lg == 0) { sg[nent] = H; sg[nent + 1] = 0xFFFFFFFFu; }     // end of the last entry; stopper of the walk
         }
         wave_lds_sync();
         if (act) {
+            // ---- row 7b: element i of the list goes to lane i/16, register i%16: the lane finds the entry that holds its first
+            //      element, then walks; the 16 loads are independent of each other
+            const uint32_t i0 = lg * kMidR;
+            uint32_t lo = 0, hi = nent;                          // last entry with offset <= i0
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sg[mid] <= i0) lo = mid; else hi = mid; }
+            uint32_t e = lo;
 #pragma unroll
-            for (uint32_t r = 0; r < kMidR; ++r) key[r] = buf[lg * ROW + r];
+            for (uint32_t r = 0; r < kMidR; ++r) {
+                const uint32_t i = i0 + r;
+                while (sg[e + 1] <= i) ++e;                      // i >= H ends on the stopper entry
+                const uint64_t pay = buf[e];
+                const uint32_t first = sg[e];
+                const bool single = sg[e + 1] - first == 1;
+                key[r] = i >= H ? ~0ull : single ? pay : tab.values[pay + (i - first)];
+            }
+        }
+        wave_lds_sync();
+        if (act) {
             // ---- row 8: bitonic sort, "flip" formulation (every merge ascending: the lower index keeps the minimum)
 #pragma unroll
             for (uint32_t k = 2; k <= kMidR; k <<= 1) {
@@ -1411,10 +1435,26 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, uint32_t s,
             for (uint32_t r = 0; r < kMidR; ++r) buf[lg * ROW + r] = key[r];
         }
         wave_lds_sync();
+        uint32_t nsegTotal = 0;
         if (act) {
-            // ---- row 9: the CPU's scan over this lane's keys; list positions are < 256, hits <= 256
-            uint32_t nseg = 0;
+            // ---- row 9: the CPU's scan over this lane's keys (list positions < 256, hits <= 256).  Segments = (best end position |
+            //      hits << 16) per target run, written to ONE list per query: their number per lane is counted first.
             const uint32_t i0 = lg * kMidR;
+            uint32_t cnt = 0;
+            if (i0 < H) {
+                cnt = 1;
+#pragma unroll
+                for (uint32_t r = 1; r < kMidR; ++r)
+                    if (i0 + r < H && (uint32_t)(key[r] >> 32) != (uint32_t)(key[r - 1] >> 32)) ++cnt;
+            }
+            uint32_t incl = cnt;
+#pragma unroll
+            for (uint32_t d = 1; d < G; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, G);
+                if (lg >= d) incl += o;
+            }
+            nsegTotal = __shfl(incl, G - 1, G);
+            uint32_t nseg = incl - cnt;
             if (i0 < H) {
                 uint32_t curTgt = (uint32_t)(key[0] >> 32), fst = i0, hits = 1;
                 if (lg > 0 && (uint32_t)(buf[mid_ix(i0 - 1)] >> 32) == curTgt) {
@@ -1437,37 +1477,47 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, uint32_t s,
                             while (fst != i && (win - (uint32_t)buf[mid_ix(fst)]) >= maxWin) { --hits; ++fst; }
                             if (hits > bestHits) { bestHits = hits; bestPos = i; }
                         } else {
-                            segs[nseg++] = bestPos | (bestHits << 16);
+                            sg[nseg++] = bestPos | (bestHits << 16);
                             curTgt = tgt; fst = i; hits = 1; bestHits = 1; bestPos = i;
                         }
                     }
                 }
-                segs[nseg++] = bestPos | (bestHits << 16);
+                sg[nseg++] = bestPos | (bestHits << 16);
             }
-            cntS[wave][lane] = nseg;
         }
         wave_lds_sync();
         if (act && lg == 0) {
-            // ---- row 10: segments in list order; pieces of one target's run are adjacent
+            // ---- row 10: segments in list order; pieces of one target's run are adjacent.  Four segments (and their targets) are
+            //      fetched at a time; a candidate that cannot enter a full list is dropped with one comparison.
             LaneCand top[kLaneK];
             uint32_t toptax[kLaneK];
 #pragma unroll
             for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
-            uint32_t pTgt = 0, pHits = 0, pPos = 0;
-            for (uint32_t l = 0; l < G; ++l) {
-                const uint32_t c = cntS[wave][lane + l];
-                const uint32_t* sg = segS[wave] + (lane + l) * ROW;
-                for (uint32_t j = 0; j < c; ++j) {
-                    const uint32_t sv = sg[j], pos = sv & 0xFFFFu, h = sv >> 16;
-                    const uint32_t tgt = (uint32_t)(buf[mid_ix(pos)] >> 32);
-                    if (pHits && tgt == pTgt) { if (h > pHits) { pHits = h; pPos = pos; } }
-                    else {
-                        if (pHits) { LaneCand x; x.tgt = pTgt; x.hits = pHits; x.beg = pPos; x.end = 0; top_insert(top, toptax, x, K, taxkey, tab.tgtMask); }
-                        pTgt = tgt; pHits = h; pPos = pos;
+            uint32_t pTgt = 0, pHits = 0, pPos = 0, lastHits = 0;
+            auto flush = [&]() {
+                if (pHits > lastHits || lastHits == 0) {         // candidate_generation.hpp:178-181 and :189-201: otherwise no effect
+                    LaneCand x; x.tgt = pTgt; x.hits = pHits; x.beg = pPos; x.end = 0;
+                    top_insert(top, toptax, x, K, taxkey, tab.tgtMask);
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
+                }
+            };
+            for (uint32_t j0 = 0; j0 < nsegTotal; j0 += 4) {
+                uint32_t sv[4]; uint64_t kk[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) sv[u] = j0 + u < nsegTotal ? sg[j0 + u] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) kk[u] = buf[mid_ix(sv[u] & 0xFFFFu)];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    if (j0 + u < nsegTotal) {
+                        const uint32_t pos = sv[u] & 0xFFFFu, h = sv[u] >> 16, tgt = (uint32_t)(kk[u] >> 32);
+                        if (pHits && tgt == pTgt) { if (h > pHits) { pHits = h; pPos = pos; } }
+                        else { if (pHits) flush(); pTgt = tgt; pHits = h; pPos = pos; }
                     }
                 }
             }
-            if (pHits) { LaneCand x; x.tgt = pTgt; x.hits = pHits; x.beg = pPos; x.end = 0; top_insert(top, toptax, x, K, taxkey, tab.tgtMask); }
+            if (pHits) flush();
             mc_candidate_dev* out = cands + (size_t)q * K;
 #pragma unroll
             for (uint32_t i = 0; i < kLaneK; ++i)
@@ -1486,18 +1536,21 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, uint32_t s,
     }
 }
 
-void launch_mid_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
     // persistent grids: the work lists are usually short (their lengths stay on the device)
     const uint32_t blocks = 256 * 3;
-    hipLaunchKernelGGL(mid_cands_kernel<4>, dim3(std::min<uint32_t>(blocks, (b.n + 63) / 64)), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey,
-                       (mc_candidate_dev*)cands, 0u);
-    hipLaunchKernelGGL(mid_cands_kernel<8>, dim3(std::min<uint32_t>(blocks, (b.n + 31) / 32)), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey,
-                       (mc_candidate_dev*)cands, 1u);
-    hipLaunchKernelGGL(mid_cands_kernel<16>, dim3(std::min<uint32_t>(blocks, (b.n + 15) / 16)), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey,
-                       (mc_candidate_dev*)cands, 2u);
+    if (cls == 0)
+        hipLaunchKernelGGL(mid_cands_kernel<4>, dim3(std::min<uint32_t>(blocks, (b.n + 63) / 64)), dim3(256), 0, st, b, tab, ws, maxCand,
+                           taxkey, (mc_candidate_dev*)cands, 0u);
+    else if (cls == 1)
+        hipLaunchKernelGGL(mid_cands_kernel<8>, dim3(std::min<uint32_t>(blocks, (b.n + 31) / 32)), dim3(256), 0, st, b, tab, ws, maxCand,
+                           taxkey, (mc_candidate_dev*)cands, 1u);
+    else
+        hipLaunchKernelGGL(mid_cands_kernel<16>, dim3(std::min<uint32_t>(blocks, (b.n + 15) / 16)), dim3(256), 0, st, b, tab, ws, maxCand,
+                           taxkey, (mc_candidate_dev*)cands, 2u);
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }

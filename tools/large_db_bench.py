@@ -81,9 +81,12 @@ def main():
     out = torch.zeros((B, K, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
+    qst = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+
     def step(i):
         r = db.query_device(batches[i % len(batches)].data_ptr(), qinfo.data_ptr(), B, B * bench.PAD_LEN, max_win_uniform=max_win)
         db.copy_results(out.data_ptr(), r.cands, B * K * 16)
+        db.copy_results(qst.data_ptr(), r.hit_counts, B * 16)
         db.synchronize()
 
     for i in range(2):
@@ -94,13 +97,15 @@ def main():
         step(i)
     el = time.perf_counter() - t0
     db.timing(False)
-    kt = {k: db.timing_get(k) for k in ("plan", "sketch_lane", "probe_cands", "mid_cands", "query_wave", "scan", "sort_candidates")}
+    kt = {k: db.timing_get(k) for k in ("plan", "sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "scan", "sort_candidates")}
     st = db.last_batch_stats()
     c = out.cpu().numpy().view(np.uint32).reshape(B, K, 4)
     res["query"] = {"reads_per_step": B, "steps": args.steps, "ms_per_step": round(el / args.steps * 1e3, 3),
                     "Mreads_per_min": round(B * args.steps / el * 60 / 1e6, 1),
                     "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
                     "features_per_read": round(st["features"] / B, 2), "locations_per_read": round(st["locations"] / B, 2),
+                    "list_length_classes": {k: int(v) for k, v in zip(("<=32", "33-64", "65-128", "129-256", ">256"),
+                                                                       np.histogram(qst[:, 0].cpu().numpy(), bins=[0, 33, 65, 129, 257, 1 << 30])[0])},
                     "stats": st, "reads_with_candidate": float((c[:, 0, 1] > 0).mean()),
                     "mean_top_hits": float(c[:, 0, 1].mean())}
     print(json.dumps(res, indent=1))
