@@ -98,7 +98,7 @@ struct Workspace {           // device buffers sized by the host for this batch
                              //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel
     uint32_t* counter;       // [1]        (unused)
     uint32_t* midCount;      // [4]        lengths of the three work lists of mid_cands_kernel (zeroed per batch)
-    uint32_t* midList;       // [3][n] x uint4 {query, first feature slot, feature slots, locations}: lists of 33..64 / 65..128 / 129..256
+    uint32_t* midList;       // [3][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations

@@ -1200,24 +1200,30 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
     QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps;
     ws.qstat[q] = qs;
     if (H > kLaneHits || spill) {
-        // too long for a lane: leave (size, payload) per found feature for the wave kernel -- straight from the row when
-        // everything was recorded (no second round of lookups), found features first, unused slots zeroed
+        // too long for a lane: leave (size, payload) per found feature for the wave / mid kernels -- straight from the row when
+        // everything was recorded (no second round of lookups)
+        // entry j = (size | start offset in the list << 16, payload); found features only, in the first nent slots
+        uint32_t nent = 0, off = 0;
         if (!spill) {
-            for (uint32_t j = 0; j < n; ++j) { ws.psize[fbase + j] = 1u; ws.ppay[fbase + j] = L[j]; }
+            for (uint32_t j = 0; j < n; ++j) { ws.psize[fbase + j] = 1u | (j << 16); ws.ppay[fbase + j] = L[j]; }
+            off = n;
             for (uint32_t i = 0; i < m; ++i) {
                 const uint64_t d = L[kLaneHits - i];
-                ws.psize[fbase + n + i] = (uint32_t)(d >> 48); ws.ppay[fbase + n + i] = d & 0xFFFFFFFFFFFFull;
+                const uint32_t size = (uint32_t)(d >> 48);
+                ws.psize[fbase + n + i] = size | (off << 16); ws.ppay[fbase + n + i] = d & 0xFFFFFFFFFFFFull;
+                off += size;
             }
-            for (uint32_t j = n + m; j < nf; ++j) ws.psize[fbase + j] = 0u;
+            nent = n + m;
         } else {
             for (uint32_t e = 0; e < nf; ++e) {
                 uint32_t g, sz, st = 0; uint64_t pay; BucketRegs h;
                 const uint32_t f = feats[e];
                 probe_start(tab, f, g, h);
                 probe_finish(tab, f, g, h, sz, pay, st);
-                ws.psize[fbase + e] = sz; ws.ppay[fbase + e] = pay;
+                if (sz) { ws.psize[fbase + nent] = sz | (off << 16); ws.ppay[fbase + nent] = pay; ++nent; off += sz; }
             }
         }
+        if (H > kMidMax) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;   // the wave kernel reads all nf slots
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
         // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
         const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : 3u;
@@ -1231,7 +1237,7 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(&ws.midCount[c], (uint32_t)__popcll(mask));
                 base = __shfl(base, leader);
-                reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nf, H);
+                reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 8), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
             }
         }
         return;
@@ -1314,11 +1320,38 @@ void launch_probe_cands(const BatchView& b, const SketchParams& sp, const Device
 constexpr uint32_t kMidR = 16;                                // keys per lane
 __device__ __forceinline__ uint32_t mid_ix(uint32_t i) { return i + (i >> 4); }   // list index -> padded LDS index
 
-__device__ __forceinline__ void ce64(uint64_t& a, uint64_t& b)              // ascending compare-exchange
+// 64-bit keys live in two 32-bit registers each.  Ascending compare-exchange with ONE comparison: the borrow of the 64-bit
+// subtraction b - a is (b < a); four selects on it.  (Written as umin/umax the compiler emits two v_cmp_*_u64 per exchange.)
+__device__ __forceinline__ void ce64(uint32_t& a0, uint32_t& a1, uint32_t& b0, uint32_t& b1)
 {
-    const bool sw = b < a;
-    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
-    a = lo; b = hi;
+    uint32_t l0, l1, h0, h1, t;
+    asm("v_sub_co_u32 %4, vcc, %7, %5\n\t"
+        "v_subb_co_u32 %4, vcc, %8, %6, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %0, %5, %7, vcc\n\t"
+        "v_cndmask_b32 %1, %6, %8, vcc\n\t"
+        "v_cndmask_b32 %2, %7, %5, vcc\n\t"
+        "v_cndmask_b32 %3, %8, %6, vcc"
+        : "=&v"(l0), "=&v"(l1), "=&v"(h0), "=&v"(h1), "=&v"(t)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+        : "vcc");
+    a0 = l0; a1 = l1; b0 = h0; b1 = h1;
+}
+// cross-lane step: keep min(a, o) in the lanes of 'flipMask' == 0, max(a, o) in the others: select o where (o < a) != flip
+__device__ __forceinline__ void sel64(uint32_t& a0, uint32_t& a1, uint32_t o0, uint32_t o1, uint64_t flipMask)
+{
+    uint32_t r0, r1, t;
+    asm("v_sub_co_u32 %2, vcc, %5, %3\n\t"
+        "v_subb_co_u32 %2, vcc, %6, %4, vcc\n\t"
+        "s_nop 1\n\t"
+        "s_xor_b64 vcc, vcc, %7\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %0, %3, %5, vcc\n\t"
+        "v_cndmask_b32 %1, %4, %6, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(t)
+        : "v"(a0), "v"(a1), "v"(o0), "v"(o1), "s"(flipMask)
+        : "vcc");
+    a0 = r0; a1 = r1;
 }
 
 template <uint32_t G>
@@ -1335,45 +1368,42 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
     const uint32_t total = ws.midCount[cls];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)cls * b.n;
     const uint32_t nWaves = gridDim.x * 4;
-    for (uint32_t w = blockIdx.x * 4 + wave; w * QPW < total; w += nWaves) {
+    // two-deep software pipeline over the work list: the record of iteration t+2 and the first kRounds x G entries of iteration
+    // t+1 are requested while iteration t is processed (three dependent HBM round trips per query otherwise)
+    auto load_rec = [&](uint32_t w) -> uint4 {
         const uint32_t slot = w * QPW + qi;
-        const bool act = slot < total;
-        uint32_t q = 0, H = 0, maxWin = 1, nent = 0;
-        uint64_t key[kMidR];
+        return (w * QPW < total && slot < total) ? work[slot] : make_uint4(0, 0, 0, 0);      // .z (entries | locations << 8) == 0: idle group
+    };
+    uint32_t esz[kRounds]; uint64_t epay[kRounds];
+    auto load_entries = [&](const uint4& rec) {
+#pragma unroll
+        for (uint32_t u = 0; u < kRounds; ++u) {
+            const uint32_t e = u * G + lg;
+            esz[u] = e < (rec.z & 0xFFu) ? ws.psize[rec.y + e] : 0u;
+            epay[u] = e < (rec.z & 0xFFu) ? ws.ppay[rec.y + e] : 0ull;
+        }
+    };
+    const uint32_t w0 = blockIdx.x * 4 + wave;
+    uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
+    load_entries(rec);
+    for (uint32_t w = w0; w * QPW < total; w += nWaves) {
+        const bool act = rec.z != 0;
+        const uint32_t q = rec.x, fbase = rec.y, nent = rec.z & 0xFFu, H = rec.z >> 8, maxWin = rec.w;
+        uint32_t klo[kMidR], khi[kMidR];
         if (act) {
-            const uint4 rec = work[slot];                        // {query, first feature slot, feature slots, locations}
-            q = rec.x; H = rec.w;
-            const uint32_t fbase = rec.y, nf = rec.z;
-            maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-            // ---- row 7a: (size, payload) entries -> table of the FOUND entries in LDS (payload in the list area, start offset in
-            //      the segment area; at most one entry per location, so they always fit).  kRounds x G entries are loaded before
-            //      the first of them is used; slot index and start offset come from ONE scan over (size | found << 16).
-            uint32_t base = 0;
-            for (uint32_t e0 = 0; e0 < nf; e0 += kRounds * G) {
-                uint32_t sz[kRounds]; uint64_t pay[kRounds];
+            // ---- row 7a: entry table in LDS: payload in the list area, start offset in the segment area (at most one entry per
+            //      location, so it always fits)
 #pragma unroll
-                for (uint32_t u = 0; u < kRounds; ++u) {
-                    const uint32_t e = e0 + u * G + lg;
-                    sz[u] = e < nf ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
-                    pay[u] = e < nf ? ws.ppay[fbase + e] : 0ull;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kRounds; ++u) {
-                    const uint32_t v = sz[u] | (sz[u] ? 1u << 16 : 0u);
-                    uint32_t incl = v;
-#pragma unroll
-                    for (uint32_t d = 1; d < G; d <<= 1) {
-                        const uint32_t o = __shfl_up(incl, d, G);
-                        if (lg >= d) incl += o;
-                    }
-                    const uint32_t ex = base + incl - v;
-                    if (sz[u]) { buf[ex >> 16] = pay[u]; sg[ex >> 16] = ex & 0xFFFFu; }
-                    base += __shfl(incl, G - 1, G);
-                }
+            for (uint32_t u = 0; u < kRounds; ++u) {
+                const uint32_t e = u * G + lg;
+                if (e < nent) { buf[e] = epay[u]; sg[e] = esz[u] >> 16; }
             }
-            nent = base >> 16;
+            for (uint32_t e = kRounds * G + lg; e < nent; e += G) { buf[e] = ws.ppay[fbase + e]; sg[e] = ws.psize[fbase + e] >> 16; }
             if (lg == 0) { sg[nent] = H; sg[nent + 1] = 0xFFFFFFFFu; }     // end of the last entry; stopper of the walk
         }
+        rec = recNext;
+        recNext = load_rec(w + 2 * nWaves);
+        load_entries(rec);
         wave_lds_sync();
         if (act) {
             // ---- row 7b: element i of the list goes to lane i/16, register i%16: the lane finds the entry that holds its first
@@ -1389,7 +1419,8 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
                 const uint64_t pay = buf[e];
                 const uint32_t first = sg[e];
                 const bool single = sg[e + 1] - first == 1;
-                key[r] = i >= H ? ~0ull : single ? pay : tab.values[pay + (i - first)];
+                const uint64_t kv = i >= H ? ~0ull : single ? pay : tab.values[pay + (i - first)];
+                klo[r] = (uint32_t)kv; khi[r] = (uint32_t)(kv >> 32);
             }
         }
         wave_lds_sync();
@@ -1398,41 +1429,42 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
 #pragma unroll
             for (uint32_t k = 2; k <= kMidR; k <<= 1) {
 #pragma unroll
-                for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ (k - 1); if (p > r) ce64(key[r], key[p]); }
+                for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ (k - 1); if (p > r) ce64(klo[r], khi[r], klo[p], khi[p]); }
 #pragma unroll
                 for (uint32_t j = k >> 2; j > 0; j >>= 1)
 #pragma unroll
-                    for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ j; if (p > r) ce64(key[r], key[p]); }
+                    for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ j; if (p > r) ce64(klo[r], khi[r], klo[p], khi[p]); }
             }
 #pragma unroll
             for (uint32_t k = 2 * kMidR; k <= N; k <<= 1) {
                 {   // flip: partner element i ^ (k-1) = lane ^ (k/16 - 1), register 15 - r
                     const uint32_t lm = k / kMidR - 1;
-                    const bool lower = (lg & (k / (2 * kMidR))) == 0;
+                    const uint64_t upper = __ballot((lg & (k / (2 * kMidR))) != 0);
 #pragma unroll
                     for (uint32_t r = 0; r < kMidR / 2; ++r) {
-                        const uint64_t o1 = __shfl_xor(key[kMidR - 1 - r], lm), o2 = __shfl_xor(key[r], lm);
-                        const uint64_t a = key[r], c = key[kMidR - 1 - r];
-                        key[r] = lower ? (o1 < a ? o1 : a) : (o1 > a ? o1 : a);
-                        key[kMidR - 1 - r] = lower ? (o2 < c ? o2 : c) : (o2 > c ? o2 : c);
+                        const uint32_t p = kMidR - 1 - r;
+                        const uint32_t x0 = __shfl_xor(klo[p], lm), x1 = __shfl_xor(khi[p], lm);
+                        const uint32_t y0 = __shfl_xor(klo[r], lm), y1 = __shfl_xor(khi[r], lm);
+                        sel64(klo[r], khi[r], x0, x1, upper);
+                        sel64(klo[p], khi[p], y0, y1, upper);
                     }
                 }
 #pragma unroll
                 for (uint32_t j = k >> 2; j >= kMidR; j >>= 1) {
-                    const bool lower = (lg & (j / kMidR)) == 0;
+                    const uint64_t upper = __ballot((lg & (j / kMidR)) != 0);
 #pragma unroll
                     for (uint32_t r = 0; r < kMidR; ++r) {
-                        const uint64_t o = __shfl_xor(key[r], j / kMidR), a = key[r];
-                        key[r] = lower ? (o < a ? o : a) : (o > a ? o : a);
+                        const uint32_t o0 = __shfl_xor(klo[r], j / kMidR), o1 = __shfl_xor(khi[r], j / kMidR);
+                        sel64(klo[r], khi[r], o0, o1, upper);
                     }
                 }
 #pragma unroll
                 for (uint32_t j = kMidR / 2; j > 0; j >>= 1)
 #pragma unroll
-                    for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ j; if (p > r) ce64(key[r], key[p]); }
+                    for (uint32_t r = 0; r < kMidR; ++r) { const uint32_t p = r ^ j; if (p > r) ce64(klo[r], khi[r], klo[p], khi[p]); }
             }
 #pragma unroll
-            for (uint32_t r = 0; r < kMidR; ++r) buf[lg * ROW + r] = key[r];
+            for (uint32_t r = 0; r < kMidR; ++r) buf[lg * ROW + r] = ((uint64_t)khi[r] << 32) | klo[r];
         }
         wave_lds_sync();
         uint32_t nsegTotal = 0;
@@ -1445,7 +1477,7 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
                 cnt = 1;
 #pragma unroll
                 for (uint32_t r = 1; r < kMidR; ++r)
-                    if (i0 + r < H && (uint32_t)(key[r] >> 32) != (uint32_t)(key[r - 1] >> 32)) ++cnt;
+                    if (i0 + r < H && khi[r] != khi[r - 1]) ++cnt;
             }
             uint32_t incl = cnt;
 #pragma unroll
@@ -1456,12 +1488,12 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
             nsegTotal = __shfl(incl, G - 1, G);
             uint32_t nseg = incl - cnt;
             if (i0 < H) {
-                uint32_t curTgt = (uint32_t)(key[0] >> 32), fst = i0, hits = 1;
+                uint32_t curTgt = khi[0], fst = i0, hits = 1;
                 if (lg > 0 && (uint32_t)(buf[mid_ix(i0 - 1)] >> 32) == curTgt) {
                     // the run began in an earlier lane: left end of the range that ends here (candidate_generation.hpp:79-85)
-                    const uint32_t win = (uint32_t)key[0];
+                    const uint32_t win = klo[0];
                     const uint32_t lowWin = win >= maxWin - 1 ? win - (maxWin - 1) : 0u;
-                    const uint64_t lb = (key[0] & 0xFFFFFFFF00000000ull) | lowWin;
+                    const uint64_t lb = ((uint64_t)curTgt << 32) | lowWin;
                     uint32_t lo = 0, hi = i0;
                     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (buf[mid_ix(mid)] < lb) lo = mid + 1; else hi = mid; }
                     fst = lo; hits = i0 - fst + 1;
@@ -1471,7 +1503,7 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
                 for (uint32_t r = 1; r < kMidR; ++r) {
                     const uint32_t i = i0 + r;
                     if (i < H) {
-                        const uint32_t tgt = (uint32_t)(key[r] >> 32), win = (uint32_t)key[r];
+                        const uint32_t tgt = khi[r], win = klo[r];
                         if (tgt == curTgt) {
                             ++hits;
                             while (fst != i && (win - (uint32_t)buf[mid_ix(fst)]) >= maxWin) { --hits; ++fst; }
