@@ -226,7 +226,7 @@ def main():
         F, H = st["features"] / B, st["locations"] / B
         V = 6                                                 # uint16 target ids: 6-byte locations in the file format
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
-        dom = max(("sketch_lane", "probe_cands", "query_wave", "sort_candidates"), key=lambda k: kt[k][0])
+        dom = max(("sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "sort_candidates"), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * B / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom) if B == 1_000_000 else (None, None)
