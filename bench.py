@@ -78,8 +78,8 @@ def measured_traffic(kernel_timer_name: str):
     kernel's access pattern in profiles/r01_fetch_calibration.md: probe_cands reads 64-byte buckets = 64-byte
     sector requests, which are counted at their true size, so no doubling here.  None if no summary exists."""
     import csv, glob
-    names = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",),
-             "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",)}[kernel_timer_name]
+    names = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "sketch_probe": ("sketch_probe_lane",),
+             "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",)}.get(kernel_timer_name, ())
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), reverse=True):
         vals = {}
         for r in csv.DictReader(open(fn)):
@@ -221,12 +221,12 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kt = {k: db.timing_get(k) for k in ("plan", "sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "scan", "sort_candidates")}
+        kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "scan", "sort_candidates")}
         st = db.last_batch_stats()                            # of the last timed batch
         F, H = st["features"] / B, st["locations"] / B
         V = 6                                                 # uint16 target ids: 6-byte locations in the file format
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
-        dom = max(("sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "sort_candidates"), key=lambda k: kt[k][0])
+        dom = max(("sketch_probe", "sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "sort_candidates"), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * B / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom) if B == 1_000_000 else (None, None)

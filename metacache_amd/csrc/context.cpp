@@ -161,6 +161,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->loadFactor = (cfg->max_load_factor > 0.05f && cfg->max_load_factor <= 0.99f) ? cfg->max_load_factor : 0.5f;
     ctx->parts.resize(cfg->num_parts);
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
+    if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1';           // experiment switch
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream");
@@ -511,9 +512,14 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     const bool fuse = !wantAllhits && !taxkey;
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
-        { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
         HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 16, st));
-        { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        if (ctx->fuseLane) {
+            ScopedTimer t(ctx, "sketch_probe", st);
+            launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st);
+        } else {
+            { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
+            { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        }
         { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, ctx->bCands.p, st); }

@@ -88,6 +88,9 @@ struct mc_ctx {
     // single-part tables are built on the device (table_build.hip): staging for one batch of the file
     mcamd::DevBuf bLdKeys, bLdSizes, bLdVals, bLdFileSz, bLdStoreSz, bLdFileOff, bLdStoreOff, bLdScan, bLdCounters;
     bool useLanePath = true;               // lane-parallel fast path for short reads (off: wave kernels only)
+    bool fuseLane = false;                 // sketching + probing of the lane path in ONE kernel (MC_LANE_FUSION=1); measured
+                                           // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on
+                                           // strain-rich tables -- off by default
     uint32_t lastN = 0;
 
     // timing

@@ -127,6 +127,8 @@ void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
 void launch_table_values(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
+void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                              const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 bool lane_path_supported(const SketchParams& sp);

@@ -981,11 +981,9 @@ __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32
     }
 }
 
-__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, const uint32_t* __restrict__ winOff,
-                                                          uint32_t* __restrict__ features, uint32_t* __restrict__ qflag)
+__device__ __forceinline__ uint32_t sketch_lane_one(const BatchView& b, const SketchParams& sp, const uint32_t* __restrict__ winOff,
+                                                    uint32_t* features, const uint32_t q)
 {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= b.n) return;
     const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
     const uint32_t k = sp.k, s = sp.s, stride = sp.stride;
     const bool noTail = qi.w == kNoTail;
@@ -993,8 +991,7 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
     if (noTail || qi.y > kLaneMaxLen || qi.w > kLaneMaxLen) {
         const uint32_t nw = winOff[q + 1] - widx0;
         for (uint32_t i = 0; i < nw * s; ++i) features[(size_t)widx0 * s + i] = 0xFFFFFFFFu;   // nothing to probe here
-        qflag[q] = kFlagSketch;
-        return;
+        return kFlagSketch;
     }
     const uint32_t kmask = 0xFFFFFFFFu >> (32u - 2u * k);
     const uint32_t rcshift = 2u * k - 2u;
@@ -1054,7 +1051,15 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
             }
         }
     }
-    qflag[q] = dup ? kFlagSketch : kFlagProbe;
+    return dup ? kFlagSketch : kFlagProbe;
+}
+
+__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, const uint32_t* __restrict__ winOff,
+                                                          uint32_t* __restrict__ features, uint32_t* __restrict__ qflag)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= b.n) return;
+    qflag[q] = sketch_lane_one(b, sp, winOff, features, q);
 }
 
 // probe_cands_kernel: ONE LANE PER QUERY for rows 6-10.
@@ -1120,16 +1125,12 @@ __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&t
     }
 }
 
-__global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
-                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
+__device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32_t s, const DeviceTable& tab, const Workspace& ws, const uint32_t K,
+                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, const uint32_t q,
+                                                uint64_t* L)
 {
-    __shared__ uint64_t lst[kLaneBlock * kLaneRow];
-    const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
-    if (q >= b.n) return;
-    if (ws.qflag[q] != kFlagProbe) return;
-    uint64_t* L = lst + threadIdx.x * kLaneRow;
     const uint32_t fbase = ws.winOff[q] * s, nf = (ws.winOff[q + 1] - ws.winOff[q]) * s;
-    const uint32_t* __restrict__ feats = ws.features + fbase;
+    const uint32_t* feats = ws.features + fbase;
 
     // kLaneU lookup slots per lane, each a little state machine: a slot takes the lane's next feature and
     // issues the load of its home bucket; when the bucket arrives the lookup either ends (found / free slot
@@ -1290,6 +1291,39 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
             out[i] = e;
         }
     ws.qflag[q] = kFlagDone;
+}
+
+__global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ uint64_t lst[kLaneBlock * kLaneRow];
+    const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
+    if (q >= b.n) return;
+    if (ws.qflag[q] != kFlagProbe) return;
+    probe_cands_one(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow);
+}
+
+// Both halves in one kernel: sketching is ALU work (rolling k-mers, hash, 16-entry insertion chain), probing is waiting for random
+// HBM lines; with waves of one CU in different phases the two overlap instead of running one after the other.  The window
+// sketches still go through ws.features (a lane reads back what it wrote itself; they are also the MC_WANT_FEATURES output).
+__global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, uint32_t K,
+                                                                       const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ uint64_t lst[kLaneBlock * kLaneRow];
+    const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
+    if (q >= b.n) return;
+    const uint32_t flag = sketch_lane_one(b, sp, ws.winOff, ws.features, q);
+    if (flag != kFlagProbe) { ws.qflag[q] = flag; return; }
+    __threadfence_block();                                        // own feature stores before own feature loads
+    probe_cands_one(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow);
+}
+
+void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                              const uint32_t* taxkey, void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(sketch_probe_lane_kernel, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
+                       taxkey, (mc_candidate_dev*)cands);
 }
 
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)

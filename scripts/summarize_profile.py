@@ -14,10 +14,10 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(k):
-    if "sketch_probe_kernel<true>" in k: return "sketch_probe<probe>"
-    if "sketch_probe_kernel<false>" in k: return "sketch_probe<sketch-only>"
     if "query_kernel<true>" in k: return "query_kernel<fused>"
     if "query_kernel<false>" in k: return "query_kernel<unfused>"
+    if "sketch_probe_lane" in k: return "sketch_probe_lane"
+    if "mid_cands_kernel" in k: return "mid_cands"
     for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs"):
         if n in k: return n
     return None
