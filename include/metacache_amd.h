@@ -81,6 +81,11 @@ typedef struct {
     uint32_t copy_allhits;           /* 1: sorted location lists are copied back too (-allhits) */
     int32_t  single_part;            /* mc_open_database: -1 = load every part; p >= 0 = only <name>.cache<p>, as one part
                                         (database::read singlePartId, database.cpp:196-205) -- one part per GPU */
+    /* key sharding of ONE part over several GPUs ("Mode K"): only the features f with mc_key_owner(f, count) == index are
+     * kept while loading; count <= 1 keeps everything.  A sharded context answers mc_query_device(MC_WANT_ALLHITS) with
+     * the PARTIAL location lists of its keys; the union of all shards goes through mc_candidates_from_hits. */
+    uint32_t key_shard_index;
+    uint32_t key_shard_count;
 } mc_config;
 
 void mc_config_default(mc_config* cfg);
@@ -176,6 +181,21 @@ typedef struct {
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);
 int mc_synchronize(mc_ctx* ctx);
+
+/* Mode K.  Owner shard of a feature (independent of the table's own bucket hash). */
+uint32_t mc_key_owner(uint32_t feature, uint32_t shard_count);
+/* rows 8-10 on location lists that are already gathered (DEVICE pointers; query i = hits[hit_offsets[i] .. hit_offsets[i+1]),
+ * any order inside a list, e.g. the concatenated partial lists of all key shards): sort by (tgt, win), best window range per
+ * target, top candidates -- query_handler.hpp:75-101 + candidate_generation.hpp:47-231 on a single-part list.
+ * Results as mc_query_device (out->cands; out->hits / hit_offsets = the sorted lists).  Asynchronous on 'stream'. */
+typedef struct {
+    const mc_location* hits;
+    const uint64_t*    hit_offsets;   /* [n + 1] */
+    const uint32_t*    max_win;       /* [n] or NULL with max_win_uniform > 0 */
+    uint32_t           max_win_uniform;
+    uint32_t           num_queries;
+} mc_device_hits;
+int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowest_rank, mc_device_results* out, void* stream);
 /* copies out of the ctx-owned result buffers, asynchronous on the context's stream
  * (kind: 0 = device -> device, 1 = device -> host) */
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);

@@ -25,7 +25,8 @@ class McConfig(C.Structure):
                 ("winstride", C.c_uint32), ("max_candidates", C.c_uint32), ("target_id_bytes", C.c_uint32),
                 ("num_parts", C.c_uint32), ("max_locations_per_feature", C.c_uint32), ("remove_overpopulated", C.c_uint32),
                 ("max_load_factor", C.c_float), ("num_slots", C.c_uint32), ("slot_max_queries", C.c_uint32),
-                ("slot_max_chars", C.c_uint32), ("copy_allhits", C.c_uint32), ("single_part", C.c_int32)]
+                ("slot_max_chars", C.c_uint32), ("copy_allhits", C.c_uint32), ("single_part", C.c_int32),
+                ("key_shard_index", C.c_uint32), ("key_shard_count", C.c_uint32)]
 
 
 class McResults(C.Structure):
@@ -38,6 +39,11 @@ class McDeviceBatch(C.Structure):
                 ("num_queries", C.c_uint32), ("num_chars", C.c_uint64)]
 
 
+class McDeviceHits(C.Structure):
+    _fields_ = [("hits", C.c_void_p), ("hit_offsets", C.c_void_p), ("max_win", C.c_void_p), ("max_win_uniform", C.c_uint32),
+                ("num_queries", C.c_uint32)]
+
+
 class McDeviceResults(C.Structure):
     _fields_ = [("cands", C.c_void_p), ("hit_counts", C.c_void_p), ("hit_offsets", C.c_void_p), ("hits", C.c_void_p),
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
@@ -46,7 +52,7 @@ class McDeviceResults(C.Structure):
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end",
            "mc_open_database", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
-           "mc_copy_results",
+           "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
            "mc_build_begin", "mc_build_add_target", "mc_build_finish", "mc_build_write", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
@@ -90,6 +96,9 @@ def lib() -> C.CDLL:
         L.mc_batch_clear.argtypes = [C.c_void_p, C.c_uint32]
         L.mc_query_device.argtypes = [C.c_void_p, C.POINTER(McDeviceBatch), C.c_int, C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
         L.mc_synchronize.argtypes = [C.c_void_p]
+        L.mc_key_owner.argtypes = [C.c_uint32, C.c_uint32]
+        L.mc_key_owner.restype = C.c_uint32
+        L.mc_candidates_from_hits.argtypes = [C.c_void_p, C.POINTER(McDeviceHits), C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
         L.mc_copy_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.mc_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.mc_timing_reset.argtypes = [C.c_void_p]
@@ -257,6 +266,14 @@ class Database:
         r = McDeviceResults()
         self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0), C.byref(r),
                                           stream or None))
+        return r
+
+    def candidates_from_hits(self, hits_ptr: int, hit_offsets_ptr: int, n: int, max_win_ptr: int = 0, max_win_uniform: int = 0,
+                             lowest: int = 0, stream: int = 0) -> McDeviceResults:
+        """Mode K: rows 8-10 on gathered location lists (device pointers)"""
+        h = McDeviceHits(hits_ptr, hit_offsets_ptr, max_win_ptr or None, max_win_uniform, n)
+        r = McDeviceResults()
+        self._check(lib().mc_candidates_from_hits(self.h, C.byref(h), lowest, C.byref(r), stream or None))
         return r
 
     def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False):

@@ -86,7 +86,7 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     if (P.keysLoaded + nb > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
     if (fileVals >= (1ull << 32)) return fail(ctx, MC_ERR_INVALID, "load_chunk_device: chunk too large");
     const uint32_t tb = ctx->cfg.target_id_bytes;
-    const uint32_t maxLocs = ctx->cfg.max_locations_per_feature, rmOver = ctx->cfg.remove_overpopulated;
+    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count};
     hipStream_t st = ctx->stream;
     int rc = 0;
     if ((rc = ensure(ctx, ctx->bLdFileSz, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdStoreSz, (size_t)nb * 4)) ||
@@ -96,16 +96,16 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     auto* fileSz = (uint32_t*)ctx->bLdFileSz.p; auto* storeSz = (uint32_t*)ctx->bLdStoreSz.p;
     auto* fileOff = (uint32_t*)ctx->bLdFileOff.p; auto* storeOff = (uint32_t*)ctx->bLdStoreOff.p;
     auto* counters = (unsigned long long*)ctx->bLdCounters.p;
-    launch_table_prep(dsizes, nb, maxLocs, rmOver, fileSz, storeSz, counters, st);
+    launch_table_prep(dkeys, dsizes, nb, lf, fileSz, storeSz, counters, st);
     launch_scan_u32(fileSz, 1, nb, fileOff, nullptr, ctx->bLdScan.p, st);
     launch_scan_u32(storeSz, 1, nb, storeOff, nullptr, ctx->bLdScan.p, st);
     uint32_t stored = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
-    launch_table_insert(dkeys, dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
+    launch_table_insert(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
                         (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st);
-    launch_table_values(dsizes, nb, maxLocs, rmOver, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
+    launch_table_values(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));                   // staging buffers are reused by the next chunk
     P.valuesStored += stored;
@@ -132,6 +132,7 @@ void mc_config_default(mc_config* c)
     c->slot_max_chars = 1u << 24;
     c->copy_allhits = 0;
     c->single_part = -1;
+    c->key_shard_index = 0; c->key_shard_count = 1;
 }
 
 const char* mc_last_error(const mc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
@@ -147,6 +148,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (cfg->target_id_bytes != 2 && cfg->target_id_bytes != 4) return fail(nullptr, MC_ERR_INVALID, "target_id_bytes must be 2 or 4");
     if (cfg->num_parts < 1 || cfg->num_parts > 255) return fail(nullptr, MC_ERR_UNSUPPORTED, "num_parts must be 1..255");
     if (cfg->max_candidates < 1) return fail(nullptr, MC_ERR_INVALID, "max_candidates must be >= 1");
+    if (cfg->key_shard_count > 1 && cfg->key_shard_index >= cfg->key_shard_count) return fail(nullptr, MC_ERR_INVALID, "key_shard_index out of range");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -221,6 +223,14 @@ static int allocate_table(mc_ctx* ctx)
     Part& T = ctx->parts[0];
     uint64_t nkeys = 0, nvalues = 0;
     for (auto& p : ctx->parts) { nkeys += p.expectKeys; nvalues += p.expectValues; }
+    if (ctx->cfg.key_shard_count > 1) {
+        // Mode K: this context keeps ~1/count of the keys (hashed: near uniform) and of the locations (lumpier: wider margin;
+        // running out fails loudly in load_chunk_device)
+        if (ctx->parts.size() > 1) return fail(ctx, MC_ERR_UNSUPPORTED, "key sharding needs a single-part database");
+        const uint64_t c = ctx->cfg.key_shard_count;
+        nkeys = std::min<uint64_t>(nkeys, nkeys / c + nkeys / (8 * c) + 4096);
+        nvalues = std::min<uint64_t>(nvalues, nvalues / c + nvalues / (3 * c) + (1u << 16));
+    }
     uint64_t nb = (uint64_t)((double)nkeys / (kSlotsPerBucket * (double)ctx->loadFactor)) + 2;
     nb += nb & 1;                                            // two buckets per line
     if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
@@ -556,6 +566,49 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     out->hits = wantAllhits ? (const mc_location*)ws.hits : nullptr;
     out->features = ws.features;
     out->win_offsets = ws.winOff;
+    return MC_OK;
+}
+
+uint32_t mc_key_owner(uint32_t feature, uint32_t shardCount) { return key_owner(feature, shardCount); }
+
+int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRank, mc_device_results* out, void* streamv)
+{
+    if (!ctx || !in || !out || !in->hit_offsets) return MC_ERR_INVALID;
+    if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    const uint32_t n = in->num_queries;
+    const uint32_t K = ctx->cfg.max_candidates;
+    const uint32_t* taxkey = nullptr;
+    int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
+    if (rc) return rc;
+    uint64_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, in->hit_offsets + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const size_t hb = (size_t)(total + 1) * 8;
+    if ((rc = ensure(ctx, ctx->bHits, hb)) || (rc = ensure(ctx, ctx->bCscr, hb)) || (taxkey && (rc = ensure(ctx, ctx->bCscr2, hb)))) return rc;
+    if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, ctx->bQstat, (size_t)(n + 1) * sizeof(QueryStat))) ||
+        (rc = ensure(ctx, ctx->bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
+        return rc;
+    // the lists are sorted in place: work on a copy inside the context
+    if (total) HIP_TRY(ctx, hipMemcpyAsync(ctx->bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
+    Workspace ws{};
+    ws.hits = (uint64_t*)ctx->bHits.p; ws.cscr = (uint64_t*)ctx->bCscr.p; ws.cscr2 = (uint64_t*)ctx->bCscr2.p;
+    ws.hitOff = (uint64_t*)ctx->bHitOff.p; ws.qstat = (QueryStat*)ctx->bQstat.p;
+    BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
+    DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
+    {
+        ScopedTimer t(ctx, "cands_from_hits", st);
+        launch_cands_from_hits(b, tab, ws, taxkey, K, ctx->bCands.p, st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->lastN = 0;
+    out->cands = (const mc_candidate*)ctx->bCands.p;
+    out->hit_counts = (const uint32_t*)ctx->bQstat.p;
+    out->hit_offsets = ws.hitOff;
+    out->hits = (const mc_location*)ws.hits;
+    out->features = nullptr; out->win_offsets = nullptr;
     return MC_OK;
 }
 

@@ -41,6 +41,9 @@ __host__ __device__ inline uint32_t next_bucket(uint32_t home, uint32_t cur, uin
     return nx >= nbuckets ? 0u : nx;
 }
 
+// Mode K: which key shard owns a feature (a different mix than the bucket hash, so a shard's keys spread over its whole table)
+__host__ __device__ inline uint32_t key_owner(uint32_t key, uint32_t shards);
+
 // table hash: features are the SMALLEST hash values of a window, i.e. far from uniform in their
 // high bits, so they are mixed again (murmur3 fmix32) before the multiply-shift range reduction
 // bucket = (mix32(key) * nbuckets) >> 32.
@@ -48,6 +51,11 @@ __host__ __device__ inline uint32_t mix32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
+}
+
+__host__ __device__ inline uint32_t key_owner(uint32_t key, uint32_t shards)
+{
+    return shards <= 1 ? 0u : (uint32_t)(((uint64_t)mix32(key ^ 0x9E3779B9u) * shards) >> 32);
 }
 
 struct DeviceTable {
@@ -120,17 +128,20 @@ void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Worksp
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                         const uint32_t* taxkey, void* cands, hipStream_t st);
 // table_build.hip: GPU-side table construction from the file's batch stream
-void launch_table_prep(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, uint32_t* fileSz, uint32_t* storeSz,
+struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt; };   // load-time modifiers + key shard
+void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
                        unsigned long long* counters, hipStream_t st);
-void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff,
+void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff,
                          const uint32_t* storeOff, const uint8_t* vals, uint32_t tb, uint64_t storeBase, TableBucket* buckets,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
-void launch_table_values(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff, const uint32_t* storeOff,
+void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
+void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* taxkey, uint32_t maxCand,
+                            void* cands, hipStream_t st);
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS

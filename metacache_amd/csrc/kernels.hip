@@ -607,6 +607,42 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(
     }
 }
 
+// rows 8-10 on lists that are already gathered (Mode K: the union of the key shards' partial lists): ws.hits[hitOff[q] ..
+// hitOff[q+1]) in any order; sorted in place (LDS copy for short lists), the sorted list is written back.
+__global__ __launch_bounds__(256) void cands_from_hits_kernel(BatchView b, DeviceTable tab, Workspace ws, const uint32_t* __restrict__ taxkey,
+                                                              uint32_t K, mc_candidate_dev* __restrict__ cands)
+{
+    __shared__ SortLds lds[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (q >= b.n) return;
+    SortLds& L = lds[wave];
+    mc_candidate_dev* out = cands + (size_t)q * K;
+    const uint64_t hoff = ws.hitOff[q];
+    const uint64_t H64 = ws.hitOff[q + 1] - hoff;
+    if (lane == 0) { QueryStat qs; qs.hits = (uint32_t)min(H64, (uint64_t)0xFFFFFFFFu); qs.nfeat = 0; qs.nfound = 0; qs.nsteps = 0; ws.qstat[q] = qs; }
+    if (H64 == 0 || H64 > kMaxHitsPerQuery) { emit_empty(out, 0, K, lane); return; }
+    const uint32_t H = (uint32_t)H64;
+    const uint32_t maxWin = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+    if (H <= kLdsCap) {
+        for (uint32_t i = lane; i < H; i += 64) L.buf[i] = ws.hits[hoff + i];
+        wave_lds_sync();
+        sort_list<true>(L.buf, H, lane);
+        for (uint32_t i = lane; i < H; i += 64) ws.hits[hoff + i] = L.buf[i];
+        candidates_from_sorted<true>(L.buf, L.c, L.c2, H, maxWin, K, taxkey, tab.tgtMask, out, lane);
+    } else {
+        sort_list<false>(ws.hits + hoff, H, lane);
+        candidates_from_sorted<false>(ws.hits + hoff, ws.cscr + hoff, ws.cscr2 + hoff, H, maxWin, K, taxkey, tab.tgtMask, out, lane);
+    }
+}
+
+void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* taxkey, uint32_t maxCand,
+                            void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(cands_from_hits_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, tab, ws, taxkey, maxCand, (mc_candidate_dev*)cands);
+}
+
 void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws,
                             const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits, void* cands, hipStream_t st)
 {

@@ -14,11 +14,12 @@ namespace mcamd {
 
 namespace {
 
-__device__ __forceinline__ uint32_t effective_size(uint32_t fileSize, uint32_t maxLocs, uint32_t rmOver)
+__device__ __forceinline__ uint32_t effective_size(uint32_t key, uint32_t fileSize, const LoadFilter& lf)
 {
     uint32_t size = fileSize;
-    if (rmOver && size > rmOver) size = 0;                 // bucket emptied (host_hashmap.hpp:480-495)
-    if (maxLocs && size > maxLocs) size = maxLocs;         // keep the FIRST n values (:454-466)
+    if (lf.rmOver && size > lf.rmOver) size = 0;           // bucket emptied (host_hashmap.hpp:480-495)
+    if (lf.maxLocs && size > lf.maxLocs) size = lf.maxLocs; // keep the FIRST n values (:454-466)
+    if (lf.shardCnt > 1 && key_owner(key, lf.shardCnt) != lf.shardIdx) size = 0;   // Mode K: another GPU's key
     return size;
 }
 
@@ -31,7 +32,7 @@ __device__ __forceinline__ uint64_t decode_value(const uint8_t* p, uint32_t tb)
     return ((uint64_t)tgt << 32) | win;
 }
 
-__global__ __launch_bounds__(256) void table_prep_kernel(const uint8_t* __restrict__ sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver,
+__global__ __launch_bounds__(256) void table_prep_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n, LoadFilter lf,
                                                          uint32_t* __restrict__ fileSz, uint32_t* __restrict__ storeSz,
                                                          unsigned long long* __restrict__ counters)
 {
@@ -39,18 +40,17 @@ __global__ __launch_bounds__(256) void table_prep_kernel(const uint8_t* __restri
     uint32_t eff = 0;
     if (i < n) {
         const uint32_t fs = sizes[i];
-        eff = effective_size(fs, maxLocs, rmOver);
+        eff = effective_size(keys[i], fs, lf);
         fileSz[i] = fs;
         storeSz[i] = eff > 1 ? eff : 0;
     }
     // counters[0] = keys stored, [1] = locations kept: one atomic per wave
-    uint32_t keys = eff > 0 ? 1u : 0u, locs = eff;
-    for (int off = 32; off > 0; off >>= 1) { keys += __shfl_down(keys, off); locs += __shfl_down(locs, off); }
-    if ((threadIdx.x & 63) == 0 && keys) { atomicAdd(&counters[0], (unsigned long long)keys); atomicAdd(&counters[1], (unsigned long long)locs); }
+    uint32_t nk = eff > 0 ? 1u : 0u, locs = eff;
+    for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off); locs += __shfl_down(locs, off); }
+    if ((threadIdx.x & 63) == 0 && nk) { atomicAdd(&counters[0], (unsigned long long)nk); atomicAdd(&counters[1], (unsigned long long)locs); }
 }
 
-__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n,
-                                                           uint32_t maxLocs, uint32_t rmOver,
+__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n, LoadFilter lf,
                                                            const uint32_t* __restrict__ fileOff, const uint32_t* __restrict__ storeOff,
                                                            const uint8_t* __restrict__ vals, uint32_t tb, uint64_t storeBase,
                                                            TableBucket* __restrict__ buckets, uint32_t nbuckets,
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __res
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t eff = effective_size(sizes[i], maxLocs, rmOver);
-    if (eff == 0) return;
     const uint32_t key = keys[i];
+    const uint32_t eff = effective_size(key, sizes[i], lf);
+    if (eff == 0) return;
     const uint32_t home = (uint32_t)(((uint64_t)mix32(key) * nbuckets) >> 32);
     uint32_t cur = home, probe = 1, slot = kSlotsPerBucket;
     TableBucket* b = nullptr;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __res
     if (probe > 1) atomicMax(maxProbe, probe);
 }
 
-__global__ __launch_bounds__(256) void table_values_kernel(const uint8_t* __restrict__ sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver,
+__global__ __launch_bounds__(256) void table_values_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n, LoadFilter lf,
                                                            const uint32_t* __restrict__ fileOff, const uint32_t* __restrict__ storeOff,
                                                            const uint8_t* __restrict__ vals, uint32_t tb, uint64_t totalFileVals,
                                                            uint64_t* __restrict__ dst)
@@ -99,32 +99,32 @@ __global__ __launch_bounds__(256) void table_values_kernel(const uint8_t* __rest
         const uint32_t mid = lo + (hi - lo) / 2;
         if (fileOff[mid] <= v) lo = mid; else hi = mid;
     }
-    const uint32_t eff = effective_size(sizes[lo], maxLocs, rmOver);
+    const uint32_t eff = effective_size(keys[lo], sizes[lo], lf);
     const uint32_t t = (uint32_t)(v - fileOff[lo]);
     if (eff > 1 && t < eff) dst[storeOff[lo] + t] = decode_value(vals + v * (4 + tb), tb);
 }
 
 }  // namespace
 
-void launch_table_prep(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, uint32_t* fileSz, uint32_t* storeSz,
+void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
                        unsigned long long* counters, hipStream_t st)
 {
-    if (n) hipLaunchKernelGGL(table_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sizes, n, maxLocs, rmOver, fileSz, storeSz, counters);
+    if (n) hipLaunchKernelGGL(table_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys, sizes, n, lf, fileSz, storeSz, counters);
 }
 
-void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff,
+void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff,
                          const uint32_t* storeOff, const uint8_t* vals, uint32_t tb, uint64_t storeBase, TableBucket* buckets,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st)
 {
-    if (n) hipLaunchKernelGGL(table_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys, sizes, n, maxLocs, rmOver, fileOff, storeOff,
+    if (n) hipLaunchKernelGGL(table_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys, sizes, n, lf, fileOff, storeOff,
                               vals, tb, storeBase, buckets, nbuckets, maxProbe, full);
 }
 
-void launch_table_values(const uint8_t* sizes, uint32_t n, uint32_t maxLocs, uint32_t rmOver, const uint32_t* fileOff, const uint32_t* storeOff,
+void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st)
 {
     if (n && totalFileVals)
-        hipLaunchKernelGGL(table_values_kernel, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, sizes, n, maxLocs, rmOver,
+        hipLaunchKernelGGL(table_values_kernel, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, keys, sizes, n, lf,
                            fileOff, storeOff, vals, tb, totalFileVals, dst);
 }
 

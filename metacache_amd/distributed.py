@@ -85,3 +85,70 @@ def classify_partitioned(local: torch.Tensor, group=None) -> torch.Tensor:
     bufs = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(bufs, local.contiguous(), group=group)
     return merge_part_candidates(bufs)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Mode K: ONE database part whose features are key-sharded over the GPUs
+# (mc_config.key_shard_index / key_shard_count; every feature lives on exactly one GPU).  Per batch:
+#   1. every rank runs the hot path up to the sorted location lists on ALL reads of the batch against ITS keys
+#      (mc_query_device(MC_WANT_ALLHITS) on a sharded context) -> partial lists;
+#   2. the partial lists travel to the rank that owns the read (contiguous read shards, shard_bounds):
+#      one all-to-all of the per-read counts, one all-to-all-v of the locations (RCCL over xGMI);
+#   3. the owner concatenates the partial lists of each of its reads and runs rows 8-10 on the union
+#      (mc_candidates_from_hits) -- a full sort of the union = the single-part reference result, bit for bit.
+# (The sketches are recomputed on every rank instead of all-gathered: 0.28 ms per 10^6 reads of ALU work per rank
+#  against 128 MB of traffic per 10^6 reads; revisit when the sketch time shows up in the 8-GPU scaling.)
+# ------------------------------------------------------------------------------------------------------
+def exchange_partial_hits(counts: torch.Tensor, hits: torch.Tensor, group=None):
+    """counts: int64 [n] locations per read in this rank's partial lists; hits: int64 [sum(counts)] the lists back to back
+    in read order.  Returns for this rank's read shard [lo, hi): (per_source_counts int64 [world, hi-lo],
+    per_source_hits list of int64 tensors in source-rank order)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = counts.numel()
+    if world == 1:
+        return counts[None, :], [hits]
+    bounds = [shard_bounds(n, r, world) for r in range(world)]
+    lo, hi = bounds[rank]
+    send_reads = [b[1] - b[0] for b in bounds]
+    recv_counts = torch.empty(world * (hi - lo), dtype=torch.int64, device=counts.device)
+    dist.all_to_all_single(recv_counts, counts.contiguous(), output_split_sizes=[hi - lo] * world, input_split_sizes=send_reads, group=group)
+    recv_counts = recv_counts.view(world, hi - lo)
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=counts.device)
+    offs[1:] = torch.cumsum(counts, 0)
+    send_elems = [int(offs[b[1]] - offs[b[0]]) for b in bounds]
+    recv_elems = [int(x) for x in recv_counts.sum(dim=1).tolist()]
+    recv_hits = torch.empty(sum(recv_elems), dtype=hits.dtype, device=hits.device)
+    dist.all_to_all_single(recv_hits, hits.contiguous(), output_split_sizes=recv_elems, input_split_sizes=send_elems, group=group)
+    return recv_counts, list(torch.split(recv_hits, recv_elems))
+
+
+def union_partial_hits(per_source_counts: torch.Tensor, per_source_hits: list[torch.Tensor]):
+    """Concatenates, read by read, the partial lists of all sources (source order inside a read; the order does not matter,
+    the union is sorted afterwards).  -> (hit_offsets int64 [m + 1], hits int64 [total])"""
+    world, m = per_source_counts.shape
+    dev = per_source_counts.device
+    total_per_read = per_source_counts.sum(dim=0)
+    offsets = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(total_per_read, 0)
+    out = torch.empty(int(offsets[-1]), dtype=per_source_hits[0].dtype if per_source_hits else torch.int64, device=dev)
+    before = torch.zeros(m, dtype=torch.int64, device=dev)               # locations of earlier sources inside each read
+    for s in range(world):
+        c = per_source_counts[s]
+        ne = int(c.sum())
+        if ne:
+            src_off = torch.cumsum(c, 0) - c                             # start of each read inside this source's block
+            read_of = torch.repeat_interleave(torch.arange(m, device=dev), c)
+            within = torch.arange(ne, device=dev) - src_off[read_of]
+            out[offsets[:-1][read_of] + before[read_of] + within] = per_source_hits[s]
+        before = before + c
+    return offsets, out
+
+
+def classify_key_sharded(counts: torch.Tensor, hits: torch.Tensor, candidates_fn, group=None):
+    """counts/hits: this rank's partial lists for the WHOLE batch (step 1).  candidates_fn(hit_offsets, hits) -> int32
+    [m, K, 4] runs rows 8-10 for this rank's read shard (step 3).  Returns this rank's [m, K, 4] (gather_candidates hands
+    them to rank 0)."""
+    psc, psh = exchange_partial_hits(counts, hits, group=group)
+    offsets, union = union_partial_hits(psc, psh)
+    return candidates_fn(offsets, union)

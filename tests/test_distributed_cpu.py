@@ -134,3 +134,79 @@ def test_mode_p_one_part_per_rank_matches_intended_multipart(golden):
             else:
                 assert got[i, j, 1] == 0
     db.close()
+
+
+# ---- Mode K: features key-sharded over the ranks, partial location lists exchanged to the read's owner -------------------
+def _worker_mode_k(rank, world, port, n, K, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import cpuref
+    from metacache_amd import api
+    from metacache_amd.distributed import classify_key_sharded, gather_candidates
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gold = os.path.join(here, "golden")
+    z = np.load(os.path.join(gold, "toy_reads.npz"))
+    off = z["single_off"]
+    reads = [z["single"][int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+    orc = cpuref.oracle()
+    db = orc.open(os.path.join(gold, "toy32"))
+    owner = api.lib().mc_key_owner
+    # step 1 (stand-in for the sharded GPU context): this rank's partial lists = lookups of the features it owns
+    counts, chunks = [], []
+    for r in reads:
+        feats, cnt = orc.sketch(r, db.k, db.s, db.w, db.stride)
+        mine = [db.lookup(int(f)) for w in range(len(cnt)) for f in feats[w, :cnt[w]] if owner(int(f), world) == rank]
+        lst = np.concatenate(mine) if mine else np.zeros(0, dtype=np.uint64)
+        counts.append(len(lst)); chunks.append(lst)
+    counts_t = torch.tensor(counts, dtype=torch.int64)
+    hits_t = torch.from_numpy(np.concatenate(chunks).astype(np.int64)) if sum(counts) else torch.zeros(0, dtype=torch.int64)
+
+    def candidates(offsets, union):
+        m = offsets.numel() - 1
+        lo, _ = shard_bounds(n, rank, world)
+        out = torch.zeros((m, K, 4), dtype=torch.int32)
+        u = union.numpy().astype(np.uint64)
+        for i in range(m):
+            lst = np.sort(u[int(offsets[i]):int(offsets[i + 1])])                # row 8 on the union
+            max_win = 2 + len(reads[lo + i]) // db.stride
+            c = orc.candidates(lst, max_win, K)
+            for j in range(min(K, len(c))):
+                out[i, j] = torch.tensor([int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], dtype=torch.int64).to(torch.int32)
+        return out
+
+    local = classify_key_sharded(counts_t, hits_t, candidates)
+    parts = gather_candidates(local, dst=0)
+    if rank == 0:
+        q.put(torch.cat(parts, dim=0).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_mode_k_union_equals_whole_table(golden):
+    import cpuref
+    n, K, world = 160, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mode_k, args=(r, world, port, n, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, _, _ = golden.reads()
+    db = cpuref.oracle().open(golden.db_path("toy32"))
+    some = 0
+    for i in range(n):
+        _, c = db.query(single[i], b"", K, 0, 0)
+        for j in range(K):
+            if j < len(c):
+                assert tuple(int(x) for x in got[i, j].view(np.uint32)) == (int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])), (i, j)
+                some += 1
+            else:
+                assert got[i, j, 1] == 0
+    assert some > n
+    db.close()
