@@ -30,7 +30,7 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
         if "mcamd" in r["Name"]:
-            w.writerow([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+            w.writerow([r["Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 # 2. PMC counters per kernel (mean per dispatch over the dispatches of each separate --pmc pass)
 res = collections.defaultdict(lambda: collections.defaultdict(list))
