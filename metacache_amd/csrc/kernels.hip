@@ -1175,7 +1175,20 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     // (Measured alternatives at the same 1.2 ms: 8 lanes per 128-byte group with ballots; cooperative 4-lane
     // fetch of the bucket handed to its owner through LDS.)
     uint32_t H = 0, n = 0, m = 0, nfeat = 0, nfound = 0, nsteps = 0;
-    bool spill = false;
+    bool over = false;
+    uint32_t gnent = 0, goff = 0;                                // hand-over area: entries written, locations they stand for
+    // hand-over entry j = (size | start offset in the list << 16, payload); found features only, singletons first
+    auto dump_row = [&]() {
+        for (uint32_t j = 0; j < n; ++j) { ws.psize[fbase + j] = 1u | (j << 16); ws.ppay[fbase + j] = L[j]; }
+        goff = n;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint64_t d = L[kLaneHits - i];
+            const uint32_t size = (uint32_t)(d >> 48);
+            ws.psize[fbase + n + i] = size | (goff << 16); ws.ppay[fbase + n + i] = d & 0xFFFFFFFFFFFFull;
+            goff += size;
+        }
+        gnent = n + m;
+    };
     uint32_t e = 0;                                              // next feature of this lane
     uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
     BucketRegs r[kLaneU];
@@ -1220,7 +1233,11 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                     H += size;
                     // singletons are the location itself; longer lists are only noted here (descriptor = first index |
                     // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
-                    if (n + m >= kLaneHits) spill = true;                      // > 32 found features (pairs only)
+                    if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // > 32 found features (pairs): the row moves to
+                    if (over) {                                                      // the hand-over area, later entries go there directly
+                        ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
+                        ++gnent; goff += size;
+                    }
                     else if (size == 1) L[n++] = pay;
                     else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
                     busy[u] = false;
@@ -1236,30 +1253,11 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     }
     QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps;
     ws.qstat[q] = qs;
-    if (H > kLaneHits || spill) {
-        // too long for a lane: leave (size, payload) per found feature for the wave / mid kernels -- straight from the row when
-        // everything was recorded (no second round of lookups)
-        // entry j = (size | start offset in the list << 16, payload); found features only, in the first nent slots
-        uint32_t nent = 0, off = 0;
-        if (!spill) {
-            for (uint32_t j = 0; j < n; ++j) { ws.psize[fbase + j] = 1u | (j << 16); ws.ppay[fbase + j] = L[j]; }
-            off = n;
-            for (uint32_t i = 0; i < m; ++i) {
-                const uint64_t d = L[kLaneHits - i];
-                const uint32_t size = (uint32_t)(d >> 48);
-                ws.psize[fbase + n + i] = size | (off << 16); ws.ppay[fbase + n + i] = d & 0xFFFFFFFFFFFFull;
-                off += size;
-            }
-            nent = n + m;
-        } else {
-            for (uint32_t e = 0; e < nf; ++e) {
-                uint32_t g, sz, st = 0; uint64_t pay; BucketRegs h;
-                const uint32_t f = feats[e];
-                probe_start(tab, f, g, h);
-                probe_finish(tab, f, g, h, sz, pay, st);
-                if (sz) { ws.psize[fbase + nent] = sz | (off << 16); ws.ppay[fbase + nent] = pay; ++nent; off += sz; }
-            }
-        }
+    if (H > kLaneHits || over) {
+        // too long for a lane: (size, payload) per found feature go to the wave / mid kernels straight from the row -- no second
+        // round of lookups
+        if (!over) dump_row();
+        const uint32_t nent = gnent;
         if (H > kMidMax) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;   // the wave kernel reads all nf slots
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
         // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
