@@ -32,7 +32,7 @@ import torch  # noqa: E402  (plumbing: device memory, streams, torch.distributed
 import torch.distributed as dist  # noqa: E402
 
 from metacache_amd import api, synth  # noqa: E402
-from metacache_amd.distributed import gather_candidates  # noqa: E402
+from metacache_amd.distributed import gather_candidates_async  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--maxcand", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,8 +149,9 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     K = args.maxcand
@@ -185,20 +187,40 @@ def main():
     slack = torch.zeros(16, dtype=torch.uint8, device=dev)
     batches = [torch.cat([b, slack]) for b in batches]
     max_win = db.max_windows_in_range(READ_LEN)              # = 3 for 150 bp
-    out_cands = torch.zeros((B, K, 4), dtype=torch.int32, device=dev)
+    # N > 1: the per-rank candidate lists go to rank 0 over RCCL (north_star: "per-rank partial hit lists gathered over RCCL/xGMI
+    # before host-side taxonomy assignment").  Two buffers per rank: the gather of batch i runs while batch i+1 is computed.
+    dist_path = world > 1 or args.force_dist
+    nbuf = 2 if dist_path else 1
+    out_bufs = [torch.zeros((B, K, 4), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    out_cands = out_bufs[0]
+    recv = [[torch.zeros((B, K, 4), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(nbuf)] if dist_path and rank == 0 else None
+    works = [None] * nbuf
     torch.cuda.synchronize()
+
+    def finish(j: int):
+        if works[j] is not None:
+            works[j].wait()
+            torch.cuda.current_stream().synchronize()
+            works[j] = None
 
     def step(i: int):
         b = batches[i % nb]
+        j = i % nbuf
+        finish(j)                                            # the gather that used this buffer two batches ago
         res = db.query_device(b.data_ptr(), qinfo.data_ptr(), B, B * PAD_LEN, max_win_uniform=max_win)
-        db.copy_results(out_cands.data_ptr(), res.cands, B * K * 16)
+        db.copy_results(out_bufs[j].data_ptr(), res.cands, B * K * 16)
         db.synchronize()
-        if world > 1:                                        # per-rank hit lists -> rank 0 (RCCL over xGMI)
-            gather_candidates(out_cands, dst=0)
+        if dist_path:
+            works[j] = gather_candidates_async(out_bufs[j], recv[j] if recv is not None else None, dst=0)
         return res
+
+    def drain():
+        for j in range(nbuf):
+            finish(j)
 
     for i in range(args.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     db.timing(True)
     db.timing_reset()
@@ -209,6 +231,7 @@ def main():
     F_sum = H_sum = 0
     for i in range(args.steps):
         step(i)
+    drain()                                                  # every gather has arrived on rank 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -249,6 +272,7 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             res = step(0)
+            drain()
             db.synchronize()
             gpu_c = out_cands.cpu().numpy().view(np.uint32).reshape(B, K, 4)
             gc = np.zeros((B, K), dtype=api.cand_dtype)
@@ -259,7 +283,7 @@ def main():
             result["parity"] = par
         print(json.dumps(result), flush=True)
     db.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -39,6 +39,18 @@ def gather_candidates(local: torch.Tensor, dst: int = 0, group=None):
     return [b[: int(s.item())] for b, s in zip(bufs, sizes)]
 
 
+def gather_candidates_async(local: torch.Tensor, recv: list[torch.Tensor] | None, dst: int = 0, group=None):
+    """Equal shard sizes known in advance (the streaming case: fixed batches per rank): no size exchange, no host wait.
+    local: [m, K, 4] on every rank; recv: on dst a list of world tensors like local, elsewhere None.  Returns the
+    torch.distributed work handle (wait() before reusing local / reading recv), or None with a single rank.  The copy runs on
+    the backend's own stream / thread, i.e. concurrently with the next batch's kernels."""
+    if not dist.is_initialized():
+        if recv is not None:
+            recv[0].copy_(local)
+        return None
+    return dist.gather(local, recv if dist.get_rank(group) == dst else None, dst=dst, group=group, async_op=True)
+
+
 def classify_sharded(num_queries: int, classify_fn, dst: int = 0, group=None):
     """classify_fn(lo, hi) -> int32 tensor [hi-lo, K, 4] for queries lo..hi-1 (runs the hot path on
     this rank's GPU).  Returns on dst the concatenated [num_queries, K, 4] tensor, else None."""

@@ -210,3 +210,52 @@ def test_two_ranks_gloo_mode_k_union_equals_whole_table(golden):
                 assert got[i, j, 1] == 0
     assert some > n
     db.close()
+
+
+def _worker_async_gather(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    from metacache_amd.distributed import gather_candidates_async
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, K = 50, 2
+    bufs = [torch.zeros((m, K, 4), dtype=torch.int32) for _ in range(2)]
+    recv = [[torch.zeros((m, K, 4), dtype=torch.int32) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+    works = [None, None]
+    seen = []
+    for step in range(5):                                   # double buffering as in bench.py
+        j = step % 2
+        if works[j] is not None:
+            works[j].wait()
+            if rank == 0:
+                seen.append(torch.stack(recv[j]).clone())
+        bufs[j].fill_(1000 * step + rank)
+        works[j] = gather_candidates_async(bufs[j], recv[j] if recv is not None else None, dst=0)
+    for j in ((5 % 2), (6 % 2)):
+        if works[j] is not None:
+            works[j].wait()
+            if rank == 0:
+                seen.append(torch.stack(recv[j]).clone())
+    if rank == 0:
+        q.put(torch.stack(seen).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_async_gather_double_buffered():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async_gather, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)                                # [5 steps, world, m, K, 4]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got.shape[0] == 5
+    for step in range(5):
+        for r in range(world):
+            assert (got[step, r] == 1000 * step + r).all()
