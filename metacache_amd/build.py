@@ -73,7 +73,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     src = os.path.join(CSRC, "mcq_main.cpp")
     if force or _stale(MCQ, [src, LIB, os.path.join(ROOT, "include", "metacache_amd.h")]):
         cmd = ["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", MCQ,
-               "-L", LIBDIR, "-lmetacache_amd", "-Wl,-rpath,$ORIGIN/../lib", "-pthread"]
+               "-L", LIBDIR, "-lmetacache_amd", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-pthread"]
         if verbose:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -16,10 +16,12 @@
 //       [-no-query-params] [-no-summary] [-threads n (accepted, ignored)] [-batch-size n]
 #include "metacache_amd.h"
 
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <array>
@@ -100,15 +102,17 @@ struct Options {
     int hitsMin = 0; float hitsDiff = 1.0f;
     uint64_t maxCand = 2, insertMax = 0;
     enum Pairing { unpaired, files, sequences } pairing = unpaired;
-    bool tophits = false, allhits = false, queryIds = false, lineage = false, separateCols = false;
+    bool tophits = false, allhits = false, locations = false, queryIds = false, lineage = false, separateCols = false;
     bool showName = true, showRank = true, showId = false;
     enum MapView { mv_none, mv_mapped, mv_all } mapView = mv_all;
     bool collapseUnclassified = true;
     std::string comment = "# ", none = "--", column = "\t|\t", taxSep = ",", rankSuffix = ":", idPrefix = "(", idSuffix = ")";
-    bool showQueryParams = true, showSummary = true;
+    bool showQueryParams = true, showSummary = true, showErrors = true, splitOut = false;
     uint32_t sketchlen = 0, winlen = 0, winstride = 0, batchSize = 1u << 16;
     int maxLocs = -1, threads = 0;
     bool removeOverpopulated = false; float maxLoadFac = 0;
+    uint64_t minReadLen = 0, maxReadLen = std::numeric_limits<uint64_t>::max();
+    int64_t queryLimit = std::numeric_limits<int64_t>::max();
 };
 
 std::string sanitize_special_chars(const std::string& s)   // cmdline_utility: "\t" etc. typed literally
@@ -125,17 +129,37 @@ std::string sanitize_special_chars(const std::string& s)   // cmdline_utility: "
     return r;
 }
 
-Options parse(int argc, char** argv)
+// files_in_directory (filesys_utility.cpp:34-75): entries in readdir order, directories expanded at most 'recurse' levels deep
+std::vector<std::string> files_in_directory(std::string dirName, int recurse = 10)
 {
-    Options o;
-    if (argc < 4 || std::string(argv[1]) != "query") throw std::runtime_error("usage: mcq query <database> <sequence files>... [options]");
-    o.db = argv[2];
-    auto need = [&](int& i) -> std::string { if (i + 1 >= argc) throw std::runtime_error(std::string("value missing after '") + argv[i] + "'"); return argv[++i]; };
-    for (int i = 3; i < argc; ++i) {
-        const std::string a = argv[i];
+    while (!dirName.empty() && (dirName.back() == '/' || dirName.back() == '\\')) { dirName.pop_back(); break; }
+    std::vector<std::string> files;
+    if (DIR* dir = opendir(dirName.c_str())) {
+        while (dirent* e = readdir(dir)) {
+            const std::string nm = e->d_name;
+            if (nm == "." || nm == "..") continue;
+            const std::string path = dirName + "/" + nm;
+            std::vector<std::string> sub;
+            if (recurse > 0) sub = files_in_directory(path, recurse - 1);
+            if (sub.empty()) files.push_back(path); else files.insert(files.end(), sub.begin(), sub.end());
+        }
+        closedir(dir);
+    }
+    return files;
+}
+
+// Command line options of `metacache query` (options.cpp:860-1295); 'o' carries the defaults (interactive mode: the options of
+// the initial command line).  args = everything after the database name.
+Options parse(const std::vector<std::string>& args, Options o)
+{
+    o.infiles.clear();
+    auto need = [&](size_t& i) -> std::string { if (i + 1 >= args.size()) throw std::runtime_error("value missing after '" + args[i] + "'"); return args[++i]; };
+    for (size_t i = 0; i < args.size(); ++i) {
+        const std::string& a = args[i];
         if (a.empty()) continue;
         if (a[0] != '-') { o.infiles.push_back(a); continue; }
         if (a == "-out") o.outfile = need(i);
+        else if (a == "-split-out" || a == "-splitout") { o.splitOut = true; o.outfile = need(i); }
         else if (a == "-lowest") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); o.lowest = r; }
         else if (a == "-highest") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); o.highest = r; }
         else if (a == "-hitmin" || a == "-hit-min" || a == "-hits-min" || a == "-hitsmin") o.hitsMin = std::stoi(need(i));
@@ -143,6 +167,7 @@ Options parse(int argc, char** argv)
         else if (a == "-maxcand" || a == "-max-cand") o.maxCand = std::stoull(need(i));
         else if (a == "-tophits" || a == "-top-hits") o.tophits = true;
         else if (a == "-allhits" || a == "-all-hits") o.allhits = true;
+        else if (a == "-locations") { o.locations = true; o.tophits = true; }
         else if (a == "-queryids" || a == "-query-ids") o.queryIds = true;
         else if (a == "-mapped-only" || a == "-mappedonly") o.mapView = Options::mv_mapped;
         else if (a == "-no-map" || a == "-nomap") o.mapView = Options::mv_none;
@@ -151,10 +176,14 @@ Options parse(int argc, char** argv)
         else if (a == "-omit-ranks" || a == "-omitranks") o.showRank = false;
         else if (a == "-separate-cols" || a == "-separatecols") o.separateCols = true;
         else if (a == "-separator") o.column = sanitize_special_chars(need(i));
+        else if (a == "-comment") o.comment = need(i);
         else if (a == "-lineage" || a == "-lineages") o.lineage = true;
         else if (a == "-pairfiles" || a == "-pair-files" || a == "-paired-files") o.pairing = Options::files;
         else if (a == "-pairseq" || a == "-pair-seq" || a == "-paired-seq") o.pairing = Options::sequences;
         else if (a == "-insertsize" || a == "-insert-size") o.insertMax = std::stoull(need(i));
+        else if (a == "-min-readlen") o.minReadLen = std::stoull(need(i));
+        else if (a == "-max-readlen") o.maxReadLen = std::stoull(need(i));
+        else if (a == "-query-limit") o.queryLimit = std::stoll(need(i));
         else if (a == "-sketchlen") o.sketchlen = (uint32_t)std::stoul(need(i));
         else if (a == "-winlen") o.winlen = (uint32_t)std::stoul(need(i));
         else if (a == "-winstride") o.winstride = (uint32_t)std::stoul(need(i));
@@ -163,21 +192,32 @@ Options parse(int argc, char** argv)
         else if (a == "-max-load-fac" || a == "-max-load-factor") o.maxLoadFac = std::stof(need(i));
         else if (a == "-no-query-params" || a == "-no-queryparams") o.showQueryParams = false;
         else if (a == "-no-summary" || a == "-nosummary") o.showSummary = false;
+        else if (a == "-no-err" || a == "-no-errors") o.showErrors = false;
         else if (a == "-threads") o.threads = std::stoi(need(i));
         else if (a == "-batch-size" || a == "-batchsize") o.batchSize = (uint32_t)std::stoul(need(i));
         else throw std::runtime_error("unknown option '" + a + "'");
     }
     // process_query_options (options.cpp:1297-1366)
+    {   // replace_directories_with_contained_files (options.cpp:146-165)
+        std::vector<std::string> expanded;
+        for (const auto& name : o.infiles) {
+            auto sub = files_in_directory(name);
+            if (sub.empty()) expanded.push_back(name); else expanded.insert(expanded.end(), sub.begin(), sub.end());
+        }
+        o.infiles.swap(expanded);
+    }
     if (o.pairing == Options::files) { if (o.infiles.size() > 1) std::sort(o.infiles.begin(), o.infiles.end()); else o.pairing = Options::unpaired; }
     if (o.hitsDiff > 1) o.hitsDiff *= 0.01;       // double factor, as options.cpp:1312
     if (o.lowest > o.highest) o.lowest = o.highest;
+    if (o.batchSize < 1) o.batchSize = 1;
+    if (o.queryLimit < 0) o.queryLimit = 0;
     if (o.separateCols) { o.collapseUnclassified = false; o.taxSep = o.column; o.rankSuffix = o.column; o.idPrefix = o.column; o.idSuffix = ""; }
     if (o.mapView == Options::mv_none && o.tophits) o.mapView = Options::mv_mapped;
     else if (o.allhits) o.mapView = Options::mv_all;
     return o;
 }
 
-// ---- sequence files (uncompressed FASTA / 4-line FASTQ), memory-mapped ---------------------------------------------
+// ---- sequence files (FASTA / 4-line FASTQ; plain = memory-mapped, gzip = inflated into memory) ---------------------------------------------
 struct View { const char* p = nullptr; size_t n = 0; bool empty() const { return n == 0; } };
 
 class SeqFile {
@@ -187,15 +227,36 @@ public:
         fd_ = ::open(fn.c_str(), O_RDONLY);
         struct stat st;
         if (fd_ < 0 || fstat(fd_, &st) != 0) throw std::runtime_error("file '" + fn + "' could not be opened");
+        unsigned char magic[2] = {0, 0};
+        const bool gz = st.st_size >= 2 && pread(fd_, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (gz) {
+            // compressed input (the reference reads it through zlib as well): inflated into memory, then handled like a mapped file
+            gzFile g = gzdopen(dup(fd_), "rb");
+            if (!g) throw std::runtime_error("file '" + fn + "' could not be opened");
+            gzbuffer(g, 1u << 20);
+            size_t cap = std::max<size_t>((size_t)st.st_size * 4, 1u << 20);
+            own_.resize(cap);
+            for (;;) {
+                if (size_ == own_.size()) own_.resize(own_.size() * 2);
+                const int got = gzread(g, own_.data() + size_, (unsigned)std::min<size_t>(own_.size() - size_, 1u << 30));
+                if (got < 0) { gzclose(g); throw std::runtime_error("file '" + fn + "' could not be decompressed"); }
+                if (got == 0) break;
+                size_ += (size_t)got;
+            }
+            gzclose(g);
+            data_ = own_.data();
+            return;
+        }
         size_ = (size_t)st.st_size;
         if (size_) {
             void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
             if (m == MAP_FAILED) throw std::runtime_error("file '" + fn + "' could not be mapped");
             data_ = (const char*)m;
+            mapped_ = true;
             madvise(m, size_, MADV_SEQUENTIAL);
         }
     }
-    ~SeqFile() { if (data_) munmap((void*)data_, size_); if (fd_ >= 0) ::close(fd_); }
+    ~SeqFile() { if (mapped_) munmap((void*)data_, size_); if (fd_ >= 0) ::close(fd_); }
     SeqFile(const SeqFile&) = delete;
 
     // record starts = lines beginning with '>' (FASTA) or '@' header lines of 4-line FASTQ records; found by all threads
@@ -272,7 +333,8 @@ private:
     int fd_ = -1;
     const char* data_ = nullptr;
     size_t size_ = 0;
-    bool fastq_ = false;
+    bool fastq_ = false, mapped_ = false;
+    std::vector<char> own_;
     std::vector<uint64_t> starts_;
 };
 
@@ -370,52 +432,76 @@ uint32_t classify(const Options& o, const Taxonomy& tx, const std::vector<Cand>&
     return lca;
 }
 
-}  // namespace
+// ---- database session: the loaded context is kept between jobs (interactive mode) as long as its load-time settings fit ----
+struct Session {
+    mc_ctx* ctx = nullptr;
+    mc_config cfg{};
+    std::string db;
+    Taxonomy tx;
+    uint32_t dbStride = 0, dbSketch = 0, dbWinlen = 0;
+    unsigned threads = 1, workers = 1;
+    ~Session() { if (ctx) mc_destroy(ctx); }
 
-int main(int argc, char** argv)
-{
-    try {
-        Options o = parse(argc, argv);
-        if (o.infiles.empty()) throw std::runtime_error("no sequence files given");
-
-        mc_config cfg; mc_config_default(&cfg);
-        cfg.kmerlen = 0; cfg.sketchlen = o.sketchlen; cfg.winlen = o.winlen; cfg.winstride = o.winstride;
-        const bool unlimited = o.maxCand < 1;
-        cfg.max_candidates = unlimited ? 256 : (uint32_t)std::min<uint64_t>(o.maxCand, 4096);
-        cfg.copy_allhits = o.allhits ? 1 : 0;
+    void open(const Options& o)
+    {
+        mc_config c; mc_config_default(&c);
+        c.kmerlen = 0; c.sketchlen = o.sketchlen; c.winlen = o.winlen; c.winstride = o.winstride;
+        c.max_candidates = o.maxCand < 1 ? 256 : (uint32_t)std::min<uint64_t>(o.maxCand, 4096);
+        c.copy_allhits = o.allhits ? 1 : 0;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned threads = o.threads > 0 ? (unsigned)o.threads : hw;      // options.hpp: numThreads defaults to all hardware threads
-        const unsigned workers = std::min(threads, 48u);                        // one batch slot (pinned staging) per worker
-        cfg.num_slots = workers;
-        cfg.slot_max_queries = o.batchSize;
-        cfg.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
-        cfg.max_load_factor = o.maxLoadFac;
+        threads = o.threads > 0 ? (unsigned)o.threads : hw;                     // options.hpp: numThreads defaults to all hardware threads
+        workers = std::min(threads, 48u);                                       // one batch slot (pinned staging) per worker
+        c.num_slots = workers;
+        c.slot_max_queries = o.batchSize;
+        c.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
+        c.max_load_factor = o.maxLoadFac;
         if (o.removeOverpopulated) {                                            // read_database, mode_query.cpp:69-92
             int maxlpf = o.maxLocs - 1;
             if (maxlpf < 0 || maxlpf >= 254) maxlpf = 253;
-            cfg.remove_overpopulated = (uint32_t)maxlpf;                           // clamped to the DB's cap - 1 by mc_open_database
-            cfg.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
-        } else if (o.maxLocs > 1) cfg.max_locations_per_feature = (uint32_t)o.maxLocs;
-        mc_ctx* ctx = nullptr;
-        if (mc_open_database(o.db.c_str(), &cfg, &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+            c.remove_overpopulated = (uint32_t)maxlpf;                             // clamped to the DB's cap - 1 by mc_open_database
+            c.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
+        } else if (o.maxLocs > 1) c.max_locations_per_feature = (uint32_t)o.maxLocs;
+        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0) return;  // same table, same slots: keep it
+        if (ctx) { mc_destroy(ctx); ctx = nullptr; }
+        if (mc_open_database(o.db.c_str(), &c, &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+        cfg = c; db = o.db;
         uint64_t info[8]; mc_db_info(ctx, info);
-        const uint32_t dbStride = (uint32_t)info[3], dbSketch = (uint32_t)info[1];
-        if (o.hitsMin < 1) o.hitsMin = dbSketch >= 6 ? int(dbSketch / 3.0) : (dbSketch >= 4 ? 2 : 1);        // querying.cpp:257-268
+        dbSketch = (uint32_t)info[1]; dbWinlen = (uint32_t)info[2]; dbStride = (uint32_t)info[3];
+        tx = Taxonomy{};
+        uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
+        for (uint64_t i = 0; i < nt; ++i) {
+            uint32_t rk; const char* nm;
+            mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
+            tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm; tx.byId.emplace(tx.taxa[i].id, (uint32_t)i);
+        }
+        mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets);
+    }
+};
 
-        Taxonomy tx;
-        { uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
-          for (uint64_t i = 0; i < nt; ++i) { uint32_t rk; const char* nm; mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm); tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm; tx.byId.emplace(tx.taxa[i].id, (uint32_t)i); }
-          mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets); }
+// process_input_files (querying.cpp:40-128): parameters, table layout, mappings of all given files, summary -> one output
+void run_job(Session& S, Options o, const std::vector<std::string>& infiles, const std::string& outfile)
+{
+        S.open(o);
+        mc_ctx* ctx = S.ctx;
+        const Taxonomy& tx = S.tx;
+        const mc_config& cfg = S.cfg;
+        const uint32_t dbStride = S.dbStride, dbSketch = S.dbSketch;
+        const unsigned threads = S.threads, workers = S.workers;
+        const bool unlimited = o.maxCand < 1;
+        if (o.hitsMin < 1) o.hitsMin = dbSketch >= 6 ? int(dbSketch / 3.0) : (dbSketch >= 4 ? 2 : 1);        // querying.cpp:257-268
+        o.infiles = infiles;
 
         std::ofstream fout;
-        if (!o.outfile.empty()) { fout.open(o.outfile); if (!fout.good()) throw std::runtime_error("could not write to file " + o.outfile); }
-        std::ostream& os = o.outfile.empty() ? std::cout : fout;
+        if (!outfile.empty()) { fout.open(outfile); if (!fout.good()) throw std::runtime_error("Could not write to file " + outfile); }
+        std::ostream& os = outfile.empty() ? std::cout : fout;
 
         if (o.showQueryParams) {                                                 // printing.cpp:47-131
             if (o.mapView != Options::mv_none) {
                 os << o.comment << "Reporting per-read mappings (non-mapping lines start with '" << o.comment << "').\n";
                 os << o.comment << (o.lineage ? "The complete lineage will be reported starting with the lowest match.\n" : "Only the lowest matching rank will be reported.\n");
             } else os << o.comment << "Per-Read mappings will not be shown.\n";
+            if (o.minReadLen > 0) os << o.comment << "Only reads with a minimum length of " << o.minReadLen << " bp will be mapped.\n";
+            if (o.maxReadLen < std::numeric_limits<uint64_t>::max()) os << o.comment << "Only reads with a maximum length of " << o.maxReadLen << " bp will be mapped.\n";
             os << o.comment << "Classification will be constrained to ranks from '" << kRankNames[o.lowest] << "' to '" << kRankNames[o.highest] << "'.\n";
             os << o.comment << "Classification hit threshold is " << o.hitsMin << " per query\n";
             os << o.comment << "At maximum " << (unlimited ? std::numeric_limits<size_t>::max() : o.maxCand) << " classification candidates will be considered per query.\n";
@@ -429,6 +515,7 @@ int main(int argc, char** argv)
             os << "query_header" << o.column;
             if (o.allhits) os << "all_hits" << o.column;
             if (o.tophits) os << "top_hits" << o.column;
+            if (o.locations) os << "candidate_locations" << o.column;
             const int rmax = o.lineage ? o.highest : o.lowest;
             auto hdr = [&](int r, bool named) {
                 if (o.showRank) os << (named ? kRankNames[r] : "rank") << o.rankSuffix;
@@ -443,9 +530,11 @@ int main(int argc, char** argv)
         uint64_t assigned[kNumRanks + 1] = {};                                   // classification_statistics::assign
 
         // ---- all inputs are indexed first: batches = runs of consecutive queries, ids continue across files -------------
-        struct Batch { size_t f1, f2; size_t qBeg, qEnd; uint64_t firstId; std::string prefix; };
+        struct Batch { size_t f1, f2; size_t qBeg, qEnd; uint64_t idBase; std::string prefix; const std::vector<uint64_t>* sel; };
         std::vector<std::unique_ptr<SeqFile>> files;
+        std::vector<std::unique_ptr<std::vector<uint64_t>>> selections;
         std::vector<Batch> batches;
+        const bool lengthFilter = o.minReadLen > 0 || o.maxReadLen < std::numeric_limits<uint64_t>::max();
         {
             uint64_t idOffset = 0;
             const size_t stride = o.pairing == Options::files ? 2 : 1;
@@ -466,12 +555,42 @@ int main(int argc, char** argv)
                         files.back()->index(workers);
                         nq = std::min(nq, files.back()->records());
                     }
-                } catch (std::exception& e) { std::cerr << "FAIL: " << e.what() << '\n'; nq = 0; }   // database_query.hpp:397-399
-                for (size_t q = 0; q == 0 || q < nq; q += o.batchSize) {
-                    batches.push_back(Batch{f1, f2, q, std::min<size_t>(nq, q + o.batchSize), idOffset + q, q == 0 ? prefix : std::string()});
-                    if (nq == 0) break;
+                } catch (std::exception& e) { if (o.showErrors) std::cerr << "FAIL: " << e.what() << '\n'; nq = 0; }   // database_query.hpp:397-399
+                // query_batched (database_query.hpp:258-284): at most -query-limit queries per file; with a read length filter a
+                // query that fails it is replaced by the next record -- except when the file ends there
+                const std::vector<uint64_t>* sel = nullptr;
+                size_t nsel = std::min<uint64_t>(nq, (uint64_t)o.queryLimit), nread = nsel;
+                if (lengthFilter && nq > 0) {
+                    std::vector<uint32_t> len(nq);
+                    {
+                        std::vector<std::thread> pool;
+                        const size_t per = (nq + workers - 1) / workers;
+                        for (unsigned t = 0; t < workers; ++t)
+                            pool.emplace_back([&, t] {
+                                View h, sq; std::string scratch;
+                                for (size_t q = t * per; q < std::min(nq, (t + 1) * per); ++q) {
+                                    files[f1]->record(o.pairing == Options::sequences ? 2 * q : q, h, sq, scratch);
+                                    len[q] = (uint32_t)std::min<size_t>(sq.n, 0xFFFFFFFFu);
+                                }
+                            });
+                        for (auto& th : pool) th.join();
+                    }
+                    auto fails = [&](size_t q) { return len[q] < o.minReadLen || len[q] > o.maxReadLen; };
+                    selections.emplace_back(new std::vector<uint64_t>());
+                    auto& kept = *selections.back();
+                    size_t q = 0, discarded = 0;
+                    for (int64_t limit = o.queryLimit; q < nq && limit >= 1; --limit) {
+                        size_t cur = q++;
+                        while (fails(cur)) { ++discarded; if (q >= nq) break; cur = q++; }
+                        kept.push_back(cur);
+                    }
+                    nread = q; nsel = kept.size(); sel = &kept;
                 }
-                idOffset += nq;
+                for (size_t q = 0; q == 0 || q < nsel; q += o.batchSize) {
+                    batches.push_back(Batch{f1, f2, q, std::min<size_t>(nsel, q + o.batchSize), idOffset, q == 0 ? prefix : std::string(), sel});
+                    if (nsel == 0) break;
+                }
+                idOffset += nread;                                               // reader.index(): records (pairs) consumed
             }
         }
 
@@ -505,12 +624,13 @@ int main(int argc, char** argv)
                     metas.clear();
                     for (; q < B.qEnd; ++q) {
                         View h1, s1, h2, s2;
+                        const size_t qi = B.sel ? (size_t)(*B.sel)[q] : q;          // query index inside the file (pair)
                         if (o.pairing == Options::sequences) {
-                            files[B.f1]->record(2 * q, h1, s1, scratch1);
-                            if (2 * q + 1 < files[B.f1]->records()) files[B.f1]->record(2 * q + 1, h2, s2, scratch2);
+                            files[B.f1]->record(2 * qi, h1, s1, scratch1);
+                            if (2 * qi + 1 < files[B.f1]->records()) files[B.f1]->record(2 * qi + 1, h2, s2, scratch2);
                         } else {
-                            files[B.f1]->record(q, h1, s1, scratch1);
-                            if (o.pairing == Options::files) files[B.f2]->record(q, h2, s2, scratch2);
+                            files[B.f1]->record(qi, h1, s1, scratch1);
+                            if (o.pairing == Options::files) files[B.f2]->record(qi, h2, s2, scratch2);
                         }
                         if (std::max(s1.n, s2.n) >= 0xFFFFFFF0ull) { fail("sequence too long"); break; }
                         const uint32_t maxWin = (uint32_t)(2 + std::max<uint64_t>(s1.n + s2.n, o.insertMax) / dbStride);   // candidate_structs.hpp:143-145
@@ -522,7 +642,7 @@ int main(int argc, char** argv)
                             continue;
                         }
                         if (rc < 0) { fail(mc_last_error(ctx)); break; }
-                        metas.push_back(Meta{B.firstId + (q - B.qBeg) + 1, h1, h1.empty() || s1.empty()});
+                        metas.push_back(Meta{B.idBase + qi + 1, h1, h1.empty() || s1.empty()});
                     }
                     if (failed) break;
                     mc_results r;
@@ -552,6 +672,10 @@ int main(int argc, char** argv)
                         out << o.column;
                         if (o.allhits) { show_matches(out, o, tx, r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i]); out << o.column; }
                         if (o.tophits) { show_candidates(out, o, tx, cands); out << o.column; }
+                        if (o.locations) {                                       // show_candidate_ranges, printing.cpp:370-380
+                            for (const Cand& c : cands) out << '[' << (uint64_t)dbStride * c.beg << ',' << (uint64_t)dbStride * c.end + S.dbWinlen << "] ";
+                            out << o.column;
+                        }
                         show_taxon(out, o, tx, best, isTarget, tgt);
                         out << '\n';
                     }
@@ -591,7 +715,55 @@ int main(int argc, char** argv)
                 }
             } else std::cerr << o.comment << "No valid query sequences found.\n";
         }
-        mc_destroy(ctx);
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    try {
+        if (argc < 3 || std::string(argv[1]) != "query") throw std::runtime_error("usage: mcq query <database> [<sequence file/directory>...] [options]");
+        Options init;
+        init.db = argv[2];
+        init = parse(std::vector<std::string>(argv + 3, argv + argc), init);
+        Session S;
+        auto process = [&](const Options& o) {                                   // process_input_files, querying.cpp:141-222
+            if (!o.splitOut) { run_job(S, o, o.infiles, o.outfile); return; }
+            const size_t stride = (o.pairing == Options::files && o.infiles.size() > 1) ? 2 : 1;
+            for (size_t i = 0; i + stride <= o.infiles.size(); i += stride) {
+                std::vector<std::string> in(o.infiles.begin() + i, o.infiles.begin() + i + stride);
+                std::string suffix;
+                for (const auto& f : in) suffix += "_" + f.substr(f.find_last_of("/\\") + 1);
+                run_job(S, o, in, o.outfile.empty() ? std::string() : o.outfile + suffix + ".txt");
+            }
+        };
+        if (!init.infiles.empty()) { process(init); return 0; }
+        // run_interactive_query_mode (querying.cpp:274-322)
+        S.open(init);
+        std::cout << "Running in interactive mode:\n"
+                     " - Enter input file name(s) and command line options and press return.\n"
+                     " - The initially given command line options will be used as defaults.\n"
+                     " - All command line options that would modify the database are ignored.\n"
+                     " - Each line will be processed separately.\n"
+                     " - Lines starting with '#' will be ignored.\n"
+                     " - Enter an empty line or press Ctrl-D to quit MetaCache.\n" << std::endl;
+        for (;;) {
+            std::cout << "$> " << std::flush;
+            std::string line;
+            std::getline(std::cin, line);
+            if (line.empty() || line.find(":q") == 0) { std::cout << "Terminate." << std::endl; return 0; }
+            if (line[0] == '#') continue;
+            std::vector<std::string> args;
+            std::istringstream iss(line);
+            for (std::string w; iss >> w;) args.push_back(w);
+            try {
+                Options o = parse(args, init);
+                // load-time settings stay those of the initial command line
+                o.maxLocs = init.maxLocs; o.removeOverpopulated = init.removeOverpopulated; o.maxLoadFac = init.maxLoadFac;
+                if (o.infiles.empty()) { if (init.showErrors) std::cerr << "No input filenames provided!\n"; continue; }
+                process(o);
+            } catch (std::exception& e) { if (init.showErrors) std::cerr << e.what() << '\n'; }
+        }
     } catch (std::exception& e) {
         std::cerr << "ABORT: " << e.what() << "!" << std::endl;                  // main.cpp:65-68
         return 1;

@@ -45,6 +45,26 @@ CASES = {
     "sketch_params": (["cli_reads.fa"], ["-sketchlen", "12", "-winlen", "100", "-winstride", "80", "-tophits"]),
     "max_locations": (["cli_reads.fa"], ["-max-locations-per-feature", "4", "-tophits"]),
     "remove_overpopulated": (["cli_reads.fa"], ["-remove-overpopulated-features", "-max-locations-per-feature", "20", "-tophits"]),
+    "gzip_input": (["cli_reads.fa.gz"], ["-tophits", "-queryids"]),
+    "directory_input": (["cli_dir"], ["-queryids"]),
+    "readlen_filter": (["cli_reads.fa"], ["-min-readlen", "100", "-max-readlen", "300", "-queryids"]),
+    "readlen_filter_limit": (["cli_reads.fa", "cli_pairs.fq"], ["-min-readlen", "140", "-query-limit", "60", "-queryids"]),
+    "query_limit": (["cli_reads.fa", "cli_pairs.fq"], ["-query-limit", "50", "-queryids", "-pairseq"]),
+    "comment_token": (["cli_reads.fa"], ["-comment", "%%", "-mapped-only"]),
+    "locations": (["cli_reads.fa"], ["-locations", "-maxcand", "3"]),
+    "locations_pairs": (["cli_pairs.fq"], ["-pairseq", "-locations", "-insertsize", "600"]),
+}
+
+# name -> (input files, options incl. '-split-out'): one output file per input (pair)
+SPLIT_CASES = {
+    "split_out": (["cli_reads.fa", "cli_pairs.fq"], ["-queryids"]),
+    "split_out_pairfiles": (["cli_p1.fa", "cli_p2.fa"], ["-pairfiles", "-tophits"]),
+}
+
+# interactive mode: lines typed at the prompt (each gets its own -out file); defaults from the initial options
+INTERACTIVE = {
+    "initial": ["-tophits"],
+    "lines": [["cli_reads.fa", "-queryids"], ["cli_pairs.fq", "-pairseq", "-lowest", "species"], ["cli_p1.fa", "cli_p2.fa", "-pairfiles", "-maxcand", "3"]],
 }
 
 
@@ -80,6 +100,14 @@ def main():
             for n in range(120):
                 f.write(f">pair{n:03d}\n{mates[n].decode()}\n")
 
+    with open(os.path.join(HERE, "cli_reads.fa"), "rb") as f, open(os.path.join(HERE, "cli_reads.fa.gz"), "wb") as raw:
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as g:
+            g.write(f.read())
+    os.makedirs(os.path.join(HERE, "cli_dir", "sub"), exist_ok=True)
+    with open(os.path.join(HERE, "cli_dir", "sub", "nested_reads.fa"), "w") as f:      # one file, two levels down
+        for n in range(40):
+            f.write(f">nested{n:03d}\n{single[n + 300].decode()}\n")
+
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, (files, args) in CASES.items():
@@ -89,6 +117,28 @@ def main():
             subprocess.check_call(cmd, cwd=HERE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             with open(res) as f:
                 out[name] = {"files": files, "args": args, "lines": f.read().split("\n")}
+        for name, (files, args) in SPLIT_CASES.items():
+            prefix = os.path.join(tmp, name)
+            cmd = [REF, "query", "toy32"] + files + args + ["-threads", "1", "-split-out", prefix]
+            print("+", " ".join(cmd))
+            subprocess.check_call(cmd, cwd=HERE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            outs = {}
+            for fn in sorted(os.listdir(tmp)):
+                if fn.startswith(name + "_"):
+                    with open(os.path.join(tmp, fn)) as f:
+                        outs[fn[len(name):]] = f.read().split("\n")
+            out[name] = {"files": files, "args": args, "split": outs}
+        stdin = ""
+        for i, line in enumerate(INTERACTIVE["lines"]):
+            stdin += " ".join(line + ["-out", os.path.join(tmp, f"inter{i}.txt")]) + "\n"
+        cmd = [REF, "query", "toy32"] + INTERACTIVE["initial"] + ["-threads", "1"]
+        print("+", " ".join(cmd), "<<", repr(stdin))
+        subprocess.run(cmd, cwd=HERE, input=stdin + "\n", text=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        outs = []
+        for i in range(len(INTERACTIVE["lines"])):
+            with open(os.path.join(tmp, f"inter{i}.txt")) as f:
+                outs.append(f.read().split("\n"))
+        out["interactive"] = {"initial": INTERACTIVE["initial"], "lines": INTERACTIVE["lines"], "outputs": outs}
     with gzip.open(os.path.join(HERE, "cli_expected.json.gz"), "wt") as f:
         json.dump(out, f)
     print("wrote", len(out), "cases")

@@ -4,6 +4,7 @@ oracle/_ref/metacache_u32).  Every line must be identical except the two wall-cl
 import gzip
 import json
 import os
+import re
 import subprocess
 
 import pytest
@@ -23,11 +24,56 @@ CASES = _cases()
 
 
 def _volatile(line: str) -> bool:
-    return line.startswith("# time:") or line.startswith("# speed:")
+    return re.match(r"^(# |%%)(time:    |speed:   )", line) is not None
+
+
+def _same(got, exp, tag):
+    assert len(got) == len(exp), (tag, len(got), len(exp))
+    for i, (g, e) in enumerate(zip(got, exp)):
+        if _volatile(e):
+            assert _volatile(g)
+            continue
+        assert g == e, (tag, i, g[:300], e[:300])
+
+
+PLAIN = sorted(k for k, v in CASES.items() if "lines" in v and "files" in v)
+SPLIT = sorted(k for k, v in CASES.items() if "split" in v)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("case", SPLIT)
+def test_cli_split_out_matches_reference(case, tmp_path):
+    """-split-out: one output file (parameters, mappings, statistics) per input file / file pair, query ids restart"""
+    build.build_library()
+    c = CASES[case]
+    prefix = str(tmp_path / case)
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-threads", "1", "-split-out", prefix]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    produced = sorted(f for f in os.listdir(tmp_path) if f.startswith(case + "_"))
+    assert [f[len(case):] for f in produced] == sorted(c["split"])
+    for suffix, exp in c["split"].items():
+        _same(open(prefix + suffix).read().split("\n"), exp, (case, suffix))
+
+
+@pytest.mark.gpu
+def test_cli_interactive_mode_matches_reference(tmp_path):
+    """no input files on the command line: lines from stdin, the initial options are the defaults, the database stays loaded"""
+    build.build_library()
+    c = CASES["interactive"]
+    stdin = ""
+    for i, line in enumerate(c["lines"]):
+        stdin += " ".join(line + ["-out", str(tmp_path / f"inter{i}.txt")]) + "\n"
+    r = subprocess.run([build.MCQ, "query", "toy32"] + c["initial"] + ["-threads", "1"], cwd=GOLD, input=stdin + "\n", capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Running in interactive mode" in r.stdout and "Terminate." in r.stdout
+    for i, exp in enumerate(c["outputs"]):
+        _same(open(tmp_path / f"inter{i}.txt").read().split("\n"), exp, ("interactive", i))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PLAIN)
 def test_cli_matches_reference_output(case, tmp_path):
     build.build_library()
     c = CASES[case]
