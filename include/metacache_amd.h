@@ -123,6 +123,8 @@ int mc_db_info(const mc_ctx* ctx, uint64_t info[8]);
  * negative ids, id = -(target)-1 (taxonomy.hpp:930). */
 int mc_db_num_taxa(const mc_ctx* ctx, uint64_t* n);
 int mc_db_taxon(const mc_ctx* ctx, uint64_t index, int64_t* id, int64_t* parent, uint32_t* rank, const char** name);
+/* file_source of a taxon (taxonomy.hpp:264-280; meaningful for targets): file name, sequence index in that file, window count */
+int mc_db_taxon_source(const mc_ctx* ctx, uint64_t index, const char** filename, uint64_t* file_index, uint64_t* windows);
 int mc_db_lineages(const mc_ctx* ctx, const uint32_t** lin, uint64_t* num_targets);
 
 /* host batch slots: query_batch::add_paired_read (query_batch.cuh:85-186), database::query_gpu_async

@@ -199,6 +199,16 @@ int mc_db_taxon(const mc_ctx* ctx, uint64_t i, int64_t* id, int64_t* parent, uin
     return MC_OK;
 }
 
+int mc_db_taxon_source(const mc_ctx* ctx, uint64_t i, const char** filename, uint64_t* index, uint64_t* windows)
+{
+    if (!ctx || i >= ctx->taxa.size()) return MC_ERR_INVALID;
+    const Taxon& t = ctx->taxa[i];
+    if (filename) *filename = t.filename.c_str();
+    if (index) *index = t.index;
+    if (windows) *windows = t.windows;
+    return MC_OK;
+}
+
 int mc_db_lineages(const mc_ctx* ctx, const uint32_t** lin, uint64_t* nt)
 {
     if (!ctx || !lin || !nt) return MC_ERR_INVALID;

@@ -36,6 +36,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <cmath>
+#include <iomanip>
 #include <limits>
 #include <memory>
 #include <sstream>
@@ -59,7 +61,7 @@ int rank_from_name(std::string n)                    // taxonomy.hpp:174-214
     return -1;
 }
 
-struct Taxon { int64_t id = 0, parent = 0; int rank = kNumRanks; std::string name; };
+struct Taxon { int64_t id = 0, parent = 0; int rank = kNumRanks; std::string name; uint64_t windows = 0; };
 using Lineage = std::array<uint32_t, kNumRanks>;     // taxon index + 1, 0 = none
 
 struct Taxonomy {
@@ -113,6 +115,9 @@ struct Options {
     bool removeOverpopulated = false; float maxLoadFac = 0;
     uint64_t minReadLen = 0, maxReadLen = std::numeric_limits<uint64_t>::max();
     int64_t queryLimit = std::numeric_limits<int64_t>::max();
+    bool hitsPerRef = false, abundances = false;
+    int abundancePer = kNumRanks;                    // none
+    std::string targetsFile, abundanceFile;
 };
 
 std::string sanitize_special_chars(const std::string& s)   // cmdline_utility: "\t" etc. typed literally
@@ -169,6 +174,11 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-allhits" || a == "-all-hits") o.allhits = true;
         else if (a == "-locations") { o.locations = true; o.tophits = true; }
         else if (a == "-queryids" || a == "-query-ids") o.queryIds = true;
+        // an optional file name follows (clipp opt_value: the next word unless it is an option)
+        else if (a == "-abundances" || a == "-abundance") { o.abundances = true; if (i + 1 < args.size() && args[i + 1][0] != '-') o.abundanceFile = args[++i]; }
+        else if (a == "-abundance-per") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); if (r < kNumRanks - 1) o.abundancePer = r; }
+        else if (a == "-hits-per-ref" || a == "-hits-per-seq" || a == "-hits-per-tgt" || a == "-hits-per-target") {
+            o.hitsPerRef = true; if (i + 1 < args.size() && args[i + 1][0] != '-') o.targetsFile = args[++i]; }
         else if (a == "-mapped-only" || a == "-mappedonly") o.mapView = Options::mv_mapped;
         else if (a == "-no-map" || a == "-nomap") o.mapView = Options::mv_none;
         else if (a == "-taxids" || a == "-taxid") o.showId = true;
@@ -211,6 +221,9 @@ Options parse(const std::vector<std::string>& args, Options o)
     if (o.lowest > o.highest) o.lowest = o.highest;
     if (o.batchSize < 1) o.batchSize = 1;
     if (o.queryLimit < 0) o.queryLimit = 0;
+    if (o.targetsFile == o.outfile) o.targetsFile.clear();
+    if (o.abundanceFile == o.outfile) o.abundanceFile.clear();
+    if (o.hitsPerRef) o.queryIds = true;
     if (o.separateCols) { o.collapseUnclassified = false; o.taxSep = o.column; o.rankSuffix = o.column; o.idPrefix = o.column; o.idSuffix = ""; }
     if (o.mapView == Options::mv_none && o.tophits) o.mapView = Options::mv_mapped;
     else if (o.allhits) o.mapView = Options::mv_all;
@@ -473,13 +486,15 @@ struct Session {
             uint32_t rk; const char* nm;
             mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
             tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm; tx.byId.emplace(tx.taxa[i].id, (uint32_t)i);
+            mc_db_taxon_source(ctx, i, nullptr, nullptr, &tx.taxa[i].windows);
         }
         mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets);
     }
 };
 
 // process_input_files (querying.cpp:40-128): parameters, table layout, mappings of all given files, summary -> one output
-void run_job(Session& S, Options o, const std::vector<std::string>& infiles, const std::string& outfile)
+void run_job(Session& S, Options o, const std::vector<std::string>& infiles, const std::string& outfile, const std::string& targetsFile,
+             const std::string& abundanceFile)
 {
         S.open(o);
         mc_ctx* ctx = S.ctx;
@@ -494,6 +509,15 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         std::ofstream fout;
         if (!outfile.empty()) { fout.open(outfile); if (!fout.good()) throw std::runtime_error("Could not write to file " + outfile); }
         std::ostream& os = outfile.empty() ? std::cout : fout;
+        std::ofstream ftargets, ftaxa;                                          // process_input_files, querying.cpp:84-112
+        if (!targetsFile.empty()) { ftargets.open(targetsFile); if (!ftargets.good()) throw std::runtime_error("Could not write to file " + targetsFile); }
+        if (!abundanceFile.empty()) { ftaxa.open(abundanceFile); if (!ftaxa.good()) throw std::runtime_error("Could not write to file " + abundanceFile); }
+        std::ostream& perTargetOut = targetsFile.empty() ? os : ftargets;
+        std::ostream& perTaxonOut = abundanceFile.empty() ? os : ftaxa;
+        const bool taxCountsWanted = o.abundances || o.abundancePer != kNumRanks;
+        struct Cover { uint32_t tgt; uint64_t qid; uint32_t beg, end, hits; };
+        std::vector<Cover> covers;                                              // matches_per_target, all workers
+        std::map<uint32_t, double> bestCounts;                                  // taxon (index + 1) -> queries classified as it
 
         if (o.showQueryParams) {                                                 // printing.cpp:47-131
             if (o.mapView != Options::mv_none) {
@@ -507,6 +531,9 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             os << o.comment << "At maximum " << (unlimited ? std::numeric_limits<size_t>::max() : o.maxCand) << " classification candidates will be considered per query.\n";
             if (o.pairing == Options::files) os << o.comment << "File based paired-end mode:\n" << o.comment << "  Reads from two consecutive files will be interleaved.\n" << o.comment << "  Max insert size considered " << o.insertMax << ".\n";
             else if (o.pairing == Options::sequences) os << o.comment << "Per file paired-end mode:\n" << o.comment << "  Reads from two consecutive sequences in each file will be paired up.\n" << o.comment << "  Max insert size considered " << o.insertMax << ".\n";
+            if (o.hitsPerRef) os << o.comment << "A list of hits per reference sequence will be generated after the read mapping.\n";
+            if (o.abundances) os << o.comment << "A list of absolute and relative abundances per taxon will be generated after the read mapping.\n";
+            if (o.abundancePer != kNumRanks) os << o.comment << "A list of absolute and relative abundances for each '" << kRankNames[o.abundancePer] << "' will be generated after the read mapping.\n";
             os << o.comment << "Using " << threads << " threads\n";
         }
         if (o.mapView != Options::mv_none) {                                     // show_query_mapping_header, classification.cpp:432-460
@@ -614,6 +641,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::string scratch1, scratch2;
             std::ostringstream out;
             uint64_t mine[kNumRanks + 1] = {};
+            std::map<uint32_t, double> myCounts;
+            std::vector<Cover> myCovers;
             auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = m; };
             for (size_t b; !failed && (b = nextBatch++) < batches.size();) {
                 const Batch& B = batches[b];
@@ -665,6 +694,9 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                         bool isTarget; uint32_t tgt;
                         const uint32_t best = classify(o, tx, cands, isTarget, tgt);
                         ++mine[best ? tx.taxon(best)->rank : kNumRanks];
+                        if (taxCountsWanted && best) ++myCounts[best];           // classify_and_evaluate, classification.cpp:552-554
+                        if (o.hitsPerRef)                                        // matches_per_target::insert (matches_per_target.hpp:100-110)
+                            for (const Cand& c : cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) myCovers.push_back(Cover{c.tgt, m.id, c.beg, c.end, c.hits});
                         if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) continue;
                         if (o.queryIds) out << m.id << o.column;
                         const void* sp = memchr(m.header.p, ' ', m.header.n);
@@ -685,6 +717,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             }
             std::lock_guard<std::mutex> l(errMtx);
             for (int r = 0; r <= kNumRanks; ++r) assigned[r] += mine[r];
+            for (const auto& kv : myCounts) bestCounts[kv.first] += kv.second;
+            covers.insert(covers.end(), myCovers.begin(), myCovers.end());
         };
         {
             std::vector<std::thread> pool;
@@ -693,6 +727,103 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (auto& t : pool) t.join();
         }
         if (failed) throw std::runtime_error(firstError);
+
+        uint64_t nAssigned = 0;
+        for (int r = 0; r < kNumRanks; ++r) nAssigned += assigned[r];
+        const uint64_t nUnassigned = assigned[kNumRanks], nTotal = nAssigned + nUnassigned;
+
+        if (o.hitsPerRef) {                                                      // show_matches_per_targets, printing.cpp:385-420
+            std::sort(covers.begin(), covers.end(), [](const Cover& a, const Cover& b) {   // per target: by window range, then query id
+                if (a.tgt != b.tgt) return a.tgt < b.tgt;
+                if (a.beg != b.beg) return a.beg < b.beg;
+                if (a.end != b.end) return a.end < b.end;
+                return a.qid < b.qid;
+            });
+            perTargetOut << o.comment << "--- list of hits for each reference sequence ---\n"
+                         << o.comment << "window start position within sequence = window_index * window_stride(=" << dbStride << ")\n";
+            perTargetOut << o.comment << "TABLE_LAYOUT: " << " sequence " << o.column << " windows_in_sequence " << o.column
+                         << "queryid/first_window_index+additional_windows:hits,queryid/...\n";
+            for (size_t i = 0; i < covers.size();) {
+                const uint32_t tgt = covers[i].tgt;
+                const Lineage lin = tx.target_ranks(tgt);
+                show_lineage(perTargetOut, o, tx, lin, 0, o.lineage ? o.highest : 0);
+                perTargetOut << o.column << (tx.taxon(lin[0]) ? tx.taxon(lin[0])->windows : 0) << o.column;
+                for (bool first = true; i < covers.size() && covers[i].tgt == tgt; ++i, first = false) {
+                    if (!first) perTargetOut << ',';
+                    perTargetOut << covers[i].qid << '/' << covers[i].beg << '+' << (covers[i].end - covers[i].beg) << ':' << covers[i].hits;
+                }
+                perTargetOut << '\n';
+            }
+        }
+
+        if (taxCountsWanted) {
+            // taxon_count_map (classification.hpp:48-56): higher ranks first, then ascending taxon id
+            auto higher = [&tx](uint32_t a, uint32_t b) {
+                const Taxon* x = tx.taxon(a); const Taxon* y = tx.taxon(b);
+                if (x->rank != y->rank) return x->rank > y->rank;
+                return x->id < y->id;
+            };
+            std::map<uint32_t, double, decltype(higher)> counts(higher);
+            for (const auto& kv : bestCounts) counts[kv.first] = kv.second;
+            auto table = [&]() {                                                 // show_abundance_table, printing.cpp:424-468
+                perTaxonOut << o.comment << "rank" << o.rankSuffix << "name" << o.column << "taxid" << o.column << "number of reads" << o.column
+                            << "abundance\n";
+                double ipart = 0.0;
+                for (const auto& tc : counts) {
+                    const Taxon* t = tx.taxon(tc.first);
+                    perTaxonOut << (t->rank == kNumRanks ? "none" : kRankNames[t->rank]) << o.rankSuffix << t->name << o.column;
+                    perTaxonOut << (t->rank == 0 ? t->parent : t->id) << o.column;
+                    if (std::modf(tc.second, &ipart) == 0.0) perTaxonOut << ipart;
+                    else perTaxonOut << std::setprecision(15) << tc.second << std::setprecision(6);
+                    perTaxonOut << o.column << (tc.second / double(nTotal) * 100) << "%\n";
+                }
+                perTaxonOut << "unclassified" << o.column << "--" << o.column << '0' << o.column << nUnassigned << o.column
+                            << (nTotal > 0 ? nUnassigned / double(nTotal) : 0.0) * 100 << "%\n";
+            };
+            if (o.abundances) { perTaxonOut << o.comment << "query summary: number of queries mapped per taxon\n"; table(); }
+            if (o.abundancePer != kNumRanks) {
+                // estimate_abundance (classification.cpp:304-374)
+                const int rank = o.abundancePer;
+                auto first_ancestor = [&](uint32_t t, int from, auto&& accept) -> uint32_t {
+                    const Lineage lin = tx.ranks_of(t);
+                    for (int r = from; r < kNumRanks; ++r) if (lin[r] && accept(lin[r])) return lin[r];
+                    return 0;
+                };
+                if (rank != 0) {
+                    // counts below the estimation rank move up to the closest ancestor on or above it (first position that is not
+                    // "higher" than an imaginary taxon of rank-1 with id 0)
+                    auto it = counts.begin();
+                    while (it != counts.end()) {
+                        const Taxon* t = tx.taxon(it->first);
+                        if (t->rank > rank - 1 || (t->rank == rank - 1 && t->id < 0)) ++it; else break;
+                    }
+                    while (it != counts.end()) {
+                        const uint32_t anc = first_ancestor(it->first, rank, [](uint32_t) { return true; });
+                        if (anc) { counts[anc] += it->second; it = counts.erase(it); } else ++it;
+                    }
+                }
+                std::unordered_map<uint32_t, std::vector<uint32_t>> children;
+                std::unordered_map<uint32_t, uint64_t> weight;
+                for (const auto& tc : counts) weight[tc.first] = 0;
+                for (auto it = counts.rbegin(); it != counts.rend(); ++it) {   // leaves to root: own count + weight go to the closest counted ancestor
+                    const uint32_t parent = first_ancestor(it->first, tx.taxon(it->first)->rank + 1, [&](uint32_t a) { return weight.count(a) > 0; });
+                    if (parent) {
+                        weight[parent] = (uint64_t)(weight[parent] + (weight[it->first] + it->second));
+                        children[parent].push_back(it->first);
+                    }
+                }
+                for (auto it = counts.begin(); it != counts.end();) {            // root to leaves: a parent's count is shared out proportionally
+                    auto ch = children.find(it->first);
+                    if (ch != children.end()) {
+                        const uint64_t sumChildren = weight[it->first];
+                        for (uint32_t c : ch->second) counts[c] += it->second * (counts[c] + weight[c]) / sumChildren;
+                        it = counts.erase(it);
+                    } else ++it;
+                }
+                perTaxonOut << o.comment << "estimated abundance (number of queries) per " << kRankNames[rank] << "\n";
+                table();
+            }
+        }
         if (o.showSummary) {                                                     // show_summary, printing.cpp:601-620
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             uint64_t nassigned = 0;
@@ -728,13 +859,14 @@ int main(int argc, char** argv)
         init = parse(std::vector<std::string>(argv + 3, argv + argc), init);
         Session S;
         auto process = [&](const Options& o) {                                   // process_input_files, querying.cpp:141-222
-            if (!o.splitOut) { run_job(S, o, o.infiles, o.outfile); return; }
+            if (!o.splitOut) { run_job(S, o, o.infiles, o.outfile, o.targetsFile, o.abundanceFile); return; }
             const size_t stride = (o.pairing == Options::files && o.infiles.size() > 1) ? 2 : 1;
             for (size_t i = 0; i + stride <= o.infiles.size(); i += stride) {
                 std::vector<std::string> in(o.infiles.begin() + i, o.infiles.begin() + i + stride);
                 std::string suffix;
                 for (const auto& f : in) suffix += "_" + f.substr(f.find_last_of("/\\") + 1);
-                run_job(S, o, in, o.outfile.empty() ? std::string() : o.outfile + suffix + ".txt");
+                auto named = [&](const std::string& f) { return f.empty() ? std::string() : f + suffix + ".txt"; };
+                run_job(S, o, in, named(o.outfile), named(o.targetsFile), named(o.abundanceFile));
             }
         };
         if (!init.infiles.empty()) { process(init); return 0; }

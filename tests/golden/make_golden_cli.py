@@ -53,6 +53,17 @@ CASES = {
     "comment_token": (["cli_reads.fa"], ["-comment", "%%", "-mapped-only"]),
     "locations": (["cli_reads.fa"], ["-locations", "-maxcand", "3"]),
     "locations_pairs": (["cli_pairs.fq"], ["-pairseq", "-locations", "-insertsize", "600"]),
+    "abundances": (["cli_reads.fa"], ["-abundances"]),
+    "abundances_species": (["cli_reads.fa", "cli_pairs.fq"], ["-abundances", "-abundance-per", "species", "-lowest", "subspecies"]),
+    "abundance_per_genus_nomap": (["cli_reads.fa"], ["-no-map", "-abundance-per", "genus"]),
+    "abundance_per_sequence": (["cli_pairs.fq"], ["-pairseq", "-no-map", "-abundance-per", "sequence", "-hitdiff", "50", "-maxcand", "4"]),
+    "hits_per_ref": (["cli_reads.fa"], ["-no-map", "-hits-per-ref"]),
+    "hits_per_ref_lineage": (["cli_pairs.fq"], ["-pairseq", "-hits-per-ref", "-lineage", "-highest", "genus", "-taxids", "-maxcand", "3"]),
+}
+
+# name -> (input files, options with {targets} / {abund} standing for extra output files)
+EXTRA_FILE_CASES = {
+    "analysis_files": (["cli_reads.fa"], ["-hits-per-ref", "{targets}", "-abundances", "{abund}", "-abundance-per", "family", "-mapped-only"]),
 }
 
 # name -> (input files, options incl. '-split-out'): one output file per input (pair)
@@ -117,6 +128,16 @@ def main():
             subprocess.check_call(cmd, cwd=HERE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             with open(res) as f:
                 out[name] = {"files": files, "args": args, "lines": f.read().split("\n")}
+        for name, (files, args) in EXTRA_FILE_CASES.items():
+            res = os.path.join(tmp, name + ".txt")
+            extra = {"targets": os.path.join(tmp, name + ".targets"), "abund": os.path.join(tmp, name + ".abund")}
+            cmd = [REF, "query", "toy32"] + files + [a.format(**extra) for a in args] + ["-threads", "1", "-out", res]
+            print("+", " ".join(cmd))
+            subprocess.check_call(cmd, cwd=HERE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            rec = {"files": files, "args": args, "main": open(res).read().split("\n"), "extra": {}}
+            for k, fn in extra.items():
+                rec["extra"][k] = open(fn).read().split("\n")
+            out[name] = rec
         for name, (files, args) in SPLIT_CASES.items():
             prefix = os.path.join(tmp, name)
             cmd = [REF, "query", "toy32"] + files + args + ["-threads", "1", "-split-out", prefix]
