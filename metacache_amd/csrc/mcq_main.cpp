@@ -463,7 +463,7 @@ struct Session {
         c.copy_allhits = o.allhits ? 1 : 0;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         threads = o.threads > 0 ? (unsigned)o.threads : hw;                     // options.hpp: numThreads defaults to all hardware threads
-        workers = std::min(threads, 48u);                                       // one batch slot (pinned staging) per worker
+        workers = std::min(threads, 128u);                                      // one batch slot (pinned staging) per worker
         c.num_slots = workers;
         c.slot_max_queries = o.batchSize;
         c.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--reads", type=int, default=4_000_000)
     ap.add_argument("--cpu-reads", type=int, default=400_000, help="reads whose mapping lines are diffed against the reference CLI")
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-ref", action="store_true")
     args = ap.parse_args()
     build.build_library()
     G, GL = 16, 5_000_000
@@ -93,11 +94,15 @@ def main():
         wall = run([mcq, "query", db, fa] + extra + ["-out", o])
         q, ms = speed_of(o)
         res[name] = {"wall_s_incl_db_load": round(wall, 3), "query_ms": ms, "Mreads_per_min": round(q / (ms / 1e3) * 60 / 1e6, 1)}
-    for t in (1, 8):
+    for t in (1, 8, 32, 64, 128):
         wall = run([mcq, "query", db, fa, "-no-map", "-threads", str(t), "-out", o])
         q, ms = speed_of(o)
         res[f"mcq_nomap_threads{t}"] = {"query_ms": ms, "Mreads_per_min": round(q / (ms / 1e3) * 60 / 1e6, 1)}
-    if os.path.exists(ref):
+    for t, bs in ((16, 262144), (16, 1048576)):
+        wall = run([mcq, "query", db, fa, "-no-map", "-threads", str(t), "-batch-size", str(bs), "-out", o])
+        q, ms = speed_of(o)
+        res[f"mcq_nomap_threads{t}_batch{bs}"] = {"query_ms": ms, "Mreads_per_min": round(q / (ms / 1e3) * 60 / 1e6, 1)}
+    if os.path.exists(ref) and not args.no_ref:
         oref = os.path.join(tmp, "oref.txt")
         wall = run([ref, "query", db, fa, "-no-map", "-out", oref])
         q, ms = speed_of(oref)
