@@ -52,11 +52,11 @@ struct ScopedTimer {
     mc_ctx* ctx; const char* name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     ScopedTimer(mc_ctx* c, const char* n, hipStream_t s) : ctx(c), name(n), st(s)
     {
-        if (ctx->timing) { a = get_event(ctx); b = get_event(ctx); (void)hipEventRecord(a, st); }
+        if (ctx->timing) { std::lock_guard<std::mutex> l(ctx->timerMtx); a = get_event(ctx); b = get_event(ctx); (void)hipEventRecord(a, st); }
     }
     ~ScopedTimer()
     {
-        if (a) { (void)hipEventRecord(b, st); ctx->timers[name].pending.emplace_back(a, b); }
+        if (a) { std::lock_guard<std::mutex> l(ctx->timerMtx); (void)hipEventRecord(b, st); ctx->timers[name].pending.emplace_back(a, b); }
     }
 };
 
@@ -168,6 +168,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
         delete ctx;
         return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream");
     }
+    ctx->pipe0.stream = ctx->stream;
     // host slots
     ctx->slots.resize(cfg->num_slots);
     const size_t K = cfg->max_candidates;
@@ -182,6 +183,14 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
                   hipHostMalloc((void**)&s.hhitoff, (nq + 1) * 8) == hipSuccess && hipEventCreate(&s.done) == hipSuccess;
         if (!ok) { mc_destroy(ctx); return fail(nullptr, MC_ERR_NOMEM, "cannot allocate slot buffers"); }
     }
+    uint32_t npipes = std::min<uint32_t>(cfg->num_slots, 8);
+    if (const char* e = std::getenv("MC_PIPES")) npipes = std::max(1, std::atoi(e));
+    for (uint32_t i = 0; i < npipes && i < cfg->num_slots; ++i) {
+        Pipe* p = new Pipe;
+        ctx->pipes.push_back(p);
+        if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { mc_destroy(ctx); return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream"); }
+        ctx->freePipes.push_back(p);
+    }
     *out = ctx;
     return MC_OK;
 }
@@ -193,9 +202,18 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->parts) { if (p.dbuckets) (void)hipFree(p.dbuckets); if (p.dvalues) (void)hipFree(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
-    DevBuf* bufs[] = {&ctx->bWinCount, &ctx->bWinOff, &ctx->bFeatures, &ctx->bPsize, &ctx->bPpay, &ctx->bQstat, &ctx->bHitOff,
-                      &ctx->bHits, &ctx->bCscr, &ctx->bCscr2, &ctx->bScan, &ctx->bStats, &ctx->bCands, &ctx->bScanIn, &ctx->bQflag, &ctx->bHitlist, &ctx->bMid,
-                      &ctx->bLdKeys, &ctx->bLdSizes, &ctx->bLdVals, &ctx->bLdFileSz, &ctx->bLdStoreSz, &ctx->bLdFileOff, &ctx->bLdStoreOff,
+    auto free_pipe = [](Pipe& P, bool ownStream) {
+        DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bHitlist, &P.bMid};
+        if (P.stream) (void)hipStreamSynchronize(P.stream);
+        if (P.hTotal) (void)hipHostFree(P.hTotal);
+        for (auto* b : pb) if (b->p) (void)hipFree(b->p);
+        if (ownStream && P.stream) (void)hipStreamDestroy(P.stream);
+    };
+    free_pipe(ctx->pipe0, false);
+    for (Pipe* p : ctx->pipes) { free_pipe(*p, true); delete p; }
+    ctx->pipes.clear(); ctx->freePipes.clear();
+    DevBuf* bufs[] = {&ctx->bLdKeys, &ctx->bLdSizes, &ctx->bLdVals, &ctx->bLdFileSz, &ctx->bLdStoreSz, &ctx->bLdFileOff, &ctx->bLdStoreOff,
                       &ctx->bLdScan, &ctx->bLdCounters};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& s : ctx->slots) {
@@ -446,6 +464,7 @@ static int taxkey_for_rank(mc_ctx* ctx, int rank, const uint32_t** out)
     *out = nullptr;
     if (rank <= 0) return MC_OK;
     if (rank >= MC_NUM_RANKS) return fail(ctx, MC_ERR_INVALID, "lowest_rank out of range");
+    std::lock_guard<std::mutex> lock(ctx->taxMtx);             // slots submit concurrently
     auto it = ctx->taxkeyDev.find(rank);
     if (it != ctx->taxkeyDev.end()) { *out = it->second; return MC_OK; }
     if (ctx->lineages.empty()) return fail(ctx, MC_ERR_STATE, "lowest_rank > sequence needs mc_set_lineages first");
@@ -465,15 +484,21 @@ static int taxkey_for_rank(mc_ctx* ctx, int rank, const uint32_t** out)
 // ------------------------------------------------------------------------------------------------
 // the per-batch pipeline
 // ------------------------------------------------------------------------------------------------
+static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st);
+
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
+{
+    if (!ctx || !in || !out) return MC_ERR_INVALID;
+    return query_on_pipe(ctx, ctx->pipe0, in, lowestRank, flags, out, streamv ? (hipStream_t)streamv : ctx->stream);
+}
+
+static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st)
 {
     const int wantAllhits = flags & MC_WANT_ALLHITS;
     const bool wantFeatures = (flags & MC_WANT_FEATURES) != 0;
-    if (!ctx || !in || !out) return MC_ERR_INVALID;
     if (!ctx->tableReady) return fail(ctx, MC_ERR_STATE, "no database loaded (every part needs mc_load_begin .. mc_load_end)");
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
     const uint32_t n = in->num_queries;
     const SketchParams sp = ctx->querySketch;
     const uint32_t K = ctx->cfg.max_candidates;
@@ -485,34 +510,34 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     const uint64_t maxWindows = in->num_chars / sp.stride + 4ull * n + 1;
     if (maxWindows * sp.s > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "batch too large (feature index exceeds 32 bits)");
     const size_t nfeat = (size_t)maxWindows * sp.s;
-    if ((rc = ensure(ctx, ctx->bWinCount, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bWinOff, (size_t)(n + 2) * 4))) return rc;
+    if ((rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4))) return rc;
     // the lane path delivers top candidates only: -allhits and K > 4 go through the wave kernels
     const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAllhits && lane_candidates_supported(K);
-    if ((wantFeatures || lanePath) && (rc = ensure(ctx, ctx->bFeatures, nfeat * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bPsize, nfeat * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bPpay, nfeat * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
-    if ((rc = ensure(ctx, ctx->bScanIn, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bQflag, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bHitlist, 64))) return rc;
-    if (lanePath && (rc = ensure(ctx, ctx->bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 16))) return rc;
-    if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->bScan, scan_tmp_bytes(n + 1)))) return rc;
-    if ((rc = ensure(ctx, ctx->bStats, 64))) return rc;
-    if ((rc = ensure(ctx, ctx->bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
+    if ((wantFeatures || lanePath) && (rc = ensure(ctx, P.bFeatures, nfeat * 4))) return rc;
+    if ((rc = ensure(ctx, P.bPsize, nfeat * 4))) return rc;
+    if ((rc = ensure(ctx, P.bPpay, nfeat * 8))) return rc;
+    if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
+    if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, P.bHitlist, 64))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
+    if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
+    if ((rc = ensure(ctx, P.bStats, 64))) return rc;
+    if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
-    ws.winCount = (uint32_t*)ctx->bWinCount.p; ws.winOff = (uint32_t*)ctx->bWinOff.p;
-    ws.features = (wantFeatures || lanePath) ? (uint32_t*)ctx->bFeatures.p : nullptr; ws.psize = (uint32_t*)ctx->bPsize.p; ws.ppay = (uint64_t*)ctx->bPpay.p;
-    ws.qstat = (QueryStat*)ctx->bQstat.p; ws.hitScan = (uint32_t*)ctx->bScanIn.p; ws.qflag = (uint32_t*)ctx->bQflag.p; ws.counter = (uint32_t*)ctx->bHitlist.p; ws.hitOff = (uint64_t*)ctx->bHitOff.p;
-    ws.scanTmp = ctx->bScan.p; ws.stats = (uint64_t*)ctx->bStats.p;
-    if (lanePath) { ws.midCount = (uint32_t*)ctx->bMid.p; ws.midList = ws.midCount + 4; }
+    ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
+    ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
+    ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.counter = (uint32_t*)P.bHitlist.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
+    ws.scanTmp = P.bScan.p; ws.stats = (uint64_t*)P.bStats.p;
+    if (lanePath) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 4; }
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
-    const Part& P = ctx->parts[0];
+    const Part& T = ctx->parts[0];
     const bool multiPart = ctx->parts.size() > 1;
-    DeviceTable tab{P.dbuckets, P.dvalues, P.nbuckets, multiPart ? 0x00FFFFFFu : 0xFFFFFFFFu, P.maxProbe};
+    DeviceTable tab{T.dbuckets, T.dvalues, T.nbuckets, multiPart ? 0x00FFFFFFu : 0xFFFFFFFFu, T.maxProbe};
 
     {
         ScopedTimer t(ctx, "plan", st);
@@ -525,43 +550,44 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
         HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 16, st));
         if (ctx->fuseLane) {
             ScopedTimer t(ctx, "sketch_probe", st);
-            launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st);
+            launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, st);
         } else {
             { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
-            { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, ctx->bCands.p, st); }
+            { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         }
-        { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
-        { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
-        { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, ctx->bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, P.bCands.p, st); }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }
     {
         // wave-per-query kernel for whatever the lane path did not take (long reads, duplicate hashes, ...)
         ScopedTimer t(ctx, "query_wave", st);
-        launch_query(b, sp, tab, fuse, wantAllhits != 0, ws, K, ctx->bCands.p, st);
+        launch_query(b, sp, tab, fuse, wantAllhits != 0, ws, K, P.bCands.p, st);
     }
     {
         ScopedTimer t(ctx, "scan", st);
         launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
     }
     // the only host round trip of a batch: how many locations need a segment in HBM
-    uint64_t totalHits = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&totalHits, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
+    if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 64));
+    HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint64_t totalHits = *P.hTotal;
     const size_t hb = (size_t)(totalHits + 1) * 8;
-    if ((rc = ensure(ctx, ctx->bHits, hb))) return rc;
-    if ((rc = ensure(ctx, ctx->bCscr, hb))) return rc;
-    if (taxkey && (rc = ensure(ctx, ctx->bCscr2, hb))) return rc;
-    ws.hits = (uint64_t*)ctx->bHits.p; ws.cscr = (uint64_t*)ctx->bCscr.p; ws.cscr2 = (uint64_t*)ctx->bCscr2.p;
+    if ((rc = ensure(ctx, P.bHits, hb))) return rc;
+    if ((rc = ensure(ctx, P.bCscr, hb))) return rc;
+    if (taxkey && (rc = ensure(ctx, P.bCscr2, hb))) return rc;
+    ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     {
         ScopedTimer t(ctx, "sort_candidates", st);
-        launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits != 0, ctx->bCands.p, st);
+        launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits != 0, P.bCands.p, st);
     }
     HIP_TRY(ctx, hipGetLastError());
-    ctx->lastN = n;
-    out->cands = (const mc_candidate*)ctx->bCands.p;
-    out->hit_counts = (const uint32_t*)ctx->bQstat.p;       // QueryStat.hits: stride 4 words
+    P.lastN = n;
+    out->cands = (const mc_candidate*)P.bCands.p;
+    out->hit_counts = (const uint32_t*)P.bQstat.p;       // QueryStat.hits: stride 4 words
     out->hit_offsets = wantAllhits ? ws.hitOff : nullptr;
     out->hits = wantAllhits ? (const mc_location*)ws.hits : nullptr;
     out->features = ws.features;
@@ -576,6 +602,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (!ctx || !in || !out || !in->hit_offsets) return MC_ERR_INVALID;
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Pipe& P = ctx->pipe0;
     hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
     const uint32_t n = in->num_queries;
     const uint32_t K = ctx->cfg.max_candidates;
@@ -586,26 +613,26 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     HIP_TRY(ctx, hipMemcpyAsync(&total, in->hit_offsets + n, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const size_t hb = (size_t)(total + 1) * 8;
-    if ((rc = ensure(ctx, ctx->bHits, hb)) || (rc = ensure(ctx, ctx->bCscr, hb)) || (taxkey && (rc = ensure(ctx, ctx->bCscr2, hb)))) return rc;
-    if ((rc = ensure(ctx, ctx->bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, ctx->bQstat, (size_t)(n + 1) * sizeof(QueryStat))) ||
-        (rc = ensure(ctx, ctx->bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
+    if ((rc = ensure(ctx, P.bHits, hb)) || (rc = ensure(ctx, P.bCscr, hb)) || (taxkey && (rc = ensure(ctx, P.bCscr2, hb)))) return rc;
+    if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) ||
+        (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     // the lists are sorted in place: work on a copy inside the context
-    if (total) HIP_TRY(ctx, hipMemcpyAsync(ctx->bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.hits = (uint64_t*)ctx->bHits.p; ws.cscr = (uint64_t*)ctx->bCscr.p; ws.cscr2 = (uint64_t*)ctx->bCscr2.p;
-    ws.hitOff = (uint64_t*)ctx->bHitOff.p; ws.qstat = (QueryStat*)ctx->bQstat.p;
+    ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
+    ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
     DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
     {
         ScopedTimer t(ctx, "cands_from_hits", st);
-        launch_cands_from_hits(b, tab, ws, taxkey, K, ctx->bCands.p, st);
+        launch_cands_from_hits(b, tab, ws, taxkey, K, P.bCands.p, st);
     }
     HIP_TRY(ctx, hipGetLastError());
-    ctx->lastN = 0;
-    out->cands = (const mc_candidate*)ctx->bCands.p;
-    out->hit_counts = (const uint32_t*)ctx->bQstat.p;
+    P.lastN = 0;
+    out->cands = (const mc_candidate*)P.bCands.p;
+    out->hit_counts = (const uint32_t*)P.bQstat.p;
     out->hit_offsets = ws.hitOff;
     out->hits = (const mc_location*)ws.hits;
     out->features = nullptr; out->win_offsets = nullptr;
@@ -633,10 +660,11 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     if (!ctx) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::memset(stats, 0, 64);
-    if (!ctx->bStats.p || !ctx->bQstat.p) return MC_OK;
+    Pipe& P = ctx->pipe0;
+    if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.qstat = (QueryStat*)ctx->bQstat.p; ws.winOff = (uint32_t*)ctx->bWinOff.p; ws.stats = (uint64_t*)ctx->bStats.p;
-    launch_batch_stats(ws, ctx->lastN, ctx->stream);
+    ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
+    launch_batch_stats(ws, P.lastN, ctx->stream);
     HIP_TRY(ctx, hipMemcpyAsync(stats, ws.stats, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MC_OK;
@@ -705,9 +733,21 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
     Slot& S = ctx->slots[slot];
     if (S.submitted) return fail(ctx, MC_ERR_STATE, "mc_batch_submit: slot already submitted");
-    std::lock_guard<std::mutex> lock(ctx->submitMtx);     // ordered submission (database_query.hpp:110-113)
+    // every slot has its own stream and device workspace: batches of different slots overlap on the device (the reference orders
+    // submissions with a mutex and overlaps through per-batch CUDA streams, database_query.hpp:110-113, query_batch.cu)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    {
+        std::unique_lock<std::mutex> lk(ctx->pipeMtx);
+        ctx->pipeCv.wait(lk, [&] { return !ctx->freePipes.empty(); });
+        S.pipe = ctx->freePipes.back();
+        ctx->freePipes.pop_back();
+    }
+    struct Giveback {                                           // an error on the way returns the pipe at once
+        mc_ctx* c; Slot& s; bool armed = true;
+        ~Giveback() { if (armed && s.pipe) { (void)hipStreamSynchronize(s.pipe->stream); std::lock_guard<std::mutex> l(c->pipeMtx); c->freePipes.push_back(s.pipe); s.pipe = nullptr; c->pipeCv.notify_one(); } }
+    } giveback{ctx, S};
+    Pipe& P = *S.pipe;
+    hipStream_t st = P.stream;
     const uint32_t n = S.nq;
     S.submittedQueries = n;
     if (n == 0) { HIP_TRY(ctx, hipEventRecord(S.done, st)); S.submitted = true; return MC_OK; }
@@ -717,11 +757,11 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     mc_device_batch in{S.dseq, S.dqinfo, S.dmaxwin, 0, n, S.nchars};
     mc_device_results res{};
     const int wantAll = ctx->cfg.copy_allhits ? 1 : 0;
-    int rc = mc_query_device(ctx, &in, lowestRank, wantAll, &res, st);
+    int rc = query_on_pipe(ctx, P, &in, lowestRank, wantAll, &res, st);
     if (rc) return rc;
     const size_t K = ctx->cfg.max_candidates;
     HIP_TRY(ctx, hipMemcpyAsync(S.hcands, res.cands, (size_t)n * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(S.hqstat, ctx->bQstat.p, (size_t)n * sizeof(QueryStat), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.hqstat, P.bQstat.p, (size_t)n * sizeof(QueryStat), hipMemcpyDeviceToHost, st));
     if (wantAll) {
         HIP_TRY(ctx, hipMemcpyAsync(S.hhitoff, res.hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -736,7 +776,17 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     }
     HIP_TRY(ctx, hipEventRecord(S.done, st));
     S.submitted = true;
+    giveback.armed = false;                                     // mc_batch_wait returns the pipe
     return MC_OK;
+}
+
+static void release_pipe(mc_ctx* ctx, Slot& S)
+{
+    if (!S.pipe) return;
+    std::lock_guard<std::mutex> l(ctx->pipeMtx);
+    ctx->freePipes.push_back(S.pipe);
+    S.pipe = nullptr;
+    ctx->pipeCv.notify_one();
 }
 
 int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
@@ -745,6 +795,7 @@ int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
     Slot& S = ctx->slots[slot];
     if (!S.submitted) return fail(ctx, MC_ERR_STATE, "mc_batch_wait: slot not submitted");
     HIP_TRY(ctx, hipEventSynchronize(S.done));
+    release_pipe(ctx, S);                                       // the results are in the slot's pinned buffers
     const uint32_t n = S.submittedQueries;
     int status = MC_OK;
     for (uint32_t i = 0; i < n; ++i) {
@@ -766,6 +817,7 @@ int mc_batch_clear(mc_ctx* ctx, uint32_t slot)
     if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
     Slot& S = ctx->slots[slot];
     if (S.submitted) (void)hipEventSynchronize(S.done);
+    release_pipe(ctx, S);
     S.submitted = false; S.nq = 0; S.nchars = 0;
     return MC_OK;
 }

@@ -4,6 +4,7 @@
 #include "../../include/metacache_amd.h"
 #include "kernels.h"
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -14,6 +15,14 @@ namespace mcamd {
 struct DevBuf {                 // grow-only device allocation
     void* p = nullptr;
     size_t cap = 0;
+};
+
+struct Pipe {                   // the device workspace of ONE batch in flight + the stream its work is enqueued on
+    hipStream_t stream = nullptr;
+    DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
+        bCands, bScanIn, bQflag, bHitlist, bMid;
+    uint32_t lastN = 0;
+    uint64_t* hTotal = nullptr;   // pinned: the one host round trip of a batch lands here (a pageable target makes the copy blocking)
 };
 
 struct Part {
@@ -50,6 +59,7 @@ struct Slot {
     hipEvent_t done = nullptr;
     bool submitted = false;
     uint32_t submittedQueries = 0;
+    Pipe* pipe = nullptr;
 };
 
 // table_build: insert one chunk of a single-part database whose batch arrays already live in device memory
@@ -82,16 +92,22 @@ struct mc_ctx {
     std::vector<uint32_t> lineages;        // [targets * 21], taxon index + 1
     std::map<int, uint32_t*> taxkeyDev;    // lowest_rank -> device array [targets]
 
-    // workspace
-    mcamd::DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
-        bCands, bScanIn, bQflag, bHitlist, bMid;
+    // workspace of mc_query_device / mc_candidates_from_hits callers (pipe0.stream == stream); every host batch slot has its own
+    // Pipe, so that the H2D copy, the kernels and the D2H copy of different slots overlap on the device
+    mcamd::Pipe pipe0;
+    std::mutex taxMtx, timerMtx;
+    // host batch slots borrow a pipe from this pool between mc_batch_submit and mc_batch_wait: a few batches in flight are
+    // enough to overlap H2D, kernels and D2H, and the pool bounds both the device memory and the number of threads inside the
+    // HIP runtime at once (measured: 128 threads submitting on 128 streams spend 99 % of their time in runtime locks)
+    std::vector<mcamd::Pipe*> pipes, freePipes;
+    std::mutex pipeMtx;
+    std::condition_variable pipeCv;
     // single-part tables are built on the device (table_build.hip): staging for one batch of the file
     mcamd::DevBuf bLdKeys, bLdSizes, bLdVals, bLdFileSz, bLdStoreSz, bLdFileOff, bLdStoreOff, bLdScan, bLdCounters;
     bool useLanePath = true;               // lane-parallel fast path for short reads (off: wave kernels only)
     bool fuseLane = false;                 // sketching + probing of the lane path in ONE kernel (MC_LANE_FUSION=1); measured
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on
                                            // strain-rich tables -- off by default
-    uint32_t lastN = 0;
 
     // timing
     bool timing = false;
@@ -100,5 +116,4 @@ struct mc_ctx {
 
     // slots
     std::vector<mcamd::Slot> slots;
-    std::mutex submitMtx;
 };

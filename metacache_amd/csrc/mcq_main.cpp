@@ -463,7 +463,7 @@ struct Session {
         c.copy_allhits = o.allhits ? 1 : 0;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         threads = o.threads > 0 ? (unsigned)o.threads : hw;                     // options.hpp: numThreads defaults to all hardware threads
-        workers = std::min(threads, 128u);                                      // one batch slot (pinned staging) per worker
+        workers = std::min(threads, 64u);                                      // one batch slot (pinned staging) per worker
         c.num_slots = workers;
         c.slot_max_queries = o.batchSize;
         c.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
@@ -621,6 +621,10 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             }
         }
 
+        const bool profile = std::getenv("MCQ_PROFILE") != nullptr;              // phase times on stderr (development aid)
+        const double tIndexed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::atomic<uint64_t> nsParse{0}, nsSubmit{0}, nsWait{0}, nsClassify{0};
+        auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // ---- workers: one batch slot each; output delivered in batch order -------------------------------------------------
         std::atomic<size_t> nextBatch{0};
         std::mutex outMtx, errMtx;
@@ -651,6 +655,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 size_t q = B.qBeg;
                 while (q < B.qEnd && !failed) {
                     metas.clear();
+                    const uint64_t tp0 = now_ns();
                     for (; q < B.qEnd; ++q) {
                         View h1, s1, h2, s2;
                         const size_t qi = B.sel ? (size_t)(*B.sel)[q] : q;          // query index inside the file (pair)
@@ -675,7 +680,11 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     }
                     if (failed) break;
                     mc_results r;
-                    if (mc_batch_submit(ctx, slot, o.lowest) != MC_OK || mc_batch_wait(ctx, slot, &r) != MC_OK) { fail(mc_last_error(ctx)); break; }
+                    const uint64_t tp1 = now_ns();
+                    if (mc_batch_submit(ctx, slot, o.lowest) != MC_OK) { fail(mc_last_error(ctx)); break; }
+                    const uint64_t tp2 = now_ns();
+                    if (mc_batch_wait(ctx, slot, &r) != MC_OK) { fail(mc_last_error(ctx)); break; }
+                    const uint64_t tp3 = now_ns();
                     for (uint32_t i = 0; i < r.num_queries; ++i) {
                         const Meta& m = metas[i];
                         if (m.empty) continue;                                    // processQuery, classification.cpp:780
@@ -712,6 +721,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                         out << '\n';
                     }
                     mc_batch_clear(ctx, slot);
+                    if (profile) { nsParse += tp1 - tp0; nsSubmit += tp2 - tp1; nsWait += tp3 - tp2; nsClassify += now_ns() - tp3; }
                 }
                 deliver(b, out.str());
             }
@@ -727,6 +737,10 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (auto& t : pool) t.join();
         }
         if (failed) throw std::runtime_error(firstError);
+        if (profile)
+            std::cerr << "mcq profile: index " << tIndexed * 1e3 << " ms, total " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3
+                      << " ms; summed over " << workers << " workers: parse+add " << nsParse / 1e6 << " ms, submit " << nsSubmit / 1e6 << " ms, wait "
+                      << nsWait / 1e6 << " ms, classify+format " << nsClassify / 1e6 << " ms; batches " << batches.size() << "\n";
 
         uint64_t nAssigned = 0;
         for (int r = 0; r < kNumRanks; ++r) nAssigned += assigned[r];

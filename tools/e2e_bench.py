@@ -50,6 +50,9 @@ def speed_of(path: str):
 def run(cmd, **kw):
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    for line in r.stderr.splitlines():
+        if line.startswith("mcq profile"):
+            print(" ".join(cmd[4:8]), "|", line, flush=True)
     if r.returncode != 0:
         raise RuntimeError(" ".join(cmd) + "\n" + r.stderr[-2000:])
     return time.perf_counter() - t0
