@@ -244,7 +244,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "scan", "sort_candidates")}
+        kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "query_wave", "scan", "sort_candidates")}
         st = db.last_batch_stats()                            # of the last timed batch
         F, H = st["features"] / B, st["locations"] / B
         V = 6                                                 # uint16 target ids: 6-byte locations in the file format

@@ -105,7 +105,9 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint32_t* qflag;         // [n]        0 = done, 1 = needs sketch+probe (wave), 2 = needs candidates (wave),
                              //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel
     uint32_t* counter;       // [1]        (unused)
-    uint32_t* midCount;      // [4]        lengths of the three work lists of mid_cands_kernel (zeroed per batch)
+    uint32_t* midCount;      // [4]        lengths of the three work lists of mid_cands_kernel, [3] = chunk records (zeroed per batch)
+    uint2*    chunkList;     // [W/4 + n]  {query, chunk}: long single reads, cut into chunks of 4 windows for the lane kernels
+    uint32_t* chunkLeft;     // [n]        chunks of a long read still to be probed
     uint32_t* midList;       // [3][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
@@ -136,6 +138,7 @@ void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
 void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
+void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,

@@ -6,6 +6,9 @@
 //
 // No MFMA anywhere: this is integer hashing and gathering; the bound is HBM/L2 random access.
 #include "kernels.h"
+#ifndef MC_CHUNK_WINS
+#define MC_CHUNK_WINS 1
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -13,7 +16,7 @@
 namespace mcamd {
 
 // per-query state: what is still to be done (Workspace::qflag)
-constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagLaneCands = 3, kFlagProbe = 4, kFlagMid = 5;
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagLaneCands = 3, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6;
 
 // ================================================================================================
 // wave64 primitives
@@ -1002,6 +1005,8 @@ constexpr uint32_t kLaneMaxLen = 512;     // longest mate handled by one lane
 constexpr uint32_t kLaneS = 16;           // sketch entries held in registers
 constexpr uint32_t kLaneHits = 32;        // longest location list handled by one lane
 constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
+constexpr uint32_t kLaneU = 4;            // lookups in flight per lane
+constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
 
 __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
 {
@@ -1017,6 +1022,65 @@ __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32
     }
 }
 
+// rows 1-5 for `len` characters at seq + off by ONE lane: rolling canonical k-mers, hash, 16-entry insertion chain; a window is complete
+// after `stride` k-mers or at the end of the span (the k-mers of a sequence partition into its windows because stride = w - k + 1).
+// Window sketches go to out0 + wcount * s (wcount advances); dup = a window held the same hash twice (the wave path sorts that out).
+__device__ __forceinline__ void lane_sketch_span(const uint8_t* __restrict__ seq, const uint64_t off, const uint32_t len, const uint32_t k,
+                                                 const uint32_t s, const uint32_t stride, uint32_t* out0, uint32_t& wcount, bool& dup)
+{
+    const uint32_t kmask = 0xFFFFFFFFu >> (32u - 2u * k);
+    const uint32_t rcshift = 2u * k - 2u;
+    uint32_t sk[kLaneS];
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneS; ++i) sk[i] = 0xFFFFFFFFu;
+    uint32_t fwd = 0, rc = 0, since = 0, wpos = 0;
+    const uint4* src = reinterpret_cast<const uint4*>(seq + off);       // sequences start 4-byte aligned
+    uint4 nxt = src[0];
+    for (uint32_t j0 = 0; j0 < len; j0 += 16) {
+        const uint4 cur = nxt;
+        if (j0 + 16 < len) nxt = src[(j0 >> 4) + 1];
+        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            uint32_t codes, ambs;
+            lane_encode4(wd[d], codes, ambs);
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) {
+                const uint32_t j = j0 + d * 4 + t;
+                if (j < len) {
+                    const uint32_t c = (codes >> (8 * t)) & 3u;
+                    const bool a = (ambs >> t) & 1u;
+                    fwd = ((fwd << 2) | c) & kmask;
+                    rc = (rc >> 2) | ((3u - c) << rcshift);
+                    since = a ? 0u : since + 1u;
+                    if (j + 1 >= k) {
+                        uint32_t h = 0xFFFFFFFFu;
+                        if (since >= k) h = tm_hash(fwd < rc ? fwd : rc);
+                        // insertion chain: sk stays sorted ascending, the largest value falls out
+#pragma unroll
+                        for (uint32_t i = 0; i < kLaneS; ++i) {
+                            const uint32_t lo = min(sk[i], h);
+                            h = max(sk[i], h);
+                            sk[i] = lo;
+                        }
+                        ++wpos;
+                        if (wpos == stride || j + 1 == len) {              // window complete (row 1: k-mers partition)
+                            uint32_t* out = out0 + (size_t)wcount * s;
+#pragma unroll
+                            for (uint32_t i = 0; i < kLaneS; ++i) {
+                                if (i < s) out[i] = sk[i];
+                                if (i + 1 < s) dup = dup || (sk[i] == sk[i + 1] && sk[i] != 0xFFFFFFFFu);
+                                sk[i] = 0xFFFFFFFFu;
+                            }
+                            ++wcount; wpos = 0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t sketch_lane_one(const BatchView& b, const SketchParams& sp, const uint32_t* __restrict__ winOff,
                                                     uint32_t* features, const uint32_t q)
 {
@@ -1029,73 +1093,176 @@ __device__ __forceinline__ uint32_t sketch_lane_one(const BatchView& b, const Sk
         for (uint32_t i = 0; i < nw * s; ++i) features[(size_t)widx0 * s + i] = 0xFFFFFFFFu;   // nothing to probe here
         return kFlagSketch;
     }
-    const uint32_t kmask = 0xFFFFFFFFu >> (32u - 2u * k);
-    const uint32_t rcshift = 2u * k - 2u;
     bool dup = false;
     uint32_t wcount = 0;
     for (uint32_t mate = 0; mate < 2; ++mate) {
         const uint32_t off = mate ? qi.z : qi.x;
         const uint32_t len = mate ? qi.w : qi.y;
         if (len < k) continue;
-        uint32_t sk[kLaneS];
+        lane_sketch_span(b.seq, off, len, k, s, stride, features + (size_t)widx0 * s, wcount, dup);
+    }
+    return dup ? kFlagSketch : kFlagProbe;
+}
+
+constexpr uint32_t kChunkWins = MC_CHUNK_WINS;   // windows per chunk lane of a long read
+
+// Long single reads (> kLaneMaxLen) are cut into chunks of kChunkWins windows; every chunk is sketched and probed by its own
+// lane (chunk_sketch_kernel / chunk_probe_kernel), so a 19 000 bp read keeps 43 lanes busy instead of one wave for 170 windows.
+// Here: the read's lane appends its chunk records {query, chunk} to the work list (one atomic per wave).
+__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, Workspace ws)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool chunkable = (sp.stride & 3u) == 0 && ws.chunkList != nullptr;    // chunk starts stay 4-byte aligned
+    uint32_t nch = 0;
+    if (q < b.n && chunkable) {
+        const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+        if (qi.w == 0 && qi.y > kLaneMaxLen) nch = (ws.winOff[q + 1] - ws.winOff[q] + kChunkWins - 1) / kChunkWins;
+    }
+    const uint32_t incl = wave_incl_scan_u32(nch, lane);
+    const uint32_t total = rdlane(incl, 63);
+    if (total) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ws.midCount[3], total);
+        base = rdlane(base, 0);
+        // the wave writes its records together (64 consecutive ones per round); record r belongs to the first lane with incl > r
+        for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+            const uint32_t r = r0 + lane;
+            uint32_t lo = 0, hi = 63;
 #pragma unroll
-        for (uint32_t i = 0; i < kLaneS; ++i) sk[i] = 0xFFFFFFFFu;
-        uint32_t fwd = 0, rc = 0, since = 0, wpos = 0;
-        const uint4* src = reinterpret_cast<const uint4*>(b.seq + off);       // sequences start 4-byte aligned
-        uint4 nxt = src[0];
-        for (uint32_t j0 = 0; j0 < len; j0 += 16) {
-            const uint4 cur = nxt;
-            if (j0 + 16 < len) nxt = src[(j0 >> 4) + 1];
-            const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+            for (uint32_t it = 0; it < 6; ++it) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t v = __shfl(incl, mid);
+                if (v > r) hi = mid; else lo = mid + 1;
+            }
+            const uint32_t owner = min(lo, 63u);
+            const uint32_t first = __shfl(incl, owner) - __shfl(nch, owner);
+            const uint32_t oq = __shfl(q, owner);
+            if (r < total) ws.chunkList[base + r] = make_uint2(oq, r - first);
+        }
+    }
+    if (q >= b.n) return;
+    if (nch) {
+        ws.qflag[q] = kFlagChunks;
+        return;
+    }
+    ws.qflag[q] = sketch_lane_one(b, sp, ws.winOff, ws.features, q);
+}
+
+// one lane per chunk: the window sketches of its <= kChunkWins windows
+__global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchParams sp, Workspace ws)
+{
+    const uint32_t total = ws.midCount[3];
+    for (uint32_t id = blockIdx.x * 128 + threadIdx.x; id < total; id += gridDim.x * 128) {
+        const uint2 rec = ws.chunkList[id];
+        const uint32_t q = rec.x, c = rec.y;
+        const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+        const uint32_t p0 = c * kChunkWins * sp.stride;                            // first k-mer of the chunk
+        const uint32_t len = min(qi.y - p0, kChunkWins * sp.stride + sp.k - 1);
+        uint32_t wcount = 0; bool dup = false;
+        const uint32_t w0 = ws.winOff[q] + c * kChunkWins, w1 = min(ws.winOff[q + 1], w0 + kChunkWins);
+        for (uint32_t i = w0 * sp.s; i < w1 * sp.s; ++i) ws.psize[i] = 0u;        // chunk_probe_kernel writes the found features only
+        lane_sketch_span(b.seq, (uint64_t)qi.x + p0, len, sp.k, sp.s, sp.stride, ws.features + (size_t)w0 * sp.s, wcount, dup);
+        if (dup) ws.qflag[q] = kFlagSketch;                                         // the wave kernel redoes the whole read
+    }
+}
+
+// one lane per chunk: lookups of its <= kChunkWins * s features (kLaneU in flight), (size, payload) per feature slot for the
+// wave kernel, the lane that finishes the read's last chunk hands it over
+__global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
+{
+    const uint32_t total = ws.midCount[3];
+    for (uint32_t id = blockIdx.x * 128 + threadIdx.x; id < total; id += gridDim.x * 128) {
+        const uint2 rec = ws.chunkList[id];
+        const uint32_t q = rec.x, c = rec.y;
+        if (ws.qflag[q] != kFlagChunks) continue;                                  // a chunk saw duplicate hashes
+        const uint32_t w0 = ws.winOff[q] + c * kChunkWins, w1 = min(ws.winOff[q + 1], w0 + kChunkWins);
+        const uint32_t fbase = w0 * s, nf = (w1 - w0) * s;
+        const uint32_t* feats = ws.features + fbase;
+        uint32_t e = 0;
+        uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU], slot[kLaneU];
+        BucketRegs r[kLaneU];
+        bool busy[kLaneU];
 #pragma unroll
-            for (uint32_t d = 0; d < 4; ++d) {
-                uint32_t codes, ambs;
-                lane_encode4(wd[d], codes, ambs);
+        for (uint32_t u = 0; u < kLaneU; ++u) busy[u] = false;
+        for (;;) {
+            bool any = false;
 #pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) {
-                    const uint32_t j = j0 + d * 4 + t;
-                    if (j < len) {
-                        const uint32_t c = (codes >> (8 * t)) & 3u;
-                        const bool a = (ambs >> t) & 1u;
-                        fwd = ((fwd << 2) | c) & kmask;
-                        rc = (rc >> 2) | ((3u - c) << rcshift);
-                        since = a ? 0u : since + 1u;
-                        if (j + 1 >= k) {
-                            uint32_t h = 0xFFFFFFFFu;
-                            if (since >= k) h = tm_hash(fwd < rc ? fwd : rc);
-                            // insertion chain: sk stays sorted ascending, the largest value falls out
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (!busy[u] && e < nf) {
+                    slot[u] = e;
+                    f[u] = feats[e++];
+                    if (f[u] != 0xFFFFFFFFu) {
+                        home[u] = home_group(f[u], tab.nbuckets);
+                        cur[u] = home[u]; step[u] = 1;
+                        r[u] = load_bucket(tab, cur[u]);
+                        busy[u] = true;
+                    }
+                }
+                any = any || busy[u];
+            }
+            if (!any && e >= nf) break;
 #pragma unroll
-                            for (uint32_t i = 0; i < kLaneS; ++i) {
-                                const uint32_t lo = min(sk[i], h);
-                                h = max(sk[i], h);
-                                sk[i] = lo;
-                            }
-                            ++wpos;
-                            if (wpos == stride || j + 1 == len) {              // window complete (row 1: k-mers partition)
-                                uint32_t* out = features + (size_t)(widx0 + wcount) * s;
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (busy[u]) {
+                    const uint32_t keys[4] = {r[u].k.x, r[u].k.y, r[u].k.z, r[u].k.w};
+                    const uint32_t s01 = r[u].sz.x, s23 = r[u].sz.y;
+                    const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
+                    const uint64_t pl[4] = {((uint64_t)r[u].p0.y << 32) | r[u].p0.x, ((uint64_t)r[u].p0.w << 32) | r[u].p0.z,
+                                            ((uint64_t)r[u].p1.y << 32) | r[u].p1.x, ((uint64_t)r[u].p1.w << 32) | r[u].p1.z};
+                    uint32_t size = 0; uint64_t pay = 0;
+                    bool anyFree = false;
 #pragma unroll
-                                for (uint32_t i = 0; i < kLaneS; ++i) {
-                                    if (i < s) out[i] = sk[i];
-                                    if (i + 1 < s) dup = dup || (sk[i] == sk[i + 1] && sk[i] != 0xFFFFFFFFu);
-                                    sk[i] = 0xFFFFFFFFu;
-                                }
-                                ++wcount; wpos = 0;
-                            }
-                        }
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        anyFree = anyFree || sz[i] == 0;
+                        if (sz[i] != 0 && keys[i] == f[u]) { size = sz[i]; pay = pl[i]; }
+                    }
+                    if (size || anyFree || step[u] >= tab.maxProbe) {
+                        if (size) { ws.psize[fbase + slot[u]] = size; ws.ppay[fbase + slot[u]] = pay; }
+                        busy[u] = false;
+                    } else {
+                        cur[u] = next_bucket(home[u], cur[u], step[u], tab.nbuckets);
+                        ++step[u];
+                        r[u] = load_bucket(tab, cur[u]);
                     }
                 }
             }
         }
     }
-    return dup ? kFlagSketch : kFlagProbe;
 }
 
-__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, const uint32_t* __restrict__ winOff,
-                                                          uint32_t* __restrict__ features, uint32_t* __restrict__ qflag)
+// one wave per long read (found through its first chunk record): totals over the read's feature slots, hand-over to the wave kernel.
+// (Collecting the totals with atomics in chunk_probe_kernel cost more than this pass; a per-lane device-scope fence for a
+// "last chunk finishes the read" scheme cost far more: the L2s of the 8 XCDs are written back and invalidated every time.
+// Compacting short lists here for mid_cands_kernel was measured too: what the wave kernel saves, the compaction costs.)
+__global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace ws)
 {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= b.n) return;
-    qflag[q] = sketch_lane_one(b, sp, winOff, features, q);
+    const uint32_t total = ws.midCount[3];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t base = waveId * 64; base < total; base += nWaves * 64) {
+        const uint32_t id = base + lane;
+        uint2 rec = make_uint2(0, 1);
+        if (id < total) rec = ws.chunkList[id];
+        uint64_t m = __ballot(rec.y == 0 && ws.qflag[rec.x] == kFlagChunks);    // first chunk records = one per long read
+        while (m) {
+            const uint32_t j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t q = rdlane(rec.x, j);
+            uint32_t H = 0, nfound = 0, nfeat = 0;
+            for (uint32_t i = ws.winOff[q] * s + lane; i < ws.winOff[q + 1] * s; i += 64) {   // the whole wave sums the read's slots
+                const uint32_t sz = ws.psize[i] & 0xFFFFu;
+                H += sz; nfound += sz ? 1u : 0u; nfeat += ws.features[i] != 0xFFFFFFFFu ? 1u : 0u;
+            }
+            H = wave_sum_u32(H); nfound = wave_sum_u32(nfound); nfeat = wave_sum_u32(nfeat);
+            if (lane == 0) {
+                QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nfeat;   // probe steps are not counted on this path
+                ws.qstat[q] = qs;
+                ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
+                ws.qflag[q] = kFlagCands;
+            }
+        }
+    }
 }
 
 // probe_cands_kernel: ONE LANE PER QUERY for rows 6-10.
@@ -1111,9 +1278,7 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
 // Lists longer than kLaneHits: second pass that stores (size, payload) per feature for sort_candidates_kernel.
 struct LaneCand { uint32_t tgt, hits, beg, end; };
 constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in u64): conflict-free lane-private rows
-constexpr uint32_t kLaneU = 4;                                // lookups in flight per lane
 constexpr uint32_t kLaneBlock = 128;
-constexpr uint32_t kMidMax = 256;                             // longest list taken by mid_cands_kernel
 
 // rows 10: one candidate enters the lane's top list exactly as on the CPU (candidate_generation.hpp:172-231)
 __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK], LaneCand c, const uint32_t K,
@@ -1272,7 +1437,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(&ws.midCount[c], (uint32_t)__popcll(mask));
                 base = __shfl(base, leader);
-                reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 8), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
+                reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 12), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
             }
         }
         return;
@@ -1363,7 +1528,17 @@ void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const 
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
 {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(sketch_lane_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, ws.winOff, ws.features, ws.qflag);
+    hipLaunchKernelGGL(sketch_lane_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, ws);
+}
+void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st)
+{
+    if (b.n == 0 || !ws.chunkList) return;
+    // persistent grids over the chunk work list (usually empty: its length stays on the device)
+    if (stage == 0) hipLaunchKernelGGL(chunk_sketch_kernel, dim3(2048), dim3(128), 0, st, b, sp, ws);
+    else {
+        hipLaunchKernelGGL(chunk_probe_kernel, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
+        hipLaunchKernelGGL(chunk_finish_kernel, dim3(1024), dim3(256), 0, st, sp.s, ws);
+    }
 }
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                         const uint32_t* taxkey, void* cands, hipStream_t st)
@@ -1440,15 +1615,15 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
     // t+1 are requested while iteration t is processed (three dependent HBM round trips per query otherwise)
     auto load_rec = [&](uint32_t w) -> uint4 {
         const uint32_t slot = w * QPW + qi;
-        return (w * QPW < total && slot < total) ? work[slot] : make_uint4(0, 0, 0, 0);      // .z (entries | locations << 8) == 0: idle group
+        return (w * QPW < total && slot < total) ? work[slot] : make_uint4(0, 0, 0, 0);      // .z (entries | locations << 12) == 0: idle group
     };
     uint32_t esz[kRounds]; uint64_t epay[kRounds];
     auto load_entries = [&](const uint4& rec) {
 #pragma unroll
         for (uint32_t u = 0; u < kRounds; ++u) {
             const uint32_t e = u * G + lg;
-            esz[u] = e < (rec.z & 0xFFu) ? ws.psize[rec.y + e] : 0u;
-            epay[u] = e < (rec.z & 0xFFu) ? ws.ppay[rec.y + e] : 0ull;
+            esz[u] = e < (rec.z & 0xFFFu) ? ws.psize[rec.y + e] : 0u;
+            epay[u] = e < (rec.z & 0xFFFu) ? ws.ppay[rec.y + e] : 0ull;
         }
     };
     const uint32_t w0 = blockIdx.x * 4 + wave;
@@ -1456,7 +1631,7 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
     load_entries(rec);
     for (uint32_t w = w0; w * QPW < total; w += nWaves) {
         const bool act = rec.z != 0;
-        const uint32_t q = rec.x, fbase = rec.y, nent = rec.z & 0xFFu, H = rec.z >> 8, maxWin = rec.w;
+        const uint32_t q = rec.x, fbase = rec.y, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
         uint32_t klo[kMidR], khi[kMidR];
         if (act) {
             // ---- row 7a: entry table in LDS: payload in the list area, start offset in the segment area (at most one entry per

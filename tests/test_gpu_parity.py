@@ -281,3 +281,46 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K):
     for i in range(1500):
         check(pc, i, reads[i], mates[i], 400)
     odb.close()
+
+
+@pytest.mark.parametrize("lowest,K", [(0, 2), (4, 4)])
+def test_long_reads_chunk_lanes_against_oracle(golden, lowest, K):
+    """Single reads above 512 bp are cut into chunks of 4 windows, each sketched and probed by its own lane (chunk_sketch_kernel /
+    chunk_probe_kernel), then sorted by the wave kernel: 513 .. 12000 bp, with substitutions, N runs and lower case, mixed with
+    short reads in one batch, against the oracle (which is pinned to the reference)."""
+    from metacache_amd import synth
+    rng = np.random.default_rng(777 + K)
+    names = [golden.db_path("toy32")]
+    odb = cpuref.oracle().open(names[0])
+    # the toy genomes are not stored in the fixtures: long reads = concatenations of the golden reads (real k-mers of the targets)
+    single, _, _ = golden.reads()
+    pool = [r for r in single[:1500] if len(r) == 150]
+    reads = []
+    for L in [513, 514, 560, 575, 576, 577, 1024, 1025, 2000, 4095, 4096, 4097, 9000, 12000] + [int(x) for x in rng.integers(520, 6000, 60)]:
+        parts, tot = [], 0
+        while tot < L:
+            p = pool[int(rng.integers(0, len(pool)))]
+            parts.append(p); tot += len(p)
+        r = bytearray(b"".join(parts)[:L])
+        for _ in range(int(L * 0.03)):
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, L - 40)); r[a:a + 30] = b"N" * 30
+        if rng.random() < 0.2:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    reads += [bytes(p) for p in pool[:200]]                                # short reads in the same batches
+    db = api.Database.open(names[0], max_candidates=K, slot_max_queries=64, slot_max_chars=1 << 18)
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    db.close()
+    for i, r in enumerate(reads):
+        h, e = odb.query(r, b"", K, lowest, 0)
+        assert counts[i] == len(h), (i, len(r))
+        e = e[:K]
+        for j in range(K):
+            if j < len(e):
+                assert (cands[i, j]["tgt"], cands[i, j]["hits"], cands[i, j]["beg"], cands[i, j]["end"]) == \
+                       (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]), (i, len(r), j, cands[i], e)
+            else:
+                assert cands[i, j]["hits"] == 0, (i, j)
+    odb.close()
