@@ -204,7 +204,7 @@ void mc_destroy(mc_ctx* ctx)
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
-                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bHitlist, &P.bMid, &P.bChunkList, &P.bChunkLeft};
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
@@ -520,9 +520,8 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, P.bHitlist, 64))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 16))) return rc;
-    if (lanePath && ((rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8)) || (rc = ensure(ctx, P.bChunkLeft, (size_t)(n + 1) * 4)))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
     if ((rc = ensure(ctx, P.bStats, 64))) return rc;
@@ -531,11 +530,11 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     Workspace ws{};
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
-    ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.counter = (uint32_t*)P.bHitlist.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
+    ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
     ws.scanTmp = P.bScan.p; ws.stats = (uint64_t*)P.bStats.p;
     if (lanePath) {
         ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 4;
-        ws.chunkList = (uint2*)P.bChunkList.p; ws.chunkLeft = (uint32_t*)P.bChunkLeft.p;
+        ws.chunkList = (uint2*)P.bChunkList.p;
     }
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};

@@ -103,11 +103,10 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint64_t* ppay;          // [W*s]      payload per feature
     QueryStat* qstat;        // [n]
     uint32_t* qflag;         // [n]        0 = done, 1 = needs sketch+probe (wave), 2 = needs candidates (wave),
-                             //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel
-    uint32_t* counter;       // [1]        (unused)
+                             //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel,
+                             //            6 = long read handled by the chunk lane kernels
     uint32_t* midCount;      // [4]        lengths of the three work lists of mid_cands_kernel, [3] = chunk records (zeroed per batch)
-    uint2*    chunkList;     // [W/4 + n]  {query, chunk}: long single reads, cut into chunks of 4 windows for the lane kernels
-    uint32_t* chunkLeft;     // [n]        chunks of a long read still to be probed
+    uint2*    chunkList;     // [W + n]    {query, chunk}: long single reads, cut into one-window chunks for the chunk lane kernels
     uint32_t* midList;       // [3][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan

@@ -16,7 +16,7 @@
 namespace mcamd {
 
 // per-query state: what is still to be done (Workspace::qflag)
-constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagLaneCands = 3, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6;
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6;
 
 // ================================================================================================
 // wave64 primitives
