@@ -5,15 +5,20 @@
  * replaces.  The library behind it is hand-written HIP for gfx950; there is NO CPU fallback: every
  * call that needs the GPU fails with MC_ERR_HIP if no device is usable.
  *
- * Pipeline per batch of queries (a query = one read or one read pair):
- *   sketch_probe kernel : windows -> 2-bit/LDS -> canonical k-mers -> min-hash sketch -> bucket probe
- *   scan                : per-query hit counts -> segment offsets
- *   sort_candidates     : gather location lists -> sort (tgt,win) -> contiguous-window-range
- *                         candidates -> top-K                (semantics = reference CPU classifier)
+ * Pipeline per batch of queries (a query = one read or one read pair), details in DESIGN.md §3:
+ *   plan / scan          : windows per query -> offsets
+ *   sketch_lane          : one lane per short read: rolling canonical k-mers -> min-hash sketches
+ *   chunk_sketch / probe : long single reads, one lane per window
+ *   probe_cands          : one lane per query: bucket lookups, location list, sort, window-range candidates, top-K
+ *   mid_cands            : lists of 33..256 locations, 4 / 8 / 16 lanes per query, register sort
+ *   query_wave / sort_candidates : one wave per query for everything else (and for -allhits)
+ *   (semantics = reference CPU classifier, bit for bit)
  *
- * Threading: one mc_ctx per (process, device).  mc_batch_* calls are thread-safe for DISTINCT slots
- * (one slot per host thread, like one query_handler / query_host_data per thread in the reference,
- * database_query.hpp:204-205, query_batch.cuh:369-371); mc_batch_submit is serialised internally.
+ * Threading: one mc_ctx per (process, device).  mc_batch_* calls are thread-safe for DISTINCT slots (one slot per host
+ * thread, like one query_handler / query_host_data per thread in the reference, database_query.hpp:204-205,
+ * query_batch.cuh:369-371).  Between mc_batch_submit and mc_batch_wait a slot borrows one of a few device pipes (stream +
+ * workspace), so the copies and kernels of different slots overlap on the device.  mc_query_device and
+ * mc_candidates_from_hits use the context's own pipe: one caller at a time.
  */
 #ifndef METACACHE_AMD_H_
 #define METACACHE_AMD_H_
