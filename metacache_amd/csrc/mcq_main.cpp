@@ -30,6 +30,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <regex>
 #include <thread>
 #include <cstdint>
 #include <cstdio>
@@ -70,7 +71,46 @@ struct Taxonomy {
     const uint32_t* targetLineages = nullptr;        // [targets * 21]
     uint64_t numTargets = 0;
 
+    std::map<std::string, uint32_t> targetByName;    // name2tax_ (taxonomy.hpp:1108-1127): sequence-level taxa by name
+    std::vector<char> coveredCache;                 // covers(): taxa on the full lineage of any target
+
     const Taxon* taxon(uint32_t idxPlus1) const { return idxPlus1 ? &taxa[idxPlus1 - 1] : nullptr; }
+    uint32_t with_name(const std::string& n) const { if (n.empty()) return 0; auto i = targetByName.find(n); return i == targetByName.end() ? 0 : i->second; }
+    uint32_t with_similar_name(const std::string& n) const
+    {
+        if (n.empty()) return 0;
+        auto i = targetByName.upper_bound(n);
+        if (i == targetByName.end() || i->first.compare(0, n.size(), n) != 0) return 0;
+        return i->second;
+    }
+    uint32_t with_id(int64_t id) const { auto i = byId.find(id); return i == byId.end() ? 0 : i->second + 1; }
+    // cached_next_ranked_ancestor (taxonomy.hpp:1245-1256)
+    uint32_t next_ranked_ancestor(uint32_t t) const
+    {
+        if (!t) return 0;
+        if (taxon(t)->rank != kNumRanks) return t;
+        for (uint32_t a : ranks_of(t)) if (a) return a;
+        return 0;
+    }
+    bool covers(uint32_t t) const { return t && coveredCache[t]; }   // taxonomy.hpp:1355-1366
+    void build_covered()
+    {
+        {
+            coveredCache.assign(taxa.size() + 1, 0);
+            for (size_t i = 0; i < taxa.size(); ++i) {
+                if (taxa[i].rank != 0 || taxa[i].id >= 0) continue;          // targets only
+                coveredCache[i + 1] = 1;
+                int64_t id = taxa[i].parent;
+                for (int guard = 0; id != 0 && guard < 1000; ++guard) {
+                    auto it = byId.find(id);
+                    if (it == byId.end()) break;
+                    coveredCache[it->second + 1] = 1;
+                    if (taxa[it->second].parent == id) break;
+                    id = taxa[it->second].parent;
+                }
+            }
+        }
+    }
     Lineage target_ranks(uint32_t tgt) const
     {
         Lineage l{};
@@ -116,6 +156,7 @@ struct Options {
     uint64_t minReadLen = 0, maxReadLen = std::numeric_limits<uint64_t>::max();
     int64_t queryLimit = std::numeric_limits<int64_t>::max();
     bool hitsPerRef = false, abundances = false;
+    bool showGroundTruth = false, determineGroundTruth = false, precision = false, taxonCoverage = false;
     int abundancePer = kNumRanks;                    // none
     std::string targetsFile, abundanceFile;
 };
@@ -174,6 +215,9 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-allhits" || a == "-all-hits") o.allhits = true;
         else if (a == "-locations") { o.locations = true; o.tophits = true; }
         else if (a == "-queryids" || a == "-query-ids") o.queryIds = true;
+        else if (a == "-ground-truth") { o.determineGroundTruth = true; o.showGroundTruth = true; }
+        else if (a == "-precision") { o.precision = true; o.determineGroundTruth = true; }
+        else if (a == "-taxon-coverage") { o.taxonCoverage = true; o.precision = true; o.determineGroundTruth = true; }
         // an optional file name follows (clipp opt_value: the next word unless it is an option)
         else if (a == "-abundances" || a == "-abundance") { o.abundances = true; if (i + 1 < args.size() && args[i + 1][0] != '-') o.abundanceFile = args[++i]; }
         else if (a == "-abundance-per") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); if (r < kNumRanks - 1) o.abundancePer = r; }
@@ -421,6 +465,60 @@ void show_matches(std::ostream& os, const Options& o, const Taxonomy& tx, const 
     emit(hits[cur], count);
 }
 
+// ---- ground truth from the query header (classification.cpp:104-137; sequence_io.cpp:479-673) ---------------------------
+const std::regex& accession_regex()
+{
+    static const std::regex re("(^|[^[:alnum:]])(([A-Z][_A-Z]{1,9}[0-9]{5,})(\\.[0-9]+)?)", std::regex::optimize);
+    return re;
+}
+
+std::string leading_word(const std::string& t)
+{
+    auto fst = std::find_if(t.begin(), t.end(), [](char c) { return !std::isspace((unsigned char)c); });
+    if (fst == t.end()) return t;
+    auto lst = std::find_if(fst + 1, t.end(), [](char c) { return std::isspace((unsigned char)c); });
+    return std::string(fst, lst);
+}
+
+std::string filename_without_extension(const std::string& t)
+{
+    if (t.empty()) return t;
+    auto fst = std::find(t.rbegin(), t.rend(), '/').base();
+    auto ext = std::find(fst, t.end(), '.');
+    return std::string(fst, ext);
+}
+
+int64_t taxon_id_in_header(const std::string& t)
+{
+    auto i = t.find("taxid");
+    if (i == std::string::npos) return 0;
+    i += 6;                                                   // "taxid" + one separator character
+    if (i > t.size()) return 0;
+    auto j = t.find('|', i);
+    if (j == std::string::npos) { j = t.find(' ', i); if (j == std::string::npos) j = t.size(); }
+    try { return (int64_t)std::stoull(t.substr(i, j - i)); } catch (std::exception&) { return 0; }
+}
+
+uint32_t ground_truth(const Taxonomy& tx, const std::string& header)
+{
+    if (header.empty()) return 0;
+    std::smatch m;
+    std::regex_search(header, m, accession_regex());
+    uint32_t t = tx.with_name(m[4].length() ? m[2].str() : std::string());      // accession.version
+    if (t) return tx.next_ranked_ancestor(t);
+    t = tx.with_similar_name(m[3].str());                                       // accession, any version
+    if (t) return tx.next_ranked_ancestor(t);
+    t = tx.with_id(taxon_id_in_header(header));
+    if (t) return tx.next_ranked_ancestor(t);
+    t = tx.with_name(header);
+    if (t) return tx.next_ranked_ancestor(t);
+    t = tx.with_name(leading_word(header));
+    if (t) return tx.next_ranked_ancestor(t);
+    t = tx.with_name(filename_without_extension(header));
+    if (t) return tx.next_ranked_ancestor(t);
+    return 0;
+}
+
 // classification.cpp:146-189
 uint32_t classify(const Options& o, const Taxonomy& tx, const std::vector<Cand>& cand, bool& isTarget, uint32_t& tgt)
 {
@@ -487,8 +585,10 @@ struct Session {
             mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
             tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm; tx.byId.emplace(tx.taxa[i].id, (uint32_t)i);
             mc_db_taxon_source(ctx, i, nullptr, nullptr, &tx.taxa[i].windows);
+            if (tx.taxa[i].rank == 0 && tx.taxa[i].id < 0) tx.targetByName.emplace(tx.taxa[i].name, (uint32_t)i + 1);
         }
         mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets);
+        tx.build_covered();
     }
 };
 
@@ -540,21 +640,28 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             os << o.comment << "TABLE_LAYOUT: ";
             if (o.queryIds) os << "query_id" << o.column;
             os << "query_header" << o.column;
+            const int rmax = o.lineage ? o.highest : o.lowest;
+            auto taxon_header = [&](const std::string& prefix) {              // show_taxon_header, printing.cpp:133-172
+                auto hdr = [&](int r, bool named) {
+                    if (o.showRank) os << prefix << (named ? kRankNames[r] : "rank") << o.rankSuffix;
+                    if (o.showName) { os << prefix << "taxname"; if (o.showId) os << o.idPrefix << prefix << "taxid" << o.idSuffix; }
+                    else if (o.showId) os << prefix << "taxid";
+                };
+                if (o.lowest == rmax) hdr(o.lowest, false);
+                else for (int r = o.lowest; r <= rmax; ++r) { hdr(r, true); if (r < rmax) os << o.taxSep; }
+            };
+            if (o.showGroundTruth) { taxon_header("truth_"); os << o.column; }
             if (o.allhits) os << "all_hits" << o.column;
             if (o.tophits) os << "top_hits" << o.column;
             if (o.locations) os << "candidate_locations" << o.column;
-            const int rmax = o.lineage ? o.highest : o.lowest;
-            auto hdr = [&](int r, bool named) {
-                if (o.showRank) os << (named ? kRankNames[r] : "rank") << o.rankSuffix;
-                if (o.showName) { os << "taxname"; if (o.showId) os << o.idPrefix << "taxid" << o.idSuffix; } else if (o.showId) os << "taxid";
-            };
-            if (o.lowest == rmax) hdr(o.lowest, false);
-            else for (int r = o.lowest; r <= rmax; ++r) { hdr(r, true); if (r < rmax) os << o.taxSep; }
+            taxon_header("");
             os << '\n';
         }
 
         const auto t0 = std::chrono::steady_clock::now();
-        uint64_t assigned[kNumRanks + 1] = {};                                   // classification_statistics::assign
+        uint64_t assigned[kNumRanks + 1] = {};                                   // classification_statistics (classification_statistics.hpp)
+        uint64_t known[kNumRanks + 1] = {}, correct[kNumRanks + 1] = {}, wrong[kNumRanks + 1] = {}, covFalsePos[kNumRanks + 1] = {};
+        uint64_t covTotalDomain = 0;
 
         // ---- all inputs are indexed first: batches = runs of consecutive queries, ids continue across files -------------
         struct Batch { size_t f1, f2; size_t qBeg, qEnd; uint64_t idBase; std::string prefix; const std::vector<uint64_t>* sel; };
@@ -644,7 +751,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::vector<Cand> cands;
             std::string scratch1, scratch2;
             std::ostringstream out;
-            uint64_t mine[kNumRanks + 1] = {};
+            uint64_t mine[kNumRanks + 1] = {}, myKnown[kNumRanks + 1] = {}, myCorrect[kNumRanks + 1] = {}, myWrong[kNumRanks + 1] = {};
+            uint64_t myFalsePos[kNumRanks + 1] = {}, myCovDomain = 0;
             std::map<uint32_t, double> myCounts;
             std::vector<Cover> myCovers;
             auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = m; };
@@ -702,7 +810,35 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                         }
                         bool isTarget; uint32_t tgt;
                         const uint32_t best = classify(o, tx, cands, isTarget, tgt);
-                        ++mine[best ? tx.taxon(best)->rank : kNumRanks];
+                        const int bestRank = best ? tx.taxon(best)->rank : kNumRanks;
+                        ++mine[bestRank];
+                        uint32_t truth = 0;
+                        if (o.determineGroundTruth) truth = ground_truth(tx, std::string(m.header.p, m.header.n));
+                        if (o.precision) {                                       // evaluate_classification, classification.cpp:272-295
+                            const int knownRank = truth ? tx.taxon(truth)->rank : kNumRanks;
+                            int correctRank = kNumRanks;                         // rank of the ranked LCA of mapping and truth
+                            if (best && truth) {
+                                const Lineage la = tx.ranks_of(best), lb = tx.ranks_of(truth);
+                                for (int r = 0; r < kNumRanks; ++r) if (la[r] && la[r] == lb[r]) { correctRank = tx.taxon(la[r])->rank; break; }
+                            }
+                            // assign_known_correct (classification_statistics.hpp:86-106)
+                            if (correctRank < bestRank) correctRank = bestRank;
+                            if (correctRank < knownRank) correctRank = knownRank;
+                            ++myKnown[knownRank];
+                            if (knownRank != kNumRanks) {
+                                ++myCorrect[correctRank];
+                                if (correctRank > knownRank && correctRank > bestRank) ++myWrong[correctRank - 1];
+                            }
+                            if (o.taxonCoverage && truth) {                       // update_coverage_statistics, classification.cpp:242-265
+                                for (uint32_t t : tx.ranks_of(truth)) {
+                                    if (!t) continue;
+                                    const int r = tx.taxon(t)->rank;
+                                    const bool classifiedOnRank = best && r >= bestRank;
+                                    if (!tx.covers(t) && classifiedOnRank) ++myFalsePos[r];
+                                    if (r == 19) ++myCovDomain;
+                                }
+                            }
+                        }
                         if (taxCountsWanted && best) ++myCounts[best];           // classify_and_evaluate, classification.cpp:552-554
                         if (o.hitsPerRef)                                        // matches_per_target::insert (matches_per_target.hpp:100-110)
                             for (const Cand& c : cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) myCovers.push_back(Cover{c.tgt, m.id, c.beg, c.end, c.hits});
@@ -711,6 +847,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                         const void* sp = memchr(m.header.p, ' ', m.header.n);
                         out.write(m.header.p, sp ? (const char*)sp - m.header.p : (std::streamsize)m.header.n);
                         out << o.column;
+                        if (o.showGroundTruth) { show_taxon(out, o, tx, truth, false, 0); out << o.column; }
                         if (o.allhits) { show_matches(out, o, tx, r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i]); out << o.column; }
                         if (o.tophits) { show_candidates(out, o, tx, cands); out << o.column; }
                         if (o.locations) {                                       // show_candidate_ranges, printing.cpp:370-380
@@ -726,7 +863,10 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 deliver(b, out.str());
             }
             std::lock_guard<std::mutex> l(errMtx);
-            for (int r = 0; r <= kNumRanks; ++r) assigned[r] += mine[r];
+            for (int r = 0; r <= kNumRanks; ++r) {
+                assigned[r] += mine[r]; known[r] += myKnown[r]; correct[r] += myCorrect[r]; wrong[r] += myWrong[r]; covFalsePos[r] += myFalsePos[r];
+            }
+            covTotalDomain += myCovDomain;
             for (const auto& kv : myCounts) bestCounts[kv.first] += kv.second;
             covers.insert(covers.end(), myCovers.begin(), myCovers.end());
         };
@@ -852,10 +992,29 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     if (unassigned > 0) os << o.comment << "unclassified: " << (100 * (unassigned / double(total))) << "% (" << unassigned << ")\n";
                     os << o.comment << "classified:\n";
                     const int shown[] = {0, 3, 4, 6, 10, 12, 14, 16, 18, 19, 20};
-                    for (int r : shown) {
-                        uint64_t upto = 0;
-                        for (int x = 0; x <= r; ++x) upto += assigned[x];
-                        if (upto > 0) { std::string rn = kRankNames[r]; rn.resize(11, ' '); os << o.comment << "  " << rn << (100 * (upto / double(total))) << "% (" << upto << ")\n"; }
+                    auto upto = [](const uint64_t* a, int r) { uint64_t s = 0; for (int x = 0; x <= r; ++x) s += a[x]; return s; };
+                    auto padded = [](int r) { std::string rn = kRankNames[r]; rn.resize(11, ' '); return rn; };
+                    for (int r : shown)
+                        if (upto(assigned, r) > 0) os << o.comment << "  " << padded(r) << (100 * (upto(assigned, r) / double(total))) << "% (" << upto(assigned, r) << ")\n";
+                    if (upto(known, kNumRanks - 1) > 0) {                         // ground truth block, printing.cpp:537-592
+                        if (known[kNumRanks] > 0) os << o.comment << "ground truth unknown: " << (100 * (known[kNumRanks] / double(total))) << "% (" << known[kNumRanks] << ")\n";
+                        os << o.comment << "ground truth known:\n";
+                        for (int r : shown) if (upto(assigned, r) > 0) os << o.comment << "  " << padded(r) << (100 * (upto(known, r) / double(total))) << "% (" << upto(known, r) << ")\n";
+                        os << o.comment << "correctly classified:\n";
+                        for (int r : shown) if (upto(assigned, r) > 0) os << o.comment << "  " << padded(r) << upto(correct, r) << '\n';
+                        auto wrongFrom = [&](int r) { uint64_t s = 0; for (int x = r; x < kNumRanks; ++x) s += wrong[x]; return s; };
+                        os << o.comment << "precision (correctly classified / classified) if ground truth known:\n";
+                        for (int r : shown) if (upto(assigned, r) > 0) {
+                            const double tot = double(upto(correct, r)) + double(wrongFrom(r));
+                            os << o.comment << "  " << padded(r) << (100 * (tot > 0 ? upto(correct, r) / tot : 0.0)) << "%\n";
+                        }
+                        os << o.comment << "sensitivity (correctly classified / all) if ground truth known:\n";
+                        for (int r : shown) if (upto(assigned, r) > 0)
+                            os << o.comment << "  " << padded(r) << (100 * (upto(known, r) > 0 ? upto(correct, r) / double(upto(known, r)) : 0.0)) << "%\n";
+                        if (covTotalDomain > 0) {
+                            os << o.comment << "false positives (hit on taxa not covered in DB):\n";
+                            for (int r : shown) if (upto(assigned, r) > 0) os << o.comment << "  " << padded(r) << covFalsePos[r] << "\n";
+                        }
                     }
                 }
             } else std::cerr << o.comment << "No valid query sequences found.\n";

@@ -59,6 +59,10 @@ CASES = {
     "abundance_per_sequence": (["cli_pairs.fq"], ["-pairseq", "-no-map", "-abundance-per", "sequence", "-hitdiff", "50", "-maxcand", "4"]),
     "hits_per_ref": (["cli_reads.fa"], ["-no-map", "-hits-per-ref"]),
     "hits_per_ref_lineage": (["cli_pairs.fq"], ["-pairseq", "-hits-per-ref", "-lineage", "-highest", "genus", "-taxids", "-maxcand", "3"]),
+    "ground_truth": (["cli_truth.fa"], ["-ground-truth", "-taxids"]),
+    "precision": (["cli_truth.fa"], ["-precision", "-mapped-only", "-lowest", "species"]),
+    "precision_truth_lineage": (["cli_truth.fa"], ["-precision", "-ground-truth", "-lineage", "-separate-cols", "-tophits"]),
+    "reference_test_matrix": (["cli_truth.fa"], ["-mapped-only", "-precision", "-ground-truth", "-tophits", "-allhits", "-abundances", "-abundance-per", "species"]),
 }
 
 # name -> (input files, options with {targets} / {abund} standing for extra output files)
@@ -102,6 +106,20 @@ def main():
                 f.write(body + "\n")
             if n % 50 == 7:
                 f.write("\n")                                                           # blank lines are skipped
+    # headers that carry a ground truth in the forms ground_truth() understands (classification.cpp:104-137): accession.version of
+    # a target, accession without version, taxid|<id>, a target name as leading word, nothing usable
+    taxids = [562, 813, 2151, 9, 56, 29459, 37372, 74109, 99999]
+    with open(os.path.join(HERE, "cli_truth.fa"), "w") as f:
+        for n in range(300):
+            kind = n % 6
+            acc = f"NC_{(n * 7) % 24 + 1:06d}"
+            if kind == 0: hdr = f"t{n:04d} {acc}.1 sampled"
+            elif kind == 1: hdr = f"t{n:04d}|{acc}|frag"
+            elif kind == 2: hdr = f"t{n:04d} taxid|{taxids[n % len(taxids)]}|x"
+            elif kind == 3: hdr = f"{acc}.1"
+            elif kind == 4: hdr = f"t{n:04d} nothing here"
+            else: hdr = f"gi|12345|ref|{acc}.2| taxid {taxids[(n // 6) % len(taxids)]}"
+            f.write(f">{hdr}\n{single[n].decode()}\n")
     with open(os.path.join(HERE, "cli_pairs.fq"), "w") as f:
         for n in range(120):
             for m, s in ((1, p1[n]), (2, p2[n])):
