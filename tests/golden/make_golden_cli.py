@@ -83,6 +83,17 @@ INTERACTIVE = {
 }
 
 
+def format_matrix():
+    """the option matrix of the reference's own formatting test (test/run_tests:86-117): 3 x 4 x 12 = 144 combinations"""
+    lines = []
+    for outer in ("", "-mapped-only", "-separator /%/"):
+        for mid in ("", "-omit-ranks", "-queryids", "-queryids -omit-ranks"):
+            for tax in ("", "-taxids", "-taxids-only"):
+                for lay in ("", "-lineage", "-separate-cols", "-lineage -separate-cols"):
+                    lines.append(("-no-summary -no-query-params " + " ".join(x for x in (outer, mid, lay, tax) if x)).split())
+    return lines
+
+
 def wrap(seq: bytes, width: int) -> str:
     s = seq.decode()
     return "\n".join(s[i:i + width] for i in range(0, len(s), width)) if s else ""
@@ -178,6 +189,21 @@ def main():
             with open(os.path.join(tmp, f"inter{i}.txt")) as f:
                 outs.append(f.read().split("\n"))
         out["interactive"] = {"initial": INTERACTIVE["initial"], "lines": INTERACTIVE["lines"], "outputs": outs}
+        # the reference's formatting matrix, one interactive session, 30 reads
+        with open(os.path.join(HERE, "cli_fmt.fa"), "w") as f:
+            for n in range(30):
+                f.write(f">fmt{n:02d} NC_{n % 24 + 1:06d}.1\n{single[n * 11].decode()}\n")
+        matrix = format_matrix()
+        stdin = ""
+        for i, line in enumerate(matrix):
+            stdin += " ".join(["cli_fmt.fa"] + line + ["-out", os.path.join(tmp, f"fmt{i}.txt")]) + "\n"
+        subprocess.run([REF, "query", "toy32", "-threads", "1"], cwd=HERE, input=stdin + "\n", text=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, check=True)
+        outs = []
+        for i in range(len(matrix)):
+            with open(os.path.join(tmp, f"fmt{i}.txt")) as f:
+                outs.append(f.read().split("\n"))
+        out["format_matrix"] = {"matrix": matrix, "outputs": outs}
     with gzip.open(os.path.join(HERE, "cli_expected.json.gz"), "wt") as f:
         json.dump(out, f)
     print("wrote", len(out), "cases")

@@ -93,6 +93,22 @@ def test_cli_interactive_mode_matches_reference(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_reference_formatting_matrix(tmp_path):
+    """The 144 option combinations of the reference's own formatting test (test/run_tests:86-117), typed into ONE interactive
+    session: -mapped-only / -separator x -omit-ranks / -queryids x -taxids / -taxids-only x -lineage / -separate-cols."""
+    build.build_library()
+    c = CASES["format_matrix"]
+    stdin = ""
+    for i, line in enumerate(c["matrix"]):
+        stdin += " ".join(["cli_fmt.fa"] + line + ["-out", str(tmp_path / f"fmt{i}.txt")]) + "\n"
+    r = subprocess.run([build.MCQ, "query", "toy32", "-threads", "1"], cwd=GOLD, input=stdin + "\n", capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert len(c["matrix"]) == 144
+    for i, exp in enumerate(c["outputs"]):
+        _same(open(tmp_path / f"fmt{i}.txt").read().split("\n"), exp, ("format_matrix", i, c["matrix"][i]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", PLAIN)
 def test_cli_matches_reference_output(case, tmp_path):
     build.build_library()
