@@ -6,6 +6,9 @@
 //
 // No MFMA anywhere: this is integer hashing and gathering; the bound is HBM/L2 random access.
 #include "kernels.h"
+#ifndef MC_LANE_HITS
+#define MC_LANE_HITS 24
+#endif
 #ifndef MC_CHUNK_WINS
 #define MC_CHUNK_WINS 1
 #endif
@@ -1003,7 +1006,9 @@ void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable&
 // ================================================================================================
 constexpr uint32_t kLaneMaxLen = 512;     // longest mate handled by one lane
 constexpr uint32_t kLaneS = 16;           // sketch entries held in registers
-constexpr uint32_t kLaneHits = 32;        // longest location list handled by one lane
+constexpr uint32_t kLaneHits = MC_LANE_HITS;  // longest location list handled by one lane.  The row length sets the occupancy of
+                                              // probe_cands_kernel (LDS): 32 -> 8 waves/CU, 24 -> 12, 20 -> 14; measured on configs[1]
+                                              // (mean list 15.8): 44.3 / 48.6 / 49.5 / 41.1 G reads/min for 32 / 24 / 20 / 16
 constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
 constexpr uint32_t kLaneU = 4;            // lookups in flight per lane
 constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
@@ -1398,7 +1403,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                     H += size;
                     // singletons are the location itself; longer lists are only noted here (descriptor = first index |
                     // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
-                    if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // > 32 found features (pairs): the row moves to
+                    if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // row full (pairs, rich tables): it moves to
                     if (over) {                                                      // the hand-over area, later entries go there directly
                         ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
                         ++gnent; goff += size;
