@@ -324,3 +324,88 @@ def test_long_reads_chunk_lanes_against_oracle(golden, lowest, K):
             else:
                 assert cands[i, j]["hits"] == 0, (i, j)
     odb.close()
+
+
+def test_size_independent_properties_at_bench_scale(tmp_path):
+    """10^6 reads of the bench workload shape (random genomes, 150 bp, 1 % substitutions): properties that need no oracle --
+    (1) an all-N batch and a batch of reads shorter than k produce no candidates at all;
+    (2) batching is invisible: the same reads in batches of 65 536 and of 1 000 000 give identical results;
+    (3) the lane / mid kernels and the wave kernels agree (MC_NO_LANE_PATH=1);
+    (4) every sorted location list is non-decreasing and as long as the reported hit count, candidates are ordered by hits."""
+    import os
+    import torch
+    from metacache_amd import synth
+    import bench
+    dev = torch.device("cuda", 0)
+    G, GL, n = 8, 1_000_000, 1_000_000
+    genomes = bench.make_genomes(G, GL, seed=5)
+    bld = api.Builder(target_id_bytes=2, max_candidates=2)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"P{i}", parent_taxid=1000 + i)
+    bld.finish(load=False)
+    name = str(tmp_path / "prop")
+    bld.write(name, [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"sp{i}") for i in range(G)])
+    bld.free()
+    gcat = torch.from_numpy(np.concatenate(genomes)).to(dev)
+    goff = torch.arange(G, device=dev, dtype=torch.int64) * GL
+    reads = bench.synth_reads_gpu(gcat, goff, GL, n, seed=77)                       # [n, 152] ASCII, zero padded
+    allN = torch.zeros_like(reads)
+    allN[:, :150] = ord("N")
+    qinfo = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    qinfo[:, 0] = torch.arange(n, device=dev, dtype=torch.int32) * 152
+    qinfo[:, 1] = 150
+    qinfo[:, 2] = qinfo[:, 0]
+    slack = torch.zeros(16, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def run(db, batch, lo, hi, allhits=False):
+        m = hi - lo
+        seq = torch.cat([batch[lo:hi].reshape(-1), slack])
+        qi = qinfo[:m].contiguous()
+        out = torch.zeros((m, 2, 4), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        r = db.query_device(seq.data_ptr(), qi.data_ptr(), m, m * 152, max_win_uniform=3, want_allhits=allhits)
+        db.copy_results(out.data_ptr(), r.cands, m * 32)
+        extra = None
+        if allhits:
+            off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+            db.copy_results(off.data_ptr(), r.hit_offsets, (m + 1) * 8)
+            db.synchronize()
+            hits = torch.zeros(int(off[-1]), dtype=torch.int64, device=dev)
+            db.copy_results(hits.data_ptr(), r.hits, hits.numel() * 8)
+            extra = (off, hits)
+        db.synchronize()
+        return out, extra
+
+    db = api.Database.open(name, max_candidates=2)
+    whole, _ = run(db, reads, 0, n)
+    assert int((whole[:, 0, 1] > 0).sum()) > 0.9 * n
+    empty, _ = run(db, allN, 0, 100_000)
+    assert int(empty[:, :, 1].abs().sum()) == 0                                     # (1)
+    qinfo[:, 1] = 15                                                                # shorter than k = 16
+    torch.cuda.synchronize()
+    short, _ = run(db, reads, 0, 100_000)
+    assert int(short[:, :, 1].abs().sum()) == 0
+    qinfo[:, 1] = 150
+    torch.cuda.synchronize()
+    for lo in range(0, n, 65536 * 4):                                               # (2), every fourth small batch
+        part, _ = run(db, reads, lo, min(n, lo + 65536))
+        assert torch.equal(part, whole[lo:min(n, lo + 65536)])
+    assert bool((whole[:, 0, 1] >= whole[:, 1, 1]).all())                           # (4) candidates by hits
+    sub, (off, hits) = run(db, reads, 0, 200_000, allhits=True)                     # wave kernels + sorted lists
+    assert torch.equal(sub, whole[:200_000])                                        # (3) -allhits takes the wave path
+    cnt = off[1:] - off[:-1]
+    nondecr = hits[1:] >= hits[:-1]
+    starts = off[1:-1]                                                              # first element of every list but the first
+    nondecr[(starts - 1)[(starts > 0) & (starts < hits.numel())]] = True            # list boundaries do not count
+    assert bool(nondecr.all())
+    assert bool((sub[:, 0, 1].long() <= cnt).all())
+    db.close()
+    os.environ["MC_NO_LANE_PATH"] = "1"
+    try:
+        dbw = api.Database.open(name, max_candidates=2)
+        wave, _ = run(dbw, reads, 0, 300_000)
+        dbw.close()
+    finally:
+        os.environ.pop("MC_NO_LANE_PATH", None)
+    assert torch.equal(wave, whole[:300_000])                                       # (3)
