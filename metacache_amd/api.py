@@ -175,6 +175,13 @@ class Database:
         self._check(lib().mc_db_info(self.h, info.ctypes.data_as(C.c_void_p)))
         return list(map(int, info))
 
+    def set_lineages(self, lin: np.ndarray):
+        """lin[targets, 21] uint32: taxon index + 1 per rank, 0 = none (mc_set_lineages) -- needed for lowest > 0 on contexts that
+        were not opened from database files"""
+        lin = np.ascontiguousarray(lin, dtype=np.uint32)
+        assert lin.ndim == 2 and lin.shape[1] == 21
+        self._check(lib().mc_set_lineages(self.h, lin.ctypes.data_as(C.c_void_p), lin.shape[0]))
+
     # ---- taxonomy --------------------------------------------------------------------------
     def taxa(self):
         n = C.c_uint64()

@@ -1286,8 +1286,9 @@ constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in 
 constexpr uint32_t kLaneBlock = 128;
 
 // rows 10: one candidate enters the lane's top list exactly as on the CPU (candidate_generation.hpp:172-231)
+// pre: the candidate's taxon if the caller has it already (mid_cands_kernel fetches them in parallel), else ~0u = look it up here
 __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK], LaneCand c, const uint32_t K,
-                                           const uint32_t* __restrict__ taxkey, const uint32_t tgtMask)
+                                           const uint32_t* __restrict__ taxkey, const uint32_t tgtMask, const uint32_t pre = ~0u)
 {
     uint32_t ctax = 0;
     bool moving = false;
@@ -1299,7 +1300,7 @@ __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&t
 #pragma unroll
         for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
         if (lastHits > 0 && lastHits >= c.hits) return;
-        ctax = taxkey[c.tgt & tgtMask];
+        ctax = pre != ~0u ? pre : taxkey[c.tgt & tgtMask];
         if (ctax == 0) return;
         bool found = false;
 #pragma unroll
@@ -1602,7 +1603,7 @@ __device__ __forceinline__ void sel64(uint32_t& a0, uint32_t& a1, uint32_t o0, u
     a0 = r0; a1 = r1;
 }
 
-template <uint32_t G>
+template <uint32_t G, bool TAX>
 __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
                                                         const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, uint32_t cls)
 {
@@ -1613,6 +1614,7 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
     const uint32_t lg = lane % G, qi = lane / G;
     uint64_t* buf = listS[wave] + qi * (G * ROW);            // this query's list, padded: element i at mid_ix(i)
     uint32_t* sg = segS[wave] + qi * (G * ROW);              // entry offsets while gathering, then the query's segments
+
     const uint32_t total = ws.midCount[cls];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)cls * b.n;
     const uint32_t nWaves = gridDim.x * 4;
@@ -1773,27 +1775,31 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
             uint32_t toptax[kLaneK];
 #pragma unroll
             for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
-            uint32_t pTgt = 0, pHits = 0, pPos = 0, lastHits = 0;
+            uint32_t pTgt = 0, pHits = 0, pPos = 0, pTax = ~0u, lastHits = 0;
             auto flush = [&]() {
                 if (pHits > lastHits || lastHits == 0) {         // candidate_generation.hpp:178-181 and :189-201: otherwise no effect
                     LaneCand x; x.tgt = pTgt; x.hits = pHits; x.beg = pPos; x.end = 0;
-                    top_insert(top, toptax, x, K, taxkey, tab.tgtMask);
+                    top_insert(top, toptax, x, K, taxkey, tab.tgtMask, pTax);
 #pragma unroll
                     for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
                 }
             };
             for (uint32_t j0 = 0; j0 < nsegTotal; j0 += 4) {
-                uint32_t sv[4]; uint64_t kk[4];
+                uint32_t sv[4], tv[4]; uint64_t kk[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) sv[u] = j0 + u < nsegTotal ? sg[j0 + u] : 0u;
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) kk[u] = buf[mid_ix(sv[u] & 0xFFFFu)];
+                // taxon merging: the four taxa are requested together (one lane walks: a dependent global load per candidate would
+                // cost more than everything else in this kernel)
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) tv[u] = (TAX && j0 + u < nsegTotal) ? taxkey[(uint32_t)(kk[u] >> 32) & tab.tgtMask] : ~0u;
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) {
                     if (j0 + u < nsegTotal) {
                         const uint32_t pos = sv[u] & 0xFFFFu, h = sv[u] >> 16, tgt = (uint32_t)(kk[u] >> 32);
                         if (pHits && tgt == pTgt) { if (h > pHits) { pHits = h; pPos = pos; } }
-                        else { if (pHits) flush(); pTgt = tgt; pHits = h; pPos = pos; }
+                        else { if (pHits) flush(); pTgt = tgt; pHits = h; pPos = pos; pTax = tv[u]; }
                     }
                 }
             }
@@ -1816,21 +1822,23 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
     }
 }
 
+template <uint32_t G>
+static void launch_mid_g(uint32_t grid, uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                         const uint32_t* taxkey, void* cands, hipStream_t st)
+{
+    if (taxkey) hipLaunchKernelGGL((mid_cands_kernel<G, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+    else        hipLaunchKernelGGL((mid_cands_kernel<G, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+}
+
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
-    // persistent grids: the work lists are usually short (their lengths stay on the device)
+    // persistent grids: the work lists are usually short (their lengths stay on the device); 3 blocks fit a CU (53 KB of LDS each)
     const uint32_t blocks = 256 * 3;
-    if (cls == 0)
-        hipLaunchKernelGGL(mid_cands_kernel<4>, dim3(std::min<uint32_t>(blocks, (b.n + 63) / 64)), dim3(256), 0, st, b, tab, ws, maxCand,
-                           taxkey, (mc_candidate_dev*)cands, 0u);
-    else if (cls == 1)
-        hipLaunchKernelGGL(mid_cands_kernel<8>, dim3(std::min<uint32_t>(blocks, (b.n + 31) / 32)), dim3(256), 0, st, b, tab, ws, maxCand,
-                           taxkey, (mc_candidate_dev*)cands, 1u);
-    else
-        hipLaunchKernelGGL(mid_cands_kernel<16>, dim3(std::min<uint32_t>(blocks, (b.n + 15) / 16)), dim3(256), 0, st, b, tab, ws, maxCand,
-                           taxkey, (mc_candidate_dev*)cands, 2u);
+    if (cls == 0)      launch_mid_g<4>(std::min<uint32_t>(blocks, (b.n + 63) / 64), 0u, b, tab, ws, maxCand, taxkey, cands, st);
+    else if (cls == 1) launch_mid_g<8>(std::min<uint32_t>(blocks, (b.n + 31) / 32), 1u, b, tab, ws, maxCand, taxkey, cands, st);
+    else               launch_mid_g<16>(std::min<uint32_t>(blocks, (b.n + 15) / 16), 2u, b, tab, ws, maxCand, taxkey, cands, st);
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }

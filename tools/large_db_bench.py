@@ -63,6 +63,11 @@ def main():
     t_finish = time.time() - t1
     bld.free()
     # taxonomy for merging above sequence level: species = parent
+    if args.lowest:
+        lin = np.zeros((G, 21), dtype=np.uint32)
+        lin[:, 0] = np.arange(G) + 1                                                # every target its own sequence-level taxon
+        lin[:, 4] = G + 1 + np.arange(G) // args.strains                            # species = index of the strain group
+        db.set_lineages(lin)
     info = db.info()
     res = {"targets": G, "bases": G * GL, "strains_per_species": args.strains, "divergence": args.divergence,
            "db_info": {"k": info[0], "s": info[1], "w": info[2], "stride": info[3], "max_locs": info[4], "targets": info[5], "locations": info[7]},
@@ -84,7 +89,7 @@ def main():
     qst = torch.zeros((B, 4), dtype=torch.int32, device=dev)
 
     def step(i):
-        r = db.query_device(batches[i % len(batches)].data_ptr(), qinfo.data_ptr(), B, B * bench.PAD_LEN, max_win_uniform=max_win)
+        r = db.query_device(batches[i % len(batches)].data_ptr(), qinfo.data_ptr(), B, B * bench.PAD_LEN, max_win_uniform=max_win, lowest=args.lowest)
         db.copy_results(out.data_ptr(), r.cands, B * K * 16)
         db.copy_results(qst.data_ptr(), r.hit_counts, B * 16)
         db.synchronize()
