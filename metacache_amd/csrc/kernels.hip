@@ -1334,9 +1334,10 @@ __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&t
 
 __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32_t s, const DeviceTable& tab, const Workspace& ws, const uint32_t K,
                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, const uint32_t q,
-                                                uint64_t* L)
+                                                uint64_t* L, const bool valid)
 {
-    const uint32_t fbase = ws.winOff[q] * s, nf = (ws.winOff[q + 1] - ws.winOff[q]) * s;
+    // lanes without a query of their own (valid == false) stay in the wave: they help with the cooperative hand-over below
+    const uint32_t fbase = valid ? ws.winOff[q] * s : 0u, nf = valid ? (ws.winOff[q + 1] - ws.winOff[q]) * s : 0u;
     const uint32_t* feats = ws.features + fbase;
 
     // kLaneU lookup slots per lane, each a little state machine: a slot takes the lane's next feature and
@@ -1422,12 +1423,46 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
             }
         }
     }
-    QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps;
-    ws.qstat[q] = qs;
-    if (H > kLaneHits || over) {
-        // too long for a lane: (size, payload) per found feature go to the wave / mid kernels straight from the row -- no second
-        // round of lookups
-        if (!over) dump_row();
+    if (valid) { QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps; ws.qstat[q] = qs; }
+    // Lists too long for a lane go to the mid / wave kernels as (size | list offset << 16, payload) per found feature, straight from
+    // the row -- no second round of lookups.  Rows that are still in LDS are written out by the WAVE: row after row, one lane per
+    // entry, so that a row becomes two contiguous stores instead of 2 x entries scattered ones (the per-lane version of this
+    // hand-over cost as much as a third of the lookups on strain-rich tables).
+    const bool hand = valid && (H > kLaneHits || over);
+    const bool coop = hand && !over;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (coop) {
+        uint32_t off = n;                                         // descriptors get their list offset: index(40) | size(16) | offset(8)
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint64_t d = L[kLaneHits - i];
+            const uint64_t size = d >> 48;
+            L[kLaneHits - i] = (d & 0xFFFFFFFFFFull) | (size << 40) | ((uint64_t)(off & 0xFFu) << 56);
+            off += (uint32_t)size;
+        }
+        gnent = n + m;
+    }
+    uint64_t rows = __ballot(coop);
+    if (rows) {
+        wave_lds_sync();
+        const uint64_t* wrows = L - (size_t)lane * kLaneRow;     // row of wave lane r = wrows + r * kLaneRow
+        while (rows) {
+            const uint32_t r = __ffsll((unsigned long long)rows) - 1;
+            rows &= rows - 1;
+            const uint32_t rn = rdlane(n, r), rm = rdlane(m, r), rfb = rdlane(fbase, r);
+            if (lane < rn + rm) {
+                const uint64_t* row = wrows + (size_t)r * kLaneRow;
+                uint32_t ps; uint64_t pp;
+                if (lane < rn) { ps = 1u | (lane << 16); pp = row[lane]; }
+                else {
+                    const uint64_t d = row[kLaneHits - (lane - rn)];
+                    ps = (uint32_t)((d >> 40) & 0xFFFFu) | ((uint32_t)(d >> 56) << 16); pp = d & 0xFFFFFFFFFFull;
+                }
+                ws.psize[rfb + lane] = ps; ws.ppay[rfb + lane] = pp;
+            }
+        }
+    }
+    if (!valid) return;
+    if (hand) {
         const uint32_t nent = gnent;
         if (H > kMidMax) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;   // the wave kernel reads all nf slots
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
@@ -1503,9 +1538,8 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
 {
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
-    if (q >= b.n) return;
-    if (ws.qflag[q] != kFlagProbe) return;
-    probe_cands_one(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow);
+    const bool valid = q < b.n && ws.qflag[q] == kFlagProbe;
+    probe_cands_one(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, valid);
 }
 
 // Both halves in one kernel: sketching is ALU work (rolling k-mers, hash, 16-entry insertion chain), probing is waiting for random
@@ -1516,11 +1550,10 @@ __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView
 {
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
-    if (q >= b.n) return;
-    const uint32_t flag = sketch_lane_one(b, sp, ws.winOff, ws.features, q);
-    if (flag != kFlagProbe) { ws.qflag[q] = flag; return; }
+    uint32_t flag = kFlagDone;
+    if (q < b.n) { flag = sketch_lane_one(b, sp, ws.winOff, ws.features, q); if (flag != kFlagProbe) ws.qflag[q] = flag; }
     __threadfence_block();                                        // own feature stores before own feature loads
-    probe_cands_one(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow);
+    probe_cands_one(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
 }
 
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,

@@ -49,11 +49,11 @@ void run(const uint4* tab, size_t bytes, uint32_t* out, int blocksPerCU)
 
 int main()
 {
-    const size_t maxBytes = 8ull << 30;
+    const size_t maxBytes = 32ull << 30;
     uint4* tab; uint32_t* out;
     hipMalloc(&tab, maxBytes); hipMalloc(&out, 256u * 8 * 256 * 4);
     hipMemset(tab, 1, maxBytes);
-    for (size_t mb : {64ull, 228ull, 1024ull, 8192ull}) {
+    for (size_t mb : {228ull, 1024ull, 8192ull, 32768ull}) {
         const size_t bytes = mb << 20;
         run<8, 1>(tab, bytes, out, 8); run<8, 2>(tab, bytes, out, 8); run<8, 4>(tab, bytes, out, 8); run<8, 8>(tab, bytes, out, 8);
         run<8, 4>(tab, bytes, out, 4);

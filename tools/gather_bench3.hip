@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 __device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; return x; }
 
 template <int NV, int U>
@@ -40,9 +41,11 @@ void run(const uint4* tab, size_t bytes, uint32_t* out, int bpc)
     const double lines = (double)blocks * 256 * iters * U;
     printf("lane-private: %d x16B per line, U=%d, blocks/CU=%d : %7.2f Glines/s  (%.2f ms)\n", NV, U, bpc, lines / ms / 1e6, ms);
 }
-int main()
+int main(int argc, char** argv)
 {
-    const size_t bytes = 366ull << 20;
+    // table size in MiB (default 366 = the configs[1] table; pass e.g. 16384 to leave the 256 MB infinity cache and the TLB reach)
+    const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 366ull) << 20;
+    printf("table: %zu MiB\n", bytes >> 20);
     uint4* tab; uint32_t* out;
     hipMalloc(&tab, bytes); hipMalloc(&out, 256u * 8 * 256 * 4);
     hipMemset(tab, 1, bytes);
