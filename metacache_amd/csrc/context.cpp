@@ -164,6 +164,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->parts.resize(cfg->num_parts);
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1';           // experiment switch
+    if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream");
@@ -556,9 +557,9 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, st);
         } else {
             { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
-            { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, st); }
-            { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, st); }
-            { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+            { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
+            { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, ctx->quadLookup, st); }
+            { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st); }
         }
         { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }

@@ -126,8 +126,9 @@ void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Worksp
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
+// quadMode: -1 = by table size, 0 = lane-private bucket loads, 1 = quad-cooperative bucket loads
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                        const uint32_t* taxkey, void* cands, hipStream_t st);
+                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st);
 // table_build.hip: GPU-side table construction from the file's batch stream
 struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt; };   // load-time modifiers + key shard
 void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
@@ -137,7 +138,7 @@ void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
 void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
-void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);
+void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int quadMode, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,

@@ -273,6 +273,55 @@ __device__ __forceinline__ BucketRegs load_bucket(const DeviceTable& tab, uint32
     BucketRegs r; r.k = p[0]; r.sz = p[1]; r.p0 = p[2]; r.p1 = p[3];
     return r;
 }
+// Quad-cooperative bucket fetch.  A lane that loads its own 64-byte bucket with four 16-byte loads touches 64 different lines per
+// load instruction; on tables far larger than the infinity cache every one of these accesses pays the full price (measured,
+// tools/gather_bench3.hip: 52 G buckets/s on a 366 MB table, 16 G/s on 16 GB), whereas four neighbouring lanes reading the four
+// quarters of ONE bucket stay at 48 G/s whatever the table size (tools/gather_bench.hip).  So the four lanes of a quad fetch the
+// buckets of its members one after the other (lane i of the quad always loads quarter i) and a 4 x 4 register transpose inside the
+// quad (DPP quad_perm, no LDS) gives every lane the four quarters of its own bucket.
+// Both calls must be made by all four lanes of a quad together; kNoBucket = this lane wants nothing.
+constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
+constexpr uint64_t kQuadTableBytes = 1ull << 30;               // tables larger than this are probed quad-cooperatively
+struct QuadRaw { uint4 v[4]; };                                 // v[t] = my quarter of the bucket wanted by lane t of my quad
+
+__device__ __forceinline__ void quad_issue(const DeviceTable& tab, uint32_t want, QuadRaw& raw)
+{
+    const uint32_t part = threadIdx.x & 3u;
+    const uint32_t w[4] = {dpp_mov<0x00>(want), dpp_mov<0x55>(want), dpp_mov<0xAA>(want), dpp_mov<0xFF>(want)};   // quad broadcasts
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t)
+        if (w[t] != kNoBucket) raw.v[t] = reinterpret_cast<const uint4*>(tab.buckets + w[t])[part];
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint4 dpp_mov4(uint4 v)
+{
+    return make_uint4(dpp_mov<CTRL>(v.x), dpp_mov<CTRL>(v.y), dpp_mov<CTRL>(v.z), dpp_mov<CTRL>(v.w));
+}
+__device__ __forceinline__ uint4 sel4(bool c, uint4 a, uint4 b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+
+__device__ __forceinline__ BucketRegs quad_collect(const QuadRaw& raw)
+{
+    // butterfly transpose: after the stage with distance d, register j of lane i holds what register j^d of lane i^d held wherever
+    // bit d of i and of j differ
+    const bool b0 = (threadIdx.x & 1u) != 0, b1 = (threadIdx.x & 2u) != 0;
+    uint4 m0 = raw.v[0], m1 = raw.v[1], m2 = raw.v[2], m3 = raw.v[3];
+    {
+        const uint4 ra = dpp_mov4<0xB1>(sel4(b0, m0, m1));      // quad_perm [1,0,3,2]
+        const uint4 rb = dpp_mov4<0xB1>(sel4(b0, m2, m3));
+        m0 = sel4(b0, ra, m0); m1 = sel4(b0, m1, ra);
+        m2 = sel4(b0, rb, m2); m3 = sel4(b0, m3, rb);
+    }
+    {
+        const uint4 ra = dpp_mov4<0x4E>(sel4(b1, m0, m2));      // quad_perm [2,3,0,1]
+        const uint4 rb = dpp_mov4<0x4E>(sel4(b1, m1, m3));
+        m0 = sel4(b1, ra, m0); m2 = sel4(b1, m2, ra);
+        m1 = sel4(b1, rb, m1); m3 = sel4(b1, m3, rb);
+    }
+    BucketRegs r; r.k = m0; r.sz = m1; r.p0 = m2; r.p1 = m3;
+    return r;
+}
+
 __device__ __forceinline__ void probe_start(const DeviceTable& tab, uint32_t f, uint32_t& home, BucketRegs& r)
 {
     home = home_group(f, tab.nbuckets);
@@ -1172,49 +1221,40 @@ __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchPa
     }
 }
 
-// one lane per chunk: lookups of its <= kChunkWins * s features (kLaneU in flight), (size, payload) per feature slot for the
-// wave kernel, the lane that finishes the read's last chunk hands it over
+// one lane per chunk: lookups of its <= kChunkWins * s features (kLaneU in flight), (size, payload) of the found features for the wave
+// kernel.  QUAD as in probe_cands_one.
+template <bool QUAD>
 __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
 {
     const uint32_t total = ws.midCount[3];
-    for (uint32_t id = blockIdx.x * 128 + threadIdx.x; id < total; id += gridDim.x * 128) {
-        const uint2 rec = ws.chunkList[id];
+    for (uint32_t base = blockIdx.x * 128; base < total; base += gridDim.x * 128) {   // block-uniform: quads stay together
+        const uint32_t id = base + threadIdx.x;
+        uint2 rec = make_uint2(0, 0);
+        if (id < total) rec = ws.chunkList[id];
         const uint32_t q = rec.x, c = rec.y;
-        if (ws.qflag[q] != kFlagChunks) continue;                                  // a chunk saw duplicate hashes
+        const bool valid = id < total && ws.qflag[q] == kFlagChunks;                 // not: a chunk of the read saw duplicate hashes
         const uint32_t w0 = ws.winOff[q] + c * kChunkWins, w1 = min(ws.winOff[q + 1], w0 + kChunkWins);
-        const uint32_t fbase = w0 * s, nf = (w1 - w0) * s;
+        const uint32_t fbase = w0 * s, nf = valid ? (w1 - w0) * s : 0u;
         const uint32_t* feats = ws.features + fbase;
         uint32_t e = 0;
         uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU], slot[kLaneU];
-        BucketRegs r[kLaneU];
+        QuadRaw raw[kLaneU];
         bool busy[kLaneU];
 #pragma unroll
         for (uint32_t u = 0; u < kLaneU; ++u) busy[u] = false;
-        for (;;) {
-            bool any = false;
+        for (bool first = true;; first = false) {
 #pragma unroll
             for (uint32_t u = 0; u < kLaneU; ++u) {
-                if (!busy[u] && e < nf) {
-                    slot[u] = e;
-                    f[u] = feats[e++];
-                    if (f[u] != 0xFFFFFFFFu) {
-                        home[u] = home_group(f[u], tab.nbuckets);
-                        cur[u] = home[u]; step[u] = 1;
-                        r[u] = load_bucket(tab, cur[u]);
-                        busy[u] = true;
-                    }
-                }
-                any = any || busy[u];
-            }
-            if (!any && e >= nf) break;
-#pragma unroll
-            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (first || !__ballot(busy[u])) continue;
+                BucketRegs r;
+                if constexpr (QUAD) r = quad_collect(raw[u]);
+                else { r.k = raw[u].v[0]; r.sz = raw[u].v[1]; r.p0 = raw[u].v[2]; r.p1 = raw[u].v[3]; }
                 if (busy[u]) {
-                    const uint32_t keys[4] = {r[u].k.x, r[u].k.y, r[u].k.z, r[u].k.w};
-                    const uint32_t s01 = r[u].sz.x, s23 = r[u].sz.y;
+                    const uint32_t keys[4] = {r.k.x, r.k.y, r.k.z, r.k.w};
+                    const uint32_t s01 = r.sz.x, s23 = r.sz.y;
                     const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
-                    const uint64_t pl[4] = {((uint64_t)r[u].p0.y << 32) | r[u].p0.x, ((uint64_t)r[u].p0.w << 32) | r[u].p0.z,
-                                            ((uint64_t)r[u].p1.y << 32) | r[u].p1.x, ((uint64_t)r[u].p1.w << 32) | r[u].p1.z};
+                    const uint64_t pl[4] = {((uint64_t)r.p0.y << 32) | r.p0.x, ((uint64_t)r.p0.w << 32) | r.p0.z,
+                                            ((uint64_t)r.p1.y << 32) | r.p1.x, ((uint64_t)r.p1.w << 32) | r.p1.z};
                     uint32_t size = 0; uint64_t pay = 0;
                     bool anyFree = false;
 #pragma unroll
@@ -1228,9 +1268,29 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
                     } else {
                         cur[u] = next_bucket(home[u], cur[u], step[u], tab.nbuckets);
                         ++step[u];
-                        r[u] = load_bucket(tab, cur[u]);
                     }
                 }
+            }
+            bool any = false;
+#pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                while (!busy[u] && e < nf) {
+                    slot[u] = e;
+                    f[u] = feats[e++];
+                    if (f[u] != 0xFFFFFFFFu) {
+                        home[u] = home_group(f[u], tab.nbuckets);
+                        cur[u] = home[u]; step[u] = 1;
+                        busy[u] = true;
+                    }
+                }
+                any = any || busy[u];
+            }
+            if (!__ballot(any)) break;
+#pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (!__ballot(busy[u])) continue;
+                if constexpr (QUAD) quad_issue(tab, busy[u] ? cur[u] : kNoBucket, raw[u]);
+                else if (busy[u]) { const BucketRegs r = load_bucket(tab, cur[u]); raw[u].v[0] = r.k; raw[u].v[1] = r.sz; raw[u].v[2] = r.p0; raw[u].v[3] = r.p1; }
             }
         }
     }
@@ -1332,6 +1392,8 @@ __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&t
     }
 }
 
+// QUAD: quad-cooperative bucket fetches (tables beyond the reach of the infinity cache / TLBs), else lane-private 4 x 16-byte loads
+template <bool QUAD>
 __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32_t s, const DeviceTable& tab, const Workspace& ws, const uint32_t K,
                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, const uint32_t q,
                                                 uint64_t* L, const bool valid)
@@ -1361,64 +1423,135 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         }
         gnent = n + m;
     };
-    uint32_t e = 0;                                              // next feature of this lane
-    uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
-    BucketRegs r[kLaneU];
-    bool busy[kLaneU];
-#pragma unroll
-    for (uint32_t u = 0; u < kLaneU; ++u) busy[u] = false;
-    for (;;) {
-        bool any = false;
-#pragma unroll
-        for (uint32_t u = 0; u < kLaneU; ++u) {
-            if (!busy[u] && e < nf) {
-                f[u] = feats[e++];
-                if (f[u] != 0xFFFFFFFFu) {
-                    ++nfeat;
-                    home[u] = home_group(f[u], tab.nbuckets);
-                    cur[u] = home[u]; step[u] = 1;
-                    r[u] = load_bucket(tab, cur[u]);
-                    busy[u] = true;
+    if constexpr (QUAD) {
+        uint32_t e = 0;                                              // next feature of this lane
+        uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
+        QuadRaw raw[kLaneU];
+        bool busy[kLaneU];
+    #pragma unroll
+        for (uint32_t u = 0; u < kLaneU; ++u) busy[u] = false;
+        // Every round: (1) resolve the lookups whose buckets were requested in the previous round, (2) hand idle slots their next
+        // feature, (3) request the bucket every busy slot needs now.  The requests are quad-cooperative (quad_issue), so all branches
+        // around them are wave-uniform; a lane that has run out of features idles along until the wave is done.
+        for (bool first = true;; first = false) {
+    #pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (first || !__ballot(busy[u])) continue;
+                const BucketRegs r = quad_collect(raw[u]);
+                if (busy[u]) {
+                    ++nsteps;
+                    const uint32_t keys[4] = {r.k.x, r.k.y, r.k.z, r.k.w};
+                    const uint32_t s01 = r.sz.x, s23 = r.sz.y;
+                    const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
+                    const uint64_t pl[4] = {((uint64_t)r.p0.y << 32) | r.p0.x, ((uint64_t)r.p0.w << 32) | r.p0.z,
+                                            ((uint64_t)r.p1.y << 32) | r.p1.x, ((uint64_t)r.p1.w << 32) | r.p1.z};
+                    uint32_t size = 0; uint64_t pay = 0;
+                    bool anyFree = false;
+    #pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        anyFree = anyFree || sz[i] == 0;
+                        if (sz[i] != 0 && keys[i] == f[u]) { size = sz[i]; pay = pl[i]; }
+                    }
+                    if (size) {
+                        ++nfound;
+                        H += size;
+                        // singletons are the location itself; longer lists are only noted here (descriptor = first index |
+                        // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
+                        if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // row full (pairs, rich tables): it moves to
+                        if (over) {                                                      // the hand-over area, later entries go there directly
+                            ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
+                            ++gnent; goff += size;
+                        }
+                        else if (size == 1) L[n++] = pay;
+                        else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
+                        busy[u] = false;
+                    } else if (anyFree || step[u] >= tab.maxProbe) {
+                        busy[u] = false;                               // a bucket with a free slot ends the chain
+                    } else {
+                        cur[u] = next_bucket(home[u], cur[u], step[u], tab.nbuckets);
+                        ++step[u];                                     // stays busy: its next bucket is requested below
+                    }
                 }
             }
-            any = any || busy[u];
-        }
-        if (!any && e >= nf) break;
-#pragma unroll
-        for (uint32_t u = 0; u < kLaneU; ++u) {
-            if (busy[u]) {
-                ++nsteps;
-                const uint32_t keys[4] = {r[u].k.x, r[u].k.y, r[u].k.z, r[u].k.w};
-                const uint32_t s01 = r[u].sz.x, s23 = r[u].sz.y;
-                const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
-                const uint64_t pl[4] = {((uint64_t)r[u].p0.y << 32) | r[u].p0.x, ((uint64_t)r[u].p0.w << 32) | r[u].p0.z,
-                                        ((uint64_t)r[u].p1.y << 32) | r[u].p1.x, ((uint64_t)r[u].p1.w << 32) | r[u].p1.z};
-                uint32_t size = 0; uint64_t pay = 0;
-                bool anyFree = false;
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
-                    anyFree = anyFree || sz[i] == 0;
-                    if (sz[i] != 0 && keys[i] == f[u]) { size = sz[i]; pay = pl[i]; }
-                }
-                if (size) {
-                    ++nfound;
-                    H += size;
-                    // singletons are the location itself; longer lists are only noted here (descriptor = first index |
-                    // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
-                    if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // row full (pairs, rich tables): it moves to
-                    if (over) {                                                      // the hand-over area, later entries go there directly
-                        ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
-                        ++gnent; goff += size;
+            bool any = false;
+    #pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                while (!busy[u] && e < nf) {
+                    f[u] = feats[e++];
+                    if (f[u] != 0xFFFFFFFFu) {
+                        ++nfeat;
+                        home[u] = home_group(f[u], tab.nbuckets);
+                        cur[u] = home[u]; step[u] = 1;
+                        busy[u] = true;
                     }
-                    else if (size == 1) L[n++] = pay;
-                    else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
-                    busy[u] = false;
-                } else if (anyFree || step[u] >= tab.maxProbe) {
-                    busy[u] = false;                               // a bucket with a free slot ends the chain
-                } else {
-                    cur[u] = next_bucket(home[u], cur[u], step[u], tab.nbuckets);
-                    ++step[u];
-                    r[u] = load_bucket(tab, cur[u]);               // stays pending; resolved in the next iteration
+                }
+                any = any || busy[u];
+            }
+            if (!__ballot(any)) break;
+    #pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u)
+                if (__ballot(busy[u])) quad_issue(tab, busy[u] ? cur[u] : kNoBucket, raw[u]);
+        }
+    } else {
+        uint32_t e = 0;                                              // next feature of this lane
+        uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
+        BucketRegs r[kLaneU];
+        bool busy[kLaneU];
+    #pragma unroll
+        for (uint32_t u = 0; u < kLaneU; ++u) busy[u] = false;
+        for (;;) {
+            bool any = false;
+    #pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (!busy[u] && e < nf) {
+                    f[u] = feats[e++];
+                    if (f[u] != 0xFFFFFFFFu) {
+                        ++nfeat;
+                        home[u] = home_group(f[u], tab.nbuckets);
+                        cur[u] = home[u]; step[u] = 1;
+                        r[u] = load_bucket(tab, cur[u]);
+                        busy[u] = true;
+                    }
+                }
+                any = any || busy[u];
+            }
+            if (!any && e >= nf) break;
+    #pragma unroll
+            for (uint32_t u = 0; u < kLaneU; ++u) {
+                if (busy[u]) {
+                    ++nsteps;
+                    const uint32_t keys[4] = {r[u].k.x, r[u].k.y, r[u].k.z, r[u].k.w};
+                    const uint32_t s01 = r[u].sz.x, s23 = r[u].sz.y;
+                    const uint32_t sz[4] = {s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16};
+                    const uint64_t pl[4] = {((uint64_t)r[u].p0.y << 32) | r[u].p0.x, ((uint64_t)r[u].p0.w << 32) | r[u].p0.z,
+                                            ((uint64_t)r[u].p1.y << 32) | r[u].p1.x, ((uint64_t)r[u].p1.w << 32) | r[u].p1.z};
+                    uint32_t size = 0; uint64_t pay = 0;
+                    bool anyFree = false;
+    #pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        anyFree = anyFree || sz[i] == 0;
+                        if (sz[i] != 0 && keys[i] == f[u]) { size = sz[i]; pay = pl[i]; }
+                    }
+                    if (size) {
+                        ++nfound;
+                        H += size;
+                        // singletons are the location itself; longer lists are only noted here (descriptor = first index |
+                        // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
+                        if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // row full (pairs, rich tables): it moves to
+                        if (over) {                                                      // the hand-over area, later entries go there directly
+                            ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
+                            ++gnent; goff += size;
+                        }
+                        else if (size == 1) L[n++] = pay;
+                        else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
+                        busy[u] = false;
+                    } else if (anyFree || step[u] >= tab.maxProbe) {
+                        busy[u] = false;                               // a bucket with a free slot ends the chain
+                    } else {
+                        cur[u] = next_bucket(home[u], cur[u], step[u], tab.nbuckets);
+                        ++step[u];
+                        r[u] = load_bucket(tab, cur[u]);               // stays pending; resolved in the next iteration
+                    }
                 }
             }
         }
@@ -1533,13 +1666,14 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     ws.qflag[q] = kFlagDone;
 }
 
+template <bool QUAD>
 __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                  const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
     const bool valid = q < b.n && ws.qflag[q] == kFlagProbe;
-    probe_cands_one(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, valid);
+    probe_cands_one<QUAD>(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, valid);
 }
 
 // Both halves in one kernel: sketching is ALU work (rolling k-mers, hash, 16-entry insertion chain), probing is waiting for random
@@ -1553,7 +1687,7 @@ __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView
     uint32_t flag = kFlagDone;
     if (q < b.n) { flag = sketch_lane_one(b, sp, ws.winOff, ws.features, q); if (flag != kFlagProbe) ws.qflag[q] = flag; }
     __threadfence_block();                                        // own feature stores before own feature loads
-    probe_cands_one(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
+    probe_cands_one<false>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
 }
 
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
@@ -1569,22 +1703,28 @@ void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Worksp
     if (b.n == 0) return;
     hipLaunchKernelGGL(sketch_lane_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp, ws);
 }
-void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st)
+void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int quadMode, hipStream_t st)
 {
     if (b.n == 0 || !ws.chunkList) return;
     // persistent grids over the chunk work list (usually empty: its length stays on the device)
     if (stage == 0) hipLaunchKernelGGL(chunk_sketch_kernel, dim3(2048), dim3(128), 0, st, b, sp, ws);
     else {
-        hipLaunchKernelGGL(chunk_probe_kernel, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
+        const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
+        if (quad) hipLaunchKernelGGL(chunk_probe_kernel<true>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
+        else      hipLaunchKernelGGL(chunk_probe_kernel<false>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
         hipLaunchKernelGGL(chunk_finish_kernel, dim3(1024), dim3(256), 0, st, sp.s, ws);
     }
 }
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                        const uint32_t* taxkey, void* cands, hipStream_t st)
+                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st)
 {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(probe_cands_kernel, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
-                       taxkey, (mc_candidate_dev*)cands);
+    // tables that reach beyond the infinity cache and the TLBs: quad-cooperative bucket fetches (see quad_issue)
+    const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
+    if (quad) hipLaunchKernelGGL(probe_cands_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
+                                 taxkey, (mc_candidate_dev*)cands);
+    else      hipLaunchKernelGGL(probe_cands_kernel<false>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
+                                 taxkey, (mc_candidate_dev*)cands);
 }
 // ================================================================================================
 // mid_cands_kernel<G>: location lists of 33 .. 16*G entries (G = 4, 8, 16 lanes per query; 64/G queries per wave).

@@ -236,12 +236,14 @@ def test_mode_p_single_parts_merge_equals_whole_database(golden):
         assert np.array_equal(merged[:, :, j], cw[f]), f
 
 
+@pytest.mark.parametrize("quad", ["0", "1"])
 @pytest.mark.parametrize("lowest,K", [(0, 2), (0, 4), (4, 2), (4, 3)])
-def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K):
+def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad, monkeypatch):
     """5 species x 8 strains (0.5 % divergence): a 150 bp read collects 50..250 locations over up to 8 targets, pairs more --
     the list lengths handled by mid_cands_kernel (4 / 8 / 16 lanes per query, register bitonic sort), sequence level and
     merged at species level, against the oracle."""
     from metacache_amd import synth
+    monkeypatch.setenv("MC_QUAD_LOOKUP", quad)     # both bucket fetch schemes of probe_cands (the second one is for large tables)
     rng = np.random.default_rng(4242 + lowest + K)
     genomes, parents = [], []
     for sp in range(5):
@@ -283,12 +285,14 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K):
     odb.close()
 
 
+@pytest.mark.parametrize("quad", ["0", "1"])
 @pytest.mark.parametrize("lowest,K", [(0, 2), (4, 4)])
-def test_long_reads_chunk_lanes_against_oracle(golden, lowest, K):
+def test_long_reads_chunk_lanes_against_oracle(golden, lowest, K, quad, monkeypatch):
     """Single reads above 512 bp are cut into chunks of 4 windows, each sketched and probed by its own lane (chunk_sketch_kernel /
     chunk_probe_kernel), then sorted by the wave kernel: 513 .. 12000 bp, with substitutions, N runs and lower case, mixed with
     short reads in one batch, against the oracle (which is pinned to the reference)."""
     from metacache_amd import synth
+    monkeypatch.setenv("MC_QUAD_LOOKUP", quad)
     rng = np.random.default_rng(777 + K)
     names = [golden.db_path("toy32")]
     odb = cpuref.oracle().open(names[0])
@@ -409,3 +413,11 @@ def test_size_independent_properties_at_bench_scale(tmp_path):
     finally:
         os.environ.pop("MC_NO_LANE_PATH", None)
     assert torch.equal(wave, whole[:300_000])                                       # (3)
+    os.environ["MC_QUAD_LOOKUP"] = "1"                                              # the bucket fetch scheme for large tables
+    try:
+        dbq = api.Database.open(name, max_candidates=2)
+        quad, _ = run(dbq, reads, 0, n)
+        dbq.close()
+    finally:
+        os.environ.pop("MC_QUAD_LOOKUP", None)
+    assert torch.equal(quad, whole)
