@@ -110,8 +110,9 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
 int mc_load_end(mc_ctx* ctx, uint32_t part);
 
 /* convenience: database::read (database.cpp:183-242) -- reads <name>.meta (header, sketching,
- * taxonomy -> lineages) and every <name>.cache<p>, creates the context with the DB's sketching
- * parameters (cfg->kmerlen.. == 0 => take from DB) and loads all parts. */
+ * taxonomy -> lineages) and every <name>.cache<p>, creates the context and loads all parts.  Query
+ * sketching as adapt_options_to_database (querying.cpp:225-251): kmerlen always the DB's; sketchlen /
+ * winlen == 0 => the DB's; winstride == 0 => winlen - kmerlen + 1 (not the DB's stride). */
 int mc_open_database(const char* name, const mc_config* cfg, mc_ctx** out);
 
 /* target lineage table (ranked_lineages_of_targets, taxonomy.hpp:919-1030; uploaded like
@@ -226,7 +227,8 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8]);
  * call order, window ids = running index of windows with >= k characters, buckets hold the first
  * max_locations_per_feature locations in (target, window) order (host_hashmap.hpp:593-605), and
  * database::write (database.cpp:247-325) for the file format.  cfg fields used: device, kmerlen,
- * sketchlen, winlen, winstride, target_id_bytes, max_locations_per_feature (0 => 254). */
+ * sketchlen, winlen, winstride, target_id_bytes, max_locations_per_feature (0 => 254), remove_overpopulated (!= 0 => features
+ * that reached the limit are dropped from the files and the table: -remove-overpopulated-features, building.cpp:516-534). */
 typedef struct mc_builder mc_builder;
 typedef struct {
     int64_t  id;
@@ -238,6 +240,13 @@ typedef struct {
 int  mc_build_begin(const mc_config* cfg, mc_builder** out);
 int  mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parent_taxid,
                          const char* source_filename);
+/* the same with the position of the sequence inside its file (taxon::file_source::index, building.cpp:414-416) */
+int  mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parent_taxid,
+                             const char* source_filename, uint64_t source_index);
+/* re-ranks a target after it was added (try_to_rank_unranked_targets, building.cpp:196-232) */
+int  mc_build_set_parent(mc_builder* b, uint64_t target, int64_t parent_taxid);
+/* number of windows of a target (taxon::file_source::windows, database.cpp:64) */
+int  mc_build_target_windows(const mc_builder* b, uint64_t target, uint64_t* windows);
 /* sorts + bucketises everything added so far; if out_ctx != NULL also loads the table into a fresh
  * query context (see mc_build_set_query_config). */
 int  mc_build_finish(mc_builder* b, mc_ctx** out_ctx);

@@ -71,7 +71,8 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     """mcq: plain host C++14 linked against the C ABI only (rpath to the in-tree library)."""
     os.makedirs(BINDIR, exist_ok=True)
     src = os.path.join(CSRC, "mcq_main.cpp")
-    if force or _stale(MCQ, [src, LIB, os.path.join(ROOT, "include", "metacache_amd.h")]):
+    if force or _stale(MCQ, [src, os.path.join(CSRC, "mcq_common.h"), os.path.join(CSRC, "mcq_build.h"), LIB,
+                           os.path.join(ROOT, "include", "metacache_amd.h")]):
         cmd = ["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", MCQ,
                "-L", LIBDIR, "-lmetacache_amd", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-pthread"]
         if verbose:

@@ -21,12 +21,13 @@
 
 using namespace mcamd;
 
-struct TargetRec { std::string name, filename; int64_t parent; uint64_t windows; };
+struct TargetRec { std::string name, filename; int64_t parent; uint64_t windows, fileIndex; };
 
 struct mc_builder {
     mc_config cfg{};
     SketchParams sp{};
     uint32_t maxLocs = 254;
+    bool rmOver = false;              // -remove-overpopulated-features at build time (building.cpp:516-534)
     hipStream_t st = nullptr;
     std::string err;
     std::vector<TargetRec> targets;
@@ -187,6 +188,7 @@ int mc_build_begin(const mc_config* cfg, mc_builder** out)
     b->cfg = *cfg;
     b->sp = SketchParams{cfg->kmerlen, cfg->sketchlen, cfg->winlen, cfg->winstride};
     b->maxLocs = cfg->max_locations_per_feature ? std::min<uint32_t>(cfg->max_locations_per_feature, 254) : 254;
+    b->rmOver = cfg->remove_overpopulated != 0 && b->maxLocs > 1;      // buckets of one location always stay
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) {
         delete b;
         set_global_error("cannot create HIP stream");
@@ -197,6 +199,26 @@ int mc_build_begin(const mc_config* cfg, mc_builder** out)
 }
 
 int mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parentTaxid, const char* filename)
+{
+    return mc_build_add_target_src(b, seq, len, name, parentTaxid, filename, 0);
+}
+
+int mc_build_set_parent(mc_builder* b, uint64_t target, int64_t parentTaxid)
+{
+    if (!b || target >= b->targets.size()) return MC_ERR_INVALID;
+    b->targets[target].parent = parentTaxid < 1 ? 0 : parentTaxid;
+    return MC_OK;
+}
+
+int mc_build_target_windows(const mc_builder* b, uint64_t target, uint64_t* windows)
+{
+    if (!b || !windows || target >= b->targets.size()) return MC_ERR_INVALID;
+    *windows = b->targets[target].windows;
+    return MC_OK;
+}
+
+int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parentTaxid, const char* filename,
+                            uint64_t fileIndex)
 {
     if (!b || (!seq && len)) return MC_ERR_INVALID;
     if (b->finished) { b->err = "builder already finished"; return MC_ERR_STATE; }
@@ -230,7 +252,7 @@ int mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const char
         pos += (uint64_t)kChunkWindows * sp.stride;
     }
     TargetRec r;
-    r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid; r.windows = total;
+    r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid; r.windows = total; r.fileIndex = fileIndex;
     b->targets.push_back(std::move(r));
     return MC_OK;
 }
@@ -297,7 +319,8 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
     if (outCtx) {
         *outCtx = nullptr;
         mc_config qc = b->cfg;
-        qc.max_locations_per_feature = 0; qc.remove_overpopulated = 0; qc.num_parts = 1;
+        qc.max_locations_per_feature = 0; qc.num_parts = 1;
+        qc.remove_overpopulated = b->rmOver ? b->maxLocs - 1 : 0;   // applied while the table is filled (table_build.hip)
         qc.target_id_bytes = 4;                                    // values are handed over as {u32 win, u32 tgt}
         mc_ctx* ctx = nullptr;
         int rc = mc_create(&qc, &ctx);
@@ -373,33 +396,43 @@ int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, ui
             wr(f, &id, 8); wr(f, &b->targets[t].parent, 8);
             const uint8_t rk = 0; wr(f, &rk, 1);                       // rank::Sequence (taxonomy.hpp:453)
             wr_str(f, b->targets[t].name); wr_str(f, b->targets[t].filename);
-            const uint64_t idx = 0; wr(f, &idx, 8); wr(f, &b->targets[t].windows, 8);
+            wr(f, &b->targets[t].fileIndex, 8); wr(f, &b->targets[t].windows, 8);
         }
         std::fclose(f);
     }
-    {   // .cache0  (hash_multimap.hpp:1037-1082)
+    {   // .cache0  (hash_multimap.hpp:1037-1082): only non-empty buckets are written; with -remove-overpopulated-features the buckets
+        // that reached the limit are gone (remove_features_with_more_locations_than(maxLocs - 1), building.cpp:516-534)
         FILE* f = std::fopen((std::string(name) + ".cache0").c_str(), "wb");
         if (!f) { b->err = "cannot write .cache0"; return MC_ERR_IO; }
-        const uint64_t nk = b->keys.size(), nv = b->values.size(), batch = 1ull << 20;
+        auto kept = [&](uint64_t i) { return !(b->rmOver && b->sizes[i] > b->maxLocs - 1); };
+        uint64_t nk = 0, nv = 0;
+        for (uint64_t i = 0; i < b->keys.size(); ++i) if (kept(i)) { ++nk; nv += b->sizes[i]; }
+        const uint64_t batch = 1ull << 20;
         wr(f, &nk, 8); wr(f, &nv, 8); wr(f, &batch, 8);
-        std::vector<uint8_t> packed;
-        uint64_t voff = 0;
-        for (uint64_t i = 0; i < nk; i += batch) {
-            const uint64_t nb = std::min<uint64_t>(batch, nk - i);
-            wr(f, b->keys.data() + i, nb * 4);
-            wr(f, b->sizes.data() + i, nb);
-            uint64_t bv = 0;
-            for (uint64_t t = 0; t < nb; ++t) bv += b->sizes[i + t];
-            packed.resize(bv * (4 + tb));
-            for (uint64_t t = 0; t < bv; ++t) {
-                const uint64_t v = b->values[voff + t];
-                const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
-                std::memcpy(&packed[t * (4 + tb)], &win, 4);
-                if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(&packed[t * 6 + 4], &t16, 2); }
-                else std::memcpy(&packed[t * 8 + 4], &tgt, 4);
+        std::vector<uint32_t> bk; std::vector<uint8_t> bs, packed;
+        uint64_t voff = 0, i = 0;
+        while (i < b->keys.size()) {
+            bk.clear(); bs.clear(); packed.clear();
+            for (; i < b->keys.size() && bk.size() < batch; ++i) {
+                const uint32_t sz = b->sizes[i];
+                if (kept(i)) {
+                    bk.push_back(b->keys[i]); bs.push_back((uint8_t)sz);
+                    for (uint32_t t = 0; t < sz; ++t) {
+                        const uint64_t v = b->values[voff + t];
+                        const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
+                        const size_t at = packed.size();
+                        packed.resize(at + 4 + tb);
+                        std::memcpy(&packed[at], &win, 4);
+                        if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(&packed[at + 4], &t16, 2); }
+                        else std::memcpy(&packed[at + 4], &tgt, 4);
+                    }
+                }
+                voff += sz;
             }
+            if (bk.empty()) continue;
+            wr(f, bk.data(), bk.size() * 4);
+            wr(f, bs.data(), bs.size());
             wr(f, packed.data(), packed.size());
-            voff += bv;
         }
         std::fclose(f);
     }

@@ -142,7 +142,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     cfg.kmerlen = m.k;                                      // k always comes from the DB (querying.cpp:232-243)
     if (!cfg.sketchlen) cfg.sketchlen = m.s;
     if (!cfg.winlen) cfg.winlen = m.w;
-    if (!cfg.winstride) cfg.winstride = m.stride;
+    if (!cfg.winstride) cfg.winstride = cfg.winlen - m.k + 1;   // NOT the database's stride: adapt_options_to_database, querying.cpp:237-239
     cfg.target_id_bytes = m.targetBytes;
     if (m.numParts < 1 || m.numParts > 255) { set_global_error("unsupported number of database parts"); return MC_ERR_UNSUPPORTED; }
     cfg.num_parts = m.numParts;

@@ -1,0 +1,483 @@
+// mcq_build.h -- `metacache build` (and the build half of `build+query`) on MI355X: reference sequences -> database, host C++14 above
+// the C ABI's builder (mc_build_*: sketching, sorting and bucketising run on the GPU, builder.hip).  SURVEY.md §8f rank 1.  Mirrors
+//   option handling       options.cpp:251-265 (database name), :298-370 (info level, id format, taxonomy), :375-485 (sketching, storage),
+//                         :490-520 (augment_taxonomy_options), :535-640 (build mode), :1498-1575 (build+query: -targets / -query / -save-db)
+//   taxonomy dumps        taxonomy_io.cpp:55-175 (names.dmp, merged.dmp, nodes.dmp -> non-target taxa), taxonomy.hpp:182-221 (rank names)
+//   sequence -> taxon id  taxonomy_io.cpp:180-318 (assembly_summary tables), building.cpp:80-150 (*.accession2taxid after the build),
+//                         :196-232 (try_to_rank_unranked_targets), :240-262 (find_taxon_id)
+//   adding targets        building.cpp:283-327 (one sequence), :335-455 (all files; here: files and records in the given order = the
+//                         reference's single-part build), database.cpp:36-82 (ids, names of duplicates), sequence_io.cpp:470-673 (ids)
+//   post-processing       building.cpp:516-534 (-remove-overpopulated-features)
+// Not offered: -remove-ambig-features (needs per-feature lineages on the host; the reference's own GPU build has none either),
+// -parts > 1 (the reference spreads targets over parts in thread-schedule order; the multi-GPU modes use key shards instead).
+#ifndef MCQ_BUILD_H_
+#define MCQ_BUILD_H_
+#include "mcq_common.h"
+
+#include <set>
+
+namespace mcq {
+
+enum class IdType { smart, ncbi, genbank, filename, leading_word };
+
+inline std::string trimmed(std::string s)
+{
+    size_t b = 0, e = s.size();
+    while (b < e && std::isspace((unsigned char)s[b])) ++b;
+    while (e > b && std::isspace((unsigned char)s[e - 1])) --e;
+    return s.substr(b, e - b);
+}
+
+inline std::string ncbi_accession_number(const std::string& text)             // sequence_io.cpp:541-573
+{
+    if (text.empty()) return "";
+    std::smatch m;
+    std::regex_search(text, m, accession_regex());
+    return m[2];
+}
+
+inline std::string genbank_identifier(const std::string& text)                // sequence_io.cpp:581-603
+{
+    if (text.empty()) return "";
+    auto i = text.find("gi|");
+    if (i == std::string::npos) i = text.find("gi:");
+    if (i == std::string::npos) i = text.find("gi=");
+    if (i == std::string::npos) return "";
+    i += 3;
+    auto j = text.find('|', i);
+    if (j == std::string::npos) { j = text.find(' ', i); if (j == std::string::npos) j = text.size(); }
+    return trimmed(text.substr(i, j - i));
+}
+
+inline std::string accession_string(const std::string& text, IdType t)        // extract_accession_string, sequence_io.cpp:608-642
+{
+    if (text.empty()) return "";
+    switch (t) {
+        case IdType::ncbi: return ncbi_accession_number(text);
+        case IdType::genbank: return genbank_identifier(text);
+        case IdType::leading_word: return leading_word(text);
+        case IdType::filename: return filename_without_extension(text);
+        case IdType::smart: {
+            auto s = ncbi_accession_number(text);
+            if (!s.empty()) return s;
+            s = genbank_identifier(text);
+            if (!s.empty()) return s;
+            s = filename_without_extension(text);
+            if (!s.empty()) return s;
+        }
+    }
+    return text;
+}
+
+struct BuildOptions {
+    std::string dbfile;
+    std::vector<std::string> infiles;
+    std::string taxPath;
+    std::vector<std::string> mapPost;               // -taxpostmap + the defaults of augment_taxonomy_options
+    IdType idType = IdType::smart;
+    enum Info { silent, moderate, verbose } info = moderate;
+    uint32_t k = 16, s = 16, w = 127, stride = 0;   // options.hpp:102
+    bool resetParents = false, removeOverpopulated = false, saveDb = false;
+    int maxLocs = -1, parts = 1, targetIdBytes = 4;
+    float maxLoadFac = -1;
+    int removeAmbigRank = kNumRanks;
+};
+
+// args: everything after the mode word.  build: <database> <files>... ; build+query: -targets <files>... [-query <files>...] and every
+// word this parser does not know goes to the query parser (queryArgs).
+inline BuildOptions parse_build(const std::vector<std::string>& args, bool buildQuery, std::vector<std::string>& queryArgs)
+{
+    BuildOptions o;
+    bool haveDb = buildQuery;
+    auto need = [&](size_t& i) -> std::string { if (i + 1 >= args.size()) throw std::runtime_error("value missing after '" + args[i] + "'"); return args[++i]; };
+    auto values = [&](size_t& i, std::vector<std::string>& dst) { while (i + 1 < args.size() && !args[i + 1].empty() && args[i + 1][0] != '-') dst.push_back(args[++i]); };
+    auto set_db = [&](std::string name) {                                      // sanitize_database_name, options.cpp:110-128
+        auto pos = name.find(".meta");
+        if (pos != std::string::npos) name.erase(pos);
+        else { pos = name.find(".cache"); if (pos != std::string::npos) name.erase(pos); }
+        o.dbfile = name;
+    };
+    for (size_t i = 0; i < args.size(); ++i) {
+        const std::string& a = args[i];
+        if (a.empty()) continue;
+        if (a[0] != '-') {
+            if (!haveDb) { set_db(a); haveDb = true; }
+            else if (!buildQuery) o.infiles.push_back(a);
+            else queryArgs.push_back(a);
+            continue;
+        }
+        if (a == "-targets" && buildQuery) values(i, o.infiles);
+        else if (a == "-query" && buildQuery) values(i, queryArgs);
+        else if (a == "-save-db" && buildQuery) { set_db(need(i)); o.saveDb = true; }
+        else if (a == "-taxonomy") o.taxPath = need(i);
+        else if (a == "-taxpostmap") values(i, o.mapPost);
+        else if (a == "-sequence-id-format") {
+            const std::string v = need(i);
+            if (v == "smart") o.idType = IdType::smart; else if (v == "ncbi") o.idType = IdType::ncbi;
+            else if (v == "gi") o.idType = IdType::genbank; else if (v == "filename") o.idType = IdType::filename;
+            else if (v == "leadingword") o.idType = IdType::leading_word;
+            else throw std::runtime_error("unknown sequence id format '" + v + "'");
+        }
+        else if (a == "-silent") o.info = BuildOptions::silent;
+        else if (a == "-verbose") o.info = BuildOptions::verbose;
+        else if (a == "-kmerlen") o.k = (uint32_t)std::stoul(need(i));
+        else if (a == "-sketchlen") o.s = (uint32_t)std::stoul(need(i));
+        else if (a == "-winlen") o.w = (uint32_t)std::stoul(need(i));
+        else if (a == "-winstride") o.stride = (uint32_t)std::stoul(need(i));
+        else if (a == "-reset-taxa" || a == "-reset-parents") o.resetParents = true;
+        else if (a == "-max-locations-per-feature") o.maxLocs = std::stoi(need(i));
+        else if (a == "-remove-overpopulated-features") o.removeOverpopulated = true;
+        else if (a == "-remove-ambig-features") { o.removeAmbigRank = rank_from_name(need(i)); if (o.removeAmbigRank < 0) throw std::runtime_error("unknown rank"); }
+        else if (a == "-max-ambig-per-feature") (void)need(i);
+        else if (a == "-max-load-fac" || a == "-max-load-factor") o.maxLoadFac = std::stof(need(i));
+        else if (a == "-parts") o.parts = std::stoi(need(i));
+        else if (a == "-max-part-size") (void)need(i);
+        else if (a == "-target-id-type") {                                    // the reference's compile-time MC_TARGET_ID_TYPE (config.hpp:57-61)
+            const std::string v = need(i);
+            if (v == "uint16_t" || v == "16") o.targetIdBytes = 2; else if (v == "uint32_t" || v == "32") o.targetIdBytes = 4;
+            else throw std::runtime_error("target id type must be uint16_t or uint32_t");
+        }
+        else if (a == "-threads" && !buildQuery) (void)need(i);               // accepted: sketching and sorting run on the GPU
+        else if (buildQuery) queryArgs.push_back(a);
+        else throw std::runtime_error("unknown option '" + a + "'");
+    }
+    if (!buildQuery && o.dbfile.empty()) throw std::runtime_error("Database name is missing");
+    // process_build_options (options.cpp:614-626)
+    {
+        std::vector<std::string> expanded;
+        for (const auto& name : o.infiles) {
+            auto sub = files_in_directory(name);
+            if (sub.empty()) expanded.push_back(name); else expanded.insert(expanded.end(), sub.begin(), sub.end());
+        }
+        o.infiles.swap(expanded);
+    }
+    if (o.infiles.empty()) throw std::runtime_error("No reference sequence files provided or found");
+    if (o.maxLocs < 0) o.maxLocs = 254;                                       // database::max_supported_locations_per_feature()
+    if (o.stride == 0) o.stride = o.w - o.k + 1;
+    if (o.removeAmbigRank != kNumRanks) throw std::runtime_error("-remove-ambig-features is not available in this GPU build");
+    if (o.parts > 1) throw std::runtime_error("-parts > 1 is not available: one part per build (see DESIGN.md, multi-GPU modes)");
+    // augment_taxonomy_options (options.cpp:490-520)
+    if (!o.taxPath.empty() && o.taxPath.back() != '/') o.taxPath += '/';
+    for (const char* f : {"nucl_gb.accession2taxid", "nucl_wgs.accession2taxid", "nucl_est.accession2taxid", "nucl_gss.accession2taxid"})
+        o.mapPost.push_back(o.taxPath + f);
+    for (const auto& f : files_in_directory(o.taxPath))
+        if (f.find(".accession2taxid") != std::string::npos && std::find(o.mapPost.begin(), o.mapPost.end(), f) == o.mapPost.end()) o.mapPost.push_back(f);
+    return o;
+}
+
+// ---- taxonomy dumps (taxonomy_io.cpp:55-175): taxa above sequence level; the first record of an id wins (unordered_set::emplace) ----
+struct TaxTree {
+    std::vector<Taxon> taxa;
+    std::unordered_map<int64_t, uint32_t> byId;
+    bool emplace(int64_t id, int64_t parent, std::string name, int rank)
+    {
+        if (id == 0 || byId.count(id)) return false;
+        Taxon t; t.id = id; t.parent = parent; t.rank = rank; t.name = std::move(name);
+        byId.emplace(id, (uint32_t)taxa.size());
+        taxa.push_back(std::move(t));
+        return true;
+    }
+};
+
+// fields of one "a\t|\tb\t|\tc\t|" row
+inline std::vector<std::string> dump_fields(const std::string& line)
+{
+    std::vector<std::string> f;
+    size_t p = 0;
+    while (p <= line.size()) {
+        size_t q = line.find('|', p);
+        if (q == std::string::npos) q = line.size();
+        std::string x = line.substr(p, q - p);
+        while (!x.empty() && x.front() == '\t') x.erase(x.begin());
+        while (!x.empty() && (x.back() == '\t' || x.back() == '\r')) x.pop_back();
+        f.push_back(std::move(x));
+        p = q + 1;
+    }
+    return f;
+}
+
+inline TaxTree read_taxonomy_dumps(const BuildOptions& o)
+{
+    const bool info = o.info != BuildOptions::silent;
+    TaxTree tax;
+    std::map<int64_t, std::string> names;
+    {
+        std::ifstream is(o.taxPath + "names.dmp");
+        if (is.good()) {
+            if (info) std::cout << "Reading taxon names ... " << std::flush;
+            int64_t lastId = 0;
+            for (std::string line; std::getline(is, line);) {
+                auto f = dump_fields(line);
+                if (f.size() < 4 || f[0].empty()) continue;
+                int64_t id = 0;
+                try { id = std::stoll(f[0]); } catch (std::exception&) { continue; }
+                if (id == lastId) continue;                                    // a scientific name was already taken for this id
+                if (leading_word(f[3]).find("scientific") != std::string::npos) { lastId = id; names.emplace(id, f[1]); }
+            }
+            if (info) std::cout << "done." << std::endl;
+        } else if (info) std::cerr << "Could not read taxon names file " << o.taxPath << "names.dmp; continuing with ids only." << std::endl;
+    }
+    std::map<int64_t, int64_t> merged;
+    {
+        std::ifstream is(o.taxPath + "merged.dmp");
+        if (is.good()) {
+            if (info) std::cout << "Reading taxonomic node mergers ... " << std::flush;
+            for (std::string line; std::getline(is, line);) {
+                auto f = dump_fields(line);
+                if (f.size() < 2 || f[0].empty()) continue;
+                try {
+                    const int64_t oldId = std::stoll(f[0]), newId = std::stoll(f[1]);
+                    merged.emplace(oldId, newId);
+                    tax.emplace(oldId, newId, "", kNumRanks);
+                } catch (std::exception&) {}
+            }
+            if (info) std::cout << "done." << std::endl;
+        }
+    }
+    {
+        std::ifstream is(o.taxPath + "nodes.dmp");
+        if (!is.good()) {
+            if (info) std::cerr << "Could not read taxonomic nodes file " << o.taxPath << "nodes.dmp" << std::endl;
+            return tax;
+        }
+        if (info) std::cout << "Reading taxonomic tree ... " << std::flush;
+        for (std::string line; std::getline(is, line);) {
+            auto f = dump_fields(line);
+            if (f.size() < 3 || f[0].empty()) continue;
+            int64_t id = 0, parent = 0;
+            try { id = std::stoll(f[0]); parent = std::stoll(f[1]); } catch (std::exception&) { continue; }
+            auto it = names.find(id);
+            std::string name = it != names.end() ? it->second : std::string("--");
+            if (name.empty()) name = "<" + std::to_string(id) + ">";
+            auto mi = merged.find(id);
+            if (mi != merged.end()) id = mi->second;
+            mi = merged.find(parent);
+            if (mi != merged.end()) parent = mi->second;
+            tax.emplace(id, parent, std::move(name), rank_from_dump_name(f[2]));
+        }
+        if (info) std::cout << tax.taxa.size() << " taxa read." << std::endl;
+    }
+    auto root = tax.byId.find(1);
+    if (root != tax.byId.end()) tax.taxa[root->second].rank = kNumRanks - 1;   // reset_rank(1, root)
+    return tax;
+}
+
+// ---- sequence id -> taxon id tables (taxonomy_io.cpp:180-318) ----
+inline void read_id_table(const std::string& file, std::map<std::string, int64_t>& map, bool info)
+{
+    std::ifstream is(file);
+    if (!is.good()) return;
+    if (info) std::cout << "Reading sequence to taxon mappings from " << file << std::endl;
+    std::vector<std::string> lines;
+    for (std::string l; std::getline(is, l);) lines.push_back(std::move(l));
+    // header row = the last of the leading '#' lines (at most 10 are looked at)
+    int headerRow = 0;
+    for (int i = 0; i < 10; ++i, ++headerRow) { if (i >= (int)lines.size() || lines[i].empty() || lines[i][0] != '#') break; }
+    if (headerRow > 0) --headerRow;
+    if (headerRow >= (int)lines.size()) return;
+    int keycol = 0, taxcol = 0;
+    {
+        std::istringstream hs(lines[headerRow]);
+        int col = 0;
+        for (std::string h; hs >> h; ++col) {
+            if (h.size() == 1 && h[0] == '#') hs >> h;
+            if (h == "taxid") taxcol = col;
+            else if (h == "accession.version" || h == "assembly_accession") keycol = col;
+        }
+    }
+    size_t first = (size_t)headerRow + 1;
+    if (taxcol < 1) { taxcol = 1; first = 0; }                                // no header: 1st column = key, 2nd = taxon id, from the top
+    for (size_t r = first; r < lines.size(); ++r) {
+        // the reference moves 'keycol' tabs forward, reads the key, then 'taxcol' MORE tabs forward (taxonomy_io.cpp:271-277)
+        const std::string& l = lines[r];
+        size_t p = 0;
+        bool ok = true;
+        for (int i = 0; i < keycol && ok; ++i) { auto t = l.find('\t', p); if (t == std::string::npos) ok = false; else p = t + 1; }
+        if (!ok) continue;
+        const std::string key = leading_word(l.substr(p));
+        size_t q = l.find(key, p) + key.size();
+        for (int i = 0; i < taxcol && ok; ++i) { auto t = l.find('\t', q); if (t == std::string::npos) ok = false; else q = t + 1; }
+        if (!ok || key.empty()) continue;
+        int64_t id = 0;
+        try { id = std::stoll(l.substr(q)); } catch (std::exception&) { break; }   // a failed extraction ends the reference's loop
+        map.emplace(key, id);
+    }
+}
+
+inline int64_t find_taxon_id(const std::map<std::string, int64_t>& m, const std::string& name)   // building.cpp:240-262
+{
+    if (m.empty() || name.empty()) return 0;
+    auto i = m.find(name);
+    if (i != m.end()) return i->second;
+    i = m.upper_bound(name);
+    if (i == m.end()) return 0;
+    if (i->first.compare(0, name.size(), name) != 0) return 0;
+    return i->second;
+}
+
+struct BuilderError : std::runtime_error { using std::runtime_error::runtime_error; };   // device / capacity failures: fatal
+
+// ---- the built database: builder handle (device arrays) + taxonomy records (non-target taxa, then one taxon per target) ----
+struct BuiltDatabase {
+    mc_builder* b = nullptr;
+    BuildOptions opt;
+    std::vector<Taxon> nonTarget;
+    std::vector<Taxon> targets;                     // id = -(target) - 1, rank sequence
+    ~BuiltDatabase() { if (b) mc_build_free(b); }
+
+    void write() const                              // write_database, building.cpp:546-566
+    {
+        const bool info = opt.info != BuildOptions::silent;
+        if (info) std::cout << "------------------------------------------------\nWriting database to file ... " << std::endl;
+        std::vector<mc_taxon_rec> recs(nonTarget.size());
+        for (size_t i = 0; i < nonTarget.size(); ++i) recs[i] = mc_taxon_rec{nonTarget[i].id, nonTarget[i].parent, (uint32_t)nonTarget[i].rank, nonTarget[i].name.c_str()};
+        if (mc_build_write(b, opt.dbfile.c_str(), recs.data(), recs.size()) != MC_OK) {
+            if (info) std::cout << "FAIL" << std::endl;
+            std::cerr << "Could not write database file!\n";
+            return;
+        }
+        if (info) std::cout << "Completed database writing." << std::endl;
+    }
+};
+
+inline void build_database(const BuildOptions& o, BuiltDatabase& db)
+{
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    const bool info = o.info != BuildOptions::silent;
+    db.opt = o;
+    // prepare_database (building.cpp:462-508)
+    if (info) std::cout << "Max locations per feature set to " << o.maxLocs << std::endl;
+    if (o.maxLoadFac > 0.4f && o.maxLoadFac < 0.99f && info) std::cout << "Using custom hash table load factor of " << o.maxLoadFac << std::endl;
+    if (!o.taxPath.empty()) {
+        TaxTree t = read_taxonomy_dumps(o);
+        db.nonTarget = std::move(t.taxa);
+        if (info) std::cout << "Taxonomy applied to database." << std::endl;
+    }
+    if (db.nonTarget.empty() && info)
+        std::cout << "The datbase doesn't contain a taxonomic hierarchy yet.\nYou can add one or update later via:\n"
+                     "   metacache modify <database> -taxonomy <directory>" << std::endl;
+
+    mc_config c; mc_config_default(&c);
+    c.kmerlen = o.k; c.sketchlen = o.s; c.winlen = o.w; c.winstride = o.stride;
+    c.target_id_bytes = (uint32_t)o.targetIdBytes;
+    c.max_locations_per_feature = (uint32_t)std::max(1, std::min(o.maxLocs, 254));
+    c.remove_overpopulated = o.removeOverpopulated ? 1 : 0;
+    if (o.maxLoadFac > 0.4f && o.maxLoadFac < 0.99f) c.max_load_factor = o.maxLoadFac;
+    if (mc_build_begin(&c, &db.b) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+
+    // make_sequence_to_taxon_id_map (taxonomy_io.cpp:290-318)
+    std::map<std::string, int64_t> seq2tax;
+    {
+        std::set<std::string> dirs;                                            // unique_directories, filesys_utility.cpp:82-92
+        for (const auto& f : o.infiles) dirs.insert(f.substr(0, f.find_last_of("/\\")));
+        for (const auto& d : dirs) read_id_table(d + "/assembly_summary.txt", seq2tax, info);
+        for (const char* f : {"assembly_summary_refseq.txt", "assembly_summary_refseq_historical.txt", "assembly_summary_genbank.txt",
+                              "assembly_summary_genbank_historical.txt"})
+            read_id_table(o.taxPath + f, seq2tax, info);
+    }
+    if (info) {
+        const char* idn[] = {"smart", "ncbi", "gi", "filename", "leadingword"};
+        std::cout << "Sequence ID extraction method: " << idn[(int)o.idType] << "\nProcessing reference sequences." << std::endl;
+    }
+    // add_targets_to_database (building.cpp:335-455) with one consumer: files in the given order, records in file order
+    std::map<std::string, uint32_t> name2tgt;                                  // taxonomy_cache::name2tax_ (taxonomy.hpp:1135-1160)
+    for (size_t fi = 0; fi < o.infiles.size(); ++fi) {
+        const std::string& filename = o.infiles[fi];
+        if (o.info == BuildOptions::verbose) std::cerr << "  (" << fi << '/' << o.infiles.size() << ") " << filename << std::endl;
+        try {
+            std::string fileAcc = accession_string(filename, o.idType);
+            int64_t fileTax = find_taxon_id(seq2tax, fileAcc);
+            if (fileTax == 0 && o.idType == IdType::smart) { fileAcc = accession_string(filename, IdType::filename); fileTax = find_taxon_id(seq2tax, fileAcc); }
+            if (o.info == BuildOptions::verbose) std::cerr << "      accession '" << fileAcc << "' -> taxid " << fileTax << std::endl;
+            SeqFile file(filename);
+            file.index(std::max(1u, std::thread::hardware_concurrency()));
+            std::string scratch;
+            for (size_t r = 0; r < file.records(); ++r) {
+                View h, s;
+                file.record(r, h, s, scratch);
+                if (s.empty()) continue;                                       // building.cpp:295
+                const std::string header(h.p, h.n);
+                std::string seqId = accession_string(header, o.idType);
+                if (seqId.empty()) seqId = header;
+                int64_t parent = fileTax;
+                if (parent == 0) parent = find_taxon_id(seq2tax, seqId);
+                if (parent == 0) parent = taxon_id_in_header(header);
+                if (parent < 1) parent = 0;                                    // database.cpp:58
+                // a name that is already taken gets "!1", "!1!2", ... appended until it is new (taxonomy.hpp:1141-1146)
+                std::string sid = seqId;
+                int dupl = 0;
+                while (name2tgt.find(sid) != name2tgt.end()) { ++dupl; sid += "!" + std::to_string(dupl); }
+                const uint32_t tgt = (uint32_t)db.targets.size();
+                if (mc_build_add_target_src(db.b, s.p, s.n, sid.c_str(), parent, filename.c_str(), r) != MC_OK)
+                    throw BuilderError(mc_build_last_error(db.b));
+                if (dupl > 0 && info)
+                    std::cerr << "Warning: duplicate sequence id! '" << seqId << "' already in database - '" << filename << "/" << r
+                              << "' inserted as '" << sid << "'\n";
+                name2tgt.emplace(sid, tgt);
+                Taxon t; t.id = -(int64_t)tgt - 1; t.parent = parent; t.rank = 0; t.name = sid;
+                mc_build_target_windows(db.b, tgt, &t.windows);
+                db.targets.push_back(std::move(t));
+                if (o.info == BuildOptions::verbose) {
+                    std::cerr << "    P0  [" << seqId;
+                    if (parent > 0) std::cerr << ":" << parent;
+                    std::cerr << "]  " << s.n << " bp" << (dupl > 0 ? "  --  not added to database!\n" : "\n");
+                }
+            }
+        } catch (BuilderError&) {
+            throw;
+        } catch (std::exception& e) {                                          // unreadable file: the reference reports it only with -verbose
+            if (o.info == BuildOptions::verbose) std::cerr << "FAIL: " << e.what() << '\n';
+        }
+    }
+    if (mc_build_finish(db.b, nullptr) != MC_OK) throw std::runtime_error(mc_build_last_error(db.b));
+    if (info)
+        std::cout << "Added " << db.targets.size() << " reference sequences in "
+                  << std::chrono::duration<double>(clock::now() - t0).count() << " s" << std::endl;
+
+    // try_to_rank_unranked_targets (building.cpp:196-232)
+    {
+        std::set<uint32_t> unranked;
+        for (uint32_t t = 0; t < db.targets.size(); ++t) if (o.resetParents || db.targets[t].parent == 0) unranked.insert(t);
+        if (!unranked.empty()) {
+            if (info) std::cout << unranked.size() << " targets are unranked (no taxon was assigned)." << std::endl;
+            for (const auto& file : o.mapPost) {
+                // rank_targets_with_mapping_file (building.cpp:80-150): rows "accession accession.version taxid gi" after one header line
+                std::ifstream is(file);
+                if (!is.good()) continue;
+                if (info) std::cout << "Try to map sequences to taxa using '" << file << "'" << std::endl;
+                std::string acc, accver, gi; uint64_t taxid = 0;
+                std::getline(is, acc); acc.clear();
+                auto with_name = [&](const std::string& n) -> int64_t { if (n.empty()) return -1; auto i = name2tgt.find(n); return i == name2tgt.end() ? -1 : (int64_t)i->second; };
+                auto with_similar = [&](const std::string& n) -> int64_t {
+                    if (n.empty()) return -1;
+                    auto i = name2tgt.upper_bound(n);
+                    if (i == name2tgt.end() || i->first.compare(0, n.size(), n) != 0) return -1;
+                    return (int64_t)i->second; };
+                while (is >> acc >> accver >> taxid >> gi) {
+                    int64_t t = with_name(accver);
+                    if (t < 0) { t = with_similar(acc); if (t < 0) t = with_name(gi); }
+                    if (t >= 0) {
+                        auto u = unranked.find((uint32_t)t);
+                        if (u != unranked.end()) {
+                            db.targets[t].parent = (int64_t)taxid;
+                            mc_build_set_parent(db.b, (uint64_t)t, (int64_t)taxid);
+                            unranked.erase(u);
+                            if (unranked.empty()) break;
+                        }
+                    }
+                }
+                if (unranked.empty()) break;
+            }
+        }
+        size_t still = 0;
+        for (const auto& t : db.targets) if (t.parent == 0) ++still;
+        if (info) {
+            if (!still) std::cout << "All targets are ranked (have a taxon assigned)." << std::endl;
+            else std::cout << still << " targets remain unranked (no taxon was assigned)." << std::endl;
+        }
+    }
+}
+
+}  // namespace mcq
+#endif

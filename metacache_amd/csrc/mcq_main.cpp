@@ -14,128 +14,11 @@
 //       [-separate-cols] [-separator s] [-lineage] [-pairfiles | -pairseq] [-insertsize n] [-sketchlen s] [-winlen w]
 //       [-winstride l] [-max-locations-per-feature n] [-remove-overpopulated-features] [-max-load-fac f]
 //       [-no-query-params] [-no-summary] [-threads n (accepted, ignored)] [-batch-size n]
-#include "metacache_amd.h"
-
-#include <dirent.h>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-#include <zlib.h>
-
-#include <algorithm>
-#include <array>
-#include <atomic>
-#include <chrono>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <regex>
-#include <thread>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <fstream>
-#include <iostream>
-#include <cmath>
-#include <iomanip>
-#include <limits>
-#include <memory>
-#include <sstream>
-#include <stdexcept>
-#include <string>
-#include <unordered_map>
-#include <vector>
+#include "mcq_build.h"
 
 namespace {
 
-constexpr int kNumRanks = MC_NUM_RANKS;      // 21, index 21 = none
-const char* const kRankNames[] = {"sequence", "form", "variety", "subspecies", "species", "subgenus", "genus", "subtribe", "tribe",
-                                  "subfamily", "family", "suborder", "order", "subclass", "class", "subphylum", "phylum",
-                                  "subkingdom", "kingdom", "domain", "root", "none"};
-
-int rank_from_name(std::string n)                    // taxonomy.hpp:174-214
-{
-    std::transform(n.begin(), n.end(), n.begin(), ::tolower);
-    for (int i = 0; i <= kNumRanks; ++i) if (n == kRankNames[i]) return i;
-    if (n == "genome") return 0;
-    return -1;
-}
-
-struct Taxon { int64_t id = 0, parent = 0; int rank = kNumRanks; std::string name; uint64_t windows = 0; };
-using Lineage = std::array<uint32_t, kNumRanks>;     // taxon index + 1, 0 = none
-
-struct Taxonomy {
-    std::vector<Taxon> taxa;
-    std::unordered_map<int64_t, uint32_t> byId;
-    const uint32_t* targetLineages = nullptr;        // [targets * 21]
-    uint64_t numTargets = 0;
-
-    std::map<std::string, uint32_t> targetByName;    // name2tax_ (taxonomy.hpp:1108-1127): sequence-level taxa by name
-    std::vector<char> coveredCache;                 // covers(): taxa on the full lineage of any target
-
-    const Taxon* taxon(uint32_t idxPlus1) const { return idxPlus1 ? &taxa[idxPlus1 - 1] : nullptr; }
-    uint32_t with_name(const std::string& n) const { if (n.empty()) return 0; auto i = targetByName.find(n); return i == targetByName.end() ? 0 : i->second; }
-    uint32_t with_similar_name(const std::string& n) const
-    {
-        if (n.empty()) return 0;
-        auto i = targetByName.upper_bound(n);
-        if (i == targetByName.end() || i->first.compare(0, n.size(), n) != 0) return 0;
-        return i->second;
-    }
-    uint32_t with_id(int64_t id) const { auto i = byId.find(id); return i == byId.end() ? 0 : i->second + 1; }
-    // cached_next_ranked_ancestor (taxonomy.hpp:1245-1256)
-    uint32_t next_ranked_ancestor(uint32_t t) const
-    {
-        if (!t) return 0;
-        if (taxon(t)->rank != kNumRanks) return t;
-        for (uint32_t a : ranks_of(t)) if (a) return a;
-        return 0;
-    }
-    bool covers(uint32_t t) const { return t && coveredCache[t]; }   // taxonomy.hpp:1355-1366
-    void build_covered()
-    {
-        {
-            coveredCache.assign(taxa.size() + 1, 0);
-            for (size_t i = 0; i < taxa.size(); ++i) {
-                if (taxa[i].rank != 0 || taxa[i].id >= 0) continue;          // targets only
-                coveredCache[i + 1] = 1;
-                int64_t id = taxa[i].parent;
-                for (int guard = 0; id != 0 && guard < 1000; ++guard) {
-                    auto it = byId.find(id);
-                    if (it == byId.end()) break;
-                    coveredCache[it->second + 1] = 1;
-                    if (taxa[it->second].parent == id) break;
-                    id = taxa[it->second].parent;
-                }
-            }
-        }
-    }
-    Lineage target_ranks(uint32_t tgt) const
-    {
-        Lineage l{};
-        if (tgt < numTargets) std::copy(targetLineages + (size_t)tgt * kNumRanks, targetLineages + (size_t)(tgt + 1) * kNumRanks, l.begin());
-        return l;
-    }
-    // taxonomy::make_ranks (taxonomy.hpp:576-597)
-    Lineage ranks_of(uint32_t idxPlus1) const
-    {
-        Lineage l{};
-        const Taxon* t = taxon(idxPlus1);
-        if (!t) return l;
-        if (t->rank < kNumRanks) l[t->rank] = idxPlus1;
-        int64_t id = t->parent;
-        while (id != 0) {
-            auto it = byId.find(id);
-            if (it == byId.end()) break;
-            const Taxon& p = taxa[it->second];
-            if (p.rank < kNumRanks) l[p.rank] = it->second + 1;
-            if (p.parent == id) break;
-            id = p.parent;
-        }
-        return l;
-    }
-};
+using namespace mcq;
 
 struct Options {
     std::string db, outfile;
@@ -173,25 +56,6 @@ std::string sanitize_special_chars(const std::string& s)   // cmdline_utility: "
         r += s[i];
     }
     return r;
-}
-
-// files_in_directory (filesys_utility.cpp:34-75): entries in readdir order, directories expanded at most 'recurse' levels deep
-std::vector<std::string> files_in_directory(std::string dirName, int recurse = 10)
-{
-    while (!dirName.empty() && (dirName.back() == '/' || dirName.back() == '\\')) { dirName.pop_back(); break; }
-    std::vector<std::string> files;
-    if (DIR* dir = opendir(dirName.c_str())) {
-        while (dirent* e = readdir(dir)) {
-            const std::string nm = e->d_name;
-            if (nm == "." || nm == "..") continue;
-            const std::string path = dirName + "/" + nm;
-            std::vector<std::string> sub;
-            if (recurse > 0) sub = files_in_directory(path, recurse - 1);
-            if (sub.empty()) files.push_back(path); else files.insert(files.end(), sub.begin(), sub.end());
-        }
-        closedir(dir);
-    }
-    return files;
 }
 
 // Command line options of `metacache query` (options.cpp:860-1295); 'o' carries the defaults (interactive mode: the options of
@@ -274,127 +138,6 @@ Options parse(const std::vector<std::string>& args, Options o)
     return o;
 }
 
-// ---- sequence files (FASTA / 4-line FASTQ; plain = memory-mapped, gzip = inflated into memory) ---------------------------------------------
-struct View { const char* p = nullptr; size_t n = 0; bool empty() const { return n == 0; } };
-
-class SeqFile {
-public:
-    explicit SeqFile(const std::string& fn)
-    {
-        fd_ = ::open(fn.c_str(), O_RDONLY);
-        struct stat st;
-        if (fd_ < 0 || fstat(fd_, &st) != 0) throw std::runtime_error("file '" + fn + "' could not be opened");
-        unsigned char magic[2] = {0, 0};
-        const bool gz = st.st_size >= 2 && pread(fd_, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-        if (gz) {
-            // compressed input (the reference reads it through zlib as well): inflated into memory, then handled like a mapped file
-            gzFile g = gzdopen(dup(fd_), "rb");
-            if (!g) throw std::runtime_error("file '" + fn + "' could not be opened");
-            gzbuffer(g, 1u << 20);
-            size_t cap = std::max<size_t>((size_t)st.st_size * 4, 1u << 20);
-            own_.resize(cap);
-            for (;;) {
-                if (size_ == own_.size()) own_.resize(own_.size() * 2);
-                const int got = gzread(g, own_.data() + size_, (unsigned)std::min<size_t>(own_.size() - size_, 1u << 30));
-                if (got < 0) { gzclose(g); throw std::runtime_error("file '" + fn + "' could not be decompressed"); }
-                if (got == 0) break;
-                size_ += (size_t)got;
-            }
-            gzclose(g);
-            data_ = own_.data();
-            return;
-        }
-        size_ = (size_t)st.st_size;
-        if (size_) {
-            void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
-            if (m == MAP_FAILED) throw std::runtime_error("file '" + fn + "' could not be mapped");
-            data_ = (const char*)m;
-            mapped_ = true;
-            madvise(m, size_, MADV_SEQUENTIAL);
-        }
-    }
-    ~SeqFile() { if (mapped_) munmap((void*)data_, size_); if (fd_ >= 0) ::close(fd_); }
-    SeqFile(const SeqFile&) = delete;
-
-    // record starts = lines beginning with '>' (FASTA) or '@' header lines of 4-line FASTQ records; found by all threads
-    void index(unsigned threads)
-    {
-        size_t first = 0;                                                         // sequence_io.cpp:168-173: skip to the first '>' / '@' line
-        while (first < size_ && data_[first] != '>' && data_[first] != '@') first = next_line(first);
-        if (first >= size_) return;
-        fastq_ = data_[first] == '@';
-        threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, size_ / (1u << 22) + 1));
-        std::vector<std::vector<uint64_t>> found(threads);
-        std::vector<std::thread> pool;
-        const size_t span = (size_ - first + threads - 1) / threads;
-        for (unsigned t = 0; t < threads; ++t)
-            pool.emplace_back([&, t] { scan(first + t * span, std::min(size_, first + (t + 1) * span), found[t]); });
-        for (auto& th : pool) th.join();
-        for (auto& v : found) starts_.insert(starts_.end(), v.begin(), v.end());
-    }
-    size_t records() const { return starts_.size(); }
-
-    // sequence_reader::read_next: header without the marker, sequence lines joined ('scratch' only for multi-line records)
-    void record(size_t i, View& header, View& seq, std::string& scratch) const
-    {
-        const size_t b = starts_[i], e = i + 1 < starts_.size() ? starts_[i + 1] : size_;
-        size_t eol = line_end(b, e);
-        header = trimmed(b + 1, eol);
-        size_t p = std::min(eol + 1, e);
-        if (fastq_) { seq = trimmed(p, line_end(p, e)); return; }
-        seq = View{};
-        bool multi = false;
-        while (p < e) {
-            eol = line_end(p, e);
-            const View l = trimmed(p, eol);
-            if (l.n) {
-                if (seq.n == 0 && !multi) seq = l;
-                else { if (!multi) { scratch.assign(seq.p, seq.n); multi = true; } scratch.append(l.p, l.n); }
-            }
-            p = eol + 1;
-        }
-        if (multi) seq = View{scratch.data(), scratch.size()};
-    }
-
-private:
-    size_t next_line(size_t p) const { const void* nl = memchr(data_ + p, '\n', size_ - p); return nl ? (size_t)((const char*)nl - data_) + 1 : size_; }
-    size_t line_end(size_t p, size_t e) const { if (p >= e) return e; const void* nl = memchr(data_ + p, '\n', e - p); return nl ? (size_t)((const char*)nl - data_) : e; }
-    View trimmed(size_t b, size_t e) const { while (e > b && (data_[e - 1] == '\r' || data_[e - 1] == '\n')) --e; return View{data_ + b, e > b ? e - b : 0}; }
-    bool fastq_header_at(size_t p) const
-    {
-        if (p >= size_ || data_[p] != '@') return false;
-        const size_t l2 = next_line(next_line(p));
-        return l2 < size_ && data_[l2] == '+';
-    }
-    void scan(size_t lo, size_t hi, std::vector<uint64_t>& out) const
-    {
-        if (!fastq_) {
-            for (size_t p = lo; p < hi;) {
-                const void* g = memchr(data_ + p, '>', hi - p);
-                if (!g) break;
-                const size_t q = (size_t)((const char*)g - data_);
-                if (q == 0 || data_[q - 1] == '\n') out.push_back(q);
-                p = q + 1;
-            }
-            return;
-        }
-        size_t p = lo;
-        if (p > 0 && data_[p - 1] != '\n') p = next_line(p);
-        while (p < hi && !fastq_header_at(p)) p = next_line(p);                   // an '@' line whose line+2 starts with '+' is a header
-        while (p < hi) {
-            out.push_back(p);
-            p = next_line(next_line(next_line(next_line(p))));
-            while (p < size_ && data_[p] != '@') p = next_line(p);                // blank lines between records
-        }
-    }
-    int fd_ = -1;
-    const char* data_ = nullptr;
-    size_t size_ = 0;
-    bool fastq_ = false, mapped_ = false;
-    std::vector<char> own_;
-    std::vector<uint64_t> starts_;
-};
-
 // ---- output (printing.cpp:160-365) ----------------------------------------------------------------------------------
 void print_taxon(std::ostream& os, const Options& o, const std::string& name, int64_t id, int rank)
 {
@@ -466,39 +209,6 @@ void show_matches(std::ostream& os, const Options& o, const Taxonomy& tx, const 
 }
 
 // ---- ground truth from the query header (classification.cpp:104-137; sequence_io.cpp:479-673) ---------------------------
-const std::regex& accession_regex()
-{
-    static const std::regex re("(^|[^[:alnum:]])(([A-Z][_A-Z]{1,9}[0-9]{5,})(\\.[0-9]+)?)", std::regex::optimize);
-    return re;
-}
-
-std::string leading_word(const std::string& t)
-{
-    auto fst = std::find_if(t.begin(), t.end(), [](char c) { return !std::isspace((unsigned char)c); });
-    if (fst == t.end()) return t;
-    auto lst = std::find_if(fst + 1, t.end(), [](char c) { return std::isspace((unsigned char)c); });
-    return std::string(fst, lst);
-}
-
-std::string filename_without_extension(const std::string& t)
-{
-    if (t.empty()) return t;
-    auto fst = std::find(t.rbegin(), t.rend(), '/').base();
-    auto ext = std::find(fst, t.end(), '.');
-    return std::string(fst, ext);
-}
-
-int64_t taxon_id_in_header(const std::string& t)
-{
-    auto i = t.find("taxid");
-    if (i == std::string::npos) return 0;
-    i += 6;                                                   // "taxid" + one separator character
-    if (i > t.size()) return 0;
-    auto j = t.find('|', i);
-    if (j == std::string::npos) { j = t.find(' ', i); if (j == std::string::npos) j = t.size(); }
-    try { return (int64_t)std::stoull(t.substr(i, j - i)); } catch (std::exception&) { return 0; }
-}
-
 uint32_t ground_truth(const Taxonomy& tx, const std::string& header)
 {
     if (header.empty()) return 0;
@@ -553,6 +263,9 @@ struct Session {
     unsigned threads = 1, workers = 1;
     ~Session() { if (ctx) mc_destroy(ctx); }
 
+    BuiltDatabase* built = nullptr;                  // build+query: the table comes from the builder's device arrays, not from files
+    std::vector<uint32_t> builtLineages;
+
     void open(const Options& o)
     {
         mc_config c; mc_config_default(&c);
@@ -566,7 +279,9 @@ struct Session {
         c.slot_max_queries = o.batchSize;
         c.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
         c.max_load_factor = o.maxLoadFac;
-        if (o.removeOverpopulated) {                                            // read_database, mode_query.cpp:69-92
+        if (built) {
+            if (built->opt.maxLoadFac > 0.4f && built->opt.maxLoadFac < 0.99f) c.max_load_factor = built->opt.maxLoadFac;
+        } else if (o.removeOverpopulated) {                                     // read_database, mode_query.cpp:69-92
             int maxlpf = o.maxLocs - 1;
             if (maxlpf < 0 || maxlpf >= 254) maxlpf = 253;
             c.remove_overpopulated = (uint32_t)maxlpf;                             // clamped to the DB's cap - 1 by mc_open_database
@@ -574,18 +289,38 @@ struct Session {
         } else if (o.maxLocs > 1) c.max_locations_per_feature = (uint32_t)o.maxLocs;
         if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0) return;  // same table, same slots: keep it
         if (ctx) { mc_destroy(ctx); ctx = nullptr; }
-        if (mc_open_database(o.db.c_str(), &c, &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+        tx = Taxonomy{};
+        if (built) {
+            // add_to_database_and_query (mode_build_query.cpp:41-77): a query context over the builder's arrays
+            if (mc_build_set_query_config(built->b, &c) != MC_OK || mc_build_finish(built->b, &ctx) != MC_OK)
+                throw std::runtime_error(mc_build_last_error(built->b));
+            tx.taxa = built->nonTarget;
+            tx.taxa.insert(tx.taxa.end(), built->targets.begin(), built->targets.end());
+        } else {
+            if (mc_open_database(o.db.c_str(), &c, &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+            uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
+            for (uint64_t i = 0; i < nt; ++i) {
+                uint32_t rk; const char* nm;
+                mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
+                tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm;
+                mc_db_taxon_source(ctx, i, nullptr, nullptr, &tx.taxa[i].windows);
+            }
+        }
         cfg = c; db = o.db;
         uint64_t info[8]; mc_db_info(ctx, info);
         dbSketch = (uint32_t)info[1]; dbWinlen = (uint32_t)info[2]; dbStride = (uint32_t)info[3];
-        tx = Taxonomy{};
-        uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
-        for (uint64_t i = 0; i < nt; ++i) {
-            uint32_t rk; const char* nm;
-            mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
-            tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm; tx.byId.emplace(tx.taxa[i].id, (uint32_t)i);
-            mc_db_taxon_source(ctx, i, nullptr, nullptr, &tx.taxa[i].windows);
+        for (size_t i = 0; i < tx.taxa.size(); ++i) {
+            tx.byId.emplace(tx.taxa[i].id, (uint32_t)i);
             if (tx.taxa[i].rank == 0 && tx.taxa[i].id < 0) tx.targetByName.emplace(tx.taxa[i].name, (uint32_t)i + 1);
+        }
+        if (built) {                                                            // ranked lineages of the targets (taxonomy.hpp:576-597)
+            const size_t nt = built->targets.size(), base = built->nonTarget.size();
+            builtLineages.assign(nt * kNumRanks, 0);
+            for (size_t t = 0; t < nt; ++t) {
+                const Lineage l = tx.ranks_of((uint32_t)(base + t) + 1);
+                std::copy(l.begin(), l.end(), builtLineages.begin() + t * kNumRanks);
+            }
+            if (mc_set_lineages(ctx, builtLineages.data(), nt) != MC_OK) throw std::runtime_error(mc_last_error(ctx));
         }
         mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets);
         tx.build_covered();
@@ -1021,54 +756,102 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         }
 }
 
+// query mode proper / the query half of build+query: files of the command line, or the interactive loop
+int query_main(Session& S, const Options& init)
+{
+    auto process = [&](const Options& o) {                                   // process_input_files, querying.cpp:141-222
+        if (!o.splitOut) { run_job(S, o, o.infiles, o.outfile, o.targetsFile, o.abundanceFile); return; }
+        const size_t stride = (o.pairing == Options::files && o.infiles.size() > 1) ? 2 : 1;
+        for (size_t i = 0; i + stride <= o.infiles.size(); i += stride) {
+            std::vector<std::string> in(o.infiles.begin() + i, o.infiles.begin() + i + stride);
+            std::string suffix;
+            for (const auto& f : in) suffix += "_" + f.substr(f.find_last_of("/\\") + 1);
+            auto named = [&](const std::string& f) { return f.empty() ? std::string() : f + suffix + ".txt"; };
+            run_job(S, o, in, named(o.outfile), named(o.targetsFile), named(o.abundanceFile));
+        }
+    };
+    if (!init.infiles.empty()) { process(init); return 0; }
+    // run_interactive_query_mode (querying.cpp:274-322)
+    S.open(init);
+    std::cout << "Running in interactive mode:\n"
+                 " - Enter input file name(s) and command line options and press return.\n"
+                 " - The initially given command line options will be used as defaults.\n"
+                 " - All command line options that would modify the database are ignored.\n"
+                 " - Each line will be processed separately.\n"
+                 " - Lines starting with '#' will be ignored.\n"
+                 " - Enter an empty line or press Ctrl-D to quit MetaCache.\n" << std::endl;
+    for (;;) {
+        std::cout << "$> " << std::flush;
+        std::string line;
+        std::getline(std::cin, line);
+        if (line.empty() || line.find(":q") == 0) { std::cout << "Terminate." << std::endl; return 0; }
+        if (line[0] == '#') continue;
+        std::vector<std::string> args;
+        std::istringstream iss(line);
+        for (std::string w; iss >> w;) args.push_back(w);
+        try {
+            Options o = parse(args, init);
+            // load-time settings stay those of the initial command line
+            o.maxLocs = init.maxLocs; o.removeOverpopulated = init.removeOverpopulated; o.maxLoadFac = init.maxLoadFac;
+            if (o.infiles.empty()) { if (init.showErrors) std::cerr << "No input filenames provided!\n"; continue; }
+            process(o);
+        } catch (std::exception& e) { if (init.showErrors) std::cerr << e.what() << '\n'; }
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
     try {
-        if (argc < 3 || std::string(argv[1]) != "query") throw std::runtime_error("usage: mcq query <database> [<sequence file/directory>...] [options]");
-        Options init;
-        init.db = argv[2];
-        init = parse(std::vector<std::string>(argv + 3, argv + argc), init);
-        Session S;
-        auto process = [&](const Options& o) {                                   // process_input_files, querying.cpp:141-222
-            if (!o.splitOut) { run_job(S, o, o.infiles, o.outfile, o.targetsFile, o.abundanceFile); return; }
-            const size_t stride = (o.pairing == Options::files && o.infiles.size() > 1) ? 2 : 1;
-            for (size_t i = 0; i + stride <= o.infiles.size(); i += stride) {
-                std::vector<std::string> in(o.infiles.begin() + i, o.infiles.begin() + i + stride);
-                std::string suffix;
-                for (const auto& f : in) suffix += "_" + f.substr(f.find_last_of("/\\") + 1);
-                auto named = [&](const std::string& f) { return f.empty() ? std::string() : f + suffix + ".txt"; };
-                run_job(S, o, in, named(o.outfile), named(o.targetsFile), named(o.abundanceFile));
-            }
-        };
-        if (!init.infiles.empty()) { process(init); return 0; }
-        // run_interactive_query_mode (querying.cpp:274-322)
-        S.open(init);
-        std::cout << "Running in interactive mode:\n"
-                     " - Enter input file name(s) and command line options and press return.\n"
-                     " - The initially given command line options will be used as defaults.\n"
-                     " - All command line options that would modify the database are ignored.\n"
-                     " - Each line will be processed separately.\n"
-                     " - Lines starting with '#' will be ignored.\n"
-                     " - Enter an empty line or press Ctrl-D to quit MetaCache.\n" << std::endl;
-        for (;;) {
-            std::cout << "$> " << std::flush;
-            std::string line;
-            std::getline(std::cin, line);
-            if (line.empty() || line.find(":q") == 0) { std::cout << "Terminate." << std::endl; return 0; }
-            if (line[0] == '#') continue;
-            std::vector<std::string> args;
-            std::istringstream iss(line);
-            for (std::string w; iss >> w;) args.push_back(w);
-            try {
-                Options o = parse(args, init);
-                // load-time settings stay those of the initial command line
-                o.maxLocs = init.maxLocs; o.removeOverpopulated = init.removeOverpopulated; o.maxLoadFac = init.maxLoadFac;
-                if (o.infiles.empty()) { if (init.showErrors) std::cerr << "No input filenames provided!\n"; continue; }
-                process(o);
-            } catch (std::exception& e) { if (init.showErrors) std::cerr << e.what() << '\n'; }
+        const std::string mode = argc > 1 ? argv[1] : "";
+        const std::vector<std::string> args(argv + std::min(argc, 2), argv + argc);
+        if (mode == "query") {
+            if (args.empty()) throw std::runtime_error("usage: mcq query <database> [<sequence file/directory>...] [options]");
+            Options init;
+            init.db = args[0];
+            init = parse(std::vector<std::string>(args.begin() + 1, args.end()), init);
+            Session S;
+            return query_main(S, init);
         }
+        if (mode == "build") {                                                  // main_mode_build, mode_build.cpp:93-106, :41-66
+            using clock = std::chrono::steady_clock;
+            std::vector<std::string> none;
+            const BuildOptions bo = parse_build(args, false, none);
+            const bool info = bo.info != BuildOptions::silent;
+            if (info) std::cout << "Building new database '" << bo.dbfile << "' from reference sequences." << std::endl;
+            const auto t0 = clock::now();
+            BuiltDatabase db;
+            build_database(bo, db);
+            const double btime = std::chrono::duration<double>(clock::now() - t0).count();
+            db.write();
+            const double total = std::chrono::duration<double>(clock::now() - t0).count();
+            if (info)
+                std::cout << "------------------------------------------------\n"
+                          << "Construction time: " << btime << " s\n"
+                          << "Writing time:      " << total - btime << " s\n"
+                          << "Total build time:  " << total << " s" << std::endl;
+            return 0;
+        }
+        if (mode == "build+query") {                                            // main_mode_build_query, mode_build_query.cpp:41-94
+            std::vector<std::string> qargs;
+            const BuildOptions bo = parse_build(args, true, qargs);
+            if (bo.info != BuildOptions::silent) std::cout << "Building new database from reference sequences." << std::endl;
+            BuiltDatabase db;
+            build_database(bo, db);
+            Options init;
+            init.db = "<built in memory>";
+            init = parse(qargs, init);
+            int rc = 0;
+            {
+                Session S;
+                S.built = &db;
+                rc = query_main(S, init);
+            }
+            if (bo.saveDb) db.write();
+            return rc;
+        }
+        throw std::runtime_error("usage: mcq query|build|build+query ... (see the header of mcq_main.cpp / mcq_build.h)");
     } catch (std::exception& e) {
         std::cerr << "ABORT: " << e.what() << "!" << std::endl;                  // main.cpp:65-68
         return 1;
