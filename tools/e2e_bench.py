@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=400_000, help="reads whose mapping lines are diffed against the reference CLI")
     ap.add_argument("--out", default="")
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--build", action="store_true", help="also time `build` from FASTA files (mcq and the reference)")
     args = ap.parse_args()
     build.build_library()
     G, GL = 16, 5_000_000
@@ -116,6 +117,31 @@ def main():
         a = sorted(l for l in open(oref) if not l.startswith("#"))
         b = sorted(l for l in open(o) if not l.startswith("#"))
         res["identical_mapping_lines"] = {"reference": len(a), "mcq": len(b), "differing": sum(x != y for x, y in zip(a, b)) + abs(len(a) - len(b))}
+    if args.build:
+        # `build` from FASTA files on disk (80-column lines, one file per genome, taxon id in the header): mcq beside the reference
+        gdir = os.path.join(tmp, "genomes")
+        os.makedirs(gdir)
+        files = []
+        for i, g in enumerate(genomes):
+            fn = os.path.join(gdir, f"syn{i:03d}.fa")
+            body = np.full((GL // 80 + 1, 81), ord("\n"), dtype=np.uint8)
+            pad = np.full(body.shape[0] * 80, ord("A"), dtype=np.uint8)
+            pad[:GL] = g
+            body[:, :80] = pad.reshape(-1, 80)
+            with open(fn, "wb") as f:
+                f.write(f">SYN_{i:06d}.1 synthetic genome taxid|{1000 + i}|\n".encode())
+                f.write(body.tobytes()[: GL + GL // 80 + 1])
+                f.write(b"\n")
+            files.append(fn)
+        bdb = os.path.join(tmp, "built_mcq")
+        run([mcq, "build", bdb] + files[:1] + ["-silent"])                      # warm-up (runtime start, page cache)
+        wall = run([mcq, "build", bdb] + files + ["-silent"])
+        res["mcq_build"] = {"wall_s": round(wall, 3), "Mbp": G * GL / 1e6, "Mbp_per_s": round(G * GL / 1e6 / wall, 1)}
+        ref32 = os.path.join(ROOT, "oracle", "_ref", "metacache_u32")
+        if os.path.exists(ref32) and not args.no_ref:
+            rdb = os.path.join(tmp, "built_ref")
+            wall = run([ref32, "build", rdb] + files + ["-silent"])
+            res["reference_cpu_build"] = {"wall_s": round(wall, 3), "threads": os.cpu_count(), "Mbp_per_s": round(G * GL / 1e6 / wall, 1)}
     print(json.dumps(res, indent=1))
     if args.out:
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
