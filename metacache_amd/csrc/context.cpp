@@ -521,7 +521,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 16 + (size_t)3 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 32 + (size_t)4 * std::max<uint32_t>(n, 1) * 16))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -534,7 +534,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
     ws.scanTmp = P.bScan.p; ws.stats = (uint64_t*)P.bStats.p;
     if (lanePath) {
-        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 4;
+        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 8;
         ws.chunkList = (uint2*)P.bChunkList.p;
     }
 
@@ -551,7 +551,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const bool fuse = !wantAllhits && !taxkey;
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
-        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 16, st));
+        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 32, st));
         if (ctx->fuseLane) {
             ScopedTimer t(ctx, "sketch_probe", st);
             launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, st);
@@ -564,6 +564,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "hash_cands", st); launch_hash_cands(b, tab, ws, K, taxkey, P.bCands.p, st); }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }

@@ -1061,6 +1061,7 @@ constexpr uint32_t kLaneHits = MC_LANE_HITS;  // longest location list handled b
 constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
 constexpr uint32_t kLaneU = 4;            // lookups in flight per lane
 constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
+constexpr uint32_t kHashMax = 1024, kHashSlots = 2048, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: list, table, entries, maxWindowsInRange
 
 __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
 {
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
     const uint32_t total = rdlane(incl, 63);
     if (total) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ws.midCount[3], total);
+        if (lane == 0) base = atomicAdd(&ws.midCount[4], total);
         base = rdlane(base, 0);
         // the wave writes its records together (64 consecutive ones per round); record r belongs to the first lane with incl > r
         for (uint32_t r0 = 0; r0 < total; r0 += 64) {
@@ -1206,7 +1207,7 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
 // one lane per chunk: the window sketches of its <= kChunkWins windows
 __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchParams sp, Workspace ws)
 {
-    const uint32_t total = ws.midCount[3];
+    const uint32_t total = ws.midCount[4];
     for (uint32_t id = blockIdx.x * 128 + threadIdx.x; id < total; id += gridDim.x * 128) {
         const uint2 rec = ws.chunkList[id];
         const uint32_t q = rec.x, c = rec.y;
@@ -1226,7 +1227,7 @@ __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchPa
 template <bool QUAD>
 __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
 {
-    const uint32_t total = ws.midCount[3];
+    const uint32_t total = ws.midCount[4];
     for (uint32_t base = blockIdx.x * 128; base < total; base += gridDim.x * 128) {   // block-uniform: quads stay together
         const uint32_t id = base + threadIdx.x;
         uint2 rec = make_uint2(0, 0);
@@ -1302,7 +1303,7 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
 // Compacting short lists here for mid_cands_kernel was measured too: what the wave kernel saves, the compaction costs.)
 __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace ws)
 {
-    const uint32_t total = ws.midCount[3];
+    const uint32_t total = ws.midCount[4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + (threadIdx.x >> 6);
     for (uint32_t base = waveId * 64; base < total; base += nWaves * 64) {
@@ -1565,11 +1566,12 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     const bool coop = hand && !over;
     const uint32_t lane = threadIdx.x & 63u;
     if (coop) {
-        uint32_t off = n;                                         // descriptors get their list offset: index(40) | size(16) | offset(8)
+        uint32_t off = n;                                         // descriptors get their list offset: index(36) | size(16) | offset(12)
+                                                                  // (offsets matter up to kHashMax only; 2^36 locations = 512 GB)
         for (uint32_t i = 0; i < m; ++i) {
             const uint64_t d = L[kLaneHits - i];
             const uint64_t size = d >> 48;
-            L[kLaneHits - i] = (d & 0xFFFFFFFFFFull) | (size << 40) | ((uint64_t)(off & 0xFFu) << 56);
+            L[kLaneHits - i] = (d & 0xFFFFFFFFFull) | (size << 36) | ((uint64_t)(off & 0xFFFu) << 52);
             off += (uint32_t)size;
         }
         gnent = n + m;
@@ -1588,7 +1590,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                 if (lane < rn) { ps = 1u | (lane << 16); pp = row[lane]; }
                 else {
                     const uint64_t d = row[kLaneHits - (lane - rn)];
-                    ps = (uint32_t)((d >> 40) & 0xFFFFu) | ((uint32_t)(d >> 56) << 16); pp = d & 0xFFFFFFFFFFull;
+                    ps = (uint32_t)((d >> 36) & 0xFFFFu) | ((uint32_t)(d >> 52) << 16); pp = d & 0xFFFFFFFFFull;
                 }
                 ws.psize[rfb + lane] = ps; ws.ppay[rfb + lane] = pp;
             }
@@ -1600,11 +1602,14 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         if (H > kMidMax) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;   // the wave kernel reads all nf slots
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
         // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
-        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : 3u;
-        ws.qflag[q] = cls < 3 ? kFlagMid : kFlagCands;
+        // ... and of hash_cands_kernel (257 .. 1024 locations, one wave per query, no sort); longer ones, wide window ranges -> wave kernel
+        const uint32_t mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : (H <= kHashMax && nent <= kHashEnt && mw <= kHashWin) ? 3u : 4u;
+        ws.qflag[q] = cls < 4 ? kFlagMid : kFlagCands;
+        if (cls == 3) ws.hitScan[q] = 0u;                        // no segment in HBM
         const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-        for (uint32_t c = 0; c < 3; ++c) {
+        for (uint32_t c = 0; c < 4; ++c) {
             const uint64_t mask = __ballot(cls == c);
             if (cls == c) {
                 const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
@@ -2012,6 +2017,212 @@ void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, 
     if (cls == 0)      launch_mid_g<4>(std::min<uint32_t>(blocks, (b.n + 63) / 64), 0u, b, tab, ws, maxCand, taxkey, cands, st);
     else if (cls == 1) launch_mid_g<8>(std::min<uint32_t>(blocks, (b.n + 31) / 32), 1u, b, tab, ws, maxCand, taxkey, cands, st);
     else               launch_mid_g<16>(std::min<uint32_t>(blocks, (b.n + 15) / 16), 2u, b, tab, ws, maxCand, taxkey, cands, st);
+}
+// ================================================================================================
+// hash_cands_kernel: location lists of 257 .. 1024 entries (RefSeq-scale tables: 32-bit features collide, a 150 bp read collects
+// ~300 locations, most of them single hits on unrelated targets), one WAVE per query, NO sort.  What rows 8-10 deliver is, per
+// target, the window range with the most list entries (the earliest one among equals), and of those the K best by (hits
+// descending, target ascending) -- at most one per taxon when merging.  None of that needs the list in order:
+//   1. every location is counted in an LDS hash table keyed by (target, window) (64-bit CAS claims a slot, packed 16-bit counters);
+//   2. the lane that claimed a slot adds the counts of the windows w-1 .. w-(maxWindowsInRange-1) of its target: hits of the range
+//      that ENDS in w, begin = smallest window present (candidate_generation.hpp:47-108 evaluates exactly these ranges; the first
+//      one that reaches the maximum is the one with the smallest end window);
+//   3. every lane keeps its K best (range per target / taxon) under the total order (hits desc, target asc, window asc); K rounds of
+//      a wave-wide maximum pick the result, a picked target / taxon is struck from all lanes' lists.  The winner of a target under
+//      that order is its earliest best range, and the order among winners is the CPU's insertion order (ties keep arrival order =
+//      ascending target), so the result equals the sequential top-K insert (candidate_generation.hpp:172-231).
+// ================================================================================================
+__device__ __forceinline__ uint32_t hash_slot(uint64_t v)
+{
+    uint32_t h = (uint32_t)v * 0x9E3779B1u ^ (uint32_t)(v >> 32) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    return h >> 21;                                               // log2(kHashSlots) = 11 bits
+}
+
+template <bool TAX>
+__global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
+                                                         const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
+{
+    constexpr uint32_t kPer = kHashMax / 64, kRounds = kHashEnt / 64, kMask = kHashSlots - 1;
+    constexpr uint64_t kEmpty = ~0ull;
+    __shared__ uint64_t keyS[2][kHashSlots];
+    __shared__ uint32_t cntS[2][kHashSlots / 2];
+    __shared__ uint64_t entPayS[2][kHashEnt];
+    __shared__ uint32_t entOffS[2][kHashEnt + 2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t* keys = keyS[wave];
+    uint32_t* cnts = cntS[wave];
+    uint64_t* entPay = entPayS[wave];
+    uint32_t* entOff = entOffS[wave];
+    const uint32_t total = ws.midCount[3];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)3 * b.n;
+    const uint32_t nWaves = gridDim.x * 2;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    uint32_t esz[kRounds]; uint64_t epay[kRounds];
+    auto load_entries = [&](const uint4& rec) {
+#pragma unroll
+        for (uint32_t u = 0; u < kRounds; ++u) {
+            const uint32_t e = u * 64 + lane;
+            esz[u] = e < (rec.z & 0xFFFu) ? ws.psize[rec.y + e] : 0u;
+            epay[u] = e < (rec.z & 0xFFFu) ? ws.ppay[rec.y + e] : 0ull;
+        }
+    };
+    auto count_of = [&](uint32_t slot) -> uint32_t { return (cnts[slot >> 1] >> (16u * (slot & 1u))) & 0xFFFFu; };
+    const uint32_t w0 = blockIdx.x * 2 + wave;
+    uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
+    load_entries(rec);
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
+        // ---- empty table; entry table (payload, first list index) in LDS
+        {
+            uint4* k4 = reinterpret_cast<uint4*>(keys);
+            uint4* c4 = reinterpret_cast<uint4*>(cnts);
+#pragma unroll
+            for (uint32_t i = 0; i < kHashSlots / 2 / 64; ++i) k4[i * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+            for (uint32_t i = 0; i < kHashSlots / 8 / 64; ++i) c4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kRounds; ++u) {
+            const uint32_t e = u * 64 + lane;
+            if (e < nent) { entPay[e] = epay[u]; entOff[e] = esz[u] >> 16; }
+        }
+        if (lane == 0) { entOff[nent] = H; entOff[nent + 1] = 0xFFFFFFFFu; }
+        rec = recNext;                                             // the next query's record and entries are on their way meanwhile
+        recNext = load_rec(w + 2 * nWaves);
+        load_entries(rec);
+        wave_lds_sync();
+        // ---- 1. gather (lane: per consecutive list elements, as mid_cands_kernel) and count
+        const uint32_t per = (H + 63u) / 64u, i0 = lane * per;
+        uint64_t v[kPer];
+        {
+            uint32_t lo = 0, hi = nent;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (entOff[mid] <= i0) lo = mid; else hi = mid; }
+            uint32_t e = lo;
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; ++r) {
+                const uint32_t i = i0 + r;
+                v[r] = kEmpty;
+                if (r < per && i < H) {
+                    while (entOff[e + 1] <= i) ++e;
+                    const uint64_t pay = entPay[e];
+                    const uint32_t first = entOff[e];
+                    v[r] = entOff[e + 1] - first == 1 ? pay : tab.values[pay + (i - first)];
+                }
+            }
+        }
+        uint32_t info[kPer];                                       // slot | claimed << 31
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; ++r) {
+            info[r] = 0;
+            if (v[r] != kEmpty) {
+                uint32_t slot = hash_slot(v[r]);
+                bool claimed = false;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
+                    if (old == kEmpty) { claimed = true; break; }
+                    if (old == v[r]) break;
+                    slot = (slot + 1) & kMask;
+                }
+                atomicAdd(&cnts[slot >> 1], 1u << (16u * (slot & 1u)));
+                info[r] = slot | (claimed ? 0x80000000u : 0u);
+            }
+        }
+        wave_lds_sync();
+        // ---- 2. ranges that end in the windows this lane claimed; 3a. the lane's K best, one per target / taxon
+        uint32_t ptax[kPer];
+        if constexpr (TAX) {
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; ++r) ptax[r] = (info[r] >> 31) ? taxkey[(uint32_t)(keys[info[r] & kMask] >> 32) & tab.tgtMask] : 0u;
+        }
+        uint64_t lk[kLaneK];                                       // hits << 32 | ~target   (0 = unused)
+        uint32_t lw[kLaneK], lg[kLaneK], ld[kLaneK];               // end window, group (target / taxon), end - begin
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) { lk[i] = 0; lw[i] = 0; lg[i] = 0; ld[i] = 0; }
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; ++r) {
+            if (!(info[r] >> 31)) continue;
+            const uint32_t slot = info[r] & kMask;
+            const uint64_t key = keys[slot];
+            const uint32_t t = (uint32_t)(key >> 32), win = (uint32_t)key;
+            uint32_t T = count_of(slot), dmax = 0;
+            for (uint32_t d = 1; d < maxWin && d <= win; ++d) {
+                const uint64_t want = key - d;
+                uint32_t sl = hash_slot(want);
+                for (;;) {
+                    const uint64_t k = keys[sl];
+                    if (k == want) { T += count_of(sl); dmax = d; break; }
+                    if (k == kEmpty) break;
+                    sl = (sl + 1) & kMask;
+                }
+            }
+            uint32_t g = t;
+            if constexpr (TAX) { g = ptax[r]; if (g == 0) continue; }           // no taxon at that rank: skipped (candidate_generation.hpp:185)
+            const uint64_t ck = ((uint64_t)T << 32) | (uint32_t)~t;
+            // the group's entry, if listed, gives way to a better range of the group (else the new one is dropped) ...
+            bool drop = false;
+            uint32_t gone = kLaneK;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) {
+                const bool same = lk[i] != 0 && lg[i] == g;
+                if (same) { if (lk[i] > ck || (lk[i] == ck && lw[i] <= win)) drop = true; else gone = i; }
+            }
+            if (drop) continue;
+#pragma unroll
+            for (uint32_t i = 0; i + 1 < kLaneK; ++i)
+                if (i >= gone) { lk[i] = lk[i + 1]; lw[i] = lw[i + 1]; lg[i] = lg[i + 1]; ld[i] = ld[i + 1]; }
+            if (gone < kLaneK) lk[kLaneK - 1] = 0;
+            // ... then the range takes its place in the order (hits desc, target asc, window asc); what falls off the end is gone
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) pos += (lk[i] > ck || (lk[i] == ck && lw[i] < win)) ? 1u : 0u;
+#pragma unroll
+            for (uint32_t i = kLaneK - 1; i > 0; --i)
+                if (i > pos) { lk[i] = lk[i - 1]; lw[i] = lw[i - 1]; lg[i] = lg[i - 1]; ld[i] = ld[i - 1]; }
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) {
+                if (i == pos) { lk[i] = ck; lw[i] = win; lg[i] = g; ld[i] = dmax; }
+                if (i >= K) lk[i] = 0;
+            }
+        }
+        // ---- 3b. K rounds: the best head of all lanes; its group is struck everywhere
+        mc_candidate_dev* out = cands + (size_t)q * K;
+        uint32_t alive = 0xFu;
+        for (uint32_t rnd = 0; rnd < K; ++rnd) {
+            uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
+#pragma unroll
+            for (uint32_t i = kLaneK; i-- > 0;)
+                if (i < K && ((alive >> i) & 1u) && lk[i] != 0) { hk = lk[i]; hw = lw[i]; hg = lg[i]; hd = ld[i]; }
+            uint64_t m = hk;
+#pragma unroll
+            for (uint32_t off = 32; off > 0; off >>= 1) {
+                const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
+                m = o > m ? o : m;
+            }
+            mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+            if (m != 0) {
+                uint32_t wm = hk == m ? hw : 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t off = 32; off > 0; off >>= 1) wm = min(wm, __shfl_xor(wm, off));
+                const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
+                const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) if (lk[i] != 0 && lg[i] == g) alive &= ~(1u << i);
+                e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
+            }
+            if (lane == 0) out[rnd] = e;
+        }
+        if (lane == 0) ws.qflag[q] = kFlagDone;
+        wave_lds_sync();
+    }
+}
+
+void launch_hash_cands(const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 1) / 2);   // persistent; 3 blocks of 2 waves fit a CU (52 KB of LDS each)
+    if (taxkey) hipLaunchKernelGGL(hash_cands_kernel<true>, dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands);
+    else        hipLaunchKernelGGL(hash_cands_kernel<false>, dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands);
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }

@@ -285,6 +285,56 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad
     odb.close()
 
 
+@pytest.mark.parametrize("lowest,K", [(0, 1), (0, 2), (0, 4), (4, 2), (4, 3), (6, 4)])
+def test_long_lists_hash_cands_against_oracle(tmp_path, lowest, K):
+    """6 species x 20 strains (0.5 % divergence, 2 genera): a 150 bp read collects 150..600 locations, a pair up to ~900 -- the
+    lists hash_cands_kernel takes (one wave per query, (target, window) counts in an LDS hash table instead of a sort).  Near-identical
+    strains make ties in hits the rule, so the order among equals (ascending target, earliest window range) is what is tested;
+    sequence level, merged at species and at genus level, against the oracle."""
+    from metacache_amd import synth
+    rng = np.random.default_rng(991 + 10 * lowest + K)
+    genomes, parents = [], []
+    for sp in range(6):
+        base = synth.random_genome(rng, 30_000)
+        if sp % 2:                                   # a repeat inside the genome: several window ranges of one target compete
+            base[20_000:20_560] = base[2_240:2_800]
+        for st in range(20):
+            genomes.append(synth.mutate(rng, base, 0.005) if st else base)
+            parents.append(1000 + sp)
+    bld = api.Builder(target_id_bytes=4, max_candidates=K)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"S{i:04d}.1", parent_taxid=parents[i])
+    name = str(tmp_path / "manystrains")
+    bld.finish(load=False)
+    taxa = [(1, 1, 20, "root"), (500, 1, 6, "genus a"), (501, 1, 6, "genus b")] + [(1000 + i, 500 + i % 2, 4, f"sp{i}") for i in range(6)]
+    bld.write(name, taxa)
+    bld.free()
+    reads, _, _ = synth.sample_reads(rng, genomes, 4000, 150, 0.01, 0.002)
+    reads = [bytes(r) for r in reads]
+    mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:120] for r in reads[:1000]]
+    odb = cpuref.oracle().open(name)
+    db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 12, slot_max_chars=1 << 21)
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    pc, pcounts, _ = db.query(reads[:1000], mates, lowest=lowest, insert_max=400)
+    db.close()
+    assert 0.3 < np.mean((counts > 256) & (counts <= 1024)) and 0.5 < np.mean((pcounts > 256) & (pcounts <= 1024))
+
+    def check(got, i, a, b, ins):
+        _, e = odb.query(a, b, K, lowest, ins)
+        e = e[:K]
+        for j in range(K):
+            if j < len(e):
+                assert (got[i, j]["tgt"], got[i, j]["hits"], got[i, j]["beg"], got[i, j]["end"]) == \
+                       (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]), (i, j, got[i], e)
+            else:
+                assert got[i, j]["hits"] == 0, (i, j, got[i], e)
+    for i in range(len(reads)):
+        check(cands, i, reads[i], b"", 0)
+    for i in range(1000):
+        check(pc, i, reads[i], mates[i], 400)
+    odb.close()
+
+
 @pytest.mark.parametrize("quad", ["0", "1"])
 @pytest.mark.parametrize("lowest,K", [(0, 2), (4, 4)])
 def test_long_reads_chunk_lanes_against_oracle(golden, lowest, K, quad, monkeypatch):
