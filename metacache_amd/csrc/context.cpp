@@ -521,7 +521,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 32 + (size_t)4 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 32 + (size_t)5 * std::max<uint32_t>(n, 1) * 16))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -564,7 +564,8 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, P.bCands.p, st); }
-        { ScopedTimer t(ctx, "hash_cands", st); launch_hash_cands(b, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "hash_cands_512", st); launch_hash_cands(3, b, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }

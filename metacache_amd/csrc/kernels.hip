@@ -1061,7 +1061,7 @@ constexpr uint32_t kLaneHits = MC_LANE_HITS;  // longest location list handled b
 constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
 constexpr uint32_t kLaneU = 4;            // lookups in flight per lane
 constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
-constexpr uint32_t kHashMax = 1024, kHashSlots = 2048, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: list, table, entries, maxWindowsInRange
+constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: longest list, entries, maxWindowsInRange
 
 __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
 {
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
     const uint32_t total = rdlane(incl, 63);
     if (total) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ws.midCount[4], total);
+        if (lane == 0) base = atomicAdd(&ws.midCount[5], total);
         base = rdlane(base, 0);
         // the wave writes its records together (64 consecutive ones per round); record r belongs to the first lane with incl > r
         for (uint32_t r0 = 0; r0 < total; r0 += 64) {
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
 // one lane per chunk: the window sketches of its <= kChunkWins windows
 __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchParams sp, Workspace ws)
 {
-    const uint32_t total = ws.midCount[4];
+    const uint32_t total = ws.midCount[5];
     for (uint32_t id = blockIdx.x * 128 + threadIdx.x; id < total; id += gridDim.x * 128) {
         const uint2 rec = ws.chunkList[id];
         const uint32_t q = rec.x, c = rec.y;
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchPa
 template <bool QUAD>
 __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
 {
-    const uint32_t total = ws.midCount[4];
+    const uint32_t total = ws.midCount[5];
     for (uint32_t base = blockIdx.x * 128; base < total; base += gridDim.x * 128) {   // block-uniform: quads stay together
         const uint32_t id = base + threadIdx.x;
         uint2 rec = make_uint2(0, 0);
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
 // Compacting short lists here for mid_cands_kernel was measured too: what the wave kernel saves, the compaction costs.)
 __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace ws)
 {
-    const uint32_t total = ws.midCount[4];
+    const uint32_t total = ws.midCount[5];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + (threadIdx.x >> 6);
     for (uint32_t base = waveId * 64; base < total; base += nWaves * 64) {
@@ -1604,12 +1604,12 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
         // ... and of hash_cands_kernel (257 .. 1024 locations, one wave per query, no sort); longer ones, wide window ranges -> wave kernel
         const uint32_t mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : (H <= kHashMax && nent <= kHashEnt && mw <= kHashWin) ? 3u : 4u;
-        ws.qflag[q] = cls < 4 ? kFlagMid : kFlagCands;
-        if (cls == 3) ws.hitScan[q] = 0u;                        // no segment in HBM
+        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : (H <= kHashMax && nent <= kHashEnt && mw <= kHashWin) ? (H <= kHashMax / 2 ? 3u : 4u) : 5u;
+        ws.qflag[q] = cls < 5 ? kFlagMid : kFlagCands;
+        if (cls == 3 || cls == 4) ws.hitScan[q] = 0u;                        // no segment in HBM
         const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
+        for (uint32_t c = 0; c < 5; ++c) {
             const uint64_t mask = __ballot(cls == c);
             if (cls == c) {
                 const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
@@ -2032,31 +2032,35 @@ void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, 
 //      that order is its earliest best range, and the order among winners is the CPU's insertion order (ties keep arrival order =
 //      ascending target), so the result equals the sequential top-K insert (candidate_generation.hpp:172-231).
 // ================================================================================================
+template <uint32_t LOG2S>
 __device__ __forceinline__ uint32_t hash_slot(uint64_t v)
 {
     uint32_t h = (uint32_t)v * 0x9E3779B1u ^ (uint32_t)(v >> 32) * 0x85EBCA77u;
     h ^= h >> 15; h *= 0x2C1B3C6Du;
-    return h >> 21;                                               // log2(kHashSlots) = 11 bits
+    return h >> (32 - LOG2S);
 }
 
-template <bool TAX>
-__global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
-                                                         const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
+// LOG2S: log2 of the table slots; lists of up to 2^(LOG2S-1) locations (class 3: 512 in 1024 slots, 4 waves per block; class 4: 1024
+// in 2048 slots, 2 waves per block).  All LDS traffic of a phase is issued for the lane's elements together (the operations of
+// different elements are independent); only collisions fall back to a serial walk.
+template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
+__global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
+                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, uint32_t cls)
 {
-    constexpr uint32_t kPer = kHashMax / 64, kRounds = kHashEnt / 64, kMask = kHashSlots - 1;
+    constexpr uint32_t kSlots = 1u << LOG2S, kPer = kSlots / 2 / 64, kRounds = kHashEnt / 64, kMask = kSlots - 1;
     constexpr uint64_t kEmpty = ~0ull;
-    __shared__ uint64_t keyS[2][kHashSlots];
-    __shared__ uint32_t cntS[2][kHashSlots / 2];
-    __shared__ uint64_t entPayS[2][kHashEnt];
-    __shared__ uint32_t entOffS[2][kHashEnt + 2];
+    __shared__ uint64_t keyS[WAVES][kSlots];
+    __shared__ uint32_t cntS[WAVES][kSlots / 2];
+    __shared__ uint64_t entPayS[WAVES][kHashEnt];
+    __shared__ uint32_t entOffS[WAVES][kHashEnt + 2];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint64_t* keys = keyS[wave];
     uint32_t* cnts = cntS[wave];
     uint64_t* entPay = entPayS[wave];
     uint32_t* entOff = entOffS[wave];
-    const uint32_t total = ws.midCount[3];
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)3 * b.n;
-    const uint32_t nWaves = gridDim.x * 2;
+    const uint32_t total = ws.midCount[cls];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)cls * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
     uint32_t esz[kRounds]; uint64_t epay[kRounds];
     auto load_entries = [&](const uint4& rec) {
@@ -2068,7 +2072,7 @@ __global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTabl
         }
     };
     auto count_of = [&](uint32_t slot) -> uint32_t { return (cnts[slot >> 1] >> (16u * (slot & 1u))) & 0xFFFFu; };
-    const uint32_t w0 = blockIdx.x * 2 + wave;
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
     uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
     load_entries(rec);
     for (uint32_t w = w0; w < total; w += nWaves) {
@@ -2078,9 +2082,9 @@ __global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTabl
             uint4* k4 = reinterpret_cast<uint4*>(keys);
             uint4* c4 = reinterpret_cast<uint4*>(cnts);
 #pragma unroll
-            for (uint32_t i = 0; i < kHashSlots / 2 / 64; ++i) k4[i * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t i = 0; i < kSlots / 2 / 64; ++i) k4[i * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
-            for (uint32_t i = 0; i < kHashSlots / 8 / 64; ++i) c4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = 0; i < kSlots / 8 / 64; ++i) c4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (uint32_t u = 0; u < kRounds; ++u) {
@@ -2092,7 +2096,8 @@ __global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTabl
         recNext = load_rec(w + 2 * nWaves);
         load_entries(rec);
         wave_lds_sync();
-        // ---- 1. gather (lane: per consecutive list elements, as mid_cands_kernel) and count
+        // ---- 1. gather (lane: per consecutive list elements, one search, then a walk -- as mid_cands_kernel; handing element i to
+        //      lane i % 64 makes a wave's loads coalesce, but costs a search per element and was not faster) and count
         const uint32_t per = (H + 63u) / 64u, i0 = lane * per;
         uint64_t v[kPer];
         {
@@ -2111,88 +2116,87 @@ __global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTabl
                 }
             }
         }
-        uint32_t info[kPer];                                       // slot | claimed << 31
+        uint32_t slot[kPer];                                       // slot | claimed << 31
+        {
+            unsigned long long old[kPer];
+            bool coll = false;
 #pragma unroll
-        for (uint32_t r = 0; r < kPer; ++r) {
-            info[r] = 0;
-            if (v[r] != kEmpty) {
-                uint32_t slot = hash_slot(v[r]);
-                bool claimed = false;
-                for (;;) {
-                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
-                    if (old == kEmpty) { claimed = true; break; }
-                    if (old == v[r]) break;
-                    slot = (slot + 1) & kMask;
+            for (uint32_t r = 0; r < kPer; ++r) {
+                slot[r] = hash_slot<LOG2S>(v[r]);
+                old[r] = v[r] != kEmpty ? atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot[r]]), (unsigned long long)kEmpty, (unsigned long long)v[r]) : v[r];
+                coll = coll || (old[r] != kEmpty && old[r] != v[r]);
+            }
+            if (__ballot(coll)) {                                  // somebody else's key in the home slot: next slots, one at a time
+#pragma unroll
+                for (uint32_t r = 0; r < kPer; ++r) {
+                    if (old[r] != kEmpty && old[r] != v[r]) {
+                        uint32_t sl = slot[r];
+                        for (;;) {
+                            sl = (sl + 1) & kMask;
+                            old[r] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
+                            if (old[r] == kEmpty || old[r] == v[r]) break;
+                        }
+                        slot[r] = sl;
+                    }
                 }
-                atomicAdd(&cnts[slot >> 1], 1u << (16u * (slot & 1u)));
-                info[r] = slot | (claimed ? 0x80000000u : 0u);
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; ++r) {
+                if (v[r] != kEmpty) atomicAdd(&cnts[slot[r] >> 1], 1u << (16u * (slot[r] & 1u)));
+                slot[r] |= (v[r] != kEmpty && old[r] == kEmpty) ? 0x80000000u : 0u;
             }
         }
         wave_lds_sync();
-        // ---- 2. ranges that end in the windows this lane claimed; 3a. the lane's K best, one per target / taxon
+        // ---- 2. ranges that end in the windows this lane claimed: hits | (end - begin) << 16
         uint32_t ptax[kPer];
         if constexpr (TAX) {
 #pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) ptax[r] = (info[r] >> 31) ? taxkey[(uint32_t)(keys[info[r] & kMask] >> 32) & tab.tgtMask] : 0u;
+            for (uint32_t r = 0; r < kPer; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[(uint32_t)(v[r] >> 32) & tab.tgtMask] : 0u;
         }
-        uint64_t lk[kLaneK];                                       // hits << 32 | ~target   (0 = unused)
-        uint32_t lw[kLaneK], lg[kLaneK], ld[kLaneK];               // end window, group (target / taxon), end - begin
+        uint32_t T[kPer];
 #pragma unroll
-        for (uint32_t i = 0; i < kLaneK; ++i) { lk[i] = 0; lw[i] = 0; lg[i] = 0; ld[i] = 0; }
+        for (uint32_t r = 0; r < kPer; ++r) T[r] = (slot[r] >> 31) ? count_of(slot[r] & kMask) : 0u;
+        for (uint32_t d = 1; d < maxWin; ++d) {
+            uint64_t k[kPer]; uint32_t sl[kPer];
+            bool chain = false;
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; ++r) {
+                sl[r] = hash_slot<LOG2S>(v[r] - d);
+                k[r] = keys[sl[r]];
+                const bool live = (slot[r] >> 31) && (uint32_t)v[r] >= d;
+                if (!live) { k[r] = kEmpty; sl[r] = 0xFFFFFFFFu; }   // (target 0, window < d: v - d would equal the empty key)
+                chain = chain || (live && k[r] != v[r] - d && k[r] != kEmpty);
+            }
+            if (__ballot(chain)) {
+#pragma unroll
+                for (uint32_t r = 0; r < kPer; ++r)
+                    while (sl[r] != 0xFFFFFFFFu && k[r] != v[r] - d && k[r] != kEmpty) { sl[r] = (sl[r] + 1) & kMask; k[r] = keys[sl[r]]; }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; ++r) {
+                const uint32_t c = count_of(sl[r] & kMask);
+                if (sl[r] != 0xFFFFFFFFu && k[r] == v[r] - d) T[r] = ((T[r] & 0xFFFFu) + c) | (d << 16);
+            }
+        }
+        // ---- 3. K rounds: every lane offers the best of its ranges whose target / taxon has not been picked yet, the wave takes the
+        //      maximum under (hits desc, target asc, window asc) and strikes that target / taxon everywhere
+        uint32_t live = 0;                                         // bit r: this lane's range r is still in the race
 #pragma unroll
         for (uint32_t r = 0; r < kPer; ++r) {
-            if (!(info[r] >> 31)) continue;
-            const uint32_t slot = info[r] & kMask;
-            const uint64_t key = keys[slot];
-            const uint32_t t = (uint32_t)(key >> 32), win = (uint32_t)key;
-            uint32_t T = count_of(slot), dmax = 0;
-            for (uint32_t d = 1; d < maxWin && d <= win; ++d) {
-                const uint64_t want = key - d;
-                uint32_t sl = hash_slot(want);
-                for (;;) {
-                    const uint64_t k = keys[sl];
-                    if (k == want) { T += count_of(sl); dmax = d; break; }
-                    if (k == kEmpty) break;
-                    sl = (sl + 1) & kMask;
-                }
-            }
-            uint32_t g = t;
-            if constexpr (TAX) { g = ptax[r]; if (g == 0) continue; }           // no taxon at that rank: skipped (candidate_generation.hpp:185)
-            const uint64_t ck = ((uint64_t)T << 32) | (uint32_t)~t;
-            // the group's entry, if listed, gives way to a better range of the group (else the new one is dropped) ...
-            bool drop = false;
-            uint32_t gone = kLaneK;
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) {
-                const bool same = lk[i] != 0 && lg[i] == g;
-                if (same) { if (lk[i] > ck || (lk[i] == ck && lw[i] <= win)) drop = true; else gone = i; }
-            }
-            if (drop) continue;
-#pragma unroll
-            for (uint32_t i = 0; i + 1 < kLaneK; ++i)
-                if (i >= gone) { lk[i] = lk[i + 1]; lw[i] = lw[i + 1]; lg[i] = lg[i + 1]; ld[i] = ld[i + 1]; }
-            if (gone < kLaneK) lk[kLaneK - 1] = 0;
-            // ... then the range takes its place in the order (hits desc, target asc, window asc); what falls off the end is gone
-            uint32_t pos = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) pos += (lk[i] > ck || (lk[i] == ck && lw[i] < win)) ? 1u : 0u;
-#pragma unroll
-            for (uint32_t i = kLaneK - 1; i > 0; --i)
-                if (i > pos) { lk[i] = lk[i - 1]; lw[i] = lw[i - 1]; lg[i] = lg[i - 1]; ld[i] = ld[i - 1]; }
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) {
-                if (i == pos) { lk[i] = ck; lw[i] = win; lg[i] = g; ld[i] = dmax; }
-                if (i >= K) lk[i] = 0;
-            }
+            bool ok = (slot[r] >> 31) != 0;
+            if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
+            live |= ok ? (1u << r) : 0u;
         }
-        // ---- 3b. K rounds: the best head of all lanes; its group is struck everywhere
         mc_candidate_dev* out = cands + (size_t)q * K;
-        uint32_t alive = 0xFu;
         for (uint32_t rnd = 0; rnd < K; ++rnd) {
             uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
 #pragma unroll
-            for (uint32_t i = kLaneK; i-- > 0;)
-                if (i < K && ((alive >> i) & 1u) && lk[i] != 0) { hk = lk[i]; hw = lw[i]; hg = lg[i]; hd = ld[i]; }
+            for (uint32_t r = 0; r < kPer; ++r) {
+                const uint32_t t = (uint32_t)(v[r] >> 32), win = (uint32_t)v[r];
+                const uint64_t ck = ((uint64_t)(T[r] & 0xFFFFu) << 32) | (uint32_t)~t;
+                const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
+                if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
+            }
             uint64_t m = hk;
 #pragma unroll
             for (uint32_t off = 32; off > 0; off >>= 1) {
@@ -2207,7 +2211,11 @@ __global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTabl
                 const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
                 const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
 #pragma unroll
-                for (uint32_t i = 0; i < kLaneK; ++i) if (lk[i] != 0 && lg[i] == g) alive &= ~(1u << i);
+                for (uint32_t r = 0; r < kPer; ++r) {
+                    uint32_t gr;
+                    if constexpr (TAX) gr = ptax[r]; else gr = (uint32_t)(v[r] >> 32);
+                    if (gr == g) live &= ~(1u << r);
+                }
                 e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
             }
             if (lane == 0) out[rnd] = e;
@@ -2217,12 +2225,20 @@ __global__ __launch_bounds__(128) void hash_cands_kernel(BatchView b, DeviceTabl
     }
 }
 
-void launch_hash_cands(const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st)
+void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands,
+                       hipStream_t st)
 {
     if (b.n == 0) return;
-    const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 1) / 2);   // persistent; 3 blocks of 2 waves fit a CU (52 KB of LDS each)
-    if (taxkey) hipLaunchKernelGGL(hash_cands_kernel<true>, dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands);
-    else        hipLaunchKernelGGL(hash_cands_kernel<false>, dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands);
+    // persistent grids; 3 blocks fit a CU either way (52 / 50 KB of LDS)
+    if (cls == 3) {
+        const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 3) / 4);
+        if (taxkey) hipLaunchKernelGGL((hash_cands_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+        else        hipLaunchKernelGGL((hash_cands_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+    } else {
+        const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 1) / 2);
+        if (taxkey) hipLaunchKernelGGL((hash_cands_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+        else        hipLaunchKernelGGL((hash_cands_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+    }
 }
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }
