@@ -237,10 +237,11 @@ uint32_t classify(const Options& o, const Taxonomy& tx, const std::vector<Cand>&
     if (cand[0].hits < (uint32_t)o.hitsMin) return 0;
     uint32_t lca = cand[0].tax;
     const float threshold = cand[0].hits > (uint32_t)o.hitsMin ? (cand[0].hits - o.hitsMin) * o.hitsDiff : 0;
-    const Lineage top = tx.target_ranks(cand[0].tgt);
+    auto ranks = [&](const Cand& c) { return c.tgt < tx.numTargets ? tx.target_ranks(c.tgt) : tx.ranks_of(c.tax); };   // classification.cpp:166-176
+    const Lineage top = ranks(cand[0]);
     for (size_t i = 1; i < cand.size() && cand[i].hits > 0; ++i) {
         if (cand[i].hits > threshold) {
-            const Lineage cr = tx.target_ranks(cand[i].tgt);
+            const Lineage cr = ranks(cand[i]);
             const int from = tx.taxon(lca)->rank;
             uint32_t l = 0;
             for (int r = from; r <= kNumRanks - 1; ++r) if (top[r] && top[r] == cr[r]) { l = top[r]; break; }   // ranked_lca
@@ -328,10 +329,13 @@ struct Session {
 };
 
 // process_input_files (querying.cpp:40-128): parameters, table layout, mappings of all given files, summary -> one output
+// merge mode (mode_merge.cpp): the candidates come from result files instead of the database
+struct MergedInput { std::vector<std::string> files, headers; std::vector<std::vector<Cand>> cands; };
+
 void run_job(Session& S, Options o, const std::vector<std::string>& infiles, const std::string& outfile, const std::string& targetsFile,
-             const std::string& abundanceFile)
+             const std::string& abundanceFile, const MergedInput* merged = nullptr)
 {
-        S.open(o);
+        if (!merged) S.open(o);
         mc_ctx* ctx = S.ctx;
         const Taxonomy& tx = S.tx;
         const mc_config& cfg = S.cfg;
@@ -370,6 +374,10 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             if (o.abundances) os << o.comment << "A list of absolute and relative abundances per taxon will be generated after the read mapping.\n";
             if (o.abundancePer != kNumRanks) os << o.comment << "A list of absolute and relative abundances for each '" << kRankNames[o.abundancePer] << "' will be generated after the read mapping.\n";
             os << o.comment << "Using " << threads << " threads\n";
+        }
+        if (merged) {                                                            // merge_result_files, mode_merge.cpp:266-269
+            os << o.comment << "Merging " << merged->files.size() << " files:\n";
+            for (const auto& f : merged->files) os << o.comment << f << '\n';
         }
         if (o.mapView != Options::mv_none) {                                     // show_query_mapping_header, classification.cpp:432-460
             os << o.comment << "TABLE_LAYOUT: ";
@@ -467,6 +475,70 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         const double tIndexed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::atomic<uint64_t> nsParse{0}, nsSubmit{0}, nsWait{0}, nsClassify{0};
         auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        // one query: classification, statistics, mapping line (classify_and_evaluate, classification.cpp:470-559)
+        struct Acc {
+            uint64_t mine[kNumRanks + 1] = {}, known[kNumRanks + 1] = {}, correct[kNumRanks + 1] = {}, wrong[kNumRanks + 1] = {}, falsePos[kNumRanks + 1] = {}, covDomain = 0;
+            std::map<uint32_t, double> counts;
+            std::vector<Cover> covers;
+        };
+        auto emit = [&](Acc& A, std::ostream& out, uint64_t id, View header, const std::vector<Cand>& cands, const mc_location* hits, uint64_t nhits) {
+            bool isTarget; uint32_t tgt;
+            const uint32_t best = classify(o, tx, cands, isTarget, tgt);
+            const int bestRank = best ? tx.taxon(best)->rank : kNumRanks;
+            ++A.mine[bestRank];
+            uint32_t truth = 0;
+            if (o.determineGroundTruth) truth = ground_truth(tx, std::string(header.p, header.n));
+            if (o.precision) {                                       // evaluate_classification, classification.cpp:272-295
+                const int knownRank = truth ? tx.taxon(truth)->rank : kNumRanks;
+                int correctRank = kNumRanks;                         // rank of the ranked LCA of mapping and truth
+                if (best && truth) {
+                    const Lineage la = tx.ranks_of(best), lb = tx.ranks_of(truth);
+                    for (int r = 0; r < kNumRanks; ++r) if (la[r] && la[r] == lb[r]) { correctRank = tx.taxon(la[r])->rank; break; }
+                }
+                // assign_known_correct (classification_statistics.hpp:86-106)
+                if (correctRank < bestRank) correctRank = bestRank;
+                if (correctRank < knownRank) correctRank = knownRank;
+                ++A.known[knownRank];
+                if (knownRank != kNumRanks) {
+                    ++A.correct[correctRank];
+                    if (correctRank > knownRank && correctRank > bestRank) ++A.wrong[correctRank - 1];
+                }
+                if (o.taxonCoverage && truth) {                       // update_coverage_statistics, classification.cpp:242-265
+                    for (uint32_t t : tx.ranks_of(truth)) {
+                        if (!t) continue;
+                        const int r = tx.taxon(t)->rank;
+                        const bool classifiedOnRank = best && r >= bestRank;
+                        if (!tx.covers(t) && classifiedOnRank) ++A.falsePos[r];
+                        if (r == 19) ++A.covDomain;
+                    }
+                }
+            }
+            if (taxCountsWanted && best) ++A.counts[best];           // classify_and_evaluate, classification.cpp:552-554
+            if (o.hitsPerRef)                                        // matches_per_target::insert (matches_per_target.hpp:100-110)
+                for (const Cand& c : cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) A.covers.push_back(Cover{c.tgt, id, c.beg, c.end, c.hits});
+            if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) return;
+            if (o.queryIds) out << id << o.column;
+            const void* sp = memchr(header.p, ' ', header.n);
+            out.write(header.p, sp ? (const char*)sp - header.p : (std::streamsize)header.n);
+            out << o.column;
+            if (o.showGroundTruth) { show_taxon(out, o, tx, truth, false, 0); out << o.column; }
+            if (o.allhits) { if (hits) show_matches(out, o, tx, hits, nhits); out << o.column; }
+            if (o.tophits) { show_candidates(out, o, tx, cands); out << o.column; }
+            if (o.locations) {                                       // show_candidate_ranges, printing.cpp:370-380
+                for (const Cand& c : cands) out << '[' << (uint64_t)dbStride * c.beg << ',' << (uint64_t)dbStride * c.end + S.dbWinlen << "] ";
+                out << o.column;
+            }
+            show_taxon(out, o, tx, best, isTarget, tgt);
+            out << '\n';
+        };
+        auto collect = [&](const Acc& A) {
+            for (int r = 0; r <= kNumRanks; ++r) {
+                assigned[r] += A.mine[r]; known[r] += A.known[r]; correct[r] += A.correct[r]; wrong[r] += A.wrong[r]; covFalsePos[r] += A.falsePos[r];
+            }
+            covTotalDomain += A.covDomain;
+            for (const auto& kv : A.counts) bestCounts[kv.first] += kv.second;
+            covers.insert(covers.end(), A.covers.begin(), A.covers.end());
+        };
         // ---- workers: one batch slot each; output delivered in batch order -------------------------------------------------
         std::atomic<size_t> nextBatch{0};
         std::mutex outMtx, errMtx;
@@ -486,10 +558,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::vector<Cand> cands;
             std::string scratch1, scratch2;
             std::ostringstream out;
-            uint64_t mine[kNumRanks + 1] = {}, myKnown[kNumRanks + 1] = {}, myCorrect[kNumRanks + 1] = {}, myWrong[kNumRanks + 1] = {};
-            uint64_t myFalsePos[kNumRanks + 1] = {}, myCovDomain = 0;
-            std::map<uint32_t, double> myCounts;
-            std::vector<Cover> myCovers;
+            Acc A;
             auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = m; };
             for (size_t b; !failed && (b = nextBatch++) < batches.size();) {
                 const Batch& B = batches[b];
@@ -543,54 +612,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                             }
                             cands.push_back(x);
                         }
-                        bool isTarget; uint32_t tgt;
-                        const uint32_t best = classify(o, tx, cands, isTarget, tgt);
-                        const int bestRank = best ? tx.taxon(best)->rank : kNumRanks;
-                        ++mine[bestRank];
-                        uint32_t truth = 0;
-                        if (o.determineGroundTruth) truth = ground_truth(tx, std::string(m.header.p, m.header.n));
-                        if (o.precision) {                                       // evaluate_classification, classification.cpp:272-295
-                            const int knownRank = truth ? tx.taxon(truth)->rank : kNumRanks;
-                            int correctRank = kNumRanks;                         // rank of the ranked LCA of mapping and truth
-                            if (best && truth) {
-                                const Lineage la = tx.ranks_of(best), lb = tx.ranks_of(truth);
-                                for (int r = 0; r < kNumRanks; ++r) if (la[r] && la[r] == lb[r]) { correctRank = tx.taxon(la[r])->rank; break; }
-                            }
-                            // assign_known_correct (classification_statistics.hpp:86-106)
-                            if (correctRank < bestRank) correctRank = bestRank;
-                            if (correctRank < knownRank) correctRank = knownRank;
-                            ++myKnown[knownRank];
-                            if (knownRank != kNumRanks) {
-                                ++myCorrect[correctRank];
-                                if (correctRank > knownRank && correctRank > bestRank) ++myWrong[correctRank - 1];
-                            }
-                            if (o.taxonCoverage && truth) {                       // update_coverage_statistics, classification.cpp:242-265
-                                for (uint32_t t : tx.ranks_of(truth)) {
-                                    if (!t) continue;
-                                    const int r = tx.taxon(t)->rank;
-                                    const bool classifiedOnRank = best && r >= bestRank;
-                                    if (!tx.covers(t) && classifiedOnRank) ++myFalsePos[r];
-                                    if (r == 19) ++myCovDomain;
-                                }
-                            }
-                        }
-                        if (taxCountsWanted && best) ++myCounts[best];           // classify_and_evaluate, classification.cpp:552-554
-                        if (o.hitsPerRef)                                        // matches_per_target::insert (matches_per_target.hpp:100-110)
-                            for (const Cand& c : cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) myCovers.push_back(Cover{c.tgt, m.id, c.beg, c.end, c.hits});
-                        if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) continue;
-                        if (o.queryIds) out << m.id << o.column;
-                        const void* sp = memchr(m.header.p, ' ', m.header.n);
-                        out.write(m.header.p, sp ? (const char*)sp - m.header.p : (std::streamsize)m.header.n);
-                        out << o.column;
-                        if (o.showGroundTruth) { show_taxon(out, o, tx, truth, false, 0); out << o.column; }
-                        if (o.allhits) { show_matches(out, o, tx, r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i]); out << o.column; }
-                        if (o.tophits) { show_candidates(out, o, tx, cands); out << o.column; }
-                        if (o.locations) {                                       // show_candidate_ranges, printing.cpp:370-380
-                            for (const Cand& c : cands) out << '[' << (uint64_t)dbStride * c.beg << ',' << (uint64_t)dbStride * c.end + S.dbWinlen << "] ";
-                            out << o.column;
-                        }
-                        show_taxon(out, o, tx, best, isTarget, tgt);
-                        out << '\n';
+                        emit(A, out, m.id, m.header, cands, o.allhits ? r.hits + r.hit_offsets[i] : nullptr, o.allhits ? r.hit_offsets[i + 1] - r.hit_offsets[i] : 0);
                     }
                     mc_batch_clear(ctx, slot);
                     if (profile) { nsParse += tp1 - tp0; nsSubmit += tp2 - tp1; nsWait += tp3 - tp2; nsClassify += now_ns() - tp3; }
@@ -598,12 +620,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 deliver(b, out.str());
             }
             std::lock_guard<std::mutex> l(errMtx);
-            for (int r = 0; r <= kNumRanks; ++r) {
-                assigned[r] += mine[r]; known[r] += myKnown[r]; correct[r] += myCorrect[r]; wrong[r] += myWrong[r]; covFalsePos[r] += myFalsePos[r];
-            }
-            covTotalDomain += myCovDomain;
-            for (const auto& kv : myCounts) bestCounts[kv.first] += kv.second;
-            covers.insert(covers.end(), myCovers.begin(), myCovers.end());
+            collect(A);
         };
         {
             std::vector<std::thread> pool;
@@ -612,6 +629,16 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (auto& t : pool) t.join();
         }
         if (failed) throw std::runtime_error(firstError);
+        if (merged) {                                                            // map_candidates_to_targets, classification.cpp:891-911
+            Acc A;
+            std::ostringstream out;
+            for (size_t i = 0; i < merged->headers.size(); ++i) {
+                const std::string& h = merged->headers[i];
+                emit(A, out, i + 1, View{h.data(), h.size()}, merged->cands[i], nullptr, 0);
+            }
+            os << out.str();
+            collect(A);
+        }
         if (profile)
             std::cerr << "mcq profile: index " << tIndexed * 1e3 << " ms, total " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3
                       << " ms; summed over " << workers << " workers: parse+add " << nsParse / 1e6 << " ms, submit " << nsSubmit / 1e6 << " ms, wait "
@@ -756,6 +783,167 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         }
 }
 
+// ---- merge mode (mode_merge.cpp): result files of queries against single database parts -> one classification ------------------
+// get_results_file_properties (mode_merge.cpp:79-150): no sequence-level results, the column of the top hits, number of result lines
+struct ResultsSource { std::string filename; size_t firstLine = 0, numQueries = 0; int tophitsColumn = 0; std::vector<std::string> lines; };
+
+ResultsSource results_file_properties(const std::string& filename)
+{
+    ResultsSource res;
+    res.filename = filename;
+    std::ifstream is(filename);
+    if (!is.good()) throw std::runtime_error("could not open file " + filename);
+    for (std::string l; std::getline(is, l);) res.lines.push_back(std::move(l));
+    size_t i = 0;
+    for (;; ++i) {
+        if (i >= res.lines.size() || res.lines[i].empty() || res.lines[i][0] != '#') throw std::runtime_error("classificaion ranks not found in file " + filename);
+        if (res.lines[i].compare(0, 16, "# Classification") == 0) {
+            if (res.lines[i].find("sequence") != std::string::npos) throw std::runtime_error("cannot merge results on sequence level");
+            break;
+        }
+    }
+    for (++i;; ++i) {
+        if (i >= res.lines.size() || res.lines[i].empty() || res.lines[i][0] != '#') throw std::runtime_error("TABLE_LAYOUT not found in file " + filename);
+        if (res.lines[i].compare(0, 15, "# TABLE_LAYOUT:") == 0) {
+            std::istringstream ls(res.lines[i].substr(15));
+            std::string column;
+            ls >> column;
+            if (column != "query_id") throw std::runtime_error("no query_id in file " + filename);
+            int col = 0;
+            while (ls.good()) {
+                ls.ignore(std::numeric_limits<std::streamsize>::max(), '|');
+                ls >> column;
+                ++col;
+                if (column == "top_hits") { res.tophitsColumn = col; break; }
+            }
+            break;
+        }
+    }
+    if (res.tophitsColumn < 1) throw std::runtime_error("no top_hits in file " + filename);
+    for (++i; i < res.lines.size() && !res.lines[i].empty() && res.lines[i][0] == '#'; ++i) {}
+    res.firstLine = i;
+    for (; i < res.lines.size(); ++i) if (res.lines[i].empty() || res.lines[i][0] != '#') ++res.numQueries;
+    return res;
+}
+
+// best_distinct_matches_in_contiguous_window_ranges::insert for a candidate that names its taxon (candidate_generation.hpp:172-231)
+void insert_taxon_candidate(std::vector<Cand>& top, Cand c, int mergeBelow, size_t maxCand)
+{
+    if (top.size() == maxCand && top.back().hits >= c.hits) return;
+    if (!c.tax) return;
+    auto upper = [&] { size_t j = 0; while (j < top.size() && top[j].hits >= c.hits) ++j; return j; };   // upper_bound, hits descending
+    auto place = [&] {
+        const size_t j = upper();
+        if (j != top.size() || top.size() < maxCand) { top.insert(top.begin() + j, c); if (top.size() > maxCand) top.resize(maxCand); }
+    };
+    if (mergeBelow == 0) { place(); return; }
+    size_t i = 0;
+    while (i < top.size() && top[i].tax != c.tax) ++i;
+    if (i == top.size()) { place(); return; }
+    if (c.hits > top[i].hits) {
+        top[i] = c;
+        for (size_t j = i; j > 0 && top[j].hits > top[j - 1].hits; --j) std::swap(top[j], top[j - 1]);   // std::sort on <= 16 elements: insertion sort
+    }
+}
+
+// read_results (mode_merge.cpp:158-244)
+void read_results(const ResultsSource& res, const Taxonomy& tx, int mergeBelow, size_t maxCand, MergedInput& M, bool info)
+{
+    // "preallocate" (mode_merge.cpp:172-174) is a plain resize to this file's number of result lines: when ids have gaps (skipped
+    // reads) the lists of the highest ids collected from earlier files are cut off here and start again -- kept as the reference has it
+    M.cands.resize(res.numQueries); M.headers.resize(res.numQueries);
+    for (size_t li = res.firstLine; li < res.lines.size(); ++li) {
+        const std::string& l = res.lines[li];
+        if (l.empty() || l[0] == '#') continue;
+        const char* p = l.c_str();
+        char* end = nullptr;
+        size_t queryId = (size_t)std::strtoull(p, &end, 10);
+        p = end;
+        if (queryId > 0) --queryId;
+        if (queryId + 1 > M.cands.size()) { M.cands.resize(queryId + 1); M.headers.resize(queryId + 1); }
+        auto forward = [&](char c) { const char* q = std::strchr(p, c); p = q ? q + 1 : l.c_str() + l.size(); };
+        forward('|');
+        if (M.headers[queryId].empty()) {
+            const char* a = p;
+            while (*a && std::isspace((unsigned char)*a)) ++a;
+            const char* b = a;
+            while (*b && !std::isspace((unsigned char)*b)) ++b;
+            if (b > a) M.headers[queryId].assign(a, b);
+        }
+        for (int i = 1; i < res.tophitsColumn; ++i) forward('|');
+        forward('\t');
+        while (*p && *p != '\t') {
+            int64_t taxid = std::strtoll(p, &end, 10);
+            if (end == p) { taxid = 0; if (info) std::cerr << "Query " << queryId + 1 << ": Could not read taxid.\n"; }
+            p = end;
+            forward(':');
+            const uint32_t hits = (uint32_t)std::strtoul(p, &end, 10);
+            p = end;
+            const uint32_t t = tx.with_id(taxid);
+            if (t) insert_taxon_candidate(M.cands[queryId], Cand{0xFFFFFFFFu, hits, 0, 0, t}, mergeBelow, maxCand);
+            else if (info) std::cerr << "Query " << queryId + 1 << ": taxid " << taxid << " not found. Skipping hit.\n";
+            if (!*p) break;
+            if (*p == '\t') break;                                              // end of the top hits
+            ++p;                                                                // ',' between them
+        }
+    }
+}
+
+int merge_main(const std::vector<std::string>& args)
+{
+    // get_merge_options (options.cpp:1776-1887)
+    std::vector<std::string> qargs;
+    std::vector<std::string> none;
+    std::string taxPath;
+    int info = 1;
+    for (size_t i = 0; i < args.size(); ++i) {
+        if (args[i] == "-taxonomy") { if (i + 1 >= args.size()) throw std::runtime_error("Taxonomy path missing after '-taxonomy'"); taxPath = args[++i]; }
+        else if (args[i] == "-silent") info = 0;
+        else if (args[i] == "-verbose") info = 2;
+        else qargs.push_back(args[i]);
+    }
+    if (taxPath.empty()) throw std::runtime_error("Taxonomy path missing. Use '-taxonomy <path>'");
+    Options o;
+    o = parse(qargs, o);
+    if (o.infiles.empty()) throw std::runtime_error("No query output filenames provided");
+    std::sort(o.infiles.begin(), o.infiles.end());
+    if (o.hitsMin == 0) o.hitsMin = 5;
+    if (o.lowest < 4) o.lowest = 4;                                             // species
+    if (o.infiles.size() < 2) throw std::runtime_error("At least two files are needed for merging");
+    // main_mode_merge (mode_merge.cpp:401-432): a database without targets, taxa from the dumps
+    BuildOptions bo;
+    bo.taxPath = taxPath;
+    if (bo.taxPath.back() != '/') bo.taxPath += '/';
+    bo.info = info == 0 ? BuildOptions::silent : BuildOptions::moderate;
+    Session S;
+    {
+        std::ostringstream quiet;                                               // the dump reader reports on stdout
+        std::streambuf* old = std::cout.rdbuf(quiet.rdbuf());
+        TaxTree t = read_taxonomy_dumps(bo);
+        std::cout.rdbuf(old);
+        if (info) std::cout << quiet.str();
+        S.tx.taxa = std::move(t.taxa);
+    }
+    for (size_t i = 0; i < S.tx.taxa.size(); ++i) S.tx.byId.emplace(S.tx.taxa[i].id, (uint32_t)i);
+    S.tx.build_covered();
+    if (info) std::cerr << "Applied taxonomy to database.\n";
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    S.threads = o.threads > 0 ? (unsigned)o.threads : hw;
+    S.workers = 1;
+    if (info) std::cerr << "Merging result files.\n";
+    bool anyReadable = false;
+    for (const auto& f : o.infiles) { std::ifstream is(f); anyReadable = anyReadable || is.good(); }
+    if (!anyReadable) throw std::runtime_error("None of the query sequence files could be opened");
+    if (!o.outfile.empty() && info) std::cout << "Per-Read mappings will be written to file: " << o.outfile << std::endl;
+    MergedInput M;
+    M.files = o.infiles;
+    const size_t maxCand = o.maxCand > 0 ? (size_t)o.maxCand : 2;               // merge_result_files, mode_merge.cpp:254-258
+    for (const auto& f : o.infiles) read_results(results_file_properties(f), S.tx, o.lowest, maxCand, M, info != 0);
+    if (info) std::cerr << "Completed merge. Starting classification.\n";
+    run_job(S, o, {}, o.outfile, "", o.abundanceFile, &M);
+    return 0;
+}
+
 // query mode proper / the query half of build+query: files of the command line, or the interactive loop
 int query_main(Session& S, const Options& init)
 {
@@ -814,6 +1002,7 @@ int main(int argc, char** argv)
             Session S;
             return query_main(S, init);
         }
+        if (mode == "merge") return merge_main(args);
         if (mode == "build") {                                                  // main_mode_build, mode_build.cpp:93-106, :41-66
             using clock = std::chrono::steady_clock;
             std::vector<std::string> none;
@@ -851,7 +1040,7 @@ int main(int argc, char** argv)
             if (bo.saveDb) db.write();
             return rc;
         }
-        throw std::runtime_error("usage: mcq query|build|build+query ... (see the header of mcq_main.cpp / mcq_build.h)");
+        throw std::runtime_error("usage: mcq query|build|build+query|merge ... (see the header of mcq_main.cpp / mcq_build.h)");
     } catch (std::exception& e) {
         std::cerr << "ABORT: " << e.what() << "!" << std::endl;                  // main.cpp:65-68
         return 1;
