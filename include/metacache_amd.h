@@ -228,7 +228,8 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8]);
  * max_locations_per_feature locations in (target, window) order (host_hashmap.hpp:593-605), and
  * database::write (database.cpp:247-325) for the file format.  cfg fields used: device, kmerlen,
  * sketchlen, winlen, winstride, target_id_bytes, max_locations_per_feature (0 => 254), remove_overpopulated (!= 0 => features
- * that reached the limit are dropped from the files and the table: -remove-overpopulated-features, building.cpp:516-534). */
+ * that reached the limit are dropped from the files and the table: -remove-overpopulated-features, building.cpp:516-534),
+ * key_shard_index / key_shard_count (> 1: only this shard's features are kept; see mc_build_finish_shards). */
 typedef struct mc_builder mc_builder;
 typedef struct {
     int64_t  id;
@@ -250,6 +251,10 @@ int  mc_build_target_windows(const mc_builder* b, uint64_t target, uint64_t* win
 /* sorts + bucketises everything added so far; if out_ctx != NULL also loads the table into a fresh
  * query context (see mc_build_set_query_config). */
 int  mc_build_finish(mc_builder* b, mc_ctx** out_ctx);
+/* One query table from n builders that were given the SAME targets and the key shards 0 .. n-1 of n (cfg.key_shard_index / _count:
+ * a builder keeps only the features of its shard, as a Mode K context does): tables beyond the 2^32 (feature, location) pairs one
+ * device sort takes are built shard after shard.  n == 1: the loading half of mc_build_finish. */
+int  mc_build_finish_shards(mc_builder** builders, uint32_t n, mc_ctx** out_ctx);
 /* fields of the query context mc_build_finish creates (max_candidates, slots, copy_allhits, load factor) */
 int  mc_build_set_query_config(mc_builder* b, const mc_config* qcfg);
 /* writes <name>.meta and <name>.cache0 in the reference's format (after mc_build_finish) */

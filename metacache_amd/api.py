@@ -54,7 +54,7 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
-           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_finish", "mc_build_write", "mc_build_free", "mc_build_last_error",
+           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_finish", "mc_build_finish_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
 
 _lib = None
@@ -338,6 +338,19 @@ class Builder:
         self._sync_cfg()
         self._check(lib().mc_build_finish(self.h, C.byref(out)))
         return Database.from_handle(out.value, self.cfg)
+
+    @staticmethod
+    def finish_shards(builders: "list[Builder]") -> "Database":
+        """One query table from builders that were given the same targets and the key shards 0 .. n-1 of n (mc_build_finish_shards)."""
+        for b in builders:
+            b._sync_cfg()
+        arr = (C.c_void_p * len(builders))(*[b.h for b in builders])
+        out = C.c_void_p()
+        lib().mc_build_finish_shards.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]
+        builders[0]._check(lib().mc_build_finish_shards(arr, len(builders), C.byref(out)))
+        cfg = McConfig.from_buffer_copy(builders[0].cfg)
+        cfg.key_shard_index, cfg.key_shard_count = 0, 1
+        return Database.from_handle(out.value, cfg)
 
     def _sync_cfg(self):
         lib().mc_build_set_query_config.argtypes = [C.c_void_p, C.POINTER(McConfig)]

@@ -76,6 +76,22 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
     }
 }
 
+// key-sharded build (cfg.key_shard_count > 1): which of the emitted pairs belong to this builder's shard ...
+__global__ __launch_bounds__(256) void own_flags_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shardIdx, uint32_t shardCnt,
+                                                        uint32_t* __restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = (keys[i] != 0xFFFFFFFFu && key_owner(keys[i], shardCnt) == shardIdx) ? 1u : 0u;
+}
+// ... and their move to the front, order kept (the sort that follows is stable: locations stay in (target, window) order)
+__global__ __launch_bounds__(256) void own_scatter_kernel(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ vals, uint64_t n,
+                                                          const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+                                                          uint32_t* __restrict__ okeys, uint64_t* __restrict__ ovals)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flags[i]) { okeys[pos[i]] = keys[i]; ovals[pos[i]] = vals[i]; }
+}
+
 // per run (= feature): kept size and its u32 copy for the scan
 __global__ __launch_bounds__(256) void keep_sizes_kernel(const uint32_t* __restrict__ counts, uint32_t nruns, uint32_t maxLocs,
                                                          uint8_t* __restrict__ sizes, uint32_t* __restrict__ keep32)
@@ -150,13 +166,41 @@ int flush(mc_builder* b)
     uint32_t W = 0;
     B_TRY(b, hipMemcpyAsync(&W, dwo + nq, 4, hipMemcpyDeviceToHost, b->st));
     B_TRY(b, hipStreamSynchronize(b->st));
-    int rc = grow_pairs(b, b->npairs + (uint64_t)W * sp.s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s,
-                       b->dkeys + b->npairs, b->dvals + b->npairs);
-    B_TRY(b, hipGetLastError());
-    B_TRY(b, hipStreamSynchronize(b->st));
-    b->npairs += (uint64_t)W * sp.s;
+    const uint64_t emitted = (uint64_t)W * sp.s;
+    if (b->cfg.key_shard_count > 1) {
+        // only this shard's features are kept: emitted into scratch, then compacted (order kept) behind the pairs so far
+        uint32_t *tk = nullptr, *flags = nullptr, *pos = nullptr; uint64_t* tv = nullptr; void* stmp = nullptr;
+        B_TRY(b, hipMalloc((void**)&tk, (emitted + 1) * 4));
+        B_TRY(b, hipMalloc((void**)&tv, (emitted + 1) * 8));
+        B_TRY(b, hipMalloc((void**)&flags, (emitted + 1) * 4));
+        B_TRY(b, hipMalloc((void**)&pos, (emitted + 2) * 4));
+        B_TRY(b, hipMalloc(&stmp, scan_tmp_bytes((uint32_t)emitted + 1)));
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s, tk, tv);
+        uint32_t kept = 0;
+        if (emitted) {
+            hipLaunchKernelGGL(own_flags_kernel, dim3((uint32_t)((emitted + 255) / 256)), dim3(256), 0, b->st, tk, emitted, b->cfg.key_shard_index,
+                               b->cfg.key_shard_count, flags);
+            launch_scan_u32(flags, 1, (uint32_t)emitted, pos, nullptr, stmp, b->st);
+            B_TRY(b, hipMemcpyAsync(&kept, pos + emitted, 4, hipMemcpyDeviceToHost, b->st));
+            B_TRY(b, hipStreamSynchronize(b->st));
+        }
+        int rc = grow_pairs(b, b->npairs + kept);
+        if (rc) return rc;
+        if (emitted) hipLaunchKernelGGL(own_scatter_kernel, dim3((uint32_t)((emitted + 255) / 256)), dim3(256), 0, b->st, tk, tv, emitted, flags, pos,
+                                        b->dkeys + b->npairs, b->dvals + b->npairs);
+        B_TRY(b, hipGetLastError());
+        B_TRY(b, hipStreamSynchronize(b->st));
+        b->npairs += kept;
+        for (void* p : {(void*)tk, (void*)tv, (void*)flags, (void*)pos, stmp}) (void)hipFree(p);
+    } else {
+        int rc = grow_pairs(b, b->npairs + emitted);
+        if (rc) return rc;
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s,
+                           b->dkeys + b->npairs, b->dvals + b->npairs);
+        B_TRY(b, hipGetLastError());
+        B_TRY(b, hipStreamSynchronize(b->st));
+        b->npairs += emitted;
+    }
     for (void* p : {(void*)dseq, (void*)dq, (void*)dtgt, (void*)dfirst, (void*)dwc, (void*)dwo, (void*)dfeat, (void*)dhs, (void*)dqs, dscan})
         (void)hipFree(p);
     b->hseq.clear(); b->hqinfo.clear(); b->hqtgt.clear(); b->hqfirst.clear();
@@ -179,6 +223,7 @@ int mc_build_begin(const mc_config* cfg, mc_builder** out)
         set_global_error("mc_build_begin: unsupported sketching parameters");
         return MC_ERR_UNSUPPORTED;
     }
+    if (cfg->key_shard_count > 1 && cfg->key_shard_index >= cfg->key_shard_count) { set_global_error("mc_build_begin: key_shard_index out of range"); return MC_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
         set_global_error("no usable HIP device (this library has no CPU fallback)");
@@ -317,31 +362,55 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
         b->finished = true;
     }
     if (outCtx) {
-        *outCtx = nullptr;
-        mc_config qc = b->cfg;
-        qc.max_locations_per_feature = 0; qc.num_parts = 1;
-        qc.remove_overpopulated = b->rmOver ? b->maxLocs - 1 : 0;   // applied while the table is filled (table_build.hip)
-        qc.target_id_bytes = 4;                                    // values are handed over as {u32 win, u32 tgt}
-        mc_ctx* ctx = nullptr;
-        int rc = mc_create(&qc, &ctx);
-        if (rc) { b->err = mc_last_error(nullptr); return rc; }
-        ctx->targetCount = b->targets.size();
-        ctx->maxLocs = b->maxLocs;
-        rc = mc_load_begin(ctx, 0, b->nkeys, b->nvals);
-        // device arrays go straight into the table builder, in chunks whose value count stays below 2^32
-        const uint64_t chunk = 1ull << 22;
+        mc_builder* one[1] = {b};
+        return mc_build_finish_shards(one, 1, outCtx);
+    }
+    return MC_OK;
+}
+
+// One query table from the results of several builders that sketched the SAME targets with different key shards
+// (cfg.key_shard_index = 0 .. n-1 of key_shard_count = n): a table beyond the 2^32 (feature, location) pairs one sort can take is
+// built shard after shard.  With n = 1 this is the loading half of mc_build_finish.
+int mc_build_finish_shards(mc_builder** bs, uint32_t n, mc_ctx** outCtx)
+{
+    if (!bs || !n || !outCtx || !bs[0]) return MC_ERR_INVALID;
+    mc_builder* b = bs[0];
+    *outCtx = nullptr;
+    uint64_t nkeys = 0, nvals = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!bs[i]) return MC_ERR_INVALID;
+        if (!bs[i]->finished) { int rc = mc_build_finish(bs[i], nullptr); if (rc) { b->err = bs[i]->err; return rc; } }
+        if (bs[i]->targets.size() != b->targets.size() || bs[i]->cfg.key_shard_count != (n > 1 ? n : bs[i]->cfg.key_shard_count) ||
+            (n > 1 && bs[i]->cfg.key_shard_index != i)) { b->err = "mc_build_finish_shards: builders do not form one key-sharded set"; return MC_ERR_INVALID; }
+        nkeys += bs[i]->nkeys; nvals += bs[i]->nvals;
+    }
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    mc_config qc = b->cfg;
+    qc.max_locations_per_feature = 0; qc.num_parts = 1;
+    qc.remove_overpopulated = b->rmOver ? b->maxLocs - 1 : 0;   // applied while the table is filled (table_build.hip)
+    qc.target_id_bytes = 4;                                    // values are handed over as {u32 win, u32 tgt}
+    if (n > 1) { qc.key_shard_index = 0; qc.key_shard_count = 1; }   // the table holds all shards
+    mc_ctx* ctx = nullptr;
+    int rc = mc_create(&qc, &ctx);
+    if (rc) { b->err = mc_last_error(nullptr); return rc; }
+    ctx->targetCount = b->targets.size();
+    ctx->maxLocs = b->maxLocs;
+    rc = mc_load_begin(ctx, 0, nkeys, nvals);
+    // device arrays go straight into the table builder, in chunks whose value count stays below 2^32
+    const uint64_t chunk = 1ull << 22;
+    for (uint32_t s = 0; !rc && s < n; ++s) {
         uint64_t vbeg = 0;
-        for (uint64_t i = 0; !rc && i < b->nkeys; i += chunk) {
-            const uint64_t nb = std::min<uint64_t>(chunk, b->nkeys - i);
+        for (uint64_t i = 0; !rc && i < bs[s]->nkeys; i += chunk) {
+            const uint64_t nb = std::min<uint64_t>(chunk, bs[s]->nkeys - i);
             uint64_t vend = 0;
-            if (hipMemcpy(&vend, b->rVoff + i + nb, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = MC_ERR_HIP; break; }
-            rc = load_chunk_device(ctx, b->rK + i, b->rS + i, reinterpret_cast<const uint8_t*>(b->rV + vbeg), (uint32_t)nb, vend - vbeg);
+            if (hipMemcpy(&vend, bs[s]->rVoff + i + nb, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = MC_ERR_HIP; break; }
+            rc = load_chunk_device(ctx, bs[s]->rK + i, bs[s]->rS + i, reinterpret_cast<const uint8_t*>(bs[s]->rV + vbeg), (uint32_t)nb, vend - vbeg);
             vbeg = vend;
         }
-        if (!rc) rc = mc_load_end(ctx, 0);
-        if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
-        *outCtx = ctx;
     }
+    if (!rc) rc = mc_load_end(ctx, 0);
+    if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
+    *outCtx = ctx;
     return MC_OK;
 }
 
@@ -358,6 +427,7 @@ int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, ui
 {
     if (!b || !name) return MC_ERR_INVALID;
     if (!b->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
+    if (b->cfg.key_shard_count > 1) { b->err = "mc_build_write: a key-sharded builder holds only part of the database"; return MC_ERR_UNSUPPORTED; }
     const uint32_t tb = b->cfg.target_id_bytes;
     if (!b->onHost) {
         B_TRY(b, hipSetDevice(b->cfg.device));

@@ -87,3 +87,31 @@ def test_builder_buckets_files_and_queries(tmp_path, tb):
         assert np.array_equal(rdb.lineages(), odb.lineages())
         rdb.close()
     odb.close(); db.close(); db2.close()
+
+
+def test_key_sharded_builders_make_the_same_table(tmp_path):
+    """mc_build_finish_shards: three builders, each keeping one key shard of the same targets, loaded into ONE table -- every query
+    answers as with the table of a single builder (sorted location lists and candidates)."""
+    rng = np.random.default_rng(77)
+    genomes = make_genomes(rng)
+    whole = api.Builder(target_id_bytes=4, max_candidates=3, copy_allhits=1)
+    shards = [api.Builder(target_id_bytes=4, max_candidates=3, copy_allhits=1, key_shard_index=i, key_shard_count=3) for i in range(3)]
+    for i, g in enumerate(genomes):
+        for b in [whole] + shards:
+            b.add_target(g, f"SYN_{i:05d}.1", parent_taxid=1000 + i % 5, filename=f"f{i}.fa")
+    db1 = whole.finish(load=True)
+    db3 = api.Builder.finish_shards(shards)
+    assert db1.info()[7] == db3.info()[7] and db1.info()[5] == db3.info()[5]          # locations, targets
+    reads, _, _ = synth.sample_reads(rng, [g for g in genomes if g.size > 2000], 1500, 150, 0.01, 0.002)
+    reads = [bytes(r) for r in reads]
+    c1, n1, h1 = db1.query(reads, lowest=0)
+    c3, n3, h3 = db3.query(reads, lowest=0)
+    assert np.array_equal(n1, n3)
+    for i in range(len(reads)):
+        assert np.array_equal(h1[i], h3[i]), i
+        assert np.array_equal(c1[i], c3[i]), i
+    with pytest.raises(api.McError):
+        shards[0].write(str(tmp_path / "partial"), [(1, 1, 20, "root")])              # a shard is not a database
+    db1.close(); db3.close()
+    for b in [whole] + shards:
+        b.free()

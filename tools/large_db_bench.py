@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--maxcand", type=int, default=2)
     ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--lowest", type=int, default=0, help="taxon rank for candidate merging (0 = sequence, 4 = species)")
+    ap.add_argument("--passes", type=int, default=1, help="build the table in this many key shards (mc_build_finish_shards): beyond 2^32 pairs")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -41,7 +42,9 @@ def main():
     gen.manual_seed(3100)
     gcat = torch.empty(G * GL, dtype=torch.uint8, device=dev)                      # all targets, ASCII, resident for read synthesis
     t0 = time.time()
-    bld = api.Builder(target_id_bytes=4, max_candidates=args.maxcand, max_load_factor=args.load_factor)
+    P = max(1, args.passes)
+    blds = [api.Builder(target_id_bytes=4, max_candidates=args.maxcand, max_load_factor=args.load_factor,
+                        **({"key_shard_index": 0, "key_shard_count": P} if P > 1 else {}))]
     t_add = 0.0
     for sp in range(args.species):
         base = torch.randint(0, 4, (GL,), generator=gen, device=dev, dtype=torch.uint8)
@@ -55,13 +58,29 @@ def main():
             gcat[t * GL:(t + 1) * GL] = lut[code.long()]
             host = gcat[t * GL:(t + 1) * GL].cpu().numpy()
             t1 = time.time()
-            bld.add_target(host, f"SYN_{t:06d}.1", parent_taxid=1000 + sp, filename=f"syn{t}.fa")
+            blds[0].add_target(host, f"SYN_{t:06d}.1", parent_taxid=1000 + sp, filename=f"syn{t}.fa")
             t_add += time.time() - t1
     t_gen = time.time() - t0
     t1 = time.time()
-    db = bld.finish(load=True)
+    blds[0].finish(load=False)
+    for p in range(1, P):                                      # the other key shards: the same targets again, from HBM
+        b = api.Builder(target_id_bytes=4, max_candidates=args.maxcand, max_load_factor=args.load_factor, key_shard_index=p, key_shard_count=P)
+        for t in range(G):
+            b.add_target(gcat[t * GL:(t + 1) * GL].cpu().numpy(), f"SYN_{t:06d}.1", parent_taxid=1000 + t // args.strains, filename=f"syn{t}.fa")
+        b.finish(load=False)
+        blds.append(b)
+    # reads are drawn before the genomes leave HBM (the table needs the room)
+    B = args.batch
+    goff = torch.arange(G, device=dev, dtype=torch.int64) * GL
+    batches = [torch.cat([bench.synth_reads_gpu(gcat, goff, GL, B, seed=3100 + s).reshape(-1), torch.zeros(16, dtype=torch.uint8, device=dev)])
+               for s in range(min(args.steps, 4))]
+    if P > 1:
+        del gcat
+        torch.cuda.empty_cache()
+    db = api.Builder.finish_shards(blds) if P > 1 else blds[0].finish(load=True)
     t_finish = time.time() - t1
-    bld.free()
+    for b in blds:
+        b.free()
     # taxonomy for merging above sequence level: species = parent
     if args.lowest:
         lin = np.zeros((G, 21), dtype=np.uint32)
@@ -71,13 +90,10 @@ def main():
     info = db.info()
     res = {"targets": G, "bases": G * GL, "strains_per_species": args.strains, "divergence": args.divergence,
            "db_info": {"k": info[0], "s": info[1], "w": info[2], "stride": info[3], "max_locs": info[4], "targets": info[5], "locations": info[7]},
-           "seconds": {"generate_and_add_targets": round(t_gen, 2), "of_which_add_target": round(t_add, 2), "sort_rle_table": round(t_finish, 2)},
+           "build_passes": P, "seconds": {"generate_and_add_targets": round(t_gen, 2), "of_which_add_target": round(t_add, 2), "sort_rle_table": round(t_finish, 2)},
            "hbm_allocated_GB": round(torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9, 2)}
 
-    B, K = args.batch, args.maxcand
-    goff = torch.arange(G, device=dev, dtype=torch.int64) * GL
-    batches = [torch.cat([bench.synth_reads_gpu(gcat, goff, GL, B, seed=3100 + s).reshape(-1), torch.zeros(16, dtype=torch.uint8, device=dev)])
-               for s in range(min(args.steps, 4))]
+    K = args.maxcand
     qinfo = torch.zeros((B, 4), dtype=torch.int32, device=dev)
     qinfo[:, 0] = torch.arange(B, device=dev, dtype=torch.int32) * bench.PAD_LEN
     qinfo[:, 1] = bench.READ_LEN
