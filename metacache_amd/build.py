@@ -45,7 +45,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     hipcc = _hipcc()
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", os.path.join(ROOT, "include"),
-             "-Wno-unused-result"]
+             "-Wno-unused-result"] + os.environ.get("MC_HIPCC_FLAGS", "").split()
     procs = []
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s).rsplit(".", 1)[0] + ".o")
