@@ -2071,7 +2071,7 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
             epay[u] = e < (rec.z & 0xFFFu) ? ws.ppay[rec.y + e] : 0ull;
         }
     };
-    auto count_of = [&](uint32_t slot) -> uint32_t { return (cnts[slot >> 1] >> (16u * (slot & 1u))) & 0xFFFFu; };
+    auto count_of = [&](uint32_t slot) -> uint32_t { return reinterpret_cast<const uint16_t*>(cnts)[slot]; };   // ds_read_u16
     const uint32_t w0 = blockIdx.x * WAVES + wave;
     uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
     load_entries(rec);
