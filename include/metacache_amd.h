@@ -114,6 +114,9 @@ int mc_load_end(mc_ctx* ctx, uint32_t part);
  * sketching as adapt_options_to_database (querying.cpp:225-251): kmerlen always the DB's; sketchlen /
  * winlen == 0 => the DB's; winstride == 0 => winlen - kmerlen + 1 (not the DB's stride). */
 int mc_open_database(const char* name, const mc_config* cfg, mc_ctx** out);
+/* database::read with scope::metadata_only (database.cpp:183-242), what `info` mode needs (mode_info.cpp:55-230): taxa, sources,
+ * lineages and the header fields for the mc_db_* calls -- no table, no device; query calls on it fail with MC_ERR_STATE. */
+int mc_open_metadata(const char* name, mc_ctx** out);
 
 /* target lineage table (ranked_lineages_of_targets, taxonomy.hpp:919-1030; uploaded like
  * copy_target_lineages_to_gpus gpu_hashmap.cu:1383-1396): lin[tgt*21 + rank] = taxon index + 1,

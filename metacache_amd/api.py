@@ -50,7 +50,7 @@ class McDeviceResults(C.Structure):
 
 
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end",
-           "mc_open_database", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
+           "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",

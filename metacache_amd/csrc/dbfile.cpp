@@ -181,6 +181,33 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     return MC_OK;
 }
 
+// database::read with scope::metadata_only (database.cpp:183-242; `info` mode, mode_info.cpp): header, sketching, taxa, lineages --
+// no table, no device.  Every query call on such a context fails with MC_ERR_STATE.
+int mc_open_metadata(const char* name, mc_ctx** out)
+{
+    if (!name || !out) return MC_ERR_INVALID;
+    *out = nullptr;
+    Meta m{};
+    std::string err;
+    int rc = read_meta(name, m, err);
+    if (rc) { set_global_error(err); return rc; }
+    auto* ctx = new mc_ctx;
+    mc_config_default(&ctx->cfg);
+    ctx->cfg.kmerlen = m.k; ctx->cfg.sketchlen = m.s; ctx->cfg.winlen = m.w; ctx->cfg.winstride = m.stride;
+    ctx->cfg.target_id_bytes = m.targetBytes; ctx->cfg.num_parts = m.numParts;
+    ctx->querySketch = ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
+    ctx->targetCount = m.targetCount;
+    ctx->maxLocs = m.maxLocs;
+    ctx->parts.resize(std::max<uint32_t>(m.numParts, 1));
+    ctx->taxa = std::move(m.taxa);
+    Meta tmp{}; tmp.targetCount = ctx->targetCount; tmp.taxa = ctx->taxa;
+    std::vector<uint32_t> lin;
+    make_lineages(tmp, lin);
+    ctx->lineages = std::move(lin);
+    *out = ctx;
+    return MC_OK;
+}
+
 int mc_db_num_taxa(const mc_ctx* ctx, uint64_t* n)
 {
     if (!ctx || !n) return MC_ERR_INVALID;

@@ -944,6 +944,136 @@ int merge_main(const std::vector<std::string>& args)
     return 0;
 }
 
+// ---- info mode (mode_info.cpp), the parts that read metadata only: database properties, targets, lineage table, rank statistics ----
+int info_main(const std::vector<std::string>& args)
+{
+    auto static_properties = [](uint32_t tb, uint64_t k, uint64_t sk, uint64_t w, uint64_t stride, uint64_t maxLocs) {   // printing.cpp:625-657
+        const char* tid = tb == 2 ? "unsigned short int 16 bits" : "unsigned int 32 bits";
+        std::cout << "------------------------------------------------\n"
+                  << "MetaCache version  mcq / metacache_amd (MI355X)\n"
+                  << "database version   20200820\n"
+                  << "------------------------------------------------\n"
+                  << "sequence type      mc::char_sequence\n"
+                  << "target id type     " << tid << "\n"
+                  << "target limit       " << (tb == 2 ? 65535ull : 4294967295ull) << "\n"
+                  << "------------------------------------------------\n"
+                  << "window id type     unsigned int 32 bits\n"
+                  << "window limit       4294967295\n"
+                  << "window length      " << w << "\n"
+                  << "window stride      " << stride << "\n"
+                  << "------------------------------------------------\n"
+                  << "sketcher type      mc::single_function_unique_min_hasher<unsigned int, mc::same_size_hash<unsigned int> >\n"
+                  << "feature type       unsigned int 32 bits\n"
+                  << "feature hash       mc::same_size_hash<unsigned int>\n"
+                  << "kmer size          " << k << "\n"
+                  << "kmer limit         16\n"
+                  << "sketch size        " << sk << "\n"
+                  << "------------------------------------------------\n"
+                  << "bucket size type   unsigned char 8 bits\n"
+                  << "max. locations     " << maxLocs << "\n"
+                  << "location limit     254\n"
+                  << "------------------------------------------------" << std::endl;
+    };
+    auto query_config = [] {
+        std::cout << "hit classifier       mc::best_distinct_matches_in_contiguous_window_ranges\n"
+                  << "------------------------------------------------\n";
+    };
+    if (args.empty()) { static_properties(4, 0, 0, 0, 0, 254); query_config(); std::cout << std::endl; return 0; }   // show_basic_exec_info: an empty database
+    std::string name = args[0];
+    { auto pos = name.find(".meta"); if (pos != std::string::npos) name.erase(pos); else { pos = name.find(".cache"); if (pos != std::string::npos) name.erase(pos); } }
+    const std::string what = args.size() > 1 ? args[1] : "";
+    if (what == "statistics" || what == "stat" || what == "locations" || what == "loc" || what == "featuremap" || what == "features" || what == "featurecounts")
+        throw std::runtime_error("'info " + what + "' describes the reference's host hash table; not available here");
+    std::cerr << "Reading database '" << name << "' ... Reading database metadata ...\nCompleted database reading.\ndone." << std::endl;
+    mc_ctx* ctx = nullptr;
+    if (mc_open_metadata(name.c_str(), &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+    struct Guard { mc_ctx* c; ~Guard() { mc_destroy(c); } } guard{ctx};
+    uint64_t info[8]; mc_db_info(ctx, info);
+    Taxonomy tx;
+    std::vector<std::string> srcFile; std::vector<uint64_t> srcIndex;
+    uint64_t nt = 0; mc_db_num_taxa(ctx, &nt);
+    tx.taxa.resize(nt); srcFile.resize(nt); srcIndex.resize(nt);
+    for (uint64_t i = 0; i < nt; ++i) {
+        uint32_t rk; const char *nm, *fn;
+        mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
+        tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm;
+        mc_db_taxon_source(ctx, i, &fn, &srcIndex[i], &tx.taxa[i].windows);
+        srcFile[i] = fn;
+        tx.byId.emplace(tx.taxa[i].id, (uint32_t)i);
+        if (tx.taxa[i].rank == 0 && tx.taxa[i].id < 0) tx.targetByName.emplace(tx.taxa[i].name, (uint32_t)i + 1);
+    }
+    mc_db_lineages(ctx, &tx.targetLineages, &tx.numTargets);
+    if (what.empty()) {                                                          // show_database_config
+        uint32_t tb = 4;
+        { std::ifstream is(name + ".meta", std::ios::binary); char hdr[10] = {}; is.read(hdr, 10); if (is.gcount() == 10) tb = (uint8_t)hdr[9]; }
+        static_properties(tb, info[0], info[1], info[2], info[3], info[4]);
+        query_config();
+        std::cout << "database parts       " << info[6] << "\n------------------------------------------------\n";
+        return 0;
+    }
+    auto show_target = [&](uint32_t tgt) {                                       // show_target_info, mode_info.cpp:106-121
+        const Lineage lin = tx.target_ranks(tgt);
+        const Taxon* t = tx.taxon(lin[0]);
+        if (!t) return;
+        std::cout << "Target " << t->name << "):\n    source:     " << srcFile[lin[0] - 1] << " / " << srcIndex[lin[0] - 1]
+                  << "\n    length:     " << t->windows << " windows";
+        for (uint32_t l : lin) {
+            const Taxon* a = tx.taxon(l);
+            if (!a) continue;
+            std::string rn = std::string(kRankNames[a->rank]) + ":";
+            rn.resize(12, ' ');
+            std::cout << "\n    " << rn << "(" << a->id << ") " << a->name;
+        }
+        std::cout << '\n';
+    };
+    if (what == "targets" || what == "target" || what == "reference" || what == "references" || what == "ref" || what == "sequence" || what == "sequences" || what == "seq") {
+        if (args.size() > 2) {
+            for (size_t i = 2; i < args.size(); ++i) {
+                const uint32_t t = tx.with_name(args[i]);
+                if (t && tx.taxon(t)->id < 0) show_target((uint32_t)(-tx.taxon(t)->id - 1));
+                else std::cout << "Target (reference sequence) '" << args[i] << "' not found in database.\n";
+            }
+        } else {
+            std::cout << "Targets (reference sequences) in database:\n";
+            for (uint64_t t = 0; t < tx.numTargets; ++t) show_target((uint32_t)t);
+        }
+        return 0;
+    }
+    if (what == "lineages" || what == "lineage" || what == "lin") {              // show_lineage_table, mode_info.cpp:157-186
+        if (tx.numTargets < 1) return 0;
+        std::cout << "name";
+        for (int r = 0; r <= 19; ++r) std::cout << '\t' << kRankNames[r];
+        std::cout << '\n';
+        for (uint64_t t = 0; t < tx.numTargets; ++t) {
+            const Lineage lin = tx.target_ranks((uint32_t)t);
+            const Taxon* me = tx.taxon(lin[0]);
+            std::cout << (me ? me->name : std::string());
+            for (int r = 0; r <= 19; ++r) { const Taxon* a = tx.taxon(lin[r]); std::cout << '\t' << (a ? a->id : 0); }
+            std::cout << '\n';
+        }
+        return 0;
+    }
+    if (what == "rank") {                                                        // show_rank_statistics, mode_info.cpp:193-232
+        const int rank = args.size() > 2 ? rank_from_name(args[2]) : -1;
+        if (rank < 0 || rank >= kNumRanks) {
+            std::cerr << "Please specify a taxonomic rank:\n";
+            for (int r = 0; r <= 19; ++r) std::cerr << "    " << kRankNames[r] << '\n';
+            return 0;
+        }
+        std::vector<std::pair<uint32_t, size_t>> stat;                           // the reference walks a map keyed by taxon address
+        for (uint64_t t = 0; t < tx.numTargets; ++t) {
+            const uint32_t a = tx.target_ranks((uint32_t)t)[rank];
+            if (!a) continue;
+            auto it = std::find_if(stat.begin(), stat.end(), [&](const std::pair<uint32_t, size_t>& x) { return x.first == a; });
+            if (it == stat.end()) stat.emplace_back(a, 1); else ++it->second;
+        }
+        std::cout << "Sequence distribution for rank '" << kRankNames[rank] << "':\n" << "taxid \t taxon_name \t sequences" << std::endl;
+        for (const auto& x : stat) std::cout << tx.taxon(x.first)->id << " \t " << tx.taxon(x.first)->name << " \t " << x.second << '\n';
+        return 0;
+    }
+    throw std::runtime_error("unknown info topic '" + what + "'");
+}
+
 // query mode proper / the query half of build+query: files of the command line, or the interactive loop
 int query_main(Session& S, const Options& init)
 {
@@ -1003,6 +1133,7 @@ int main(int argc, char** argv)
             return query_main(S, init);
         }
         if (mode == "merge") return merge_main(args);
+        if (mode == "info") return info_main(args);
         if (mode == "build") {                                                  // main_mode_build, mode_build.cpp:93-106, :41-66
             using clock = std::chrono::steady_clock;
             std::vector<std::string> none;
@@ -1040,7 +1171,7 @@ int main(int argc, char** argv)
             if (bo.saveDb) db.write();
             return rc;
         }
-        throw std::runtime_error("usage: mcq query|build|build+query|merge ... (see the header of mcq_main.cpp / mcq_build.h)");
+        throw std::runtime_error("usage: mcq query|build|build+query|merge|info ... (see the header of mcq_main.cpp / mcq_build.h)");
     } catch (std::exception& e) {
         std::cerr << "ABORT: " << e.what() << "!" << std::endl;                  // main.cpp:65-68
         return 1;

@@ -49,3 +49,29 @@ def test_merge_refuses_sequence_level_and_single_files(tmp_path):
     seq.write_text("# Classification will be constrained to ranks from 'sequence' to 'domain'.\n# TABLE_LAYOUT: query_id\t|\tquery_header\t|\ttop_hits\t|\trank:taxname\n")
     r = subprocess.run([build.MCQ, "merge", str(seq), "merge_in/part0.txt", "-taxonomy", "build_in/taxonomy"], cwd=GOLD, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "sequence level" in r.stderr
+
+
+# ---- info mode (metadata topics; no GPU needed: mc_open_metadata) -----------------------------------------------------------------
+with gzip.open(os.path.join(GOLD, "info_expected.json.gz"), "rt") as f:
+    INFO = json.load(f)
+
+
+@pytest.mark.parametrize("case", sorted(INFO))
+def test_info_matches_reference(case):
+    """stdout of `mcq info ...` against the reference's: identical except the program version line; the rows of `info rank` are
+    compared as a set (the reference walks a map keyed by taxon address)"""
+    build.build_library()
+    c = INFO[case]
+    r = subprocess.run([build.MCQ, "info"] + c["args"], cwd=GOLD, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    drop = lambda ls: [l for l in ls if not l.startswith("MetaCache version")]
+    got, exp = drop(r.stdout.split("\n")), drop(c["stdout"])
+    if case.startswith("rank"):
+        got, exp = sorted(got), sorted(exp)
+    assert got == exp, (case, [(g, e) for g, e in zip(got, exp) if g != e][:5], len(got), len(exp))
+
+
+def test_info_topics_of_the_host_table_are_refused():
+    build.build_library()
+    r = subprocess.run([build.MCQ, "info", "toy32", "statistics"], cwd=GOLD, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "ABORT" in r.stderr
