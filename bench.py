@@ -36,7 +36,7 @@ from metacache_amd.distributed import gather_candidates_async  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
-DEFAULT_BATCH = 4_000_000        # reads per step: one batch of synthetic input (fixed per-batch costs are amortised over it)
+DEFAULT_BATCH = 10_000_000       # reads per step: the 10 M reads of configs[1] as one batch (4 M: 6 % slower per read, fixed per-batch costs)
 PAD_LEN = 152                  # every read starts 4-byte aligned
 
 

@@ -1136,6 +1136,107 @@ __device__ __forceinline__ void lane_sketch_span(const uint8_t* __restrict__ seq
     }
 }
 
+// k = 16 and a stride that is a multiple of 16 (the defaults: 112): the same multiset of the s smallest hashes per window, selected in
+// batches.  The insertion chain above spends 32 min/max per k-mer; sorting 16 hashes with Batcher's odd-even merge network (63
+// compare-exchanges, checked on all 2^16 0/1 inputs) and merging the sorted batch into the sorted sketch (16 min + a 32-exchange bitonic
+// merge) costs 13 per k-mer.  Character t of a 16-character step completes k-mer (step * 16 + t - 15): slot (t + 1) % 16 of a batch, so
+// every register index is a compile-time constant; windows end on batch boundaries.
+__device__ __forceinline__ void sort16(uint32_t (&x)[16])
+{
+    auto ce = [&](const uint32_t i, const uint32_t j) { const uint32_t lo = min(x[i], x[j]); x[j] = max(x[i], x[j]); x[i] = lo; };
+    ce(0, 1); ce(2, 3); ce(0, 2); ce(1, 3); ce(1, 2); ce(4, 5); ce(6, 7); ce(4, 6); ce(5, 7); ce(5, 6); ce(0, 4); ce(2, 6); ce(2,
+    4); ce(1, 5); ce(3, 7); ce(3, 5); ce(1, 2); ce(3, 4); ce(5, 6); ce(8, 9); ce(10, 11); ce(8, 10); ce(9, 11); ce(9, 10); ce(12,
+    13); ce(14, 15); ce(12, 14); ce(13, 15); ce(13, 14); ce(8, 12); ce(10, 14); ce(10, 12); ce(9, 13); ce(11, 15); ce(11, 13);
+    ce(9, 10); ce(11, 12); ce(13, 14); ce(0, 8); ce(4, 12); ce(4, 8); ce(2, 10); ce(6, 14); ce(6, 10); ce(2, 4); ce(6, 8); ce(10,
+    12); ce(1, 9); ce(5, 13); ce(5, 9); ce(3, 11); ce(7, 15); ce(7, 11); ce(3, 5); ce(7, 9); ce(11, 13); ce(1, 2); ce(3, 4); ce(5,
+    6); ce(7, 8); ce(9, 10); ce(11, 12); ce(13, 14);
+}
+// sk (ascending) <- the 16 smallest of sk and x (ascending), ascending
+__device__ __forceinline__ void merge16(uint32_t (&sk)[16], const uint32_t (&x)[16])
+{
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) sk[i] = min(sk[i], x[15 - i]);               // bitonic: falls, then rises
+#pragma unroll
+    for (uint32_t dist = 8; dist > 0; dist >>= 1)
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i)
+            if ((i & dist) == 0) { const uint32_t lo = min(sk[i], sk[i + dist]); sk[i + dist] = max(sk[i], sk[i + dist]); sk[i] = lo; }
+}
+
+__device__ __forceinline__ void lane_sketch_span16(const uint8_t* __restrict__ seq, const uint64_t off, const uint32_t len, const uint32_t s,
+                                                   const uint32_t stride, uint32_t* out0, uint32_t& wcount, bool& dup)
+{
+    static_assert(kLaneS == 16, "batch = sketch registers");
+    uint32_t sk[16], hb[16];
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) { sk[i] = 0xFFFFFFFFu; hb[i] = 0xFFFFFFFFu; }
+    uint32_t fwd = 0, rc = 0, since = 0, wpos = 0;
+    bool pending = false;                                               // hb holds hashes that are not in sk yet
+    auto flush = [&]() {
+        sort16(hb);
+        merge16(sk, hb);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) hb[i] = 0xFFFFFFFFu;
+        pending = false;
+    };
+    auto emit = [&]() {
+        uint32_t* out = out0 + (size_t)wcount * s;
+        if (s == 16) {                                                  // a window's sketch = one 64-byte line: four 16-byte stores (every
+            uint4* o4 = reinterpret_cast<uint4*>(out);                  // lane writes its own line, so 4 instead of 16 requests per line)
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) o4[i] = make_uint4(sk[4 * i], sk[4 * i + 1], sk[4 * i + 2], sk[4 * i + 3]);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) {
+            if (s != 16 && i < s) out[i] = sk[i];
+            if (i + 1 < s) dup = dup || (sk[i] == sk[i + 1] && sk[i] != 0xFFFFFFFFu);
+            sk[i] = 0xFFFFFFFFu;
+        }
+        ++wcount; wpos = 0;
+    };
+    const uint4* src = reinterpret_cast<const uint4*>(seq + off);       // sequences start 4-byte aligned
+    uint4 nxt = src[0];
+    // one step = 16 characters.  GUARD = false: every lane of the wave is inside its sequence and past its first 15 characters, so
+    // the per-character tests (and their exec-mask bookkeeping) are gone; first and last steps take the guarded form.
+    auto step = [&](const uint32_t j0, const uint4 cur, auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            uint32_t codes, ambs;
+            lane_encode4(wd[d], codes, ambs);
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) {
+                const uint32_t dt = d * 4 + t, j = j0 + dt;
+                if (!GUARD || j < len) {
+                    const uint32_t c = (codes >> (8 * t)) & 3u;
+                    const bool a = (ambs >> t) & 1u;
+                    fwd = (fwd << 2) | c;
+                    rc = (rc >> 2) | ((3u - c) << 30);
+                    since = a ? 0u : since + 1u;
+                    if (!GUARD || j >= 15) {
+                        hb[(dt + 1) & 15] = since >= 16 ? tm_hash(fwd < rc ? fwd : rc) : 0xFFFFFFFFu;
+                        pending = true;
+                        ++wpos;
+                    }
+                }
+                if (dt == 14) {                                         // the batch that began with the previous step's last character is complete
+                    if (!GUARD || pending) flush();
+                    if (wpos == stride) emit();                         // window complete (row 1: the k-mers partition)
+                }
+            }
+        }
+    };
+    for (uint32_t j0 = 0; j0 < len; j0 += 16) {
+        const uint4 cur = nxt;
+        if (j0 + 16 < len) nxt = src[(j0 >> 4) + 1];
+        const bool inside = j0 >= 16 && j0 + 16 <= len;
+        if (__all(inside)) step(j0, cur, std::false_type{});
+        else step(j0, cur, std::true_type{});
+    }
+    if (wpos > 0) { if (pending) flush(); emit(); }                     // tail window
+}
+
 __device__ __forceinline__ uint32_t sketch_lane_one(const BatchView& b, const SketchParams& sp, const uint32_t* __restrict__ winOff,
                                                     uint32_t* features, const uint32_t q)
 {
@@ -1154,7 +1255,8 @@ __device__ __forceinline__ uint32_t sketch_lane_one(const BatchView& b, const Sk
         const uint32_t off = mate ? qi.z : qi.x;
         const uint32_t len = mate ? qi.w : qi.y;
         if (len < k) continue;
-        lane_sketch_span(b.seq, off, len, k, s, stride, features + (size_t)widx0 * s, wcount, dup);
+        if (k == 16 && (stride & 15u) == 0) lane_sketch_span16(b.seq, off, len, s, stride, features + (size_t)widx0 * s, wcount, dup);
+        else lane_sketch_span(b.seq, off, len, k, s, stride, features + (size_t)widx0 * s, wcount, dup);
     }
     return dup ? kFlagSketch : kFlagProbe;
 }
@@ -1217,7 +1319,8 @@ __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchPa
         uint32_t wcount = 0; bool dup = false;
         const uint32_t w0 = ws.winOff[q] + c * kChunkWins, w1 = min(ws.winOff[q + 1], w0 + kChunkWins);
         for (uint32_t i = w0 * sp.s; i < w1 * sp.s; ++i) ws.psize[i] = 0u;        // chunk_probe_kernel writes the found features only
-        lane_sketch_span(b.seq, (uint64_t)qi.x + p0, len, sp.k, sp.s, sp.stride, ws.features + (size_t)w0 * sp.s, wcount, dup);
+        if (sp.k == 16 && (sp.stride & 15u) == 0) lane_sketch_span16(b.seq, (uint64_t)qi.x + p0, len, sp.s, sp.stride, ws.features + (size_t)w0 * sp.s, wcount, dup);
+        else lane_sketch_span(b.seq, (uint64_t)qi.x + p0, len, sp.k, sp.s, sp.stride, ws.features + (size_t)w0 * sp.s, wcount, dup);
         if (dup) ws.qflag[q] = kFlagSketch;                                         // the wave kernel redoes the whole read
     }
 }
