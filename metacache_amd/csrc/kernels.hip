@@ -1527,8 +1527,18 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         }
         gnent = n + m;
     };
+    // the lane's features arrive four at a time (s % 4 == 0: sketches are 16-byte aligned): every lane reads its own line, so what
+    // counts is the number of requests, not their width
+    uint32_t e = 0;                                                  // next feature of this lane
+    uint4 fcache = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    const bool wide = (s & 3u) == 0;
+    auto next_feature = [&]() -> uint32_t {
+        if (!wide) return feats[e++];
+        if ((e & 3u) == 0) fcache = reinterpret_cast<const uint4*>(feats)[e >> 2];
+        const uint32_t i = e++ & 3u;
+        return i == 0 ? fcache.x : i == 1 ? fcache.y : i == 2 ? fcache.z : fcache.w;
+    };
     if constexpr (QUAD) {
-        uint32_t e = 0;                                              // next feature of this lane
         uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
         QuadRaw raw[kLaneU];
         bool busy[kLaneU];
@@ -1581,7 +1591,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     #pragma unroll
             for (uint32_t u = 0; u < kLaneU; ++u) {
                 while (!busy[u] && e < nf) {
-                    f[u] = feats[e++];
+                    f[u] = next_feature();
                     if (f[u] != 0xFFFFFFFFu) {
                         ++nfeat;
                         home[u] = home_group(f[u], tab.nbuckets);
@@ -1597,7 +1607,6 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                 if (__ballot(busy[u])) quad_issue(tab, busy[u] ? cur[u] : kNoBucket, raw[u]);
         }
     } else {
-        uint32_t e = 0;                                              // next feature of this lane
         uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
         BucketRegs r[kLaneU];
         bool busy[kLaneU];
@@ -1608,7 +1617,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     #pragma unroll
             for (uint32_t u = 0; u < kLaneU; ++u) {
                 if (!busy[u] && e < nf) {
-                    f[u] = feats[e++];
+                    f[u] = next_feature();
                     if (f[u] != 0xFFFFFFFFu) {
                         ++nfeat;
                         home[u] = home_group(f[u], tab.nbuckets);
