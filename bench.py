@@ -282,10 +282,17 @@ def main():
             cb, par = cpu_baseline(os.path.join(dbdir, "syn16"), reads_host, gc, K, 2, args.cpu_seconds)
             result["cpu_baseline"] = cb
             result["parity"] = par
-        print(json.dumps(result), flush=True)
     db.close()
     if dist.is_initialized():
         dist.barrier()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which is
+        # flushed here, before the line, instead of at process exit after it
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
