@@ -283,14 +283,14 @@ def main():
             result["cpu_baseline"] = cb
             result["parity"] = par
     db.close()
+    # the JSON line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which every rank
+    # flushes here, before the barrier and the line, instead of at process exit after it
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which is
-        # flushed here, before the line, instead of at process exit after it
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
