@@ -1,19 +1,24 @@
-// mcq -- `metacache query` on MI355X: the reference's query command line for the per-read mapping output
-// (SURVEY.md §8f rank 2), host C++ above the C ABI.  Mirrors, for the supported options,
+// mcq -- the reference's command lines on MI355X, host C++14 above the C ABI (include/metacache_amd.h):
+//   mcq query <database> [<reads.fa|fq[.gz]|directory>...] [options]     mode_query.cpp, querying.cpp (interactive without files)
+//   mcq build <database> <sequence files|directories>... [options]        mode_build.cpp, building.cpp        (mcq_build.h)
+//   mcq build+query -targets <files>... [-query <files>...] [options]     mode_build_query.cpp                (mcq_build.h)
+//   mcq merge <result files>... -taxonomy <dir> [options]                 mode_merge.cpp
+//   mcq info [<database> [targets [name...] | lineages | rank <r>]]       mode_info.cpp (metadata topics)
+// Query mode mirrors
 //   option handling      options.cpp:860-1430 (query subset), querying.cpp:225-269 (adapt_options_to_database)
 //   read ingest          sequence_io.cpp:160-228, :293-322 (FASTA / FASTQ, -pairfiles / -pairseq), database_query.hpp:258-284;
-//                        files are memory-mapped, record starts are indexed by all threads in parallel
-//                        (query ids = record order, as reader.index()), and every worker thread drives one batch slot:
-//                        parse -> mc_batch_add -> submit -> wait -> classify + format; output is written in file order
-//   classification       classification.cpp:146-189 (classify: ranked-LCA vote over the top candidates)
-//   output lines         classification.cpp:470-526 (show_query_mapping), printing.cpp:160-365
-// Not offered (later rows): -precision/-ground-truth, -hits-per-ref, -abundances, -align, gzip input, summary block.
-//
-//   mcq query <database> <reads.fa|fq>... [-out file] [-lowest rank] [-highest rank] [-hitmin n] [-hitdiff f]
-//       [-maxcand n] [-tophits] [-allhits] [-queryids] [-mapped-only] [-no-map] [-taxids] [-taxids-only] [-omit-ranks]
-//       [-separate-cols] [-separator s] [-lineage] [-pairfiles | -pairseq] [-insertsize n] [-sketchlen s] [-winlen w]
-//       [-winstride l] [-max-locations-per-feature n] [-remove-overpopulated-features] [-max-load-fac f]
-//       [-no-query-params] [-no-summary] [-threads n (accepted, ignored)] [-batch-size n]
+//                        files are memory-mapped (gzip: inflated into memory), record starts are indexed by all
+//                        threads in parallel (query ids = record order, as reader.index()), and every worker thread drives one
+//                        batch slot: parse -> mc_batch_add -> submit -> wait -> classify + format; output is written in file order
+//   classification       classification.cpp:146-189 (classify: ranked-LCA vote over the top candidates), :104-137 (ground truth),
+//                        :272-295 (evaluation), :304-374 (abundance estimation)
+//   output lines         classification.cpp:470-526 (show_query_mapping), printing.cpp:47-620 (parameters, candidates, matches,
+//                        hits per reference sequence, abundance tables, summary)
+// Options: -out -split-out -lowest -highest -hitmin -hitdiff -maxcand -tophits -allhits -locations -queryids -mapped-only -no-map
+//   -taxids -taxids-only -omit-ranks -separate-cols -separator -comment -lineage -pairfiles -pairseq -insertsize -min-readlen
+//   -max-readlen -query-limit -sketchlen -winlen -winstride -max-locations-per-feature -remove-overpopulated-features -max-load-fac
+//   -no-query-params -no-summary -no-err -threads -batch-size -abundances [file] -abundance-per <rank> -hits-per-ref [file]
+//   -ground-truth -precision -taxon-coverage.  Not offered: -cov-percentile, -align.
 #include "mcq_build.h"
 
 namespace {
