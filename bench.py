@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--maxcand", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--load-factor", type=float, default=0.3)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
     args = ap.parse_args()
 

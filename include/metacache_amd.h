@@ -78,7 +78,7 @@ typedef struct {
     uint32_t max_locations_per_feature; /* load-time truncation to the first n values (host_hashmap.hpp:454-466); 0 = keep */
     uint32_t remove_overpopulated;   /* load-time: empty buckets with more than n values (host_hashmap.hpp:480-495); 0 = off;
                                         mc_open_database clamps n to the DB's own bucket cap - 1 (mode_query.cpp:69-76) */
-    float    max_load_factor;        /* hash table load factor (-max-load-fac, mode_query.cpp:49-55); 0 = default 0.5 */
+    float    max_load_factor;        /* hash table load factor (-max-load-fac, mode_query.cpp:49-55); 0 = default 0.3 */
     /* host batch slots (query_batch ctor, database_query.hpp:192-202) */
     uint32_t num_slots;
     uint32_t slot_max_queries;

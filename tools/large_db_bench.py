@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1_000_000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--maxcand", type=int, default=2)
-    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--load-factor", type=float, default=0.3)
     ap.add_argument("--lowest", type=int, default=0, help="taxon rank for candidate merging (0 = sequence, 4 = species)")
     ap.add_argument("--passes", type=int, default=1, help="build the table in this many key shards (mc_build_finish_shards): beyond 2^32 pairs")
     ap.add_argument("--out", default="")
