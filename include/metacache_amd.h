@@ -262,6 +262,8 @@ int  mc_build_finish_shards(mc_builder** builders, uint32_t n, mc_ctx** out_ctx)
 int  mc_build_set_query_config(mc_builder* b, const mc_config* qcfg);
 /* writes <name>.meta and <name>.cache0 in the reference's format (after mc_build_finish) */
 int  mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa);
+/* the same for the builders of one key-sharded set (see mc_build_finish_shards): one complete database */
+int  mc_build_write_shards(mc_builder** builders, uint32_t n, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa);
 void mc_build_free(mc_builder* b);
 const char* mc_build_last_error(const mc_builder* b);
 

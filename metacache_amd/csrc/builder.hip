@@ -40,9 +40,6 @@ struct mc_builder {
     bool finished = false;
     uint32_t* rK = nullptr; uint8_t* rS = nullptr; uint64_t* rV = nullptr; uint64_t* rVoff = nullptr;   // rVoff[nkeys + 1]
     uint64_t nkeys = 0, nvals = 0;
-    // ... and on the host once mc_build_write needs them
-    bool onHost = false;
-    std::vector<uint32_t> keys; std::vector<uint8_t> sizes; std::vector<uint64_t> values;
 };
 
 namespace {
@@ -425,20 +422,25 @@ int mc_build_set_query_config(mc_builder* b, const mc_config* q)
 
 int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa)
 {
-    if (!b || !name) return MC_ERR_INVALID;
-    if (!b->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
-    if (b->cfg.key_shard_count > 1) { b->err = "mc_build_write: a key-sharded builder holds only part of the database"; return MC_ERR_UNSUPPORTED; }
-    const uint32_t tb = b->cfg.target_id_bytes;
-    if (!b->onHost) {
-        B_TRY(b, hipSetDevice(b->cfg.device));
-        b->keys.resize(b->nkeys); b->sizes.resize(b->nkeys); b->values.resize(b->nvals);
-        if (b->nkeys) {
-            B_TRY(b, hipMemcpy(b->keys.data(), b->rK, b->nkeys * 4, hipMemcpyDeviceToHost));
-            B_TRY(b, hipMemcpy(b->sizes.data(), b->rS, b->nkeys, hipMemcpyDeviceToHost));
-        }
-        if (b->nvals) B_TRY(b, hipMemcpy(b->values.data(), b->rV, b->nvals * 8, hipMemcpyDeviceToHost));
-        b->onHost = true;
+    if (!b) return MC_ERR_INVALID;
+    if (b->cfg.key_shard_count > 1) { b->err = "mc_build_write: a key-sharded builder holds only part of the database (mc_build_write_shards)"; return MC_ERR_UNSUPPORTED; }
+    mc_builder* one[1] = {b};
+    return mc_build_write_shards(one, 1, name, taxa, ntaxa);
+}
+
+// <name>.meta + <name>.cache0 from the builders of one key-sharded set (n == 1: a whole builder): the shards' features follow each
+// other in the file's batch stream (any order of keys is a valid file: the reader inserts key by key, hash_multimap.hpp:970-1030)
+int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa)
+{
+    if (!bs || !n || !bs[0] || !name) return MC_ERR_INVALID;
+    mc_builder* b = bs[0];
+    for (uint32_t s = 0; s < n; ++s) {
+        if (!bs[s]) return MC_ERR_INVALID;
+        if (!bs[s]->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
+        if (bs[s]->targets.size() != b->targets.size() || (n > 1 && (bs[s]->cfg.key_shard_count != n || bs[s]->cfg.key_shard_index != s))) {
+            b->err = "mc_build_write_shards: builders do not form one key-sharded set"; return MC_ERR_INVALID; }
     }
+    const uint32_t tb = b->cfg.target_id_bytes;
     {   // .meta  (database.cpp:247-290)
         FILE* f = std::fopen((std::string(name) + ".meta").c_str(), "wb");
         if (!f) { b->err = "cannot write .meta"; return MC_ERR_IO; }
@@ -474,36 +476,60 @@ int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, ui
         // that reached the limit are gone (remove_features_with_more_locations_than(maxLocs - 1), building.cpp:516-534)
         FILE* f = std::fopen((std::string(name) + ".cache0").c_str(), "wb");
         if (!f) { b->err = "cannot write .cache0"; return MC_ERR_IO; }
-        auto kept = [&](uint64_t i) { return !(b->rmOver && b->sizes[i] > b->maxLocs - 1); };
-        uint64_t nk = 0, nv = 0;
-        for (uint64_t i = 0; i < b->keys.size(); ++i) if (kept(i)) { ++nk; nv += b->sizes[i]; }
         const uint64_t batch = 1ull << 20;
-        wr(f, &nk, 8); wr(f, &nv, 8); wr(f, &batch, 8);
-        std::vector<uint32_t> bk; std::vector<uint8_t> bs, packed;
-        uint64_t voff = 0, i = 0;
-        while (i < b->keys.size()) {
-            bk.clear(); bs.clear(); packed.clear();
-            for (; i < b->keys.size() && bk.size() < batch; ++i) {
-                const uint32_t sz = b->sizes[i];
-                if (kept(i)) {
-                    bk.push_back(b->keys[i]); bs.push_back((uint8_t)sz);
-                    for (uint32_t t = 0; t < sz; ++t) {
-                        const uint64_t v = b->values[voff + t];
-                        const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
-                        const size_t at = packed.size();
-                        packed.resize(at + 4 + tb);
-                        std::memcpy(&packed[at], &win, 4);
-                        if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(&packed[at + 4], &t16, 2); }
-                        else std::memcpy(&packed[at + 4], &tgt, 4);
-                    }
-                }
-                voff += sz;
-            }
-            if (bk.empty()) continue;
-            wr(f, bk.data(), bk.size() * 4);
-            wr(f, bs.data(), bs.size());
+        uint64_t hdr[3] = {0, 0, batch};
+        wr(f, hdr, 24);                                                // key / value totals follow when all shards are through
+        std::vector<uint32_t> keys, outK; std::vector<uint8_t> sizes, outS, packed; std::vector<uint64_t> values;
+        auto flush_batch = [&]() {
+            if (outK.empty()) return;
+            hdr[0] += outK.size();
+            wr(f, outK.data(), outK.size() * 4);
+            wr(f, outS.data(), outS.size());
             wr(f, packed.data(), packed.size());
+            outK.clear(); outS.clear(); packed.clear();
+        };
+        for (uint32_t s = 0; s < n; ++s) {
+            mc_builder* c = bs[s];
+            // one shard at a time on the host, in slices of 2^24 keys
+            const uint64_t slice = 1ull << 24;
+            uint64_t vbeg = 0;
+            for (uint64_t k0 = 0; k0 < c->nkeys; k0 += slice) {
+                const uint64_t nk = std::min<uint64_t>(slice, c->nkeys - k0);
+                uint64_t vend = 0;
+                B_TRY(b, hipSetDevice(c->cfg.device));
+                B_TRY(b, hipMemcpy(&vend, c->rVoff + k0 + nk, 8, hipMemcpyDeviceToHost));
+                keys.resize(nk); sizes.resize(nk); values.resize(vend - vbeg);
+                B_TRY(b, hipMemcpy(keys.data(), c->rK + k0, nk * 4, hipMemcpyDeviceToHost));
+                B_TRY(b, hipMemcpy(sizes.data(), c->rS + k0, nk, hipMemcpyDeviceToHost));
+                if (vend > vbeg) B_TRY(b, hipMemcpy(values.data(), c->rV + vbeg, (vend - vbeg) * 8, hipMemcpyDeviceToHost));
+                vbeg = vend;
+                auto kept = [&](uint64_t i) { return !(c->rmOver && sizes[i] > c->maxLocs - 1); };
+                // the reader takes batches of exactly 'batch' keys (the last one may be shorter): a batch runs on across slices and shards
+                uint64_t voff = 0;
+                for (uint64_t i = 0; i < nk; ++i) {
+                    const uint32_t sz = sizes[i];
+                    if (kept(i)) {
+                        outK.push_back(keys[i]); outS.push_back((uint8_t)sz);
+                        const size_t at0 = packed.size();
+                        packed.resize(at0 + (size_t)sz * (4 + tb));
+                        for (uint32_t t = 0; t < sz; ++t) {
+                            const uint64_t v = values[voff + t];
+                            const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
+                            uint8_t* at = &packed[at0 + (size_t)t * (4 + tb)];
+                            std::memcpy(at, &win, 4);
+                            if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(at + 4, &t16, 2); }
+                            else std::memcpy(at + 4, &tgt, 4);
+                        }
+                        hdr[1] += sz;
+                        if (outK.size() == batch) flush_batch();
+                    }
+                    voff += sz;
+                }
+            }
         }
+        flush_batch();
+        std::fseek(f, 0, SEEK_SET);
+        wr(f, hdr, 24);
         std::fclose(f);
     }
     return MC_OK;

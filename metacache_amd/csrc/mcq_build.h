@@ -79,6 +79,7 @@ struct BuildOptions {
     uint32_t k = 16, s = 16, w = 127, stride = 0;   // options.hpp:102
     bool resetParents = false, removeOverpopulated = false, saveDb = false;
     int maxLocs = -1, parts = 1, targetIdBytes = 4;
+    int shards = 0;                                 // key shards of the build (0 = from the input size: one device sort takes 2^32 pairs)
     float maxLoadFac = -1;
     int removeAmbigRank = kNumRanks;
 };
@@ -137,6 +138,7 @@ inline BuildOptions parse_build(const std::vector<std::string>& args, bool build
             if (v == "uint16_t" || v == "16") o.targetIdBytes = 2; else if (v == "uint32_t" || v == "32") o.targetIdBytes = 4;
             else throw std::runtime_error("target id type must be uint16_t or uint32_t");
         }
+        else if (a == "-build-shards") o.shards = std::stoi(need(i));          // not a reference option: see BuildOptions::shards
         else if (a == "-threads" && !buildQuery) (void)need(i);               // accepted: sketching and sorting run on the GPU
         else if (buildQuery) queryArgs.push_back(a);
         else throw std::runtime_error("unknown option '" + a + "'");
@@ -319,11 +321,11 @@ struct BuilderError : std::runtime_error { using std::runtime_error::runtime_err
 
 // ---- the built database: builder handle (device arrays) + taxonomy records (non-target taxa, then one taxon per target) ----
 struct BuiltDatabase {
-    mc_builder* b = nullptr;
+    std::vector<mc_builder*> bs;                    // one builder, or one per key shard (all are given every target)
     BuildOptions opt;
     std::vector<Taxon> nonTarget;
     std::vector<Taxon> targets;                     // id = -(target) - 1, rank sequence
-    ~BuiltDatabase() { if (b) mc_build_free(b); }
+    ~BuiltDatabase() { for (mc_builder* b : bs) mc_build_free(b); }
 
     void write() const                              // write_database, building.cpp:546-566
     {
@@ -331,7 +333,7 @@ struct BuiltDatabase {
         if (info) std::cout << "------------------------------------------------\nWriting database to file ... " << std::endl;
         std::vector<mc_taxon_rec> recs(nonTarget.size());
         for (size_t i = 0; i < nonTarget.size(); ++i) recs[i] = mc_taxon_rec{nonTarget[i].id, nonTarget[i].parent, (uint32_t)nonTarget[i].rank, nonTarget[i].name.c_str()};
-        if (mc_build_write(b, opt.dbfile.c_str(), recs.data(), recs.size()) != MC_OK) {
+        if (mc_build_write_shards(const_cast<mc_builder**>(bs.data()), (uint32_t)bs.size(), opt.dbfile.c_str(), recs.data(), recs.size()) != MC_OK) {
             if (info) std::cout << "FAIL" << std::endl;
             std::cerr << "Could not write database file!\n";
             return;
@@ -364,7 +366,22 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
     c.max_locations_per_feature = (uint32_t)std::max(1, std::min(o.maxLocs, 254));
     c.remove_overpopulated = o.removeOverpopulated ? 1 : 0;
     if (o.maxLoadFac > 0.4f && o.maxLoadFac < 0.99f) c.max_load_factor = o.maxLoadFac;
-    if (mc_build_begin(&c, &db.b) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+    // one device sort takes 2^32 (feature, location) pairs: larger inputs are built in key shards (every shard sketches every target
+    // and keeps its share of the features; mc_build_finish_shards / mc_build_write_shards put them together)
+    uint32_t shards = o.shards > 0 ? (uint32_t)o.shards : 1u;
+    if (o.shards <= 0) {
+        uint64_t bytes = 0;
+        for (const auto& f : o.infiles) { struct stat st; if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0 ? 4 : 1); }
+        const uint64_t pairs = bytes / std::max<uint32_t>(o.stride, 1) * o.s;
+        shards = (uint32_t)(pairs / 3000000000ull) + 1;
+    }
+    for (uint32_t i = 0; i < shards; ++i) {
+        mc_builder* b = nullptr;
+        c.key_shard_index = i; c.key_shard_count = shards;
+        if (mc_build_begin(&c, &b) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+        db.bs.push_back(b);
+    }
+    if (info && shards > 1) std::cout << "Building in " << shards << " key shards." << std::endl;
 
     // make_sequence_to_taxon_id_map (taxonomy_io.cpp:290-318)
     std::map<std::string, int64_t> seq2tax;
@@ -409,14 +426,15 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
                 int dupl = 0;
                 while (name2tgt.find(sid) != name2tgt.end()) { ++dupl; sid += "!" + std::to_string(dupl); }
                 const uint32_t tgt = (uint32_t)db.targets.size();
-                if (mc_build_add_target_src(db.b, s.p, s.n, sid.c_str(), parent, filename.c_str(), r) != MC_OK)
-                    throw BuilderError(mc_build_last_error(db.b));
+                for (mc_builder* b : db.bs)
+                    if (mc_build_add_target_src(b, s.p, s.n, sid.c_str(), parent, filename.c_str(), r) != MC_OK)
+                        throw BuilderError(mc_build_last_error(b));
                 if (dupl > 0 && info)
                     std::cerr << "Warning: duplicate sequence id! '" << seqId << "' already in database - '" << filename << "/" << r
                               << "' inserted as '" << sid << "'\n";
                 name2tgt.emplace(sid, tgt);
                 Taxon t; t.id = -(int64_t)tgt - 1; t.parent = parent; t.rank = 0; t.name = sid;
-                mc_build_target_windows(db.b, tgt, &t.windows);
+                mc_build_target_windows(db.bs[0], tgt, &t.windows);
                 db.targets.push_back(std::move(t));
                 if (o.info == BuildOptions::verbose) {
                     std::cerr << "    P0  [" << seqId;
@@ -430,7 +448,7 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
             if (o.info == BuildOptions::verbose) std::cerr << "FAIL: " << e.what() << '\n';
         }
     }
-    if (mc_build_finish(db.b, nullptr) != MC_OK) throw std::runtime_error(mc_build_last_error(db.b));
+    for (mc_builder* b : db.bs) if (mc_build_finish(b, nullptr) != MC_OK) throw std::runtime_error(mc_build_last_error(b));
     if (info)
         std::cout << "Added " << db.targets.size() << " reference sequences in "
                   << std::chrono::duration<double>(clock::now() - t0).count() << " s" << std::endl;
@@ -461,7 +479,7 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
                         auto u = unranked.find((uint32_t)t);
                         if (u != unranked.end()) {
                             db.targets[t].parent = (int64_t)taxid;
-                            mc_build_set_parent(db.b, (uint64_t)t, (int64_t)taxid);
+                            for (mc_builder* b : db.bs) mc_build_set_parent(b, (uint64_t)t, (int64_t)taxid);
                             unranked.erase(u);
                             if (unranked.empty()) break;
                         }

@@ -298,8 +298,9 @@ struct Session {
         tx = Taxonomy{};
         if (built) {
             // add_to_database_and_query (mode_build_query.cpp:41-77): a query context over the builder's arrays
-            if (mc_build_set_query_config(built->b, &c) != MC_OK || mc_build_finish(built->b, &ctx) != MC_OK)
-                throw std::runtime_error(mc_build_last_error(built->b));
+            for (mc_builder* b : built->bs) if (mc_build_set_query_config(b, &c) != MC_OK) throw std::runtime_error(mc_build_last_error(b));
+            if (mc_build_finish_shards(built->bs.data(), (uint32_t)built->bs.size(), &ctx) != MC_OK)
+                throw std::runtime_error(mc_build_last_error(built->bs[0]));
             tx.taxa = built->nonTarget;
             tx.taxa.insert(tx.taxa.end(), built->targets.begin(), built->targets.end());
         } else {

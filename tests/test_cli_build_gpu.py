@@ -108,6 +108,31 @@ def test_build_writes_the_reference_database(case, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["default", "overpopulated", "u16"])
+def test_build_in_key_shards_writes_the_same_database(case, tmp_path):
+    """-build-shards 3: three builders keep a third of the features each (what inputs beyond 2^32 (feature, location) pairs get
+    automatically); mc_build_write_shards puts them into one file set with the content of the reference's database"""
+    build.build_library()
+    c = EXP["build"][case]
+    db = str(tmp_path / case)
+    r = subprocess.run([build.MCQ, "build", db] + c["args"] + c["mcq_extra"] + ["-build-shards", "3"], cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "3 key shards" in r.stdout
+    same_db(parse_db(db), c["db"], case)
+
+
+@pytest.mark.gpu
+def test_build_query_in_key_shards(tmp_path):
+    build.build_library()
+    c = EXP["bq"]["bq_species"]
+    out = tmp_path / "bq.txt"
+    r = subprocess.run([build.MCQ, "build+query"] + c["args"] + ["-build-shards", "2", "-threads", "1", "-out", str(out)],
+                       cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    _same(out.read_text().split("\n"), c["lines"], "bq_species/shards")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(EXP["bq"]))
 def test_build_query_in_memory(case, tmp_path):
     """build+query: the table is filled from the builder's device arrays, no database file in between (-save-db writes one afterwards)"""
