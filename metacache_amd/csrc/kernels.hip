@@ -1516,16 +1516,28 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     bool over = false;
     uint32_t gnent = 0, goff = 0;                                // hand-over area: entries written, locations they stand for
     // hand-over entry j = (size | start offset in the list << 16, payload); found features only, singletons first
+    // entries written by the lane itself go out two at a time (8 + 16 bytes): every store of a lane is a request of its own
+    uint32_t heldSize = 0; uint64_t heldPay = 0;                 // the even entry of the pair being formed
+    const bool pairs = (fbase & 1u) == 0;
+    auto put_entry = [&](uint32_t ps, uint64_t pp) {
+        if (!pairs) { ws.psize[fbase + gnent] = ps; ws.ppay[fbase + gnent] = pp; }
+        else if ((gnent & 1u) == 0) { heldSize = ps; heldPay = pp; }
+        else {
+            *reinterpret_cast<uint2*>(ws.psize + fbase + gnent - 1) = make_uint2(heldSize, ps);
+            *reinterpret_cast<uint4*>(ws.ppay + fbase + gnent - 1) = make_uint4((uint32_t)heldPay, (uint32_t)(heldPay >> 32), (uint32_t)pp, (uint32_t)(pp >> 32));
+        }
+        ++gnent;
+    };
+    auto flush_entries = [&]() { if (pairs && (gnent & 1u)) { ws.psize[fbase + gnent - 1] = heldSize; ws.ppay[fbase + gnent - 1] = heldPay; } };
     auto dump_row = [&]() {
-        for (uint32_t j = 0; j < n; ++j) { ws.psize[fbase + j] = 1u | (j << 16); ws.ppay[fbase + j] = L[j]; }
+        for (uint32_t j = 0; j < n; ++j) put_entry(1u | (j << 16), L[j]);
         goff = n;
         for (uint32_t i = 0; i < m; ++i) {
             const uint64_t d = L[kLaneHits - i];
             const uint32_t size = (uint32_t)(d >> 48);
-            ws.psize[fbase + n + i] = size | (goff << 16); ws.ppay[fbase + n + i] = d & 0xFFFFFFFFFFFFull;
+            put_entry(size | (goff << 16), d & 0xFFFFFFFFFFFFull);
             goff += size;
         }
-        gnent = n + m;
     };
     // the lane's features arrive four at a time (s % 4 == 0: sketches are 16-byte aligned): every lane reads its own line, so what
     // counts is the number of requests, not their width
@@ -1573,8 +1585,8 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                         // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
                         if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // row full (pairs, rich tables): it moves to
                         if (over) {                                                      // the hand-over area, later entries go there directly
-                            ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
-                            ++gnent; goff += size;
+                            put_entry(size | (goff << 16), pay);
+                            goff += size;
                         }
                         else if (size == 1) L[n++] = pay;
                         else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
@@ -1652,8 +1664,8 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                         // size << 48, kept at the END of the row, growing downwards) and fetched after the lookups
                         if (!over && n + m >= kLaneHits) { dump_row(); over = true; }   // row full (pairs, rich tables): it moves to
                         if (over) {                                                      // the hand-over area, later entries go there directly
-                            ws.psize[fbase + gnent] = size | (goff << 16); ws.ppay[fbase + gnent] = pay;
-                            ++gnent; goff += size;
+                            put_entry(size | (goff << 16), pay);
+                            goff += size;
                         }
                         else if (size == 1) L[n++] = pay;
                         else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
@@ -1669,6 +1681,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
             }
         }
     }
+    if (over) flush_entries();
     if (valid) { QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps; ws.qstat[q] = qs; }
     // Lists too long for a lane go to the mid / wave kernels as (size | list offset << 16, payload) per found feature, straight from
     // the row -- no second round of lookups.  Rows that are still in LDS are written out by the WAVE: row after row, one lane per
