@@ -1341,6 +1341,8 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
         const uint32_t fbase = w0 * s, nf = valid ? (w1 - w0) * s : 0u;
         const uint32_t* feats = ws.features + fbase;
         uint32_t e = 0;
+        uint4 fcache = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        const bool wide = (s & 3u) == 0;
         uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU], slot[kLaneU];
         QuadRaw raw[kLaneU];
         bool busy[kLaneU];
@@ -1380,7 +1382,11 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
             for (uint32_t u = 0; u < kLaneU; ++u) {
                 while (!busy[u] && e < nf) {
                     slot[u] = e;
-                    f[u] = feats[e++];
+                    if (wide) {                                   // four features per request
+                        if ((e & 3u) == 0) fcache = reinterpret_cast<const uint4*>(feats)[e >> 2];
+                        const uint32_t i4 = e++ & 3u;
+                        f[u] = i4 == 0 ? fcache.x : i4 == 1 ? fcache.y : i4 == 2 ? fcache.z : fcache.w;
+                    } else f[u] = feats[e++];
                     if (f[u] != 0xFFFFFFFFu) {
                         home[u] = home_group(f[u], tab.nbuckets);
                         cur[u] = home[u]; step[u] = 1;
