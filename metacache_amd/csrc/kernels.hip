@@ -1318,7 +1318,10 @@ __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchPa
         const uint32_t len = min(qi.y - p0, kChunkWins * sp.stride + sp.k - 1);
         uint32_t wcount = 0; bool dup = false;
         const uint32_t w0 = ws.winOff[q] + c * kChunkWins, w1 = min(ws.winOff[q + 1], w0 + kChunkWins);
-        for (uint32_t i = w0 * sp.s; i < w1 * sp.s; ++i) ws.psize[i] = 0u;        // chunk_probe_kernel writes the found features only
+        if ((sp.s & 3u) == 0) {                                                    // chunk_probe_kernel writes the found features only
+            uint4* z = reinterpret_cast<uint4*>(ws.psize + (size_t)w0 * sp.s);
+            for (uint32_t i = 0; i < (w1 - w0) * sp.s / 4; ++i) z[i] = make_uint4(0, 0, 0, 0);
+        } else for (uint32_t i = w0 * sp.s; i < w1 * sp.s; ++i) ws.psize[i] = 0u;
         if (sp.k == 16 && (sp.stride & 15u) == 0) lane_sketch_span16(b.seq, (uint64_t)qi.x + p0, len, sp.s, sp.stride, ws.features + (size_t)w0 * sp.s, wcount, dup);
         else lane_sketch_span(b.seq, (uint64_t)qi.x + p0, len, sp.k, sp.s, sp.stride, ws.features + (size_t)w0 * sp.s, wcount, dup);
         if (dup) ws.qflag[q] = kFlagSketch;                                         // the wave kernel redoes the whole read
