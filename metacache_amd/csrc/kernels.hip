@@ -1059,7 +1059,10 @@ constexpr uint32_t kLaneHits = MC_LANE_HITS;  // longest location list handled b
                                               // probe_cands_kernel (LDS): 32 -> 8 waves/CU, 24 -> 12, 20 -> 14; measured on configs[1]
                                               // (mean list 15.8): 44.3 / 48.6 / 49.5 / 41.1 G reads/min for 32 / 24 / 20 / 16
 constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
-constexpr uint32_t kLaneU = 4;            // lookups in flight per lane
+#ifndef MC_LANE_U
+#define MC_LANE_U 2
+#endif
+constexpr uint32_t kLaneU = MC_LANE_U;    // lookups in flight per lane
 constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
 constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: longest list, entries, maxWindowsInRange
 
