@@ -2377,6 +2377,26 @@ void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab,
         else        hipLaunchKernelGGL((hash_cands_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
     }
 }
+// after the lane kernels: how many queries are left for the wave kernels (midCount[6]: to be sketched, [7]: candidates from a list in
+// HBM).  The host reads the eight counters once and launches only the kernels that have work -- a batch of 65 536 short reads spent
+// a fifth of its device time on launches of kernels with nothing to do.
+__global__ __launch_bounds__(256) void flag_count_kernel(const uint32_t* __restrict__ qflag, uint32_t n, uint32_t* __restrict__ counts)
+{
+    uint32_t a = 0, c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t f = qflag[i];
+        a += f == kFlagSketch; c += f == kFlagCands;
+    }
+    const uint64_t ma = __ballot(a != 0), mc = __ballot(c != 0);
+    if (ma) { for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off); if ((threadIdx.x & 63) == 0) atomicAdd(&counts[6], a); }
+    if (mc) { for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off); if ((threadIdx.x & 63) == 0) atomicAdd(&counts[7], c); }
+}
+
+void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(flag_count_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), dim3(256), 0, st, ws.qflag, n, ws.midCount);
+}
+
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
 bool lane_candidates_supported(uint32_t maxCand) { return maxCand <= kLaneK; }
 
