@@ -2233,129 +2233,149 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
         recNext = load_rec(w + 2 * nWaves);
         load_entries(rec);
         wave_lds_sync();
-        // ---- 1. gather (lane: per consecutive list elements, one search, then a walk -- as mid_cands_kernel; handing element i to
-        //      lane i % 64 makes a wave's loads coalesce, but costs a search per element and was not faster) and count
-        const uint32_t per = (H + 63u) / 64u, i0 = lane * per;
-        uint64_t v[kPer];
-        {
-            uint32_t lo = 0, hi = nent;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (entOff[mid] <= i0) lo = mid; else hi = mid; }
-            uint32_t e = lo;
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) {
-                const uint32_t i = i0 + r;
-                v[r] = kEmpty;
-                if (r < per && i < H) {
-                    while (entOff[e + 1] <= i) ++e;
-                    const uint64_t pay = entPay[e];
-                    const uint32_t first = entOff[e];
-                    v[r] = entOff[e + 1] - first == 1 ? pay : tab.values[pay + (i - first)];
-                }
-            }
-        }
-        uint32_t slot[kPer];                                       // slot | claimed << 31
-        {
-            unsigned long long old[kPer];
-            bool coll = false;
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) {
-                slot[r] = hash_slot<LOG2S>(v[r]);
-                old[r] = v[r] != kEmpty ? atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot[r]]), (unsigned long long)kEmpty, (unsigned long long)v[r]) : v[r];
-                coll = coll || (old[r] != kEmpty && old[r] != v[r]);
-            }
-            if (__ballot(coll)) {                                  // somebody else's key in the home slot: next slots, one at a time
-#pragma unroll
-                for (uint32_t r = 0; r < kPer; ++r) {
-                    if (old[r] != kEmpty && old[r] != v[r]) {
-                        uint32_t sl = slot[r];
-                        for (;;) {
-                            sl = (sl + 1) & kMask;
-                            old[r] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
-                            if (old[r] == kEmpty || old[r] == v[r]) break;
-                        }
-                        slot[r] = sl;
+        // the lane's share of the list: per elements.  The rest of the query is instantiated for a few values of PER >= per, so that the
+        // unrolled per-element code is not run for slots no lane fills (289 locations = 5 per lane; at PER = 8 the wave spent 40 % of
+        // its instructions on empty slots)
+        const uint32_t per = (H + 63u) / 64u;
+        auto body = [&](auto perc) {
+            constexpr uint32_t PER = decltype(perc)::value;
+            // ---- 1. gather (lane: per consecutive list elements, one search, then a walk -- as mid_cands_kernel; handing element i to
+            //      lane i % 64 makes a wave's loads coalesce, but costs a search per element and was not faster) and count
+            const uint32_t i0 = lane * per;
+            uint64_t v[PER];
+            {
+                uint32_t lo = 0, hi = nent;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (entOff[mid] <= i0) lo = mid; else hi = mid; }
+                uint32_t e = lo;
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) {
+                    const uint32_t i = i0 + r;
+                    v[r] = kEmpty;
+                    if (r < per && i < H) {
+                        while (entOff[e + 1] <= i) ++e;
+                        const uint64_t pay = entPay[e];
+                        const uint32_t first = entOff[e];
+                        v[r] = entOff[e + 1] - first == 1 ? pay : tab.values[pay + (i - first)];
                     }
                 }
             }
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) {
-                if (v[r] != kEmpty) atomicAdd(&cnts[slot[r] >> 1], 1u << (16u * (slot[r] & 1u)));
-                slot[r] |= (v[r] != kEmpty && old[r] == kEmpty) ? 0x80000000u : 0u;
-            }
-        }
-        wave_lds_sync();
-        // ---- 2. ranges that end in the windows this lane claimed: hits | (end - begin) << 16
-        uint32_t ptax[kPer];
-        if constexpr (TAX) {
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[(uint32_t)(v[r] >> 32) & tab.tgtMask] : 0u;
-        }
-        uint32_t T[kPer];
-#pragma unroll
-        for (uint32_t r = 0; r < kPer; ++r) T[r] = (slot[r] >> 31) ? count_of(slot[r] & kMask) : 0u;
-        for (uint32_t d = 1; d < maxWin; ++d) {
-            uint64_t k[kPer]; uint32_t sl[kPer];
-            bool chain = false;
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) {
-                sl[r] = hash_slot<LOG2S>(v[r] - d);
-                k[r] = keys[sl[r]];
-                const bool live = (slot[r] >> 31) && (uint32_t)v[r] >= d;
-                if (!live) { k[r] = kEmpty; sl[r] = 0xFFFFFFFFu; }   // (target 0, window < d: v - d would equal the empty key)
-                chain = chain || (live && k[r] != v[r] - d && k[r] != kEmpty);
-            }
-            if (__ballot(chain)) {
-#pragma unroll
-                for (uint32_t r = 0; r < kPer; ++r)
-                    while (sl[r] != 0xFFFFFFFFu && k[r] != v[r] - d && k[r] != kEmpty) { sl[r] = (sl[r] + 1) & kMask; k[r] = keys[sl[r]]; }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) {
-                const uint32_t c = count_of(sl[r] & kMask);
-                if (sl[r] != 0xFFFFFFFFu && k[r] == v[r] - d) T[r] = ((T[r] & 0xFFFFu) + c) | (d << 16);
-            }
-        }
-        // ---- 3. K rounds: every lane offers the best of its ranges whose target / taxon has not been picked yet, the wave takes the
-        //      maximum under (hits desc, target asc, window asc) and strikes that target / taxon everywhere
-        uint32_t live = 0;                                         // bit r: this lane's range r is still in the race
-#pragma unroll
-        for (uint32_t r = 0; r < kPer; ++r) {
-            bool ok = (slot[r] >> 31) != 0;
-            if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
-            live |= ok ? (1u << r) : 0u;
-        }
-        mc_candidate_dev* out = cands + (size_t)q * K;
-        for (uint32_t rnd = 0; rnd < K; ++rnd) {
-            uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < kPer; ++r) {
-                const uint32_t t = (uint32_t)(v[r] >> 32), win = (uint32_t)v[r];
-                const uint64_t ck = ((uint64_t)(T[r] & 0xFFFFu) << 32) | (uint32_t)~t;
-                const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
-                if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
-            }
-            uint64_t m = hk;
-#pragma unroll
-            for (uint32_t off = 32; off > 0; off >>= 1) {
-                const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
-                m = o > m ? o : m;
-            }
-            mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
-            if (m != 0) {
-                uint32_t wm = hk == m ? hw : 0xFFFFFFFFu;
-#pragma unroll
-                for (uint32_t off = 32; off > 0; off >>= 1) wm = min(wm, __shfl_xor(wm, off));
-                const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
-                const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
-#pragma unroll
-                for (uint32_t r = 0; r < kPer; ++r) {
-                    uint32_t gr;
-                    if constexpr (TAX) gr = ptax[r]; else gr = (uint32_t)(v[r] >> 32);
-                    if (gr == g) live &= ~(1u << r);
+            uint32_t slot[PER];                                       // slot | claimed << 31
+            {
+                unsigned long long old[PER];
+                bool coll = false;
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) {
+                    slot[r] = hash_slot<LOG2S>(v[r]);
+                    old[r] = v[r] != kEmpty ? atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot[r]]), (unsigned long long)kEmpty, (unsigned long long)v[r]) : v[r];
+                    coll = coll || (old[r] != kEmpty && old[r] != v[r]);
                 }
-                e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
+                if (__ballot(coll)) {                                  // somebody else's key in the home slot: next slots, one at a time
+    #pragma unroll
+                    for (uint32_t r = 0; r < PER; ++r) {
+                        if (old[r] != kEmpty && old[r] != v[r]) {
+                            uint32_t sl = slot[r];
+                            for (;;) {
+                                sl = (sl + 1) & kMask;
+                                old[r] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
+                                if (old[r] == kEmpty || old[r] == v[r]) break;
+                            }
+                            slot[r] = sl;
+                        }
+                    }
+                }
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) {
+                    if (v[r] != kEmpty) atomicAdd(&cnts[slot[r] >> 1], 1u << (16u * (slot[r] & 1u)));
+                    slot[r] |= (v[r] != kEmpty && old[r] == kEmpty) ? 0x80000000u : 0u;
+                }
             }
-            if (lane == 0) out[rnd] = e;
+            wave_lds_sync();
+            // ---- 2. ranges that end in the windows this lane claimed: hits | (end - begin) << 16
+            uint32_t ptax[PER];
+            if constexpr (TAX) {
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[(uint32_t)(v[r] >> 32) & tab.tgtMask] : 0u;
+            }
+            uint32_t T[PER];
+    #pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) T[r] = (slot[r] >> 31) ? count_of(slot[r] & kMask) : 0u;
+            for (uint32_t d = 1; d < maxWin; ++d) {
+                uint64_t k[PER]; uint32_t sl[PER];
+                bool chain = false;
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) {
+                    sl[r] = hash_slot<LOG2S>(v[r] - d);
+                    k[r] = keys[sl[r]];
+                    const bool live = (slot[r] >> 31) && (uint32_t)v[r] >= d;
+                    if (!live) { k[r] = kEmpty; sl[r] = 0xFFFFFFFFu; }   // (target 0, window < d: v - d would equal the empty key)
+                    chain = chain || (live && k[r] != v[r] - d && k[r] != kEmpty);
+                }
+                if (__ballot(chain)) {
+    #pragma unroll
+                    for (uint32_t r = 0; r < PER; ++r)
+                        while (sl[r] != 0xFFFFFFFFu && k[r] != v[r] - d && k[r] != kEmpty) { sl[r] = (sl[r] + 1) & kMask; k[r] = keys[sl[r]]; }
+                }
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) {
+                    const uint32_t c = count_of(sl[r] & kMask);
+                    if (sl[r] != 0xFFFFFFFFu && k[r] == v[r] - d) T[r] = ((T[r] & 0xFFFFu) + c) | (d << 16);
+                }
+            }
+            // ---- 3. K rounds: every lane offers the best of its ranges whose target / taxon has not been picked yet, the wave takes the
+            //      maximum under (hits desc, target asc, window asc) and strikes that target / taxon everywhere
+            uint32_t live = 0;                                         // bit r: this lane's range r is still in the race
+    #pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) {
+                bool ok = (slot[r] >> 31) != 0;
+                if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
+                live |= ok ? (1u << r) : 0u;
+            }
+            mc_candidate_dev* out = cands + (size_t)q * K;
+            for (uint32_t rnd = 0; rnd < K; ++rnd) {
+                uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
+    #pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) {
+                    const uint32_t t = (uint32_t)(v[r] >> 32), win = (uint32_t)v[r];
+                    const uint64_t ck = ((uint64_t)(T[r] & 0xFFFFu) << 32) | (uint32_t)~t;
+                    const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
+                    if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
+                }
+                uint64_t m = hk;
+    #pragma unroll
+                for (uint32_t off = 32; off > 0; off >>= 1) {
+                    const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
+                    m = o > m ? o : m;
+                }
+                mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+                if (m != 0) {
+                    uint32_t wm = hk == m ? hw : 0xFFFFFFFFu;
+    #pragma unroll
+                    for (uint32_t off = 32; off > 0; off >>= 1) wm = min(wm, __shfl_xor(wm, off));
+                    const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
+                    const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
+    #pragma unroll
+                    for (uint32_t r = 0; r < PER; ++r) {
+                        uint32_t gr;
+                        if constexpr (TAX) gr = ptax[r]; else gr = (uint32_t)(v[r] >> 32);
+                        if (gr == g) live &= ~(1u << r);
+                    }
+                    e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
+                }
+                if (lane == 0) out[rnd] = e;
+            }
+        };
+        if constexpr (kPer == 8) {
+            switch (per) {
+                case 5: body(std::integral_constant<uint32_t, 5>{}); break;
+                case 6: body(std::integral_constant<uint32_t, 6>{}); break;
+                case 7: body(std::integral_constant<uint32_t, 7>{}); break;
+                default: body(std::integral_constant<uint32_t, 8>{}); break;
+            }
+        } else {
+            if (per <= kPer * 5 / 8) body(std::integral_constant<uint32_t, kPer * 5 / 8>{});
+            else if (per <= kPer * 6 / 8) body(std::integral_constant<uint32_t, kPer * 6 / 8>{});
+            else if (per <= kPer * 7 / 8) body(std::integral_constant<uint32_t, kPer * 7 / 8>{});
+            else body(std::integral_constant<uint32_t, kPer>{});
         }
         if (lane == 0) ws.qflag[q] = kFlagDone;
         wave_lds_sync();
