@@ -213,7 +213,7 @@ int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256",
- * "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
+ * "hash_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);
 int mc_timing_reset(mc_ctx* ctx);
 int mc_timing_get(mc_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);

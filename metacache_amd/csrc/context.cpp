@@ -521,7 +521,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 32 + (size_t)5 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)6 * std::max<uint32_t>(n, 1) * 16))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -534,7 +534,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
     ws.scanTmp = P.bScan.p; ws.stats = (uint64_t*)P.bStats.p;
     if (lanePath) {
-        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 8;
+        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
         ws.chunkList = (uint2*)P.bChunkList.p;
     }
 
@@ -552,7 +552,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     bool waveWork = true;                                        // wave kernels needed (always without the lane path)
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
-        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 32, st));
+        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 64, st));
         if (ctx->fuseLane) {
             ScopedTimer t(ctx, "sketch_probe", st);
             launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, st);
@@ -564,18 +564,19 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         }
         // small batches take one look at the work lists and launch only the kernels with work (a launch costs as much as such a
         // batch's kernel: 0.37 -> 0.32 ms per 65 536 reads); large ones skip the round trip and launch everything
-        uint32_t all[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        uint32_t all[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         uint32_t* hcnt = all;
         if (n <= (1u << 20)) {
-            if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 64));
+            if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
             hcnt = reinterpret_cast<uint32_t*>(P.hTotal + 1);
             launch_flag_count(ws, n, st);
-            HIP_TRY(ctx, hipMemcpyAsync(hcnt, ws.midCount, 32, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(hcnt, ws.midCount, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipStreamSynchronize(st));
         }
         if (hcnt[0]) { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[1]) { ScopedTimer t(ctx, "mid_cands_128", st); launch_mid_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[2]) { ScopedTimer t(ctx, "mid_cands_256", st); launch_mid_cands(2, b, tab, ws, K, taxkey, P.bCands.p, st); }
+        if (hcnt[8]) { ScopedTimer t(ctx, "hash_cands_256", st); launch_hash_cands(5, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[3]) { ScopedTimer t(ctx, "hash_cands_512", st); launch_hash_cands(3, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[4]) { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
         waveWork = hcnt[6] != 0 || hcnt[7] != 0;
@@ -594,7 +595,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
         }
         // how many locations need a segment in HBM
-        if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 64));
+        if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
         HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         totalHits = *P.hTotal;

@@ -105,9 +105,9 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint32_t* qflag;         // [n]        0 = done, 1 = needs sketch+probe (wave), 2 = needs candidates (wave),
                              //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel,
                              //            6 = long read handled by the chunk lane kernels
-    uint32_t* midCount;      // [8]        lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
+    uint32_t* midCount;      // [16]; [8] = third work list of hash_cands_kernel (129..256);       lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
     uint2*    chunkList;     // [W + n]    {query, chunk}: long single reads, cut into one-window chunks for the chunk lane kernels
-    uint32_t* midList;       // [5][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
+    uint32_t* midList;       // [6][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations

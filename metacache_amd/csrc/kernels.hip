@@ -1741,17 +1741,20 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
         // ... and of hash_cands_kernel (257 .. 1024 locations, one wave per query, no sort); longer ones, wide window ranges -> wave kernel
         const uint32_t mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? 2u : (H <= kHashMax && nent <= kHashEnt && mw <= kHashWin) ? (H <= kHashMax / 2 ? 3u : 4u) : 5u;
-        ws.qflag[q] = cls < 5 ? kFlagMid : kFlagCands;
-        if (cls == 3 || cls == 4) ws.hitScan[q] = 0u;                        // no segment in HBM
+        // work list slots: 0 / 1 / 2 mid_cands (64 / 128 / 256), 3 / 4 / 5 hash_cands (512 / 1024 / 256), 6 = wave kernel.  From 129 locations
+        // on counting beats sorting (measured per list: 3.3 vs 4.7 ns at 129..256); below, the register sort wins (1.6 vs 2 ns)
+        const bool hashOK = nent <= kHashEnt && mw <= kHashWin;
+        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
+        ws.qflag[q] = cls < 6 ? kFlagMid : kFlagCands;
+        if (cls >= 3 && cls <= 5) ws.hitScan[q] = 0u;                            // no segment in HBM
         const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-        for (uint32_t c = 0; c < 5; ++c) {
+        for (uint32_t c = 0; c < 6; ++c) {
             const uint64_t mask = __ballot(cls == c);
             if (cls == c) {
                 const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&ws.midCount[c], (uint32_t)__popcll(mask));
+                if (lane == leader) base = atomicAdd(&ws.midCount[c < 5 ? c : 8u], (uint32_t)__popcll(mask));
                 base = __shfl(base, leader);
                 reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 12), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
             }
@@ -2195,7 +2198,7 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
     uint32_t* cnts = cntS[wave];
     uint64_t* entPay = entPayS[wave];
     uint32_t* entOff = entOffS[wave];
-    const uint32_t total = ws.midCount[cls];
+    const uint32_t total = ws.midCount[cls < 5 ? cls : 8u];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)cls * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
@@ -2364,7 +2367,9 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
                 if (lane == 0) out[rnd] = e;
             }
         };
-        if constexpr (kPer == 8) {
+        if constexpr (kPer == 4) {
+            if (per <= 3) body(std::integral_constant<uint32_t, 3>{}); else body(std::integral_constant<uint32_t, 4>{});
+        } else if constexpr (kPer == 8) {
             switch (per) {
                 case 5: body(std::integral_constant<uint32_t, 5>{}); break;
                 case 6: body(std::integral_constant<uint32_t, 6>{}); break;
@@ -2386,15 +2391,19 @@ void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab,
                        hipStream_t st)
 {
     if (b.n == 0) return;
-    // persistent grids; 3 blocks fit a CU either way (52 / 50 KB of LDS)
+    // persistent grids; LDS per block: 52 KB (512), 50 KB (1024), 40 KB (256)
     if (cls == 3) {
         const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 3) / 4);
         if (taxkey) hipLaunchKernelGGL((hash_cands_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
         else        hipLaunchKernelGGL((hash_cands_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
-    } else {
+    } else if (cls == 4) {
         const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 1) / 2);
         if (taxkey) hipLaunchKernelGGL((hash_cands_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
         else        hipLaunchKernelGGL((hash_cands_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+    } else {
+        const uint32_t grid = std::min<uint32_t>(256 * 4, (b.n + 3) / 4);
+        if (taxkey) hipLaunchKernelGGL((hash_cands_kernel<9, 4, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
+        else        hipLaunchKernelGGL((hash_cands_kernel<9, 4, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
     }
 }
 // after the lane kernels: how many queries are left for the wave kernels (midCount[6]: to be sketched, [7]: candidates from a list in

@@ -118,7 +118,7 @@ def main():
         step(i)
     el = time.perf_counter() - t0
     db.timing(False)
-    kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates")}
+    kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates")}
     st = db.last_batch_stats()
     c = out.cpu().numpy().view(np.uint32).reshape(B, K, 4)
     res["query"] = {"reads_per_step": B, "steps": args.steps, "ms_per_step": round(el / args.steps * 1e3, 3),

@@ -66,7 +66,7 @@ def run(db, seq, qinfo, max_win, n, nchars, K, steps):
         step()
     el = (time.perf_counter() - t0) / steps
     db.timing(False)
-    names = ("plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates")
+    names = ("plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates")
     kt = {k: db.timing_get(k) for k in names}
     st = db.last_batch_stats()
     c = out.cpu().numpy().view(np.uint32)
