@@ -1744,7 +1744,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // work list slots: 0 / 1 / 2 mid_cands (64 / 128 / 256), 3 / 4 / 5 hash_cands (512 / 1024 / 256), 6 = wave kernel.  From 129 locations
         // on counting beats sorting (measured per list: 3.3 vs 4.7 ns at 129..256); below, the register sort wins (1.6 vs 2 ns)
         const bool hashOK = nent <= kHashEnt && mw <= kHashWin;
-        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? 1u : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
+        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
         ws.qflag[q] = cls < 6 ? kFlagMid : kFlagCands;
         if (cls >= 3 && cls <= 5) ws.hitScan[q] = 0u;                            // no segment in HBM
         const uint32_t lane = threadIdx.x & 63u;
@@ -2368,7 +2368,7 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
             }
         };
         if constexpr (kPer == 4) {
-            if (per <= 3) body(std::integral_constant<uint32_t, 3>{}); else body(std::integral_constant<uint32_t, 4>{});
+            if (per <= 2) body(std::integral_constant<uint32_t, 2>{}); else if (per <= 3) body(std::integral_constant<uint32_t, 3>{}); else body(std::integral_constant<uint32_t, 4>{});
         } else if constexpr (kPer == 8) {
             switch (per) {
                 case 5: body(std::integral_constant<uint32_t, 5>{}); break;
