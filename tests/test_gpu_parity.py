@@ -265,8 +265,10 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad
     db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 12, slot_max_chars=1 << 21)
     cands, counts, _ = db.query(reads, lowest=lowest)
     pc, pcounts, _ = db.query(reads[:1500], mates, lowest=lowest, insert_max=400)
+    # window ranges wider than 8 (insert size 1200 => 12 windows): the counting kernel refuses, lists up to 256 are sorted in registers
+    pw, _, _ = db.query(reads[:1500], mates, lowest=lowest, insert_max=1200)
     db.close()
-    assert 0.5 < np.mean((counts > 32) & (counts <= 256))          # most reads take the mid path
+    assert 0.5 < np.mean((counts > 32) & (counts <= 256))          # most reads take the mid / counting path
     assert np.any((counts > 32) & (counts <= 64)) and np.any((counts > 64) & (counts <= 128)) and np.any(counts > 128)
 
     def check(got, i, a, b, ins):
@@ -282,6 +284,7 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad
         check(cands, i, reads[i], b"", 0)
     for i in range(1500):
         check(pc, i, reads[i], mates[i], 400)
+        check(pw, i, reads[i], mates[i], 1200)
     odb.close()
 
 
