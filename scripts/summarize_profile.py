@@ -18,7 +18,8 @@ def short(k):
     if "query_kernel<false>" in k: return "query_kernel<unfused>"
     if "sketch_probe_lane" in k: return "sketch_probe_lane"
     if "mid_cands_kernel" in k: return "mid_cands"
-    for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs"):
+    if "hash_cands_kernel" in k: return "hash_cands"
+    for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs", "chunk_sketch", "chunk_probe", "chunk_finish", "flag_count", "table_seal"):
         if n in k: return n
     return None
 
