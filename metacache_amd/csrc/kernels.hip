@@ -2175,9 +2175,7 @@ void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, 
 template <uint32_t LOG2S>
 __device__ __forceinline__ uint32_t hash_slot(uint64_t v)
 {
-    uint32_t h = (uint32_t)v * 0x9E3779B1u ^ (uint32_t)(v >> 32) * 0x85EBCA77u;
-    h ^= h >> 15; h *= 0x2C1B3C6Du;
-    return h >> (32 - LOG2S);
+    return ((uint32_t)v * 0x9E3779B1u + (uint32_t)(v >> 32) * 0x85EBCA77u) >> (32 - LOG2S);   // multiplicative: the high bits
 }
 
 // LOG2S: log2 of the table slots; lists of up to 2^(LOG2S-1) locations (class 3: 512 in 1024 slots, 4 waves per block; class 4: 1024
