@@ -249,6 +249,15 @@ int  mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const
                              const char* source_filename, uint64_t source_index);
 /* re-ranks a target after it was added (try_to_rank_unranked_targets, building.cpp:196-232) */
 int  mc_build_set_parent(mc_builder* b, uint64_t target, int64_t parent_taxid);
+/* after mc_build_finish: features and locations the builder holds (database::feature_count / location_count, database.hpp:420-440) */
+int  mc_build_counts(const mc_builder* b, uint64_t* keys, uint64_t* values);
+/* After mc_build_finish: drops every feature whose locations lie in more than max_ambig (0 => 1) different taxa on one rank
+ * (-remove-ambig-features <rank> -max-ambig-per-feature <n>: database.hpp:259-270, host_hashmap.hpp:499-540, called from
+ * post_process_features, building.cpp:550-566).  ancestor_of_target[t] = any id of target t's ancestor on that rank, 0 = none
+ * (all targets without one count as ONE taxon, as the reference's null pointer does); rank 'sequence': t + 1.  Key-sharded
+ * builders: call it on every shard.  *removed (may be NULL) = number of features dropped. */
+int  mc_build_remove_ambiguous(mc_builder* b, const uint32_t* ancestor_of_target, uint64_t num_targets, uint32_t max_ambig,
+                               uint64_t* removed);
 /* number of windows of a target (taxon::file_source::windows, database.cpp:64) */
 int  mc_build_target_windows(const mc_builder* b, uint64_t target, uint64_t* windows);
 /* sorts + bucketises everything added so far; if out_ctx != NULL also loads the table into a fresh

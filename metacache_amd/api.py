@@ -54,7 +54,7 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
-           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
+           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
 
 _lib = None
@@ -351,6 +351,22 @@ class Builder:
         cfg = McConfig.from_buffer_copy(builders[0].cfg)
         cfg.key_shard_index, cfg.key_shard_count = 0, 1
         return Database.from_handle(out.value, cfg)
+
+    def counts(self) -> tuple[int, int]:
+        """(features, locations) held after finish (mc_build_counts)"""
+        k, v = C.c_uint64(), C.c_uint64()
+        lib().mc_build_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self._check(lib().mc_build_counts(self.h, C.byref(k), C.byref(v)))
+        return k.value, v.value
+
+    def remove_ambiguous(self, ancestor_of_target: np.ndarray, max_ambig: int = 1) -> int:
+        """-remove-ambig-features after finish(load=False): ancestor_of_target[t] = id of target t's taxon on the chosen rank (0 = none).
+        Returns the number of features dropped (mc_build_remove_ambiguous)."""
+        a = np.ascontiguousarray(ancestor_of_target, dtype=np.uint32)
+        rem = C.c_uint64()
+        lib().mc_build_remove_ambiguous.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+        self._check(lib().mc_build_remove_ambiguous(self.h, a.ctypes.data_as(C.c_void_p), a.size, max_ambig, C.byref(rem)))
+        return rem.value
 
     def _sync_cfg(self):
         lib().mc_build_set_query_config.argtypes = [C.c_void_p, C.POINTER(McConfig)]

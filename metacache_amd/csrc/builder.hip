@@ -111,6 +111,56 @@ __global__ __launch_bounds__(256) void compact_values_kernel(const uint64_t* __r
     for (uint32_t t = 0; t < k; ++t) out[dst + t] = sorted[src + t];
 }
 
+// -remove-ambig-features (host_hashmap.hpp:499-540): a feature whose locations lie in more than maxAmbig different taxa on the chosen
+// rank goes.  anc[target] = the target's ancestor on that rank (0 = none: counts as one taxon like the reference's null pointer;
+// rank 'sequence': the target itself).  One thread per feature; targets come sorted, so runs of one target cost one comparison.
+__global__ __launch_bounds__(256) void ambig_flags_kernel(const uint64_t* __restrict__ vals, const uint64_t* __restrict__ voff,
+                                                          const uint8_t* __restrict__ sizes, uint32_t nkeys,
+                                                          const uint32_t* __restrict__ anc, uint32_t maxAmbig,
+                                                          uint32_t* __restrict__ keep, uint32_t* __restrict__ keepSize)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nkeys) return;
+    const uint64_t* v = vals + voff[i];
+    const uint32_t sz = sizes[i];
+    uint32_t distinct = 0, prevTgt = 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < sz && distinct <= maxAmbig; ++t) {
+        const uint32_t tgt = (uint32_t)(v[t] >> 32);
+        if (tgt == prevTgt) continue;
+        prevTgt = tgt;
+        const uint32_t a = anc[tgt];
+        bool seen = false;
+        for (uint32_t j = 0; j < t && !seen; ++j) seen = anc[(uint32_t)(v[j] >> 32)] == a;
+        distinct += seen ? 0u : 1u;
+    }
+    const uint32_t k = (sz != 0 && distinct <= maxAmbig) ? 1u : 0u;
+    keep[i] = k; keepSize[i] = k ? sz : 0u;
+}
+__global__ __launch_bounds__(256) void ambig_compact_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes,
+                                                            const uint64_t* __restrict__ vals, const uint64_t* __restrict__ voff,
+                                                            uint32_t nkeys, const uint32_t* __restrict__ keep,
+                                                            const uint64_t* __restrict__ kpos, const uint64_t* __restrict__ nvoff,
+                                                            uint32_t* __restrict__ okeys, uint8_t* __restrict__ osizes,
+                                                            uint64_t* __restrict__ ovals)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nkeys || !keep[i]) return;
+    const uint64_t at = kpos[i];
+    okeys[at] = keys[i]; osizes[at] = sizes[i];
+    const uint64_t* src = vals + voff[i];
+    uint64_t* dst = ovals + nvoff[i];
+    for (uint32_t t = 0, sz = sizes[i]; t < sz; ++t) dst[t] = src[t];
+}
+
+__global__ __launch_bounds__(256) void ambig_offsets_kernel(const uint32_t* __restrict__ keep, const uint64_t* __restrict__ kpos,
+                                                            const uint64_t* __restrict__ nvoff, uint32_t nkeys, uint64_t nvNew, uint64_t nkNew,
+                                                            uint64_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) out[nkNew] = nvNew;
+    if (i < nkeys && keep[i]) out[kpos[i]] = nvoff[i];
+}
+
 int grow_pairs(mc_builder* b, uint64_t need)
 {
     if (need <= b->cap) return MC_OK;
@@ -408,6 +458,65 @@ int mc_build_finish_shards(mc_builder** bs, uint32_t n, mc_ctx** outCtx)
     if (!rc) rc = mc_load_end(ctx, 0);
     if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
     *outCtx = ctx;
+    return MC_OK;
+}
+
+int mc_build_counts(const mc_builder* b, uint64_t* keys, uint64_t* values)
+{
+    if (!b || !b->finished) return MC_ERR_STATE;
+    if (keys) *keys = b->nkeys;
+    if (values) *values = b->nvals;
+    return MC_OK;
+}
+
+int mc_build_remove_ambiguous(mc_builder* b, const uint32_t* ancestorOfTarget, uint64_t numTargets, uint32_t maxAmbig, uint64_t* removed)
+{
+    if (!b || !ancestorOfTarget) return MC_ERR_INVALID;
+    if (!b->finished) { b->err = "mc_build_remove_ambiguous: call mc_build_finish first"; return MC_ERR_STATE; }
+    if (numTargets != b->targets.size()) { b->err = "mc_build_remove_ambiguous: one ancestor per target expected"; return MC_ERR_INVALID; }
+    if (removed) *removed = 0;
+    if (maxAmbig == 0) maxAmbig = 1;                                           // host_hashmap.hpp:505
+    const uint32_t nk = (uint32_t)b->nkeys;
+    if (!nk) return MC_OK;
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    hipStream_t st = b->st;
+    uint32_t *danc = nullptr, *keep = nullptr, *keepSize = nullptr, *oK = nullptr; uint8_t* oS = nullptr;
+    uint64_t *kpos = nullptr, *nvoff = nullptr, *oV = nullptr; void* scanTmp = nullptr;
+    B_TRY(b, hipMalloc((void**)&danc, (numTargets + 1) * 4));
+    B_TRY(b, hipMemcpyAsync(danc, ancestorOfTarget, numTargets * 4, hipMemcpyHostToDevice, st));
+    B_TRY(b, hipMalloc((void**)&keep, ((size_t)nk + 1) * 4));
+    B_TRY(b, hipMalloc((void**)&keepSize, ((size_t)nk + 1) * 4));
+    B_TRY(b, hipMalloc((void**)&kpos, ((size_t)nk + 2) * 8));
+    B_TRY(b, hipMalloc((void**)&nvoff, ((size_t)nk + 2) * 8));
+    B_TRY(b, hipMalloc(&scanTmp, scan_tmp_bytes(nk + 1)));
+    hipLaunchKernelGGL(ambig_flags_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, b->rV, b->rVoff, b->rS, nk, danc, maxAmbig, keep, keepSize);
+    launch_scan_u32(keep, 1, nk, nullptr, kpos, scanTmp, st);
+    launch_scan_u32(keepSize, 1, nk, nullptr, nvoff, scanTmp, st);
+    uint64_t nkNew = 0, nvNew = 0;
+    B_TRY(b, hipMemcpyAsync(&nkNew, kpos + nk, 8, hipMemcpyDeviceToHost, st));
+    B_TRY(b, hipMemcpyAsync(&nvNew, nvoff + nk, 8, hipMemcpyDeviceToHost, st));
+    B_TRY(b, hipStreamSynchronize(st));
+    if (nkNew != nk) {
+        B_TRY(b, hipMalloc((void**)&oK, (nkNew + 1) * 4));
+        B_TRY(b, hipMalloc((void**)&oS, nkNew + 16));
+        B_TRY(b, hipMalloc((void**)&oV, (nvNew + 2) * 8));
+        hipLaunchKernelGGL(ambig_compact_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, b->rK, b->rS, b->rV, b->rVoff, nk, keep, kpos, nvoff, oK, oS, oV);
+        B_TRY(b, hipGetLastError());
+        B_TRY(b, hipStreamSynchronize(st));
+        (void)hipFree(b->rK); (void)hipFree(b->rS); (void)hipFree(b->rV);
+        b->rK = oK; b->rS = oS; b->rV = oV;
+        // rVoff[j] for the kept features = nvoff at their old places, moved to the front
+        uint64_t* oOff = nullptr;
+        B_TRY(b, hipMalloc((void**)&oOff, (nkNew + 2) * 8));
+        hipLaunchKernelGGL(ambig_offsets_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, keep, kpos, nvoff, nk, nvNew, nkNew, oOff);
+        B_TRY(b, hipGetLastError());
+        B_TRY(b, hipStreamSynchronize(st));
+        (void)hipFree(b->rVoff);
+        b->rVoff = oOff;
+        if (removed) *removed = nk - nkNew;
+        b->nkeys = nkNew; b->nvals = nvNew;
+    }
+    for (void* p : {(void*)danc, (void*)keep, (void*)keepSize, (void*)kpos, (void*)nvoff, scanTmp}) (void)hipFree(p);
     return MC_OK;
 }
 

@@ -7,8 +7,8 @@
 //                         :196-232 (try_to_rank_unranked_targets), :240-262 (find_taxon_id)
 //   adding targets        building.cpp:283-327 (one sequence), :335-455 (all files; here: files and records in the given order = the
 //                         reference's single-part build), database.cpp:36-82 (ids, names of duplicates), sequence_io.cpp:470-673 (ids)
-//   post-processing       building.cpp:516-534 (-remove-overpopulated-features)
-// Not offered: -remove-ambig-features (needs per-feature lineages on the host; the reference's own GPU build has none either),
+//   post-processing       building.cpp:516-534 (-remove-overpopulated-features), :550-566 (-remove-ambig-features)
+// Not offered:
 // -parts > 1 (the reference spreads targets over parts in thread-schedule order; the multi-GPU modes use key shards instead).
 #ifndef MCQ_BUILD_H_
 #define MCQ_BUILD_H_
@@ -82,6 +82,7 @@ struct BuildOptions {
     int shards = 0;                                 // key shards of the build (0 = from the input size: one device sort takes 2^32 pairs)
     float maxLoadFac = -1;
     int removeAmbigRank = kNumRanks;
+    int maxAmbig = 1;                                        // options.hpp:78
 };
 
 // args: everything after the mode word.  build: <database> <files>... ; build+query: -targets <files>... [-query <files>...] and every
@@ -129,7 +130,7 @@ inline BuildOptions parse_build(const std::vector<std::string>& args, bool build
         else if (a == "-max-locations-per-feature") o.maxLocs = std::stoi(need(i));
         else if (a == "-remove-overpopulated-features") o.removeOverpopulated = true;
         else if (a == "-remove-ambig-features") { o.removeAmbigRank = rank_from_name(need(i)); if (o.removeAmbigRank < 0) throw std::runtime_error("unknown rank"); }
-        else if (a == "-max-ambig-per-feature") (void)need(i);
+        else if (a == "-max-ambig-per-feature") o.maxAmbig = std::stoi(need(i));
         else if (a == "-max-load-fac" || a == "-max-load-factor") o.maxLoadFac = std::stof(need(i));
         else if (a == "-parts") o.parts = std::stoi(need(i));
         else if (a == "-max-part-size") (void)need(i);
@@ -156,7 +157,6 @@ inline BuildOptions parse_build(const std::vector<std::string>& args, bool build
     if (o.infiles.empty()) throw std::runtime_error("No reference sequence files provided or found");
     if (o.maxLocs < 0) o.maxLocs = 254;                                       // database::max_supported_locations_per_feature()
     if (o.stride == 0) o.stride = o.w - o.k + 1;
-    if (o.removeAmbigRank != kNumRanks) throw std::runtime_error("-remove-ambig-features is not available in this GPU build");
     if (o.parts > 1) throw std::runtime_error("-parts > 1 is not available: one part per build (see DESIGN.md, multi-GPU modes)");
     // augment_taxonomy_options (options.cpp:490-520)
     if (!o.taxPath.empty() && o.taxPath.back() != '/') o.taxPath += '/';
@@ -359,6 +359,10 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
     if (db.nonTarget.empty() && info)
         std::cout << "The datbase doesn't contain a taxonomic hierarchy yet.\nYou can add one or update later via:\n"
                      "   metacache modify <database> -taxonomy <directory>" << std::endl;
+    if (o.removeAmbigRank != kNumRanks && info) {                                // building.cpp:508-518
+        if (db.nonTarget.size() > 1) std::cout << "Ambiguous features on rank " << kRankNames[o.removeAmbigRank] << " will be removed afterwards." << std::endl;
+        else std::cout << "Could not determine amiguous features due to missing taxonomic information." << std::endl;
+    }
 
     mc_config c; mc_config_default(&c);
     c.kmerlen = o.k; c.sketchlen = o.s; c.winlen = o.w; c.winstride = o.stride;
@@ -494,6 +498,35 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
             if (!still) std::cout << "All targets are ranked (have a taxon assigned)." << std::endl;
             else std::cout << still << " targets remain unranked (no taxon was assigned)." << std::endl;
         }
+    }
+    // post_process_features (building.cpp:550-566): -remove-ambig-features, after the targets got their final parents
+    if (o.removeAmbigRank != kNumRanks && db.nonTarget.size() > 1) {
+        if (info) std::cout << "\nRemoving ambiguous features on rank " << kRankNames[o.removeAmbigRank] << "... " << std::flush;
+        std::unordered_map<int64_t, uint32_t> byId;
+        for (uint32_t i = 0; i < db.nonTarget.size(); ++i) byId.emplace(db.nonTarget[i].id, i);
+        // the target's entry of that rank in its ranked lineage (taxonomy::make_ranks, taxonomy.hpp:576-597): the last taxon of the
+        // rank on the way to the root; 0 = none
+        std::vector<uint32_t> anc(db.targets.size(), 0);
+        for (uint32_t t = 0; t < db.targets.size(); ++t) {
+            if (o.removeAmbigRank == 0) { anc[t] = t + 1; continue; }
+            int64_t id = db.targets[t].parent;
+            while (id != 0) {
+                auto it = byId.find(id);
+                if (it == byId.end()) break;
+                const Taxon& p = db.nonTarget[it->second];
+                if (p.rank == o.removeAmbigRank) anc[t] = it->second + 1;
+                if (p.parent == id) break;
+                id = p.parent;
+            }
+        }
+        uint64_t old = 0, rem = 0;
+        for (mc_builder* b : db.bs) {
+            uint64_t k = 0, v = 0, r = 0;
+            mc_build_counts(b, &k, &v); old += k;
+            if (mc_build_remove_ambiguous(b, anc.data(), anc.size(), (uint32_t)std::max(0, o.maxAmbig), &r) != MC_OK) throw std::runtime_error(mc_build_last_error(b));
+            rem += r;
+        }
+        if (info) std::cout << rem << " of " << old << "." << std::endl;
     }
 }
 

@@ -53,6 +53,9 @@ BUILD_CASES = {
     "sketching": (REF32, ["-kmerlen", "12", "-sketchlen", "8", "-winlen", "64", "-winstride", "40"], None),
     "no_taxonomy": (REF32, None, None),                      # built without -taxonomy
     "reset_taxa": (REF32, ["-reset-taxa"], None),
+    "ambig_species": (REF32, ["-remove-ambig-features", "species"], None),
+    "ambig_genus_2": (REF32, ["-remove-ambig-features", "genus", "-max-ambig-per-feature", "2"], None),
+    "ambig_sequence_3": (REF32, ["-remove-ambig-features", "sequence", "-max-ambig-per-feature", "3", "-max-locations-per-feature", "20"], None),
 }
 QUERY_ARGS = ["-tophits", "-allhits", "-queryids", "-lowest", "species", "-taxids", "-lineage"]
 # build+query has no thread option for its build half: with several input files the reference builds in several parts whose
@@ -62,6 +65,7 @@ BQ_CASES = {
     "bq_default": ([], ["-tophits", "-queryids", "-taxids"]),
     "bq_species": (["-max-locations-per-feature", "6", "-remove-overpopulated-features"], ["-lowest", "species", "-tophits", "-allhits", "-maxcand", "3"]),
     "bq_save": (["-save-db", "{savedb}"], ["-tophits", "-lowest", "genus"]),
+    "bq_ambig": (["-remove-ambig-features", "species"], ["-tophits", "-allhits", "-taxids"]),
 }
 
 

@@ -108,7 +108,7 @@ def test_build_writes_the_reference_database(case, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["default", "overpopulated", "u16"])
+@pytest.mark.parametrize("case", ["default", "overpopulated", "u16", "ambig_species"])
 def test_build_in_key_shards_writes_the_same_database(case, tmp_path):
     """-build-shards 3: three builders keep a third of the features each (what inputs beyond 2^32 (feature, location) pairs get
     automatically); mc_build_write_shards puts them into one file set with the content of the reference's database"""

@@ -115,3 +115,49 @@ def test_key_sharded_builders_make_the_same_table(tmp_path):
     db1.close(); db3.close()
     for b in [whole] + shards:
         b.free()
+
+
+@pytest.mark.parametrize("shards,max_ambig", [(1, 1), (1, 2), (3, 1), (1, 0)])
+def test_remove_ambiguous_features(tmp_path, shards, max_ambig):
+    """mc_build_remove_ambiguous (host_hashmap.hpp:499-540): a feature stays iff its (capped) location list touches at most max_ambig
+    different taxa; targets without a taxon on the rank count as one taxon; 0 means 1.  Checked on the written files."""
+    rng = np.random.default_rng(300 + shards + max_ambig)
+    orc = cpuref.oracle()
+    genomes = make_genomes(rng)
+    anc = np.array([0 if t % 7 == 3 else 1 + t % 4 for t in range(len(genomes))], dtype=np.uint32)
+    bs = [api.Builder(target_id_bytes=4, key_shard_index=i, key_shard_count=shards) for i in range(shards)]
+    for i, g in enumerate(genomes):
+        for b in bs:
+            b.add_target(g, f"SYN_{i:05d}.1", parent_taxid=0, filename=f"f{i}.fa")
+    before = after = removed = 0
+    for b in bs:
+        b.finish(load=False)
+        before += b.counts()[0]
+        removed += b.remove_ambiguous(anc, max_ambig)
+        after += b.counts()[0]
+    expect = {}
+    for t, g in enumerate(genomes):
+        feats, counts = orc.sketch(g.tobytes(), 16, 16, 127, 112)
+        for w in range(len(counts)):
+            for f in feats[w, :counts[w]]:
+                expect.setdefault(int(f), []).append((t << 32) | w)
+    lim = max(max_ambig, 1)
+    kept = {f: l[:254] for f, l in expect.items() if len({int(anc[v >> 32]) for v in l[:254]}) <= lim}
+    assert before == len(expect) and after == len(kept) and removed == before - after and 0 < after < before
+    name = str(tmp_path / "ambig")
+    from metacache_amd.api import lib
+    import ctypes as C
+    arr = (C.c_void_p * shards)(*[b.h for b in bs])
+    lib().mc_build_write_shards.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint64]
+    assert lib().mc_build_write_shards(arr, shards, name.encode(), None, 0) == 0
+    odb = orc.open(name)
+    assert odb.n_locations == sum(len(l) for l in kept.values())
+    for f, l in expect.items():
+        got = odb.lookup(f)
+        assert np.array_equal(got, np.array(kept.get(f, []), dtype=np.uint64)), f
+    # the table loaded from the builders answers like the files
+    db = api.Builder.finish_shards(bs)
+    assert db.n_locations == odb.n_locations
+    odb.close(); db.close()
+    for b in bs:
+        b.free()
