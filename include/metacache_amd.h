@@ -249,6 +249,14 @@ int  mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const
                              const char* source_filename, uint64_t source_index);
 /* re-ranks a target after it was added (try_to_rank_unranked_targets, building.cpp:196-232) */
 int  mc_build_set_parent(mc_builder* b, uint64_t target, int64_t parent_taxid);
+/* modify mode (main_mode_modify, mode_build.cpp:74-88: an existing database is read, then added to): the database's targets
+ * (taxon::file_source fields from mc_db_taxon / mc_db_taxon_source) and the batches of its .cache file (hash_multimap.hpp:1037-1082:
+ * keys, bucket sizes, packed {u32 window, target id of target_bytes} values) go into a fresh builder BEFORE the first new target;
+ * their lists keep their order and stand in front of what is sketched afterwards, as in the reference's table after reading. */
+int  mc_build_add_existing_target(mc_builder* b, const char* name, int64_t parent_taxid, const char* source_filename,
+                                  uint64_t source_index, uint64_t windows);
+int  mc_build_add_locations(mc_builder* b, const uint32_t* keys, const uint8_t* sizes, const void* values, uint64_t num_keys,
+                            uint32_t target_bytes);
 /* after mc_build_finish: features and locations the builder holds (database::feature_count / location_count, database.hpp:420-440) */
 int  mc_build_counts(const mc_builder* b, uint64_t* keys, uint64_t* values);
 /* After mc_build_finish: drops every feature whose locations lie in more than max_ambig (0 => 1) different taxa on one rank

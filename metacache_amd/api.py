@@ -54,7 +54,7 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
-           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
+           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
 
 _lib = None

@@ -21,7 +21,7 @@
 
 using namespace mcamd;
 
-struct TargetRec { std::string name, filename; int64_t parent; uint64_t windows, fileIndex; };
+struct TargetRec { std::string name, filename; int64_t parent = 0; uint64_t windows = 0, fileIndex = 0; bool existing = false; };
 
 struct mc_builder {
     mc_config cfg{};
@@ -346,6 +346,51 @@ int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const 
     TargetRec r;
     r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid; r.windows = total; r.fileIndex = fileIndex;
     b->targets.push_back(std::move(r));
+    return MC_OK;
+}
+
+// modify mode (mode_build.cpp:74-88): the targets and location lists of an existing database come first, new targets after them
+int mc_build_add_existing_target(mc_builder* b, const char* name, int64_t parentTaxid, const char* filename, uint64_t fileIndex, uint64_t windows)
+{
+    if (!b) return MC_ERR_INVALID;
+    if (b->finished) { b->err = "builder is finished"; return MC_ERR_STATE; }
+    if (!b->targets.empty() && !b->targets.back().existing) { b->err = "existing targets go in before new ones"; return MC_ERR_STATE; }
+    TargetRec r;
+    r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid;
+    r.windows = windows; r.fileIndex = fileIndex; r.existing = true;
+    b->targets.push_back(std::move(r));
+    return MC_OK;
+}
+
+// one batch of a .cache file (hash_multimap.hpp:1037-1082): keys, bucket sizes, packed {u32 window, target id} values.  The lists keep
+// their order and stand before everything sketched later, as in a table that was read from the file and then inserted into.
+int mc_build_add_locations(mc_builder* b, const uint32_t* keys, const uint8_t* sizes, const void* values, uint64_t nkeys, uint32_t targetBytes)
+{
+    if (!b || (nkeys && (!keys || !sizes || !values)) || (targetBytes != 2 && targetBytes != 4)) return MC_ERR_INVALID;
+    if (b->finished) { b->err = "builder is finished"; return MC_ERR_STATE; }
+    if (!b->targets.empty() && !b->targets.back().existing) { b->err = "existing location lists go in before new targets"; return MC_ERR_STATE; }
+    std::vector<uint32_t> hk; std::vector<uint64_t> hv;
+    const uint8_t* v = static_cast<const uint8_t*>(values);
+    const uint32_t shards = std::max<uint32_t>(b->cfg.key_shard_count, 1);
+    for (uint64_t i = 0; i < nkeys; ++i) {
+        const bool own = shards == 1 || key_owner(keys[i], shards) == b->cfg.key_shard_index;
+        for (uint32_t t = 0; t < sizes[i]; ++t, v += 4 + targetBytes) {
+            if (!own) continue;
+            uint32_t win, tgt;
+            std::memcpy(&win, v, 4);
+            if (targetBytes == 2) { uint16_t t16; std::memcpy(&t16, v + 4, 2); tgt = t16; } else std::memcpy(&tgt, v + 4, 4);
+            if (tgt >= b->targets.size()) { b->err = "location of a target the builder does not know"; return MC_ERR_INVALID; }
+            hk.push_back(keys[i]); hv.push_back(((uint64_t)tgt << 32) | win);
+        }
+    }
+    if (hk.empty()) return MC_OK;
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    int rc = grow_pairs(b, b->npairs + hk.size());
+    if (rc) return rc;
+    B_TRY(b, hipMemcpyAsync(b->dkeys + b->npairs, hk.data(), hk.size() * 4, hipMemcpyHostToDevice, b->st));
+    B_TRY(b, hipMemcpyAsync(b->dvals + b->npairs, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, b->st));
+    B_TRY(b, hipStreamSynchronize(b->st));
+    b->npairs += hk.size();
     return MC_OK;
 }
 

@@ -83,6 +83,7 @@ struct BuildOptions {
     float maxLoadFac = -1;
     int removeAmbigRank = kNumRanks;
     int maxAmbig = 1;                                        // options.hpp:78
+    bool modify = false, maxLocsGiven = false;      // modify mode: the database <dbfile> is read first (mode_build.cpp:74-88)
 };
 
 // args: everything after the mode word.  build: <database> <files>... ; build+query: -targets <files>... [-query <files>...] and every
@@ -127,7 +128,7 @@ inline BuildOptions parse_build(const std::vector<std::string>& args, bool build
         else if (a == "-winlen") o.w = (uint32_t)std::stoul(need(i));
         else if (a == "-winstride") o.stride = (uint32_t)std::stoul(need(i));
         else if (a == "-reset-taxa" || a == "-reset-parents") o.resetParents = true;
-        else if (a == "-max-locations-per-feature") o.maxLocs = std::stoi(need(i));
+        else if (a == "-max-locations-per-feature") { o.maxLocs = std::stoi(need(i)); o.maxLocsGiven = true; }
         else if (a == "-remove-overpopulated-features") o.removeOverpopulated = true;
         else if (a == "-remove-ambig-features") { o.removeAmbigRank = rank_from_name(need(i)); if (o.removeAmbigRank < 0) throw std::runtime_error("unknown rank"); }
         else if (a == "-max-ambig-per-feature") o.maxAmbig = std::stoi(need(i));
@@ -376,7 +377,12 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
     if (o.shards <= 0) {
         uint64_t bytes = 0;
         for (const auto& f : o.infiles) { struct stat st; if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0 ? 4 : 1); }
-        const uint64_t pairs = bytes / std::max<uint32_t>(o.stride, 1) * o.s;
+        uint64_t pairs = bytes / std::max<uint32_t>(o.stride, 1) * o.s;
+        if (o.modify) {                                                        // + the locations the database already holds
+            std::ifstream is(o.dbfile + ".cache0", std::ios::binary);
+            uint64_t hdr[3] = {0, 0, 0};
+            if (is.read(reinterpret_cast<char*>(hdr), 24)) pairs += hdr[1];
+        }
         shards = (uint32_t)(pairs / 3000000000ull) + 1;
     }
     for (uint32_t i = 0; i < shards; ++i) {
@@ -403,6 +409,59 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
     }
     // add_targets_to_database (building.cpp:335-455) with one consumer: files in the given order, records in file order
     std::map<std::string, uint32_t> name2tgt;                                  // taxonomy_cache::name2tax_ (taxonomy.hpp:1135-1160)
+    if (o.modify) {
+        // make_database(opt.dbfile) (mode_build.cpp:80): targets with their sources, the taxa above them unless -taxonomy replaces them
+        // (reset_taxa_above_sequence_level, building.cpp:487-495), and the location lists of the (single) part
+        mc_ctx* meta = nullptr;
+        if (mc_open_metadata(o.dbfile.c_str(), &meta) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+        struct Guard { mc_ctx* c; ~Guard() { mc_destroy(c); } } guard{meta};
+        uint64_t dbi[8]; mc_db_info(meta, dbi);
+        if (dbi[6] != 1) throw std::runtime_error("modify: databases of more than one part are not supported");
+        uint64_t nt = 0; mc_db_num_taxa(meta, &nt);
+        std::vector<Taxon> old(dbi[5]); std::vector<std::string> oldFile(dbi[5]); std::vector<uint64_t> oldIndex(dbi[5]);
+        const bool keepTaxa = o.taxPath.empty();
+        for (uint64_t i = 0; i < nt; ++i) {
+            Taxon t; uint32_t rk; const char *nm, *fn; uint64_t idx = 0;
+            mc_db_taxon(meta, i, &t.id, &t.parent, &rk, &nm);
+            t.rank = int(rk); t.name = nm;
+            mc_db_taxon_source(meta, i, &fn, &idx, &t.windows);
+            if (t.id < 0 && t.rank == 0) {
+                const uint64_t tgt = (uint64_t)(-t.id - 1);
+                if (tgt >= old.size()) throw std::runtime_error("modify: target id beyond the database's target count");
+                oldFile[tgt] = fn; oldIndex[tgt] = idx; old[tgt] = std::move(t);
+            }
+            else if (keepTaxa) db.nonTarget.push_back(std::move(t));
+        }
+        for (uint64_t t = 0; t < old.size(); ++t) {
+            for (mc_builder* b : db.bs)
+                if (mc_build_add_existing_target(b, old[t].name.c_str(), old[t].parent, oldFile[t].c_str(), oldIndex[t], old[t].windows) != MC_OK)
+                    throw BuilderError(mc_build_last_error(b));
+            name2tgt.emplace(old[t].name, (uint32_t)t);
+            db.targets.push_back(std::move(old[t]));
+        }
+        std::ifstream is(o.dbfile + ".cache0", std::ios::binary);
+        uint64_t hdr[3] = {0, 0, 0};
+        if (!is.read(reinterpret_cast<char*>(hdr), 24)) throw std::runtime_error("Could not read database file '" + o.dbfile + ".cache0'");
+        const size_t vb = 4 + (size_t)o.targetIdBytes;
+        std::vector<uint32_t> keys; std::vector<uint8_t> sizes; std::vector<char> vals;
+        for (uint64_t done = 0; done < hdr[0];) {
+            const uint64_t nb = std::min<uint64_t>(hdr[2], hdr[0] - done);
+            keys.resize(nb); sizes.resize(nb);
+            is.read(reinterpret_cast<char*>(keys.data()), nb * 4);
+            is.read(reinterpret_cast<char*>(sizes.data()), nb);
+            uint64_t bv = 0;
+            for (uint64_t i = 0; i < nb; ++i) bv += sizes[i];
+            vals.resize(bv * vb + 8);
+            is.read(vals.data(), bv * vb);
+            if (!is) throw std::runtime_error("truncated " + o.dbfile + ".cache0");
+            for (mc_builder* b : db.bs)
+                if (mc_build_add_locations(b, keys.data(), sizes.data(), vals.data(), nb, (uint32_t)o.targetIdBytes) != MC_OK)
+                    throw BuilderError(mc_build_last_error(b));
+            done += nb;
+        }
+        if (info) std::cout << "Database holds " << db.targets.size() << " reference sequences." << std::endl;
+    }
+    const size_t initTargets = db.targets.size();
     for (size_t fi = 0; fi < o.infiles.size(); ++fi) {
         const std::string& filename = o.infiles[fi];
         if (o.info == BuildOptions::verbose) std::cerr << "  (" << fi << '/' << o.infiles.size() << ") " << filename << std::endl;
@@ -454,7 +513,7 @@ inline void build_database(const BuildOptions& o, BuiltDatabase& db)
     }
     for (mc_builder* b : db.bs) if (mc_build_finish(b, nullptr) != MC_OK) throw std::runtime_error(mc_build_last_error(b));
     if (info)
-        std::cout << "Added " << db.targets.size() << " reference sequences in "
+        std::cout << "Added " << db.targets.size() - initTargets << " reference sequences in "
                   << std::chrono::duration<double>(clock::now() - t0).count() << " s" << std::endl;
 
     // try_to_rank_unranked_targets (building.cpp:196-232)

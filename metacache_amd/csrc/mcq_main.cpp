@@ -1,6 +1,7 @@
 // mcq -- the reference's command lines on MI355X, host C++14 above the C ABI (include/metacache_amd.h):
 //   mcq query <database> [<reads.fa|fq[.gz]|directory>...] [options]     mode_query.cpp, querying.cpp (interactive without files)
 //   mcq build <database> <sequence files|directories>... [options]        mode_build.cpp, building.cpp        (mcq_build.h)
+//   mcq modify <database> <sequence files|directories>... [options]       mode_build.cpp:74-88: adds to an existing database (mcq_build.h)
 //   mcq build+query -targets <files>... [-query <files>...] [options]     mode_build_query.cpp                (mcq_build.h)
 //   mcq merge <result files>... -taxonomy <dir> [options]                 mode_merge.cpp
 //   mcq info [<database> [targets [name...] | lineages | rank <r>]]       mode_info.cpp (metadata topics)
@@ -1159,6 +1160,32 @@ int main(int argc, char** argv)
                           << "Total build time:  " << total << " s" << std::endl;
             return 0;
         }
+        if (mode == "modify") {                                                 // main_mode_modify, mode_build.cpp:74-88
+            std::vector<std::string> none;
+            BuildOptions bo = parse_build(args, false, none);
+            std::cout << "Modify database " << bo.dbfile << std::endl;
+            {   // get_modify_options (options.cpp:765-795): sketching and limits of the database file are the defaults
+                mc_ctx* meta = nullptr;
+                if (mc_open_metadata(bo.dbfile.c_str(), &meta) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+                uint64_t info[8]; mc_db_info(meta, info);
+                mc_destroy(meta);
+                bo.k = (uint32_t)info[0]; bo.s = (uint32_t)info[1]; bo.w = (uint32_t)info[2]; bo.stride = (uint32_t)info[3];
+                if (!bo.maxLocsGiven) bo.maxLocs = (int)info[4];
+                std::ifstream is(bo.dbfile + ".meta", std::ios::binary);
+                char hdr[10] = {};
+                is.read(hdr, 10);
+                bo.targetIdBytes = (is.gcount() == 10 && (uint8_t)hdr[9] == 2) ? 2 : 4;
+            }
+            bo.modify = true;
+            // the reference parses the command line twice (options.cpp:772 and :786) and its value list grows both times: every new
+            // file is added twice, the second copy's sequences under '<id>!1' names
+            { const std::vector<std::string> once = bo.infiles; bo.infiles.insert(bo.infiles.end(), once.begin(), once.end()); }
+            if (bo.info != BuildOptions::silent) std::cout << "Adding reference sequences to database..." << std::endl;
+            BuiltDatabase db;
+            build_database(bo, db);
+            db.write();
+            return 0;
+        }
         if (mode == "build+query") {                                            // main_mode_build_query, mode_build_query.cpp:41-94
             std::vector<std::string> qargs;
             const BuildOptions bo = parse_build(args, true, qargs);
@@ -1177,7 +1204,7 @@ int main(int argc, char** argv)
             if (bo.saveDb) db.write();
             return rc;
         }
-        throw std::runtime_error("usage: mcq query|build|build+query|merge|info ... (see the header of mcq_main.cpp / mcq_build.h)");
+        throw std::runtime_error("usage: mcq query|build|modify|build+query|merge|info ... (see the header of mcq_main.cpp / mcq_build.h)");
     } catch (std::exception& e) {
         std::cerr << "ABORT: " << e.what() << "!" << std::endl;                  // main.cpp:65-68
         return 1;

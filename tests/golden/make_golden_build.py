@@ -57,6 +57,17 @@ BUILD_CASES = {
     "ambig_genus_2": (REF32, ["-remove-ambig-features", "genus", "-max-ambig-per-feature", "2"], None),
     "ambig_sequence_3": (REF32, ["-remove-ambig-features", "sequence", "-max-ambig-per-feature", "3", "-max-locations-per-feature", "20"], None),
 }
+# modify: name -> (binary, files + options of the first build, files + options of `modify`, mcq's extra options for both)
+MODIFY_CASES = {
+    # modify takes no -threads: the generator pins the reference to one CPU so that target ids follow the file order.  The reference
+    # parses the command line twice (options.cpp:772,786) and so adds every new file TWICE, the second time under '<id>!1' names.
+    "modify_default": (REF32, FILES[:4] + TAX, FILES[4:], []),
+    "modify_adds_taxonomy": (REF32, FILES[:4], FILES[4:] + TAX, []),
+    # (no case with a -max-locations-per-feature below 254 in the first build: the reference's modify then lets the buckets it read from
+    #  the file grow past that limit -- 6 + 6 locations under a header that says 6 -- which mcq does not imitate: it keeps the first n)
+    "modify_u16": (REF16, FILES[:3] + FILES[4:] + TAX, FILES[3:4], ["-target-id-type", "uint16_t"]),
+    "modify_ambig": (REF32, FILES[:3] + FILES[4:] + TAX, FILES[3:4] + TAX + ["-remove-ambig-features", "genus", "-reset-taxa"], []),
+}
 QUERY_ARGS = ["-tophits", "-allhits", "-queryids", "-lowest", "species", "-taxids", "-lineage"]
 # build+query has no thread option for its build half: with several input files the reference builds in several parts whose
 # consumer threads take target ids in schedule order.  ONE input file => one part => reproducible ids.
@@ -241,6 +252,14 @@ def main():
             res = os.path.join(tmp, name + ".txt")
             run([ref, "query", db, "build_reads.fa"] + QUERY_ARGS + ["-threads", "1", "-out", res])
             out["build"][name] = {"args": args, "mcq_extra": mcq_extra or [], "db": parse_db(db), "query": open(res).read().split("\n")}
+        out["modify"] = {}
+        for name, (ref, first, second, mcq_extra) in MODIFY_CASES.items():
+            db = os.path.join(tmp, name)
+            run([ref, "build", db] + first + ["-threads", "1"])
+            run(["taskset", "-c", "0", ref, "modify", db] + second)      # one hardware thread = one build part: files in the given order
+            res = os.path.join(tmp, name + ".txt")
+            run([ref, "query", db, "build_reads.fa"] + QUERY_ARGS + ["-threads", "1", "-out", res])
+            out["modify"][name] = {"first": first, "second": second, "mcq_extra": mcq_extra, "db": parse_db(db), "query": open(res).read().split("\n")}
         for name, (bargs, qargs) in BQ_CASES.items():
             res = os.path.join(tmp, name + ".txt")
             args = ["-targets"] + BQ_FILES + TAX + bargs + ["-query", "build_reads.fa"] + qargs

@@ -108,6 +108,28 @@ def test_build_writes_the_reference_database(case, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shards", [1, 3])
+@pytest.mark.parametrize("case", sorted(EXP.get("modify", {})))
+def test_modify_adds_to_a_database(case, shards, tmp_path):
+    """mcq modify: the database mcq built from the first files is read back into a builder (targets, location lists), the other files
+    are added, taxonomy / ranking / feature removal run over everything -- the files equal those the reference's build + modify wrote"""
+    build.build_library()
+    c = EXP["modify"][case]
+    db = str(tmp_path / case)
+    more = ["-build-shards", str(shards)] if shards > 1 else []
+    for mode, args in (("build", c["first"]), ("modify", c["second"])):
+        r = subprocess.run([build.MCQ, mode, db] + args + (c["mcq_extra"] if mode == "build" else []) + more, cwd=GOLD, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (mode, r.stderr)
+    same_db(parse_db(db), c["db"], case)
+    out = tmp_path / "q.txt"
+    r = subprocess.run([build.MCQ, "query", db, "build_reads.fa"] + EXP["query_args"] + ["-threads", "1", "-out", str(out)], cwd=GOLD,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    _same(out.read_text().split("\n"), c["query"], case)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["default", "overpopulated", "u16", "ambig_species"])
 def test_build_in_key_shards_writes_the_same_database(case, tmp_path):
     """-build-shards 3: three builders keep a third of the features each (what inputs beyond 2^32 (feature, location) pairs get
