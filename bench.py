@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- MetaCache query hot path on MI355X: Mreads/min (150 bp) + roofline + CPU baseline.
 
-Workload (BASELINE.json configs[1]): 16-genome synthetic DB (16 x 5 Mbp i.i.d. ACGT, seed 16, uint16
-target ids, one partition), 10 M synthetic 150 bp reads (seed 1016; 1 % substitutions, 0.1 % N, both
-strands).  A "step" = one pass of the hot path (sketch+probe -> scan -> sort+candidates) over one
-batch of reads that is already resident in HBM; default 10 steps x 1 M reads = the 10 M reads.
+Default workload = BASELINE.json configs[2]: a RefSeq-scale synthetic database (SURVEY.md §8d "Config 3": 40 000 targets,
+150 Gbp, a genus -> species -> strain phylogeny with 0.5-10 % divergence, uint32 target ids, k = 16) built ON the GPU by this
+repo's builder in key shards (the targets are a pure function of (target, position), metacache_amd/synth: generated in HBM group
+by group, never resident as a whole), queried with synthetic 150 bp reads (1 % substitutions, 0.1 % N, both strands; seed 3100)
+that are resident in HBM before the timed region.  A "step" = one pass of the hot path (sketch -> probe -> candidates) over one
+batch of reads; the driver's `--steps 20` x 5 M reads = the 100 M reads of the configuration.
+`--config 1` = configs[1] (16 x 5 Mbp, uint16 targets, 10 M reads per step) as in round 1; `--scale f` shrinks configs[2] for
+quick runs (f = 1: 2000 genera; the line then says so in config.workload).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the database is replicated, every rank
-processes its own shard of reads (weak scaling: reads per GPU fixed) and the per-rank top-candidate
-lists are gathered to rank 0 over RCCL inside the timed region -- the hand-over to host-side
-taxonomy assignment.  No other collective: the path has no exchange step in this mode.
+N > 1 (launched by torch.distributed.run, one rank per GPU), mode R: the database is replicated (every rank builds it), every
+rank processes its own reads (weak scaling) and the per-rank top-candidate lists are gathered to rank 0 over RCCL inside the
+timed region -- the hand-over to host-side taxonomy assignment.  No other collective: the path has no exchange step in this mode.
+
+Checker legs (rank 0, N = 1, after the timed region; oracle/ is loaded only here):
+  parity        the C oracle builds the buckets of a read sample's features ITSELF from the same collection (mco_db_build) and
+                classifies the sample; every candidate is compared with the GPU's.  configs[1]: the reference (oracle/_ref) on the
+                database files this repo wrote.
+  cpu_baseline  the same checker timed on the host cores, thread sweep, best value.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,13 +40,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402  (plumbing: device memory, streams, torch.distributed)
 import torch.distributed as dist  # noqa: E402
 
-from metacache_amd import api, synth  # noqa: E402
+from metacache_amd import api, synth, synthdb  # noqa: E402
 from metacache_amd.distributed import gather_candidates_async  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
-DEFAULT_BATCH = 10_000_000       # reads per step: the 10 M reads of configs[1] as one batch (4 M: 6 % slower per read, fixed per-batch costs)
 PAD_LEN = 152                  # every read starts 4-byte aligned
+KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_cands", "big_cands_2", "query_wave", "scan",
+           "sort_candidates")
+PMC_NAMES = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "sketch_probe": ("sketch_probe_lane",),
+             "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",),
+             "big_cands": ("big_cands",), "big_cands_2": ("big_cands",), "hash_cands_256": ("hash_cands",), "hash_cands_512": ("hash_cands",),
+             "hash_cands_1024": ("hash_cands",), "mid_cands_64": ("mid_cands",), "mid_cands_128": ("mid_cands",), "mid_cands_256": ("mid_cands",)}
+# configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
+CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
 
 
 def make_genomes(n_genomes: int, length: int, seed: int):
@@ -46,7 +63,7 @@ def make_genomes(n_genomes: int, length: int, seed: int):
 
 
 def synth_reads_gpu(gcat: torch.Tensor, goff: torch.Tensor, glen: int, n: int, seed: int) -> torch.Tensor:
-    """n reads of READ_LEN on the GPU: uniform genome, uniform start, random strand, 1 % substitutions,
+    """configs[1]: n reads of READ_LEN on the GPU: uniform genome, uniform start, random strand, 1 % substitutions,
     0.1 % N.  Returns uint8 [n, PAD_LEN] (zero padded)."""
     dev = gcat.device
     g = torch.Generator(device=dev)
@@ -72,23 +89,22 @@ def synth_reads_gpu(gcat: torch.Tensor, goff: torch.Tensor, glen: int, n: int, s
     return padded
 
 
-def measured_traffic(kernel_timer_name: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
-    workload (profiles/*_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes).
-    gfx950 caveat of MI355X_MICROARCH.md (FETCH_SIZE tallies every request at 64 B) calibrated for this
-    kernel's access pattern in profiles/r01_fetch_calibration.md: probe_cands reads 64-byte buckets = 64-byte
-    sector requests, which are counted at their true size, so no doubling here.  None if no summary exists."""
-    import csv, glob
-    names = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "sketch_probe": ("sketch_probe_lane",),
-             "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",)}.get(kernel_timer_name, ())
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), reverse=True):
-        vals = {}
-        for r in csv.DictReader(open(fn)):
-            if r["kernel"] in names and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
-        for k in names:
-            if k in vals and len(vals[k]) == 2:
-                return (vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
+def measured_traffic(kernel_timer_name: str, tag: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
+    (profiles/<tag>_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes; gfx950 caveat of
+    MI355X_MICROARCH.md calibrated in profiles/r01_fetch_calibration.md).  None if no summary of this configuration exists."""
+    import csv
+    names = PMC_NAMES.get(kernel_timer_name, ())
+    fn = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
+    if not os.path.exists(fn):
+        return None, None
+    vals = {}
+    for r in csv.DictReader(open(fn)):
+        if r["kernel"] in names and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
+    for k in names:
+        if k in vals and len(vals[k]) == 2:
+            return (vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
     return None, None
 
 
@@ -97,35 +113,81 @@ def algorithmic_bytes_per_read(F: float, H: float, K: int, V: int) -> float:
     return (READ_LEN + 3) // 4 + (READ_LEN + 7) // 8 + 12.0 * F + V * H + 16.0 * K
 
 
-def cpu_baseline(dbname: str, reads_host: np.ndarray, gpu_cands: np.ndarray, K: int, target_bytes: int, budget_s: float):
-    """Times the reference (oracle/_ref, kind 'reference') or our C restatement (kind 'port') on this
-    box's host cores on a bounded sample of the same reads, and compares its candidates with the GPU's."""
+def count_mismatches(gpu_cands: np.ndarray, cpu_cands: np.ndarray) -> int:
+    mism = np.zeros(len(cpu_cands), dtype=bool)
+    g = gpu_cands[:len(cpu_cands)]
+    for f in ("tgt", "hits", "beg", "end"):
+        mism |= ((g[f] != cpu_cands[f]) & ((g["hits"] > 0) | (cpu_cands["hits"] > 0))).any(axis=1)
+    return int(mism.sum())
+
+
+def thread_sweep(run, n_reads: int, budget_s: float, max_threads: int):
+    """times run(n, threads) over a thread sweep inside the budget; -> (best Mreads/min, threads, {threads: Mreads/min})"""
+    sweep, best = {}, (0.0, 1)
+    probe_n = min(n_reads, 2000)
+    t1, _ = run(probe_n, 1)
+    rate1 = probe_n / max(t1, 1e-9)
+    cands = [t for t in (1, 8, 32, 64, 128, 256) if t <= max_threads]
+    per = budget_s / max(len(cands), 1)
+    for t in cands:
+        n = int(min(n_reads, max(2000 * t, rate1 * min(t, 64) * per)))
+        el, _ = run(n, t)
+        v = n / max(el, 1e-9) * 60.0 / 1e6
+        sweep[t] = round(v, 2)
+        if v > best[0]:
+            best = (v, t)
+    return best[0], best[1], sweep
+
+
+def cpu_leg_config1(dbname, reads_host, gpu_cands, K, budget_s):
+    """configs[1]: the reference (oracle/_ref; the C oracle where it is absent) on the database files this repo wrote."""
     import cpuref
     n_total = reads_host.shape[0]
-    kind = "reference" if cpuref.have_reference(target_bytes) else "port"
-    ref = cpuref.reference(target_bytes) if kind == "reference" else cpuref.oracle()
-    cores = (os.cpu_count() or 1) if kind == "reference" else 1
+    kind = "reference" if cpuref.have_reference(2) else "port"
+    ref = cpuref.reference(2) if kind == "reference" else cpuref.oracle()
     db = ref.open(dbname)
 
-    def run(n):
+    def run(n, threads):
         seqs = np.ascontiguousarray(reads_host[:n, :READ_LEN]).reshape(-1)
         offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(READ_LEN)
-        return db.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=cores)
+        return db.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
 
-    probe_n = min(n_total, 20000 * cores)
-    t, _ = run(probe_n)
-    rate = probe_n / max(t, 1e-9)
-    n = int(min(n_total, max(probe_n, rate * budget_s)))
-    t, cands = run(n)
+    best, bt, sweep = thread_sweep(run, n_total, budget_s * 0.6, os.cpu_count() or 1)
+    n = int(min(n_total, max(100_000, best * 1e6 / 60.0 * budget_s * 0.4)))
+    t, cands = run(n, bt)
     db.close()
-    mism = 0
-    g = gpu_cands[:n]
-    for f in ("tgt", "hits", "beg", "end"):
-        mism_f = (g[f] != cands[f]) & ((g["hits"] > 0) | (cands["hits"] > 0))
-        mism = max(mism, int(mism_f.any(axis=1).sum()))
-    return {"value": n / t * 60.0 / 1e6, "unit": "Mreads/min", "cores": cores, "kind": kind,
-            "sample": f"{n} reads of the same workload (batch 0), {cores} host thread(s), database files written by this repo"}, \
-           {"checked": n, "mismatches": mism, "against": kind}
+    return ({"value": round(max(best, n / t * 60 / 1e6), 2), "unit": "Mreads/min", "cores": bt, "kind": kind, "thread_sweep": sweep,
+             "sample": f"{n} reads of the same workload (batch 0) on {bt} host threads (best of the sweep), database files written by this repo"},
+            {"checked": n, "mismatches": count_mismatches(gpu_cands, cands), "against": kind})
+
+
+def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s):
+    """configs[2]: a 100+ GB table is out of the checker's budget (the reference would need the whole database written to files and
+    loaded single-threaded: minutes), but a read sample only ever looks at the buckets of ITS features: the C oracle builds exactly
+    those from the same collection (mco_db_build: its own restatement of the database build) and classifies the sample."""
+    import scale_util
+    threads = os.cpu_count() or 1
+    n = min(n_parity, reads_host.shape[0])
+    t0 = time.time()
+    wanted = scale_util.sample_features([reads_host[i, :READ_LEN].tobytes() for i in range(n)])
+    odb = scale_util.oracle_database(spec, wanted, threads=threads)
+    build_s = time.time() - t0
+
+    def run(m, th):
+        seqs = np.ascontiguousarray(reads_host[:m, :READ_LEN]).reshape(-1)
+        offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+        return odb.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=th)
+
+    t, cands = run(n, min(threads, 64))
+    mism = count_mismatches(gpu_cands, cands)
+    best, bt, sweep = thread_sweep(run, n, budget_s, threads)
+    info = odb.info()
+    odb.close()
+    return ({"value": round(best, 2), "unit": "Mreads/min", "cores": bt, "kind": "port", "thread_sweep": sweep,
+             "sample": f"{n} reads of the same workload (batch 0); C oracle on {bt} host threads (best of the sweep) against the buckets of the "
+                       f"sample's {len(wanted)} features ({info[7]} locations), which it built itself from the same collection in {build_s:.0f} s "
+                       f"on {threads} threads; the reference itself cannot load a table of this size inside the budget"},
+            {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
 
 
 def main():
@@ -133,12 +195,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="reads per step per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2), help="BASELINE.json configs[i]")
+    ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: 5 M for configs[2], 10 M for configs[1])")
+    ap.add_argument("--scale", type=float, default=1.0, help="configs[2]: fraction of the 2000 genera (quick runs)")
+    ap.add_argument("--build-shards", type=int, default=0, help="configs[2]: key-shard passes of the build (0 = by size)")
     ap.add_argument("--genomes", type=int, default=16)
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--maxcand", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--load-factor", type=float, default=0.3)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip both checker legs)")
+    ap.add_argument("--parity-reads", type=int, default=200_000, help="configs[2]: reads checked against the oracle")
+    ap.add_argument("--load-factor", type=float, default=0.0, help="0 = 0.3 for configs[1], 0.5 for configs[2]")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
     args = ap.parse_args()
 
@@ -156,31 +222,59 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     K = args.maxcand
-    B = args.batch
-    # ---- database (replicated on every rank): built on the GPU by our builder ------------------
-    genomes = make_genomes(args.genomes, args.genome_len, seed=16)
-    t0 = time.time()
-    bld = api.Builder(device=local, target_id_bytes=2, max_candidates=K, max_load_factor=args.load_factor)
-    for i, gnm in enumerate(genomes):
-        bld.add_target(gnm, f"SYN_{i:06d}.1", parent_taxid=1000 + i, filename=f"syn{i}.fa")
-    db = bld.finish(load=True)
-    build_s = time.time() - t0
+    cfg = args.config
+    B = args.batch or (5_000_000 if cfg == 2 else 10_000_000)
+    lf = args.load_factor or (0.5 if cfg == 2 else 0.3)
+    nb = max(1, min(max(args.steps, args.warmup), 8 if cfg == 1 else 4))         # distinct batches resident in HBM, reused cyclically
+    spec = None
     dbdir = None
-    if rank == 0 and args.cpu_seconds > 0:
-        dbdir = tempfile.mkdtemp(prefix="mcbench")
-        taxa = [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"synthetic species {i}") for i in range(args.genomes)]
-        bld.write(os.path.join(dbdir, "syn16"), taxa)
-    bld.free()
+    build_info = {}
+    t0 = time.time()
+    if cfg == 1:
+        # ---- configs[1]: 16 x 5 Mbp, uint16 targets, replicated on every rank, built on the GPU by our builder ------------------
+        genomes = make_genomes(args.genomes, args.genome_len, seed=16)
+        bld = api.Builder(device=local, target_id_bytes=2, max_candidates=K, max_load_factor=lf)
+        for i, gnm in enumerate(genomes):
+            bld.add_target(gnm, f"SYN_{i:06d}.1", parent_taxid=1000 + i, filename=f"syn{i}.fa")
+        db = bld.finish(load=True)
+        if rank == 0 and args.cpu_seconds > 0 and world == 1:
+            dbdir = tempfile.mkdtemp(prefix="mcbench")
+            taxa = [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"synthetic species {i}") for i in range(args.genomes)]
+            bld.write(os.path.join(dbdir, "syn16"), taxa)
+        bld.free()
+        gcat = torch.from_numpy(np.concatenate(genomes)).to(dev)
+        goff = torch.arange(args.genomes, device=dev, dtype=torch.int64) * args.genome_len
+        batches = [synth_reads_gpu(gcat, goff, args.genome_len, B, seed=1016 + 7919 * rank + s).reshape(-1) for s in range(nb)]
+        del gcat
+        V = 6                                                  # uint16 target ids: 6-byte locations in the file format
+        workload = (f"configs[1]: {args.genomes}x{args.genome_len} bp synthetic DB (uint16 target ids, 1 partition), "
+                    f"{world * args.steps * B} synthetic 150 bp reads")
+        pmc_tag = "r02c1"
+    else:
+        # ---- configs[2]: RefSeq-scale phylogeny, uint32 targets, built on this GPU in key shards ---------------------------------
+        c2 = dict(CFG2)
+        c2["genera"] = max(2, int(round(c2["genera"] * args.scale)))
+        spec = synthdb.phylogeny(**c2)
+        est_pairs = spec.total_bases // 112 * 16
+        shards = args.build_shards or max(1, int(np.ceil(est_pairs / 1.4e9)))
+        say = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if rank == 0 else None
+        db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say)
+        gen = synthdb.GpuSynth(local)
+        P = synthdb.read_params(spec, 3100)
+        assert P.row_bytes == PAD_LEN
+        batches = []
+        for s in range(nb):
+            t = torch.zeros(B * PAD_LEN, dtype=torch.uint8, device=dev)
+            gen.reads(spec, P, (rank * 64 + s) * B, B, t)
+            batches.append(t)
+        V = 8
+        workload = (f"configs[2]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
+                    f"(genus>species>strain phylogeny, uint32 target ids, 1 partition{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
+                    f"{world * args.steps * B} synthetic 150 bp reads")
+        pmc_tag = "r02"
+    build_s = time.time() - t0
     db_info = db.info()
 
-    # ---- reads: resident in HBM before the timed region ----------------------------------------
-    gcat = torch.from_numpy(np.concatenate(genomes)).to(dev)
-    goff = torch.arange(args.genomes, device=dev, dtype=torch.int64) * args.genome_len
-    nb = max(1, min(max(args.steps, args.warmup), 8))                            # distinct batches resident in HBM, reused cyclically
-    batches = []
-    for s in range(nb):
-        batches.append(synth_reads_gpu(gcat, goff, args.genome_len, B, seed=1016 + 7919 * rank + s).reshape(-1))
-    del gcat
     qinfo = torch.zeros((B, 4), dtype=torch.int32, device=dev)
     qinfo[:, 0] = torch.arange(B, device=dev, dtype=torch.int32) * PAD_LEN
     qinfo[:, 1] = READ_LEN
@@ -229,7 +323,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    F_sum = H_sum = 0
     for i in range(args.steps):
         step(i)
     drain()                                                  # every gather has arrived on rank 0
@@ -245,25 +338,24 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kt = {k: db.timing_get(k) for k in ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "scan", "sort_candidates")}
+        kt = {k: db.timing_get(k) for k in KERNELS}
         st = db.last_batch_stats()                            # of the last timed batch
         F, H = st["features"] / B, st["locations"] / B
-        V = 6                                                 # uint16 target ids: 6-byte locations in the file format
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
-        dom = max(("sketch_probe", "sketch_lane", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "query_wave", "sort_candidates"), key=lambda k: kt[k][0])
+        dom = max((k for k in KERNELS if k not in ("plan", "scan")), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * B / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(dom) if B == DEFAULT_BATCH else (None, None)   # the committed PMC passes ran the default batch
+        traffic, traffic_src = measured_traffic(dom, pmc_tag)
         total_reads = world * args.steps * B
         value = total_reads / elapsed * 60.0 / 1e6
         result = {
             "metric": "Mreads/min (150 bp)", "value": round(value, 2), "unit": "Mreads/min", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.genomes}x{args.genome_len} bp synthetic DB (uint16 target ids, 1 partition), "
-                                   f"{total_reads} synthetic 150 bp reads", "reads_per_step_per_gpu": B,
+            "config": {"workload": workload, "reads_per_step_per_gpu": B,
                        "maxcand": K, "k": db.k, "sketchlen": db.s, "winlen": db.w, "winstride": db.stride,
-                       "db_locations": db_info[7], "db_build_s": round(build_s, 2), "load_factor": args.load_factor,
+                       "db_targets": db_info[5], "db_locations": db_info[7], "db_build_s": round(build_s, 2), "db_build": build_info, "load_factor": lf,
+                       "hbm_used_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
                        "parallelism": f"replicated DB x{world}, reads sharded, RCCL gather of top candidates"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -272,14 +364,18 @@ def main():
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
         if world == 1 and args.cpu_seconds > 0:
-            res = step(0)
+            step(0)
             drain()
             db.synchronize()
-            gpu_c = out_cands.cpu().numpy().view(np.uint32).reshape(B, K, 4)
-            gc = np.zeros((B, K), dtype=api.cand_dtype)
+            n_chk = B if cfg == 1 else min(B, args.parity_reads)
+            gpu_c = out_cands[:n_chk].cpu().numpy().view(np.uint32).reshape(n_chk, K, 4)
+            gc = np.zeros((n_chk, K), dtype=api.cand_dtype)
             gc["tgt"], gc["hits"], gc["beg"], gc["end"] = gpu_c[..., 0], gpu_c[..., 1], gpu_c[..., 2], gpu_c[..., 3]
-            reads_host = batches[0][: B * PAD_LEN].reshape(B, PAD_LEN).cpu().numpy()
-            cb, par = cpu_baseline(os.path.join(dbdir, "syn16"), reads_host, gc, K, 2, args.cpu_seconds)
+            reads_host = batches[0][: n_chk * PAD_LEN].reshape(n_chk, PAD_LEN).cpu().numpy()
+            if cfg == 1:
+                cb, par = cpu_leg_config1(os.path.join(dbdir, "syn16"), reads_host, gc, K, args.cpu_seconds)
+            else:
+                cb, par = cpu_leg_config2(spec, reads_host, gc, K, args.parity_reads, args.cpu_seconds)
             result["cpu_baseline"] = cb
             result["parity"] = par
     db.close()

@@ -247,6 +247,16 @@ int  mc_build_add_target(mc_builder* b, const char* seq, uint64_t len, const cha
 /* the same with the position of the sequence inside its file (taxon::file_source::index, building.cpp:414-416) */
 int  mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parent_taxid,
                              const char* source_filename, uint64_t source_index);
+/* the same for a sequence that already lies in DEVICE memory (start 4-byte aligned, 16 readable bytes behind its last character):
+ * nothing is staged or copied, the sketch kernels read it in place.  The memory must stay untouched until mc_build_flush or
+ * mc_build_finish returns.  (The reference's GPU build takes host sequences only, gpu_hashmap.cu:1024-1120; collections that
+ * are generated or decoded on the device -- bench.py's RefSeq-scale synthetic database -- go in without a PCIe round trip.) */
+int  mc_build_add_target_device(mc_builder* b, const void* dseq, uint64_t len, const char* name, int64_t parent_taxid,
+                                const char* source_filename, uint64_t source_index);
+/* sketches everything staged so far (sources of mc_build_add_target_device calls may be reused afterwards) */
+int  mc_build_flush(mc_builder* b);
+/* allocates room for this many (feature, location) pairs up front (a builder that grows step by step holds two copies while growing) */
+int  mc_build_reserve(mc_builder* b, uint64_t pairs);
 /* re-ranks a target after it was added (try_to_rank_unranked_targets, building.cpp:196-232) */
 int  mc_build_set_parent(mc_builder* b, uint64_t target, int64_t parent_taxid);
 /* modify mode (main_mode_modify, mode_build.cpp:74-88: an existing database is read, then added to): the database's targets
@@ -275,6 +285,15 @@ int  mc_build_finish(mc_builder* b, mc_ctx** out_ctx);
  * a builder keeps only the features of its shard, as a Mode K context does): tables beyond the 2^32 (feature, location) pairs one
  * device sort takes are built shard after shard.  n == 1: the loading half of mc_build_finish. */
 int  mc_build_finish_shards(mc_builder** builders, uint32_t n, mc_ctx** out_ctx);
+/* Streaming form of mc_build_finish_shards for tables that do not fit next to all their builders (RefSeq scale: 2 x 10^10 locations):
+ *   mc_build_table_begin  creates the query context and sizes its table for expect_keys features / expect_values locations
+ *                         (0 = estimate from the FINISHED builder b: its counts times its key_shard_count, plus a margin);
+ *   mc_build_table_add    inserts one finished builder -- a whole one or one key shard, same targets -- from its device arrays;
+ *                         the builder can be freed right after;
+ *   mc_build_table_end    closes the load (mc_load_end).  More keys or locations than announced fail with MC_ERR_INVALID. */
+int  mc_build_table_begin(mc_builder* b, uint64_t expect_keys, uint64_t expect_values, mc_ctx** out_ctx);
+int  mc_build_table_add(mc_ctx* ctx, mc_builder* shard);
+int  mc_build_table_end(mc_ctx* ctx);
 /* fields of the query context mc_build_finish creates (max_candidates, slots, copy_allhits, load factor) */
 int  mc_build_set_query_config(mc_builder* b, const mc_config* qcfg);
 /* writes <name>.meta and <name>.cache0 in the reference's format (after mc_build_finish) */

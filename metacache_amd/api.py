@@ -54,7 +54,8 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
-           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
+           "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_add_target_device", "mc_build_flush", "mc_build_reserve",
+           "mc_build_table_begin", "mc_build_table_add", "mc_build_table_end", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
 
 _lib = None
@@ -141,6 +142,9 @@ class Database:
     def __init__(self, handle, cfg: McConfig):
         self.h = C.c_void_p(handle)
         self.cfg = cfg
+        self.refresh_info()
+
+    def refresh_info(self):
         info = np.zeros(8, dtype=np.uint64)
         self._check(lib().mc_db_info(self.h, info.ctypes.data_as(C.c_void_p)))
         (self.k, self.s, self.w, self.stride, self.max_locs, self.n_targets, self.n_parts, self.n_locations) = map(int, info)
@@ -325,6 +329,40 @@ class Builder:
     def add_target(self, seq: np.ndarray | bytes, name: str, parent_taxid: int = 0, filename: str = ""):
         a = np.frombuffer(seq, dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(seq, dtype=np.uint8)
         self._check(lib().mc_build_add_target(self.h, a.ctypes.data_as(C.c_void_p), a.size, name.encode(), parent_taxid, filename.encode()))
+
+    def add_target_device(self, ptr: int, length: int, name: str, parent_taxid: int = 0, filename: str = "", file_index: int = 0):
+        """a target whose characters are already in device memory (mc_build_add_target_device): valid until flush() / finish()"""
+        L = lib()
+        L.mc_build_add_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int64, C.c_char_p, C.c_uint64]
+        self._check(L.mc_build_add_target_device(self.h, ptr, length, name.encode(), parent_taxid, filename.encode(), file_index))
+
+    def flush(self):
+        lib().mc_build_flush.argtypes = [C.c_void_p]
+        self._check(lib().mc_build_flush(self.h))
+
+    def reserve(self, pairs: int):
+        lib().mc_build_reserve.argtypes = [C.c_void_p, C.c_uint64]
+        self._check(lib().mc_build_reserve(self.h, pairs))
+
+    def table_begin(self, expect_keys: int = 0, expect_values: int = 0) -> "Database":
+        """streaming table build (mc_build_table_begin): -> Database whose table takes finished builders through table_add()"""
+        self._sync_cfg()
+        out = C.c_void_p()
+        lib().mc_build_table_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+        self._check(lib().mc_build_table_begin(self.h, expect_keys, expect_values, C.byref(out)))
+        cfg = McConfig.from_buffer_copy(self.cfg)
+        cfg.key_shard_index, cfg.key_shard_count = 0, 1
+        return Database.from_handle(out.value, cfg)
+
+    def table_add(self, db: "Database"):
+        lib().mc_build_table_add.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(lib().mc_build_table_add(db.h, self.h))
+
+    @staticmethod
+    def table_end(db: "Database"):
+        lib().mc_build_table_end.argtypes = [C.c_void_p]
+        db._check(lib().mc_build_table_end(db.h))
+        db.refresh_info()
 
     def finish(self, load: bool = True, **query_kw) -> "Database | None":
         """Sort + bucketise.  load=True also returns a query Database holding the table."""

@@ -64,7 +64,33 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     build_cli(force=force, verbose=verbose)
+    build_synth(force=force, verbose=verbose)
     return LIB
+
+
+SYNTH_DIR = os.path.join(PKG, "synth")
+SYNTH_LIB = os.path.join(LIBDIR, "libmcsynth.so")
+SYNTH_CPU_LIB = os.path.join(LIBDIR, "libmcsynth_cpu.so")
+
+
+def build_synth(force: bool = False, verbose: bool = False) -> tuple[str, str]:
+    """The synthetic-workload generators (metacache_amd/synth): libmcsynth.so (HIP) and libmcsynth_cpu.so (C).
+    Workload generation for bench.py / tests / tools only -- separate libraries, nothing of it is in the product."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    spec = os.path.join(SYNTH_DIR, "synth_spec.h")
+    hip = os.path.join(SYNTH_DIR, "synth.hip")
+    cpu = os.path.join(SYNTH_DIR, "synth_cpu.c")
+    if force or _stale(SYNTH_LIB, [hip, spec]):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-o", SYNTH_LIB, hip]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or _stale(SYNTH_CPU_LIB, [cpu, spec]):
+        cmd = ["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-o", SYNTH_CPU_LIB, cpu]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SYNTH_LIB, SYNTH_CPU_LIB
 
 
 def build_cli(force: bool = False, verbose: bool = False) -> str:

@@ -31,9 +31,11 @@ struct mc_builder {
     hipStream_t st = nullptr;
     std::string err;
     std::vector<TargetRec> targets;
-    // staged chunks (host)
+    // staged chunk records: their characters are either copied into hseq (host sources) or stay where the caller put them in
+    // device memory (mc_build_add_target_device: offsets relative to devBase, valid until the next flush)
     std::vector<uint8_t> hseq;
     std::vector<uint32_t> hqinfo, hqtgt, hqfirst;
+    const uint8_t* devBase = nullptr; uint64_t devChars = 0;   // device sources of the staged records; characters they cover
     // all pairs so far (device, grow-only)
     uint32_t* dkeys = nullptr; uint64_t* dvals = nullptr; uint64_t npairs = 0, cap = 0;
     // result: the file's arrays -- keys, bucket sizes, location lists ((tgt << 32) | win = {u32 win; u32 tgt}) -- on the device
@@ -45,7 +47,8 @@ struct mc_builder {
 namespace {
 
 constexpr uint32_t kChunkWindows = 256;
-constexpr uint64_t kFlushChars = 96ull << 20;
+constexpr uint64_t kFlushChars = 96ull << 20;          // host sources: staged and uploaded in pieces of this size
+constexpr uint64_t kFlushCharsDevice = 3ull << 30;   // device sources: characters per flush (feature scratch = 64 B per window)
 
 #define B_TRY(b, expr)                                                                              \
     do {                                                                                            \
@@ -53,40 +56,51 @@ constexpr uint64_t kFlushChars = 96ull << 20;
         if (e_ != hipSuccess) { (b)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return MC_ERR_HIP; } \
     } while (0)
 
-// one thread per window: pairs[(w*s + j)] = (feature, (tgt << 32) | window id)
-__global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ features, const uint32_t* __restrict__ winOff,
-                                                         const uint32_t* __restrict__ qtgt, const uint32_t* __restrict__ qfirst,
-                                                         uint32_t nq, uint32_t s, uint32_t* __restrict__ keys, uint64_t* __restrict__ vals)
+// The window sketches of a flush become (feature, location) pairs behind the pairs so far -- only the valid features (the padding
+// 0xFFFFFFFF of short sketches never leaves) and, in a key-sharded builder, only this shard's.  Two passes, one wave per chunk
+// record, order kept (the sort that follows is stable: the locations of a feature stay in (target, window) order):
+//   own_count : features of the record that are kept            -> scan -> first pair index of every record
+//   own_emit  : pairs[(first + rank)] = (feature, (tgt << 32) | window id)
+__device__ __forceinline__ bool own_feature(uint32_t f, uint32_t shardIdx, uint32_t shardCnt)
+{
+    return f != 0xFFFFFFFFu && (shardCnt <= 1 || key_owner(f, shardCnt) == shardIdx);
+}
+__global__ __launch_bounds__(256) void own_count_kernel(const uint32_t* __restrict__ features, const uint32_t* __restrict__ winOff, uint32_t nq,
+                                                        uint32_t s, uint32_t shardIdx, uint32_t shardCnt, uint32_t* __restrict__ recCount)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
-    const uint32_t w0 = winOff[q], w1 = winOff[q + 1];
+    const uint32_t w0 = winOff[q], total = (winOff[q + 1] - w0) * s;
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < total; i += 64) cnt += own_feature(features[(size_t)w0 * s + i], shardIdx, shardCnt) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if (lane == 0) recCount[q] = cnt;
+}
+__global__ __launch_bounds__(256) void own_emit_kernel(const uint32_t* __restrict__ features, const uint32_t* __restrict__ winOff,
+                                                       const uint32_t* __restrict__ qtgt, const uint32_t* __restrict__ qfirst, uint32_t nq,
+                                                       uint32_t s, uint32_t shardIdx, uint32_t shardCnt, const uint32_t* __restrict__ recPos,
+                                                       uint32_t* __restrict__ keys, uint64_t* __restrict__ vals)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const uint32_t w0 = winOff[q], total = (winOff[q + 1] - w0) * s;
     const uint64_t tgt = qtgt[q];
     const uint32_t first = qfirst[q];
-    const uint32_t total = (w1 - w0) * s;
-    for (uint32_t i = lane; i < total; i += 64) {
-        const uint32_t w = i / s;
-        const size_t idx = (size_t)w0 * s + i;
-        keys[idx] = features[idx];
-        vals[idx] = (tgt << 32) | (first + w);
+    uint32_t at = recPos[q];
+    for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t f = i < total ? features[(size_t)w0 * s + i] : 0xFFFFFFFFu;
+        const bool own = own_feature(f, shardIdx, shardCnt);
+        const uint64_t mask = __ballot(own);
+        if (own) {
+            const uint32_t o = at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            keys[o] = f;
+            vals[o] = (tgt << 32) | (first + i / s);
+        }
+        at += (uint32_t)__popcll(mask);
     }
-}
-
-// key-sharded build (cfg.key_shard_count > 1): which of the emitted pairs belong to this builder's shard ...
-__global__ __launch_bounds__(256) void own_flags_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shardIdx, uint32_t shardCnt,
-                                                        uint32_t* __restrict__ flags)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) flags[i] = (keys[i] != 0xFFFFFFFFu && key_owner(keys[i], shardCnt) == shardIdx) ? 1u : 0u;
-}
-// ... and their move to the front, order kept (the sort that follows is stable: locations stay in (target, window) order)
-__global__ __launch_bounds__(256) void own_scatter_kernel(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ vals, uint64_t n,
-                                                          const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
-                                                          uint32_t* __restrict__ okeys, uint64_t* __restrict__ ovals)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n && flags[i]) { okeys[pos[i]] = keys[i]; ovals[pos[i]] = vals[i]; }
 }
 
 // per run (= feature): kept size and its u32 copy for the scan
@@ -161,13 +175,13 @@ __global__ __launch_bounds__(256) void ambig_offsets_kernel(const uint32_t* __re
     if (i < nkeys && keep[i]) out[kpos[i]] = nvoff[i];
 }
 
-int grow_pairs(mc_builder* b, uint64_t need)
+int grow_pairs(mc_builder* b, uint64_t need, bool exact = false)
 {
     if (need <= b->cap) return MC_OK;
-    uint64_t ncap = std::max<uint64_t>(need + need / 2, 1u << 20);
+    uint64_t ncap = exact ? need : std::max<uint64_t>(need + need / 2, 1u << 20);
     uint32_t* nk = nullptr; uint64_t* nv = nullptr;
     B_TRY(b, hipMalloc((void**)&nk, ncap * 4));
-    B_TRY(b, hipMalloc((void**)&nv, ncap * 8));
+    if (hipMalloc((void**)&nv, ncap * 8) != hipSuccess) { (void)hipFree(nk); b->err = "out of device memory for (feature, location) pairs"; return MC_ERR_NOMEM; }
     if (b->npairs) {
         B_TRY(b, hipMemcpyAsync(nk, b->dkeys, b->npairs * 4, hipMemcpyDeviceToDevice, b->st));
         B_TRY(b, hipMemcpyAsync(nv, b->dvals, b->npairs * 8, hipMemcpyDeviceToDevice, b->st));
@@ -179,78 +193,66 @@ int grow_pairs(mc_builder* b, uint64_t need)
     return MC_OK;
 }
 
+// scratch of one flush: freed on every way out
+struct FlushBufs {
+    std::vector<void*> p;
+    ~FlushBufs() { for (void* q : p) if (q) (void)hipFree(q); }
+    template <class T> hipError_t get(T** out, size_t bytes) { void* q = nullptr; hipError_t e = hipMalloc(&q, bytes ? bytes : 16); if (e == hipSuccess) { p.push_back(q); *out = (T*)q; } return e; }
+};
+
 int flush(mc_builder* b)
 {
     const uint32_t nq = (uint32_t)(b->hqinfo.size() / 4);
     if (nq == 0) return MC_OK;
-    const uint64_t nchars = b->hseq.size();
+    const bool fromDevice = b->devBase != nullptr;
+    const uint64_t nchars = fromDevice ? b->devChars : b->hseq.size();
     const SketchParams sp = b->sp;
     const uint64_t maxWindows = nchars / sp.stride + 4ull * nq + 1;
+    FlushBufs fb;
     uint8_t* dseq = nullptr; uint32_t *dq = nullptr, *dtgt = nullptr, *dfirst = nullptr, *dwc = nullptr, *dwo = nullptr, *dfeat = nullptr;
-    uint32_t* dhs = nullptr; QueryStat* dqs = nullptr; void* dscan = nullptr;
-    B_TRY(b, hipMalloc((void**)&dseq, nchars + 16));
-    B_TRY(b, hipMalloc((void**)&dq, (size_t)nq * 16));
-    B_TRY(b, hipMalloc((void**)&dtgt, (size_t)nq * 4));
-    B_TRY(b, hipMalloc((void**)&dfirst, (size_t)nq * 4));
-    B_TRY(b, hipMalloc((void**)&dwc, (size_t)(nq + 1) * 4));
-    B_TRY(b, hipMalloc((void**)&dwo, (size_t)(nq + 2) * 4));
-    B_TRY(b, hipMalloc((void**)&dfeat, (size_t)maxWindows * sp.s * 4));
-    B_TRY(b, hipMalloc((void**)&dhs, (size_t)(nq + 1) * 4));
-    B_TRY(b, hipMalloc((void**)&dqs, (size_t)(nq + 1) * sizeof(QueryStat)));
-    B_TRY(b, hipMalloc(&dscan, scan_tmp_bytes(nq + 1)));
-    B_TRY(b, hipMemsetAsync(dseq + nchars, 0, 16, b->st));
-    B_TRY(b, hipMemcpyAsync(dseq, b->hseq.data(), nchars, hipMemcpyHostToDevice, b->st));
+    uint32_t *dflag = nullptr, *dcnt = nullptr, *dpos = nullptr; void* dscan = nullptr;
+    if (!fromDevice) {
+        B_TRY(b, fb.get(&dseq, nchars + 16));
+        B_TRY(b, hipMemsetAsync(dseq + nchars, 0, 16, b->st));
+        B_TRY(b, hipMemcpyAsync(dseq, b->hseq.data(), nchars, hipMemcpyHostToDevice, b->st));
+    }
+    B_TRY(b, fb.get(&dq, (size_t)nq * 16));
+    B_TRY(b, fb.get(&dtgt, (size_t)nq * 4));
+    B_TRY(b, fb.get(&dfirst, (size_t)nq * 4));
+    B_TRY(b, fb.get(&dwc, (size_t)(nq + 1) * 4));
+    B_TRY(b, fb.get(&dwo, (size_t)(nq + 2) * 4));
+    B_TRY(b, fb.get(&dfeat, (size_t)maxWindows * sp.s * 4));
+    B_TRY(b, fb.get(&dflag, (size_t)(nq + 1) * 4));
+    B_TRY(b, fb.get(&dcnt, (size_t)(nq + 1) * 4));
+    B_TRY(b, fb.get(&dpos, (size_t)(nq + 2) * 4));
+    B_TRY(b, fb.get(&dscan, scan_tmp_bytes(nq + 1)));
     B_TRY(b, hipMemcpyAsync(dq, b->hqinfo.data(), (size_t)nq * 16, hipMemcpyHostToDevice, b->st));
     B_TRY(b, hipMemcpyAsync(dtgt, b->hqtgt.data(), (size_t)nq * 4, hipMemcpyHostToDevice, b->st));
     B_TRY(b, hipMemcpyAsync(dfirst, b->hqfirst.data(), (size_t)nq * 4, hipMemcpyHostToDevice, b->st));
 
-    BatchView bv{dseq, dq, nullptr, 1, nq};
+    BatchView bv{fromDevice ? b->devBase : dseq, dq, nullptr, 1, nq};
     Workspace ws{};
-    ws.winCount = dwc; ws.winOff = dwo; ws.features = dfeat; ws.qstat = dqs; ws.hitScan = dhs; ws.scanTmp = dscan;
+    ws.winCount = dwc; ws.winOff = dwo; ws.features = dfeat; ws.qflag = dflag; ws.scanTmp = dscan;
     launch_plan(bv, sp, dwc, b->st);
     launch_scan_u32(dwc, 1, nq, dwo, nullptr, dscan, b->st);
-    launch_sketch_only(bv, sp, ws, b->st);
-    uint32_t W = 0;
+    launch_build_sketch(bv, sp, ws, b->st);
+    const uint32_t shardIdx = b->cfg.key_shard_index, shardCnt = std::max<uint32_t>(b->cfg.key_shard_count, 1);
+    hipLaunchKernelGGL(own_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, nq, sp.s, shardIdx, shardCnt, dcnt);
+    launch_scan_u32(dcnt, 1, nq, dpos, nullptr, dscan, b->st);
+    uint32_t W = 0, kept = 0;
     B_TRY(b, hipMemcpyAsync(&W, dwo + nq, 4, hipMemcpyDeviceToHost, b->st));
+    B_TRY(b, hipMemcpyAsync(&kept, dpos + nq, 4, hipMemcpyDeviceToHost, b->st));
     B_TRY(b, hipStreamSynchronize(b->st));
-    const uint64_t emitted = (uint64_t)W * sp.s;
-    if (b->cfg.key_shard_count > 1) {
-        // only this shard's features are kept: emitted into scratch, then compacted (order kept) behind the pairs so far
-        uint32_t *tk = nullptr, *flags = nullptr, *pos = nullptr; uint64_t* tv = nullptr; void* stmp = nullptr;
-        B_TRY(b, hipMalloc((void**)&tk, (emitted + 1) * 4));
-        B_TRY(b, hipMalloc((void**)&tv, (emitted + 1) * 8));
-        B_TRY(b, hipMalloc((void**)&flags, (emitted + 1) * 4));
-        B_TRY(b, hipMalloc((void**)&pos, (emitted + 2) * 4));
-        B_TRY(b, hipMalloc(&stmp, scan_tmp_bytes((uint32_t)emitted + 1)));
-        hipLaunchKernelGGL(emit_pairs_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s, tk, tv);
-        uint32_t kept = 0;
-        if (emitted) {
-            hipLaunchKernelGGL(own_flags_kernel, dim3((uint32_t)((emitted + 255) / 256)), dim3(256), 0, b->st, tk, emitted, b->cfg.key_shard_index,
-                               b->cfg.key_shard_count, flags);
-            launch_scan_u32(flags, 1, (uint32_t)emitted, pos, nullptr, stmp, b->st);
-            B_TRY(b, hipMemcpyAsync(&kept, pos + emitted, 4, hipMemcpyDeviceToHost, b->st));
-            B_TRY(b, hipStreamSynchronize(b->st));
-        }
-        int rc = grow_pairs(b, b->npairs + kept);
-        if (rc) return rc;
-        if (emitted) hipLaunchKernelGGL(own_scatter_kernel, dim3((uint32_t)((emitted + 255) / 256)), dim3(256), 0, b->st, tk, tv, emitted, flags, pos,
-                                        b->dkeys + b->npairs, b->dvals + b->npairs);
-        B_TRY(b, hipGetLastError());
-        B_TRY(b, hipStreamSynchronize(b->st));
-        b->npairs += kept;
-        for (void* p : {(void*)tk, (void*)tv, (void*)flags, (void*)pos, stmp}) (void)hipFree(p);
-    } else {
-        int rc = grow_pairs(b, b->npairs + emitted);
-        if (rc) return rc;
-        hipLaunchKernelGGL(emit_pairs_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s,
-                           b->dkeys + b->npairs, b->dvals + b->npairs);
-        B_TRY(b, hipGetLastError());
-        B_TRY(b, hipStreamSynchronize(b->st));
-        b->npairs += emitted;
-    }
-    for (void* p : {(void*)dseq, (void*)dq, (void*)dtgt, (void*)dfirst, (void*)dwc, (void*)dwo, (void*)dfeat, (void*)dhs, (void*)dqs, dscan})
-        (void)hipFree(p);
+    if ((uint64_t)W > maxWindows) { b->err = "flush: more windows than planned"; return MC_ERR_STATE; }
+    int rc = grow_pairs(b, b->npairs + kept);
+    if (rc) return rc;
+    if (kept) hipLaunchKernelGGL(own_emit_kernel, dim3((nq + 3) / 4), dim3(256), 0, b->st, dfeat, dwo, dtgt, dfirst, nq, sp.s, shardIdx, shardCnt, dpos,
+                                 b->dkeys + b->npairs, b->dvals + b->npairs);
+    B_TRY(b, hipGetLastError());
+    B_TRY(b, hipStreamSynchronize(b->st));
+    b->npairs += kept;
     b->hseq.clear(); b->hqinfo.clear(); b->hqtgt.clear(); b->hqfirst.clear();
+    b->devBase = nullptr; b->devChars = 0;
     return MC_OK;
 }
 
@@ -309,8 +311,10 @@ int mc_build_target_windows(const mc_builder* b, uint64_t target, uint64_t* wind
     return MC_OK;
 }
 
-int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parentTaxid, const char* filename,
-                            uint64_t fileIndex)
+// the chunk records of one target: window-aligned pieces of <= kChunkWindows windows, all but the last full windows only (tail
+// suppressed); host sources are copied into the staging buffer, device sources stay where they are
+static int add_target_impl(mc_builder* b, const uint8_t* seq, bool onDevice, uint64_t len, const char* name, int64_t parentTaxid,
+                           const char* filename, uint64_t fileIndex)
 {
     if (!b || (!seq && len)) return MC_ERR_INVALID;
     if (b->finished) { b->err = "builder already finished"; return MC_ERR_STATE; }
@@ -318,11 +322,17 @@ int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const 
     if (b->targets.size() >= maxTargets) { b->err = "target count limit exceeded"; return MC_ERR_UNSUPPORTED; }
     if (len >= (1ull << 32) - 16) { b->err = "target sequence too long for one call"; return MC_ERR_UNSUPPORTED; }
     B_TRY(b, hipSetDevice(b->cfg.device));
+    if (onDevice) {
+        if (reinterpret_cast<uintptr_t>(seq) & 3u) { b->err = "mc_build_add_target_device: sequence must start 4-byte aligned"; return MC_ERR_INVALID; }
+        // one flush covers one 32-bit offset range of device memory; host and device sources are not mixed in a flush
+        const bool fits = b->devBase && seq >= b->devBase && (uint64_t)(seq - b->devBase) + len + 16 < 0xFFFFFFF0ull && b->devChars < kFlushCharsDevice;
+        if (!b->hseq.empty() || (b->devBase && !fits)) { int rc = flush(b); if (rc) return rc; }
+        if (!b->devBase) b->devBase = seq;
+    } else if (b->devBase) { int rc = flush(b); if (rc) return rc; }
     const SketchParams sp = b->sp;
     const uint32_t tgt = (uint32_t)b->targets.size();
     const uint32_t L = (uint32_t)len;
     const uint32_t total = windows_of_host(L, sp);
-    // window-aligned chunks: all but the last consist of full windows only (tail suppressed)
     uint32_t firstWin = 0;
     uint64_t pos = 0;
     const uint32_t fullWins = L > sp.w ? (L - sp.w) / sp.stride + 1 : 0;
@@ -331,14 +341,19 @@ int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const 
         uint32_t clen;
         if (last) clen = (uint32_t)(L - pos);
         else clen = (kChunkWindows - 1) * sp.stride + sp.w;
-        const uint64_t off = b->hseq.size();
-        if (off + clen + 8 > 0xFFFFFFF0ull) { int rc = flush(b); if (rc) return rc; continue; }
-        b->hseq.insert(b->hseq.end(), (const uint8_t*)seq + pos, (const uint8_t*)seq + pos + clen);
-        b->hseq.resize((b->hseq.size() + 3) / 4 * 4, 0);
+        uint64_t off;
+        if (onDevice) off = (uint64_t)(seq - b->devBase) + pos;
+        else {
+            off = b->hseq.size();
+            if (off + clen + 8 > 0xFFFFFFF0ull) { int rc = flush(b); if (rc) return rc; continue; }
+            b->hseq.insert(b->hseq.end(), seq + pos, seq + pos + clen);
+            b->hseq.resize((b->hseq.size() + 3) / 4 * 4, 0);
+        }
         b->hqinfo.push_back((uint32_t)off); b->hqinfo.push_back(clen); b->hqinfo.push_back((uint32_t)off);
         b->hqinfo.push_back(last ? 0u : kNoTail);
         b->hqtgt.push_back(tgt); b->hqfirst.push_back(firstWin);
-        if (b->hseq.size() >= kFlushChars) { int rc = flush(b); if (rc) return rc; }
+        if (onDevice) b->devChars += clen;
+        else if (b->hseq.size() >= kFlushChars) { int rc = flush(b); if (rc) return rc; }
         if (last) break;
         firstWin += kChunkWindows;
         pos += (uint64_t)kChunkWindows * sp.stride;
@@ -347,6 +362,38 @@ int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const 
     r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid; r.windows = total; r.fileIndex = fileIndex;
     b->targets.push_back(std::move(r));
     return MC_OK;
+}
+
+int mc_build_add_target_src(mc_builder* b, const char* seq, uint64_t len, const char* name, int64_t parentTaxid, const char* filename,
+                            uint64_t fileIndex)
+{
+    return add_target_impl(b, reinterpret_cast<const uint8_t*>(seq), false, len, name, parentTaxid, filename, fileIndex);
+}
+
+// a target whose characters already are in device memory (4-byte aligned start, 16 readable bytes behind the last character): no
+// host staging, no copy.  The memory must stay as it is until mc_build_flush / mc_build_finish returns.
+int mc_build_add_target_device(mc_builder* b, const void* dseq, uint64_t len, const char* name, int64_t parentTaxid, const char* filename,
+                               uint64_t fileIndex)
+{
+    return add_target_impl(b, static_cast<const uint8_t*>(dseq), true, len, name, parentTaxid, filename, fileIndex);
+}
+
+// sketches everything staged so far; afterwards the sources of mc_build_add_target_device calls may be reused
+int mc_build_flush(mc_builder* b)
+{
+    if (!b) return MC_ERR_INVALID;
+    if (b->finished) return MC_OK;
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    return flush(b);
+}
+
+// room for this many (feature, location) pairs up front: a builder that grows step by step holds two copies while it grows
+int mc_build_reserve(mc_builder* b, uint64_t pairs)
+{
+    if (!b) return MC_ERR_INVALID;
+    if (b->finished) { b->err = "builder already finished"; return MC_ERR_STATE; }
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    return grow_pairs(b, pairs, true);
 }
 
 // modify mode (mode_build.cpp:74-88): the targets and location lists of an existing database come first, new targets after them
@@ -460,6 +507,64 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
     return MC_OK;
 }
 
+// A query table filled from finished builders.  mc_build_table_begin creates the context (table sized for the expected totals),
+// mc_build_table_add inserts one finished builder (a whole one or one key shard) straight from its device arrays,
+// mc_build_table_end closes the load.  mc_build_finish_shards is the three in a row for builders that all fit next to the table;
+// the streaming form lets the caller free every shard's builder before the next one is sketched.
+int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValues, mc_ctx** outCtx)
+{
+    if (!b || !outCtx) return MC_ERR_INVALID;
+    *outCtx = nullptr;
+    if (expectKeys == 0 || expectValues == 0) {
+        // not given: the first shard times the shard count (keys are dealt out by a hash: shards differ by fractions of a percent)
+        if (!b->finished) { b->err = "mc_build_table_begin: expected totals missing and the builder is not finished"; return MC_ERR_STATE; }
+        const uint64_t n = std::max<uint32_t>(b->cfg.key_shard_count, 1);
+        if (!expectKeys) expectKeys = n == 1 ? b->nkeys : b->nkeys * n + b->nkeys * n / 64 + (1u << 16);
+        if (!expectValues) expectValues = n == 1 ? b->nvals : b->nvals * n + b->nvals * n / 32 + (1u << 20);
+    }
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    mc_config qc = b->cfg;
+    qc.max_locations_per_feature = 0; qc.num_parts = 1;
+    qc.remove_overpopulated = b->rmOver ? b->maxLocs - 1 : 0;   // applied while the table is filled (table_build.hip)
+    qc.target_id_bytes = 4;                                    // values are handed over as {u32 win, u32 tgt}
+    qc.key_shard_index = 0; qc.key_shard_count = 1;            // the table holds all shards
+    mc_ctx* ctx = nullptr;
+    int rc = mc_create(&qc, &ctx);
+    if (rc) { b->err = mc_last_error(nullptr); return rc; }
+    ctx->targetCount = b->targets.size();
+    ctx->maxLocs = b->maxLocs;
+    rc = mc_load_begin(ctx, 0, expectKeys, expectValues);
+    if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
+    *outCtx = ctx;
+    return MC_OK;
+}
+
+int mc_build_table_add(mc_ctx* ctx, mc_builder* b)
+{
+    if (!ctx || !b) return MC_ERR_INVALID;
+    if (!b->finished) { int rc = mc_build_finish(b, nullptr); if (rc) return rc; }
+    if (b->targets.size() != ctx->targetCount) { b->err = "mc_build_table_add: builder holds other targets than the table"; return MC_ERR_INVALID; }
+    B_TRY(b, hipSetDevice(b->cfg.device));
+    // device arrays go straight into the table builder, in chunks whose value count stays below 2^32
+    const uint64_t chunk = 1ull << 22;
+    uint64_t vbeg = 0;
+    for (uint64_t i = 0; i < b->nkeys; i += chunk) {
+        const uint64_t nb = std::min<uint64_t>(chunk, b->nkeys - i);
+        uint64_t vend = 0;
+        B_TRY(b, hipMemcpy(&vend, b->rVoff + i + nb, 8, hipMemcpyDeviceToHost));
+        const int rc = load_chunk_device(ctx, b->rK + i, b->rS + i, reinterpret_cast<const uint8_t*>(b->rV + vbeg), (uint32_t)nb, vend - vbeg);
+        if (rc) { b->err = mc_last_error(ctx); return rc; }
+        vbeg = vend;
+    }
+    return MC_OK;
+}
+
+int mc_build_table_end(mc_ctx* ctx)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    return mc_load_end(ctx, 0);
+}
+
 // One query table from the results of several builders that sketched the SAME targets with different key shards
 // (cfg.key_shard_index = 0 .. n-1 of key_shard_count = n): a table beyond the 2^32 (feature, location) pairs one sort can take is
 // built shard after shard.  With n = 1 this is the loading half of mc_build_finish.
@@ -476,32 +581,12 @@ int mc_build_finish_shards(mc_builder** bs, uint32_t n, mc_ctx** outCtx)
             (n > 1 && bs[i]->cfg.key_shard_index != i)) { b->err = "mc_build_finish_shards: builders do not form one key-sharded set"; return MC_ERR_INVALID; }
         nkeys += bs[i]->nkeys; nvals += bs[i]->nvals;
     }
-    B_TRY(b, hipSetDevice(b->cfg.device));
-    mc_config qc = b->cfg;
-    qc.max_locations_per_feature = 0; qc.num_parts = 1;
-    qc.remove_overpopulated = b->rmOver ? b->maxLocs - 1 : 0;   // applied while the table is filled (table_build.hip)
-    qc.target_id_bytes = 4;                                    // values are handed over as {u32 win, u32 tgt}
-    if (n > 1) { qc.key_shard_index = 0; qc.key_shard_count = 1; }   // the table holds all shards
     mc_ctx* ctx = nullptr;
-    int rc = mc_create(&qc, &ctx);
-    if (rc) { b->err = mc_last_error(nullptr); return rc; }
-    ctx->targetCount = b->targets.size();
-    ctx->maxLocs = b->maxLocs;
-    rc = mc_load_begin(ctx, 0, nkeys, nvals);
-    // device arrays go straight into the table builder, in chunks whose value count stays below 2^32
-    const uint64_t chunk = 1ull << 22;
-    for (uint32_t s = 0; !rc && s < n; ++s) {
-        uint64_t vbeg = 0;
-        for (uint64_t i = 0; !rc && i < bs[s]->nkeys; i += chunk) {
-            const uint64_t nb = std::min<uint64_t>(chunk, bs[s]->nkeys - i);
-            uint64_t vend = 0;
-            if (hipMemcpy(&vend, bs[s]->rVoff + i + nb, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = MC_ERR_HIP; break; }
-            rc = load_chunk_device(ctx, bs[s]->rK + i, bs[s]->rS + i, reinterpret_cast<const uint8_t*>(bs[s]->rV + vbeg), (uint32_t)nb, vend - vbeg);
-            vbeg = vend;
-        }
-    }
-    if (!rc) rc = mc_load_end(ctx, 0);
-    if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
+    int rc = mc_build_table_begin(b, std::max<uint64_t>(nkeys, 1), std::max<uint64_t>(nvals, 1), &ctx);
+    if (rc) return rc;
+    for (uint32_t s = 0; !rc && s < n; ++s) { rc = mc_build_table_add(ctx, bs[s]); if (rc) b->err = bs[s]->err; }
+    if (!rc) { rc = mc_build_table_end(ctx); if (rc) b->err = mc_last_error(ctx); }
+    if (rc) { mc_destroy(ctx); return rc; }
     *outCtx = ctx;
     return MC_OK;
 }

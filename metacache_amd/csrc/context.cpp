@@ -165,6 +165,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1';           // experiment switch
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
+    if (const char* e = std::getenv("MC_BIG_MIN")) ctx->bigMin = (uint32_t)std::max(0, std::atoi(e));   // tests / tuning
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream");
@@ -521,7 +522,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)6 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -535,6 +536,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     ws.scanTmp = P.bScan.p; ws.stats = (uint64_t*)P.bStats.p;
     if (lanePath) {
         ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
+        ws.bigMin = ctx->bigMin;
         ws.chunkList = (uint2*)P.bChunkList.p;
     }
 
@@ -579,7 +581,11 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if (hcnt[8]) { ScopedTimer t(ctx, "hash_cands_256", st); launch_hash_cands(5, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[3]) { ScopedTimer t(ctx, "hash_cands_512", st); launch_hash_cands(3, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[4]) { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
-        waveWork = hcnt[6] != 0 || hcnt[7] != 0;
+        if (hcnt[9]) {
+            { ScopedTimer t(ctx, "big_cands", st); launch_big_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
+            { ScopedTimer t(ctx, "big_cands_2", st); launch_big_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }
+        }
+        waveWork = hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }

@@ -107,7 +107,8 @@ struct Workspace {           // device buffers sized by the host for this batch
                              //            6 = long read handled by the chunk lane kernels
     uint32_t* midCount;      // [16]; [8] = third work list of hash_cands_kernel (129..256);       lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
     uint2*    chunkList;     // [W + n]    {query, chunk}: long single reads, cut into one-window chunks for the chunk lane kernels
-    uint32_t* midList;       // [6][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
+    uint32_t  bigMin;        // lists longer than this (and > 256) from <= 64 found features go to big_cands_kernel (midCount[9] / [10], lists 6 / 7)
+    uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations
@@ -123,6 +124,10 @@ void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* 
                      void* tmp, hipStream_t st);
 size_t scan_tmp_bytes(uint32_t n);
 void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
+// database builder: window sketches of window-aligned chunk records (<= build_record_windows() windows each); lanes where the
+// sketching parameters allow, the exact wave path for the rest.  Needs ws.winOff, ws.features, ws.qflag.
+void launch_build_sketch(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
+uint32_t build_record_windows();
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
@@ -143,6 +148,7 @@ void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const 
                               const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
+void launch_big_cands(uint32_t stage, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* taxkey, uint32_t maxCand,

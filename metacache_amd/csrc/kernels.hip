@@ -1012,12 +1012,14 @@ __global__ __launch_bounds__(256) void query_kernel(BatchView b, SketchParams sp
 }
 
 // sketch-only use of the wave path (database builder): windows -> features, nothing else
+template <bool FLAGGED>
 __global__ __launch_bounds__(256) void sketch_only_kernel(BatchView b, SketchParams sp, Workspace ws)
 {
     __shared__ FusedLds lds[4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     if (q >= b.n) return;
+    if (FLAGGED && ws.qflag[q] != kFlagSketch) return;          // only the records the lane sketcher could not finish
     DeviceTable none{};
     Workspace w = ws;
     w.psize = nullptr;
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(256) void sketch_only_kernel(BatchView b, SketchPar
 void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
 {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(sketch_only_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, ws);
+    hipLaunchKernelGGL(sketch_only_kernel<false>, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, ws);
 }
 
 void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, bool fuse, bool wantAllhits,
@@ -1065,6 +1067,7 @@ constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
 constexpr uint32_t kLaneU = MC_LANE_U;    // lookups in flight per lane
 constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
 constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: longest list, entries, maxWindowsInRange
+constexpr uint32_t kBigEnt = 64;          // big_cands_kernel: found features per query (one lane each)
 
 __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
 {
@@ -1330,6 +1333,45 @@ __global__ __launch_bounds__(128) void chunk_sketch_kernel(BatchView b, SketchPa
         if (dup) ws.qflag[q] = kFlagSketch;                                         // the wave kernel redoes the whole read
     }
 }
+
+// Database builder: the chunk records of target sequences (<= kBuildRecWins windows each, window-aligned, tail only in a target's last
+// record) sketched by lanes: ONE WAVE per record, lane l takes the windows [l * kBuildLaneWins, (l + 1) * kBuildLaneWins) -- the k-mers
+// of a sequence partition into its windows (stride = w - k + 1), so a lane only needs its own characters.  A window that holds the
+// same hash twice flags its record: sketch_only_kernel<true> redoes those records with the exact wave path.
+constexpr uint32_t kBuildLaneWins = 4, kBuildRecWins = 64 * kBuildLaneWins;
+__global__ __launch_bounds__(256) void build_sketch_lanes_kernel(BatchView b, SketchParams sp, Workspace ws)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= b.n) return;
+    const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+    const uint32_t w0 = ws.winOff[q], nw = ws.winOff[q + 1] - w0;
+    const uint32_t first = lane * kBuildLaneWins;
+    bool dup = false;
+    if (first < nw) {
+        const uint32_t p0 = first * sp.stride;
+        const uint32_t len = min(qi.y - p0, kBuildLaneWins * sp.stride + sp.k - 1);
+        uint32_t wcount = 0;
+        uint32_t* out = ws.features + (size_t)(w0 + first) * sp.s;
+        if (sp.k == 16 && (sp.stride & 15u) == 0) lane_sketch_span16(b.seq, (uint64_t)qi.x + p0, len, sp.s, sp.stride, out, wcount, dup);
+        else lane_sketch_span(b.seq, (uint64_t)qi.x + p0, len, sp.k, sp.s, sp.stride, out, wcount, dup);
+    }
+    const bool any = __ballot(dup) != 0;
+    if (lane == 0) ws.qflag[q] = any ? kFlagSketch : kFlagDone;
+}
+
+template <bool FLAGGED>
+__global__ __launch_bounds__(256) void sketch_only_kernel(BatchView b, SketchParams sp, Workspace ws);
+
+void launch_build_sketch(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
+{
+    if (b.n == 0) return;
+    if (lane_path_supported(sp) && (sp.stride & 3u) == 0 && ws.qflag) {
+        hipLaunchKernelGGL(build_sketch_lanes_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, ws);
+        hipLaunchKernelGGL(sketch_only_kernel<true>, dim3((b.n + 3) / 4), dim3(256), 0, st, b, sp, ws);
+    } else launch_sketch_only(b, sp, ws, st);
+}
+uint32_t build_record_windows() { return kBuildRecWins; }
 
 // one lane per chunk: lookups of its <= kChunkWins * s features (kLaneU in flight), (size, payload) of the found features for the wave
 // kernel.  QUAD as in probe_cands_one.
@@ -1744,19 +1786,22 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // work list slots: 0 / 1 / 2 mid_cands (64 / 128 / 256), 3 / 4 / 5 hash_cands (512 / 1024 / 256), 6 = wave kernel.  From 129 locations
         // on counting beats sorting (measured per list: 3.3 vs 4.7 ns at 129..256); below, the register sort wins (1.6 vs 2 ns)
         const bool hashOK = nent <= kHashEnt && mw <= kHashWin;
-        const uint32_t cls = H <= 64 ? 0u : H <= 128 ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
-        ws.qflag[q] = cls < 6 ? kFlagMid : kFlagCands;
-        if (cls >= 3 && cls <= 5) ws.hitScan[q] = 0u;                            // no segment in HBM
+        // 7 = big_cands_kernel (filter first): lists beyond ws.bigMin locations from at most kBigEnt found features
+        const bool bigOK = nent <= kBigEnt && mw <= kHashWin && H > ws.bigMin && H > kMidMax;
+        const uint32_t cls = bigOK ? 7u : H <= 64 ? 0u : H <= 128 ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
+        ws.qflag[q] = cls != 6 ? kFlagMid : kFlagCands;
+        if (cls >= 3 && cls != 6) ws.hitScan[q] = 0u;                            // no segment in HBM
         const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-        for (uint32_t c = 0; c < 6; ++c) {
+        for (uint32_t c = 0; c < 8; ++c) {
+            if (c == 6) continue;
             const uint64_t mask = __ballot(cls == c);
             if (cls == c) {
                 const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&ws.midCount[c < 5 ? c : 8u], (uint32_t)__popcll(mask));
+                if (lane == leader) base = atomicAdd(&ws.midCount[c < 5 ? c : c == 5 ? 8u : 9u], (uint32_t)__popcll(mask));
                 base = __shfl(base, leader);
-                reinterpret_cast<uint4*>(ws.midList)[(size_t)c * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 12), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
+                reinterpret_cast<uint4*>(ws.midList)[(size_t)(c == 7 ? 6u : c) * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 12), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
             }
         }
         return;
@@ -2178,6 +2223,128 @@ __device__ __forceinline__ uint32_t hash_slot(uint64_t v)
     return ((uint32_t)v * 0x9E3779B1u + (uint32_t)(v >> 32) * 0x85EBCA77u) >> (32 - LOG2S);   // multiplicative: the high bits
 }
 
+// Steps 1 (counting) to 3 (the K rounds) on the PER elements v[] every lane holds (kEmptyLoc = none), with the wave's (target, window)
+// table in LDS (keys: 2^LOG2S slots, all empty; cnts: packed 16-bit counters, all zero).  Writes the K candidates of the query to out;
+// returns the number of them that have >= 2 hits (the ones that cannot be displaced by a single-hit target, see big_cands_kernel).
+constexpr uint64_t kEmptyLoc = ~0ull;
+template <uint32_t LOG2S, uint32_t PER, bool TAX>
+__device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uint64_t* keys, uint32_t* cnts, const uint32_t lane, const uint32_t maxWin,
+                                                   const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
+                                                   mc_candidate_dev* __restrict__ out, uint32_t (&picked)[kLaneK])
+{
+    constexpr uint32_t kMask = (1u << LOG2S) - 1;
+    constexpr uint64_t kEmpty = kEmptyLoc;
+    auto count_of = [&](uint32_t slot) -> uint32_t { return reinterpret_cast<const uint16_t*>(cnts)[slot]; };   // ds_read_u16
+    uint32_t slot[PER];                                       // slot | claimed << 31
+    {
+        unsigned long long old[PER];
+        bool coll = false;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            slot[r] = hash_slot<LOG2S>(v[r]);
+            old[r] = v[r] != kEmpty ? atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot[r]]), (unsigned long long)kEmpty, (unsigned long long)v[r]) : v[r];
+            coll = coll || (old[r] != kEmpty && old[r] != v[r]);
+        }
+        if (__ballot(coll)) {                                  // somebody else's key in the home slot: next slots, one at a time
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) {
+                if (old[r] != kEmpty && old[r] != v[r]) {
+                    uint32_t sl = slot[r];
+                    for (;;) {
+                        sl = (sl + 1) & kMask;
+                        old[r] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
+                        if (old[r] == kEmpty || old[r] == v[r]) break;
+                    }
+                    slot[r] = sl;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            if (v[r] != kEmpty) atomicAdd(&cnts[slot[r] >> 1], 1u << (16u * (slot[r] & 1u)));
+            slot[r] |= (v[r] != kEmpty && old[r] == kEmpty) ? 0x80000000u : 0u;
+        }
+    }
+    wave_lds_sync();
+    // ---- 2. ranges that end in the windows this lane claimed: hits | (end - begin) << 16
+    uint32_t ptax[PER];
+    if constexpr (TAX) {
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[(uint32_t)(v[r] >> 32) & tab.tgtMask] : 0u;
+    }
+    uint32_t T[PER];
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) T[r] = (slot[r] >> 31) ? count_of(slot[r] & kMask) : 0u;
+    for (uint32_t d = 1; d < maxWin; ++d) {
+        uint64_t k[PER]; uint32_t sl[PER];
+        bool chain = false;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            sl[r] = hash_slot<LOG2S>(v[r] - d);
+            k[r] = keys[sl[r]];
+            const bool live = (slot[r] >> 31) && (uint32_t)v[r] >= d;
+            if (!live) { k[r] = kEmpty; sl[r] = 0xFFFFFFFFu; }   // (target 0, window < d: v - d would equal the empty key)
+            chain = chain || (live && k[r] != v[r] - d && k[r] != kEmpty);
+        }
+        if (__ballot(chain)) {
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r)
+                while (sl[r] != 0xFFFFFFFFu && k[r] != v[r] - d && k[r] != kEmpty) { sl[r] = (sl[r] + 1) & kMask; k[r] = keys[sl[r]]; }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t c = count_of(sl[r] & kMask);
+            if (sl[r] != 0xFFFFFFFFu && k[r] == v[r] - d) T[r] = ((T[r] & 0xFFFFu) + c) | (d << 16);
+        }
+    }
+    // ---- 3. K rounds: every lane offers the best of its ranges whose target / taxon has not been picked yet, the wave takes the
+    //      maximum under (hits desc, target asc, window asc) and strikes that target / taxon everywhere
+    uint32_t live = 0;                                         // bit r: this lane's range r is still in the race
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) {
+        bool ok = (slot[r] >> 31) != 0;
+        if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
+        live |= ok ? (1u << r) : 0u;
+    }
+    uint32_t strong = 0;
+    for (uint32_t rnd = 0; rnd < K; ++rnd) {
+        uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t t = (uint32_t)(v[r] >> 32), win = (uint32_t)v[r];
+            const uint64_t ck = ((uint64_t)(T[r] & 0xFFFFu) << 32) | (uint32_t)~t;
+            const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
+            if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
+        }
+        uint64_t m = hk;
+#pragma unroll
+        for (uint32_t off = 32; off > 0; off >>= 1) {
+            const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
+            m = o > m ? o : m;
+        }
+        mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+        if (m != 0) {
+            uint32_t wm = hk == m ? hw : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t off = 32; off > 0; off >>= 1) wm = min(wm, __shfl_xor(wm, off));
+            const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
+            const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) {
+                uint32_t gr;
+                if constexpr (TAX) gr = ptax[r]; else gr = (uint32_t)(v[r] >> 32);
+                if (gr == g) live &= ~(1u << r);
+            }
+            e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
+            strong += e.hits >= 2 ? 1u : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) if (i == rnd) picked[i] = ~(uint32_t)m;      // the stored target id (part folded in)
+        }
+        if (lane == 0) out[rnd] = e;
+    }
+    return strong;
+}
+
 // LOG2S: log2 of the table slots; lists of up to 2^(LOG2S-1) locations (class 3: 512 in 1024 slots, 4 waves per block; class 4: 1024
 // in 2048 slots, 2 waves per block).  All LDS traffic of a phase is issued for the lane's elements together (the operations of
 // different elements are independent); only collisions fall back to a serial walk.
@@ -2185,8 +2352,8 @@ template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
 __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, uint32_t cls)
 {
-    constexpr uint32_t kSlots = 1u << LOG2S, kPer = kSlots / 2 / 64, kRounds = kHashEnt / 64, kMask = kSlots - 1;
-    constexpr uint64_t kEmpty = ~0ull;
+    constexpr uint32_t kSlots = 1u << LOG2S, kPer = kSlots / 2 / 64, kRounds = kHashEnt / 64;
+    constexpr uint64_t kEmpty = kEmptyLoc;
     __shared__ uint64_t keyS[WAVES][kSlots];
     __shared__ uint32_t cntS[WAVES][kSlots / 2];
     __shared__ uint64_t entPayS[WAVES][kHashEnt];
@@ -2209,7 +2376,6 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
             epay[u] = e < (rec.z & 0xFFFu) ? ws.ppay[rec.y + e] : 0ull;
         }
     };
-    auto count_of = [&](uint32_t slot) -> uint32_t { return reinterpret_cast<const uint16_t*>(cnts)[slot]; };   // ds_read_u16
     const uint32_t w0 = blockIdx.x * WAVES + wave;
     uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
     load_entries(rec);
@@ -2241,7 +2407,7 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
         auto body = [&](auto perc) {
             constexpr uint32_t PER = decltype(perc)::value;
             // ---- 1. gather (lane: per consecutive list elements, one search, then a walk -- as mid_cands_kernel; handing element i to
-            //      lane i % 64 makes a wave's loads coalesce, but costs a search per element and was not faster) and count
+            //      lane i % 64 makes a wave's loads coalesce, but costs a search per element and was not faster)
             const uint32_t i0 = lane * per;
             uint64_t v[PER];
             {
@@ -2260,110 +2426,8 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
                     }
                 }
             }
-            uint32_t slot[PER];                                       // slot | claimed << 31
-            {
-                unsigned long long old[PER];
-                bool coll = false;
-    #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) {
-                    slot[r] = hash_slot<LOG2S>(v[r]);
-                    old[r] = v[r] != kEmpty ? atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot[r]]), (unsigned long long)kEmpty, (unsigned long long)v[r]) : v[r];
-                    coll = coll || (old[r] != kEmpty && old[r] != v[r]);
-                }
-                if (__ballot(coll)) {                                  // somebody else's key in the home slot: next slots, one at a time
-    #pragma unroll
-                    for (uint32_t r = 0; r < PER; ++r) {
-                        if (old[r] != kEmpty && old[r] != v[r]) {
-                            uint32_t sl = slot[r];
-                            for (;;) {
-                                sl = (sl + 1) & kMask;
-                                old[r] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
-                                if (old[r] == kEmpty || old[r] == v[r]) break;
-                            }
-                            slot[r] = sl;
-                        }
-                    }
-                }
-    #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) {
-                    if (v[r] != kEmpty) atomicAdd(&cnts[slot[r] >> 1], 1u << (16u * (slot[r] & 1u)));
-                    slot[r] |= (v[r] != kEmpty && old[r] == kEmpty) ? 0x80000000u : 0u;
-                }
-            }
-            wave_lds_sync();
-            // ---- 2. ranges that end in the windows this lane claimed: hits | (end - begin) << 16
-            uint32_t ptax[PER];
-            if constexpr (TAX) {
-    #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[(uint32_t)(v[r] >> 32) & tab.tgtMask] : 0u;
-            }
-            uint32_t T[PER];
-    #pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) T[r] = (slot[r] >> 31) ? count_of(slot[r] & kMask) : 0u;
-            for (uint32_t d = 1; d < maxWin; ++d) {
-                uint64_t k[PER]; uint32_t sl[PER];
-                bool chain = false;
-    #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) {
-                    sl[r] = hash_slot<LOG2S>(v[r] - d);
-                    k[r] = keys[sl[r]];
-                    const bool live = (slot[r] >> 31) && (uint32_t)v[r] >= d;
-                    if (!live) { k[r] = kEmpty; sl[r] = 0xFFFFFFFFu; }   // (target 0, window < d: v - d would equal the empty key)
-                    chain = chain || (live && k[r] != v[r] - d && k[r] != kEmpty);
-                }
-                if (__ballot(chain)) {
-    #pragma unroll
-                    for (uint32_t r = 0; r < PER; ++r)
-                        while (sl[r] != 0xFFFFFFFFu && k[r] != v[r] - d && k[r] != kEmpty) { sl[r] = (sl[r] + 1) & kMask; k[r] = keys[sl[r]]; }
-                }
-    #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) {
-                    const uint32_t c = count_of(sl[r] & kMask);
-                    if (sl[r] != 0xFFFFFFFFu && k[r] == v[r] - d) T[r] = ((T[r] & 0xFFFFu) + c) | (d << 16);
-                }
-            }
-            // ---- 3. K rounds: every lane offers the best of its ranges whose target / taxon has not been picked yet, the wave takes the
-            //      maximum under (hits desc, target asc, window asc) and strikes that target / taxon everywhere
-            uint32_t live = 0;                                         // bit r: this lane's range r is still in the race
-    #pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) {
-                bool ok = (slot[r] >> 31) != 0;
-                if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
-                live |= ok ? (1u << r) : 0u;
-            }
-            mc_candidate_dev* out = cands + (size_t)q * K;
-            for (uint32_t rnd = 0; rnd < K; ++rnd) {
-                uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
-    #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) {
-                    const uint32_t t = (uint32_t)(v[r] >> 32), win = (uint32_t)v[r];
-                    const uint64_t ck = ((uint64_t)(T[r] & 0xFFFFu) << 32) | (uint32_t)~t;
-                    const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
-                    if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
-                }
-                uint64_t m = hk;
-    #pragma unroll
-                for (uint32_t off = 32; off > 0; off >>= 1) {
-                    const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
-                    m = o > m ? o : m;
-                }
-                mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
-                if (m != 0) {
-                    uint32_t wm = hk == m ? hw : 0xFFFFFFFFu;
-    #pragma unroll
-                    for (uint32_t off = 32; off > 0; off >>= 1) wm = min(wm, __shfl_xor(wm, off));
-                    const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
-                    const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
-    #pragma unroll
-                    for (uint32_t r = 0; r < PER; ++r) {
-                        uint32_t gr;
-                        if constexpr (TAX) gr = ptax[r]; else gr = (uint32_t)(v[r] >> 32);
-                        if (gr == g) live &= ~(1u << r);
-                    }
-                    e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
-                }
-                if (lane == 0) out[rnd] = e;
-            }
+            uint32_t picked[kLaneK];
+            count_and_pick<LOG2S, PER, TAX>(v, keys, cnts, lane, maxWin, K, taxkey, tab, cands + (size_t)q * K, picked);
         };
         if constexpr (kPer == 4) {
             if (per <= 2) body(std::integral_constant<uint32_t, 2>{}); else if (per <= 3) body(std::integral_constant<uint32_t, 3>{}); else body(std::integral_constant<uint32_t, 4>{});
@@ -2382,6 +2446,253 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
         }
         if (lane == 0) ws.qflag[q] = kFlagDone;
         wave_lds_sync();
+    }
+}
+
+// ================================================================================================
+// big_cands_kernel: location lists beyond hash_cands_kernel's reach (RefSeq scale: 2 x 10^10 locations behind 32-bit features, a
+// 150 bp read collects 1000 .. 8000 locations), one WAVE per query.  Nearly all of those locations are single hits on unrelated
+// targets; what rows 8-10 keep of them is at most "the smallest target ids with one hit" when fewer than K targets reach two.  So
+// the list is FILTERED before anything is counted per (target, window):
+//   A. every location sets a 2-bit state (seen once / seen twice or more) in an LDS bit table indexed by a hash of its TARGET
+//      (32768 states in 8 KB: two ds_or per repeated target, one per new one);
+//   B. second sweep over the list: locations whose target state says "twice or more" go to an LDS list -- all locations of every
+//      target with >= 2 hits and a few percent of the rest (hash collisions) -- typically a fifth of the list;
+//   C. count_and_pick (hash_cands_kernel's steps 1-3) on that list: exact hits per window range, K rounds;
+//   D. only if fewer than K picked candidates have >= 2 hits: the open places go to the smallest targets among ALL other
+//      locations, each with its smallest window (hits = 1 candidates are ordered by target id alone = arrival order in the sorted
+//      list, candidate_generation.hpp:172-201) -- third sweep.  With taxon merging this case goes to the wave kernel.
+// The sweeps read the bucket lists straight from the table: one coalesced wave load per 64 locations of a bucket ("round"),
+// kBigU rounds in flight; sweeps B and D re-read what sweep A brought into the L2 / infinity cache.
+// Lists whose filtered part does not fit LOG2S-1 bits go to the next larger instance (work list 7), then to the wave kernel.
+// ================================================================================================
+constexpr uint32_t kBigU = 8;             // rounds in flight
+constexpr uint32_t kBigBitsLog2 = 15;     // target states
+
+template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
+__global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
+                                                               const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
+                                                               uint32_t listIdx, uint32_t countIdx)
+{
+    constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2, kBitWords = (1u << kBigBitsLog2) / 16;
+    constexpr uint32_t kRegionWords = (kSlots * 2 > kBitWords) ? kSlots * 2 : kBitWords;
+    constexpr uint32_t kMaxRounds = kBigEnt * 4;
+    __shared__ uint32_t regionS[WAVES][kRegionWords];            // A/B: target states; C: (target, window) keys
+    __shared__ uint32_t cntS[WAVES][kSlots / 2];
+    __shared__ uint64_t listS[WAVES][kList];
+    __shared__ uint64_t entPayS[WAVES][kBigEnt];
+    __shared__ uint32_t entSzS[WAVES][kBigEnt];
+    __shared__ uint64_t roundS[WAVES][kMaxRounds + kBigU];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* bits = regionS[wave];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(regionS[wave]);
+    uint32_t* cnts = cntS[wave];
+    uint64_t* list = listS[wave];
+    uint64_t* entPay = entPayS[wave];
+    uint32_t* entSz = entSzS[wave];
+    uint64_t* rounds = roundS[wave];
+    const uint32_t total = ws.midCount[countIdx];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)listIdx * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
+    uint32_t esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
+    uint64_t epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
+    auto state_of = [&](uint64_t v, uint32_t& word, uint32_t& bit1) {
+        const uint32_t h = ((uint32_t)(v >> 32) * 0x9E3779B1u) >> (32 - kBigBitsLog2);
+        word = h >> 4; bit1 = 1u << (2u * (h & 15u));
+    };
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
+        // ---- states cleared; entry table and round table (one round = up to 64 consecutive locations of one bucket) in LDS
+        {
+            uint4* z4 = reinterpret_cast<uint4*>(bits);
+#pragma unroll
+            for (uint32_t i = 0; i < kBitWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        const uint32_t mySz = esz & 0xFFFFu;
+        const uint64_t myPay = epay;
+        if (lane < nent) { entPay[lane] = myPay; entSz[lane] = mySz; }
+        const uint32_t myRounds = (lane < nent && mySz > 1) ? (mySz + 63u) / 64u : 0u;
+        const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
+        const uint32_t R = rdlane(incl, 63);
+        if (R > kMaxRounds) {                                      // merged buckets of a partitioned database can be longer than 254
+            if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
+            rec = recNext;
+            recNext = load_rec(w + 2 * nWaves);
+            esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
+            epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
+            wave_lds_sync();
+            continue;
+        }
+        for (uint32_t j = 0; j < myRounds; ++j)
+            rounds[incl - myRounds + j] = (myPay + 64ull * j) | ((uint64_t)min(64u, mySz - 64u * j) << 40);
+        if (lane < kBigU) rounds[R + lane] = 0ull;
+        const bool single = lane < nent && mySz == 1;
+        rec = recNext;                                             // the next query's record and entries are on their way meanwhile
+        recNext = load_rec(w + 2 * nWaves);
+        esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
+        epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
+        wave_lds_sync();
+        // one sweep over the query's locations: f(v) for the lane's element of every round, kBigU rounds' loads in flight
+        auto sweep = [&](auto&& f) {
+            f(single ? myPay : kEmptyLoc);
+            for (uint32_t g0 = 0; g0 < R; g0 += kBigU) {
+                uint64_t rv[kBigU];
+#pragma unroll
+                for (uint32_t u = 0; u < kBigU; ++u) {
+                    const uint64_t rd = rounds[g0 + u];
+                    rv[u] = lane < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + lane] : kEmptyLoc;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
+            }
+        };
+        // ---- A. target states
+        sweep([&](uint64_t v) {
+            if (v != kEmptyLoc) {
+                uint32_t word, bit1;
+                state_of(v, word, bit1);
+                const uint32_t old = atomicOr(&bits[word], bit1);
+                if (old & bit1) atomicOr(&bits[word], bit1 << 1);
+            }
+        });
+        wave_lds_sync();
+        // ---- B. locations of targets seen twice or more -> list
+        uint32_t n2 = 0;
+        sweep([&](uint64_t v) {
+            bool keep = false;
+            if (v != kEmptyLoc) {
+                uint32_t word, bit1;
+                state_of(v, word, bit1);
+                keep = (bits[word] & (bit1 << 1)) != 0;
+            }
+            const uint64_t m = __ballot(keep);
+            if (keep) {
+                const uint32_t at = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (at < kList) list[at] = v;
+            }
+            n2 += (uint32_t)__popcll(m);
+        });
+        wave_lds_sync();
+        if (n2 > kList) {
+            // does not fit this instance: on to the larger one, or to the wave kernel
+            if (lane == 0) {
+                if (listIdx == 6) {
+                    const uint32_t at = atomicAdd(&ws.midCount[10], 1u);
+                    reinterpret_cast<uint4*>(ws.midList)[(size_t)7 * b.n + at] = make_uint4(q, work[w].y, nent | (H << 12), maxWin);
+                } else { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
+            }
+            wave_lds_sync();
+            continue;
+        }
+        // ---- C. exact counting of the filtered list
+        {
+            uint4* k4 = reinterpret_cast<uint4*>(keys);
+            uint4* c4 = reinterpret_cast<uint4*>(cnts);
+#pragma unroll
+            for (uint32_t i = 0; i < kSlots / 2 / 64; ++i) k4[i * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+            for (uint32_t i = 0; i < (kSlots / 8 + 63) / 64; ++i) if (i * 64 + lane < kSlots / 8) c4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        wave_lds_sync();
+        uint32_t picked[kLaneK];
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) picked[i] = 0xFFFFFFFFu;
+        uint32_t strong = 0;
+        mc_candidate_dev* out = cands + (size_t)q * K;
+        auto body = [&](auto perc) {
+            constexpr uint32_t PER = decltype(perc)::value;
+            uint64_t v[PER];
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? list[r * 64 + lane] : kEmptyLoc;
+            strong = count_and_pick<LOG2S, PER, TAX>(v, keys, cnts, lane, maxWin, K, taxkey, tab, out, picked);
+        };
+        const uint32_t per = (n2 + 63u) / 64u;
+        if constexpr (kList / 64 <= 8) {
+            if (per <= 1) body(std::integral_constant<uint32_t, 1>{});
+            else if (per <= 2) body(std::integral_constant<uint32_t, 2>{});
+            else if (per <= 3) body(std::integral_constant<uint32_t, 3>{});
+            else if (per <= 4) body(std::integral_constant<uint32_t, 4>{});
+            else if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
+            else body(std::integral_constant<uint32_t, 8>{});
+        } else {
+            if (per <= 10) body(std::integral_constant<uint32_t, 10>{});
+            else if (per <= 12) body(std::integral_constant<uint32_t, 12>{});
+            else body(std::integral_constant<uint32_t, kList / 64>{});
+        }
+        strong = __builtin_amdgcn_readfirstlane(strong);
+        if (strong < K) {
+            if constexpr (TAX) {
+                // places left for single-hit taxa: the order among those depends on every target's taxon -> the exact wave kernel
+                if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
+                wave_lds_sync();
+                continue;
+            } else {
+                // ---- D. the open places: smallest targets (with their smallest window) among the locations of all targets that were
+                //      not picked with >= 2 hits -- every such target's best range is a single location
+                uint64_t best[kLaneK];
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kEmptyLoc;
+                sweep([&](uint64_t v) {
+                    if (v == kEmptyLoc) return;
+                    const uint32_t t = (uint32_t)(v >> 32);
+                    bool skip = false;
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) skip = skip || (i < strong && picked[i] == t);
+                    if (skip) return;
+                    bool same = false;
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i)
+                        if (best[i] != kEmptyLoc && (uint32_t)(best[i] >> 32) == t) { same = true; best[i] = min(best[i], v); }
+                    if (same) return;
+                    uint64_t c = v;                                 // sorted insert, the largest falls out
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) { const uint64_t lo = min(best[i], c); c = max(best[i], c); best[i] = lo; }
+                });
+                for (uint32_t rnd = strong; rnd < K; ++rnd) {
+                    uint64_t m = best[0];
+#pragma unroll
+                    for (uint32_t off = 32; off > 0; off >>= 1) {
+                        const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
+                        m = o < m ? o : m;
+                    }
+                    mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+                    if (m != kEmptyLoc) {
+                        const uint32_t t = (uint32_t)(m >> 32);
+                        e.tgt = t & tab.tgtMask; e.hits = 1; e.beg = e.end = (uint32_t)m;
+#pragma unroll
+                        for (uint32_t i = 0; i < kLaneK; ++i) {      // that target leaves every lane's list
+                            if (best[i] != kEmptyLoc && (uint32_t)(best[i] >> 32) == t) {
+#pragma unroll
+                                for (uint32_t j = i; j + 1 < kLaneK; ++j) best[j] = best[j + 1];
+                                best[kLaneK - 1] = kEmptyLoc;
+                            }
+                        }
+                    }
+                    if (lane == 0) out[rnd] = e;
+                }
+            }
+        }
+        if (lane == 0) ws.qflag[q] = kFlagDone;
+        wave_lds_sync();
+    }
+}
+
+void launch_big_cands(uint32_t stage, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands,
+                      hipStream_t st)
+{
+    if (b.n == 0) return;
+    // persistent grids; stage 0: filtered lists up to 512 locations (work list 6), stage 1: up to 1024 (work list 7, fed by stage 0)
+    if (stage == 0) {
+        const uint32_t grid = std::min<uint32_t>(256 * 2, (b.n + 3) / 4);
+        if (taxkey) hipLaunchKernelGGL((big_cands_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 6u, 9u);
+        else        hipLaunchKernelGGL((big_cands_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 6u, 9u);
+    } else {
+        const uint32_t grid = std::min<uint32_t>(256 * 2, (b.n + 1) / 2);
+        if (taxkey) hipLaunchKernelGGL((big_cands_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 7u, 10u);
+        else        hipLaunchKernelGGL((big_cands_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 7u, 10u);
     }
 }
 

@@ -30,6 +30,8 @@ int64_t mco_db_target_name(void* db, uint64_t tgt, char* buf, uint64_t cap);
 /* row 6: one lookup; returns bucket size, *vals -> values as (tgt<<32 | win) */
 uint32_t mco_db_lookup(void* db, uint32_t part, uint32_t feature, const uint64_t** vals);
 
+uint64_t mco_db_part_arrays(void* db, uint32_t part, const uint32_t** keys, const uint32_t** sizes, const uint64_t** offs, const uint64_t** values);
+
 /* rows 7-10 */
 void* mco_handler_new(void);
 void  mco_handler_free(void* h);
@@ -48,10 +50,18 @@ int mco_query(void* db, void* handler,
 uint64_t mco_candidates(const uint64_t* locs, uint64_t n, uint32_t maxWindowsInRange, uint64_t maxCand,
                         const int64_t* taxkey, int mergeAboveSequence, mco_cand* out, uint64_t cap);
 
-/* single-thread throughput probe used by bench.py's cpu_baseline leg when oracle/_ref is absent */
+/* many single-end reads on 'threads' host threads (one handler each); returns elapsed seconds.  bench.py's cpu_baseline leg
+   (kind "port") and the bulk parity checks */
 double mco_query_many(void* db, const char* seqs, const uint64_t* offs, uint64_t n,
-                      uint64_t maxCand, int lowestRank, uint64_t insertSizeMax, int threads_unused,
+                      uint64_t maxCand, int lowestRank, uint64_t insertSizeMax, int threads,
                       mco_cand* cands);
+
+/* the database BUILD restated (database.cpp:34-81, host_hashmap.hpp:570-605), restricted to the features in wanted[nWanted]
+   (NULL = all): target t = lengths[t] characters written by gen(user, t, dst); lineage = [numTargets * 21] taxon ids or NULL;
+   targetWindowsOut (may be NULL) receives the window count of every target.  Returns a database handle for mco_query & co. */
+void* mco_db_build(uint32_t k, uint32_t s, uint32_t w, uint32_t stride, uint32_t maxLocs, int targetBytes,
+                   uint32_t numTargets, const uint32_t* lengths, void (*gen)(void*, uint32_t, char*), void* user,
+                   const uint32_t* wanted, uint64_t nWanted, const int64_t* lineage, int threads, uint64_t* targetWindowsOut);
 
 #ifdef __cplusplus
 }

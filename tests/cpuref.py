@@ -70,8 +70,34 @@ class CpuRef:
             self.lib.mco_db_lookup.restype = C.c_uint32
             self.lib.mco_db_lookup.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
 
+            self.lib.mco_db_build.restype = C.c_void_p
+            self.lib.mco_db_build.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+            self.lib.mco_db_part_arrays.restype = C.c_uint64
+            self.lib.mco_db_part_arrays.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_void_p)] * 4
+
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
+
+    def build_db(self, lengths: np.ndarray, gen_addr: int, gen_user: int, wanted: np.ndarray | None = None,
+                 lineage: np.ndarray | None = None, threads: int = 1, k=16, s=16, w=127, stride=112, max_locs=254,
+                 target_bytes=4) -> "CpuDb":
+        """The oracle's restatement of the database BUILD (mco_db_build), optionally restricted to the features in `wanted`.
+        gen_addr = address of  void gen(void* user, uint32_t target, char* dst)  which writes target `target` (lengths[target]
+        characters); a ctypes CFUNCTYPE object or a C function of another library (metacache_amd/synth)."""
+        assert self.is_oracle
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        w_arr = None if wanted is None else np.ascontiguousarray(wanted, dtype=np.uint32)
+        lin = None if lineage is None else np.ascontiguousarray(lineage, dtype=np.int64)
+        tw = np.zeros(len(lengths), dtype=np.uint64)
+        h = self.lib.mco_db_build(k, s, w, stride, max_locs, target_bytes, len(lengths), _ptr(lengths), gen_addr, gen_user,
+                                  None if w_arr is None else _ptr(w_arr), 0 if w_arr is None else len(w_arr),
+                                  None if lin is None else _ptr(lin), threads, _ptr(tw))
+        if not h:
+            raise RuntimeError("mco_db_build failed")
+        db = CpuDb(self, h)
+        db.target_windows = tw
+        return db
 
     # ---- sketching -------------------------------------------------------------------------
     def sketch(self, seq: bytes, k=16, s=16, w=127, stride=112):
@@ -147,6 +173,20 @@ class CpuDb:
         buf = C.create_string_buffer(4096)
         n = self.ref._f("db_target_name")(self.h, t, buf, 4096)
         return buf.raw[:n].decode() if n >= 0 else ""
+
+    def part_arrays(self, part: int = 0):
+        """-> (keys u32[n], sizes u32[n], offs u64[n], values u64[...]) views of one part (oracle only)"""
+        assert self.ref.is_oracle
+        pk, ps, po, pv = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = int(self.ref.lib.mco_db_part_arrays(self.h, part, C.byref(pk), C.byref(ps), C.byref(po), C.byref(pv)))
+        if n == 0:
+            return (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+        keys = np.ctypeslib.as_array(C.cast(pk, C.POINTER(C.c_uint32)), shape=(n,))
+        sizes = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_uint32)), shape=(n,))
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n,))
+        nv = int(offs[-1]) + 255
+        vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_uint64)), shape=(nv,))
+        return keys, sizes, offs, vals
 
     def lookup(self, feature: int, part: int = 0) -> np.ndarray:
         assert self.ref.is_oracle

@@ -1,0 +1,180 @@
+"""GPU: what BASELINE.json configs[2] (RefSeq-scale table) stands on -- the synthetic collection on the device, the builder's
+device / key-shard / streaming-table path, the filtered candidate kernel for location lists beyond 1024, and one database
+large enough that the quad bucket fetch is chosen automatically -- all against the C oracle, which builds the buckets it needs
+ITSELF from the same collection (oracle/mc_oracle.c: mco_db_build), bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import cpuref
+import scale_util
+from metacache_amd import api, synth, synthdb
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 128)
+
+
+def _check(got, e, K, tag):
+    e = e[:K]
+    for j in range(K):
+        if j < len(e):
+            assert (got[j]["tgt"], got[j]["hits"], got[j]["beg"], got[j]["end"]) == (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]), (tag, j, got, e)
+        else:
+            assert got[j]["hits"] == 0, (tag, j, got, e)
+
+
+def test_synthetic_collection_gpu_equals_cpu():
+    import torch
+    spec = synthdb.phylogeny(3, 2, 3, 20_001, 40_003, seed=7)
+    cs, gs = synthdb.CpuSynth(), synthdb.GpuSynth(0)
+    off = spec.offsets(0, len(spec.targets))
+    buf = torch.zeros(int(off[-1]) + 64, dtype=torch.uint8, device="cuda:0")
+    gs.targets(spec, 0, len(spec.targets), buf)
+    host = buf.cpu().numpy()
+    for t in range(len(spec.targets)):
+        L = int(spec.targets["length"][t])
+        assert np.array_equal(host[int(off[t]):int(off[t]) + L], cs.target(spec, t)), t
+    for paired in (False, True):
+        P = synthdb.read_params(spec, 99, paired=paired)
+        n = 5000
+        a = torch.zeros((n, P.row_bytes), dtype=torch.uint8, device="cuda:0")
+        b = torch.zeros((n, P.row_bytes), dtype=torch.uint8, device="cuda:0")
+        gs.reads(spec, P, 1000, n, a, b if paired else None)
+        torch.cuda.synchronize()
+        exp = cs.reads(spec, P, 1000, n)
+        if paired:
+            assert np.array_equal(a.cpu().numpy(), exp[0]) and np.array_equal(b.cpu().numpy(), exp[1])
+        else:
+            assert np.array_equal(a.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_builder_device_sources_key_shards_streaming_table(tmp_path, shards):
+    """Targets generated in HBM -> mc_build_add_target_device (lane sketcher, per-shard pair selection) -> mc_build_table_* must give
+    the table the host-source builder gives (its files are read by the oracle), and both the table the oracle builds itself."""
+    spec = synthdb.phylogeny(4, 2, 3, 30_000, 90_000, seed=21 + shards)
+    cs = synthdb.CpuSynth()
+    K = 3
+    db, info = synthdb.build_database(spec, shards=shards, chunk_bytes=400_000, max_candidates=K)     # several flush groups
+    # the same collection through the host path, written as database files
+    bld = api.Builder(target_id_bytes=4, max_candidates=K)
+    for t in range(len(spec.targets)):
+        bld.add_target(cs.target(spec, t), f"SYN_{t:06d}.1", parent_taxid=spec.parent_taxid(t))
+    bld.finish(load=False)
+    name = str(tmp_path / "syn")
+    bld.write(name, spec.taxa())
+    nk, nv = bld.counts()
+    bld.free()
+    assert db.n_locations == nv
+    ofile = cpuref.oracle().open(name)
+    oself = scale_util.oracle_database(spec, None, threads=4)
+    k1, s1, _, _ = ofile.part_arrays(); k2, s2, _, _ = oself.part_arrays()
+    assert len(k1) == len(k2) == nk and int(s1.sum()) == int(s2.sum()) == nv
+    for f in k1[::53]:
+        assert np.array_equal(ofile.lookup(int(f)), oself.lookup(int(f)))
+    P = synthdb.read_params(spec, 5)
+    reads = cs.reads(spec, P, 0, 1500)
+    rl = [bytes(r[:150]) for r in reads] + [bytes(synth.random_genome(np.random.default_rng(1), 150)) for _ in range(50)]
+    cands, counts, _ = db.query(rl)
+    for i, r in enumerate(rl):
+        _, e = oself.query(r, b"", K, 0, 0)
+        _check(cands[i], e, K, i)
+        _, e2 = ofile.query(r, b"", K, 0, 0)
+        assert [tuple(x)[1:] for x in e.tolist()] == [tuple(x)[1:] for x in e2.tolist()]
+    db.close(); ofile.close(); oself.close()
+
+
+@pytest.mark.parametrize("lowest,K", [(0, 1), (0, 2), (0, 4), (4, 2), (6, 3)])
+def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K):
+    """k = 10: the feature space is so small that every bucket fills up with locations of unrelated targets, as 32-bit features do at
+    RefSeq scale: a 150 bp read collects 1000 .. 5000 locations, a handful of them on its true targets -- the lists big_cands_kernel
+    filters by target before counting.  Reads of the collection (strong candidates), random reads and reads of a single window
+    (fewer than K targets with two hits: the open places go to the smallest single-hit targets), sequence level and merged."""
+    monkeypatch.setenv("MC_BIG_MIN", "0")
+    spec = synthdb.phylogeny(120, 2, 3, 40_000, 60_000, seed=100 + lowest + K)
+    sk = dict(kmerlen=10, sketchlen=16, winlen=121, winstride=112)
+    db, info = synthdb.build_database(spec, shards=2, max_candidates=K, **sk)
+    db.set_lineages(spec.lineages())
+    odb = scale_util.oracle_database(spec, None, threads=THREADS, with_lineages=True, k=10, s=16, w=121, stride=112)
+    cs = synthdb.CpuSynth()
+    P = synthdb.read_params(spec, 77, sub_rate=0.02)
+    reads = [bytes(r[:150]) for r in cs.reads(spec, P, 0, 2500)]
+    rng = np.random.default_rng(5)
+    reads += [bytes(synth.random_genome(rng, 150)) for _ in range(700)]
+    reads += [r[:70] for r in reads[:300]]
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    assert np.mean(counts > 1024) > 0.5, (np.mean(counts > 1024), counts.max())
+    for i, r in enumerate(reads):
+        _, e = odb.query(r, b"", K, lowest, 0)
+        _check(cands[i], e, K, (i, counts[i]))
+    # pairs: twice the features (up to 64 entries), maxWindowsInRange 4 / 5
+    mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:110] for r in reads[:800]]
+    pc, pcounts, _ = db.query(reads[:800], mates, lowest=lowest, insert_max=400)
+    for i in range(800):
+        _, e = odb.query(reads[i], mates[i], K, lowest, 400)
+        _check(pc[i], e, K, ("pair", i, pcounts[i]))
+    db.close(); odb.close()
+
+
+@pytest.mark.parametrize("lowest,K", [(0, 2), (0, 4), (4, 3)])
+def test_big_cands_strain_rich_lists_overflow_paths(monkeypatch, lowest, K):
+    """4 species x 70 strains: nearly every location of a read's list lies on a target with many hits, so the filter keeps almost
+    everything: lists beyond the first instance's 512 go on to the second (1024) and from there to the wave kernel; ties between
+    near-identical strains everywhere."""
+    monkeypatch.setenv("MC_BIG_MIN", "0")
+    spec = synthdb.phylogeny(2, 2, 70, 20_000, 24_000, seed=300 + lowest + K, div_strain=(0.002, 0.01))
+    db, info = synthdb.build_database(spec, shards=1, max_candidates=K)
+    db.set_lineages(spec.lineages())
+    odb = scale_util.oracle_database(spec, None, threads=THREADS, with_lineages=True)
+    cs = synthdb.CpuSynth()
+    P = synthdb.read_params(spec, 78)
+    reads = [bytes(r[:150]) for r in cs.reads(spec, P, 0, 2000)]
+    for j, L in enumerate((20, 24, 30, 40, 60, 100)):                               # fewer k-mers, fewer features: shorter lists
+        reads += [bytes(r[:L]) for r in cs.reads(spec, P, 5000 + 300 * j, 300)]
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    assert np.mean(counts > 1024) > 0.3 and np.any((counts > 256) & (counts <= 512)), np.percentile(counts, [5, 50, 95])
+    for i, r in enumerate(reads):
+        _, e = odb.query(r, b"", K, lowest, 0)
+        _check(cands[i], e, K, (i, counts[i]))
+    db.close(); odb.close()
+
+
+def test_two_gbp_database_auto_quad_against_oracle():
+    """BASELINE configs[2] in small: a 2.1 Gbp phylogeny (100 genera x 2 species x 3 strains x 3.5 Mbp, uint32 targets), built in 2 key
+    shards through the streaming table; the bucket array (> 1 GiB) makes probe_cands choose the quad-cooperative fetch BY ITSELF.
+    20 000 single reads and 8 000 pairs against the oracle, which builds the buckets of the sample's features on the host cores."""
+    assert "MC_QUAD_LOOKUP" not in os.environ and "MC_BIG_MIN" not in os.environ
+    spec = synthdb.phylogeny(100, 2, 3, 3_400_000, 3_600_000, seed=2100)
+    K = 2
+    db, info = synthdb.build_database(spec, shards=2, max_candidates=K, max_load_factor=0.3)
+    assert info["bases"] > 2_000_000_000
+    import torch
+    gen = synthdb.GpuSynth(0)
+    n1, n2 = 20_000, 8_000
+    P1 = synthdb.read_params(spec, 3100)
+    P2 = synthdb.read_params(spec, 4100, paired=True)
+    a = torch.zeros((n1, P1.row_bytes), dtype=torch.uint8, device="cuda:0")
+    m1 = torch.zeros((n2, P2.row_bytes), dtype=torch.uint8, device="cuda:0")
+    m2 = torch.zeros((n2, P2.row_bytes), dtype=torch.uint8, device="cuda:0")
+    gen.reads(spec, P1, 0, n1, a)
+    gen.reads(spec, P2, 0, n2, m1, m2)
+    torch.cuda.synchronize()
+    singles = [bytes(r[:150]) for r in a.cpu().numpy()]
+    p1 = [bytes(r[:150]) for r in m1.cpu().numpy()]
+    p2 = [bytes(r[:150]) for r in m2.cpu().numpy()]
+    # features of the sample (oracle sketcher) -> the oracle's own restricted build
+    odb = scale_util.oracle_database(spec, scale_util.sample_features(singles + p1 + p2), threads=THREADS)
+    st = db.info()
+    assert st[5] == len(spec.targets)
+    cands, counts, _ = db.query(singles)
+    pc, pcounts, _ = db.query(p1, p2, insert_max=0)
+    for i in range(n1):
+        _, e = odb.query(singles[i], b"", K, 0, 0)
+        _check(cands[i], e, K, (i, counts[i]))
+    for i in range(n2):
+        _, e = odb.query(p1[i], p2[i], K, 0, 0)
+        _check(pc[i], e, K, ("pair", i, pcounts[i]))
+    assert np.mean(cands[:, 0]["hits"] >= 8) > 0.9
+    db.close(); odb.close()
