@@ -39,7 +39,7 @@ struct mc_builder {
     // all pairs so far (device, grow-only)
     uint32_t* dkeys = nullptr; uint64_t* dvals = nullptr; uint64_t npairs = 0, cap = 0;
     // result: the file's arrays -- keys, bucket sizes, location lists ((tgt << 32) | win = {u32 win; u32 tgt}) -- on the device
-    bool finished = false;
+    bool finished = false, failed = false;
     uint32_t* rK = nullptr; uint8_t* rS = nullptr; uint64_t* rV = nullptr; uint64_t* rVoff = nullptr;   // rVoff[nkeys + 1]
     uint64_t nkeys = 0, nvals = 0;
 };
@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void own_emit_kernel(const uint32_t* __restric
         }
         at += (uint32_t)__popcll(mask);
     }
+}
+
+// number of runs of equal keys in a sorted array
+__global__ __launch_bounds__(256) void count_runs_kernel(const uint32_t* __restrict__ keys, uint64_t n, unsigned long long* __restrict__ out)
+{
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
 // per run (= feature): kept size and its u32 copy for the scan
@@ -197,6 +206,7 @@ int grow_pairs(mc_builder* b, uint64_t need, bool exact = false)
 struct FlushBufs {
     std::vector<void*> p;
     ~FlushBufs() { for (void* q : p) if (q) (void)hipFree(q); }
+    void drop(void* q) { for (auto& x : p) if (x == q && q) { (void)hipFree(q); x = nullptr; } }
     template <class T> hipError_t get(T** out, size_t bytes) { void* q = nullptr; hipError_t e = hipMalloc(&q, bytes ? bytes : 16); if (e == hipSuccess) { p.push_back(q); *out = (T*)q; } return e; }
 };
 
@@ -256,8 +266,15 @@ int flush(mc_builder* b)
     return MC_OK;
 }
 
-void wr(FILE* f, const void* p, size_t n) { std::fwrite(p, 1, n, f); }
-void wr_str(FILE* f, const std::string& s) { uint64_t n = s.size(); wr(f, &n, 8); if (n) wr(f, s.data(), n); }
+// file output: the first failed write is remembered, the caller checks once per file (and removes what it began)
+struct OutFile {
+    FILE* f = nullptr; bool bad = false; std::string name;
+    explicit OutFile(const std::string& n) : f(std::fopen(n.c_str(), "wb")), name(n) {}
+    ~OutFile() { if (f) std::fclose(f); }
+    bool close() { if (f) { if (std::fflush(f) != 0 || std::fclose(f) != 0) bad = true; f = nullptr; } return !bad; }
+};
+void wr(OutFile& o, const void* p, size_t n) { if (n && std::fwrite(p, 1, n, o.f) != n) o.bad = true; }
+void wr_str(OutFile& o, const std::string& s) { uint64_t n = s.size(); wr(o, &n, 8); if (n) wr(o, s.data(), n); }
 
 }  // namespace
 
@@ -273,6 +290,7 @@ int mc_build_begin(const mc_config* cfg, mc_builder** out)
         return MC_ERR_UNSUPPORTED;
     }
     if (cfg->key_shard_count > 1 && cfg->key_shard_index >= cfg->key_shard_count) { set_global_error("mc_build_begin: key_shard_index out of range"); return MC_ERR_INVALID; }
+    if (build_record_windows() != kChunkWindows) { set_global_error("mc_build_begin: chunk records and the lane sketcher disagree about their size"); return MC_ERR_STATE; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
         set_global_error("no usable HIP device (this library has no CPU fallback)");
@@ -441,63 +459,78 @@ int mc_build_add_locations(mc_builder* b, const uint32_t* keys, const uint8_t* s
     return MC_OK;
 }
 
+// sort + run-length encode + truncate: split off so that every scratch buffer is released on every way out (FlushBufs)
+static int finish_sorted(mc_builder* b)
+{
+    const uint64_t n = b->npairs;
+    hipStream_t st = b->st;
+    FlushBufs fb;
+    uint32_t* k2 = nullptr; uint64_t* v2 = nullptr; void* tmp = nullptr; size_t tmpBytes = 0;
+    B_TRY(b, fb.get(&k2, n * 4));
+    B_TRY(b, fb.get(&v2, n * 8));
+    B_TRY(b, rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
+    B_TRY(b, fb.get(&tmp, tmpBytes + 16));
+    B_TRY(b, rocprim::radix_sort_pairs(tmp, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
+    B_TRY(b, hipStreamSynchronize(st));
+    fb.drop(tmp); tmp = nullptr;
+    (void)hipFree(b->dkeys); (void)hipFree(b->dvals);
+    b->dkeys = nullptr; b->dvals = nullptr; b->cap = 0; b->npairs = 0;
+    b->failed = true;                      // from here on the pairs are gone: an error leaves a builder that cannot be finished again
+    // runs of equal features, counted first so that the run arrays are as long as the runs (at RefSeq scale a feature has ~35 locations)
+    unsigned long long* dcount = nullptr;
+    B_TRY(b, fb.get(&dcount, 16));
+    B_TRY(b, hipMemsetAsync(dcount, 0, 16, st));
+    hipLaunchKernelGGL(count_runs_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536)), dim3(256), 0, st, k2, n, dcount);
+    unsigned long long nrunsAll = 0;
+    B_TRY(b, hipMemcpyAsync(&nrunsAll, dcount, 8, hipMemcpyDeviceToHost, st));
+    B_TRY(b, hipStreamSynchronize(st));
+    uint32_t *uniq = nullptr, *counts = nullptr, *dnruns = nullptr;
+    B_TRY(b, fb.get(&uniq, (nrunsAll + 1) * 4));
+    B_TRY(b, fb.get(&counts, (nrunsAll + 1) * 4));
+    B_TRY(b, fb.get(&dnruns, 16));
+    B_TRY(b, rocprim::run_length_encode(nullptr, tmpBytes, k2, (unsigned int)n, uniq, counts, dnruns, st));
+    B_TRY(b, fb.get(&tmp, tmpBytes + 16));
+    B_TRY(b, rocprim::run_length_encode(tmp, tmpBytes, k2, (unsigned int)n, uniq, counts, dnruns, st));
+    uint32_t nruns = 0, lastKey = 0;
+    B_TRY(b, hipMemcpyAsync(&nruns, dnruns, 4, hipMemcpyDeviceToHost, st));
+    B_TRY(b, hipStreamSynchronize(st));
+    if (nruns != nrunsAll) { b->err = "mc_build_finish: run count mismatch"; return MC_ERR_STATE; }
+    if (nruns) B_TRY(b, hipMemcpy(&lastKey, uniq + nruns - 1, 4, hipMemcpyDeviceToHost));
+    if (nruns && lastKey == 0xFFFFFFFFu) --nruns;            // the padding feature can never be stored (hash_dna.hpp:233)
+    fb.drop(tmp); fb.drop(k2); fb.drop(dnruns);
+    uint32_t* keep32 = nullptr; uint64_t* runOff = nullptr; void* scanTmp = nullptr;
+    B_TRY(b, hipMalloc((void**)&b->rS, (size_t)nruns + 16));
+    B_TRY(b, fb.get(&keep32, ((size_t)nruns + 1) * 4));
+    B_TRY(b, fb.get(&runOff, ((size_t)nruns + 2) * 8));
+    B_TRY(b, hipMalloc((void**)&b->rVoff, ((size_t)nruns + 2) * 8));
+    B_TRY(b, fb.get(&scanTmp, scan_tmp_bytes(nruns + 1)));
+    if (nruns) hipLaunchKernelGGL(keep_sizes_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, counts, nruns, b->maxLocs, b->rS, keep32);
+    launch_scan_u32(counts, 1, nruns, nullptr, runOff, scanTmp, st);
+    launch_scan_u32(keep32, 1, nruns, nullptr, b->rVoff, scanTmp, st);
+    uint64_t nvals = 0;
+    B_TRY(b, hipMemcpyAsync(&nvals, b->rVoff + nruns, 8, hipMemcpyDeviceToHost, st));
+    B_TRY(b, hipStreamSynchronize(st));
+    B_TRY(b, hipMalloc((void**)&b->rV, (nvals + 2) * 8));
+    if (nruns) hipLaunchKernelGGL(compact_values_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, v2, runOff, b->rVoff, b->rS, nruns, b->rV);
+    B_TRY(b, hipGetLastError());
+    B_TRY(b, hipStreamSynchronize(st));
+    B_TRY(b, hipMalloc((void**)&b->rK, ((size_t)nruns + 1) * 4));
+    B_TRY(b, hipMemcpy(b->rK, uniq, (size_t)nruns * 4, hipMemcpyDeviceToDevice));
+    b->nkeys = nruns; b->nvals = nvals;
+    b->failed = false;
+    return MC_OK;
+}
+
 int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
 {
     if (!b) return MC_ERR_INVALID;
+    if (b->failed) { b->err = "builder failed earlier (" + b->err + "): start a new one"; return MC_ERR_STATE; }
     B_TRY(b, hipSetDevice(b->cfg.device));
     if (!b->finished) {
         int rc = flush(b);
         if (rc) return rc;
-        const uint64_t n = b->npairs;
-        if (n >= 0xFFFFFFF0ull) { b->err = "more than 2^32 (feature, location) pairs in one builder"; return MC_ERR_UNSUPPORTED; }
-        if (n) {
-            hipStream_t st = b->st;
-            uint32_t* k2 = nullptr; uint64_t* v2 = nullptr; void* tmp = nullptr; size_t tmpBytes = 0;
-            B_TRY(b, hipMalloc((void**)&k2, n * 4));
-            B_TRY(b, hipMalloc((void**)&v2, n * 8));
-            B_TRY(b, rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
-            B_TRY(b, hipMalloc(&tmp, tmpBytes + 16));
-            B_TRY(b, rocprim::radix_sort_pairs(tmp, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
-            B_TRY(b, hipStreamSynchronize(st));
-            (void)hipFree(tmp); tmp = nullptr;
-            (void)hipFree(b->dkeys); (void)hipFree(b->dvals);
-            b->dkeys = nullptr; b->dvals = nullptr; b->cap = 0;
-            // runs of equal features; the padding feature 0xFFFFFFFF sorts last and is dropped
-            uint32_t *uniq = nullptr, *counts = nullptr, *dnruns = nullptr;
-            B_TRY(b, hipMalloc((void**)&uniq, n * 4));
-            B_TRY(b, hipMalloc((void**)&counts, n * 4));
-            B_TRY(b, hipMalloc((void**)&dnruns, 16));
-            B_TRY(b, rocprim::run_length_encode(nullptr, tmpBytes, k2, (unsigned int)n, uniq, counts, dnruns, st));
-            B_TRY(b, hipMalloc(&tmp, tmpBytes + 16));
-            B_TRY(b, rocprim::run_length_encode(tmp, tmpBytes, k2, (unsigned int)n, uniq, counts, dnruns, st));
-            uint32_t nruns = 0, lastKey = 0;
-            B_TRY(b, hipMemcpyAsync(&nruns, dnruns, 4, hipMemcpyDeviceToHost, st));
-            B_TRY(b, hipStreamSynchronize(st));
-            if (nruns) B_TRY(b, hipMemcpy(&lastKey, uniq + nruns - 1, 4, hipMemcpyDeviceToHost));
-            if (nruns && lastKey == 0xFFFFFFFFu) --nruns;
-            (void)hipFree(tmp); (void)hipFree(k2); (void)hipFree(dnruns);
-            uint32_t* keep32 = nullptr; uint64_t *runOff = nullptr; void* scanTmp = nullptr;
-            B_TRY(b, hipMalloc((void**)&b->rS, (size_t)nruns + 16));
-            B_TRY(b, hipMalloc((void**)&keep32, ((size_t)nruns + 1) * 4));
-            B_TRY(b, hipMalloc((void**)&runOff, ((size_t)nruns + 2) * 8));
-            B_TRY(b, hipMalloc((void**)&b->rVoff, ((size_t)nruns + 2) * 8));
-            B_TRY(b, hipMalloc(&scanTmp, scan_tmp_bytes(nruns + 1)));
-            if (nruns) hipLaunchKernelGGL(keep_sizes_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, counts, nruns, b->maxLocs, b->rS, keep32);
-            launch_scan_u32(counts, 1, nruns, nullptr, runOff, scanTmp, st);
-            launch_scan_u32(keep32, 1, nruns, nullptr, b->rVoff, scanTmp, st);
-            uint64_t nvals = 0;
-            B_TRY(b, hipMemcpyAsync(&nvals, b->rVoff + nruns, 8, hipMemcpyDeviceToHost, st));
-            B_TRY(b, hipStreamSynchronize(st));
-            B_TRY(b, hipMalloc((void**)&b->rV, (nvals + 2) * 8));
-            if (nruns) hipLaunchKernelGGL(compact_values_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, v2, runOff, b->rVoff, b->rS, nruns, b->rV);
-            B_TRY(b, hipGetLastError());
-            B_TRY(b, hipStreamSynchronize(st));
-            // keys: shrink the allocation to the number of runs
-            B_TRY(b, hipMalloc((void**)&b->rK, ((size_t)nruns + 1) * 4));
-            B_TRY(b, hipMemcpy(b->rK, uniq, (size_t)nruns * 4, hipMemcpyDeviceToDevice));
-            (void)hipFree(uniq); (void)hipFree(counts); (void)hipFree(keep32); (void)hipFree(runOff); (void)hipFree(scanTmp); (void)hipFree(v2);
-            b->nkeys = nruns; b->nvals = nvals;
-        }
+        if (b->npairs >= 0xFFFFFFF0ull) { b->err = "more than 2^32 (feature, location) pairs in one builder"; return MC_ERR_UNSUPPORTED; }
+        if (b->npairs && (rc = finish_sorted(b))) return rc;
         b->finished = true;
     }
     if (outCtx) {
@@ -681,8 +714,8 @@ int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const m
     }
     const uint32_t tb = b->cfg.target_id_bytes;
     {   // .meta  (database.cpp:247-290)
-        FILE* f = std::fopen((std::string(name) + ".meta").c_str(), "wb");
-        if (!f) { b->err = "cannot write .meta"; return MC_ERR_IO; }
+        OutFile f(std::string(name) + ".meta");
+        if (!f.f) { b->err = "cannot write .meta"; return MC_ERR_IO; }
         const uint64_t ver = 20200820ull;
         wr(f, &ver, 8);
         const uint8_t wd[7] = {4, (uint8_t)tb, 4, 1, 4, 8, MC_NUM_RANKS};
@@ -709,12 +742,16 @@ int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const m
             wr_str(f, b->targets[t].name); wr_str(f, b->targets[t].filename);
             wr(f, &b->targets[t].fileIndex, 8); wr(f, &b->targets[t].windows, 8);
         }
-        std::fclose(f);
+        if (!f.close()) { std::remove(f.name.c_str()); b->err = "write error on " + f.name + " (disk full?)"; return MC_ERR_IO; }
     }
     {   // .cache0  (hash_multimap.hpp:1037-1082): only non-empty buckets are written; with -remove-overpopulated-features the buckets
         // that reached the limit are gone (remove_features_with_more_locations_than(maxLocs - 1), building.cpp:516-534)
-        FILE* f = std::fopen((std::string(name) + ".cache0").c_str(), "wb");
-        if (!f) { b->err = "cannot write .cache0"; return MC_ERR_IO; }
+        OutFile f(std::string(name) + ".cache0");
+        if (!f.f) { b->err = "cannot write .cache0"; return MC_ERR_IO; }
+        auto give_up = [&](const std::string& why) {            // no half-written database stays behind
+            f.close(); std::remove(f.name.c_str()); std::remove((std::string(name) + ".meta").c_str());
+            b->err = why; return MC_ERR_IO;
+        };
         const uint64_t batch = 1ull << 20;
         uint64_t hdr[3] = {0, 0, batch};
         wr(f, hdr, 24);                                                // key / value totals follow when all shards are through
@@ -760,16 +797,16 @@ int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const m
                             else std::memcpy(at + 4, &tgt, 4);
                         }
                         hdr[1] += sz;
-                        if (outK.size() == batch) flush_batch();
+                        if (outK.size() == batch) { flush_batch(); if (f.bad) return give_up("write error on " + f.name + " (disk full?)"); }
                     }
                     voff += sz;
                 }
             }
         }
         flush_batch();
-        std::fseek(f, 0, SEEK_SET);
+        if (std::fseek(f.f, 0, SEEK_SET) != 0) f.bad = true;
         wr(f, hdr, 24);
-        std::fclose(f);
+        if (!f.close()) return give_up("write error on " + f.name + " (disk full?)");
     }
     return MC_OK;
 }

@@ -94,11 +94,21 @@ void make_lineages(const Meta& m, std::vector<uint32_t>& lin)
 
 struct PartHeader { uint64_t nkeys = 0, nvalues = 0, batch = 0; };
 
-int read_part_header(mc_ctx* ctx, const std::string& fname, PartHeader& h)
+// a .cache header is only believed as far as the file's size allows: every key costs at least 5 bytes (u32 key + u8 size), every
+// value 4 + targetBytes; batch 0 with keys to read would never advance (hash_multimap.hpp:970-1030 loops the same way)
+int read_part_header(mc_ctx* ctx, const std::string& fname, PartHeader& h, uint32_t targetBytes)
 {
     File f(fname);
     if (!f.f) { ctx->err = "Could not read database file '" + fname + "'"; return MC_ERR_IO; }
     if (!f.rd(&h.nkeys, 8) || !f.rd(&h.nvalues, 8) || !f.rd(&h.batch, 8)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+    std::fseek(f.f, 0, SEEK_END);
+    const long long size = ftello(f.f);
+    const unsigned long long body = size > 24 ? (unsigned long long)size - 24 : 0ull;
+    if ((h.nkeys && h.batch == 0) || h.nkeys > body / 5 || h.nvalues > body / (4 + targetBytes) ||
+        h.nkeys * 5 + h.nvalues * (4 + targetBytes) > body) {
+        ctx->err = "corrupt header in " + fname + " (key / value counts do not fit the file)";
+        return MC_ERR_IO;
+    }
     return MC_OK;
 }
 
@@ -108,6 +118,8 @@ int load_part(mc_ctx* ctx, uint32_t part, const std::string& fname, uint32_t tar
     if (!f.f) { ctx->err = "Could not read database file '" + fname + "'"; return MC_ERR_IO; }
     uint64_t nkeys = 0, nvalues = 0, batch = 0;
     if (!f.rd(&nkeys, 8) || !f.rd(&nvalues, 8) || !f.rd(&batch, 8)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+    if (nkeys && batch == 0) { ctx->err = "corrupt header in " + fname; return MC_ERR_IO; }      // validated by read_part_header before
+    batch = std::min<uint64_t>(batch, 1ull << 26);
     int rc;
     const size_t vb = 4 + targetBytes;
     std::vector<uint32_t> keys(std::min<uint64_t>(batch, nkeys));
@@ -163,7 +175,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     // every part is announced first (the merged table is sized for all of them), then loaded in part order
     for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
         PartHeader h;
-        rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(firstPart + p), h);
+        rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(firstPart + p), h, m.targetBytes);
         if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
     }
     for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)

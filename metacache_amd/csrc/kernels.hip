@@ -1350,7 +1350,8 @@ __global__ __launch_bounds__(256) void build_sketch_lanes_kernel(BatchView b, Sk
     bool dup = false;
     if (first < nw) {
         const uint32_t p0 = first * sp.stride;
-        const uint32_t len = min(qi.y - p0, kBuildLaneWins * sp.stride + sp.k - 1);
+        // (a target's last record holds up to kBuildRecWins full windows PLUS the tail window: the last lane takes that one too)
+        const uint32_t len = lane == 63u ? qi.y - p0 : min(qi.y - p0, kBuildLaneWins * sp.stride + sp.k - 1);
         uint32_t wcount = 0;
         uint32_t* out = ws.features + (size_t)(w0 + first) * sp.s;
         if (sp.k == 16 && (sp.stride & 15u) == 0) lane_sketch_span16(b.seq, (uint64_t)qi.x + p0, len, sp.s, sp.stride, out, wcount, dup);

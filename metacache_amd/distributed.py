@@ -70,11 +70,15 @@ def classify_sharded(num_queries: int, classify_fn, dst: int = 0, group=None):
 # list is the stable merge, by hits descending, of the per-part top-K lists taken in part order --
 # exactly what feeding the parts' candidates one after the other into the reference's sorted insert
 # (candidate_generation.hpp:193-201) gives at sequence level.  Communication: one all-gather of
-# [n, K, 4] int32 per batch (RCCL over xGMI); nothing else of the path crosses GPUs.
+# [n, K, 4] int32 per batch (RCCL over xGMI); nothing else of the path crosses GPUs.  With taxon merging (-lowest above
+# sequence) the candidates' taxon keys travel along and the merge replays the reference's per-taxon insert over the parts' lists.
 # ------------------------------------------------------------------------------------------------------
-def merge_part_candidates(per_part: list[torch.Tensor]) -> torch.Tensor:
+def merge_part_candidates(per_part: list[torch.Tensor], per_part_taxa: list[torch.Tensor] | None = None) -> torch.Tensor:
     """per_part[p]: int32 [n, K, 4] = (tgt, hits, beg, end) of part p, unused entries hits == 0.
+    per_part_taxa (taxon merging, -lowest above sequence): per_part_taxa[p][n, K] = taxon key of every candidate (0 = none).
     Returns the merged [n, K, 4]."""
+    if per_part_taxa is not None:
+        return _merge_part_candidates_by_taxon(per_part, per_part_taxa)
     K = per_part[0].shape[1]
     allc = torch.cat(per_part, dim=1)                                     # [n, P*K, 4] in part order
     hits = allc[:, :, 1].to(torch.int64)
@@ -88,15 +92,65 @@ def merge_part_candidates(per_part: list[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def classify_partitioned(local: torch.Tensor, group=None) -> torch.Tensor:
-    """local: this rank's (= this part's) candidates [n, K, 4] for the WHOLE batch.  Every rank returns the
-    merged result (all-gather)."""
+def _merge_part_candidates_by_taxon(per_part: list[torch.Tensor], per_part_taxa: list[torch.Tensor]) -> torch.Tensor:
+    """Taxon merging across parts (candidate_generation.hpp:203-228): at most one entry per taxon, an entry is replaced only by
+    strictly more hits and then moves up behind the entries with at least as many.  What that sequential insert leaves is, per
+    taxon, its best hit count (first target to reach it, in (part, target) order) and, among equal counts, the order in which the
+    entries REACHED their final count.  A part's own list already is the top-K of exactly that ordering over its targets, and a
+    taxon outside a part's top-K cannot enter the overall top-K through that part (K taxa of the part are at least as good and as
+    early) -- so replaying the insert over the per-part lists, part after part, list order inside a part, gives the result of the
+    insert over all targets.  Vectorised over the reads; K * parts steps."""
+    K = per_part[0].shape[1]
+    n = per_part[0].shape[0]
+    dev = per_part[0].device
+    allc = torch.cat(per_part, dim=1)
+    allt = torch.cat(per_part_taxa, dim=1).to(torch.int64)
+    top = torch.zeros((n, K, 4), dtype=allc.dtype, device=dev)
+    top[:, :, 0] = -1
+    toptax = torch.zeros((n, K), dtype=torch.int64, device=dev)
+    ar = torch.arange(K, device=dev)[None, :]
+    for c in range(allc.shape[1]):
+        cand = allc[:, c, :]
+        h = cand[:, 1].to(torch.int64)
+        t = allt[:, c]
+        th = top[:, :, 1].to(torch.int64)
+        live = (h > 0) & (t != 0)
+        same = (toptax == t[:, None]) & (th > 0) & live[:, None]
+        found = same.any(dim=1)
+        pos = torch.where(found, same.to(torch.int64).argmax(dim=1), torch.full((n,), K, device=dev))
+        better = found & (h > th.gather(1, pos.clamp(max=K - 1)[:, None])[:, 0])
+        fresh = live & ~found
+        # where the candidate lands: behind every entry with >= hits (among the entries before its old place / in the whole list)
+        ge = th >= h[:, None]
+        land_better = (ge & (ar < pos[:, None])).sum(dim=1)
+        land_fresh = (ge & (th > 0)).sum(dim=1)
+        land = torch.where(better, land_better, land_fresh)
+        upto = torch.where(better, pos, torch.full((n,), K - 1, device=dev))        # entries land .. upto-1 move one place down
+        act = better | (fresh & (land < K))
+        # new list: j < land: old j; j == land: candidate; land < j <= upto: old j - 1; j > upto: old j
+        src = torch.where((ar > land[:, None]) & (ar <= upto[:, None]), ar - 1, ar)
+        src = torch.where(act[:, None], src, ar)
+        ntop = top.gather(1, src[:, :, None].expand(-1, -1, 4))
+        ntax = toptax.gather(1, src)
+        put = act[:, None] & (ar == land[:, None])
+        top = torch.where(put[:, :, None], cand[:, None, :].expand(-1, K, -1), ntop)
+        toptax = torch.where(put, t[:, None].expand(-1, K), ntax)
+    return top
+
+
+def classify_partitioned(local: torch.Tensor, group=None, taxa: torch.Tensor | None = None) -> torch.Tensor:
+    """local: this rank's (= this part's) candidates [n, K, 4] for the WHOLE batch; taxa: with taxon merging (-lowest above
+    sequence) the taxon key [n, K] of every candidate (0 = none), else None.  Every rank returns the merged result (all-gather)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local
     bufs = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(bufs, local.contiguous(), group=group)
-    return merge_part_candidates(bufs)
+    if taxa is None:
+        return merge_part_candidates(bufs)
+    tb = [torch.zeros_like(taxa) for _ in range(world)]
+    dist.all_gather(tb, taxa.contiguous(), group=group)
+    return merge_part_candidates(bufs, tb)
 
 
 # ------------------------------------------------------------------------------------------------------

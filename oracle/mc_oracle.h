@@ -17,6 +17,11 @@ typedef struct { int64_t taxid; uint32_t tgt; uint32_t hits; uint32_t beg; uint3
 int64_t mco_sketch(const char* seq, uint64_t len, uint32_t k, uint32_t s, uint32_t w, uint32_t stride,
                    uint32_t* feats, uint32_t* counts, uint64_t maxWindows);
 
+/* one window [p, p + n): up to s features ascending into out, returns their count, -1 = shorter than k (no window).  _plain is
+   the restatement every other entry uses, _fast the rolling form the database build uses; tests hold them against each other */
+int mco_sketch_window_plain(const char* p, uint64_t n, unsigned k, uint32_t s, uint32_t* out);
+int mco_sketch_window_fast(const char* p, uint64_t n, unsigned k, uint32_t s, uint32_t* out);
+
 /* row 11-13: database files */
 void* mco_db_open(const char* name);
 void* mco_db_open_part(const char* name, int part);

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -259,3 +260,43 @@ def test_two_ranks_gloo_async_gather_double_buffered():
     for step in range(5):
         for r in range(world):
             assert (got[step, r] == 1000 * step + r).all()
+
+
+@pytest.mark.parametrize("lowest,K", [(4, 1), (4, 2), (4, 3), (6, 2), (6, 4)])
+def test_mode_p_taxon_merging_equals_intended_multipart(golden, lowest, K):
+    """Mode P with -lowest above sequence: the merge of the per-part top-K lists (each merged per taxon inside its part) replays the
+    reference's per-taxon insert (candidate_generation.hpp:203-228) over the parts -- against the oracle's intended multi-part
+    semantics on the whole 2-part database (no process group needed: the merge itself is what is new)."""
+    import cpuref
+    from metacache_amd.distributed import merge_part_candidates
+    orc = cpuref.oracle()
+    single, p1, p2 = golden.reads()
+    reads = [(s, b"") for s in single[:700]] + list(zip(p1[:200], p2[:200]))
+    n = len(reads)
+    whole = orc.open(golden.db_path("toy32p2"))
+    parts = [orc.open_part(golden.db_path("toy32p2"), p) for p in range(2)]
+    per_part, per_tax = [], []
+    for pdb in parts:
+        c4 = torch.zeros((n, K, 4), dtype=torch.int32); c4[:, :, 0] = -1
+        tx = torch.zeros((n, K), dtype=torch.int64)
+        for i, (a, b) in enumerate(reads):
+            _, c = pdb.query(a, b, K, lowest, 0)
+            for j in range(min(K, len(c))):
+                c4[i, j] = torch.tensor([int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], dtype=torch.int64).to(torch.int32)
+                tx[i, j] = int(c[j]["taxid"])
+        per_part.append(c4); per_tax.append(tx)
+    got = merge_part_candidates(per_part, per_tax).numpy()
+    nontrivial = 0
+    for i, (a, b) in enumerate(reads):
+        _, e = whole.query(a, b, K, lowest, 0, mode=1)
+        e = e[:K]
+        for j in range(K):
+            if j < len(e):
+                assert [int(x) for x in got[i, j].view(np.uint32)] == [int(e[j]["tgt"]) & 0xFFFFFF, int(e[j]["hits"]), int(e[j]["beg"]), int(e[j]["end"])], (i, j, got[i], e)
+            else:
+                assert got[i, j, 1] == 0, (i, j, got[i], e)
+        nontrivial += int(len(e) > 0 and any(int(per_part[1][i, j, 1]) > 0 for j in range(K)) and any(int(per_part[0][i, j, 1]) > 0 for j in range(K)))
+    assert nontrivial > 100                                       # both parts contributed for many reads
+    whole.close()
+    for pdb in parts:
+        pdb.close()

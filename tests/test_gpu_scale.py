@@ -55,6 +55,10 @@ def test_builder_device_sources_key_shards_streaming_table(tmp_path, shards):
     """Targets generated in HBM -> mc_build_add_target_device (lane sketcher, per-shard pair selection) -> mc_build_table_* must give
     the table the host-source builder gives (its files are read by the oracle), and both the table the oracle builds itself."""
     spec = synthdb.phylogeny(4, 2, 3, 30_000, 90_000, seed=21 + shards)
+    # window-count edge cases of the chunk records (256 windows each; a target's last record: up to 256 full windows + the tail)
+    edge = [255 * 112 + 127, 255 * 112 + 127 + 15, 255 * 112 + 127 + 16, 255 * 112 + 127 + 67, 511 * 112 + 127 + 30, 256 * 112 + 127,
+            126, 127, 128, 16, 15, 254 * 112 + 127 + 111]
+    spec.targets["length"][:len(edge)] = edge
     cs = synthdb.CpuSynth()
     K = 3
     db, info = synthdb.build_database(spec, shards=shards, chunk_bytes=400_000, max_candidates=K)     # several flush groups
@@ -120,11 +124,11 @@ def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K):
 
 @pytest.mark.parametrize("lowest,K", [(0, 2), (0, 4), (4, 3)])
 def test_big_cands_strain_rich_lists_overflow_paths(monkeypatch, lowest, K):
-    """4 species x 70 strains: nearly every location of a read's list lies on a target with many hits, so the filter keeps almost
+    """4 species x 110 strains: nearly every location of a read's list lies on a target with many hits, so the filter keeps almost
     everything: lists beyond the first instance's 512 go on to the second (1024) and from there to the wave kernel; ties between
     near-identical strains everywhere."""
     monkeypatch.setenv("MC_BIG_MIN", "0")
-    spec = synthdb.phylogeny(2, 2, 70, 20_000, 24_000, seed=300 + lowest + K, div_strain=(0.002, 0.01))
+    spec = synthdb.phylogeny(2, 2, 110, 20_000, 24_000, seed=300 + lowest + K, div_strain=(0.002, 0.01))
     db, info = synthdb.build_database(spec, shards=1, max_candidates=K)
     db.set_lineages(spec.lineages())
     odb = scale_util.oracle_database(spec, None, threads=THREADS, with_lineages=True)
@@ -134,7 +138,7 @@ def test_big_cands_strain_rich_lists_overflow_paths(monkeypatch, lowest, K):
     for j, L in enumerate((20, 24, 30, 40, 60, 100)):                               # fewer k-mers, fewer features: shorter lists
         reads += [bytes(r[:L]) for r in cs.reads(spec, P, 5000 + 300 * j, 300)]
     cands, counts, _ = db.query(reads, lowest=lowest)
-    assert np.mean(counts > 1024) > 0.3 and np.any((counts > 256) & (counts <= 512)), np.percentile(counts, [5, 50, 95])
+    assert np.mean(counts > 1024) > 0.3 and np.any((counts > 256) & (counts <= 512)) and np.any((counts > 512) & (counts <= 1024)), np.percentile(counts, [5, 50, 95])
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, counts[i]))

@@ -132,3 +132,24 @@ def test_oracle_database_from_synthetic_collection_matches_python_restatement():
     for f in list(expect)[::37]:
         assert odb.lookup(f).tolist() == expect[f][:254]
     odb.close()
+
+
+def test_oracle_fast_window_sketcher_equals_the_plain_one():
+    """mco_db_build sketches with a rolling form of the window sketcher; it must give what the plain restatement (pinned against the
+    reference's vectors in test_oracle_golden.py) gives: random windows with ambiguity codes, lower case, U, all lengths around k."""
+    lib = cpuref.oracle().lib
+    for f in (lib.mco_sketch_window_plain, lib.mco_sketch_window_fast):
+        f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.c_uint32, C.c_void_p]
+        f.restype = C.c_int
+    rng = np.random.default_rng(1)
+    alphabet = np.frombuffer(b"ACGTacgtNUuR-", dtype=np.uint8)
+    p = np.array([.22, .22, .22, .22, .02, .02, .02, .02, .01, .01, .005, .01, .005])
+    for it in range(6000):
+        n = int(rng.integers(0, 200)); k = int(rng.choice([16, 16, 16, 10, 7, 12, 1])); s = int(rng.choice([16, 16, 8, 4, 32, 1]))
+        seq = rng.choice(alphabet, size=n + 1, p=p / p.sum())
+        if it % 50 == 0 and n >= 40:
+            seq[10:40] = seq[60:90] if n >= 90 else seq[10]                      # repeats: equal hashes inside a window
+        a = np.zeros(64, np.uint32); b = np.zeros(64, np.uint32)
+        ca = lib.mco_sketch_window_plain(seq.ctypes.data, n, k, s, a.ctypes.data)
+        cb = lib.mco_sketch_window_fast(seq.ctypes.data, n, k, s, b.ctypes.data)
+        assert ca == cb and (ca <= 0 or np.array_equal(a[:ca], b[:cb])), (it, n, k, s)
