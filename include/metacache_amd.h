@@ -207,6 +207,21 @@ typedef struct {
     uint32_t           num_queries;
 } mc_device_hits;
 int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowest_rank, mc_device_results* out, void* stream);
+/* Mode K owner side in ONE call, everything on the device: the partial lists of num_sources key shards for this rank's num_queries
+ * reads -- counts[s * num_queries + i] locations of read i from source s; each source's locations back to back in read order, the
+ * sources' blocks back to back in hits (exactly what an all-to-all-v of the shards' sorted partial lists delivers; total_hits = its
+ * receive size, known to the host from the split sizes) -- are concatenated per read and go through rows 8-10 like
+ * mc_candidates_from_hits.  Replaces the reference's per-part forwarding chain (query_batch.cu:464-527, :638-652). */
+typedef struct {
+    const uint32_t*    counts;        /* [num_sources * num_queries] */
+    const mc_location* hits;          /* [total_hits] */
+    uint64_t           total_hits;
+    const uint32_t*    max_win;       /* [num_queries] or NULL with max_win_uniform > 0 */
+    uint32_t           max_win_uniform;
+    uint32_t           num_queries;
+    uint32_t           num_sources;
+} mc_device_partial_hits;
+int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* in, int lowest_rank, mc_device_results* out, void* stream);
 /* copies out of the ctx-owned result buffers, asynchronous on the context's stream
  * (kind: 0 = device -> device, 1 = device -> host) */
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);

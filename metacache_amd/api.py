@@ -44,6 +44,11 @@ class McDeviceHits(C.Structure):
                 ("num_queries", C.c_uint32)]
 
 
+class McDevicePartialHits(C.Structure):
+    _fields_ = [("counts", C.c_void_p), ("hits", C.c_void_p), ("total_hits", C.c_uint64), ("max_win", C.c_void_p), ("max_win_uniform", C.c_uint32),
+                ("num_queries", C.c_uint32), ("num_sources", C.c_uint32)]
+
+
 class McDeviceResults(C.Structure):
     _fields_ = [("cands", C.c_void_p), ("hit_counts", C.c_void_p), ("hit_offsets", C.c_void_p), ("hits", C.c_void_p),
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
@@ -52,7 +57,7 @@ class McDeviceResults(C.Structure):
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end",
            "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
-           "mc_key_owner", "mc_candidates_from_hits", "mc_copy_results",
+           "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
            "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_add_target_device", "mc_build_flush", "mc_build_reserve",
            "mc_build_table_begin", "mc_build_table_add", "mc_build_table_end", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
@@ -285,6 +290,16 @@ class Database:
         h = McDeviceHits(hits_ptr, hit_offsets_ptr, max_win_ptr or None, max_win_uniform, n)
         r = McDeviceResults()
         self._check(lib().mc_candidates_from_hits(self.h, C.byref(h), lowest, C.byref(r), stream or None))
+        return r
+
+    def candidates_from_partial_hits(self, counts_ptr: int, hits_ptr: int, total_hits: int, n: int, sources: int, max_win_ptr: int = 0,
+                                     max_win_uniform: int = 0, lowest: int = 0, stream: int = 0) -> McDeviceResults:
+        """Mode K owner side: union of the sources' partial lists + rows 8-10, all on the device (mc_candidates_from_partial_hits)"""
+        L = lib()
+        L.mc_candidates_from_partial_hits.argtypes = [C.c_void_p, C.POINTER(McDevicePartialHits), C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
+        h = McDevicePartialHits(counts_ptr, hits_ptr or None, total_hits, max_win_ptr or None, max_win_uniform, n, sources)
+        r = McDeviceResults()
+        self._check(L.mc_candidates_from_partial_hits(self.h, C.byref(h), lowest, C.byref(r), stream or None))
         return r
 
     def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False):

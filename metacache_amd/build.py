@@ -65,6 +65,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
     build_cli(force=force, verbose=verbose)
     build_synth(force=force, verbose=verbose)
+    build_gather_peak(force=force, verbose=verbose)
     return LIB
 
 
@@ -91,6 +92,21 @@ def build_synth(force: bool = False, verbose: bool = False) -> tuple[str, str]:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return SYNTH_LIB, SYNTH_CPU_LIB
+
+
+GATHER_LIB = os.path.join(LIBDIR, "libmcgather.so")
+
+
+def build_gather_peak(force: bool = False, verbose: bool = False) -> str:
+    """tools/gather_peak.hip -> libmcgather.so: the random-access microbenchmark behind bench.py's second roofline (measurement tool)"""
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(ROOT, "tools", "gather_peak.hip")
+    if force or _stale(GATHER_LIB, [src]):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-Wno-unused-result", "-o", GATHER_LIB, src]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return GATHER_LIB
 
 
 def build_cli(force: bool = False, verbose: bool = False) -> str:

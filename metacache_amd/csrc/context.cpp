@@ -670,6 +670,47 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     return MC_OK;
 }
 
+// Mode K, owner side in one call: union of the sources' partial lists (device side, no host round trip), then rows 8-10 on it
+int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* in, int lowestRank, mc_device_results* out, void* streamv)
+{
+    if (!ctx || !in || !out || !in->counts || (!in->hits && in->total_hits) || in->num_sources < 1) return MC_ERR_INVALID;
+    if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Pipe& P = ctx->pipe0;
+    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    const uint32_t n = in->num_queries, S = in->num_sources;
+    const uint32_t K = ctx->cfg.max_candidates;
+    const uint32_t* taxkey = nullptr;
+    int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
+    if (rc) return rc;
+    const size_t hb = (size_t)(in->total_hits + 1) * 8;
+    if ((rc = ensure(ctx, P.bHits, hb)) || (rc = ensure(ctx, P.bCscr, hb)) || (taxkey && (rc = ensure(ctx, P.bCscr2, hb)))) return rc;
+    if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) ||
+        (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))) ||
+        (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
+        (rc = ensure(ctx, P.bPpay, (size_t)S * (n + 2) * 8)))
+        return rc;
+    launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, (uint64_t*)P.bPpay.p, (uint64_t*)P.bHitOff.p,
+                         (uint64_t*)P.bHits.p, P.bScan.p, st);
+    Workspace ws{};
+    ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
+    ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
+    BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
+    DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
+    {
+        ScopedTimer t(ctx, "cands_from_hits", st);
+        launch_cands_from_hits(b, tab, ws, taxkey, K, P.bCands.p, st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    P.lastN = 0;
+    out->cands = (const mc_candidate*)P.bCands.p;
+    out->hit_counts = (const uint32_t*)P.bQstat.p;
+    out->hit_offsets = ws.hitOff;
+    out->hits = (const mc_location*)ws.hits;
+    out->features = nullptr; out->win_offsets = nullptr;
+    return MC_OK;
+}
+
 int mc_synchronize(mc_ctx* ctx)
 {
     if (!ctx) return MC_ERR_INVALID;

@@ -698,6 +698,44 @@ void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Wo
     hipLaunchKernelGGL(cands_from_hits_kernel, dim3((b.n + 3) / 4), dim3(256), 0, st, b, tab, ws, taxkey, maxCand, (mc_candidate_dev*)cands);
 }
 
+// Mode K, owner side: the partial location lists of `sources` key shards (counts[s * m + i] locations of read i from source s; the
+// locations of one source back to back in read order, the sources' blocks back to back in `hits`) -> one list per read.
+//   union_totals : locations per read over all sources                      (-> scan -> ws.hitOff)
+//   union_copy   : one wave per read copies its pieces, source after source; srcStart[s * (m + 1) + i] = first location of read i
+//                  inside source s' block (exclusive scans of the counts), the block of source s begins where the blocks before end
+__global__ __launch_bounds__(256) void union_totals_kernel(const uint32_t* __restrict__ counts, uint32_t sources, uint32_t m, uint32_t* __restrict__ tot)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    uint32_t t = 0;
+    for (uint32_t s = 0; s < sources; ++s) t += counts[(size_t)s * m + i];
+    tot[i] = t;
+}
+__global__ __launch_bounds__(256) void union_copy_kernel(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ srcStart, uint32_t sources, uint32_t m,
+                                                         const uint64_t* __restrict__ hits, const uint64_t* __restrict__ hitOff, uint64_t* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    uint64_t dst = hitOff[i], base = 0;
+    for (uint32_t s = 0; s < sources; ++s) {
+        const uint32_t c = counts[(size_t)s * m + i];
+        const uint64_t* src = hits + base + srcStart[(size_t)s * (m + 1) + i];
+        for (uint32_t t = lane; t < c; t += 64) out[dst + t] = src[t];
+        dst += c;
+        base += srcStart[(size_t)s * (m + 1) + m];
+    }
+}
+void launch_union_partial(const uint32_t* counts, uint32_t sources, uint32_t m, const uint64_t* hits, uint32_t* tot, uint64_t* srcStart, uint64_t* hitOff,
+                          uint64_t* out, void* scanTmp, hipStream_t st)
+{
+    if (m == 0) return;
+    hipLaunchKernelGGL(union_totals_kernel, dim3((m + 255) / 256), dim3(256), 0, st, counts, sources, m, tot);
+    launch_scan_u32(tot, 1, m, nullptr, hitOff, scanTmp, st);
+    for (uint32_t s = 0; s < sources; ++s) launch_scan_u32(counts + (size_t)s * m, 1, m, nullptr, srcStart + (size_t)s * (m + 1), scanTmp, st);
+    hipLaunchKernelGGL(union_copy_kernel, dim3((m + 3) / 4), dim3(256), 0, st, counts, srcStart, sources, m, hits, hitOff, out);
+}
+
 void launch_sort_candidates(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws,
                             const uint32_t* taxkey, uint32_t maxCand, bool wantAllhits, void* cands, hipStream_t st)
 {

@@ -218,3 +218,67 @@ def classify_key_sharded(counts: torch.Tensor, hits: torch.Tensor, candidates_fn
     psc, psh = exchange_partial_hits(counts, hits, group=group)
     offsets, union = union_partial_hits(psc, psh)
     return candidates_fn(offsets, union)
+
+
+# ---- Mode K, device data path ----------------------------------------------------------------------------------------------
+# The functions above are the reference semantics of the exchange in torch (and what the gloo tests run).  On GPUs the per-batch
+# path is: ONE small device-to-host copy (the world + 1 list offsets that become the all-to-all-v split sizes), one tiny
+# all-to-all of those sizes, the all-to-all of the per-read counts (int32) and of the locations -- and then
+# mc_candidates_from_partial_hits: union of the sources' pieces per read (union_copy_kernel), sort, window ranges, top candidates,
+# all on the device, no per-rank host round trips and no torch index arithmetic per source.
+def partial_lists_of(db, res, n: int, device):
+    """the partial location lists a key-sharded context returned for a batch (mc_query_device(MC_WANT_ALLHITS)), as torch tensors:
+    (offsets int64 [n + 1], hits int64 [total])"""
+    off = torch.empty(n + 1, dtype=torch.int64, device=device)
+    db.copy_results(off.data_ptr(), res.hit_offsets, (n + 1) * 8)
+    db.synchronize()
+    total = int(off[-1])                                                   # sizes the hits tensor
+    hits = torch.empty(max(total, 1), dtype=torch.int64, device=device)
+    if total:
+        db.copy_results(hits.data_ptr(), res.hits, total * 8)
+        db.synchronize()
+    return off, hits[:total]
+
+
+def exchange_partial_lists(offsets: torch.Tensor, hits: torch.Tensor, group=None):
+    """offsets int64 [n + 1] / hits int64: this rank's partial lists for the WHOLE batch.  Sends every rank the pieces of ITS reads
+    (contiguous read shards, shard_bounds).  -> (counts int32 [world * m] source-major, hits int64 [total], total) for this rank's
+    m reads: the inputs of mc_candidates_from_partial_hits."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = offsets.numel() - 1
+    counts = (offsets[1:] - offsets[:-1]).to(torch.int32)
+    if world == 1:
+        return counts, hits, int(hits.numel())
+    bounds = [shard_bounds(n, r, world) for r in range(world)]
+    lo, hi = bounds[rank]
+    m = hi - lo
+    cut = torch.tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=offsets.device)
+    send_elems_t = offsets[cut][1:] - offsets[cut][:-1]                   # locations going to each rank
+    recv_elems_t = torch.empty_like(send_elems_t)
+    dist.all_to_all_single(recv_elems_t, send_elems_t, group=group)
+    sizes = torch.stack([send_elems_t, recv_elems_t]).cpu()               # the one host round trip of the exchange
+    send_elems, recv_elems = [int(x) for x in sizes[0]], [int(x) for x in sizes[1]]
+    recv_counts = torch.empty(world * m, dtype=torch.int32, device=offsets.device)
+    dist.all_to_all_single(recv_counts, counts.contiguous(), output_split_sizes=[m] * world, input_split_sizes=[b[1] - b[0] for b in bounds], group=group)
+    total = sum(recv_elems)
+    recv_hits = torch.empty(max(total, 1), dtype=hits.dtype, device=hits.device)
+    dist.all_to_all_single(recv_hits[:total], hits.contiguous(), output_split_sizes=recv_elems, input_split_sizes=send_elems, group=group)
+    return recv_counts, recv_hits[:total], total
+
+
+def classify_key_sharded_device(db, res, n: int, K: int, max_win_uniform: int, lowest: int = 0, group=None) -> torch.Tensor:
+    """Mode K for one batch on this rank's GPU: res = db.query_device(..., want_allhits=True) of the key-sharded context db over all
+    n reads.  Returns int32 [m, K, 4] for this rank's read shard (gather_candidates hands the shards to rank 0)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    device = torch.device("cuda", db.cfg.device)
+    off, hits = partial_lists_of(db, res, n, device)
+    counts, rhits, total = exchange_partial_lists(off, hits, group=group)
+    lo, hi = shard_bounds(n, rank, world)
+    m = hi - lo
+    r2 = db.candidates_from_partial_hits(counts.data_ptr(), rhits.data_ptr() if total else 0, total, m, world, max_win_uniform=max_win_uniform, lowest=lowest)
+    out = torch.empty((m, K, 4), dtype=torch.int32, device=device)
+    db.copy_results(out.data_ptr(), r2.cands, m * K * 16)
+    db.synchronize()
+    return out

@@ -177,6 +177,13 @@ def _worker_mode_k(rank, world, port, n, K, q):
                 out[i, j] = torch.tensor([int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], dtype=torch.int64).to(torch.int32)
         return out
 
+    # the exchange of the device data path (one size round trip, int32 counts source-major) must deliver what the reference form does
+    from metacache_amd.distributed import exchange_partial_hits, exchange_partial_lists
+    offs_t = torch.zeros(n + 1, dtype=torch.int64); offs_t[1:] = torch.cumsum(counts_t, 0)
+    psc, psh = exchange_partial_hits(counts_t, hits_t)
+    cnt32, rh, total = exchange_partial_lists(offs_t, hits_t)
+    assert torch.equal(cnt32.view(world, -1).to(torch.int64), psc) and total == sum(int(x.numel()) for x in psh)
+    assert torch.equal(rh, torch.cat(psh) if total else rh)
     local = classify_key_sharded(counts_t, hits_t, candidates)
     parts = gather_candidates(local, dst=0)
     if rank == 0:

@@ -58,6 +58,17 @@ def test_three_key_shards_union_equals_whole_table(golden, lowest, K):
                                          lowest=lowest)
         whole.copy_results(got[lo:hi].data_ptr(), res.cands, (hi - lo) * K * 16)
         whole.synchronize()
+    # the device data path of the owner side: counts source-major + the sources' pieces back to back -> union kernel + rows 8-10
+    got2 = torch.zeros((n, K, 4), dtype=torch.int32, device=dev)
+    for o in range(world):
+        lo, hi = shard_bounds(n, o, world)
+        cnt = torch.cat([c[lo:hi].to(torch.int32) for c in counts]).contiguous()
+        pieces = torch.cat([h[int(off[lo]):int(off[hi])] for off, h in hits]).contiguous()
+        res = whole.candidates_from_partial_hits(cnt.data_ptr(), pieces.data_ptr() if pieces.numel() else 0, pieces.numel(), hi - lo, world,
+                                                 max_win_ptr=max_win[lo:hi].contiguous().data_ptr(), lowest=lowest)
+        whole.copy_results(got2[lo:hi].data_ptr(), res.cands, (hi - lo) * K * 16)
+        whole.synchronize()
+    assert torch.equal(got, got2)
     got = got.cpu().numpy().view(np.uint32)
     exp, _, _ = whole.query(reads, lowest=lowest)
     whole.close()
@@ -73,3 +84,16 @@ def test_three_key_shards_union_equals_whole_table(golden, lowest, K):
             for j in range(min(K, len(c))):
                 assert (got[i, j, 0], got[i, j, 1], got[i, j, 2], got[i, j, 3]) == (c[j]["tgt"], c[j]["hits"], c[j]["beg"], c[j]["end"]), (i, j)
     odb.close()
+
+
+@pytest.mark.gpu
+def test_modes_over_rccl_single_rank_process(golden):
+    """tools/dist_modes_check.py in its own process: Mode R gather, Mode P merge (sequence level and per taxon) and the Mode K device
+    data path (all-to-all of counts and locations, union kernel) over a real RCCL process group of world size 1 on this GPU, each
+    against the oracle.  (World sizes > 1 run the same script under torch.distributed.run; the exchange logic itself is covered with
+    two gloo ranks in tests/test_distributed_cpu.py.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_modes_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST MODES OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -22,6 +22,15 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--reads", type=int, default=3000)
     args = ap.parse_args()
+    total, bad = run(args.iters, args.seed, args.reads, lambda m: print(m, flush=True))
+    print("SOAK", "OK" if bad == 0 else "FAILED", total, "queries,", bad, "mismatches")
+
+
+def run(iters: int, seed: int, nreads: int, log):
+    """-> (queries, mismatches); one log line per database"""
+    class A:
+        pass
+    args = A(); args.iters, args.seed, args.reads = iters, seed, nreads
     orc = cpuref.oracle()
     tmp = tempfile.mkdtemp(prefix="mcsoak", dir="/tmp")
     total = bad = 0
@@ -31,6 +40,8 @@ def main():
         K = int(rng.integers(1, 5))
         lowest = int(rng.choice([0, 0, 4, 6]))
         lf = float(rng.choice([0.3, 0.5, 0.8]))
+        big_min = str(rng.choice([0, 300, 1024]))                   # lists beyond this take big_cands_kernel (read at mc_create)
+        os.environ["MC_BIG_MIN"] = big_min
         genomes, parents = [], []
         ngroups = int(rng.integers(2, 8))
         for sp in range(ngroups):
@@ -83,15 +94,16 @@ def main():
             if not ok:
                 nbad += 1
                 if nbad <= 2:
-                    print("MISMATCH it", it, "read", i, "len", len(reads[i]), len(mates[i]), "H", counts[i], cands[i], e, flush=True)
+                    log(f"MISMATCH it {it} read {i} len {len(reads[i])} {len(mates[i])} H {counts[i]} {cands[i]} {e}")
         odb.close()
         total += len(reads); bad += nbad
-        print(f"iter {it}: targets {len(genomes)} tb {tb} K {K} lowest {lowest} lf {lf} ins {ins} max H {int(counts.max())} "
-              f"classes <=24 {int((counts <= 24).sum())} <=256 {int(((counts > 24) & (counts <= 256)).sum())} <=1024 {int(((counts > 256) & (counts <= 1024)).sum())} "
-              f">1024 {int((counts > 1024).sum())}: mismatches {nbad}", flush=True)
+        log(f"iter {it}: targets {len(genomes)} tb {tb} K {K} lowest {lowest} lf {lf} ins {ins} big_min {big_min} max H {int(counts.max())} "
+            f"classes <=24 {int((counts <= 24).sum())} <=256 {int(((counts > 24) & (counts <= 256)).sum())} <=1024 {int(((counts > 256) & (counts <= 1024)).sum())} "
+            f">1024 {int((counts > 1024).sum())}: mismatches {nbad}")
         for ext in (".meta", ".cache0"):
             os.remove(name + ext)
-    print("SOAK", "OK" if bad == 0 else "FAILED", total, "queries,", bad, "mismatches")
+    os.environ.pop("MC_BIG_MIN", None)
+    return total, bad
 
 
 if __name__ == "__main__":
