@@ -47,12 +47,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
 PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
-           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_cands", "big_cands_2", "query_wave", "scan",
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_count", "big_count_2", "query_wave", "scan",
            "sort_candidates")
 PMC_NAMES = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "sketch_probe": ("sketch_probe_lane",),
              "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",),
-             "big_cands": ("big_cands",), "big_cands_2": ("big_cands",), "hash_cands_256": ("hash_cands",), "hash_cands_512": ("hash_cands",),
-             "hash_cands_1024": ("hash_cands",), "mid_cands_64": ("mid_cands",), "mid_cands_128": ("mid_cands",), "mid_cands_256": ("mid_cands",)}
+             "big_filter": ("big_filter",), "big_count": ("big_count",), "big_count_2": ("big_count_2",), "hash_cands_256": ("hash_cands_256", "hash_cands"),
+             "hash_cands_512": ("hash_cands_512", "hash_cands"), "hash_cands_1024": ("hash_cands_1024", "hash_cands"), "mid_cands_64": ("mid_cands",), "mid_cands_128": ("mid_cands",), "mid_cands_256": ("mid_cands",)}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
 

@@ -58,7 +58,7 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
-           "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats",
+           "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats", "mc_set_tuning",
            "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_add_target_device", "mc_build_flush", "mc_build_reserve",
            "mc_build_table_begin", "mc_build_table_add", "mc_build_table_end", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
@@ -304,6 +304,11 @@ class Database:
 
     def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False):
         self._check(lib().mc_copy_results(self.h, dst_ptr, src_ptr, nbytes, 1 if to_host else 0))
+
+    def set_tuning(self, name: str, value: int):
+        L = lib()
+        L.mc_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        self._check(L.mc_set_tuning(self.h, name.encode(), value))
 
     def synchronize(self):
         self._check(lib().mc_synchronize(self.h))

@@ -206,7 +206,7 @@ void mc_destroy(mc_ctx* ctx)
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
-                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList};
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
@@ -522,7 +522,15 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)9 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    // pool of the filtered location lists (big_filter_kernel -> big_count_kernel): 384 per query on average, at least 4 MB
+    // (tables whose features have few locations each never produce such lists: a token pool; a full pool sends lists to the wave kernel)
+    const Part& T0 = ctx->parts[0];
+    uint64_t locs = 0;
+    for (auto& p : ctx->parts) locs += p.locations;
+    const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 256.0;
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * (longLists ? 384 : 8), 1u << 19));
+    if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -537,6 +545,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if (lanePath) {
         ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
         ws.bigMin = ctx->bigMin;
+        ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap;
         ws.chunkList = (uint2*)P.bChunkList.p;
     }
 
@@ -582,8 +591,9 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if (hcnt[3]) { ScopedTimer t(ctx, "hash_cands_512", st); launch_hash_cands(3, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[4]) { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[9]) {
-            { ScopedTimer t(ctx, "big_cands", st); launch_big_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
-            { ScopedTimer t(ctx, "big_cands_2", st); launch_big_cands(1, b, tab, ws, K, taxkey, P.bCands.p, st); }
+            { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+            { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+            { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         }
         waveWork = hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
     } else {
@@ -708,6 +718,18 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     out->hit_offsets = ws.hitOff;
     out->hits = (const mc_location*)ws.hits;
     out->features = nullptr; out->win_offsets = nullptr;
+    return MC_OK;
+}
+
+// tuning / test hook: the switches the MC_* environment variables set at mc_create, changeable on a live context (no batch in flight)
+int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return MC_ERR_INVALID;
+    const std::string n(name);
+    if (n == "big_min") ctx->bigMin = (uint32_t)std::max<int64_t>(0, value);
+    else if (n == "quad_lookup") ctx->quadLookup = value < 0 ? -1 : (value != 0);
+    else if (n == "lane_path") ctx->useLanePath = value != 0;
+    else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }
 

@@ -107,8 +107,11 @@ struct Workspace {           // device buffers sized by the host for this batch
                              //            6 = long read handled by the chunk lane kernels
     uint32_t* midCount;      // [16]; [8] = third work list of hash_cands_kernel (129..256);       lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
     uint2*    chunkList;     // [W + n]    {query, chunk}: long single reads, cut into one-window chunks for the chunk lane kernels
-    uint32_t  bigMin;        // lists longer than this (and > 256) from <= 64 found features go to big_cands_kernel (midCount[9] / [10], lists 6 / 7)
-    uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
+    uint32_t  bigMin;        // lists longer than this (and > 256) from <= 64 found features go to big_filter_kernel (midCount[9], list 6), which
+                             // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
+    uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
+    uint32_t  bigPoolCap;
+    uint32_t* midList;       // [9][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations
@@ -148,7 +151,8 @@ void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const 
                               const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
-void launch_big_cands(uint32_t stage, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
+void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                      const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* taxkey, uint32_t maxCand,

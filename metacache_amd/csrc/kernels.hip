@@ -2489,49 +2489,87 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 }
 
 // ================================================================================================
-// big_cands_kernel: location lists beyond hash_cands_kernel's reach (RefSeq scale: 2 x 10^10 locations behind 32-bit features, a
-// 150 bp read collects 1000 .. 8000 locations), one WAVE per query.  Nearly all of those locations are single hits on unrelated
-// targets; what rows 8-10 keep of them is at most "the smallest target ids with one hit" when fewer than K targets reach two.  So
-// the list is FILTERED before anything is counted per (target, window):
+// big_filter_kernel + big_count_kernel: location lists beyond hash_cands_kernel's reach (RefSeq scale: 2 x 10^10 locations behind
+// 32-bit features, a 150 bp read collects 1000 .. 8000 locations), one WAVE per query.  Nearly all of those locations are single
+// hits on unrelated targets; what rows 8-10 keep of them is at most "the smallest target ids with one hit" when fewer than K targets
+// reach two.  So the list is FILTERED before anything is counted per (target, window):
+//   big_filter_kernel
 //   A. every location sets a 2-bit state (seen once / seen twice or more) in an LDS bit table indexed by a hash of its TARGET
-//      (32768 states in 8 KB: two ds_or per repeated target, one per new one);
-//   B. second sweep over the list: locations whose target state says "twice or more" go to an LDS list -- all locations of every
-//      target with >= 2 hits and a few percent of the rest (hash collisions) -- typically a fifth of the list;
-//   C. count_and_pick (hash_cands_kernel's steps 1-3) on that list: exact hits per window range, K rounds;
+//      (16384 states in 4 KB: two ds_or per repeated target, one per new one);
+//   B. second sweep over the list: locations whose target state says "twice or more" are compacted (ballot) into an LDS list and
+//      leave for a pool in HBM -- all locations of every target with >= 2 hits and a few percent of the rest (hash collisions),
+//      typically a quarter of the list.
+//   big_count_kernel
+//   C. count_and_pick (hash_cands_kernel's steps 1-3) on the filtered list: exact hits per window range, K rounds;
 //   D. only if fewer than K picked candidates have >= 2 hits: the open places go to the smallest targets among ALL other
 //      locations, each with its smallest window (hits = 1 candidates are ordered by target id alone = arrival order in the sorted
-//      list, candidate_generation.hpp:172-201) -- third sweep.  With taxon merging this case goes to the wave kernel.
+//      list, candidate_generation.hpp:172-201) -- a sweep over the original lists.  With taxon merging this case goes to the wave kernel.
+// Two kernels because both halves wait for memory most of their time and are held back by different resources: the sweeps need few
+// registers and 11 KB of LDS per wave (14 waves per CU in flight), the counting 150 registers and a 10 KB hash table.  Fused they
+// ran at 8 waves per CU: 22 us per list, nearly all of it memory latency of the sweeps (R / kBigU dependent round trips each).
 // The sweeps read the bucket lists straight from the table: one coalesced wave load per 64 locations of a bucket ("round"),
-// kBigU rounds in flight; sweeps B and D re-read what sweep A brought into the L2 / infinity cache.
-// Lists whose filtered part does not fit LOG2S-1 bits go to the next larger instance (work list 7), then to the wave kernel.
+// kBigU rounds in flight; sweep B re-reads what sweep A brought into the L2 / infinity cache.
+// Filtered lists beyond 512 take the instance with the larger hash table (work list 8), beyond 1024 (or when the pool is full) the
+// wave kernel.
 // ================================================================================================
 constexpr uint32_t kBigU = 8;             // rounds in flight
-constexpr uint32_t kBigBitsLog2 = 15;     // target states
+constexpr uint32_t kBigBitsLog2 = 14;     // target states
+constexpr uint32_t kBigStage = 512;       // filtered locations staged in LDS before they leave for the pool
+constexpr uint32_t kBigMaxFiltered = 1024;
+constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
-template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
-__global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
-                                                               const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
-                                                               uint32_t listIdx, uint32_t countIdx)
+struct BigTables {                        // per wave: entry table and round table of one query
+    uint64_t entPay[kBigEnt];
+    uint32_t entSz[kBigEnt];
+    uint64_t rounds[kBigMaxRounds + kBigU];
+};
+
+// entries -> LDS tables; returns the number of rounds (> kBigMaxRounds: merged buckets of a partitioned database, not handled here)
+__device__ __forceinline__ uint32_t big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay)
 {
-    constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2, kBitWords = (1u << kBigBitsLog2) / 16;
-    constexpr uint32_t kRegionWords = (kSlots * 2 > kBitWords) ? kSlots * 2 : kBitWords;
-    constexpr uint32_t kMaxRounds = kBigEnt * 4;
-    __shared__ uint32_t regionS[WAVES][kRegionWords];            // A/B: target states; C: (target, window) keys
-    __shared__ uint32_t cntS[WAVES][kSlots / 2];
-    __shared__ uint64_t listS[WAVES][kList];
-    __shared__ uint64_t entPayS[WAVES][kBigEnt];
-    __shared__ uint32_t entSzS[WAVES][kBigEnt];
-    __shared__ uint64_t roundS[WAVES][kMaxRounds + kBigU];
+    if (lane < nent) { T.entPay[lane] = myPay; T.entSz[lane] = mySz; }
+    const uint32_t myRounds = (lane < nent && mySz > 1) ? (mySz + 63u) / 64u : 0u;
+    const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
+    const uint32_t R = rdlane(incl, 63);
+    if (R <= kBigMaxRounds) {
+        for (uint32_t j = 0; j < myRounds; ++j)
+            T.rounds[incl - myRounds + j] = (myPay + 64ull * j) | ((uint64_t)min(64u, mySz - 64u * j) << 40);
+        if (lane < kBigU) T.rounds[R + lane] = 0ull;
+    }
+    return R;
+}
+// one sweep over a query's locations: f(v) for the lane's element of every round (kEmptyLoc = none), kBigU rounds' loads in flight
+template <class F>
+__device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const uint32_t R, const uint64_t single, F&& f)
+{
+    f(single);
+    for (uint32_t g0 = 0; g0 < R; g0 += kBigU) {
+        uint64_t rv[kBigU];
+#pragma unroll
+        for (uint32_t u = 0; u < kBigU; ++u) {
+            const uint64_t rd = T.rounds[g0 + u];
+            rv[u] = lane < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + lane] : kEmptyLoc;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
+    }
+}
+
+template <uint32_t WAVES>
+__global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
+{
+    constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
+    __shared__ uint32_t bitS[WAVES][kBitWords];
+    __shared__ uint64_t stageS[WAVES][kBigStage];
+    __shared__ BigTables tabS[WAVES];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* bits = regionS[wave];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(regionS[wave]);
-    uint32_t* cnts = cntS[wave];
-    uint64_t* list = listS[wave];
-    uint64_t* entPay = entPayS[wave];
-    uint32_t* entSz = entSzS[wave];
-    uint64_t* rounds = roundS[wave];
-    const uint32_t total = ws.midCount[countIdx];
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)listIdx * b.n;
+    uint32_t* bits = bitS[wave];
+    uint64_t* stage = stageS[wave];
+    BigTables& T = tabS[wave];
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    uint4* __restrict__ outSmall = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
+    uint4* __restrict__ outLarge = reinterpret_cast<uint4*>(ws.midList) + (size_t)8 * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
@@ -2544,7 +2582,6 @@ __global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, Devi
     };
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
-        // ---- states cleared; entry table and round table (one round = up to 64 consecutive locations of one bucket) in LDS
         {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
 #pragma unroll
@@ -2552,81 +2589,104 @@ __global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, Devi
         }
         const uint32_t mySz = esz & 0xFFFFu;
         const uint64_t myPay = epay;
-        if (lane < nent) { entPay[lane] = myPay; entSz[lane] = mySz; }
-        const uint32_t myRounds = (lane < nent && mySz > 1) ? (mySz + 63u) / 64u : 0u;
-        const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
-        const uint32_t R = rdlane(incl, 63);
-        if (R > kMaxRounds) {                                      // merged buckets of a partitioned database can be longer than 254
-            if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
-            rec = recNext;
-            recNext = load_rec(w + 2 * nWaves);
-            esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
-            epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
-            wave_lds_sync();
-            continue;
-        }
-        for (uint32_t j = 0; j < myRounds; ++j)
-            rounds[incl - myRounds + j] = (myPay + 64ull * j) | ((uint64_t)min(64u, mySz - 64u * j) << 40);
-        if (lane < kBigU) rounds[R + lane] = 0ull;
-        const bool single = lane < nent && mySz == 1;
+        const uint32_t R = big_setup(T, lane, nent, mySz, myPay);
+        const uint64_t single = (lane < nent && mySz == 1) ? myPay : kEmptyLoc;
         rec = recNext;                                             // the next query's record and entries are on their way meanwhile
         recNext = load_rec(w + 2 * nWaves);
         esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
         epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
         wave_lds_sync();
-        // one sweep over the query's locations: f(v) for the lane's element of every round, kBigU rounds' loads in flight
-        auto sweep = [&](auto&& f) {
-            f(single ? myPay : kEmptyLoc);
-            for (uint32_t g0 = 0; g0 < R; g0 += kBigU) {
-                uint64_t rv[kBigU];
-#pragma unroll
-                for (uint32_t u = 0; u < kBigU; ++u) {
-                    const uint64_t rd = rounds[g0 + u];
-                    rv[u] = lane < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + lane] : kEmptyLoc;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
-            }
-        };
-        // ---- A. target states
-        sweep([&](uint64_t v) {
-            if (v != kEmptyLoc) {
-                uint32_t word, bit1;
-                state_of(v, word, bit1);
-                const uint32_t old = atomicOr(&bits[word], bit1);
-                if (old & bit1) atomicOr(&bits[word], bit1 << 1);
-            }
-        });
-        wave_lds_sync();
-        // ---- B. locations of targets seen twice or more -> list
+        bool fallback = R > kBigMaxRounds;
         uint32_t n2 = 0;
-        sweep([&](uint64_t v) {
-            bool keep = false;
-            if (v != kEmptyLoc) {
-                uint32_t word, bit1;
-                state_of(v, word, bit1);
-                keep = (bits[word] & (bit1 << 1)) != 0;
-            }
-            const uint64_t m = __ballot(keep);
-            if (keep) {
-                const uint32_t at = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (at < kList) list[at] = v;
-            }
-            n2 += (uint32_t)__popcll(m);
-        });
-        wave_lds_sync();
-        if (n2 > kList) {
-            // does not fit this instance: on to the larger one, or to the wave kernel
-            if (lane == 0) {
-                if (listIdx == 6) {
-                    const uint32_t at = atomicAdd(&ws.midCount[10], 1u);
-                    reinterpret_cast<uint4*>(ws.midList)[(size_t)7 * b.n + at] = make_uint4(q, work[w].y, nent | (H << 12), maxWin);
-                } else { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
-            }
+        if (!fallback) {
+            // ---- A. target states
+            big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
+                if (v != kEmptyLoc) {
+                    uint32_t word, bit1;
+                    state_of(v, word, bit1);
+                    const uint32_t old = atomicOr(&bits[word], bit1);
+                    if (old & bit1) atomicOr(&bits[word], bit1 << 1);
+                }
+            });
             wave_lds_sync();
-            continue;
+            // ---- B. locations of targets seen twice or more -> stage (the first kBigStage of them), counted
+            big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
+                bool keep = false;
+                if (v != kEmptyLoc) {
+                    uint32_t word, bit1;
+                    state_of(v, word, bit1);
+                    keep = (bits[word] & (bit1 << 1)) != 0;
+                }
+                const uint64_t m = __ballot(keep);
+                if (keep) {
+                    const uint32_t at = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (at < kBigStage) stage[at] = v;
+                }
+                n2 += (uint32_t)__popcll(m);
+            });
+            wave_lds_sync();
+            fallback = n2 > kBigMaxFiltered;
         }
-        // ---- C. exact counting of the filtered list
+        uint32_t poolAt = 0;
+        if (!fallback) {
+            if (lane == 0) poolAt = atomicAdd(&ws.midCount[11], n2);
+            poolAt = rdlane(poolAt, 0);
+            fallback = (uint64_t)poolAt + n2 > ws.bigPoolCap;
+        }
+        if (fallback) {
+            if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
+        } else {
+            uint64_t* dst = ws.bigPool + poolAt;
+            if (n2 <= kBigStage) {
+                for (uint32_t i = lane; i < n2; i += 64) dst[i] = stage[i];
+            } else {
+                // rare: more than the stage holds -- the same sweep again, straight into the pool
+                uint32_t at2 = 0;
+                big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
+                    bool keep = false;
+                    if (v != kEmptyLoc) {
+                        uint32_t word, bit1;
+                        state_of(v, word, bit1);
+                        keep = (bits[word] & (bit1 << 1)) != 0;
+                    }
+                    const uint64_t m = __ballot(keep);
+                    if (keep) dst[at2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+                    at2 += (uint32_t)__popcll(m);
+                });
+            }
+            if (lane == 0) {
+                const bool large = n2 > kBigStage;
+                const uint32_t at = atomicAdd(&ws.midCount[large ? 12 : 10], 1u);
+                (large ? outLarge : outSmall)[at] = make_uint4(q, poolAt, n2 | (nent << 16), maxWin);
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
+__global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+                                                               const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
+                                                               uint32_t listIdx, uint32_t countIdx)
+{
+    constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
+    __shared__ uint64_t keyS[WAVES][kSlots];
+    __shared__ uint32_t cntS[WAVES][kSlots / 2];
+    __shared__ BigTables tabS[WAVES];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t* keys = keyS[wave];
+    uint32_t* cnts = cntS[wave];
+    BigTables& T = tabS[wave];
+    const uint32_t total = ws.midCount[countIdx];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)listIdx * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    uint4 rec = load_rec(w0);
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint32_t q = rec.x, n2 = rec.z & 0xFFFFu, nent = rec.z >> 16, maxWin = rec.w;
+        const uint64_t* __restrict__ src = ws.bigPool + rec.y;
+        rec = load_rec(w + nWaves);
         {
             uint4* k4 = reinterpret_cast<uint4*>(keys);
             uint4* c4 = reinterpret_cast<uint4*>(cnts);
@@ -2645,7 +2705,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, Devi
             constexpr uint32_t PER = decltype(perc)::value;
             uint64_t v[PER];
 #pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? list[r * 64 + lane] : kEmptyLoc;
+            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kEmptyLoc;
             strong = count_and_pick<LOG2S, PER, TAX>(v, keys, cnts, lane, maxWin, K, taxkey, tab, out, picked);
         };
         const uint32_t per = (n2 + 63u) / 64u;
@@ -2662,19 +2722,24 @@ __global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, Devi
             else body(std::integral_constant<uint32_t, kList / 64>{});
         }
         strong = __builtin_amdgcn_readfirstlane(strong);
+        bool done = true;
         if (strong < K) {
             if constexpr (TAX) {
                 // places left for single-hit taxa: the order among those depends on every target's taxon -> the exact wave kernel
-                if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
-                wave_lds_sync();
-                continue;
+                if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+                done = false;
             } else {
                 // ---- D. the open places: smallest targets (with their smallest window) among the locations of all targets that were
                 //      not picked with >= 2 hits -- every such target's best range is a single location
+                const uint32_t fbase = ws.winOff[q] * s;
+                const uint32_t mySz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
+                const uint64_t myPay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
+                const uint32_t R = big_setup(T, lane, nent, mySz, myPay);
+                wave_lds_sync();
                 uint64_t best[kLaneK];
 #pragma unroll
                 for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kEmptyLoc;
-                sweep([&](uint64_t v) {
+                big_sweep(T, tab, lane, R, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v) {
                     if (v == kEmptyLoc) return;
                     const uint32_t t = (uint32_t)(v >> 32);
                     bool skip = false;
@@ -2714,24 +2779,27 @@ __global__ __launch_bounds__(WAVES * 64) void big_cands_kernel(BatchView b, Devi
                 }
             }
         }
-        if (lane == 0) ws.qflag[q] = kFlagDone;
+        if (done && lane == 0) ws.qflag[q] = kFlagDone;
         wave_lds_sync();
     }
 }
 
-void launch_big_cands(uint32_t stage, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands,
-                      hipStream_t st)
+void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                      const uint32_t* taxkey, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
-    // persistent grids; stage 0: filtered lists up to 512 locations (work list 6), stage 1: up to 1024 (work list 7, fed by stage 0)
+    mc_candidate_dev* c = (mc_candidate_dev*)cands;
+    // persistent grids.  stage 0: the filter; 1: counting of filtered lists up to 512 (work list 7); 2: up to 1024 (work list 8)
     if (stage == 0) {
-        const uint32_t grid = std::min<uint32_t>(256 * 2, (b.n + 3) / 4);
-        if (taxkey) hipLaunchKernelGGL((big_cands_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 6u, 9u);
-        else        hipLaunchKernelGGL((big_cands_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 6u, 9u);
+        hipLaunchKernelGGL((big_filter_kernel<4>), dim3(std::min<uint32_t>(256 * 4, (b.n + 3) / 4)), dim3(256), 0, st, b, tab, ws);
+    } else if (stage == 1) {
+        const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 3) / 4);
+        if (taxkey) hipLaunchKernelGGL((big_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 7u, 10u);
+        else        hipLaunchKernelGGL((big_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 7u, 10u);
     } else {
         const uint32_t grid = std::min<uint32_t>(256 * 2, (b.n + 1) / 2);
-        if (taxkey) hipLaunchKernelGGL((big_cands_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 7u, 10u);
-        else        hipLaunchKernelGGL((big_cands_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, 7u, 10u);
+        if (taxkey) hipLaunchKernelGGL((big_count_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 8u, 12u);
+        else        hipLaunchKernelGGL((big_count_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 8u, 12u);
     }
 }
 

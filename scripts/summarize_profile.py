@@ -6,10 +6,10 @@ import glob
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles")
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(src, "summary") if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
@@ -18,8 +18,16 @@ def short(k):
     if "query_kernel<false>" in k: return "query_kernel<unfused>"
     if "sketch_probe_lane" in k: return "sketch_probe_lane"
     if "mid_cands_kernel" in k: return "mid_cands"
+    if "hash_cands_kernel<9" in k: return "hash_cands_256"
+    if "hash_cands_kernel<10" in k: return "hash_cands_512"
+    if "hash_cands_kernel<11" in k: return "hash_cands_1024"
     if "hash_cands_kernel" in k: return "hash_cands"
-    for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs", "chunk_sketch", "chunk_probe", "chunk_finish", "flag_count", "table_seal"):
+    if "big_cands_kernel<10" in k: return "big_cands"
+    if "big_cands_kernel<11" in k: return "big_cands_2"
+    if "big_filter_kernel" in k: return "big_filter"
+    if "big_count_kernel<10" in k: return "big_count"
+    if "big_count_kernel<11" in k: return "big_count_2"
+    for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs", "chunk_sketch", "chunk_probe", "chunk_finish", "flag_count", "table_seal", "build_sketch_lanes", "own_count", "own_emit", "union_copy"):
         if n in k: return n
     return None
 
