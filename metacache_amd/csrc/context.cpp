@@ -522,14 +522,14 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)9 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
     // pool of the filtered location lists (big_filter_kernel -> big_count_kernel): 384 per query on average, at least 4 MB
     // (tables whose features have few locations each never produce such lists: a token pool; a full pool sends lists to the wave kernel)
     const Part& T0 = ctx->parts[0];
     uint64_t locs = 0;
     for (auto& p : ctx->parts) locs += p.locations;
     const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 256.0;
-    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * (longLists ? 384 : 8), 1u << 19));
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * (longLists ? 448 : 8), (uint64_t)big_filter_grid(n) * 4 * 1024));   // >= one full list per wave
     if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;

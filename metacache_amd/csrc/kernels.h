@@ -111,7 +111,7 @@ struct Workspace {           // device buffers sized by the host for this batch
                              // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
     uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
     uint32_t  bigPoolCap;
-    uint32_t* midList;       // [9][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
+    uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan
     uint64_t* hits;          // [H]        gathered + sorted locations
@@ -153,6 +153,7 @@ void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
+uint32_t big_filter_grid(uint32_t n);     // blocks of 4 waves the filter runs with: the pool is cut into one slice per wave
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* taxkey, uint32_t maxCand,

@@ -2512,12 +2512,15 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 // Filtered lists beyond 512 take the instance with the larger hash table (work list 8), beyond 1024 (or when the pool is full) the
 // wave kernel.
 // ================================================================================================
-constexpr uint32_t kBigU = 8;             // rounds in flight
+#ifndef MC_BIG_U
+#define MC_BIG_U 16
+#endif
+constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
 constexpr uint32_t kBigBitsLog2 = 14;     // target states
-constexpr uint32_t kBigStage = 512;       // filtered locations staged in LDS before they leave for the pool
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
+uint32_t big_filter_grid(uint32_t n);
 struct BigTables {                        // per wave: entry table and round table of one query
     uint64_t entPay[kBigEnt];
     uint32_t entSz[kBigEnt];
@@ -2555,24 +2558,28 @@ __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable&
     }
 }
 
+// No atomics on global memory: a wave appends its filtered lists to ITS OWN slice of the pool (a million waves bumping one cursor
+// cost more than the sweeps: 43 ms instead of 14), and the record for big_count_kernel goes to the place of the query's own work
+// record (list 7 runs parallel to list 6; n2 = 0xFFFF marks lists that went to the wave kernel instead).
 template <uint32_t WAVES>
 __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
     constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
     __shared__ uint32_t bitS[WAVES][kBitWords];
-    __shared__ uint64_t stageS[WAVES][kBigStage];
     __shared__ BigTables tabS[WAVES];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* bits = bitS[wave];
-    uint64_t* stage = stageS[wave];
     BigTables& T = tabS[wave];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
-    uint4* __restrict__ outSmall = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
-    uint4* __restrict__ outLarge = reinterpret_cast<uint4*>(ws.midList) + (size_t)8 * b.n;
+    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
+    // this wave's slice of the pool
+    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
+    uint64_t* const slice = ws.bigPool + (uint64_t)w0 * sliceCap;
+    uint64_t sliceUsed = 0;
     uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
     uint32_t esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
     uint64_t epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
@@ -2609,7 +2616,9 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
                 }
             });
             wave_lds_sync();
-            // ---- B. locations of targets seen twice or more -> stage (the first kBigStage of them), counted
+            // ---- B. locations of targets seen twice or more -> this wave's pool slice (as long as they fit), counted
+            uint64_t* dst = slice + sliceUsed;
+            const uint32_t room = (uint32_t)min((uint64_t)kBigMaxFiltered, sliceCap - sliceUsed);
             big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
@@ -2620,46 +2629,17 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
                 const uint64_t m = __ballot(keep);
                 if (keep) {
                     const uint32_t at = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (at < kBigStage) stage[at] = v;
+                    if (at < room) dst[at] = v;
                 }
                 n2 += (uint32_t)__popcll(m);
             });
-            wave_lds_sync();
-            fallback = n2 > kBigMaxFiltered;
+            fallback = n2 > room;                                  // too long for big_count_kernel, or the slice is full
         }
-        uint32_t poolAt = 0;
-        if (!fallback) {
-            if (lane == 0) poolAt = atomicAdd(&ws.midCount[11], n2);
-            poolAt = rdlane(poolAt, 0);
-            fallback = (uint64_t)poolAt + n2 > ws.bigPoolCap;
+        if (lane == 0) {
+            if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, 0xFFFFu, maxWin); }
+            else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2 | (nent << 16), maxWin);
         }
-        if (fallback) {
-            if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; }
-        } else {
-            uint64_t* dst = ws.bigPool + poolAt;
-            if (n2 <= kBigStage) {
-                for (uint32_t i = lane; i < n2; i += 64) dst[i] = stage[i];
-            } else {
-                // rare: more than the stage holds -- the same sweep again, straight into the pool
-                uint32_t at2 = 0;
-                big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
-                    bool keep = false;
-                    if (v != kEmptyLoc) {
-                        uint32_t word, bit1;
-                        state_of(v, word, bit1);
-                        keep = (bits[word] & (bit1 << 1)) != 0;
-                    }
-                    const uint64_t m = __ballot(keep);
-                    if (keep) dst[at2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
-                    at2 += (uint32_t)__popcll(m);
-                });
-            }
-            if (lane == 0) {
-                const bool large = n2 > kBigStage;
-                const uint32_t at = atomicAdd(&ws.midCount[large ? 12 : 10], 1u);
-                (large ? outLarge : outSmall)[at] = make_uint4(q, poolAt, n2 | (nent << 16), maxWin);
-            }
-        }
+        if (!fallback) sliceUsed += n2;
         wave_lds_sync();
     }
 }
@@ -2667,7 +2647,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
 template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
 __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
-                                                               uint32_t listIdx, uint32_t countIdx)
+                                                               uint32_t minN2)
 {
     constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
     __shared__ uint64_t keyS[WAVES][kSlots];
@@ -2677,16 +2657,19 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
     uint64_t* keys = keyS[wave];
     uint32_t* cnts = cntS[wave];
     BigTables& T = tabS[wave];
-    const uint32_t total = ws.midCount[countIdx];
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)listIdx * b.n;
+    // the records big_filter_kernel left (list 7, one per query of work list 6); this instance takes the filtered lists that fit its
+    // table: n2 in (minN2, kList]
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
-    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0xFFFFu, 0); };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
     uint4 rec = load_rec(w0);
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, n2 = rec.z & 0xFFFFu, nent = rec.z >> 16, maxWin = rec.w;
         const uint64_t* __restrict__ src = ws.bigPool + rec.y;
         rec = load_rec(w + nWaves);
+        if (n2 > kList || n2 <= minN2) continue;
         {
             uint4* k4 = reinterpret_cast<uint4*>(keys);
             uint4* c4 = reinterpret_cast<uint4*>(cnts);
@@ -2789,19 +2772,20 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
 {
     if (b.n == 0) return;
     mc_candidate_dev* c = (mc_candidate_dev*)cands;
-    // persistent grids.  stage 0: the filter; 1: counting of filtered lists up to 512 (work list 7); 2: up to 1024 (work list 8)
+    // persistent grids.  stage 0: the filter; 1: counting of filtered lists up to 512; 2: 513 .. 1024
     if (stage == 0) {
-        hipLaunchKernelGGL((big_filter_kernel<4>), dim3(std::min<uint32_t>(256 * 4, (b.n + 3) / 4)), dim3(256), 0, st, b, tab, ws);
+        hipLaunchKernelGGL((big_filter_kernel<4>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 1) {
         const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 3) / 4);
-        if (taxkey) hipLaunchKernelGGL((big_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 7u, 10u);
-        else        hipLaunchKernelGGL((big_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 7u, 10u);
+        if (taxkey) hipLaunchKernelGGL((big_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+        else        hipLaunchKernelGGL((big_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
     } else {
         const uint32_t grid = std::min<uint32_t>(256 * 2, (b.n + 1) / 2);
-        if (taxkey) hipLaunchKernelGGL((big_count_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 8u, 12u);
-        else        hipLaunchKernelGGL((big_count_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 8u, 12u);
+        if (taxkey) hipLaunchKernelGGL((big_count_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
+        else        hipLaunchKernelGGL((big_count_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
     }
 }
+uint32_t big_filter_grid(uint32_t n) { return std::min<uint32_t>(256 * 5, (n + 3) / 4); }
 
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands,
                        hipStream_t st)

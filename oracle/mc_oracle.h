@@ -67,6 +67,10 @@ double mco_query_many(void* db, const char* seqs, const uint64_t* offs, uint64_t
 void* mco_db_build(uint32_t k, uint32_t s, uint32_t w, uint32_t stride, uint32_t maxLocs, int targetBytes,
                    uint32_t numTargets, const uint32_t* lengths, void (*gen)(void*, uint32_t, char*), void* user,
                    const uint32_t* wanted, uint64_t nWanted, const int64_t* lineage, int threads, uint64_t* targetWindowsOut);
+/* the same; every thread takes `claim` consecutive targets at a time (lets a generator reuse work between neighbouring targets) */
+void* mco_db_build_claim(uint32_t k, uint32_t s, uint32_t w, uint32_t stride, uint32_t maxLocs, int targetBytes,
+                         uint32_t numTargets, const uint32_t* lengths, void (*gen)(void*, uint32_t, char*), void* user,
+                         const uint32_t* wanted, uint64_t nWanted, const int64_t* lineage, int threads, uint32_t claim, uint64_t* targetWindowsOut);
 
 #ifdef __cplusplus
 }

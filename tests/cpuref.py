@@ -70,9 +70,9 @@ class CpuRef:
             self.lib.mco_db_lookup.restype = C.c_uint32
             self.lib.mco_db_lookup.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
 
-            self.lib.mco_db_build.restype = C.c_void_p
-            self.lib.mco_db_build.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+            self.lib.mco_db_build_claim.restype = C.c_void_p
+            self.lib.mco_db_build_claim.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
             self.lib.mco_db_part_arrays.restype = C.c_uint64
             self.lib.mco_db_part_arrays.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_void_p)] * 4
 
@@ -81,7 +81,7 @@ class CpuRef:
 
     def build_db(self, lengths: np.ndarray, gen_addr: int, gen_user: int, wanted: np.ndarray | None = None,
                  lineage: np.ndarray | None = None, threads: int = 1, k=16, s=16, w=127, stride=112, max_locs=254,
-                 target_bytes=4) -> "CpuDb":
+                 target_bytes=4, claim: int = 1) -> "CpuDb":
         """The oracle's restatement of the database BUILD (mco_db_build), optionally restricted to the features in `wanted`.
         gen_addr = address of  void gen(void* user, uint32_t target, char* dst)  which writes target `target` (lengths[target]
         characters); a ctypes CFUNCTYPE object or a C function of another library (metacache_amd/synth)."""
@@ -90,9 +90,9 @@ class CpuRef:
         w_arr = None if wanted is None else np.ascontiguousarray(wanted, dtype=np.uint32)
         lin = None if lineage is None else np.ascontiguousarray(lineage, dtype=np.int64)
         tw = np.zeros(len(lengths), dtype=np.uint64)
-        h = self.lib.mco_db_build(k, s, w, stride, max_locs, target_bytes, len(lengths), _ptr(lengths), gen_addr, gen_user,
-                                  None if w_arr is None else _ptr(w_arr), 0 if w_arr is None else len(w_arr),
-                                  None if lin is None else _ptr(lin), threads, _ptr(tw))
+        h = self.lib.mco_db_build_claim(k, s, w, stride, max_locs, target_bytes, len(lengths), _ptr(lengths), gen_addr, gen_user,
+                                        None if w_arr is None else _ptr(w_arr), 0 if w_arr is None else len(w_arr),
+                                        None if lin is None else _ptr(lin), threads, claim, _ptr(tw))
         if not h:
             raise RuntimeError("mco_db_build failed")
         db = CpuDb(self, h)

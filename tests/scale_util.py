@@ -18,9 +18,26 @@ def oracle_database(spec: "synthdb.Phylogeny", wanted_features: np.ndarray | Non
         lin = np.zeros((n, 21), dtype=np.int64)
         lin[:, 4] = 1000 + spec.species
         lin[:, 6] = 2_000_000 + spec.genus
-    db = cpuref.oracle().build_db(T["length"], cs.target_callback(), T.ctypes.data, wanted=wanted_features, lineage=lin, threads=threads, **sk)
+    # a thread takes whole genera (consecutive targets with one ancestor): the generator then derives species and strains from cached codes
+    g = spec.genus
+    claim = int(np.bincount(g).max()) if len(g) else 1
+    db = cpuref.oracle().build_db(T["length"], cs.target_callback(), T.ctypes.data, wanted=wanted_features, lineage=lin, threads=threads,
+                                  claim=claim, **sk)
     db._keep = (cs, T)
     return db
+
+
+def effective_cpus() -> int:
+    """host threads worth using: the cgroup CPU quota where there is one (the GPU boxes show 256 CPUs and grant 16), else the CPU count"""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(round(int(q) / int(p)))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def sample_features(reads: list[bytes]) -> np.ndarray:
