@@ -206,8 +206,7 @@ public:
     // record starts = lines beginning with '>' (FASTA) or '@' header lines of 4-line FASTQ records; found by all threads
     void index(unsigned threads)
     {
-        size_t first = 0;                                                         // sequence_io.cpp:168-173: skip to the first '>' / '@' line
-        while (first < size_ && data_[first] != '>' && data_[first] != '@') first = next_line(first);
+        const size_t first = skip_stray(0);                                       // sequence_io.cpp:168-173: skip to the first '>' / '@' line
         if (first >= size_) return;
         fastq_ = data_[first] == '@';
         threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, size_ / (1u << 22) + 1));
@@ -217,18 +216,21 @@ public:
         for (unsigned t = 0; t < threads; ++t)
             pool.emplace_back([&, t] { scan(first + t * span, std::min(size_, first + (t + 1) * span), found[t]); });
         for (auto& th : pool) th.join();
+        if (irregular_.load()) { scan_exact(first); return; }
         for (auto& v : found) starts_.insert(starts_.end(), v.begin(), v.end());
     }
-    size_t records() const { return starts_.size(); }
+    size_t records() const { return exact_ ? recs_.size() : starts_.size(); }
 
     // sequence_reader::read_next: header without the marker, sequence lines joined ('scratch' only for multi-line records)
     void record(size_t i, View& header, View& seq, std::string& scratch) const
     {
-        const size_t b = starts_[i], e = i + 1 < starts_.size() ? starts_[i + 1] : size_;
+        size_t b, e;
+        if (exact_) { b = recs_[i].start; e = recs_[i].seqEnd; }
+        else { b = starts_[i]; e = i + 1 < starts_.size() ? starts_[i + 1] : size_; }
         size_t eol = line_end(b, e);
         header = trimmed(b + 1, eol);
         size_t p = std::min(eol + 1, e);
-        if (fastq_) { seq = trimmed(p, line_end(p, e)); return; }
+        if (fastq_ && !exact_) { seq = trimmed(p, line_end(p, e)); return; }
         seq = View{};
         bool multi = false;
         while (p < e) {
@@ -253,7 +255,11 @@ private:
         const size_t l2 = next_line(next_line(p));
         return l2 < size_ && data_[l2] == '+';
     }
-    void scan(size_t lo, size_t hi, std::vector<uint64_t>& out) const
+    // The fast scans below assume well-formed input: FASTA without lines that begin with '+', FASTQ as strict 4-line records.
+    // Anything else (sequences over several lines in FASTQ, stray lines, records of both kinds in one file) is what the reference's
+    // reader handles with ONE sequential state machine (sequence_reader::read_next, sequence_io.cpp:160-236): a scan that meets such
+    // input raises irregular_, and index() repeats the job with scan_exact(), which restates that machine line by line.
+    void scan(size_t lo, size_t hi, std::vector<uint64_t>& out)
     {
         if (!fastq_) {
             for (size_t p = lo; p < hi;) {
@@ -263,6 +269,13 @@ private:
                 if (q == 0 || data_[q - 1] == '\n') out.push_back(q);
                 p = q + 1;
             }
+            for (size_t p = lo; p < hi;) {                                         // a line that begins with '+' ends a record there
+                const void* g = memchr(data_ + p, '+', hi - p);
+                if (!g) break;
+                const size_t q = (size_t)((const char*)g - data_);
+                if (q == 0 || data_[q - 1] == '\n') { irregular_.store(true); return; }
+                p = q + 1;
+            }
             return;
         }
         size_t p = lo;
@@ -270,10 +283,45 @@ private:
         while (p < hi && !fastq_header_at(p)) p = next_line(p);                   // an '@' line whose line+2 starts with '+' is a header
         while (p < hi) {
             out.push_back(p);
-            p = next_line(next_line(next_line(next_line(p))));
-            while (p < size_ && data_[p] != '@') p = next_line(p);                // blank lines between records
+            const size_t l1 = next_line(p), l2 = next_line(l1), l3 = next_line(l2);
+            // strict record: header, ONE non-empty sequence line that is not a marker line, '+' line, quality line
+            if (l1 >= size_ || data_[l1] == '+' || data_[l1] == '>' || data_[l1] == '\n' || data_[l1] == '\r' || l2 >= size_ || data_[l2] != '+') {
+                if (l1 < size_) { irregular_.store(true); return; }
+            }
+            p = next_line(l3);
+            if (p < size_ && data_[p] != '@') { irregular_.store(true); return; } // stray lines, FASTA records: the exact scan decides
         }
     }
+    // sequence_reader::read_next restated: a record begins at the next line that starts with '>' or '@'; its sequence is every
+    // non-empty line up to a line that starts with '>' or '+'; after a '+' line exactly one more line (the qualities) is dropped.
+    void scan_exact(size_t first)
+    {
+        exact_ = true;
+        starts_.clear();
+        size_t p = first;
+        while (p < size_) {
+            p = skip_stray(p);
+            if (p >= size_) break;
+            Rec r; r.start = p;
+            p = next_line(p);
+            while (p < size_ && data_[p] != '>' && data_[p] != '+') p = next_line(p);   // empty lines are skipped when the record is read
+            r.seqEnd = p;
+            recs_.push_back(r);
+            if (p < size_ && data_[p] == '+') p = next_line(next_line(p));          // '+' line and ONE quality line
+        }
+    }
+    // lines that do not begin a record are dropped (read_next :168-173).  Mirrored detail: the reader takes a line's first character
+    // and then skips "the rest of the line" -- for an EMPTY line the character it took was the newline itself, so the skip swallows
+    // the FOLLOWING line, whatever it holds (a record header after a blank stray line is lost).
+    size_t skip_stray(size_t p) const
+    {
+        while (p < size_ && data_[p] != '>' && data_[p] != '@') p = data_[p] == '\n' ? next_line(p + 1) : next_line(p);
+        return p;
+    }
+    struct Rec { size_t start, seqEnd; };
+    bool exact_ = false;
+    std::atomic<bool> irregular_{false};
+    std::vector<Rec> recs_;
     int fd_ = -1;
     const char* data_ = nullptr;
     size_t size_ = 0;

@@ -62,6 +62,11 @@ CASES = {
     "ground_truth": (["cli_truth.fa"], ["-ground-truth", "-taxids"]),
     "precision": (["cli_truth.fa"], ["-precision", "-mapped-only", "-lowest", "species"]),
     "precision_truth_lineage": (["cli_truth.fa"], ["-precision", "-ground-truth", "-lineage", "-separate-cols", "-tophits"]),
+    # input the strict 4-line / no-'+' fast scans cannot take: the reader's sequential state machine decides (sequence_io.cpp:160-236)
+    "fastq_irregular": (["cli_irregular.fq"], ["-queryids", "-tophits"]),
+    "fastq_irregular_pairseq": (["cli_irregular.fq"], ["-pairseq", "-queryids"]),
+    "fasta_plus_lines": (["cli_irregular.fa"], ["-queryids", "-tophits"]),
+    "irregular_with_regular": (["cli_irregular.fa", "cli_pairs.fq", "cli_irregular.fq"], ["-queryids"]),
     "reference_test_matrix": (["cli_truth.fa"], ["-mapped-only", "-precision", "-ground-truth", "-tophits", "-allhits", "-abundances", "-abundance-per", "species"]),
 }
 
@@ -135,6 +140,40 @@ def main():
         for n in range(120):
             for m, s in ((1, p1[n]), (2, p2[n])):
                 f.write(f"@pair{n:03d}/{m} len={len(s)}\n{s.decode()}\n+\n{'I' * len(s)}\n")
+    with open(os.path.join(HERE, "cli_irregular.fq"), "w") as f:
+        for n in range(60):
+            sq = single[n + 700].decode()
+            kind = n % 10
+            if kind == 0:                                                           # sequence over three lines
+                f.write(f"@irr{n:02d} multi\n{sq[:50]}\n{sq[50:100]}\n{sq[100:]}\n+\n{'I' * len(sq)}\n")
+            elif kind == 1:                                                         # blank line inside the sequence
+                f.write(f"@irr{n:02d} blank\n{sq[:70]}\n\n{sq[70:]}\n+irr{n:02d}\n{'F' * len(sq)}\n")
+            elif kind == 2:                                                         # qualities over two lines: the second one is a stray line
+                f.write(f"@irr{n:02d} q2\n{sq}\n+\n{'I' * 75}\n{'I' * 75}\n")
+            elif kind == 3:                                                         # stray lines between records
+                f.write(f"stray line\n\n@irr{n:02d} stray\n{sq}\n+\n{'I' * len(sq)}\n# another one\n")
+            elif kind == 4:                                                         # a FASTA record among FASTQ records, two lines
+                f.write(f">irr{n:02d} fasta\n{sq[:80]}\n{sq[80:]}\n")
+            elif kind == 5:                                                         # no sequence at all
+                f.write(f"@irr{n:02d} empty\n+\n\n")
+            elif kind == 6:                                                         # quality line that begins with '@' followed by a strict record
+                f.write(f"@irr{n:02d} atq\n{sq}\n+\n@{'I' * (len(sq) - 1)}\n")
+            elif kind == 7:                                                         # Windows line ends
+                f.write(f"@irr{n:02d} crlf\r\n{sq}\r\n+\r\n{'I' * len(sq)}\r\n")
+            else:
+                f.write(f"@irr{n:02d} plain\n{sq}\n+\n{'I' * len(sq)}\n")
+        f.write(f"@irr_last no quality, no newline\n{single[777].decode()}")
+    with open(os.path.join(HERE, "cli_irregular.fa"), "w") as f:
+        for n in range(40):
+            sq = single[n + 800].decode()
+            if n % 8 == 3:                                                          # a '+' line ends the record, the line after it is dropped
+                f.write(f">pl{n:02d} plus\n{sq[:90]}\n+\n{sq[90:]}\n")
+            elif n % 8 == 5:                                                        # FASTQ record inside a FASTA file
+                f.write(f"@pl{n:02d} fastq\n{sq}\n+\n{'I' * len(sq)}\n")
+            elif n % 8 == 6:                                                        # sequence line that begins with '@' is data
+                f.write(f">pl{n:02d} at\n{sq[:60]}\n@{sq[60:]}\n")
+            else:
+                f.write(f">pl{n:02d}\n{wrap(single[n + 800], 70)}\n")
     for name, mates in (("cli_p1.fa", p1), ("cli_p2.fa", p2)):
         with open(os.path.join(HERE, name), "w") as f:
             for n in range(120):
