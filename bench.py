@@ -108,6 +108,32 @@ def measured_traffic(kernel_timer_name: str, tag: str):
     return None, None
 
 
+def gather_peak(gib: float):
+    """the box's random-access peak (tools/gather_peak.hip): 64-byte requests per second for the three access shapes of the path, on
+    a scratch buffer of `gib` GiB that is freed again before the database is built"""
+    import ctypes
+    from metacache_amd import build
+    lib = ctypes.CDLL(build.build_gather_peak())
+    lib.mcg_gather_peak.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]
+    r = (ctypes.c_double * 3)()
+    if lib.mcg_gather_peak(int(gib * (1 << 30)), r) != 0:
+        return None
+    return {"buffer_GiB": gib, "lane_private_64B": r[0], "quad_64B": r[1], "wave_512B_list": r[2]}
+
+
+def measured_requests(kernel_timer_name: str, tag: str):
+    """TCC_EA0_RDREQ of the dominant kernel per launch from the committed PMC summary (64-byte requests, profiles/r01_fetch_calibration.md)"""
+    import csv
+    names = PMC_NAMES.get(kernel_timer_name, ())
+    fn = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
+    if not os.path.exists(fn):
+        return None
+    for r in csv.DictReader(open(fn)):
+        if r["kernel"] in names and r["counter"] == "TCC_EA0_RDREQ_sum":
+            return float(r["mean_per_dispatch"])
+    return None
+
+
 def algorithmic_bytes_per_read(F: float, H: float, K: int, V: int) -> float:
     """ceil(L/4) + ceil(L/8) + 12 F + V H + 16 K"""
     return (READ_LEN + 3) // 4 + (READ_LEN + 7) // 8 + 12.0 * F + V * H + 16.0 * K
@@ -127,7 +153,7 @@ def thread_sweep(run, n_reads: int, budget_s: float, max_threads: int):
     probe_n = min(n_reads, 2000)
     t1, _ = run(probe_n, 1)
     rate1 = probe_n / max(t1, 1e-9)
-    cands = [t for t in (1, 8, 32, 64, 128, 256) if t <= max_threads]
+    cands = [t for t in (1, 8, 16, 32, 64, 128, 256) if t <= max_threads]
     per = budget_s / max(len(cands), 1)
     for t in cands:
         n = int(min(n_reads, max(2000 * t, rate1 * min(t, 64) * per)))
@@ -152,12 +178,16 @@ def cpu_leg_config1(dbname, reads_host, gpu_cands, K, budget_s):
         offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(READ_LEN)
         return db.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
 
-    best, bt, sweep = thread_sweep(run, n_total, budget_s * 0.6, os.cpu_count() or 1)
+    import scale_util
+    eff = scale_util.effective_cpus()                         # cgroup quota: more threads than that only take turns
+    best, bt, sweep = thread_sweep(run, n_total, budget_s * 0.6, min(os.cpu_count() or 1, 4 * eff))
     n = int(min(n_total, max(100_000, best * 1e6 / 60.0 * budget_s * 0.4)))
     t, cands = run(n, bt)
     db.close()
     return ({"value": round(max(best, n / t * 60 / 1e6), 2), "unit": "Mreads/min", "cores": bt, "kind": kind, "thread_sweep": sweep,
-             "sample": f"{n} reads of the same workload (batch 0) on {bt} host threads (best of the sweep), database files written by this repo"},
+             "host_cpus_granted": eff,
+             "sample": f"{n} reads of the same workload (batch 0) on {bt} host threads (best of the sweep; the box grants {eff} CPUs), "
+                       "database files written by this repo"},
             {"checked": n, "mismatches": count_mismatches(gpu_cands, cands), "against": kind})
 
 
@@ -166,7 +196,8 @@ def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s):
     loaded single-threaded: minutes), but a read sample only ever looks at the buckets of ITS features: the C oracle builds exactly
     those from the same collection (mco_db_build: its own restatement of the database build) and classifies the sample."""
     import scale_util
-    threads = os.cpu_count() or 1
+    eff = scale_util.effective_cpus()                         # cgroup quota (the GPU boxes show 256 CPUs and grant 16)
+    threads = min(os.cpu_count() or 1, 2 * eff)
     n = min(n_parity, reads_host.shape[0])
     t0 = time.time()
     wanted = scale_util.sample_features([reads_host[i, :READ_LEN].tobytes() for i in range(n)])
@@ -178,13 +209,13 @@ def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s):
         offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(READ_LEN)
         return odb.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=th)
 
-    t, cands = run(n, min(threads, 64))
+    t, cands = run(n, threads)
     mism = count_mismatches(gpu_cands, cands)
-    best, bt, sweep = thread_sweep(run, n, budget_s, threads)
+    best, bt, sweep = thread_sweep(run, n, budget_s, min(os.cpu_count() or 1, 4 * eff))
     info = odb.info()
     odb.close()
-    return ({"value": round(best, 2), "unit": "Mreads/min", "cores": bt, "kind": "port", "thread_sweep": sweep,
-             "sample": f"{n} reads of the same workload (batch 0); C oracle on {bt} host threads (best of the sweep) against the buckets of the "
+    return ({"value": round(best, 2), "unit": "Mreads/min", "cores": bt, "kind": "port", "thread_sweep": sweep, "host_cpus_granted": eff,
+             "sample": f"{n} reads of the same workload (batch 0); C oracle on {bt} host threads (best of the sweep; the box grants {eff} CPUs) against the buckets of the "
                        f"sample's {len(wanted)} features ({info[7]} locations), which it built itself from the same collection in {build_s:.0f} s "
                        f"on {threads} threads; the reference itself cannot load a table of this size inside the budget"},
             {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
@@ -205,6 +236,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip both checker legs)")
     ap.add_argument("--parity-reads", type=int, default=200_000, help="configs[2]: reads checked against the oracle")
     ap.add_argument("--load-factor", type=float, default=0.0, help="0 = 0.3 for configs[1], 0.5 for configs[2]")
+    ap.add_argument("--gather-gib", type=float, default=64.0, help="scratch buffer of the random-access microbenchmark (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
     args = ap.parse_args()
 
@@ -221,6 +253,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    peak = gather_peak(args.gather_gib) if rank == 0 and args.gather_gib > 0 else None
     K = args.maxcand
     cfg = args.config
     B = args.batch or (5_000_000 if cfg == 2 else 10_000_000)
@@ -363,6 +396,20 @@ def main():
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3),
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
+        # second roofline: 64-byte read requests per second of the dominant kernel against the box's measured random-access
+        # peak for that kernel's access shape.  Requests per launch: TCC_EA0_RDREQ of the committed PMC pass (same batch size only).
+        req = measured_requests(dom, pmc_tag)
+        shape = "wave_512B_list" if dom.startswith("big_") or dom.startswith("hash_") or dom.startswith("mid_") else \
+                ("quad_64B" if db_info[7] > 2_000_000_000 else "lane_private_64B")
+        if peak is not None:
+            ra = {"shape": shape, "peak_requests_per_s": round(peak[shape]), "peak_all_shapes": {k: round(v) if k != "buffer_GiB" else v for k, v in peak.items()}}
+            if req is not None:
+                ra["requests_per_launch"] = req
+                ra["requests_per_s"] = round(req / (dom_ms * 1e-3))
+                ra["frac"] = round(ra["requests_per_s"] / max(peak[shape], 1.0), 4)
+            else:
+                ra["requests_per_s"] = None; ra["frac"] = None
+            result["roofline"]["random_access"] = ra
         if world == 1 and args.cpu_seconds > 0:
             step(0)
             drain()

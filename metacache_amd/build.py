@@ -102,7 +102,7 @@ def build_gather_peak(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     src = os.path.join(ROOT, "tools", "gather_peak.hip")
     if force or _stale(GATHER_LIB, [src]):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-Wno-unused-result", "-o", GATHER_LIB, src]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value", "-o", GATHER_LIB, src]
         if verbose:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -105,7 +105,7 @@ struct mc_ctx {
     // single-part tables are built on the device (table_build.hip): staging for one batch of the file
     mcamd::DevBuf bLdKeys, bLdSizes, bLdVals, bLdFileSz, bLdStoreSz, bLdFileOff, bLdStoreOff, bLdScan, bLdCounters;
     bool useLanePath = true;               // lane-parallel fast path for short reads (off: wave kernels only)
-    uint32_t bigMin = 1024;                // location lists longer than this take big_cands_kernel (filter before counting); MC_BIG_MIN
+    uint32_t bigMin = 256;                 // location lists longer than this take big_cands_kernel (filter before counting); MC_BIG_MIN
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
     bool fuseLane = false;                 // sketching + probing of the lane path in ONE kernel (MC_LANE_FUSION=1); measured
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on

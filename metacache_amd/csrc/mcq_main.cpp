@@ -31,6 +31,7 @@ struct Options {
     std::vector<std::string> infiles;
     int lowest = 0, highest = 19;                    // sequence .. domain (options.hpp:246-260)
     int hitsMin = 0; float hitsDiff = 1.0f;
+    float covPercentile = 0.0f;          // -cov-percentile (options.cpp:918-930, :1313)
     uint64_t maxCand = 2, insertMax = 0;
     enum Pairing { unpaired, files, sequences } pairing = unpaired;
     bool tophits = false, allhits = false, locations = false, queryIds = false, lineage = false, separateCols = false;
@@ -40,6 +41,7 @@ struct Options {
     std::string comment = "# ", none = "--", column = "\t|\t", taxSep = ",", rankSuffix = ":", idPrefix = "(", idSuffix = ")";
     bool showQueryParams = true, showSummary = true, showErrors = true, splitOut = false;
     uint32_t sketchlen = 0, winlen = 0, winstride = 0, batchSize = 1u << 16;
+    uint32_t refBatchSize = 0;           // -batch-size as given (the reference's batches matter for -cov-percentile)
     int maxLocs = -1, threads = 0;
     bool removeOverpopulated = false; float maxLoadFac = 0;
     uint64_t minReadLen = 0, maxReadLen = std::numeric_limits<uint64_t>::max();
@@ -78,6 +80,7 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-split-out" || a == "-splitout") { o.splitOut = true; o.outfile = need(i); }
         else if (a == "-lowest") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); o.lowest = r; }
         else if (a == "-highest") { int r = rank_from_name(need(i)); if (r < 0) throw std::runtime_error("unknown rank"); o.highest = r; }
+        else if (a == "-cov-percentile") { o.covPercentile = std::stof(need(i)); if (o.covPercentile > 1) o.covPercentile *= 0.01f; }
         else if (a == "-hitmin" || a == "-hit-min" || a == "-hits-min" || a == "-hitsmin") o.hitsMin = std::stoi(need(i));
         else if (a == "-hitdiff" || a == "-hit-diff" || a == "-hitsdiff" || a == "-hits-diff") o.hitsDiff = std::stof(need(i));
         else if (a == "-maxcand" || a == "-max-cand") o.maxCand = std::stoull(need(i));
@@ -118,7 +121,7 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-no-summary" || a == "-nosummary") o.showSummary = false;
         else if (a == "-no-err" || a == "-no-errors") o.showErrors = false;
         else if (a == "-threads") o.threads = std::stoi(need(i));
-        else if (a == "-batch-size" || a == "-batchsize") o.batchSize = (uint32_t)std::stoul(need(i));
+        else if (a == "-batch-size" || a == "-batchsize") { o.batchSize = (uint32_t)std::stoul(need(i)); o.refBatchSize = o.batchSize; }
         else throw std::runtime_error("unknown option '" + a + "'");
     }
     // process_query_options (options.cpp:1297-1366)
@@ -488,6 +491,12 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::map<uint32_t, double> counts;
             std::vector<Cover> covers;
         };
+        // -cov-percentile (map_queries_to_targets_default, classification.cpp:747-838): nothing is classified while the reads are
+        // queried; every read's candidates are kept, the targets are filtered by their coverage afterwards, and the reads are
+        // classified from the candidates that are left
+        const bool covMode = o.covPercentile > 0 && !merged;
+        struct Deferred { uint64_t id; View header; std::vector<Cand> cands; };
+        std::vector<std::vector<Deferred>> deferred(covMode ? batches.size() : 0);
         auto emit = [&](Acc& A, std::ostream& out, uint64_t id, View header, const std::vector<Cand>& cands, const mc_location* hits, uint64_t nhits) {
             bool isTarget; uint32_t tgt;
             const uint32_t best = classify(o, tx, cands, isTarget, tgt);
@@ -521,7 +530,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 }
             }
             if (taxCountsWanted && best) ++A.counts[best];           // classify_and_evaluate, classification.cpp:552-554
-            if (o.hitsPerRef)                                        // matches_per_target::insert (matches_per_target.hpp:100-110)
+            if (o.hitsPerRef && !covMode)                            // matches_per_target::insert (matches_per_target.hpp:100-110)
                 for (const Cand& c : cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) A.covers.push_back(Cover{c.tgt, id, c.beg, c.end, c.hits});
             if (o.mapView == Options::mv_none || (o.mapView == Options::mv_mapped && !best)) return;
             if (o.queryIds) out << id << o.column;
@@ -619,7 +628,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                             }
                             cands.push_back(x);
                         }
-                        emit(A, out, m.id, m.header, cands, o.allhits ? r.hits + r.hit_offsets[i] : nullptr, o.allhits ? r.hit_offsets[i + 1] - r.hit_offsets[i] : 0);
+                        if (covMode) deferred[b].push_back(Deferred{m.id, m.header, cands});
+                        else emit(A, out, m.id, m.header, cands, o.allhits ? r.hits + r.hit_offsets[i] : nullptr, o.allhits ? r.hit_offsets[i + 1] - r.hit_offsets[i] : 0);
                     }
                     mc_batch_clear(ctx, slot);
                     if (profile) { nsParse += tp1 - tp0; nsSubmit += tp2 - tp1; nsWait += tp3 - tp2; nsClassify += now_ns() - tp3; }
@@ -636,6 +646,70 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (auto& t : pool) t.join();
         }
         if (failed) throw std::runtime_error(firstError);
+        if (covMode) {
+            // The reference keeps (target -> candidates) in std::unordered_map objects: one per batch of -batch-size reads (4096 unless
+            // given, options.hpp:232; batches do not span input files), merged into a global one batch after batch
+            // (matches_per_target.hpp:100-125).  filter_targets_by_coverage (classification.cpp:591-634) then walks the global map
+            // in ITS iteration order, sums float coverages in that order, std::sorts them and erases targets from the low end: the order
+            // of equal coverages and the rounding of the sums come from the containers.  Same containers, same insertion sequence here
+            // (the reference's -threads 1 order), so the same targets go.
+            const size_t refBatch = o.refBatchSize ? o.refBatchSize : 4096;
+            std::unordered_map<uint32_t, std::vector<Cover>> tgtMatches;
+            {
+                std::unordered_map<uint32_t, std::vector<Cover>> batchMap;
+                size_t inBatch = 0, curFile = (size_t)-1;
+                auto flush = [&]() {
+                    for (auto& m : batchMap) { auto& t = tgtMatches[m.first]; t.insert(t.end(), m.second.begin(), m.second.end()); }
+                    batchMap = std::unordered_map<uint32_t, std::vector<Cover>>();
+                    inBatch = 0;
+                };
+                for (size_t b = 0; b < batches.size(); ++b) {
+                    if (batches[b].f1 != curFile || batches[b].qBeg == 0) { if (inBatch) flush(); curFile = batches[b].f1; }
+                    for (const Deferred& d : deferred[b]) {
+                        for (const Cand& c : d.cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) batchMap[c.tgt].push_back(Cover{c.tgt, d.id, c.beg, c.end, c.hits});
+                        if (++inBatch == refBatch) flush();
+                    }
+                }
+                if (inBatch) flush();
+            }
+            {
+                using CovP = std::pair<uint32_t, float>;
+                std::vector<CovP> cov;
+                cov.reserve(tgtMatches.size());
+                float sum = 0;
+                for (const auto& m : tgtMatches) {
+                    const Lineage lin = tx.target_ranks(m.first);
+                    const uint32_t targetSize = tx.taxon(lin[0]) ? (uint32_t)tx.taxon(lin[0])->windows : 0u;
+                    std::unordered_set<uint32_t> hitWindows;
+                    for (const Cover& c : m.second) for (uint32_t w = c.beg; w <= c.end; ++w) hitWindows.emplace(w);
+                    const float covP = float(hitWindows.size()) / targetSize;
+                    sum += covP;
+                    cov.emplace_back(m.first, covP);
+                }
+                std::sort(cov.begin(), cov.end(), [](CovP& a, CovP& b) { return a.second < b.second; });
+                float part = 0;
+                for (auto it = cov.begin(); it != cov.end(); ++it) {
+                    part += it->second;
+                    if (part > o.covPercentile * sum) break;
+                    tgtMatches.erase(it->first);
+                }
+            }
+            // redo_classification_batched: candidates of erased targets go, then classification and output as usual
+            Acc A;
+            std::ostringstream out;
+            std::vector<Cand> left;
+            for (size_t b = 0; b < batches.size(); ++b) {
+                for (const Deferred& d : deferred[b]) {
+                    left.clear();
+                    for (const Cand& c : d.cands) if (tgtMatches.find(c.tgt) != tgtMatches.end()) left.push_back(c);
+                    emit(A, out, d.id, d.header, left, nullptr, 0);
+                }
+                os << out.str();
+                out.str(std::string());
+            }
+            collect(A);
+            for (const auto& m : tgtMatches) covers.insert(covers.end(), m.second.begin(), m.second.end());
+        }
         if (merged) {                                                            // map_candidates_to_targets, classification.cpp:891-911
             Acc A;
             std::ostringstream out;

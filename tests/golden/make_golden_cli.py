@@ -67,6 +67,10 @@ CASES = {
     "fastq_irregular_pairseq": (["cli_irregular.fq"], ["-pairseq", "-queryids"]),
     "fasta_plus_lines": (["cli_irregular.fa"], ["-queryids", "-tophits"]),
     "irregular_with_regular": (["cli_irregular.fa", "cli_pairs.fq", "cli_irregular.fq"], ["-queryids"]),
+    # -cov-percentile: targets with the lowest coverage are dropped, the reads re-classified (classification.cpp:591-634, :747-838)
+    "cov_percentile": (["cli_reads.fa"], ["-cov-percentile", "0.3", "-tophits", "-queryids"]),
+    "cov_percentile_pct_hits_per_ref": (["cli_reads.fa", "cli_pairs.fq"], ["-cov-percentile", "55", "-hits-per-ref", "-maxcand", "3", "-batch-size", "100"]),
+    "cov_percentile_species": (["cli_pairs.fq"], ["-pairseq", "-cov-percentile", "0.5", "-lowest", "species", "-abundances", "-tophits"]),
     "reference_test_matrix": (["cli_truth.fa"], ["-mapped-only", "-precision", "-ground-truth", "-tophits", "-allhits", "-abundances", "-abundance-per", "species"]),
 }
 

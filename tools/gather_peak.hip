@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4* __restrict__ t
         for (int u = 0; u < U; ++u) {
             const uint32_t id = SHAPE == 0 ? tid : SHAPE == 1 ? (tid >> 2) : (tid >> 6);
             const uint32_t h1 = mix32(id * 0x9E3779B1u + (it * U + u) * 0x85EBCA77u + 999u), h2 = mix32(h1 ^ 0x5bd1e995u);
-            const uint64_t r = (((uint64_t)h1 << 32) | h2) % nunits;
+            const uint64_t r = __umul64hi(((uint64_t)h1 << 32) | h2, nunits);            // uniform in [0, nunits), no division
             if (SHAPE == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[u][j] = tab[r * 4 + j];                      // unit = 64-byte bucket
