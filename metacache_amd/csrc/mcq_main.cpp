@@ -264,6 +264,44 @@ uint32_t classify(const Options& o, const Taxonomy& tx, const std::vector<Cand>&
 }
 
 // ---- database session: the loaded context is kept between jobs (interactive mode) as long as its load-time settings fit ----
+// Rows 9-10 on the host for ONE read's sorted location list: the reference's loop (for_all_contiguous_window_ranges,
+// candidate_generation.hpp:47-108) and its sorted insert without a limit (:172-231, same std:: calls so that equal hit counts fall
+// the same way).  Used when -maxcand 0 meets a read with more candidates than the device list holds.
+static void host_candidates(const mc_location* h, uint64_t n, uint32_t maxWin, const Taxonomy& tx, int lowest, std::vector<Cand>& top)
+{
+    top.clear();
+    auto greater = [](const Cand& a, const Cand& b) { return a.hits > b.hits; };
+    auto insert = [&](Cand c) {
+        c.tax = 0;
+        if (c.tgt < tx.numTargets) {
+            const uint32_t* lin = tx.targetLineages + (size_t)c.tgt * kNumRanks;
+            if (lowest > 0) { for (int rk = lowest; rk < kNumRanks; ++rk) if (lin[rk]) { c.tax = lin[rk]; break; } }
+            else c.tax = lin[0];
+        }
+        if (!c.tax) return;
+        if (lowest <= 0) { top.insert(std::upper_bound(top.begin(), top.end(), c, greater), c); return; }
+        auto i = std::find_if(top.begin(), top.end(), [&](const Cand& x) { return x.tax == c.tax; });
+        if (i != top.end()) { if (c.hits > i->hits) { *i = c; std::sort(top.begin(), i + 1, greater); } }
+        else top.insert(std::upper_bound(top.begin(), top.end(), c, greater), c);
+    };
+    if (n == 0) return;
+    uint64_t fst = 0;
+    uint32_t hits = 1;
+    Cand best{h[0].tgt, 1, h[0].win, h[0].win, 0};
+    for (uint64_t lst = 1; lst < n; ++lst) {
+        if (h[lst].tgt == best.tgt) {
+            ++hits;
+            while (fst != lst && (uint32_t)(h[lst].win - h[fst].win) >= maxWin) { --hits; ++fst; }
+            if (hits > best.hits) { best.hits = hits; best.beg = h[fst].win; best.end = h[lst].win; }
+        } else {
+            insert(best);
+            fst = lst; hits = 1;
+            best = Cand{h[lst].tgt, 1, h[lst].win, h[lst].win, 0};
+        }
+    }
+    insert(best);
+}
+
 struct Session {
     mc_ctx* ctx = nullptr;
     mc_config cfg{};
@@ -276,12 +314,19 @@ struct Session {
     BuiltDatabase* built = nullptr;                  // build+query: the table comes from the builder's device arrays, not from files
     std::vector<uint32_t> builtLineages;
 
+    static uint32_t unlimitedCap()
+    {
+        const char* e = std::getenv("MCQ_UNLIMITED_CAP");                       // tests: a small cap makes the host path run on toy data
+        return e ? (uint32_t)std::max(1, std::atoi(e)) : 256u;
+    }
     void open(const Options& o)
     {
         mc_config c; mc_config_default(&c);
         c.kmerlen = 0; c.sketchlen = o.sketchlen; c.winlen = o.winlen; c.winstride = o.winstride;
-        c.max_candidates = o.maxCand < 1 ? 256 : (uint32_t)std::min<uint64_t>(o.maxCand, 4096);
-        c.copy_allhits = o.allhits ? 1 : 0;
+        // -maxcand 0 = no limit (options.cpp:1315-1317): the device lists hold unlimitedCap() candidates; a read that fills its list gets
+        // its candidates from the HOST instead -- rows 9-10 over the read's sorted location list, which is copied back for that
+        c.max_candidates = o.maxCand < 1 ? unlimitedCap() : (uint32_t)std::min<uint64_t>(o.maxCand, 4096);
+        c.copy_allhits = (o.allhits || o.maxCand < 1) ? 1 : 0;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         threads = o.threads > 0 ? (unsigned)o.threads : hw;                     // options.hpp: numThreads defaults to all hardware threads
         workers = std::min(threads, 64u);                                      // one batch slot (pinned staging) per worker
@@ -477,6 +522,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     batches.push_back(Batch{f1, f2, q, std::min<size_t>(nsel, q + o.batchSize), idOffset, q == 0 ? prefix : std::string(), sel});
                     if (nsel == 0) break;
                 }
+                if (o.pairing == Options::sequences && nread == nq && nq > 0 && (files[f1]->records() & 1u)) --nread;   // (the half pair did not count)
                 idOffset += nread;                                               // reader.index(): records (pairs) consumed
             }
         }
@@ -569,7 +615,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 os.write(it->second.data(), (std::streamsize)it->second.size());
         };
         auto work = [&](unsigned slot) {
-            struct Meta { uint64_t id; View header; bool empty; };
+            struct Meta { uint64_t id; View header; bool empty; uint64_t len; };
             std::vector<Meta> metas;
             std::vector<Cand> cands;
             std::string scratch1, scratch2;
@@ -604,7 +650,10 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                             continue;
                         }
                         if (rc < 0) { fail(mc_last_error(ctx)); break; }
-                        metas.push_back(Meta{B.idBase + qi + 1, h1, h1.empty() || s1.empty()});
+                        // query id = the reader's index after the read (database_query.hpp:264); a last pair without its second
+                        // sequence does not advance the index (sequence_io.cpp:312-318), so it shares the id of the pair before it
+                        const bool halfPair = o.pairing == Options::sequences && 2 * qi + 1 >= files[B.f1]->records();
+                        metas.push_back(Meta{B.idBase + qi + (halfPair ? 0 : 1), h1, h1.empty() || s1.empty(), (uint64_t)s1.n + s2.n});
                     }
                     if (failed) break;
                     mc_results r;
@@ -627,6 +676,10 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                                 else x.tax = lin[0];
                             }
                             cands.push_back(x);
+                        }
+                        if (o.maxCand < 1 && cands.size() == r.max_candidates) {   // list full: there may be more candidates than it holds
+                            const uint32_t mw = (uint32_t)(2 + std::max<uint64_t>(m.len, o.insertMax) / dbStride);
+                            host_candidates(r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i], mw, tx, o.lowest, cands);
                         }
                         if (covMode) deferred[b].push_back(Deferred{m.id, m.header, cands});
                         else emit(A, out, m.id, m.header, cands, o.allhits ? r.hits + r.hit_offsets[i] : nullptr, o.allhits ? r.hit_offsets[i + 1] - r.hit_offsets[i] : 0);

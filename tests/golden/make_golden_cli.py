@@ -37,6 +37,7 @@ CASES = {
     "mapped_only_vote": (["cli_reads.fa"], ["-mapped-only", "-hitmin", "5", "-hitdiff", "0.5", "-maxcand", "4", "-tophits"]),
     "hitdiff_percent": (["cli_reads.fa"], ["-hitdiff", "80", "-maxcand", "3", "-lowest", "species", "-tophits", "-queryids"]),
     "maxcand_unlimited": (["cli_reads.fa"], ["-maxcand", "0", "-tophits", "-lowest", "subspecies"]),
+    "maxcand_unlimited_seq": (["cli_reads.fa", "cli_pairs.fq"], ["-maxcand", "0", "-tophits", "-queryids"]),
     "separator": (["cli_reads.fa"], ["-separator", ";", "-taxids", "-lineage", "-highest", "genus"]),
     "pairseq": (["cli_pairs.fq"], ["-pairseq", "-tophits", "-queryids"]),
     "pairseq_insert": (["cli_pairs.fq"], ["-pairseq", "-insertsize", "700", "-tophits", "-lowest", "species"]),

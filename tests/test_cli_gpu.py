@@ -121,6 +121,21 @@ def test_cli_matches_reference_output(case, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cap", ["1", "2", "5"])
+@pytest.mark.parametrize("case", ["maxcand_unlimited", "maxcand_unlimited_seq"])
+def test_cli_maxcand_unlimited_beyond_the_device_list(case, cap, tmp_path):
+    """-maxcand 0 = no limit: a read with more candidates than the device list holds (MCQ_UNLIMITED_CAP shrinks the list so that
+    the toy database reaches it) gets them from the host's rows 9-10 over its sorted location list -- same output as the reference."""
+    build.build_library()
+    c = CASES[case]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-threads", "1", "-out", str(out)]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600, env=dict(os.environ, MCQ_UNLIMITED_CAP=cap))
+    assert r.returncode == 0, r.stderr
+    _same(out.read_text().split("\n"), c["lines"], (case, cap))
+
+
+@pytest.mark.gpu
 def test_cli_small_batches_same_output(tmp_path):
     """-batch-size only changes how reads are grouped into device batches."""
     build.build_library()
