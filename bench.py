@@ -14,6 +14,12 @@ N > 1 (launched by torch.distributed.run, one rank per GPU), mode R: the databas
 rank processes its own reads (weak scaling) and the per-rank top-candidate lists are gathered to rank 0 over RCCL inside the
 timed region -- the hand-over to host-side taxonomy assignment.  No other collective: the path has no exchange step in this mode.
 
+`--mode P` / `--mode K` run the two sharded forms of the path instead: P = the targets dealt out round-robin into N parts,
+one part per rank, every rank classifies all reads of the step against its part, all-gather of the per-part top candidates, merge;
+K = ONE part whose features are key-sharded over the ranks, every rank looks all reads up in its shard, all-to-all of the partial
+location lists to the reads' owner ranks, union + candidates there (mc_candidates_from_partial_hits), gather to rank 0.
+`--pairs` = configs[3]'s reads: 2 x 150 bp pairs (fragment 300-500, seed 4100, maxWindowsInRange 4); a pair counts as 2 reads.
+
 Checker legs (rank 0, N = 1, after the timed region; oracle/ is loaded only here):
   parity        the C oracle builds the buckets of a read sample's features ITSELF from the same collection (mco_db_build) and
                 classifies the sample; every candidate is compared with the GPU's.  configs[1]: the reference (oracle/_ref) on the
@@ -191,7 +197,7 @@ def cpu_leg_config1(dbname, reads_host, gpu_cands, K, budget_s):
             {"checked": n, "mismatches": count_mismatches(gpu_cands, cands), "against": kind})
 
 
-def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s):
+def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s, mates_host=None):
     """configs[2]: a 100+ GB table is out of the checker's budget (the reference would need the whole database written to files and
     loaded single-threaded: minutes), but a read sample only ever looks at the buckets of ITS features: the C oracle builds exactly
     those from the same collection (mco_db_build: its own restatement of the database build) and classifies the sample."""
@@ -200,9 +206,29 @@ def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s):
     threads = min(os.cpu_count() or 1, 2 * eff)
     n = min(n_parity, reads_host.shape[0])
     t0 = time.time()
-    wanted = scale_util.sample_features([reads_host[i, :READ_LEN].tobytes() for i in range(n)])
+    sample = [reads_host[i, :READ_LEN].tobytes() for i in range(n)]
+    if mates_host is not None:
+        sample += [mates_host[i, :READ_LEN].tobytes() for i in range(n)]
+    wanted = scale_util.sample_features(sample)
     odb = scale_util.oracle_database(spec, wanted, threads=threads)
     build_s = time.time() - t0
+    if mates_host is not None:
+        # pairs: the oracle one pair at a time (its bulk entry takes single reads); the baseline value is then pairs x 2 per minute
+        t1 = time.time()
+        mism = 0
+        for i in range(n):
+            _, e = odb.query(sample[i], sample[n + i], K, 0, 0)
+            g = gpu_cands[i]
+            ok = all((g[j]["tgt"], g[j]["hits"], g[j]["beg"], g[j]["end"]) == (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]) if j < len(e)
+                     else g[j]["hits"] == 0 for j in range(K))
+            mism += 0 if ok else 1
+        el = time.time() - t1
+        info = odb.info()
+        odb.close()
+        return ({"value": round(2 * n / el * 60 / 1e6, 3), "unit": "Mreads/min", "cores": 1, "kind": "port", "host_cpus_granted": eff,
+                 "sample": f"{n} pairs of the same workload (batch 0), one host thread through the oracle's per-query entry (Python loop included); "
+                           f"buckets of the sample's {len(wanted)} features ({info[7]} locations) built by the oracle itself in {build_s:.0f} s"},
+                {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
 
     def run(m, th):
         seqs = np.ascontiguousarray(reads_host[:m, :READ_LEN]).reshape(-1)
@@ -237,6 +263,8 @@ def main():
     ap.add_argument("--parity-reads", type=int, default=200_000, help="configs[2]: reads checked against the oracle")
     ap.add_argument("--load-factor", type=float, default=0.0, help="0 = 0.3 for configs[1], 0.5 for configs[2]")
     ap.add_argument("--gather-gib", type=float, default=64.0, help="scratch buffer of the random-access microbenchmark (0 = skip)")
+    ap.add_argument("--mode", default="R", choices=("R", "P", "K"), help="configs[2]: R replicated table (default), P one part per rank, K key shards")
+    ap.add_argument("--pairs", action="store_true", help="configs[2]: 2 x 150 bp read pairs (configs[3]'s reads) instead of single reads")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
     args = ap.parse_args()
 
@@ -291,39 +319,70 @@ def main():
         est_pairs = spec.total_bases // 112 * 16
         shards = args.build_shards or max(1, int(np.ceil(est_pairs / 1.4e9)))
         say = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if rank == 0 else None
-        db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say)
+        mode = args.mode
+        part_sel = None
+        if mode == "P":                                        # part r = targets r, r + N, r + 2N, ... (round-robin like the reference's -parts)
+            part_sel = np.arange(rank, len(spec.targets), world)
+            pspec = spec.subset(part_sel)
+            pshards = max(1, int(np.ceil(pspec.total_bases // 112 * 16 / 1.4e9)))
+            db, build_info = synthdb.build_database(pspec, device=local, shards=pshards, max_candidates=K, max_load_factor=lf, report=say)
+        elif mode == "K":
+            kshards = max(1, int(np.ceil(shards / world)))
+            db, build_info = synthdb.build_database(spec, device=local, shards=kshards, key_shard=(rank, world), max_candidates=K, max_load_factor=lf,
+                                                    report=say)
+        else:
+            db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say)
         gen = synthdb.GpuSynth(local)
-        P = synthdb.read_params(spec, 3100)
+        P = synthdb.read_params(spec, 4100 if args.pairs else 3100, paired=args.pairs)
         assert P.row_bytes == PAD_LEN
-        batches = []
-        for s in range(nb):
-            t = torch.zeros(B * PAD_LEN, dtype=torch.uint8, device=dev)
-            gen.reads(spec, P, (rank * 64 + s) * B, B, t)
-            batches.append(t)
+        # modes P and K: every rank works on ALL reads of a step (N x B); mode R: on its own B
+        nloc = B * world if mode in ("P", "K") else B
+        batches, mates = [], []
+        for sidx in range(nb):
+            t = torch.zeros(nloc * PAD_LEN, dtype=torch.uint8, device=dev)
+            t2 = torch.zeros(nloc * PAD_LEN + 16, dtype=torch.uint8, device=dev) if args.pairs else None
+            first = sidx * nloc if mode in ("P", "K") else (rank * 64 + sidx) * B
+            gen.reads(spec, P, first, nloc, t, t2)
+            batches.append(t); mates.append(t2)
         V = 8
-        workload = (f"configs[2]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
-                    f"(genus>species>strain phylogeny, uint32 target ids, 1 partition{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
-                    f"{world * args.steps * B} synthetic 150 bp reads")
-        pmc_tag = "r02"
+        shape = "2 x 150 bp read pairs" if args.pairs else "150 bp reads"
+        how = {"R": "1 partition", "P": f"{world} partitions (targets round-robin), one per GPU", "K": f"1 partition key-sharded over {world} GPUs"}[mode]
+        workload = (f"configs[{3 if (args.pairs or mode != 'R') else 2}]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
+                    f"(genus>species>strain phylogeny, uint32 target ids, {how}{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
+                    f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
+        pmc_tag = "r02" if (mode == "R" and not args.pairs) else "r02m"
     build_s = time.time() - t0
     db_info = db.info()
 
-    qinfo = torch.zeros((B, 4), dtype=torch.int32, device=dev)
-    qinfo[:, 0] = torch.arange(B, device=dev, dtype=torch.int32) * PAD_LEN
+    mode = args.mode if cfg == 2 else "R"
+    pairs = bool(args.pairs) and cfg == 2
+    nloc = B * world if mode in ("P", "K") else B               # reads (pairs) this rank looks up per step
+    qinfo = torch.zeros((nloc, 4), dtype=torch.int32, device=dev)
+    qinfo[:, 0] = torch.arange(nloc, device=dev, dtype=torch.int32) * PAD_LEN
     qinfo[:, 1] = READ_LEN
     qinfo[:, 2] = qinfo[:, 0]
     slack = torch.zeros(16, dtype=torch.uint8, device=dev)
-    batches = [torch.cat([b, slack]) for b in batches]
-    max_win = db.max_windows_in_range(READ_LEN)              # = 3 for 150 bp
+    if pairs:
+        # one character buffer per batch: mate-1 rows, then mate-2 rows
+        batches = [torch.cat([b1, m2]) for b1, m2 in zip(batches, mates)]
+        qinfo[:, 2] = qinfo[:, 0] + nloc * PAD_LEN
+        qinfo[:, 3] = READ_LEN
+    else:
+        batches = [torch.cat([b, slack]) for b in batches]
+    nchars = nloc * PAD_LEN * (2 if pairs else 1)
+    max_win = db.max_windows_in_range(READ_LEN, READ_LEN if pairs else 0)      # 3 for a 150 bp read, 4 for a 2 x 150 pair
+    part_sel_t = torch.from_numpy(part_sel).to(dev).to(torch.int32) if (cfg == 2 and mode == "P") else None
     # N > 1: the per-rank candidate lists go to rank 0 over RCCL (north_star: "per-rank partial hit lists gathered over RCCL/xGMI
     # before host-side taxonomy assignment").  Two buffers per rank: the gather of batch i runs while batch i+1 is computed.
     dist_path = world > 1 or args.force_dist
     nbuf = 2 if dist_path else 1
-    out_bufs = [torch.zeros((B, K, 4), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    nout = B if mode in ("R", "K") else nloc                    # candidate rows this rank ends up with per step
+    out_bufs = [torch.zeros((nout, K, 4), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     out_cands = out_bufs[0]
-    recv = [[torch.zeros((B, K, 4), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(nbuf)] if dist_path and rank == 0 else None
+    recv = [[torch.zeros((B, K, 4), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(nbuf)] if dist_path and rank == 0 and mode != "P" else None
     works = [None] * nbuf
     torch.cuda.synchronize()
+    from metacache_amd.distributed import classify_key_sharded_device, classify_partitioned
 
     def finish(j: int):
         if works[j] is not None:
@@ -335,10 +394,21 @@ def main():
         b = batches[i % nb]
         j = i % nbuf
         finish(j)                                            # the gather that used this buffer two batches ago
-        res = db.query_device(b.data_ptr(), qinfo.data_ptr(), B, B * PAD_LEN, max_win_uniform=max_win)
-        db.copy_results(out_bufs[j].data_ptr(), res.cands, B * K * 16)
-        db.synchronize()
-        if dist_path:
+        if mode == "K":
+            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_allhits=True)
+            out_bufs[j].copy_(classify_key_sharded_device(db, res, nloc, K, max_win))   # all-to-all of the partial lists, union, rows 8-10
+            torch.cuda.current_stream().synchronize()
+        else:
+            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win)
+            db.copy_results(out_bufs[j].data_ptr(), res.cands, nloc * K * 16)
+            db.synchronize()
+        if mode == "P":
+            c = out_bufs[j]
+            live = c[:, :, 1] > 0                            # part-local target numbers -> numbers in the whole collection
+            c[:, :, 0] = torch.where(live, part_sel_t[c[:, :, 0].clamp(min=0, max=part_sel_t.numel() - 1).long()], c[:, :, 0])
+            out_bufs[j].copy_(classify_partitioned(c))       # all-gather + merge: every rank holds the merged lists
+            torch.cuda.current_stream().synchronize()
+        elif dist_path:
             works[j] = gather_candidates_async(out_bufs[j], recv[j] if recv is not None else None, dst=0)
         return res
 
@@ -373,13 +443,14 @@ def main():
     if rank == 0:
         kt = {k: db.timing_get(k) for k in KERNELS}
         st = db.last_batch_stats()                            # of the last timed batch
-        F, H = st["features"] / B, st["locations"] / B
+        per_read = 2 if pairs else 1                           # a pair counts as 2 reads (printing.cpp:605-608)
+        F, H = st["features"] / (nloc * per_read), st["locations"] / (nloc * per_read)
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
         dom = max((k for k in KERNELS if k not in ("plan", "scan")), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
-        achieved = bytes_per_read * B / (dom_ms * 1e-3) / 1e9
+        achieved = bytes_per_read * nloc * per_read / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom, pmc_tag)
-        total_reads = world * args.steps * B
+        total_reads = world * args.steps * B * per_read
         value = total_reads / elapsed * 60.0 / 1e6
         result = {
             "metric": "Mreads/min (150 bp)", "value": round(value, 2), "unit": "Mreads/min", "n_gpus": world,
@@ -389,10 +460,14 @@ def main():
                        "maxcand": K, "k": db.k, "sketchlen": db.s, "winlen": db.w, "winstride": db.stride,
                        "db_targets": db_info[5], "db_locations": db_info[7], "db_build_s": round(build_s, 2), "db_build": build_info, "load_factor": lf,
                        "hbm_used_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
-                       "parallelism": f"replicated DB x{world}, reads sharded, RCCL gather of top candidates"},
+                       "mode": mode, "pairs": pairs,
+                       "parallelism": {"R": f"replicated DB x{world}, reads sharded, RCCL gather of top candidates",
+                                       "P": f"{world} parts, one per GPU; all reads against every part, RCCL all-gather of per-part candidates, merge",
+                                       "K": f"1 part key-sharded over {world} GPUs; all reads against every shard, RCCL all-to-all of partial location lists, "
+                                            "union + candidates on the owner, gather"}[mode]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": round(bytes_per_read * B),
+                         "algorithmic_bytes_per_launch": round(bytes_per_read * nloc * per_read),
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3),
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
@@ -414,15 +489,16 @@ def main():
             step(0)
             drain()
             db.synchronize()
-            n_chk = B if cfg == 1 else min(B, args.parity_reads)
+            n_chk = B if cfg == 1 else min(B, args.parity_reads if not pairs else min(args.parity_reads, 20_000))
             gpu_c = out_cands[:n_chk].cpu().numpy().view(np.uint32).reshape(n_chk, K, 4)
             gc = np.zeros((n_chk, K), dtype=api.cand_dtype)
             gc["tgt"], gc["hits"], gc["beg"], gc["end"] = gpu_c[..., 0], gpu_c[..., 1], gpu_c[..., 2], gpu_c[..., 3]
             reads_host = batches[0][: n_chk * PAD_LEN].reshape(n_chk, PAD_LEN).cpu().numpy()
+            mates_host = batches[0][nloc * PAD_LEN: (nloc + n_chk) * PAD_LEN].reshape(n_chk, PAD_LEN).cpu().numpy() if pairs else None
             if cfg == 1:
                 cb, par = cpu_leg_config1(os.path.join(dbdir, "syn16"), reads_host, gc, K, args.cpu_seconds)
             else:
-                cb, par = cpu_leg_config2(spec, reads_host, gc, K, args.parity_reads, args.cpu_seconds)
+                cb, par = cpu_leg_config2(spec, reads_host, gc, K, n_chk, args.cpu_seconds, mates_host)
             result["cpu_baseline"] = cb
             result["parity"] = par
     db.close()

@@ -60,6 +60,11 @@ class Phylogeny:
         off[1:] = np.cumsum(ln)
         return off
 
+    def subset(self, sel: np.ndarray) -> "Phylogeny":
+        """the targets sel (ascending) as a collection of their own -- one PART of a partitioned database; taxa keep their numbers"""
+        sel = np.asarray(sel, dtype=np.int64)
+        return Phylogeny(np.ascontiguousarray(self.targets[sel]), self.species[sel].copy(), self.genus[sel].copy(), self.n_species, self.n_genera)
+
     def lineages(self) -> np.ndarray:
         """[targets, 21] taxon index + 1 per rank for mc_set_lineages: sequence level = the target itself, rank 4 = species,
         rank 6 = genus (taxonomy.hpp:68-91); taxon indices: targets first, then species, then genera"""
@@ -189,11 +194,13 @@ class GpuSynth:
             raise RuntimeError(f"mcs_reads -> {rc}")
 
 
-def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_bytes: int = 3 << 30, report=None, **cfg):
+def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_bytes: int = 3 << 30, report=None, key_shard=(0, 1), **cfg):
     """The collection as a query table in HBM, built by the product's builder (mc_build_*) from targets that are generated on the
     device group by group: `shards` key-shard passes (every pass sketches all targets and keeps 1/shards of the features, sorts them
     and inserts them into the table: mc_build_table_*), so that neither the targets (150 Gbp) nor all (feature, location) pairs
-    (2 x 10^10) ever exist at once.  cfg: Builder / mc_config fields (max_candidates, max_load_factor, target_id_bytes, ...).
+    (2 x 10^10) ever exist at once.  key_shard = (i, n): only the features of key shard i of n (mc_key_owner) -- one rank's table in
+    Mode K; its `shards` build passes are the sub-shards i * shards .. i * shards + shards - 1 of n * shards.
+    cfg: Builder / mc_config fields (max_candidates, max_load_factor, target_id_bytes, ...).
     -> (api.Database, info dict with seconds per phase)"""
     import time
     import torch
@@ -224,10 +231,10 @@ def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_byte
     t_all = time.time()
     for sh in range(shards):
         kw = dict(cfg)
-        if shards > 1:
-            kw.update(key_shard_index=sh, key_shard_count=shards)
+        if shards * key_shard[1] > 1:
+            kw.update(key_shard_index=key_shard[0] * shards + sh, key_shard_count=key_shard[1] * shards)
         b = api.Builder(device=device, **kw)
-        b.reserve(int(est_pairs / shards * 1.02) + (1 << 20))
+        b.reserve(int(est_pairs / (shards * key_shard[1]) * 1.02) + (1 << 20))
         for f, c in groups:
             t0 = time.time()
             off = gen.targets(spec, f, c, buf)
@@ -246,7 +253,8 @@ def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_byte
         b.finish(load=False)
         t1 = time.time()
         if db is None:
-            db = b.table_begin()
+            k0, v0 = b.counts()                                   # the passes of one table are alike: keys are dealt out by a hash
+            db = b.table_begin(int(k0 * shards * 1.02) + (1 << 16), int(v0 * shards * 1.04) + (1 << 20)) if shards > 1 else b.table_begin(max(k0, 1), max(v0, 1))
         b.table_add(db)
         t2 = time.time()
         info["seconds"]["sort"] += t1 - t0; info["seconds"]["insert"] += t2 - t1

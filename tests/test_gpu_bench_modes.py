@@ -1,0 +1,33 @@
+"""GPU: bench.py end to end at toy scale -- the default mode R line and the sharded modes P and K with configs[3]'s read pairs,
+each over a real RCCL process group of one rank (--force-dist), each with its parity block against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.004", "--batch", "30000", "--steps", "2", "--warmup", "1",
+           "--gather-gib", "0", "--parity-reads", "3000", "--cpu-seconds", "2"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("extra", [[], ["--pairs"], ["--mode", "P", "--force-dist"], ["--mode", "P", "--pairs", "--force-dist"],
+                                   ["--mode", "K", "--force-dist"], ["--mode", "K", "--pairs", "--force-dist"], ["--config", "1", "--batch", "200000", "--genome-len", "200000"]])
+def test_bench_line_and_parity(extra):
+    res = _run(extra)
+    assert res["metric"].startswith("Mreads/min") and res["value"] > 0 and res["n_gpus"] == 1
+    assert res["parity"]["mismatches"] == 0 and res["parity"]["checked"] >= 3000, res["parity"]
+    assert "roofline" in res and res["roofline"]["frac"] > 0 and "cpu_baseline" in res
+    if "--config" not in extra:
+        assert res["config"]["workload"].startswith("configs[")
+        assert res["config"]["mode"] == (extra[extra.index("--mode") + 1] if "--mode" in extra else "R")
