@@ -41,6 +41,7 @@ struct Options {
     std::string comment = "# ", none = "--", column = "\t|\t", taxSep = ",", rankSuffix = ":", idPrefix = "(", idSuffix = ")";
     bool showQueryParams = true, showSummary = true, showErrors = true, splitOut = false;
     uint32_t sketchlen = 0, winlen = 0, winstride = 0, batchSize = 1u << 16;
+    uint32_t replication = 1;            // -replicate: copies of the table on GPUs 0 .. n-1, the workers are dealt out over them (options.cpp:1155-1163)
     uint32_t refBatchSize = 0;           // -batch-size as given (the reference's batches matter for -cov-percentile)
     int maxLocs = -1, threads = 0;
     bool removeOverpopulated = false; float maxLoadFac = 0;
@@ -121,6 +122,7 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-no-summary" || a == "-nosummary") o.showSummary = false;
         else if (a == "-no-err" || a == "-no-errors") o.showErrors = false;
         else if (a == "-threads") o.threads = std::stoi(need(i));
+        else if (a == "-replicate") o.replication = (uint32_t)std::max(1, std::stoi(need(i)));
         else if (a == "-batch-size" || a == "-batchsize") { o.batchSize = (uint32_t)std::stoul(need(i)); o.refBatchSize = o.batchSize; }
         else throw std::runtime_error("unknown option '" + a + "'");
     }
@@ -309,7 +311,11 @@ struct Session {
     Taxonomy tx;
     uint32_t dbStride = 0, dbSketch = 0, dbWinlen = 0;
     unsigned threads = 1, workers = 1;
-    ~Session() { if (ctx) mc_destroy(ctx); }
+    std::vector<mc_ctx*> replicas;                   // -replicate n: the same table on the GPUs 1 .. n-1 (ctx is the one on GPU 0)
+    uint32_t replication = 1;
+    mc_ctx* replica(unsigned i) const { return i == 0 ? ctx : replicas[i - 1]; }
+    void close_replicas() { for (mc_ctx* r : replicas) mc_destroy(r); replicas.clear(); }
+    ~Session() { close_replicas(); if (ctx) mc_destroy(ctx); }
 
     BuiltDatabase* built = nullptr;                  // build+query: the table comes from the builder's device arrays, not from files
     std::vector<uint32_t> builtLineages;
@@ -330,7 +336,9 @@ struct Session {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         threads = o.threads > 0 ? (unsigned)o.threads : hw;                     // options.hpp: numThreads defaults to all hardware threads
         workers = std::min(threads, 64u);                                      // one batch slot (pinned staging) per worker
-        c.num_slots = workers;
+        const uint32_t nrep = built ? 1u : std::max(1u, o.replication);
+        workers = std::max(workers, nrep);
+        c.num_slots = (workers + nrep - 1) / nrep;                              // worker w: replica w % n, slot w / n
         c.slot_max_queries = o.batchSize;
         c.slot_max_chars = std::max<uint32_t>(1u << 24, o.batchSize * 320u);
         c.max_load_factor = o.maxLoadFac;
@@ -342,8 +350,10 @@ struct Session {
             c.remove_overpopulated = (uint32_t)maxlpf;                             // clamped to the DB's cap - 1 by mc_open_database
             c.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
         } else if (o.maxLocs > 1) c.max_locations_per_feature = (uint32_t)o.maxLocs;
-        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0) return;  // same table, same slots: keep it
+        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0 && replication == nrep) return;  // same table, same slots: keep it
+        close_replicas();
         if (ctx) { mc_destroy(ctx); ctx = nullptr; }
+        replication = nrep;
         tx = Taxonomy{};
         if (built) {
             // add_to_database_and_query (mode_build_query.cpp:41-77): a query context over the builder's arrays
@@ -354,6 +364,13 @@ struct Session {
             tx.taxa.insert(tx.taxa.end(), built->targets.begin(), built->targets.end());
         } else {
             if (mc_open_database(o.db.c_str(), &c, &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+            for (uint32_t r = 1; r < nrep; ++r) {                                // database::read with replication (database.cpp:207-215)
+                mc_config cr = c; cr.device = (int32_t)r;
+                mc_ctx* rc = nullptr;
+                if (mc_open_database(o.db.c_str(), &cr, &rc) != MC_OK)
+                    throw std::runtime_error(std::string("-replicate ") + std::to_string(nrep) + ": GPU " + std::to_string(r) + ": " + mc_last_error(nullptr));
+                replicas.push_back(rc);
+            }
             uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
             for (uint64_t i = 0; i < nt; ++i) {
                 uint32_t rk; const char* nm;
@@ -614,7 +631,9 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (auto it = finished.begin(); it != finished.end() && it->first == nextToWrite; it = finished.erase(it), ++nextToWrite)
                 os.write(it->second.data(), (std::streamsize)it->second.size());
         };
-        auto work = [&](unsigned slot) {
+        auto work = [&](unsigned worker) {
+            const unsigned slot = worker / S.replication;
+            mc_ctx* const ctx = S.replica(worker % S.replication);
             struct Meta { uint64_t id; View header; bool empty; uint64_t len; };
             std::vector<Meta> metas;
             std::vector<Cand> cands;

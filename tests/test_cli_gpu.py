@@ -136,6 +136,27 @@ def test_cli_maxcand_unlimited_beyond_the_device_list(case, cap, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_replicate_over_gpus(tmp_path):
+    """-replicate n (options.cpp:1155-1163): the table on the GPUs 0 .. n-1, the worker threads dealt out over them; the output does
+    not depend on it.  More copies than GPUs must fail loudly, naming the GPU that is missing."""
+    import torch
+    build.build_library()
+    c = CASES["everything_species"]
+    ngpu = torch.cuda.device_count()
+    for n in (1, 2):
+        out = tmp_path / f"out{n}.txt"
+        cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-threads", "4", "-replicate", str(n), "-out", str(out)]
+        r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600)
+        if n <= ngpu:
+            assert r.returncode == 0, r.stderr
+            got = [l for l in out.read_text().split("\n") if not _volatile(l) and "threads" not in l]
+            exp = [l for l in c["lines"] if not _volatile(l) and "threads" not in l]
+            assert got == exp
+        else:
+            assert r.returncode != 0 and "GPU 1" in (r.stdout + r.stderr), (r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.gpu
 def test_cli_small_batches_same_output(tmp_path):
     """-batch-size only changes how reads are grouped into device batches."""
     build.build_library()
