@@ -2650,13 +2650,13 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
                                                                uint32_t minN2)
 {
     constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
+    static_assert(sizeof(BigTables) <= kSlots * 8, "step D's tables live in the key table, which is done with by then");
     __shared__ uint64_t keyS[WAVES][kSlots];
     __shared__ uint32_t cntS[WAVES][kSlots / 2];
-    __shared__ BigTables tabS[WAVES];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint64_t* keys = keyS[wave];
     uint32_t* cnts = cntS[wave];
-    BigTables& T = tabS[wave];
+    BigTables& T = *reinterpret_cast<BigTables*>(keyS[wave]);      // (10 KB instead of 13 KB of LDS per wave: 16 waves per CU instead of 12)
     // the records big_filter_kernel left (list 7, one per query of work list 6); this instance takes the filtered lists that fit its
     // table: n2 in (minN2, kList]
     const uint32_t total = ws.midCount[9];
@@ -2776,7 +2776,7 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
     if (stage == 0) {
         hipLaunchKernelGGL((big_filter_kernel<4>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 1) {
-        const uint32_t grid = std::min<uint32_t>(256 * 3, (b.n + 3) / 4);
+        const uint32_t grid = std::min<uint32_t>(256 * 4, (b.n + 3) / 4);
         if (taxkey) hipLaunchKernelGGL((big_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
         else        hipLaunchKernelGGL((big_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
     } else {
@@ -2785,7 +2785,11 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         else        hipLaunchKernelGGL((big_count_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
     }
 }
-uint32_t big_filter_grid(uint32_t n) { return std::min<uint32_t>(256 * 5, (n + 3) / 4); }
+uint32_t big_filter_grid(uint32_t n)
+{
+    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 5u; }();
+    return std::min<uint32_t>(256 * bpc, (n + 3) / 4);
+}
 
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands,
                        hipStream_t st)
