@@ -2517,6 +2517,10 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 #endif
 constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
 constexpr uint32_t kBigBitsLog2 = 14;     // target states
+#ifndef MC_BIG_STAGE
+#define MC_BIG_STAGE 1536
+#endif
+constexpr uint32_t kBigStage = MC_BIG_STAGE;   // lists up to this length are held in LDS between the filter's sweeps (0: never)
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
@@ -2545,16 +2549,20 @@ __device__ __forceinline__ uint32_t big_setup(BigTables& T, const uint32_t lane,
 template <class F>
 __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const uint32_t R, const uint64_t single, F&& f)
 {
-    f(single);
+    // f(v, i): i = index of the lane's location in the query's list as the sweep walks it (singles first, then round after round)
+    const uint64_t sm = __ballot(single != kEmptyLoc);
+    f(single, (uint32_t)__popcll(sm & ((1ull << lane) - 1ull)));
+    uint32_t pos = (uint32_t)__popcll(sm);
     for (uint32_t g0 = 0; g0 < R; g0 += kBigU) {
-        uint64_t rv[kBigU];
+        uint64_t rv[kBigU]; uint32_t rc[kBigU];
 #pragma unroll
         for (uint32_t u = 0; u < kBigU; ++u) {
             const uint64_t rd = T.rounds[g0 + u];
-            rv[u] = lane < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + lane] : kEmptyLoc;
+            rc[u] = (uint32_t)(rd >> 40);
+            rv[u] = lane < rc[u] ? tab.values[(rd & 0xFFFFFFFFFFull) + lane] : kEmptyLoc;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
+        for (uint32_t u = 0; u < kBigU; ++u) { f(rv[u], pos + lane); pos += rc[u]; }
     }
 }
 
@@ -2567,9 +2575,11 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
     constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
     __shared__ uint32_t bitS[WAVES][kBitWords];
     __shared__ BigTables tabS[WAVES];
+    __shared__ uint64_t stageS[WAVES][kBigStage];                 // the list itself between the sweeps (lists up to kBigStage locations)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* bits = bitS[wave];
     BigTables& T = tabS[wave];
+    uint64_t* stage = stageS[wave];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
@@ -2606,20 +2616,23 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
         bool fallback = R > kBigMaxRounds;
         uint32_t n2 = 0;
         if (!fallback) {
-            // ---- A. target states
-            big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
+            // ---- A. target states; lists that fit the stage stay in LDS for sweep B (half of this kernel's fabric requests were B
+            //      reading again what A had just read: the kernel runs at the request rate of the memory system, not at its latency)
+            const bool staged = H <= kBigStage;
+            big_sweep(T, tab, lane, R, single, [&](uint64_t v, uint32_t i) {
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
                     state_of(v, word, bit1);
                     const uint32_t old = atomicOr(&bits[word], bit1);
                     if (old & bit1) atomicOr(&bits[word], bit1 << 1);
+                    if (staged) stage[i] = v;
                 }
             });
             wave_lds_sync();
             // ---- B. locations of targets seen twice or more -> this wave's pool slice (as long as they fit), counted
             uint64_t* dst = slice + sliceUsed;
             const uint32_t room = (uint32_t)min((uint64_t)kBigMaxFiltered, sliceCap - sliceUsed);
-            big_sweep(T, tab, lane, R, single, [&](uint64_t v) {
+            auto keepB = [&](uint64_t v, uint32_t) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
@@ -2632,7 +2645,9 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
                     if (at < room) dst[at] = v;
                 }
                 n2 += (uint32_t)__popcll(m);
-            });
+            };
+            if (staged) { for (uint32_t i0 = 0; i0 < H; i0 += 64) keepB(i0 + lane < H ? stage[i0 + lane] : kEmptyLoc, 0u); }
+            else big_sweep(T, tab, lane, R, single, keepB);
             fallback = n2 > room;                                  // too long for big_count_kernel, or the slice is full
         }
         if (lane == 0) {
@@ -2722,7 +2737,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
                 uint64_t best[kLaneK];
 #pragma unroll
                 for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kEmptyLoc;
-                big_sweep(T, tab, lane, R, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v) {
+                big_sweep(T, tab, lane, R, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v, uint32_t) {
                     if (v == kEmptyLoc) return;
                     const uint32_t t = (uint32_t)(v >> 32);
                     bool skip = false;
@@ -2787,7 +2802,7 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
 }
 uint32_t big_filter_grid(uint32_t n)
 {
-    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 5u; }();
+    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 4u; }();
     return std::min<uint32_t>(256 * bpc, (n + 3) / 4);
 }
 
