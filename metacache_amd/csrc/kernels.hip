@@ -2518,9 +2518,11 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
 constexpr uint32_t kBigBitsLog2 = 14;     // target states
 #ifndef MC_BIG_STAGE
-#define MC_BIG_STAGE 1536
+#define MC_BIG_STAGE 0
 #endif
-constexpr uint32_t kBigStage = MC_BIG_STAGE;   // lists up to this length are held in LDS between the filter's sweeps (0: never)
+constexpr uint32_t kBigStage = MC_BIG_STAGE;   // lists up to this length are held in LDS between the filter's sweeps; 0 = never (the default:
+                                               // measured at full scale 1536 / 1024 / 2048: 31.6 / 37.2 / 57.5 ms against 26.5 ms -- the LDS costs more
+                                               // waves per CU than the re-read costs requests)
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
@@ -2575,7 +2577,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
     constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
     __shared__ uint32_t bitS[WAVES][kBitWords];
     __shared__ BigTables tabS[WAVES];
-    __shared__ uint64_t stageS[WAVES][kBigStage];                 // the list itself between the sweeps (lists up to kBigStage locations)
+    __shared__ uint64_t stageS[WAVES][kBigStage ? kBigStage : 1];                 // the list itself between the sweeps (lists up to kBigStage locations)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* bits = bitS[wave];
     BigTables& T = tabS[wave];
