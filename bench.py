@@ -262,7 +262,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip both checker legs)")
     ap.add_argument("--parity-reads", type=int, default=200_000, help="configs[2]: reads checked against the oracle")
     ap.add_argument("--load-factor", type=float, default=0.0, help="0 = 0.3 for configs[1], 0.5 for configs[2]")
-    ap.add_argument("--gather-gib", type=float, default=64.0, help="scratch buffer of the random-access microbenchmark (0 = skip)")
+    ap.add_argument("--gather-gib", type=float, default=-1.0, help="scratch buffer of the random-access microbenchmark (0 = skip; default: 64 for "
+                    "configs[2], 0.6 = the table's size for configs[1])")
     ap.add_argument("--mode", default="R", choices=("R", "P", "K"), help="configs[2]: R replicated table (default), P one part per rank, K key shards")
     ap.add_argument("--pairs", action="store_true", help="configs[2]: 2 x 150 bp read pairs (configs[3]'s reads) instead of single reads")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
@@ -281,6 +282,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.gather_gib < 0:
+        args.gather_gib = 64.0 if args.config == 2 else 0.6
     peak = gather_peak(args.gather_gib) if rank == 0 and args.gather_gib > 0 else None
     K = args.maxcand
     cfg = args.config

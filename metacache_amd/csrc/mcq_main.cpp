@@ -479,12 +479,25 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         uint64_t covTotalDomain = 0;
 
         // ---- all inputs are indexed first: batches = runs of consecutive queries, ids continue across files -------------
-        struct Batch { size_t f1, f2; size_t qBeg, qEnd; uint64_t idBase; std::string prefix; const std::vector<uint64_t>* sel; };
+        // Batches are produced while the workers already run: plain files are indexed chunk by chunk (SeqFile::stream_*), and a batch
+        // goes out as soon as its records are known -- the first one after a few megabytes instead of after the whole file.
+        struct Batch { size_t f1, f2; size_t qBeg, qEnd; uint64_t idBase; std::string prefix; const std::vector<uint64_t>* sel; bool halfLast; };
         std::vector<std::unique_ptr<SeqFile>> files;
+        files.reserve(o.infiles.size() + 2);                                   // workers read files[...] while the producer appends
         std::vector<std::unique_ptr<std::vector<uint64_t>>> selections;
-        std::vector<Batch> batches;
+        std::deque<Batch> batches;                                             // grows at the back only: references stay valid
+        std::mutex batchMtx;
+        std::condition_variable batchCv;
+        bool producing = true;
+        std::string producerError;
+        auto push_batch = [&](Batch&& B) {
+            { std::lock_guard<std::mutex> l(batchMtx); batches.push_back(std::move(B)); }
+            batchCv.notify_all();
+        };
         const bool lengthFilter = o.minReadLen > 0 || o.maxReadLen < std::numeric_limits<uint64_t>::max();
-        {
+        double tIndexed = 0;
+        auto produce = [&]() {
+          try {
             uint64_t idOffset = 0;
             const size_t stride = o.pairing == Options::files ? 2 : 1;
             for (size_t fi = 0; fi < o.infiles.size(); fi += stride) {
@@ -493,8 +506,37 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 if (o.pairing == Options::files) prefix += " + " + o.infiles[fi + 1];
                 prefix += '\n';
                 size_t nq = 0, f1 = files.size(), f2 = files.size();
+                bool streamed = false;
                 try {
                     files.emplace_back(new SeqFile(o.infiles[fi]));
+                    SeqFile& F = *files.back();
+                    if (F.can_stream() && o.pairing != Options::files && !lengthFilter && o.queryLimit >= (int64_t)1 << 62 && !std::getenv("MCQ_NO_STREAM")) {
+                        // streaming: batches of this file go out while its later chunks are still being indexed
+                        streamed = true;
+                        const size_t per = o.pairing == Options::sequences ? 2 : 1;
+                        F.stream_begin(std::max(1u, std::min(workers, 16u)));
+                        size_t q = 0;
+                        bool first = true;
+                        for (;;) {
+                            const size_t readable = F.stream_wait((q + o.batchSize) * per);
+                            const bool done = F.stream_done();
+                            const size_t qAvail = done ? (F.records() + per - 1) / per : readable / per;
+                            while (q + o.batchSize <= qAvail || (done && q < qAvail)) {
+                                const size_t qe = std::min(qAvail, q + o.batchSize);
+                                const bool half = done && per == 2 && qe == qAvail && (F.records() & 1u);
+                                push_batch(Batch{f1, f2, q, qe, idOffset, first ? prefix : std::string(), nullptr, half});
+                                first = false; q = qe;
+                            }
+                            if (done) break;
+                        }
+                        F.stream_end();
+                        if (first) push_batch(Batch{f1, f2, 0, 0, idOffset, prefix, nullptr, false});     // no records: the file's comment line only
+                        nq = (F.records() + per - 1) / per;
+                        size_t nread = nq;
+                        if (per == 2 && nq > 0 && (F.records() & 1u)) --nread;                           // (the half pair did not count)
+                        idOffset += nread;
+                        continue;
+                    }
                     files.back()->index(workers);
                     nq = files.back()->records();
                     if (o.pairing == Options::sequences) nq = (nq + 1) / 2;
@@ -535,17 +577,24 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     }
                     nread = q; nsel = kept.size(); sel = &kept;
                 }
+                const bool oddFile = o.pairing == Options::sequences && nq > 0 && (files[f1]->records() & 1u);
                 for (size_t q = 0; q == 0 || q < nsel; q += o.batchSize) {
-                    batches.push_back(Batch{f1, f2, q, std::min<size_t>(nsel, q + o.batchSize), idOffset, q == 0 ? prefix : std::string(), sel});
+                    const size_t qe = std::min<size_t>(nsel, q + o.batchSize);
+                    // the file's last query is a half pair: when it is among the selected ones, it is the last of them
+                    const bool half = oddFile && qe == nsel && nsel > 0 && (sel ? (*sel)[nsel - 1] : nsel - 1) == nq - 1;
+                    push_batch(Batch{f1, f2, q, qe, idOffset, q == 0 ? prefix : std::string(), sel, half});
                     if (nsel == 0) break;
                 }
-                if (o.pairing == Options::sequences && nread == nq && nq > 0 && (files[f1]->records() & 1u)) --nread;   // (the half pair did not count)
+                if (oddFile && nread == nq) --nread;                             // (the half pair did not count)
                 idOffset += nread;                                               // reader.index(): records (pairs) consumed
             }
-        }
+          } catch (std::exception& e) { std::lock_guard<std::mutex> l(batchMtx); producerError = e.what(); }
+          tIndexed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          { std::lock_guard<std::mutex> l(batchMtx); producing = false; }
+          batchCv.notify_all();
+        };
 
         const bool profile = std::getenv("MCQ_PROFILE") != nullptr;              // phase times on stderr (development aid)
-        const double tIndexed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::atomic<uint64_t> nsParse{0}, nsSubmit{0}, nsWait{0}, nsClassify{0};
         auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // one query: classification, statistics, mapping line (classify_and_evaluate, classification.cpp:470-559)
@@ -559,7 +608,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         // classified from the candidates that are left
         const bool covMode = o.covPercentile > 0 && !merged;
         struct Deferred { uint64_t id; View header; std::vector<Cand> cands; };
-        std::vector<std::vector<Deferred>> deferred(covMode ? batches.size() : 0);
+        std::deque<std::vector<Deferred>> deferred;                              // [batch]; grown (under batchMtx) when a worker takes a batch
         auto emit = [&](Acc& A, std::ostream& out, uint64_t id, View header, const std::vector<Cand>& cands, const mc_location* hits, uint64_t nhits) {
             bool isTarget; uint32_t tgt;
             const uint32_t best = classify(o, tx, cands, isTarget, tgt);
@@ -619,7 +668,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             covers.insert(covers.end(), A.covers.begin(), A.covers.end());
         };
         // ---- workers: one batch slot each; output delivered in batch order -------------------------------------------------
-        std::atomic<size_t> nextBatch{0};
+        size_t nextBatch = 0;                                                   // under batchMtx
         std::mutex outMtx, errMtx;
         std::map<size_t, std::string> finished;
         size_t nextToWrite = 0;
@@ -641,8 +690,18 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::ostringstream out;
             Acc A;
             auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = m; };
-            for (size_t b; !failed && (b = nextBatch++) < batches.size();) {
-                const Batch& B = batches[b];
+            for (;;) {
+                size_t b;
+                const Batch* Bp = nullptr;
+                {
+                    std::unique_lock<std::mutex> l(batchMtx);
+                    batchCv.wait(l, [&] { return failed || nextBatch < batches.size() || !producing; });
+                    if (failed || nextBatch >= batches.size()) break;           // (no batch left and the producer is through)
+                    b = nextBatch++;
+                    Bp = &batches[b];
+                    if (covMode) while (deferred.size() <= b) deferred.emplace_back();
+                }
+                const Batch& B = *Bp;
                 out.str(std::string());
                 out << B.prefix;
                 size_t q = B.qBeg;
@@ -654,7 +713,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                         const size_t qi = B.sel ? (size_t)(*B.sel)[q] : q;          // query index inside the file (pair)
                         if (o.pairing == Options::sequences) {
                             files[B.f1]->record(2 * qi, h1, s1, scratch1);
-                            if (2 * qi + 1 < files[B.f1]->records()) files[B.f1]->record(2 * qi + 1, h2, s2, scratch2);
+                            if (!(B.halfLast && q + 1 == B.qEnd)) files[B.f1]->record(2 * qi + 1, h2, s2, scratch2);
                         } else {
                             files[B.f1]->record(qi, h1, s1, scratch1);
                             if (o.pairing == Options::files) files[B.f2]->record(qi, h2, s2, scratch2);
@@ -671,7 +730,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                         if (rc < 0) { fail(mc_last_error(ctx)); break; }
                         // query id = the reader's index after the read (database_query.hpp:264); a last pair without its second
                         // sequence does not advance the index (sequence_io.cpp:312-318), so it shares the id of the pair before it
-                        const bool halfPair = o.pairing == Options::sequences && 2 * qi + 1 >= files[B.f1]->records();
+                        const bool halfPair = B.halfLast && q + 1 == B.qEnd;
                         metas.push_back(Meta{B.idBase + qi + (halfPair ? 0 : 1), h1, h1.empty() || s1.empty(), (uint64_t)s1.n + s2.n});
                     }
                     if (failed) break;
@@ -712,11 +771,16 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             collect(A);
         };
         {
+            std::thread producer(produce);
             std::vector<std::thread> pool;
             for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work, w);
             work(0);
             for (auto& t : pool) t.join();
+            { std::lock_guard<std::mutex> l(batchMtx); }
+            batchCv.notify_all();
+            producer.join();
         }
+        if (!producerError.empty()) throw std::runtime_error(producerError);
         if (failed) throw std::runtime_error(firstError);
         if (covMode) {
             // The reference keeps (target -> candidates) in std::unordered_map objects: one per batch of -batch-size reads (4096 unless
@@ -735,7 +799,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     batchMap = std::unordered_map<uint32_t, std::vector<Cover>>();
                     inBatch = 0;
                 };
-                for (size_t b = 0; b < batches.size(); ++b) {
+                for (size_t b = 0; b < batches.size() && b < deferred.size(); ++b) {
                     if (batches[b].f1 != curFile || batches[b].qBeg == 0) { if (inBatch) flush(); curFile = batches[b].f1; }
                     for (const Deferred& d : deferred[b]) {
                         for (const Cand& c : d.cands) if (c.tax && c.hits >= (uint32_t)o.hitsMin) batchMap[c.tgt].push_back(Cover{c.tgt, d.id, c.beg, c.end, c.hits});
@@ -770,7 +834,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             Acc A;
             std::ostringstream out;
             std::vector<Cand> left;
-            for (size_t b = 0; b < batches.size(); ++b) {
+            for (size_t b = 0; b < batches.size() && b < deferred.size(); ++b) {
                 for (const Deferred& d : deferred[b]) {
                     left.clear();
                     for (const Cand& c : d.cands) if (tgtMatches.find(c.tgt) != tgtMatches.end()) left.push_back(c);

@@ -136,6 +136,26 @@ def test_cli_maxcand_unlimited_beyond_the_device_list(case, cap, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["everything_species", "pairseq", "two_files", "fastq_irregular", "fastq_irregular_pairseq", "fasta_plus_lines",
+                                  "irregular_with_regular", "cov_percentile_pct_hits_per_ref", "hits_per_ref"])
+def test_cli_streaming_index_same_output(case, tmp_path):
+    """Plain input files are indexed chunk by chunk while the first batches already run (SeqFile::stream_*); MCQ_STREAM_MIN / _CHUNK
+    shrink the thresholds so that the toy files take that path in ~20 chunks, with tiny batches and 4 worker threads."""
+    build.build_library()
+    c = CASES[case]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-threads", "4", "-out", str(out)]
+    if "-batch-size" not in c["args"]:
+        cmd += ["-batch-size", "23"]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600, env=dict(os.environ, MCQ_STREAM_MIN="0", MCQ_STREAM_CHUNK="3000"))
+    assert r.returncode == 0, r.stderr
+    unordered = any(a.startswith("-hits-per-") for a in c["args"])
+    got = [l for l in out.read_text().split("\n") if not _volatile(l) and "threads" not in l]
+    exp = [l for l in c["lines"] if not _volatile(l) and "threads" not in l]
+    assert (sorted(got) == sorted(exp)) if unordered else (got == exp)
+
+
+@pytest.mark.gpu
 def test_cli_replicate_over_gpus(tmp_path):
     """-replicate n (options.cpp:1155-1163): the table on the GPUs 0 .. n-1, the worker threads dealt out over them; the output does
     not depend on it.  More copies than GPUs must fail loudly, naming the GPU that is missing."""
