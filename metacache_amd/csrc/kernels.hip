@@ -2355,17 +2355,15 @@ __device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uin
             const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
             if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
         }
-        uint64_t m = hk;
-#pragma unroll
-        for (uint32_t off = 32; off > 0; off >>= 1) {
-            const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
-            m = o > m ? o : m;
-        }
+        // wave-wide maximum of (hits, ~target), then the smallest window among its holders: three 32-bit DPP reductions (VALU speed)
+        // instead of 18 ds_bpermute round trips per round
+        const uint32_t khi = (uint32_t)(hk >> 32), klo = (uint32_t)hk;
+        const uint32_t mhi = wave_max_u32(khi);
+        const uint32_t mlo = wave_max_u32(khi == mhi ? klo : 0u);
+        const uint64_t m = ((uint64_t)mhi << 32) | mlo;
         mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
-        if (m != 0) {
-            uint32_t wm = hk == m ? hw : 0xFFFFFFFFu;
-#pragma unroll
-            for (uint32_t off = 32; off > 0; off >>= 1) wm = min(wm, __shfl_xor(wm, off));
+        if (mhi != 0) {
+            const uint32_t wm = wave_min_u32(hk == m ? hw : 0xFFFFFFFFu);
             const uint32_t winner = __ffsll((unsigned long long)__ballot(hk == m && hw == wm)) - 1;
             const uint32_t g = rdlane(hg, winner), d = rdlane(hd, winner);
 #pragma unroll
