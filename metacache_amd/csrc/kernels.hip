@@ -2515,54 +2515,54 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 #endif
 constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
 constexpr uint32_t kBigBitsLog2 = 14;     // target states
-#ifndef MC_BIG_STAGE
-#define MC_BIG_STAGE 0
-#endif
-constexpr uint32_t kBigStage = MC_BIG_STAGE;   // lists up to this length are held in LDS between the filter's sweeps; 0 = never (the default:
-                                               // measured at full scale 1536 / 1024 / 2048: 31.6 / 37.2 / 57.5 ms against 26.5 ms -- the LDS costs more
-                                               // waves per CU than the re-read costs requests)
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
 uint32_t big_filter_grid(uint32_t n);
+// A ROUND = up to G consecutive locations of one bucket, read by G neighbouring lanes; 64 / G rounds share one wave load.  G = 16
+// unless the query's buckets would need more than kBigMaxRounds such rounds (then G = 64): a bucket of 16 locations fills a quarter
+// of a 64-lane round but a whole 16-lane one, one of 49 takes 4 x 16 either way -- at 430 locations per read the sweeps issue a
+// third of the wave loads (26 buckets of 17), at 1 270 (26 buckets of 49) 60 %.
 struct BigTables {                        // per wave: entry table and round table of one query
     uint64_t entPay[kBigEnt];
     uint32_t entSz[kBigEnt];
-    uint64_t rounds[kBigMaxRounds + kBigU];
+    uint64_t rounds[kBigMaxRounds + kBigU * 4];
 };
+static_assert(kBigU * 4 <= 64, "one lane per padding entry");
+struct BigShape { uint32_t rounds, shift; };   // rounds of 1 << shift lanes
 
-// entries -> LDS tables; returns the number of rounds (> kBigMaxRounds: merged buckets of a partitioned database, not handled here)
-__device__ __forceinline__ uint32_t big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay)
+// entries -> LDS tables; rounds > kBigMaxRounds even at 64 lanes per round: merged buckets of a partitioned database, not handled here
+__device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay)
 {
     if (lane < nent) { T.entPay[lane] = myPay; T.entSz[lane] = mySz; }
-    const uint32_t myRounds = (lane < nent && mySz > 1) ? (mySz + 63u) / 64u : 0u;
+    const bool list = lane < nent && mySz > 1;
+    const uint32_t r16 = wave_sum_u32(list ? (mySz + 15u) / 16u : 0u);
+    const uint32_t shift = r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
+    const uint32_t myRounds = list ? (mySz + G - 1u) >> shift : 0u;
     const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
     const uint32_t R = rdlane(incl, 63);
     if (R <= kBigMaxRounds) {
         for (uint32_t j = 0; j < myRounds; ++j)
-            T.rounds[incl - myRounds + j] = (myPay + 64ull * j) | ((uint64_t)min(64u, mySz - 64u * j) << 40);
-        if (lane < kBigU) T.rounds[R + lane] = 0ull;
+            T.rounds[incl - myRounds + j] = (myPay + (uint64_t)G * j) | ((uint64_t)min(G, mySz - G * j) << 40);
+        T.rounds[R + lane] = 0ull;                                             // (kBigU * 4 <= 64 entries of padding)
     }
-    return R;
+    return BigShape{R, shift};
 }
-// one sweep over a query's locations: f(v) for the lane's element of every round (kEmptyLoc = none), kBigU rounds' loads in flight
+// one sweep over a query's locations: f(v) for the lane's element of every wave load (kEmptyLoc = none), kBigU loads in flight
 template <class F>
-__device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const uint32_t R, const uint64_t single, F&& f)
+__device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const BigShape sh, const uint64_t single, F&& f)
 {
-    // f(v, i): i = index of the lane's location in the query's list as the sweep walks it (singles first, then round after round)
-    const uint64_t sm = __ballot(single != kEmptyLoc);
-    f(single, (uint32_t)__popcll(sm & ((1ull << lane) - 1ull)));
-    uint32_t pos = (uint32_t)__popcll(sm);
-    for (uint32_t g0 = 0; g0 < R; g0 += kBigU) {
-        uint64_t rv[kBigU]; uint32_t rc[kBigU];
+    f(single);
+    const uint32_t perLoad = 64u >> sh.shift, grp = lane >> sh.shift, sub = lane & ((1u << sh.shift) - 1u);
+    for (uint32_t g0 = 0; g0 < sh.rounds; g0 += kBigU * perLoad) {
+        uint64_t rv[kBigU];
 #pragma unroll
         for (uint32_t u = 0; u < kBigU; ++u) {
-            const uint64_t rd = T.rounds[g0 + u];
-            rc[u] = (uint32_t)(rd >> 40);
-            rv[u] = lane < rc[u] ? tab.values[(rd & 0xFFFFFFFFFFull) + lane] : kEmptyLoc;
+            const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
+            rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + sub] : kEmptyLoc;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < kBigU; ++u) { f(rv[u], pos + lane); pos += rc[u]; }
+        for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
     }
 }
 
@@ -2575,11 +2575,9 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
     constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
     __shared__ uint32_t bitS[WAVES][kBitWords];
     __shared__ BigTables tabS[WAVES];
-    __shared__ uint64_t stageS[WAVES][kBigStage ? kBigStage : 1];                 // the list itself between the sweeps (lists up to kBigStage locations)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* bits = bitS[wave];
     BigTables& T = tabS[wave];
-    uint64_t* stage = stageS[wave];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
@@ -2606,33 +2604,31 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
         }
         const uint32_t mySz = esz & 0xFFFFu;
         const uint64_t myPay = epay;
-        const uint32_t R = big_setup(T, lane, nent, mySz, myPay);
+        const BigShape sh = big_setup(T, lane, nent, mySz, myPay);
         const uint64_t single = (lane < nent && mySz == 1) ? myPay : kEmptyLoc;
         rec = recNext;                                             // the next query's record and entries are on their way meanwhile
         recNext = load_rec(w + 2 * nWaves);
         esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
         epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
         wave_lds_sync();
-        bool fallback = R > kBigMaxRounds;
+        bool fallback = sh.rounds > kBigMaxRounds;
         uint32_t n2 = 0;
         if (!fallback) {
-            // ---- A. target states; lists that fit the stage stay in LDS for sweep B (half of this kernel's fabric requests were B
-            //      reading again what A had just read: the kernel runs at the request rate of the memory system, not at its latency)
-            const bool staged = H <= kBigStage;
-            big_sweep(T, tab, lane, R, single, [&](uint64_t v, uint32_t i) {
+            // ---- A. target states.  (Holding the list in LDS for sweep B was measured: at 1536 / 1024 / 2048 staged locations the kernel
+            //      took 31.6 / 37.2 / 57.5 ms instead of 26.5 per 5 x 10^6 reads -- the LDS costs more waves than the re-read costs.)
+            big_sweep(T, tab, lane, sh, single, [&](uint64_t v) {
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
                     state_of(v, word, bit1);
                     const uint32_t old = atomicOr(&bits[word], bit1);
                     if (old & bit1) atomicOr(&bits[word], bit1 << 1);
-                    if (staged) stage[i] = v;
                 }
             });
             wave_lds_sync();
             // ---- B. locations of targets seen twice or more -> this wave's pool slice (as long as they fit), counted
             uint64_t* dst = slice + sliceUsed;
             const uint32_t room = (uint32_t)min((uint64_t)kBigMaxFiltered, sliceCap - sliceUsed);
-            auto keepB = [&](uint64_t v, uint32_t) {
+            big_sweep(T, tab, lane, sh, single, [&](uint64_t v) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
@@ -2645,9 +2641,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
                     if (at < room) dst[at] = v;
                 }
                 n2 += (uint32_t)__popcll(m);
-            };
-            if (staged) { for (uint32_t i0 = 0; i0 < H; i0 += 64) keepB(i0 + lane < H ? stage[i0 + lane] : kEmptyLoc, 0u); }
-            else big_sweep(T, tab, lane, R, single, keepB);
+            });
             fallback = n2 > room;                                  // too long for big_count_kernel, or the slice is full
         }
         if (lane == 0) {
@@ -2732,12 +2726,12 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
                 const uint32_t fbase = ws.winOff[q] * s;
                 const uint32_t mySz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
                 const uint64_t myPay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
-                const uint32_t R = big_setup(T, lane, nent, mySz, myPay);
+                const BigShape sh = big_setup(T, lane, nent, mySz, myPay);
                 wave_lds_sync();
                 uint64_t best[kLaneK];
 #pragma unroll
                 for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kEmptyLoc;
-                big_sweep(T, tab, lane, R, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v, uint32_t) {
+                big_sweep(T, tab, lane, sh, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v) {
                     if (v == kEmptyLoc) return;
                     const uint32_t t = (uint32_t)(v >> 32);
                     bool skip = false;
