@@ -441,6 +441,20 @@ class Builder:
             arr[i] = Rec(tid, par, rk, b)
         self._check(lib().mc_build_write(self.h, name.encode(), C.cast(arr, C.c_void_p), len(taxa)))
 
+    @staticmethod
+    def write_shards(builders: "list[Builder]", name: str, taxa: list[tuple[int, int, int, str]]):
+        """<name>.meta + <name>.cache0 from the finished builders of one key-sharded set (mc_build_write_shards)"""
+        class Rec(C.Structure):
+            _fields_ = [("id", C.c_int64), ("parent", C.c_int64), ("rank", C.c_uint32), ("name", C.c_char_p)]
+        arr = (Rec * max(len(taxa), 1))()
+        keep = []
+        for i, (tid, par, rk, nm) in enumerate(taxa):
+            b = nm.encode(); keep.append(b)
+            arr[i] = Rec(tid, par, rk, b)
+        hs = (C.c_void_p * len(builders))(*[b.h for b in builders])
+        lib().mc_build_write_shards.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint64]
+        builders[0]._check(lib().mc_build_write_shards(hs, len(builders), name.encode(), C.cast(arr, C.c_void_p), len(taxa)))
+
     def free(self):
         if self.h:
             lib().mc_build_free(self.h)

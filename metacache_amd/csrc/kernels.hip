@@ -2515,6 +2515,10 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 #endif
 constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
 constexpr uint32_t kBigBitsLog2 = 14;     // target states
+#ifndef MC_BIG_MIN_SHIFT
+#define MC_BIG_MIN_SHIFT 4
+#endif
+constexpr uint32_t kBigMinShift = MC_BIG_MIN_SHIFT;   // smallest round: 1 << shift lanes
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
@@ -2526,9 +2530,9 @@ uint32_t big_filter_grid(uint32_t n);
 struct BigTables {                        // per wave: entry table and round table of one query
     uint64_t entPay[kBigEnt];
     uint32_t entSz[kBigEnt];
-    uint64_t rounds[kBigMaxRounds + kBigU * 4];
+    uint64_t rounds[kBigMaxRounds + kBigU * 8];
 };
-static_assert(kBigU * 4 <= 64, "one lane per padding entry");
+static_assert(kBigU * 8 <= 128, "two padding entries per lane");
 struct BigShape { uint32_t rounds, shift; };   // rounds of 1 << shift lanes
 
 // entries -> LDS tables; rounds > kBigMaxRounds even at 64 lanes per round: merged buckets of a partitioned database, not handled here
@@ -2536,15 +2540,15 @@ __device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane,
 {
     if (lane < nent) { T.entPay[lane] = myPay; T.entSz[lane] = mySz; }
     const bool list = lane < nent && mySz > 1;
-    const uint32_t r16 = wave_sum_u32(list ? (mySz + 15u) / 16u : 0u);
-    const uint32_t shift = r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
+    const uint32_t r8 = wave_sum_u32(list ? (mySz + 7u) / 8u : 0u), r16 = wave_sum_u32(list ? (mySz + 15u) / 16u : 0u);
+    const uint32_t shift = (kBigMinShift <= 3 && r8 <= kBigMaxRounds) ? 3u : r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
     const uint32_t myRounds = list ? (mySz + G - 1u) >> shift : 0u;
     const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
     const uint32_t R = rdlane(incl, 63);
     if (R <= kBigMaxRounds) {
         for (uint32_t j = 0; j < myRounds; ++j)
             T.rounds[incl - myRounds + j] = (myPay + (uint64_t)G * j) | ((uint64_t)min(G, mySz - G * j) << 40);
-        T.rounds[R + lane] = 0ull;                                             // (kBigU * 4 <= 64 entries of padding)
+        T.rounds[R + lane] = 0ull; T.rounds[R + 64 + lane] = 0ull;             // (kBigU * 8 <= 128 entries of padding)
     }
     return BigShape{R, shift};
 }
