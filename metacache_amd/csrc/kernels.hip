@@ -2516,7 +2516,7 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
 constexpr uint32_t kBigBitsLog2 = 14;     // target states
 #ifndef MC_BIG_MIN_SHIFT
-#define MC_BIG_MIN_SHIFT 4
+#define MC_BIG_MIN_SHIFT 3
 #endif
 constexpr uint32_t kBigMinShift = MC_BIG_MIN_SHIFT;   // smallest round: 1 << shift lanes
 constexpr uint32_t kBigMaxFiltered = 1024;
