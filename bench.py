@@ -197,6 +197,34 @@ def cpu_leg_config1(dbname, reads_host, gpu_cands, K, budget_s):
             {"checked": n, "mismatches": count_mismatches(gpu_cands, cands), "against": kind})
 
 
+def cpu_leg_reference_files(dbname, reads_host, gpu_cands, K, budget_s):
+    """configs[2] with --reference-files: the reference itself loads the database files this run wrote and classifies the sample"""
+    import cpuref
+    import scale_util
+    eff = scale_util.effective_cpus()
+    t0 = time.time()
+    db = cpuref.reference(4).open(dbname)
+    load_s = time.time() - t0
+    n = reads_host.shape[0]
+
+    def run(m, threads):
+        seqs = np.ascontiguousarray(reads_host[:m, :READ_LEN]).reshape(-1)
+        offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+        return db.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
+
+    t, cands = run(n, min(os.cpu_count() or 1, 2 * eff))
+    mism = count_mismatches(gpu_cands, cands)
+    best, bt, sweep = thread_sweep(run, n, budget_s, min(os.cpu_count() or 1, 4 * eff))
+    db.close()
+    size = sum(os.path.getsize(dbname + e) for e in (".meta", ".cache0"))
+    for e in (".meta", ".cache0"):
+        os.remove(dbname + e)
+    return ({"value": round(best, 2), "unit": "Mreads/min", "cores": bt, "kind": "reference", "thread_sweep": sweep, "host_cpus_granted": eff,
+             "sample": f"{n} reads of the same workload (batch 0); the reference (oracle/_ref) on {bt} host threads (best of the sweep; the box grants {eff} "
+                       f"CPUs) on the database files this run wrote ({size / 1e9:.0f} GB, loaded in {load_s:.0f} s)"},
+            {"checked": n, "mismatches": mism, "against": "reference"})
+
+
 def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s, mates_host=None):
     """configs[2]: a 100+ GB table is out of the checker's budget (the reference would need the whole database written to files and
     loaded single-threaded: minutes), but a read sample only ever looks at the buckets of ITS features: the C oracle builds exactly
@@ -266,6 +294,8 @@ def main():
                     "configs[2], 0.6 = the table's size for configs[1])")
     ap.add_argument("--mode", default="R", choices=("R", "P", "K"), help="configs[2]: R replicated table (default), P one part per rank, K key shards")
     ap.add_argument("--pairs", action="store_true", help="configs[2]: 2 x 150 bp read pairs (configs[3]'s reads) instead of single reads")
+    ap.add_argument("--reference-files", default="", help="configs[2], N = 1: also write the database as files under this name (e.g. /dev/shm/mcdb: "
+                    "190 GB at full scale) and let the REFERENCE (oracle/_ref) load them and be the checker and the CPU baseline instead of the oracle")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
     args = ap.parse_args()
 
@@ -334,7 +364,8 @@ def main():
             db, build_info = synthdb.build_database(spec, device=local, shards=kshards, key_shard=(rank, world), max_candidates=K, max_load_factor=lf,
                                                     report=say)
         else:
-            db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say)
+            db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say,
+                                                    write_to=(args.reference_files if (rank == 0 and world == 1) else "") or None)
         gen = synthdb.GpuSynth(local)
         P = synthdb.read_params(spec, 4100 if args.pairs else 3100, paired=args.pairs)
         assert P.row_bytes == PAD_LEN
@@ -500,6 +531,8 @@ def main():
             mates_host = batches[0][nloc * PAD_LEN: (nloc + n_chk) * PAD_LEN].reshape(n_chk, PAD_LEN).cpu().numpy() if pairs else None
             if cfg == 1:
                 cb, par = cpu_leg_config1(os.path.join(dbdir, "syn16"), reads_host, gc, K, args.cpu_seconds)
+            elif args.reference_files and mode == "R" and not pairs:
+                cb, par = cpu_leg_reference_files(args.reference_files, reads_host, gc, K, args.cpu_seconds)
             else:
                 cb, par = cpu_leg_config2(spec, reads_host, gc, K, n_chk, args.cpu_seconds, mates_host)
             result["cpu_baseline"] = cb

@@ -320,6 +320,13 @@ int  mc_build_set_query_config(mc_builder* b, const mc_config* qcfg);
 int  mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa);
 /* the same for the builders of one key-sharded set (see mc_build_finish_shards): one complete database */
 int  mc_build_write_shards(mc_builder** builders, uint32_t n, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa);
+/* the same shard by shard (a RefSeq-scale set of builders does not exist at once): begin writes <name>.meta (targets of b) and opens
+ * <name>.cache0, add appends one finished builder (key shards 0 .. n-1 in order), end patches the totals into the header and closes;
+ * any failure removes both files. */
+typedef struct mc_db_writer mc_db_writer;
+int  mc_build_write_begin(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa, mc_db_writer** out);
+int  mc_build_write_add(mc_db_writer* w, mc_builder* shard);
+int  mc_build_write_end(mc_db_writer* w);
 void mc_build_free(mc_builder* b);
 const char* mc_build_last_error(const mc_builder* b);
 

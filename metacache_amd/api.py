@@ -60,7 +60,7 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats", "mc_set_tuning",
            "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_add_target_device", "mc_build_flush", "mc_build_reserve",
-           "mc_build_table_begin", "mc_build_table_add", "mc_build_table_end", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_free", "mc_build_last_error",
+           "mc_build_table_begin", "mc_build_table_add", "mc_build_table_end", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_write_begin", "mc_build_write_add", "mc_build_write_end", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
 
 _lib = None
@@ -454,6 +454,31 @@ class Builder:
         hs = (C.c_void_p * len(builders))(*[b.h for b in builders])
         lib().mc_build_write_shards.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint64]
         builders[0]._check(lib().mc_build_write_shards(hs, len(builders), name.encode(), C.cast(arr, C.c_void_p), len(taxa)))
+
+    def write_begin(self, name: str, taxa: list[tuple[int, int, int, str]]):
+        """streaming writer (mc_build_write_begin): -> handle for write_add / write_end"""
+        class Rec(C.Structure):
+            _fields_ = [("id", C.c_int64), ("parent", C.c_int64), ("rank", C.c_uint32), ("name", C.c_char_p)]
+        arr = (Rec * max(len(taxa), 1))()
+        keep = []
+        for i, (tid, par, rk, nm) in enumerate(taxa):
+            b = nm.encode(); keep.append(b)
+            arr[i] = Rec(tid, par, rk, b)
+        w = C.c_void_p()
+        lib().mc_build_write_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        self._check(lib().mc_build_write_begin(self.h, name.encode(), C.cast(arr, C.c_void_p), len(taxa), C.byref(w)))
+        return w
+
+    def write_add(self, writer):
+        lib().mc_build_write_add.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(lib().mc_build_write_add(writer, self.h))
+
+    @staticmethod
+    def write_end(writer):
+        lib().mc_build_write_end.argtypes = [C.c_void_p]
+        rc = lib().mc_build_write_end(writer)
+        if rc < 0:
+            raise McError(f"mc_build_write_end -> {rc}")
 
     def free(self):
         if self.h:

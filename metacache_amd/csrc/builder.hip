@@ -700,18 +700,43 @@ int mc_build_write(mc_builder* b, const char* name, const mc_taxon_rec* taxa, ui
     return mc_build_write_shards(one, 1, name, taxa, ntaxa);
 }
 
-// <name>.meta + <name>.cache0 from the builders of one key-sharded set (n == 1: a whole builder): the shards' features follow each
-// other in the file's batch stream (any order of keys is a valid file: the reader inserts key by key, hash_multimap.hpp:970-1030)
-int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa)
-{
-    if (!bs || !n || !bs[0] || !name) return MC_ERR_INVALID;
-    mc_builder* b = bs[0];
-    for (uint32_t s = 0; s < n; ++s) {
-        if (!bs[s]) return MC_ERR_INVALID;
-        if (!bs[s]->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
-        if (bs[s]->targets.size() != b->targets.size() || (n > 1 && (bs[s]->cfg.key_shard_count != n || bs[s]->cfg.key_shard_index != s))) {
-            b->err = "mc_build_write_shards: builders do not form one key-sharded set"; return MC_ERR_INVALID; }
+// <name>.meta + <name>.cache0, written shard by shard: the shards' features follow each other in the file's batch stream (any order of
+// keys is a valid file: the reader inserts key by key, hash_multimap.hpp:970-1030), so a builder can be written and freed before the next
+// one is sketched -- a RefSeq-scale database (2 x 10^10 locations) never has to exist as a whole next to its files.
+struct mc_db_writer {
+    std::string name, err;
+    OutFile* f = nullptr;
+    uint32_t tb = 4, maxLocs = 254, shardCount = 1, nextShard = 0;
+    size_t targets = 0;
+    uint64_t hdr[3] = {0, 0, 1ull << 20};
+    std::vector<uint32_t> outK; std::vector<uint8_t> outS, packed;
+    bool failed = false;
+    ~mc_db_writer() { delete f; }
+    void flush_batch()
+    {
+        if (outK.empty()) return;
+        hdr[0] += outK.size();
+        wr(*f, outK.data(), outK.size() * 4);
+        wr(*f, outS.data(), outS.size());
+        wr(*f, packed.data(), packed.size());
+        outK.clear(); outS.clear(); packed.clear();
     }
+    int give_up(mc_builder* b, const std::string& why)           // no half-written database stays behind
+    {
+        failed = true;
+        if (f) { f->close(); std::remove(f->name.c_str()); }
+        std::remove((name + ".meta").c_str());
+        err = why;
+        if (b) b->err = why;
+        return MC_ERR_IO;
+    }
+};
+
+int mc_build_write_begin(mc_builder* b, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa, mc_db_writer** out)
+{
+    if (!b || !name || !out) return MC_ERR_INVALID;
+    *out = nullptr;
+    if (!b->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
     const uint32_t tb = b->cfg.target_id_bytes;
     {   // .meta  (database.cpp:247-290)
         OutFile f(std::string(name) + ".meta");
@@ -744,71 +769,101 @@ int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const m
         }
         if (!f.close()) { std::remove(f.name.c_str()); b->err = "write error on " + f.name + " (disk full?)"; return MC_ERR_IO; }
     }
-    {   // .cache0  (hash_multimap.hpp:1037-1082): only non-empty buckets are written; with -remove-overpopulated-features the buckets
-        // that reached the limit are gone (remove_features_with_more_locations_than(maxLocs - 1), building.cpp:516-534)
-        OutFile f(std::string(name) + ".cache0");
-        if (!f.f) { b->err = "cannot write .cache0"; return MC_ERR_IO; }
-        auto give_up = [&](const std::string& why) {            // no half-written database stays behind
-            f.close(); std::remove(f.name.c_str()); std::remove((std::string(name) + ".meta").c_str());
-            b->err = why; return MC_ERR_IO;
-        };
-        const uint64_t batch = 1ull << 20;
-        uint64_t hdr[3] = {0, 0, batch};
-        wr(f, hdr, 24);                                                // key / value totals follow when all shards are through
-        std::vector<uint32_t> keys, outK; std::vector<uint8_t> sizes, outS, packed; std::vector<uint64_t> values;
-        auto flush_batch = [&]() {
-            if (outK.empty()) return;
-            hdr[0] += outK.size();
-            wr(f, outK.data(), outK.size() * 4);
-            wr(f, outS.data(), outS.size());
-            wr(f, packed.data(), packed.size());
-            outK.clear(); outS.clear(); packed.clear();
-        };
-        for (uint32_t s = 0; s < n; ++s) {
-            mc_builder* c = bs[s];
-            // one shard at a time on the host, in slices of 2^24 keys
-            const uint64_t slice = 1ull << 24;
-            uint64_t vbeg = 0;
-            for (uint64_t k0 = 0; k0 < c->nkeys; k0 += slice) {
-                const uint64_t nk = std::min<uint64_t>(slice, c->nkeys - k0);
-                uint64_t vend = 0;
-                B_TRY(b, hipSetDevice(c->cfg.device));
-                B_TRY(b, hipMemcpy(&vend, c->rVoff + k0 + nk, 8, hipMemcpyDeviceToHost));
-                keys.resize(nk); sizes.resize(nk); values.resize(vend - vbeg);
-                B_TRY(b, hipMemcpy(keys.data(), c->rK + k0, nk * 4, hipMemcpyDeviceToHost));
-                B_TRY(b, hipMemcpy(sizes.data(), c->rS + k0, nk, hipMemcpyDeviceToHost));
-                if (vend > vbeg) B_TRY(b, hipMemcpy(values.data(), c->rV + vbeg, (vend - vbeg) * 8, hipMemcpyDeviceToHost));
-                vbeg = vend;
-                auto kept = [&](uint64_t i) { return !(c->rmOver && sizes[i] > c->maxLocs - 1); };
-                // the reader takes batches of exactly 'batch' keys (the last one may be shorter): a batch runs on across slices and shards
-                uint64_t voff = 0;
-                for (uint64_t i = 0; i < nk; ++i) {
-                    const uint32_t sz = sizes[i];
-                    if (kept(i)) {
-                        outK.push_back(keys[i]); outS.push_back((uint8_t)sz);
-                        const size_t at0 = packed.size();
-                        packed.resize(at0 + (size_t)sz * (4 + tb));
-                        for (uint32_t t = 0; t < sz; ++t) {
-                            const uint64_t v = values[voff + t];
-                            const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
-                            uint8_t* at = &packed[at0 + (size_t)t * (4 + tb)];
-                            std::memcpy(at, &win, 4);
-                            if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(at + 4, &t16, 2); }
-                            else std::memcpy(at + 4, &tgt, 4);
-                        }
-                        hdr[1] += sz;
-                        if (outK.size() == batch) { flush_batch(); if (f.bad) return give_up("write error on " + f.name + " (disk full?)"); }
-                    }
-                    voff += sz;
+    auto* w = new mc_db_writer;
+    w->name = name; w->tb = tb; w->maxLocs = b->maxLocs; w->targets = b->targets.size();
+    w->shardCount = std::max<uint32_t>(b->cfg.key_shard_count, 1);
+    // .cache0  (hash_multimap.hpp:1037-1082): only non-empty buckets are written; the key / value totals of the header follow at the end
+    w->f = new OutFile(std::string(name) + ".cache0");
+    if (!w->f->f) { std::remove((w->name + ".meta").c_str()); b->err = "cannot write .cache0"; delete w; return MC_ERR_IO; }
+    wr(*w->f, w->hdr, 24);
+    *out = w;
+    return MC_OK;
+}
+
+int mc_build_write_add(mc_db_writer* w, mc_builder* c)
+{
+    if (!w || !c) return MC_ERR_INVALID;
+    if (w->failed) return MC_ERR_STATE;
+    if (!c->finished) { c->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
+    if (c->targets.size() != w->targets || c->cfg.target_id_bytes != w->tb || std::max<uint32_t>(c->cfg.key_shard_count, 1) != w->shardCount ||
+        (w->shardCount > 1 && c->cfg.key_shard_index != w->nextShard)) {
+        c->err = "mc_build_write: builders do not form one key-sharded set (shards 0 .. n-1 in order, same targets)"; return MC_ERR_INVALID; }
+    ++w->nextShard;
+    const uint32_t tb = w->tb;
+    const uint64_t batch = w->hdr[2];
+    std::vector<uint32_t> keys; std::vector<uint8_t> sizes; std::vector<uint64_t> values;
+    // one shard at a time on the host, in slices of 2^24 keys; with -remove-overpopulated-features the buckets that reached the limit
+    // are gone (remove_features_with_more_locations_than(maxLocs - 1), building.cpp:516-534)
+    const uint64_t slice = 1ull << 24;
+    uint64_t vbeg = 0;
+    for (uint64_t k0 = 0; k0 < c->nkeys; k0 += slice) {
+        const uint64_t nk = std::min<uint64_t>(slice, c->nkeys - k0);
+        uint64_t vend = 0;
+        B_TRY(c, hipSetDevice(c->cfg.device));
+        B_TRY(c, hipMemcpy(&vend, c->rVoff + k0 + nk, 8, hipMemcpyDeviceToHost));
+        keys.resize(nk); sizes.resize(nk); values.resize(vend - vbeg);
+        B_TRY(c, hipMemcpy(keys.data(), c->rK + k0, nk * 4, hipMemcpyDeviceToHost));
+        B_TRY(c, hipMemcpy(sizes.data(), c->rS + k0, nk, hipMemcpyDeviceToHost));
+        if (vend > vbeg) B_TRY(c, hipMemcpy(values.data(), c->rV + vbeg, (vend - vbeg) * 8, hipMemcpyDeviceToHost));
+        vbeg = vend;
+        auto kept = [&](uint64_t i) { return !(c->rmOver && sizes[i] > c->maxLocs - 1); };
+        // the reader takes batches of exactly 'batch' keys (the last one may be shorter): a batch runs on across slices and shards
+        uint64_t voff = 0;
+        for (uint64_t i = 0; i < nk; ++i) {
+            const uint32_t sz = sizes[i];
+            if (kept(i)) {
+                w->outK.push_back(keys[i]); w->outS.push_back((uint8_t)sz);
+                const size_t at0 = w->packed.size();
+                w->packed.resize(at0 + (size_t)sz * (4 + tb));
+                for (uint32_t t = 0; t < sz; ++t) {
+                    const uint64_t v = values[voff + t];
+                    const uint32_t win = (uint32_t)v, tgt = (uint32_t)(v >> 32);
+                    uint8_t* at = &w->packed[at0 + (size_t)t * (4 + tb)];
+                    std::memcpy(at, &win, 4);
+                    if (tb == 2) { uint16_t t16 = (uint16_t)tgt; std::memcpy(at + 4, &t16, 2); }
+                    else std::memcpy(at + 4, &tgt, 4);
                 }
+                w->hdr[1] += sz;
+                if (w->outK.size() == batch) { w->flush_batch(); if (w->f->bad) return w->give_up(c, "write error on " + w->f->name + " (disk full?)"); }
             }
+            voff += sz;
         }
-        flush_batch();
-        if (std::fseek(f.f, 0, SEEK_SET) != 0) f.bad = true;
-        wr(f, hdr, 24);
-        if (!f.close()) return give_up("write error on " + f.name + " (disk full?)");
     }
     return MC_OK;
+}
+
+int mc_build_write_end(mc_db_writer* w)
+{
+    if (!w) return MC_ERR_INVALID;
+    int rc = MC_OK;
+    if (w->failed) rc = MC_ERR_IO;
+    else if (w->shardCount > 1 && w->nextShard != w->shardCount) rc = w->give_up(nullptr, "mc_build_write_end: not every key shard was written");
+    else {
+        w->flush_batch();
+        if (std::fseek(w->f->f, 0, SEEK_SET) != 0) w->f->bad = true;
+        wr(*w->f, w->hdr, 24);
+        if (!w->f->close()) rc = w->give_up(nullptr, "write error on " + w->f->name + " (disk full?)");
+    }
+    delete w;
+    return rc;
+}
+
+int mc_build_write_shards(mc_builder** bs, uint32_t n, const char* name, const mc_taxon_rec* taxa, uint64_t ntaxa)
+{
+    if (!bs || !n || !bs[0] || !name) return MC_ERR_INVALID;
+    mc_builder* b = bs[0];
+    for (uint32_t s = 0; s < n; ++s) {
+        if (!bs[s]) return MC_ERR_INVALID;
+        if (!bs[s]->finished) { b->err = "mc_build_write: call mc_build_finish first"; return MC_ERR_STATE; }
+        if (bs[s]->targets.size() != b->targets.size() || (n > 1 && (bs[s]->cfg.key_shard_count != n || bs[s]->cfg.key_shard_index != s))) {
+            b->err = "mc_build_write_shards: builders do not form one key-sharded set"; return MC_ERR_INVALID; }
+    }
+    mc_db_writer* w = nullptr;
+    int rc = mc_build_write_begin(b, name, taxa, ntaxa, &w);
+    if (rc) return rc;
+    for (uint32_t s = 0; s < n && !rc; ++s) { rc = mc_build_write_add(w, bs[s]); if (rc) b->err = bs[s]->err; }
+    const int rc2 = mc_build_write_end(w);
+    return rc ? rc : rc2;
 }
 
 void mc_build_free(mc_builder* b)

@@ -528,7 +528,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const Part& T0 = ctx->parts[0];
     uint64_t locs = 0;
     for (auto& p : ctx->parts) locs += p.locations;
-    const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 256.0;
+    const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * (longLists ? 448 : 8), (uint64_t)big_filter_grid(n) * 4 * 1024));   // >= one full list per wave
     if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;

@@ -194,12 +194,13 @@ class GpuSynth:
             raise RuntimeError(f"mcs_reads -> {rc}")
 
 
-def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_bytes: int = 3 << 30, report=None, key_shard=(0, 1), **cfg):
+def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_bytes: int = 3 << 30, report=None, key_shard=(0, 1), write_to: str | None = None, **cfg):
     """The collection as a query table in HBM, built by the product's builder (mc_build_*) from targets that are generated on the
     device group by group: `shards` key-shard passes (every pass sketches all targets and keeps 1/shards of the features, sorts them
     and inserts them into the table: mc_build_table_*), so that neither the targets (150 Gbp) nor all (feature, location) pairs
     (2 x 10^10) ever exist at once.  key_shard = (i, n): only the features of key shard i of n (mc_key_owner) -- one rank's table in
     Mode K; its `shards` build passes are the sub-shards i * shards .. i * shards + shards - 1 of n * shards.
+    write_to: also write the database as files <write_to>.meta / .cache0 in the reference's format, shard by shard (mc_build_write_*).
     cfg: Builder / mc_config fields (max_candidates, max_load_factor, target_id_bytes, ...).
     -> (api.Database, info dict with seconds per phase)"""
     import time
@@ -226,6 +227,7 @@ def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_byte
     info = {"targets": n, "bases": int(lens.sum()), "shards": shards, "seconds": {"generate": 0.0, "sketch": 0.0, "sort": 0.0, "insert": 0.0}}
     names = [f"SYN_{t:06d}.1".encode() for t in range(n)]
     db = None
+    writer = None
     L = api.lib()
     L.mc_build_add_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int64, C.c_char_p, C.c_uint64]
     t_all = time.time()
@@ -257,11 +259,18 @@ def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_byte
             db = b.table_begin(int(k0 * shards * 1.02) + (1 << 16), int(v0 * shards * 1.04) + (1 << 20)) if shards > 1 else b.table_begin(max(k0, 1), max(v0, 1))
         b.table_add(db)
         t2 = time.time()
+        if write_to:
+            if writer is None:
+                writer = b.write_begin(write_to, spec.taxa())
+            b.write_add(writer)
+            info["seconds"]["write_files"] = info["seconds"].get("write_files", 0.0) + time.time() - t2
         info["seconds"]["sort"] += t1 - t0; info["seconds"]["insert"] += t2 - t1
         if report:
             report(f"shard {sh + 1}/{shards}: {b.counts()} (features, locations), {time.time() - t_all:.1f} s")
         b.free()
     api.Builder.table_end(db)
+    if writer is not None:
+        api.Builder.write_end(writer)
     del buf
     torch.cuda.empty_cache()
     info["seconds"] = {k: round(v, 2) for k, v in info["seconds"].items()}
