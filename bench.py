@@ -384,7 +384,8 @@ def main():
         workload = (f"configs[{3 if (args.pairs or mode != 'R') else 2}]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
                     f"(genus>species>strain phylogeny, uint32 target ids, {how}{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
                     f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
-        pmc_tag = "r02" if (mode == "R" and not args.pairs) else "r02m"
+        # the committed PMC passes (profiles/r02_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
+        pmc_tag = "r02" if (mode == "R" and not args.pairs and args.scale == 1.0 and B == 5_000_000) else "r02-none"
     build_s = time.time() - t0
     db_info = db.info()
 
