@@ -364,8 +364,19 @@ def main():
             db, build_info = synthdb.build_database(spec, device=local, shards=kshards, key_shard=(rank, world), max_candidates=K, max_load_factor=lf,
                                                     report=say)
         else:
-            db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say,
-                                                    write_to=(args.reference_files if (rank == 0 and world == 1) else "") or None)
+            write_to = (args.reference_files if (rank == 0 and world == 1) else "") or None
+            if write_to:
+                # the files (and the reference's copy of them in RAM) must fit the memory this process group is granted: a full-scale set
+                # (190 GB, twice) does not fit the GPU boxes' allowance -- that run took the box down; mid scale (19 GB) is fine
+                need = spec.total_bases // 112 * 16 * 9 * 2.5
+                try:
+                    lim = open("/sys/fs/cgroup/memory.max").read().strip()
+                    lim = float("inf") if lim == "max" else float(lim)
+                except OSError:
+                    lim = float("inf")
+                if need > 0.5 * lim or need > 120e9:
+                    sys.exit(f"--reference-files: about {need / 1e9:.0f} GB of files + reference tables do not fit this box's memory allowance; use --scale <= 0.2")
+            db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say, write_to=write_to)
         gen = synthdb.GpuSynth(local)
         P = synthdb.read_params(spec, 4100 if args.pairs else 3100, paired=args.pairs)
         assert P.row_bytes == PAD_LEN
@@ -430,7 +441,7 @@ def main():
         j = i % nbuf
         finish(j)                                            # the gather that used this buffer two batches ago
         if mode == "K":
-            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_allhits=True)
+            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=True)
             out_bufs[j].copy_(classify_key_sharded_device(db, res, nloc, K, max_win))   # all-to-all of the partial lists, union, rows 8-10
             torch.cuda.current_stream().synchronize()
         else:

@@ -189,6 +189,8 @@ typedef struct {
 
 #define MC_WANT_ALLHITS  1   /* keep the sorted location lists (hit_offsets / hits) */
 #define MC_WANT_FEATURES 2   /* keep the window sketches (features) */
+#define MC_WANT_PARTIAL_HITS 4 /* keep the location lists (hit_offsets / hits) in ANY order inside a list: what a key-sharded context hands to
+                                 the exchange of Mode K (the owner sorts the union); unlike MC_WANT_ALLHITS this keeps the fast lane path */
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);
 int mc_synchronize(mc_ctx* ctx);

@@ -496,7 +496,10 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
 
 static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st)
 {
-    const int wantAllhits = flags & MC_WANT_ALLHITS;
+    // MC_WANT_PARTIAL_HITS: the location lists as they are (unsorted), lane path allowed -- a key shard's side of Mode K; the queries the
+    // lane path does not take go through the wave kernels as with MC_WANT_ALLHITS (their lists come out sorted, which is allowed)
+    const bool wantPartial = (flags & MC_WANT_PARTIAL_HITS) != 0 && !(flags & MC_WANT_ALLHITS);
+    const int wantAllhits = (flags & MC_WANT_ALLHITS) | (wantPartial ? 1 : 0);
     const bool wantFeatures = (flags & MC_WANT_FEATURES) != 0;
     if (!ctx->tableReady) return fail(ctx, MC_ERR_STATE, "no database loaded (every part needs mc_load_begin .. mc_load_end)");
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
@@ -515,7 +518,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4))) return rc;
     // the lane path delivers top candidates only: -allhits and K > 4 go through the wave kernels
-    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAllhits && lane_candidates_supported(K);
+    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && (!wantAllhits || wantPartial) && lane_candidates_supported(K);
     if ((wantFeatures || lanePath) && (rc = ensure(ctx, P.bFeatures, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, P.bPsize, nfeat * 4))) return rc;
     if ((rc = ensure(ctx, P.bPpay, nfeat * 8))) return rc;
@@ -545,6 +548,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if (lanePath) {
         ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
         ws.bigMin = ctx->bigMin;
+        ws.partialLists = wantPartial ? 1u : 0u;
         ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap;
         ws.chunkList = (uint2*)P.bChunkList.p;
     }
@@ -576,8 +580,9 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         // small batches take one look at the work lists and launch only the kernels with work (a launch costs as much as such a
         // batch's kernel: 0.37 -> 0.32 ms per 65 536 reads); large ones skip the round trip and launch everything
         uint32_t all[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-        uint32_t* hcnt = all;
-        if (n <= (1u << 20)) {
+        uint32_t none[16] = {0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};      // partial lists: no candidate kernels, the wave kernels for the rest
+        uint32_t* hcnt = wantPartial ? none : all;
+        if (!wantPartial && n <= (1u << 20)) {
             if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
             hcnt = reinterpret_cast<uint32_t*>(P.hTotal + 1);
             launch_flag_count(ws, n, st);
@@ -595,7 +600,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
             { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         }
-        waveWork = hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
+        waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }
@@ -620,6 +625,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if ((rc = ensure(ctx, P.bCscr, hb))) return rc;
         if (taxkey && (rc = ensure(ctx, P.bCscr2, hb))) return rc;
         ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
+        if (wantPartial && lanePath) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, st); }
         {
             ScopedTimer t(ctx, "sort_candidates", st);
             launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits != 0, P.bCands.p, st);

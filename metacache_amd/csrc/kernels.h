@@ -107,6 +107,7 @@ struct Workspace {           // device buffers sized by the host for this batch
                              //            6 = long read handled by the chunk lane kernels
     uint32_t* midCount;      // [16]; [8] = third work list of hash_cands_kernel (129..256);       lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
     uint2*    chunkList;     // [W + n]    {query, chunk}: long single reads, cut into one-window chunks for the chunk lane kernels
+    uint32_t  partialLists;  // 1: every lane-path query hands its entry table over and ends there (MC_WANT_PARTIAL_HITS: gather_lists_kernel copies the lists)
     uint32_t  bigMin;        // lists longer than this (and > 256) from <= 64 found features go to big_filter_kernel (midCount[9], list 6), which
                              // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
     uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
@@ -153,6 +154,7 @@ void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
+void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);
 uint32_t big_filter_grid(uint32_t n);     // blocks of 4 waves the filter runs with: the pool is cut into one slice per wave
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);

@@ -19,7 +19,7 @@
 namespace mcamd {
 
 // per-query state: what is still to be done (Workspace::qflag)
-constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6;
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6, kFlagGather = 7;
 
 // ================================================================================================
 // wave64 primitives
@@ -1780,7 +1780,8 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     // the row -- no second round of lookups.  Rows that are still in LDS are written out by the WAVE: row after row, one lane per
     // entry, so that a row becomes two contiguous stores instead of 2 x entries scattered ones (the per-lane version of this
     // hand-over cost as much as a third of the lookups on strain-rich tables).
-    const bool hand = valid && (H > kLaneHits || over);
+    // (ws.partialLists: the caller wants every query's location list as it is -- a key shard's partial lists -- so every row is handed over)
+    const bool hand = valid && (H > kLaneHits || over || ws.partialLists);
     const bool coop = hand && !over;
     const uint32_t lane = threadIdx.x & 63u;
     if (coop) {
@@ -1815,6 +1816,12 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         }
     }
     if (!valid) return;
+    if (hand && ws.partialLists) {
+        // gather_lists_kernel copies the lists to their place in ws.hits (hitOff = scan of hitScan); entries = the found features
+        ws.hitScan[q] = H <= kMaxHitsPerQuery ? H : 0u;
+        ws.qflag[q] = kFlagGather;
+        return;
+    }
     if (hand) {
         const uint32_t nent = gnent;
         if (H > kMidMax) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;   // the wave kernel reads all nf slots
@@ -1944,6 +1951,48 @@ void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, c
         hipLaunchKernelGGL(chunk_finish_kernel, dim3(1024), dim3(256), 0, st, sp.s, ws);
     }
 }
+// Mode K, shard side: the location lists of the lane path's queries as they are (any order inside a list; the owner rank sorts the
+// union), copied from the table to ws.hits + hitOff[q].  One wave per 64 queries' flags, then one query at a time: its found
+// features (entry table of probe_cands: nfound entries from fbase on), bucket after bucket, coalesced.
+__global__ __launch_bounds__(256) void gather_lists_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t base = waveId * 64; base < b.n; base += nWaves * 64) {
+        const uint32_t qq = base + lane;
+        uint64_t m = __ballot(qq < b.n && ws.qflag[qq] == kFlagGather);
+        while (m) {
+            const uint32_t j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t q = base + j;
+            const uint32_t fbase = ws.winOff[q] * s, nent = ws.qstat[q].nfound;
+            uint64_t* dst = ws.hits + ws.hitOff[q];
+            for (uint32_t e0 = 0; e0 < nent; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
+                const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
+                const uint32_t incl = wave_incl_scan_u32(sz, lane);
+                if (sz == 1) dst[incl - 1] = pay;                                  // a single location is its own payload
+                uint64_t lists = __ballot(sz > 1);
+                while (lists) {
+                    const uint32_t l = __ffsll((unsigned long long)lists) - 1;
+                    lists &= lists - 1;
+                    const uint32_t lsz = rdlane(sz, l), lat = rdlane(incl, l) - lsz;
+                    const uint64_t* src = tab.values + rdlane64(pay, l);
+                    for (uint32_t t = lane; t < lsz; t += 64) dst[lat + t] = src[t];
+                }
+                dst += rdlane(incl, 63);
+            }
+            if (lane == 0) ws.qflag[q] = kFlagDone;
+        }
+    }
+}
+void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(gather_lists_kernel, dim3(std::min<uint32_t>((b.n + 255) / 256, 256 * 8)), dim3(256), 0, st, b, sp.s, tab, ws);
+}
+
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                         const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st)
 {

@@ -268,8 +268,8 @@ def exchange_partial_lists(offsets: torch.Tensor, hits: torch.Tensor, group=None
 
 
 def classify_key_sharded_device(db, res, n: int, K: int, max_win_uniform: int, lowest: int = 0, group=None) -> torch.Tensor:
-    """Mode K for one batch on this rank's GPU: res = db.query_device(..., want_allhits=True) of the key-sharded context db over all
-    n reads.  Returns int32 [m, K, 4] for this rank's read shard (gather_candidates hands the shards to rank 0)."""
+    """Mode K for one batch on this rank's GPU: res = db.query_device(..., want_partial_hits=True) (or want_allhits) of the key-sharded
+    context db over all n reads.  Returns int32 [m, K, 4] for this rank's read shard (gather_candidates hands the shards to rank 0)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     device = torch.device("cuda", db.cfg.device)
