@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace
             if (lane == 0) {
                 QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nfeat;   // probe steps are not counted on this path
                 ws.qstat[q] = qs;
-                ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
+                ws.hitScan[q] = (H <= kMaxHitsPerQuery && (H > kLdsCap || ws.partialLists)) ? H : 0u;   // (lists wanted: every query gets its segment)
                 ws.qflag[q] = kFlagCands;
             }
         }
