@@ -212,8 +212,10 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowest_ra
 /* Mode K owner side in ONE call, everything on the device: the partial lists of num_sources key shards for this rank's num_queries
  * reads -- counts[s * num_queries + i] locations of read i from source s; each source's locations back to back in read order, the
  * sources' blocks back to back in hits (exactly what an all-to-all-v of the shards' sorted partial lists delivers; total_hits = its
- * receive size, known to the host from the split sizes) -- are concatenated per read and go through rows 8-10 like
- * mc_candidates_from_hits.  Replaces the reference's per-part forwarding chain (query_batch.cu:464-527, :638-652). */
+ * receive size, known to the host from the split sizes) -- are concatenated per read and go through rows 8-10: united lists of more
+ * than 256 locations through the target filter and the (target, window) counting of the replicated mode (the union buffer standing
+ * in for the table's location store), the others through the sort of mc_candidates_from_hits.  out->hits / hit_offsets = the united
+ * lists (sorted only where the sort ran).  Replaces the reference's per-part forwarding chain (query_batch.cu:464-527, :638-652). */
 typedef struct {
     const uint32_t*    counts;        /* [num_sources * num_queries] */
     const mc_location* hits;          /* [total_hits] */

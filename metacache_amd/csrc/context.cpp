@@ -704,14 +704,37 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) ||
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))) ||
         (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
-        (rc = ensure(ctx, P.bPpay, (size_t)S * (n + 2) * 8)))
+        (rc = ensure(ctx, P.bPpay, ((size_t)S * (n + 2) + n + 1) * 8)) || (rc = ensure(ctx, P.bPsize, (size_t)(n + 1) * 4)) ||
+        (rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4)) || (rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4)) ||
+        (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bMid, 64 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)))
         return rc;
-    launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, (uint64_t*)P.bPpay.p, (uint64_t*)P.bHitOff.p,
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * 448, (uint64_t)big_filter_grid(n) * 4 * 1024));
+    if ((rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
+    // srcStart (union) and the one-entry-per-read tables of the filtered path share bPpay: [S * (n + 2)] u64 | [n] u64
+    uint64_t* srcStart = (uint64_t*)P.bPpay.p;
+    launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
+    // Long united lists (RefSeq scale: 1 300 locations per read) take the filtered path of the replicated mode instead of a sort: the union
+    // buffer stands in for the table's location store, a read's whole list is ONE entry of it (rounds of 16 / 64 locations); what the
+    // filter cannot take (more than 16 384 locations, wide window ranges) and what it hands back goes through the sort as before.
+    const bool filtered = lane_candidates_supported(K) && ctx->useLanePath;
+    if (filtered) {
+        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
+        ws.bigMin = ctx->bigMin; ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap;
+        ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = srcStart + (size_t)S * (n + 2);
+        ws.winOff = (uint32_t*)P.bWinOff.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bWinCount.p;
+        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 64, st));
+        launch_owner_classify(b, ws, std::max<uint32_t>(ctx->bigMin, 256u), st);
+        DeviceTable utab{nullptr, ws.hits, 0, 0xFFFFFFFFu, 1};
+        const SketchParams one{16, 1, 16, 1};                                  // step D finds a read's entry at winOff[q] * s = q
+        { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, one, utab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, one, utab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, one, utab, ws, K, taxkey, P.bCands.p, st); }
+    }
     DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
     {
         ScopedTimer t(ctx, "cands_from_hits", st);

@@ -671,6 +671,7 @@ __global__ __launch_bounds__(256) void cands_from_hits_kernel(BatchView b, Devic
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     if (q >= b.n) return;
+    if (ws.qflag && ws.qflag[q] != kFlagCands) return;           // (owner side of Mode K: the long lists took the filtered path)
     SortLds& L = lds[wave];
     mc_candidate_dev* out = cands + (size_t)q * K;
     const uint64_t hoff = ws.hitOff[q];
@@ -726,6 +727,43 @@ __global__ __launch_bounds__(256) void union_copy_kernel(const uint32_t* __restr
         base += srcStart[(size_t)s * (m + 1) + m];
     }
 }
+// Mode K, owner side: which united lists take the filtered path (big_filter_kernel / big_count_kernel with the union buffer standing in
+// for the table's location store: ONE entry per read = its whole list) and which the sort.  Also the identity 'window offsets' the
+// counting kernel's step D finds a read's entry through.
+__global__ __launch_bounds__(256) void owner_classify_kernel(BatchView b, Workspace ws, uint32_t minLen)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool big = false;
+    uint32_t H = 0, mw = 0;
+    if (q < b.n) {
+        const uint64_t H64 = ws.hitOff[q + 1] - ws.hitOff[q];
+        mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+        big = H64 > minLen && H64 <= 0xFFFFull && mw <= 8u;          // (8 = kHashWin, the widest window range the counting kernel takes)
+        H = (uint32_t)min(H64, (uint64_t)0xFFFFFFFFu);
+        ws.winOff[q] = q;
+        if (q + 1 == b.n) ws.winOff[b.n] = b.n;
+        ws.qflag[q] = big ? kFlagMid : kFlagCands;
+        if (big) {
+            ws.psize[q] = H; ws.ppay[q] = ws.hitOff[q];
+            QueryStat qs; qs.hits = H; qs.nfeat = 0; qs.nfound = 1; qs.nsteps = 0;
+            ws.qstat[q] = qs;
+        }
+    }
+    const uint64_t mask = __ballot(big);
+    if (big) {
+        const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&ws.midCount[9], (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        reinterpret_cast<uint4*>(ws.midList)[(size_t)6 * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, q, 1u | (H << 12), mw);
+    }
+}
+void launch_owner_classify(const BatchView& b, const Workspace& ws, uint32_t minLen, hipStream_t st)
+{
+    if (b.n) hipLaunchKernelGGL(owner_classify_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, ws, minLen);
+}
+
 void launch_union_partial(const uint32_t* counts, uint32_t sources, uint32_t m, const uint64_t* hits, uint32_t* tot, uint64_t* srcStart, uint64_t* hitOff,
                           uint64_t* out, void* scanTmp, hipStream_t st)
 {

@@ -113,6 +113,32 @@ def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K):
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, counts[i]))
+    # Mode K's two halves on the same lists: the shard side hands the lists over as they are (MC_WANT_PARTIAL_HITS, lane path), the
+    # owner side unites them (one source here) and sends the long ones through the same filter with the union buffer as its table
+    import torch
+    sub = [r for r in reads[:1500] if len(r) == 150]
+    buf = np.zeros(len(sub) * 152 + 16, dtype=np.uint8)
+    for i, r in enumerate(sub):
+        buf[i * 152:i * 152 + 150] = np.frombuffer(r, dtype=np.uint8)
+    dseq = torch.from_numpy(buf).cuda()
+    qinfo = torch.zeros((len(sub), 4), dtype=torch.int32, device="cuda")
+    qinfo[:, 0] = torch.arange(len(sub), dtype=torch.int32, device="cuda") * 152; qinfo[:, 1] = 150; qinfo[:, 2] = qinfo[:, 0]
+    res = db.query_device(dseq.data_ptr(), qinfo.data_ptr(), len(sub), len(sub) * 152, max_win_uniform=3, want_partial_hits=True)
+    off = torch.zeros(len(sub) + 1, dtype=torch.int64, device="cuda")
+    db.copy_results(off.data_ptr(), res.hit_offsets, (len(sub) + 1) * 8); db.synchronize()
+    hits = torch.zeros(int(off[-1]), dtype=torch.int64, device="cuda")
+    db.copy_results(hits.data_ptr(), res.hits, hits.numel() * 8); db.synchronize()
+    cnt = (off[1:] - off[:-1]).to(torch.int32).contiguous()
+    r2 = db.candidates_from_partial_hits(cnt.data_ptr(), hits.data_ptr(), hits.numel(), len(sub), 1, max_win_uniform=3, lowest=lowest)
+    oc = torch.zeros((len(sub), K, 4), dtype=torch.int32, device="cuda")
+    db.copy_results(oc.data_ptr(), r2.cands, len(sub) * K * 16); db.synchronize()
+    oc = oc.cpu().numpy().view(np.uint32)
+    idx = {r: i for i, r in enumerate(reads)}
+    assert int((cnt > 1024).sum()) > len(sub) // 3
+    for j, r in enumerate(sub):
+        g = cands[idx[r]]
+        assert [tuple(int(x) for x in oc[j, k]) if g[k]["hits"] else 0 for k in range(K)] == \
+               [(int(g[k]["tgt"]), int(g[k]["hits"]), int(g[k]["beg"]), int(g[k]["end"])) if g[k]["hits"] else 0 for k in range(K)], (j, oc[j], g)
     # pairs: twice the features (up to 64 entries), maxWindowsInRange 4 / 5
     mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:110] for r in reads[:800]]
     pc, pcounts, _ = db.query(reads[:800], mates, lowest=lowest, insert_max=400)
