@@ -105,7 +105,11 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
     launch_table_insert(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
                         (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st);
-    launch_table_values(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
+    if (P.compact)
+        launch_table_values_compact(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, reinterpret_cast<uint32_t*>(P.dvalues) + P.valuesStored,
+                                    P.winBits, ctx->locMaxTarget, ctx->locMaxWindow, (unsigned int*)(counters + 3), st);
+    else
+        launch_table_values(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));                   // staging buffers are reused by the next chunk
     P.valuesStored += stored;
@@ -165,6 +169,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1';           // experiment switch
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
+    if (const char* e = std::getenv("MC_COMPACT_LOCATIONS")) ctx->compactAllowed = e[0] != '0';   // tests / tuning
     if (const char* e = std::getenv("MC_BIG_MIN")) ctx->bigMin = (uint32_t)std::max(0, std::atoi(e));   // tests / tuning
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -258,7 +263,13 @@ static int allocate_table(mc_ctx* ctx)
     if (ctx->parts.size() == 1) {
         // one part: the table is built on the device, batch by batch (table_build.hip)
         T.dvaluesCap = nvalues + 1;
-        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, T.dvaluesCap * sizeof(uint64_t)));
+        T.compact = false;
+        if (ctx->locRangeKnown && ctx->compactAllowed) {
+            const uint32_t wb = bits_for(ctx->locMaxWindow), tbits = bits_for(ctx->locMaxTarget);
+            // 0xFFFFFFFF stays free: the kernels' "no location" in the compact form
+            if (wb + tbits <= 32 && (((uint64_t)ctx->locMaxTarget << wb) | ctx->locMaxWindow) < 0xFFFFFFFFull) { T.compact = true; T.winBits = wb; }
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, T.dvaluesCap * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
         HIP_TRY(ctx, hipMalloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
         HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
         int rc = ensure(ctx, ctx->bLdCounters, 4 * sizeof(unsigned long long));
@@ -292,6 +303,22 @@ static int load_batch_device(mc_ctx* ctx, const uint32_t* keys, const uint8_t* s
         values += fileVals * vb;
         done += nb;
     }
+    return MC_OK;
+}
+
+int mc_load_location_range(mc_ctx* ctx, uint32_t maxTarget, uint32_t maxWindow)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    for (auto& p : ctx->parts) if (p.announced) return fail(ctx, MC_ERR_STATE, "mc_load_location_range: call it before mc_load_begin");
+    ctx->locRangeKnown = true; ctx->locMaxTarget = maxTarget; ctx->locMaxWindow = maxWindow;
+    return MC_OK;
+}
+
+int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4])
+{
+    if (!ctx || !layout || ctx->parts.empty()) return MC_ERR_INVALID;
+    const Part& T = ctx->parts[0];
+    layout[0] = T.compact ? 4 : 8; layout[1] = T.compact ? T.winBits : 0; layout[2] = T.nbuckets; layout[3] = T.valuesStored;
     return MC_OK;
 }
 
@@ -417,6 +444,8 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
                         &ctx->bLdScan};
         for (auto* b : st) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
         if (full) return fail(ctx, MC_ERR_NOMEM, "hash table full");
+        if (c[3]) ctx->locRangeViolated = true;
+        if (c[3]) return fail(ctx, MC_ERR_INVALID, "a location lies outside the range announced with mc_load_location_range");
         ctx->tableReady = true;
         return MC_OK;
     }
@@ -557,6 +586,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const Part& T = ctx->parts[0];
     const bool multiPart = ctx->parts.size() > 1;
     DeviceTable tab{T.dbuckets, T.dvalues, T.nbuckets, multiPart ? 0x00FFFFFFu : 0xFFFFFFFFu, T.maxProbe};
+    if (T.compact) { tab.values = nullptr; tab.values32 = reinterpret_cast<const uint32_t*>(T.dvalues); tab.winBits = T.winBits; }
 
     {
         ScopedTimer t(ctx, "plan", st);
@@ -758,6 +788,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     if (n == "big_min") ctx->bigMin = (uint32_t)std::max<int64_t>(0, value);
     else if (n == "quad_lookup") ctx->quadLookup = value < 0 ? -1 : (value != 0);
     else if (n == "lane_path") ctx->useLanePath = value != 0;
+    else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }

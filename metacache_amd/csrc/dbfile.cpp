@@ -166,20 +166,36 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         firstPart = (uint32_t)cfg.single_part; cfg.num_parts = 1;
     }
     mc_ctx* ctx = nullptr;
-    if ((rc = mc_create(&cfg, &ctx))) return rc;
-    ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
-    ctx->targetCount = m.targetCount;
-    ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
-    ctx->taxa = std::move(m.taxa);
-    m.taxa.clear();
-    // every part is announced first (the merged table is sized for all of them), then loaded in part order
-    for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
-        PartHeader h;
-        rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(firstPart + p), h, m.targetBytes);
-        if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
+    // Single-part databases whose target ids and window ids fit 32 bits together get the compact location store (4 bytes per
+    // location, DeviceTable::values32); the range comes from the target metadata (every target's window count).  Should a file
+    // hold a location outside of what its own metadata says, the load is repeated with 8-byte locations.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = mc_create(&cfg, &ctx))) return rc;
+        ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
+        ctx->targetCount = m.targetCount;
+        ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
+        ctx->taxa = std::move(m.taxa);
+        m.taxa.clear();
+        uint64_t maxWindows = 0;
+        for (const auto& t : ctx->taxa) maxWindows = std::max<uint64_t>(maxWindows, t.windows);
+        const bool tryCompact = attempt == 0 && cfg.num_parts == 1 && m.targetCount > 0 && m.targetCount <= 0xFFFFFFFFull &&
+                                maxWindows > 0 && maxWindows <= 0xFFFFFFFFull;
+        if (tryCompact) rc = mc_load_location_range(ctx, (uint32_t)(m.targetCount - 1), (uint32_t)(maxWindows - 1));
+        // every part is announced first (the merged table is sized for all of them), then loaded in part order
+        for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
+            PartHeader h;
+            rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(firstPart + p), h, m.targetBytes);
+            if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
+        }
+        for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
+            rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
+        if (rc && tryCompact && ctx->locRangeViolated) {
+            m.taxa = std::move(ctx->taxa);
+            mc_destroy(ctx); ctx = nullptr; rc = 0;
+            continue;
+        }
+        break;
     }
-    for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
-        rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
     if (rc) {
         set_global_error(ctx->err);
         mc_destroy(ctx);

@@ -64,7 +64,16 @@ struct DeviceTable {
     uint32_t nbuckets;
     uint32_t tgtMask;         // multi-part tables store (part << 24 | target) as target: mask to get the real id
     uint32_t maxProbe;        // longest probe sequence (in groups) needed by any stored key
+    // COMPACT location store (mc_load_location_range): when the database's target ids and window ids fit 32 bits TOGETHER, a location
+    // is stored as (tgt << winBits) | win in 4 bytes -- same order as the 8-byte form, half the bytes per list on the fabric and in HBM.
+    // values32 != nullptr selects it (values is unused then); the inline singleton payloads of the buckets keep the 8-byte form.
+    const uint32_t* values32 = nullptr;
+    uint32_t winBits = 0;
+
+    __device__ __forceinline__ static uint64_t widen(uint32_t p, uint32_t wb) { return ((uint64_t)(p >> wb) << 32) | (p & ((1u << wb) - 1u)); }
+    __device__ __forceinline__ uint64_t loc(uint64_t i) const { return values32 ? widen(values32[i], winBits) : values[i]; }
 };
+__host__ __device__ inline uint32_t bits_for(uint32_t maxValue) { uint32_t b = 1; while (b < 32 && (maxValue >> b)) ++b; return b; }
 
 struct SketchParams { uint32_t k, s, w, stride; };
 
@@ -147,6 +156,10 @@ void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
                          uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
 void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
+// compact store: dst32[...] = (tgt << winBits) | win; a location beyond (maxTgt, maxWin) raises *rangeErr instead
+void launch_table_values_compact(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
+                                 const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, uint32_t winBits, uint32_t maxTgt,
+                                 uint32_t maxWin, unsigned int* rangeErr, hipStream_t st);
 void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int quadMode, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);

@@ -601,7 +601,7 @@ __device__ __forceinline__ void gather_and_sort(uint64_t* buf, const Workspace& 
             multi &= multi - 1;
             const uint32_t nj = rdlane(sz, j), dj = rdlane(dst, j);
             const uint64_t src = rdlane64(pay, j);
-            for (uint32_t t = lane; t < nj; t += 64) buf[dj + t] = tab.values[src + t];   // coalesced copy
+            for (uint32_t t = lane; t < nj; t += 64) buf[dj + t] = tab.loc(src + t);   // coalesced copy
         }
         base += rdlane(incl, 63);
     }
@@ -949,7 +949,7 @@ __device__ __forceinline__ void fused_candidates(FusedLds& L, uint32_t size, uin
         mm &= mm - 1;
         const uint32_t nj = rdlane(size, j);
         const uint64_t src = rdlane64(pay, j);
-        if (lane < nj) L.sbuf[base + lane] = tab.values[src + lane];    // nj <= H <= 32 < 64
+        if (lane < nj) L.sbuf[base + lane] = tab.loc(src + lane);    // nj <= H <= 32 < 64
         base += nj;
     }
     wave_lds_sync();
@@ -1895,8 +1895,8 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     for (uint32_t i = 0; i < m; ++i) {
         const uint64_t d = L[kLaneHits - m + 1 + i];
         const uint32_t size = (uint32_t)(d >> 48);
-        const uint64_t* __restrict__ src = tab.values + (d & 0xFFFFFFFFFFFFull);
-        for (uint32_t t = 0; t < size; ++t) L[n++] = src[t];
+        const uint64_t src = d & 0xFFFFFFFFFFFFull;
+        for (uint32_t t = 0; t < size; ++t) L[n++] = tab.loc(src + t);
     }
     ws.hitScan[q] = 0;
     for (uint32_t t = 1; t < n; ++t) {                            // row 8: insertion sort by (tgt, win)
@@ -2016,8 +2016,8 @@ __global__ __launch_bounds__(256) void gather_lists_kernel(BatchView b, uint32_t
                     const uint32_t l = __ffsll((unsigned long long)lists) - 1;
                     lists &= lists - 1;
                     const uint32_t lsz = rdlane(sz, l), lat = rdlane(incl, l) - lsz;
-                    const uint64_t* src = tab.values + rdlane64(pay, l);
-                    for (uint32_t t = lane; t < lsz; t += 64) dst[lat + t] = src[t];
+                    const uint64_t src = rdlane64(pay, l);
+                    for (uint32_t t = lane; t < lsz; t += 64) dst[lat + t] = tab.loc(src + t);
                 }
                 dst += rdlane(incl, 63);
             }
@@ -2158,7 +2158,7 @@ __global__ __launch_bounds__(256) void mid_cands_kernel(BatchView b, DeviceTable
                 const uint64_t pay = buf[e];
                 const uint32_t first = sg[e];
                 const bool single = sg[e + 1] - first == 1;
-                const uint64_t kv = i >= H ? ~0ull : single ? pay : tab.values[pay + (i - first)];
+                const uint64_t kv = i >= H ? ~0ull : single ? pay : tab.loc(pay + (i - first));
                 klo[r] = (uint32_t)kv; khi[r] = (uint32_t)(kv >> 32);
             }
         }
@@ -2546,7 +2546,7 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
                         while (entOff[e + 1] <= i) ++e;
                         const uint64_t pay = entPay[e];
                         const uint32_t first = entOff[e];
-                        v[r] = entOff[e + 1] - first == 1 ? pay : tab.values[pay + (i - first)];
+                        v[r] = entOff[e + 1] - first == 1 ? pay : tab.loc(pay + (i - first));
                     }
                 }
             }
@@ -2606,6 +2606,10 @@ constexpr uint32_t kBigBitsLog2 = 14;     // target states
 #define MC_BIG_MIN_SHIFT 3
 #endif
 constexpr uint32_t kBigMinShift = MC_BIG_MIN_SHIFT;   // smallest round: 1 << shift lanes
+#ifndef MC_BIG_MIN_SHIFT_COMPACT
+#define MC_BIG_MIN_SHIFT_COMPACT 4
+#endif
+constexpr uint32_t kBigMinShiftCompact = MC_BIG_MIN_SHIFT_COMPACT;   // compact location store: 16 lanes x 4 bytes = one 64-byte request
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
@@ -2623,12 +2627,13 @@ static_assert(kBigU * 8 <= 128, "two padding entries per lane");
 struct BigShape { uint32_t rounds, shift; };   // rounds of 1 << shift lanes
 
 // entries -> LDS tables; rounds > kBigMaxRounds even at 64 lanes per round: merged buckets of a partitioned database, not handled here
-__device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay)
+__device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay,
+                                              const uint32_t minShift = kBigMinShift)
 {
     if (lane < nent) { T.entPay[lane] = myPay; T.entSz[lane] = mySz; }
     const bool list = lane < nent && mySz > 1;
     const uint32_t r8 = wave_sum_u32(list ? (mySz + 7u) / 8u : 0u), r16 = wave_sum_u32(list ? (mySz + 15u) / 16u : 0u);
-    const uint32_t shift = (kBigMinShift <= 3 && r8 <= kBigMaxRounds) ? 3u : r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
+    const uint32_t shift = (minShift <= 3 && r8 <= kBigMaxRounds) ? 3u : r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
     const uint32_t myRounds = list ? (mySz + G - 1u) >> shift : 0u;
     const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
     const uint32_t R = rdlane(incl, 63);
@@ -2640,29 +2645,43 @@ __device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane,
     return BigShape{R, shift};
 }
 // one sweep over a query's locations: f(v) for the lane's element of every wave load (kEmptyLoc = none), kBigU loads in flight
-template <class F>
+// COMPACT: the table's 4-byte location store (DeviceTable::values32; 0xFFFFFFFF is never a stored location)
+template <bool COMPACT, class F>
 __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const BigShape sh, const uint64_t single, F&& f)
 {
     f(single);
     const uint32_t perLoad = 64u >> sh.shift, grp = lane >> sh.shift, sub = lane & ((1u << sh.shift) - 1u);
     for (uint32_t g0 = 0; g0 < sh.rounds; g0 += kBigU * perLoad) {
-        uint64_t rv[kBigU];
+        if constexpr (COMPACT) {
+            uint32_t rv[kBigU];
 #pragma unroll
-        for (uint32_t u = 0; u < kBigU; ++u) {
-            const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
-            rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + sub] : kEmptyLoc;
+            for (uint32_t u = 0; u < kBigU; ++u) {
+                const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
+                rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values32[(rd & 0xFFFFFFFFFFull) + sub] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kBigU; ++u) f(rv[u] == 0xFFFFFFFFu ? kEmptyLoc : DeviceTable::widen(rv[u], tab.winBits));
+        } else {
+            uint64_t rv[kBigU];
+#pragma unroll
+            for (uint32_t u = 0; u < kBigU; ++u) {
+                const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
+                rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + sub] : kEmptyLoc;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
         }
-#pragma unroll
-        for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
     }
 }
 
 // No atomics on global memory: a wave appends its filtered lists to ITS OWN slice of the pool (a million waves bumping one cursor
 // cost more than the sweeps: 43 ms instead of 14), and the record for big_count_kernel goes to the place of the query's own work
 // record (list 7 runs parallel to list 6; n2 = 0xFFFF marks lists that went to the wave kernel instead).
-template <uint32_t WAVES>
+template <uint32_t WAVES, bool COMPACT>
 __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
+    // COMPACT: locations are read from the 4-byte store and the pool holds them in that form too (its slices are the same number of ENTRIES)
+    using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
     constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
     __shared__ uint32_t bitS[WAVES][kBitWords];
     __shared__ BigTables tabS[WAVES];
@@ -2677,7 +2696,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
     const uint32_t w0 = blockIdx.x * WAVES + wave;
     // this wave's slice of the pool
     const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint64_t* const slice = ws.bigPool + (uint64_t)w0 * sliceCap;
+    pool_t* const slice = reinterpret_cast<pool_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
     uint64_t sliceUsed = 0;
     uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
     uint32_t esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
@@ -2695,7 +2714,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
         }
         const uint32_t mySz = esz & 0xFFFFu;
         const uint64_t myPay = epay;
-        const BigShape sh = big_setup(T, lane, nent, mySz, myPay);
+        const BigShape sh = big_setup(T, lane, nent, mySz, myPay, COMPACT ? kBigMinShiftCompact : kBigMinShift);
         const uint64_t single = (lane < nent && mySz == 1) ? myPay : kEmptyLoc;
         rec = recNext;                                             // the next query's record and entries are on their way meanwhile
         recNext = load_rec(w + 2 * nWaves);
@@ -2707,7 +2726,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
         if (!fallback) {
             // ---- A. target states.  (Holding the list in LDS for sweep B was measured: at 1536 / 1024 / 2048 staged locations the kernel
             //      took 31.6 / 37.2 / 57.5 ms instead of 26.5 per 5 x 10^6 reads -- the LDS costs more waves than the re-read costs.)
-            big_sweep(T, tab, lane, sh, single, [&](uint64_t v) {
+            big_sweep<COMPACT>(T, tab, lane, sh, single, [&](uint64_t v) {
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
                     state_of(v, word, bit1);
@@ -2717,9 +2736,9 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
             });
             wave_lds_sync();
             // ---- B. locations of targets seen twice or more -> this wave's pool slice (as long as they fit), counted
-            uint64_t* dst = slice + sliceUsed;
+            pool_t* dst = slice + sliceUsed;
             const uint32_t room = (uint32_t)min((uint64_t)kBigMaxFiltered, sliceCap - sliceUsed);
-            big_sweep(T, tab, lane, sh, single, [&](uint64_t v) {
+            big_sweep<COMPACT>(T, tab, lane, sh, single, [&](uint64_t v) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
@@ -2729,7 +2748,10 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
                 const uint64_t m = __ballot(keep);
                 if (keep) {
                     const uint32_t at = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (at < room) dst[at] = v;
+                    if (at < room) {
+                        if constexpr (COMPACT) dst[at] = ((uint32_t)(v >> 32) << tab.winBits) | (uint32_t)v;
+                        else dst[at] = v;
+                    }
                 }
                 n2 += (uint32_t)__popcll(m);
             });
@@ -2744,7 +2766,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
     }
 }
 
-template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
+template <uint32_t LOG2S, uint32_t WAVES, bool TAX, bool COMPACT>
 __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
                                                                uint32_t minN2)
@@ -2767,7 +2789,8 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
     uint4 rec = load_rec(w0);
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, n2 = rec.z & 0xFFFFu, nent = rec.z >> 16, maxWin = rec.w;
-        const uint64_t* __restrict__ src = ws.bigPool + rec.y;
+        using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
+        const pool_t* __restrict__ src = reinterpret_cast<const pool_t*>(ws.bigPool) + rec.y;
         rec = load_rec(w + nWaves);
         if (n2 > kList || n2 <= minN2) continue;
         {
@@ -2787,8 +2810,16 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
         auto body = [&](auto perc) {
             constexpr uint32_t PER = decltype(perc)::value;
             uint64_t v[PER];
+            if constexpr (COMPACT) {
+                uint32_t p[PER];
 #pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kEmptyLoc;
+                for (uint32_t r = 0; r < PER; ++r) p[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) v[r] = p[r] == 0xFFFFFFFFu ? kEmptyLoc : DeviceTable::widen(p[r], tab.winBits);
+            } else {
+#pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kEmptyLoc;
+            }
             strong = count_and_pick<LOG2S, PER, TAX>(v, keys, cnts, lane, maxWin, K, taxkey, tab, out, picked);
         };
         const uint32_t per = (n2 + 63u) / 64u;
@@ -2817,12 +2848,12 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
                 const uint32_t fbase = ws.winOff[q] * s;
                 const uint32_t mySz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
                 const uint64_t myPay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
-                const BigShape sh = big_setup(T, lane, nent, mySz, myPay);
+                const BigShape sh = big_setup(T, lane, nent, mySz, myPay, COMPACT ? kBigMinShiftCompact : kBigMinShift);
                 wave_lds_sync();
                 uint64_t best[kLaneK];
 #pragma unroll
                 for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kEmptyLoc;
-                big_sweep(T, tab, lane, sh, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v) {
+                big_sweep<COMPACT>(T, tab, lane, sh, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v) {
                     if (v == kEmptyLoc) return;
                     const uint32_t t = (uint32_t)(v >> 32);
                     bool skip = false;
@@ -2873,16 +2904,24 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
     if (b.n == 0) return;
     mc_candidate_dev* c = (mc_candidate_dev*)cands;
     // persistent grids.  stage 0: the filter; 1: counting of filtered lists up to 512; 2: 513 .. 1024
+    const bool compact = tab.values32 != nullptr;
+    auto count = [&](auto log2s, auto waves, uint32_t grid, uint32_t minN2) {
+        constexpr uint32_t L = decltype(log2s)::value, W = decltype(waves)::value;
+        if (compact) {
+            if (taxkey) hipLaunchKernelGGL((big_count_kernel<L, W, true, true>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
+            else        hipLaunchKernelGGL((big_count_kernel<L, W, false, true>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
+        } else {
+            if (taxkey) hipLaunchKernelGGL((big_count_kernel<L, W, true, false>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
+            else        hipLaunchKernelGGL((big_count_kernel<L, W, false, false>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
+        }
+    };
     if (stage == 0) {
-        hipLaunchKernelGGL((big_filter_kernel<4>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        else         hipLaunchKernelGGL((big_filter_kernel<4, false>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 1) {
-        const uint32_t grid = std::min<uint32_t>(256 * 4, (b.n + 3) / 4);
-        if (taxkey) hipLaunchKernelGGL((big_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
-        else        hipLaunchKernelGGL((big_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+        count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * 4, (b.n + 3) / 4), 0u);
     } else {
-        const uint32_t grid = std::min<uint32_t>(256 * 2, (b.n + 1) / 2);
-        if (taxkey) hipLaunchKernelGGL((big_count_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
-        else        hipLaunchKernelGGL((big_count_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
+        count(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 2>{}, std::min<uint32_t>(256 * 2, (b.n + 1) / 2), 512u);
     }
 }
 uint32_t big_filter_grid(uint32_t n)

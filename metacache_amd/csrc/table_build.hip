@@ -86,10 +86,12 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __res
     if (probe > 1) atomicMax(maxProbe, probe);
 }
 
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void table_values_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n, LoadFilter lf,
                                                            const uint32_t* __restrict__ fileOff, const uint32_t* __restrict__ storeOff,
                                                            const uint8_t* __restrict__ vals, uint32_t tb, uint64_t totalFileVals,
-                                                           uint64_t* __restrict__ dst)
+                                                           uint64_t* __restrict__ dst, uint32_t* __restrict__ dst32, uint32_t winBits,
+                                                           uint32_t maxTgt, uint32_t maxWin, unsigned int* __restrict__ rangeErr)
 {
     const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= totalFileVals) return;
@@ -101,7 +103,16 @@ __global__ __launch_bounds__(256) void table_values_kernel(const uint32_t* __res
     }
     const uint32_t eff = effective_size(keys[lo], sizes[lo], lf);
     const uint32_t t = (uint32_t)(v - fileOff[lo]);
-    if (eff > 1 && t < eff) dst[storeOff[lo] + t] = decode_value(vals + v * (4 + tb), tb);
+    if (eff > 1 && t < eff) {
+        const uint64_t loc = decode_value(vals + v * (4 + tb), tb);
+        if constexpr (COMPACT) {
+            const uint32_t tgt = (uint32_t)(loc >> 32), win = (uint32_t)loc;
+            if (tgt > maxTgt || win > maxWin) atomicExch(rangeErr, 1u);
+            else dst32[storeOff[lo] + t] = (tgt << winBits) | win;
+        } else {
+            dst[storeOff[lo] + t] = loc;
+        }
+    }
 }
 
 }  // namespace
@@ -124,8 +135,17 @@ void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st)
 {
     if (n && totalFileVals)
-        hipLaunchKernelGGL(table_values_kernel, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, keys, sizes, n, lf,
-                           fileOff, storeOff, vals, tb, totalFileVals, dst);
+        hipLaunchKernelGGL(table_values_kernel<false>, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, keys, sizes, n, lf,
+                           fileOff, storeOff, vals, tb, totalFileVals, dst, nullptr, 0u, 0u, 0u, nullptr);
+}
+
+void launch_table_values_compact(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
+                                 const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, uint32_t winBits, uint32_t maxTgt,
+                                 uint32_t maxWin, unsigned int* rangeErr, hipStream_t st)
+{
+    if (n && totalFileVals)
+        hipLaunchKernelGGL(table_values_kernel<true>, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, keys, sizes, n, lf,
+                           fileOff, storeOff, vals, tb, totalFileVals, nullptr, dst32, winBits, maxTgt, maxWin, rangeErr);
 }
 
 }  // namespace mcamd

@@ -30,13 +30,18 @@ def taxid_of(db_taxa, lin, tgt, lowest):
     return 0
 
 
+@pytest.mark.parametrize("store", ["compact", "wide"])
 @pytest.mark.parametrize("name", ["toy32", "toy16"])
-def test_golden_single_and_pairs(golden, name):
+def test_golden_single_and_pairs(golden, name, store, monkeypatch):
+    # both location stores: 4 bytes per location (mc_open_database takes the range from the reference-built file's target metadata)
+    # and the reference's 8
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", "1" if store == "compact" else "0")
     single, p1, p2 = golden.reads()
     exp_hits = golden.expected(name, "single_allhits")
     for rname, mc, low, ins in SINGLE_RULES:
         K = mc if mc else 64
         db = api.Database.open(golden.db_path(name), max_candidates=K, copy_allhits=1, slot_max_queries=700, slot_max_chars=1 << 18)
+        assert db.table_layout()["location_bytes"] == (4 if store == "compact" else 8)
         cands, counts, allhits = db.query(single, lowest=low, insert_max=ins)
         exp = golden.expected(name, "single_" + rname)
         taxa, lin = db.taxa(), db.lineages()
@@ -244,6 +249,7 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad
     merged at species level, against the oracle."""
     from metacache_amd import synth
     monkeypatch.setenv("MC_QUAD_LOOKUP", quad)     # both bucket fetch schemes of probe_cands (the second one is for large tables)
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", quad)   # ... and both location stores: 8 bytes per location / 4 (mc_load_location_range)
     rng = np.random.default_rng(4242 + lowest + K)
     genomes, parents = [], []
     for sp in range(5):
@@ -263,6 +269,7 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad
     mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:120] for r in reads[:1500]]
     odb = cpuref.oracle().open(name)
     db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 12, slot_max_chars=1 << 21)
+    assert db.table_layout()["location_bytes"] == (4 if quad == "1" else 8)
     cands, counts, _ = db.query(reads, lowest=lowest)
     pc, pcounts, _ = db.query(reads[:1500], mates, lowest=lowest, insert_max=400)
     # window ranges wider than 8 (insert size 1200 => 12 windows): the counting kernel refuses, lists up to 256 are sorted in registers
@@ -289,12 +296,13 @@ def test_strain_rich_database_mid_lists_against_oracle(tmp_path, lowest, K, quad
 
 
 @pytest.mark.parametrize("lowest,K", [(0, 1), (0, 2), (0, 4), (4, 2), (4, 3), (6, 4)])
-def test_long_lists_hash_cands_against_oracle(tmp_path, lowest, K):
+def test_long_lists_hash_cands_against_oracle(tmp_path, lowest, K, monkeypatch):
     """6 species x 20 strains (0.5 % divergence, 2 genera): a 150 bp read collects 150..600 locations, a pair up to ~900 -- the
     lists hash_cands_kernel takes (one wave per query, (target, window) counts in an LDS hash table instead of a sort).  Near-identical
     strains make ties in hits the rule, so the order among equals (ascending target, earliest window range) is what is tested;
     sequence level, merged at species and at genus level, against the oracle."""
     from metacache_amd import synth
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", str(K & 1))          # both location stores (8 / 4 bytes per location)
     rng = np.random.default_rng(991 + 10 * lowest + K)
     genomes, parents = [], []
     for sp in range(6):
@@ -317,6 +325,7 @@ def test_long_lists_hash_cands_against_oracle(tmp_path, lowest, K):
     mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:120] for r in reads[:1000]]
     odb = cpuref.oracle().open(name)
     db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 12, slot_max_chars=1 << 21)
+    assert db.table_layout()["location_bytes"] == (4 if K & 1 else 8)
     cands, counts, _ = db.query(reads, lowest=lowest)
     pc, pcounts, _ = db.query(reads[:1000], mates, lowest=lowest, insert_max=400)
     db.close()
@@ -346,6 +355,7 @@ def test_long_reads_chunk_lanes_against_oracle(golden, lowest, K, quad, monkeypa
     short reads in one batch, against the oracle (which is pinned to the reference)."""
     from metacache_amd import synth
     monkeypatch.setenv("MC_QUAD_LOOKUP", quad)
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", quad)
     rng = np.random.default_rng(777 + K)
     names = [golden.db_path("toy32")]
     odb = cpuref.oracle().open(names[0])
@@ -474,3 +484,36 @@ def test_size_independent_properties_at_bench_scale(tmp_path):
     finally:
         os.environ.pop("MC_QUAD_LOOKUP", None)
     assert torch.equal(quad, whole)
+
+
+def test_location_range_is_enforced_and_optional():
+    """mc_load_location_range: a location beyond the announced range fails the load loudly (the compact store could not hold it);
+    without the call, and with ranges that do not fit 32 bits together, the table keeps 8-byte locations."""
+    import ctypes as C
+    L = api.lib()
+    keys = np.array([11, 22, 33], dtype=np.uint32)
+    sizes = np.array([2, 1, 3], dtype=np.uint8)
+    vals = np.array([[5, 0], [9, 1], [7, 2], [1, 0], [2, 1], [300, 2]], dtype=np.uint32)      # {win, tgt}; the last window is 300
+
+    def load(rng):
+        cfg = api.default_config(target_id_bytes=4)
+        h = C.c_void_p()
+        assert L.mc_create(C.byref(cfg), C.byref(h)) == 0
+        if rng:
+            assert L.mc_load_location_range(h, rng[0], rng[1]) == 0
+        assert L.mc_load_begin(h, 0, 3, 6) == 0
+        rc = L.mc_load_batch(h, 0, keys.ctypes.data, sizes.ctypes.data, vals.ctypes.data, 3)
+        rc = rc or L.mc_load_end(h, 0)
+        lay = (C.c_uint64 * 4)()
+        L.mc_table_layout(h, lay)
+        err = L.mc_last_error(h).decode()
+        L.mc_destroy(h)
+        return rc, int(lay[0]), int(lay[1]), err
+    assert load(None)[:2] == (0, 8)
+    assert load((2, 300))[:3] == (0, 4, 9)
+    assert load((2, 511))[:3] == (0, 4, 9)
+    rc, _, _, err = load((2, 299))
+    assert rc != 0 and "range" in err
+    assert load((1 << 20, 1 << 20))[:2] == (0, 8)                  # 21 + 21 bits: stays wide
+    assert load((0xFFFF, 0xFFFF))[:2] == (0, 8)                    # exactly 32 bits, but the all-ones pattern would be a location
+    assert load((0xFFFF, 0xFFFE))[:3] == (0, 4, 16)

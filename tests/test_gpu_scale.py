@@ -90,16 +90,18 @@ def test_builder_device_sources_key_shards_streaming_table(tmp_path, shards):
     db.close(); ofile.close(); oself.close()
 
 
-@pytest.mark.parametrize("lowest,K", [(0, 1), (0, 2), (0, 4), (4, 2), (6, 3)])
-def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K):
+@pytest.mark.parametrize("lowest,K,store", [(0, 1, 4), (0, 2, 8), (0, 4, 4), (4, 2, 4), (6, 3, 8)])
+def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K, store):
     """k = 10: the feature space is so small that every bucket fills up with locations of unrelated targets, as 32-bit features do at
     RefSeq scale: a 150 bp read collects 1000 .. 5000 locations, a handful of them on its true targets -- the lists big_cands_kernel
     filters by target before counting.  Reads of the collection (strong candidates), random reads and reads of a single window
     (fewer than K targets with two hits: the open places go to the smallest single-hit targets), sequence level and merged."""
     monkeypatch.setenv("MC_BIG_MIN", "0")
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", "1" if store == 4 else "0")      # location store: 4 / 8 bytes per location
     spec = synthdb.phylogeny(120, 2, 3, 40_000, 60_000, seed=100 + lowest + K)
     sk = dict(kmerlen=10, sketchlen=16, winlen=121, winstride=112)
     db, info = synthdb.build_database(spec, shards=2, max_candidates=K, **sk)
+    assert db.table_layout()["location_bytes"] == store
     db.set_lineages(spec.lineages())
     odb = scale_util.oracle_database(spec, None, threads=THREADS, with_lineages=True, k=10, s=16, w=121, stride=112)
     cs = synthdb.CpuSynth()
@@ -148,14 +150,16 @@ def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K):
     db.close(); odb.close()
 
 
-@pytest.mark.parametrize("lowest,K", [(0, 2), (0, 4), (4, 3)])
-def test_big_cands_strain_rich_lists_overflow_paths(monkeypatch, lowest, K):
+@pytest.mark.parametrize("lowest,K,store", [(0, 2, 4), (0, 4, 8), (4, 3, 4)])
+def test_big_cands_strain_rich_lists_overflow_paths(monkeypatch, lowest, K, store):
     """4 species x 110 strains: nearly every location of a read's list lies on a target with many hits, so the filter keeps almost
     everything: lists beyond the first instance's 512 go on to the second (1024) and from there to the wave kernel; ties between
     near-identical strains everywhere."""
     monkeypatch.setenv("MC_BIG_MIN", "0")
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", "1" if store == 4 else "0")
     spec = synthdb.phylogeny(2, 2, 110, 20_000, 24_000, seed=300 + lowest + K, div_strain=(0.002, 0.01))
     db, info = synthdb.build_database(spec, shards=1, max_candidates=K)
+    assert db.table_layout()["location_bytes"] == store
     db.set_lineages(spec.lineages())
     odb = scale_util.oracle_database(spec, None, threads=THREADS, with_lineages=True)
     cs = synthdb.CpuSynth()
@@ -198,6 +202,7 @@ def test_two_gbp_database_auto_quad_against_oracle():
     odb = scale_util.oracle_database(spec, scale_util.sample_features(singles + p1 + p2), threads=THREADS)
     st = db.info()
     assert st[5] == len(spec.targets)
+    assert db.table_layout()["location_bytes"] == 4                 # 600 targets x 32 000 windows: the compact store, chosen by the builder
     cands, counts, _ = db.query(singles)
     pc, pcounts, _ = db.query(p1, p2, insert_max=0)
     for i in range(n1):
