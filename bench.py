@@ -489,6 +489,9 @@ def main():
     if rank == 0:
         kt = {k: db.timing_get(k) for k in KERNELS}
         st = db.last_batch_stats()                            # of the last timed batch
+        layout = db.table_layout()
+        if cfg != 1:
+            V = layout["location_bytes"]                       # SURVEY's V = bytes per location as the table holds them: 4 with the compact store
         per_read = 2 if pairs else 1                           # a pair counts as 2 reads (printing.cpp:605-608)
         F, H = st["features"] / (nloc * per_read), st["locations"] / (nloc * per_read)
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
@@ -514,7 +517,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(bytes_per_read * nloc * per_read),
-                         "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3),
+                         "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3), "V": V,
+                         "table_location_bytes": layout["location_bytes"],
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
         # second roofline: 64-byte read requests per second of the dominant kernel against the box's measured random-access

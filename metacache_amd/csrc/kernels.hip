@@ -2353,22 +2353,31 @@ __device__ __forceinline__ uint32_t hash_slot(uint64_t v)
 // table in LDS (keys: 2^LOG2S slots, all empty; cnts: packed 16-bit counters, all zero).  Writes the K candidates of the query to out;
 // returns the number of them that have >= 2 hits (the ones that cannot be displaced by a single-hit target, see big_cands_kernel).
 constexpr uint64_t kEmptyLoc = ~0ull;
-template <uint32_t LOG2S, uint32_t PER, bool TAX>
-__device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uint64_t* keys, uint32_t* cnts, const uint32_t lane, const uint32_t maxWin,
+template <uint32_t LOG2S>
+__device__ __forceinline__ uint32_t hash_slot(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - LOG2S); }
+// KT = uint64_t: keys are locations (tgt << 32) | win.  KT = uint32_t: the compact form (tgt << tab.winBits) | win of tables with the
+// 4-byte location store -- half the key table, 32-bit compare-and-swap; the arithmetic on windows (v - d, win >= d) is the same.
+template <uint32_t LOG2S, uint32_t PER, bool TAX, class KT>
+__device__ __forceinline__ uint32_t count_and_pick(const KT (&v)[PER], KT* keys, uint32_t* cnts, const uint32_t lane, const uint32_t maxWin,
                                                    const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
                                                    mc_candidate_dev* __restrict__ out, uint32_t (&picked)[kLaneK])
 {
     constexpr uint32_t kMask = (1u << LOG2S) - 1;
-    constexpr uint64_t kEmpty = kEmptyLoc;
+    constexpr KT kEmpty = (KT)~(KT)0;
+    constexpr bool kWide = sizeof(KT) == 8;
+    using cas_t = std::conditional_t<kWide, unsigned long long, unsigned int>;
+    const uint32_t wb = kWide ? 32u : tab.winBits;
+    auto tgt_of = [&](KT x) -> uint32_t { if constexpr (kWide) return (uint32_t)(x >> 32); else return (uint32_t)x >> wb; };
+    auto win_of = [&](KT x) -> uint32_t { if constexpr (kWide) return (uint32_t)x; else return (uint32_t)x & ((1u << wb) - 1u); };
     auto count_of = [&](uint32_t slot) -> uint32_t { return reinterpret_cast<const uint16_t*>(cnts)[slot]; };   // ds_read_u16
     uint32_t slot[PER];                                       // slot | claimed << 31
     {
-        unsigned long long old[PER];
+        KT old[PER];
         bool coll = false;
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) {
             slot[r] = hash_slot<LOG2S>(v[r]);
-            old[r] = v[r] != kEmpty ? atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot[r]]), (unsigned long long)kEmpty, (unsigned long long)v[r]) : v[r];
+            old[r] = v[r] != kEmpty ? (KT)atomicCAS(reinterpret_cast<cas_t*>(&keys[slot[r]]), (cas_t)kEmpty, (cas_t)v[r]) : v[r];
             coll = coll || (old[r] != kEmpty && old[r] != v[r]);
         }
         if (__ballot(coll)) {                                  // somebody else's key in the home slot: next slots, one at a time
@@ -2378,7 +2387,7 @@ __device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uin
                     uint32_t sl = slot[r];
                     for (;;) {
                         sl = (sl + 1) & kMask;
-                        old[r] = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[sl]), (unsigned long long)kEmpty, (unsigned long long)v[r]);
+                        old[r] = (KT)atomicCAS(reinterpret_cast<cas_t*>(&keys[sl]), (cas_t)kEmpty, (cas_t)v[r]);
                         if (old[r] == kEmpty || old[r] == v[r]) break;
                     }
                     slot[r] = sl;
@@ -2396,19 +2405,19 @@ __device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uin
     uint32_t ptax[PER];
     if constexpr (TAX) {
 #pragma unroll
-        for (uint32_t r = 0; r < PER; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[(uint32_t)(v[r] >> 32) & tab.tgtMask] : 0u;
+        for (uint32_t r = 0; r < PER; ++r) ptax[r] = (slot[r] >> 31) ? taxkey[tgt_of(v[r]) & tab.tgtMask] : 0u;
     }
     uint32_t T[PER];
 #pragma unroll
     for (uint32_t r = 0; r < PER; ++r) T[r] = (slot[r] >> 31) ? count_of(slot[r] & kMask) : 0u;
     for (uint32_t d = 1; d < maxWin; ++d) {
-        uint64_t k[PER]; uint32_t sl[PER];
+        KT k[PER]; uint32_t sl[PER];
         bool chain = false;
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) {
-            sl[r] = hash_slot<LOG2S>(v[r] - d);
+            sl[r] = hash_slot<LOG2S>((KT)(v[r] - d));
             k[r] = keys[sl[r]];
-            const bool live = (slot[r] >> 31) && (uint32_t)v[r] >= d;
+            const bool live = (slot[r] >> 31) && win_of(v[r]) >= d;
             if (!live) { k[r] = kEmpty; sl[r] = 0xFFFFFFFFu; }   // (target 0, window < d: v - d would equal the empty key)
             chain = chain || (live && k[r] != v[r] - d && k[r] != kEmpty);
         }
@@ -2437,7 +2446,7 @@ __device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uin
         uint64_t hk = 0; uint32_t hw = 0xFFFFFFFFu, hg = 0, hd = 0;
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) {
-            const uint32_t t = (uint32_t)(v[r] >> 32), win = (uint32_t)v[r];
+            const uint32_t t = tgt_of(v[r]), win = win_of(v[r]);
             const uint64_t ck = ((uint64_t)(T[r] & 0xFFFFu) << 32) | (uint32_t)~t;
             const bool take = ((live >> r) & 1u) && (ck > hk || (ck == hk && win < hw));
             if (take) { hk = ck; hw = win; hd = T[r] >> 16; if constexpr (TAX) hg = ptax[r]; else hg = t; }
@@ -2456,7 +2465,7 @@ __device__ __forceinline__ uint32_t count_and_pick(const uint64_t (&v)[PER], uin
 #pragma unroll
             for (uint32_t r = 0; r < PER; ++r) {
                 uint32_t gr;
-                if constexpr (TAX) gr = ptax[r]; else gr = (uint32_t)(v[r] >> 32);
+                if constexpr (TAX) gr = ptax[r]; else gr = tgt_of(v[r]);
                 if (gr == g) live &= ~(1u << r);
             }
             e.tgt = ~(uint32_t)m & tab.tgtMask; e.hits = (uint32_t)(m >> 32); e.end = wm; e.beg = wm - d;
@@ -2598,10 +2607,15 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 // wave kernel.
 // ================================================================================================
 #ifndef MC_BIG_U
-#define MC_BIG_U 16
+#define MC_BIG_U 8
 #endif
-constexpr uint32_t kBigU = MC_BIG_U;      // rounds in flight
-constexpr uint32_t kBigBitsLog2 = 14;     // target states
+constexpr uint32_t kBigU = MC_BIG_U;      // wave loads in flight per wave.  8, 12 or 16 make no difference at equal waves per CU (18.4 / - / 18.0 ms
+                                          // per 5 x 10^6 reads at 16 waves); 8 keeps the kernel at 62 registers and 7.3 KB of LDS per wave,
+                                          // which lets a fifth block onto each CU: 15.9 ms at 20 waves
+#ifndef MC_BIG_BITS
+#define MC_BIG_BITS 14
+#endif
+constexpr uint32_t kBigBitsLog2 = MC_BIG_BITS;     // target states
 #ifndef MC_BIG_MIN_SHIFT
 #define MC_BIG_MIN_SHIFT 3
 #endif
@@ -2614,23 +2628,25 @@ constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
 uint32_t big_filter_grid(uint32_t n);
+static uint32_t big_count_bpc(bool compact)
+{
+    static const uint32_t env = [] { const char* e = std::getenv("MC_BIG_COUNT_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 0u; }();
+    return env ? env : compact ? 6u : 4u;
+}
 // A ROUND = up to G consecutive locations of one bucket, read by G neighbouring lanes; 64 / G rounds share one wave load.  G = 16
 // unless the query's buckets would need more than kBigMaxRounds such rounds (then G = 64): a bucket of 16 locations fills a quarter
 // of a 64-lane round but a whole 16-lane one, one of 49 takes 4 x 16 either way -- at 430 locations per read the sweeps issue a
 // third of the wave loads (26 buckets of 17), at 1 270 (26 buckets of 49) 60 %.
-struct BigTables {                        // per wave: entry table and round table of one query
-    uint64_t entPay[kBigEnt];
-    uint32_t entSz[kBigEnt];
-    uint64_t rounds[kBigMaxRounds + kBigU * 8];
+struct BigTables {                        // per wave: the round table of one query (the entries themselves stay in the lanes' registers:
+    uint64_t rounds[kBigMaxRounds + kBigU * 8];   // 768 bytes less per wave is what lets a sixth block of big_filter_kernel onto a CU)
 };
-static_assert(kBigU * 8 <= 128, "two padding entries per lane");
+static_assert(kBigU * 8 % 64 == 0, "whole waves of padding entries");
 struct BigShape { uint32_t rounds, shift; };   // rounds of 1 << shift lanes
 
 // entries -> LDS tables; rounds > kBigMaxRounds even at 64 lanes per round: merged buckets of a partitioned database, not handled here
 __device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay,
                                               const uint32_t minShift = kBigMinShift)
 {
-    if (lane < nent) { T.entPay[lane] = myPay; T.entSz[lane] = mySz; }
     const bool list = lane < nent && mySz > 1;
     const uint32_t r8 = wave_sum_u32(list ? (mySz + 7u) / 8u : 0u), r16 = wave_sum_u32(list ? (mySz + 15u) / 16u : 0u);
     const uint32_t shift = (minShift <= 3 && r8 <= kBigMaxRounds) ? 3u : r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
@@ -2640,7 +2656,8 @@ __device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane,
     if (R <= kBigMaxRounds) {
         for (uint32_t j = 0; j < myRounds; ++j)
             T.rounds[incl - myRounds + j] = (myPay + (uint64_t)G * j) | ((uint64_t)min(G, mySz - G * j) << 40);
-        T.rounds[R + lane] = 0ull; T.rounds[R + 64 + lane] = 0ull;             // (kBigU * 8 <= 128 entries of padding)
+#pragma unroll
+        for (uint32_t i = 0; i < kBigU * 8; i += 64) T.rounds[R + i + lane] = 0ull;   // the last batch of a sweep reads up to kBigU * 8 entries past R
     }
     return BigShape{R, shift};
 }
@@ -2677,8 +2694,13 @@ __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable&
 // No atomics on global memory: a wave appends its filtered lists to ITS OWN slice of the pool (a million waves bumping one cursor
 // cost more than the sweeps: 43 ms instead of 14), and the record for big_count_kernel goes to the place of the query's own work
 // record (list 7 runs parallel to list 6; n2 = 0xFFFF marks lists that went to the wave kernel instead).
+#ifdef MC_BIG_WPE
+#define MC_BIG_WPE_ATTR __attribute__((amdgpu_waves_per_eu(MC_BIG_WPE, MC_BIG_WPE)))
+#else
+#define MC_BIG_WPE_ATTR
+#endif
 template <uint32_t WAVES, bool COMPACT>
-__global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
+__global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
     // COMPACT: locations are read from the 4-byte store and the pool holds them in that form too (its slices are the same number of ENTRIES)
     using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
@@ -2766,17 +2788,23 @@ __global__ __launch_bounds__(WAVES * 64) void big_filter_kernel(BatchView b, Dev
     }
 }
 
+#ifndef MC_BIG_COUNT_WPE
+#define MC_BIG_COUNT_WPE 6     // compact keys: 6 KB of LDS per wave; at 80 registers six blocks fit a CU (8.0 / 7.3 / 6.9 ms at 16 / 20 / 24 waves)
+#endif
 template <uint32_t LOG2S, uint32_t WAVES, bool TAX, bool COMPACT>
-__global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+__global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT_WPE : 1) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
                                                                uint32_t minN2)
 {
     constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
-    static_assert(sizeof(BigTables) <= kSlots * 8, "step D's tables live in the key table, which is done with by then");
-    __shared__ uint64_t keyS[WAVES][kSlots];
+    // COMPACT: the pool holds 4-byte locations and they are the keys of the (target, window) table as they are: 6 KB of LDS per wave
+    // instead of 10 (24 waves per CU instead of 16), 32-bit compare-and-swap
+    using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
+    static_assert(sizeof(BigTables) <= kSlots * sizeof(pool_t), "step D's tables live in the key table, which is done with by then");
+    __shared__ __attribute__((aligned(16))) pool_t keyS[WAVES][kSlots];
     __shared__ uint32_t cntS[WAVES][kSlots / 2];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint64_t* keys = keyS[wave];
+    pool_t* keys = keyS[wave];
     uint32_t* cnts = cntS[wave];
     BigTables& T = *reinterpret_cast<BigTables*>(keyS[wave]);      // (10 KB instead of 13 KB of LDS per wave: 16 waves per CU instead of 12)
     // the records big_filter_kernel left (list 7, one per query of work list 6); this instance takes the filtered lists that fit its
@@ -2789,7 +2817,6 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
     uint4 rec = load_rec(w0);
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, n2 = rec.z & 0xFFFFu, nent = rec.z >> 16, maxWin = rec.w;
-        using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
         const pool_t* __restrict__ src = reinterpret_cast<const pool_t*>(ws.bigPool) + rec.y;
         rec = load_rec(w + nWaves);
         if (n2 > kList || n2 <= minN2) continue;
@@ -2797,7 +2824,7 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
             uint4* k4 = reinterpret_cast<uint4*>(keys);
             uint4* c4 = reinterpret_cast<uint4*>(cnts);
 #pragma unroll
-            for (uint32_t i = 0; i < kSlots / 2 / 64; ++i) k4[i * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t i = 0; i < kSlots * sizeof(pool_t) / 16 / 64; ++i) k4[i * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
             for (uint32_t i = 0; i < (kSlots / 8 + 63) / 64; ++i) if (i * 64 + lane < kSlots / 8) c4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         }
@@ -2809,17 +2836,9 @@ __global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint
         mc_candidate_dev* out = cands + (size_t)q * K;
         auto body = [&](auto perc) {
             constexpr uint32_t PER = decltype(perc)::value;
-            uint64_t v[PER];
-            if constexpr (COMPACT) {
-                uint32_t p[PER];
+            pool_t v[PER];
 #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) p[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : 0xFFFFFFFFu;
-#pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) v[r] = p[r] == 0xFFFFFFFFu ? kEmptyLoc : DeviceTable::widen(p[r], tab.winBits);
-            } else {
-#pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kEmptyLoc;
-            }
+            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : (pool_t)~(pool_t)0;
             strong = count_and_pick<LOG2S, PER, TAX>(v, keys, cnts, lane, maxWin, K, taxkey, tab, out, picked);
         };
         const uint32_t per = (n2 + 63u) / 64u;
@@ -2919,14 +2938,16 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
         else         hipLaunchKernelGGL((big_filter_kernel<4, false>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 1) {
-        count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * 4, (b.n + 3) / 4), 0u);
+        // blocks per CU by LDS: 40 KB per block with 8-byte keys, 24 KB with the compact ones
+        count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(compact), (b.n + 3) / 4), 0u);
     } else {
-        count(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 2>{}, std::min<uint32_t>(256 * 2, (b.n + 1) / 2), 512u);
+        static const uint32_t bpc2 = [] { const char* e = std::getenv("MC_BIG_COUNT2_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 4u; }();
+        count(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 2>{}, std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2), 512u);
     }
 }
 uint32_t big_filter_grid(uint32_t n)
 {
-    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 4u; }();
+    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 6u; }();    // 26 KB of LDS per block: six per CU (4 / 5 / 6 blocks: 18.4 / 15.9 / 15.0 ms)
     return std::min<uint32_t>(256 * bpc, (n + 3) / 4);
 }
 

@@ -13,7 +13,7 @@ from metacache_amd import api, synth, synthdb
 
 pytestmark = pytest.mark.gpu
 
-THREADS = min(os.cpu_count() or 1, 128)
+THREADS = max(4, 2 * scale_util.effective_cpus())      # the GPU boxes show 256 CPUs and grant 16
 
 
 def _check(got, e, K, tag):
@@ -212,4 +212,43 @@ def test_two_gbp_database_auto_quad_against_oracle():
         _, e = odb.query(p1[i], p2[i], K, 0, 0)
         _check(pc[i], e, K, ("pair", i, pcounts[i]))
     assert np.mean(cands[:, 0]["hits"] >= 8) > 0.9
+    db.close(); odb.close()
+
+
+def test_more_than_2_32_locations_against_oracle():
+    """A table beyond 2^32 locations (location offsets, list store and the builder's streaming shards all past 32 bits): 8 800 targets /
+    33 Gbp of the bench collection's shape (440 genera x 4 species x 5 strains, 2.5 - 5 Mbp), built in 4 key shards; 20 000 reads and
+    4 000 pairs against the oracle's restricted build.  Lists of 300 - 500 locations per read: the filtered path at its short end."""
+    assert "MC_BIG_MIN" not in os.environ and "MC_COMPACT_LOCATIONS" not in os.environ
+    spec = synthdb.phylogeny(440, 4, 5, 2_500_000, 5_000_000, seed=3100)
+    K = 2
+    db, info = synthdb.build_database(spec, shards=4, max_candidates=K)
+    st = db.info()
+    assert st[5] == 8800 and st[7] > (1 << 32), st
+    lay = db.table_layout()
+    assert lay["location_bytes"] == 4 and lay["list_locations"] > (1 << 32), lay
+    import torch
+    gen = synthdb.GpuSynth(0)
+    n1, n2 = 20_000, 4_000
+    P1 = synthdb.read_params(spec, 3100)
+    P2 = synthdb.read_params(spec, 4100, paired=True)
+    a = torch.zeros((n1, P1.row_bytes), dtype=torch.uint8, device="cuda:0")
+    m1 = torch.zeros((n2, P2.row_bytes), dtype=torch.uint8, device="cuda:0")
+    m2 = torch.zeros((n2, P2.row_bytes), dtype=torch.uint8, device="cuda:0")
+    gen.reads(spec, P1, 0, n1, a)
+    gen.reads(spec, P2, 0, n2, m1, m2)
+    torch.cuda.synchronize()
+    singles = [bytes(r[:150]) for r in a.cpu().numpy()]
+    p1 = [bytes(r[:150]) for r in m1.cpu().numpy()]
+    p2 = [bytes(r[:150]) for r in m2.cpu().numpy()]
+    odb = scale_util.oracle_database(spec, scale_util.sample_features(singles + p1 + p2), threads=THREADS)
+    cands, counts, _ = db.query(singles)
+    pc, pcounts, _ = db.query(p1, p2, insert_max=0)
+    assert np.mean(counts > 256) > 0.5, np.percentile(counts, [5, 50, 95])
+    for i in range(n1):
+        _, e = odb.query(singles[i], b"", K, 0, 0)
+        _check(cands[i], e, K, (i, counts[i]))
+    for i in range(n2):
+        _, e = odb.query(p1[i], p2[i], K, 0, 0)
+        _check(pc[i], e, K, ("pair", i, pcounts[i]))
     db.close(); odb.close()
