@@ -203,6 +203,10 @@ typedef struct {
 #define MC_WANT_FEATURES 2   /* keep the window sketches (features) */
 #define MC_WANT_PARTIAL_HITS 4 /* keep the location lists (hit_offsets / hits) in ANY order inside a list: what a key-sharded context hands to
                                  the exchange of Mode K (the owner sorts the union); unlike MC_WANT_ALLHITS this keeps the fast lane path */
+#define MC_SECOND_PIPE 8     /* run on the context's SECOND pipe (own stream, workspace and result buffers): one more caller thread may have a
+                                 call in flight there while another runs on the first pipe, so the kernels of two batches overlap on the
+                                 device the way several query_batch objects do in the reference (query_batch.cuh:369-371).  The
+                                 results of a pipe stay valid until the next call on the SAME pipe. */
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);
 int mc_synchronize(mc_ctx* ctx);
@@ -241,6 +245,8 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
 /* copies out of the ctx-owned result buffers, asynchronous on the context's stream
  * (kind: 0 = device -> device, 1 = device -> host) */
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
+/* the same on the caller's stream (the one its mc_query_device call ran on; NULL = the context's) */
+int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind, void* stream);
 
 /* tuning / test hook (not needed for normal use): the switches the MC_BIG_MIN / MC_QUAD_LOOKUP / MC_NO_LANE_PATH environment variables
  * set at mc_create, on a live context with no batch in flight.  names: "big_min" (location lists longer than this are filtered by

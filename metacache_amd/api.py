@@ -58,7 +58,7 @@ EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_
            "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
-           "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats", "mc_set_tuning",
+           "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats", "mc_set_tuning", "mc_copy_results_on",
            "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_add_target_device", "mc_build_flush", "mc_build_reserve",
            "mc_build_table_begin", "mc_build_table_add", "mc_build_table_end", "mc_build_set_parent", "mc_build_target_windows", "mc_build_remove_ambiguous", "mc_build_counts", "mc_build_add_existing_target", "mc_build_add_locations", "mc_build_finish", "mc_build_finish_shards", "mc_build_write_shards", "mc_build_write", "mc_build_write_begin", "mc_build_write_add", "mc_build_write_end", "mc_build_free", "mc_build_last_error",
            "mc_build_set_query_config"]
@@ -279,10 +279,10 @@ class Database:
     # ---- device path (pointers are device addresses, e.g. torch tensors' data_ptr()) ----------
     def query_device(self, seq_ptr: int, qinfo_ptr: int, n: int, num_chars: int, max_win_ptr: int = 0, max_win_uniform: int = 0,
                      lowest: int = 0, want_allhits: bool = False, want_features: bool = False,
-                     stream: int = 0, want_partial_hits: bool = False) -> McDeviceResults:
+                     stream: int = 0, want_partial_hits: bool = False, second_pipe: bool = False) -> McDeviceResults:
         b = McDeviceBatch(seq_ptr, qinfo_ptr, max_win_ptr or None, max_win_uniform, n, num_chars)
         r = McDeviceResults()
-        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0) | (4 if want_partial_hits else 0), C.byref(r),
+        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0) | (4 if want_partial_hits else 0) | (8 if second_pipe else 0), C.byref(r),
                                           stream or None))
         return r
 
@@ -304,8 +304,10 @@ class Database:
         self._check(L.mc_candidates_from_partial_hits(self.h, C.byref(h), lowest, C.byref(r), stream or None))
         return r
 
-    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False):
-        self._check(lib().mc_copy_results(self.h, dst_ptr, src_ptr, nbytes, 1 if to_host else 0))
+    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False, stream: int = 0):
+        L = lib()
+        L.mc_copy_results_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        self._check(L.mc_copy_results_on(self.h, dst_ptr, src_ptr, nbytes, 1 if to_host else 0, stream or None))
 
     def table_layout(self) -> dict:
         """bytes per stored location (4 = compact store), window bits, buckets, stored list locations (mc_table_layout)"""

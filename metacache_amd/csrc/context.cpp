@@ -218,6 +218,7 @@ void mc_destroy(mc_ctx* ctx)
         if (ownStream && P.stream) (void)hipStreamDestroy(P.stream);
     };
     free_pipe(ctx->pipe0, false);
+    free_pipe(ctx->pipe1, true);
     for (Pipe* p : ctx->pipes) { free_pipe(*p, true); delete p; }
     ctx->pipes.clear(); ctx->freePipes.clear();
     DevBuf* bufs[] = {&ctx->bLdKeys, &ctx->bLdSizes, &ctx->bLdVals, &ctx->bLdFileSz, &ctx->bLdStoreSz, &ctx->bLdFileOff, &ctx->bLdStoreOff,
@@ -520,6 +521,13 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
 {
     if (!ctx || !in || !out) return MC_ERR_INVALID;
+    if (flags & MC_SECOND_PIPE) {
+        if (!ctx->pipe1.stream) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe1.stream, hipStreamNonBlocking));
+        }
+        return query_on_pipe(ctx, ctx->pipe1, in, lowestRank, flags, out, streamv ? (hipStream_t)streamv : ctx->pipe1.stream);
+    }
     return query_on_pipe(ctx, ctx->pipe0, in, lowestRank, flags, out, streamv ? (hipStream_t)streamv : ctx->stream);
 }
 
@@ -562,7 +570,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     for (auto& p : ctx->parts) locs += p.locations;
     const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * (longLists ? 448 : 8), (uint64_t)big_filter_grid(n) * 4 * 1024));   // >= one full list per wave
-    if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -801,11 +809,13 @@ int mc_synchronize(mc_ctx* ctx)
     return MC_OK;
 }
 
-int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind)
+int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind) { return mc_copy_results_on(ctx, dst, src, bytes, kind, nullptr); }
+
+int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind, void* stream)
 {
     if (!ctx || !dst || !src) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream ? (hipStream_t)stream : ctx->stream));
     return MC_OK;
 }
 

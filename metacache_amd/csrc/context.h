@@ -101,6 +101,7 @@ struct mc_ctx {
     // workspace of mc_query_device / mc_candidates_from_hits callers (pipe0.stream == stream); every host batch slot has its own
     // Pipe, so that the H2D copy, the kernels and the D2H copy of different slots overlap on the device
     mcamd::Pipe pipe0;
+    mcamd::Pipe pipe1;                     // MC_SECOND_PIPE callers: a second batch in flight next to pipe0's (stream created on first use)
     std::mutex taxMtx, timerMtx;
     // host batch slots borrow a pipe from this pool between mc_batch_submit and mc_batch_wait: a few batches in flight are
     // enough to overlap H2D, kernels and D2H, and the pool bounds both the device memory and the number of threads inside the

@@ -212,6 +212,40 @@ def test_two_gbp_database_auto_quad_against_oracle():
         _, e = odb.query(p1[i], p2[i], K, 0, 0)
         _check(pc[i], e, K, ("pair", i, pcounts[i]))
     assert np.mean(cands[:, 0]["hits"] >= 8) > 0.9
+    # two batches in flight from two host threads: the context's second pipe (MC_SECOND_PIPE) next to the first, each on its own stream
+    import threading
+    rows = a[:, :152].contiguous() if P1.row_bytes >= 152 else None
+    assert rows is not None
+    seqs = [torch.cat([rows[:n1 // 2].reshape(-1), torch.zeros(16, dtype=torch.uint8, device="cuda:0")]),
+            torch.cat([rows[n1 // 2:].reshape(-1), torch.zeros(16, dtype=torch.uint8, device="cuda:0")])]
+    m = n1 // 2
+    qinfo = torch.zeros((m, 4), dtype=torch.int32, device="cuda:0")
+    qinfo[:, 0] = torch.arange(m, dtype=torch.int32, device="cuda:0") * 152; qinfo[:, 1] = 150; qinfo[:, 2] = qinfo[:, 0]
+    outs = [torch.zeros((m, K, 4), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def worker(t):
+        try:
+            for _ in range(3):
+                r = db.query_device(seqs[t].data_ptr(), qinfo.data_ptr(), m, m * 152, max_win_uniform=3, stream=streams[t].cuda_stream, second_pipe=(t == 1))
+                db.copy_results(outs[t].data_ptr(), r.cands, m * K * 16, stream=streams[t].cuda_stream)
+                streams[t].synchronize()
+        except Exception as e:                                      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    got = torch.cat(outs).cpu().numpy().view(np.uint32)
+    for i in range(n1):
+        for k in range(K):
+            g = cands[i][k]
+            exp = (int(g["tgt"]), int(g["hits"]), int(g["beg"]), int(g["end"])) if g["hits"] else None
+            assert (tuple(int(x) for x in got[i, k]) if got[i, k, 1] else None) == exp, (i, k, got[i], g)
     db.close(); odb.close()
 
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--big-min", default="1024,512,256")
     ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--two-pipes", action="store_true", help="after the single-caller runs: two host threads, one batch in flight each (MC_SECOND_PIPE)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     c2 = dict(bench.CFG2); c2["genera"] = max(2, int(round(c2["genera"] * args.scale)))
@@ -67,6 +68,35 @@ def main():
         kt = {k: db.timing_get(k) for k in bench.KERNELS}
         run = {"big_min": bm, "ms_per_step": round(el / args.steps * 1e3, 3), "Mreads_per_min": round(B * args.steps / el * 60 / 1e6, 1),
                "same_candidates_as_first_setting": same, "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in kt.items() if v[0] > 0.02}}
+        print(json.dumps(run), flush=True)
+        res["runs"].append(run)
+    if args.two_pipes:
+        import threading
+        outs = [torch.zeros((B, 2, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        n_steps = max(4, 2 * args.steps)
+
+        def worker(t, n):
+            st = streams[t]
+            for i in range(t, n, 2):
+                r = db.query_device(batches[i % 2].data_ptr(), qinfo.data_ptr(), B, B * bench.PAD_LEN, max_win_uniform=3, stream=st.cuda_stream,
+                                    second_pipe=(t == 1))
+                db.copy_results(outs[t].data_ptr(), r.cands, B * 32, stream=st.cuda_stream)
+                st.synchronize()
+
+        def run_two(n):
+            th = [threading.Thread(target=worker, args=(t, n)) for t in range(2)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            return time.perf_counter() - t0
+        run_two(4)
+        el = run_two(n_steps)
+        same = bool(torch.equal(outs[0], ref)) and bool(torch.equal(outs[1][: B], (lambda: (step(1), out.clone())[1])()))
+        run = {"two_pipes": True, "ms_per_step": round(el / n_steps * 1e3, 3), "Mreads_per_min": round(B * n_steps / el * 60 / 1e6, 1),
+               "same_candidates": same}
         print(json.dumps(run), flush=True)
         res["runs"].append(run)
     if args.out:
