@@ -257,7 +257,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256",
- * "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_count", "big_count_2", "query_wave", "scan", "sort_candidates"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
+ * "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_filter_2", "big_count", "big_count_2", "query_wave", "scan", "sort_candidates"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);
 int mc_timing_reset(mc_ctx* ctx);
 int mc_timing_get(mc_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);

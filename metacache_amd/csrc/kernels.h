@@ -119,6 +119,7 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint32_t  partialLists;  // 1: every lane-path query hands its entry table over and ends there (MC_WANT_PARTIAL_HITS: gather_lists_kernel copies the lists)
     uint32_t  bigMin;        // lists longer than this (and > 256) from <= 64 found features go to big_filter_kernel (midCount[9], list 6), which
                              // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
+    uint32_t* sliceFill;     // [waves of big_filter_kernel] entries each wave's pool slice holds after the first instance (nullptr: single instance)
     uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
     uint32_t  bigPoolCap;
     uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256

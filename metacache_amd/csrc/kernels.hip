@@ -1143,7 +1143,8 @@ constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
 constexpr uint32_t kLaneU = MC_LANE_U;    // lookups in flight per lane
 constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
 constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: longest list, entries, maxWindowsInRange
-constexpr uint32_t kBigEnt = 64;          // big_cands_kernel: found features per query (one lane each)
+constexpr uint32_t kBigEnt = 64;          // big_filter_kernel: found features per query, one lane each ...
+constexpr uint32_t kBigEPL = 3;           // ... or up to three per lane in its second instance (reads and pairs of 5 .. 10 windows: 2 x 250 bp, 500 bp)
 
 __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
 {
@@ -1871,7 +1872,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // on counting beats sorting (measured per list: 3.3 vs 4.7 ns at 129..256); below, the register sort wins (1.6 vs 2 ns)
         const bool hashOK = nent <= kHashEnt && mw <= kHashWin;
         // 7 = big_cands_kernel (filter first): lists beyond ws.bigMin locations from at most kBigEnt found features
-        const bool bigOK = nent <= kBigEnt && mw <= kHashWin && H > ws.bigMin && H > kMidMax;
+        const bool bigOK = nent <= kBigEnt * kBigEPL && mw <= kHashWin && H > ws.bigMin && H > kMidMax;
         const uint32_t cls = bigOK ? 7u : H <= 64 ? 0u : H <= 128 ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
         ws.qflag[q] = cls != 6 ? kFlagMid : kFlagCands;
         if (cls >= 3 && cls != 6) ws.hitScan[q] = 0u;                            // no segment in HBM
@@ -1887,6 +1888,10 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
                 base = __shfl(base, leader);
                 reinterpret_cast<uint4*>(ws.midList)[(size_t)(c == 7 ? 6u : c) * b.n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nent | (H << 12), b.maxWin ? b.maxWin[q] : b.maxWinUniform);
             }
+        }
+        {   // [10]: how many of the filter's queries have more than kBigEnt entries (its second instance runs only for those)
+            const uint64_t wide = __ballot(cls == 7 && nent > kBigEnt);
+            if (wide && lane == (uint32_t)__ffsll((unsigned long long)wide) - 1) atomicAdd(&ws.midCount[10], (uint32_t)__popcll(wide));
         }
         return;
     }
@@ -2643,19 +2648,34 @@ struct BigTables {                        // per wave: the round table of one qu
 static_assert(kBigU * 8 % 64 == 0, "whole waves of padding entries");
 struct BigShape { uint32_t rounds, shift; };   // rounds of 1 << shift lanes
 
-// entries -> LDS tables; rounds > kBigMaxRounds even at 64 lanes per round: merged buckets of a partitioned database, not handled here
-__device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t mySz, const uint64_t myPay,
+// entries -> LDS tables (EPL entries per lane: entry e * 64 + lane); rounds > kBigMaxRounds even at 64 lanes per round: merged buckets
+// of a partitioned database, not handled here
+template <uint32_t EPL>
+__device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane, const uint32_t nent, const uint32_t (&mySz)[EPL], const uint64_t (&myPay)[EPL],
                                               const uint32_t minShift = kBigMinShift)
 {
-    const bool list = lane < nent && mySz > 1;
-    const uint32_t r8 = wave_sum_u32(list ? (mySz + 7u) / 8u : 0u), r16 = wave_sum_u32(list ? (mySz + 15u) / 16u : 0u);
+    uint32_t m8 = 0, m16 = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < EPL; ++e) {
+        const bool list = e * 64 + lane < nent && mySz[e] > 1;
+        m8 += list ? (mySz[e] + 7u) / 8u : 0u; m16 += list ? (mySz[e] + 15u) / 16u : 0u;
+    }
+    const uint32_t r8 = wave_sum_u32(m8), r16 = wave_sum_u32(m16);
     const uint32_t shift = (minShift <= 3 && r8 <= kBigMaxRounds) ? 3u : r16 <= kBigMaxRounds ? 4u : 6u, G = 1u << shift;
-    const uint32_t myRounds = list ? (mySz + G - 1u) >> shift : 0u;
+    uint32_t myRounds = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < EPL; ++e) myRounds += (e * 64 + lane < nent && mySz[e] > 1) ? (mySz[e] + G - 1u) >> shift : 0u;
     const uint32_t incl = wave_incl_scan_u32(myRounds, lane);
     const uint32_t R = rdlane(incl, 63);
     if (R <= kBigMaxRounds) {
-        for (uint32_t j = 0; j < myRounds; ++j)
-            T.rounds[incl - myRounds + j] = (myPay + (uint64_t)G * j) | ((uint64_t)min(G, mySz - G * j) << 40);
+        uint32_t at = incl - myRounds;
+#pragma unroll
+        for (uint32_t e = 0; e < EPL; ++e) {
+            const uint32_t n = (e * 64 + lane < nent && mySz[e] > 1) ? (mySz[e] + G - 1u) >> shift : 0u;
+            for (uint32_t j = 0; j < n; ++j)
+                T.rounds[at + j] = (myPay[e] + (uint64_t)G * j) | ((uint64_t)min(G, mySz[e] - G * j) << 40);
+            at += n;
+        }
 #pragma unroll
         for (uint32_t i = 0; i < kBigU * 8; i += 64) T.rounds[R + i + lane] = 0ull;   // the last batch of a sweep reads up to kBigU * 8 entries past R
     }
@@ -2664,9 +2684,8 @@ __device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane,
 // one sweep over a query's locations: f(v) for the lane's element of every wave load (kEmptyLoc = none), kBigU loads in flight
 // COMPACT: the table's 4-byte location store (DeviceTable::values32; 0xFFFFFFFF is never a stored location)
 template <bool COMPACT, class F>
-__device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const BigShape sh, const uint64_t single, F&& f)
+__device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const BigShape sh, F&& f)
 {
-    f(single);
     const uint32_t perLoad = 64u >> sh.shift, grp = lane >> sh.shift, sub = lane & ((1u << sh.shift) - 1u);
     for (uint32_t g0 = 0; g0 < sh.rounds; g0 += kBigU * perLoad) {
         if constexpr (COMPACT) {
@@ -2699,7 +2718,9 @@ __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable&
 #else
 #define MC_BIG_WPE_ATTR
 #endif
-template <uint32_t WAVES, bool COMPACT>
+// EPL = 1: the queries with up to 64 found features (one entry per lane).  EPL > 1: the instance for the others (up to 64 * EPL: reads
+// and pairs of 5 .. 10 windows); it runs after the first one on the same grid and goes on in the same pool slices (ws.sliceFill).
+template <uint32_t WAVES, bool COMPACT, uint32_t EPL>
 __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
     // COMPACT: locations are read from the 4-byte store and the pool holds them in that form too (its slices are the same number of ENTRIES)
@@ -2711,56 +2732,76 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
     uint32_t* bits = bitS[wave];
     BigTables& T = tabS[wave];
     const uint32_t total = ws.midCount[9];
+    if (EPL > 1 && ws.midCount[10] == 0) return;                  // no query with more than kBigEnt entries in this batch
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    auto mine = [](uint32_t nent) { return EPL == 1 ? nent <= kBigEnt : nent > kBigEnt; };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
     // this wave's slice of the pool
     const uint64_t sliceCap = ws.bigPoolCap / nWaves;
     pool_t* const slice = reinterpret_cast<pool_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
-    uint64_t sliceUsed = 0;
+    uint64_t sliceUsed = (EPL > 1 && ws.sliceFill) ? ws.sliceFill[w0] : 0u;
     uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
-    uint32_t esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
-    uint64_t epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
+    uint32_t esz[EPL]; uint64_t epay[EPL];
+    auto load_entries = [&](const uint4& r) {
+        const uint32_t ne = mine(r.z & 0xFFFu) ? (r.z & 0xFFFu) : 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < EPL; ++e) {
+            esz[e] = e * 64 + lane < ne ? ws.psize[r.y + e * 64 + lane] : 0u;
+            epay[e] = e * 64 + lane < ne ? ws.ppay[r.y + e * 64 + lane] : 0ull;
+        }
+    };
+    load_entries(rec);
     auto state_of = [&](uint64_t v, uint32_t& word, uint32_t& bit1) {
         const uint32_t h = ((uint32_t)(v >> 32) * 0x9E3779B1u) >> (32 - kBigBitsLog2);
         word = h >> 4; bit1 = 1u << (2u * (h & 15u));
     };
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
+        if (!mine(nent)) {                                         // the other instance's query
+            rec = recNext; recNext = load_rec(w + 2 * nWaves);
+            load_entries(rec);
+            continue;
+        }
         {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
 #pragma unroll
             for (uint32_t i = 0; i < kBitWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         }
-        const uint32_t mySz = esz & 0xFFFFu;
-        const uint64_t myPay = epay;
-        const BigShape sh = big_setup(T, lane, nent, mySz, myPay, COMPACT ? kBigMinShiftCompact : kBigMinShift);
-        const uint64_t single = (lane < nent && mySz == 1) ? myPay : kEmptyLoc;
+        uint32_t mySz[EPL]; uint64_t myPay[EPL], single[EPL];
+#pragma unroll
+        for (uint32_t e = 0; e < EPL; ++e) {
+            mySz[e] = esz[e] & 0xFFFFu; myPay[e] = epay[e];
+            single[e] = (e * 64 + lane < nent && mySz[e] == 1) ? myPay[e] : kEmptyLoc;     // inline locations of buckets of one
+        }
+        const BigShape sh = big_setup<EPL>(T, lane, nent, mySz, myPay, COMPACT ? kBigMinShiftCompact : kBigMinShift);
         rec = recNext;                                             // the next query's record and entries are on their way meanwhile
         recNext = load_rec(w + 2 * nWaves);
-        esz = lane < (rec.z & 0xFFFu) ? ws.psize[rec.y + lane] : 0u;
-        epay = lane < (rec.z & 0xFFFu) ? ws.ppay[rec.y + lane] : 0ull;
+        load_entries(rec);
         wave_lds_sync();
         bool fallback = sh.rounds > kBigMaxRounds;
         uint32_t n2 = 0;
         if (!fallback) {
             // ---- A. target states.  (Holding the list in LDS for sweep B was measured: at 1536 / 1024 / 2048 staged locations the kernel
             //      took 31.6 / 37.2 / 57.5 ms instead of 26.5 per 5 x 10^6 reads -- the LDS costs more waves than the re-read costs.)
-            big_sweep<COMPACT>(T, tab, lane, sh, single, [&](uint64_t v) {
+            auto mark = [&](uint64_t v) {
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
                     state_of(v, word, bit1);
                     const uint32_t old = atomicOr(&bits[word], bit1);
                     if (old & bit1) atomicOr(&bits[word], bit1 << 1);
                 }
-            });
+            };
+#pragma unroll
+            for (uint32_t e = 0; e < EPL; ++e) mark(single[e]);
+            big_sweep<COMPACT>(T, tab, lane, sh, mark);
             wave_lds_sync();
             // ---- B. locations of targets seen twice or more -> this wave's pool slice (as long as they fit), counted
             pool_t* dst = slice + sliceUsed;
             const uint32_t room = (uint32_t)min((uint64_t)kBigMaxFiltered, sliceCap - sliceUsed);
-            big_sweep<COMPACT>(T, tab, lane, sh, single, [&](uint64_t v) {
+            auto take = [&](uint64_t v) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
                     uint32_t word, bit1;
@@ -2776,7 +2817,10 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
                     }
                 }
                 n2 += (uint32_t)__popcll(m);
-            });
+            };
+#pragma unroll
+            for (uint32_t e = 0; e < EPL; ++e) take(single[e]);
+            big_sweep<COMPACT>(T, tab, lane, sh, take);
             fallback = n2 > room;                                  // too long for big_count_kernel, or the slice is full
         }
         if (lane == 0) {
@@ -2786,6 +2830,7 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
         if (!fallback) sliceUsed += n2;
         wave_lds_sync();
     }
+    if (EPL == 1 && ws.sliceFill && lane == 0) ws.sliceFill[w0] = (uint32_t)sliceUsed;
 }
 
 #ifndef MC_BIG_COUNT_WPE
@@ -2857,22 +2902,24 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
         strong = __builtin_amdgcn_readfirstlane(strong);
         bool done = true;
         if (strong < K) {
-            if constexpr (TAX) {
+            if (TAX || nent > kBigEnt) {
                 // places left for single-hit taxa: the order among those depends on every target's taxon -> the exact wave kernel
+                // (so do the few queries of the filter's second instance that come here: step D below reads one entry per lane)
                 if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
                 done = false;
-            } else {
+            } else if constexpr (!TAX) {
                 // ---- D. the open places: smallest targets (with their smallest window) among the locations of all targets that were
                 //      not picked with >= 2 hits -- every such target's best range is a single location
                 const uint32_t fbase = ws.winOff[q] * s;
-                const uint32_t mySz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
-                const uint64_t myPay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
-                const BigShape sh = big_setup(T, lane, nent, mySz, myPay, COMPACT ? kBigMinShiftCompact : kBigMinShift);
+                const uint32_t mySz1[1] = {lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u};
+                const uint64_t myPay1[1] = {lane < nent ? ws.ppay[fbase + lane] : 0ull};
+                const uint32_t mySz = mySz1[0]; const uint64_t myPay = myPay1[0];
+                const BigShape sh = big_setup<1>(T, lane, nent, mySz1, myPay1, COMPACT ? kBigMinShiftCompact : kBigMinShift);
                 wave_lds_sync();
                 uint64_t best[kLaneK];
 #pragma unroll
                 for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kEmptyLoc;
-                big_sweep<COMPACT>(T, tab, lane, sh, (lane < nent && mySz == 1) ? myPay : kEmptyLoc, [&](uint64_t v) {
+                auto visit = [&](uint64_t v) {
                     if (v == kEmptyLoc) return;
                     const uint32_t t = (uint32_t)(v >> 32);
                     bool skip = false;
@@ -2887,7 +2934,9 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
                     uint64_t c = v;                                 // sorted insert, the largest falls out
 #pragma unroll
                     for (uint32_t i = 0; i < kLaneK; ++i) { const uint64_t lo = min(best[i], c); c = max(best[i], c); best[i] = lo; }
-                });
+                };
+                visit((lane < nent && mySz == 1) ? myPay : kEmptyLoc);
+                big_sweep<COMPACT>(T, tab, lane, sh, visit);
                 for (uint32_t rnd = strong; rnd < K; ++rnd) {
                     uint64_t m = best[0];
 #pragma unroll
@@ -2935,8 +2984,11 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         }
     };
     if (stage == 0) {
-        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
-        else         hipLaunchKernelGGL((big_filter_kernel<4, false>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true, 1>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        else         hipLaunchKernelGGL((big_filter_kernel<4, false, 1>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+    } else if (stage == 3) {                                   // the filter's second instance: queries with 65 .. 192 found features
+        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true, kBigEPL>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        else         hipLaunchKernelGGL((big_filter_kernel<4, false, kBigEPL>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 1) {
         // blocks per CU by LDS: 40 KB per block with 8-byte keys, 24 KB with the compact ones
         count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(compact), (b.n + 3) / 4), 0u);

@@ -286,3 +286,42 @@ def test_more_than_2_32_locations_against_oracle():
         _, e = odb.query(p1[i], p2[i], K, 0, 0)
         _check(pc[i], e, K, ("pair", i, pcounts[i]))
     db.close(); odb.close()
+
+
+@pytest.mark.parametrize("lowest,K,store", [(0, 2, 4), (0, 3, 8), (4, 2, 4)])
+def test_filter_second_instance_reads_of_five_to_ten_windows(monkeypatch, lowest, K, store):
+    """Reads of 300 .. 512 bp and 2 x 250 bp pairs find 65 .. 160 features: more entries than big_filter_kernel's one per lane -- its
+    second instance (three per lane, same pool slices after the first).  12 strains per species: lists of 200 .. 2000 locations, filtered
+    lists on both sides of the counting kernels' limits; mixed with 150 bp reads (first instance) in the same batches."""
+    monkeypatch.setenv("MC_BIG_MIN", "0")
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", "1" if store == 4 else "0")
+    spec = synthdb.phylogeny(4, 2, 12, 30_000, 40_000, seed=500 + lowest + K, div_strain=(0.002, 0.01))
+    db, info = synthdb.build_database(spec, shards=1, max_candidates=K)
+    assert db.table_layout()["location_bytes"] == store
+    db.set_lineages(spec.lineages())
+    odb = scale_util.oracle_database(spec, None, threads=THREADS, with_lineages=True)
+    cs = synthdb.CpuSynth()
+    reads = []
+    for j, L in enumerate((300, 380, 450, 500, 512, 150)):
+        P = synthdb.read_params(spec, 900 + j, read_len=L)
+        reads += [bytes(r[:L]) for r in cs.reads(spec, P, 0, 500)]
+    rng = np.random.default_rng(9)
+    reads += [bytes(synth.random_genome(rng, 480)) for _ in range(100)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    db.timing(True); db.timing_reset()
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    assert db.timing_get("big_filter_2")[1] > 0 and db.timing_get("big_filter")[1] > 0
+    assert np.mean(counts > 256) > 0.5, np.percentile(counts, [5, 50, 95])
+    for i, r in enumerate(reads):
+        _, e = odb.query(r, b"", K, lowest, 0)
+        _check(cands[i], e, K, (i, len(r), counts[i]))
+    P2 = synthdb.read_params(spec, 950, read_len=250, paired=True)
+    m1, m2 = cs.reads(spec, P2, 0, 1200)
+    p1 = [bytes(r[:250]) for r in m1]; p2 = [bytes(r[:250]) for r in m2]
+    pc, pcounts, _ = db.query(p1, p2, lowest=lowest, insert_max=0)
+    for i in range(len(p1)):
+        _, e = odb.query(p1[i], p2[i], K, lowest, 0)
+        _check(pc[i], e, K, ("pair", i, pcounts[i]))
+    db.timing(False)
+    db.close(); odb.close()
