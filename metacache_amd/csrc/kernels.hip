@@ -2833,6 +2833,9 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
     if (EPL == 1 && ws.sliceFill && lane == 0) ws.sliceFill[w0] = (uint32_t)sliceUsed;
 }
 
+#ifndef MC_BIG_COUNT_PREFETCH
+#define MC_BIG_COUNT_PREFETCH 1
+#endif
 #ifndef MC_BIG_COUNT_WPE
 #define MC_BIG_COUNT_WPE 6     // compact keys: 6 KB of LDS per wave; at 80 registers six blocks fit a CU (8.0 / 7.3 / 6.9 ms at 16 / 20 / 24 waves)
 #endif
@@ -2859,11 +2862,31 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
     const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0xFFFFu, 0); };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
-    uint4 rec = load_rec(w0);
+    // the first instance fetches the NEXT query's filtered list while it works on this one (the list was one exposed memory round trip
+    // per query); the second one holds 16 elements per lane and loads them where they are used
+    constexpr bool kPrefetch = MC_BIG_COUNT_PREFETCH && LOG2S == 10;
+    constexpr uint32_t kPre = kPrefetch ? kList / 64 : 1;
+    constexpr pool_t kNone = (pool_t)~(pool_t)0;
+    uint4 rec = load_rec(w0), recN = load_rec(w0 + nWaves);
+    pool_t pre[kPre];
+    auto fetch = [&](const uint4& r) {
+        if constexpr (kPrefetch) {
+            uint32_t n = r.z & 0xFFFFu;
+            if (n > kList || n <= minN2) n = 0;
+            const pool_t* __restrict__ p = reinterpret_cast<const pool_t*>(ws.bigPool) + r.y;
+#pragma unroll
+            for (uint32_t i = 0; i < kPre; ++i) pre[i] = i * 64 + lane < n ? p[i * 64 + lane] : kNone;
+        }
+    };
+    fetch(rec);
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, n2 = rec.z & 0xFFFFu, nent = rec.z >> 16, maxWin = rec.w;
         const pool_t* __restrict__ src = reinterpret_cast<const pool_t*>(ws.bigPool) + rec.y;
-        rec = load_rec(w + nWaves);
+        pool_t cur[kPre];
+#pragma unroll
+        for (uint32_t i = 0; i < kPre; ++i) cur[i] = pre[i];
+        rec = recN; recN = load_rec(w + 2 * nWaves);
+        fetch(rec);
         if (n2 > kList || n2 <= minN2) continue;
         {
             uint4* k4 = reinterpret_cast<uint4*>(keys);
@@ -2883,7 +2906,10 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
             constexpr uint32_t PER = decltype(perc)::value;
             pool_t v[PER];
 #pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : (pool_t)~(pool_t)0;
+            for (uint32_t r = 0; r < PER; ++r) {
+                if constexpr (kPrefetch) v[r] = cur[r < kPre ? r : 0];
+                else v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kNone;
+            }
             strong = count_and_pick<LOG2S, PER, TAX>(v, keys, cnts, lane, maxWin, K, taxkey, tab, out, picked);
         };
         const uint32_t per = (n2 + 63u) / 64u;
