@@ -2617,10 +2617,17 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 constexpr uint32_t kBigU = MC_BIG_U;      // wave loads in flight per wave.  8, 12 or 16 make no difference at equal waves per CU (18.4 / - / 18.0 ms
                                           // per 5 x 10^6 reads at 16 waves); 8 keeps the kernel at 62 registers and 7.3 KB of LDS per wave,
                                           // which lets a fifth block onto each CU: 15.9 ms at 20 waves
-#ifndef MC_BIG_BITS
-#define MC_BIG_BITS 14
+// Target states of the filter: two blocked Bloom filters in LDS.  "seen": 2 bits of ONE 32-bit word per target (word and bits from a
+// multiplicative hash), set with a single returning ds_or -- both bits found set = the target was seen before (or, 1 % of the time, two
+// other targets set them); "twice": the same for the targets found seen, read in sweep B.  16 384 + 8 192 bits = 3 KB per wave; the
+// first form (16 384 two-bit states, 4 KB) let 7.6 % of the single-hit locations through, this one about 1 %.
+#ifndef MC_BIG_T1
+#define MC_BIG_T1 14
 #endif
-constexpr uint32_t kBigBitsLog2 = MC_BIG_BITS;     // target states
+#ifndef MC_BIG_T2
+#define MC_BIG_T2 13
+#endif
+constexpr uint32_t kBigT1Log2 = MC_BIG_T1, kBigT2Log2 = MC_BIG_T2;     // bits of the two filters
 #ifndef MC_BIG_MIN_SHIFT
 #define MC_BIG_MIN_SHIFT 3
 #endif
@@ -2725,7 +2732,8 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
 {
     // COMPACT: locations are read from the 4-byte store and the pool holds them in that form too (its slices are the same number of ENTRIES)
     using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
-    constexpr uint32_t kBitWords = (1u << kBigBitsLog2) / 16;
+    constexpr uint32_t kW1 = (1u << kBigT1Log2) / 32, kW2 = (1u << kBigT2Log2) / 32, kBitWords = kW1 + kW2;
+    static_assert(kBitWords % 256 == 0, "cleared with one uint4 per lane and step");
     __shared__ uint32_t bitS[WAVES][kBitWords];
     __shared__ BigTables tabS[WAVES];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2754,9 +2762,13 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
         }
     };
     load_entries(rec);
-    auto state_of = [&](uint64_t v, uint32_t& word, uint32_t& bit1) {
-        const uint32_t h = ((uint32_t)(v >> 32) * 0x9E3779B1u) >> (32 - kBigBitsLog2);
-        word = h >> 4; bit1 = 1u << (2u * (h & 15u));
+    auto seen_of = [&](uint64_t v, uint32_t& word, uint32_t& mask) {
+        const uint32_t h = (uint32_t)(v >> 32) * 0x9E3779B1u;
+        word = h >> (32 - (kBigT1Log2 - 5)); mask = (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u));
+    };
+    auto twice_of = [&](uint64_t v, uint32_t& word, uint32_t& mask) {            // the same hash: other bits for the word, the same two bits in it
+        const uint32_t h = (uint32_t)(v >> 32) * 0x9E3779B1u;
+        word = kW1 + ((h >> 17) & (kW2 - 1u)); mask = (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u));
     };
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
@@ -2788,10 +2800,10 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
             //      took 31.6 / 37.2 / 57.5 ms instead of 26.5 per 5 x 10^6 reads -- the LDS costs more waves than the re-read costs.)
             auto mark = [&](uint64_t v) {
                 if (v != kEmptyLoc) {
-                    uint32_t word, bit1;
-                    state_of(v, word, bit1);
-                    const uint32_t old = atomicOr(&bits[word], bit1);
-                    if (old & bit1) atomicOr(&bits[word], bit1 << 1);
+                    uint32_t word, mask;
+                    seen_of(v, word, mask);
+                    const uint32_t old = atomicOr(&bits[word], mask);
+                    if ((old & mask) == mask) { uint32_t w2, m2; twice_of(v, w2, m2); atomicOr(&bits[w2], m2); }
                 }
             };
 #pragma unroll
@@ -2804,9 +2816,9 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
             auto take = [&](uint64_t v) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
-                    uint32_t word, bit1;
-                    state_of(v, word, bit1);
-                    keep = (bits[word] & (bit1 << 1)) != 0;
+                    uint32_t word, mask;
+                    twice_of(v, word, mask);
+                    keep = (bits[word] & mask) == mask;
                 }
                 const uint64_t m = __ballot(keep);
                 if (keep) {
@@ -2834,7 +2846,7 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
 }
 
 #ifndef MC_BIG_COUNT_PREFETCH
-#define MC_BIG_COUNT_PREFETCH 1
+#define MC_BIG_COUNT_PREFETCH 0     // fetching the next query's filtered list during this one: measured, no gain (7.35 against 7.28 ms; spills at 80 registers)
 #endif
 #ifndef MC_BIG_COUNT_WPE
 #define MC_BIG_COUNT_WPE 6     // compact keys: 6 KB of LDS per wave; at 80 registers six blocks fit a CU (8.0 / 7.3 / 6.9 ms at 16 / 20 / 24 waves)
@@ -2862,8 +2874,7 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
     const uint32_t nWaves = gridDim.x * WAVES;
     auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0xFFFFu, 0); };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
-    // the first instance fetches the NEXT query's filtered list while it works on this one (the list was one exposed memory round trip
-    // per query); the second one holds 16 elements per lane and loads them where they are used
+    // (MC_BIG_COUNT_PREFETCH: the first instance fetches the NEXT query's filtered list while it works on this one)
     constexpr bool kPrefetch = MC_BIG_COUNT_PREFETCH && LOG2S == 10;
     constexpr uint32_t kPre = kPrefetch ? kList / 64 : 1;
     constexpr pool_t kNone = (pool_t)~(pool_t)0;
@@ -3025,7 +3036,7 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
 }
 uint32_t big_filter_grid(uint32_t n)
 {
-    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 6u; }();    // 26 KB of LDS per block: six per CU (4 / 5 / 6 blocks: 18.4 / 15.9 / 15.0 ms)
+    static const uint32_t bpc = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 7u; }();    // 22.5 KB of LDS per block, 66 registers: seven per CU (4 / 5 / 6 blocks with the 4 KB state table: 18.4 / 15.9 / 15.0 ms)
     return std::min<uint32_t>(256 * bpc, (n + 3) / 4);
 }
 
