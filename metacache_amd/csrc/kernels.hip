@@ -2593,22 +2593,21 @@ __global__ __launch_bounds__(WAVES * 64) void hash_cands_kernel(BatchView b, Dev
 // hits on unrelated targets; what rows 8-10 keep of them is at most "the smallest target ids with one hit" when fewer than K targets
 // reach two.  So the list is FILTERED before anything is counted per (target, window):
 //   big_filter_kernel
-//   A. every location sets a 2-bit state (seen once / seen twice or more) in an LDS bit table indexed by a hash of its TARGET
-//      (16384 states in 4 KB: two ds_or per repeated target, one per new one);
-//   B. second sweep over the list: locations whose target state says "twice or more" are compacted (ballot) into an LDS list and
-//      leave for a pool in HBM -- all locations of every target with >= 2 hits and a few percent of the rest (hash collisions),
-//      typically a quarter of the list.
+//   A. every location enters its TARGET into a Bloom filter in LDS ("seen"); a target found there already goes into a second one
+//      ("twice") -- 3 KB per wave, one returning ds_or per location, one more for repeats;
+//   B. second sweep over the list: locations whose target is in "twice" are compacted (ballot) into the wave's slice of a pool in
+//      HBM -- all locations of every target with >= 2 hits and about 1 % of the rest, typically a fifth of the list.
 //   big_count_kernel
 //   C. count_and_pick (hash_cands_kernel's steps 1-3) on the filtered list: exact hits per window range, K rounds;
 //   D. only if fewer than K picked candidates have >= 2 hits: the open places go to the smallest targets among ALL other
 //      locations, each with its smallest window (hits = 1 candidates are ordered by target id alone = arrival order in the sorted
 //      list, candidate_generation.hpp:172-201) -- a sweep over the original lists.  With taxon merging this case goes to the wave kernel.
-// Two kernels because both halves wait for memory most of their time and are held back by different resources: the sweeps need few
-// registers and 11 KB of LDS per wave (14 waves per CU in flight), the counting 150 registers and a 10 KB hash table.  Fused they
+// Two kernels because both halves wait most of their time and are held back by different resources: the sweeps need 66 registers and
+// 5.6 KB of LDS per wave (28 waves per CU), the counting 80+ registers and a 6 - 10 KB hash table (24 / 16 waves).  Fused they
 // ran at 8 waves per CU: 22 us per list, nearly all of it memory latency of the sweeps (R / kBigU dependent round trips each).
 // The sweeps read the bucket lists straight from the table: one coalesced wave load per 64 locations of a bucket ("round"),
 // kBigU rounds in flight; sweep B re-reads what sweep A brought into the L2 / infinity cache.
-// Filtered lists beyond 512 take the instance with the larger hash table (work list 8), beyond 1024 (or when the pool is full) the
+// Filtered lists beyond 512 take the counting instance with the larger hash table, beyond 1024 (or when the pool is full) the
 // wave kernel.
 // ================================================================================================
 #ifndef MC_BIG_U
