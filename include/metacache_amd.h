@@ -12,7 +12,7 @@
  *   probe_cands          : one lane per query: bucket lookups, location list, sort, window-range candidates, top-K
  *   mid_cands            : lists of 33..256 locations, 4 / 8 / 16 lanes per query, register sort
  *   hash_cands           : lists of 65..256 locations, one wave per query, (target, window) counts in an LDS table
- *   big_filter / big_count : lists above 256 (RefSeq-scale tables): filtered by target, then counted
+ *   big_filter / big_count : lists above 128 (RefSeq-scale tables): filtered by target, then counted
  *   query_wave / sort_candidates : one wave per query for everything else (and for -allhits)
  *   (semantics = reference CPU classifier, bit for bit)
  *

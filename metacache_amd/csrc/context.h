@@ -112,7 +112,8 @@ struct mc_ctx {
     // single-part tables are built on the device (table_build.hip): staging for one batch of the file
     mcamd::DevBuf bLdKeys, bLdSizes, bLdVals, bLdFileSz, bLdStoreSz, bLdFileOff, bLdStoreOff, bLdScan, bLdCounters;
     bool useLanePath = true;               // lane-parallel fast path for short reads (off: wave kernels only)
-    uint32_t bigMin = 256;                 // location lists longer than this take big_cands_kernel (filter before counting); MC_BIG_MIN
+    uint32_t bigMin = 128;                 // location lists longer than this (and than 64) are filtered before they are counted (big_filter_kernel); MC_BIG_MIN.
+                                           // 256 / 128 / 64 at 15 Gbp (195 locations per read): 3.92 / 3.53 / 3.48 ms per 10^6 reads; at 4.5 Gbp (100): 3.01 / 3.12 / 3.25
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
     bool fuseLane = false;                 // sketching + probing of the lane path in ONE kernel (MC_LANE_FUSION=1); measured
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on

@@ -1863,7 +1863,8 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     }
     if (hand) {
         const uint32_t nent = gnent;
-        if (H > kMidMax) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;   // the wave kernel reads all nf slots
+        // the wave kernel reads all nf slots -- it gets the lists beyond the lane kernels' reach and whatever the filtered path hands back
+        if (H > kMidMax || H > ws.bigMin) for (uint32_t j = nent; j < nf; ++j) ws.psize[fbase + j] = 0u;
         ws.hitScan[q] = (H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u;
         // lists of up to 256 locations: work lists of mid_cands_kernel (4 / 8 / 16 lanes per query); one atomic per wave and class
         // ... and of hash_cands_kernel (257 .. 1024 locations, one wave per query, no sort); longer ones, wide window ranges -> wave kernel
@@ -1872,7 +1873,7 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // on counting beats sorting (measured per list: 3.3 vs 4.7 ns at 129..256); below, the register sort wins (1.6 vs 2 ns)
         const bool hashOK = nent <= kHashEnt && mw <= kHashWin;
         // 7 = big_cands_kernel (filter first): lists beyond ws.bigMin locations from at most kBigEnt found features
-        const bool bigOK = nent <= kBigEnt * kBigEPL && mw <= kHashWin && H > ws.bigMin && H > kMidMax;
+        const bool bigOK = nent <= kBigEnt * kBigEPL && mw <= kHashWin && H > ws.bigMin && H > 64u;   // (lists up to 64 are sorted in registers, mid_cands_kernel)
         const uint32_t cls = bigOK ? 7u : H <= 64 ? 0u : H <= 128 ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
         ws.qflag[q] = cls != 6 ? kFlagMid : kFlagCands;
         if (cls >= 3 && cls != 6) ws.hitScan[q] = 0u;                            // no segment in HBM
@@ -2882,7 +2883,7 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
     auto fetch = [&](const uint4& r) {
         if constexpr (kPrefetch) {
             uint32_t n = r.z & 0xFFFFu;
-            if (n > kList || n <= minN2) n = 0;
+            if (n > kList || (minN2 != 0 && n <= minN2)) n = 0;
             const pool_t* __restrict__ p = reinterpret_cast<const pool_t*>(ws.bigPool) + r.y;
 #pragma unroll
             for (uint32_t i = 0; i < kPre; ++i) pre[i] = i * 64 + lane < n ? p[i * 64 + lane] : kNone;
@@ -2897,7 +2898,7 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
         for (uint32_t i = 0; i < kPre; ++i) cur[i] = pre[i];
         rec = recN; recN = load_rec(w + 2 * nWaves);
         fetch(rec);
-        if (n2 > kList || n2 <= minN2) continue;
+        if (n2 > kList || (minN2 != 0 && n2 <= minN2)) continue;   // (an EMPTY filtered list -- no target seen twice -- is the first instance's: step D fills the places)
         {
             uint4* k4 = reinterpret_cast<uint4*>(keys);
             uint4* c4 = reinterpret_cast<uint4*>(cnts);

@@ -303,6 +303,7 @@ def test_long_lists_hash_cands_against_oracle(tmp_path, lowest, K, monkeypatch):
     sequence level, merged at species and at genus level, against the oracle."""
     from metacache_amd import synth
     monkeypatch.setenv("MC_COMPACT_LOCATIONS", str(K & 1))          # both location stores (8 / 4 bytes per location)
+    monkeypatch.setenv("MC_BIG_MIN", "4096")                        # keep these lists with hash_cands_kernel (by default lists above 128 are filtered first)
     rng = np.random.default_rng(991 + 10 * lowest + K)
     genomes, parents = [], []
     for sp in range(6):
