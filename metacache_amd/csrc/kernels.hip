@@ -2727,12 +2727,18 @@ __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable&
 #endif
 // EPL = 1: the queries with up to 64 found features (one entry per lane).  EPL > 1: the instance for the others (up to 64 * EPL: reads
 // and pairs of 5 .. 10 windows); it runs after the first one on the same grid and goes on in the same pool slices (ws.sliceFill).
-template <uint32_t WAVES, bool COMPACT, uint32_t EPL>
+// POS (the second instance): the filters are keyed on (target, block of 16 windows) in two grids half a block apart instead of the
+// target alone -- two locations that can share a window range (maxWindowsInRange <= kHashWin = 8) share a block in one of the grids.
+// A read of 500 bp collects 4 500 locations at RefSeq scale and hits 250 targets TWICE BY CHANCE, at unrelated places: keyed on targets
+// the filtered list outgrows the counting kernels (1024), keyed on places only true neighbours stay.  Twice the keys of 3.5 x the
+// locations: T1LOG2 / T2LOG2 = 17 / 14 (18 KB per wave, two waves per block).
+template <uint32_t WAVES, bool COMPACT, uint32_t EPL, bool POS, uint32_t T1LOG2, uint32_t T2LOG2>
 __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
+    static_assert(!POS || kHashWin <= 8, "two grids of 16 windows, 8 apart, cover window ranges up to 8");
     // COMPACT: locations are read from the 4-byte store and the pool holds them in that form too (its slices are the same number of ENTRIES)
     using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
-    constexpr uint32_t kW1 = (1u << kBigT1Log2) / 32, kW2 = (1u << kBigT2Log2) / 32, kBitWords = kW1 + kW2;
+    constexpr uint32_t kW1 = (1u << T1LOG2) / 32, kW2 = (1u << T2LOG2) / 32, kBitWords = kW1 + kW2;
     static_assert(kBitWords % 256 == 0, "cleared with one uint4 per lane and step");
     __shared__ uint32_t bitS[WAVES][kBitWords];
     __shared__ BigTables tabS[WAVES];
@@ -2762,14 +2768,19 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
         }
     };
     load_entries(rec);
-    auto seen_of = [&](uint64_t v, uint32_t& word, uint32_t& mask) {
-        const uint32_t h = (uint32_t)(v >> 32) * 0x9E3779B1u;
-        word = h >> (32 - (kBigT1Log2 - 5)); mask = (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u));
+    // key g of a location: 0 = its target (POS: and its block of 16 windows), 1 (POS only) = the block of the grid shifted by 8 windows
+    auto hash_of = [&](uint64_t v, uint32_t g) -> uint32_t {
+        const uint32_t t = (uint32_t)(v >> 32) * 0x9E3779B1u;
+        if constexpr (POS) return (t + ((((uint32_t)v + 8u * g) >> 4) * 2u + g) * 0x85EBCA77u) * 0xC2B2AE3Du;
+        else return t;
     };
-    auto twice_of = [&](uint64_t v, uint32_t& word, uint32_t& mask) {            // the same hash: other bits for the word, the same two bits in it
-        const uint32_t h = (uint32_t)(v >> 32) * 0x9E3779B1u;
+    auto seen_of = [&](uint32_t h, uint32_t& word, uint32_t& mask) {
+        word = h >> (32 - (T1LOG2 - 5)); mask = (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u));
+    };
+    auto twice_of = [&](uint32_t h, uint32_t& word, uint32_t& mask) {            // the same hash: other bits for the word, the same two bits in it
         word = kW1 + ((h >> 17) & (kW2 - 1u)); mask = (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u));
     };
+    constexpr uint32_t kKeys = POS ? 2 : 1;
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
         if (!mine(nent)) {                                         // the other instance's query
@@ -2800,10 +2811,14 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
             //      took 31.6 / 37.2 / 57.5 ms instead of 26.5 per 5 x 10^6 reads -- the LDS costs more waves than the re-read costs.)
             auto mark = [&](uint64_t v) {
                 if (v != kEmptyLoc) {
-                    uint32_t word, mask;
-                    seen_of(v, word, mask);
-                    const uint32_t old = atomicOr(&bits[word], mask);
-                    if ((old & mask) == mask) { uint32_t w2, m2; twice_of(v, w2, m2); atomicOr(&bits[w2], m2); }
+#pragma unroll
+                    for (uint32_t g = 0; g < kKeys; ++g) {
+                        const uint32_t h = hash_of(v, g);
+                        uint32_t word, mask;
+                        seen_of(h, word, mask);
+                        const uint32_t old = atomicOr(&bits[word], mask);
+                        if ((old & mask) == mask) { uint32_t w2, m2; twice_of(h, w2, m2); atomicOr(&bits[w2], m2); }
+                    }
                 }
             };
 #pragma unroll
@@ -2816,9 +2831,12 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
             auto take = [&](uint64_t v) {
                 bool keep = false;
                 if (v != kEmptyLoc) {
-                    uint32_t word, mask;
-                    twice_of(v, word, mask);
-                    keep = (bits[word] & mask) == mask;
+#pragma unroll
+                    for (uint32_t g = 0; g < kKeys; ++g) {
+                        uint32_t word, mask;
+                        twice_of(hash_of(v, g), word, mask);
+                        keep = keep || (bits[word] & mask) == mask;
+                    }
                 }
                 const uint64_t m = __ballot(keep);
                 if (keep) {
@@ -3021,11 +3039,12 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         }
     };
     if (stage == 0) {
-        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true, 1>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
-        else         hipLaunchKernelGGL((big_filter_kernel<4, false, 1>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        else         hipLaunchKernelGGL((big_filter_kernel<4, false, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 3) {                                   // the filter's second instance: queries with 65 .. 192 found features
-        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true, kBigEPL>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
-        else         hipLaunchKernelGGL((big_filter_kernel<4, false, kBigEPL>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        // two waves per block, twice the blocks: the same number of waves -- and so the same pool slices -- as the first instance
+        if (compact) hipLaunchKernelGGL((big_filter_kernel<2, true, kBigEPL, true, 17, 14>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
+        else         hipLaunchKernelGGL((big_filter_kernel<2, false, kBigEPL, true, 17, 14>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
     } else if (stage == 1) {
         // blocks per CU by LDS: 40 KB per block with 8-byte keys, 24 KB with the compact ones
         count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(compact), (b.n + 3) / 4), 0u);
