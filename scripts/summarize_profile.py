@@ -24,7 +24,9 @@ def short(k):
     if "hash_cands_kernel" in k: return "hash_cands"
     if "big_cands_kernel<10" in k: return "big_cands"
     if "big_cands_kernel<11" in k: return "big_cands_2"
-    if "big_filter_kernel" in k: return "big_filter" if k.rstrip().endswith(" 1u>") or ", 1u>" in k else "big_filter_2"
+    if "big_filter_kernel" in k:                                  # <WAVES, COMPACT, EPL, ...>: EPL = 1 is the first instance
+        args = k.split("big_filter_kernel<", 1)[1].split(">")[0].split(",") if "big_filter_kernel<" in k else []
+        return "big_filter" if len(args) < 3 or args[2].strip() in ("1u", "1") else "big_filter_2"
     if "big_count_kernel<10" in k: return "big_count"
     if "big_count_kernel<11" in k: return "big_count_2"
     for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs", "chunk_sketch", "chunk_probe", "chunk_finish", "flag_count", "table_seal", "build_sketch_lanes", "own_count", "own_emit", "union_copy"):
