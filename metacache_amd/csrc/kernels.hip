@@ -2628,6 +2628,12 @@ constexpr uint32_t kBigU = MC_BIG_U;      // wave loads in flight per wave.  8, 
 #define MC_BIG_T2 13
 #endif
 constexpr uint32_t kBigT1Log2 = MC_BIG_T1, kBigT2Log2 = MC_BIG_T2;     // bits of the two filters
+#ifndef MC_BIG_POS_T1
+#define MC_BIG_POS_T1 17                  // ... of the second instance (twice the keys of 3.5 x the locations)
+#endif
+#ifndef MC_BIG_POS_T2
+#define MC_BIG_POS_T2 14
+#endif
 #ifndef MC_BIG_MIN_SHIFT
 #define MC_BIG_MIN_SHIFT 3
 #endif
@@ -3043,8 +3049,8 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         else         hipLaunchKernelGGL((big_filter_kernel<4, false, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 3) {                                   // the filter's second instance: queries with 65 .. 192 found features
         // two waves per block, twice the blocks: the same number of waves -- and so the same pool slices -- as the first instance
-        if (compact) hipLaunchKernelGGL((big_filter_kernel<2, true, kBigEPL, true, 17, 14>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
-        else         hipLaunchKernelGGL((big_filter_kernel<2, false, kBigEPL, true, 17, 14>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
+        if (compact) hipLaunchKernelGGL((big_filter_kernel<2, true, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
+        else         hipLaunchKernelGGL((big_filter_kernel<2, false, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
     } else if (stage == 1) {
         // blocks per CU by LDS: 40 KB per block with 8-byte keys, 24 KB with the compact ones
         count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(compact), (b.n + 3) / 4), 0u);
