@@ -2872,11 +2872,14 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
 #ifndef MC_BIG_COUNT_PREFETCH
 #define MC_BIG_COUNT_PREFETCH 0     // fetching the next query's filtered list during this one: measured, no gain (7.35 against 7.28 ms; spills at 80 registers)
 #endif
+#ifndef MC_BIG_COUNT2_WPE
+#define MC_BIG_COUNT2_WPE 3     // second instance, compact keys: 168 registers, six blocks of two waves per CU (pairs at full scale: 9.4 -> 7.2 ms)
+#endif
 #ifndef MC_BIG_COUNT_WPE
 #define MC_BIG_COUNT_WPE 6     // compact keys: 6 KB of LDS per wave; at 80 registers six blocks fit a CU (8.0 / 7.3 / 6.9 ms at 16 / 20 / 24 waves)
 #endif
 template <uint32_t LOG2S, uint32_t WAVES, bool TAX, bool COMPACT>
-__global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT_WPE : 1) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+__global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT_WPE : (COMPACT && LOG2S == 11) ? MC_BIG_COUNT2_WPE : 1) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
                                                                uint32_t minN2)
 {
@@ -3055,7 +3058,8 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         // blocks per CU by LDS: 40 KB per block with 8-byte keys, 24 KB with the compact ones
         count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(compact), (b.n + 3) / 4), 0u);
     } else {
-        static const uint32_t bpc2 = [] { const char* e = std::getenv("MC_BIG_COUNT2_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 4u; }();
+        static const uint32_t env2 = [] { const char* e = std::getenv("MC_BIG_COUNT2_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 0u; }();
+        const uint32_t bpc2 = env2 ? env2 : compact ? 6u : 4u;
         count(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 2>{}, std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2), 512u);
     }
 }
