@@ -119,7 +119,9 @@ int load_part(mc_ctx* ctx, uint32_t part, const std::string& fname, uint32_t tar
     uint64_t nkeys = 0, nvalues = 0, batch = 0;
     if (!f.rd(&nkeys, 8) || !f.rd(&nvalues, 8) || !f.rd(&batch, 8)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
     if (nkeys && batch == 0) { ctx->err = "corrupt header in " + fname; return MC_ERR_IO; }      // validated by read_part_header before
-    batch = std::min<uint64_t>(batch, 1ull << 26);
+    // the file's layout IS its batch size (keys[batch] | sizes[batch] | values, hash_multimap.hpp:898-912): reading with another one would
+    // take key bytes for sizes.  The reference and this repository's writer use 2^20; anything beyond 2^26 is refused, not reinterpreted.
+    if (batch > (1ull << 26)) { ctx->err = "unsupported batch size in " + fname + " (header says " + std::to_string(batch) + " keys per batch)"; return MC_ERR_UNSUPPORTED; }
     int rc;
     const size_t vb = 4 + targetBytes;
     std::vector<uint32_t> keys(std::min<uint64_t>(batch, nkeys));

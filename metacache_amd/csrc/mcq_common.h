@@ -229,9 +229,9 @@ public:
         size_t b, e;
         bool exactRec = exact_;
         if (streaming_) {
-            const size_t sc = streamCount_.load();
+            const size_t sc = streamCount_.load(std::memory_order_acquire);
             if (i >= sc) { b = recs_[i - sc].start; e = recs_[i - sc].seqEnd; exactRec = true; }
-            else { b = stream_start(i); e = i + 1 < sc ? stream_start(i + 1) : streamEnd_; exactRec = false; }
+            else { b = stream_start(i); e = i + 1 < sc ? stream_start(i + 1) : streamEnd_.load(std::memory_order_acquire); exactRec = false; }
         }
         else if (exact_) { b = recs_[i].start; e = recs_[i].seqEnd; }
         else { b = starts_[i]; e = i + 1 < starts_.size() ? starts_[i + 1] : size_; }
@@ -322,11 +322,13 @@ private:
         streamPool_.clear();
         l.lock();
         size_t from = streamFirstByte_;
-        if (streamCount_.load() > 0) { from = stream_start(streamCount_.load() - 1); streamCount_.store(streamCount_.load() - 1); }
-        streamEnd_ = from;
-        const bool wasExact = exact_;
-        scan_exact(from);
-        exact_ = wasExact;
+        // the end of the last record that stays published first, then the smaller count: a worker that reads the new count must
+        // see the new end (record(): e = streamEnd_ for the last streamed record)
+        const size_t sc = streamCount_.load();
+        if (sc > 0) from = stream_start(sc - 1);
+        streamEnd_.store(from, std::memory_order_release);
+        if (sc > 0) streamCount_.store(sc - 1, std::memory_order_release);
+        scan_exact(from, /*keepMode=*/true);                                     // exact_ is read by the workers: not touched while streaming
         streamDone_ = true;
     }
     size_t stream_start(size_t i) const
@@ -337,7 +339,8 @@ private:
     }
     bool streaming_ = false, streamDone_ = false;
     std::atomic<size_t> streamCount_{0}, published_{0};
-    size_t streamEnd_ = 0, streamFirstByte_ = 0;
+    std::atomic<size_t> streamEnd_{0};
+    size_t streamFirstByte_ = 0;
     std::vector<std::vector<uint64_t>> chunkStarts_;
     std::vector<uint64_t> chunkFirst_;
     std::vector<std::atomic<int>> chunkState_;
@@ -393,9 +396,9 @@ private:
     }
     // sequence_reader::read_next restated: a record begins at the next line that starts with '>' or '@'; its sequence is every
     // non-empty line up to a line that starts with '>' or '+'; after a '+' line exactly one more line (the qualities) is dropped.
-    void scan_exact(size_t first)
+    void scan_exact(size_t first, bool keepMode = false)
     {
-        exact_ = true;
+        if (!keepMode) exact_ = true;
         starts_.clear();
         size_t p = first;
         while (p < size_) {

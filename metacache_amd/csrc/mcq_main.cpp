@@ -693,13 +693,14 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (;;) {
                 size_t b;
                 const Batch* Bp = nullptr;
+                std::vector<Deferred>* Dp = nullptr;                             // taken under the lock: operator[] walks the deque's map, which emplace_back may reallocate
                 {
                     std::unique_lock<std::mutex> l(batchMtx);
                     batchCv.wait(l, [&] { return failed || nextBatch < batches.size() || !producing; });
                     if (failed || nextBatch >= batches.size()) break;           // (no batch left and the producer is through)
                     b = nextBatch++;
                     Bp = &batches[b];
-                    if (covMode) while (deferred.size() <= b) deferred.emplace_back();
+                    if (covMode) { while (deferred.size() <= b) deferred.emplace_back(); Dp = &deferred[b]; }
                 }
                 const Batch& B = *Bp;
                 out.str(std::string());
@@ -759,7 +760,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                             const uint32_t mw = (uint32_t)(2 + std::max<uint64_t>(m.len, o.insertMax) / dbStride);
                             host_candidates(r.hits + r.hit_offsets[i], r.hit_offsets[i + 1] - r.hit_offsets[i], mw, tx, o.lowest, cands);
                         }
-                        if (covMode) deferred[b].push_back(Deferred{m.id, m.header, cands});
+                        if (covMode) Dp->push_back(Deferred{m.id, m.header, cands});
                         else emit(A, out, m.id, m.header, cands, o.allhits ? r.hits + r.hit_offsets[i] : nullptr, o.allhits ? r.hit_offsets[i + 1] - r.hit_offsets[i] : 0);
                     }
                     mc_batch_clear(ctx, slot);

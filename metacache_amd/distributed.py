@@ -275,6 +275,11 @@ def classify_key_sharded_device(db, res, n: int, K: int, max_win_uniform: int, l
     device = torch.device("cuda", db.cfg.device)
     off, hits = partial_lists_of(db, res, n, device)
     counts, rhits, total = exchange_partial_lists(off, hits, group=group)
+    # The all-to-alls run on torch's current stream (RCCL only makes THAT stream wait, the host is not blocked); the owner-side
+    # kernels run on the context's own non-blocking stream.  Order them: the receive buffers must be complete before union_totals /
+    # union_copy read them.
+    if device.type == "cuda" and torch.cuda.is_available():
+        torch.cuda.current_stream(device).synchronize()
     lo, hi = shard_bounds(n, rank, world)
     m = hi - lo
     r2 = db.candidates_from_partial_hits(counts.data_ptr(), rhits.data_ptr() if total else 0, total, m, world, max_win_uniform=max_win_uniform, lowest=lowest)
