@@ -107,17 +107,21 @@ const char* mc_last_error(const mc_ctx* ctx);   /* ctx may be NULL: error of the
  * (:1037-1082): per batch keys[n] (u32), sizes[n] (u8), values[sum sizes] packed
  * {window_id win (u32); target_id tgt (u16|u32)}. */
 int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues);
-/* Optional, before the first mc_load_begin: no location of the database has a target id above max_target_id or a window id above
- * max_window_id (the reference knows both from its target metadata: database.hpp target_count(), every target's source().windows).
- * When the two ranges fit 32 bits TOGETHER and the database is a single part, the table stores a location as
- * (tgt << window_bits) | win in 4 bytes instead of the reference's 8-byte {win, tgt} (config.hpp:56-62 / candidate_structs.hpp:44-62):
- * same order, same results, half the bytes per location list in HBM and on the fabric -- a 2 x 10^10-location table takes 86 GB
- * instead of 172.  A location outside the announced range makes mc_load_end fail (MC_ERR_INVALID).  mc_open_database and the
- * builder's tables call this themselves; mc_set_tuning(ctx, "compact_locations", 0) / MC_COMPACT_LOCATIONS=0 keep the 8-byte store. */
+/* Optional, before the first mc_load_begin: the number of windows of every target (the reference knows them from its target metadata:
+ * database.hpp target_count(), every target's source().windows, taxonomy.hpp:264-280).  When all windows of the database -- plus a gap
+ * of 1024 numbers per target -- can be numbered in 32 bits (up to ~480 Gbp at the default window stride, whatever the single targets
+ * look like) and the database is a single part, the table stores a location as ONE global window number
+ *     gw = first_number(target) + window
+ * in 4 bytes instead of the reference's 8-byte {win, tgt} (config.hpp:56-62 / candidate_structs.hpp:44-62): same order, same results,
+ * half the bytes per location list in HBM and on the fabric -- a 2 x 10^10-location table takes 86 GB instead of 172.  A location
+ * outside its target's announced windows makes mc_load_end fail (MC_ERR_INVALID).  mc_open_database and the builder's tables call
+ * this themselves; mc_set_tuning(ctx, "compact_locations", 0) / MC_COMPACT_LOCATIONS=0 keep the 8-byte store. */
+int mc_load_target_windows(mc_ctx* ctx, const uint32_t* windows_per_target, uint64_t num_targets);
+/* the same announcement from bounds alone: targets 0 .. max_target_id with max_window_id + 1 windows each */
 int mc_load_location_range(mc_ctx* ctx, uint32_t max_target_id, uint32_t max_window_id);
-/* how the loaded table lies in HBM: layout[0] = bytes per stored location (8, or 4 with the compact store), [1] = window bits of the
- * compact form (0 otherwise), [2] = number of 64-byte buckets, [3] = locations in the list store (lists of >= 2; single locations
- * live in their bucket) */
+/* how the loaded table lies in HBM: layout[0] = bytes per stored location (8, or 4 with the compact store), [1] = the gap between two
+ * targets' window numbers in the compact form (0 otherwise), [2] = number of 64-byte buckets, [3] = locations in the list store
+ * (lists of >= 2; single locations live in their bucket) */
 int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4]);
 int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_t* sizes,
                   const void* values, uint64_t nkeys_in_batch);

@@ -54,7 +54,7 @@ class McDeviceResults(C.Structure):
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
 
 
-EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_table_layout",
+EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout",
            "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         L.mc_load_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_load_end.argtypes = [C.c_void_p, C.c_uint32]
         L.mc_load_location_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.mc_load_target_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_table_layout.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_set_lineages.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_db_info.argtypes = [C.c_void_p, C.c_void_p]
@@ -310,10 +311,10 @@ class Database:
         self._check(L.mc_copy_results_on(self.h, dst_ptr, src_ptr, nbytes, 1 if to_host else 0, stream or None))
 
     def table_layout(self) -> dict:
-        """bytes per stored location (4 = compact store), window bits, buckets, stored list locations (mc_table_layout)"""
+        """bytes per stored location (4 = compact store: global window numbers), gap between two targets' numbers, buckets, stored list locations (mc_table_layout)"""
         a = (C.c_uint64 * 4)()
         self._check(lib().mc_table_layout(self.h, a))
-        return {"location_bytes": int(a[0]), "window_bits": int(a[1]), "buckets": int(a[2]), "list_locations": int(a[3])}
+        return {"location_bytes": int(a[0]), "window_gap": int(a[1]), "buckets": int(a[2]), "list_locations": int(a[3])}
 
     def set_tuning(self, name: str, value: int):
         L = lib()

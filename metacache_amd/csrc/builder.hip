@@ -567,11 +567,13 @@ int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValu
     ctx->targetCount = b->targets.size();
     ctx->maxLocs = b->maxLocs;
     {
-        // every location is (target < targets, window < that target's windows): the table may store them in 4 bytes (DeviceTable::values32)
-        uint64_t maxWindows = 0;
-        for (const auto& t : b->targets) maxWindows = std::max<uint64_t>(maxWindows, t.windows);
-        if (!b->targets.empty() && maxWindows > 0 && maxWindows <= 0xFFFFFFFFull)
-            (void)mc_load_location_range(ctx, (uint32_t)(b->targets.size() - 1), (uint32_t)(maxWindows - 1));
+        // every location is (target < targets, window < that target's windows): the table may store them as global window numbers,
+        // 4 bytes each (DeviceTable::values32)
+        std::vector<uint32_t> windows;
+        windows.reserve(b->targets.size());
+        bool fits = !b->targets.empty();
+        for (const auto& t : b->targets) { fits = fits && t.windows <= 0xFFFFFFF0ull; windows.push_back((uint32_t)t.windows); }
+        if (fits) (void)mc_load_target_windows(ctx, windows.data(), windows.size());
     }
     rc = mc_load_begin(ctx, 0, expectKeys, expectValues);
     if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }

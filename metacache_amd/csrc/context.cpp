@@ -103,11 +103,12 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
+    const GwLayout gwl = P.compact ? GwLayout{ctx->dGwBase, ctx->gwTargets, ctx->gwGap} : GwLayout{};
     launch_table_insert(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
-                        (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st);
+                        (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st, gwl, (unsigned int*)(counters + 3));
     if (P.compact)
         launch_table_values_compact(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, reinterpret_cast<uint32_t*>(P.dvalues) + P.valuesStored,
-                                    P.winBits, ctx->locMaxTarget, ctx->locMaxWindow, (unsigned int*)(counters + 3), st);
+                                    gwl, (unsigned int*)(counters + 3), st);
     else
         launch_table_values(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
     HIP_TRY(ctx, hipGetLastError());
@@ -209,6 +210,8 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->parts) { if (p.dbuckets) (void)hipFree(p.dbuckets); if (p.dvalues) (void)hipFree(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
+    if (ctx->dGwBase) (void)hipFree(ctx->dGwBase);
+    if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
                         &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill};
@@ -265,12 +268,37 @@ static int allocate_table(mc_ctx* ctx)
         // one part: the table is built on the device, batch by batch (table_build.hip)
         T.dvaluesCap = nvalues + 1;
         T.compact = false;
-        if (ctx->locRangeKnown && ctx->compactAllowed) {
-            const uint32_t wb = bits_for(ctx->locMaxWindow), tbits = bits_for(ctx->locMaxTarget);
-            // 0xFFFFFFFF stays free: the kernels' "no location" in the compact form
-            if (wb + tbits <= 32 && (((uint64_t)ctx->locMaxTarget << wb) | ctx->locMaxWindow) < 0xFFFFFFFFull) { T.compact = true; T.winBits = wb; }
+        if (!ctx->targetWindows.empty() && ctx->compactAllowed) {
+            // global window numbers: gwBase[0] = gap, gwBase[t + 1] = gwBase[t] + windows(t) + gap; 0xFFFFFFFF stays free (the kernels' "no location")
+            uint32_t gap = kGwGap;
+            if (const char* e = std::getenv("MC_GW_GAP")) gap = (uint32_t)std::max(8, std::atoi(e));   // tests: reads whose window range exceeds the gap
+            const size_t nt = ctx->targetWindows.size();
+            uint64_t total = gap;
+            for (uint32_t w : ctx->targetWindows) total += (uint64_t)w + gap;
+            if (total < 0xFFFFFFFFull) {
+                std::vector<uint32_t> base(nt + 1);
+                base[0] = gap;
+                for (size_t t = 0; t < nt; ++t) base[t + 1] = base[t] + ctx->targetWindows[t] + gap;
+                uint32_t shift = 6;
+                while (((total >> shift) + 2) > (1ull << 22)) ++shift;            // directory of at most 4 M entries
+                const size_t nd = (size_t)(total >> shift) + 2;
+                std::vector<uint32_t> dir(nd);
+                size_t t = 0;
+                for (size_t blk = 0; blk < nd; ++blk) {                            // dir[blk] = target whose numbers (gap included) hold max(blk << shift, gap)
+                    const uint64_t g = std::max<uint64_t>((uint64_t)blk << shift, gap);
+                    while (t + 1 < nt && g >= base[t + 1]) ++t;
+                    dir[blk] = (uint32_t)t;
+                }
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->dGwBase, (nt + 1) * 4));
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->dGwDir, nd * 4));
+                HIP_TRY(ctx, hipMemcpy(ctx->dGwBase, base.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(ctx->dGwDir, dir.data(), nd * 4, hipMemcpyHostToDevice));
+                ctx->gwDirShift = shift; ctx->gwGap = gap; ctx->gwTargets = (uint32_t)nt;
+                T.compact = true;
+            }
         }
-        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, T.dvaluesCap * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
+        // (+ 4 entries: the filter reads the compact lists 16 bytes at a time, a list's last load may reach 3 entries past its end)
+        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, (T.dvaluesCap + 4) * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
         HIP_TRY(ctx, hipMalloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
         HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
         int rc = ensure(ctx, ctx->bLdCounters, 4 * sizeof(unsigned long long));
@@ -307,11 +335,22 @@ static int load_batch_device(mc_ctx* ctx, const uint32_t* keys, const uint8_t* s
     return MC_OK;
 }
 
+int mc_load_target_windows(mc_ctx* ctx, const uint32_t* windows, uint64_t numTargets)
+{
+    if (!ctx || (!windows && numTargets)) return MC_ERR_INVALID;
+    for (auto& p : ctx->parts) if (p.announced) return fail(ctx, MC_ERR_STATE, "mc_load_target_windows: call it before mc_load_begin");
+    if (numTargets >= 0xFFFFFFFFull) return fail(ctx, MC_ERR_INVALID, "mc_load_target_windows: too many targets");
+    ctx->targetWindows.assign(windows, windows + numTargets);
+    return MC_OK;
+}
+
+// the same announcement when only bounds are known: targets 0 .. maxTarget, each with maxWindow + 1 windows
 int mc_load_location_range(mc_ctx* ctx, uint32_t maxTarget, uint32_t maxWindow)
 {
     if (!ctx) return MC_ERR_INVALID;
     for (auto& p : ctx->parts) if (p.announced) return fail(ctx, MC_ERR_STATE, "mc_load_location_range: call it before mc_load_begin");
-    ctx->locRangeKnown = true; ctx->locMaxTarget = maxTarget; ctx->locMaxWindow = maxWindow;
+    ctx->targetWindows.clear();
+    if (((uint64_t)maxTarget + 1) * ((uint64_t)maxWindow + 1 + kGwGap) < 0xFFFFFFFFull) ctx->targetWindows.assign((size_t)maxTarget + 1, maxWindow + 1);
     return MC_OK;
 }
 
@@ -319,7 +358,7 @@ int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4])
 {
     if (!ctx || !layout || ctx->parts.empty()) return MC_ERR_INVALID;
     const Part& T = ctx->parts[0];
-    layout[0] = T.compact ? 4 : 8; layout[1] = T.compact ? T.winBits : 0; layout[2] = T.nbuckets; layout[3] = T.valuesStored;
+    layout[0] = T.compact ? 4 : 8; layout[1] = T.compact ? ctx->gwGap : 0; layout[2] = T.nbuckets; layout[3] = T.valuesStored;
     return MC_OK;
 }
 
@@ -446,7 +485,7 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
         for (auto* b : st) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
         if (full) return fail(ctx, MC_ERR_NOMEM, "hash table full");
         if (c[3]) ctx->locRangeViolated = true;
-        if (c[3]) return fail(ctx, MC_ERR_INVALID, "a location lies outside the range announced with mc_load_location_range");
+        if (c[3]) return fail(ctx, MC_ERR_INVALID, "a location lies outside the range announced with mc_load_target_windows / mc_load_location_range");
         ctx->tableReady = true;
         return MC_OK;
     }
@@ -598,7 +637,10 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const Part& T = ctx->parts[0];
     const bool multiPart = ctx->parts.size() > 1;
     DeviceTable tab{T.dbuckets, T.dvalues, T.nbuckets, multiPart ? 0x00FFFFFFu : 0xFFFFFFFFu, T.maxProbe};
-    if (T.compact) { tab.values = nullptr; tab.values32 = reinterpret_cast<const uint32_t*>(T.dvalues); tab.winBits = T.winBits; }
+    if (T.compact) {
+        tab.values = nullptr; tab.values32 = reinterpret_cast<const uint32_t*>(T.dvalues);
+        tab.gwBase = ctx->dGwBase; tab.gwDir = ctx->dGwDir; tab.gwDirShift = ctx->gwDirShift; tab.gwGap = ctx->gwGap; tab.gwTargets = ctx->gwTargets;
+    }
 
     {
         ScopedTimer t(ctx, "plan", st);

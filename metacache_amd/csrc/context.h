@@ -36,10 +36,9 @@ struct Part {
     uint32_t nbuckets = 0, maxProbe = 1;
     bool loading = false, ready = false, announced = false;
     TableBucket* dbuckets = nullptr;
-    uint64_t* dvalues = nullptr;    // compact: the same allocation holds uint32_t entries ((tgt << winBits) | win)
+    uint64_t* dvalues = nullptr;    // compact: the same allocation holds uint32_t entries (global window numbers, kernels.h DeviceTable)
     uint64_t dvaluesCap = 0;
     bool compact = false;
-    uint32_t winBits = 0;
 };
 
 struct Taxon {
@@ -86,10 +85,14 @@ struct mc_ctx {
     uint64_t maxLocs = 254, targetCount = 0;
     std::vector<mcamd::Part> parts;
     float loadFactor = 0.5f;
-    // mc_load_location_range: no location of the database has a larger target id / window id.  When both fit 32 bits together
-    // (and the table is a single part) the location lists are stored in 4 bytes each (DeviceTable::values32).
-    bool locRangeKnown = false, compactAllowed = true, locRangeViolated = false;
-    uint32_t locMaxTarget = 0, locMaxWindow = 0;
+    // mc_load_target_windows: every target's window count.  When all windows of the database (plus a gap per target) can be numbered
+    // in 32 bits and the table is a single part, the location lists are stored as global window numbers, 4 bytes each
+    // (DeviceTable::values32 / gwBase / gwDir).
+    bool compactAllowed = true, locRangeViolated = false;
+    std::vector<uint32_t> targetWindows;   // empty: not announced
+    uint32_t* dGwBase = nullptr;           // [targets + 1]
+    uint32_t* dGwDir = nullptr;
+    uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0;
     bool tableReady = false;
     std::vector<uint64_t> hvalues;          // multi-part load: all location lists on the host until the last part is in
 

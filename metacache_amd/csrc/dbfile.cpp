@@ -168,9 +168,10 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         firstPart = (uint32_t)cfg.single_part; cfg.num_parts = 1;
     }
     mc_ctx* ctx = nullptr;
-    // Single-part databases whose target ids and window ids fit 32 bits together get the compact location store (4 bytes per
-    // location, DeviceTable::values32); the range comes from the target metadata (every target's window count).  Should a file
-    // hold a location outside of what its own metadata says, the load is repeated with 8-byte locations.
+    // Single-part databases whose windows can be numbered in 32 bits get the compact location store (4 bytes per location: global
+    // window numbers, DeviceTable::values32); every target's window count comes from the target metadata (taxonomy.hpp:264-280
+    // file_source::windows; targets carry the ids -(target) - 1, taxonomy.hpp:930).  Should a file hold a location outside of what
+    // its own metadata says, the load is repeated with 8-byte locations.
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = mc_create(&cfg, &ctx))) return rc;
         ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
@@ -178,11 +179,19 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
         ctx->taxa = std::move(m.taxa);
         m.taxa.clear();
-        uint64_t maxWindows = 0;
-        for (const auto& t : ctx->taxa) maxWindows = std::max<uint64_t>(maxWindows, t.windows);
-        const bool tryCompact = attempt == 0 && cfg.num_parts == 1 && m.targetCount > 0 && m.targetCount <= 0xFFFFFFFFull &&
-                                maxWindows > 0 && maxWindows <= 0xFFFFFFFFull;
-        if (tryCompact) rc = mc_load_location_range(ctx, (uint32_t)(m.targetCount - 1), (uint32_t)(maxWindows - 1));
+        bool tryCompact = attempt == 0 && cfg.num_parts == 1 && m.targetCount > 0 && m.targetCount < 0xFFFFFFFFull;
+        if (tryCompact) {
+            std::vector<uint32_t> windows((size_t)m.targetCount, 0u);
+            uint64_t seen = 0;
+            for (const auto& t : ctx->taxa) {
+                if (t.id >= 0) continue;
+                const uint64_t tgt = (uint64_t)(-(t.id + 1));
+                if (tgt >= m.targetCount || t.windows > 0xFFFFFFF0ull) { tryCompact = false; break; }
+                windows[(size_t)tgt] = (uint32_t)t.windows; ++seen;
+            }
+            tryCompact = tryCompact && seen == m.targetCount;
+            if (tryCompact) rc = mc_load_target_windows(ctx, windows.data(), windows.size());
+        }
         // every part is announced first (the merged table is sized for all of them), then loaded in part order
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
             PartHeader h;

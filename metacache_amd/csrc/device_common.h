@@ -1,0 +1,97 @@
+// metacache_amd/csrc/device_common.h -- what the kernel files (kernels.hip, gw_kernels.hip) share on the device side: per-query state
+// flags, wave64 primitives, the candidate record and the limits of the work-list classes.  Internal.
+#pragma once
+
+#include "kernels.h"
+
+namespace mcamd {
+
+// per-query state: what is still to be done (Workspace::qflag)
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6, kFlagGather = 7;
+
+// ================================================================================================
+// wave64 primitives
+// ================================================================================================
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// DPP controls: quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l)
+{
+    return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+
+// all 64 lanes must be active
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dpp_mov<0xB1>(v));
+    v = min(v, dpp_mov<0x4E>(v));
+    v = min(v, dpp_mov<0x141>(v));
+    v = min(v, dpp_mov<0x140>(v));
+    return min(min(rdlane(v, 0), rdlane(v, 16)), min(rdlane(v, 32), rdlane(v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+// orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote).
+// Heavy: waits for every outstanding global load AND store of the wave.
+__device__ __forceinline__ void wave_mem_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// LDS-only flavour: DS operations of one wave execute in issue order, so all that is needed is that
+// the compiler keeps the order and earlier DS results have landed; outstanding global stores are NOT
+// drained (an s_waitcnt vmcnt(0) per window exposed the full HBM write latency).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_mov<0xB1>(v));
+    v = max(v, dpp_mov<0x4E>(v));
+    v = max(v, dpp_mov<0x141>(v));
+    v = max(v, dpp_mov<0x140>(v));
+    return max(max(rdlane(v, 0), rdlane(v, 16)), max(rdlane(v, 32), rdlane(v, 48)));
+}
+
+
+struct mc_candidate_dev { uint32_t tgt, hits, beg, end; };
+
+constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
+constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
+constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: longest list, entries, maxWindowsInRange
+constexpr uint32_t kBigEnt = 64;          // big_filter_kernel: found features per query, one lane each ...
+constexpr uint32_t kBigEPL = 3;           // ... or up to three per lane in its second instance (reads and pairs of 5 .. 10 windows: 2 x 250 bp, 500 bp)
+
+// big_filter_kernel / gw_filter_kernel -> counting kernels: longest filtered list the counting kernels take
+constexpr uint32_t kBigMaxFilteredCount = 1024;
+constexpr uint32_t kGwSmallH = 2048;      // compact store: reads with more locations take gw_filter_kernel's instance with the larger filters
+
+// gw_kernels.hip: the filtered path of tables with the compact location store (stages as launch_big_cands)
+void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                     const uint32_t* taxkey, void* cands, hipStream_t st);
+
+}  // namespace mcamd

@@ -1,0 +1,675 @@
+// metacache_amd/csrc/gw_kernels.hip -- the filtered candidate path of tables with the COMPACT location store:
+// a location is one 32-bit GLOBAL WINDOW NUMBER gw = gwBase[target] + window (kernels.h DeviceTable), with gwGap unused numbers
+// between two targets.  That layout is what these kernels are built on:
+//   * two locations can lie in one window range (candidate_generation.hpp:47-108: same target, windows less than maxWindowsInRange
+//     apart) iff their numbers differ by less than maxWindowsInRange -- no target needed;
+//   * gw - d is "the same target, d windows earlier" or no location at all;
+//   * the order of the numbers is the order of (target, window) (database.hpp:151-156), so "hits descending, then the smaller
+//     number" is the insertion order of the reference's top list (candidate_generation.hpp:172-201).
+// One WAVE per read throughout, persistent grids over the work list probe_cands_kernel / chunk_finish_kernel leave (list 6).
+//
+//   gw_filter_kernel   keeps the locations that have a neighbour (another location of the read less than maxWindowsInRange away):
+//                      only those can be part of a window range with two or more hits.  RefSeq scale: 1 271 locations per 150 bp read,
+//                      about 250 kept.
+//   gw_count_kernel    exact hits per window range of the kept locations in an LDS hash table keyed by the number itself, K rounds
+//                      of a wave-wide maximum; the places candidates with ONE hit may take (step D) from a sweep over all lists.
+// Both are bound by VALU issue, not by memory (round 2's kernels: 7.5 x 10^9 and 3.1 x 10^9 wave instructions per 5 x 10^6 reads are
+// 14 and 6 ms of the SIMDs' time): everything below is written to need few instructions per location -- 16-byte loads of four
+// locations per lane, the read's whole list held in registers between the filter's two phases (no second pass over the fabric),
+// 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction), one LDS operation per location and phase.
+#include "device_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace mcamd {
+
+namespace {
+
+constexpr uint32_t kGwNone = 0xFFFFFFFFu;                 // never a stored number
+constexpr uint32_t kGwRounds = 128;                       // rounds (16 consecutive numbers of one bucket list = 64 bytes) per batch: 8 wave loads
+constexpr uint32_t kGwLoads = kGwRounds / 16;             // 16-byte loads per lane and batch: 32 registers hold 2 048 list places
+constexpr uint32_t kGwMaxKept = 65535;                    // longest filtered list handed on
+
+struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };   // 16-byte load from a 4-byte aligned address (global_load_dwordx4)
+
+// ---- the filter's key: the location's BLOCK of 2^A window numbers.  Two locations less than maxWindowsInRange apart share a block
+// unless a block boundary lies between them -- and then both are within D = maxWindowsInRange - 1 of that boundary: such locations
+// are kept without asking.  With 2^A >= 64 D that is 3 % of the single hits at most; blocks this small hardly ever hold two unrelated
+// locations of one read (1 271 numbers in 1.3 x 10^9), which a filter keyed on targets does 40 times per read at RefSeq scale.
+__device__ __forceinline__ uint32_t gw_block_shift(uint32_t maxWin)
+{
+    const uint32_t D = maxWin > 1 ? maxWin - 1 : 1;
+    const uint32_t A = 32u - (uint32_t)__builtin_clz(64u * D - 1u);     // 2^A >= 64 D
+    return A < 8u ? 8u : A;                                              // (keys below 2^24: 24-bit multiply)
+}
+
+// blocked Bloom filters in LDS, as round 2's: "seen" = 2 bits of ONE word per key, set with a returning ds_or; both found set = the
+// key was seen before (or two other keys set them) -> the same bits in "twice".  T1 == T2: "twice" is the word at a fixed distance
+// (no second address computation).
+template <uint32_t T1LOG2, uint32_t T2LOG2>
+struct GwBloom {
+    static constexpr uint32_t kW1 = (1u << T1LOG2) / 32, kW2 = (1u << T2LOG2) / 32, kWords = kW1 + kW2;
+    static constexpr bool kSame = T1LOG2 == T2LOG2;
+    static_assert(kWords % 256 == 0, "cleared with one uint4 per lane and step");
+    // 24-bit multiply (keys are below 2^24): full rate, where v_mul_lo_u32 takes four issue slots.  (Written as an instruction: the
+    // compiler turns __umul24 of a value it knows to be short back into a 32-bit multiply.)
+    __device__ __forceinline__ static uint32_t hash(uint32_t key)
+    {
+        uint32_t h;
+        asm("v_mul_u32_u24_e32 %0, 0x9e3779, %1" : "=v"(h) : "v"(key));
+        return h;
+    }
+    // two bits of one word: positions h[4:0] (the shifter takes the low five bits by itself) and h[16:12]
+    __device__ __forceinline__ static uint32_t mask_of(uint32_t h)
+    {
+        uint32_t m1, m;
+        asm("v_lshlrev_b32_e64 %0, %1, 1" : "=v"(m1) : "v"(h));
+        asm("v_lshl_or_b32 %0, 1, %1, %2" : "=v"(m) : "v"(h >> 12), "v"(m1));
+        return m;
+    }
+    __device__ __forceinline__ static uint32_t seen_index(uint32_t h)                                            // the word: the product's top bits
+    {
+        uint32_t i;                                            // (as an instruction: the compiler would fold the shift into shift + and + add)
+        asm("v_lshrrev_b32_e32 %0, %1, %2" : "=v"(i) : "n"(37u - T1LOG2), "v"(h));
+        return i;
+    }
+    __device__ __forceinline__ static uint32_t twice_index(uint32_t seen, uint32_t h)
+    {
+        if constexpr (kSame) return seen + kW1;
+        else return kW1 + ((h >> 17) & (kW2 - 1u));
+    }
+    // phase A for four keys: the four returning ds_or go out together (one LDS round trip instead of four), then the four into "twice"
+    // -- unconditional: an or with 0 costs less than the branch around it
+    __device__ __forceinline__ static void mark4(uint32_t* bits, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
+    {
+        const uint32_t k[4] = {k0, k1, k2, k3};
+        uint32_t m[4], i1[4], i2[4], old[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t h = hash(k[j]); m[j] = mask_of(h); i1[j] = seen_index(h); i2[j] = twice_index(i1[j], h); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) old[j] = atomicOr(&bits[i1[j]], m[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicOr(&bits[i2[j]], (old[j] & m[j]) == m[j] ? m[j] : 0u);
+    }
+    __device__ __forceinline__ static void mark(uint32_t* bits, uint32_t key)
+    {
+        const uint32_t h = hash(key), m = mask_of(h), i1 = seen_index(h);
+        const uint32_t old = atomicOr(&bits[i1], m);
+        atomicOr(&bits[twice_index(i1, h)], (old & m) == m ? m : 0u);
+    }
+    __device__ __forceinline__ static bool twice(const uint32_t* bits, uint32_t key)
+    {
+        const uint32_t h = hash(key), m = mask_of(h);
+        return (bits[twice_index(seen_index(h), h)] & m) == m;
+    }
+};
+
+// What both filter kernels share: the per-read frame (block size of the keys, edge test, the pool slice) and the two phases on a
+// batch of kGwRounds rounds held in registers.
+struct GwFrame {
+    uint32_t A, D, blockMask, inner;                           // keys = number >> A; (number & blockMask) - D >= inner: within D of a block boundary
+    __device__ __forceinline__ explicit GwFrame(uint32_t maxWin)
+    {
+        A = gw_block_shift(maxWin); D = maxWin > 1 ? maxWin - 1 : 0u;
+        blockMask = (1u << A) - 1u; inner = (1u << A) - 2u * D;
+    }
+    __device__ __forceinline__ bool edge(uint32_t v) const { return ((v & blockMask) - D) >= inner; }
+};
+
+// round table of the batch [r0, r0 + kGwRounds) of an entry chunk's rounds: first index | numbers << 40.  start / myR: the lane's entry
+// begins at round 'start' of the chunk and has myR rounds.
+__device__ __forceinline__ void gw_fill_rounds(uint64_t* T, uint32_t lane, uint32_t r0, uint32_t Rc, uint32_t start, uint32_t myR, uint32_t sz, uint64_t pay)
+{
+    for (uint32_t i = lane; i < kGwRounds; i += 64) if (r0 + i >= Rc) T[i] = 0ull;
+    const uint32_t jlo = r0 > start ? r0 - start : 0u, jhi = min(myR, r0 + kGwRounds > start ? r0 + kGwRounds - start : 0u);
+    for (uint32_t j = jlo; j < jhi; ++j) T[start + j - r0] = (pay + 16ull * j) | ((uint64_t)min(16u, sz - 16u * j) << 40);
+}
+// the batch's numbers: 16 bytes per lane and load, four lanes per round; places without a round read as kGwNone
+__device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads])
+{
+#pragma unroll
+    for (uint32_t u = 0; u < kGwLoads; ++u) {
+        const uint64_t rd = T[u * 16 + grp];
+        x[u] = make_uint4(kGwNone, kGwNone, kGwNone, kGwNone);
+        if (sub4 < (uint32_t)(rd >> 40)) {
+            const U4 t = *reinterpret_cast<const U4*>(values32 + (rd & 0xFFFFFFFFFFull) + sub4);
+            x[u] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    }
+}
+// phase A on a batch: every place of the loaded lines marks its block (places past a list's end hold other lists' numbers: more
+// marks, never fewer)
+template <class Bloom>
+__device__ __forceinline__ void gw_mark_rounds(uint32_t* bits, const uint4 (&x)[kGwLoads], uint32_t A)
+{
+#pragma unroll
+    for (uint32_t u = 0; u < kGwLoads; ++u) Bloom::mark4(bits, x[u].x >> A, x[u].y >> A, x[u].z >> A, x[u].w >> A);
+}
+// phase B: a number is kept if its block was marked twice or it lies within D of a block boundary; the kept ones are appended to dst
+// (ballot compaction), n2 counts them whether they fit or not
+struct GwSink { uint32_t* dst; uint32_t room, n2; };
+template <class Bloom>
+__device__ __forceinline__ void gw_take(const uint32_t* bits, const GwFrame& F, GwSink& S, uint32_t v, bool valid)
+{
+    const bool keep = valid & (Bloom::twice(bits, v >> F.A) | F.edge(v));
+    const uint64_t m = __ballot(keep);
+    if (keep) {
+        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, S.n2));
+        if (at < S.room) S.dst[at] = v;
+    }
+    S.n2 += (uint32_t)__popcll(m);
+}
+// four numbers at a time: the four filter words are read together (one LDS round trip), no branch but the ones around the stores.
+// CHECK = false: the caller has made sure that everything this read can keep fits the slice.
+template <class Bloom, bool CHECK>
+__device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F, GwSink& S, const uint4 x, const int32_t rem)
+{
+    const uint32_t v[4] = {x.x, x.y, x.z, x.w};
+    uint32_t m[4], wd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t h = Bloom::hash(v[j] >> F.A);
+        m[j] = Bloom::mask_of(h);
+        wd[j] = bits[Bloom::twice_index(Bloom::seen_index(h), h)];
+    }
+    // (ballots of the three compares, combined on the scalar unit: a ballot of the combined condition costs two VALU instructions more)
+    uint64_t km[4]; bool kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool valid = rem > j, hit = (wd[j] & m[j]) == m[j], edge = F.edge(v[j]);
+        kb[j] = valid & (hit | edge);
+        km[j] = __ballot(valid) & (__ballot(hit) | __ballot(edge));
+    }
+    uint32_t n2 = S.n2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (kb[j]) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(km[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km[j], n2));
+            if (!CHECK || at < S.room) S.dst[at] = v[j];
+        }
+        n2 += (uint32_t)__popcll(km[j]);
+    }
+    S.n2 = n2;
+}
+template <class Bloom, bool CHECK>
+__device__ __forceinline__ void gw_take_rounds(const uint32_t* bits, const uint64_t* T, const GwFrame& F, GwSink& S, uint32_t grp, uint32_t sub4,
+                                               const uint4 (&x)[kGwLoads])
+{
+#pragma unroll
+    for (uint32_t u = 0; u < kGwLoads; ++u) {
+        const int32_t rem = (int32_t)(uint32_t)(T[u * 16 + grp] >> 40) - (int32_t)sub4;     // numbers of the round from this lane's first on
+        gw_take4<Bloom, CHECK>(bits, F, S, x[u], rem);
+    }
+}
+
+constexpr uint32_t kGwDefer = 0xFFFFFFFEu;                 // record of list 7: left to gw_filter_stream_kernel
+constexpr uint32_t kGwFallback = 0xFFFFFFFFu;              // ... handed to the wave kernel
+
+}  // namespace
+
+// The common case in ONE batch: a read with up to 64 found features whose lists are up to kGwRounds rounds (150 bp reads and most pairs
+// at RefSeq scale: 26 lists of 49 numbers = 104 rounds).  The numbers are loaded ONCE -- 8 x 16 bytes per lane -- and stay in registers
+// for both phases.  Reads that do not fit (and all with more than kGwSmallH locations) are left to gw_filter_stream_kernel.
+#ifndef MC_GW_FILTER_WPE
+#define MC_GW_FILTER_WPE 4
+#endif
+template <uint32_t WAVES, uint32_t TLOG2>
+__global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
+{
+    using Bloom = GwBloom<TLOG2, TLOG2>;
+    __shared__ uint32_t bitS[WAVES][Bloom::kWords];
+    __shared__ uint64_t roundS[WAVES][kGwRounds];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the wave's pointers and counters live in scalar registers)
+    uint32_t* bits = bitS[wave];
+    uint64_t* T = roundS[wave];
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    // this wave's slice of the pool (no atomics on global memory: round 2 measured 43 ms for two shared cursors)
+    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
+    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
+    uint64_t sliceUsed = 0;
+    uint32_t deferred = 0;
+    uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
+    uint32_t esz = 0; uint64_t epay = 0;                           // the read's entries, fetched one read ahead
+    auto load_entries = [&](const uint4& r) {
+        const uint32_t ne = (r.z >> 12) <= kGwSmallH ? min(r.z & 0xFFFu, 64u) : 0u;
+        esz = lane < ne ? ws.psize[r.y + lane] : 0u;
+        epay = lane < ne ? ws.ppay[r.y + lane] : 0ull;
+    };
+    load_entries(rec);
+    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
+        const uint32_t sz = esz & 0xFFFFu; const uint64_t pay = epay;
+        rec = recNext;                                             // the next read's record and entries are on their way meanwhile
+        recNext = load_rec(w + 2 * nWaves);
+        load_entries(rec);
+        if (H > kGwSmallH) continue;                               // the other kernel's read
+        const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
+        const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
+        // (a slice that cannot take everything one batch may keep -- kGwRounds x 16 + 64 numbers -- sends the read on as well: the stores
+        // below are not bounds-checked)
+        if (nent > 64u || Rc > kGwRounds || maxWin > tab.gwGap || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
+            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin);
+            ++deferred;
+            continue;
+        }
+        {
+            uint4* z4 = reinterpret_cast<uint4*>(bits);
+#pragma unroll
+            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        gw_fill_rounds(T, lane, 0, Rc, incl - myR, myR, sz, pay);
+        wave_lds_sync();
+        const GwFrame F(maxWin);
+        uint4 x[kGwLoads];
+        gw_load_rounds(T, tab.values32, grp, sub4, x);
+        const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;     // single locations live in their buckets in the 8-byte form
+        GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+        // ---- A
+        Bloom::mark(bits, sv >> F.A);
+        gw_mark_rounds<Bloom>(bits, x, F.A);
+        wave_lds_sync();
+        // ---- B
+        gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+        gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
+        // longer than what is handed on, or the slice is full; (for now) longer than the counting kernels take
+        const bool fallback = S.n2 > S.room || S.n2 > kBigMaxFilteredCount || maxWin > kHashWin;
+        if (lane == 0) {
+            if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
+            else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+        }
+        if (!fallback) sliceUsed += S.n2;
+        wave_lds_sync();
+    }
+    if (lane == 0) {
+        if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
+        if (deferred) atomicAdd(&ws.midCount[10], deferred);       // (one atomic per wave that met such reads at all)
+    }
+}
+
+// Everything else: reads with more than 64 found features, lists of more than kGwRounds rounds, more than kGwSmallH locations (long
+// reads: thousands to tens of thousands).  Entries in chunks of 64, rounds in batches of kGwRounds, two passes over the lists (the
+// second one finds them in the L2 / infinity cache), filters sized for tens of thousands of keys.  Same waves, same pool slices
+// (ws.sliceFill) as gw_filter_kernel, after which it runs; returns at once when the batch has no such read (midCount[10]).
+template <uint32_t WAVES, uint32_t T1LOG2, uint32_t T2LOG2>
+__global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView b, DeviceTable tab, Workspace ws)
+{
+    using Bloom = GwBloom<T1LOG2, T2LOG2>;
+    __shared__ uint32_t bitS[WAVES][Bloom::kWords];
+    __shared__ uint64_t roundS[WAVES][kGwRounds];
+    if (ws.midCount[10] == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* bits = bitS[wave];
+    uint64_t* T = roundS[wave];
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
+    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
+    uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;
+    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint4 rec = work[w];
+        const uint32_t q = rec.x, fbase = rec.y, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
+        if (H <= kGwSmallH && outRec[w].z != kGwDefer) continue;   // gw_filter_kernel's read, done
+        {
+            uint4* z4 = reinterpret_cast<uint4*>(bits);
+#pragma unroll
+            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        const GwFrame F(maxWin);
+        GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+        bool fallback = maxWin > tab.gwGap;                        // (window ranges wider than the gap between two targets: the kernels that know the targets)
+        const uint32_t nchunks = (nent + 63u) / 64u;
+        if (!fallback) {
+            for (uint32_t pass = 0; pass < 2; ++pass) {
+                for (uint32_t c = 0; c < nchunks; ++c) {
+                    const uint32_t e = c * 64u + lane;
+                    const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
+                    const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
+                    const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
+                    if (pass == 0) Bloom::mark(bits, sv >> F.A); else gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+                    const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
+                    const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
+                    for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
+                        gw_fill_rounds(T, lane, r0, Rc, incl - myR, myR, sz, pay);
+                        wave_lds_sync();
+                        uint4 x[kGwLoads];
+                        gw_load_rounds(T, tab.values32, grp, sub4, x);
+                        if (pass == 0) gw_mark_rounds<Bloom>(bits, x, F.A); else gw_take_rounds<Bloom, true>(bits, T, F, S, grp, sub4, x);
+                        wave_lds_sync();                           // the table is rewritten by the next batch
+                    }
+                }
+                wave_lds_sync();
+            }
+            fallback = S.n2 > S.room || S.n2 > kBigMaxFilteredCount || maxWin > kHashWin;
+        }
+        if (lane == 0) {
+            if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
+            else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+        }
+        if (!fallback) sliceUsed += S.n2;
+        wave_lds_sync();
+    }
+}
+
+namespace {
+
+// ================================================================================================
+// gw_count_kernel: rows 8-10 on a filtered list, without a sort (round 1's hash_cands_kernel on global window numbers):
+//   1. every number is counted in an LDS hash table of {number, count} slots (32-bit compare-and-swap claims a slot, the count sits
+//      in the same 8 bytes: one ds_read_b64 per lookup);
+//   2. the lane that claimed number g adds the counts of g - 1 .. g - (maxWindowsInRange - 1): the hits of the window range that
+//      ENDS in g (candidate_generation.hpp:47-108 evaluates exactly these; the first to reach a target's maximum is the one with the
+//      smallest end window); begin = the smallest number present among them;
+//   3. K rounds: wave-wide maximum of the hits, the smallest number among its holders, that target (its numbers: one look at the
+//      directory per round) or taxon is struck from the race -- the sequential top-K insert of candidate_generation.hpp:172-231;
+//   D. when fewer than K picked candidates have two or more hits, the open places go to the smallest numbers of other targets among
+//      ALL the read's locations (hits = 1 candidates arrive in (target, window) order and keep it) -- one sweep over the lists.
+// ================================================================================================
+template <uint32_t LOG2S>
+__device__ __forceinline__ uint32_t gw_slot(uint32_t g)                 // byte offset of the home slot
+{
+    return (__umul24(g ^ (g >> 12), 0x9E3779u) >> (29u - LOG2S)) & (((1u << LOG2S) - 1u) << 3);
+}
+
+template <uint32_t LOG2S, uint32_t PER, bool TAX>
+__device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], uint2* slots, const uint32_t lane, const uint32_t maxWin,
+                                                      const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
+                                                      mc_candidate_dev* __restrict__ out, uint32_t (&pickLo)[kLaneK], uint32_t (&pickHi)[kLaneK])
+{
+    constexpr uint32_t kByteMask = ((1u << LOG2S) - 1u) << 3;
+    char* base = reinterpret_cast<char*>(slots);
+    auto key_at = [&](uint32_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(base + off); };
+    uint32_t off[PER];                                        // byte offset of the number's slot | 1 if this lane claimed it
+    {
+        uint32_t old[PER];
+        bool coll = false;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            off[r] = gw_slot<LOG2S>(v[r]);
+            old[r] = v[r] != kGwNone ? atomicCAS(key_at(off[r]), kGwNone, v[r]) : v[r];
+            coll = coll || (old[r] != kGwNone && old[r] != v[r]);
+        }
+        if (__ballot(coll)) {                                  // somebody else's number in the home slot: next slots, one at a time
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) {
+                if (old[r] != kGwNone && old[r] != v[r]) {
+                    uint32_t o = off[r];
+                    for (;;) {
+                        o = (o + 8u) & kByteMask;
+                        old[r] = atomicCAS(key_at(o), kGwNone, v[r]);
+                        if (old[r] == kGwNone || old[r] == v[r]) break;
+                    }
+                    off[r] = o;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            if (v[r] != kGwNone) atomicAdd(key_at(off[r]) + 1, 1u);
+            off[r] |= (v[r] != kGwNone && old[r] == kGwNone) ? 1u : 0u;
+        }
+    }
+    wave_lds_sync();
+    // ---- 2. ranges that end in the numbers this lane claimed: hits | (end - begin) << 16
+    uint32_t ptax[PER];
+    if constexpr (TAX) {
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) ptax[r] = (off[r] & 1u) ? taxkey[tab.gw_target(v[r])] : 0u;
+    }
+    uint32_t R[PER];
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) R[r] = (off[r] & 1u) ? key_at(off[r] & ~1u)[1] : 0u;
+    for (uint32_t d = 1; d < maxWin; ++d) {
+        uint2 kc[PER]; uint32_t o[PER];
+        bool chain = false;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            o[r] = gw_slot<LOG2S>(v[r] - d);                   // (v - d is never kGwNone: numbers start at gwGap >= maxWin)
+            kc[r] = *reinterpret_cast<const uint2*>(base + o[r]);
+            const bool live = (off[r] & 1u) != 0;
+            if (!live) kc[r].x = kGwNone;
+            chain = chain || (kc[r].x != v[r] - d && kc[r].x != kGwNone);
+        }
+        if (__ballot(chain)) {
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r)
+                while (kc[r].x != v[r] - d && kc[r].x != kGwNone) { o[r] = (o[r] + 8u) & kByteMask; kc[r] = *reinterpret_cast<const uint2*>(base + o[r]); }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r)
+            if (kc[r].x == v[r] - d) R[r] = ((R[r] & 0xFFFFu) + kc[r].y) | (d << 16);
+    }
+    // ---- 3. K rounds
+    uint32_t live = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) {
+        bool ok = (off[r] & 1u) != 0;
+        if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
+        live |= ok ? (1u << r) : 0u;
+    }
+    uint32_t strong = 0;
+    for (uint32_t rnd = 0; rnd < K; ++rnd) {
+        uint32_t hh = 0, hv = kGwNone, hd = 0, hg = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t h = R[r] & 0xFFFFu;
+            const bool take = ((live >> r) & 1u) && (h > hh || (h == hh && v[r] < hv));
+            if (take) { hh = h; hv = v[r]; hd = R[r] >> 16; if constexpr (TAX) hg = ptax[r]; }
+        }
+        const uint32_t mh = wave_max_u32(hh);
+        mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+        if (mh != 0) {
+            const uint32_t mv = wave_min_u32(hh == mh ? hv : kGwNone);
+            const uint32_t winner = __ffsll((unsigned long long)__ballot(hh == mh && hv == mv)) - 1;
+            const uint32_t d = rdlane(hd, winner);
+            const uint32_t t = tab.gw_target(mv), lo = tab.gwBase[t], hi = tab.gwBase[t + 1];     // wave-uniform: scalar loads
+            if constexpr (TAX) {
+                const uint32_t g = rdlane(hg, winner);
+#pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) if (ptax[r] == g) live &= ~(1u << r);
+            } else {
+#pragma unroll
+                for (uint32_t r = 0; r < PER; ++r) if (v[r] - lo < hi - lo) live &= ~(1u << r);
+            }
+            e.tgt = t; e.hits = mh; e.end = mv - lo; e.beg = e.end - d;
+            strong += mh >= 2 ? 1u : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) if (i == rnd) { pickLo[i] = lo; pickHi[i] = hi; }
+        }
+        if (lane == 0) out[rnd] = e;
+    }
+    return strong;
+}
+
+}  // namespace
+
+#ifndef MC_GW_COUNT_WPE
+#define MC_GW_COUNT_WPE 5
+#endif
+template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
+__global__ __launch_bounds__(WAVES * 64, LOG2S == 10 ? MC_GW_COUNT_WPE : 1) void gw_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+                                                                                             const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
+                                                                                             uint32_t minN2)
+{
+    constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
+    static_assert(kGwRounds * 8 <= kSlots * 8, "step D's round table lives in the slot table, which is done with by then");
+    __shared__ __attribute__((aligned(16))) uint2 slotS[WAVES][kSlots];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the wave's pointers and loop counters live in scalar registers)
+    uint2* slots = slotS[wave];
+    uint64_t* T = reinterpret_cast<uint64_t*>(slotS[wave]);
+    // the records gw_filter_kernel left (list 7, one per read of work list 6); this instance takes the filtered lists that fit its
+    // table: n2 in (minN2, kList], window ranges up to kHashWin
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint4* __restrict__ work6 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0xFFFFFFFFu, 0); };
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    uint4 rec = load_rec(w0), recN = load_rec(w0 + nWaves);
+    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint32_t q = rec.x, n2 = rec.z, maxWin = rec.w;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(ws.bigPool) + rec.y;
+        rec = recN; recN = load_rec(w + 2 * nWaves);
+        if (n2 > kList || (minN2 != 0 && n2 <= minN2) || maxWin > kHashWin) continue;   // (an EMPTY filtered list is the first instance's: step D fills the places)
+        {
+            uint4* k4 = reinterpret_cast<uint4*>(slots);
+#pragma unroll
+            for (uint32_t i = 0; i < kSlots * 8 / 16 / 64; ++i) k4[i * 64 + lane] = make_uint4(kGwNone, 0u, kGwNone, 0u);
+        }
+        wave_lds_sync();
+        uint32_t pickLo[kLaneK], pickHi[kLaneK];
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = 0; pickHi[i] = 0; }
+        uint32_t strong = 0;
+        mc_candidate_dev* out = cands + (size_t)q * K;
+        auto body = [&](auto perc) {
+            constexpr uint32_t PER = decltype(perc)::value;
+            uint32_t v[PER];
+#pragma unroll
+            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
+            strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, out, pickLo, pickHi);
+        };
+        const uint32_t per = (n2 + 63u) / 64u;
+        if constexpr (kList / 64 <= 8) {
+            if (per <= 1) body(std::integral_constant<uint32_t, 1>{});
+            else if (per <= 2) body(std::integral_constant<uint32_t, 2>{});
+            else if (per <= 3) body(std::integral_constant<uint32_t, 3>{});
+            else if (per <= 4) body(std::integral_constant<uint32_t, 4>{});
+            else if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
+            else body(std::integral_constant<uint32_t, 8>{});
+        } else {
+            if (per <= 10) body(std::integral_constant<uint32_t, 10>{});
+            else if (per <= 12) body(std::integral_constant<uint32_t, 12>{});
+            else body(std::integral_constant<uint32_t, kList / 64>{});
+        }
+        strong = __builtin_amdgcn_readfirstlane(strong);
+        bool done = true;
+        if (strong < K) {
+            const uint4 r6 = work6[w];
+            const uint32_t fbase = r6.y, nent = r6.z & 0xFFFu;
+            if (TAX || nent > kBigEnt) {
+                // places left for single-hit taxa: the order among those depends on every target's taxon -> the exact wave kernel
+                // (so do reads with more than 64 found features: the sweep below reads one entry per lane)
+                if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+                done = false;
+            } else if constexpr (!TAX) {
+                // ---- D. the smallest numbers of targets that were not picked with >= 2 hits -- every such target's best range is a
+                //      single location, and the first of them in (target, window) order are what the CPU's list keeps
+                wave_lds_sync();
+                const uint32_t sz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
+                const uint64_t pay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
+                const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
+                const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
+                // every lane keeps the kLaneK smallest numbers it sees (several may be one target's: the rounds below strike whole
+                // targets, and a lane that had to drop numbers and is left with none cannot vouch for its minimum any more)
+                uint32_t best[kLaneK];
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kGwNone;
+                uint32_t seen = 0;
+                auto visit = [&](uint32_t g, bool valid) {
+                    if (!valid) return;
+                    bool skip = false;
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) skip = skip || (i < strong && g - pickLo[i] < pickHi[i] - pickLo[i]);
+                    if (skip) return;
+                    ++seen;
+                    uint32_t c = g;                                 // sorted insert, the largest falls out
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) { const uint32_t lo = min(best[i], c); c = max(best[i], c); best[i] = lo; }
+                };
+                visit(sz == 1 ? tab.gw_of(pay) : kGwNone, sz == 1);
+                for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
+                    for (uint32_t i = lane; i < kGwRounds; i += 64) if (r0 + i >= Rc) T[i] = 0ull;
+                    const uint32_t jlo = r0 > start ? r0 - start : 0u, jhi = min(myR, r0 + kGwRounds > start ? r0 + kGwRounds - start : 0u);
+                    for (uint32_t j = jlo; j < jhi; ++j) T[start + j - r0] = (pay + 16ull * j) | ((uint64_t)min(16u, sz - 16u * j) << 40);
+                    wave_lds_sync();
+#pragma unroll
+                    for (uint32_t u = 0; u < kGwLoads; ++u) {
+                        const uint64_t rd = T[u * 16 + grp];
+                        const int32_t rem = (int32_t)(uint32_t)(rd >> 40) - (int32_t)sub4;
+                        if (rem > 0) {
+                            const U4 t = *reinterpret_cast<const U4*>(tab.values32 + (rd & 0xFFFFFFFFFFull) + sub4);
+                            visit(t.x, true); visit(t.y, rem > 1); visit(t.z, rem > 2); visit(t.w, rem > 3);
+                        }
+                    }
+                    wave_lds_sync();
+                }
+                const bool dropped = seen > kLaneK;
+                bool unsure = false;
+                for (uint32_t rnd = strong; rnd < K; ++rnd) {
+                    if (__ballot(dropped && best[0] == kGwNone)) { unsure = true; break; }
+                    const uint32_t m = wave_min_u32(best[0]);
+                    mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+                    if (m != kGwNone) {
+                        const uint32_t t = tab.gw_target(m), lo = tab.gwBase[t], hi = tab.gwBase[t + 1];
+                        e.tgt = t; e.hits = 1; e.beg = e.end = m - lo;
+                        // that target leaves every lane's list (its numbers are neighbours in the sorted list: compact the rest)
+                        uint32_t kept[kLaneK];
+#pragma unroll
+                        for (uint32_t i = 0; i < kLaneK; ++i) kept[i] = kGwNone;
+                        uint32_t n = 0;
+#pragma unroll
+                        for (uint32_t i = 0; i < kLaneK; ++i) {
+                            const bool stay = best[i] != kGwNone && !(best[i] - lo < hi - lo);
+#pragma unroll
+                            for (uint32_t j = 0; j < kLaneK; ++j) if (stay && j == n) kept[j] = best[i];
+                            n += stay ? 1u : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kept[i];
+                    }
+                    if (lane == 0) out[rnd] = e;
+                }
+                if (unsure) {
+                    if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+                    done = false;
+                }
+            }
+        }
+        if (done && lane == 0) ws.qflag[q] = kFlagDone;
+        wave_lds_sync();
+    }
+}
+
+static uint32_t gw_env(const char* name, uint32_t dflt)
+{
+    const char* e = std::getenv(name);
+    return e ? (uint32_t)std::max(1, std::atoi(e)) : dflt;
+}
+
+void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
+                     const uint32_t* taxkey, void* cands, hipStream_t st)
+{
+    if (b.n == 0) return;
+    mc_candidate_dev* c = (mc_candidate_dev*)cands;
+    const uint32_t fgrid = big_filter_grid(b.n);               // blocks of 4 waves: the pool is cut into one slice per wave
+    if (stage == 0) {
+        hipLaunchKernelGGL((gw_filter_kernel<4, 14>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
+    } else if (stage == 3) {
+        // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
+        hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
+    } else if (stage == 1) {
+        static const uint32_t bpc = gw_env("MC_BIG_COUNT_BPC", 5u);   // 32 KB of LDS per block
+        const uint32_t grid = std::min<uint32_t>(256 * bpc, (b.n + 3) / 4);
+        if (taxkey) hipLaunchKernelGGL((gw_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+        else        hipLaunchKernelGGL((gw_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+    } else if (stage == 2) {
+        static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
+        const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);
+        if (taxkey) hipLaunchKernelGGL((gw_count_kernel<11, 2, true>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
+        else        hipLaunchKernelGGL((gw_count_kernel<11, 2, false>), dim3(grid), dim3(128), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 512u);
+    }
+}
+
+}  // namespace mcamd

@@ -12,6 +12,8 @@ constexpr uint32_t kMaxSketch = 32;       // MC_MAX_SKETCH
 constexpr uint32_t kMaxWinLen = 1024;     // MC_MAX_WINLEN
 constexpr uint32_t kNoTail = 0xFFFFFFFFu; // qinfo[3] marker: single sequence, tail window suppressed
 constexpr uint32_t kMaxHitsPerQuery = (1u << 20) - 1;  // packed candidate fields are 20 bits wide
+constexpr uint32_t kGwGap = 1024;         // compact location store: unused window numbers between two targets (DeviceTable); window ranges up to this width
+                                          // (reads up to 114 kbp at the default stride) stay on the kernels that work on the numbers as they are
 
 // Table layout: an array of 64-byte BUCKETS of 4 slots, two per 128-byte line, structure-of-arrays so
 // that a single LANE looks a feature up with four 16-byte loads of ONE half line and has key, size and
@@ -64,14 +66,29 @@ struct DeviceTable {
     uint32_t nbuckets;
     uint32_t tgtMask;         // multi-part tables store (part << 24 | target) as target: mask to get the real id
     uint32_t maxProbe;        // longest probe sequence (in groups) needed by any stored key
-    // COMPACT location store (mc_load_location_range): when the database's target ids and window ids fit 32 bits TOGETHER, a location
-    // is stored as (tgt << winBits) | win in 4 bytes -- same order as the 8-byte form, half the bytes per list on the fabric and in HBM.
-    // values32 != nullptr selects it (values is unused then); the inline singleton payloads of the buckets keep the 8-byte form.
+    // COMPACT location store (mc_load_target_windows): a location is stored as ONE 32-bit GLOBAL WINDOW NUMBER
+    //     gw = gwBase[tgt] + win,   gwBase[0] = gwGap,   gwBase[t + 1] = gwBase[t] + windows(t) + gwGap
+    // -- same order as (tgt, win), half the bytes per list on the fabric and in HBM, and it fits whatever the targets look like as long
+    // as all windows of the database (plus a gap per target) stay below 2^32 (481 Gbp at the default window stride).  The GAP between
+    // two targets' numbers is what makes gw arithmetic safe without knowing the target: two locations lie in one window range
+    // (candidate_generation.hpp:47-108) iff their numbers differ by less than maxWindowsInRange <= gwGap, and gw - d (d < gwGap) is
+    // never another target's window.  values32 != nullptr selects the store (values is unused then); the inline singleton payloads of
+    // the buckets keep the 8-byte form.  0xFFFFFFFF is never a stored number.
     const uint32_t* values32 = nullptr;
-    uint32_t winBits = 0;
+    const uint32_t* gwBase = nullptr;     // [targets + 1]
+    const uint32_t* gwDir = nullptr;      // [(gwBase[targets] >> gwDirShift) + 1]: the target whose numbers (gap included) hold block << gwDirShift
+    uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0;
 
-    __device__ __forceinline__ static uint64_t widen(uint32_t p, uint32_t wb) { return ((uint64_t)(p >> wb) << 32) | (p & ((1u << wb) - 1u)); }
-    __device__ __forceinline__ uint64_t loc(uint64_t i) const { return values32 ? widen(values32[i], winBits) : values[i]; }
+    // target of a global window number (two dependent loads that hit the L2 / infinity cache: the directory has one entry per 2^gwDirShift windows)
+    __device__ __forceinline__ uint32_t gw_target(uint32_t gw) const
+    {
+        uint32_t t = gwDir[gw >> gwDirShift];
+        while (gw >= gwBase[t + 1]) ++t;
+        return t;
+    }
+    __device__ __forceinline__ uint64_t gw_widen(uint32_t gw) const { const uint32_t t = gw_target(gw); return ((uint64_t)t << 32) | (gw - gwBase[t]); }
+    __device__ __forceinline__ uint32_t gw_of(uint64_t loc) const { return gwBase[(uint32_t)(loc >> 32)] + (uint32_t)loc; }
+    __device__ __forceinline__ uint64_t loc(uint64_t i) const { return values32 ? gw_widen(values32[i]) : values[i]; }
 };
 __host__ __device__ inline uint32_t bits_for(uint32_t maxValue) { uint32_t b = 1; while (b < 32 && (maxValue >> b)) ++b; return b; }
 
@@ -150,17 +167,18 @@ void launch_probe_cands(const BatchView& b, const SketchParams& sp, const Device
                         const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st);
 // table_build.hip: GPU-side table construction from the file's batch stream
 struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt; };   // load-time modifiers + key shard
+struct GwLayout { const uint32_t* base = nullptr; uint32_t targets = 0, gap = 0; };   // compact store: gwBase[targets + 1] (DeviceTable)
 void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
                        unsigned long long* counters, hipStream_t st);
 void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff,
                          const uint32_t* storeOff, const uint8_t* vals, uint32_t tb, uint64_t storeBase, TableBucket* buckets,
-                         uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st);
+                         uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st,
+                         GwLayout gw = GwLayout{}, unsigned int* rangeErr = nullptr);   // gw.base: inline single locations are range-checked too
 void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
                          const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint64_t* dst, hipStream_t st);
-// compact store: dst32[...] = (tgt << winBits) | win; a location beyond (maxTgt, maxWin) raises *rangeErr instead
+// compact store: dst32[...] = gwBase[tgt] + win; a location outside its target's windows (or of an unknown target) raises *rangeErr instead
 void launch_table_values_compact(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
-                                 const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, uint32_t winBits, uint32_t maxTgt,
-                                 uint32_t maxWin, unsigned int* rangeErr, hipStream_t st);
+                                 const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, GwLayout gw, unsigned int* rangeErr, hipStream_t st);
 void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int quadMode, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);

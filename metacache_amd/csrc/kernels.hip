@@ -6,6 +6,7 @@
 //
 // No MFMA anywhere: this is integer hashing and gathering; the bound is HBM/L2 random access.
 #include "kernels.h"
+#include "device_common.h"
 #ifndef MC_LANE_HITS
 #define MC_LANE_HITS 24
 #endif
@@ -17,68 +18,6 @@
 #include <cstdlib>
 
 namespace mcamd {
-
-// per-query state: what is still to be done (Workspace::qflag)
-constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6, kFlagGather = 7;
-
-// ================================================================================================
-// wave64 primitives
-// ================================================================================================
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-// DPP controls: quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l)
-{
-    return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
-}
-
-// all 64 lanes must be active
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-    v = min(v, dpp_mov<0xB1>(v));
-    v = min(v, dpp_mov<0x4E>(v));
-    v = min(v, dpp_mov<0x141>(v));
-    v = min(v, dpp_mov<0x140>(v));
-    return min(min(rdlane(v, 0), rdlane(v, 16)), min(rdlane(v, 32), rdlane(v, 48)));
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    v += dpp_mov<0x141>(v);
-    v += dpp_mov<0x140>(v);
-    return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += o;
-    }
-    return v;
-}
-// orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote).
-// Heavy: waits for every outstanding global load AND store of the wave.
-__device__ __forceinline__ void wave_mem_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-// LDS-only flavour: DS operations of one wave execute in issue order, so all that is needed is that
-// the compiler keeps the order and earlier DS results have landed; outstanding global stores are NOT
-// drained (an s_waitcnt vmcnt(0) per window exposed the full HBM write latency).
-__device__ __forceinline__ void wave_lds_sync()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // ================================================================================================
 // rows 3-4: canonical k-mer + hash   (dna_encoding.hpp:168-177, :215-226; hash_int.hpp:41-48)
@@ -457,8 +396,6 @@ __device__ __forceinline__ uint64_t pack_cand(uint32_t hits, uint32_t ord, uint3
     return ((uint64_t)hits << 40) | ((uint64_t)((~ord) & 0xFFFFFu) << 20) | besti;
 }
 
-struct mc_candidate_dev { uint32_t tgt, hits, beg, end; };
-
 __device__ __forceinline__ void emit_empty(mc_candidate_dev* out, uint32_t from, uint32_t K, uint32_t lane)
 {
     for (uint32_t r = from + lane; r < K; r += 64) {
@@ -805,15 +742,6 @@ struct FusedLds {
     uint64_t sbuf[kFuseCap + 32];
 };
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    v = max(v, dpp_mov<0xB1>(v));
-    v = max(v, dpp_mov<0x4E>(v));
-    v = max(v, dpp_mov<0x141>(v));
-    v = max(v, dpp_mov<0x140>(v));
-    return max(max(rdlane(v, 0), rdlane(v, 16)), max(rdlane(v, 32), rdlane(v, 48)));
-}
-
 // Stage 'n' characters starting at seq[start] (n <= kMaxWinLen); branch-free per lane.
 template <class LDS>
 __device__ __forceinline__ void stage_segment(const uint8_t* __restrict__ seq, uint64_t start, uint32_t n, LDS& L, uint32_t lane)
@@ -1136,15 +1064,10 @@ constexpr uint32_t kLaneS = 16;           // sketch entries held in registers
 constexpr uint32_t kLaneHits = MC_LANE_HITS;  // longest location list handled by one lane.  The row length sets the occupancy of
                                               // probe_cands_kernel (LDS): 32 -> 8 waves/CU, 24 -> 12, 20 -> 14; measured on configs[1]
                                               // (mean list 15.8): 44.3 / 48.6 / 49.5 / 41.1 G reads/min for 32 / 24 / 20 / 16
-constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
 #ifndef MC_LANE_U
 #define MC_LANE_U 2
 #endif
 constexpr uint32_t kLaneU = MC_LANE_U;    // lookups in flight per lane
-constexpr uint32_t kMidMax = 256;         // longest list taken by mid_cands_kernel
-constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cands_kernel: longest list, entries, maxWindowsInRange
-constexpr uint32_t kBigEnt = 64;          // big_filter_kernel: found features per query, one lane each ...
-constexpr uint32_t kBigEPL = 3;           // ... or up to three per lane in its second instance (reads and pairs of 5 .. 10 windows: 2 x 250 bp, 500 bp)
 
 __device__ __forceinline__ void lane_encode4(uint32_t w, uint32_t& codes, uint32_t& ambs)
 {
@@ -1891,7 +1814,8 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
             }
         }
         {   // [10]: how many of the filter's queries have more than kBigEnt entries (its second instance runs only for those)
-            const uint64_t wide = __ballot(cls == 7 && nent > kBigEnt);
+            // (compact store: how many have more than kGwSmallH locations -- gw_filter_kernel's second instance)
+            const uint64_t wide = __ballot(cls == 7 && (tab.values32 ? H > kGwSmallH : nent > kBigEnt));
             if (wide && lane == (uint32_t)__ffsll((unsigned long long)wide) - 1) atomicAdd(&ws.midCount[10], (uint32_t)__popcll(wide));
         }
         return;
@@ -2361,8 +2285,8 @@ __device__ __forceinline__ uint32_t hash_slot(uint64_t v)
 constexpr uint64_t kEmptyLoc = ~0ull;
 template <uint32_t LOG2S>
 __device__ __forceinline__ uint32_t hash_slot(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - LOG2S); }
-// KT = uint64_t: keys are locations (tgt << 32) | win.  KT = uint32_t: the compact form (tgt << tab.winBits) | win of tables with the
-// 4-byte location store -- half the key table, 32-bit compare-and-swap; the arithmetic on windows (v - d, win >= d) is the same.
+// KT = uint64_t: keys are locations (tgt << 32) | win.  (Tables with the compact location store count global window numbers instead:
+// gw_count_kernel, gw_kernels.hip.)
 template <uint32_t LOG2S, uint32_t PER, bool TAX, class KT>
 __device__ __forceinline__ uint32_t count_and_pick(const KT (&v)[PER], KT* keys, uint32_t* cnts, const uint32_t lane, const uint32_t maxWin,
                                                    const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
@@ -2372,9 +2296,9 @@ __device__ __forceinline__ uint32_t count_and_pick(const KT (&v)[PER], KT* keys,
     constexpr KT kEmpty = (KT)~(KT)0;
     constexpr bool kWide = sizeof(KT) == 8;
     using cas_t = std::conditional_t<kWide, unsigned long long, unsigned int>;
-    const uint32_t wb = kWide ? 32u : tab.winBits;
-    auto tgt_of = [&](KT x) -> uint32_t { if constexpr (kWide) return (uint32_t)(x >> 32); else return (uint32_t)x >> wb; };
-    auto win_of = [&](KT x) -> uint32_t { if constexpr (kWide) return (uint32_t)x; else return (uint32_t)x & ((1u << wb) - 1u); };
+    static_assert(kWide, "keys are 8-byte locations (the compact store has its own kernels: gw_kernels.hip)");
+    auto tgt_of = [&](KT x) -> uint32_t { return (uint32_t)(x >> 32); };
+    auto win_of = [&](KT x) -> uint32_t { return (uint32_t)x; };
     auto count_of = [&](uint32_t slot) -> uint32_t { return reinterpret_cast<const uint16_t*>(cnts)[slot]; };   // ds_read_u16
     uint32_t slot[PER];                                       // slot | claimed << 31
     {
@@ -2638,10 +2562,6 @@ constexpr uint32_t kBigT1Log2 = MC_BIG_T1, kBigT2Log2 = MC_BIG_T2;     // bits o
 #define MC_BIG_MIN_SHIFT 3
 #endif
 constexpr uint32_t kBigMinShift = MC_BIG_MIN_SHIFT;   // smallest round: 1 << shift lanes
-#ifndef MC_BIG_MIN_SHIFT_COMPACT
-#define MC_BIG_MIN_SHIFT_COMPACT 4
-#endif
-constexpr uint32_t kBigMinShiftCompact = MC_BIG_MIN_SHIFT_COMPACT;   // compact location store: 16 lanes x 4 bytes = one 64-byte request
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
@@ -2695,31 +2615,19 @@ __device__ __forceinline__ BigShape big_setup(BigTables& T, const uint32_t lane,
     return BigShape{R, shift};
 }
 // one sweep over a query's locations: f(v) for the lane's element of every wave load (kEmptyLoc = none), kBigU loads in flight
-// COMPACT: the table's 4-byte location store (DeviceTable::values32; 0xFFFFFFFF is never a stored location)
-template <bool COMPACT, class F>
+template <class F>
 __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable& tab, const uint32_t lane, const BigShape sh, F&& f)
 {
     const uint32_t perLoad = 64u >> sh.shift, grp = lane >> sh.shift, sub = lane & ((1u << sh.shift) - 1u);
     for (uint32_t g0 = 0; g0 < sh.rounds; g0 += kBigU * perLoad) {
-        if constexpr (COMPACT) {
-            uint32_t rv[kBigU];
+        uint64_t rv[kBigU];
 #pragma unroll
-            for (uint32_t u = 0; u < kBigU; ++u) {
-                const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
-                rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values32[(rd & 0xFFFFFFFFFFull) + sub] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kBigU; ++u) f(rv[u] == 0xFFFFFFFFu ? kEmptyLoc : DeviceTable::widen(rv[u], tab.winBits));
-        } else {
-            uint64_t rv[kBigU];
-#pragma unroll
-            for (uint32_t u = 0; u < kBigU; ++u) {
-                const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
-                rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + sub] : kEmptyLoc;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
+        for (uint32_t u = 0; u < kBigU; ++u) {
+            const uint64_t rd = T.rounds[g0 + u * perLoad + grp];
+            rv[u] = sub < (uint32_t)(rd >> 40) ? tab.values[(rd & 0xFFFFFFFFFFull) + sub] : kEmptyLoc;
         }
+#pragma unroll
+        for (uint32_t u = 0; u < kBigU; ++u) f(rv[u]);
     }
 }
 
@@ -2738,12 +2646,11 @@ __device__ __forceinline__ void big_sweep(const BigTables& T, const DeviceTable&
 // A read of 500 bp collects 4 500 locations at RefSeq scale and hits 250 targets TWICE BY CHANCE, at unrelated places: keyed on targets
 // the filtered list outgrows the counting kernels (1024), keyed on places only true neighbours stay.  Twice the keys of 3.5 x the
 // locations: T1LOG2 / T2LOG2 = 17 / 14 (18 KB per wave, two waves per block).
-template <uint32_t WAVES, bool COMPACT, uint32_t EPL, bool POS, uint32_t T1LOG2, uint32_t T2LOG2>
+template <uint32_t WAVES, uint32_t EPL, bool POS, uint32_t T1LOG2, uint32_t T2LOG2>
 __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
     static_assert(!POS || kHashWin <= 8, "two grids of 16 windows, 8 apart, cover window ranges up to 8");
-    // COMPACT: locations are read from the 4-byte store and the pool holds them in that form too (its slices are the same number of ENTRIES)
-    using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
+    using pool_t = uint64_t;
     constexpr uint32_t kW1 = (1u << T1LOG2) / 32, kW2 = (1u << T2LOG2) / 32, kBitWords = kW1 + kW2;
     static_assert(kBitWords % 256 == 0, "cleared with one uint4 per lane and step");
     __shared__ uint32_t bitS[WAVES][kBitWords];
@@ -2805,7 +2712,7 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
             mySz[e] = esz[e] & 0xFFFFu; myPay[e] = epay[e];
             single[e] = (e * 64 + lane < nent && mySz[e] == 1) ? myPay[e] : kEmptyLoc;     // inline locations of buckets of one
         }
-        const BigShape sh = big_setup<EPL>(T, lane, nent, mySz, myPay, COMPACT ? kBigMinShiftCompact : kBigMinShift);
+        const BigShape sh = big_setup<EPL>(T, lane, nent, mySz, myPay, kBigMinShift);
         rec = recNext;                                             // the next query's record and entries are on their way meanwhile
         recNext = load_rec(w + 2 * nWaves);
         load_entries(rec);
@@ -2829,7 +2736,7 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
             };
 #pragma unroll
             for (uint32_t e = 0; e < EPL; ++e) mark(single[e]);
-            big_sweep<COMPACT>(T, tab, lane, sh, mark);
+            big_sweep(T, tab, lane, sh, mark);
             wave_lds_sync();
             // ---- B. locations of targets seen twice or more -> this wave's pool slice (as long as they fit), counted
             pool_t* dst = slice + sliceUsed;
@@ -2848,15 +2755,14 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
                 if (keep) {
                     const uint32_t at = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (at < room) {
-                        if constexpr (COMPACT) dst[at] = ((uint32_t)(v >> 32) << tab.winBits) | (uint32_t)v;
-                        else dst[at] = v;
+                        dst[at] = v;
                     }
                 }
                 n2 += (uint32_t)__popcll(m);
             };
 #pragma unroll
             for (uint32_t e = 0; e < EPL; ++e) take(single[e]);
-            big_sweep<COMPACT>(T, tab, lane, sh, take);
+            big_sweep(T, tab, lane, sh, take);
             fallback = n2 > room;                                  // too long for big_count_kernel, or the slice is full
         }
         if (lane == 0) {
@@ -2878,15 +2784,13 @@ __global__ __launch_bounds__(WAVES * 64) MC_BIG_WPE_ATTR void big_filter_kernel(
 #ifndef MC_BIG_COUNT_WPE
 #define MC_BIG_COUNT_WPE 6     // compact keys: 6 KB of LDS per wave; at 80 registers six blocks fit a CU (8.0 / 7.3 / 6.9 ms at 16 / 20 / 24 waves)
 #endif
-template <uint32_t LOG2S, uint32_t WAVES, bool TAX, bool COMPACT>
-__global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT_WPE : (COMPACT && LOG2S == 11) ? MC_BIG_COUNT2_WPE : 1) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
+__global__ __launch_bounds__(WAVES * 64) void big_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
                                                                uint32_t minN2)
 {
     constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
-    // COMPACT: the pool holds 4-byte locations and they are the keys of the (target, window) table as they are: 6 KB of LDS per wave
-    // instead of 10 (24 waves per CU instead of 16), 32-bit compare-and-swap
-    using pool_t = std::conditional_t<COMPACT, uint32_t, uint64_t>;
+    using pool_t = uint64_t;
     static_assert(sizeof(BigTables) <= kSlots * sizeof(pool_t), "step D's tables live in the key table, which is done with by then");
     __shared__ __attribute__((aligned(16))) pool_t keyS[WAVES][kSlots];
     __shared__ uint32_t cntS[WAVES][kSlots / 2];
@@ -2978,7 +2882,7 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
                 const uint32_t mySz1[1] = {lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u};
                 const uint64_t myPay1[1] = {lane < nent ? ws.ppay[fbase + lane] : 0ull};
                 const uint32_t mySz = mySz1[0]; const uint64_t myPay = myPay1[0];
-                const BigShape sh = big_setup<1>(T, lane, nent, mySz1, myPay1, COMPACT ? kBigMinShiftCompact : kBigMinShift);
+                const BigShape sh = big_setup<1>(T, lane, nent, mySz1, myPay1, kBigMinShift);
                 wave_lds_sync();
                 uint64_t best[kLaneK];
 #pragma unroll
@@ -3000,7 +2904,7 @@ __global__ __launch_bounds__(WAVES * 64, (COMPACT && LOG2S == 10) ? MC_BIG_COUNT
                     for (uint32_t i = 0; i < kLaneK; ++i) { const uint64_t lo = min(best[i], c); c = max(best[i], c); best[i] = lo; }
                 };
                 visit((lane < nent && mySz == 1) ? myPay : kEmptyLoc);
-                big_sweep<COMPACT>(T, tab, lane, sh, visit);
+                big_sweep(T, tab, lane, sh, visit);
                 for (uint32_t rnd = strong; rnd < K; ++rnd) {
                     uint64_t m = best[0];
 #pragma unroll
@@ -3034,32 +2938,26 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
                       const uint32_t* taxkey, void* cands, hipStream_t st)
 {
     if (b.n == 0) return;
+    // tables with the compact location store (global window numbers): their own kernels, gw_kernels.hip
+    if (tab.values32) { launch_gw_cands(stage, b, sp, tab, ws, maxCand, taxkey, cands, st); return; }
     mc_candidate_dev* c = (mc_candidate_dev*)cands;
     // persistent grids.  stage 0: the filter; 1: counting of filtered lists up to 512; 2: 513 .. 1024
-    const bool compact = tab.values32 != nullptr;
     auto count = [&](auto log2s, auto waves, uint32_t grid, uint32_t minN2) {
         constexpr uint32_t L = decltype(log2s)::value, W = decltype(waves)::value;
-        if (compact) {
-            if (taxkey) hipLaunchKernelGGL((big_count_kernel<L, W, true, true>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
-            else        hipLaunchKernelGGL((big_count_kernel<L, W, false, true>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
-        } else {
-            if (taxkey) hipLaunchKernelGGL((big_count_kernel<L, W, true, false>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
-            else        hipLaunchKernelGGL((big_count_kernel<L, W, false, false>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
-        }
+        if (taxkey) hipLaunchKernelGGL((big_count_kernel<L, W, true>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
+        else        hipLaunchKernelGGL((big_count_kernel<L, W, false>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
     };
     if (stage == 0) {
-        if (compact) hipLaunchKernelGGL((big_filter_kernel<4, true, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
-        else         hipLaunchKernelGGL((big_filter_kernel<4, false, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
+        hipLaunchKernelGGL((big_filter_kernel<4, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 3) {                                   // the filter's second instance: queries with 65 .. 192 found features
         // two waves per block, twice the blocks: the same number of waves -- and so the same pool slices -- as the first instance
-        if (compact) hipLaunchKernelGGL((big_filter_kernel<2, true, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
-        else         hipLaunchKernelGGL((big_filter_kernel<2, false, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
+        hipLaunchKernelGGL((big_filter_kernel<2, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n)), dim3(128), 0, st, b, tab, ws);
     } else if (stage == 1) {
-        // blocks per CU by LDS: 40 KB per block with 8-byte keys, 24 KB with the compact ones
-        count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(compact), (b.n + 3) / 4), 0u);
-    } else {
+        // blocks per CU by LDS: 40 KB per block
+        count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(false), (b.n + 3) / 4), 0u);
+    } else if (stage == 2) {
         static const uint32_t env2 = [] { const char* e = std::getenv("MC_BIG_COUNT2_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 0u; }();
-        const uint32_t bpc2 = env2 ? env2 : compact ? 6u : 4u;
+        const uint32_t bpc2 = env2 ? env2 : 4u;
         count(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 2>{}, std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2), 512u);
     }
 }

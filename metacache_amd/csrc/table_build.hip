@@ -5,7 +5,8 @@
 //   table_prep    : per key, the size after the load-time modifiers (host_hashmap.hpp:454-495)
 //   table_insert  : one lane per key walks the key's probe sequence (kernels.h next_bucket) and claims the first
 //                   free slot with a 64-bit CAS on the bucket's four u16 sizes; key and payload are written after
-//   table_values  : one lane per FILE value: binary search for its key, decode {win, tgt} -> (tgt << 32) | win
+//   table_values  : one lane per FILE value: binary search for its key, decode {win, tgt} -> (tgt << 32) | win, or -> the global
+//                   window number gwBase[tgt] + win of the compact store (kernels.h DeviceTable)
 // Slot placement depends on the claim order, lookup results do not: a key always sits in the first bucket of its
 // probe sequence that had a free slot when it arrived, and nothing is ever removed.
 #include "kernels.h"
@@ -32,6 +33,11 @@ __device__ __forceinline__ uint64_t decode_value(const uint8_t* p, uint32_t tb)
     return ((uint64_t)tgt << 32) | win;
 }
 
+__device__ __forceinline__ bool in_gw_range(const GwLayout& gw, uint32_t tgt, uint32_t win)
+{
+    return tgt < gw.targets && win < gw.base[tgt + 1] - gw.base[tgt] - gw.gap;
+}
+
 __global__ __launch_bounds__(256) void table_prep_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n, LoadFilter lf,
                                                          uint32_t* __restrict__ fileSz, uint32_t* __restrict__ storeSz,
                                                          unsigned long long* __restrict__ counters)
@@ -54,7 +60,8 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ fileOff, const uint32_t* __restrict__ storeOff,
                                                            const uint8_t* __restrict__ vals, uint32_t tb, uint64_t storeBase,
                                                            TableBucket* __restrict__ buckets, uint32_t nbuckets,
-                                                           unsigned int* __restrict__ maxProbe, unsigned int* __restrict__ full)
+                                                           unsigned int* __restrict__ maxProbe, unsigned int* __restrict__ full,
+                                                           GwLayout gw, unsigned int* __restrict__ rangeErr)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -82,7 +89,14 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t* __res
         cur = next_bucket(home, cur, probe, nbuckets);
     }
     b->key[slot] = key;
-    b->payload[slot] = eff == 1 ? decode_value(vals + (size_t)fileOff[i] * (4 + tb), tb) : storeBase + storeOff[i];
+    uint64_t pay = storeBase + storeOff[i];
+    if (eff == 1) {
+        // a single location stays in the bucket in its 8-byte form; with the compact store the kernels turn it into a global window
+        // number (DeviceTable::gw_of), so it must lie inside its target's windows like every location of the lists
+        pay = decode_value(vals + (size_t)fileOff[i] * (4 + tb), tb);
+        if (gw.base && !in_gw_range(gw, (uint32_t)(pay >> 32), (uint32_t)pay)) atomicExch(rangeErr, 1u);
+    }
+    b->payload[slot] = pay;
     if (probe > 1) atomicMax(maxProbe, probe);
 }
 
@@ -90,8 +104,8 @@ template <bool COMPACT>
 __global__ __launch_bounds__(256) void table_values_kernel(const uint32_t* __restrict__ keys, const uint8_t* __restrict__ sizes, uint32_t n, LoadFilter lf,
                                                            const uint32_t* __restrict__ fileOff, const uint32_t* __restrict__ storeOff,
                                                            const uint8_t* __restrict__ vals, uint32_t tb, uint64_t totalFileVals,
-                                                           uint64_t* __restrict__ dst, uint32_t* __restrict__ dst32, uint32_t winBits,
-                                                           uint32_t maxTgt, uint32_t maxWin, unsigned int* __restrict__ rangeErr)
+                                                           uint64_t* __restrict__ dst, uint32_t* __restrict__ dst32, GwLayout gw,
+                                                           unsigned int* __restrict__ rangeErr)
 {
     const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= totalFileVals) return;
@@ -107,8 +121,8 @@ __global__ __launch_bounds__(256) void table_values_kernel(const uint32_t* __res
         const uint64_t loc = decode_value(vals + v * (4 + tb), tb);
         if constexpr (COMPACT) {
             const uint32_t tgt = (uint32_t)(loc >> 32), win = (uint32_t)loc;
-            if (tgt > maxTgt || win > maxWin) atomicExch(rangeErr, 1u);
-            else dst32[storeOff[lo] + t] = (tgt << winBits) | win;
+            if (!in_gw_range(gw, tgt, win)) atomicExch(rangeErr, 1u);
+            else dst32[storeOff[lo] + t] = gw.base[tgt] + win;
         } else {
             dst[storeOff[lo] + t] = loc;
         }
@@ -125,10 +139,10 @@ void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, L
 
 void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff,
                          const uint32_t* storeOff, const uint8_t* vals, uint32_t tb, uint64_t storeBase, TableBucket* buckets,
-                         uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st)
+                         uint32_t nbuckets, unsigned int* maxProbe, unsigned int* full, hipStream_t st, GwLayout gw, unsigned int* rangeErr)
 {
     if (n) hipLaunchKernelGGL(table_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys, sizes, n, lf, fileOff, storeOff,
-                              vals, tb, storeBase, buckets, nbuckets, maxProbe, full);
+                              vals, tb, storeBase, buckets, nbuckets, maxProbe, full, gw, rangeErr);
 }
 
 void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
@@ -136,16 +150,15 @@ void launch_table_values(const uint32_t* keys, const uint8_t* sizes, uint32_t n,
 {
     if (n && totalFileVals)
         hipLaunchKernelGGL(table_values_kernel<false>, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, keys, sizes, n, lf,
-                           fileOff, storeOff, vals, tb, totalFileVals, dst, nullptr, 0u, 0u, 0u, nullptr);
+                           fileOff, storeOff, vals, tb, totalFileVals, dst, nullptr, GwLayout{}, nullptr);
 }
 
 void launch_table_values_compact(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff, const uint32_t* storeOff,
-                                 const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, uint32_t winBits, uint32_t maxTgt,
-                                 uint32_t maxWin, unsigned int* rangeErr, hipStream_t st)
+                                 const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, GwLayout gw, unsigned int* rangeErr, hipStream_t st)
 {
     if (n && totalFileVals)
         hipLaunchKernelGGL(table_values_kernel<true>, dim3((uint32_t)((totalFileVals + 255) / 256)), dim3(256), 0, st, keys, sizes, n, lf,
-                           fileOff, storeOff, vals, tb, totalFileVals, nullptr, dst32, winBits, maxTgt, maxWin, rangeErr);
+                           fileOff, storeOff, vals, tb, totalFileVals, nullptr, dst32, gw, rangeErr);
 }
 
 }  // namespace mcamd

@@ -488,20 +488,24 @@ def test_size_independent_properties_at_bench_scale(tmp_path):
 
 
 def test_location_range_is_enforced_and_optional():
-    """mc_load_location_range: a location beyond the announced range fails the load loudly (the compact store could not hold it);
-    without the call, and with ranges that do not fit 32 bits together, the table keeps 8-byte locations."""
+    """mc_load_target_windows / mc_load_location_range: a location outside its target's announced windows fails the load loudly (the
+    compact store numbers windows globally and could not hold it) -- single locations, which stay in their buckets, included; without
+    the call, and with more windows than 32 bits can number, the table keeps 8-byte locations."""
     import ctypes as C
     L = api.lib()
     keys = np.array([11, 22, 33], dtype=np.uint32)
     sizes = np.array([2, 1, 3], dtype=np.uint8)
     vals = np.array([[5, 0], [9, 1], [7, 2], [1, 0], [2, 1], [300, 2]], dtype=np.uint32)      # {win, tgt}; the last window is 300
 
-    def load(rng):
+    def load(rng=None, windows=None):
         cfg = api.default_config(target_id_bytes=4)
         h = C.c_void_p()
         assert L.mc_create(C.byref(cfg), C.byref(h)) == 0
         if rng:
             assert L.mc_load_location_range(h, rng[0], rng[1]) == 0
+        if windows is not None:
+            w = np.asarray(windows, dtype=np.uint32)
+            assert L.mc_load_target_windows(h, w.ctypes.data, len(w)) == 0
         assert L.mc_load_begin(h, 0, 3, 6) == 0
         rc = L.mc_load_batch(h, 0, keys.ctypes.data, sizes.ctypes.data, vals.ctypes.data, 3)
         rc = rc or L.mc_load_end(h, 0)
@@ -510,11 +514,18 @@ def test_location_range_is_enforced_and_optional():
         err = L.mc_last_error(h).decode()
         L.mc_destroy(h)
         return rc, int(lay[0]), int(lay[1]), err
-    assert load(None)[:2] == (0, 8)
-    assert load((2, 300))[:3] == (0, 4, 9)
-    assert load((2, 511))[:3] == (0, 4, 9)
+    assert load()[:2] == (0, 8)
+    assert load((2, 300))[:3] == (0, 4, 1024)                     # (layout[1] = the gap between two targets' window numbers)
+    assert load((2, 511))[:2] == (0, 4)
     rc, _, _, err = load((2, 299))
     assert rc != 0 and "range" in err
-    assert load((1 << 20, 1 << 20))[:2] == (0, 8)                  # 21 + 21 bits: stays wide
-    assert load((0xFFFF, 0xFFFF))[:2] == (0, 8)                    # exactly 32 bits, but the all-ones pattern would be a location
-    assert load((0xFFFF, 0xFFFE))[:3] == (0, 4, 16)
+    assert load(windows=[6, 3, 301])[:2] == (0, 4)                # every target exactly as long as its last window
+    rc, _, _, err = load(windows=[6, 3, 300])
+    assert rc != 0 and "range" in err                             # window 300 of target 2
+    rc, _, _, err = load(windows=[6, 2, 301])
+    assert rc != 0 and "range" in err                             # the SINGLE location (window 2 of target 1): range-checked as well
+    rc, _, _, err = load(windows=[6, 3])
+    assert rc != 0 and "range" in err                             # unknown target
+    assert load((1 << 20, 1 << 20))[:2] == (0, 8)                  # 2^40 windows: stays wide
+    assert load((0xFFFF, 0xFFFE))[:2] == (0, 8)                    # 2^32 windows + gaps: stays wide
+    assert load((0xFFFF, 0x7FFF))[:2] == (0, 4)
