@@ -610,7 +610,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
     // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, in->num_chars * 3) : (uint64_t)n * 8,
-                                                                                  (uint64_t)big_filter_grid(n) * 4 * 1024));   // >= one full list per wave
+                                                                                  (uint64_t)big_filter_grid(n) * 4 * 4096));   // >= one full list per wave (gw_filter_kernel: one batch of 2 112 numbers)
     if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
     if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n) * 4 * 4 + 64))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
@@ -681,7 +681,9 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if (hcnt[4]) { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[9]) {
             { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-            if (hcnt[10]) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+            // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
+            // host's look at the counters: always launched, returns at once with nothing to do)
+            if (hcnt[10] || T.compact) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
             { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
             { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         }

@@ -519,12 +519,12 @@ def test_location_range_is_enforced_and_optional():
     assert load((2, 511))[:2] == (0, 4)
     rc, _, _, err = load((2, 299))
     assert rc != 0 and "range" in err
-    assert load(windows=[6, 3, 301])[:2] == (0, 4)                # every target exactly as long as its last window
-    rc, _, _, err = load(windows=[6, 3, 300])
+    assert load(windows=[6, 10, 301])[:2] == (0, 4)               # every target exactly as long as its last window
+    rc, _, _, err = load(windows=[6, 10, 300])
     assert rc != 0 and "range" in err                             # window 300 of target 2
-    rc, _, _, err = load(windows=[6, 2, 301])
-    assert rc != 0 and "range" in err                             # the SINGLE location (window 2 of target 1): range-checked as well
-    rc, _, _, err = load(windows=[6, 3])
+    rc, _, _, err = load(windows=[6, 9, 301])
+    assert rc != 0 and "range" in err                             # the SINGLE location (window 9 of target 1): range-checked as well
+    rc, _, _, err = load(windows=[6, 10])
     assert rc != 0 and "range" in err                             # unknown target
     assert load((1 << 20, 1 << 20))[:2] == (0, 8)                  # 2^40 windows: stays wide
     assert load((0xFFFF, 0xFFFE))[:2] == (0, 8)                    # 2^32 windows + gaps: stays wide
