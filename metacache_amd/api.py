@@ -338,7 +338,9 @@ class Database:
     def last_batch_stats(self):
         st = np.zeros(8, dtype=np.uint64)
         self._check(lib().mc_last_batch_stats(self.h, st.ctypes.data_as(C.c_void_p)))
-        return dict(windows=int(st[0]), features=int(st[1]), locations=int(st[2]), found=int(st[3]), probe_steps=int(st[4]))
+        return dict(windows=int(st[0]), features=int(st[1]), locations=int(st[2]), found=int(st[3]), probe_steps=int(st[4]),
+                    filtered_kept=int(st[5]), filtered_reads=int(st[6]) & 0xFFFFFFFF, filtered_over_512=int(st[6]) >> 32,
+                    filter_second_kernel=int(st[7]) & 0xFFFFFFFF, filter_handed_back=int(st[7]) >> 32)
 
 
 class Builder:

@@ -846,6 +846,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "quad_lookup") ctx->quadLookup = value < 0 ? -1 : (value != 0);
     else if (n == "lane_path") ctx->useLanePath = value != 0;
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
+    else if (n == "gw_diag") mcamd::g_gwDiag = (int)value;                     // timing experiments on gw_filter_kernel (wrong results)
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }
@@ -877,6 +878,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
+    if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16; }
     launch_batch_stats(ws, P.lastN, ctx->stream);
     HIP_TRY(ctx, hipMemcpyAsync(stats, ws.stats, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

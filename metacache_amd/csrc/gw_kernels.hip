@@ -79,8 +79,8 @@ struct GwBloom {
         if constexpr (kSame) return seen + kW1;
         else return kW1 + ((h >> 17) & (kW2 - 1u));
     }
-    // phase A for four keys: the four returning ds_or go out together (one LDS round trip instead of four), then the four into "twice"
-    // -- unconditional: an or with 0 costs less than the branch around it
+    // phase A for four keys: the four returning ds_or go out together (one LDS round trip instead of four); "twice" is written by the
+    // lanes that found their bits set only (a fifth of them: few lanes, few bank conflicts)
     __device__ __forceinline__ static void mark4(uint32_t* bits, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
     {
         const uint32_t k[4] = {k0, k1, k2, k3};
@@ -90,13 +90,13 @@ struct GwBloom {
 #pragma unroll
         for (int j = 0; j < 4; ++j) old[j] = atomicOr(&bits[i1[j]], m[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicOr(&bits[i2[j]], (old[j] & m[j]) == m[j] ? m[j] : 0u);
+        for (int j = 0; j < 4; ++j) if ((old[j] & m[j]) == m[j]) atomicOr(&bits[i2[j]], m[j]);
     }
     __device__ __forceinline__ static void mark(uint32_t* bits, uint32_t key)
     {
         const uint32_t h = hash(key), m = mask_of(h), i1 = seen_index(h);
         const uint32_t old = atomicOr(&bits[i1], m);
-        atomicOr(&bits[twice_index(i1, h)], (old & m) == m ? m : 0u);
+        if ((old & m) == m) atomicOr(&bits[twice_index(i1, h)], m);
     }
     __device__ __forceinline__ static bool twice(const uint32_t* bits, uint32_t key)
     {
@@ -126,6 +126,7 @@ __device__ __forceinline__ void gw_fill_rounds(uint64_t* T, uint32_t lane, uint3
     for (uint32_t j = jlo; j < jhi; ++j) T[start + j - r0] = (pay + 16ull * j) | ((uint64_t)min(16u, sz - 16u * j) << 40);
 }
 // the batch's numbers: 16 bytes per lane and load, four lanes per round; places without a round read as kGwNone
+template <bool ALIGN_TEST = false>
 __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads])
 {
 #pragma unroll
@@ -133,7 +134,7 @@ __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t
         const uint64_t rd = T[u * 16 + grp];
         x[u] = make_uint4(kGwNone, kGwNone, kGwNone, kGwNone);
         if (sub4 < (uint32_t)(rd >> 40)) {
-            const U4 t = *reinterpret_cast<const U4*>(values32 + (rd & 0xFFFFFFFFFFull) + sub4);
+            const U4 t = *reinterpret_cast<const U4*>(values32 + ((rd & 0xFFFFFFFFFFull) & (ALIGN_TEST ? ~3ull : ~0ull)) + sub4);
             x[u] = make_uint4(t.x, t.y, t.z, t.w);
         }
     }
@@ -144,7 +145,8 @@ template <class Bloom>
 __device__ __forceinline__ void gw_mark_rounds(uint32_t* bits, const uint4 (&x)[kGwLoads], uint32_t A)
 {
 #pragma unroll
-    for (uint32_t u = 0; u < kGwLoads; ++u) Bloom::mark4(bits, x[u].x >> A, x[u].y >> A, x[u].z >> A, x[u].w >> A);
+    for (uint32_t u = 0; u < kGwLoads; ++u)                    // (lanes without a round hold kGwNone: sixty-four of them on ONE filter word would take turns)
+        if (x[u].x != kGwNone) Bloom::mark4(bits, x[u].x >> A, x[u].y >> A, x[u].z >> A, x[u].w >> A);
 }
 // phase B: a number is kept if its block was marked twice or it lies within D of a block boundary; the kept ones are appended to dst
 // (ballot compaction), n2 counts them whether they fit or not
@@ -214,8 +216,10 @@ constexpr uint32_t kGwFallback = 0xFFFFFFFFu;              // ... handed to the 
 #ifndef MC_GW_FILTER_WPE
 #define MC_GW_FILTER_WPE 4
 #endif
-template <uint32_t WAVES, uint32_t TLOG2>
-__global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
+// DIAG != 0: timing experiments (tools/tune_gw.py; results are wrong): 1 = loads from 16-byte aligned addresses, 2 = loads only (no
+// filter phases), 3 = filter phases only (no loads)
+template <uint32_t WAVES, uint32_t TLOG2, int DIAG, uint32_t WPE = MC_GW_FILTER_WPE>
+__global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
     using Bloom = GwBloom<TLOG2, TLOG2>;
     __shared__ uint32_t bitS[WAVES][Bloom::kWords];
@@ -268,16 +272,26 @@ __global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter_kernel
         wave_lds_sync();
         const GwFrame F(maxWin);
         uint4 x[kGwLoads];
-        gw_load_rounds(T, tab.values32, grp, sub4, x);
+        if constexpr (DIAG == 3) {
+#pragma unroll
+            for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = make_uint4(lane * 977u + u * 13u + w, lane * 7717u + u + q, (lane ^ u) * 40503u + w, lane * 31u + u * 5u + q * 3u);
+        } else gw_load_rounds<DIAG == 1>(T, tab.values32, grp, sub4, x);
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;     // single locations live in their buckets in the 8-byte form
         GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+        if constexpr (DIAG == 2) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < kGwLoads; ++u) acc |= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w;
+            S.n2 = (uint32_t)__popcll(__ballot(acc == 0x12345u));
+        } else {
         // ---- A
-        Bloom::mark(bits, sv >> F.A);
+        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
         gw_mark_rounds<Bloom>(bits, x, F.A);
         wave_lds_sync();
         // ---- B
         gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
         gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
+        }
         // longer than what is handed on, or the slice is full; (for now) longer than the counting kernels take
         const bool fallback = S.n2 > S.room || S.n2 > kBigMaxFilteredCount || maxWin > kHashWin;
         if (lane == 0) {
@@ -316,10 +330,17 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
     uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    for (uint32_t w = w0; w < total; w += nWaves) {
-        const uint4 rec = work[w];
-        const uint32_t q = rec.x, fbase = rec.y, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
-        if (H <= kGwSmallH && outRec[w].z != kGwDefer) continue;   // gw_filter_kernel's read, done
+    // (the records 64 at a time, as gw_count_kernel: this kernel takes a few of them)
+    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
+      const bool inb = chunk + lane < total;
+      const uint4 myRec = inb ? work[chunk + lane] : make_uint4(0, 0, 0, 0);
+      const uint32_t myZ = inb ? outRec[chunk + lane].z : 0u;
+      uint64_t todo = __ballot(inb && ((myRec.z >> 12) > kGwSmallH || myZ == kGwDefer));   // (the others: gw_filter_kernel's reads, done)
+      while (todo) {
+        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t w = chunk + j, q = rdlane(myRec.x, j), fbase = rdlane(myRec.y, j), recZ = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
+        const uint32_t nent = recZ & 0xFFFu, H = recZ >> 12;
         {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
 #pragma unroll
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
                     const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
                     const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
                     const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
-                    if (pass == 0) Bloom::mark(bits, sv >> F.A); else gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+                    if (pass == 0) { if (sv != kGwNone) Bloom::mark(bits, sv >> F.A); } else gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
                     const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
                     const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
                     for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
         }
         if (!fallback) sliceUsed += S.n2;
         wave_lds_sync();
+      }
     }
 }
 
@@ -378,18 +400,28 @@ namespace {
 template <uint32_t LOG2S>
 __device__ __forceinline__ uint32_t gw_slot(uint32_t g)                 // byte offset of the home slot
 {
-    return (__umul24(g ^ (g >> 12), 0x9E3779u) >> (29u - LOG2S)) & (((1u << LOG2S) - 1u) << 3);
+    uint32_t h;                                                // (24-bit multiply as an instruction, see GwBloom::hash)
+    asm("v_mul_u32_u24_e32 %0, 0x9e3779, %1" : "=v"(h) : "v"(g ^ (g >> 12)));
+    return (h >> (29u - LOG2S)) & (((1u << LOG2S) - 1u) << 3);
 }
 
 template <uint32_t LOG2S, uint32_t PER, bool TAX>
 __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], uint2* slots, const uint32_t lane, const uint32_t maxWin,
                                                       const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
-                                                      mc_candidate_dev* __restrict__ out, uint32_t (&pickLo)[kLaneK], uint32_t (&pickHi)[kLaneK])
+                                                      mc_candidate_dev* __restrict__ out, uint32_t (&pickLo)[kLaneK], uint32_t (&pickHi)[kLaneK], bool& again)
 {
     constexpr uint32_t kByteMask = ((1u << LOG2S) - 1u) << 3;
     char* base = reinterpret_cast<char*>(slots);
     auto key_at = [&](uint32_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(base + off); };
     uint32_t off[PER];                                        // byte offset of the number's slot | 1 if this lane claimed it
+    // the targets of the numbers (for striking a picked target's other ranges in step 3): two dependent loads that hit the L2, started
+    // here and there so that they run behind the LDS phases instead of inside the K rounds
+    // (taxon merging only: without it the K rounds strike REGIONS and the targets of the K winners are looked up afterwards)
+    uint32_t tgt[TAX ? PER : 1], thi[TAX ? PER : 1];
+    if constexpr (TAX) {
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) tgt[r] = v[r] != kGwNone ? tab.gwDir[v[r] >> tab.gwDirShift] : 0u;
+    }
     {
         uint32_t old[PER];
         bool coll = false;
@@ -419,13 +451,12 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
             off[r] |= (v[r] != kGwNone && old[r] == kGwNone) ? 1u : 0u;
         }
     }
-    wave_lds_sync();
-    // ---- 2. ranges that end in the numbers this lane claimed: hits | (end - begin) << 16
-    uint32_t ptax[PER];
     if constexpr (TAX) {
 #pragma unroll
-        for (uint32_t r = 0; r < PER; ++r) ptax[r] = (off[r] & 1u) ? taxkey[tab.gw_target(v[r])] : 0u;
+        for (uint32_t r = 0; r < PER; ++r) thi[r] = (off[r] & 1u) ? tab.gwBase[tgt[r] + 1] : 0u;
     }
+    wave_lds_sync();
+    // ---- 2. ranges that end in the numbers this lane claimed: hits | (end - begin) << 16
     uint32_t R[PER];
 #pragma unroll
     for (uint32_t r = 0; r < PER; ++r) R[r] = (off[r] & 1u) ? key_at(off[r] & ~1u)[1] : 0u;
@@ -449,7 +480,21 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
         for (uint32_t r = 0; r < PER; ++r)
             if (kc[r].x == v[r] - d) R[r] = ((R[r] & 0xFFFFu) + kc[r].y) | (d << 16);
     }
-    // ---- 3. K rounds
+    uint32_t ptax[TAX ? PER : 1];
+    if constexpr (TAX) {
+        // (a directory entry names the target of its block's FIRST number: the few numbers behind a target boundary inside a block move on)
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            while ((off[r] & 1u) && v[r] >= thi[r]) { ++tgt[r]; thi[r] = tab.gwBase[tgt[r] + 1]; }
+            ptax[r] = (off[r] & 1u) ? taxkey[tgt[r]] : 0u;
+        }
+    }
+    // ---- 3. K rounds: wave-wide maximum of the hits, the smallest number among its holders.  Struck from the race: the winner's taxon
+    //      (taxon merging), else every number within gwGap of the winner -- its REGION, which lies inside its target (that is what the
+    //      gap is for).  The targets of the K winners are looked up afterwards, all at once; should two of them be one target (two
+    //      regions of it more than 115 kbp apart, both with hits to show) the caller hands the read to the exact wave kernel ('again').
+    //      Why that is exact: region striking offers, in every round, a superset of what target striking offers; its winner is either
+    //      the same or a number of an earlier winner's target -- which the comparison finds.
     uint32_t live = 0;
 #pragma unroll
     for (uint32_t r = 0; r < PER; ++r) {
@@ -458,6 +503,7 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
         live |= ok ? (1u << r) : 0u;
     }
     uint32_t strong = 0;
+    uint32_t wv = kGwNone, wh = 0, wd = 0;                     // lane i keeps winner i: number, hits, end - begin
     for (uint32_t rnd = 0; rnd < K; ++rnd) {
         uint32_t hh = 0, hv = kGwNone, hd = 0, hg = 0;
 #pragma unroll
@@ -467,26 +513,39 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
             if (take) { hh = h; hv = v[r]; hd = R[r] >> 16; if constexpr (TAX) hg = ptax[r]; }
         }
         const uint32_t mh = wave_max_u32(hh);
-        mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
-        if (mh != 0) {
-            const uint32_t mv = wave_min_u32(hh == mh ? hv : kGwNone);
-            const uint32_t winner = __ffsll((unsigned long long)__ballot(hh == mh && hv == mv)) - 1;
-            const uint32_t d = rdlane(hd, winner);
-            const uint32_t t = tab.gw_target(mv), lo = tab.gwBase[t], hi = tab.gwBase[t + 1];     // wave-uniform: scalar loads
-            if constexpr (TAX) {
-                const uint32_t g = rdlane(hg, winner);
+        if (mh == 0) break;
+        const uint32_t mv = wave_min_u32(hh == mh ? hv : kGwNone);
+        const uint32_t winner = __ffsll((unsigned long long)__ballot(hh == mh && hv == mv)) - 1;
+        const uint32_t d = rdlane(hd, winner);
+        if constexpr (TAX) {
+            const uint32_t g = rdlane(hg, winner);
 #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) if (ptax[r] == g) live &= ~(1u << r);
-            } else {
+            for (uint32_t r = 0; r < PER; ++r) if (ptax[r] == g) live &= ~(1u << r);
+        } else {
+            const uint32_t from = mv - tab.gwGap, span = 2u * tab.gwGap;
 #pragma unroll
-                for (uint32_t r = 0; r < PER; ++r) if (v[r] - lo < hi - lo) live &= ~(1u << r);
-            }
-            e.tgt = t; e.hits = mh; e.end = mv - lo; e.beg = e.end - d;
-            strong += mh >= 2 ? 1u : 0u;
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneK; ++i) if (i == rnd) { pickLo[i] = lo; pickHi[i] = hi; }
+            for (uint32_t r = 0; r < PER; ++r) if (v[r] - from <= span) live &= ~(1u << r);
         }
-        if (lane == 0) out[rnd] = e;
+        if (lane == rnd) { wv = mv; wh = mh; wd = d; }
+        strong += mh >= 2 ? 1u : 0u;
+    }
+    // the winners' targets: lane i looks up winner i
+    uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
+    if (wv != kGwNone) { wt = tab.gw_target(wv); wlo = tab.gwBase[wt]; whi = tab.gwBase[wt + 1]; }
+    again = false;
+    if constexpr (!TAX) {
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < kLaneK; ++i) {
+            const uint32_t ti = rdlane(wt, i);
+            again = again || (__ballot(lane > i && lane < K && wt == ti && ti != 0xFFFFFFFFu) != 0);
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = rdlane(wlo, i); pickHi[i] = rdlane(whi, i); }
+    if (lane < K) {
+        mc_candidate_dev e; e.tgt = wt; e.hits = wh; e.end = wv - wlo; e.beg = e.end - wd;
+        if (wv == kGwNone) { e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0; }
+        out[lane] = e;
     }
     return strong;
 }
@@ -494,10 +553,10 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
 }  // namespace
 
 #ifndef MC_GW_COUNT_WPE
-#define MC_GW_COUNT_WPE 5
+#define MC_GW_COUNT_WPE 6
 #endif
 template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
-__global__ __launch_bounds__(WAVES * 64, LOG2S == 10 ? MC_GW_COUNT_WPE : 1) void gw_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+__global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void gw_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                                              const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
                                                                                              uint32_t minN2)
 {
@@ -513,15 +572,34 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 10 ? MC_GW_COUNT_WPE : 1) void
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint4* __restrict__ work6 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
-    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0xFFFFFFFFu, 0); };
     const uint32_t w0 = blockIdx.x * WAVES + wave;
-    uint4 rec = load_rec(w0), recN = load_rec(w0 + nWaves);
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    for (uint32_t w = w0; w < total; w += nWaves) {
-        const uint32_t q = rec.x, n2 = rec.z, maxWin = rec.w;
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(ws.bigPool) + rec.y;
-        rec = recN; recN = load_rec(w + 2 * nWaves);
-        if (n2 > kList || (minN2 != 0 && n2 <= minN2) || maxWin > kHashWin) continue;   // (an EMPTY filtered list is the first instance's: step D fills the places)
+    const uint32_t* __restrict__ pool = reinterpret_cast<const uint32_t*>(ws.bigPool);
+    // The records are taken 64 at a time: one coalesced load, a ballot of the ones that are this instance's, their fields by
+    // v_readlane -- an instance that takes a few hundred of 5 x 10^6 records spent a millisecond on one dependent load per record.
+    // The smallest instance (most reads) fetches the NEXT list while it works on this one.
+    constexpr uint32_t kPre = LOG2S == 9 ? kList / 64 : 1;
+    uint32_t pre[kPre];
+    auto fetch = [&](uint32_t off, uint32_t n) {
+        if constexpr (LOG2S == 9) {
+#pragma unroll
+            for (uint32_t r = 0; r < kPre; ++r) pre[r] = r * 64 + lane < n ? pool[off + r * 64 + lane] : kGwNone;
+        }
+    };
+    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
+      const uint4 myRec = chunk + lane < total ? work[chunk + lane] : make_uint4(0, 0, kGwFallback, 0);
+      // n2 in (minN2, kList], window ranges up to kHashWin (an EMPTY filtered list is the first instance's: step D fills the places)
+      uint64_t todo = __ballot(myRec.z <= kList && (minN2 == 0 || myRec.z > minN2) && myRec.w <= kHashWin);
+      if (todo) { const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1; fetch(rdlane(myRec.y, j), rdlane(myRec.z, j)); }
+      while (todo) {
+        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t w = chunk + j, q = rdlane(myRec.x, j), n2 = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
+        const uint32_t* __restrict__ src = pool + rdlane(myRec.y, j);
+        uint32_t cur[kPre];
+#pragma unroll
+        for (uint32_t r = 0; r < kPre; ++r) cur[r] = pre[r];
+        if (todo) { const uint32_t jn = (uint32_t)__ffsll((unsigned long long)todo) - 1; fetch(rdlane(myRec.y, jn), rdlane(myRec.z, jn)); }
         {
             uint4* k4 = reinterpret_cast<uint4*>(slots);
 #pragma unroll
@@ -532,21 +610,26 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 10 ? MC_GW_COUNT_WPE : 1) void
 #pragma unroll
         for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = 0; pickHi[i] = 0; }
         uint32_t strong = 0;
+        bool again = false;
         mc_candidate_dev* out = cands + (size_t)q * K;
         auto body = [&](auto perc) {
             constexpr uint32_t PER = decltype(perc)::value;
             uint32_t v[PER];
 #pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
-            strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, out, pickLo, pickHi);
+            for (uint32_t r = 0; r < PER; ++r) {
+                if constexpr (LOG2S == 9) v[r] = cur[r < kPre ? r : 0];
+                else v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
+            }
+            strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, out, pickLo, pickHi, again);
         };
         const uint32_t per = (n2 + 63u) / 64u;
-        if constexpr (kList / 64 <= 8) {
+        if constexpr (LOG2S == 9) {
             if (per <= 1) body(std::integral_constant<uint32_t, 1>{});
             else if (per <= 2) body(std::integral_constant<uint32_t, 2>{});
             else if (per <= 3) body(std::integral_constant<uint32_t, 3>{});
-            else if (per <= 4) body(std::integral_constant<uint32_t, 4>{});
-            else if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
+            else body(std::integral_constant<uint32_t, 4>{});
+        } else if constexpr (LOG2S == 10) {
+            if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
             else body(std::integral_constant<uint32_t, 8>{});
         } else {
             if (per <= 10) body(std::integral_constant<uint32_t, 10>{});
@@ -555,7 +638,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 10 ? MC_GW_COUNT_WPE : 1) void
         }
         strong = __builtin_amdgcn_readfirstlane(strong);
         bool done = true;
-        if (strong < K) {
+        if (again) {                                               // two winners of one target: the exact wave kernel
+            if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+            done = false;
+        } else if (strong < K) {
             const uint4 r6 = work6[w];
             const uint32_t fbase = r6.y, nent = r6.z & 0xFFFu;
             if (TAX || nent > kBigEnt) {
@@ -639,8 +725,11 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 10 ? MC_GW_COUNT_WPE : 1) void
         }
         if (done && lane == 0) ws.qflag[q] = kFlagDone;
         wave_lds_sync();
+      }
     }
 }
+
+int g_gwDiag = 0;                                              // mc_set_tuning(ctx, "gw_diag", n): timing experiments, see gw_filter_kernel
 
 static uint32_t gw_env(const char* name, uint32_t dflt)
 {
@@ -655,15 +744,28 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     mc_candidate_dev* c = (mc_candidate_dev*)cands;
     const uint32_t fgrid = big_filter_grid(b.n);               // blocks of 4 waves: the pool is cut into one slice per wave
     if (stage == 0) {
-        hipLaunchKernelGGL((gw_filter_kernel<4, 14>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
+        switch (g_gwDiag) {
+            case 1: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 1>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+            case 2: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 2>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+            case 3: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 3>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+            case 4: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+            case 5: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+            default: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+        }
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
     } else if (stage == 1) {
-        static const uint32_t bpc = gw_env("MC_BIG_COUNT_BPC", 5u);   // 32 KB of LDS per block
-        const uint32_t grid = std::min<uint32_t>(256 * bpc, (b.n + 3) / 4);
-        if (taxkey) hipLaunchKernelGGL((gw_count_kernel<10, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
-        else        hipLaunchKernelGGL((gw_count_kernel<10, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+        // filtered lists up to 256 (4 KB of LDS per wave), then 257 .. 512
+        static const uint32_t bpc = gw_env("MC_BIG_COUNT_BPC", 8u);
+        const uint32_t grid = std::min<uint32_t>(256 * bpc, (b.n + 3) / 4), grid1 = std::min<uint32_t>(256 * 5, (b.n + 3) / 4);
+        if (taxkey) {
+            hipLaunchKernelGGL((gw_count_kernel<9, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+            hipLaunchKernelGGL((gw_count_kernel<10, 4, true>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
+        } else {
+            hipLaunchKernelGGL((gw_count_kernel<9, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+            hipLaunchKernelGGL((gw_count_kernel<10, 4, false>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
+        }
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
         const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);

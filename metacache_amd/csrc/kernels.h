@@ -196,6 +196,7 @@ void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Wo
 void launch_union_partial(const uint32_t* counts, uint32_t sources, uint32_t m, const uint64_t* hits, uint32_t* tot, uint64_t* srcStart, uint64_t* hitOff,
                           uint64_t* out, void* scanTmp, hipStream_t st);
 void launch_owner_classify(const BatchView& b, const Workspace& ws, uint32_t minLen, hipStream_t st);
+extern int g_gwDiag;                      // timing experiments on gw_filter_kernel (mc_set_tuning "gw_diag")
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS

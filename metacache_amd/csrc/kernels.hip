@@ -3031,12 +3031,29 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __res
     }
 }
 
+// the filtered path's records of the batch (list 7): [5] = locations kept by the filter, [6] = reads that took the filtered path |
+// those with more than 512 kept << 32, [7] = reads the first filter kernel left to the second (compact store) | handed to the wave kernel << 32
+__global__ __launch_bounds__(256) void big_stats_kernel(const uint32_t* __restrict__ midCount, const uint4* __restrict__ list7, uint64_t* __restrict__ stats)
+{
+    const uint32_t total = midCount[9];
+    uint32_t kept = 0, over = 0, fb = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t n2 = list7[i].z;
+        if (n2 >= 0xFFFFu) ++fb; else { kept += n2; over += n2 > 512u ? 1u : 0u; }
+    }
+    atomicAdd((unsigned long long*)&stats[5], (unsigned long long)kept);
+    atomicAdd((unsigned long long*)&stats[6], (unsigned long long)over << 32);
+    atomicAdd((unsigned long long*)&stats[7], (unsigned long long)fb << 32);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd((unsigned long long*)&stats[6], (unsigned long long)total); atomicAdd((unsigned long long*)&stats[7], (unsigned long long)midCount[10]); }
+}
+
 void launch_batch_stats(const Workspace& ws, uint32_t n, hipStream_t st)
 {
     (void)hipMemsetAsync(ws.stats, 0, 8 * sizeof(uint64_t), st);
     if (n == 0) return;
     uint32_t blocks = min((n + 255u) / 256u, 1024u);
     hipLaunchKernelGGL(batch_stats_kernel, dim3(blocks), dim3(256), 0, st, ws.qstat, ws.winOff, n, ws.stats);
+    if (ws.midCount) hipLaunchKernelGGL(big_stats_kernel, dim3(blocks), dim3(256), 0, st, ws.midCount, reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n, ws.stats);
 }
 
 }  // namespace mcamd

@@ -27,6 +27,11 @@ def short(k):
     if "big_filter_kernel" in k:                                  # <WAVES, COMPACT, EPL, ...>: EPL = 1 is the first instance
         args = k.split("big_filter_kernel<", 1)[1].split(">")[0].split(",") if "big_filter_kernel<" in k else []
         return "big_filter" if len(args) < 3 or args[2].strip() in ("1u", "1") else "big_filter_2"
+    if "gw_filter_stream_kernel" in k: return "big_filter_2"
+    if "gw_filter_kernel" in k: return "big_filter"
+    if "gw_count_kernel<10" in k: return "big_count"
+    if "gw_count_kernel<11" in k: return "big_count_2"
+    if "gw_sort" in k or "gw_sorted" in k: return "gw_sorted_cands"
     if "big_count_kernel<10" in k: return "big_count"
     if "big_count_kernel<11" in k: return "big_count_2"
     for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs", "chunk_sketch", "chunk_probe", "chunk_finish", "flag_count", "table_seal", "build_sketch_lanes", "own_count", "own_emit", "union_copy"):

@@ -1,0 +1,82 @@
+"""Builds the configs[2] table once (bench.py's collection at --scale) and times the hot path for settings of run-time tuning switches
+(mc_set_tuning), e.g. the diagnostic variants of gw_filter_kernel:  python tools/tune_gw.py --scale 1 --set gw_diag=0,1,2,3"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from metacache_amd import synthdb  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=5_000_000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--set", default="gw_diag=0", help="name=v1,v2,...: one timed run per value")
+    ap.add_argument("--load-factor", type=float, default=0.3)
+    ap.add_argument("--pairs", action="store_true")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    c2 = dict(bench.CFG2); c2["genera"] = max(2, int(round(c2["genera"] * args.scale)))
+    spec = synthdb.phylogeny(**c2)
+    shards = max(1, int(np.ceil(spec.total_bases // 112 * 16 / 1.4e9)))
+    db, info = synthdb.build_database(spec, shards=shards, max_candidates=2, max_load_factor=args.load_factor,
+                                      report=lambda m: print(m, file=sys.stderr, flush=True))
+    B = args.batch
+    gen = synthdb.GpuSynth(0)
+    P = synthdb.read_params(spec, 3100)
+    batches = []
+    for s in range(2):
+        t = torch.zeros(B * bench.PAD_LEN + 16, dtype=torch.uint8, device=dev)
+        gen.reads(spec, P, s * B, B, t)
+        batches.append(t)
+    qinfo = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    qinfo[:, 0] = torch.arange(B, device=dev, dtype=torch.int32) * bench.PAD_LEN
+    qinfo[:, 1] = bench.READ_LEN; qinfo[:, 2] = qinfo[:, 0]
+    out = torch.zeros((B, 2, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    name, vals = args.set.split("=")
+    res = {"build": info, "table": db.table_layout(), "runs": []}
+    ref = None
+    for v in [int(x) for x in vals.split(",")]:
+        db.set_tuning(name, v)
+
+        def step(i):
+            r = db.query_device(batches[i % 2].data_ptr(), qinfo.data_ptr(), B, B * bench.PAD_LEN, max_win_uniform=3)
+            db.copy_results(out.data_ptr(), r.cands, B * 32)
+            db.synchronize()
+        step(0); step(1)
+        db.timing(True); db.timing_reset()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        el = time.perf_counter() - t0
+        db.timing(False)
+        step(0)
+        bs = db.last_batch_stats()
+        c = out.clone()
+        same = None if ref is None else bool(torch.equal(c, ref))
+        if ref is None:
+            ref = c
+        kt = {k: db.timing_get(k) for k in bench.KERNELS}
+        run = {name: v, "ms_per_step": round(el / args.steps * 1e3, 3), "Mreads_per_min": round(B * args.steps / el * 60 / 1e6, 1),
+               "same_candidates_as_first_setting": same, "stats": {k: bs[k] for k in ("locations", "filtered_kept", "filtered_reads", "filtered_over_512", "filter_second_kernel", "filter_handed_back")}, "kernel_ms": {k: round(x[0] / max(x[1], 1), 3) for k, x in kt.items() if x[0] > 0.02}}
+        print(json.dumps(run), flush=True)
+        res["runs"].append(run)
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+    db.close()
+
+
+if __name__ == "__main__":
+    main()
