@@ -214,7 +214,7 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
-                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill};
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
@@ -293,7 +293,7 @@ static int allocate_table(mc_ctx* ctx)
                 HIP_TRY(ctx, hipMalloc((void**)&ctx->dGwDir, nd * 4));
                 HIP_TRY(ctx, hipMemcpy(ctx->dGwBase, base.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
                 HIP_TRY(ctx, hipMemcpy(ctx->dGwDir, dir.data(), nd * 4, hipMemcpyHostToDevice));
-                ctx->gwDirShift = shift; ctx->gwGap = gap; ctx->gwTargets = (uint32_t)nt;
+                ctx->gwDirShift = shift; ctx->gwGap = gap; ctx->gwTargets = (uint32_t)nt; ctx->gwBits = bits_for((uint32_t)total);
                 T.compact = true;
             }
         }
@@ -686,6 +686,28 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             if (hcnt[10] || T.compact) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
             { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
             { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+            if (T.compact) {
+                // filtered lists the counting kernels do not take (long reads: thousands of numbers, wide window ranges) are sorted --
+                // one segmented sort over the pool -- and scanned (gw_sorted_cands_kernel); the filter kernels counted them
+                if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
+                uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
+                HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                if (*nsorted) {
+                    if ((rc = ensure(ctx, P.bBigPool2, poolCap * 4))) return rc;
+                    ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
+                    size_t tmpBytes = 0;
+                    if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap, ws, n, ctx->gwBits, st) != 0)
+                        return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
+                    if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
+                    {
+                        ScopedTimer t(ctx, "gw_sort", st);
+                        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap, ws, n, ctx->gwBits, st) != 0)
+                            return fail(ctx, MC_ERR_HIP, "segmented sort failed");
+                    }
+                    { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+                }
+            }
         }
         waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
     } else {

@@ -20,7 +20,7 @@ struct DevBuf {                 // grow-only device allocation
 struct Pipe {                   // the device workspace of ONE batch in flight + the stream its work is enqueued on
     hipStream_t stream = nullptr;
     DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
-        bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill;
+        bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp;
     uint32_t lastN = 0;
     uint64_t* hTotal = nullptr;   // pinned: the one host round trip of a batch lands here (a pageable target makes the copy blocking)
 };
@@ -92,7 +92,7 @@ struct mc_ctx {
     std::vector<uint32_t> targetWindows;   // empty: not announced
     uint32_t* dGwBase = nullptr;           // [targets + 1]
     uint32_t* dGwDir = nullptr;
-    uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0;
+    uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0, gwBits = 32;   // gwBits: bits of the largest window number
     bool tableReady = false;
     std::vector<uint64_t> hvalues;          // multi-part load: all location lists on the host until the last part is in
 

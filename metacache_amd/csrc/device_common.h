@@ -86,10 +86,63 @@ constexpr uint32_t kHashMax = 1024, kHashEnt = 256, kHashWin = 8;   // hash_cand
 constexpr uint32_t kBigEnt = 64;          // big_filter_kernel: found features per query, one lane each ...
 constexpr uint32_t kBigEPL = 3;           // ... or up to three per lane in its second instance (reads and pairs of 5 .. 10 windows: 2 x 250 bp, 500 bp)
 
+struct LaneCand { uint32_t tgt, hits, beg, end; };
+
+// rows 10: one candidate enters the lane's top list exactly as on the CPU (candidate_generation.hpp:172-231)
+// pre: the candidate's taxon if the caller has it already (mid_cands_kernel fetches them in parallel), else ~0u = look it up here
+__device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK], LaneCand c, const uint32_t K,
+                                           const uint32_t* __restrict__ taxkey, const uint32_t tgtMask, const uint32_t pre = ~0u)
+{
+    uint32_t ctax = 0;
+    bool moving = false;
+    if (taxkey) {
+        // candidate_generation.hpp:178-216: full list and not better than its last entry -> ignored;
+        // no taxon -> skipped; taxon already listed -> replaced only by more hits, then moved up behind
+        // the entries with >= hits (std::sort on <= 16 elements = insertion sort)
+        uint32_t lastHits = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
+        if (lastHits > 0 && lastHits >= c.hits) return;
+        ctax = pre != ~0u ? pre : taxkey[c.tgt & tgtMask];
+        if (ctax == 0) return;
+        bool found = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) {
+            if (i < K && !found && top[i].hits > 0 && toptax[i] == ctax) {
+                found = true;
+                if (c.hits > top[i].hits) {
+                    top[i] = c;
+#pragma unroll
+                    for (uint32_t j = kLaneK - 1; j > 0; --j) {       // bubble up while strictly more hits
+                        if (j <= i && top[j].hits > top[j - 1].hits) {
+                            const LaneCand t = top[j]; top[j] = top[j - 1]; top[j - 1] = t;
+                            const uint32_t tt = toptax[j]; toptax[j] = toptax[j - 1]; toptax[j - 1] = tt;
+                        }
+                    }
+                }
+            }
+        }
+        if (found) return;
+    }
+    // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i) {
+        if (i < K && (moving || c.hits > top[i].hits)) {
+            const LaneCand t = top[i]; top[i] = c; c = t;
+            const uint32_t tt = toptax[i]; toptax[i] = ctax; ctax = tt;
+            moving = true;
+        }
+    }
+}
+
 // big_filter_kernel / gw_filter_kernel -> counting kernels: longest filtered list the counting kernels take
 constexpr uint32_t kBigMaxFilteredCount = 1024;
 constexpr uint32_t kGwSmallH = 2048;      // compact store: reads with more locations take gw_filter_kernel's instance with the larger filters
 
+constexpr uint32_t kGwMaxKept = 65535;    // longest filtered list handed on (gw_filter kernels)
+// a filtered list (n2 numbers, window range maxWin) that is sorted instead of counted
+__host__ __device__ inline bool gw_sorted_class(uint32_t n2, uint32_t maxWin) { return n2 <= kGwMaxKept && (n2 > kBigMaxFilteredCount || maxWin > kHashWin); }
+// (stage 4 of launch_gw_cands: candidates of the sorted lists; needs ws.bigPool2 filled by launch_gw_segsort, kernels.h)
 // gw_kernels.hip: the filtered path of tables with the compact location store (stages as launch_big_cands)
 void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                      const uint32_t* taxkey, void* cands, hipStream_t st);

@@ -29,7 +29,6 @@ namespace {
 constexpr uint32_t kGwNone = 0xFFFFFFFFu;                 // never a stored number
 constexpr uint32_t kGwRounds = 128;                       // rounds (16 consecutive numbers of one bucket list = 64 bytes) per batch: 8 wave loads
 constexpr uint32_t kGwLoads = kGwRounds / 16;             // 16-byte loads per lane and batch: 32 registers hold 2 048 list places
-constexpr uint32_t kGwMaxKept = 65535;                    // longest filtered list handed on
 
 struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };   // 16-byte load from a 4-byte aligned address (global_load_dwordx4)
 
@@ -292,11 +291,13 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
         gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
         gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
         }
-        // longer than what is handed on, or the slice is full; (for now) longer than the counting kernels take
-        const bool fallback = S.n2 > S.room || S.n2 > kBigMaxFilteredCount || maxWin > kHashWin;
+        const bool fallback = S.n2 > S.room;                       // longer than what is handed on, or the slice is full
         if (lane == 0) {
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
-            else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+            else {
+                outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+                if (gw_sorted_class(S.n2, maxWin)) atomicAdd(&ws.midCount[13], 1u);     // not the counting kernels': sorted (the host launches that path when there are any)
+            }
         }
         if (!fallback) sliceUsed += S.n2;
         wave_lds_sync();
@@ -371,11 +372,14 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
                 }
                 wave_lds_sync();
             }
-            fallback = S.n2 > S.room || S.n2 > kBigMaxFilteredCount || maxWin > kHashWin;
+            fallback = S.n2 > S.room;
         }
         if (lane == 0) {
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
-            else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+            else {
+                outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+                if (gw_sorted_class(S.n2, maxWin)) atomicAdd(&ws.midCount[13], 1u);
+            }
         }
         if (!fallback) sliceUsed += S.n2;
         wave_lds_sync();
@@ -729,6 +733,101 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
     }
 }
 
+// ================================================================================================
+// gw_sorted_cands_kernel: rows 9-10 on a SORTED filtered list (gw_sort.hip) -- long reads (thousands of kept locations, window ranges
+// of tens to hundreds), pairs with large insert sizes.  One wave per read; every lane scans a contiguous piece of the list with the
+// CPU's sliding window (candidate_generation.hpp:47-108: numbers less than maxWindowsInRange apart are one target's, that is what the
+// gap between two targets' numbers is for), one candidate per target run through the CPU's top-list insert (top_insert: ties, taxon
+// merging); a run that crosses into the next lane's piece yields a candidate there too.  Then K rounds over the lanes' lists: the
+// best under (hits desc, target asc, end window asc), its target (taxon) struck everywhere -- every lane loses at most one entry per
+// round, so its K entries are enough.  Reads with fewer than K candidates of two or more hits go to the exact wave kernel (single
+// hits of other targets were filtered away).
+// ================================================================================================
+template <bool TAX>
+__global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
+                                                              mc_candidate_dev* __restrict__ cands)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t nWaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
+      const uint4 myRec = chunk + lane < total ? work[chunk + lane] : make_uint4(0, 0, kGwFallback, 0);
+      uint64_t todo = __ballot(gw_sorted_class(myRec.z, myRec.w));
+      while (todo) {
+        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t q = rdlane(myRec.x, j), n = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
+        const uint32_t* __restrict__ g = ws.bigPool2 + rdlane(myRec.y, j);
+        const uint32_t D = maxWin - 1u;
+        LaneCand top[kLaneK];
+        uint32_t toptax[kLaneK];
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
+        const uint32_t per = (n + 63u) / 64u, a = lane * per, e = min(n, a + per);
+        if (a < e) {
+            uint32_t gi = g[a];
+            uint32_t fst;
+            {   // first list position that can share a window range with this piece's first number
+                uint32_t lo = 0, hi = a;
+                const uint32_t want = gi - D;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g[mid] < want) lo = mid + 1; else hi = mid; }
+                fst = lo;
+            }
+            uint32_t gf = g[fst];
+            uint32_t t = tab.gw_target(gi), tlo = tab.gwBase[t], thi = tab.gwBase[t + 1];
+            LaneCand best; best.tgt = t; best.hits = 0; best.beg = 0; best.end = 0;
+            for (uint32_t i = a; i < e; ++i) {
+                gi = g[i];
+                if (gi >= thi) {
+                    top_insert(top, toptax, best, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+                    t = tab.gw_target(gi); tlo = tab.gwBase[t]; thi = tab.gwBase[t + 1];
+                    best.tgt = t; best.hits = 0;
+                }
+                while (gi - gf > D) { ++fst; gf = g[fst]; }
+                const uint32_t hits = i - fst + 1u;
+                if (hits > best.hits) { best.hits = hits; best.beg = gf - tlo; best.end = gi - tlo; }
+            }
+            top_insert(top, toptax, best, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+        }
+        // ---- K rounds over the lanes' lists (each sorted: entry 0 is the lane's best)
+        mc_candidate_dev* out = cands + (size_t)q * K;
+        uint32_t strong = 0;
+        for (uint32_t rnd = 0; rnd < K; ++rnd) {
+            const uint32_t mh = wave_max_u32(top[0].hits);
+            mc_candidate_dev ev; ev.tgt = 0xFFFFFFFFu; ev.hits = 0; ev.beg = 0; ev.end = 0;
+            if (mh != 0) {
+                const uint32_t mt = wave_min_u32(top[0].hits == mh ? top[0].tgt : 0xFFFFFFFFu);
+                const uint32_t me = wave_min_u32(top[0].hits == mh && top[0].tgt == mt ? top[0].end : 0xFFFFFFFFu);
+                const uint32_t winner = __ffsll((unsigned long long)__ballot(top[0].hits == mh && top[0].tgt == mt && top[0].end == me)) - 1;
+                ev.tgt = mt; ev.hits = mh; ev.end = me; ev.beg = rdlane(top[0].beg, winner);
+                const uint32_t mtax = rdlane(toptax[0], winner);
+                strong += mh >= 2 ? 1u : 0u;
+                // the picked target (taxon) leaves every lane's list
+                LaneCand kept[kLaneK]; uint32_t ktax[kLaneK];
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) { kept[i].tgt = 0xFFFFFFFFu; kept[i].hits = 0; kept[i].beg = 0; kept[i].end = 0; ktax[i] = 0; }
+                uint32_t nk = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) {
+                    const bool stay = top[i].hits != 0 && (TAX ? toptax[i] != mtax : top[i].tgt != mt);
+#pragma unroll
+                    for (uint32_t jj = 0; jj < kLaneK; ++jj) if (stay && jj == nk) { kept[jj] = top[i]; ktax[jj] = toptax[i]; }
+                    nk += stay ? 1u : 0u;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) { top[i] = kept[i]; toptax[i] = ktax[i]; }
+            }
+            if (lane == 0) out[rnd] = ev;
+        }
+        if (lane == 0) {
+            if (strong < K) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+            else ws.qflag[q] = kFlagDone;
+        }
+      }
+    }
+}
+
 int g_gwDiag = 0;                                              // mc_set_tuning(ctx, "gw_diag", n): timing experiments, see gw_filter_kernel
 
 static uint32_t gw_env(const char* name, uint32_t dflt)
@@ -766,6 +865,10 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             hipLaunchKernelGGL((gw_count_kernel<9, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
             hipLaunchKernelGGL((gw_count_kernel<10, 4, false>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
         }
+    } else if (stage == 4) {                                   // candidates of the sorted lists (after launch_gw_segsort)
+        const uint32_t grid = std::min<uint32_t>(256 * 8, (b.n + 3) / 4);
+        if (taxkey) hipLaunchKernelGGL((gw_sorted_cands_kernel<true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else        hipLaunchKernelGGL((gw_sorted_cands_kernel<false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
         const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);

@@ -138,6 +138,7 @@ struct Workspace {           // device buffers sized by the host for this batch
                              // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
     uint32_t* sliceFill;     // [waves of big_filter_kernel] entries each wave's pool slice holds after the first instance (nullptr: single instance)
     uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
+    uint32_t* bigPool2;      // [bigPoolCap] compact store: the filtered lists that are sorted (gw_sort.hip), at their pool offsets
     uint32_t  bigPoolCap;
     uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
@@ -187,6 +188,10 @@ void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab,
 void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);
+// gw_sort.hip: the filtered lists that are sorted instead of counted (list 7 records of the sorted class), pool -> out at the same offsets;
+// temp == nullptr: size query
+int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t endBit,
+                      hipStream_t st);
 uint32_t big_filter_grid(uint32_t n);     // blocks of 4 waves the filter runs with: the pool is cut into one slice per wave
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);

@@ -1459,7 +1459,9 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
 // (Collecting the totals with atomics in chunk_probe_kernel cost more than this pass; a per-lane device-scope fence for a
 // "last chunk finishes the read" scheme cost far more: the L2s of the 8 XCDs are written back and invalidated every time.
 // Compacting short lists here for mid_cands_kernel was measured too: what the wave kernel saves, the compaction costs.)
-__global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace ws)
+// Tables with the compact location store: the read goes on the filtered path's work list (gw_filter_stream_kernel reads its feature
+// slots, found or not, as the entries) instead of the wave kernel's sort of everything.
+__global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace ws, BatchView b, DeviceTable tab)
 {
     const uint32_t total = ws.midCount[5];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1484,6 +1486,13 @@ __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace
                 ws.qstat[q] = qs;
                 ws.hitScan[q] = (H <= kMaxHitsPerQuery && (H > kLdsCap || ws.partialLists)) ? H : 0u;   // (lists wanted: every query gets its segment)
                 ws.qflag[q] = kFlagCands;
+                const uint32_t slots = (ws.winOff[q + 1] - ws.winOff[q]) * s, mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+                if (tab.values32 && !ws.partialLists && H > ws.bigMin && H > 64u && H <= kMaxHitsPerQuery && slots <= 0xFFFu && mw <= tab.gwGap) {
+                    const uint32_t at = atomicAdd(&ws.midCount[9], 1u);          // (one per long read: few)
+                    reinterpret_cast<uint4*>(ws.midList)[(size_t)6 * b.n + at] = make_uint4(q, ws.winOff[q] * s, slots | (H << 12), mw);
+                    if (H > kGwSmallH) atomicAdd(&ws.midCount[10], 1u);
+                    ws.hitScan[q] = 0u; ws.qflag[q] = kFlagMid;
+                }
             }
         }
     }
@@ -1500,56 +1509,8 @@ __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace
 // random-line rate (tools/gather_bench3.hip: 57 G lines/s vs 55 G lines/s cooperative) with a tenth of the
 // instructions -- no ballots, no cross-lane compaction, no per-query serial section.
 // Lists longer than kLaneHits: second pass that stores (size, payload) per feature for sort_candidates_kernel.
-struct LaneCand { uint32_t tgt, hits, beg, end; };
 constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in u64): conflict-free lane-private rows
 constexpr uint32_t kLaneBlock = 128;
-
-// rows 10: one candidate enters the lane's top list exactly as on the CPU (candidate_generation.hpp:172-231)
-// pre: the candidate's taxon if the caller has it already (mid_cands_kernel fetches them in parallel), else ~0u = look it up here
-__device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK], LaneCand c, const uint32_t K,
-                                           const uint32_t* __restrict__ taxkey, const uint32_t tgtMask, const uint32_t pre = ~0u)
-{
-    uint32_t ctax = 0;
-    bool moving = false;
-    if (taxkey) {
-        // candidate_generation.hpp:178-216: full list and not better than its last entry -> ignored;
-        // no taxon -> skipped; taxon already listed -> replaced only by more hits, then moved up behind
-        // the entries with >= hits (std::sort on <= 16 elements = insertion sort)
-        uint32_t lastHits = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < kLaneK; ++i) if (i + 1 == K) lastHits = top[i].hits;
-        if (lastHits > 0 && lastHits >= c.hits) return;
-        ctax = pre != ~0u ? pre : taxkey[c.tgt & tgtMask];
-        if (ctax == 0) return;
-        bool found = false;
-#pragma unroll
-        for (uint32_t i = 0; i < kLaneK; ++i) {
-            if (i < K && !found && top[i].hits > 0 && toptax[i] == ctax) {
-                found = true;
-                if (c.hits > top[i].hits) {
-                    top[i] = c;
-#pragma unroll
-                    for (uint32_t j = kLaneK - 1; j > 0; --j) {       // bubble up while strictly more hits
-                        if (j <= i && top[j].hits > top[j - 1].hits) {
-                            const LaneCand t = top[j]; top[j] = top[j - 1]; top[j - 1] = t;
-                            const uint32_t tt = toptax[j]; toptax[j] = toptax[j - 1]; toptax[j - 1] = tt;
-                        }
-                    }
-                }
-            }
-        }
-        if (found) return;
-    }
-    // behind every entry with >= hits (ties keep arrival order); displaced entries shift down in order
-#pragma unroll
-    for (uint32_t i = 0; i < kLaneK; ++i) {
-        if (i < K && (moving || c.hits > top[i].hits)) {
-            const LaneCand t = top[i]; top[i] = c; c = t;
-            const uint32_t tt = toptax[i]; toptax[i] = ctax; ctax = tt;
-            moving = true;
-        }
-    }
-}
 
 // QUAD: quad-cooperative bucket fetches (tables beyond the reach of the infinity cache / TLBs), else lane-private 4 x 16-byte loads
 template <bool QUAD>
@@ -1796,7 +1757,10 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         // on counting beats sorting (measured per list: 3.3 vs 4.7 ns at 129..256); below, the register sort wins (1.6 vs 2 ns)
         const bool hashOK = nent <= kHashEnt && mw <= kHashWin;
         // 7 = big_cands_kernel (filter first): lists beyond ws.bigMin locations from at most kBigEnt found features
-        const bool bigOK = nent <= kBigEnt * kBigEPL && mw <= kHashWin && H > ws.bigMin && H > 64u;   // (lists up to 64 are sorted in registers, mid_cands_kernel)
+        // (compact store: any number of entries the record can name, any window range the gap between two targets covers; filtered lists
+        // the counting kernels do not take are sorted, gw_sorted_cands_kernel)
+        const bool bigOK = H > ws.bigMin && H > 64u &&              // (lists up to 64 are sorted in registers, mid_cands_kernel)
+                           (tab.values32 ? (nent <= 0xFFFu && mw <= tab.gwGap && H <= kMaxHitsPerQuery) : (nent <= kBigEnt * kBigEPL && mw <= kHashWin));
         const uint32_t cls = bigOK ? 7u : H <= 64 ? 0u : H <= 128 ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u) : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
         ws.qflag[q] = cls != 6 ? kFlagMid : kFlagCands;
         if (cls >= 3 && cls != 6) ws.hitScan[q] = 0u;                            // no segment in HBM
@@ -1916,7 +1880,7 @@ void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, c
         const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
         if (quad) hipLaunchKernelGGL(chunk_probe_kernel<true>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
         else      hipLaunchKernelGGL(chunk_probe_kernel<false>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
-        hipLaunchKernelGGL(chunk_finish_kernel, dim3(1024), dim3(256), 0, st, sp.s, ws);
+        hipLaunchKernelGGL(chunk_finish_kernel, dim3(1024), dim3(256), 0, st, sp.s, ws, b, tab);
     }
 }
 // Mode K, shard side: the location lists of the lane path's queries as they are (any order inside a list; the owner rank sorts the

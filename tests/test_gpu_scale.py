@@ -249,14 +249,54 @@ def test_two_gbp_database_auto_quad_against_oracle():
     db.close(); odb.close()
 
 
-def test_more_than_2_32_locations_against_oracle():
-    """A table beyond 2^32 locations (location offsets, list store and the builder's streaming shards all past 32 bits): 8 800 targets /
-    33 Gbp of the bench collection's shape (440 genera x 4 species x 5 strains, 2.5 - 5 Mbp), built in 4 key shards; 20 000 reads and
-    4 000 pairs against the oracle's restricted build.  Lists of 300 - 500 locations per read: the filtered path at its short end."""
+@pytest.fixture(scope="module")
+def table33():
+    """8 800 targets / 33 Gbp of the bench collection's shape (440 genera x 4 species x 5 strains, 2.5 - 5 Mbp), built in 4 key shards:
+    more than 2^32 locations.  One build for the tests below."""
     assert "MC_BIG_MIN" not in os.environ and "MC_COMPACT_LOCATIONS" not in os.environ
     spec = synthdb.phylogeny(440, 4, 5, 2_500_000, 5_000_000, seed=3100)
+    db, info = synthdb.build_database(spec, shards=4, max_candidates=2)
+    yield spec, db
+    db.close()
+
+
+def test_long_reads_length_distribution_against_oracle(table33):
+    """BASELINE configs[4]'s reads on the 33 Gbp table: 2 000 single reads, lengths log-normal around a median of 480 bp, clipped to
+    200 .. 19 000 (README.md:5), 7.5 % substitutions, seed 5100; maxWindowsInRange = 2 + length / 112 (candidate_structs.hpp:143-145): up to
+    171.  They collect hundreds to tens of thousands of locations; beyond 512 bp they are sketched and probed by the chunk lanes, filtered by
+    gw_filter_stream_kernel, sorted (gw_sort.hip) and scanned (gw_sorted_cands_kernel).  Every candidate against the oracle's restricted
+    build."""
+    import torch
+    spec, db = table33
     K = 2
-    db, info = synthdb.build_database(spec, shards=4, max_candidates=K)
+    n, Lmax = 2000, 19_000
+    rng = np.random.default_rng(5100)
+    lens = np.clip(np.exp(rng.normal(np.log(480.0), 0.95, n)), 200, Lmax).astype(np.int64)
+    lens[:4] = (Lmax, 12_345, 200, 513)                       # the ends of the range are in whatever the draw says
+    P = synthdb.read_params(spec, 5100, read_len=Lmax, sub_rate=0.075)
+    rows = torch.zeros((n, P.row_bytes), dtype=torch.uint8, device="cuda:0")
+    synthdb.GpuSynth(0).reads(spec, P, 0, n, rows)
+    torch.cuda.synchronize()
+    host = rows.cpu().numpy()
+    reads = [bytes(host[i, :int(lens[i])]) for i in range(n)]
+    assert np.median(lens) < 600 and lens.max() == Lmax and (lens > 2000).sum() > 50
+    odb = scale_util.oracle_database(spec, scale_util.sample_features(reads), threads=THREADS)
+    db.timing(True); db.timing_reset()
+    cands, counts, _ = db.query(reads)
+    db.timing(False)
+    assert db.timing_get("gw_sort")[1] > 0 and db.timing_get("gw_sorted_cands")[1] > 0      # the sorted path ran
+    assert counts.max() > 20_000, counts.max()
+    for i in range(n):
+        _, e = odb.query(reads[i], b"", K, 0, 0)
+        _check(cands[i], e, K, (i, int(lens[i]), counts[i]))
+    odb.close()
+
+
+def test_more_than_2_32_locations_against_oracle(table33):
+    """A table beyond 2^32 locations (location offsets, list store and the builder's streaming shards all past 32 bits); 20 000 reads and
+    4 000 pairs against the oracle's restricted build.  Lists of 300 - 500 locations per read: the filtered path at its short end."""
+    spec, db = table33
+    K = 2
     st = db.info()
     assert st[5] == 8800 and st[7] > (1 << 32), st
     lay = db.table_layout()
@@ -285,7 +325,7 @@ def test_more_than_2_32_locations_against_oracle():
     for i in range(n2):
         _, e = odb.query(p1[i], p2[i], K, 0, 0)
         _check(pc[i], e, K, ("pair", i, pcounts[i]))
-    db.close(); odb.close()
+    odb.close()
 
 
 @pytest.mark.parametrize("lowest,K,store", [(0, 2, 4), (0, 3, 8), (4, 2, 4)])
