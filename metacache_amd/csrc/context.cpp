@@ -214,7 +214,7 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
-                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp};
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp, &P.bSide};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
@@ -610,9 +610,10 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
     // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, in->num_chars * 3) : (uint64_t)n * 8,
-                                                                                  (uint64_t)big_filter_grid(n) * 4 * 4096));   // >= one full list per wave (gw_filter_kernel: one batch of 2 112 numbers)
+                                                                                  (uint64_t)big_filter_grid(n) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
     if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
     if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n) * 4 * 4 + 64))) return rc;
+    if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -630,6 +631,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         ws.partialLists = wantPartial ? 1u : 0u;
         ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap;
         ws.sliceFill = (uint32_t*)P.bSliceFill.p;
+        ws.sideList = (uint32_t*)P.bSide.p;
         ws.chunkList = (uint2*)P.bChunkList.p;
     }
 
@@ -649,6 +651,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     }
     const bool fuse = !wantAllhits && !taxkey;
     bool waveWork = true;                                        // wave kernels needed (always without the lane path)
+    bool skipWaveSketch = false;                                 // ... their sketching and probing has run already
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
         HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 64, st));
@@ -679,7 +682,14 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if (hcnt[8]) { ScopedTimer t(ctx, "hash_cands_256", st); launch_hash_cands(5, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[3]) { ScopedTimer t(ctx, "hash_cands_512", st); launch_hash_cands(3, b, tab, ws, K, taxkey, P.bCands.p, st); }
         if (hcnt[4]) { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
-        if (hcnt[9]) {
+        bool waveDone = false;
+        if (T.compact && !wantPartial && hcnt[6]) {
+            // compact store: the wave kernel's sketching and probing first, so that its reads can join the filtered path
+            { ScopedTimer t(ctx, "query_wave", st); launch_query(b, sp, tab, fuse, false, ws, K, P.bCands.p, st); }
+            launch_wave_rejoin(b, sp, tab, ws, st);
+            waveDone = true;
+        }
+        if (hcnt[9] || waveDone) {
             { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
             // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
             // host's look at the counters: always launched, returns at once with nothing to do)
@@ -710,12 +720,13 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             }
         }
         waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
+        skipWaveSketch = waveDone;
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }
     uint64_t totalHits = 0;
     if (waveWork) {
-        {
+        if (!skipWaveSketch) {
             // wave-per-query kernel for whatever the lane path did not take (long reads, duplicate hashes, ...)
             ScopedTimer t(ctx, "query_wave", st);
             launch_query(b, sp, tab, fuse, wantAllhits != 0, ws, K, P.bCands.p, st);

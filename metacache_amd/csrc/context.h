@@ -20,7 +20,7 @@ struct DevBuf {                 // grow-only device allocation
 struct Pipe {                   // the device workspace of ONE batch in flight + the stream its work is enqueued on
     hipStream_t stream = nullptr;
     DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
-        bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp;
+        bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide;
     uint32_t lastN = 0;
     uint64_t* hTotal = nullptr;   // pinned: the one host round trip of a batch lands here (a pageable target makes the copy blocking)
 };

@@ -296,7 +296,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
             else {
                 outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
-                if (gw_sorted_class(S.n2, maxWin)) atomicAdd(&ws.midCount[13], 1u);     // not the counting kernels': sorted (the host launches that path when there are any)
             }
         }
         if (!fallback) sliceUsed += S.n2;
@@ -305,6 +304,41 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
     if (lane == 0) {
         if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
         if (deferred) atomicAdd(&ws.midCount[10], deferred);       // (one atomic per wave that met such reads at all)
+    }
+}
+
+// The kernels that take FEW of the batch's records get their record numbers as compact lists (ws.sideList), so that they can deal them
+// out wave by wave -- scanning 5 x 10^6 records for a few hundred cost a millisecond per kernel, and taking them 64 at a time puts 64
+// long reads on one wave (and into one pool slice).  stage 0, after gw_filter_kernel: the reads gw_filter_stream_kernel takes;
+// stage 1, after it: filtered lists of 257 .. 512 and 513 .. 1024 numbers (counting instances) and the ones that are sorted.
+// One atomic per class and 64 records.
+__global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t n, uint32_t stage)
+{
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ rec6 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * n;
+    const uint4* __restrict__ rec7 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (total + 63u) / 64u * 64u; i += gridDim.x * 256) {
+        const bool inb = i < total;
+        uint32_t cls = 4;
+        if (inb) {
+            if (stage == 0) { if ((rec6[i].z >> 12) > kGwSmallH || rec7[i].z == kGwDefer) cls = 0; }
+            else {
+                const uint4 r = rec7[i];
+                if (gw_sorted_class(r.z, r.w)) cls = 3;
+                else if (r.z <= kBigMaxFilteredCount && r.w <= kHashWin) cls = r.z > 512u ? 2u : r.z > 256u ? 1u : 4u;
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint64_t m = __ballot(cls == c);
+            if (m == 0) continue;
+            const uint32_t leader = __ffsll((unsigned long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&ws.midCount[c == 0 ? 12u : c == 1 ? 14u : c == 2 ? 15u : 13u], (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (cls == c) ws.sideList[(size_t)c * n + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
     }
 }
 
@@ -318,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     using Bloom = GwBloom<T1LOG2, T2LOG2>;
     __shared__ uint32_t bitS[WAVES][Bloom::kWords];
     __shared__ uint64_t roundS[WAVES][kGwRounds];
-    if (ws.midCount[10] == 0) return;
+    if (ws.midCount[12] == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* bits = bitS[wave];
     uint64_t* T = roundS[wave];
@@ -331,16 +365,13 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
     uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    // (the records 64 at a time, as gw_count_kernel: this kernel takes a few of them)
-    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
-      const bool inb = chunk + lane < total;
-      const uint4 myRec = inb ? work[chunk + lane] : make_uint4(0, 0, 0, 0);
-      const uint32_t myZ = inb ? outRec[chunk + lane].z : 0u;
-      uint64_t todo = __ballot(inb && ((myRec.z >> 12) > kGwSmallH || myZ == kGwDefer));   // (the others: gw_filter_kernel's reads, done)
-      while (todo) {
-        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t w = chunk + j, q = rdlane(myRec.x, j), fbase = rdlane(myRec.y, j), recZ = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
+    const uint32_t mine = ws.midCount[12];
+    const uint32_t* __restrict__ side = ws.sideList;
+    {
+      for (uint32_t i = w0; i < mine; i += nWaves) {
+        const uint32_t w = side[i];
+        const uint4 rec = work[w];
+        const uint32_t q = rec.x, fbase = rec.y, recZ = rec.z, maxWin = rec.w;
         const uint32_t nent = recZ & 0xFFFu, H = recZ >> 12;
         {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
@@ -378,7 +409,6 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
             else {
                 outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
-                if (gw_sorted_class(S.n2, maxWin)) atomicAdd(&ws.midCount[13], 1u);
             }
         }
         if (!fallback) sliceUsed += S.n2;
@@ -590,15 +620,22 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
             for (uint32_t r = 0; r < kPre; ++r) pre[r] = r * 64 + lane < n ? pool[off + r * 64 + lane] : kGwNone;
         }
     };
-    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
-      const uint4 myRec = chunk + lane < total ? work[chunk + lane] : make_uint4(0, 0, kGwFallback, 0);
+    // the first instance (most reads) takes ALL records, 64 per step; the others get theirs from the compact lists gw_compact_kernel
+    // made (ws.sideList [1] / [2]), 8 per step: with few of them every wave should have some
+    constexpr uint32_t kStep = LOG2S == 9 ? 64u : 8u;
+    const uint32_t nmine = LOG2S == 9 ? total : ws.midCount[LOG2S == 10 ? 14 : 15];
+    const uint32_t* __restrict__ side = ws.sideList + (size_t)(LOG2S == 10 ? 1 : 2) * b.n;
+    for (uint32_t chunk = w0 * kStep; chunk < nmine; chunk += nWaves * kStep) {
+      const bool inb = lane < kStep && chunk + lane < nmine;
+      const uint32_t myW = LOG2S == 9 ? chunk + lane : (inb ? side[chunk + lane] : 0u);
+      const uint4 myRec = inb ? work[myW] : make_uint4(0, 0, kGwFallback, 0);
       // n2 in (minN2, kList], window ranges up to kHashWin (an EMPTY filtered list is the first instance's: step D fills the places)
       uint64_t todo = __ballot(myRec.z <= kList && (minN2 == 0 || myRec.z > minN2) && myRec.w <= kHashWin);
       if (todo) { const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1; fetch(rdlane(myRec.y, j), rdlane(myRec.z, j)); }
       while (todo) {
         const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
-        const uint32_t w = chunk + j, q = rdlane(myRec.x, j), n2 = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
+        const uint32_t w = rdlane(myW, j), q = rdlane(myRec.x, j), n2 = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
         const uint32_t* __restrict__ src = pool + rdlane(myRec.y, j);
         uint32_t cur[kPre];
 #pragma unroll
@@ -748,17 +785,15 @@ __global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, Devic
                                                               mc_candidate_dev* __restrict__ cands)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t nWaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
-    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
-      const uint4 myRec = chunk + lane < total ? work[chunk + lane] : make_uint4(0, 0, kGwFallback, 0);
-      uint64_t todo = __ballot(gw_sorted_class(myRec.z, myRec.w));
-      while (todo) {
-        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t q = rdlane(myRec.x, j), n = rdlane(myRec.z, j), maxWin = rdlane(myRec.w, j);
-        const uint32_t* __restrict__ g = ws.bigPool2 + rdlane(myRec.y, j);
+    const uint32_t nmine = ws.midCount[13];
+    const uint32_t* __restrict__ side = ws.sideList + (size_t)3 * b.n;
+    {
+      for (uint32_t i = w0; i < nmine; i += nWaves) {
+        const uint4 rec = work[side[i]];
+        const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
+        const uint32_t* __restrict__ g = ws.bigPool2 + rec.y;
         const uint32_t D = maxWin - 1u;
         LaneCand top[kLaneK];
         uint32_t toptax[kLaneK];
@@ -853,7 +888,10 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         }
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
+        const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
+        hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
+        hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1) {
         // filtered lists up to 256 (4 KB of LDS per wave), then 257 .. 512
         static const uint32_t bpc = gw_env("MC_BIG_COUNT_BPC", 8u);

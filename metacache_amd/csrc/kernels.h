@@ -138,6 +138,8 @@ struct Workspace {           // device buffers sized by the host for this batch
                              // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
     uint32_t* sliceFill;     // [waves of big_filter_kernel] entries each wave's pool slice holds after the first instance (nullptr: single instance)
     uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
+    uint32_t* sideList;      // [4][n] compact store: record numbers (list 6 / 7) of the reads gw_filter_stream_kernel takes ([0], length midCount[12]), of the
+                             // filtered lists of 257 .. 512 ([1], midCount[14]) and 513 .. 1024 numbers ([2], midCount[15]) and of the sorted ones ([3], midCount[13])
     uint32_t* bigPool2;      // [bigPoolCap] compact store: the filtered lists that are sorted (gw_sort.hip), at their pool offsets
     uint32_t  bigPoolCap;
     uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
@@ -184,6 +186,8 @@ void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, c
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);
+// compact store: reads sketched and probed by the wave kernel join the filtered path's work list (list 6) where it can take them
+void launch_wave_rejoin(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);

@@ -2950,6 +2950,36 @@ void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab,
         else        hipLaunchKernelGGL((hash_cands_kernel<9, 4, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, (mc_candidate_dev*)cands, cls);
     }
 }
+// Compact store: reads the wave kernel sketched and probed (equal hashes inside a sketch, odd sketching parameters, pairs with a long
+// mate) join the filtered path's work list when it can take them -- their feature slots, found or not, are the entries -- instead of
+// having their whole location lists sorted by sort_candidates_kernel (a 10 kbp read: 3 x 10^4 locations, 0.2 ms of ONE wave).
+__global__ __launch_bounds__(256) void wave_rejoin_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u;
+    bool join = false;
+    uint32_t H = 0, slots = 0, mw = 0;
+    if (q < b.n && ws.qflag[q] == kFlagCands) {
+        H = ws.qstat[q].hits; slots = (ws.winOff[q + 1] - ws.winOff[q]) * s; mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+        join = H > ws.bigMin && H > 64u && H <= kMaxHitsPerQuery && slots <= 0xFFFu && mw <= tab.gwGap;
+    }
+    const uint64_t m = __ballot(join);
+    if (!m) return;
+    const uint32_t leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&ws.midCount[9], (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    const uint64_t large = __ballot(join && H > kGwSmallH);
+    if (large && lane == leader) atomicAdd(&ws.midCount[10], (uint32_t)__popcll(large));
+    if (join) {
+        reinterpret_cast<uint4*>(ws.midList)[(size_t)6 * b.n + base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint4(q, ws.winOff[q] * s, slots | (H << 12), mw);
+        ws.hitScan[q] = 0u; ws.qflag[q] = kFlagMid;
+    }
+}
+void launch_wave_rejoin(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st)
+{
+    if (b.n && tab.values32) hipLaunchKernelGGL(wave_rejoin_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp.s, tab, ws);
+}
+
 // after the lane kernels: how many queries are left for the wave kernels (midCount[6]: to be sketched, [7]: candidates from a list in
 // HBM).  The host reads the eight counters once and launches only the kernels that have work -- a batch of 65 536 short reads spent
 // a fifth of its device time on launches of kernels with nothing to do.

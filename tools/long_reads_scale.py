@@ -73,6 +73,7 @@ def main():
         odb.close()
         run = {"read_len": L, "reads": n, "max_windows_in_range": mw, "ms_per_batch": round(el * 1e3, 2), "Gbases_per_s": round(n * L / el / 1e9, 3),
                "reads_per_s": round(n / el), "locations_per_read": round(st["locations"] / n, 1), "checked": args.check, "mismatches": bad,
+               "filtered": {k: st[k] for k in ("filtered_kept", "filtered_reads", "filtered_over_512", "filter_second_kernel", "filter_handed_back")},
                "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in kt.items() if v[0] > 0.05}}
         print(json.dumps(run), flush=True)
         res["runs"].append(run)
