@@ -95,6 +95,40 @@ def synth_reads_gpu(gcat: torch.Tensor, goff: torch.Tensor, glen: int, n: int, s
     return padded
 
 
+def make_long_reads(spec, gen, n: int, seed: int, dev, stride: int = 112):
+    """BASELINE configs[4]'s reads (SURVEY §8d "Config 5"): n single reads, lengths log-normal around a median of 480 bp clipped to
+    200 .. 19 000 (README.md:5), 7.5 % substitutions, 0.1 % N, both strands, uniform over the collection.  One packed character buffer
+    (every read 4-byte aligned), qinfo rows {offset, length, offset, 0} and maxWindowsInRange = 2 + length / stride per read
+    (candidate_structs.hpp:143-145).  Generated longest reads first, in groups with one row length."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.exp(rng.normal(np.log(480.0), 0.95, n)), 200, 19_000).astype(np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum((lens + 3) // 4 * 4)
+    if offs[-1] + 16 >= (1 << 32):
+        sys.exit("--long-reads: batch too large (character offsets are 32 bits)")
+    seq = torch.zeros(int(offs[-1]) + 16, dtype=torch.uint8, device=dev)
+    order = np.argsort(-lens, kind="stable")
+    lens_t = torch.from_numpy(lens).to(dev)
+    offs_t = torch.from_numpy(offs[:-1].copy()).to(dev)
+    done = 0
+    while done < n:
+        Lc = int(lens[order[done]])
+        m = int(min(n - done, max(256, (96 << 20) // Lc)))
+        sel = torch.from_numpy(order[done:done + m].copy()).to(dev)
+        P = synthdb.read_params(spec, seed, read_len=Lc, sub_rate=0.075)
+        rows = torch.zeros((m, P.row_bytes), dtype=torch.uint8, device=dev)
+        gen.reads(spec, P, done, m, rows)
+        pos = torch.arange(Lc, device=dev)[None, :]
+        keep = pos < lens_t[sel][:, None]
+        seq[(offs_t[sel][:, None] + pos)[keep]] = rows[:, :Lc][keep]
+        done += m
+    qinfo = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    qinfo[:, 0] = offs_t.to(torch.int32); qinfo[:, 1] = lens_t.to(torch.int32); qinfo[:, 2] = qinfo[:, 0]
+    maxwin = (2 + lens_t // stride).to(torch.int32)
+    torch.cuda.synchronize()
+    return {"seq": seq, "qinfo": qinfo, "maxwin": maxwin, "nchars": int(offs[-1]), "bases": int(lens.sum()), "lens": lens, "offs": offs}
+
+
 def measured_traffic(kernel_timer_name: str, tag: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
     (profiles/<tag>_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes; gfx950 caveat of
@@ -275,6 +309,99 @@ def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s, mates_ho
             {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
 
 
+def cpu_leg_long_reads(spec, db, lb, K, n_parity, budget_s, rerun, out_cands):
+    """--long-reads: a sample of the first batch against the C oracle, which builds the buckets of the sample's features itself (as
+    cpu_leg_config2); the sample is bounded by its BASES (long reads collect tens of thousands of locations each)."""
+    import scale_util
+    eff = scale_util.effective_cpus()
+    threads = min(os.cpu_count() or 1, 2 * eff)
+    rerun()
+    n = int(min(len(lb["lens"]), n_parity, max(200, np.searchsorted(np.cumsum(lb["lens"]), 4_000_000))))
+    host = lb["seq"][: int(lb["offs"][n])].cpu().numpy()
+    sample = [host[int(lb["offs"][i]): int(lb["offs"][i]) + int(lb["lens"][i])].tobytes() for i in range(n)]
+    t0 = time.time()
+    wanted = scale_util.sample_features(sample)
+    odb = scale_util.oracle_database(spec, wanted, threads=threads)
+    build_s = time.time() - t0
+    gpu_c = out_cands[:n].cpu().numpy().view(np.uint32).reshape(n, K, 4)
+    seqs = np.frombuffer(b"".join(sample), dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lb["lens"][:n])
+    t, cands = odb.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
+    gc = np.zeros((n, K), dtype=api.cand_dtype)
+    gc["tgt"], gc["hits"], gc["beg"], gc["end"] = gpu_c[..., 0], gpu_c[..., 1], gpu_c[..., 2], gpu_c[..., 3]
+    mism = count_mismatches(gc, cands)
+    info = odb.info()
+    odb.close()
+    bases = int(lb["lens"][:n].sum())
+    return ({"value": round(n / t * 60 / 1e6, 3), "unit": "Mreads/min", "cores": threads, "kind": "port", "host_cpus_granted": eff,
+             "Gbases_per_s": round(bases / t / 1e9, 4),
+             "sample": f"{n} reads ({bases} bases) of the same workload (batch 0); C oracle on {threads} host threads (the box grants {eff} CPUs) against the "
+                       f"buckets of the sample's {len(wanted)} features ({info[7]} locations), which it built itself in {build_s:.0f} s"},
+            {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
+
+
+def reference_calibration(scale: float, K: int, lf: float, device: int, budget_s: float):
+    """what the port's figure means in terms of the REFERENCE.  The same collection at `scale` (a table the reference can
+    load inside the budget) is built on the GPU, written as database files (mc_build_write_shards) to /dev/shm, loaded by oracle/_ref,
+    and the same reads are classified by the reference on the whole table and by the port on buckets restricted to the reads' features
+    (what the full-scale leg does) -- same threads.  Candidates of both are compared as well."""
+    import cpuref
+    import scale_util
+    if not cpuref.have_reference(4):
+        return None
+    c2 = dict(CFG2); c2["genera"] = max(2, int(round(c2["genera"] * scale)))
+    spec = synthdb.phylogeny(**c2)
+    need = spec.total_bases // 112 * 16 * 9 * 2.5
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        lim = float("inf") if lim == "max" else float(lim)
+    except OSError:
+        lim = float("inf")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    if need > 0.4 * lim or need > 100e9 or need > 0.8 * __import__("shutil").disk_usage(shm).free:
+        return None
+    name = os.path.join(shm, f"mcbench_cal_{os.getpid()}")
+    eff = scale_util.effective_cpus()
+    threads = min(os.cpu_count() or 1, 2 * eff)
+    try:
+        shards = max(1, int(np.ceil(spec.total_bases // 112 * 16 / 1.4e9)))
+        t0 = time.time()
+        db, _ = synthdb.build_database(spec, device=device, shards=shards, max_candidates=K, max_load_factor=lf, write_to=name)
+        n = 100_000
+        P = synthdb.read_params(spec, 3100)
+        rows = torch.zeros((n, P.row_bytes), dtype=torch.uint8, device=torch.device("cuda", device))
+        synthdb.GpuSynth(device).reads(spec, P, 0, n, rows)
+        gpu, counts, _ = db.query([bytes(r[:READ_LEN]) for r in rows.cpu().numpy()][:20_000])
+        locs = int(db.info()[7])
+        db.close()
+        build_s = time.time() - t0
+        reads_host = rows.cpu().numpy()
+        seqs = np.ascontiguousarray(reads_host[:, :READ_LEN]).reshape(-1)
+        offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+        t0 = time.time()
+        ref = cpuref.reference(4).open(name)
+        load_s = time.time() - t0
+        ref.query_many(seqs[: 2000 * READ_LEN], offs[:2001], max_cand=K, lowest=0, insert_max=0, threads=threads)
+        t_ref, c_ref = ref.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
+        ref.close()
+        sample = [reads_host[i, :READ_LEN].tobytes() for i in range(n)]
+        odb = scale_util.oracle_database(spec, scale_util.sample_features(sample), threads=threads)
+        odb.query_many(seqs[: 2000 * READ_LEN], offs[:2001], max_cand=K, lowest=0, insert_max=0, threads=threads)
+        t_port, c_port = odb.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
+        odb.close()
+        return {"scale": scale, "db_bases": int(spec.total_bases), "db_locations": locs, "reads": n, "threads": threads,
+                "locations_per_read": round(float(counts.mean()), 1),
+                "port_Mreads_min": round(n / t_port * 60 / 1e6, 2), "reference_Mreads_min": round(n / t_ref * 60 / 1e6, 2),
+                "port_over_reference": round(t_ref / t_port, 3),
+                "reference_vs_port_mismatches": count_mismatches(c_ref, c_port), "reference_vs_gpu_mismatches": count_mismatches(gpu, c_ref[:len(gpu)]),
+                "reference_load_s": round(load_s, 1), "build_and_write_s": round(build_s, 1)}
+    finally:
+        for e in (".meta", ".cache0"):
+            if os.path.exists(name + e):
+                os.remove(name + e)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +424,11 @@ def main():
     ap.add_argument("--reference-files", default="", help="configs[2], N = 1: also write the database as files under this name (e.g. /dev/shm/mcdb: "
                     "190 GB at full scale) and let the REFERENCE (oracle/_ref) load them and be the checker and the CPU baseline instead of the oracle")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
+    ap.add_argument("--long-reads", action="store_true", help="configs[2] table, BASELINE configs[4]'s reads: single reads of 200 .. 19 000 bp (log-normal, "
+                    "median 480), 7.5 %% substitutions, seed 5100; --batch = reads per step (default 250 000)")
+    ap.add_argument("--calibrate-scale", type=float, default=0.05, help="configs[2], N = 1: after the run, the same collection at this scale is built, written "
+                    "as database files and classified by the REFERENCE (oracle/_ref) and by the port on the same reads: cpu_baseline.reference_calibration "
+                    "(0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -317,9 +449,16 @@ def main():
     peak = gather_peak(args.gather_gib) if rank == 0 and args.gather_gib > 0 else None
     K = args.maxcand
     cfg = args.config
-    B = args.batch or (5_000_000 if cfg == 2 else 10_000_000)
+    B = args.batch or ((250_000 if args.long_reads else 5_000_000) if cfg == 2 else 10_000_000)
+    if args.long_reads and (cfg != 2 or args.mode != "R" or args.pairs):
+        sys.exit("--long-reads: configs[2] table, mode R, single reads")
     lf = args.load_factor or 0.3                             # configs[2]: 0.5 -> 0.3 is 5.15 -> 4.55 ms of probing per 5 M reads for 10 GB more buckets
-    nb = max(1, min(max(args.steps, args.warmup), 8 if cfg == 1 else 4))         # distinct batches resident in HBM, reused cyclically
+    # distinct batches resident in HBM: configs[2] in mode R one per step, warm-up included (25 x 0.76 GB: no timed batch has been
+    # through the path before); configs[1] and the sharded modes (N x B reads per rank and step) cycle through a few
+    if cfg == 2 and args.mode == "R" and not args.long_reads:
+        nb = max(1, min(args.steps + args.warmup, 48))
+    else:
+        nb = max(1, min(max(args.steps, args.warmup), 8 if cfg == 1 else 4))
     spec = None
     dbdir = None
     build_info = {}
@@ -378,12 +517,14 @@ def main():
                     sys.exit(f"--reference-files: about {need / 1e9:.0f} GB of files + reference tables do not fit this box's memory allowance; use --scale <= 0.2")
             db, build_info = synthdb.build_database(spec, device=local, shards=shards, max_candidates=K, max_load_factor=lf, report=say, write_to=write_to)
         gen = synthdb.GpuSynth(local)
+        if args.long_reads:
+            long_batches = [make_long_reads(spec, gen, B, 5100 + 7919 * rank + sidx, dev) for sidx in range(nb)]
         P = synthdb.read_params(spec, 4100 if args.pairs else 3100, paired=args.pairs)
         assert P.row_bytes == PAD_LEN
         # modes P and K: every rank works on ALL reads of a step (N x B); mode R: on its own B
         nloc = B * world if mode in ("P", "K") else B
         batches, mates = [], []
-        for sidx in range(nb):
+        for sidx in range(0 if args.long_reads else nb):
             t = torch.zeros(nloc * PAD_LEN, dtype=torch.uint8, device=dev)
             t2 = torch.zeros(nloc * PAD_LEN + 16, dtype=torch.uint8, device=dev) if args.pairs else None
             first = sidx * nloc if mode in ("P", "K") else (rank * 64 + sidx) * B
@@ -392,9 +533,11 @@ def main():
         V = 8
         shape = "2 x 150 bp read pairs" if args.pairs else "150 bp reads"
         how = {"R": "1 partition", "P": f"{world} partitions (targets round-robin), one per GPU", "K": f"1 partition key-sharded over {world} GPUs"}[mode]
-        workload = (f"configs[{3 if (args.pairs or mode != 'R') else 2}]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
+        workload = (f"configs[{4 if args.long_reads else 3 if (args.pairs or mode != 'R') else 2}]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
                     f"(genus>species>strain phylogeny, uint32 target ids, {how}{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
-                    f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
+                    + (f"{world * args.steps * B} synthetic long reads (200-19000 bp, log-normal, median 480; 7.5 % substitutions)" if args.long_reads else
+                       f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
+                    + ("" if nb >= args.steps + args.warmup else f" ({world * nb * B * (2 if args.pairs else 1)} distinct, cycled)"))
         # the committed PMC passes (profiles/r02_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
         pmc_tag = "r02" if (mode == "R" and not args.pairs and args.scale == 1.0 and B == 5_000_000) else "r02-none"
     build_s = time.time() - t0
@@ -437,13 +580,18 @@ def main():
             works[j] = None
 
     def step(i: int):
-        b = batches[i % nb]
+        b = batches[i % nb] if batches else None
         j = i % nbuf
         finish(j)                                            # the gather that used this buffer two batches ago
         if mode == "K":
             res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=True)
             out_bufs[j].copy_(classify_key_sharded_device(db, res, nloc, K, max_win))   # all-to-all of the partial lists, union, rows 8-10
             torch.cuda.current_stream().synchronize()
+        elif args.long_reads:
+            lb = long_batches[i % nb]
+            res = db.query_device(lb["seq"].data_ptr(), lb["qinfo"].data_ptr(), nloc, lb["nchars"], max_win_ptr=lb["maxwin"].data_ptr())
+            db.copy_results(out_bufs[j].data_ptr(), res.cands, nloc * K * 16)
+            db.synchronize()
         else:
             res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win)
             db.copy_results(out_bufs[j].data_ptr(), res.cands, nloc * K * 16)
@@ -495,6 +643,9 @@ def main():
         per_read = 2 if pairs else 1                           # a pair counts as 2 reads (printing.cpp:605-608)
         F, H = st["features"] / (nloc * per_read), st["locations"] / (nloc * per_read)
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
+        if args.long_reads:                                    # SURVEY's formula with the reads' own lengths: ceil(L/4) + ceil(L/8) summed over the last timed batch
+            lb = long_batches[(args.steps - 1) % nb]
+            bytes_per_read = float(((lb["lens"] + 3) // 4 + (lb["lens"] + 7) // 8).sum()) / nloc + 12.0 * F + V * H + 16.0 * K
         dom = max((k for k in KERNELS if k not in ("plan", "scan")), key=lambda k: kt[k][0])
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * nloc * per_read / (dom_ms * 1e-3) / 1e9
@@ -502,7 +653,8 @@ def main():
         total_reads = world * args.steps * B * per_read
         value = total_reads / elapsed * 60.0 / 1e6
         result = {
-            "metric": "Mreads/min (150 bp)", "value": round(value, 2), "unit": "Mreads/min", "n_gpus": world,
+            "metric": "Mreads/min (long reads: 200-19000 bp, median 480)" if args.long_reads else "Mreads/min (150 bp)",
+            "value": round(value, 2), "unit": "Mreads/min", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "reads_per_step_per_gpu": B,
@@ -515,7 +667,10 @@ def main():
                                        "K": f"1 part key-sharded over {world} GPUs; all reads against every shard, RCCL all-to-all of partial location lists, "
                                             "union + candidates on the owner, gather"}[mode]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         # the same bytes over the WHOLE step (all kernels, launches, the copy of the candidates)
+                         "step_frac": round(bytes_per_read * nloc * per_read / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(bytes_per_read * nloc * per_read),
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3), "V": V,
                          "table_location_bytes": layout["location_bytes"],
@@ -535,7 +690,15 @@ def main():
             else:
                 ra["requests_per_s"] = None; ra["frac"] = None
             result["roofline"]["random_access"] = ra
-        if world == 1 and args.cpu_seconds > 0:
+        if args.long_reads:
+            tot_bases = sum(long_batches[i % nb]["bases"] for i in range(args.steps))
+            result["config"]["Gbases_per_s"] = round(world * tot_bases / elapsed / 1e9, 3)
+            result["config"]["mean_read_len"] = round(tot_bases / (args.steps * B), 1)
+        if world == 1 and args.cpu_seconds > 0 and args.long_reads:
+            cb, par = cpu_leg_long_reads(spec, db, long_batches[0], K, args.parity_reads, args.cpu_seconds, lambda: (step(0), drain(), db.synchronize()), out_cands)
+            result["cpu_baseline"] = cb
+            result["parity"] = par
+        elif world == 1 and args.cpu_seconds > 0:
             step(0)
             drain()
             db.synchronize()
@@ -554,6 +717,12 @@ def main():
             result["cpu_baseline"] = cb
             result["parity"] = par
     db.close()
+    if rank == 0 and world == 1 and cfg == 2 and mode == "R" and not pairs and not args.long_reads and args.cpu_seconds > 0 and args.calibrate_scale > 0 \
+            and "cpu_baseline" in result and not args.reference_files:
+        torch.cuda.empty_cache()
+        cal = reference_calibration(args.calibrate_scale, K, lf, local, args.cpu_seconds)
+        if cal:
+            result["cpu_baseline"]["reference_calibration"] = cal
     # the JSON line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which every rank
     # flushes here, before the barrier and the line, instead of at process exit after it
     import ctypes

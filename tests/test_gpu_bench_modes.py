@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.004", "--batch", "30000", "--steps", "2", "--warmup", "1",
-           "--gather-gib", "0", "--parity-reads", "3000", "--cpu-seconds", "2"] + extra
+           "--gather-gib", "0", "--parity-reads", "3000", "--cpu-seconds", "2", "--calibrate-scale", "0.002"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
@@ -22,12 +22,18 @@ def _run(extra):
 
 
 @pytest.mark.parametrize("extra", [[], ["--pairs"], ["--mode", "P", "--force-dist"], ["--mode", "P", "--pairs", "--force-dist"],
-                                   ["--mode", "K", "--force-dist"], ["--mode", "K", "--pairs", "--force-dist"], ["--config", "1", "--batch", "200000", "--genome-len", "200000"]])
+                                   ["--mode", "K", "--force-dist"], ["--mode", "K", "--pairs", "--force-dist"], ["--config", "1", "--batch", "200000", "--genome-len", "200000"],
+                                   ["--long-reads", "--batch", "3000"]])
 def test_bench_line_and_parity(extra):
     res = _run(extra)
     assert res["metric"].startswith("Mreads/min") and res["value"] > 0 and res["n_gpus"] == 1
-    assert res["parity"]["mismatches"] == 0 and res["parity"]["checked"] >= 3000, res["parity"]
-    assert "roofline" in res and res["roofline"]["frac"] > 0 and "cpu_baseline" in res
+    assert res["parity"]["mismatches"] == 0 and res["parity"]["checked"] >= (200 if "--long-reads" in extra else 3000), res["parity"]
+    assert "roofline" in res and res["roofline"]["frac"] > 0 and res["roofline"]["step_frac"] > 0 and "cpu_baseline" in res
+    if extra == []:                                        # the default line carries the reference's speed next to the port's
+        cal = res["cpu_baseline"]["reference_calibration"]
+        assert cal["reference_Mreads_min"] > 0 and cal["port_Mreads_min"] > 0 and cal["reference_vs_port_mismatches"] == 0 and cal["reference_vs_gpu_mismatches"] == 0, cal
+    if "--long-reads" in extra:
+        assert res["config"]["Gbases_per_s"] > 0 and res["config"]["workload"].startswith("configs[4]")
     if "--config" not in extra:
         assert res["config"]["workload"].startswith("configs[")
         assert res["config"]["mode"] == (extra[extra.index("--mode") + 1] if "--mode" in extra else "R")
