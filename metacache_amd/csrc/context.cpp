@@ -601,7 +601,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
     if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
     if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 64 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
     // pool of the filtered location lists (big_filter_kernel -> big_count_kernel): 384 per query on average, at least 4 MB
     // (tables whose features have few locations each never produce such lists: a token pool; a full pool sends lists to the wave kernel)
     const Part& T0 = ctx->parts[0];
@@ -611,7 +611,10 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, in->num_chars * 3) : (uint64_t)n * 8,
                                                                                   (uint64_t)big_filter_grid(n) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
-    if (lanePath && (rc = ensure(ctx, P.bBigPool, poolCap * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
+    // compact store: behind the waves' slices an OVERFLOW region for filtered lists that may not fit their wave's slice (the longest
+    // reads of a batch keep 10^5 numbers): reserved with one atomic per such read (midCount[16..17])
+    const uint64_t ovfCap = T0.compact ? std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20)) : 0;
+    if (lanePath && (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
     if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n) * 4 * 4 + 64))) return rc;
     if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
@@ -626,10 +629,10 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
     ws.scanTmp = P.bScan.p; ws.stats = (uint64_t*)P.bStats.p;
     if (lanePath) {
-        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
+        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32;
         ws.bigMin = ctx->bigMin;
         ws.partialLists = wantPartial ? 1u : 0u;
-        ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap;
+        ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap; ws.bigOvfCap = (uint32_t)ovfCap;
         ws.sliceFill = (uint32_t*)P.bSliceFill.p;
         ws.sideList = (uint32_t*)P.bSide.p;
         ws.chunkList = (uint2*)P.bChunkList.p;
@@ -654,7 +657,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     bool skipWaveSketch = false;                                 // ... their sketching and probing has run already
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
-        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 64, st));
+        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
         if (ctx->fuseLane) {
             ScopedTimer t(ctx, "sketch_probe", st);
             launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, st);
@@ -704,15 +707,15 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
                 HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(ctx, hipStreamSynchronize(st));
                 if (*nsorted) {
-                    if ((rc = ensure(ctx, P.bBigPool2, poolCap * 4))) return rc;
+                    if ((rc = ensure(ctx, P.bBigPool2, (poolCap + ovfCap) * 4))) return rc;
                     ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
                     size_t tmpBytes = 0;
-                    if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap, ws, n, ctx->gwBits, st) != 0)
+                    if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap + ovfCap, ws, n, ctx->gwBits, st) != 0)
                         return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
                     if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
                     {
                         ScopedTimer t(ctx, "gw_sort", st);
-                        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap, ws, n, ctx->gwBits, st) != 0)
+                        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap + ovfCap, ws, n, ctx->gwBits, st) != 0)
                             return fail(ctx, MC_ERR_HIP, "segmented sort failed");
                     }
                     { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
@@ -826,7 +829,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
         (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
         (rc = ensure(ctx, P.bPpay, ((size_t)S * (n + 2) + n + 1) * 8)) || (rc = ensure(ctx, P.bPsize, (size_t)(n + 1) * 4)) ||
         (rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4)) || (rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4)) ||
-        (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bMid, 64 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)))
+        (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)))
         return rc;
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * 448, (uint64_t)big_filter_grid(n) * 4 * 1024));
     if ((rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
@@ -843,11 +846,11 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     // filter cannot take (more than 16 384 locations, wide window ranges) and what it hands back goes through the sort as before.
     const bool filtered = lane_candidates_supported(K) && ctx->useLanePath;
     if (filtered) {
-        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16;
+        ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32;
         ws.bigMin = ctx->bigMin; ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap;
         ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = srcStart + (size_t)S * (n + 2);
         ws.winOff = (uint32_t*)P.bWinOff.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bWinCount.p;
-        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 64, st));
+        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
         launch_owner_classify(b, ws, std::max<uint32_t>(ctx->bigMin, 256u), st);
         DeviceTable utab{nullptr, ws.hits, 0, 0xFFFFFFFFu, 1};
         const SketchParams one{16, 1, 16, 1};                                  // step D finds a read's entry at winOff[q] * s = q
@@ -911,7 +914,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
-    if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 16; }
+    if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);
     HIP_TRY(ctx, hipMemcpyAsync(stats, ws.stats, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -139,7 +139,7 @@ __device__ __forceinline__ void top_insert(LaneCand (&top)[kLaneK], uint32_t (&t
 constexpr uint32_t kBigMaxFilteredCount = 1024;
 constexpr uint32_t kGwSmallH = 2048;      // compact store: reads with more locations take gw_filter_kernel's instance with the larger filters
 
-constexpr uint32_t kGwMaxKept = 65535;    // longest filtered list handed on (gw_filter kernels)
+constexpr uint32_t kGwMaxKept = kMaxHitsPerQuery;   // longest filtered list handed on (gw_filter kernels)
 // a filtered list (n2 numbers, window range maxWin) that is sorted instead of counted
 __host__ __device__ inline bool gw_sorted_class(uint32_t n2, uint32_t maxWin) { return n2 <= kGwMaxKept && (n2 > kBigMaxFilteredCount || maxWin > kHashWin); }
 // (stage 4 of launch_gw_cands: candidates of the sorted lists; needs ws.bigPool2 filled by launch_gw_segsort, kernels.h)

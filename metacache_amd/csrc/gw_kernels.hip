@@ -380,6 +380,18 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
         }
         const GwFrame F(maxWin);
         GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+        uint64_t listAt = (uint64_t)w0 * sliceCap + sliceUsed;
+        bool inSlice = true;
+        if (H > S.room) {
+            // the list may not fit what is left of this wave's slice: H places of the pool's overflow region (the filter keeps H at most)
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(reinterpret_cast<unsigned long long*>(ws.midCount + 16), (unsigned long long)H);
+            at = ((unsigned long long)rdlane((uint32_t)(at >> 32), 0) << 32) | rdlane((uint32_t)at, 0);
+            if (at + H <= ws.bigOvfCap) {
+                listAt = (uint64_t)ws.bigPoolCap + at;
+                S.dst = reinterpret_cast<uint32_t*>(ws.bigPool) + listAt; S.room = H; inSlice = false;
+            }
+        }
         bool fallback = maxWin > tab.gwGap;                        // (window ranges wider than the gap between two targets: the kernels that know the targets)
         const uint32_t nchunks = (nent + 63u) / 64u;
         if (!fallback) {
@@ -408,10 +420,10 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
         if (lane == 0) {
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
             else {
-                outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+                outRec[w] = make_uint4(q, (uint32_t)listAt, S.n2, maxWin);
             }
         }
-        if (!fallback) sliceUsed += S.n2;
+        if (!fallback && inSlice) sliceUsed += S.n2;
         wave_lds_sync();
       }
     }

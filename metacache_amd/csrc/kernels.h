@@ -131,7 +131,7 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint32_t* qflag;         // [n]        0 = done, 1 = needs sketch+probe (wave), 2 = needs candidates (wave),
                              //            4 = sketched by a lane (probe_cands_kernel takes it from there), 5 = on a work list of mid_cands_kernel,
                              //            6 = long read handled by the chunk lane kernels
-    uint32_t* midCount;      // [16]; [8] = third work list of hash_cands_kernel (129..256);       lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
+    uint32_t* midCount;      // [32]; [8] = third work list of hash_cands_kernel (129..256);       lengths of the three work lists of mid_cands_kernel, [3], [4] = of hash_cands_kernel, [5] = chunk records, [6], [7] = queries left for the wave kernels (launch_flag_count) (zeroed per batch)
     uint2*    chunkList;     // [W + n]    {query, chunk}: long single reads, cut into one-window chunks for the chunk lane kernels
     uint32_t  partialLists;  // 1: every lane-path query hands its entry table over and ends there (MC_WANT_PARTIAL_HITS: gather_lists_kernel copies the lists)
     uint32_t  bigMin;        // lists longer than this (and > 256) from <= 64 found features go to big_filter_kernel (midCount[9], list 6), which
@@ -142,6 +142,7 @@ struct Workspace {           // device buffers sized by the host for this batch
                              // filtered lists of 257 .. 512 ([1], midCount[14]) and 513 .. 1024 numbers ([2], midCount[15]) and of the sorted ones ([3], midCount[13])
     uint32_t* bigPool2;      // [bigPoolCap] compact store: the filtered lists that are sorted (gw_sort.hip), at their pool offsets
     uint32_t  bigPoolCap;
+    uint32_t  bigOvfCap;     // compact store: entries behind bigPoolCap for filtered lists that may not fit their wave's slice (cursor: midCount[16..17] as u64)
     uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
     uint32_t* hitScan;       // [n]        hits that need a segment in 'hits' (all, or only lists too long for LDS)
     uint64_t* hitOff;        // [n+1]      exclusive scan of hitScan

@@ -3030,12 +3030,12 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __res
 __global__ __launch_bounds__(256) void big_stats_kernel(const uint32_t* __restrict__ midCount, const uint4* __restrict__ list7, uint64_t* __restrict__ stats)
 {
     const uint32_t total = midCount[9];
-    uint32_t kept = 0, over = 0, fb = 0;
+    unsigned long long kept = 0; uint32_t over = 0, fb = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t n2 = list7[i].z;
-        if (n2 >= 0xFFFFu) ++fb; else { kept += n2; over += n2 > 512u ? 1u : 0u; }
+        if (n2 >= 0xFFFFFFFEu) ++fb; else { kept += n2; over += n2 > 512u ? 1u : 0u; }
     }
-    atomicAdd((unsigned long long*)&stats[5], (unsigned long long)kept);
+    atomicAdd((unsigned long long*)&stats[5], kept);
     atomicAdd((unsigned long long*)&stats[6], (unsigned long long)over << 32);
     atomicAdd((unsigned long long*)&stats[7], (unsigned long long)fb << 32);
     if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd((unsigned long long*)&stats[6], (unsigned long long)total); atomicAdd((unsigned long long*)&stats[7], (unsigned long long)midCount[10]); }
