@@ -252,12 +252,11 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
         rec = recNext;                                             // the next read's record and entries are on their way meanwhile
         recNext = load_rec(w + 2 * nWaves);
         load_entries(rec);
-        if (H > kGwSmallH) continue;                               // the other kernel's read
         const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
         const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
         // (a slice that cannot take everything one batch may keep -- kGwRounds x 16 + 64 numbers -- sends the read on as well: the stores
         // below are not bounds-checked)
-        if (nent > 64u || Rc > kGwRounds || maxWin > tab.gwGap || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
+        if (H > kGwSmallH || nent > 64u || Rc > kGwRounds || maxWin > tab.gwGap || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
             if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin);
             ++deferred;
             continue;
@@ -307,6 +306,92 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
     }
 }
 
+// The same for reads of up to 2 x kGwRounds rounds and 2 x kGwSmallH locations (2 x 150 bp pairs at RefSeq scale: 52 lists of 49
+// numbers = 208 rounds): TWO batches.  The second one stays in registers for phase B, the first one is read again (from the L2): one
+// and a half passes over the fabric instead of the streaming kernel's two, and its occupancy (8 KB of filter bits per wave).
+// Takes the records gw_filter_kernel left (kGwDefer), 64 at a time; leaves what does not fit either to gw_filter_stream_kernel.
+template <uint32_t WAVES, uint32_t TLOG2>
+__global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_kernel(BatchView b, DeviceTable tab, Workspace ws)
+{
+    using Bloom = GwBloom<TLOG2, TLOG2>;
+    __shared__ uint32_t bitS[WAVES][Bloom::kWords];
+    __shared__ uint64_t roundS[WAVES][kGwRounds];
+    if (ws.midCount[10] == 0) return;                              // nothing was left
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* bits = bitS[wave];
+    uint64_t* T = roundS[wave];
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
+    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
+    uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;
+    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    constexpr uint32_t kMaxRounds = 2 * kGwRounds, kMaxH = 2 * kGwSmallH;
+    uint32_t esz = 0; uint64_t epay = 0;
+    auto load_entries = [&](uint32_t fbase, uint32_t ne) {
+        esz = lane < ne ? ws.psize[fbase + lane] : 0u;
+        epay = lane < ne ? ws.ppay[fbase + lane] : 0ull;
+    };
+    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
+      const bool inb = chunk + lane < total;
+      const uint4 myRec = inb ? work[chunk + lane] : make_uint4(0, 0, 0, 0);
+      const uint32_t myZ = inb ? outRec[chunk + lane].z : 0u;
+      uint64_t todo = __ballot(inb && myZ == kGwDefer && (myRec.z >> 12) <= kMaxH && (myRec.z & 0xFFFu) <= 64u && myRec.w <= tab.gwGap);
+      if (todo) { const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1; load_entries(rdlane(myRec.y, j), rdlane(myRec.z, j) & 0xFFFu); }
+      while (todo) {
+        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t w = chunk + j, q = rdlane(myRec.x, j), H = rdlane(myRec.z, j) >> 12, maxWin = rdlane(myRec.w, j);
+        const uint32_t sz = esz & 0xFFFFu; const uint64_t pay = epay;
+        if (todo) { const uint32_t jn = (uint32_t)__ffsll((unsigned long long)todo) - 1; load_entries(rdlane(myRec.y, jn), rdlane(myRec.z, jn) & 0xFFFu); }
+        const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
+        const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
+        if (Rc > kMaxRounds || sliceCap - sliceUsed < kMaxRounds * 16u + 64u) continue;   // stays deferred: gw_filter_stream_kernel
+        {
+            uint4* z4 = reinterpret_cast<uint4*>(bits);
+#pragma unroll
+            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        const GwFrame F(maxWin);
+        const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
+        GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+        uint4 x[kGwLoads];
+        // ---- A: batch 0, then batch 1 (stays in registers)
+        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
+        gw_fill_rounds(T, lane, 0, Rc, start, myR, sz, pay);
+        wave_lds_sync();
+        gw_load_rounds(T, tab.values32, grp, sub4, x);
+        gw_mark_rounds<Bloom>(bits, x, F.A);
+        const bool two = Rc > kGwRounds;
+        if (two) {
+            wave_lds_sync();
+            gw_fill_rounds(T, lane, kGwRounds, Rc, start, myR, sz, pay);
+            wave_lds_sync();
+            gw_load_rounds(T, tab.values32, grp, sub4, x);
+            gw_mark_rounds<Bloom>(bits, x, F.A);
+        }
+        wave_lds_sync();
+        // ---- B: the batch in registers, then (two batches) batch 0 again
+        gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+        gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
+        if (two) {
+            wave_lds_sync();
+            gw_fill_rounds(T, lane, 0, Rc, start, myR, sz, pay);
+            wave_lds_sync();
+            gw_load_rounds(T, tab.values32, grp, sub4, x);
+            gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
+        }
+        if (lane == 0) outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), S.n2, maxWin);
+        sliceUsed += S.n2;
+        wave_lds_sync();
+      }
+    }
+    if (lane == 0 && ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
+}
+
 // The kernels that take FEW of the batch's records get their record numbers as compact lists (ws.sideList), so that they can deal them
 // out wave by wave -- scanning 5 x 10^6 records for a few hundred cost a millisecond per kernel, and taking them 64 at a time puts 64
 // long reads on one wave (and into one pool slice).  stage 0, after gw_filter_kernel: the reads gw_filter_stream_kernel takes;
@@ -322,7 +407,7 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
         const bool inb = i < total;
         uint32_t cls = 4;
         if (inb) {
-            if (stage == 0) { if ((rec6[i].z >> 12) > kGwSmallH || rec7[i].z == kGwDefer) cls = 0; }
+            if (stage == 0) { if (rec7[i].z == kGwDefer) cls = 0; }
             else {
                 const uint4 r = rec7[i];
                 if (gw_sorted_class(r.z, r.w)) cls = 3;
@@ -901,6 +986,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
+        hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
