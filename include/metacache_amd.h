@@ -217,6 +217,33 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int
                     mc_device_results* out, void* stream);
 int mc_synchronize(mc_ctx* ctx);
 
+/* Mode P (one database part per GPU) and part groups.  Per-part candidate lists of the same reads (DEVICE pointers, [n][max_candidates]
+ * each, in part order; target ids as mc_open_database with cfg.single_part leaves them: the database's own) -> one list per read, as if
+ * the parts had been queried one after the other with one candidate list: host_hashmap.hpp:695-723 concatenates the parts' sorted
+ * location lists, candidate_generation.hpp:172-231 inserts their candidates in that order (ties keep arrival order; lowest_rank > 0: one
+ * entry per taxon, this context's lineages).  max_candidates <= 4.  out may be lists[0].  Asynchronous on 'stream'.
+ * Replaces what the reference does across its GPUs for a partitioned database (gpu_hashmap.cu:1255-1290, query_batch.cu:464-527) and
+ * `metacache merge` of per-part result files (mode_merge.cpp:247-296). */
+int mc_merge_part_candidates(mc_ctx* ctx, const mc_candidate* const* lists, uint32_t num_lists, uint32_t num_queries, int lowest_rank,
+                             mc_candidate* out, void* stream);
+
+/* A partitioned database queried part group by part group (docs/partitioning.md:116-153, for databases beyond the node's HBM), the
+ * parts of a group spread over GPUs (options.cpp:1155-1163 lists the reference's multi-GPU switches): `resident_parts` parts are in
+ * HBM at a time -- one context each, part i of a group on devices[i % num_devices] -- and the NEXT group is loaded by a background
+ * thread while the reads run against this one.  Per batch the per-part top lists are gathered with ncclAllGather (RCCL; one
+ * communicator rank per device, ncclCommInitAll) and merged on devices[0] by mc_merge_part_candidates, together with the list the
+ * earlier groups left.  devices == NULL: cfg->device alone.  cfg: as for mc_open_database (slot_max_queries / slot_max_chars = batch size). */
+typedef struct mc_partset mc_partset;
+int  mc_partset_open(const char* name, const mc_config* cfg, uint32_t resident_parts, const int32_t* devices, uint32_t num_devices, mc_partset** out);
+void mc_partset_close(mc_partset* ps);
+/* info[0..5] = parts, resident parts, groups, devices, nanoseconds the loader thread spent loading, nanoseconds the queries waited for it */
+int  mc_partset_info(const mc_partset* ps, uint64_t info[6]);
+/* all n reads (read i = seqs + offs[i] .. offs[i + 1]; seqs2 / offs2: the mates, NULL for single reads) against every part;
+ * out[n][max_candidates] in HOST memory; insert_max as -insertsize (maxWindowsInRange, candidate_structs.hpp:143-145) */
+int  mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n,
+                         int lowest_rank, uint64_t insert_max, mc_candidate* out);
+const char* mc_partset_last_error(const mc_partset* ps);
+
 /* Mode K.  Owner shard of a feature (independent of the table's own bucket hash). */
 uint32_t mc_key_owner(uint32_t feature, uint32_t shard_count);
 /* rows 8-10 on location lists that are already gathered (DEVICE pointers; query i = hits[hit_offsets[i] .. hit_offsets[i+1]),

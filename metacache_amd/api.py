@@ -54,7 +54,8 @@ class McDeviceResults(C.Structure):
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
 
 
-EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout",
+EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
+           "mc_partset_info", "mc_partset_classify", "mc_partset_last_error",
            "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
@@ -341,6 +342,53 @@ class Database:
         return dict(windows=int(st[0]), features=int(st[1]), locations=int(st[2]), found=int(st[3]), probe_steps=int(st[4]),
                     filtered_kept=int(st[5]), filtered_reads=int(st[6]) & 0xFFFFFFFF, filtered_over_512=int(st[6]) >> 32,
                     filter_second_kernel=int(st[7]) & 0xFFFFFFFF, filter_handed_back=int(st[7]) >> 32)
+
+
+class PartSet:
+    """A partitioned database, `resident` parts in HBM at a time (mc_partset_*): the next group of parts is loaded while the reads run
+    against this one, per-part candidates gathered over RCCL and merged on the device in part order."""
+
+    def __init__(self, name: str, resident: int = 0, devices=None, **kw):
+        L = lib()
+        L.mc_partset_open.argtypes = [C.c_char_p, C.POINTER(McConfig), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mc_partset_close.argtypes = [C.c_void_p]
+        L.mc_partset_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.mc_partset_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
+        L.mc_partset_last_error.argtypes = [C.c_void_p]
+        L.mc_partset_last_error.restype = C.c_char_p
+        self.cfg = default_config(**kw)
+        self.h = C.c_void_p()
+        dv = np.asarray(devices if devices is not None else [], dtype=np.int32)
+        rc = L.mc_partset_open(name.encode(), C.byref(self.cfg), resident, dv.ctypes.data if len(dv) else None, len(dv), C.byref(self.h))
+        if rc != 0:
+            raise McError(f"mc_partset_open({name}): {L.mc_partset_last_error(None).decode()} (rc {rc})")
+
+    def info(self) -> dict:
+        a = (C.c_uint64 * 6)()
+        lib().mc_partset_info(self.h, a)
+        return dict(parts=int(a[0]), resident=int(a[1]), groups=int(a[2]), devices=int(a[3]), load_s=a[4] / 1e9, wait_s=a[5] / 1e9)
+
+    def classify(self, reads, mates=None, lowest: int = 0, insert_max: int = 0) -> np.ndarray:
+        """reads / mates: lists of bytes -> cand_dtype [n, max_candidates]"""
+        def pack(rs):
+            offs = np.zeros(len(rs) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(r) for r in rs])
+            return np.frombuffer(b"".join(rs) + b"\0", dtype=np.uint8), offs
+        n = len(reads)
+        s1, o1 = pack(reads)
+        s2, o2 = pack(mates) if mates is not None else (None, None)
+        out = np.zeros((n, self.cfg.max_candidates), dtype=cand_dtype)
+        L = lib()
+        rc = L.mc_partset_classify(self.h, s1.ctypes.data, o1.ctypes.data, s2.ctypes.data if s2 is not None else None,
+                                   o2.ctypes.data if o2 is not None else None, n, lowest, insert_max, out.ctypes.data)
+        if rc != 0:
+            raise McError(f"mc_partset_classify: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().mc_partset_close(self.h)
+            self.h = C.c_void_p()
 
 
 class Builder:

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmetacache_amd.so")
-SOURCES = ["kernels.hip", "gw_kernels.hip", "gw_sort.hip", "table_build.hip", "context.cpp", "dbfile.cpp", "builder.hip"]
+SOURCES = ["kernels.hip", "gw_kernels.hip", "gw_sort.hip", "table_build.hip", "context.cpp", "dbfile.cpp", "builder.hip", "partset.cpp"]
 HEADERS = ["kernels.h", "device_common.h", "context.h", os.path.join(ROOT, "include", "metacache_amd.h")]
 ARCH = "gfx950"
 BINDIR = os.path.join(PKG, "bin")

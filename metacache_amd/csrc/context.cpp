@@ -873,6 +873,33 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     return MC_OK;
 }
 
+// Mode P / part groups: per-part candidate lists of the same reads (device pointers, [n][max_candidates] each, in part order) -> one list
+// per read, as if the parts had been queried one after the other with one candidate list (candidate_generation.hpp:172-231).  Target ids
+// must be the database's own (mc_open_database with single_part keeps them), lowest_rank > 0 uses this context's lineages.
+int mc_merge_part_candidates(mc_ctx* ctx, const mc_candidate* const* lists, uint32_t numLists, uint32_t n, int lowestRank, mc_candidate* out, void* streamv)
+{
+    if (!ctx || !lists || !out || numLists == 0) return MC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    const uint32_t* taxkey = nullptr;
+    int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
+    if (rc) return rc;
+    const uint32_t K = ctx->cfg.max_candidates;
+    // more than 16 lists: in rounds, the merged list of a round leads the next one (the insert is sequential anyway)
+    const void* ptrs[16];
+    uint32_t done = 0;
+    bool lead = false;
+    while (done < numLists) {
+        uint32_t m = 0;
+        if (lead) ptrs[m++] = out;
+        while (m < 16 && done < numLists) ptrs[m++] = lists[done++];
+        if (launch_merge_parts(ptrs, m, n, K, taxkey, out, st) != 0) return fail(ctx, MC_ERR_UNSUPPORTED, "mc_merge_part_candidates: max_candidates above 4");
+        lead = true;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return MC_OK;
+}
+
 // tuning / test hook: the switches the MC_* environment variables set at mc_create, changeable on a live context (no batch in flight)
 int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
 {

@@ -186,6 +186,8 @@ void launch_table_values_compact(const uint32_t* keys, const uint8_t* sizes, uin
 void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int quadMode, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, hipStream_t st);
+// up to 16 candidate lists per read ([n][K] each, device), merged in list order through the CPU's top-list insert; K <= 4.  -1: not supported
+int launch_merge_parts(const void* const* lists, uint32_t nlists, uint32_t n, uint32_t K, const uint32_t* taxkey, void* out, hipStream_t st);
 void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);
 // compact store: reads sketched and probed by the wave kernel join the filtered path's work list (list 6) where it can take them
 void launch_wave_rejoin(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);

@@ -2980,6 +2980,45 @@ void launch_wave_rejoin(const BatchView& b, const SketchParams& sp, const Device
     if (b.n && tab.values32) hipLaunchKernelGGL(wave_rejoin_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b, sp.s, tab, ws);
 }
 
+// Mode P / part groups: the per-part top lists of a read, fed IN PART ORDER through the CPU's list insert (candidate_generation.hpp:
+// 172-231) -- what querying the parts one after the other with one candidate list gives (host_hashmap.hpp:695-723 concatenates the
+// parts' sorted lists; a target belongs to one part, so per-part lists are what the scan of the concatenation yields).  One lane per read.
+struct PartLists { const mc_candidate_dev* p[16]; };
+__global__ __launch_bounds__(256) void merge_parts_kernel(PartLists L, uint32_t nlists, uint32_t n, uint32_t K, const uint32_t* __restrict__ taxkey,
+                                                          mc_candidate_dev* __restrict__ out)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    LaneCand top[kLaneK];
+    uint32_t toptax[kLaneK];
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
+    for (uint32_t l = 0; l < nlists; ++l) {
+        const mc_candidate_dev* c = L.p[l] + (size_t)q * K;
+        for (uint32_t j = 0; j < K; ++j) {
+            const mc_candidate_dev x = c[j];
+            if (x.hits == 0) break;
+            LaneCand lc; lc.tgt = x.tgt; lc.hits = x.hits; lc.beg = x.beg; lc.end = x.end;
+            top_insert(top, toptax, lc, K, taxkey, 0xFFFFFFFFu);
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i)
+        if (i < K) {
+            mc_candidate_dev e; e.tgt = top[i].hits ? top[i].tgt : 0xFFFFFFFFu; e.hits = top[i].hits; e.beg = top[i].beg; e.end = top[i].end;
+            out[(size_t)q * K + i] = e;
+        }
+}
+int launch_merge_parts(const void* const* lists, uint32_t nlists, uint32_t n, uint32_t K, const uint32_t* taxkey, void* out, hipStream_t st)
+{
+    if (nlists == 0 || nlists > 16 || K > kLaneK) return -1;
+    if (n == 0) return 0;
+    PartLists L{};
+    for (uint32_t i = 0; i < nlists; ++i) L.p[i] = (const mc_candidate_dev*)lists[i];
+    hipLaunchKernelGGL(merge_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, L, nlists, n, K, taxkey, (mc_candidate_dev*)out);
+    return 0;
+}
+
 // after the lane kernels: how many queries are left for the wave kernels (midCount[6]: to be sketched, [7]: candidates from a list in
 // HBM).  The host reads the eight counters once and launches only the kernels that have work -- a batch of 65 536 short reads spent
 // a fifth of its device time on launches of kernels with nothing to do.

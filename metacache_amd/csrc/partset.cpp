@@ -1,0 +1,330 @@
+// metacache_amd/csrc/partset.cpp -- a partitioned database queried PART GROUP BY PART GROUP, parts spread over the GPUs of the node
+// (C ABI: mc_partset_*, include/metacache_amd.h).
+//
+// What it replaces: (1) the reference's parts-over-GPUs query inside one process (gpu_hashmap.cu:1255-1290 query_hashtables_async over
+// the parts' tables, query_batch.cu:464-527 forwarding the sketches GPU -> GPU), (2) its documented workflow for databases that do not
+// fit the node (docs/partitioning.md:116-153: `query` one part at a time, `merge` the result files, mode_merge.cpp:247-296).
+// Here: `resident` parts are in HBM at a time, one context each (mc_open_database with single_part), dealt out round-robin over the
+// devices; while the reads run against group g a loader thread opens the parts of group g + 1 (their H2D copies and insert kernels
+// run on those contexts' own streams: two table slots, copy behind compute).  Per batch every device queries its parts, the
+// per-part top lists are gathered on device 0 with ncclAllGather (RCCL, one communicator rank per device; over xGMI between GPUs)
+// and merged IN PART ORDER by merge_parts_kernel -- the CPU's list insert, candidate_generation.hpp:172-231 -- together with the
+// list the earlier groups left for the read.  The result is what one candidate list fed by all parts in order holds: the intended
+// semantics of host_hashmap.hpp:695-723 (the in-process reference itself is history dependent for more than one part).
+//
+// RCCL is loaded at run time (dlopen librccl.so.1): the library has no link-time dependency on it, and a process that already carries
+// an RCCL (PyTorch) shares that one.
+#include "context.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace mcamd;
+
+namespace {
+
+// ---- the few RCCL entry points used (rccl.h: ncclResult_t = int, ncclComm_t = opaque pointer, ncclChar = 0)
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = "RCCL not found (librccl.so.1)"; return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("RCCL symbol missing: ") + n; return p; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather;
+    }
+};
+Rccl g_rccl;
+
+struct DevState {                      // per device: the batch's input, the parts' candidate lists, the gathered lists
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;
+    mc_candidate* dmine = nullptr;     // [slotsPerDev][maxQ][K]: this device's parts of the resident group
+    mc_candidate* dall = nullptr;      // [ndev][slotsPerDev][maxQ][K]: everybody's (device 0 merges)
+    mc_candidate* dprior = nullptr, *dout = nullptr;   // device 0: the earlier groups' list of the batch's reads, the merged one
+    void* comm = nullptr;
+};
+
+}  // namespace
+
+struct mc_partset {
+    std::string db, err;
+    mc_config cfg{};
+    uint32_t nparts = 0, resident = 1, K = 2, stride = 112;
+    std::vector<int> devices;
+    std::vector<DevState> dev;
+    uint32_t slotsPerDev = 1;
+    std::vector<mc_ctx*> cur, next;    // contexts of the resident group / of the group being loaded (part order)
+    uint32_t curFirst = 0, nextFirst = 0;
+    std::thread loader;
+    int loaderRc = MC_OK;
+    std::string loaderErr;
+    size_t maxQ = 0, maxChars = 0;
+    uint64_t loadNs = 0, waitNs = 0;   // time the loader spent / the queries waited for it
+};
+
+namespace {
+
+int ps_fail(mc_partset* ps, int code, const std::string& msg) { if (ps) ps->err = msg; else set_global_error(msg); return code; }
+
+uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+
+void close_group(std::vector<mc_ctx*>& g) { for (mc_ctx* c : g) if (c) mc_destroy(c); g.clear(); }
+
+// opens the parts [first, first + count) as one context each, part p on device devices[(p - first) % ndev]
+int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::string& err)
+{
+    const uint32_t count = std::min(ps->resident, ps->nparts - first);
+    out.assign(count, nullptr);
+    for (uint32_t i = 0; i < count; ++i) {
+        mc_config c = ps->cfg;
+        c.single_part = (int32_t)(first + i);
+        c.device = ps->devices[i % ps->devices.size()];
+        c.num_slots = 1; c.copy_allhits = 0;
+        const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
+        if (rc != MC_OK) { err = mc_last_error(nullptr); close_group(out); return rc; }
+    }
+    return MC_OK;
+}
+
+void start_loader(mc_partset* ps, uint32_t first)
+{
+    ps->nextFirst = first;
+    ps->loaderRc = MC_OK;
+    ps->loader = std::thread([ps, first] {
+        const uint64_t t0 = now_ns();
+        ps->loaderRc = open_group(ps, first, ps->next, ps->loaderErr);
+        ps->loadNs += now_ns() - t0;
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mc_partset_last_error(const mc_partset* ps) { return ps ? ps->err.c_str() : mc_last_error(nullptr); }
+
+int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentParts, const int32_t* devices, uint32_t numDevices, mc_partset** out)
+{
+    if (!name || !cfg || !out) return MC_ERR_INVALID;
+    *out = nullptr;
+    mc_ctx* meta = nullptr;
+    int rc = mc_open_metadata(name, &meta);
+    if (rc) return rc;
+    uint64_t info[8];
+    mc_db_info(meta, info);
+    mc_destroy(meta);
+    auto* ps = new mc_partset;
+    ps->db = name; ps->cfg = *cfg;
+    ps->nparts = (uint32_t)info[6];
+    ps->stride = (uint32_t)(info[3] ? info[3] : 112);
+    ps->K = cfg->max_candidates;
+    ps->resident = std::max<uint32_t>(1, std::min<uint32_t>(residentParts ? residentParts : ps->nparts, ps->nparts));
+    if (ps->K > 4) { delete ps; return ps_fail(nullptr, MC_ERR_UNSUPPORTED, "mc_partset_open: max_candidates above 4"); }
+    int ndevAvail = 0;
+    if (hipGetDeviceCount(&ndevAvail) != hipSuccess || ndevAvail < 1) { delete ps; return ps_fail(nullptr, MC_ERR_HIP, "no usable HIP device (this library has no CPU fallback)"); }
+    if (devices && numDevices) ps->devices.assign(devices, devices + numDevices); else ps->devices.assign(1, cfg->device);
+    for (size_t i = 0; i < ps->devices.size(); ++i) {
+        if (ps->devices[i] < 0 || ps->devices[i] >= ndevAvail) { delete ps; return ps_fail(nullptr, MC_ERR_INVALID, "mc_partset_open: device ordinal out of range"); }
+        for (size_t j = 0; j < i; ++j)
+            if (ps->devices[j] == ps->devices[i]) { delete ps; return ps_fail(nullptr, MC_ERR_INVALID, "mc_partset_open: a device is listed twice"); }
+    }
+    const uint32_t nd = (uint32_t)ps->devices.size();
+    ps->slotsPerDev = (ps->resident + nd - 1) / nd;
+    ps->maxQ = std::max<uint32_t>(cfg->slot_max_queries, 1);
+    ps->maxChars = std::max<uint32_t>(cfg->slot_max_chars, 1u << 16);
+    // RCCL: one communicator rank per device of this process (ncclCommInitAll), also for a single device -- the same calls run
+    if (!g_rccl.load()) { const std::string e = g_rccl.err; delete ps; return ps_fail(nullptr, MC_ERR_UNSUPPORTED, e); }
+    std::vector<void*> comms(nd, nullptr);
+    if (int r = g_rccl.CommInitAll(comms.data(), (int)nd, ps->devices.data())) {
+        const std::string e = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+        delete ps;
+        return ps_fail(nullptr, MC_ERR_HIP, e);
+    }
+    ps->dev.resize(nd);
+    const size_t listBytes = ps->maxQ * ps->K * sizeof(mc_candidate);
+    bool ok = true;
+    for (uint32_t d = 0; d < nd && ok; ++d) {
+        DevState& D = ps->dev[d];
+        D.device = ps->devices[d]; D.comm = comms[d];
+        ok = hipSetDevice(D.device) == hipSuccess && hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking) == hipSuccess &&
+             hipMalloc((void**)&D.dseq, ps->maxChars + 64) == hipSuccess && hipMalloc((void**)&D.dqinfo, ps->maxQ * 16) == hipSuccess &&
+             hipMalloc((void**)&D.dmaxwin, ps->maxQ * 4) == hipSuccess && hipMalloc((void**)&D.dmine, ps->slotsPerDev * listBytes) == hipSuccess &&
+             hipMalloc((void**)&D.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
+        if (ok && d == 0) ok = hipMalloc((void**)&D.dprior, listBytes) == hipSuccess && hipMalloc((void**)&D.dout, listBytes) == hipSuccess;
+    }
+    if (!ok) { mc_partset_close(ps); return ps_fail(nullptr, MC_ERR_NOMEM, "mc_partset_open: cannot allocate the batch buffers"); }
+    std::string err;
+    rc = open_group(ps, 0, ps->cur, err);
+    if (rc) { mc_partset_close(ps); return ps_fail(nullptr, rc, err); }
+    ps->curFirst = 0;
+    *out = ps;
+    return MC_OK;
+}
+
+void mc_partset_close(mc_partset* ps)
+{
+    if (!ps) return;
+    if (ps->loader.joinable()) ps->loader.join();
+    close_group(ps->cur); close_group(ps->next);
+    for (DevState& D : ps->dev) {
+        (void)hipSetDevice(D.device);
+        if (D.stream) (void)hipStreamSynchronize(D.stream);
+        void* bufs[] = {D.dseq, D.dqinfo, D.dmaxwin, D.dmine, D.dall, D.dprior, D.dout};
+        for (void* b : bufs) if (b) (void)hipFree(b);
+        if (D.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(D.comm);
+        if (D.stream) (void)hipStreamDestroy(D.stream);
+    }
+    delete ps;
+}
+
+int mc_partset_info(const mc_partset* ps, uint64_t info[6])
+{
+    if (!ps || !info) return MC_ERR_INVALID;
+    info[0] = ps->nparts; info[1] = ps->resident; info[2] = (ps->nparts + ps->resident - 1) / ps->resident; info[3] = ps->devices.size();
+    info[4] = ps->loadNs; info[5] = ps->waitNs;
+    return MC_OK;
+}
+
+// All n reads (pairs: mate i = seqs2 + offs2[i] .. offs2[i + 1]; seqs2 == NULL: single reads) against every part of the database.
+// out: [n][max_candidates] in host memory.
+int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n, int lowestRank,
+                        uint64_t insertMax, mc_candidate* out)
+{
+    if (!ps || !seqs || !offs || !out || (seqs2 && !offs2)) return MC_ERR_INVALID;
+    const uint32_t K = ps->K, nd = (uint32_t)ps->devices.size();
+    const size_t listBytes = ps->maxQ * K * sizeof(mc_candidate);
+    std::memset(out, 0, n * K * sizeof(mc_candidate));
+    for (uint64_t i = 0; i < n * K; ++i) out[i].tgt = 0xFFFFFFFFu;
+    // the batches: as many reads as fit the slot limits (a sequence starts 4-byte aligned, mc_batch_add)
+    struct Batch { uint64_t first, count, chars; };
+    std::vector<Batch> batches;
+    auto need = [&](uint64_t i) {
+        const uint64_t l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
+        return (l1 + 3) / 4 * 4 + (l2 + 3) / 4 * 4;
+    };
+    for (uint64_t i = 0; i < n;) {
+        Batch b{i, 0, 0};
+        while (i < n && b.count < ps->maxQ && b.chars + need(i) <= ps->maxChars) { b.chars += need(i); ++b.count; ++i; }
+        if (b.count == 0) return ps_fail(ps, MC_ERR_INVALID, "mc_partset_classify: a read is longer than slot_max_chars");
+        batches.push_back(b);
+    }
+    std::vector<uint8_t> hseq(ps->maxChars + 64);
+    std::vector<uint32_t> hq(ps->maxQ * 4), hmw(ps->maxQ);
+    // back to the first group if an earlier call left another one resident
+    if (ps->curFirst != 0) {
+        if (ps->loader.joinable()) ps->loader.join();
+        close_group(ps->next);
+        close_group(ps->cur);
+        std::string err;
+        int rc = open_group(ps, 0, ps->cur, err);
+        if (rc) return ps_fail(ps, rc, err);
+        ps->curFirst = 0;
+    }
+    for (uint32_t first = 0; first < ps->nparts; first += ps->resident) {
+        if (first != ps->curFirst) {                                // the loader has had the whole previous group's queries to get here
+            const uint64_t t0 = now_ns();
+            if (ps->loader.joinable()) ps->loader.join();
+            ps->waitNs += now_ns() - t0;
+            if (ps->loaderRc) return ps_fail(ps, ps->loaderRc, ps->loaderErr);
+            close_group(ps->cur);
+            ps->cur.swap(ps->next);
+            ps->curFirst = first;
+        }
+        if (first + ps->resident < ps->nparts) start_loader(ps, first + ps->resident);   // the next group loads behind this group's queries
+        const uint32_t np = (uint32_t)ps->cur.size();
+        for (const Batch& B : batches) {
+            const uint32_t m = (uint32_t)B.count;
+            uint64_t at = 0;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint64_t i = B.first + j, l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
+                hq[4 * j] = (uint32_t)at; hq[4 * j + 1] = (uint32_t)l1;
+                if (l1) std::memcpy(hseq.data() + at, seqs + offs[i], l1);
+                at += (l1 + 3) / 4 * 4;
+                hq[4 * j + 2] = (uint32_t)at; hq[4 * j + 3] = (uint32_t)l2;
+                if (l2) std::memcpy(hseq.data() + at, seqs2 + offs2[i], l2);
+                at += (l2 + 3) / 4 * 4;
+                hmw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ps->stride);   // candidate_structs.hpp:143-145
+            }
+            // every device: the batch, then its parts of the group, their top lists side by side in dmine
+            std::vector<int> rcs(nd, MC_OK);
+            std::vector<std::string> errs(nd);
+            auto run_device = [&](uint32_t d) {
+                DevState& D = ps->dev[d];
+                if (hipSetDevice(D.device) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipSetDevice"; return; }
+                (void)hipMemcpyAsync(D.dseq, hseq.data(), at + 16, hipMemcpyHostToDevice, D.stream);
+                (void)hipMemcpyAsync(D.dqinfo, hq.data(), (size_t)m * 16, hipMemcpyHostToDevice, D.stream);
+                (void)hipMemcpyAsync(D.dmaxwin, hmw.data(), (size_t)m * 4, hipMemcpyHostToDevice, D.stream);
+                (void)hipMemsetAsync(D.dmine, 0, ps->slotsPerDev * listBytes, D.stream);     // slots without a part: empty lists (hits = 0)
+                uint32_t slot = 0;
+                for (uint32_t p = d; p < np; p += nd, ++slot) {
+                    mc_device_batch in{D.dseq, D.dqinfo, D.dmaxwin, 0, m, at};
+                    mc_device_results res{};
+                    int rc = mc_query_device(ps->cur[p], &in, lowestRank, 0, &res, D.stream);
+                    if (!rc) rc = mc_copy_results_on(ps->cur[p], reinterpret_cast<char*>(D.dmine) + slot * listBytes, res.cands, (uint64_t)m * K * sizeof(mc_candidate), 0, D.stream);
+                    if (rc) { rcs[d] = rc; errs[d] = mc_last_error(ps->cur[p]); return; }
+                }
+            };
+            if (nd == 1) run_device(0);
+            else {
+                std::vector<std::thread> th;
+                for (uint32_t d = 0; d < nd; ++d) th.emplace_back(run_device, d);
+                for (auto& t : th) t.join();
+            }
+            for (uint32_t d = 0; d < nd; ++d) if (rcs[d]) return ps_fail(ps, rcs[d], errs[d]);
+            // per-rank partial lists gathered over RCCL: every rank's slotsPerDev lists -> dall[rank][slot] on every device
+            g_rccl.GroupStart();
+            for (uint32_t d = 0; d < nd; ++d) {
+                DevState& D = ps->dev[d];
+                (void)hipSetDevice(D.device);
+                if (int r = g_rccl.AllGather(D.dmine, D.dall, ps->slotsPerDev * listBytes, /*ncclChar*/ 0, D.comm, D.stream)) {
+                    g_rccl.GroupEnd();
+                    return ps_fail(ps, MC_ERR_HIP, std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+                }
+            }
+            if (int r = g_rccl.GroupEnd()) return ps_fail(ps, MC_ERR_HIP, std::string("ncclGroupEnd: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+            // device 0: the earlier groups' list of these reads first, then this group's parts in part order (part p: rank p % nd, slot p / nd)
+            DevState& D0 = ps->dev[0];
+            if (hipSetDevice(D0.device) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipSetDevice");
+            std::vector<const mc_candidate*> lists;
+            if (first != 0) {
+                (void)hipMemcpyAsync(D0.dprior, out + B.first * K, (size_t)m * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D0.stream);
+                lists.push_back(D0.dprior);
+            }
+            for (uint32_t p = 0; p < np; ++p)
+                lists.push_back(reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(D0.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes));
+            int rc = mc_merge_part_candidates(ps->cur[0], lists.data(), (uint32_t)lists.size(), m, lowestRank, D0.dout, D0.stream);
+            if (rc) return ps_fail(ps, rc, mc_last_error(ps->cur[0]));
+            if (hipMemcpyAsync(out + B.first * K, D0.dout, (size_t)m * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, D0.stream) != hipSuccess ||
+                hipStreamSynchronize(D0.stream) != hipSuccess)
+                return ps_fail(ps, MC_ERR_HIP, "copy of the merged candidates failed");
+            for (uint32_t d = 1; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
+        }
+    }
+    return MC_OK;
+}
+
+}  // extern "C"
