@@ -41,6 +41,9 @@ struct Options {
     std::string comment = "# ", none = "--", column = "\t|\t", taxSep = ",", rankSuffix = ":", idPrefix = "(", idSuffix = ")";
     bool showQueryParams = true, showSummary = true, showErrors = true, splitOut = false;
     uint32_t sketchlen = 0, winlen = 0, winstride = 0, batchSize = 1u << 16;
+    uint32_t residentParts = 0;          // -resident-parts n (this program's own): a partitioned database n parts at a time, the next group loading behind
+                                         // the queries (mc_partset_*; the reference's workflow: one query run per part + merge, docs/partitioning.md:116-153)
+    std::vector<int32_t> gpus;           // -gpus a,b,...: the resident parts dealt out over these GPUs, per-part candidates gathered over RCCL
     uint32_t replication = 1;            // -replicate: copies of the table on GPUs 0 .. n-1, the workers are dealt out over them (options.cpp:1155-1163)
     uint32_t refBatchSize = 0;           // -batch-size as given (the reference's batches matter for -cov-percentile)
     int maxLocs = -1, threads = 0;
@@ -123,6 +126,11 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-no-err" || a == "-no-errors") o.showErrors = false;
         else if (a == "-threads") o.threads = std::stoi(need(i));
         else if (a == "-replicate") o.replication = (uint32_t)std::max(1, std::stoi(need(i)));
+        else if (a == "-resident-parts") o.residentParts = (uint32_t)std::max(1, std::stoi(need(i)));
+        else if (a == "-gpus") {
+            std::stringstream ss(need(i));
+            for (std::string t; std::getline(ss, t, ',');) if (!t.empty()) o.gpus.push_back((int32_t)std::stoi(t));
+        }
         else if (a == "-batch-size" || a == "-batchsize") { o.batchSize = (uint32_t)std::stoul(need(i)); o.refBatchSize = o.batchSize; }
         else throw std::runtime_error("unknown option '" + a + "'");
     }
@@ -313,9 +321,10 @@ struct Session {
     unsigned threads = 1, workers = 1;
     std::vector<mc_ctx*> replicas;                   // -replicate n: the same table on the GPUs 1 .. n-1 (ctx is the one on GPU 0)
     uint32_t replication = 1;
+    mc_partset* partset = nullptr;                   // -resident-parts / -gpus: the parts as contexts of their own (ctx then holds the metadata only)
     mc_ctx* replica(unsigned i) const { return i == 0 ? ctx : replicas[i - 1]; }
     void close_replicas() { for (mc_ctx* r : replicas) mc_destroy(r); replicas.clear(); }
-    ~Session() { close_replicas(); if (ctx) mc_destroy(ctx); }
+    ~Session() { close_replicas(); if (partset) mc_partset_close(partset); if (ctx) mc_destroy(ctx); }
 
     BuiltDatabase* built = nullptr;                  // build+query: the table comes from the builder's device arrays, not from files
     std::vector<uint32_t> builtLineages;
@@ -350,12 +359,30 @@ struct Session {
             c.remove_overpopulated = (uint32_t)maxlpf;                             // clamped to the DB's cap - 1 by mc_open_database
             c.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
         } else if (o.maxLocs > 1) c.max_locations_per_feature = (uint32_t)o.maxLocs;
-        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0 && replication == nrep) return;  // same table, same slots: keep it
+        const bool wantSet = !built && (o.residentParts > 0 || !o.gpus.empty());
+        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0 && replication == nrep && !wantSet && !partset) return;  // same table, same slots: keep it
         close_replicas();
+        if (partset) { mc_partset_close(partset); partset = nullptr; }
         if (ctx) { mc_destroy(ctx); ctx = nullptr; }
         replication = nrep;
         tx = Taxonomy{};
-        if (built) {
+        if (wantSet) {
+            if (o.allhits || o.maxCand < 1 || o.maxCand > 4 || o.covPercentile > 0)
+                throw std::runtime_error("-resident-parts / -gpus: top candidates only (-maxcand 1..4, no -allhits, no -cov-percentile)");
+            c.num_slots = 1;
+            c.slot_max_queries = std::max<uint32_t>(o.batchSize, 1u << 16);
+            c.slot_max_chars = std::max<uint32_t>(1u << 24, c.slot_max_queries * 320u);
+            if (mc_partset_open(o.db.c_str(), &c, o.residentParts, o.gpus.empty() ? nullptr : o.gpus.data(), (uint32_t)o.gpus.size(), &partset) != MC_OK)
+                throw std::runtime_error(mc_partset_last_error(nullptr));
+            if (mc_open_metadata(o.db.c_str(), &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
+            uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
+            for (uint64_t i = 0; i < nt; ++i) {
+                uint32_t rk; const char* nm;
+                mc_db_taxon(ctx, i, &tx.taxa[i].id, &tx.taxa[i].parent, &rk, &nm);
+                tx.taxa[i].rank = int(rk); tx.taxa[i].name = nm;
+                mc_db_taxon_source(ctx, i, nullptr, nullptr, &tx.taxa[i].windows);
+            }
+        } else if (built) {
             // add_to_database_and_query (mode_build_query.cpp:41-77): a query context over the builder's arrays
             for (mc_builder* b : built->bs) if (mc_build_set_query_config(b, &c) != MC_OK) throw std::runtime_error(mc_build_last_error(b));
             if (mc_build_finish_shards(built->bs.data(), (uint32_t)built->bs.size(), &ctx) != MC_OK)
@@ -771,7 +798,74 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::lock_guard<std::mutex> l(errMtx);
             collect(A);
         };
-        {
+        // -resident-parts / -gpus: the database's parts are queried group by group (mc_partset_classify loops groups outside, reads
+        // inside), so ALL reads are collected first, classified in one call, then classified / printed batch by batch as above
+        auto work_partset = [&]() {
+            struct Meta { uint64_t id; std::string header; bool empty; size_t batch; bool skipped; };
+            std::vector<Meta> metas;
+            std::string seq1, seq2, scratch1, scratch2;
+            std::vector<uint64_t> off1{0}, off2{0};
+            const bool paired = o.pairing != Options::unpaired;
+            for (size_t b = 0; b < batches.size(); ++b) {
+                const Batch& B = batches[b];
+                for (size_t q = B.qBeg; q < B.qEnd; ++q) {
+                    View h1, s1, h2, s2;
+                    const size_t qi = B.sel ? (size_t)(*B.sel)[q] : q;
+                    if (o.pairing == Options::sequences) {
+                        files[B.f1]->record(2 * qi, h1, s1, scratch1);
+                        if (!(B.halfLast && q + 1 == B.qEnd)) files[B.f1]->record(2 * qi + 1, h2, s2, scratch2);
+                    } else {
+                        files[B.f1]->record(qi, h1, s1, scratch1);
+                        if (o.pairing == Options::files) files[B.f2]->record(qi, h2, s2, scratch2);
+                    }
+                    const bool halfPair = B.halfLast && q + 1 == B.qEnd;
+                    const bool tooBig = s1.n + s2.n + 8 > cfg.slot_max_chars;
+                    if (tooBig) { std::cerr << "query batch is too small for a single read!\n"; continue; }
+                    metas.push_back(Meta{B.idBase + qi + (halfPair ? 0 : 1), std::string(h1.p, h1.n), h1.empty() || s1.empty(), b, false});
+                    seq1.append(s1.p, s1.n); off1.push_back(seq1.size());
+                    if (paired) { seq2.append(s2.p, s2.n); off2.push_back(seq2.size()); }
+                }
+            }
+            const size_t n = metas.size();
+            const uint32_t K = cfg.max_candidates;
+            std::vector<mc_candidate> all(n * K);
+            seq1.push_back('\0'); seq2.push_back('\0');
+            if (n && mc_partset_classify(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                         o.insertMax, all.data()) != MC_OK)
+                throw std::runtime_error(mc_partset_last_error(S.partset));
+            Acc A;
+            std::vector<Cand> cands;
+            std::ostringstream out;
+            size_t i = 0;
+            for (size_t b = 0; b < batches.size(); ++b) {
+                out.str(std::string());
+                out << batches[b].prefix;
+                for (; i < n && metas[i].batch == b; ++i) {
+                    const Meta& m = metas[i];
+                    if (m.empty) continue;
+                    cands.clear();
+                    for (uint32_t j = 0; j < K; ++j) {
+                        const mc_candidate& c = all[i * K + j];
+                        if (c.hits == 0) break;
+                        Cand x{c.tgt, c.hits, c.beg, c.end, 0};
+                        if (c.tgt < tx.numTargets) {
+                            const uint32_t* lin = tx.targetLineages + (size_t)c.tgt * kNumRanks;
+                            if (o.lowest > 0) { for (int rk = o.lowest; rk < kNumRanks; ++rk) if (lin[rk]) { x.tax = lin[rk]; break; } }
+                            else x.tax = lin[0];
+                        }
+                        cands.push_back(x);
+                    }
+                    emit(A, out, m.id, View{m.header.data(), m.header.size()}, cands, nullptr, 0);
+                }
+                deliver(b, out.str());
+            }
+            collect(A);
+        };
+        if (S.partset) {
+            produce();                                                           // (all batches known first: no overlap to win here)
+            if (!producerError.empty()) throw std::runtime_error(producerError);
+            work_partset();
+        } else {
             std::thread producer(produce);
             std::vector<std::thread> pool;
             for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work, w);

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -84,6 +85,7 @@ struct mc_partset {
     std::string loaderErr;
     size_t maxQ = 0, maxChars = 0;
     uint64_t loadNs = 0, waitNs = 0;   // time the loader spent / the queries waited for it
+    bool rccl = false;                 // several devices (or MC_PARTSET_RCCL=1: the same calls with a single rank, tests): gather over RCCL
 };
 
 namespace {
@@ -156,13 +158,18 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     ps->slotsPerDev = (ps->resident + nd - 1) / nd;
     ps->maxQ = std::max<uint32_t>(cfg->slot_max_queries, 1);
     ps->maxChars = std::max<uint32_t>(cfg->slot_max_chars, 1u << 16);
-    // RCCL: one communicator rank per device of this process (ncclCommInitAll), also for a single device -- the same calls run
-    if (!g_rccl.load()) { const std::string e = g_rccl.err; delete ps; return ps_fail(nullptr, MC_ERR_UNSUPPORTED, e); }
+    // RCCL: one communicator rank per device of this process (ncclCommInitAll).  A single device needs no gather (loading and
+    // initialising RCCL takes a stand-alone process 25 s); MC_PARTSET_RCCL=1 runs the same calls with one rank (tests)
+    const char* force = std::getenv("MC_PARTSET_RCCL");
+    ps->rccl = nd > 1 || (force && force[0] == '1');
     std::vector<void*> comms(nd, nullptr);
-    if (int r = g_rccl.CommInitAll(comms.data(), (int)nd, ps->devices.data())) {
-        const std::string e = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
-        delete ps;
-        return ps_fail(nullptr, MC_ERR_HIP, e);
+    if (ps->rccl) {
+        if (!g_rccl.load()) { const std::string e = g_rccl.err; delete ps; return ps_fail(nullptr, MC_ERR_UNSUPPORTED, e); }
+        if (int r = g_rccl.CommInitAll(comms.data(), (int)nd, ps->devices.data())) {
+            const std::string e = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+            delete ps;
+            return ps_fail(nullptr, MC_ERR_HIP, e);
+        }
     }
     ps->dev.resize(nd);
     const size_t listBytes = ps->maxQ * ps->K * sizeof(mc_candidate);
@@ -296,6 +303,10 @@ int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, 
             }
             for (uint32_t d = 0; d < nd; ++d) if (rcs[d]) return ps_fail(ps, rcs[d], errs[d]);
             // per-rank partial lists gathered over RCCL: every rank's slotsPerDev lists -> dall[rank][slot] on every device
+            if (!ps->rccl) {
+                (void)hipSetDevice(ps->dev[0].device);
+                (void)hipMemcpyAsync(ps->dev[0].dall, ps->dev[0].dmine, ps->slotsPerDev * listBytes, hipMemcpyDeviceToDevice, ps->dev[0].stream);
+            } else {
             g_rccl.GroupStart();
             for (uint32_t d = 0; d < nd; ++d) {
                 DevState& D = ps->dev[d];
@@ -306,6 +317,7 @@ int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, 
                 }
             }
             if (int r = g_rccl.GroupEnd()) return ps_fail(ps, MC_ERR_HIP, std::string("ncclGroupEnd: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+            }
             // device 0: the earlier groups' list of these reads first, then this group's parts in part order (part p: rank p % nd, slot p / nd)
             DevState& D0 = ps->dev[0];
             if (hipSetDevice(D0.device) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipSetDevice");

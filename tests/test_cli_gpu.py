@@ -197,3 +197,36 @@ def test_cli_fails_loudly_without_gpu_or_db(tmp_path):
     assert r.returncode != 0 and "ABORT" in r.stderr
     r = subprocess.run([build.MCQ, "query", "toy32", "cli_reads.fa", "-bogus"], cwd=GOLD, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "unknown option" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["default", "hitdiff_percent", "pairseq_insert", "mapped_only_vote", "hits_per_ref_lineage", "two_files", "precision"])
+def test_cli_resident_parts_single_part_equals_reference(tmp_path, case):
+    """-resident-parts / -gpus (mc_partset_*: parts as contexts of their own, candidates gathered over RCCL, merged on the device): on
+    the single-part toy database the output must be the reference's, line by line."""
+    build.build_library()
+    c = CASES[case]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-resident-parts", "1", "-gpus", "0", "-out", str(out)]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    unordered = "hits_per_ref" in case
+    got = [l for l in out.read_text().split("\n") if not _volatile(l) and "threads" not in l]
+    exp = [l for l in c["lines"] if not _volatile(l) and "threads" not in l]
+    assert (sorted(got) == sorted(exp)) if unordered else (got == exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resident", [1, 2, 3])
+def test_cli_resident_parts_equal_all_parts_resident(tmp_path, resident):
+    """the four-part fixture, `resident` parts in HBM at a time: the same output as with every part in one table"""
+    build.build_library()
+    args = ["cli_reads.fa", "cli_pairs.fq", "-tophits", "-queryids", "-lowest", "species", "-maxcand", "3"]
+    outs = []
+    env = dict(os.environ, MC_PARTSET_RCCL="1") if resident == 2 else None     # once through RCCL from the stand-alone program (25 s of RCCL start-up)
+    for extra in ([], ["-resident-parts", str(resident)]):
+        out = tmp_path / f"out{len(outs)}.txt"
+        r = subprocess.run([build.MCQ, "query", "toy32p4"] + args + extra + ["-out", str(out)], cwd=GOLD, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append([l for l in out.read_text().split("\n") if not _volatile(l) and "threads" not in l])
+    assert outs[0] == outs[1] and len(outs[0]) > 500

@@ -24,7 +24,8 @@ def _eq(got, exp, K, tag):
 
 
 @pytest.mark.parametrize("resident,lowest,K", [(2, 0, 2), (2, 4, 3), (1, 0, 2), (3, 4, 2), (4, 0, 4), (0, 6, 2)])
-def test_part_groups_equal_intended_multipart(golden, resident, lowest, K):
+def test_part_groups_equal_intended_multipart(golden, resident, lowest, K, monkeypatch):
+    monkeypatch.setenv("MC_PARTSET_RCCL", "1")                   # one GPU: the RCCL calls run with a single rank (several devices: always)
     single, p1, p2 = golden.reads()
     name = golden.db_path("toy32p4")
     odb = cpuref.oracle().open(name)
