@@ -1,0 +1,110 @@
+"""End-to-end `query` at RefSeq-like scale (kernel-only AND end-to-end): a cut of the bench collection (--scale 0.2: 8 000
+targets, 30 Gbp, 4.3 x 10^9 locations) is built on the GPU and written as database files to /dev/shm by the streaming writer; 10^7
+synthetic 150 bp reads go to a FASTA file; then `mcq query` (this repository, MI355X) and the reference's own command line
+(oracle/_ref/metacache_u32, all granted host threads) run on the SAME files: database load time, query time, Mreads/min, and the
+`-tophits -queryids` mapping lines of a sample diffed.  Never bench.py's `value`: parsing, PCIe, classification and printing included.
+
+    python tools/e2e_scale.py --scale 0.2 --reads 10000000 --out gpurun_out/e2e_scale02.json"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+import e2e_bench  # noqa: E402
+from metacache_amd import build, synthdb  # noqa: E402
+
+
+def timed(cmd, env=None):
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    if r.returncode != 0:
+        raise RuntimeError(" ".join(cmd) + "\n" + r.stderr[-2000:])
+    prof = [l for l in r.stderr.splitlines() if l.startswith("mcq profile")]
+    return time.perf_counter() - t0, prof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=0.2)
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--cpu-reads", type=int, default=400_000)
+    ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    build.build_library()
+    import scale_util
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    db = os.path.join(shm, f"mc_e2e_{os.getpid()}")
+    fa, fa_small, o, oref = db + "_reads.fa", db + "_small.fa", db + "_o.txt", db + "_oref.txt"
+    res = {"scale": args.scale, "reads": args.reads, "host_cpus_granted": scale_util.effective_cpus()}
+    try:
+        c2 = dict(bench.CFG2); c2["genera"] = max(2, int(round(c2["genera"] * args.scale)))
+        spec = synthdb.phylogeny(**c2)
+        shards = max(1, int(np.ceil(spec.total_bases // 112 * 16 / 1.4e9)))
+        t0 = time.time()
+        gdb, info = synthdb.build_database(spec, shards=shards, max_candidates=2, write_to=db, report=lambda m: print(m, file=sys.stderr, flush=True))
+        res["collection"] = {"targets": len(spec.targets), "bases": int(spec.total_bases), "locations": int(gdb.info()[7]),
+                             "database_file_bytes": sum(os.path.getsize(db + e) for e in (".meta", ".cache0")), "build_and_write_s": round(time.time() - t0, 1)}
+        gdb.close()
+        gen = synthdb.GpuSynth(0)
+        P = synthdb.read_params(spec, 3100)
+        with open(fa, "wb"):
+            pass
+        done = 0
+        while done < args.reads:
+            m = min(2_000_000, args.reads - done)
+            rows = torch.zeros((m, P.row_bytes), dtype=torch.uint8, device="cuda:0")
+            gen.reads(spec, P, done, m, rows)
+            host = rows.cpu().numpy()[:, :150]
+            tmpf = fa + ".part"
+            e2e_bench.write_fasta(tmpf, host)
+            if done == 0:
+                e2e_bench.write_fasta(fa_small, host[: args.cpu_reads])
+            with open(fa, "ab") as dst, open(tmpf, "rb") as src:
+                dst.write(src.read())
+            os.remove(tmpf)
+            done += m
+        del rows
+        torch.cuda.empty_cache()
+        res["fasta_bytes"] = os.path.getsize(fa)
+        mcq = build.MCQ
+        env = dict(os.environ, MCQ_PROFILE="1")
+        for name, extra in (("mcq_nomap", ["-no-map"]), ("mcq_map", []), ("mcq_tophits_ids", ["-tophits", "-queryids"])):
+            wall, prof = timed([mcq, "query", db, fa] + extra + ["-out", o], env=env)
+            q, ms = e2e_bench.speed_of(o)
+            res[name] = {"wall_s": round(wall, 2), "query_ms": ms, "database_load_and_startup_s": round(wall - ms / 1e3, 2),
+                         "Mreads_per_min_query_phase": round(q / (ms / 1e3) * 60 / 1e6, 1), "Mreads_per_min_wall": round(q / wall * 60 / 1e6, 1), "profile": prof}
+            print(name, res[name], flush=True)
+        ref = os.path.join(ROOT, "oracle", "_ref", "metacache_u32")
+        if os.path.exists(ref) and not args.no_ref:
+            wall, _ = timed([ref, "query", db, fa, "-no-map", "-out", oref])
+            q, ms = e2e_bench.speed_of(oref)
+            res["reference_cpu_nomap"] = {"wall_s": round(wall, 2), "query_ms": ms, "database_load_and_startup_s": round(wall - ms / 1e3, 2),
+                                          "Mreads_per_min_query_phase": round(q / (ms / 1e3) * 60 / 1e6, 2), "Mreads_per_min_wall": round(q / wall * 60 / 1e6, 2)}
+            print("reference", res["reference_cpu_nomap"], flush=True)
+            timed([ref, "query", db, fa_small, "-tophits", "-queryids", "-out", oref])
+            timed([mcq, "query", db, fa_small, "-tophits", "-queryids", "-out", o])
+            a = sorted(l for l in open(oref) if not l.startswith("#"))
+            b = sorted(l for l in open(o) if not l.startswith("#"))
+            res["identical_mapping_lines"] = {"reference": len(a), "mcq": len(b), "differing": sum(x != y for x, y in zip(a, b)) + abs(len(a) - len(b))}
+    finally:
+        for f in (db + ".meta", db + ".cache0", fa, fa_small, o, oref, fa + ".part"):
+            if os.path.exists(f):
+                os.remove(f)
+    print(json.dumps(res, indent=1))
+    if args.out:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
