@@ -43,13 +43,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     v += dpp_mov<0x140>(v);
     return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
 }
+// inclusive prefix sum over the wave in DPP moves (row shifts inside the rows of 16, then the row sums broadcast down): no LDS
+// round trips (the __shfl_up form is six ds_bpermute).  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += o;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 // orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote).

@@ -126,12 +126,14 @@ __device__ __forceinline__ void gw_fill_rounds(uint64_t* T, uint32_t lane, uint3
 }
 // the batch's numbers: 16 bytes per lane and load, four lanes per round; places without a round read as kGwNone
 template <bool ALIGN_TEST = false>
-__device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads])
+__device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads],
+                                               uint32_t nl = kGwLoads)   // nl: loads of this batch that have rounds at all (wave-uniform: the others are skipped)
 {
 #pragma unroll
     for (uint32_t u = 0; u < kGwLoads; ++u) {
-        const uint64_t rd = T[u * 16 + grp];
         x[u] = make_uint4(kGwNone, kGwNone, kGwNone, kGwNone);
+        if (u >= nl) continue;
+        const uint64_t rd = T[u * 16 + grp];
         if (sub4 < (uint32_t)(rd >> 40)) {
             const U4 t = *reinterpret_cast<const U4*>(values32 + ((rd & 0xFFFFFFFFFFull) & (ALIGN_TEST ? ~3ull : ~0ull)) + sub4);
             x[u] = make_uint4(t.x, t.y, t.z, t.w);
@@ -141,11 +143,11 @@ __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t
 // phase A on a batch: every place of the loaded lines marks its block (places past a list's end hold other lists' numbers: more
 // marks, never fewer)
 template <class Bloom>
-__device__ __forceinline__ void gw_mark_rounds(uint32_t* bits, const uint4 (&x)[kGwLoads], uint32_t A)
+__device__ __forceinline__ void gw_mark_rounds(uint32_t* bits, const uint4 (&x)[kGwLoads], uint32_t A, uint32_t nl = kGwLoads)
 {
 #pragma unroll
     for (uint32_t u = 0; u < kGwLoads; ++u)                    // (lanes without a round hold kGwNone: sixty-four of them on ONE filter word would take turns)
-        if (x[u].x != kGwNone) Bloom::mark4(bits, x[u].x >> A, x[u].y >> A, x[u].z >> A, x[u].w >> A);
+        if (u < nl && x[u].x != kGwNone) Bloom::mark4(bits, x[u].x >> A, x[u].y >> A, x[u].z >> A, x[u].w >> A);
 }
 // phase B: a number is kept if its block was marked twice or it lies within D of a block boundary; the kept ones are appended to dst
 // (ballot compaction), n2 counts them whether they fit or not
@@ -195,10 +197,11 @@ __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F,
 }
 template <class Bloom, bool CHECK>
 __device__ __forceinline__ void gw_take_rounds(const uint32_t* bits, const uint64_t* T, const GwFrame& F, GwSink& S, uint32_t grp, uint32_t sub4,
-                                               const uint4 (&x)[kGwLoads])
+                                               const uint4 (&x)[kGwLoads], uint32_t nl = kGwLoads)
 {
 #pragma unroll
     for (uint32_t u = 0; u < kGwLoads; ++u) {
+        if (u >= nl) continue;
         const int32_t rem = (int32_t)(uint32_t)(T[u * 16 + grp] >> 40) - (int32_t)sub4;     // numbers of the round from this lane's first on
         gw_take4<Bloom, CHECK>(bits, F, S, x[u], rem);
     }
@@ -269,11 +272,12 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
         gw_fill_rounds(T, lane, 0, Rc, incl - myR, myR, sz, pay);
         wave_lds_sync();
         const GwFrame F(maxWin);
+        const uint32_t nl = (Rc + 15u) >> 4;                        // (26 lists of 49 numbers: 104 rounds = 7 of the 8 loads)
         uint4 x[kGwLoads];
         if constexpr (DIAG == 3) {
 #pragma unroll
             for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = make_uint4(lane * 977u + u * 13u + w, lane * 7717u + u + q, (lane ^ u) * 40503u + w, lane * 31u + u * 5u + q * 3u);
-        } else gw_load_rounds<DIAG == 1>(T, tab.values32, grp, sub4, x);
+        } else gw_load_rounds<DIAG == 1>(T, tab.values32, grp, sub4, x, nl);
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;     // single locations live in their buckets in the 8-byte form
         GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
         if constexpr (DIAG == 2) {
@@ -284,11 +288,11 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
         } else {
         // ---- A
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
-        gw_mark_rounds<Bloom>(bits, x, F.A);
+        gw_mark_rounds<Bloom>(bits, x, F.A, nl);
         wave_lds_sync();
         // ---- B
         gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-        gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
+        gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
         }
         const bool fallback = S.n2 > S.room;                       // longer than what is handed on, or the slice is full
         if (lane == 0) {
@@ -399,30 +403,52 @@ __global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_kerne
 // One atomic per class and 64 records.
 __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t n, uint32_t stage)
 {
+    // a block takes a contiguous stretch of the records: it counts its members of every class first, reserves their places with ONE
+    // atomic per class (78 000 atomics on one counter -- one per 64 records -- took 0.4 ms), then writes them in record order
+    __shared__ uint32_t cnt[4][4], base[4];
     const uint32_t total = ws.midCount[9];
-    const uint4* __restrict__ rec6 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * n;
     const uint4* __restrict__ rec7 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (total + 63u) / 64u * 64u; i += gridDim.x * 256) {
-        const bool inb = i < total;
-        uint32_t cls = 4;
-        if (inb) {
-            if (stage == 0) { if (rec7[i].z == kGwDefer) cls = 0; }
-            else {
-                const uint4 r = rec7[i];
-                if (gw_sorted_class(r.z, r.w)) cls = 3;
-                else if (r.z <= kBigMaxFilteredCount && r.w <= kHashWin) cls = r.z > 512u ? 2u : r.z > 256u ? 1u : 4u;
-            }
-        }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t per = ((total + gridDim.x - 1) / gridDim.x + 255u) / 256u * 256u;          // records per block, whole 256-record steps
+    const uint32_t lo = blockIdx.x * per, hi = min(total, lo + per);
+    auto class_of = [&](uint32_t i) -> uint32_t {
+        if (i >= hi) return 4u;
+        const uint4 r = rec7[i];
+        if (stage == 0) return r.z == kGwDefer ? 0u : 4u;
+        if (gw_sorted_class(r.z, r.w)) return 3u;
+        if (r.z <= kBigMaxFilteredCount && r.w <= kHashWin) return r.z > 512u ? 2u : r.z > 256u ? 1u : 4u;
+        return 4u;
+    };
+    uint32_t mine[4] = {0, 0, 0, 0};
+    for (uint32_t i = lo + threadIdx.x; i < lo + per && lo < hi; i += 256) {
+        const uint32_t c = class_of(i);
 #pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
-            const uint64_t m = __ballot(cls == c);
-            if (m == 0) continue;
-            const uint32_t leader = __ffsll((unsigned long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&ws.midCount[c == 0 ? 12u : c == 1 ? 14u : c == 2 ? 15u : 13u], (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (cls == c) ws.sideList[(size_t)c * n + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        for (uint32_t k = 0; k < 4; ++k) mine[k] += (uint32_t)__popcll(__ballot(c == k));       // (wave-uniform counts)
+    }
+    if (lane == 0) { for (uint32_t k = 0; k < 4; ++k) cnt[wave][k] = mine[k]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t k = threadIdx.x, tot = cnt[0][k] + cnt[1][k] + cnt[2][k] + cnt[3][k];
+        base[k] = tot ? atomicAdd(&ws.midCount[k == 0 ? 12u : k == 1 ? 14u : k == 2 ? 15u : 13u], tot) : 0u;
+    }
+    __syncthreads();
+    // second pass: step s of the block holds records lo + s * 256 .. ; within a step the waves' members follow each other
+    uint32_t run[4] = {base[0], base[1], base[2], base[3]};
+    for (uint32_t i0 = lo; i0 < lo + per && lo < hi; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t c = class_of(i);
+        uint64_t m[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) m[k] = __ballot(c == k);
+        __syncthreads();
+        if (lane == 0) { for (uint32_t k = 0; k < 4; ++k) cnt[wave][k] = (uint32_t)__popcll(m[k]); }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint32_t before = 0, all = 0;
+            for (uint32_t w = 0; w < 4; ++w) { before += w < wave ? cnt[w][k] : 0u; all += cnt[w][k]; }
+            if (c == k) ws.sideList[(size_t)k * n + run[k] + before + __popcll(m[k] & ((1ull << lane) - 1ull))] = i;
+            run[k] += all;
         }
     }
 }
