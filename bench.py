@@ -61,6 +61,11 @@ PMC_NAMES = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "
              "hash_cands_512": ("hash_cands_512", "hash_cands"), "hash_cands_1024": ("hash_cands_1024", "hash_cands"), "mid_cands_64": ("mid_cands",), "mid_cands_128": ("mid_cands",), "mid_cands_256": ("mid_cands",)}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
+# --shape refseq72k: the same 150 Gbp as a collection shaped like a real bacterial RefSeq -- 72 000 targets, most of 0.5 .. 3 Mbp, 3 % of
+# the genera with genomes of 10 .. 16 Mbp (143 000 windows): target ids and window ids do NOT fit 32 bits together (17 + 18 bits), the
+# global window numbers of the compact location store do
+CFG2_72K = dict(genera=3600, species_per_genus=4, strains_per_species=5, len_min=500_000, len_max=3_000_000, seed=3100, big_fraction=0.03,
+                big_len=(10_000_000, 16_000_000))
 
 
 def make_genomes(n_genomes: int, length: int, seed: int):
@@ -411,6 +416,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: 5 M for configs[2], 10 M for configs[1])")
     ap.add_argument("--scale", type=float, default=1.0, help="configs[2]: fraction of the 2000 genera (quick runs)")
     ap.add_argument("--build-shards", type=int, default=0, help="configs[2]: key-shard passes of the build (0 = by size)")
+    ap.add_argument("--shape", default="default", choices=("default", "refseq72k"), help="configs[2]: the collection's shape (refseq72k: 72 000 targets, "
+                    "genomes up to 16 Mbp, the same 150 Gbp)")
     ap.add_argument("--genomes", type=int, default=16)
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--maxcand", type=int, default=2)
@@ -485,7 +492,7 @@ def main():
         pmc_tag = "r02c1"
     else:
         # ---- configs[2]: RefSeq-scale phylogeny, uint32 targets, built on this GPU in key shards ---------------------------------
-        c2 = dict(CFG2)
+        c2 = dict(CFG2 if args.shape == "default" else CFG2_72K)
         c2["genera"] = max(2, int(round(c2["genera"] * args.scale)))
         spec = synthdb.phylogeny(**c2)
         est_pairs = spec.total_bases // 112 * 16
@@ -531,10 +538,11 @@ def main():
             gen.reads(spec, P, first, nloc, t, t2)
             batches.append(t); mates.append(t2)
         V = 8
+        max_len = int(spec.targets["length"].max())
         shape = "2 x 150 bp read pairs" if args.pairs else "150 bp reads"
         how = {"R": "1 partition", "P": f"{world} partitions (targets round-robin), one per GPU", "K": f"1 partition key-sharded over {world} GPUs"}[mode]
         workload = (f"configs[{4 if args.long_reads else 3 if (args.pairs or mode != 'R') else 2}]: RefSeq-scale synthetic DB, {len(spec.targets)} targets / {spec.total_bases / 1e9:.1f} Gbp "
-                    f"(genus>species>strain phylogeny, uint32 target ids, {how}{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
+                    f"(genus>species>strain phylogeny{'' if args.shape == 'default' else f', genomes up to {max_len / 1e6:.1f} Mbp'}, uint32 target ids, {how}{'' if args.scale == 1.0 else f', scale {args.scale}'}), "
                     + (f"{world * args.steps * B} synthetic long reads (200-19000 bp, log-normal, median 480; 7.5 % substitutions)" if args.long_reads else
                        f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
                     + ("" if nb >= args.steps + args.warmup else f" ({world * nb * B * (2 if args.pairs else 1)} distinct, cycled)"))

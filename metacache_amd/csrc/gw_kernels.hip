@@ -565,7 +565,7 @@ __device__ __forceinline__ uint32_t gw_slot(uint32_t g)                 // byte 
 template <uint32_t LOG2S, uint32_t PER, bool TAX>
 __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], uint2* slots, const uint32_t lane, const uint32_t maxWin,
                                                       const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
-                                                      mc_candidate_dev* __restrict__ out, uint32_t (&pickLo)[kLaneK], uint32_t (&pickHi)[kLaneK], bool& again)
+                                                      uint32_t& owv, uint32_t& owh, uint32_t& owd)
 {
     constexpr uint32_t kByteMask = ((1u << LOG2S) - 1u) << 3;
     char* base = reinterpret_cast<char*>(slots);
@@ -686,10 +686,19 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
         if (lane == rnd) { wv = mv; wh = mh; wd = d; }
         strong += mh >= 2 ? 1u : 0u;
     }
-    // the winners' targets: lane i looks up winner i
-    uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
-    if (wv != kGwNone) { wt = tab.gw_target(wv); wlo = tab.gwBase[wt]; whi = tab.gwBase[wt + 1]; }
-    again = false;
+    owv = wv; owh = wh; owd = wd;                              // lane i: winner i (the caller looks their targets up: gw_winners_out)
+    return strong;
+}
+
+// The K winners of a read (lane i: number, hits, end - begin; target wt with its numbers [wlo, whi) looked up by the caller) -> the
+// candidates.  Returns true when two winners are one target (region striking met another region of a picked target): the caller hands
+// the read to the exact wave kernel.
+template <bool TAX>
+__device__ __forceinline__ bool gw_winners_out(const uint32_t lane, const uint32_t K, const uint32_t wv, const uint32_t wh, const uint32_t wd,
+                                               const uint32_t wt, const uint32_t wlo, const uint32_t whi, mc_candidate_dev* __restrict__ out,
+                                               uint32_t (&pickLo)[kLaneK], uint32_t (&pickHi)[kLaneK])
+{
+    bool again = false;
     if constexpr (!TAX) {
 #pragma unroll
         for (uint32_t i = 0; i + 1 < kLaneK; ++i) {
@@ -704,7 +713,7 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
         if (wv == kGwNone) { e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0; }
         out[lane] = e;
     }
-    return strong;
+    return again;
 }
 
 }  // namespace
@@ -745,6 +754,32 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
     };
     // the first instance (most reads) takes ALL records, 64 per step; the others get theirs from the compact lists gw_compact_kernel
     // made (ws.sideList [1] / [2]), 8 per step: with few of them every wave should have some
+    // The winners' target lookup is two dependent loads from global memory (directory, gwBase) at the very end of a read: the first
+    // instance DEFERS it -- directory entry requested when the winners are known, gwBase words before the next read's counting, the
+    // candidates written after it -- so that the loads run behind the next read's LDS phases (a read with places left for single hits
+    // finishes at once: step D needs the picked targets).
+    constexpr bool kDefer = LOG2S == 9;
+    bool pend = false;
+    uint32_t pq = 0, pwv = kGwNone, pwh = 0, pwd = 0, pdir = 0, pb0 = 0, pb1 = 0, pb2 = 0;
+    auto pend_bases = [&]() {                                        // stage 1: the three gwBase words behind the directory entry
+        if (pend && pwv != kGwNone) { pb0 = tab.gwBase[pdir]; pb1 = tab.gwBase[pdir + 1]; pb2 = tab.gwBase[min(pdir + 2, tab.gwTargets)]; }
+    };
+    auto pend_finish = [&]() {                                       // stage 2
+        if (!pend) return;
+        uint32_t t = 0xFFFFFFFFu, lo = 0, hi = 0;
+        if (pwv != kGwNone) {
+            t = pdir; lo = pb0; hi = pb1;
+            if (pwv >= pb1) { ++t; lo = pb1; hi = pb2; }
+            while (pwv >= hi) { ++t; lo = hi; hi = tab.gwBase[t + 1]; }
+        }
+        uint32_t plo[kLaneK], phi[kLaneK];
+        const bool again = gw_winners_out<TAX>(lane, K, pwv, pwh, pwd, t, lo, hi, cands + (size_t)pq * K, plo, phi);
+        if (lane == 0) {
+            if (again) { ws.hitScan[pq] = ws.qstat[pq].hits; ws.qflag[pq] = kFlagCands; }
+            else ws.qflag[pq] = kFlagDone;
+        }
+        pend = false;
+    };
     constexpr uint32_t kStep = LOG2S == 9 ? 64u : 8u;
     const uint32_t nmine = LOG2S == 9 ? total : ws.midCount[LOG2S == 10 ? 14 : 15];
     const uint32_t* __restrict__ side = ws.sideList + (size_t)(LOG2S == 10 ? 1 : 2) * b.n;
@@ -773,9 +808,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
         uint32_t pickLo[kLaneK], pickHi[kLaneK];
 #pragma unroll
         for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = 0; pickHi[i] = 0; }
-        uint32_t strong = 0;
+        uint32_t strong = 0, wv = kGwNone, wh = 0, wd = 0;
         bool again = false;
         mc_candidate_dev* out = cands + (size_t)q * K;
+        if constexpr (kDefer) pend_bases();
         auto body = [&](auto perc) {
             constexpr uint32_t PER = decltype(perc)::value;
             uint32_t v[PER];
@@ -784,7 +820,7 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
                 if constexpr (LOG2S == 9) v[r] = cur[r < kPre ? r : 0];
                 else v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
             }
-            strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, out, pickLo, pickHi, again);
+            strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, wv, wh, wd);
         };
         const uint32_t per = (n2 + 63u) / 64u;
         if constexpr (LOG2S == 9) {
@@ -801,6 +837,20 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
             else body(std::integral_constant<uint32_t, kList / 64>{});
         }
         strong = __builtin_amdgcn_readfirstlane(strong);
+        if constexpr (kDefer) {
+            pend_finish();                                         // the previous read's candidates
+            if (strong >= K) {                                     // this read's: later
+                pend = true; pq = q; pwv = wv; pwh = wh; pwd = wd;
+                pdir = wv != kGwNone ? tab.gwDir[wv >> tab.gwDirShift] : 0u;
+                wave_lds_sync();
+                continue;
+            }
+        }
+        {
+            uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
+            if (wv != kGwNone) tab.gw_target_bounds(wv, wt, wlo, whi);
+            again = gw_winners_out<TAX>(lane, K, wv, wh, wd, wt, wlo, whi, out, pickLo, pickHi);
+        }
         bool done = true;
         if (again) {                                               // two winners of one target: the exact wave kernel
             if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
@@ -891,6 +941,7 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
         wave_lds_sync();
       }
     }
+    if constexpr (kDefer) { pend_bases(); pend_finish(); }
 }
 
 // ================================================================================================

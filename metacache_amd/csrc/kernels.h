@@ -86,6 +86,16 @@ struct DeviceTable {
         while (gw >= gwBase[t + 1]) ++t;
         return t;
     }
+    // target and its numbers [lo, hi) in TWO dependent loads: the directory entry, then three neighbouring gwBase words at once (a block
+    // of 2^gwDirShift numbers rarely holds more than one target boundary; more move on one by one)
+    __device__ __forceinline__ void gw_target_bounds(uint32_t gw, uint32_t& t, uint32_t& lo, uint32_t& hi) const
+    {
+        t = gwDir[gw >> gwDirShift];
+        const uint32_t b0 = gwBase[t], b1 = gwBase[t + 1], b2 = gwBase[min(t + 2, gwTargets)];
+        lo = b0; hi = b1;
+        if (gw >= b1) { ++t; lo = b1; hi = b2; }
+        while (gw >= hi) { ++t; lo = hi; hi = gwBase[t + 1]; }
+    }
     __device__ __forceinline__ uint64_t gw_widen(uint32_t gw) const { const uint32_t t = gw_target(gw); return ((uint64_t)t << 32) | (gw - gwBase[t]); }
     __device__ __forceinline__ uint32_t gw_of(uint64_t loc) const { return gwBase[(uint32_t)(loc >> 32)] + (uint32_t)loc; }
     __device__ __forceinline__ uint64_t loc(uint64_t i) const { return values32 ? gw_widen(values32[i]) : values[i]; }

@@ -89,7 +89,7 @@ class Phylogeny:
 
 
 def phylogeny(genera: int, species_per_genus: int, strains_per_species: int, len_min: int, len_max: int, seed: int,
-              div_species=(0.04, 0.10), div_strain=(0.005, 0.02)) -> Phylogeny:
+              div_species=(0.04, 0.10), div_strain=(0.005, 0.02), big_fraction: float = 0.0, big_len=(0, 0)) -> Phylogeny:
     """genus -> species -> strain.  All members of a genus have the genus' length (substitutions only); a species differs from the
     genus ancestor in div_species of its bases, strain 0 of a species IS the species sequence, the others differ from it in
     div_strain of their bases (uniform in the given ranges, per species / per strain)."""
@@ -104,6 +104,10 @@ def phylogeny(genera: int, species_per_genus: int, strains_per_species: int, len
     sdiv = rng.uniform(div_species[0], div_species[1], size=genera * species_per_genus)
     tseed = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
     tdiv = rng.uniform(div_strain[0], div_strain[1], size=n)
+    if big_fraction > 0:                                       # a few genera of LARGE genomes (drawn from a stream of their own: the defaults stay as they were)
+        r2 = np.random.default_rng(seed + 0x5EED)
+        big = r2.random(genera) < big_fraction
+        glen = np.where(big, r2.integers(big_len[0], big_len[1] + 1, size=genera, dtype=np.int64), glen)
     i = 0
     for g in range(genera):
         for s in range(species_per_genus):

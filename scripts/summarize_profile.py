@@ -29,8 +29,11 @@ def short(k):
         return "big_filter" if len(args) < 3 or args[2].strip() in ("1u", "1") else "big_filter_2"
     if "gw_filter_stream_kernel" in k: return "big_filter_2"
     if "gw_filter_kernel" in k: return "big_filter"
-    if "gw_count_kernel<10" in k: return "big_count"
+    if "gw_count_kernel<9" in k: return "big_count"             # filtered lists up to 256 (most reads)
+    if "gw_count_kernel<10" in k: return "big_count_512"
     if "gw_count_kernel<11" in k: return "big_count_2"
+    if "gw_filter2_kernel" in k: return "big_filter_2rounds"
+    if "gw_compact_kernel" in k: return "gw_compact"
     if "gw_sort" in k or "gw_sorted" in k: return "gw_sorted_cands"
     if "big_count_kernel<10" in k: return "big_count"
     if "big_count_kernel<11" in k: return "big_count_2"
