@@ -722,7 +722,7 @@ __device__ __forceinline__ bool gw_winners_out(const uint32_t lane, const uint32
 #define MC_GW_COUNT_WPE 6
 #endif
 template <uint32_t LOG2S, uint32_t WAVES, bool TAX>
-__global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void gw_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
+__global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S == 10 ? 5 : 1) void gw_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                                              const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands,
                                                                                              uint32_t minN2)
 {
@@ -744,10 +744,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
     // The records are taken 64 at a time: one coalesced load, a ballot of the ones that are this instance's, their fields by
     // v_readlane -- an instance that takes a few hundred of 5 x 10^6 records spent a millisecond on one dependent load per record.
     // The smallest instance (most reads) fetches the NEXT list while it works on this one.
-    constexpr uint32_t kPre = LOG2S == 9 ? kList / 64 : 1;
+    constexpr uint32_t kPre = LOG2S <= 10 ? kList / 64 : 1;
     uint32_t pre[kPre];
     auto fetch = [&](uint32_t off, uint32_t n) {
-        if constexpr (LOG2S == 9) {
+        if constexpr (LOG2S <= 10) {
 #pragma unroll
             for (uint32_t r = 0; r < kPre; ++r) pre[r] = r * 64 + lane < n ? pool[off + r * 64 + lane] : kGwNone;
         }
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
     // instance DEFERS it -- directory entry requested when the winners are known, gwBase words before the next read's counting, the
     // candidates written after it -- so that the loads run behind the next read's LDS phases (a read with places left for single hits
     // finishes at once: step D needs the picked targets).
-    constexpr bool kDefer = LOG2S == 9;
+    constexpr bool kDefer = LOG2S <= 10;
     bool pend = false;
     uint32_t pq = 0, pwv = kGwNone, pwh = 0, pwd = 0, pdir = 0, pb0 = 0, pb1 = 0, pb2 = 0;
     auto pend_bases = [&]() {                                        // stage 1: the three gwBase words behind the directory entry
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : 1) void 
             uint32_t v[PER];
 #pragma unroll
             for (uint32_t r = 0; r < PER; ++r) {
-                if constexpr (LOG2S == 9) v[r] = cur[r < kPre ? r : 0];
+                if constexpr (LOG2S <= 10) v[r] = cur[r < kPre ? r : 0];
                 else v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
             }
             strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, wv, wh, wd);

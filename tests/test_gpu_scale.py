@@ -249,6 +249,45 @@ def test_two_gbp_database_auto_quad_against_oracle():
     db.close(); odb.close()
 
 
+def test_compact_store_holds_shapes_that_do_not_fit_32_bits_as_target_and_window():
+    """32 800 targets (16 bits) of which a few have 75 000 windows (17 bits): round 2's (target << bits) | window form could not hold
+    this collection in 4 bytes; the global window numbers do.  Reads over all targets against the oracle's restricted build; the large
+    genomes are strain groups, so their reads take the filtered path's kernels (MC_BIG_MIN=0: every list above 64)."""
+    import torch
+    spec = synthdb.phylogeny(8200, 2, 2, 1_000, 3_000, seed=77, big_fraction=0.0012, big_len=(8_000_000, 8_400_000))
+    lens = spec.targets["length"].astype(np.int64)
+    assert len(lens) == 32_800 and (lens // 112).max() > 65_536 and (lens > 1_000_000).sum() >= 8
+    K = 2
+    db, _ = synthdb.build_database(spec, shards=1, max_candidates=K)
+    lay = db.table_layout()
+    assert lay["location_bytes"] == 4, lay
+    db.set_tuning("big_min", 0)
+    gen = synthdb.GpuSynth(0)
+    n = 30_000
+    P = synthdb.read_params(spec, 77)
+    a = torch.zeros((n, P.row_bytes), dtype=torch.uint8, device="cuda:0")
+    gen.reads(spec, P, 0, n, a)
+    torch.cuda.synchronize()
+    reads = [bytes(r[:150]) for r in a.cpu().numpy()]
+    # reads are drawn uniformly over the TARGETS: add reads of the large genomes' windows beyond 65 536 on purpose
+    cs = synthdb.CpuSynth()
+    big = np.flatnonzero(lens > 1_000_000)
+    rng = np.random.default_rng(5)
+    for t in big[:12]:
+        for _ in range(40):
+            st = int(rng.integers(66_000 * 112, int(lens[t]) - 200))
+            reads.append(bytes(cs.target(spec, int(t), st, 150)))
+    odb = scale_util.oracle_database(spec, scale_util.sample_features(reads), threads=THREADS)
+    cands, counts, _ = db.query(reads)
+    far = 0
+    for i, r in enumerate(reads):
+        _, e = odb.query(r, b"", K, 0, 0)
+        _check(cands[i], e, K, (i, counts[i]))
+        far += int(len(e) > 0 and e[0]["end"] > 65_536)
+    assert far > 300, far                                          # candidates whose window numbers need 17 bits
+    db.close(); odb.close()
+
+
 @pytest.fixture(scope="module")
 def table33():
     """8 800 targets / 33 Gbp of the bench collection's shape (440 genera x 4 species x 5 strains, 2.5 - 5 Mbp), built in 4 key shards:
