@@ -562,61 +562,71 @@ __device__ __forceinline__ uint32_t gw_slot(uint32_t g)                 // byte 
     return (h >> (29u - LOG2S)) & (((1u << LOG2S) - 1u) << 3);
 }
 
-template <uint32_t LOG2S, uint32_t PER, bool TAX>
-__device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], uint2* slots, const uint32_t lane, const uint32_t maxWin,
-                                                      const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
-                                                      uint32_t& owv, uint32_t& owh, uint32_t& owd)
+// Phase 1 on the PER numbers every lane holds: counted in the table; the numbers a lane CLAIMED (one lane per distinct number) go,
+// with their slots, to the compact list ck -- a filtered list of 195 numbers has about 50 distinct ones, and everything after the
+// counting (neighbour windows, the K rounds) is per distinct number: one per lane instead of four.  Returns how many.
+template <uint32_t LOG2S, uint32_t PER>
+__device__ __forceinline__ uint32_t gw_count_numbers(const uint32_t (&v)[PER], uint2* slots, uint32_t* ck, const uint32_t lane)
 {
     constexpr uint32_t kByteMask = ((1u << LOG2S) - 1u) << 3;
     char* base = reinterpret_cast<char*>(slots);
     auto key_at = [&](uint32_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(base + off); };
-    uint32_t off[PER];                                        // byte offset of the number's slot | 1 if this lane claimed it
-    // the targets of the numbers (for striking a picked target's other ranges in step 3): two dependent loads that hit the L2, started
-    // here and there so that they run behind the LDS phases instead of inside the K rounds
-    // (taxon merging only: without it the K rounds strike REGIONS and the targets of the K winners are looked up afterwards)
+    uint32_t off[PER], old[PER];
+    bool coll = false;
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) {
+        off[r] = gw_slot<LOG2S>(v[r]);
+        old[r] = v[r] != kGwNone ? atomicCAS(key_at(off[r]), kGwNone, v[r]) : v[r];
+        coll = coll || (old[r] != kGwNone && old[r] != v[r]);
+    }
+    if (__ballot(coll)) {                                      // somebody else's number in the home slot: next slots, one at a time
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            if (old[r] != kGwNone && old[r] != v[r]) {
+                uint32_t o = off[r];
+                for (;;) {
+                    o = (o + 8u) & kByteMask;
+                    old[r] = atomicCAS(key_at(o), kGwNone, v[r]);
+                    if (old[r] == kGwNone || old[r] == v[r]) break;
+                }
+                off[r] = o;
+            }
+        }
+    }
+    uint32_t C = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) {
+        if (v[r] != kGwNone) atomicAdd(key_at(off[r]) + 1, 1u);
+        const bool claimed = v[r] != kGwNone && old[r] == kGwNone;
+        const uint64_t m = __ballot(claimed);
+        if (claimed) ck[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, C))] = off[r];   // (the slot holds the number)
+        C += (uint32_t)__popcll(m);
+    }
+    return C;
+}
+
+// Phases 2 and 3 on the distinct numbers (PER of them per lane, from ck): hits of the window range that ends in each, then the K rounds.
+template <uint32_t LOG2S, uint32_t PER, bool TAX>
+__device__ __forceinline__ uint32_t gw_pick(const uint32_t* ck, const uint32_t C, uint2* slots, const uint32_t lane, const uint32_t maxWin,
+                                            const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab,
+                                            uint32_t& owv, uint32_t& owh, uint32_t& owd)
+{
+    constexpr uint32_t kByteMask = ((1u << LOG2S) - 1u) << 3;
+    const char* base = reinterpret_cast<const char*>(slots);
+    uint32_t v[PER], R[PER];
+    // ---- 2. ranges that end in this lane's numbers: hits | (end - begin) << 16
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) {
+        const uint2 c = r * 64 + lane < C ? *reinterpret_cast<const uint2*>(base + ck[r * 64 + lane]) : make_uint2(kGwNone, 0u);   // {number, count}
+        v[r] = c.x; R[r] = c.y;
+    }
+    // (taxon merging: the targets of the numbers -- two dependent loads that hit the L2, started here so that they run behind the
+    // neighbour lookups; without it the K rounds strike REGIONS and the targets of the K winners are looked up afterwards)
     uint32_t tgt[TAX ? PER : 1], thi[TAX ? PER : 1];
     if constexpr (TAX) {
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) tgt[r] = v[r] != kGwNone ? tab.gwDir[v[r] >> tab.gwDirShift] : 0u;
     }
-    {
-        uint32_t old[PER];
-        bool coll = false;
-#pragma unroll
-        for (uint32_t r = 0; r < PER; ++r) {
-            off[r] = gw_slot<LOG2S>(v[r]);
-            old[r] = v[r] != kGwNone ? atomicCAS(key_at(off[r]), kGwNone, v[r]) : v[r];
-            coll = coll || (old[r] != kGwNone && old[r] != v[r]);
-        }
-        if (__ballot(coll)) {                                  // somebody else's number in the home slot: next slots, one at a time
-#pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) {
-                if (old[r] != kGwNone && old[r] != v[r]) {
-                    uint32_t o = off[r];
-                    for (;;) {
-                        o = (o + 8u) & kByteMask;
-                        old[r] = atomicCAS(key_at(o), kGwNone, v[r]);
-                        if (old[r] == kGwNone || old[r] == v[r]) break;
-                    }
-                    off[r] = o;
-                }
-            }
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < PER; ++r) {
-            if (v[r] != kGwNone) atomicAdd(key_at(off[r]) + 1, 1u);
-            off[r] |= (v[r] != kGwNone && old[r] == kGwNone) ? 1u : 0u;
-        }
-    }
-    if constexpr (TAX) {
-#pragma unroll
-        for (uint32_t r = 0; r < PER; ++r) thi[r] = (off[r] & 1u) ? tab.gwBase[tgt[r] + 1] : 0u;
-    }
-    wave_lds_sync();
-    // ---- 2. ranges that end in the numbers this lane claimed: hits | (end - begin) << 16
-    uint32_t R[PER];
-#pragma unroll
-    for (uint32_t r = 0; r < PER; ++r) R[r] = (off[r] & 1u) ? key_at(off[r] & ~1u)[1] : 0u;
     for (uint32_t d = 1; d < maxWin; ++d) {
         uint2 kc[PER]; uint32_t o[PER];
         bool chain = false;
@@ -624,8 +634,7 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
         for (uint32_t r = 0; r < PER; ++r) {
             o[r] = gw_slot<LOG2S>(v[r] - d);                   // (v - d is never kGwNone: numbers start at gwGap >= maxWin)
             kc[r] = *reinterpret_cast<const uint2*>(base + o[r]);
-            const bool live = (off[r] & 1u) != 0;
-            if (!live) kc[r].x = kGwNone;
+            if (v[r] == kGwNone) kc[r].x = kGwNone;
             chain = chain || (kc[r].x != v[r] - d && kc[r].x != kGwNone);
         }
         if (__ballot(chain)) {
@@ -642,20 +651,21 @@ __device__ __forceinline__ uint32_t gw_count_and_pick(const uint32_t (&v)[PER], 
         // (a directory entry names the target of its block's FIRST number: the few numbers behind a target boundary inside a block move on)
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) {
-            while ((off[r] & 1u) && v[r] >= thi[r]) { ++tgt[r]; thi[r] = tab.gwBase[tgt[r] + 1]; }
-            ptax[r] = (off[r] & 1u) ? taxkey[tgt[r]] : 0u;
+            thi[r] = v[r] != kGwNone ? tab.gwBase[tgt[r] + 1] : 0u;
+            while (v[r] != kGwNone && v[r] >= thi[r]) { ++tgt[r]; thi[r] = tab.gwBase[tgt[r] + 1]; }
+            ptax[r] = v[r] != kGwNone ? taxkey[tgt[r]] : 0u;
         }
     }
     // ---- 3. K rounds: wave-wide maximum of the hits, the smallest number among its holders.  Struck from the race: the winner's taxon
     //      (taxon merging), else every number within gwGap of the winner -- its REGION, which lies inside its target (that is what the
     //      gap is for).  The targets of the K winners are looked up afterwards, all at once; should two of them be one target (two
-    //      regions of it more than 115 kbp apart, both with hits to show) the caller hands the read to the exact wave kernel ('again').
+    //      regions of it more than 115 kbp apart, both with hits to show) the caller hands the read to the exact wave kernel.
     //      Why that is exact: region striking offers, in every round, a superset of what target striking offers; its winner is either
     //      the same or a number of an earlier winner's target -- which the comparison finds.
     uint32_t live = 0;
 #pragma unroll
     for (uint32_t r = 0; r < PER; ++r) {
-        bool ok = (off[r] & 1u) != 0;
+        bool ok = v[r] != kGwNone;
         if constexpr (TAX) ok = ok && ptax[r] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
         live |= ok ? (1u << r) : 0u;
     }
@@ -729,8 +739,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
     constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
     static_assert(kGwRounds * 8 <= kSlots * 8, "step D's round table lives in the slot table, which is done with by then");
     __shared__ __attribute__((aligned(16))) uint2 slotS[WAVES][kSlots];
+    __shared__ uint32_t ckS[WAVES][kList];                             // the slots of the list's distinct numbers (gw_count_numbers)
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the wave's pointers and loop counters live in scalar registers)
     uint2* slots = slotS[wave];
+    uint32_t* ck = ckS[wave];
     uint64_t* T = reinterpret_cast<uint64_t*>(slotS[wave]);
     // the records gw_filter_kernel left (list 7, one per read of work list 6); this instance takes the filtered lists that fit its
     // table: n2 in (minN2, kList], window ranges up to kHashWin
@@ -812,6 +824,7 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
         bool again = false;
         mc_candidate_dev* out = cands + (size_t)q * K;
         if constexpr (kDefer) pend_bases();
+        uint32_t C = 0;
         auto body = [&](auto perc) {
             constexpr uint32_t PER = decltype(perc)::value;
             uint32_t v[PER];
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
                 if constexpr (LOG2S <= 10) v[r] = cur[r < kPre ? r : 0];
                 else v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
             }
-            strong = gw_count_and_pick<LOG2S, PER, TAX>(v, slots, lane, maxWin, K, taxkey, tab, wv, wh, wd);
+            C = gw_count_numbers<LOG2S, PER>(v, slots, ck, lane);
         };
         const uint32_t per = (n2 + 63u) / 64u;
         if constexpr (LOG2S == 9) {
@@ -835,6 +848,19 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
             if (per <= 10) body(std::integral_constant<uint32_t, 10>{});
             else if (per <= 12) body(std::integral_constant<uint32_t, 12>{});
             else body(std::integral_constant<uint32_t, kList / 64>{});
+        }
+        C = __builtin_amdgcn_readfirstlane(C);
+        wave_lds_sync();
+        auto pick = [&](auto perc) {
+            constexpr uint32_t PER = decltype(perc)::value;
+            strong = gw_pick<LOG2S, PER, TAX>(ck, C, slots, lane, maxWin, K, taxkey, tab, wv, wh, wd);
+        };
+        if (C <= 64) pick(std::integral_constant<uint32_t, 1>{});
+        else if (C <= 128) pick(std::integral_constant<uint32_t, 2>{});
+        else if (C <= 256) pick(std::integral_constant<uint32_t, 4>{});
+        else if constexpr (LOG2S >= 10) {
+            if (C <= 512) pick(std::integral_constant<uint32_t, 8>{});
+            else if constexpr (LOG2S >= 11) pick(std::integral_constant<uint32_t, 16>{});
         }
         strong = __builtin_amdgcn_readfirstlane(strong);
         if constexpr (kDefer) {

@@ -529,3 +529,52 @@ def test_location_range_is_enforced_and_optional():
     assert load((1 << 20, 1 << 20))[:2] == (0, 8)                  # 2^40 windows: stays wide
     assert load((0xFFFF, 0xFFFE))[:2] == (0, 8)                    # 2^32 windows + gaps: stays wide
     assert load((0xFFFF, 0x7FFF))[:2] == (0, 4)
+
+
+@pytest.mark.parametrize("lowest,K", [(0, 2), (0, 3), (4, 2)])
+def test_two_regions_of_one_target_in_the_filtered_path(tmp_path, lowest, K, monkeypatch):
+    """A 400-bp segment that occurs TWICE in every strain's genome, 200 kbp (1 780 windows) apart: reads of it find two regions per
+    target with equal hits.  gw_count_kernel strikes a winner's REGION (numbers within 1 024 of it) and looks the winners' targets up
+    afterwards; here its second winner is the first winner's other region, which it must notice and hand the read to the exact path
+    (the sorted path's kernel sees whole target runs).  12 strains x 2 regions x 32 features: lists of several hundred locations."""
+    from metacache_amd import synth
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", "1")
+    monkeypatch.setenv("MC_BIG_MIN", "0")
+    rng = np.random.default_rng(99 + lowest + K)
+    genomes, parents = [], []
+    for sp in range(2):
+        base = synth.random_genome(rng, 260_000)
+        base[201_000:201_400] = base[1_000:1_400]
+        for st in range(12):
+            genomes.append(synth.mutate(rng, base, 0.004) if st else base.copy())
+            parents.append(1000 + sp)
+    bld = api.Builder(target_id_bytes=4, max_candidates=K)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"R{i:04d}.1", parent_taxid=parents[i])
+    name = str(tmp_path / "regions")
+    bld.finish(load=False)
+    bld.write(name, [(1, 1, 20, "root")] + [(1000 + i, 1, 4, f"sp{i}") for i in range(2)])
+    bld.free()
+    reads = []
+    for _ in range(1500):
+        g = genomes[int(rng.integers(0, len(genomes)))]
+        st = int(rng.integers(1_000, 1_250)) + (200_000 if rng.random() < 0.5 else 0)
+        reads.append(bytes(synth.mutate(rng, g[st:st + 150], 0.01, 0.001)))
+    others, _, _ = synth.sample_reads(rng, genomes, 1500, 150, 0.01, 0.002)
+    reads += [bytes(r) for r in others]
+    mates = [bytes(synth.revcomp(np.frombuffer(r, dtype=np.uint8)))[:130] for r in reads[:600]]
+    odb = cpuref.oracle().open(name)
+    db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 12, slot_max_chars=1 << 21)
+    assert db.table_layout()["location_bytes"] == 4
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    pc, _, _ = db.query(reads[:600], mates, lowest=lowest, insert_max=0)
+    st = db.last_batch_stats()
+    db.close()
+    assert np.mean(counts[:1500] > 256) > 0.5, np.percentile(counts[:1500], [5, 50, 95])
+    for i, r in enumerate(reads):
+        _, e = odb.query(r, b"", K, lowest, 0)
+        assert cands_equal(cands[i], e[:K]), (i, counts[i], cands[i], e[:K])
+    for i in range(600):
+        _, e = odb.query(reads[i], mates[i], K, lowest, 0)
+        assert cands_equal(pc[i], e[:K]), ("pair", i, pc[i], e[:K])
+    odb.close()
