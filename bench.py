@@ -427,6 +427,7 @@ def main():
     ap.add_argument("--gather-gib", type=float, default=-1.0, help="scratch buffer of the random-access microbenchmark (0 = skip; default: 64 for "
                     "configs[2], 0.6 = the table's size for configs[1])")
     ap.add_argument("--mode", default="R", choices=("R", "P", "K"), help="configs[2]: R replicated table (default), P one part per rank, K key shards")
+    ap.add_argument("--wire", type=int, default=4, choices=(4, 8), help="mode K: bytes per location in the exchange (4 = global window numbers, 8 = (target, window))")
     ap.add_argument("--pairs", action="store_true", help="configs[2]: 2 x 150 bp read pairs (configs[3]'s reads) instead of single reads")
     ap.add_argument("--reference-files", default="", help="configs[2], N = 1: also write the database as files under this name (e.g. /dev/shm/mcdb: "
                     "190 GB at full scale) and let the REFERENCE (oracle/_ref) load them and be the checker and the CPU baseline instead of the oracle")
@@ -593,7 +594,7 @@ def main():
         finish(j)                                            # the gather that used this buffer two batches ago
         if mode == "K":
             res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=True)
-            out_bufs[j].copy_(classify_key_sharded_device(db, res, nloc, K, max_win))   # all-to-all of the partial lists, union, rows 8-10
+            out_bufs[j].copy_(classify_key_sharded_device(db, res, nloc, K, max_win, wire=args.wire))   # all-to-all of the partial lists, rows 8-10 on the owner
             torch.cuda.current_stream().synchronize()
         elif args.long_reads:
             lb = long_batches[i % nb]
@@ -672,8 +673,8 @@ def main():
                        "mode": mode, "pairs": pairs,
                        "parallelism": {"R": f"replicated DB x{world}, reads sharded, RCCL gather of top candidates",
                                        "P": f"{world} parts, one per GPU; all reads against every part, RCCL all-gather of per-part candidates, merge",
-                                       "K": f"1 part key-sharded over {world} GPUs; all reads against every shard, RCCL all-to-all of partial location lists, "
-                                            "union + candidates on the owner, gather"}[mode]},
+                                       "K": f"1 part key-sharded over {world} GPUs; every shard looks up the features it owns for all reads, RCCL all-to-all-v of the partial "
+                                            f"location lists ({args.wire} bytes per location), candidates on the read's owner, gather"}[mode]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6),
                          # the same bytes over the WHOLE step (all kernels, launches, the copy of the candidates)

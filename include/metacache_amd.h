@@ -275,6 +275,65 @@ typedef struct {
     uint32_t           num_sources;
 } mc_device_partial_hits;
 int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* in, int lowest_rank, mc_device_results* out, void* stream);
+/* Mode K with 4-BYTE locations on the wire.  What travels between the key shards is the compact location store's own form of a
+ * location, the global window number gw = gwBase[target] + window (every context of one database numbers the windows of ALL targets the
+ * same way: the numbering comes from the targets' window counts in the metadata).  Needs a single-part database whose windows can be
+ * numbered in 32 bits (mc_load_target_windows; MC_ERR_UNSUPPORTED otherwise: use the 8-byte calls above).
+ *
+ * Shard side, after mc_query_device(MC_WANT_PARTIAL_HITS) on a key-sharded context (such a call looks up only the features the shard
+ * owns): res's partial lists as numbers, back to back in read order, and the per-read counts -- the piece for the owner of reads
+ * [lo, hi) is the contiguous range numbers[cut(lo) .. cut(hi)).  cut_offsets[i] (HOST) = first number of read cut_queries[i]
+ * (cut_queries[i] <= num_queries): the split sizes of the all-to-all-v, the one host round trip of the exchange.  out's pointers
+ * are ctx-owned device memory, valid until the next mc_partial_numbers call; filled asynchronously on 'stream'.
+ * Replaces query_batch.cu:464-527 (the reference forwards the sketches from GPU to GPU and accumulates per-part results). */
+typedef struct {
+    const uint32_t* counts;       /* device [num_queries] */
+    const uint32_t* numbers;      /* device [total] */
+    uint64_t        total;
+} mc_device_partial_numbers;
+int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t num_queries, const uint32_t* cut_queries, uint32_t num_cuts,
+                       uint64_t* cut_offsets, mc_device_partial_numbers* out, void* stream);
+/* Owner side in ONE call: rows 8-10 on the pieces num_sources (<= 64) key shards sent for this rank's num_queries reads --
+ * counts[s * num_queries + i] numbers of read i from source s, each source's numbers back to back in read order, source s' block
+ * at numbers[source_offsets[s] .. source_offsets[s + 1]) (source_offsets on the HOST: the receive displacements).  No union copy:
+ * the receive buffer stands in for the table's location store, every source's piece is one list of the read; lists of more than
+ * 64 locations take the filtered path of the replicated mode (gw_filter / gw_count / sorted lists), the rest and what that path
+ * hands back are decoded to (target, window) and sorted.  'numbers' must stay untouched until the results have been copied out and
+ * must be readable 16 bytes past its end.  Results as mc_query_device (out->cands).
+ * Replaces query_batch.cu:638-652 + the candidate generation of gpu_hashmap.cu:1255-1290 across the reference's GPUs. */
+typedef struct {
+    const uint32_t* counts;          /* device [num_sources * num_queries] */
+    const uint32_t* numbers;         /* device */
+    const uint64_t* source_offsets;  /* HOST [num_sources + 1] */
+    const uint32_t* max_win;         /* device [num_queries] or NULL with max_win_uniform > 0 */
+    uint32_t        max_win_uniform;
+    uint32_t        num_queries;
+    uint32_t        num_sources;
+} mc_device_partial_numbers_in;
+int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numbers_in* in, int lowest_rank, mc_device_results* out, void* stream);
+/* what mc_candidates_from_partial_numbers has done on this context so far: stats[0..3] = reads, reads whose pieces took the filtered path,
+ * numbers received, locations decoded for the sort (short lists + what the filtered path handed back) */
+int mc_owner_stats(const mc_ctx* ctx, uint64_t stats[4]);
+
+/* ONE database key-sharded over the GPUs of the node, driven from C++ (what `mcq query -shard keys -gpus a,b,...` runs): shard s of
+ * num_shards on devices[s % num_devices], one context each (mc_open_database with key_shard_index / key_shard_count).  Per batch
+ * every shard looks its own features up for ALL reads (mc_query_device(MC_WANT_PARTIAL_HITS)), the partial lists travel as 4-byte
+ * numbers to the shard that owns the read (contiguous read shards; grouped ncclSend / ncclRecv = all-to-all-v over RCCL/xGMI between
+ * devices, device-to-device copies between shards of one device), and the owner runs rows 8-10 (mc_candidates_from_partial_numbers).
+ * RCCL is used when num_shards == num_devices > 1 (or MC_KEYSET_RCCL=1 with one shard: the same calls with a single rank);
+ * several shards on one device are what a single-GPU box can test.  num_shards == 0: one per device.
+ * Reference: gpu_hashmap.cu:1255-1290, query_batch.cu:464-527 (its parts-over-GPUs query), options.cpp:1155-1163. */
+typedef struct mc_keyset mc_keyset;
+int  mc_keyset_open(const char* name, const mc_config* cfg, uint32_t num_shards, const int32_t* devices, uint32_t num_devices, mc_keyset** out);
+void mc_keyset_close(mc_keyset* ks);
+/* info[0..7] = shards, devices, 1 if the exchange runs over RCCL, locations of all shards, numbers sent through the exchange so far, batches,
+ * reads whose pieces took the filtered path on their owner, locations decoded for the sort (mc_owner_stats summed over the shards) */
+int  mc_keyset_info(const mc_keyset* ks, uint64_t info[8]);
+/* as mc_partset_classify: out[n][max_candidates] in HOST memory */
+int  mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n,
+                        int lowest_rank, uint64_t insert_max, mc_candidate* out);
+const char* mc_keyset_last_error(const mc_keyset* ks);
+
 /* copies out of the ctx-owned result buffers, asynchronous on the context's stream
  * (kind: 0 = device -> device, 1 = device -> host) */
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
@@ -288,7 +347,8 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256",
- * "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_filter_2", "big_count", "big_count_2", "query_wave", "scan", "sort_candidates"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
+ * "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates";
+ * Mode K: "mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);
 int mc_timing_reset(mc_ctx* ctx);
 int mc_timing_get(mc_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);

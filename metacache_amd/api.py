@@ -49,6 +49,15 @@ class McDevicePartialHits(C.Structure):
                 ("num_queries", C.c_uint32), ("num_sources", C.c_uint32)]
 
 
+class McDevicePartialNumbers(C.Structure):
+    _fields_ = [("counts", C.c_void_p), ("numbers", C.c_void_p), ("total", C.c_uint64)]
+
+
+class McDevicePartialNumbersIn(C.Structure):
+    _fields_ = [("counts", C.c_void_p), ("numbers", C.c_void_p), ("source_offsets", C.c_void_p), ("max_win", C.c_void_p), ("max_win_uniform", C.c_uint32),
+                ("num_queries", C.c_uint32), ("num_sources", C.c_uint32)]
+
+
 class McDeviceResults(C.Structure):
     _fields_ = [("cands", C.c_void_p), ("hit_counts", C.c_void_p), ("hit_offsets", C.c_void_p), ("hits", C.c_void_p),
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
@@ -56,6 +65,7 @@ class McDeviceResults(C.Structure):
 
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
            "mc_partset_info", "mc_partset_classify", "mc_partset_last_error",
+           "mc_partial_numbers", "mc_candidates_from_partial_numbers", "mc_owner_stats", "mc_keyset_open", "mc_keyset_close", "mc_keyset_info", "mc_keyset_classify", "mc_keyset_last_error",
            "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
@@ -306,6 +316,28 @@ class Database:
         self._check(L.mc_candidates_from_partial_hits(self.h, C.byref(h), lowest, C.byref(r), stream or None))
         return r
 
+    def partial_numbers(self, res: McDeviceResults, n: int, cut_queries, stream: int = 0):
+        """Mode K shard side, 4-byte wire: the partial lists of the last query_device(want_partial_hits=True) as global window numbers
+        (mc_partial_numbers).  -> (McDevicePartialNumbers, cut_offsets uint64 [len(cut_queries)])"""
+        L = lib()
+        L.mc_partial_numbers.argtypes = [C.c_void_p, C.POINTER(McDeviceResults), C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(McDevicePartialNumbers), C.c_void_p]
+        cq = np.ascontiguousarray(cut_queries, dtype=np.uint32)
+        co = np.zeros(len(cq), dtype=np.uint64)
+        out = McDevicePartialNumbers()
+        self._check(L.mc_partial_numbers(self.h, C.byref(res), n, cq.ctypes.data, len(cq), co.ctypes.data, C.byref(out), stream or None))
+        return out, co
+
+    def candidates_from_partial_numbers(self, counts_ptr: int, numbers_ptr: int, source_offsets, n: int, max_win_ptr: int = 0,
+                                        max_win_uniform: int = 0, lowest: int = 0, stream: int = 0) -> McDeviceResults:
+        """Mode K owner side, 4-byte wire (mc_candidates_from_partial_numbers); source_offsets: host array [sources + 1]"""
+        L = lib()
+        L.mc_candidates_from_partial_numbers.argtypes = [C.c_void_p, C.POINTER(McDevicePartialNumbersIn), C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
+        so = np.ascontiguousarray(source_offsets, dtype=np.uint64)
+        h = McDevicePartialNumbersIn(counts_ptr, numbers_ptr or None, so.ctypes.data, max_win_ptr or None, max_win_uniform, n, len(so) - 1)
+        r = McDeviceResults()
+        self._check(L.mc_candidates_from_partial_numbers(self.h, C.byref(h), lowest, C.byref(r), stream or None))
+        return r
+
     def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False, stream: int = 0):
         L = lib()
         L.mc_copy_results_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
@@ -388,6 +420,54 @@ class PartSet:
     def close(self):
         if self.h:
             lib().mc_partset_close(self.h)
+            self.h = C.c_void_p()
+
+
+class KeySet:
+    """ONE database key-sharded over the GPUs of the node (mc_keyset_*, Mode K from C++): every shard looks up its own features for all
+    reads, the partial lists travel as 4-byte global window numbers to the shard that owns the read (RCCL between devices)."""
+
+    def __init__(self, name: str, shards: int = 0, devices=None, **kw):
+        L = lib()
+        L.mc_keyset_open.argtypes = [C.c_char_p, C.POINTER(McConfig), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mc_keyset_close.argtypes = [C.c_void_p]
+        L.mc_keyset_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.mc_keyset_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
+        L.mc_keyset_last_error.argtypes = [C.c_void_p]
+        L.mc_keyset_last_error.restype = C.c_char_p
+        self.cfg = default_config(**kw)
+        self.h = C.c_void_p()
+        dv = np.asarray(devices if devices is not None else [], dtype=np.int32)
+        rc = L.mc_keyset_open(name.encode(), C.byref(self.cfg), shards, dv.ctypes.data if len(dv) else None, len(dv), C.byref(self.h))
+        if rc != 0:
+            raise McError(f"mc_keyset_open({name}): {L.mc_keyset_last_error(None).decode()} (rc {rc})")
+
+    def info(self) -> dict:
+        a = (C.c_uint64 * 8)()
+        lib().mc_keyset_info(self.h, a)
+        return dict(shards=int(a[0]), devices=int(a[1]), rccl=bool(a[2]), locations=int(a[3]), numbers_sent=int(a[4]), batches=int(a[5]),
+                    reads_filtered=int(a[6]), locations_sorted=int(a[7]))
+
+    def classify(self, reads, mates=None, lowest: int = 0, insert_max: int = 0) -> np.ndarray:
+        """reads / mates: lists of bytes -> cand_dtype [n, max_candidates]"""
+        def pack(rs):
+            offs = np.zeros(len(rs) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(r) for r in rs])
+            return np.frombuffer(b"".join(rs) + b"\0", dtype=np.uint8), offs
+        n = len(reads)
+        s1, o1 = pack(reads)
+        s2, o2 = pack(mates) if mates is not None else (None, None)
+        out = np.zeros((n, self.cfg.max_candidates), dtype=cand_dtype)
+        L = lib()
+        rc = L.mc_keyset_classify(self.h, s1.ctypes.data, o1.ctypes.data, s2.ctypes.data if s2 is not None else None,
+                                  o2.ctypes.data if o2 is not None else None, n, lowest, insert_max, out.ctypes.data)
+        if rc != 0:
+            raise McError(f"mc_keyset_classify: {L.mc_keyset_last_error(self.h).decode()} (rc {rc})")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().mc_keyset_close(self.h)
             self.h = C.c_void_p()
 
 

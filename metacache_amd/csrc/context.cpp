@@ -214,7 +214,7 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
-                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp, &P.bSide};
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp, &P.bSide, &P.bNumbers, &P.bCounts};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
@@ -555,6 +555,44 @@ static int taxkey_for_rank(mc_ctx* ctx, int rank, const uint32_t** out)
 // ------------------------------------------------------------------------------------------------
 // the per-batch pipeline
 // ------------------------------------------------------------------------------------------------
+// The filtered candidate path on the work list the probing kernels (or, on the owner side of Mode K, owner_entries_kernel) left
+// in list 6: filter -> counting -> [segmented sort -> scan of the sorted lists].  poolEntries: entries of ws.bigPool (slices + overflow).
+static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
+                             const uint32_t* taxkey, bool compact, bool second, uint64_t poolEntries, hipStream_t st)
+{
+    int rc = MC_OK;
+    const uint32_t n = b.n;
+    { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
+    // host's look at the counters: always launched, returns at once with nothing to do)
+    if (second || compact) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    if (compact) {
+        // filtered lists the counting kernels do not take (long reads: thousands of numbers, wide window ranges) are sorted --
+        // one segmented sort over the pool -- and scanned (gw_sorted_cands_kernel); the filter kernels counted them
+        if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
+        uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
+        HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (*nsorted) {
+            if ((rc = ensure(ctx, P.bBigPool2, poolEntries * 4))) return rc;
+            ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
+            size_t tmpBytes = 0;
+            if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, ctx->gwBits, st) != 0)
+                return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
+            if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
+            {
+                ScopedTimer t(ctx, "gw_sort", st);
+                if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, ctx->gwBits, st) != 0)
+                    return fail(ctx, MC_ERR_HIP, "segmented sort failed");
+            }
+            { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+        }
+    }
+    return MC_OK;
+}
+
 static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st);
 
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
@@ -664,6 +702,11 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         } else {
             { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
             { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
+            // a key shard's side of Mode K: only the features this shard owns are looked up (the others cannot be in its table)
+            if (wantPartial && !wantFeatures && ctx->cfg.key_shard_count > 1) {
+                ScopedTimer t(ctx, "mask_features", st);
+                launch_mask_foreign_features(ws.features, ws.winOff + n, sp.s, nfeat, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count, st);
+            }
             { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, ctx->quadLookup, st); }
             { ScopedTimer t(ctx, "probe_cands", st); launch_probe_cands(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st); }
         }
@@ -693,34 +736,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             waveDone = true;
         }
         if (hcnt[9] || waveDone) {
-            { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-            // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
-            // host's look at the counters: always launched, returns at once with nothing to do)
-            if (hcnt[10] || T.compact) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-            { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-            { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-            if (T.compact) {
-                // filtered lists the counting kernels do not take (long reads: thousands of numbers, wide window ranges) are sorted --
-                // one segmented sort over the pool -- and scanned (gw_sorted_cands_kernel); the filter kernels counted them
-                if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
-                uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
-                HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(ctx, hipStreamSynchronize(st));
-                if (*nsorted) {
-                    if ((rc = ensure(ctx, P.bBigPool2, (poolCap + ovfCap) * 4))) return rc;
-                    ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
-                    size_t tmpBytes = 0;
-                    if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap + ovfCap, ws, n, ctx->gwBits, st) != 0)
-                        return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
-                    if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
-                    {
-                        ScopedTimer t(ctx, "gw_sort", st);
-                        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolCap + ovfCap, ws, n, ctx->gwBits, st) != 0)
-                            return fail(ctx, MC_ERR_HIP, "segmented sort failed");
-                    }
-                    { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-                }
-            }
+            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st))) return rc;
         }
         waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
         skipWaveSketch = waveDone;
@@ -870,6 +886,123 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     out->hit_offsets = ws.hitOff;
     out->hits = (const mc_location*)ws.hits;
     out->features = nullptr; out->win_offsets = nullptr;
+    return MC_OK;
+}
+
+// ---- Mode K with 4-byte locations on the wire (keyshard.hip) --------------------------------------------------------------------------
+// shard side: the partial lists of the last mc_query_device(MC_WANT_PARTIAL_HITS) call as global window numbers + per-read counts
+int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t n, const uint32_t* cutQueries, uint32_t numCuts, uint64_t* cutOffsets,
+                       mc_device_partial_numbers* out, void* streamv)
+{
+    if (!ctx || !res || !out || (numCuts && (!cutQueries || !cutOffsets))) return MC_ERR_INVALID;
+    if (!res->hit_offsets) return fail(ctx, MC_ERR_STATE, "mc_partial_numbers: the results hold no location lists (MC_WANT_PARTIAL_HITS)");
+    if (ctx->parts.size() != 1 || !ctx->parts[0].compact || !ctx->dGwBase)
+        return fail(ctx, MC_ERR_UNSUPPORTED, "mc_partial_numbers: the database has no global window numbers (compact location store)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Pipe& P = ctx->pipe0;
+    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    for (uint32_t i = 0; i < numCuts; ++i) {
+        if (cutQueries[i] > n) return fail(ctx, MC_ERR_INVALID, "mc_partial_numbers: cut beyond the batch");
+        HIP_TRY(ctx, hipMemcpyAsync(&cutOffsets[i], res->hit_offsets + cutQueries[i], 8, hipMemcpyDeviceToHost, st));
+    }
+    uint64_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, res->hit_offsets + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));                    // the one host round trip of the exchange: its split sizes
+    int rc;
+    if ((rc = ensure(ctx, P.bNumbers, (size_t)(total + 8) * 4)) || (rc = ensure(ctx, P.bCounts, (size_t)(n + 1) * 4))) return rc;
+    DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
+    tab.gwBase = ctx->dGwBase; tab.gwDir = ctx->dGwDir; tab.gwDirShift = ctx->gwDirShift; tab.gwGap = ctx->gwGap; tab.gwTargets = ctx->gwTargets;
+    {
+        ScopedTimer t(ctx, "pack_numbers", st);
+        launch_pack_numbers(reinterpret_cast<const uint64_t*>(res->hits), res->hit_offsets, total, n, tab, (uint32_t*)P.bNumbers.p, (uint32_t*)P.bCounts.p, st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    out->counts = (const uint32_t*)P.bCounts.p;
+    out->numbers = (const uint32_t*)P.bNumbers.p;
+    out->total = total;
+    return MC_OK;
+}
+
+// owner side: rows 8-10 on the pieces the key shards sent for this rank's reads, where they lie in the receive buffer
+int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numbers_in* in, int lowestRank, mc_device_results* out, void* streamv)
+{
+    if (!ctx || !in || !out || !in->counts || !in->source_offsets || in->num_sources < 1 || in->num_sources > 64) return MC_ERR_INVALID;
+    if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
+    if (ctx->parts.size() != 1 || !ctx->parts[0].compact || !ctx->dGwBase)
+        return fail(ctx, MC_ERR_UNSUPPORTED, "mc_candidates_from_partial_numbers: the database has no global window numbers (compact location store)");
+    const uint32_t n = in->num_queries, S = in->num_sources;
+    const uint32_t K = ctx->cfg.max_candidates;
+    if (!lane_candidates_supported(K)) return fail(ctx, MC_ERR_UNSUPPORTED, "mc_candidates_from_partial_numbers: max_candidates above 4");
+    if ((uint64_t)n * S > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "mc_candidates_from_partial_numbers: batch too large");
+    const uint64_t totalIn = in->source_offsets[S];
+    if (totalIn && !in->numbers) return MC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Pipe& P = ctx->pipe0;
+    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    const uint32_t* taxkey = nullptr;
+    int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
+    if (rc) return rc;
+    const uint64_t avg = totalIn / std::max<uint32_t>(n, 1);
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(std::max<uint64_t>((uint64_t)n * 448, totalIn / 2),
+                                                                                  (uint64_t)big_filter_grid(n) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, avg))));
+    const uint64_t ovfCap = std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20));
+    if ((rc = ensure(ctx, P.bPsize, ((size_t)n * S + 4) * 4)) || (rc = ensure(ctx, P.bPpay, ((size_t)n * S + (size_t)S * (n + 2) + 4) * 8)) ||
+        (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) || (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) ||
+        (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
+        (rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)) ||
+        (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * 4)) || (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n) * 4 * 4 + 64)) ||
+        (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4)) ||
+        (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
+        return rc;
+    Workspace ws{};
+    ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
+    uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
+    ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
+    ws.scanTmp = P.bScan.p;
+    ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32;
+    ws.bigMin = ctx->bigMin;
+    ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap; ws.bigOvfCap = (uint32_t)ovfCap;
+    ws.sliceFill = (uint32_t*)P.bSliceFill.p; ws.sideList = (uint32_t*)P.bSide.p;
+    BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
+    // the receive buffer stands in for the table's location store
+    DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
+    tab.values32 = in->numbers;
+    tab.gwBase = ctx->dGwBase; tab.gwDir = ctx->dGwDir; tab.gwDirShift = ctx->gwDirShift; tab.gwGap = ctx->gwGap; tab.gwTargets = ctx->gwTargets;
+    KeyshardBases bases{};
+    for (uint32_t s = 0; s < S; ++s) bases.b[s] = in->source_offsets[s];
+    HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
+    {
+        ScopedTimer t(ctx, "owner_entries", st);
+        for (uint32_t s = 0; s < S; ++s) launch_scan_u32(in->counts + (size_t)s * n, 1, n, nullptr, srcStart + (size_t)s * (n + 1), ws.scanTmp, st);
+        launch_owner_entries(b, tab, ws, in->counts, srcStart, bases, S, st);
+    }
+    const SketchParams one{16, 1, 16, 1};
+    if ((rc = run_filtered_path(ctx, P, b, one, tab, ws, K, taxkey, true, true, poolCap + ovfCap, st))) return rc;
+    // what is left (short lists, reads the filtered path handed back): decoded to (target, window) lists and sorted
+    launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
+    if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
+    HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(P.hTotal + 10, ws.midCount + 9, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->ownerStats[0] += n; ctx->ownerStats[1] += *reinterpret_cast<const uint32_t*>(P.hTotal + 10); ctx->ownerStats[2] += totalIn; ctx->ownerStats[3] += *P.hTotal;
+    const size_t hb = (size_t)(*P.hTotal + 1) * 8;
+    if ((rc = ensure(ctx, P.bHits, hb)) || (rc = ensure(ctx, P.bCscr, hb)) || (taxkey && (rc = ensure(ctx, P.bCscr2, hb)))) return rc;
+    ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
+    { ScopedTimer t(ctx, "decode_union", st); launch_decode_union(b, tab, ws, in->counts, srcStart, bases, S, st); }
+    DeviceTable none{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
+    { ScopedTimer t(ctx, "cands_from_hits", st); launch_cands_from_hits(b, none, ws, taxkey, K, P.bCands.p, st); }
+    HIP_TRY(ctx, hipGetLastError());
+    P.lastN = 0;
+    out->cands = (const mc_candidate*)P.bCands.p;
+    out->hit_counts = (const uint32_t*)P.bQstat.p;
+    out->hit_offsets = nullptr; out->hits = nullptr; out->features = nullptr; out->win_offsets = nullptr;
+    return MC_OK;
+}
+
+int mc_owner_stats(const mc_ctx* ctx, uint64_t stats[4])
+{
+    if (!ctx || !stats) return MC_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) stats[i] = ctx->ownerStats[i];
     return MC_OK;
 }
 

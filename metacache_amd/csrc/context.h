@@ -20,7 +20,8 @@ struct DevBuf {                 // grow-only device allocation
 struct Pipe {                   // the device workspace of ONE batch in flight + the stream its work is enqueued on
     hipStream_t stream = nullptr;
     DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
-        bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide;
+        bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide,
+        bNumbers, bCounts;   // Mode K shard side: the partial lists as global window numbers + per-read counts (mc_partial_numbers)
     uint32_t lastN = 0;
     uint64_t* hTotal = nullptr;   // pinned: the one host round trip of a batch lands here (a pageable target makes the copy blocking)
 };
@@ -121,6 +122,8 @@ struct mc_ctx {
     bool fuseLane = false;                 // sketching + probing of the lane path in ONE kernel (MC_LANE_FUSION=1); measured
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on
                                            // strain-rich tables -- off by default
+
+    uint64_t ownerStats[4] = {0, 0, 0, 0}; // mc_owner_stats: reads, reads on the filtered path, numbers received, locations decoded for the sort
 
     // timing
     bool timing = false;

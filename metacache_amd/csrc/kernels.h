@@ -218,6 +218,15 @@ void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Wo
 void launch_union_partial(const uint32_t* counts, uint32_t sources, uint32_t m, const uint64_t* hits, uint32_t* tot, uint64_t* srcStart, uint64_t* hitOff,
                           uint64_t* out, void* scanTmp, hipStream_t st);
 void launch_owner_classify(const BatchView& b, const Workspace& ws, uint32_t minLen, hipStream_t st);
+// keyshard.hip: Mode K with 4-byte locations (global window numbers) on the wire
+struct KeyshardBases { uint64_t b[64]; };   // where each source's block begins in the receive buffer (at most 64 key shards)
+void launch_mask_foreign_features(uint32_t* features, const uint32_t* totalWindows, uint32_t s, uint64_t maxFeat, uint32_t shardIdx, uint32_t shardCnt, hipStream_t st);
+void launch_pack_numbers(const uint64_t* hits, const uint64_t* hitOff, uint64_t total, uint32_t n, const DeviceTable& tab, uint32_t* numbers, uint32_t* counts,
+                         hipStream_t st);
+void launch_owner_entries(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* counts, const uint64_t* srcStart,
+                          const KeyshardBases& bases, uint32_t S, hipStream_t st);
+void launch_decode_union(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* counts, const uint64_t* srcStart,
+                         const KeyshardBases& bases, uint32_t S, hipStream_t st);
 extern int g_gwDiag;                      // timing experiments on gw_filter_kernel (mc_set_tuning "gw_diag")
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);

@@ -44,6 +44,9 @@ struct Options {
     uint32_t residentParts = 0;          // -resident-parts n (this program's own): a partitioned database n parts at a time, the next group loading behind
                                          // the queries (mc_partset_*; the reference's workflow: one query run per part + merge, docs/partitioning.md:116-153)
     std::vector<int32_t> gpus;           // -gpus a,b,...: the resident parts dealt out over these GPUs, per-part candidates gathered over RCCL
+    bool shardKeys = false;              // -shard keys: ONE database key-sharded over the GPUs of -gpus (mc_keyset_*: every GPU holds the features it owns, the partial
+                                         // location lists travel over RCCL to the GPU that owns the read); -shard parts = the default of -gpus (parts over GPUs)
+    uint32_t keyShards = 0;              // -key-shards n: number of key shards (default: one per GPU of -gpus; more than one per GPU on a single device)
     uint32_t replication = 1;            // -replicate: copies of the table on GPUs 0 .. n-1, the workers are dealt out over them (options.cpp:1155-1163)
     uint32_t refBatchSize = 0;           // -batch-size as given (the reference's batches matter for -cov-percentile)
     int maxLocs = -1, threads = 0;
@@ -127,6 +130,11 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-threads") o.threads = std::stoi(need(i));
         else if (a == "-replicate") o.replication = (uint32_t)std::max(1, std::stoi(need(i)));
         else if (a == "-resident-parts") o.residentParts = (uint32_t)std::max(1, std::stoi(need(i)));
+        else if (a == "-shard") {
+            const std::string v = need(i);
+            if (v == "keys") o.shardKeys = true; else if (v == "parts") o.shardKeys = false; else throw std::runtime_error("-shard parts|keys");
+        }
+        else if (a == "-key-shards") o.keyShards = (uint32_t)std::max(1, std::stoi(need(i)));
         else if (a == "-gpus") {
             std::stringstream ss(need(i));
             for (std::string t; std::getline(ss, t, ',');) if (!t.empty()) o.gpus.push_back((int32_t)std::stoi(t));
@@ -322,9 +330,10 @@ struct Session {
     std::vector<mc_ctx*> replicas;                   // -replicate n: the same table on the GPUs 1 .. n-1 (ctx is the one on GPU 0)
     uint32_t replication = 1;
     mc_partset* partset = nullptr;                   // -resident-parts / -gpus: the parts as contexts of their own (ctx then holds the metadata only)
+    mc_keyset* keyset = nullptr;                     // -shard keys: key shards as contexts of their own (ctx holds the metadata only)
     mc_ctx* replica(unsigned i) const { return i == 0 ? ctx : replicas[i - 1]; }
     void close_replicas() { for (mc_ctx* r : replicas) mc_destroy(r); replicas.clear(); }
-    ~Session() { close_replicas(); if (partset) mc_partset_close(partset); if (ctx) mc_destroy(ctx); }
+    ~Session() { close_replicas(); if (partset) mc_partset_close(partset); if (keyset) mc_keyset_close(keyset); if (ctx) mc_destroy(ctx); }
 
     BuiltDatabase* built = nullptr;                  // build+query: the table comes from the builder's device arrays, not from files
     std::vector<uint32_t> builtLineages;
@@ -359,20 +368,25 @@ struct Session {
             c.remove_overpopulated = (uint32_t)maxlpf;                             // clamped to the DB's cap - 1 by mc_open_database
             c.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
         } else if (o.maxLocs > 1) c.max_locations_per_feature = (uint32_t)o.maxLocs;
-        const bool wantSet = !built && (o.residentParts > 0 || !o.gpus.empty());
-        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0 && replication == nrep && !wantSet && !partset) return;  // same table, same slots: keep it
+        const bool wantKeys = !built && o.shardKeys;
+        const bool wantSet = !built && (o.residentParts > 0 || !o.gpus.empty() || wantKeys);
+        if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0 && replication == nrep && !wantSet && !partset && !keyset) return;  // same table, same slots: keep it
         close_replicas();
         if (partset) { mc_partset_close(partset); partset = nullptr; }
+        if (keyset) { mc_keyset_close(keyset); keyset = nullptr; }
         if (ctx) { mc_destroy(ctx); ctx = nullptr; }
         replication = nrep;
         tx = Taxonomy{};
         if (wantSet) {
             if (o.allhits || o.maxCand < 1 || o.maxCand > 4 || o.covPercentile > 0)
-                throw std::runtime_error("-resident-parts / -gpus: top candidates only (-maxcand 1..4, no -allhits, no -cov-percentile)");
+                throw std::runtime_error("-resident-parts / -gpus / -shard: top candidates only (-maxcand 1..4, no -allhits, no -cov-percentile)");
             c.num_slots = 1;
             c.slot_max_queries = std::max<uint32_t>(o.batchSize, 1u << 16);
             c.slot_max_chars = std::max<uint32_t>(1u << 24, c.slot_max_queries * 320u);
-            if (mc_partset_open(o.db.c_str(), &c, o.residentParts, o.gpus.empty() ? nullptr : o.gpus.data(), (uint32_t)o.gpus.size(), &partset) != MC_OK)
+            if (wantKeys) {
+                if (mc_keyset_open(o.db.c_str(), &c, o.keyShards, o.gpus.empty() ? nullptr : o.gpus.data(), (uint32_t)o.gpus.size(), &keyset) != MC_OK)
+                    throw std::runtime_error(mc_keyset_last_error(nullptr));
+            } else if (mc_partset_open(o.db.c_str(), &c, o.residentParts, o.gpus.empty() ? nullptr : o.gpus.data(), (uint32_t)o.gpus.size(), &partset) != MC_OK)
                 throw std::runtime_error(mc_partset_last_error(nullptr));
             if (mc_open_metadata(o.db.c_str(), &ctx) != MC_OK) throw std::runtime_error(mc_last_error(nullptr));
             uint64_t nt = 0; mc_db_num_taxa(ctx, &nt); tx.taxa.resize(nt);
@@ -830,8 +844,12 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             const uint32_t K = cfg.max_candidates;
             std::vector<mc_candidate> all(n * K);
             seq1.push_back('\0'); seq2.push_back('\0');
-            if (n && mc_partset_classify(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
-                                         o.insertMax, all.data()) != MC_OK)
+            if (n && S.keyset) {
+                if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                       o.insertMax, all.data()) != MC_OK)
+                    throw std::runtime_error(mc_keyset_last_error(S.keyset));
+            } else if (n && mc_partset_classify(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                                o.insertMax, all.data()) != MC_OK)
                 throw std::runtime_error(mc_partset_last_error(S.partset));
             Acc A;
             std::vector<Cand> cands;
@@ -861,7 +879,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             }
             collect(A);
         };
-        if (S.partset) {
+        if (S.partset || S.keyset) {
             produce();                                                           // (all batches known first: no overlap to win here)
             if (!producerError.empty()) throw std::runtime_error(producerError);
             work_partset();

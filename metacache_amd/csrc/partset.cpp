@@ -12,11 +12,9 @@
 // list the earlier groups left for the read.  The result is what one candidate list fed by all parts in order holds: the intended
 // semantics of host_hashmap.hpp:695-723 (the in-process reference itself is history dependent for more than one part).
 //
-// RCCL is loaded at run time (dlopen librccl.so.1): the library has no link-time dependency on it, and a process that already carries
-// an RCCL (PyTorch) shares that one.
+// RCCL is loaded at run time (rccl_dl.h).
 #include "context.h"
-
-#include <dlfcn.h>
+#include "rccl_dl.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -29,35 +27,7 @@ using namespace mcamd;
 
 namespace {
 
-// ---- the few RCCL entry points used (rccl.h: ncclResult_t = int, ncclComm_t = opaque pointer, ncclChar = 0)
-struct Rccl {
-    void* lib = nullptr;
-    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
-    int (*CommDestroy)(void* comm) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    std::string err;
-    bool load()
-    {
-        if (lib) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
-        if (!lib) { err = "RCCL not found (librccl.so.1)"; return false; }
-        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("RCCL symbol missing: ") + n; return p; };
-        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
-        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
-        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
-        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
-        AllGather = (decltype(AllGather))sym("ncclAllGather");
-        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather;
-    }
-};
-Rccl g_rccl;
+Rccl& g_rccl = rccl();                 // rccl_dl.h
 
 struct DevState {                      // per device: the batch's input, the parts' candidate lists, the gathered lists
     int device = 0;

@@ -267,9 +267,13 @@ def exchange_partial_lists(offsets: torch.Tensor, hits: torch.Tensor, group=None
     return recv_counts, recv_hits[:total], total
 
 
-def classify_key_sharded_device(db, res, n: int, K: int, max_win_uniform: int, lowest: int = 0, group=None) -> torch.Tensor:
+def classify_key_sharded_device(db, res, n: int, K: int, max_win_uniform: int, lowest: int = 0, group=None, wire: int = 4) -> torch.Tensor:
     """Mode K for one batch on this rank's GPU: res = db.query_device(..., want_partial_hits=True) (or want_allhits) of the key-sharded
-    context db over all n reads.  Returns int32 [m, K, 4] for this rank's read shard (gather_candidates hands the shards to rank 0)."""
+    context db over all n reads.  Returns int32 [m, K, 4] for this rank's read shard (gather_candidates hands the shards to rank 0).
+    wire = 4 (default): the lists travel as 4-byte global window numbers (mc_partial_numbers / mc_candidates_from_partial_numbers; falls
+    back to 8 when the table has no such numbering); wire = 8: as (target, window) pairs (mc_candidates_from_partial_hits)."""
+    if wire == 4 and db.table_layout()["location_bytes"] == 4:
+        return classify_key_sharded_numbers(db, res, n, K, max_win_uniform, lowest=lowest, group=group)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     device = torch.device("cuda", db.cfg.device)
@@ -283,6 +287,66 @@ def classify_key_sharded_device(db, res, n: int, K: int, max_win_uniform: int, l
     lo, hi = shard_bounds(n, rank, world)
     m = hi - lo
     r2 = db.candidates_from_partial_hits(counts.data_ptr(), rhits.data_ptr() if total else 0, total, m, world, max_win_uniform=max_win_uniform, lowest=lowest)
+    out = torch.empty((m, K, 4), dtype=torch.int32, device=device)
+    db.copy_results(out.data_ptr(), r2.cands, m * K * 16)
+    db.synchronize()
+    return out
+
+
+def exchange_numbers(counts: torch.Tensor, numbers: torch.Tensor, cut_offsets, n: int, group=None):
+    """The all-to-all-v of Mode K with 4-byte locations.  counts int32 [n] / numbers int32 [total]: this rank's partial lists for the
+    WHOLE batch (numbers back to back in read order); cut_offsets (host, [world + 1]): where each rank's read shard begins in numbers --
+    known on the host without another device round trip (mc_partial_numbers).  -> (recv_counts int32 [world * m] source-major,
+    recv_numbers int32 [total_recv + 4], source_offsets list [world + 1]) for this rank's m reads."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    send_elems = [int(cut_offsets[r + 1]) - int(cut_offsets[r]) for r in range(world)]
+    if world == 1:
+        pad = torch.zeros(numbers.numel() + 4, dtype=numbers.dtype, device=numbers.device)     # (the owner's kernels read 16 bytes past the end)
+        pad[: numbers.numel()] = numbers
+        return counts, pad, [0, send_elems[0]]
+    bounds = [shard_bounds(n, r, world) for r in range(world)]
+    m = bounds[rank][1] - bounds[rank][0]
+    sizes = torch.tensor(send_elems, dtype=torch.int64, device=counts.device)
+    rsizes = torch.empty_like(sizes)
+    dist.all_to_all_single(rsizes, sizes, group=group)                       # every rank learns what it will receive
+    recv_elems = [int(x) for x in rsizes.cpu()]
+    recv_counts = torch.empty(world * m, dtype=counts.dtype, device=counts.device)
+    dist.all_to_all_single(recv_counts, counts.contiguous(), output_split_sizes=[m] * world, input_split_sizes=[b[1] - b[0] for b in bounds], group=group)
+    total = sum(recv_elems)
+    recv_numbers = torch.zeros(total + 4, dtype=numbers.dtype, device=numbers.device)
+    dist.all_to_all_single(recv_numbers[:total], numbers.contiguous(), output_split_sizes=recv_elems, input_split_sizes=send_elems, group=group)
+    so = [0]
+    for e in recv_elems:
+        so.append(so[-1] + e)
+    return recv_counts, recv_numbers, so
+
+
+def classify_key_sharded_numbers(db, res, n: int, K: int, max_win_uniform: int, lowest: int = 0, group=None, max_win: torch.Tensor | None = None) -> torch.Tensor:
+    """Mode K with 4-byte locations on the wire (the torch.distributed form of what metacache_amd/csrc/keyset.cpp does inside one
+    process): shard side mc_partial_numbers, all-to-all-v of counts and numbers, owner side mc_candidates_from_partial_numbers --
+    no union copy, the receive buffer is the owner's location store.  max_win: per-read window ranges of the WHOLE batch (int32 [n]) or
+    None with max_win_uniform."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    device = torch.device("cuda", db.cfg.device)
+    bounds = [shard_bounds(n, r, world) for r in range(world)]
+    part, cuts = db.partial_numbers(res, n, [b[0] for b in bounds] + [n])
+    db.synchronize()                                                         # the pack kernel ran on the context's stream, the collectives run on torch's
+    counts = torch.empty(n, dtype=torch.int32, device=device)
+    numbers = torch.empty(max(int(part.total), 1), dtype=torch.int32, device=device)
+    db.copy_results(counts.data_ptr(), part.counts, n * 4)
+    if part.total:
+        db.copy_results(numbers.data_ptr(), part.numbers, int(part.total) * 4)
+    db.synchronize()
+    rc, rn, so = exchange_numbers(counts, numbers[: int(part.total)], cuts, n, group=group)
+    if device.type == "cuda" and torch.cuda.is_available():
+        torch.cuda.current_stream(device).synchronize()                      # the receive buffers are complete before the owner's kernels read them
+    lo, hi = bounds[rank]
+    m = hi - lo
+    mw = max_win[lo:hi].contiguous() if max_win is not None else None
+    r2 = db.candidates_from_partial_numbers(rc.data_ptr(), rn.data_ptr(), so, m, max_win_ptr=mw.data_ptr() if mw is not None else 0,
+                                            max_win_uniform=0 if mw is not None else max_win_uniform, lowest=lowest)
     out = torch.empty((m, K, 4), dtype=torch.int32, device=device)
     db.copy_results(out.data_ptr(), r2.cands, m * K * 16)
     db.synchronize()

@@ -217,6 +217,24 @@ def test_cli_resident_parts_single_part_equals_reference(tmp_path, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,shards", [("default", 3), ("pairseq_insert", 2), ("mapped_only_vote", 4), ("two_files", 3), ("precision", 1)])
+def test_cli_key_shards_equal_reference(tmp_path, case, shards):
+    """-shard keys (mc_keyset_*: ONE database key-sharded, every shard looks up the features it owns, partial location lists as 4-byte
+    numbers to the read's owner, candidates there): the output must be the reference's, line by line.  One GPU: the shards share it;
+    shards = 1 runs the exchange through RCCL (a rank that sends to itself)."""
+    build.build_library()
+    c = CASES[case]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-shard", "keys", "-key-shards", str(shards), "-gpus", "0", "-out", str(out)]
+    env = dict(os.environ, MC_KEYSET_RCCL="1") if shards == 1 else None
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in out.read_text().split("\n") if not _volatile(l) and "threads" not in l]
+    exp = [l for l in c["lines"] if not _volatile(l) and "threads" not in l]
+    assert got == exp
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("resident", [1, 2, 3])
 def test_cli_resident_parts_equal_all_parts_resident(tmp_path, resident):
     """the four-part fixture, `resident` parts in HBM at a time: the same output as with every part in one table"""

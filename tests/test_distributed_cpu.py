@@ -184,6 +184,14 @@ def _worker_mode_k(rank, world, port, n, K, q):
     cnt32, rh, total = exchange_partial_lists(offs_t, hits_t)
     assert torch.equal(cnt32.view(world, -1).to(torch.int64), psc) and total == sum(int(x.numel()) for x in psh)
     assert torch.equal(rh, torch.cat(psh) if total else rh)
+    # ... and so must the exchange of the 4-byte wire (numbers instead of (target, window) pairs; split sizes from the host-side cuts)
+    from metacache_amd.distributed import exchange_numbers
+    num_t = (hits_t & 0x7FFFFFFF).to(torch.int32)
+    bnds = [shard_bounds(n, r, world) for r in range(world)]
+    cuts = [int(offs_t[b[0]]) for b in bnds] + [int(offs_t[n])]
+    rc4, rn4, so4 = exchange_numbers(counts_t.to(torch.int32), num_t, cuts, n)
+    assert torch.equal(rc4, cnt32) and so4[-1] == total and torch.equal(rn4[:total], (rh & 0x7FFFFFFF).to(torch.int32))
+    assert [so4[i + 1] - so4[i] for i in range(world)] == [int(x.numel()) for x in psh]
     local = classify_key_sharded(counts_t, hits_t, candidates)
     parts = gather_candidates(local, dst=0)
     if rank == 0:

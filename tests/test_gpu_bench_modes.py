@@ -22,7 +22,7 @@ def _run(extra):
 
 
 @pytest.mark.parametrize("extra", [[], ["--pairs"], ["--mode", "P", "--force-dist"], ["--mode", "P", "--pairs", "--force-dist"],
-                                   ["--mode", "K", "--force-dist"], ["--mode", "K", "--pairs", "--force-dist"], ["--config", "1", "--batch", "200000", "--genome-len", "200000"],
+                                   ["--mode", "K", "--force-dist"], ["--mode", "K", "--pairs", "--force-dist"], ["--mode", "K", "--wire", "8", "--force-dist"], ["--config", "1", "--batch", "200000", "--genome-len", "200000"],
                                    ["--long-reads", "--batch", "3000"]])
 def test_bench_line_and_parity(extra):
     res = _run(extra)

@@ -72,11 +72,12 @@ def main():
     # ---- Mode K: this rank holds the features it owns; partial lists -> all-to-all -> union kernel -> candidates
     for lowest in (0, 4):
         dbk = api.Database.open(os.path.join(gold, "toy32"), device=local, max_candidates=K, key_shard_index=rank, key_shard_count=world)
-        res = dbk.query_device(seq.data_ptr(), qinfo.data_ptr(), n, nchars, max_win_uniform=mw, want_partial_hits=(lowest == 0), want_allhits=(lowest != 0))
-        local_c = classify_key_sharded_device(dbk, res, n, K, mw, lowest=lowest)
-        parts = gather_candidates(local_c)
-        if rank == 0:
-            compare(torch.cat(parts, dim=0), odb, lowest)
+        for wire in (8, 4):                                        # (target, window) pairs, then 4-byte global window numbers
+            res = dbk.query_device(seq.data_ptr(), qinfo.data_ptr(), n, nchars, max_win_uniform=mw, want_partial_hits=(lowest == 0), want_allhits=(lowest != 0))
+            local_c = classify_key_sharded_device(dbk, res, n, K, mw, lowest=lowest, wire=wire)
+            parts = gather_candidates(local_c)
+            if rank == 0:
+                compare(torch.cat(parts, dim=0), odb, lowest)
         dbk.close()
     odb.close()
     # ---- Mode P: rank r holds part r % 2 of the 2-part database (world 1: both parts one after the other), merge per read
