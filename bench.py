@@ -55,6 +55,7 @@ PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
            "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan",
            "sort_candidates")
+KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
 PMC_NAMES = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "sketch_probe": ("sketch_probe_lane",),
              "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",),
              "big_filter": ("big_filter",), "big_count": ("big_count",), "big_count_2": ("big_count_2",), "hash_cands_256": ("hash_cands_256", "hash_cands"),
@@ -581,6 +582,7 @@ def main():
     works = [None] * nbuf
     torch.cuda.synchronize()
     from metacache_amd.distributed import classify_key_sharded_device, classify_partitioned
+    numbers_wire = mode == "K" and args.wire == 4 and db.table_layout()["location_bytes"] == 4     # the lists leave the shard as the 4-byte numbers they are stored as
 
     def finish(j: int):
         if works[j] is not None:
@@ -593,7 +595,8 @@ def main():
         j = i % nbuf
         finish(j)                                            # the gather that used this buffer two batches ago
         if mode == "K":
-            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=True)
+            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=not numbers_wire,
+                                  want_partial_numbers=numbers_wire)
             out_bufs[j].copy_(classify_key_sharded_device(db, res, nloc, K, max_win, wire=args.wire))   # all-to-all of the partial lists, rows 8-10 on the owner
             torch.cuda.current_stream().synchronize()
         elif args.long_reads:
@@ -644,7 +647,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kt = {k: db.timing_get(k) for k in KERNELS}
+        kt = {k: db.timing_get(k) for k in KERNELS + (KERNELS_MODE_K if mode == "K" else ())}
         st = db.last_batch_stats()                            # of the last timed batch
         layout = db.table_layout()
         if cfg != 1:

@@ -209,6 +209,9 @@ typedef struct {
 #define MC_WANT_FEATURES 2   /* keep the window sketches (features) */
 #define MC_WANT_PARTIAL_HITS 4 /* keep the location lists (hit_offsets / hits) in ANY order inside a list: what a key-sharded context hands to
                                  the exchange of Mode K (the owner sorts the union); unlike MC_WANT_ALLHITS this keeps the fast lane path */
+#define MC_WANT_PARTIAL_NUMBERS 16 /* as MC_WANT_PARTIAL_HITS on a table with the compact location store, the lists left as the 4-byte global
+                                 window numbers they are stored as: hit_offsets is filled, hits only for the reads the wave kernels took --
+                                 mc_partial_numbers hands the numbers out (no decoding to (target, window) and back: 5.5 -> 0.6 ms per 10^6 reads) */
 #define MC_SECOND_PIPE 8     /* run on the context's SECOND pipe (own stream, workspace and result buffers): one more caller thread may have a
                                  call in flight there while another runs on the first pipe, so the kernels of two batches overlap on the
                                  device the way several query_batch objects do in the reference (query_batch.cuh:369-371).  The

@@ -291,10 +291,10 @@ class Database:
     # ---- device path (pointers are device addresses, e.g. torch tensors' data_ptr()) ----------
     def query_device(self, seq_ptr: int, qinfo_ptr: int, n: int, num_chars: int, max_win_ptr: int = 0, max_win_uniform: int = 0,
                      lowest: int = 0, want_allhits: bool = False, want_features: bool = False,
-                     stream: int = 0, want_partial_hits: bool = False, second_pipe: bool = False) -> McDeviceResults:
+                     stream: int = 0, want_partial_hits: bool = False, second_pipe: bool = False, want_partial_numbers: bool = False) -> McDeviceResults:
         b = McDeviceBatch(seq_ptr, qinfo_ptr, max_win_ptr or None, max_win_uniform, n, num_chars)
         r = McDeviceResults()
-        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0) | (4 if want_partial_hits else 0) | (8 if second_pipe else 0), C.byref(r),
+        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0) | (4 if want_partial_hits else 0) | (8 if second_pipe else 0) | (16 if want_partial_numbers else 0), C.byref(r),
                                           stream or None))
         return r
 

@@ -612,13 +612,18 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
 {
     // MC_WANT_PARTIAL_HITS: the location lists as they are (unsorted), lane path allowed -- a key shard's side of Mode K; the queries the
     // lane path does not take go through the wave kernels as with MC_WANT_ALLHITS (their lists come out sorted, which is allowed)
-    const bool wantPartial = (flags & MC_WANT_PARTIAL_HITS) != 0 && !(flags & MC_WANT_ALLHITS);
+    // MC_WANT_PARTIAL_NUMBERS: the same, and the lists are left as the 4-byte global window numbers they are stored as (mc_partial_numbers)
+    const bool wantNumbers = (flags & MC_WANT_PARTIAL_NUMBERS) != 0 && !(flags & MC_WANT_ALLHITS);
+    const bool wantPartial = ((flags & MC_WANT_PARTIAL_HITS) != 0 || wantNumbers) && !(flags & MC_WANT_ALLHITS);
     const int wantAllhits = (flags & MC_WANT_ALLHITS) | (wantPartial ? 1 : 0);
     const bool wantFeatures = (flags & MC_WANT_FEATURES) != 0;
     if (!ctx->tableReady) return fail(ctx, MC_ERR_STATE, "no database loaded (every part needs mc_load_begin .. mc_load_end)");
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
+    if (wantNumbers && (ctx->parts.size() != 1 || !ctx->parts[0].compact || !ctx->dGwBase))
+        return fail(ctx, MC_ERR_UNSUPPORTED, "MC_WANT_PARTIAL_NUMBERS: the database has no global window numbers (compact location store)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n = in->num_queries;
+    P.numbersN = 0xFFFFFFFFu;
     const SketchParams sp = ctx->querySketch;
     const uint32_t K = ctx->cfg.max_candidates;
     const uint32_t* taxkey = nullptr;
@@ -764,10 +769,17 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if ((rc = ensure(ctx, P.bCscr, hb))) return rc;
         if (taxkey && (rc = ensure(ctx, P.bCscr2, hb))) return rc;
         ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
-        if (wantPartial && lanePath) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, st); }
+        if (wantNumbers && ((rc = ensure(ctx, P.bNumbers, (size_t)(totalHits + 8) * 4)) || (rc = ensure(ctx, P.bCounts, (size_t)(n + 1) * 4)))) return rc;
+        if (wantPartial && lanePath && !wantNumbers) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, nullptr, st); }
         {
             ScopedTimer t(ctx, "sort_candidates", st);
             launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits != 0, P.bCands.p, st);
+        }
+        if (wantNumbers) {
+            // what the wave kernels left in ws.hits -> numbers, then the lane path's (and the chunk lanes') lists straight from the table
+            { ScopedTimer t(ctx, "pack_numbers", st); launch_pack_other_reads(b, tab, ws, (uint32_t*)P.bNumbers.p, (uint32_t*)P.bCounts.p, st); }
+            if (lanePath) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, (uint32_t*)P.bNumbers.p, st); }
+            P.numbersN = n; P.numbersTotal = totalHits;
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -909,14 +921,18 @@ int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t n, co
     HIP_TRY(ctx, hipMemcpyAsync(&total, res->hit_offsets + n, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));                    // the one host round trip of the exchange: its split sizes
     int rc;
-    if ((rc = ensure(ctx, P.bNumbers, (size_t)(total + 8) * 4)) || (rc = ensure(ctx, P.bCounts, (size_t)(n + 1) * 4))) return rc;
-    DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
-    tab.gwBase = ctx->dGwBase; tab.gwDir = ctx->dGwDir; tab.gwDirShift = ctx->gwDirShift; tab.gwGap = ctx->gwGap; tab.gwTargets = ctx->gwTargets;
-    {
-        ScopedTimer t(ctx, "pack_numbers", st);
-        launch_pack_numbers(reinterpret_cast<const uint64_t*>(res->hits), res->hit_offsets, total, n, tab, (uint32_t*)P.bNumbers.p, (uint32_t*)P.bCounts.p, st);
+    if (P.numbersN == n && P.numbersTotal == total && res->hit_offsets == (const uint64_t*)P.bHitOff.p) {
+        // mc_query_device(MC_WANT_PARTIAL_NUMBERS) left the numbers and the counts where they belong
+    } else {
+        if ((rc = ensure(ctx, P.bNumbers, (size_t)(total + 8) * 4)) || (rc = ensure(ctx, P.bCounts, (size_t)(n + 1) * 4))) return rc;
+        DeviceTable tab{nullptr, nullptr, 0, 0xFFFFFFFFu, 1};
+        tab.gwBase = ctx->dGwBase; tab.gwDir = ctx->dGwDir; tab.gwDirShift = ctx->gwDirShift; tab.gwGap = ctx->gwGap; tab.gwTargets = ctx->gwTargets;
+        {
+            ScopedTimer t(ctx, "pack_numbers", st);
+            launch_pack_numbers(reinterpret_cast<const uint64_t*>(res->hits), res->hit_offsets, total, n, tab, (uint32_t*)P.bNumbers.p, (uint32_t*)P.bCounts.p, st);
+        }
+        HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipGetLastError());
     out->counts = (const uint32_t*)P.bCounts.p;
     out->numbers = (const uint32_t*)P.bNumbers.p;
     out->total = total;

@@ -23,6 +23,7 @@ struct Pipe {                   // the device workspace of ONE batch in flight +
         bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide,
         bNumbers, bCounts;   // Mode K shard side: the partial lists as global window numbers + per-read counts (mc_partial_numbers)
     uint32_t lastN = 0;
+    uint32_t numbersN = 0xFFFFFFFFu; uint64_t numbersTotal = 0;   // MC_WANT_PARTIAL_NUMBERS: bNumbers / bCounts hold this batch's lists already
     uint64_t* hTotal = nullptr;   // pinned: the one host round trip of a batch lands here (a pageable target makes the copy blocking)
 };
 

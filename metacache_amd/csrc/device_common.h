@@ -7,7 +7,8 @@
 namespace mcamd {
 
 // per-query state: what is still to be done (Workspace::qflag)
-constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6, kFlagGather = 7;
+constexpr uint32_t kFlagDone = 0, kFlagSketch = 1, kFlagCands = 2, kFlagProbe = 4, kFlagMid = 5, kFlagChunks = 6, kFlagGather = 7,
+                   kFlagGatherAll = 8;   // as kFlagGather, the read's entries at their feature slots (long reads of the chunk lanes)
 
 // ================================================================================================
 // wave64 primitives

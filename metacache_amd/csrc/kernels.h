@@ -204,7 +204,7 @@ void launch_wave_rejoin(const BatchView& b, const SketchParams& sp, const Device
 void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand, const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
-void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st);
+void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t* numbers, hipStream_t st);
 // gw_sort.hip: the filtered lists that are sorted instead of counted (list 7 records of the sorted class), pool -> out at the same offsets;
 // temp == nullptr: size query
 int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t endBit,
@@ -223,6 +223,8 @@ struct KeyshardBases { uint64_t b[64]; };   // where each source's block begins 
 void launch_mask_foreign_features(uint32_t* features, const uint32_t* totalWindows, uint32_t s, uint64_t maxFeat, uint32_t shardIdx, uint32_t shardCnt, hipStream_t st);
 void launch_pack_numbers(const uint64_t* hits, const uint64_t* hitOff, uint64_t total, uint32_t n, const DeviceTable& tab, uint32_t* numbers, uint32_t* counts,
                          hipStream_t st);
+// the lists of the reads that are NOT waiting for gather_lists_kernel (the wave kernels left them in ws.hits) as numbers, + all reads' counts
+void launch_pack_other_reads(const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t* numbers, uint32_t* counts, hipStream_t st);
 void launch_owner_entries(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* counts, const uint64_t* srcStart,
                           const KeyshardBases& bases, uint32_t S, hipStream_t st);
 void launch_decode_union(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* counts, const uint64_t* srcStart,

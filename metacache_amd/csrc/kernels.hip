@@ -1485,7 +1485,8 @@ __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace
                 QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nfeat;   // probe steps are not counted on this path
                 ws.qstat[q] = qs;
                 ws.hitScan[q] = (H <= kMaxHitsPerQuery && (H > kLdsCap || ws.partialLists)) ? H : 0u;   // (lists wanted: every query gets its segment)
-                ws.qflag[q] = kFlagCands;
+                // (a key shard's partial lists are wanted as they are: gather_lists_kernel copies them -- no sort of tens of thousands of locations)
+                ws.qflag[q] = ws.partialLists ? kFlagGatherAll : kFlagCands;
                 const uint32_t slots = (ws.winOff[q + 1] - ws.winOff[q]) * s, mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
                 if (tab.values32 && !ws.partialLists && H > ws.bigMin && H > 64u && H <= kMaxHitsPerQuery && slots <= 0xFFFu && mw <= tab.gwGap) {
                     const uint32_t at = atomicAdd(&ws.midCount[9], 1u);          // (one per long read: few)
@@ -1885,44 +1886,83 @@ void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, c
 }
 // Mode K, shard side: the location lists of the lane path's queries as they are (any order inside a list; the owner rank sorts the
 // union), copied from the table to ws.hits + hitOff[q].  One wave per 64 queries' flags, then one query at a time: its found
-// features (entry table of probe_cands: nfound entries from fbase on), bucket after bucket, coalesced.
-__global__ __launch_bounds__(256) void gather_lists_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
+// features (entry table of probe_cands: nfound entries from fbase on; long reads of the chunk lanes: one entry per feature slot),
+// bucket after bucket, coalesced.  NUM: the lists as they are STORED -- 4-byte global window numbers, to numbers + hitOff[q] -- no
+// decoding to (target, window) and back (mc_partial_numbers; 5.5 -> 0.6 ms per 10^6 reads of 195 locations).
+template <bool NUM>
+__global__ __launch_bounds__(256) void gather_lists_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t* __restrict__ numbers)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Flat copy: the 64 entries' sizes are scanned, then every lane takes one OUTPUT place and finds its list by a binary search over
+    // the scan in LDS (six reads) -- all places of a read are independent, two groups of 64 are in flight at a time.  (One list after the
+    // other -- 26 lists of 7 locations per read at 15 Gbp -- was a chain of 26 dependent load/store pairs: 2.5 ms per 10^6 reads.)
+    __shared__ uint32_t inclS[4][64];
+    __shared__ uint64_t payS[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* sIncl = inclS[wave];
+    uint64_t* sPay = payS[wave];
+    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + wave;
     for (uint32_t base = waveId * 64; base < b.n; base += nWaves * 64) {
         const uint32_t qq = base + lane;
-        uint64_t m = __ballot(qq < b.n && ws.qflag[qq] == kFlagGather);
+        const uint32_t fl = qq < b.n ? ws.qflag[qq] : kFlagDone;
+        uint64_t m = __ballot(fl == kFlagGather || fl == kFlagGatherAll);
+        const uint64_t mall = __ballot(fl == kFlagGatherAll);
         while (m) {
             const uint32_t j = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const uint32_t q = base + j;
-            const uint32_t fbase = ws.winOff[q] * s, nent = ws.qstat[q].nfound;
-            uint64_t* dst = ws.hits + ws.hitOff[q];
-            for (uint32_t e0 = 0; e0 < nent; e0 += 64) {
-                const uint32_t e = e0 + lane;
-                const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
-                const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
-                const uint32_t incl = wave_incl_scan_u32(sz, lane);
-                if (sz == 1) dst[incl - 1] = pay;                                  // a single location is its own payload
-                uint64_t lists = __ballot(sz > 1);
-                while (lists) {
-                    const uint32_t l = __ffsll((unsigned long long)lists) - 1;
-                    lists &= lists - 1;
-                    const uint32_t lsz = rdlane(sz, l), lat = rdlane(incl, l) - lsz;
-                    const uint64_t src = rdlane64(pay, l);
-                    for (uint32_t t = lane; t < lsz; t += 64) dst[lat + t] = tab.loc(src + t);
+            const uint32_t fbase = ws.winOff[q] * s, nent = ((mall >> j) & 1ull) ? (ws.winOff[q + 1] - ws.winOff[q]) * s : ws.qstat[q].nfound;
+            const uint64_t at = ws.hitOff[q];
+            if (ws.hitOff[q + 1] != at) {                                           // (a read beyond kMaxHitsPerQuery has no segment)
+                uint64_t* dst = ws.hits + at;
+                uint32_t* dst32 = numbers + at;
+                for (uint32_t e0 = 0; e0 < nent; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
+                    const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
+                    const uint32_t incl = wave_incl_scan_u32(sz, lane);
+                    if (sz == 1) {                                                  // a single location is its own payload
+                        if constexpr (NUM) dst32[incl - 1] = tab.gw_of(pay); else dst[incl - 1] = pay;
+                    }
+                    sIncl[lane] = incl; sPay[lane] = pay;
+                    wave_lds_sync();
+                    const uint32_t tot = rdlane(incl, 63);
+                    auto place = [&](uint32_t p, uint64_t& src) -> bool {         // the list holding output place p (lists of one location are done)
+                        uint32_t lo = 0;
+#pragma unroll
+                        for (uint32_t step = 32; step >= 1; step >>= 1) if (sIncl[lo + step - 1] <= p) lo += step;
+                        const uint32_t end = sIncl[lo], beg = lo ? sIncl[lo - 1] : 0u;
+                        src = sPay[lo] + (p - beg);
+                        return end - beg > 1u;
+                    };
+                    for (uint32_t p0 = 0; p0 < tot; p0 += 128) {
+                        const uint32_t pa = p0 + lane, pb = p0 + 64 + lane;
+                        uint64_t sa = 0, sb = 0;
+                        const bool da = pa < tot && place(pa, sa), db = pb < tot && place(pb, sb);
+                        if constexpr (NUM) {
+                            const uint32_t va = da ? tab.values32[sa] : 0u, vb = db ? tab.values32[sb] : 0u;
+                            if (da) dst32[pa] = va;
+                            if (db) dst32[pb] = vb;
+                        } else {
+                            const uint64_t va = da ? tab.loc(sa) : 0ull, vb = db ? tab.loc(sb) : 0ull;
+                            if (da) dst[pa] = va;
+                            if (db) dst[pb] = vb;
+                        }
+                    }
+                    wave_lds_sync();
+                    dst += tot; dst32 += tot;
                 }
-                dst += rdlane(incl, 63);
             }
             if (lane == 0) ws.qflag[q] = kFlagDone;
         }
     }
 }
-void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, hipStream_t st)
+// numbers != nullptr (compact store only): the lists as 4-byte numbers to numbers + hitOff[q] instead of ws.hits
+void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t* numbers, hipStream_t st)
 {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(gather_lists_kernel, dim3(std::min<uint32_t>((b.n + 255) / 256, 256 * 8)), dim3(256), 0, st, b, sp.s, tab, ws);
+    const dim3 grid(std::min<uint32_t>((b.n + 255) / 256, 256 * 8));
+    if (numbers && tab.values32) hipLaunchKernelGGL(gather_lists_kernel<true>, grid, dim3(256), 0, st, b, sp.s, tab, ws, numbers);
+    else hipLaunchKernelGGL(gather_lists_kernel<false>, grid, dim3(256), 0, st, b, sp.s, tab, ws, (uint32_t*)nullptr);
 }
 
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,

@@ -8,7 +8,7 @@
 // CPU result bit for bit (no per-part top lists to merge).
 //
 // Per batch:
-//   1. every shard: the batch to its device, mc_query_device(MC_WANT_PARTIAL_HITS) -- the shard sketches ALL reads (ALU work, cheap) and
+//   1. every shard: the batch to its device, mc_query_device(MC_WANT_PARTIAL_NUMBERS) -- the shard sketches ALL reads (ALU work, cheap) and
 //      looks up only the features it owns, so the lookups of a batch are done once, spread over the shards -- then mc_partial_numbers:
 //      the partial lists as 4-byte global window numbers, back to back in read order, and where the read shards' pieces begin (the
 //      one host round trip: S + 1 offsets per shard);
@@ -209,7 +209,7 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
             mc_device_batch in{Rk.dseq, Rk.dqinfo, Rk.dmaxwin, 0, m, at};
             mc_device_results res{};
             Rk.cuts.assign(S + 1, 0);
-            int rc = mc_query_device(Rk.ctx, &in, lowestRank, MC_WANT_PARTIAL_HITS, &res, Rk.stream);
+            int rc = mc_query_device(Rk.ctx, &in, lowestRank, MC_WANT_PARTIAL_NUMBERS, &res, Rk.stream);
             if (!rc) rc = mc_partial_numbers(Rk.ctx, &res, m, bounds.data(), S + 1, Rk.cuts.data(), &Rk.part, Rk.stream);
             if (!rc && !ks->rccl && hipStreamSynchronize(Rk.stream) != hipSuccess) rc = MC_ERR_HIP;   // (copies below run on the owners' streams)
             if (rc) { Rk.rc = rc; Rk.err = rc == MC_ERR_HIP && Rk.err.empty() ? "HIP error" : mc_last_error(Rk.ctx); }

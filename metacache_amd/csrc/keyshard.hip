@@ -65,6 +65,31 @@ void launch_pack_numbers(const uint64_t* hits, const uint64_t* hitOff, uint64_t 
     if (total) hipLaunchKernelGGL(pack_numbers_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 32)), dim3(256), 0, st, hits, total, tab, numbers);
 }
 
+// MC_WANT_PARTIAL_NUMBERS: the reads the wave kernels took (their lists lie in ws.hits as (target, window)) -> numbers; the reads that wait
+// for gather_lists_kernel<true> get theirs straight from the table.  Runs after sort_candidates_kernel and before the gather.
+__global__ __launch_bounds__(256) void pack_other_reads_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t* __restrict__ numbers)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nWaves = gridDim.x * 4, waveId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t base = waveId * 64; base < b.n; base += nWaves * 64) {
+        const uint32_t qq = base + lane;
+        const uint32_t fl = qq < b.n ? ws.qflag[qq] : kFlagGather;
+        uint64_t todo = __ballot(qq < b.n && fl != kFlagGather && fl != kFlagGatherAll && ws.hitOff[qq + 1] != ws.hitOff[qq]);
+        while (todo) {
+            const uint32_t j = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint64_t at = ws.hitOff[base + j], c = ws.hitOff[base + j + 1] - at;
+            for (uint64_t t = lane; t < c; t += 64) numbers[at + t] = tab.gw_of(ws.hits[at + t]);
+        }
+    }
+}
+void launch_pack_other_reads(const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t* numbers, uint32_t* counts, hipStream_t st)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(partial_counts_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, ws.hitOff, b.n, counts);
+    hipLaunchKernelGGL(pack_other_reads_kernel, dim3(std::min<uint32_t>((b.n + 255) / 256, 256 * 8)), dim3(256), 0, st, b, tab, ws, numbers);
+}
+
 // One lane per read.  counts[s * m + q] numbers of read q came from source s, at srcStart[s * (m + 1) + q] inside that source's block,
 // which begins at bases.b[s] of tab.values32 (= the receive buffer).  Entry s of read q: slot q * S + s.
 __global__ __launch_bounds__(256) void owner_entries_kernel(BatchView b, DeviceTable tab, Workspace ws, const uint32_t* __restrict__ counts,

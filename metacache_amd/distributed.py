@@ -302,9 +302,7 @@ def exchange_numbers(counts: torch.Tensor, numbers: torch.Tensor, cut_offsets, n
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     send_elems = [int(cut_offsets[r + 1]) - int(cut_offsets[r]) for r in range(world)]
     if world == 1:
-        pad = torch.zeros(numbers.numel() + 4, dtype=numbers.dtype, device=numbers.device)     # (the owner's kernels read 16 bytes past the end)
-        pad[: numbers.numel()] = numbers
-        return counts, pad, [0, send_elems[0]]
+        return counts, numbers, [0, send_elems[0]]                           # (the caller's buffer has the 16 bytes of slack the owner's kernels need)
     bounds = [shard_bounds(n, r, world) for r in range(world)]
     m = bounds[rank][1] - bounds[rank][0]
     sizes = torch.tensor(send_elems, dtype=torch.int64, device=counts.device)
@@ -334,7 +332,7 @@ def classify_key_sharded_numbers(db, res, n: int, K: int, max_win_uniform: int, 
     part, cuts = db.partial_numbers(res, n, [b[0] for b in bounds] + [n])
     db.synchronize()                                                         # the pack kernel ran on the context's stream, the collectives run on torch's
     counts = torch.empty(n, dtype=torch.int32, device=device)
-    numbers = torch.empty(max(int(part.total), 1), dtype=torch.int32, device=device)
+    numbers = torch.empty(int(part.total) + 4, dtype=torch.int32, device=device)        # (+ 16 bytes: the owner's kernels read whole 16-byte groups)
     db.copy_results(counts.data_ptr(), part.counts, n * 4)
     if part.total:
         db.copy_results(numbers.data_ptr(), part.numbers, int(part.total) * 4)

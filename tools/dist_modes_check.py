@@ -73,7 +73,8 @@ def main():
     for lowest in (0, 4):
         dbk = api.Database.open(os.path.join(gold, "toy32"), device=local, max_candidates=K, key_shard_index=rank, key_shard_count=world)
         for wire in (8, 4):                                        # (target, window) pairs, then 4-byte global window numbers
-            res = dbk.query_device(seq.data_ptr(), qinfo.data_ptr(), n, nchars, max_win_uniform=mw, want_partial_hits=(lowest == 0), want_allhits=(lowest != 0))
+            res = dbk.query_device(seq.data_ptr(), qinfo.data_ptr(), n, nchars, max_win_uniform=mw, want_partial_hits=(lowest == 0 and wire == 8),
+                                   want_partial_numbers=(lowest == 0 and wire == 4), want_allhits=(lowest != 0))
             local_c = classify_key_sharded_device(dbk, res, n, K, mw, lowest=lowest, wire=wire)
             parts = gather_candidates(local_c)
             if rank == 0:
