@@ -548,8 +548,8 @@ def main():
                     + (f"{world * args.steps * B} synthetic long reads (200-19000 bp, log-normal, median 480; 7.5 % substitutions)" if args.long_reads else
                        f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
                     + ("" if nb >= args.steps + args.warmup else f" ({world * nb * B * (2 if args.pairs else 1)} distinct, cycled)"))
-        # the committed PMC passes (profiles/r02_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
-        pmc_tag = "r02" if (mode == "R" and not args.pairs and args.scale == 1.0 and B == 5_000_000) else "r02-none"
+        # the committed PMC passes (profiles/r03_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
+        pmc_tag = "r03" if (mode == "R" and not args.pairs and not args.long_reads and args.scale == 1.0 and B == 5_000_000) else "r03-none"
     build_s = time.time() - t0
     db_info = db.info()
 
