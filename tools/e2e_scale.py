@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--cpu-reads", type=int, default=400_000)
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--key-shards", type=int, default=0, help="also run `mcq query -shard keys -key-shards n` (the database as n key shards on this GPU, mc_keyset_*)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     build.build_library()
@@ -83,6 +84,21 @@ def main():
             res[name] = {"wall_s": round(wall, 2), "query_ms": ms, "database_load_and_startup_s": round(wall - ms / 1e3, 2),
                          "Mreads_per_min_query_phase": round(q / (ms / 1e3) * 60 / 1e6, 1), "Mreads_per_min_wall": round(q / wall * 60 / 1e6, 1), "profile": prof}
             print(name, res[name], flush=True)
+        if args.key_shards:
+            ks = ["-shard", "keys", "-key-shards", str(args.key_shards), "-batch-size", "1000000"]
+            wall, prof = timed([mcq, "query", db, fa, "-no-map"] + ks + ["-out", o], env=env)
+            q, ms = e2e_bench.speed_of(o)
+            res["mcq_key_shards_nomap"] = {"shards": args.key_shards, "wall_s": round(wall, 2), "query_ms": ms, "database_load_and_startup_s": round(wall - ms / 1e3, 2),
+                                           "Mreads_per_min_query_phase": round(q / (ms / 1e3) * 60 / 1e6, 1)}
+            print("key shards", res["mcq_key_shards_nomap"], flush=True)
+            o2 = o + ".ks"
+            timed([mcq, "query", db, fa_small, "-tophits", "-queryids", "-out", o])
+            timed([mcq, "query", db, fa_small, "-tophits", "-queryids"] + ks + ["-out", o2])
+            a = [l for l in open(o) if not l.startswith("#")]
+            b = [l for l in open(o2) if not l.startswith("#")]
+            os.remove(o2)
+            res["key_shards_identical_mapping_lines"] = {"single_table": len(a), "key_shards": len(b), "differing": sum(x != y for x, y in zip(a, b)) + abs(len(a) - len(b))}
+            print("key shards vs single table", res["key_shards_identical_mapping_lines"], flush=True)
         ref = os.path.join(ROOT, "oracle", "_ref", "metacache_u32")
         if os.path.exists(ref) and not args.no_ref:
             wall, _ = timed([ref, "query", db, fa, "-no-map", "-out", oref])
