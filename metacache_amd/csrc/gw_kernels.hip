@@ -972,10 +972,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
 
 // ================================================================================================
 // gw_sorted_cands_kernel: rows 9-10 on a SORTED filtered list (gw_sort.hip) -- long reads (thousands of kept locations, window ranges
-// of tens to hundreds), pairs with large insert sizes.  One wave per read; every lane scans a contiguous piece of the list with the
-// CPU's sliding window (candidate_generation.hpp:47-108: numbers less than maxWindowsInRange apart are one target's, that is what the
-// gap between two targets' numbers is for), one candidate per target run through the CPU's top-list insert (top_insert: ties, taxon
-// merging); a run that crosses into the next lane's piece yields a candidate there too.  Then K rounds over the lanes' lists: the
+// of tens to hundreds), pairs with large insert sizes.  One wave per read; the list is taken 64 numbers at a time, one per lane, each
+// finding the begin of the CPU's sliding window that ends in it (candidate_generation.hpp:47-108: numbers less than maxWindowsInRange
+// apart are one target's, that is what the gap between two targets' numbers is for), one candidate per target through the CPU's
+// top-list insert (top_insert: ties, taxon merging) on the lane that holds the target's last number.  Then K rounds over the lanes' lists: the
 // best under (hits desc, target asc, end window asc), its target (taxon) struck everywhere -- every lane loses at most one entry per
 // round, so its K entries are enough.  Reads with fewer than K candidates of two or more hits go to the exact wave kernel (single
 // hits of other targets were filtered away).
@@ -984,7 +984,9 @@ template <bool TAX>
 __global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
                                                               mc_candidate_dev* __restrict__ cands)
 {
+    __shared__ uint32_t ringS[4][128];                         // the list's last two chunks of 64 numbers (position & 127)
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* ring = ringS[wave];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t nWaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
     const uint32_t nmine = ws.midCount[13];
@@ -999,32 +1001,72 @@ __global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, Devic
         uint32_t toptax[kLaneK];
 #pragma unroll
         for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
-        const uint32_t per = (n + 63u) / 64u, a = lane * per, e = min(n, a + per);
-        if (a < e) {
-            uint32_t gi = g[a];
-            uint32_t fst;
-            {   // first list position that can share a window range with this piece's first number
-                uint32_t lo = 0, hi = a;
-                const uint32_t want = gi - D;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g[mid] < want) lo = mid + 1; else hi = mid; }
-                fst = lo;
+        // The list is taken 64 consecutive numbers at a time, one per lane (coalesced; a lane scanning its own contiguous piece made
+        // every load of the wave 64 separate cache-line requests: 300 us of wave time per 2 kbp read).  Element i's window range begins
+        // at fst(i) = the first position whose number is >= g[i] - D (numbers less than maxWindowsInRange apart are one target's: the
+        // gap); fst is monotone.  The last two chunks lie in an LDS ring: a range of up to 64 elements -- nearly all of them -- is
+        // found by a binary search there, wider ones in the list itself.  hits = i - fst + 1.  Per target the best range = most hits,
+        // the first to reach them: a segmented max-scan over the lanes (segments = targets, contiguous in the sorted list) of
+        // hits << 6 | (63 - lane); the open target at a chunk's end is carried into the next chunk (its best so far wins ties: it came
+        // first; a chunk that lies inside it needs no target lookup).  A finished target's candidate enters the top list of the lane
+        // that holds its last element (per-lane lists in target order, merged by the K rounds below).
+        uint32_t cT = 0xFFFFFFFFu, cHits = 0, cBeg = 0, cEnd = 0, cLo = 0, cHi = 0;   // the open target, its best range so far, its numbers (wave-uniform)
+        uint32_t lowFst = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t cnt = min(64u, n - base), ei = base + lane;
+            const bool valid = lane < cnt;
+            const uint32_t gi = valid ? g[ei] : 0xFFFFFFFFu;
+            ring[ei & 127u] = gi;
+            wave_lds_sync();
+            const uint32_t want = gi - D;
+            const uint32_t rlo = base >= 64u ? base - 64u : 0u;         // positions from here on are in the ring
+            uint32_t lo = 0, hi = 0;
+            bool glob = false;
+            if (valid) {
+                if (lowFst >= rlo) { lo = lowFst; hi = ei; }
+                else if (ring[rlo & 127u] < want) { lo = rlo + 1u; hi = ei; }
+                else { lo = lowFst; hi = rlo; glob = true; }
             }
-            uint32_t gf = g[fst];
-            uint32_t t = tab.gw_target(gi), tlo = tab.gwBase[t], thi = tab.gwBase[t + 1];
-            LaneCand best; best.tgt = t; best.hits = 0; best.beg = 0; best.end = 0;
-            for (uint32_t i = a; i < e; ++i) {
-                gi = g[i];
-                if (gi >= thi) {
-                    top_insert(top, toptax, best, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
-                    t = tab.gw_target(gi); tlo = tab.gwBase[t]; thi = tab.gwBase[t + 1];
-                    best.tgt = t; best.hits = 0;
-                }
-                while (gi - gf > D) { ++fst; gf = g[fst]; }
-                const uint32_t hits = i - fst + 1u;
-                if (hits > best.hits) { best.hits = hits; best.beg = gf - tlo; best.end = gi - tlo; }
+            while (__ballot(!glob && lo < hi)) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (!glob && lo < hi) { if (ring[mid & 127u] < want) lo = mid + 1u; else hi = mid; }
             }
-            top_insert(top, toptax, best, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+            while (__ballot(glob && lo < hi)) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (glob && lo < hi) { if (g[mid] < want) lo = mid + 1u; else hi = mid; }
+            }
+            const uint32_t fst = lo;
+            const uint32_t gf = !valid ? 0u : fst >= rlo ? ring[fst & 127u] : g[fst];
+            lowFst = rdlane(fst, cnt - 1u);
+            uint32_t t = 0xFFFFFFFFu, tlo = 0, thi = 0;
+            const bool inCur = cT != 0xFFFFFFFFu && (gi - cLo) < (cHi - cLo);
+            if (valid) {
+                if (inCur) { t = cT; tlo = cLo; thi = cHi; }
+                else tab.gw_target_bounds(gi, t, tlo, thi);
+            }
+            // the open target ended with the previous chunk: its candidate is due (lane 0: before anything of this chunk)
+            if (cT != 0xFFFFFFFFu && rdlane(t, 0) != cT && lane == 0) {
+                LaneCand c; c.tgt = cT; c.hits = cHits; c.beg = cBeg; c.end = cEnd;
+                top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+            }
+            uint32_t val = valid ? (((ei - fst + 1u) << 6) | (63u - lane)) : 0u;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t ov = (uint32_t)__shfl_up((int)val, d), ot = (uint32_t)__shfl_up((int)t, d);
+                if (lane >= d && ot == t) val = max(val, ov);
+            }
+            const uint32_t tnext = (uint32_t)__shfl_down((int)t, 1);
+            const bool tail = valid && (lane + 1u >= cnt || tnext != t);
+            const uint32_t wl = 63u - (val & 63u);
+            LaneCand c; c.tgt = t; c.hits = val >> 6;
+            c.beg = (uint32_t)__shfl((int)gf, (int)wl) - tlo; c.end = (uint32_t)__shfl((int)gi, (int)wl) - tlo;
+            if (t == cT && cHits >= c.hits) { c.hits = cHits; c.beg = cBeg; c.end = cEnd; }
+            const bool last = base + 64u >= n;
+            if (tail && (last || lane + 1u < cnt)) top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+            cT = rdlane(c.tgt, cnt - 1u); cHits = rdlane(c.hits, cnt - 1u); cBeg = rdlane(c.beg, cnt - 1u); cEnd = rdlane(c.end, cnt - 1u);
+            cLo = rdlane(tlo, cnt - 1u); cHi = rdlane(thi, cnt - 1u);
         }
+        wave_lds_sync();
         // ---- K rounds over the lanes' lists (each sorted: entry 0 is the lane's best)
         mc_candidate_dev* out = cands + (size_t)q * K;
         uint32_t strong = 0;
