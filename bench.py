@@ -107,7 +107,7 @@ def make_long_reads(spec, gen, n: int, seed: int, dev, stride: int = 112):
     (every read 4-byte aligned), qinfo rows {offset, length, offset, 0} and maxWindowsInRange = 2 + length / stride per read
     (candidate_structs.hpp:143-145).  Generated longest reads first, in groups with one row length."""
     rng = np.random.default_rng(seed)
-    lens = np.clip(np.exp(rng.normal(np.log(480.0), 0.95, n)), 200, 19_000).astype(np.int64)
+    lens = np.clip(np.exp(rng.normal(np.log(480.0), 0.95, n)), 200, int(os.environ.get("MC_BENCH_LONG_CLIP", "19000"))).astype(np.int64)   # (the clip: experiments only)
     offs = np.zeros(n + 1, dtype=np.int64)
     offs[1:] = np.cumsum((lens + 3) // 4 * 4)
     if offs[-1] + 16 >= (1 << 32):

@@ -980,128 +980,195 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
 // round, so its K entries are enough.  Reads with fewer than K candidates of two or more hits go to the exact wave kernel (single
 // hits of other targets were filtered away).
 // ================================================================================================
+constexpr uint32_t kGwBigSorted = 8192;                      // sorted lists longer than this are scanned by a whole block (gw_sorted_cands_kernel<TAX, true>)
+
+// The scan of positions [first, end) of a read's sorted list g (n numbers) by ONE wave: see gw_sorted_cands_kernel.  Leaves the
+// candidates in the lanes' top lists.
 template <bool TAX>
+__device__ __forceinline__ void gw_sorted_scan(const uint32_t* __restrict__ g, const uint32_t first, const uint32_t end, const uint32_t D,
+                                               const DeviceTable& tab, const uint32_t* __restrict__ taxkey, const uint32_t K, uint32_t* ring,
+                                               const uint32_t lane, LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK])
+{
+    // The list is taken 64 consecutive numbers at a time, one per lane (coalesced; a lane scanning its own contiguous piece made
+    // every load of the wave 64 separate cache-line requests: 300 us of wave time per 2 kbp read).  Element i's window range begins
+    // at fst(i) = the first position whose number is >= g[i] - D (numbers less than maxWindowsInRange apart are one target's: the
+    // gap); fst is monotone.  The last two chunks lie in an LDS ring: a range of up to 64 elements -- nearly all of them -- is
+    // found by a binary search there, wider ones (and what lies before `first`) in the list itself.  hits = i - fst + 1.  Per target
+    // the best range = most hits, the first to reach them: a segmented max-scan over the lanes (segments = targets, contiguous in the
+    // sorted list) of hits << 6 | (63 - lane); the open target at a chunk's end is carried into the next chunk (its best so far wins
+    // ties: it came first; a chunk that lies inside it needs no target lookup).  A finished target's candidate enters the top list of
+    // the lane that holds its last element (per-lane lists in target order, merged by the K rounds).
+    uint32_t cT = 0xFFFFFFFFu, cHits = 0, cBeg = 0, cEnd = 0, cLo = 0, cHi = 0;   // the open target, its best range so far, its numbers (wave-uniform)
+    uint32_t lowFst = 0;
+    for (uint32_t base = first; base < end; base += 64) {
+        const uint32_t cnt = min(64u, end - base), ei = base + lane;
+        const bool valid = lane < cnt;
+        const uint32_t gi = valid ? g[ei] : 0xFFFFFFFFu;
+        ring[ei & 127u] = gi;
+        wave_lds_sync();
+        const uint32_t want = gi - D;
+        const uint32_t rlo = base >= first + 64u ? base - 64u : first;      // positions from here on are in the ring
+        uint32_t lo = 0, hi = 0;
+        bool glob = false;
+        if (valid) {
+            if (lowFst >= rlo) { lo = lowFst; hi = ei; }
+            else if (ring[rlo & 127u] < want) { lo = rlo + 1u; hi = ei; }
+            else { lo = lowFst; hi = rlo; glob = true; }
+        }
+        while (__ballot(!glob && lo < hi)) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (!glob && lo < hi) { if (ring[mid & 127u] < want) lo = mid + 1u; else hi = mid; }
+        }
+        while (__ballot(glob && lo < hi)) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (glob && lo < hi) { if (g[mid] < want) lo = mid + 1u; else hi = mid; }
+        }
+        const uint32_t fst = lo;
+        const uint32_t gf = !valid ? 0u : fst >= rlo ? ring[fst & 127u] : g[fst];
+        lowFst = rdlane(fst, cnt - 1u);
+        uint32_t t = 0xFFFFFFFFu, tlo = 0, thi = 0;
+        const bool inCur = cT != 0xFFFFFFFFu && (gi - cLo) < (cHi - cLo);
+        if (valid) {
+            if (inCur) { t = cT; tlo = cLo; thi = cHi; }
+            else tab.gw_target_bounds(gi, t, tlo, thi);
+        }
+        // the open target ended with the previous chunk: its candidate is due (lane 0: before anything of this chunk)
+        if (cT != 0xFFFFFFFFu && rdlane(t, 0) != cT && lane == 0) {
+            LaneCand c; c.tgt = cT; c.hits = cHits; c.beg = cBeg; c.end = cEnd;
+            top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+        }
+        uint32_t val = valid ? (((ei - fst + 1u) << 6) | (63u - lane)) : 0u;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t ov = (uint32_t)__shfl_up((int)val, d), ot = (uint32_t)__shfl_up((int)t, d);
+            if (lane >= d && ot == t) val = max(val, ov);
+        }
+        const uint32_t tnext = (uint32_t)__shfl_down((int)t, 1);
+        const bool tail = valid && (lane + 1u >= cnt || tnext != t);
+        const uint32_t wl = 63u - (val & 63u);
+        LaneCand c; c.tgt = t; c.hits = val >> 6;
+        c.beg = (uint32_t)__shfl((int)gf, (int)wl) - tlo; c.end = (uint32_t)__shfl((int)gi, (int)wl) - tlo;
+        if (t == cT && cHits >= c.hits) { c.hits = cHits; c.beg = cBeg; c.end = cEnd; }
+        const bool last = base + 64u >= end;
+        if (tail && (last || lane + 1u < cnt)) top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
+        cT = rdlane(c.tgt, cnt - 1u); cHits = rdlane(c.hits, cnt - 1u); cBeg = rdlane(c.beg, cnt - 1u); cEnd = rdlane(c.end, cnt - 1u);
+        cLo = rdlane(tlo, cnt - 1u); cHi = rdlane(thi, cnt - 1u);
+    }
+    wave_lds_sync();
+}
+
+// K rounds over the lanes' lists (each sorted: entry 0 is the lane's best): the best under (hits desc, target asc, end window asc),
+// its target (taxon) struck everywhere.  put(round, candidate, its taxon) is called by every lane with the round's wave-uniform pick.
+// Returns how many picks had two or more hits.
+template <bool TAX, class Put>
+__device__ __forceinline__ uint32_t gw_sorted_rounds(LaneCand (&top)[kLaneK], uint32_t (&toptax)[kLaneK], const uint32_t K, Put&& put)
+{
+    uint32_t strong = 0;
+    for (uint32_t rnd = 0; rnd < K; ++rnd) {
+        const uint32_t mh = wave_max_u32(top[0].hits);
+        mc_candidate_dev ev; ev.tgt = 0xFFFFFFFFu; ev.hits = 0; ev.beg = 0; ev.end = 0;
+        uint32_t mtax = 0;
+        if (mh != 0) {
+            const uint32_t mt = wave_min_u32(top[0].hits == mh ? top[0].tgt : 0xFFFFFFFFu);
+            const uint32_t me = wave_min_u32(top[0].hits == mh && top[0].tgt == mt ? top[0].end : 0xFFFFFFFFu);
+            const uint32_t winner = __ffsll((unsigned long long)__ballot(top[0].hits == mh && top[0].tgt == mt && top[0].end == me)) - 1;
+            ev.tgt = mt; ev.hits = mh; ev.end = me; ev.beg = rdlane(top[0].beg, winner);
+            mtax = rdlane(toptax[0], winner);
+            strong += mh >= 2 ? 1u : 0u;
+            // the picked target (taxon) leaves every lane's list
+            LaneCand kept[kLaneK]; uint32_t ktax[kLaneK];
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) { kept[i].tgt = 0xFFFFFFFFu; kept[i].hits = 0; kept[i].beg = 0; kept[i].end = 0; ktax[i] = 0; }
+            uint32_t nk = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) {
+                const bool stay = top[i].hits != 0 && (TAX ? toptax[i] != mtax : top[i].tgt != mt);
+#pragma unroll
+                for (uint32_t jj = 0; jj < kLaneK; ++jj) if (stay && jj == nk) { kept[jj] = top[i]; ktax[jj] = toptax[i]; }
+                nk += stay ? 1u : 0u;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) { top[i] = kept[i]; toptax[i] = ktax[i]; }
+        }
+        put(rnd, ev, mtax);
+    }
+    return strong;
+}
+
+// BIG = false: one wave per read; lists of more than kGwBigSorted numbers are only noted (ws.sideList[0], midCount[18]) -- the longest
+// read of a batch (19 kbp: 10^5 numbers at RefSeq scale) kept one wave busy long after all others had finished.
+// BIG = true (second launch): one BLOCK per noted read, its list cut into four runs of whole chunks, one per wave.  A target that
+// spans two runs leaves a candidate in each: the K rounds take the one with more hits (equal: the earlier one, it ends in the smaller
+// window) and strike the other -- as they always did between the lanes of one wave.  The waves' K picks meet in LDS, wave 0 picks
+// the K best of those 4 K.
+template <bool TAX, bool BIG>
 __global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
                                                               mc_candidate_dev* __restrict__ cands)
 {
     __shared__ uint32_t ringS[4][128];                         // the list's last two chunks of 64 numbers (position & 127)
+    __shared__ mc_candidate_dev pickS[4][kLaneK];
+    __shared__ uint32_t ptaxS[4][kLaneK];
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* ring = ringS[wave];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
-    const uint32_t nWaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
-    const uint32_t nmine = ws.midCount[13];
     const uint32_t* __restrict__ side = ws.sideList + (size_t)3 * b.n;
-    {
-      for (uint32_t i = w0; i < nmine; i += nWaves) {
-        const uint4 rec = work[side[i]];
-        const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
-        const uint32_t* __restrict__ g = ws.bigPool2 + rec.y;
-        const uint32_t D = maxWin - 1u;
-        LaneCand top[kLaneK];
-        uint32_t toptax[kLaneK];
-#pragma unroll
-        for (uint32_t i = 0; i < kLaneK; ++i) { top[i].tgt = 0xFFFFFFFFu; top[i].hits = 0; top[i].beg = 0; top[i].end = 0; toptax[i] = 0; }
-        // The list is taken 64 consecutive numbers at a time, one per lane (coalesced; a lane scanning its own contiguous piece made
-        // every load of the wave 64 separate cache-line requests: 300 us of wave time per 2 kbp read).  Element i's window range begins
-        // at fst(i) = the first position whose number is >= g[i] - D (numbers less than maxWindowsInRange apart are one target's: the
-        // gap); fst is monotone.  The last two chunks lie in an LDS ring: a range of up to 64 elements -- nearly all of them -- is
-        // found by a binary search there, wider ones in the list itself.  hits = i - fst + 1.  Per target the best range = most hits,
-        // the first to reach them: a segmented max-scan over the lanes (segments = targets, contiguous in the sorted list) of
-        // hits << 6 | (63 - lane); the open target at a chunk's end is carried into the next chunk (its best so far wins ties: it came
-        // first; a chunk that lies inside it needs no target lookup).  A finished target's candidate enters the top list of the lane
-        // that holds its last element (per-lane lists in target order, merged by the K rounds below).
-        uint32_t cT = 0xFFFFFFFFu, cHits = 0, cBeg = 0, cEnd = 0, cLo = 0, cHi = 0;   // the open target, its best range so far, its numbers (wave-uniform)
-        uint32_t lowFst = 0;
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t cnt = min(64u, n - base), ei = base + lane;
-            const bool valid = lane < cnt;
-            const uint32_t gi = valid ? g[ei] : 0xFFFFFFFFu;
-            ring[ei & 127u] = gi;
-            wave_lds_sync();
-            const uint32_t want = gi - D;
-            const uint32_t rlo = base >= 64u ? base - 64u : 0u;         // positions from here on are in the ring
-            uint32_t lo = 0, hi = 0;
-            bool glob = false;
-            if (valid) {
-                if (lowFst >= rlo) { lo = lowFst; hi = ei; }
-                else if (ring[rlo & 127u] < want) { lo = rlo + 1u; hi = ei; }
-                else { lo = lowFst; hi = rlo; glob = true; }
-            }
-            while (__ballot(!glob && lo < hi)) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (!glob && lo < hi) { if (ring[mid & 127u] < want) lo = mid + 1u; else hi = mid; }
-            }
-            while (__ballot(glob && lo < hi)) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (glob && lo < hi) { if (g[mid] < want) lo = mid + 1u; else hi = mid; }
-            }
-            const uint32_t fst = lo;
-            const uint32_t gf = !valid ? 0u : fst >= rlo ? ring[fst & 127u] : g[fst];
-            lowFst = rdlane(fst, cnt - 1u);
-            uint32_t t = 0xFFFFFFFFu, tlo = 0, thi = 0;
-            const bool inCur = cT != 0xFFFFFFFFu && (gi - cLo) < (cHi - cLo);
-            if (valid) {
-                if (inCur) { t = cT; tlo = cLo; thi = cHi; }
-                else tab.gw_target_bounds(gi, t, tlo, thi);
-            }
-            // the open target ended with the previous chunk: its candidate is due (lane 0: before anything of this chunk)
-            if (cT != 0xFFFFFFFFu && rdlane(t, 0) != cT && lane == 0) {
-                LaneCand c; c.tgt = cT; c.hits = cHits; c.beg = cBeg; c.end = cEnd;
-                top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
-            }
-            uint32_t val = valid ? (((ei - fst + 1u) << 6) | (63u - lane)) : 0u;
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-                const uint32_t ov = (uint32_t)__shfl_up((int)val, d), ot = (uint32_t)__shfl_up((int)t, d);
-                if (lane >= d && ot == t) val = max(val, ov);
-            }
-            const uint32_t tnext = (uint32_t)__shfl_down((int)t, 1);
-            const bool tail = valid && (lane + 1u >= cnt || tnext != t);
-            const uint32_t wl = 63u - (val & 63u);
-            LaneCand c; c.tgt = t; c.hits = val >> 6;
-            c.beg = (uint32_t)__shfl((int)gf, (int)wl) - tlo; c.end = (uint32_t)__shfl((int)gi, (int)wl) - tlo;
-            if (t == cT && cHits >= c.hits) { c.hits = cHits; c.beg = cBeg; c.end = cEnd; }
-            const bool last = base + 64u >= n;
-            if (tail && (last || lane + 1u < cnt)) top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
-            cT = rdlane(c.tgt, cnt - 1u); cHits = rdlane(c.hits, cnt - 1u); cBeg = rdlane(c.beg, cnt - 1u); cEnd = rdlane(c.end, cnt - 1u);
-            cLo = rdlane(tlo, cnt - 1u); cHi = rdlane(thi, cnt - 1u);
-        }
-        wave_lds_sync();
-        // ---- K rounds over the lanes' lists (each sorted: entry 0 is the lane's best)
-        mc_candidate_dev* out = cands + (size_t)q * K;
-        uint32_t strong = 0;
-        for (uint32_t rnd = 0; rnd < K; ++rnd) {
-            const uint32_t mh = wave_max_u32(top[0].hits);
-            mc_candidate_dev ev; ev.tgt = 0xFFFFFFFFu; ev.hits = 0; ev.beg = 0; ev.end = 0;
-            if (mh != 0) {
-                const uint32_t mt = wave_min_u32(top[0].hits == mh ? top[0].tgt : 0xFFFFFFFFu);
-                const uint32_t me = wave_min_u32(top[0].hits == mh && top[0].tgt == mt ? top[0].end : 0xFFFFFFFFu);
-                const uint32_t winner = __ffsll((unsigned long long)__ballot(top[0].hits == mh && top[0].tgt == mt && top[0].end == me)) - 1;
-                ev.tgt = mt; ev.hits = mh; ev.end = me; ev.beg = rdlane(top[0].beg, winner);
-                const uint32_t mtax = rdlane(toptax[0], winner);
-                strong += mh >= 2 ? 1u : 0u;
-                // the picked target (taxon) leaves every lane's list
-                LaneCand kept[kLaneK]; uint32_t ktax[kLaneK];
-#pragma unroll
-                for (uint32_t i = 0; i < kLaneK; ++i) { kept[i].tgt = 0xFFFFFFFFu; kept[i].hits = 0; kept[i].beg = 0; kept[i].end = 0; ktax[i] = 0; }
-                uint32_t nk = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < kLaneK; ++i) {
-                    const bool stay = top[i].hits != 0 && (TAX ? toptax[i] != mtax : top[i].tgt != mt);
-#pragma unroll
-                    for (uint32_t jj = 0; jj < kLaneK; ++jj) if (stay && jj == nk) { kept[jj] = top[i]; ktax[jj] = toptax[i]; }
-                    nk += stay ? 1u : 0u;
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < kLaneK; ++i) { top[i] = kept[i]; toptax[i] = ktax[i]; }
-            }
-            if (lane == 0) out[rnd] = ev;
-        }
+    uint32_t* __restrict__ bigList = ws.sideList;              // [0]: the stream filter's record list, done with by now
+    auto finish = [&](uint32_t q, uint32_t strong) {
         if (lane == 0) {
             if (strong < K) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
             else ws.qflag[q] = kFlagDone;
         }
-      }
+    };
+    if constexpr (!BIG) {
+        const uint32_t nWaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+        const uint32_t nmine = ws.midCount[13];
+        for (uint32_t i = w0; i < nmine; i += nWaves) {
+            const uint32_t w = side[i];
+            const uint4 rec = work[w];
+            const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
+            if (n > kGwBigSorted) {
+                if (lane == 0) bigList[atomicAdd(&ws.midCount[18], 1u)] = w;
+                continue;
+            }
+            LaneCand top[kLaneK];
+            uint32_t toptax[kLaneK];
+#pragma unroll
+            for (uint32_t j = 0; j < kLaneK; ++j) { top[j].tgt = 0xFFFFFFFFu; top[j].hits = 0; top[j].beg = 0; top[j].end = 0; toptax[j] = 0; }
+            gw_sorted_scan<TAX>(ws.bigPool2 + rec.y, 0u, n, maxWin - 1u, tab, taxkey, K, ring, lane, top, toptax);
+            mc_candidate_dev* out = cands + (size_t)q * K;
+            const uint32_t strong = gw_sorted_rounds<TAX>(top, toptax, K, [&](uint32_t rnd, const mc_candidate_dev& ev, uint32_t) { if (lane == 0) out[rnd] = ev; });
+            finish(q, strong);
+        }
+    } else {
+        const uint32_t nbig = ws.midCount[18];
+        for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
+            const uint4 rec = work[bigList[i]];
+            const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
+            const uint32_t chunks = (n + 63u) / 64u, cpw = (chunks + 3u) / 4u;
+            const uint32_t first = min(n, wave * cpw * 64u), end = min(n, (wave + 1u) * cpw * 64u);
+            LaneCand top[kLaneK];
+            uint32_t toptax[kLaneK];
+#pragma unroll
+            for (uint32_t j = 0; j < kLaneK; ++j) { top[j].tgt = 0xFFFFFFFFu; top[j].hits = 0; top[j].beg = 0; top[j].end = 0; toptax[j] = 0; }
+            if (first < end) gw_sorted_scan<TAX>(ws.bigPool2 + rec.y, first, end, maxWin - 1u, tab, taxkey, K, ring, lane, top, toptax);
+            gw_sorted_rounds<TAX>(top, toptax, K, [&](uint32_t rnd, const mc_candidate_dev& ev, uint32_t tax) {
+                if (lane == 0) { pickS[wave][rnd] = ev; ptaxS[wave][rnd] = tax; }
+            });
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (uint32_t j = 0; j < kLaneK; ++j) { top[j].tgt = 0xFFFFFFFFu; top[j].hits = 0; top[j].beg = 0; top[j].end = 0; toptax[j] = 0; }
+                if (lane < 4u * K) {
+                    const mc_candidate_dev e = pickS[lane / K][lane % K];
+                    top[0].tgt = e.tgt; top[0].hits = e.hits; top[0].beg = e.beg; top[0].end = e.end;
+                    toptax[0] = ptaxS[lane / K][lane % K];
+                }
+                mc_candidate_dev* out = cands + (size_t)q * K;
+                const uint32_t strong = gw_sorted_rounds<TAX>(top, toptax, K, [&](uint32_t rnd, const mc_candidate_dev& ev, uint32_t) { if (lane == 0) out[rnd] = ev; });
+                finish(q, strong);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1148,8 +1215,13 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         }
     } else if (stage == 4) {                                   // candidates of the sorted lists (after launch_gw_segsort)
         const uint32_t grid = std::min<uint32_t>(256 * 8, (b.n + 3) / 4);
-        if (taxkey) hipLaunchKernelGGL((gw_sorted_cands_kernel<true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else        hipLaunchKernelGGL((gw_sorted_cands_kernel<false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        if (taxkey) {
+            hipLaunchKernelGGL((gw_sorted_cands_kernel<true, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+            hipLaunchKernelGGL((gw_sorted_cands_kernel<true, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        } else {
+            hipLaunchKernelGGL((gw_sorted_cands_kernel<false, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+            hipLaunchKernelGGL((gw_sorted_cands_kernel<false, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        }
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
         const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);
