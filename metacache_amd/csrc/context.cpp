@@ -214,7 +214,7 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
     auto free_pipe = [](Pipe& P, bool ownStream) {
         DevBuf* pb[] = {&P.bWinCount, &P.bWinOff, &P.bFeatures, &P.bPsize, &P.bPpay, &P.bQstat, &P.bHitOff, &P.bHits, &P.bCscr, &P.bCscr2,
-                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp, &P.bSide, &P.bNumbers, &P.bCounts};
+                        &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp, &P.bSide, &P.bNumbers, &P.bCounts, &P.bOrder};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
@@ -578,13 +578,19 @@ static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const Ske
         if (*nsorted) {
             if ((rc = ensure(ctx, P.bBigPool2, poolEntries * 4))) return rc;
             ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
+            const uint32_t nseg = std::min(*nsorted, n);
+            // the sorted class longest list first: the segmented sort (a block per segment) and the scan (a wave per list) take them in this order
+            size_t ordBytes = 0;
+            if (launch_gw_order(3, ws, n, nseg, nullptr, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists: size query failed");
+            if ((rc = ensure(ctx, P.bOrder, (size_t)3 * std::max<uint32_t>(n, 1) * 4 + ordBytes + 256))) return rc;
             size_t tmpBytes = 0;
-            if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, ctx->gwBits, st) != 0)
+            if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
                 return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
             if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
             {
                 ScopedTimer t(ctx, "gw_sort", st);
-                if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, ctx->gwBits, st) != 0)
+                if (launch_gw_order(3, ws, n, nseg, (uint32_t*)P.bOrder.p, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists failed");
+                if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
                     return fail(ctx, MC_ERR_HIP, "segmented sort failed");
             }
             { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
@@ -739,6 +745,13 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             { ScopedTimer t(ctx, "query_wave", st); launch_query(b, sp, tab, fuse, false, ws, K, P.bCands.p, st); }
             launch_wave_rejoin(b, sp, tab, ws, st);
             waveDone = true;
+        }
+        if (T.compact && !wantPartial && n <= (1u << 20) && hcnt != all && hcnt[10]) {
+            // reads beyond kGwSmallH locations (long reads): the stream filter takes them longest first (launch_gw_order)
+            size_t ordBytes = 0;
+            if (launch_gw_order(0, ws, n, n, nullptr, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the stream filter's reads: size query failed");
+            if ((rc = ensure(ctx, P.bOrder, (size_t)3 * std::max<uint32_t>(n, 1) * 4 + ordBytes + 256))) return rc;
+            ws.orderScratch = (uint32_t*)P.bOrder.p; ws.orderTemp = ordBytes;
         }
         if (hcnt[9] || waveDone) {
             if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st))) return rc;

@@ -21,6 +21,7 @@ struct Pipe {                   // the device workspace of ONE batch in flight +
     hipStream_t stream = nullptr;
     DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
         bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide,
+        bOrder,              // scratch of launch_gw_order (work lists longest first)
         bNumbers, bCounts;   // Mode K shard side: the partial lists as global window numbers + per-read counts (mc_partial_numbers)
     uint32_t lastN = 0;
     uint32_t numbersN = 0xFFFFFFFFu; uint64_t numbersTotal = 0;   // MC_WANT_PARTIAL_NUMBERS: bNumbers / bCounts hold this batch's lists already

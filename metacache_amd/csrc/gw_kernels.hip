@@ -1200,6 +1200,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
         hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
+        if (ws.orderScratch) { size_t tb = ws.orderTemp; (void)launch_gw_order(0, ws, b.n, b.n, ws.orderScratch, tb, st); }   // longest reads first
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1) {

@@ -6,6 +6,7 @@
 // ~10^4 of its 3 x 10^4 locations; 2 Gbases/s are 2 x 10^9 keys per second, a tenth of what the sort delivers).
 #include "device_common.h"
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -14,28 +15,60 @@ namespace mcamd {
 
 namespace {
 
+// segment i = the list of the i-th record of the sorted class (ws.sideList[3], longest list first: launch_gw_order)
 struct SegOffset {
-    const uint4* rec; const uint32_t* midCount; uint32_t end;
+    const uint4* rec; const uint32_t* side; const uint32_t* midCount; uint32_t end;
     __device__ uint32_t operator()(uint32_t i) const
     {
-        if (i >= midCount[9]) return 0u;
-        const uint4 r = rec[i];
-        if (!gw_sorted_class(r.z, r.w)) return 0u;
+        if (i >= midCount[13]) return 0u;
+        const uint4 r = rec[side[i]];
         return r.y + (end ? r.z : 0u);
     }
 };
 
+// keys of the ordering: the work a record stands for -- list 3 (sorted class): the numbers its filtered list holds; list 0 (reads of
+// gw_filter_stream_kernel): the read's locations.  Entries beyond the list's length (device-side count) get key 0 and end up last.
+__global__ __launch_bounds__(256) void order_keys_kernel(Workspace ws, uint32_t n, uint32_t list, uint32_t count, uint32_t* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t len = ws.midCount[list == 3 ? 13 : 12];
+    uint32_t k = 0;
+    if (i < len) {
+        const uint32_t w = ws.sideList[(size_t)list * n + i];
+        k = list == 3 ? (reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n)[w].z : (reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * n)[w].z >> 12;
+    }
+    keys[i] = k;
+}
+
 }  // namespace
 
-// segments = the records of list 7 (n of them at most); temp: caller's buffer (size query with temp == nullptr)
-int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t endBit,
-                      hipStream_t st)
+// Longest first.  The kernels that take ONE read per wave (or block) over a strided work list -- the stream filter, the segmented
+// sort, the scan of the sorted lists -- finished when the wave that happened to hold several 19 kbp reads did: with the records in
+// descending order of their work a stride hands every wave the same mix.  scratch: 3 x count words + tempBytes (size query: scratch == nullptr).
+int launch_gw_order(uint32_t list, const Workspace& ws, uint32_t n, uint32_t count, uint32_t* scratch, size_t& tempBytes, hipStream_t st)
+{
+    uint32_t* side = ws.sideList + (size_t)list * n;
+    uint32_t* keysIn = scratch, *keysOut = scratch ? scratch + count : nullptr, *valsOut = scratch ? scratch + 2 * (size_t)count : nullptr;
+    void* temp = scratch ? scratch + 3 * (size_t)count : nullptr;
+    if (!scratch) return (int)rocprim::radix_sort_pairs_desc(nullptr, tempBytes, keysIn, keysOut, side, valsOut, count, 0u, 32u, st);
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(order_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, st, ws, n, list, count, keysIn);
+    const int rc = (int)rocprim::radix_sort_pairs_desc(temp, tempBytes, keysIn, keysOut, side, valsOut, count, 0u, 32u, st);
+    if (rc) return rc;
+    return (int)hipMemcpyAsync(side, valsOut, (size_t)count * 4, hipMemcpyDeviceToDevice, st);
+}
+
+// segments = the first nseg records of the sorted class (ws.sideList[3]); temp: caller's buffer (size query with temp == nullptr)
+int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t nseg,
+                      uint32_t endBit, hipStream_t st)
 {
     const uint4* rec = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
+    const uint32_t* side = ws.sideList + (size_t)3 * n;
     auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
-    auto beg = rocprim::make_transform_iterator(cnt, SegOffset{rec, ws.midCount, 0u});
-    auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, ws.midCount, 1u});
-    return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull), n, beg, end, 0u, endBit, st);
+    auto beg = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u});
+    auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u});
+    return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull), nseg, beg, end, 0u, endBit, st);
 }
 
 }  // namespace mcamd

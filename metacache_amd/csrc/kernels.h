@@ -151,6 +151,8 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint32_t* sideList;      // [4][n] compact store: record numbers (list 6 / 7) of the reads gw_filter_stream_kernel takes ([0], length midCount[12]), of the
                              // filtered lists of 257 .. 512 ([1], midCount[14]) and 513 .. 1024 numbers ([2], midCount[15]) and of the sorted ones ([3], midCount[13])
     uint32_t* bigPool2;      // [bigPoolCap] compact store: the filtered lists that are sorted (gw_sort.hip), at their pool offsets
+    uint32_t* orderScratch;  // compact store, batches up to 2^20 reads: scratch of launch_gw_order for the stream filter's list (3 n words + orderTemp bytes); nullptr: no ordering
+    size_t    orderTemp;
     uint32_t  bigPoolCap;
     uint32_t  bigOvfCap;     // compact store: entries behind bigPoolCap for filtered lists that may not fit their wave's slice (cursor: midCount[16..17] as u64)
     uint32_t* midList;       // [8][n] x uint4 {query, first entry slot, entries | locations << 8, maxWindowsInRange}: lists of 33..64 / 65..128 / 129..256
@@ -205,10 +207,12 @@ void launch_hash_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab,
 void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t* numbers, hipStream_t st);
-// gw_sort.hip: the filtered lists that are sorted instead of counted (list 7 records of the sorted class), pool -> out at the same offsets;
-// temp == nullptr: size query
-int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t endBit,
-                      hipStream_t st);
+// gw_sort.hip: the filtered lists that are sorted instead of counted (the first nseg records of ws.sideList[3]), pool -> out at the same
+// offsets; temp == nullptr: size query
+int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t nseg,
+                      uint32_t endBit, hipStream_t st);
+// ws.sideList[list] (list 0: the stream filter's reads, 3: the sorted class) in descending order of the records' work; scratch == nullptr: size query
+int launch_gw_order(uint32_t list, const Workspace& ws, uint32_t n, uint32_t count, uint32_t* scratch, size_t& tempBytes, hipStream_t st);
 uint32_t big_filter_grid(uint32_t n);     // blocks of 4 waves the filter runs with: the pool is cut into one slice per wave
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);

@@ -1470,7 +1470,9 @@ __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace
         const uint32_t id = base + lane;
         uint2 rec = make_uint2(0, 1);
         if (id < total) rec = ws.chunkList[id];
-        uint64_t m = __ballot(rec.y == 0 && ws.qflag[rec.x] == kFlagChunks);    // first chunk records = one per long read
+        const bool mineRead = rec.y == 0 && ws.qflag[rec.x] == kFlagChunks;       // first chunk records = one per long read
+        uint64_t m = __ballot(mineRead);
+        uint32_t myH = 0, myFound = 0, myFeat = 0;                                  // lane j: the sums of ITS read
         while (m) {
             const uint32_t j = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
@@ -1481,20 +1483,34 @@ __global__ __launch_bounds__(256) void chunk_finish_kernel(uint32_t s, Workspace
                 H += sz; nfound += sz ? 1u : 0u; nfeat += ws.features[i] != 0xFFFFFFFFu ? 1u : 0u;
             }
             H = wave_sum_u32(H); nfound = wave_sum_u32(nfound); nfeat = wave_sum_u32(nfeat);
-            if (lane == 0) {
-                QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nfeat;   // probe steps are not counted on this path
-                ws.qstat[q] = qs;
-                ws.hitScan[q] = (H <= kMaxHitsPerQuery && (H > kLdsCap || ws.partialLists)) ? H : 0u;   // (lists wanted: every query gets its segment)
-                // (a key shard's partial lists are wanted as they are: gather_lists_kernel copies them -- no sort of tens of thousands of locations)
-                ws.qflag[q] = ws.partialLists ? kFlagGatherAll : kFlagCands;
-                const uint32_t slots = (ws.winOff[q + 1] - ws.winOff[q]) * s, mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
-                if (tab.values32 && !ws.partialLists && H > ws.bigMin && H > 64u && H <= kMaxHitsPerQuery && slots <= 0xFFFu && mw <= tab.gwGap) {
-                    const uint32_t at = atomicAdd(&ws.midCount[9], 1u);          // (one per long read: few)
-                    reinterpret_cast<uint4*>(ws.midList)[(size_t)6 * b.n + at] = make_uint4(q, ws.winOff[q] * s, slots | (H << 12), mw);
-                    if (H > kGwSmallH) atomicAdd(&ws.midCount[10], 1u);
-                    ws.hitScan[q] = 0u; ws.qflag[q] = kFlagMid;
-                }
-            }
+            if (lane == j) { myH = H; myFound = nfound; myFeat = nfeat; }
+        }
+        // every lane finishes its own read; the work list's places are reserved with ONE atomic per wave and step (one per read --
+        // 10^5 on one counter in a batch of long reads -- took 2.5 ms)
+        bool filtered = false, wide = false;
+        const uint32_t q = rec.x;
+        uint32_t slots = 0, mw = 0;
+        if (mineRead) {
+            const uint32_t H = myH;
+            QueryStat qs; qs.hits = H; qs.nfeat = myFeat; qs.nfound = myFound; qs.nsteps = myFeat;   // probe steps are not counted on this path
+            ws.qstat[q] = qs;
+            slots = (ws.winOff[q + 1] - ws.winOff[q]) * s; mw = b.maxWin ? b.maxWin[q] : b.maxWinUniform;
+            filtered = tab.values32 && !ws.partialLists && H > ws.bigMin && H > 64u && H <= kMaxHitsPerQuery && slots <= 0xFFFu && mw <= tab.gwGap;
+            wide = filtered && H > kGwSmallH;
+            // (a key shard's partial lists are wanted as they are: gather_lists_kernel copies them -- no sort of tens of thousands of locations)
+            ws.hitScan[q] = filtered ? 0u : ((H <= kMaxHitsPerQuery && (H > kLdsCap || ws.partialLists)) ? H : 0u);   // (lists wanted: every query gets its segment)
+            ws.qflag[q] = filtered ? kFlagMid : ws.partialLists ? kFlagGatherAll : kFlagCands;
+        }
+        const uint64_t fm = __ballot(filtered);
+        if (fm) {
+            const uint32_t leader = __ffsll((unsigned long long)fm) - 1;
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(&ws.midCount[9], (uint32_t)__popcll(fm));
+            at = __shfl(at, leader);
+            if (filtered)
+                reinterpret_cast<uint4*>(ws.midList)[(size_t)6 * b.n + at + __popcll(fm & ((1ull << lane) - 1ull))] = make_uint4(q, ws.winOff[q] * s, slots | (myH << 12), mw);
+            const uint64_t wm = __ballot(wide);
+            if (wm && lane == leader) atomicAdd(&ws.midCount[10], (uint32_t)__popcll(wm));
         }
     }
 }
