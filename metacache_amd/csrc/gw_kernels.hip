@@ -1097,17 +1097,18 @@ __device__ __forceinline__ uint32_t gw_sorted_rounds(LaneCand (&top)[kLaneK], ui
 
 // BIG = false: one wave per read; lists of more than kGwBigSorted numbers are only noted (ws.sideList[0], midCount[18]) -- the longest
 // read of a batch (19 kbp: 10^5 numbers at RefSeq scale) kept one wave busy long after all others had finished.
-// BIG = true (second launch): one BLOCK per noted read, its list cut into four runs of whole chunks, one per wave.  A target that
+// BIG = true (second launch): one BLOCK of sixteen waves per noted read, its list cut into sixteen runs of whole chunks, one per wave.  A target that
 // spans two runs leaves a candidate in each: the K rounds take the one with more hits (equal: the earlier one, it ends in the smaller
 // window) and strike the other -- as they always did between the lanes of one wave.  The waves' K picks meet in LDS, wave 0 picks
-// the K best of those 4 K.
+// the K best of those 16 K.
 template <bool TAX, bool BIG>
-__global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
-                                                              mc_candidate_dev* __restrict__ cands)
+__global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
+                                                                           mc_candidate_dev* __restrict__ cands)
 {
-    __shared__ uint32_t ringS[4][128];                         // the list's last two chunks of 64 numbers (position & 127)
-    __shared__ mc_candidate_dev pickS[4][kLaneK];
-    __shared__ uint32_t ptaxS[4][kLaneK];
+    constexpr uint32_t kWaves = BIG ? 16u : 4u;                // BIG: sixteen waves share one list (16 x K picks fit one wave's lanes, K <= 4)
+    __shared__ uint32_t ringS[kWaves][128];                    // the list's last two chunks of 64 numbers (position & 127)
+    __shared__ mc_candidate_dev pickS[kWaves][kLaneK];
+    __shared__ uint32_t ptaxS[kWaves][kLaneK];
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* ring = ringS[wave];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
@@ -1144,7 +1145,7 @@ __global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, Devic
         for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
             const uint4 rec = work[bigList[i]];
             const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
-            const uint32_t chunks = (n + 63u) / 64u, cpw = (chunks + 3u) / 4u;
+            const uint32_t chunks = (n + 63u) / 64u, cpw = (chunks + kWaves - 1u) / kWaves;
             const uint32_t first = min(n, wave * cpw * 64u), end = min(n, (wave + 1u) * cpw * 64u);
             LaneCand top[kLaneK];
             uint32_t toptax[kLaneK];
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(256) void gw_sorted_cands_kernel(BatchView b, Devic
             if (wave == 0) {
 #pragma unroll
                 for (uint32_t j = 0; j < kLaneK; ++j) { top[j].tgt = 0xFFFFFFFFu; top[j].hits = 0; top[j].beg = 0; top[j].end = 0; toptax[j] = 0; }
-                if (lane < 4u * K) {
+                if (lane < kWaves * K) {
                     const mc_candidate_dev e = pickS[lane / K][lane % K];
                     top[0].tgt = e.tgt; top[0].hits = e.hits; top[0].beg = e.beg; top[0].end = e.end;
                     toptax[0] = ptaxS[lane / K][lane % K];
@@ -1218,10 +1219,10 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         const uint32_t grid = std::min<uint32_t>(256 * 8, (b.n + 3) / 4);
         if (taxkey) {
             hipLaunchKernelGGL((gw_sorted_cands_kernel<true, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-            hipLaunchKernelGGL((gw_sorted_cands_kernel<true, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+            hipLaunchKernelGGL((gw_sorted_cands_kernel<true, true>), dim3(std::min<uint32_t>(grid, 512u)), dim3(1024), 0, st, b, tab, ws, maxCand, taxkey, c);
         } else {
             hipLaunchKernelGGL((gw_sorted_cands_kernel<false, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-            hipLaunchKernelGGL((gw_sorted_cands_kernel<false, true>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+            hipLaunchKernelGGL((gw_sorted_cands_kernel<false, true>), dim3(std::min<uint32_t>(grid, 512u)), dim3(1024), 0, st, b, tab, ws, maxCand, taxkey, c);
         }
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
