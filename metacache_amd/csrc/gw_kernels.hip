@@ -151,12 +151,20 @@ __device__ __forceinline__ void gw_mark_rounds(uint32_t* bits, const uint4 (&x)[
 }
 // phase B: a number is kept if its block was marked twice or it lies within D of a block boundary; the kept ones are appended to dst
 // (ballot compaction), n2 counts them whether they fit or not
-struct GwSink { uint32_t* dst; uint32_t room, n2; };
+// (shared != nullptr: several waves fill one list -- the places are reserved in LDS, one atomic per call, n2 is not carried)
+struct GwSink { uint32_t* dst; uint32_t room, n2; uint32_t* shared = nullptr; };
+__device__ __forceinline__ uint32_t gw_reserve(uint32_t* shared, uint32_t tot)
+{
+    uint32_t at = 0;
+    if (tot && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) at = atomicAdd(shared, tot);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+}
 template <class Bloom>
 __device__ __forceinline__ void gw_take(const uint32_t* bits, const GwFrame& F, GwSink& S, uint32_t v, bool valid)
 {
     const bool keep = valid & (Bloom::twice(bits, v >> F.A) | F.edge(v));
     const uint64_t m = __ballot(keep);
+    if (S.shared) S.n2 = gw_reserve(S.shared, (uint32_t)__popcll(m));
     if (keep) {
         const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, S.n2));
         if (at < S.room) S.dst[at] = v;
@@ -184,6 +192,7 @@ __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F,
         kb[j] = valid & (hit | edge);
         km[j] = __ballot(valid) & (__ballot(hit) | __ballot(edge));
     }
+    if (S.shared) S.n2 = gw_reserve(S.shared, (uint32_t)(__popcll(km[0]) + __popcll(km[1]) + __popcll(km[2]) + __popcll(km[3])));
     uint32_t n2 = S.n2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -460,54 +469,61 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
 template <uint32_t WAVES, uint32_t T1LOG2, uint32_t T2LOG2>
 __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
+    // One BLOCK per read: its waves share ONE pair of filters (20 KB: with a pair per wave six waves fitted a CU) and take the read's
+    // entry chunks in turn -- phase A of all chunks, barrier, phase B; the kept numbers of all waves go to one list, its places
+    // reserved with an LDS counter.  The pool: the slices of this block's waves as the filter kernels before left them.
     using Bloom = GwBloom<T1LOG2, T2LOG2>;
-    __shared__ uint32_t bitS[WAVES][Bloom::kWords];
+    __shared__ uint32_t bits[Bloom::kWords];
     __shared__ uint64_t roundS[WAVES][kGwRounds];
+    __shared__ uint32_t n2S;
+    __shared__ unsigned long long ovfS;
     if (ws.midCount[12] == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* bits = bitS[wave];
     uint64_t* T = roundS[wave];
-    const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t nWaves = gridDim.x * WAVES;
-    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    const uint32_t w0 = blockIdx.x * WAVES;                        // the block's first wave (slice)
     const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
-    uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;
+    uint64_t used[WAVES];                                          // block-uniform copies
+#pragma unroll
+    for (uint32_t k = 0; k < WAVES; ++k) used[k] = ws.sliceFill ? ws.sliceFill[w0 + k] : 0u;
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
     const uint32_t mine = ws.midCount[12];
     const uint32_t* __restrict__ side = ws.sideList;
-    {
-      for (uint32_t i = w0; i < mine; i += nWaves) {
+    for (uint32_t i = blockIdx.x; i < mine; i += gridDim.x) {
         const uint32_t w = side[i];
         const uint4 rec = work[w];
         const uint32_t q = rec.x, fbase = rec.y, recZ = rec.z, maxWin = rec.w;
         const uint32_t nent = recZ & 0xFFFu, H = recZ >> 12;
         {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
-#pragma unroll
-            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+            for (uint32_t j = threadIdx.x; j < Bloom::kWords / 4; j += WAVES * 64) z4[j] = make_uint4(0, 0, 0, 0);
         }
+        if (threadIdx.x == 0) n2S = 0u;
         const GwFrame F(maxWin);
-        GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-        uint64_t listAt = (uint64_t)w0 * sliceCap + sliceUsed;
-        bool inSlice = true;
-        if (H > S.room) {
-            // the list may not fit what is left of this wave's slice: H places of the pool's overflow region (the filter keeps H at most)
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(reinterpret_cast<unsigned long long*>(ws.midCount + 16), (unsigned long long)H);
-            at = ((unsigned long long)rdlane((uint32_t)(at >> 32), 0) << 32) | rdlane((uint32_t)at, 0);
-            if (at + H <= ws.bigOvfCap) {
-                listAt = (uint64_t)ws.bigPoolCap + at;
-                S.dst = reinterpret_cast<uint32_t*>(ws.bigPool) + listAt; S.room = H; inSlice = false;
-            }
+        // where the list goes: the first of the block's slices that can take all H numbers, else H places of the overflow region
+        // (the filter keeps H at most), else what is left of the first slice (a list that outgrows it goes to the wave kernel)
+        int k = -1;
+#pragma unroll
+        for (uint32_t kk = 0; kk < WAVES; ++kk) if (k < 0 && (uint64_t)H <= min((uint64_t)kGwMaxKept, sliceCap - used[kk])) k = (int)kk;
+        uint64_t listAt = 0; uint32_t room = 0;
+        if (k >= 0) { listAt = (uint64_t)(w0 + (uint32_t)k) * sliceCap + used[k]; room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - used[k]); }
+        else {
+            if (threadIdx.x == 0) ovfS = atomicAdd(reinterpret_cast<unsigned long long*>(ws.midCount + 16), (unsigned long long)H);
+            __syncthreads();
+            const unsigned long long at = ovfS;
+            if (at + H <= ws.bigOvfCap) { listAt = (uint64_t)ws.bigPoolCap + at; room = H; }
+            else { k = 0; listAt = (uint64_t)w0 * sliceCap + used[0]; room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - used[0]); }
         }
+        GwSink S{reinterpret_cast<uint32_t*>(ws.bigPool) + listAt, room, 0u, &n2S};
+        __syncthreads();                                           // filters cleared, counter zero
         bool fallback = maxWin > tab.gwGap;                        // (window ranges wider than the gap between two targets: the kernels that know the targets)
         const uint32_t nchunks = (nent + 63u) / 64u;
+        uint32_t n2 = 0;
         if (!fallback) {
             for (uint32_t pass = 0; pass < 2; ++pass) {
-                for (uint32_t c = 0; c < nchunks; ++c) {
+                for (uint32_t c = wave; c < nchunks; c += WAVES) {
                     const uint32_t e = c * 64u + lane;
                     const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
                     const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
@@ -524,19 +540,17 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
                         wave_lds_sync();                           // the table is rewritten by the next batch
                     }
                 }
-                wave_lds_sync();
+                __syncthreads();                                   // every wave's marks before anybody's tests; every wave's numbers before the count is read
             }
-            fallback = S.n2 > S.room;
+            n2 = n2S;
+            fallback = n2 > room;
         }
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
-            else {
-                outRec[w] = make_uint4(q, (uint32_t)listAt, S.n2, maxWin);
-            }
+            else outRec[w] = make_uint4(q, (uint32_t)listAt, n2, maxWin);
         }
-        if (!fallback && inSlice) sliceUsed += S.n2;
-        wave_lds_sync();
-      }
+        if (!fallback && k >= 0) used[k] += n2;
+        __syncthreads();                                           // (the counter and the filters are reset for the next read)
     }
 }
 
@@ -1095,12 +1109,16 @@ __device__ __forceinline__ uint32_t gw_sorted_rounds(LaneCand (&top)[kLaneK], ui
     return strong;
 }
 
-// BIG = false: one wave per read; lists of more than kGwBigSorted numbers are only noted (ws.sideList[0], midCount[18]) -- the longest
-// read of a batch (19 kbp: 10^5 numbers at RefSeq scale) kept one wave busy long after all others had finished.
-// BIG = true (second launch): one BLOCK of sixteen waves per noted read, its list cut into sixteen runs of whole chunks, one per wave.  A target that
-// spans two runs leaves a candidate in each: the K rounds take the one with more hits (equal: the earlier one, it ends in the smaller
-// window) and strike the other -- as they always did between the lanes of one wave.  The waves' K picks meet in LDS, wave 0 picks
-// the K best of those 16 K.
+// BIG = false: one wave per read.  The work list is in descending order of the lists' lengths (launch_gw_order): the longest lists beyond
+// kGwBigSorted numbers -- up to kGwFewBig of them: the rare 10-19 kbp reads of a mixed batch keep 10^5 numbers at RefSeq scale, and the one
+// wave on such a list kept running long after all others had finished -- are left to the second launch (their count: midCount[18]).
+// The rest keeps one wave per read: sixteen waves per list cost more than they gain when every CU has work anyway (20 000 reads of
+// 10 kbp: 3.9 ms with one wave each, 6.5 ms with sixteen).
+// BIG = true (second launch): one BLOCK of sixteen waves per such read, its list cut into sixteen runs of whole chunks, one per wave.
+// A target that spans two runs leaves a candidate in each: the K rounds take the one with more hits (equal: the earlier one, it ends in
+// the smaller window) and strike the other -- as they always did between the lanes of one wave.  The waves' K picks meet in LDS, wave 0
+// picks the K best of those 16 K.
+constexpr uint32_t kGwFewBig = 1024;
 template <bool TAX, bool BIG>
 __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
                                                                            mc_candidate_dev* __restrict__ cands)
@@ -1113,7 +1131,6 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
     uint32_t* ring = ringS[wave];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t* __restrict__ side = ws.sideList + (size_t)3 * b.n;
-    uint32_t* __restrict__ bigList = ws.sideList;              // [0]: the stream filter's record list, done with by now
     auto finish = [&](uint32_t q, uint32_t strong) {
         if (lane == 0) {
             if (strong < K) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
@@ -1123,14 +1140,15 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
     if constexpr (!BIG) {
         const uint32_t nWaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
         const uint32_t nmine = ws.midCount[13];
-        for (uint32_t i = w0; i < nmine; i += nWaves) {
+        // how many lists are longer than kGwBigSorted (descending order: a binary search, the same in every wave)
+        uint32_t lo = 0, hi = nmine;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (work[side[mid]].z > kGwBigSorted) lo = mid + 1u; else hi = mid; }
+        const uint32_t nbig = min(lo, kGwFewBig);                  // the longest of them
+        if (w0 == 0 && lane == 0) ws.midCount[18] = nbig;
+        for (uint32_t i = nbig + w0; i < nmine; i += nWaves) {
             const uint32_t w = side[i];
             const uint4 rec = work[w];
             const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
-            if (n > kGwBigSorted) {
-                if (lane == 0) bigList[atomicAdd(&ws.midCount[18], 1u)] = w;
-                continue;
-            }
             LaneCand top[kLaneK];
             uint32_t toptax[kLaneK];
 #pragma unroll
@@ -1143,7 +1161,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
     } else {
         const uint32_t nbig = ws.midCount[18];
         for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
-            const uint4 rec = work[bigList[i]];
+            const uint4 rec = work[side[i]];
             const uint32_t q = rec.x, n = rec.z, maxWin = rec.w;
             const uint32_t chunks = (n + 63u) / 64u, cpw = (chunks + kWaves - 1u) / kWaves;
             const uint32_t first = min(n, wave * cpw * 64u), end = min(n, (wave + 1u) * cpw * 64u);
@@ -1202,6 +1220,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
         if (ws.orderScratch) { size_t tb = ws.orderTemp; (void)launch_gw_order(0, ws, b.n, b.n, ws.orderScratch, tb, st); }   // longest reads first
+        // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads)
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1) {

@@ -110,6 +110,9 @@ def test_key_shards_at_midscale_filtered_regime():
         assert np.mean(counts > 128) > 0.6, np.percentile(counts, [5, 50, 95])
         e2 = db.query(p1, p2)[0]
         e3 = db.query(longs)[0]
+        db.set_lineages(spec.lineages())
+        e4 = db.query(singles[:10_000], lowest=4)[0]               # taxon merging (per-number taxon lookups in the counting kernel, struck by taxon)
+        e5 = db.query(longs[:200], lowest=4)[0]
         db.close()
         del a, m1, m2, rows
         torch.cuda.empty_cache()
@@ -120,6 +123,8 @@ def test_key_shards_at_midscale_filtered_regime():
         assert g1info["reads_filtered"] > 0.6 * n1                # the owners' filtered path (gw_filter / gw_count on the receive buffer)
         g2 = ks.classify(p1, p2)
         g3 = ks.classify(longs)
+        g4 = ks.classify(singles[:10_000], lowest=4)
+        g5 = ks.classify(longs[:200], lowest=4)
         info = ks.info()
         sent = info["numbers_sent"]
         assert info["reads_filtered"] > g1info["reads_filtered"] + n2 // 2 + n3 // 2
@@ -127,6 +132,8 @@ def test_key_shards_at_midscale_filtered_regime():
         _same(g1, e1, "singles")
         _same(g2, e2, "pairs")
         _same(g3, e3, "long reads")
+        _same(g4, e4, "singles, species level")
+        _same(g5, e5, "long reads, species level")
         # every location of every read crossed the exchange exactly once, 4 bytes each
         assert sent > int(counts.sum())
     finally:
