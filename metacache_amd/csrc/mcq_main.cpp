@@ -844,12 +844,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             const uint32_t K = cfg.max_candidates;
             std::vector<mc_candidate> all(n * K);
             seq1.push_back('\0'); seq2.push_back('\0');
-            if (n && S.keyset) {
-                if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
-                                       o.insertMax, all.data()) != MC_OK)
-                    throw std::runtime_error(mc_keyset_last_error(S.keyset));
-            } else if (n && mc_partset_classify(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
-                                                o.insertMax, all.data()) != MC_OK)
+            if (n && mc_partset_classify(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                         o.insertMax, all.data()) != MC_OK)
                 throw std::runtime_error(mc_partset_last_error(S.partset));
             Acc A;
             std::vector<Cand> cands;
@@ -879,7 +875,91 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             }
             collect(A);
         };
-        if (S.partset || S.keyset) {
+        // -shard keys: no loop over part groups, so the batches stream -- worker threads cut the records out of the files side by side,
+        // one at a time hands its batch to mc_keyset_classify (the key set takes one call at a time), then formats its lines
+        std::mutex ksMtx;
+        auto work_keyset = [&](unsigned) {
+            struct Meta { uint64_t id; View header; bool empty; };
+            std::vector<Meta> metas;
+            std::string seq1, seq2, scratch1, scratch2;
+            std::vector<uint64_t> off1, off2;
+            std::vector<mc_candidate> all;
+            std::vector<Cand> cands;
+            std::ostringstream out;
+            Acc A;
+            const bool paired = o.pairing != Options::unpaired;
+            const uint32_t K = cfg.max_candidates;
+            auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = m; };
+            for (;;) {
+                size_t b;
+                const Batch* Bp = nullptr;
+                {
+                    std::unique_lock<std::mutex> l(batchMtx);
+                    batchCv.wait(l, [&] { return failed || nextBatch < batches.size() || !producing; });
+                    if (failed || nextBatch >= batches.size()) break;
+                    b = nextBatch++;
+                    Bp = &batches[b];
+                }
+                const Batch& B = *Bp;
+                metas.clear(); seq1.clear(); seq2.clear(); off1.assign(1, 0); off2.assign(1, 0);
+                for (size_t q = B.qBeg; q < B.qEnd; ++q) {
+                    View h1, s1, h2, s2;
+                    const size_t qi = B.sel ? (size_t)(*B.sel)[q] : q;
+                    if (o.pairing == Options::sequences) {
+                        files[B.f1]->record(2 * qi, h1, s1, scratch1);
+                        if (!(B.halfLast && q + 1 == B.qEnd)) files[B.f1]->record(2 * qi + 1, h2, s2, scratch2);
+                    } else {
+                        files[B.f1]->record(qi, h1, s1, scratch1);
+                        if (o.pairing == Options::files) files[B.f2]->record(qi, h2, s2, scratch2);
+                    }
+                    const bool halfPair = B.halfLast && q + 1 == B.qEnd;
+                    if (s1.n + s2.n + 8 > cfg.slot_max_chars) { std::cerr << "query batch is too small for a single read!\n"; continue; }
+                    metas.push_back(Meta{B.idBase + qi + (halfPair ? 0 : 1), h1, h1.empty() || s1.empty()});
+                    seq1.append(s1.p, s1.n); off1.push_back(seq1.size());
+                    if (paired) { seq2.append(s2.p, s2.n); off2.push_back(seq2.size()); }
+                }
+                const size_t n = metas.size();
+                all.assign(n * K, mc_candidate{});
+                seq1.push_back('\0'); seq2.push_back('\0');
+                if (n) {
+                    std::lock_guard<std::mutex> l(ksMtx);
+                    if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                           o.insertMax, all.data()) != MC_OK) { fail(mc_keyset_last_error(S.keyset)); break; }
+                }
+                out.str(std::string());
+                out << B.prefix;
+                for (size_t i = 0; i < n; ++i) {
+                    const Meta& m = metas[i];
+                    if (m.empty) continue;
+                    cands.clear();
+                    for (uint32_t j = 0; j < K; ++j) {
+                        const mc_candidate& c = all[i * K + j];
+                        if (c.hits == 0) break;
+                        Cand x{c.tgt, c.hits, c.beg, c.end, 0};
+                        if (c.tgt < tx.numTargets) {
+                            const uint32_t* lin = tx.targetLineages + (size_t)c.tgt * kNumRanks;
+                            if (o.lowest > 0) { for (int rk = o.lowest; rk < kNumRanks; ++rk) if (lin[rk]) { x.tax = lin[rk]; break; } }
+                            else x.tax = lin[0];
+                        }
+                        cands.push_back(x);
+                    }
+                    emit(A, out, m.id, m.header, cands, nullptr, 0);
+                }
+                deliver(b, out.str());
+            }
+            std::lock_guard<std::mutex> l(errMtx);
+            collect(A);
+        };
+        if (S.keyset) {
+            std::thread producer(produce);
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work_keyset, w);
+            work_keyset(0);
+            for (auto& t : pool) t.join();
+            { std::lock_guard<std::mutex> l(batchMtx); }
+            batchCv.notify_all();
+            producer.join();
+        } else if (S.partset) {
             produce();                                                           // (all batches known first: no overlap to win here)
             if (!producerError.empty()) throw std::runtime_error(producerError);
             work_partset();
