@@ -108,13 +108,14 @@ int mc_keyset_open(const char* name, const mc_config* cfg, uint32_t numShards, c
     const char* force = std::getenv("MC_KEYSET_RCCL");
     ks->rccl = nd > 1 || (ks->S == 1 && force && force[0] == '1');
     std::vector<void*> comms(nd, nullptr);
+    ks->rank.resize(ks->S);
+    for (uint32_t r = 0; r < ks->S; ++r) ks->rank[r].device = ks->devices[r % nd];
     if (ks->rccl) {
         Rccl& R = rccl();
         if (!R.load()) return bail(MC_ERR_UNSUPPORTED, R.err);
         if (int r = R.CommInitAll(comms.data(), (int)nd, ks->devices.data())) return bail(MC_ERR_HIP, "ncclCommInitAll: " + R.text(r));
+        for (uint32_t r = 0; r < ks->S; ++r) ks->rank[r].comm = comms[r % nd];      // (owned by the ranks from here on: mc_keyset_close destroys them)
     }
-    ks->rank.resize(ks->S);
-    for (uint32_t r = 0; r < ks->S; ++r) { ks->rank[r].device = ks->devices[r % nd]; ks->rank[r].comm = ks->rccl ? comms[r % nd] : nullptr; }
     const uint32_t mMax = (uint32_t)((ks->maxQ + ks->S - 1) / ks->S);
     // the shards load side by side (each reads the whole file and keeps its keys)
     for_each_rank(ks, [&](uint32_t r) {

@@ -40,6 +40,28 @@ def test_no_gpu_means_loud_failure():
     assert b"no CPU fallback" in api.lib().mc_last_error(None)
 
 
+def test_no_gpu_means_loud_failure_for_the_multi_gpu_drivers(golden):
+    """mc_partset_open / mc_keyset_open (parts / key shards over GPUs) fail loudly as well; bad arguments are refused before any device work"""
+    import torch
+    from metacache_amd.api import McError
+    if torch.cuda.is_available():
+        return
+    for cls, kw in ((api.PartSet, dict(resident=1)), (api.KeySet, dict(shards=2))):
+        try:
+            cls(golden.db_path("toy32"), **kw)
+        except McError as e:
+            assert "no usable HIP device" in str(e) or "no CPU fallback" in str(e), str(e)
+        else:
+            raise AssertionError(f"{cls.__name__} opened without a GPU")
+    L = api.lib()
+    L.mc_keyset_open.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    assert L.mc_keyset_open(None, None, 0, None, 0, None) == -1                       # MC_ERR_INVALID
+    L.mc_keyset_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert L.mc_keyset_info(None, None) == -1
+    L.mc_keyset_close.argtypes = [ctypes.c_void_p]
+    L.mc_keyset_close(None)                                                           # a no-op
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "metacache_amd")
     for dp, _, fs in os.walk(pkg):
