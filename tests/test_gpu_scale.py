@@ -404,3 +404,48 @@ def test_filter_second_instance_reads_of_five_to_ten_windows(monkeypatch, lowest
         _check(pc[i], e, K, ("pair", i, pcounts[i]))
     db.timing(False)
     db.close(); odb.close()
+
+
+@pytest.mark.parametrize("K,lowest,seed", [(2, 0, 11), (4, 0, 12), (1, 4, 13), (3, 4, 14), (2, 6, 15)])
+def test_sorted_path_strain_rich_long_reads_against_oracle(tmp_path, K, lowest, seed):
+    """The sorted path (stream filter -> segmented sort -> gw_sorted_cands_kernel) where its scan has the most to get wrong: long reads
+    (700 .. 19 000 bp, window ranges of 8 .. 171) on groups of up to 60 close strains -- filtered lists of tens of thousands of numbers
+    with dozens of targets, target runs that cross the 64-number chunks and the sixteen runs of the block pass, ties between strains,
+    taxon merging at species and genus level, K = 1 .. 4 -- every candidate against the oracle."""
+    from metacache_amd import synth
+    rng = np.random.default_rng(seed)
+    genomes, parents = [], []
+    for sp, (nst, size, div) in enumerate([(60, 24_000, 0.004), (25, 30_000, 0.01), (9, 21_000, 0.03), (1, 40_000, 0.0), (1, 26_000, 0.0)]):
+        base = synth.random_genome(rng, size)
+        for st in range(nst):
+            genomes.append(synth.mutate(rng, base, div) if st else base)
+            parents.append(1000 + sp)
+    bld = api.Builder(target_id_bytes=4, max_candidates=K)
+    for i, g in enumerate(genomes):
+        bld.add_target(g, f"S{i:04d}.1", parent_taxid=parents[i])
+    name = str(tmp_path / "strains")
+    bld.finish(load=False)
+    bld.write(name, [(1, 1, 20, "root"), (500, 1, 6, "genus a"), (501, 1, 6, "genus b")] + [(1000 + i, 500 + i % 2, 4, f"sp{i}") for i in range(5)])
+    bld.free()
+    reads = []
+    for i in range(160):
+        g = genomes[int(rng.integers(len(genomes)))]
+        L = int(min(g.size - 1, rng.choice([700, 1500, 3000, 6000, 12_000, 19_000])))
+        p = int(rng.integers(0, g.size - L))
+        r = synth.mutate(rng, g[p:p + L], float(rng.choice([0.0, 0.02, 0.075])))
+        if i % 5 == 0:                                            # chimeras: two genomes' pieces in one read
+            g2 = genomes[int(rng.integers(len(genomes)))]
+            r = np.concatenate([r[: L // 2], g2[: L // 2]])
+        reads.append(bytes(synth.revcomp(r) if rng.random() < 0.5 else r))
+    odb = cpuref.oracle().open(name)
+    db = api.Database.open(name, max_candidates=K, slot_max_queries=1 << 10, slot_max_chars=1 << 23)
+    assert db.table_layout()["location_bytes"] == 4
+    db.timing(True); db.timing_reset()
+    cands, counts, _ = db.query(reads, lowest=lowest)
+    db.timing(False)
+    assert db.timing_get("gw_sorted_cands")[1] > 0 and counts.max() > 30_000, counts.max()
+    db.close()
+    for i, r in enumerate(reads):
+        _, e = odb.query(r, b"", K, lowest, 0)
+        _check(cands[i], e, K, (i, len(r), counts[i]))
+    odb.close()
