@@ -659,12 +659,12 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
     // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, in->num_chars * 3) : (uint64_t)n * 8,
-                                                                                  (uint64_t)big_filter_grid(n) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
+                                                                                  (uint64_t)big_filter_grid(n, T0.compact) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
     // compact store: behind the waves' slices an OVERFLOW region for filtered lists that may not fit their wave's slice (the longest
     // reads of a batch keep 10^5 numbers): reserved with one atomic per such read (midCount[16..17])
     const uint64_t ovfCap = T0.compact ? std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20)) : 0;
     if (lanePath && (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
-    if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n) * 4 * 4 + 64))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, T0.compact) * 4 * 4 + 64))) return rc;
     if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
@@ -872,7 +872,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
         (rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4)) || (rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4)) ||
         (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)))
         return rc;
-    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * 448, (uint64_t)big_filter_grid(n) * 4 * 1024));
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * 448, (uint64_t)big_filter_grid(n, false) * 4 * 1024));
     if ((rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
     // srcStart (union) and the one-entry-per-read tables of the filtered path share bPpay: [S * (n + 2)] u64 | [n] u64
     uint64_t* srcStart = (uint64_t*)P.bPpay.p;
@@ -973,13 +973,13 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
     if (rc) return rc;
     const uint64_t avg = totalIn / std::max<uint32_t>(n, 1);
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(std::max<uint64_t>((uint64_t)n * 448, totalIn / 2),
-                                                                                  (uint64_t)big_filter_grid(n) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, avg))));
+                                                                                  (uint64_t)big_filter_grid(n, true) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, avg))));
     const uint64_t ovfCap = std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20));
     if ((rc = ensure(ctx, P.bPsize, ((size_t)n * S + 4) * 4)) || (rc = ensure(ctx, P.bPpay, ((size_t)n * S + (size_t)S * (n + 2) + 4) * 8)) ||
         (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) || (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) ||
         (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
         (rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)) ||
-        (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * 4)) || (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n) * 4 * 4 + 64)) ||
+        (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * 4)) || (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, true) * 4 * 4 + 64)) ||
         (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4)) ||
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
@@ -1071,6 +1071,8 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "quad_lookup") ctx->quadLookup = value < 0 ? -1 : (value != 0);
     else if (n == "lane_path") ctx->useLanePath = value != 0;
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
+    else if (n == "filter_bpc") mcamd::g_filterBpc = (int)value;               // blocks per CU of the filter kernels' persistent grids (0 = default)
+    else if (n == "count_bpc") mcamd::g_countBpc = (int)value;
     else if (n == "gw_diag") mcamd::g_gwDiag = (int)value;                     // timing experiments on gw_filter_kernel (wrong results)
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
