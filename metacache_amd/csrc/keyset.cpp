@@ -135,7 +135,14 @@ int mc_keyset_open(const char* name, const mc_config* cfg, uint32_t numShards, c
         hipHostMalloc((void**)&ks->hmw, ks->maxQ * 4) != hipSuccess)
         return bail(MC_ERR_NOMEM, "mc_keyset_open: cannot allocate the pinned batch staging");
     uint64_t info[8];
-    for (KsRank& R : ks->rank) { mc_db_info(R.ctx, info); ks->locations += info[7]; ks->stride = (uint32_t)(info[3] ? info[3] : 112); }
+    for (KsRank& R : ks->rank) {
+        mc_db_info(R.ctx, info); ks->locations += info[7]; ks->stride = (uint32_t)(info[3] ? info[3] : 112);
+        // what travels is the compact store's global window number: a database without that numbering (several parts, more than 2^32
+        // windows with their gaps, MC_COMPACT_LOCATIONS=0) keeps the per-process 8-byte form (metacache_amd/distributed.py, wire = 8)
+        uint64_t lay[4] = {0, 0, 0, 0};
+        if (mc_table_layout(R.ctx, lay) != MC_OK || lay[0] != 4)
+            return bail(MC_ERR_UNSUPPORTED, "mc_keyset_open: the database has no 32-bit global window numbers (single part, compact location store) to send between the shards");
+    }
     *out = ks;
     return MC_OK;
 }

@@ -140,3 +140,10 @@ def test_key_shards_at_midscale_filtered_regime():
         for e in (".meta", ".cache0"):
             if os.path.exists(name + e):
                 os.remove(name + e)
+
+
+def test_key_shards_need_the_window_numbering(golden, monkeypatch):
+    """a table that keeps 8-byte locations has nothing 4 bytes wide to send: mc_keyset_open says so instead of failing at the first batch"""
+    monkeypatch.setenv("MC_COMPACT_LOCATIONS", "0")
+    with pytest.raises(api.McError, match="global window numbers"):
+        api.KeySet(golden.db_path("toy32"), shards=2, max_candidates=2)
