@@ -1,5 +1,6 @@
 """Builds the configs[2] table once (bench.py's collection at --scale) and times the hot path for settings of run-time tuning switches
-(mc_set_tuning), e.g. the diagnostic variants of gw_filter_kernel:  python tools/tune_gw.py --scale 1 --set gw_diag=0,1,2,3"""
+(mc_set_tuning), e.g. the diagnostic variants of gw_filter_kernel or the grids' blocks per CU:
+  python tools/tune_gw.py --scale 1 --set gw_diag=0,1,2,3      python tools/tune_gw.py --scale 1 --set filter_bpc=5,10,20      --set count_bpc=8,16,24"""
 import argparse
 import json
 import os
@@ -22,7 +23,6 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--set", default="gw_diag=0", help="name=v1,v2,...: one timed run per value")
     ap.add_argument("--load-factor", type=float, default=0.3)
-    ap.add_argument("--pairs", action="store_true")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
