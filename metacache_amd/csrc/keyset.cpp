@@ -67,6 +67,13 @@ int ks_fail(mc_keyset* ks, int code, const std::string& msg) { if (ks) ks->err =
 // contiguous, balanced read shards (as metacache_amd/distributed.py shard_bounds)
 uint32_t shard_lo(uint32_t n, uint32_t r, uint32_t world) { const uint32_t base = n / world, rem = n % world; return r * base + std::min(r, rem); }
 
+// an error leaves nothing in flight: the next call (or mc_keyset_close) finds idle streams and free staging buffers
+int ks_fail_idle(mc_keyset* ks, int code, const std::string& msg)
+{
+    for (KsRank& R : ks->rank) { (void)hipSetDevice(R.device); if (R.stream) (void)hipStreamSynchronize(R.stream); }
+    return ks_fail(ks, code, msg);
+}
+
 template <class F>
 void for_each_rank(mc_keyset* ks, F&& f)
 {
@@ -228,17 +235,17 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
             if (!rc && !ks->rccl && hipStreamSynchronize(Rk.stream) != hipSuccess) rc = MC_ERR_HIP;   // (copies below run on the owners' streams)
             if (rc) { Rk.rc = rc; Rk.err = rc == MC_ERR_HIP && Rk.err.empty() ? "HIP error" : mc_last_error(Rk.ctx); }
         });
-        for (KsRank& Rk : ks->rank) if (Rk.rc) return ks_fail(ks, Rk.rc, Rk.err);
+        for (KsRank& Rk : ks->rank) if (Rk.rc) return ks_fail_idle(ks, Rk.rc, Rk.err);
         // ---- 2. the exchange.  Owner o receives from source s the numbers [cuts_s[o], cuts_s[o + 1]) and the counts of its reads
         for (uint32_t o = 0; o < S; ++o) {
             KsRank& O = ks->rank[o];
             O.srcOff.assign(S + 1, 0);
             for (uint32_t s = 0; s < S; ++s) O.srcOff[s + 1] = O.srcOff[s] + (ks->rank[s].cuts[o + 1] - ks->rank[s].cuts[o]);
             if (O.srcOff[S] + 8 > O.recvCap) {
-                if (hipSetDevice(O.device) != hipSuccess) return ks_fail(ks, MC_ERR_HIP, "hipSetDevice");
+                if (hipSetDevice(O.device) != hipSuccess) return ks_fail_idle(ks, MC_ERR_HIP, "hipSetDevice");
                 if (O.drecvNumbers) { (void)hipStreamSynchronize(O.stream); (void)hipFree(O.drecvNumbers); O.drecvNumbers = nullptr; }
                 O.recvCap = O.srcOff[S] + O.srcOff[S] / 4 + 1024;
-                if (hipMalloc((void**)&O.drecvNumbers, O.recvCap * 4) != hipSuccess) { O.recvCap = 0; return ks_fail(ks, MC_ERR_NOMEM, "mc_keyset_classify: receive buffer"); }
+                if (hipMalloc((void**)&O.drecvNumbers, O.recvCap * 4) != hipSuccess) { O.recvCap = 0; return ks_fail_idle(ks, MC_ERR_NOMEM, "mc_keyset_classify: receive buffer"); }
             }
             ks->numbersSent += O.srcOff[S];
         }
@@ -258,7 +265,7 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
                 }
             }
             const int e = R.GroupEnd();
-            if (r || e) return ks_fail(ks, MC_ERR_HIP, "RCCL exchange of the partial lists: " + R.text(r ? r : e));
+            if (r || e) return ks_fail_idle(ks, MC_ERR_HIP, "RCCL exchange of the partial lists: " + R.text(r ? r : e));
         } else {
             for (uint32_t o = 0; o < S; ++o) {
                 KsRank& O = ks->rank[o];
@@ -285,7 +292,7 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
             if (rc) { O.rc = rc; O.err = mc_last_error(O.ctx); return; }
             if (hipStreamSynchronize(O.stream) != hipSuccess) { O.rc = MC_ERR_HIP; O.err = "copy of the candidates failed"; }
         });
-        for (KsRank& Rk : ks->rank) if (Rk.rc) return ks_fail(ks, Rk.rc, Rk.err);
+        for (KsRank& Rk : ks->rank) if (Rk.rc) return ks_fail_idle(ks, Rk.rc, Rk.err);
         // (a rank without reads of its own still took part in the exchange: its sends must be done before its buffers are reused)
         for (KsRank& Rk : ks->rank) { (void)hipSetDevice(Rk.device); (void)hipStreamSynchronize(Rk.stream); }
         ++ks->batches;
