@@ -346,8 +346,8 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
 /* tuning / test hook (not needed for normal use): the switches the MC_BIG_MIN / MC_QUAD_LOOKUP / MC_NO_LANE_PATH environment variables
  * set at mc_create, on a live context with no batch in flight.  names: "big_min" (location lists longer than this are filtered by
  * target before they are counted, big_filter_kernel), "quad_lookup" (-1 by table size, 0 / 1), "lane_path" (0 / 1), "compact_locations" (0 / 1, before mc_load_begin),
- * "filter_bpc" / "count_bpc" (blocks per CU of the filter kernels' / the first counting instance's persistent grids, 0 = default; process-wide),
- * "gw_diag" (timing variants of gw_filter_kernel: wrong results). */
+ * "filter_bpc" / "count_bpc" (blocks per CU of the filter kernels' / the first counting instance's persistent grids, 0 = default; this context only),
+ * "gw_diag" (timing variants of gw_filter_kernel: wrong results by design -- refused unless MC_ALLOW_DIAG=1 is set in the environment). */
 int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).

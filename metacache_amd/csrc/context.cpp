@@ -659,12 +659,12 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
     // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, in->num_chars * 3) : (uint64_t)n * 8,
-                                                                                  (uint64_t)big_filter_grid(n, T0.compact) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
+                                                                                  (uint64_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
     // compact store: behind the waves' slices an OVERFLOW region for filtered lists that may not fit their wave's slice (the longest
     // reads of a batch keep 10^5 numbers): reserved with one atomic per such read (midCount[16..17])
     const uint64_t ovfCap = T0.compact ? std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20)) : 0;
     if (lanePath && (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
-    if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, T0.compact) * 4 * 4 + 64))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * 4 + 64))) return rc;
     if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
@@ -673,6 +673,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -832,6 +833,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -872,13 +874,14 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
         (rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4)) || (rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4)) ||
         (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)))
         return rc;
-    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * 448, (uint64_t)big_filter_grid(n, false) * 4 * 1024));
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)n * 448, (uint64_t)big_filter_grid(n, false, ctx->filterBpc) * 4 * 1024));
     if ((rc = ensure(ctx, P.bBigPool, poolCap * 8))) return rc;
     // srcStart (union) and the one-entry-per-read tables of the filtered path share bPpay: [S * (n + 2)] u64 | [n] u64
     uint64_t* srcStart = (uint64_t*)P.bPpay.p;
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -973,17 +976,18 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
     if (rc) return rc;
     const uint64_t avg = totalIn / std::max<uint32_t>(n, 1);
     const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(std::max<uint64_t>((uint64_t)n * 448, totalIn / 2),
-                                                                                  (uint64_t)big_filter_grid(n, true) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, avg))));
+                                                                                  (uint64_t)big_filter_grid(n, true, ctx->filterBpc) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, avg))));
     const uint64_t ovfCap = std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20));
     if ((rc = ensure(ctx, P.bPsize, ((size_t)n * S + 4) * 4)) || (rc = ensure(ctx, P.bPpay, ((size_t)n * S + (size_t)S * (n + 2) + 4) * 8)) ||
         (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) || (rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4)) ||
         (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
         (rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)) ||
-        (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * 4)) || (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, true) * 4 * 4 + 64)) ||
+        (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * 4)) || (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, true, ctx->filterBpc) * 4 * 4 + 64)) ||
         (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4)) ||
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1071,9 +1075,13 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "quad_lookup") ctx->quadLookup = value < 0 ? -1 : (value != 0);
     else if (n == "lane_path") ctx->useLanePath = value != 0;
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
-    else if (n == "filter_bpc") mcamd::g_filterBpc = (int)value;               // blocks per CU of the filter kernels' persistent grids (0 = default)
-    else if (n == "count_bpc") mcamd::g_countBpc = (int)value;
-    else if (n == "gw_diag") mcamd::g_gwDiag = (int)value;                     // timing experiments on gw_filter_kernel (wrong results)
+    else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
+    else if (n == "count_bpc") ctx->countBpc = (int)value;
+    else if (n == "gw_diag") {                                                 // timing experiments on gw_filter_kernel (WRONG results): only with MC_ALLOW_DIAG=1 in the environment
+        const char* e = std::getenv("MC_ALLOW_DIAG");
+        if (!(e && e[0] == '1')) return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: gw_diag needs MC_ALLOW_DIAG=1 (its results are wrong by design)");
+        ctx->gwDiag = (int)value;
+    }
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }
@@ -1104,6 +1112,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     Pipe& P = ctx->pipe0;
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

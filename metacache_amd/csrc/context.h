@@ -125,6 +125,8 @@ struct mc_ctx {
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on
                                            // strain-rich tables -- off by default
 
+    int filterBpc = 0, countBpc = 0, gwDiag = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), diagnostic variant of gw_filter_kernel -- this context only
+
     uint64_t ownerStats[4] = {0, 0, 0, 0}; // mc_owner_stats: reads, reads on the filtered path, numbers received, locations decoded for the sort
 
     // timing

@@ -1191,8 +1191,6 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
     }
 }
 
-int g_countBpc = 0;                                           // mc_set_tuning(ctx, "count_bpc", n): blocks per CU of the first counting instance (0 = default)
-int g_gwDiag = 0;                                              // mc_set_tuning(ctx, "gw_diag", n): timing experiments, see gw_filter_kernel
 
 static uint32_t gw_env(const char* name, uint32_t dflt)
 {
@@ -1205,9 +1203,9 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
 {
     if (b.n == 0) return;
     mc_candidate_dev* c = (mc_candidate_dev*)cands;
-    const uint32_t fgrid = big_filter_grid(b.n, true);               // blocks of 4 waves: the pool is cut into one slice per wave
+    const uint32_t fgrid = big_filter_grid(b.n, true, ws.filterBpc);               // blocks of 4 waves: the pool is cut into one slice per wave
     if (stage == 0) {
-        switch (g_gwDiag) {
+        switch (ws.gwDiag) {
             case 1: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 1>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
             case 2: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 2>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
             case 3: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 3>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
@@ -1229,7 +1227,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // (eight blocks per CU are resident; a grid of exactly that many left the waves with 9 or 10 steps of 64 records each and the CU waiting
         // for the last one: 5.9 ms per 5 x 10^6 reads; 16 / 24 / 32 blocks per CU: 5.23 / 5.19 / 5.15)
         static const uint32_t bpcEnv = gw_env("MC_BIG_COUNT_BPC", 24u);
-        const uint32_t bpc = g_countBpc > 0 ? (uint32_t)g_countBpc : bpcEnv;
+        const uint32_t bpc = ws.countBpc > 0 ? (uint32_t)ws.countBpc : bpcEnv;
         // (second instance: 40 KB of LDS per block = four blocks per CU at a time; its grid in whole rounds of four)
         static const uint32_t bpc1 = gw_env("MC_BIG_COUNT1_BPC", 16u);
         const uint32_t grid = std::min<uint32_t>(256 * bpc, (b.n + 3) / 4), grid1 = std::min<uint32_t>(256 * bpc1, (b.n + 3) / 4);

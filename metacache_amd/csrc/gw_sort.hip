@@ -50,7 +50,8 @@ int launch_gw_order(uint32_t list, const Workspace& ws, uint32_t n, uint32_t cou
 {
     uint32_t* side = ws.sideList + (size_t)list * n;
     uint32_t* keysIn = scratch, *keysOut = scratch ? scratch + count : nullptr, *valsOut = scratch ? scratch + 2 * (size_t)count : nullptr;
-    void* temp = scratch ? scratch + 3 * (size_t)count : nullptr;
+    // (rocPRIM lays its temporaries out from an aligned base: round up to 256 bytes -- the callers' + 256 bytes of slack are for this)
+    void* temp = scratch ? reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(scratch + 3 * (size_t)count) + 255u) & ~(uintptr_t)255u) : nullptr;
     if (!scratch) return (int)rocprim::radix_sort_pairs_desc(nullptr, tempBytes, keysIn, keysOut, side, valsOut, count, 0u, 32u, st);
     if (count == 0) return 0;
     hipLaunchKernelGGL(order_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, st, ws, n, list, count, keysIn);

@@ -163,6 +163,8 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint64_t* cscr2;         // [H]        second scratch (taxon merging, large queries)
     void*     scanTmp;       // block sums for the scans
     uint64_t* stats;         // [8]        batch statistics (on demand)
+    // host side only: the context's grid tuning switches (mc_set_tuning; 0 = default) -- per context, never process-wide
+    int32_t   filterBpc = 0, countBpc = 0, gwDiag = 0;
 };
 
 // launchers (all asynchronous on 'st')
@@ -213,7 +215,7 @@ int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_
                       uint32_t endBit, hipStream_t st);
 // ws.sideList[list] (list 0: the stream filter's reads, 3: the sorted class) in descending order of the records' work; scratch == nullptr: size query
 int launch_gw_order(uint32_t list, const Workspace& ws, uint32_t n, uint32_t count, uint32_t* scratch, size_t& tempBytes, hipStream_t st);
-uint32_t big_filter_grid(uint32_t n, bool compact);     // blocks of 4 waves the filter kernels run with (compact: the gw kernels): the pool is cut into one slice per wave
+uint32_t big_filter_grid(uint32_t n, bool compact, int bpcOverride = 0);     // (bpcOverride: mc_set_tuning "filter_bpc" of the context) blocks of 4 waves the filter kernels run with (compact: the gw kernels): the pool is cut into one slice per wave
 void launch_mid_cands(uint32_t cls, const BatchView& b, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                       const uint32_t* taxkey, void* cands, hipStream_t st);
 void launch_cands_from_hits(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* taxkey, uint32_t maxCand,
@@ -233,9 +235,6 @@ void launch_owner_entries(const BatchView& b, const DeviceTable& tab, const Work
                           const KeyshardBases& bases, uint32_t S, hipStream_t st);
 void launch_decode_union(const BatchView& b, const DeviceTable& tab, const Workspace& ws, const uint32_t* counts, const uint64_t* srcStart,
                          const KeyshardBases& bases, uint32_t S, hipStream_t st);
-extern int g_filterBpc;                   // blocks per CU of the filter kernels (mc_set_tuning "filter_bpc"; 0 = default)
-extern int g_countBpc;                    // blocks per CU of gw_count_kernel's first instance (mc_set_tuning "count_bpc"; 0 = default)
-extern int g_gwDiag;                      // timing experiments on gw_filter_kernel (mc_set_tuning "gw_diag")
 bool lane_path_supported(const SketchParams& sp);
 bool lane_candidates_supported(uint32_t maxCand);
 constexpr uint32_t kLdsCap = 256;         // location lists up to this length are sorted in LDS

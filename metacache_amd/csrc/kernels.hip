@@ -2585,7 +2585,7 @@ constexpr uint32_t kBigMinShift = MC_BIG_MIN_SHIFT;   // smallest round: 1 << sh
 constexpr uint32_t kBigMaxFiltered = 1024;
 constexpr uint32_t kBigMaxRounds = kBigEnt * 4;
 
-uint32_t big_filter_grid(uint32_t n, bool compact);
+uint32_t big_filter_grid(uint32_t n, bool compact, int bpcOverride);
 static uint32_t big_count_bpc(bool compact)
 {
     static const uint32_t env = [] { const char* e = std::getenv("MC_BIG_COUNT_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 0u; }();
@@ -2968,10 +2968,10 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         else        hipLaunchKernelGGL((big_count_kernel<L, W, false>), dim3(grid), dim3(W * 64), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, minN2);
     };
     if (stage == 0) {
-        hipLaunchKernelGGL((big_filter_kernel<4, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n, false)), dim3(256), 0, st, b, tab, ws);
+        hipLaunchKernelGGL((big_filter_kernel<4, 1, false, kBigT1Log2, kBigT2Log2>), dim3(big_filter_grid(b.n, false, ws.filterBpc)), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 3) {                                   // the filter's second instance: queries with 65 .. 192 found features
         // two waves per block, twice the blocks: the same number of waves -- and so the same pool slices -- as the first instance
-        hipLaunchKernelGGL((big_filter_kernel<2, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n, false)), dim3(128), 0, st, b, tab, ws);
+        hipLaunchKernelGGL((big_filter_kernel<2, kBigEPL, true, MC_BIG_POS_T1, MC_BIG_POS_T2>), dim3(2 * big_filter_grid(b.n, false, ws.filterBpc)), dim3(128), 0, st, b, tab, ws);
     } else if (stage == 1) {
         // blocks per CU by LDS: 40 KB per block
         count(std::integral_constant<uint32_t, 10>{}, std::integral_constant<uint32_t, 4>{}, std::min<uint32_t>(256 * big_count_bpc(false), (b.n + 3) / 4), 0u);
@@ -2981,14 +2981,13 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
         count(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 2>{}, std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2), 512u);
     }
 }
-int g_filterBpc = 0;                                          // mc_set_tuning(ctx, "filter_bpc", n): blocks per CU of the filter kernels' grids (0 = default)
 // Persistent grids of 4-wave blocks; what matters is how many of them a CU HOLDS at a time.  big_filter_kernel (8-byte store): 22.5 KB of
 // LDS per block, 66 registers: seven per CU (4 / 5 / 6 blocks with the 4 KB state table: 18.4 / 15.9 / 15.0 ms).  gw_filter_kernel
 // (compact store): 96 registers = five waves per SIMD = five blocks per CU; a grid of seven left two blocks per CU to start when the
 // first five had done their whole share (11.3 ms; six: 12.3).  Whole rounds of five: 5 -> 10.4 ms, 10 -> 10.2, 20 -> 9.96, 25 -> 9.92 ms per 5 x 10^6 reads (finer shares end closer together).
-uint32_t big_filter_grid(uint32_t n, bool compact)
+uint32_t big_filter_grid(uint32_t n, bool compact, int bpcOverride)
 {
-    if (g_filterBpc > 0) return std::min<uint32_t>(256u * (uint32_t)g_filterBpc, (n + 3) / 4);
+    if (bpcOverride > 0) return std::min<uint32_t>(256u * (uint32_t)bpcOverride, (n + 3) / 4);
     static const uint32_t env = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 0u; }();
     const uint32_t bpc = env ? env : compact ? 20u : 7u;
     return std::min<uint32_t>(256 * bpc, (n + 3) / 4);
@@ -3048,7 +3047,7 @@ void launch_wave_rejoin(const BatchView& b, const SketchParams& sp, const Device
 // parts' sorted lists; a target belongs to one part, so per-part lists are what the scan of the concatenation yields).  One lane per read.
 struct PartLists { const mc_candidate_dev* p[16]; };
 __global__ __launch_bounds__(256) void merge_parts_kernel(PartLists L, uint32_t nlists, uint32_t n, uint32_t K, const uint32_t* __restrict__ taxkey,
-                                                          mc_candidate_dev* __restrict__ out)
+                                                          mc_candidate_dev* out)   // (no __restrict__: rounds of more than 16 lists pass the output as list 0 -- a lane reads its own rows before it writes them)
 {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;

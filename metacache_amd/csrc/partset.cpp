@@ -84,6 +84,8 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
 
 void start_loader(mc_partset* ps, uint32_t first)
 {
+    if (ps->loader.joinable()) ps->loader.join();              // (never assign to a joinable thread: std::terminate)
+    close_group(ps->next);
     ps->nextFirst = first;
     ps->loaderRc = MC_OK;
     ps->loader = std::thread([ps, first] {
@@ -211,10 +213,11 @@ int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, 
     }
     std::vector<uint8_t> hseq(ps->maxChars + 64);
     std::vector<uint32_t> hq(ps->maxQ * 4), hmw(ps->maxQ);
+    // an earlier call that ended in an error may have left the loader running and a half-used group behind: settle that first
+    if (ps->loader.joinable()) ps->loader.join();
+    close_group(ps->next);
     // back to the first group if an earlier call left another one resident
     if (ps->curFirst != 0) {
-        if (ps->loader.joinable()) ps->loader.join();
-        close_group(ps->next);
         close_group(ps->cur);
         std::string err;
         int rc = open_group(ps, 0, ps->cur, err);

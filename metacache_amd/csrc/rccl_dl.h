@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <mutex>
 #include <string>
 
 namespace mcamd {
@@ -22,9 +23,18 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
     static constexpr int kChar = 0, kUint32 = 3;
+    int state = 0;                     // 0 = not tried, 1 = usable, -1 = failed (err says why): the OUTCOME is cached, not the handle
+    std::mutex mtx;                    // a keyset and a partset may be opened from two threads at once
     bool load()
     {
-        if (lib) return true;
+        std::lock_guard<std::mutex> lock(mtx);
+        if (state) return state > 0;
+        state = load_locked() ? 1 : -1;
+        if (state < 0 && lib) { dlclose(lib); lib = nullptr; }
+        return state > 0;
+    }
+    bool load_locked()
+    {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;

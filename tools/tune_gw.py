@@ -4,6 +4,7 @@
 import argparse
 import json
 import os
+os.environ.setdefault("MC_ALLOW_DIAG", "1")   # the gw_diag variants (wrong results by design) are refused without it
 import sys
 import time
 
