@@ -53,13 +53,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
 PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
-           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan",
-           "sort_candidates")
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter_rest", "gw_count", "gw_count_1024",
+           "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates")
 KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
-PMC_NAMES = {"sketch_lane": ("sketch_lane",), "probe_cands": ("probe_cands",), "sketch_probe": ("sketch_probe_lane",),
-             "query_wave": ("query_kernel<fused>", "query_kernel<unfused>"), "sort_candidates": ("sort_candidates",),
-             "big_filter": ("big_filter",), "big_count": ("big_count",), "big_count_2": ("big_count_2",), "hash_cands_256": ("hash_cands_256", "hash_cands"),
-             "hash_cands_512": ("hash_cands_512", "hash_cands"), "hash_cands_1024": ("hash_cands_1024", "hash_cands"), "mid_cands_64": ("mid_cands",), "mid_cands_128": ("mid_cands",), "mid_cands_256": ("mid_cands",)}
+# timer (mc_timing_get) -> the kernel's own name as the rocprofv3 summaries carry it (scripts/summarize_profile.py): prefixes
+KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cands_kernel",), "sketch_probe": ("sketch_probe_lane_kernel",),
+             "query_wave": ("query_kernel",), "sort_candidates": ("sort_candidates_kernel",),
+             "gw_filter_count": ("gw_filter_count_kernel", "gw_filter_count_simple_kernel"), "gw_filter": ("gw_filter_kernel",),
+             "gw_filter_rest": ("gw_filter_stream_kernel", "gw_filter2_kernel"), "gw_count": ("gw_count_kernel<9", "gw_count_kernel<10"),
+             "gw_count_1024": ("gw_count_kernel<11",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
+             "big_count_2": ("big_count_kernel<11",), "hash_cands_256": ("hash_cands_kernel<9",), "hash_cands_512": ("hash_cands_kernel<10",),
+             "hash_cands_1024": ("hash_cands_kernel<11",), "mid_cands_64": ("mid_cands_kernel",), "mid_cands_128": ("mid_cands_kernel",),
+             "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("rocprim",), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
+             "gather_lists": ("gather_lists_kernel",), "owner_entries": ("owner_entries_kernel",), "decode_union": ("decode_union_kernel",)}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
 # --shape refseq72k: the same 150 Gbp as a collection shaped like a real bacterial RefSeq -- 72 000 targets, most of 0.5 .. 3 Mbp, 3 % of
@@ -135,22 +141,26 @@ def make_long_reads(spec, gen, n: int, seed: int, dev, stride: int = 112):
     return {"seq": seq, "qinfo": qinfo, "maxwin": maxwin, "nchars": int(offs[-1]), "bases": int(lens.sum()), "lens": lens, "offs": offs}
 
 
+def _pmc_rows(kernel_timer_name: str, tag: str):
+    import csv
+    fn = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
+    if not os.path.exists(fn):
+        return None, {}
+    vals = {}
+    for r in csv.DictReader(open(fn)):
+        if any(r["kernel"].startswith(p) for p in KERNEL_OF.get(kernel_timer_name, ())):
+            vals.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
+    return fn, vals
+
+
 def measured_traffic(kernel_timer_name: str, tag: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
     (profiles/<tag>_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes; gfx950 caveat of
     MI355X_MICROARCH.md calibrated in profiles/r01_fetch_calibration.md).  None if no summary of this configuration exists."""
-    import csv
-    names = PMC_NAMES.get(kernel_timer_name, ())
-    fn = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
-    if not os.path.exists(fn):
-        return None, None
-    vals = {}
-    for r in csv.DictReader(open(fn)):
-        if r["kernel"] in names and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
-    for k in names:
-        if k in vals and len(vals[k]) == 2:
-            return (vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
+    fn, vals = _pmc_rows(kernel_timer_name, tag)
+    for k, v in vals.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
     return None, None
 
 
@@ -169,15 +179,20 @@ def gather_peak(gib: float):
 
 def measured_requests(kernel_timer_name: str, tag: str):
     """TCC_EA0_RDREQ of the dominant kernel per launch from the committed PMC summary (64-byte requests, profiles/r01_fetch_calibration.md)"""
-    import csv
-    names = PMC_NAMES.get(kernel_timer_name, ())
-    fn = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
-    if not os.path.exists(fn):
-        return None
-    for r in csv.DictReader(open(fn)):
-        if r["kernel"] in names and r["counter"] == "TCC_EA0_RDREQ_sum":
-            return float(r["mean_per_dispatch"])
+    _, vals = _pmc_rows(kernel_timer_name, tag)
+    for v in vals.values():
+        if "TCC_EA0_RDREQ_sum" in v:
+            return v["TCC_EA0_RDREQ_sum"]
     return None
+
+
+def kernel_bytes_per_read(timer: str, L: float, F: float, H: float, K: int, V: int):
+    """the kernel's OWN share of SURVEY §8(d)'s bytes per read (ceil(L/4) + ceil(L/8) + 12 F + V H + 16 K): the read's characters belong to the
+    sketching kernel, 12 F to the lookups, the V H bytes of the lists to the filter, the 16 K bytes of candidates to whoever writes them"""
+    share = {"sketch_lane": (L + 3) // 4 + (L + 7) // 8, "sketch_probe": (L + 3) // 4 + (L + 7) // 8 + 12.0 * F, "probe_cands": 12.0 * F,
+             "gw_filter_count": V * H + 16.0 * K, "gw_filter": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
+             "gather_lists": V * H}
+    return share.get(timer)
 
 
 def algorithmic_bytes_per_read(F: float, H: float, K: int, V: int) -> float:
@@ -281,20 +296,32 @@ def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s, mates_ho
     odb = scale_util.oracle_database(spec, wanted, threads=threads)
     build_s = time.time() - t0
     if mates_host is not None:
-        # pairs: the oracle one pair at a time (its bulk entry takes single reads); the baseline value is then pairs x 2 per minute
+        # pairs: the oracle's per-query entry (its bulk entry takes single reads), `threads` host threads each with a contiguous share of
+        # the pairs (the C call releases the interpreter lock); the baseline value is then pairs x 2 per minute
+        from concurrent.futures import ThreadPoolExecutor
+
+        def chunk(lo_hi):
+            lo, hi = lo_hi
+            bad = 0
+            hd = odb.new_handler()                             # (the oracle's query state: one per thread)
+            for i in range(lo, hi):
+                _, e = odb.query(sample[i], sample[n + i], K, 0, 0, handler=hd)
+                g = gpu_cands[i]
+                ok = all((g[j]["tgt"], g[j]["hits"], g[j]["beg"], g[j]["end"]) == (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]) if j < len(e)
+                         else g[j]["hits"] == 0 for j in range(K))
+                bad += 0 if ok else 1
+            odb.free_handler(hd)
+            return bad
         t1 = time.time()
-        mism = 0
-        for i in range(n):
-            _, e = odb.query(sample[i], sample[n + i], K, 0, 0)
-            g = gpu_cands[i]
-            ok = all((g[j]["tgt"], g[j]["hits"], g[j]["beg"], g[j]["end"]) == (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]) if j < len(e)
-                     else g[j]["hits"] == 0 for j in range(K))
-            mism += 0 if ok else 1
+        cuts = [(n * t // threads, n * (t + 1) // threads) for t in range(threads)]
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            mism = sum(ex.map(chunk, cuts))
         el = time.time() - t1
         info = odb.info()
         odb.close()
-        return ({"value": round(2 * n / el * 60 / 1e6, 3), "unit": "Mreads/min", "cores": 1, "kind": "port", "host_cpus_granted": eff,
-                 "sample": f"{n} pairs of the same workload (batch 0), one host thread through the oracle's per-query entry (Python loop included); "
+        return ({"value": round(2 * n / el * 60 / 1e6, 3), "unit": "Mreads/min", "cores": threads, "kind": "port", "host_cpus_granted": eff,
+                 "sample": f"{n} pairs of the same workload (batch 0), {threads} host threads through the oracle's per-query entry (the box grants {eff} CPUs; "
+                           f"the Python loop around the C call is part of the figure); "
                            f"buckets of the sample's {len(wanted)} features ({info[7]} locations) built by the oracle itself in {build_s:.0f} s"},
                 {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
 
@@ -408,6 +435,47 @@ def reference_calibration(scale: float, K: int, lf: float, device: int, budget_s
                 os.remove(name + e)
 
 
+def run_multi_gpu_selfcheck(world: int, budget_s: float) -> dict:
+    """After the timed region: tools/multi_gpu_selfcheck.py as its OWN job over the same N GPUs (its own rendezvous, its own processes, a
+    hard time limit: nothing in it can hang or fail this run) -- modes P and K across N real ranks and the C++ mc_keyset / mc_partset
+    drivers over all N devices, every candidate against the oracle.  Returns what it printed, or what went wrong."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = os.path.join(tempfile.gettempdir(), f"mc_selfcheck_{os.getpid()}.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                                                              "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID",
+                                                              "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE",
+                                                              "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "OMP_NUM_THREADS")}
+    env["MASTER_ADDR"] = "127.0.0.1"; env["MASTER_PORT"] = str(port)
+    tool = os.path.join(ROOT, "tools", "multi_gpu_selfcheck.py")
+    if world > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               tool, "--out", out]
+    else:
+        cmd = [sys.executable, tool, "--out", out]
+    t0 = time.time()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True, cwd=ROOT)
+        try:
+            _, err = p.communicate(timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)                   # exactly the process group started above
+            p.communicate()
+            return {"ranks_seen": world, "ok": False, "error": f"time limit of {budget_s:.0f} s reached", "seconds": round(time.time() - t0, 1)}
+        if os.path.exists(out):
+            res = json.loads(open(out).read())
+            os.remove(out)
+            res["exit_code"] = p.returncode
+            return res
+        return {"ranks_seen": world, "ok": False, "error": f"exit code {p.returncode}: " + (err or b"").decode(errors="replace")[-400:], "seconds": round(time.time() - t0, 1)}
+    except Exception as e:                                      # noqa: BLE001  (never fatal for the headline number)
+        return {"ranks_seen": world, "ok": False, "error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,9 +501,14 @@ def main():
     ap.add_argument("--reference-files", default="", help="configs[2], N = 1: also write the database as files under this name (e.g. /dev/shm/mcdb: "
                     "190 GB at full scale) and let the REFERENCE (oracle/_ref) load them and be the checker and the CPU baseline instead of the oracle")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 gather path with a single rank too (testing)")
+    ap.add_argument("--no-pipeline", action="store_true", help="mode R: one batch at a time on one pipe (default: two batches in flight on the context's two "
+                    "pipes, mc_query_device(MC_DEFER_TAIL) + mc_query_finish)")
+    ap.add_argument("--selfcheck-seconds", type=float, default=150.0, help="time limit of the multi-GPU self-check that follows the timed region "
+                    "(tools/multi_gpu_selfcheck.py as its own job over the same N ranks; 0 = skip)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed repeats of the K steps: the first is the line's value, all of them its value_range")
     ap.add_argument("--long-reads", action="store_true", help="configs[2] table, BASELINE configs[4]'s reads: single reads of 200 .. 19 000 bp (log-normal, "
                     "median 480), 7.5 %% substitutions, seed 5100; --batch = reads per step (default 250 000)")
-    ap.add_argument("--calibrate-scale", type=float, default=0.05, help="configs[2], N = 1: after the run, the same collection at this scale is built, written "
+    ap.add_argument("--calibrate-scale", type=float, default=0.1, help="configs[2], N = 1: after the run, the same collection at this scale is built, written "
                     "as database files and classified by the REFERENCE (oracle/_ref) and by the port on the same reads: cpu_baseline.reference_calibration "
                     "(0 = skip)")
     args = ap.parse_args()
@@ -548,8 +621,8 @@ def main():
                     + (f"{world * args.steps * B} synthetic long reads (200-19000 bp, log-normal, median 480; 7.5 % substitutions)" if args.long_reads else
                        f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
                     + ("" if nb >= args.steps + args.warmup else f" ({world * nb * B * (2 if args.pairs else 1)} distinct, cycled)"))
-        # the committed PMC passes (profiles/r03_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
-        pmc_tag = "r03" if (mode == "R" and not args.pairs and not args.long_reads and args.scale == 1.0 and B == 5_000_000) else "r03-none"
+        # the committed PMC passes (profiles/r04_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
+        pmc_tag = "r04" if (mode == "R" and not args.pairs and not args.long_reads and args.scale == 1.0 and B == 5_000_000) else "r04-none"
     build_s = time.time() - t0
     db_info = db.info()
 
@@ -574,7 +647,8 @@ def main():
     # N > 1: the per-rank candidate lists go to rank 0 over RCCL (north_star: "per-rank partial hit lists gathered over RCCL/xGMI
     # before host-side taxonomy assignment").  Two buffers per rank: the gather of batch i runs while batch i+1 is computed.
     dist_path = world > 1 or args.force_dist
-    nbuf = 2 if dist_path else 1
+    pipelined = mode == "R" and not args.long_reads and not args.no_pipeline
+    nbuf = 2 if (dist_path or pipelined) else 1
     nout = B if mode in ("R", "K") else nloc                    # candidate rows this rank ends up with per step
     out_bufs = [torch.zeros((nout, K, 4), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     out_cands = out_bufs[0]
@@ -590,10 +664,30 @@ def main():
             torch.cuda.current_stream().synchronize()
             works[j] = None
 
+    pend = {}                                                # pipe -> device pointer of the candidates its batch in flight will leave
+
+    def finish_pipe(j: int):
+        """mode R, two batches in flight: the tail of the batch on pipe j (mc_query_finish: the host looks at its counters only now, with
+        the other pipe's batch queued behind it), its candidates into out_bufs[j], then (N > 1) their gather to rank 0"""
+        if j not in pend:
+            return
+        ptr = pend.pop(j)
+        db.query_finish(second_pipe=bool(j))
+        db.copy_results(out_bufs[j].data_ptr(), ptr, nloc * K * 16, second_pipe=bool(j))
+        if dist_path:
+            db.query_wait(second_pipe=bool(j))               # RCCL reads the buffer on torch's stream
+            works[j] = gather_candidates_async(out_bufs[j], recv[j] if recv is not None else None, dst=0)
+
     def step(i: int):
         b = batches[i % nb] if batches else None
         j = i % nbuf
         finish(j)                                            # the gather that used this buffer two batches ago
+        if pipelined:
+            # batch i's main kernels go to pipe j WITHOUT any host synchronisation, then the tail and the hand-over of batch i - 1 (other pipe)
+            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, second_pipe=bool(j), defer_tail=True)
+            pend[j] = res.cands
+            finish_pipe(j ^ 1)
+            return res
         if mode == "K":
             res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=not numbers_wire,
                                   want_partial_numbers=numbers_wire)
@@ -619,6 +713,9 @@ def main():
         return res
 
     def drain():
+        if pipelined:
+            finish_pipe(0); finish_pipe(1)
+            db.synchronize()
         for j in range(nbuf):
             finish(j)
 
@@ -628,27 +725,47 @@ def main():
     torch.cuda.synchronize()
     db.timing(True)
     db.timing_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()                                                  # every gather has arrived on rank 0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+
+    def timed_region():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        drain()                                              # every batch finished, every gather has arrived on rank 0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed_region()                                 # THE timed region: exactly K steps, max over ranks -> value
     db.timing(False)
+    kt_timed = {k: db.timing_get(k) for k in KERNELS + (KERNELS_MODE_K if mode == "K" else ())} if rank == 0 else {}
+    repeats = [elapsed] + [timed_region() for _ in range(max(0, args.repeats - 1))]   # the same K steps again: the spread (value_range)
+    # per-kernel durations WITHOUT another batch's kernels beside them: a few steps one batch at a time (two batches in flight share the
+    # device, the HIP events of the timed region bracket that sharing too)
+    kt_solo = None
+    if pipelined and rank == 0:
+        db.timing(True); db.timing_reset()
+        for i in range(min(3, args.steps)):
+            r = db.query_device(batches[i % nb].data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win)
+            db.copy_results(out_bufs[0].data_ptr(), r.cands, nloc * K * 16)
+            db.synchronize()
+        db.timing(False)
+        kt_solo = {k: db.timing_get(k) for k in KERNELS}
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.barrier()
 
     if rank == 0:
-        kt = {k: db.timing_get(k) for k in KERNELS + (KERNELS_MODE_K if mode == "K" else ())}
-        st = db.last_batch_stats()                            # of the last timed batch
+        kt = kt_timed                                         # HIP events over THE timed region
+        st = db.last_batch_stats()                            # of the last batch that went through the first pipe
         layout = db.table_layout()
         if cfg != 1:
             V = layout["location_bytes"]                       # SURVEY's V = bytes per location as the table holds them: 4 with the compact store
@@ -658,9 +775,12 @@ def main():
         if args.long_reads:                                    # SURVEY's formula with the reads' own lengths: ceil(L/4) + ceil(L/8) summed over the last timed batch
             lb = long_batches[(args.steps - 1) % nb]
             bytes_per_read = float(((lb["lens"] + 3) // 4 + (lb["lens"] + 7) // 8).sum()) / nloc + 12.0 * F + V * H + 16.0 * K
-        dom = max((k for k in KERNELS if k not in ("plan", "scan")), key=lambda k: kt[k][0])
+        dom = max((k for k in kt if k not in ("plan", "scan")), key=lambda k: kt[k][0])      # (mode K: its own kernels are candidates too)
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * nloc * per_read / (dom_ms * 1e-3) / 1e9
+        L_mean = float(long_batches[(args.steps - 1) % nb]["lens"].mean()) if args.long_reads else float(READ_LEN)
+        kshare = kernel_bytes_per_read(dom, L_mean, F, H, K, V)
+        kbytes = None if kshare is None else kshare * nloc * per_read
         traffic, traffic_src = measured_traffic(dom, pmc_tag)
         total_reads = world * args.steps * B * per_read
         value = total_reads / elapsed * 60.0 / 1e6
@@ -683,15 +803,33 @@ def main():
                          # the same bytes over the WHOLE step (all kernels, launches, the copy of the candidates)
                          "step_frac": round(bytes_per_read * nloc * per_read / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         # like for like with `traffic`: the dominant kernel's OWN share of the algorithmic bytes (kernel_bytes_per_read)
+                         "kernel_name": "mcamd::" + KERNEL_OF.get(dom, (dom,))[0],
+                         "kernel_algorithmic_bytes": None if kbytes is None else round(kbytes),
+                         "kernel_frac": None if kbytes is None else round(kbytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic_over_kernel_bytes": None if (kbytes is None or traffic is None) else round(traffic / kbytes, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_read * nloc * per_read),
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3), "V": V,
                          "table_location_bytes": layout["location_bytes"],
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
+        vals = [total_reads / e * 60.0 / 1e6 for e in repeats]
+        result["value_range"] = [round(min(vals), 1), round(max(vals), 1)]
+        result["repeats_ms_per_step"] = [round(e / args.steps * 1e3, 3) for e in repeats]
+        result["config"]["batches_in_flight"] = 2 if pipelined else 1
+        if kt_solo is not None:
+            # two batches in flight share the device: the events of the timed region bracket that sharing.  The same kernels one batch at a
+            # time (3 steps after the timed region):
+            sm = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt_solo.items()}
+            sdom = max((k for k in sm if k not in ("plan", "scan")), key=lambda k: sm[k])
+            result["roofline"]["kernel_ms_solo"] = sm
+            result["roofline"]["kernel_solo"] = sdom
+            result["roofline"]["frac_solo"] = round(bytes_per_read * nloc * per_read / (sm[sdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+            result["roofline"]["step_ms_solo"] = round(sum(sm.values()), 3)
         # second roofline: 64-byte read requests per second of the dominant kernel against the box's measured random-access
         # peak for that kernel's access shape.  Requests per launch: TCC_EA0_RDREQ of the committed PMC pass (same batch size only).
         req = measured_requests(dom, pmc_tag)
-        shape = "wave_512B_list" if dom.startswith("big_") or dom.startswith("hash_") or dom.startswith("mid_") else \
+        shape = "wave_512B_list" if dom.startswith(("big_", "gw_", "hash_", "mid_")) else \
                 ("quad_64B" if db_info[7] > 2_000_000_000 else "lane_private_64B")
         if peak is not None:
             ra = {"shape": shape, "peak_requests_per_s": round(peak[shape]), "peak_all_shapes": {k: round(v) if k != "buffer_GiB" else v for k, v in peak.items()}}
@@ -733,8 +871,26 @@ def main():
             and "cpu_baseline" in result and not args.reference_files:
         torch.cuda.empty_cache()
         cal = reference_calibration(args.calibrate_scale, K, lf, local, args.cpu_seconds)
+        if cal is None and args.calibrate_scale > 0.05:         # the files of that cut do not fit this box's memory allowance: the smaller cut
+            cal = reference_calibration(0.05, K, lf, local, args.cpu_seconds)
         if cal:
             result["cpu_baseline"]["reference_calibration"] = cal
+    # ---- the sharded forms of the path on THESE N GPUs, checked against the oracle (outside every timing): its own job, rank 0 starts it
+    # and the other ranks wait for it at the rendezvous store -- on the host, their GPUs are free for the job's ranks
+    if cfg == 2 and mode == "R" and args.selfcheck_seconds > 0 and (world > 1 or args.cpu_seconds > 0):
+        del batches, out_bufs
+        torch.cuda.empty_cache()
+        store = dist.distributed_c10d._get_default_store() if dist.is_initialized() else None
+        if rank == 0:
+            result["multi_gpu_selfcheck"] = run_multi_gpu_selfcheck(world, args.selfcheck_seconds)
+            if store is not None:
+                store.set("mc_selfcheck_done", "1")
+        elif store is not None:
+            from datetime import timedelta
+            try:
+                store.wait(["mc_selfcheck_done"], timedelta(seconds=args.selfcheck_seconds + 120))
+            except Exception:                                   # noqa: BLE001
+                pass
     # the JSON line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which every rank
     # flushes here, before the barrier and the line, instead of at process exit after it
     import ctypes

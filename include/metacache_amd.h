@@ -135,6 +135,11 @@ int mc_open_database(const char* name, const mc_config* cfg, mc_ctx** out);
 /* database::read with scope::metadata_only (database.cpp:183-242), what `info` mode needs (mode_info.cpp:55-230): taxa, sources,
  * lineages and the header fields for the mc_db_* calls -- no table, no device; query calls on it fail with MC_ERR_STATE. */
 int mc_open_metadata(const char* name, mc_ctx** out);
+/* how mc_open_database read the files of a single-part context (reader threads -> pinned slabs -> copy stream -> table kernels; the
+ * reference reads every part in its own thread, database.cpp:203-226): stats[0..3] = bytes read, nanoseconds of the load in all, of its
+ * index pass (the batches' places in the file), nanoseconds the device feeder waited for the reader threads.  MC_LOAD_THREADS: reader
+ * threads (default 8); MC_LOAD_PIPELINE=0: the sequential loader. */
+int mc_load_stats(const mc_ctx* ctx, uint64_t stats[4]);
 
 /* target lineage table (ranked_lineages_of_targets, taxonomy.hpp:919-1030; uploaded like
  * copy_target_lineages_to_gpus gpu_hashmap.cu:1383-1396): lin[tgt*21 + rank] = taxon index + 1,
@@ -216,8 +221,23 @@ typedef struct {
                                  call in flight there while another runs on the first pipe, so the kernels of two batches overlap on the
                                  device the way several query_batch objects do in the reference (query_batch.cuh:369-371).  The
                                  results of a pipe stay valid until the next call on the SAME pipe. */
+#define MC_DEFER_TAIL 32     /* TWO BATCHES IN FLIGHT FROM ONE CALLER THREAD: the call enqueues the batch's main kernels and returns without any
+                                 synchronisation; what the host has to read device counters for (the sorted class of the filtered path, the
+                                 segments of the exact wave kernels' leftovers: a few reads per million) is left to mc_query_finish on the
+                                 same pipe, which the caller issues AFTER it has enqueued the next batch on the other pipe -- the device
+                                 never waits for the host.  out->cands is complete once mc_query_finish has returned (in stream order).
+                                 Honoured for batches of more than 2^20 reads on the lane path without MC_WANT_*; otherwise the call
+                                 does everything at once as without the flag (mc_query_finish is then a no-op).  A new mc_query_device
+                                 on a pipe with a pending tail runs that tail first. */
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);
+/* the tail of the last mc_query_device(MC_DEFER_TAIL) call on the first (flags = 0) or second (flags = MC_SECOND_PIPE) pipe: waits for
+ * that batch's main kernels, then runs its rare classes on the same stream.  The reference gets the same overlap from several
+ * query_batch objects, one stream each (query_batch.cuh:369-371, database_query.hpp:110-113). */
+int mc_query_finish(mc_ctx* ctx, int flags);
+/* waits for ONE pipe's stream (flags = 0: the first, MC_SECOND_PIPE: the second) -- what a two-pipe caller uses instead of mc_synchronize
+ * (which waits for both) before it hands a finished batch's results to somebody else while the other pipe's batch is still running */
+int mc_query_wait(mc_ctx* ctx, int flags);
 int mc_synchronize(mc_ctx* ctx);
 
 /* Mode P (one database part per GPU) and part groups.  Per-part candidate lists of the same reads (DEVICE pointers, [n][max_candidates]
@@ -338,9 +358,10 @@ int  mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, c
 const char* mc_keyset_last_error(const mc_keyset* ks);
 
 /* copies out of the ctx-owned result buffers, asynchronous on the context's stream
- * (kind: 0 = device -> device, 1 = device -> host) */
+ * (kind: 0 = device -> device, 1 = device -> host); mc_synchronize waits for both pipes' streams */
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
-/* the same on the caller's stream (the one its mc_query_device call ran on; NULL = the context's) */
+/* the same on the caller's stream (the one its mc_query_device call ran on; NULL = the context's, or with kind | MC_SECOND_PIPE the
+ * second pipe's own stream: results of a mc_query_device(MC_SECOND_PIPE) call that was given no stream) */
 int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind, void* stream);
 
 /* tuning / test hook (not needed for normal use): the switches the MC_BIG_MIN / MC_QUAD_LOOKUP / MC_NO_LANE_PATH environment variables
@@ -352,7 +373,9 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256",
- * "hash_cands_256", "hash_cands_512", "hash_cands_1024", "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates";
+ * "hash_cands_256", "hash_cands_512", "hash_cands_1024", the filtered path -- compact location store: "gw_filter_count" (gw_filter_count_kernel; "gw_filter" with
+ * the tuning switch "gw_fuse" 0), "gw_filter_rest" (gw_filter2 + gw_compact + gw_filter_stream), "gw_count" (gw_count_kernel<9> + <10>), "gw_count_1024" (<11>); 8-byte store:
+ * "big_filter", "big_filter_2", "big_count", "big_count_2" --, "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates";
  * Mode K: "mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union"; "sketch_probe" with MC_LANE_FUSION=1; "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);
 int mc_timing_reset(mc_ctx* ctx);

@@ -66,8 +66,8 @@ class McDeviceResults(C.Structure):
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
            "mc_partset_info", "mc_partset_classify", "mc_partset_last_error",
            "mc_partial_numbers", "mc_candidates_from_partial_numbers", "mc_owner_stats", "mc_keyset_open", "mc_keyset_close", "mc_keyset_info", "mc_keyset_classify", "mc_keyset_last_error",
-           "mc_open_database", "mc_open_metadata", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
-           "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_synchronize",
+           "mc_open_database", "mc_open_metadata", "mc_load_stats", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
+           "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_query_finish", "mc_query_wait", "mc_synchronize",
            "mc_key_owner", "mc_candidates_from_hits", "mc_candidates_from_partial_hits", "mc_copy_results",
            "mc_timing_enable", "mc_timing_reset", "mc_timing_get", "mc_last_batch_stats", "mc_set_tuning", "mc_copy_results_on",
            "mc_build_begin", "mc_build_add_target", "mc_build_add_target_src", "mc_build_add_target_device", "mc_build_flush", "mc_build_reserve",
@@ -115,6 +115,8 @@ def lib() -> C.CDLL:
         L.mc_batch_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(McResults)]
         L.mc_batch_clear.argtypes = [C.c_void_p, C.c_uint32]
         L.mc_query_device.argtypes = [C.c_void_p, C.POINTER(McDeviceBatch), C.c_int, C.c_int, C.POINTER(McDeviceResults), C.c_void_p]
+        L.mc_query_finish.argtypes = [C.c_void_p, C.c_int]
+        L.mc_query_wait.argtypes = [C.c_void_p, C.c_int]
         L.mc_synchronize.argtypes = [C.c_void_p]
         L.mc_key_owner.argtypes = [C.c_uint32, C.c_uint32]
         L.mc_key_owner.restype = C.c_uint32
@@ -291,12 +293,21 @@ class Database:
     # ---- device path (pointers are device addresses, e.g. torch tensors' data_ptr()) ----------
     def query_device(self, seq_ptr: int, qinfo_ptr: int, n: int, num_chars: int, max_win_ptr: int = 0, max_win_uniform: int = 0,
                      lowest: int = 0, want_allhits: bool = False, want_features: bool = False,
-                     stream: int = 0, want_partial_hits: bool = False, second_pipe: bool = False, want_partial_numbers: bool = False) -> McDeviceResults:
+                     stream: int = 0, want_partial_hits: bool = False, second_pipe: bool = False, want_partial_numbers: bool = False,
+                     defer_tail: bool = False) -> McDeviceResults:
         b = McDeviceBatch(seq_ptr, qinfo_ptr, max_win_ptr or None, max_win_uniform, n, num_chars)
         r = McDeviceResults()
-        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0) | (4 if want_partial_hits else 0) | (8 if second_pipe else 0) | (16 if want_partial_numbers else 0), C.byref(r),
+        self._check(lib().mc_query_device(self.h, C.byref(b), lowest, int(want_allhits) | (2 if want_features else 0) | (4 if want_partial_hits else 0) | (8 if second_pipe else 0) | (16 if want_partial_numbers else 0) | (32 if defer_tail else 0), C.byref(r),
                                           stream or None))
         return r
+
+    def query_finish(self, second_pipe: bool = False):
+        """the tail of the last query_device(defer_tail=True) call on that pipe (mc_query_finish)"""
+        self._check(lib().mc_query_finish(self.h, 8 if second_pipe else 0))
+
+    def query_wait(self, second_pipe: bool = False):
+        """waits for ONE pipe's stream (mc_query_wait)"""
+        self._check(lib().mc_query_wait(self.h, 8 if second_pipe else 0))
 
     def candidates_from_hits(self, hits_ptr: int, hit_offsets_ptr: int, n: int, max_win_ptr: int = 0, max_win_uniform: int = 0,
                              lowest: int = 0, stream: int = 0) -> McDeviceResults:
@@ -338,10 +349,19 @@ class Database:
         self._check(L.mc_candidates_from_partial_numbers(self.h, C.byref(h), lowest, C.byref(r), stream or None))
         return r
 
-    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False, stream: int = 0):
+    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False, stream: int = 0, second_pipe: bool = False):
         L = lib()
         L.mc_copy_results_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
-        self._check(L.mc_copy_results_on(self.h, dst_ptr, src_ptr, nbytes, 1 if to_host else 0, stream or None))
+        self._check(L.mc_copy_results_on(self.h, dst_ptr, src_ptr, nbytes, (1 if to_host else 0) | (8 if second_pipe else 0), stream or None))
+
+    def load_stats(self) -> dict:
+        """how mc_open_database read the database files (mc_load_stats)"""
+        L = lib()
+        L.mc_load_stats.argtypes = [C.c_void_p, C.c_void_p]
+        a = (C.c_uint64 * 4)()
+        self._check(L.mc_load_stats(self.h, a))
+        return dict(bytes=int(a[0]), seconds=a[1] / 1e9, index_seconds=a[2] / 1e9, feeder_wait_seconds=a[3] / 1e9,
+                    GB_per_s=(a[0] / a[1]) if a[1] else 0.0)
 
     def table_layout(self) -> dict:
         """bytes per stored location (4 = compact store: global window numbers), gap between two targets' numbers, buckets, stored list locations (mc_table_layout)"""

@@ -217,6 +217,7 @@ void mc_destroy(mc_ctx* ctx)
                         &P.bScan, &P.bStats, &P.bCands, &P.bScanIn, &P.bQflag, &P.bMid, &P.bChunkList, &P.bBigPool, &P.bSliceFill, &P.bBigPool2, &P.bSortTmp, &P.bSide, &P.bNumbers, &P.bCounts, &P.bOrder};
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
+        if (P.tail.mainDone) (void)hipEventDestroy(P.tail.mainDone);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
         if (ownStream && P.stream) (void)hipStreamDestroy(P.stream);
     };
@@ -555,51 +556,100 @@ static int taxkey_for_rank(mc_ctx* ctx, int rank, const uint32_t** out)
 // ------------------------------------------------------------------------------------------------
 // the per-batch pipeline
 // ------------------------------------------------------------------------------------------------
-// The filtered candidate path on the work list the probing kernels (or, on the owner side of Mode K, owner_entries_kernel) left
-// in list 6: filter -> counting -> [segmented sort -> scan of the sorted lists].  poolEntries: entries of ws.bigPool (slices + overflow).
-static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
-                             const uint32_t* taxkey, bool compact, bool second, uint64_t poolEntries, hipStream_t st)
+// the sorted class of the filtered path: filtered lists the counting kernels do not take (long reads: thousands of numbers, wide window
+// ranges) are sorted -- one segmented sort over the pool -- and scanned (gw_sorted_cands_kernel); the filter kernels counted them.
+// The one place of the filtered path where the host looks at a device counter (how many such lists: the sort's segment count).
+static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
+                           const uint32_t* taxkey, uint64_t poolEntries, bool counterCopied, hipStream_t st)
 {
     int rc = MC_OK;
     const uint32_t n = b.n;
-    { ScopedTimer t(ctx, "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
+    uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
+    if (!counterCopied) HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (!*nsorted) return MC_OK;
+    if ((rc = ensure(ctx, P.bBigPool2, poolEntries * 4))) return rc;
+    ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
+    const uint32_t nseg = std::min(*nsorted, n);
+    // the sorted class longest list first: the segmented sort (a block per segment) and the scan (a wave per list) take them in this order
+    size_t ordBytes = 0;
+    if (launch_gw_order(3, ws, n, nseg, nullptr, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists: size query failed");
+    if ((rc = ensure(ctx, P.bOrder, (size_t)3 * std::max<uint32_t>(n, 1) * 4 + ordBytes + 256))) return rc;
+    size_t tmpBytes = 0;
+    if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
+        return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
+    if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
+    {
+        ScopedTimer t(ctx, "gw_sort", st);
+        if (launch_gw_order(3, ws, n, nseg, (uint32_t*)P.bOrder.p, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists failed");
+        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
+            return fail(ctx, MC_ERR_HIP, "segmented sort failed");
+    }
+    { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    return MC_OK;
+}
+
+// The filtered candidate path on the work list the probing kernels (or, on the owner side of Mode K, owner_entries_kernel) left
+// in list 6: filter -> counting -> [segmented sort -> scan of the sorted lists].  poolEntries: entries of ws.bigPool (slices + overflow).
+// deferSorted: the sorted class is left to the caller (mc_query_finish runs run_sorted_tail).
+static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
+                             const uint32_t* taxkey, bool compact, bool second, uint64_t poolEntries, hipStream_t st, bool deferSorted = false)
+{
+    // timers carry the kernels' own names: compact store gw_filter_count_kernel (or gw_filter_kernel with "gw_fuse" 0), the rest of the
+    // filters (gw_filter2 + compaction + gw_filter_stream), gw_count_kernel<9> + <10>, gw_count_kernel<11>; 8-byte store: big_*
+    { ScopedTimer t(ctx, compact ? (ws.gwFuse ? "gw_filter_count" : "gw_filter") : "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
     // host's look at the counters: always launched, returns at once with nothing to do)
-    if (second || compact) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-    { ScopedTimer t(ctx, "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-    { ScopedTimer t(ctx, "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-    if (compact) {
-        // filtered lists the counting kernels do not take (long reads: thousands of numbers, wide window ranges) are sorted --
-        // one segmented sort over the pool -- and scanned (gw_sorted_cands_kernel); the filter kernels counted them
-        if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
-        uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
-        HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (*nsorted) {
-            if ((rc = ensure(ctx, P.bBigPool2, poolEntries * 4))) return rc;
-            ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
-            const uint32_t nseg = std::min(*nsorted, n);
-            // the sorted class longest list first: the segmented sort (a block per segment) and the scan (a wave per list) take them in this order
-            size_t ordBytes = 0;
-            if (launch_gw_order(3, ws, n, nseg, nullptr, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists: size query failed");
-            if ((rc = ensure(ctx, P.bOrder, (size_t)3 * std::max<uint32_t>(n, 1) * 4 + ordBytes + 256))) return rc;
-            size_t tmpBytes = 0;
-            if (launch_gw_segsort(nullptr, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
-                return fail(ctx, MC_ERR_HIP, "segmented sort: size query failed");
-            if ((rc = ensure(ctx, P.bSortTmp, tmpBytes + 256))) return rc;
-            {
-                ScopedTimer t(ctx, "gw_sort", st);
-                if (launch_gw_order(3, ws, n, nseg, (uint32_t*)P.bOrder.p, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists failed");
-                if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
-                    return fail(ctx, MC_ERR_HIP, "segmented sort failed");
-            }
-            { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-        }
+    if (second || compact) { ScopedTimer t(ctx, compact ? "gw_filter_rest" : "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    { ScopedTimer t(ctx, compact ? "gw_count" : "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    { ScopedTimer t(ctx, compact ? "gw_count_1024" : "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    if (compact && !deferSorted) return run_sorted_tail(ctx, P, b, sp, tab, ws, K, taxkey, poolEntries, false, st);
+    return MC_OK;
+}
+
+// What the lane path did not finish goes through the exact wave kernels (long reads, duplicate hashes, reads the filtered path handed
+// back, -allhits, ...): sketch + probe unless done, segments for their location lists (the host sizes them: one round trip), sort + candidates.
+static int run_wave_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
+                         const uint32_t* taxkey, bool fuse, bool skipWaveSketch, bool wantAllhits, bool wantPartial, bool wantNumbers, bool lanePath, hipStream_t st)
+{
+    int rc = MC_OK;
+    const uint32_t n = b.n;
+    if (!skipWaveSketch) {
+        ScopedTimer t(ctx, "query_wave", st);
+        launch_query(b, sp, tab, fuse, wantAllhits, ws, K, P.bCands.p, st);
+    }
+    {
+        ScopedTimer t(ctx, "scan", st);
+        launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
+    }
+    // how many locations need a segment in HBM
+    if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
+    HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint64_t totalHits = *P.hTotal;
+    const size_t hb = (size_t)(totalHits + 1) * 8;
+    if ((rc = ensure(ctx, P.bHits, hb))) return rc;
+    if ((rc = ensure(ctx, P.bCscr, hb))) return rc;
+    if (taxkey && (rc = ensure(ctx, P.bCscr2, hb))) return rc;
+    ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
+    if (wantNumbers && ((rc = ensure(ctx, P.bNumbers, (size_t)(totalHits + 8) * 4)) || (rc = ensure(ctx, P.bCounts, (size_t)(n + 1) * 4)))) return rc;
+    if (wantPartial && lanePath && !wantNumbers) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, nullptr, st); }
+    {
+        ScopedTimer t(ctx, "sort_candidates", st);
+        launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits, P.bCands.p, st);
+    }
+    if (wantNumbers) {
+        // what the wave kernels left in ws.hits -> numbers, then the lane path's (and the chunk lanes') lists straight from the table
+        { ScopedTimer t(ctx, "pack_numbers", st); launch_pack_other_reads(b, tab, ws, (uint32_t*)P.bNumbers.p, (uint32_t*)P.bCounts.p, st); }
+        if (lanePath) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, (uint32_t*)P.bNumbers.p, st); }
+        P.numbersN = n; P.numbersTotal = totalHits;
     }
     return MC_OK;
 }
 
 static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st);
+static int finish_on_pipe(mc_ctx* ctx, Pipe& P);
 
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
 {
@@ -623,6 +673,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const bool wantPartial = ((flags & MC_WANT_PARTIAL_HITS) != 0 || wantNumbers) && !(flags & MC_WANT_ALLHITS);
     const int wantAllhits = (flags & MC_WANT_ALLHITS) | (wantPartial ? 1 : 0);
     const bool wantFeatures = (flags & MC_WANT_FEATURES) != 0;
+    if (P.tail.pending) { int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a caller that never asked for the last batch's tail: run it, the workspace is reused now)
     if (!ctx->tableReady) return fail(ctx, MC_ERR_STATE, "no database loaded (every part needs mc_load_begin .. mc_load_end)");
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     if (wantNumbers && (ctx->parts.size() != 1 || !ctx->parts[0].compact || !ctx->dGwBase))
@@ -673,7 +724,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -754,48 +805,38 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             if ((rc = ensure(ctx, P.bOrder, (size_t)3 * std::max<uint32_t>(n, 1) * 4 + ordBytes + 256))) return rc;
             ws.orderScratch = (uint32_t*)P.bOrder.p; ws.orderTemp = ordBytes;
         }
+        // MC_DEFER_TAIL (large batches on the lane path): everything the host has to look at device counters for -- the sorted class of the
+        // filtered path, the segment sizes of the exact wave kernels' leftovers -- waits for mc_query_finish; this call returns with
+        // the main kernels enqueued and NO synchronisation, so that the caller can enqueue the next batch on the other pipe first
+        const bool defer = (flags & MC_DEFER_TAIL) != 0 && hcnt == all && !wantFeatures;
         if (hcnt[9] || waveDone) {
-            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st))) return rc;
+            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st, defer))) return rc;
         }
         waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
         skipWaveSketch = waveDone;
+        if (defer) {
+            Pipe::Tail& tl = P.tail;
+            if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
+            if (!tl.mainDone) HIP_TRY(ctx, hipEventCreateWithFlags(&tl.mainDone, hipEventDisableTiming));
+            tl.sortedPath = T.compact && (hcnt[9] || waveDone);
+            if (tl.sortedPath) HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(P.hTotal + 9), ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipEventRecord(tl.mainDone, st));
+            tl.ws = ws; tl.b = b; tl.sp = sp; tl.tab = tab; tl.K = K; tl.taxkey = taxkey; tl.compact = T.compact; tl.fuse = fuse;
+            tl.skipWaveSketch = skipWaveSketch; tl.poolEntries = poolCap + ovfCap; tl.st = st;
+            tl.pending = true;
+            HIP_TRY(ctx, hipGetLastError());
+            P.lastN = n;
+            out->cands = (const mc_candidate*)P.bCands.p;
+            out->hit_counts = (const uint32_t*)P.bQstat.p;
+            out->hit_offsets = nullptr; out->hits = nullptr;
+            out->features = ws.features;
+            out->win_offsets = ws.winOff;
+            return MC_OK;
+        }
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }
-    uint64_t totalHits = 0;
-    if (waveWork) {
-        if (!skipWaveSketch) {
-            // wave-per-query kernel for whatever the lane path did not take (long reads, duplicate hashes, ...)
-            ScopedTimer t(ctx, "query_wave", st);
-            launch_query(b, sp, tab, fuse, wantAllhits != 0, ws, K, P.bCands.p, st);
-        }
-        {
-            ScopedTimer t(ctx, "scan", st);
-            launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
-        }
-        // how many locations need a segment in HBM
-        if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
-        HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        totalHits = *P.hTotal;
-        const size_t hb = (size_t)(totalHits + 1) * 8;
-        if ((rc = ensure(ctx, P.bHits, hb))) return rc;
-        if ((rc = ensure(ctx, P.bCscr, hb))) return rc;
-        if (taxkey && (rc = ensure(ctx, P.bCscr2, hb))) return rc;
-        ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
-        if (wantNumbers && ((rc = ensure(ctx, P.bNumbers, (size_t)(totalHits + 8) * 4)) || (rc = ensure(ctx, P.bCounts, (size_t)(n + 1) * 4)))) return rc;
-        if (wantPartial && lanePath && !wantNumbers) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, nullptr, st); }
-        {
-            ScopedTimer t(ctx, "sort_candidates", st);
-            launch_sort_candidates(b, sp, tab, ws, taxkey, K, wantAllhits != 0, P.bCands.p, st);
-        }
-        if (wantNumbers) {
-            // what the wave kernels left in ws.hits -> numbers, then the lane path's (and the chunk lanes') lists straight from the table
-            { ScopedTimer t(ctx, "pack_numbers", st); launch_pack_other_reads(b, tab, ws, (uint32_t*)P.bNumbers.p, (uint32_t*)P.bCounts.p, st); }
-            if (lanePath) { ScopedTimer t(ctx, "gather_lists", st); launch_gather_lists(b, sp, tab, ws, (uint32_t*)P.bNumbers.p, st); }
-            P.numbersN = n; P.numbersTotal = totalHits;
-        }
-    }
+    if (waveWork && (rc = run_wave_tail(ctx, P, b, sp, tab, ws, K, taxkey, fuse, skipWaveSketch, wantAllhits != 0, wantPartial, wantNumbers, lanePath, st))) return rc;
     HIP_TRY(ctx, hipGetLastError());
     P.lastN = n;
     out->cands = (const mc_candidate*)P.bCands.p;
@@ -805,6 +846,27 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     out->features = ws.features;
     out->win_offsets = ws.winOff;
     return MC_OK;
+}
+
+// the rare classes of a batch whose main kernels mc_query_device(MC_DEFER_TAIL) enqueued: sorted lists, then the exact wave kernels
+static int finish_on_pipe(mc_ctx* ctx, Pipe& P)
+{
+    Pipe::Tail& tl = P.tail;
+    if (!tl.pending) return MC_OK;
+    tl.pending = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(tl.mainDone));
+    int rc = MC_OK;
+    if (tl.sortedPath && (rc = run_sorted_tail(ctx, P, tl.b, tl.sp, tl.tab, tl.ws, tl.K, tl.taxkey, tl.poolEntries, true, tl.st))) return rc;
+    if ((rc = run_wave_tail(ctx, P, tl.b, tl.sp, tl.tab, tl.ws, tl.K, tl.taxkey, tl.fuse, tl.skipWaveSketch, false, false, false, true, tl.st))) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    return MC_OK;
+}
+
+int mc_query_finish(mc_ctx* ctx, int flags)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    return finish_on_pipe(ctx, (flags & MC_SECOND_PIPE) ? ctx->pipe1 : ctx->pipe0);
 }
 
 uint32_t mc_key_owner(uint32_t feature, uint32_t shardCount) { return key_owner(feature, shardCount); }
@@ -833,7 +895,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -881,7 +943,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -987,7 +1049,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1077,6 +1139,8 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
+    else if (n == "filter_lds_pad") ctx->filterLdsPad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 120 << 10));   // bytes of unused dynamic LDS per filter block
+    else if (n == "gw_fuse") ctx->gwFuse = (int)value;                         // counting of short filtered lists inside the filter kernel: 0 = apart, 1 (default) = fused, 2 = fused + software pipeline (four waves per SIMD: measured slower), 3 = the same compiled for five waves per SIMD (spills)
     else if (n == "gw_diag") {                                                 // timing experiments on gw_filter_kernel (WRONG results): only with MC_ALLOW_DIAG=1 in the environment
         const char* e = std::getenv("MC_ALLOW_DIAG");
         if (!(e && e[0] == '1')) return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: gw_diag needs MC_ALLOW_DIAG=1 (its results are wrong by design)");
@@ -1091,6 +1155,16 @@ int mc_synchronize(mc_ctx* ctx)
     if (!ctx) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pipe1.stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe1.stream));
+    return MC_OK;
+}
+
+int mc_query_wait(mc_ctx* ctx, int flags)
+{
+    if (!ctx) return MC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (flags & MC_SECOND_PIPE) ? ctx->pipe1.stream : ctx->stream;
+    if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
     return MC_OK;
 }
 
@@ -1100,7 +1174,9 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
 {
     if (!ctx || !dst || !src) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream ? (hipStream_t)stream : ctx->stream));
+    // kind: bit 0 = device -> host (else device -> device); MC_SECOND_PIPE: on the second pipe's stream when no stream is given
+    hipStream_t st = stream ? (hipStream_t)stream : ((kind & MC_SECOND_PIPE) && ctx->pipe1.stream) ? ctx->pipe1.stream : ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, (kind & 1) == 0 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     return MC_OK;
 }
 
@@ -1112,7 +1188,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     Pipe& P = ctx->pipe0;
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

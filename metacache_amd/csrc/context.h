@@ -26,6 +26,17 @@ struct Pipe {                   // the device workspace of ONE batch in flight +
     uint32_t lastN = 0;
     uint32_t numbersN = 0xFFFFFFFFu; uint64_t numbersTotal = 0;   // MC_WANT_PARTIAL_NUMBERS: bNumbers / bCounts hold this batch's lists already
     uint64_t* hTotal = nullptr;   // pinned: the one host round trip of a batch lands here (a pageable target makes the copy blocking)
+    // MC_DEFER_TAIL: the batch's main kernels are enqueued, the rare classes (sorted lists, what is left for the exact wave kernels) wait
+    // for mc_query_finish -- the host looks at their counters THEN, while the device is busy with the other pipe's batch
+    struct Tail {
+        bool pending = false;
+        Workspace ws{}; BatchView b{}; SketchParams sp{}; DeviceTable tab{};
+        uint32_t K = 0; const uint32_t* taxkey = nullptr;
+        bool compact = false, sortedPath = false, fuse = false, skipWaveSketch = false;
+        uint64_t poolEntries = 0;
+        hipStream_t st = nullptr;
+        hipEvent_t mainDone = nullptr;   // recorded behind the main kernels and the copy of the sorted-class counter
+    } tail;
 };
 
 struct Part {
@@ -69,6 +80,12 @@ struct Slot {
 // table_build: insert one chunk of a single-part database whose batch arrays already live in device memory
 // (between mc_load_begin and mc_load_end; used by mc_load_batch after its upload and by the builder directly)
 int load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals);
+
+// the same without any synchronisation: what the chunk adds to the location store comes from the host (dbload.cpp)
+int load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals, uint64_t stored);
+// dbload.cpp: a whole .cache file of a single-part context through reader threads, pinned slabs and a copy stream (between mc_load_begin
+// and mc_load_end).  stats (may be NULL): bytes read, nanoseconds in all, of the index pass, the feeder waited for readers
+int load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t targetBytes, uint64_t stats[4]);
 
 // error text for failures that have no context yet (mc_last_error(NULL))
 void set_global_error(const std::string& msg);
@@ -125,8 +142,9 @@ struct mc_ctx {
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on
                                            // strain-rich tables -- off by default
 
-    int filterBpc = 0, countBpc = 0, gwDiag = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), diagnostic variant of gw_filter_kernel -- this context only
+    int filterBpc = 0, countBpc = 0, gwDiag = 0, gwFuse = 1, filterLdsPad = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), diagnostic variant of gw_filter_kernel -- this context only
 
+    uint64_t loadStats[4] = {0, 0, 0, 0};  // mc_load_stats: bytes read from the database files, nanoseconds of the load, of its index pass, the feeder waited for the readers
     uint64_t ownerStats[4] = {0, 0, 0, 0}; // mc_owner_stats: reads, reads on the filtered path, numbers received, locations decoded for the sort
 
     // timing

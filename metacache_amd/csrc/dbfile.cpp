@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <unordered_map>
@@ -114,6 +115,16 @@ int read_part_header(mc_ctx* ctx, const std::string& fname, PartHeader& h, uint3
 
 int load_part(mc_ctx* ctx, uint32_t part, const std::string& fname, uint32_t targetBytes)
 {
+    // a single-part context: reader threads, pinned slabs, copies and table kernels overlapped (dbload.cpp); MC_LOAD_PIPELINE=0: the
+    // sequential loop below (what multi-part contexts, whose buckets are merged on the host, always take)
+    static const bool pipelined = [] { const char* e = std::getenv("MC_LOAD_PIPELINE"); return !(e && e[0] == '0'); }();
+    if (pipelined && ctx->parts.size() == 1 && part == 0) {
+        uint64_t st[4] = {0, 0, 0, 0};
+        const int rc = load_file_pipelined(ctx, fname, targetBytes, st);
+        if (rc) return rc;
+        for (int i = 0; i < 4; ++i) ctx->loadStats[i] += st[i];
+        return mc_load_end(ctx, part);
+    }
     File f(fname);
     if (!f.f) { ctx->err = "Could not read database file '" + fname + "'"; return MC_ERR_IO; }
     uint64_t nkeys = 0, nvalues = 0, batch = 0;
@@ -244,6 +255,13 @@ int mc_open_metadata(const char* name, mc_ctx** out)
     make_lineages(tmp, lin);
     ctx->lineages = std::move(lin);
     *out = ctx;
+    return MC_OK;
+}
+
+int mc_load_stats(const mc_ctx* ctx, uint64_t stats[4])
+{
+    if (!ctx || !stats) return MC_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) stats[i] = ctx->loadStats[i];
     return MC_OK;
 }
 

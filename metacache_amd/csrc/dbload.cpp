@@ -1,0 +1,314 @@
+// metacache_amd/csrc/dbload.cpp -- a single-part database file into the device table at the speed of the host's memory and the PCIe
+// link: reader THREADS fill pinned slabs with the file's batches (pread of disjoint ranges), one feeder copies them to the device on a
+// copy stream and launches the table kernels (table_build.hip) behind the copies on the context's stream -- reads, H2D copies and insert
+// kernels of different batches overlap, and nothing on the way waits for the device (the one number the old loader fetched from it per
+// batch, how many locations the batch adds to the location store, is a pure function of the batch's keys and sizes: the readers compute it).
+//
+// What it replaces: the reference reads every part of a database in its own thread (database.cpp:203-226, std::async per part) with
+// hash_multimap::deserialize's sequential loop inside (hash_multimap.hpp:970-1030); round 3's loader here was that loop: one fread into
+// pageable memory, a blocking copy, three kernels, two synchronisations per batch -- 6.8 GB/s from /dev/shm.
+//
+// File layout (hash_multimap.hpp:1037-1082): {nkeys, nvalues, batch} u64, then per batch keys[nb] u32 | sizes[nb] u8 | values[sum sizes]
+// of (4 + target_id_bytes) bytes each: where batch i + 1 begins follows from batch i's sizes, so an INDEX PASS reads the sizes of all
+// batches first (1 byte per key: 1-2 % of the file) and the readers then know every batch's place.
+#include "context.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+using namespace mcamd;
+
+namespace {
+
+// ---- pinned slabs, kept between loads (part groups load part after part; pinning memory costs about as much as reading it) ---------
+struct Slab { uint8_t* p = nullptr; size_t cap = 0; };
+struct SlabPool {
+    std::mutex mtx;
+    std::vector<Slab> idle;
+    size_t idleBytes = 0;
+    static constexpr size_t kKeep = 3ull << 30;              // cached at most
+    Slab get(size_t need)
+    {
+        {
+            std::lock_guard<std::mutex> l(mtx);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].cap >= need && idle[i].cap <= 2 * need + (1u << 20)) { Slab s = idle[i]; idle.erase(idle.begin() + i); idleBytes -= s.cap; return s; }
+        }
+        Slab s;
+        if (hipHostMalloc((void**)&s.p, need, hipHostMallocPortable) != hipSuccess) { s.p = nullptr; return s; }
+        s.cap = need;
+        return s;
+    }
+    void put(Slab s)
+    {
+        if (!s.p) return;
+        {
+            std::lock_guard<std::mutex> l(mtx);
+            if (idleBytes + s.cap <= kKeep) { idle.push_back(s); idleBytes += s.cap; return; }
+        }
+        (void)hipHostFree(s.p);
+    }
+};
+SlabPool& pool() { static SlabPool p; return p; }
+
+bool pread_all(int fd, void* dst, size_t n, uint64_t off)
+{
+    uint8_t* d = static_cast<uint8_t*>(dst);
+    while (n) {
+        const ssize_t r = ::pread(fd, d, std::min<size_t>(n, 1u << 30), (off_t)off);
+        if (r <= 0) return false;
+        d += r; n -= (size_t)r; off += (uint64_t)r;
+    }
+    return true;
+}
+
+struct BatchPlace { uint64_t off = 0, fileVals = 0; uint32_t nkeys = 0; };   // byte offset of the batch's keys in the file
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// effective_size of table_build.hip on the host: what a key of `fileSize` locations adds to the location store
+inline uint32_t stored_of(uint32_t key, uint32_t fileSize, const LoadFilter& lf)
+{
+    uint32_t size = fileSize;
+    if (lf.rmOver && size > lf.rmOver) size = 0;
+    if (lf.maxLocs && size > lf.maxLocs) size = lf.maxLocs;
+    if (lf.shardCnt > 1 && key_owner(key, lf.shardCnt) != lf.shardIdx) size = 0;
+    return size > 1 ? size : 0;
+}
+
+}  // namespace
+
+// One chunk (<= 2^22 keys, < 2^32 file values) whose arrays are in device memory, WITHOUT any synchronisation: `stored` (what the chunk adds
+// to the location store) comes from the host.  The scratch arrays are reused chunk after chunk: the stream's order protects them.
+int mcamd::load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nb, uint64_t fileVals, uint64_t stored)
+{
+    Part& P = ctx->parts[0];
+    auto fail = [&](int code, const char* msg) { ctx->err = msg; return code; };
+    if (P.keysLoaded + nb > P.expectKeys) return fail(MC_ERR_INVALID, "database file: more keys than its header announces");
+    if (fileVals >= (1ull << 32)) return fail(MC_ERR_INVALID, "database file: a chunk holds 2^32 or more locations");
+    if (P.valuesStored + stored > P.dvaluesCap) return fail(MC_ERR_INVALID, "database file: more values than its header announces");
+    const uint32_t tb = ctx->cfg.target_id_bytes;
+    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count};
+    hipStream_t st = ctx->stream;
+    auto ensure = [&](DevBuf& b, size_t bytes) -> bool {
+        if (bytes <= b.cap) return true;
+        // (growing a scratch array the stream may still be reading: drain it first -- happens a few times per load, the sizes settle at once)
+        if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); }
+        b.p = nullptr; b.cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&b.p, want) != hipSuccess) return false;
+        b.cap = want;
+        return true;
+    };
+    if (!ensure(ctx->bLdFileSz, (size_t)nb * 4) || !ensure(ctx->bLdStoreSz, (size_t)nb * 4) || !ensure(ctx->bLdFileOff, (size_t)(nb + 2) * 4) ||
+        !ensure(ctx->bLdStoreOff, (size_t)(nb + 2) * 4) || !ensure(ctx->bLdScan, scan_tmp_bytes(nb + 1)))
+        return fail(MC_ERR_NOMEM, "database load: cannot allocate the table-build scratch");
+    auto* fileSz = (uint32_t*)ctx->bLdFileSz.p; auto* storeSz = (uint32_t*)ctx->bLdStoreSz.p;
+    auto* fileOff = (uint32_t*)ctx->bLdFileOff.p; auto* storeOff = (uint32_t*)ctx->bLdStoreOff.p;
+    auto* counters = (unsigned long long*)ctx->bLdCounters.p;
+    launch_table_prep(dkeys, dsizes, nb, lf, fileSz, storeSz, counters, st);
+    launch_scan_u32(fileSz, 1, nb, fileOff, nullptr, ctx->bLdScan.p, st);
+    launch_scan_u32(storeSz, 1, nb, storeOff, nullptr, ctx->bLdScan.p, st);
+    const GwLayout gwl = P.compact ? GwLayout{ctx->dGwBase, ctx->gwTargets, ctx->gwGap} : GwLayout{};
+    launch_table_insert(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
+                        (unsigned int*)(counters + 2), (unsigned int*)(counters + 2) + 1, st, gwl, (unsigned int*)(counters + 3));
+    if (P.compact)
+        launch_table_values_compact(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, reinterpret_cast<uint32_t*>(P.dvalues) + P.valuesStored,
+                                    gwl, (unsigned int*)(counters + 3), st);
+    else
+        launch_table_values(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
+    if (hipGetLastError() != hipSuccess) return fail(MC_ERR_HIP, "database load: a table-build kernel failed to launch");
+    P.valuesStored += stored;
+    P.keysLoaded += nb;
+    return MC_OK;
+}
+
+// The whole .cache file of a single-part context (between mc_load_begin and mc_load_end, which the caller issues).
+int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t targetBytes, uint64_t stats[4])
+{
+    auto fail = [&](int code, const std::string& msg) { ctx->err = msg; return code; };
+    if (ctx->parts.size() != 1 || !ctx->parts[0].loading) return fail(MC_ERR_STATE, "load_file_pipelined: single-part load only");
+    const int fd = ::open(fname.c_str(), O_RDONLY);
+    if (fd < 0) return fail(MC_ERR_IO, "Could not read database file '" + fname + "'");
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    uint64_t head[3] = {0, 0, 0};
+    if (!pread_all(fd, head, 24, 0)) return fail(MC_ERR_IO, "truncated " + fname);
+    const uint64_t nkeys = head[0], batch = head[2];
+    if (nkeys && batch == 0) return fail(MC_ERR_IO, "corrupt header in " + fname);
+    if (batch > (1ull << 26)) return fail(MC_ERR_UNSUPPORTED, "unsupported batch size in " + fname + " (header says " + std::to_string(batch) + " keys per batch)");
+    struct stat sb{};
+    if (fstat(fd, &sb) != 0) return fail(MC_ERR_IO, "cannot stat " + fname);
+    const uint64_t fileSize = (uint64_t)sb.st_size;
+    const size_t vb = 4 + targetBytes;
+    const uint64_t t0 = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }();
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; };
+
+    // ---- index pass: every batch's place (its sizes are read to find the next one)
+    std::vector<BatchPlace> place;
+    {
+        std::vector<uint8_t> sz((size_t)std::min<uint64_t>(batch, nkeys));
+        uint64_t off = 24;
+        for (uint64_t done = 0; done < nkeys;) {
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, nkeys - done);
+            if (off + (uint64_t)nb * 5 > fileSize || !pread_all(fd, sz.data(), nb, off + (uint64_t)nb * 4)) return fail(MC_ERR_IO, "truncated " + fname);
+            uint64_t bv = 0;
+            for (uint32_t i = 0; i < nb; ++i) bv += sz[i];
+            if (off + (uint64_t)nb * 5 + bv * vb > fileSize) return fail(MC_ERR_IO, "truncated " + fname);
+            place.push_back(BatchPlace{off, bv, nb});
+            off += (uint64_t)nb * 5 + bv * vb;
+            done += nb;
+        }
+    }
+    const uint64_t tIndex = now();
+    const size_t nbatches = place.size();
+    if (nbatches == 0) return MC_OK;
+    auto batch_bytes = [&](const BatchPlace& b) { return align16((size_t)b.nkeys * 4) + align16(b.nkeys) + align16((size_t)b.fileVals * vb) + 16; };
+    size_t slabBytes = 0;
+    for (const auto& b : place) slabBytes = std::max(slabBytes, batch_bytes(b));
+    uint32_t nthreads = 8;
+    if (const char* e = std::getenv("MC_LOAD_THREADS")) nthreads = (uint32_t)std::max(1, std::atoi(e));
+    nthreads = (uint32_t)std::min<size_t>(nthreads, nbatches);
+    const uint32_t nslabs = (uint32_t)std::min<size_t>(nbatches, nthreads + 2);
+
+    // ---- slabs: batch b lives in slab b % nslabs; a reader may fill it once the feeder has released batch b - nslabs (no deadlock: the
+    // earliest batch the feeder waits for always finds its slab free or about to be freed by the feeder's own progress)
+    std::vector<Slab> slabs(nslabs);
+    for (auto& s : slabs) {
+        s = pool().get(slabBytes);
+        if (!s.p) { for (auto& t : slabs) pool().put(t); return fail(MC_ERR_NOMEM, "database load: cannot allocate pinned staging memory"); }
+    }
+    std::mutex mtx;
+    std::condition_variable cv;
+    std::vector<uint8_t> ready(nbatches, 0);                  // 1 = in its slab, 2 = the read failed
+    std::vector<uint64_t> storedOf(nbatches, 0);
+    size_t released = 0;                                      // batches whose slab the feeder has given back
+    std::atomic<size_t> next{0};
+    bool abort = false;
+    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count};
+    auto reader = [&] {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= nbatches) return;
+            {
+                std::unique_lock<std::mutex> l(mtx);
+                cv.wait(l, [&] { return abort || b < released + nslabs; });
+                if (abort) return;
+            }
+            const BatchPlace& B = place[b];
+            uint8_t* base = slabs[b % nslabs].p;
+            uint8_t* keys = base; uint8_t* sizes = keys + align16((size_t)B.nkeys * 4); uint8_t* vals = sizes + align16(B.nkeys);
+            // the batch is one contiguous range of the file; keys | sizes | values go to 16-byte aligned places of the slab
+            bool ok = pread_all(fd, keys, (size_t)B.nkeys * 4, B.off) && pread_all(fd, sizes, B.nkeys, B.off + (uint64_t)B.nkeys * 4) &&
+                      (B.fileVals == 0 || pread_all(fd, vals, (size_t)B.fileVals * vb, B.off + (uint64_t)B.nkeys * 5));
+            uint64_t st = 0;
+            if (ok) {
+                const uint32_t* k = reinterpret_cast<const uint32_t*>(keys);
+                if (lf.shardCnt > 1 || lf.maxLocs || lf.rmOver) for (uint32_t i = 0; i < B.nkeys; ++i) st += stored_of(k[i], sizes[i], lf);
+                else for (uint32_t i = 0; i < B.nkeys; ++i) st += sizes[i] > 1 ? sizes[i] : 0u;
+            }
+            {
+                std::lock_guard<std::mutex> l(mtx);
+                storedOf[b] = st;
+                ready[b] = ok ? 1 : 2;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t t = 0; t < nthreads; ++t) threads.emplace_back(reader);
+    hipStream_t copySt = nullptr;
+    auto stop = [&](int code, const std::string& msg) {         // an error: nothing stays in flight, every slab goes back
+        { std::lock_guard<std::mutex> l(mtx); abort = true; }
+        cv.notify_all();
+        for (auto& t : threads) t.join();
+        if (copySt) (void)hipStreamSynchronize(copySt);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& s : slabs) pool().put(s);
+        return fail(code, msg);
+    };
+
+    // ---- feeder: slab -> device staging (two of them) on a copy stream, table kernels behind it on the context's stream
+    if (hipSetDevice(ctx->device) != hipSuccess) return stop(MC_ERR_HIP, "hipSetDevice");
+    hipEvent_t copied[2] = {nullptr, nullptr}, built[2] = {nullptr, nullptr};
+    DevBuf stage[2];
+    bool okInit = hipStreamCreateWithFlags(&copySt, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && okInit; ++i)
+        okInit = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&built[i], hipEventDisableTiming) == hipSuccess;
+    auto cleanup = [&] {
+        for (int i = 0; i < 2; ++i) { if (copied[i]) (void)hipEventDestroy(copied[i]); if (built[i]) (void)hipEventDestroy(built[i]); if (stage[i].p) (void)hipFree(stage[i].p); }
+        if (copySt) (void)hipStreamDestroy(copySt);
+    };
+    if (!okInit) { const int code = stop(MC_ERR_HIP, "database load: cannot create the copy stream"); cleanup(); return code; }
+    uint64_t waitNs = 0, bytesIn = 24;
+    int rc = MC_OK;
+    std::string emsg;
+    for (size_t b = 0; b < nbatches && !rc; ++b) {
+        const int k = (int)(b & 1);
+        {
+            const uint64_t w0 = now();
+            std::unique_lock<std::mutex> l(mtx);
+            cv.wait(l, [&] { return ready[b] != 0; });
+            waitNs += now() - w0;
+            if (ready[b] == 2) { rc = MC_ERR_IO; emsg = "truncated " + fname; break; }
+        }
+        const BatchPlace& B = place[b];
+        const size_t bytes = batch_bytes(B);
+        if (b >= 2 && hipEventSynchronize(built[k]) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: table build failed"; break; }   // staging k is free again
+        if (bytes > stage[k].cap) {
+            if (stage[k].p) (void)hipFree(stage[k].p);
+            stage[k].p = nullptr; stage[k].cap = 0;
+            if (hipMalloc(&stage[k].p, slabBytes) != hipSuccess) { rc = MC_ERR_NOMEM; emsg = "database load: cannot allocate the device staging"; break; }
+            stage[k].cap = slabBytes;
+        }
+        const uint8_t* hbase = slabs[b % nslabs].p;
+        if (hipMemcpyAsync(stage[k].p, hbase, bytes, hipMemcpyHostToDevice, copySt) != hipSuccess || hipEventRecord(copied[k], copySt) != hipSuccess ||
+            hipStreamWaitEvent(ctx->stream, copied[k], 0) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: copy to the device failed"; break; }
+        const uint8_t* dbase = static_cast<const uint8_t*>(stage[k].p);
+        const uint32_t* dkeys = reinterpret_cast<const uint32_t*>(dbase);
+        const uint8_t* dsizes = dbase + align16((size_t)B.nkeys * 4);
+        const uint8_t* dvals = dsizes + align16(B.nkeys);
+        const uint8_t* hsizes = hbase + align16((size_t)B.nkeys * 4);
+        // device chunks of at most 2^22 keys (the reference's and this repository's files: one per batch)
+        const uint32_t kChunk = 1u << 22;
+        if (B.nkeys <= kChunk && B.fileVals < (1ull << 32)) rc = load_chunk_device_async(ctx, dkeys, dsizes, dvals, B.nkeys, B.fileVals, storedOf[b]);
+        else {
+            const uint32_t* hkeys = reinterpret_cast<const uint32_t*>(hbase);
+            uint64_t voff = 0;
+            for (uint32_t done = 0; done < B.nkeys && !rc;) {
+                uint32_t nb = 0; uint64_t fv = 0, stc = 0;
+                while (done + nb < B.nkeys && nb < kChunk && fv + hsizes[done + nb] < (1ull << 32)) {
+                    fv += hsizes[done + nb]; stc += stored_of(hkeys[done + nb], hsizes[done + nb], lf); ++nb;
+                }
+                rc = load_chunk_device_async(ctx, dkeys + done, dsizes + done, dvals + voff * vb, nb, fv, stc);
+                done += nb; voff += fv;
+            }
+        }
+        if (rc) { emsg = ctx->err; break; }
+        if (hipEventRecord(built[k], ctx->stream) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: event"; break; }
+        bytesIn += (uint64_t)B.nkeys * 5 + B.fileVals * vb;
+        // the slab goes back to the readers when its copy has left the host: the copy of the PREVIOUS batch has had a batch's time to finish
+        if (b >= 1) {
+            if (hipEventSynchronize(copied[k ^ 1]) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: copy to the device failed"; break; }
+            { std::lock_guard<std::mutex> l(mtx); released = b; }
+            cv.notify_all();
+        }
+    }
+    if (rc) { const int code = stop(rc, emsg); cleanup(); return code; }
+    for (auto& t : threads) t.join();
+    const bool synced = hipStreamSynchronize(copySt) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    cleanup();
+    for (auto& s : slabs) pool().put(s);
+    if (!synced) return fail(MC_ERR_HIP, "database load: table build failed");
+    if (stats) { stats[0] = bytesIn; stats[1] = now() - t0; stats[2] = tIndex - t0; stats[3] = waitNs; }
+    return MC_OK;
+}

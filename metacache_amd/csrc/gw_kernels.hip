@@ -108,12 +108,22 @@ struct GwBloom {
 // batch of kGwRounds rounds held in registers.
 struct GwFrame {
     uint32_t A, D, blockMask, inner;                           // keys = number >> A; (number & blockMask) - D >= inner: within D of a block boundary
+    uint32_t shv, Dsh, twoDsh;                                 // the same test in two instructions: ((number + D) << (32 - A)) < (2 D << (32 - A))
     __device__ __forceinline__ explicit GwFrame(uint32_t maxWin)
     {
         A = gw_block_shift(maxWin); D = maxWin > 1 ? maxWin - 1 : 0u;
         blockMask = (1u << A) - 1u; inner = (1u << A) - 2u * D;
+        const uint32_t sh = 32u - A;                           // (A <= 16: 2 D < 2^A, nothing is shifted out of 2 D)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(shv) : "s"(sh));   // (kept in a vector register: a VOP3 instruction reads one scalar register at most)
+        Dsh = D << sh; twoDsh = (2u * D) << sh;
     }
-    __device__ __forceinline__ bool edge(uint32_t v) const { return ((v & blockMask) - D) >= inner; }
+    // (number + D) mod 2^A < 2 D  <=>  the number lies within D of a block boundary; the shift brings the low A bits to the top
+    __device__ __forceinline__ bool edge(uint32_t v) const
+    {
+        uint32_t t;
+        asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(t) : "v"(v), "v"(shv), "s"(Dsh));
+        return t < twoDsh;
+    }
 };
 
 // round table of the batch [r0, r0 + kGwRounds) of an entry chunk's rounds: first index | numbers << 40.  start / myR: the lane's entry
@@ -197,8 +207,10 @@ __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (kb[j]) {
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(km[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km[j], n2));
-            if (!CHECK || at < S.room) S.dst[at] = v[j];
+            // (the running count goes into the UNIFORM base of the store -- scalar arithmetic --, the lane adds its place among the kept ones)
+            const uint32_t mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(km[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km[j], 0u));
+            uint32_t* const to = S.dst + n2;
+            if (!CHECK || n2 + mine < S.room) to[mine] = v[j];
         }
         n2 += (uint32_t)__popcll(km[j]);
     }
@@ -579,7 +591,7 @@ __device__ __forceinline__ uint32_t gw_slot(uint32_t g)                 // byte 
 // Phase 1 on the PER numbers every lane holds: counted in the table; the numbers a lane CLAIMED (one lane per distinct number) go,
 // with their slots, to the compact list ck -- a filtered list of 195 numbers has about 50 distinct ones, and everything after the
 // counting (neighbour windows, the K rounds) is per distinct number: one per lane instead of four.  Returns how many.
-template <uint32_t LOG2S, uint32_t PER>
+template <uint32_t LOG2S, uint32_t PER, uint32_t CKCAP = 0xFFFFFFFFu>
 __device__ __forceinline__ uint32_t gw_count_numbers(const uint32_t (&v)[PER], uint2* slots, uint32_t* ck, const uint32_t lane)
 {
     constexpr uint32_t kByteMask = ((1u << LOG2S) - 1u) << 3;
@@ -613,7 +625,10 @@ __device__ __forceinline__ uint32_t gw_count_numbers(const uint32_t (&v)[PER], u
         if (v[r] != kGwNone) atomicAdd(key_at(off[r]) + 1, 1u);
         const bool claimed = v[r] != kGwNone && old[r] == kGwNone;
         const uint64_t m = __ballot(claimed);
-        if (claimed) ck[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, C))] = off[r];   // (the slot holds the number)
+        if (claimed) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, C));
+            if (CKCAP == 0xFFFFFFFFu || at < CKCAP) ck[at] = off[r];   // (the slot holds the number; CKCAP: the caller looks at the count returned)
+        }
         C += (uint32_t)__popcll(m);
     }
     return C;
@@ -742,6 +757,219 @@ __device__ __forceinline__ bool gw_winners_out(const uint32_t lane, const uint32
 
 }  // namespace
 
+namespace {
+
+// The winners' target lookup is two dependent loads from global memory (directory, gwBase) at the very end of a read: it is DEFERRED --
+// directory entry requested when the winners are known, gwBase words before the next read's counting, the candidates written after
+// it -- so that the loads run behind the next read's LDS phases (a read with places left for single hits finishes at once: step D
+// needs the picked targets).  One of these per wave.
+struct GwPend {
+    bool pend = false;
+    uint32_t q = 0, wv = kGwNone, wh = 0, wd = 0, dir = 0, b0 = 0, b1 = 0, b2 = 0;
+    __device__ __forceinline__ void bases(const DeviceTable& tab)   // stage 1: the three gwBase words behind the directory entry
+    {
+        if (pend && wv != kGwNone) { b0 = tab.gwBase[dir]; b1 = tab.gwBase[dir + 1]; b2 = tab.gwBase[min(dir + 2, tab.gwTargets)]; }
+    }
+    template <bool TAX>
+    __device__ __forceinline__ void finish(const uint32_t lane, const uint32_t K, const DeviceTable& tab, const Workspace& ws, mc_candidate_dev* __restrict__ cands)   // stage 2
+    {
+        if (!pend) return;
+        uint32_t t = 0xFFFFFFFFu, lo = 0, hi = 0;
+        if (wv != kGwNone) {
+            t = dir; lo = b0; hi = b1;
+            if (wv >= b1) { ++t; lo = b1; hi = b2; }
+            while (wv >= hi) { ++t; lo = hi; hi = tab.gwBase[t + 1]; }
+        }
+        uint32_t plo[kLaneK], phi[kLaneK];
+        const bool again = gw_winners_out<TAX>(lane, K, wv, wh, wd, t, lo, hi, cands + (size_t)q * K, plo, phi);
+        if (lane == 0) {
+            if (again) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+            else ws.qflag[q] = kFlagDone;
+        }
+        pend = false;
+    }
+};
+
+// Rows 8-10 for ONE read on its filtered list of n2 <= 2^LOG2S / 2 numbers, window ranges up to kHashWin: getv(r) hands this lane its
+// r-th number (position r * 64 + lane; kGwNone past the end).  slots: the wave's table of 2^LOG2S {number, count} slots, ck: room for
+// the slots of the distinct numbers, T: a round table (step D; may share memory with slots or ck).  w: the read's record in work list 6.
+// DEFER: the winners' target lookup waits in P for the caller's next read (see GwPend; the caller finishes the last one).
+// LONG (first instance's table only): the list may hold up to 2^LOG2S numbers as long as no more than half of them are DISTINCT (a filtered
+// list of 400 numbers has about 100 distinct ones); a list with more goes to the exact wave kernel.
+template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, class GetV>
+__device__ __forceinline__ void gw_count_read(const uint32_t q, const uint32_t w, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
+                                              uint2* slots, uint32_t* ck, uint64_t* T, const uint32_t lane, const uint32_t grp, const uint32_t sub4,
+                                              const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab, const Workspace& ws,
+                                              mc_candidate_dev* __restrict__ cands, const uint4* __restrict__ work6, GwPend& P)
+{
+    constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
+    {
+        uint4* k4 = reinterpret_cast<uint4*>(slots);
+#pragma unroll
+        for (uint32_t i = 0; i < kSlots * 8 / 16 / 64; ++i) k4[i * 64 + lane] = make_uint4(kGwNone, 0u, kGwNone, 0u);
+    }
+    wave_lds_sync();
+    uint32_t pickLo[kLaneK], pickHi[kLaneK];
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = 0; pickHi[i] = 0; }
+    uint32_t strong = 0, wv = kGwNone, wh = 0, wd = 0;
+    bool again = false;
+    mc_candidate_dev* out = cands + (size_t)q * K;
+    if constexpr (DEFER) P.bases(tab);
+    uint32_t C = 0;
+    auto body = [&](auto perc) {
+        constexpr uint32_t PER = decltype(perc)::value;
+        uint32_t v[PER];
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) v[r] = getv(r);
+        C = gw_count_numbers<LOG2S, PER, LONG ? kList : 0xFFFFFFFFu>(v, slots, ck, lane);
+    };
+    const uint32_t per = (n2 + 63u) / 64u;
+    if constexpr (LOG2S == 9) {
+        if (per <= 1) body(std::integral_constant<uint32_t, 1>{});
+        else if (per <= 2) body(std::integral_constant<uint32_t, 2>{});
+        else if (per <= 3) body(std::integral_constant<uint32_t, 3>{});
+        else if (!LONG || per <= 4) body(std::integral_constant<uint32_t, 4>{});
+        else if constexpr (LONG) {
+            if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
+            else body(std::integral_constant<uint32_t, 8>{});
+        }
+    } else if constexpr (LOG2S == 10) {
+        if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
+        else body(std::integral_constant<uint32_t, 8>{});
+    } else {
+        if (per <= 10) body(std::integral_constant<uint32_t, 10>{});
+        else if (per <= 12) body(std::integral_constant<uint32_t, 12>{});
+        else body(std::integral_constant<uint32_t, kList / 64>{});
+    }
+    C = __builtin_amdgcn_readfirstlane(C);
+    wave_lds_sync();
+    if constexpr (LONG) {
+        if (C > kList) {                                           // more distinct numbers than the table is made for (the neighbour lookups need free slots): the exact wave kernel
+            if constexpr (DEFER) P.template finish<TAX>(lane, K, tab, ws, cands);
+            if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+            wave_lds_sync();
+            return;
+        }
+    }
+    auto pick = [&](auto perc) {
+        constexpr uint32_t PER = decltype(perc)::value;
+        strong = gw_pick<LOG2S, PER, TAX>(ck, C, slots, lane, maxWin, K, taxkey, tab, wv, wh, wd);
+    };
+    if (C <= 64) pick(std::integral_constant<uint32_t, 1>{});
+    else if (C <= 128) pick(std::integral_constant<uint32_t, 2>{});
+    else if (C <= 256) pick(std::integral_constant<uint32_t, 4>{});
+    else if constexpr (LOG2S >= 10) {
+        if (C <= 512) pick(std::integral_constant<uint32_t, 8>{});
+        else if constexpr (LOG2S >= 11) pick(std::integral_constant<uint32_t, 16>{});
+    }
+    strong = __builtin_amdgcn_readfirstlane(strong);
+    if constexpr (DEFER) {
+        P.template finish<TAX>(lane, K, tab, ws, cands);           // the previous read's candidates
+        if (strong >= K) {                                         // this read's: later
+            P.pend = true; P.q = q; P.wv = wv; P.wh = wh; P.wd = wd;
+            P.dir = wv != kGwNone ? tab.gwDir[wv >> tab.gwDirShift] : 0u;
+            wave_lds_sync();
+            return;
+        }
+    }
+    {
+        uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
+        if (wv != kGwNone) tab.gw_target_bounds(wv, wt, wlo, whi);
+        again = gw_winners_out<TAX>(lane, K, wv, wh, wd, wt, wlo, whi, out, pickLo, pickHi);
+    }
+    bool done = true;
+    if (again) {                                                   // two winners of one target: the exact wave kernel
+        if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+        done = false;
+    } else if (strong < K) {
+        const uint4 r6 = work6[w];
+        const uint32_t fbase = r6.y, nent = r6.z & 0xFFFu;
+        if (TAX || nent > kBigEnt) {
+            // places left for single-hit taxa: the order among those depends on every target's taxon -> the exact wave kernel
+            // (so do reads with more than 64 found features: the sweep below reads one entry per lane)
+            if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+            done = false;
+        } else if constexpr (!TAX) {
+            // ---- D. the smallest numbers of targets that were not picked with >= 2 hits -- every such target's best range is a
+            //      single location, and the first of them in (target, window) order are what the CPU's list keeps
+            wave_lds_sync();
+            const uint32_t sz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
+            const uint64_t pay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
+            const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
+            const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
+            // every lane keeps the kLaneK smallest numbers it sees (several may be one target's: the rounds below strike whole
+            // targets, and a lane that had to drop numbers and is left with none cannot vouch for its minimum any more)
+            uint32_t best[kLaneK];
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kGwNone;
+            uint32_t seen = 0;
+            auto visit = [&](uint32_t g, bool valid) {
+                if (!valid) return;
+                bool skip = false;
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) skip = skip || (i < strong && g - pickLo[i] < pickHi[i] - pickLo[i]);
+                if (skip) return;
+                ++seen;
+                uint32_t c = g;                                     // sorted insert, the largest falls out
+#pragma unroll
+                for (uint32_t i = 0; i < kLaneK; ++i) { const uint32_t lo = min(best[i], c); c = max(best[i], c); best[i] = lo; }
+            };
+            visit(sz == 1 ? tab.gw_of(pay) : kGwNone, sz == 1);
+            for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
+                for (uint32_t i = lane; i < kGwRounds; i += 64) if (r0 + i >= Rc) T[i] = 0ull;
+                const uint32_t jlo = r0 > start ? r0 - start : 0u, jhi = min(myR, r0 + kGwRounds > start ? r0 + kGwRounds - start : 0u);
+                for (uint32_t j = jlo; j < jhi; ++j) T[start + j - r0] = (pay + 16ull * j) | ((uint64_t)min(16u, sz - 16u * j) << 40);
+                wave_lds_sync();
+#pragma unroll
+                for (uint32_t u = 0; u < kGwLoads; ++u) {
+                    const uint64_t rd = T[u * 16 + grp];
+                    const int32_t rem = (int32_t)(uint32_t)(rd >> 40) - (int32_t)sub4;
+                    if (rem > 0) {
+                        const U4 t = *reinterpret_cast<const U4*>(tab.values32 + (rd & 0xFFFFFFFFFFull) + sub4);
+                        visit(t.x, true); visit(t.y, rem > 1); visit(t.z, rem > 2); visit(t.w, rem > 3);
+                    }
+                }
+                wave_lds_sync();
+            }
+            const bool dropped = seen > kLaneK;
+            bool unsure = false;
+            for (uint32_t rnd = strong; rnd < K; ++rnd) {
+                if (__ballot(dropped && best[0] == kGwNone)) { unsure = true; break; }
+                const uint32_t m = wave_min_u32(best[0]);
+                mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
+                if (m != kGwNone) {
+                    const uint32_t t = tab.gw_target(m), lo = tab.gwBase[t], hi = tab.gwBase[t + 1];
+                    e.tgt = t; e.hits = 1; e.beg = e.end = m - lo;
+                    // that target leaves every lane's list (its numbers are neighbours in the sorted list: compact the rest)
+                    uint32_t kept[kLaneK];
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) kept[i] = kGwNone;
+                    uint32_t n = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) {
+                        const bool stay = best[i] != kGwNone && !(best[i] - lo < hi - lo);
+#pragma unroll
+                        for (uint32_t j = 0; j < kLaneK; ++j) if (stay && j == n) kept[j] = best[i];
+                        n += stay ? 1u : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kept[i];
+                }
+                if (lane == 0) out[rnd] = e;
+            }
+            if (unsure) {
+                if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+                done = false;
+            }
+        }
+    }
+    if (done && lane == 0) ws.qflag[q] = kFlagDone;
+    wave_lds_sync();
+}
+
+}  // namespace
+
 #ifndef MC_GW_COUNT_WPE
 #define MC_GW_COUNT_WPE 6
 #endif
@@ -779,33 +1007,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
         }
     };
     // the first instance (most reads) takes ALL records, 64 per step; the others get theirs from the compact lists gw_compact_kernel
-    // made (ws.sideList [1] / [2]), 8 per step: with few of them every wave should have some
-    // The winners' target lookup is two dependent loads from global memory (directory, gwBase) at the very end of a read: the first
-    // instance DEFERS it -- directory entry requested when the winners are known, gwBase words before the next read's counting, the
-    // candidates written after it -- so that the loads run behind the next read's LDS phases (a read with places left for single hits
-    // finishes at once: step D needs the picked targets).
+    // made (ws.sideList [1] / [2]), 8 per step: with few of them every wave should have some.  The first two instances defer the
+    // winners' target lookup behind the next read's counting (GwPend).
     constexpr bool kDefer = LOG2S <= 10;
-    bool pend = false;
-    uint32_t pq = 0, pwv = kGwNone, pwh = 0, pwd = 0, pdir = 0, pb0 = 0, pb1 = 0, pb2 = 0;
-    auto pend_bases = [&]() {                                        // stage 1: the three gwBase words behind the directory entry
-        if (pend && pwv != kGwNone) { pb0 = tab.gwBase[pdir]; pb1 = tab.gwBase[pdir + 1]; pb2 = tab.gwBase[min(pdir + 2, tab.gwTargets)]; }
-    };
-    auto pend_finish = [&]() {                                       // stage 2
-        if (!pend) return;
-        uint32_t t = 0xFFFFFFFFu, lo = 0, hi = 0;
-        if (pwv != kGwNone) {
-            t = pdir; lo = pb0; hi = pb1;
-            if (pwv >= pb1) { ++t; lo = pb1; hi = pb2; }
-            while (pwv >= hi) { ++t; lo = hi; hi = tab.gwBase[t + 1]; }
-        }
-        uint32_t plo[kLaneK], phi[kLaneK];
-        const bool again = gw_winners_out<TAX>(lane, K, pwv, pwh, pwd, t, lo, hi, cands + (size_t)pq * K, plo, phi);
-        if (lane == 0) {
-            if (again) { ws.hitScan[pq] = ws.qstat[pq].hits; ws.qflag[pq] = kFlagCands; }
-            else ws.qflag[pq] = kFlagDone;
-        }
-        pend = false;
-    };
+    GwPend P;
     constexpr uint32_t kStep = LOG2S == 9 ? 64u : 8u;
     const uint32_t nmine = LOG2S == 9 ? total : ws.midCount[LOG2S == 10 ? 14 : 15];
     const uint32_t* __restrict__ side = ws.sideList + (size_t)(LOG2S == 10 ? 1 : 2) * b.n;
@@ -825,163 +1030,312 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
 #pragma unroll
         for (uint32_t r = 0; r < kPre; ++r) cur[r] = pre[r];
         if (todo) { const uint32_t jn = (uint32_t)__ffsll((unsigned long long)todo) - 1; fetch(rdlane(myRec.y, jn), rdlane(myRec.z, jn)); }
-        {
-            uint4* k4 = reinterpret_cast<uint4*>(slots);
-#pragma unroll
-            for (uint32_t i = 0; i < kSlots * 8 / 16 / 64; ++i) k4[i * 64 + lane] = make_uint4(kGwNone, 0u, kGwNone, 0u);
-        }
-        wave_lds_sync();
-        uint32_t pickLo[kLaneK], pickHi[kLaneK];
-#pragma unroll
-        for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = 0; pickHi[i] = 0; }
-        uint32_t strong = 0, wv = kGwNone, wh = 0, wd = 0;
-        bool again = false;
-        mc_candidate_dev* out = cands + (size_t)q * K;
-        if constexpr (kDefer) pend_bases();
-        uint32_t C = 0;
-        auto body = [&](auto perc) {
-            constexpr uint32_t PER = decltype(perc)::value;
-            uint32_t v[PER];
-#pragma unroll
-            for (uint32_t r = 0; r < PER; ++r) {
-                if constexpr (LOG2S <= 10) v[r] = cur[r < kPre ? r : 0];
-                else v[r] = r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
-            }
-            C = gw_count_numbers<LOG2S, PER>(v, slots, ck, lane);
-        };
-        const uint32_t per = (n2 + 63u) / 64u;
-        if constexpr (LOG2S == 9) {
-            if (per <= 1) body(std::integral_constant<uint32_t, 1>{});
-            else if (per <= 2) body(std::integral_constant<uint32_t, 2>{});
-            else if (per <= 3) body(std::integral_constant<uint32_t, 3>{});
-            else body(std::integral_constant<uint32_t, 4>{});
-        } else if constexpr (LOG2S == 10) {
-            if (per <= 6) body(std::integral_constant<uint32_t, 6>{});
-            else body(std::integral_constant<uint32_t, 8>{});
-        } else {
-            if (per <= 10) body(std::integral_constant<uint32_t, 10>{});
-            else if (per <= 12) body(std::integral_constant<uint32_t, 12>{});
-            else body(std::integral_constant<uint32_t, kList / 64>{});
-        }
-        C = __builtin_amdgcn_readfirstlane(C);
-        wave_lds_sync();
-        auto pick = [&](auto perc) {
-            constexpr uint32_t PER = decltype(perc)::value;
-            strong = gw_pick<LOG2S, PER, TAX>(ck, C, slots, lane, maxWin, K, taxkey, tab, wv, wh, wd);
-        };
-        if (C <= 64) pick(std::integral_constant<uint32_t, 1>{});
-        else if (C <= 128) pick(std::integral_constant<uint32_t, 2>{});
-        else if (C <= 256) pick(std::integral_constant<uint32_t, 4>{});
-        else if constexpr (LOG2S >= 10) {
-            if (C <= 512) pick(std::integral_constant<uint32_t, 8>{});
-            else if constexpr (LOG2S >= 11) pick(std::integral_constant<uint32_t, 16>{});
-        }
-        strong = __builtin_amdgcn_readfirstlane(strong);
-        if constexpr (kDefer) {
-            pend_finish();                                         // the previous read's candidates
-            if (strong >= K) {                                     // this read's: later
-                pend = true; pq = q; pwv = wv; pwh = wh; pwd = wd;
-                pdir = wv != kGwNone ? tab.gwDir[wv >> tab.gwDirShift] : 0u;
-                wave_lds_sync();
-                continue;
-            }
-        }
-        {
-            uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
-            if (wv != kGwNone) tab.gw_target_bounds(wv, wt, wlo, whi);
-            again = gw_winners_out<TAX>(lane, K, wv, wh, wd, wt, wlo, whi, out, pickLo, pickHi);
-        }
-        bool done = true;
-        if (again) {                                               // two winners of one target: the exact wave kernel
-            if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
-            done = false;
-        } else if (strong < K) {
-            const uint4 r6 = work6[w];
-            const uint32_t fbase = r6.y, nent = r6.z & 0xFFFu;
-            if (TAX || nent > kBigEnt) {
-                // places left for single-hit taxa: the order among those depends on every target's taxon -> the exact wave kernel
-                // (so do reads with more than 64 found features: the sweep below reads one entry per lane)
-                if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
-                done = false;
-            } else if constexpr (!TAX) {
-                // ---- D. the smallest numbers of targets that were not picked with >= 2 hits -- every such target's best range is a
-                //      single location, and the first of them in (target, window) order are what the CPU's list keeps
-                wave_lds_sync();
-                const uint32_t sz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
-                const uint64_t pay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
-                const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
-                const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
-                // every lane keeps the kLaneK smallest numbers it sees (several may be one target's: the rounds below strike whole
-                // targets, and a lane that had to drop numbers and is left with none cannot vouch for its minimum any more)
-                uint32_t best[kLaneK];
-#pragma unroll
-                for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kGwNone;
-                uint32_t seen = 0;
-                auto visit = [&](uint32_t g, bool valid) {
-                    if (!valid) return;
-                    bool skip = false;
-#pragma unroll
-                    for (uint32_t i = 0; i < kLaneK; ++i) skip = skip || (i < strong && g - pickLo[i] < pickHi[i] - pickLo[i]);
-                    if (skip) return;
-                    ++seen;
-                    uint32_t c = g;                                 // sorted insert, the largest falls out
-#pragma unroll
-                    for (uint32_t i = 0; i < kLaneK; ++i) { const uint32_t lo = min(best[i], c); c = max(best[i], c); best[i] = lo; }
-                };
-                visit(sz == 1 ? tab.gw_of(pay) : kGwNone, sz == 1);
-                for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
-                    for (uint32_t i = lane; i < kGwRounds; i += 64) if (r0 + i >= Rc) T[i] = 0ull;
-                    const uint32_t jlo = r0 > start ? r0 - start : 0u, jhi = min(myR, r0 + kGwRounds > start ? r0 + kGwRounds - start : 0u);
-                    for (uint32_t j = jlo; j < jhi; ++j) T[start + j - r0] = (pay + 16ull * j) | ((uint64_t)min(16u, sz - 16u * j) << 40);
-                    wave_lds_sync();
-#pragma unroll
-                    for (uint32_t u = 0; u < kGwLoads; ++u) {
-                        const uint64_t rd = T[u * 16 + grp];
-                        const int32_t rem = (int32_t)(uint32_t)(rd >> 40) - (int32_t)sub4;
-                        if (rem > 0) {
-                            const U4 t = *reinterpret_cast<const U4*>(tab.values32 + (rd & 0xFFFFFFFFFFull) + sub4);
-                            visit(t.x, true); visit(t.y, rem > 1); visit(t.z, rem > 2); visit(t.w, rem > 3);
-                        }
-                    }
-                    wave_lds_sync();
-                }
-                const bool dropped = seen > kLaneK;
-                bool unsure = false;
-                for (uint32_t rnd = strong; rnd < K; ++rnd) {
-                    if (__ballot(dropped && best[0] == kGwNone)) { unsure = true; break; }
-                    const uint32_t m = wave_min_u32(best[0]);
-                    mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0;
-                    if (m != kGwNone) {
-                        const uint32_t t = tab.gw_target(m), lo = tab.gwBase[t], hi = tab.gwBase[t + 1];
-                        e.tgt = t; e.hits = 1; e.beg = e.end = m - lo;
-                        // that target leaves every lane's list (its numbers are neighbours in the sorted list: compact the rest)
-                        uint32_t kept[kLaneK];
-#pragma unroll
-                        for (uint32_t i = 0; i < kLaneK; ++i) kept[i] = kGwNone;
-                        uint32_t n = 0;
-#pragma unroll
-                        for (uint32_t i = 0; i < kLaneK; ++i) {
-                            const bool stay = best[i] != kGwNone && !(best[i] - lo < hi - lo);
-#pragma unroll
-                            for (uint32_t j = 0; j < kLaneK; ++j) if (stay && j == n) kept[j] = best[i];
-                            n += stay ? 1u : 0u;
-                        }
-#pragma unroll
-                        for (uint32_t i = 0; i < kLaneK; ++i) best[i] = kept[i];
-                    }
-                    if (lane == 0) out[rnd] = e;
-                }
-                if (unsure) {
-                    if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
-                    done = false;
-                }
-            }
-        }
-        if (done && lane == 0) ws.qflag[q] = kFlagDone;
-        wave_lds_sync();
+        gw_count_read<LOG2S, TAX, kDefer>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t {
+            if constexpr (LOG2S <= 10) return cur[r < kPre ? r : 0];
+            else return r * 64 + lane < n2 ? src[r * 64 + lane] : kGwNone;
+        }, slots, ck, T, lane, grp, sub4, K, taxkey, tab, ws, cands, work6, P);
       }
     }
-    if constexpr (kDefer) { pend_bases(); pend_finish(); }
+    if constexpr (kDefer) { P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands); }
+}
+
+constexpr uint32_t kGwCounted = 0x80000000u;      // record of list 7: the read was counted inside the filter kernel (| kept numbers)
+
+// The fused kernel WITHOUT the software pipeline (tuning switch "gw_fuse" 1; kept for comparison: 90 registers, five waves per SIMD, but
+// every read waits for its own loads): see gw_filter_count_kernel below for what it does.  Lists that keep more than 256 numbers
+// repeat phase B into the pool (the numbers are still in registers).
+template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
+__global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_simple_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
+                                                                                 mc_candidate_dev* __restrict__ cands)
+{
+    using Bloom = GwBloom<TLOG2, TLOG2>;
+    constexpr uint32_t kKeep = 512;                                // numbers kept in LDS: the counting takes them when at most 256 are distinct
+    static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
+    __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
+    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][kGwRounds];
+    __shared__ uint32_t keptS[WAVES][kKeep];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* bits = bitS[wave];
+    uint64_t* T = roundS[wave];
+    uint32_t* kept = keptS[wave];
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
+    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
+    uint64_t sliceUsed = 0;
+    uint32_t deferred = 0;
+    uint4 rec = load_rec(w0), recNext = load_rec(w0 + nWaves);
+    uint32_t esz = 0; uint64_t epay = 0;
+    auto load_entries = [&](const uint4& r) {
+        const uint32_t ne = (r.z >> 12) <= kGwSmallH ? min(r.z & 0xFFFu, 64u) : 0u;
+        esz = lane < ne ? ws.psize[r.y + lane] : 0u;
+        epay = lane < ne ? ws.ppay[r.y + lane] : 0ull;
+    };
+    load_entries(rec);
+    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    GwPend P;
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
+        const uint32_t sz = esz & 0xFFFFu; const uint64_t pay = epay;
+        rec = recNext;
+        recNext = load_rec(w + 2 * nWaves);
+        load_entries(rec);
+        const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
+        const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
+        if (H > kGwSmallH || nent > 64u || Rc > kGwRounds || maxWin > tab.gwGap || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
+            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin);
+            ++deferred;
+            continue;
+        }
+        {
+            uint4* z4 = reinterpret_cast<uint4*>(bits);
+#pragma unroll
+            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        gw_fill_rounds(T, lane, 0, Rc, incl - myR, myR, sz, pay);
+        wave_lds_sync();
+        const GwFrame F(maxWin);
+        const uint32_t nl = (Rc + 15u) >> 4;
+        uint4 x[kGwLoads];
+        gw_load_rounds<false>(T, tab.values32, grp, sub4, x, nl);
+        const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
+        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
+        gw_mark_rounds<Bloom>(bits, x, F.A, nl);
+        wave_lds_sync();
+        const bool here = maxWin <= kHashWin;
+        uint32_t n2;
+        if (here) {
+            GwSink S{kept, kKeep, 0u};
+            gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+            gw_take_rounds<Bloom, true>(bits, T, F, S, grp, sub4, x, nl);
+            n2 = S.n2;
+        } else {
+            GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+            gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+            gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
+            n2 = S.n2;
+        }
+        if (here && n2 <= kKeep) {
+            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
+            wave_lds_sync();
+            gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
+                                        reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, work, P);
+            continue;
+        }
+        if (here) {
+            GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
+            gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+            gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
+            n2 = S.n2;
+        }
+        const uint32_t room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed);
+        const bool fallback = n2 > room;
+        if (lane == 0) {
+            if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
+            else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin);
+        }
+        if (!fallback) sliceUsed += n2;
+        wave_lds_sync();
+    }
+    P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
+    if (lane == 0) {
+        if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
+        if (deferred) atomicAdd(&ws.midCount[10], deferred);
+    }
+}
+
+// FUSED filter + counting (the common case of a 150 bp read at RefSeq scale in ONE kernel): gw_filter_kernel's two phases on the read's
+// lists in registers, the kept numbers to LDS instead of the pool, gw_count_read on them right there -- no round trip of the kept
+// numbers through HBM (4.3 GB written and read back per 5 x 10^6 reads), one kernel's launch and tail less.
+// SOFTWARE PIPELINE over a wave's reads: the registers that hold read i's numbers are refilled with read i + 1's, load by load, as
+// phase B of read i is done with them (its round table is made before phase A, in a second table) -- the loads are in flight while
+// read i is counted and have landed when read i + 1's phase A wants them; its entries were fetched during read i - 1, its record
+// before that.  The kernel is bound by VALU issue; what this removes is the time all five waves of a SIMD spent waiting for
+// their lists at once (SQ_WAIT_ANY 50 % in gw_filter_kernel).
+// The slot table of the counting takes the place of the filter bits (4 KB, done with after phase B), the distinct numbers' slots that
+// of the current round table.  A list that keeps more than 256 numbers has its first 256 in LDS and the rest in the wave's pool slice
+// already (the sink switches where the running count passes 256: a scalar branch); the 256 are copied in front of them and the list
+// goes on to the other kernels as from gw_filter_kernel, as do lists with window ranges beyond kHashWin (pool from the start).
+// A record whose read was counted here is marked kGwCounted | n2.
+template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
+__global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
+                                                                          mc_candidate_dev* __restrict__ cands)
+{
+    using Bloom = GwBloom<TLOG2, TLOG2>;
+    constexpr uint32_t kKeep = 512;                                // numbers kept in LDS: the counting takes them when at most 256 are distinct
+    static_assert(Bloom::kWords * 4 >= 512 * 8, "the slot table of the counting takes the place of the filter bits");
+    static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
+    __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
+    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][2][kGwRounds];
+    __shared__ uint32_t keptS[WAVES][kKeep];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* bits = bitS[wave];
+    uint32_t* kept = keptS[wave];
+    const uint32_t total = ws.midCount[9];
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
+    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t nWaves = gridDim.x * WAVES;
+    const uint32_t w0 = blockIdx.x * WAVES + wave;
+    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
+    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
+    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
+    uint64_t sliceUsed = 0;
+    uint32_t deferred = 0;
+    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    const uint32_t* __restrict__ values32 = tab.values32;
+
+    // a read on its way through the pipeline: its record, this lane's entry, the rounds of its lists
+    struct Read { uint32_t q, nent, H, maxWin, sz, Rc, nl; uint64_t pay; bool ok; };
+    uint32_t esz = 0; uint64_t epay = 0;                           // entries of the read whose record is `rec` (fetched one read ahead)
+    auto load_entries = [&](const uint4& r) {
+        const uint32_t ne = (r.z >> 12) <= kGwSmallH ? min(r.z & 0xFFFu, 64u) : 0u;
+        esz = lane < ne ? ws.psize[r.y + lane] : 0u;
+        epay = lane < ne ? ws.ppay[r.y + lane] : 0ull;
+    };
+    // record + entries -> the read, its round table in T (read by the loads after the next wave_lds_sync)
+    auto prepare = [&](const uint4& r, uint64_t* T) -> Read {
+        Read R;
+        R.q = r.x; R.nent = r.z & 0xFFFu; R.H = r.z >> 12; R.maxWin = r.w;
+        R.sz = esz & 0xFFFFu; R.pay = epay;
+        const uint32_t myR = R.sz > 1 ? (R.sz + 15u) >> 4 : 0u;
+        const uint32_t incl = wave_incl_scan_u32(myR, lane);
+        R.Rc = rdlane(incl, 63);
+        R.ok = !(R.H > kGwSmallH || R.nent > 64u || R.Rc > kGwRounds || R.maxWin > tab.gwGap);
+        R.nl = R.ok ? (R.Rc + 15u) >> 4 : 0u;
+        if (R.ok) gw_fill_rounds(T, lane, 0, R.Rc, incl - myR, myR, R.sz, R.pay);
+        return R;
+    };
+    auto load_one = [&](const uint64_t* T, uint32_t u, uint32_t nl) -> uint4 {
+        uint4 v = make_uint4(kGwNone, kGwNone, kGwNone, kGwNone);
+        if (u < nl) {
+            const uint64_t rd = T[u * 16 + grp];
+            if (sub4 < (uint32_t)(rd >> 40)) {
+                const U4 t = *reinterpret_cast<const U4*>(values32 + (rd & 0xFFFFFFFFFFull) + sub4);
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        }
+        return v;
+    };
+
+    uint32_t c = 0;                                                // which of the two round tables is the current read's
+    uint4 x[kGwLoads];
+    uint4 recB = load_rec(w0);
+    load_entries(recB);
+    Read A = prepare(recB, roundS[wave][0]);
+    wave_lds_sync();
+#pragma unroll
+    for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = load_one(roundS[wave][0], u, A.nl);
+    recB = load_rec(w0 + nWaves);
+    load_entries(recB);
+    uint4 recC = load_rec(w0 + 2 * nWaves);
+    GwPend P;
+    for (uint32_t w = w0; w < total; w += nWaves) {
+        uint64_t* T = roundS[wave][c];
+        uint64_t* Tn = roundS[wave][c ^ 1u];
+        {
+            uint4* z4 = reinterpret_cast<uint4*>(bits);
+#pragma unroll
+            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        // the next read: its round table now, its loads as phase B frees the registers; the one after: its entries; the third: its record
+        const Read B = prepare(recB, Tn);
+        recB = recC;
+        load_entries(recB);
+        recC = load_rec(w + 3 * nWaves);
+        const uint32_t q = A.q, maxWin = A.maxWin;
+        if (!A.ok || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
+            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin);
+            ++deferred;
+            wave_lds_sync();
+#pragma unroll
+            for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = load_one(Tn, u, B.nl);
+            A = B; c ^= 1u;
+            continue;
+        }
+        const GwFrame F(maxWin);
+        const uint32_t nl = A.nl;
+        const uint32_t sv = A.sz == 1 ? tab.gw_of(A.pay) : kGwNone;   // single locations live in their buckets in the 8-byte form
+        // ---- A
+        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
+        gw_mark_rounds<Bloom>(bits, x, F.A, nl);
+        wave_lds_sync();
+        // ---- B (+ the next read's loads): into LDS while the counting can follow here and the list is short, else into the pool
+        const bool here = maxWin <= kHashWin;
+        uint32_t* const dstPool = slice + sliceUsed;
+        uint32_t n2;
+        {
+            GwSink S{here ? kept : dstPool, here ? kKeep : 64u, 0u};          // (the single locations: 64 at most)
+            if (here) { GwSink SL{kept, kKeep, 0u}; gw_take<Bloom>(bits, F, SL, sv, sv != kGwNone); n2 = SL.n2; }
+            else { GwSink SG{dstPool, 64u, 0u}; gw_take<Bloom>(bits, F, SG, sv, sv != kGwNone); n2 = SG.n2; }
+            (void)S;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kGwLoads; ++u) {
+            if (u < nl) {
+                const int32_t rem = (int32_t)(uint32_t)(T[u * 16 + grp] >> 40) - (int32_t)sub4;
+                const uint32_t v[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                uint32_t m[4], wd[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t h = Bloom::hash(v[j] >> F.A);
+                    m[j] = Bloom::mask_of(h);
+                    wd[j] = bits[Bloom::twice_index(Bloom::seen_index(h), h)];
+                }
+                uint64_t km[4]; bool kb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool valid = rem > j, hit = (wd[j] & m[j]) == m[j], edge = F.edge(v[j]);
+                    kb[j] = valid & (hit | edge);
+                    km[j] = __ballot(valid) & (__ballot(hit) | __ballot(edge));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t cnt = (uint32_t)__popcll(km[j]);
+                    if (kb[j]) {
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(km[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km[j], n2));
+                        // (n2 and cnt are wave-uniform: the choice of the sink is a scalar branch)
+                        if (!here || n2 >= kKeep) dstPool[at] = v[j];
+                        else if (n2 + cnt <= kKeep) kept[at] = v[j];
+                        else { if (at < kKeep) kept[at] = v[j]; else dstPool[at] = v[j]; }
+                    }
+                    n2 += cnt;
+                }
+            }
+            // (the refill stays BEHIND this load's phase B: hoisted, the scheduler keeps both reads' numbers in registers -- 127 instead of 96)
+            __builtin_amdgcn_sched_barrier(0);
+            x[u] = load_one(Tn, u, B.nl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (here && n2 <= kKeep) {
+            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
+            wave_lds_sync();                                       // every lane's tests of the filter bits before the slot table takes their place
+            gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
+                                        reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, work, P);
+        } else {
+            if (here) {                                            // the first 256 in front of the rest
+#pragma unroll
+                for (uint32_t r = 0; r < kKeep / 64; ++r) dstPool[r * 64 + lane] = kept[r * 64 + lane];
+            }
+            const uint32_t room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed);
+            const bool fallback = n2 > room;                       // (cannot happen with the room checked above; kept for the invariant's sake)
+            if (lane == 0) {
+                if (fallback) { ws.hitScan[q] = A.H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
+                else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin);
+            }
+            if (!fallback) sliceUsed += n2;
+            wave_lds_sync();
+        }
+        A = B; c ^= 1u;
+    }
+    P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
+    if (lane == 0) {
+        if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
+        if (deferred) atomicAdd(&ws.midCount[10], deferred);
+    }
 }
 
 // ================================================================================================
@@ -1211,7 +1565,21 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             case 3: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 3>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
             case 4: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
             case 5: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
-            default: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
+            default:
+                // the filter with the counting of lists up to 256 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
+                // (filterLdsPad: dynamic LDS the kernel never touches -- fewer blocks per CU, room for another stream's kernel beside them)
+                if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 5>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
+                else if (ws.gwFuse == 1) {
+                    if (taxkey) hipLaunchKernelGGL((gw_filter_count_simple_kernel<4, 14, true>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
+                    else hipLaunchKernelGGL((gw_filter_count_simple_kernel<4, 14, false>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
+                } else if (ws.gwFuse == 3) {
+                    if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 5>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
+                    else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 5>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
+                } else {
+                    if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 4>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
+                    else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
+                }
+                break;
         }
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks

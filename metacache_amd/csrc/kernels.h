@@ -164,7 +164,8 @@ struct Workspace {           // device buffers sized by the host for this batch
     void*     scanTmp;       // block sums for the scans
     uint64_t* stats;         // [8]        batch statistics (on demand)
     // host side only: the context's grid tuning switches (mc_set_tuning; 0 = default) -- per context, never process-wide
-    int32_t   filterBpc = 0, countBpc = 0, gwDiag = 0;
+    int32_t   filterLdsPad = 0;
+    int32_t   filterBpc = 0, countBpc = 0, gwDiag = 0, gwFuse = 1;   // gwFuse: gw_filter_count_kernel (1) or gw_filter_kernel + gw_count_kernel (0)
 };
 
 // launchers (all asynchronous on 'st')

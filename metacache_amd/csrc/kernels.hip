@@ -3128,13 +3128,14 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const QueryStat* __res
 
 // the filtered path's records of the batch (list 7): [5] = locations kept by the filter, [6] = reads that took the filtered path |
 // those with more than 512 kept << 32, [7] = reads the first filter kernel left to the second (compact store) | handed to the wave kernel << 32
-__global__ __launch_bounds__(256) void big_stats_kernel(const uint32_t* __restrict__ midCount, const uint4* __restrict__ list7, uint64_t* __restrict__ stats)
+__global__ __launch_bounds__(256) void big_stats_kernel(const uint32_t* __restrict__ midCount, const uint4* __restrict__ list7, uint64_t* __restrict__ stats, uint32_t overMin)
 {
     const uint32_t total = midCount[9];
     unsigned long long kept = 0; uint32_t over = 0, fb = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const uint32_t n2 = list7[i].z;
-        if (n2 >= 0xFFFFFFFEu) ++fb; else { kept += n2; over += n2 > 512u ? 1u : 0u; }
+        uint32_t n2 = list7[i].z;
+        if (n2 >= 0xFFFFFFFEu) ++fb;
+        else { n2 &= 0x7FFFFFFFu; kept += n2; over += n2 > overMin ? 1u : 0u; }   // (bit 31: counted inside the filter kernel, gw_filter_count_kernel)
     }
     atomicAdd((unsigned long long*)&stats[5], kept);
     atomicAdd((unsigned long long*)&stats[6], (unsigned long long)over << 32);
@@ -3148,7 +3149,9 @@ void launch_batch_stats(const Workspace& ws, uint32_t n, hipStream_t st)
     if (n == 0) return;
     uint32_t blocks = min((n + 255u) / 256u, 1024u);
     hipLaunchKernelGGL(batch_stats_kernel, dim3(blocks), dim3(256), 0, st, ws.qstat, ws.winOff, n, ws.stats);
-    if (ws.midCount) hipLaunchKernelGGL(big_stats_kernel, dim3(blocks), dim3(256), 0, st, ws.midCount, reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n, ws.stats);
+    // ("more than 512 kept"; MC_STATS_OVER=n: another threshold, for looking at the distribution of the filtered lists' lengths)
+    static const uint32_t overMin = [] { const char* e = std::getenv("MC_STATS_OVER"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 512u; }();
+    if (ws.midCount) hipLaunchKernelGGL(big_stats_kernel, dim3(blocks), dim3(256), 0, st, ws.midCount, reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n, ws.stats, overMin);
 }
 
 }  // namespace mcamd

@@ -15,4 +15,4 @@ done
 mkdir -p $OUT/trace; echo "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev" > $OUT/trace/trace_kernel_stats.csv
 python $REPO/scripts/summarize_profile.py $TAG $OUT
 find $OUT -name "pmc_counter_collection.csv" -size +20M -delete
-grep -E "^(big_filter|big_filter_2|big_count|big_count_2|probe_cands)," $OUT/summary/${TAG}_pmc_summary.csv
+grep -E "^\"?(gw_filter|gw_count|probe_cands|sketch_lane_kernel)" $OUT/summary/${TAG}_pmc_summary.csv

@@ -14,32 +14,20 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(k):
-    if "query_kernel<true>" in k: return "query_kernel<fused>"
-    if "query_kernel<false>" in k: return "query_kernel<unfused>"
-    if "sketch_probe_lane" in k: return "sketch_probe_lane"
-    if "mid_cands_kernel" in k: return "mid_cands"
-    if "hash_cands_kernel<9" in k: return "hash_cands_256"
-    if "hash_cands_kernel<10" in k: return "hash_cands_512"
-    if "hash_cands_kernel<11" in k: return "hash_cands_1024"
-    if "hash_cands_kernel" in k: return "hash_cands"
-    if "big_cands_kernel<10" in k: return "big_cands"
-    if "big_cands_kernel<11" in k: return "big_cands_2"
-    if "big_filter_kernel" in k:                                  # <WAVES, COMPACT, EPL, ...>: EPL = 1 is the first instance
-        args = k.split("big_filter_kernel<", 1)[1].split(">")[0].split(",") if "big_filter_kernel<" in k else []
-        return "big_filter" if len(args) < 3 or args[2].strip() in ("1u", "1") else "big_filter_2"
-    if "gw_filter_stream_kernel" in k: return "big_filter_2"
-    if "gw_filter_kernel" in k: return "big_filter"
-    if "gw_count_kernel<9" in k: return "big_count"             # filtered lists up to 256 (most reads)
-    if "gw_count_kernel<10" in k: return "big_count_512"
-    if "gw_count_kernel<11" in k: return "big_count_2"
-    if "gw_filter2_kernel" in k: return "big_filter_2rounds"
-    if "gw_compact_kernel" in k: return "gw_compact"
-    if "gw_sort" in k or "gw_sorted" in k: return "gw_sorted_cands"
-    if "big_count_kernel<10" in k: return "big_count"
-    if "big_count_kernel<11" in k: return "big_count_2"
-    for n in ("sketch_lane", "probe_cands", "sort_candidates", "plan_kernel", "scan_block_sums", "scan_of_sums", "scan_apply", "batch_stats", "emit_pairs", "chunk_sketch", "chunk_probe", "chunk_finish", "flag_count", "table_seal", "build_sketch_lanes", "own_count", "own_emit", "union_copy"):
-        if n in k: return n
-    return None
+    """the kernel's own name as rocprofv3 prints it, without return type, namespaces and argument list: gw_filter_count_kernel<4u, 14u, false, 4u>
+    (None for kernels that are not this library's)"""
+    if "mcamd::" not in k:
+        return None
+    k = k.replace("(anonymous namespace)::", "")
+    k = k.split("mcamd::", 1)[1]
+    depth = 0
+    for i, ch in enumerate(k):                                    # cut at the '(' of the argument list (template arguments may hold parentheses)
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0:
+            k = k[:i]
+            break
+    return k.strip()
 
 
 # 1. rocprofv3 --kernel-trace --stats summary, our kernels only (torch's synthetic-data kernels dropped)

@@ -196,14 +196,21 @@ class CpuDb:
             return np.zeros(0, dtype=np.uint64)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n,)).copy()
 
+    def new_handler(self):
+        """a query handler of its own for a caller thread (query(..., handler=h); the default one belongs to the CpuDb: one thread at a time)"""
+        return C.c_void_p(self.ref._f("handler_new")())
+
+    def free_handler(self, h):
+        self.ref._f("handler_free")(h)
+
     def query(self, s1: bytes, s2: bytes = b"", max_cand: int = 2, lowest: int = 0, insert_max: int = 0,
-              sketchlen: int = 0, winlen: int = 0, winstride: int = 0, mode: int = 0):
+              sketchlen: int = 0, winlen: int = 0, winstride: int = 0, mode: int = 0, handler=None):
         """-> (allhits[hit_dtype], tophits[cand_dtype])"""
         s1, s2 = bytes(s1), bytes(s2)
         b1 = C.create_string_buffer(s1, len(s1) + 1)
         b2 = C.create_string_buffer(s2, len(s2) + 1)
         pa, na, pt, nt = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
-        args = [self.h, self._handler, C.cast(b1, C.c_void_p), len(s1), C.cast(b2, C.c_void_p), len(s2),
+        args = [self.h, handler if handler is not None else self._handler, C.cast(b1, C.c_void_p), len(s1), C.cast(b2, C.c_void_p), len(s2),
                 sketchlen, winlen, winstride, max_cand, lowest, insert_max]
         if self.ref.is_oracle:
             args.append(mode)

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""The sharded forms of the path on the REAL ranks of a node, every candidate checked against the oracle.  CHECKER TOOL (loads oracle/
+through tests/cpuref.py; nothing here is measured or shipped).  bench.py runs it after its timed region -- as its own job, with a time
+limit, so that nothing here can hang or fail the headline number -- and puts the JSON it prints into the bench line
+("multi_gpu_selfcheck"); tests/test_gpu_multi_device.py runs the same legs.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/multi_gpu_selfcheck.py
+    python tools/multi_gpu_selfcheck.py            (one rank: every collective still runs, over a process group of one)
+
+Workload: a small cut of bench.py's collection (--scale of the 2000 genera), --reads 150 bp reads + --pairs 2 x 150 bp pairs.
+Legs (reference: gpu_hashmap.cu:1253-1292, query_batch.cu:464-527, :638-652 -- the parts / the sketches travelling between the GPUs):
+  mode_P    the targets dealt out round-robin into N parts, one part per rank (metacache_amd.distributed.classify_partitioned:
+            RCCL all-gather of the per-part top lists + merge) against the per-part ORACLE lists merged in part order
+  mode_K    ONE table key-sharded over the N ranks, 4-byte global window numbers on the wire (classify_key_sharded_device: RCCL
+            all-to-all-v, owner-side filter + counting) against the oracle on the whole cut
+  keyset    rank 0 alone: mc_keyset_open over ALL N devices of the node (C++: ncclCommInitAll, one thread per device, ncclSend /
+            ncclRecv all-to-all-v) on the cut written as database files, same expectation as mode_K
+  partset   rank 0 alone: mc_partset_open over ALL N devices on the 4-part fixture tests/golden/toy32p4 (ncclAllGather + device merge),
+            against the oracle's multi-part semantics on the same files
+Prints ONE JSON line on rank 0 (also to --out).  Exit code 0 when every leg ran and found 0 mismatches."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from metacache_amd import api, synthdb  # noqa: E402
+from metacache_amd.distributed import classify_key_sharded_device, classify_partitioned, gather_candidates, merge_part_candidates  # noqa: E402
+
+READ_LEN, PAD_LEN = 150, 152
+CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)    # = bench.CFG2
+
+
+def mismatches(got: np.ndarray, exp: np.ndarray) -> int:
+    """got / exp: uint32 [n, K, 4] = (tgt, hits, beg, end); entries with hits == 0 on both sides are equal whatever else they hold"""
+    live = (got[:, :, 1] > 0) | (exp[:, :, 1] > 0)
+    return int(((got != exp).any(axis=2) & live).any(axis=1).sum())
+
+
+def cands_array(c, K: int) -> np.ndarray:
+    """api.cand_dtype [n, K] -> uint32 [n, K, 4]"""
+    return np.stack([c["tgt"], c["hits"], c["beg"], c["end"]], axis=-1).astype(np.uint32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=0.01)
+    ap.add_argument("--reads", type=int, default=20_000)
+    ap.add_argument("--pairs", type=int, default=5_000)
+    ap.add_argument("--maxcand", type=int, default=2)
+    ap.add_argument("--legs", default="P,K,keyset,partset")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    legs = set(args.legs.split(","))
+    K = args.maxcand
+    t_start = time.time()
+    out = {"ranks_seen": world, "devices_visible": torch.cuda.device_count(), "cut": None, "legs_run": sorted(legs)}
+
+    c2 = dict(CFG2); c2["genera"] = max(world, 2, int(round(c2["genera"] * args.scale)))
+    spec = synthdb.phylogeny(**c2)
+    gen = synthdb.GpuSynth(local)
+    n1, n2 = args.reads, args.pairs
+    # the same reads on every rank (the generator is a pure function of (collection, seed, index))
+    P1 = synthdb.read_params(spec, 3100)
+    singles = torch.zeros(n1 * PAD_LEN + 16, dtype=torch.uint8, device=dev)
+    gen.reads(spec, P1, 0, n1, singles)
+    P2 = synthdb.read_params(spec, 4100, paired=True)
+    m1 = torch.zeros(n2 * PAD_LEN, dtype=torch.uint8, device=dev)
+    m2 = torch.zeros(n2 * PAD_LEN + 16, dtype=torch.uint8, device=dev)
+    gen.reads(spec, P2, 0, n2, m1, m2)
+    pairs = torch.cat([m1, m2])
+    q1 = torch.zeros((n1, 4), dtype=torch.int32, device=dev)
+    q1[:, 0] = torch.arange(n1, device=dev, dtype=torch.int32) * PAD_LEN; q1[:, 1] = READ_LEN; q1[:, 2] = q1[:, 0]
+    q2 = torch.zeros((n2, 4), dtype=torch.int32, device=dev)
+    q2[:, 0] = torch.arange(n2, device=dev, dtype=torch.int32) * PAD_LEN; q2[:, 1] = READ_LEN
+    q2[:, 2] = q2[:, 0] + n2 * PAD_LEN; q2[:, 3] = READ_LEN
+    torch.cuda.synchronize()
+    out["cut"] = {"targets": len(spec.targets), "Gbp": round(spec.total_bases / 1e9, 3), "reads": n1, "pairs": n2, "scale": args.scale}
+
+    # ---- what the oracle says (rank 0; the other ranks go on to their builds meanwhile)
+    exp = {}
+    s_host = singles[: n1 * PAD_LEN].reshape(n1, PAD_LEN).cpu().numpy()
+    a_host = m1.reshape(n2, PAD_LEN).cpu().numpy()
+    b_host = m2[: n2 * PAD_LEN].reshape(n2, PAD_LEN).cpu().numpy()
+    sreads = [s_host[i, :READ_LEN].tobytes() for i in range(n1)]
+    areads = [a_host[i, :READ_LEN].tobytes() for i in range(n2)]
+    breads = [b_host[i, :READ_LEN].tobytes() for i in range(n2)]
+    if rank == 0:
+        import cpuref
+        import scale_util
+        threads = min(os.cpu_count() or 1, 2 * scale_util.effective_cpus())
+        wanted = scale_util.sample_features(sreads + areads + breads)
+
+        def oracle_lists(sp):
+            odb = scale_util.oracle_database(sp, wanted, threads=threads)
+            seqs = np.ascontiguousarray(s_host[:, :READ_LEN]).reshape(-1)
+            offs = np.arange(n1 + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+            _, c = odb.query_many(seqs, offs, max_cand=K, lowest=0, insert_max=0, threads=threads)
+            e1 = cands_array(c, K)
+            e2 = np.zeros((n2, K, 4), dtype=np.uint32); e2[:, :, 0] = 0xFFFFFFFF
+            for i in range(n2):
+                _, e = odb.query(areads[i], breads[i], K, 0, 0)
+                for j in range(min(K, len(e))):
+                    e2[i, j] = (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"])
+            odb.close()
+            return e1, e2
+        exp["whole"] = oracle_lists(spec)
+        if "P" in legs:
+            # per-part oracle lists (part p = targets p, p + N, ...; target numbers mapped back to the collection's), merged in part order
+            per1, per2 = [], []
+            for p in range(world):
+                sel = np.arange(p, len(spec.targets), world)
+                e1, e2 = oracle_lists(spec.subset(sel))
+                for e in (e1, e2):
+                    live = e[:, :, 1] > 0
+                    e[:, :, 0] = np.where(live, sel[np.minimum(e[:, :, 0], len(sel) - 1)], e[:, :, 0])
+                per1.append(torch.from_numpy(e1.view(np.int32).copy())); per2.append(torch.from_numpy(e2.view(np.int32).copy()))
+            exp["P"] = (merge_part_candidates(per1).numpy().view(np.uint32), merge_part_candidates(per2).numpy().view(np.uint32))
+        out["oracle_s"] = round(time.time() - t_start, 1)
+
+    mw1 = 2 + READ_LEN // 112                                    # candidate_structs.hpp:143-145 at the default window stride
+    mw2 = 2 + 2 * READ_LEN // 112
+
+    # ---- mode P: one part per rank
+    if "P" in legs:
+        t0 = time.time()
+        sel = np.arange(rank, len(spec.targets), world)
+        dbp, _ = synthdb.build_database(spec.subset(sel), device=local, shards=1, max_candidates=K, max_load_factor=0.3)
+        sel_t = torch.from_numpy(sel).to(dev).to(torch.int32)
+        bad = 0
+        for idx, (seq, qi, n, nch, mw) in enumerate(((singles, q1, n1, n1 * PAD_LEN, mw1), (pairs, q2, n2, 2 * n2 * PAD_LEN, mw2))):
+            res = dbp.query_device(seq.data_ptr(), qi.data_ptr(), n, nch, max_win_uniform=mw)
+            c = torch.zeros((n, K, 4), dtype=torch.int32, device=dev)
+            dbp.copy_results(c.data_ptr(), res.cands, n * K * 16); dbp.synchronize()
+            live = c[:, :, 1] > 0
+            c[:, :, 0] = torch.where(live, sel_t[c[:, :, 0].clamp(min=0, max=sel_t.numel() - 1).long()], c[:, :, 0])
+            merged = classify_partitioned(c)                     # RCCL all-gather of the per-part lists + merge in part order
+            torch.cuda.synchronize()
+            if rank == 0:
+                bad += mismatches(merged.cpu().numpy().view(np.uint32), exp["P"][idx])
+        dbp.close()
+        out["mode_P"] = bad if rank == 0 else None
+        out["mode_P_s"] = round(time.time() - t0, 1)
+
+    # ---- mode K: one table key-sharded over the ranks, 4-byte numbers on the wire
+    if "K" in legs:
+        t0 = time.time()
+        dbk, _ = synthdb.build_database(spec, device=local, shards=1, key_shard=(rank, world), max_candidates=K, max_load_factor=0.3)
+        numbers_wire = dbk.table_layout()["location_bytes"] == 4
+        bad, sent = 0, 0
+        for idx, (seq, qi, n, nch, mw) in enumerate(((singles, q1, n1, n1 * PAD_LEN, mw1), (pairs, q2, n2, 2 * n2 * PAD_LEN, mw2))):
+            res = dbk.query_device(seq.data_ptr(), qi.data_ptr(), n, nch, max_win_uniform=mw, want_partial_hits=not numbers_wire,
+                                   want_partial_numbers=numbers_wire)
+            if numbers_wire:
+                part, _ = dbk.partial_numbers(res, n, [0, n])       # what this shard puts on the wire for the batch
+                sent += int(part.total)
+            mine = classify_key_sharded_device(dbk, res, n, K, mw, wire=4)     # RCCL all-to-all-v, owner side on this rank's read shard
+            parts = gather_candidates(mine)
+            torch.cuda.synchronize()
+            if rank == 0:
+                bad += mismatches(torch.cat(parts, dim=0).cpu().numpy().view(np.uint32), exp["whole"][idx])
+        dbk.close()
+        tsent = torch.tensor([sent], dtype=torch.int64, device=dev)
+        dist.all_reduce(tsent)
+        out["mode_K"] = bad if rank == 0 else None
+        out["mode_K_wire"] = 4 if numbers_wire else 8
+        out["wire_bytes_per_read"] = round((4 if numbers_wire else 8) * int(tsent.item()) / (n1 + 2 * n2), 1)
+        out["mode_K_s"] = round(time.time() - t0, 1)
+
+    dist.barrier()
+    torch.cuda.synchronize()
+    # ---- the C++ drivers over ALL devices of the node, from rank 0's process (the other ranks have released their tables)
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev)) if world > 1 else [local]
+    if rank == 0 and "keyset" in legs:
+        t0 = time.time()
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        name = os.path.join(shm, f"mcselfcheck_{os.getpid()}")
+        try:
+            if world == 1:
+                os.environ["MC_KEYSET_RCCL"] = "1"               # one device: the same ncclSend / ncclRecv round with a single rank
+            dbw, _ = synthdb.build_database(spec, device=local, shards=1, max_candidates=K, max_load_factor=0.3, write_to=name)
+            dbw.close()
+            ks = api.KeySet(name, shards=len(devices), devices=devices, max_candidates=K, slot_max_queries=8192, slot_max_chars=8192 * 320)
+            info = ks.info()
+            g1 = cands_array(ks.classify(sreads), K)
+            g2 = cands_array(ks.classify(areads, breads, insert_max=0), K)
+            info2 = ks.info()
+            ks.close()
+            out["keyset"] = mismatches(g1, exp["whole"][0]) + mismatches(g2, exp["whole"][1])
+            out["keyset_devices"] = info["devices"]; out["keyset_rccl"] = info["rccl"]; out["keyset_batches"] = info2["batches"]
+            out["keyset_wire_bytes_per_read"] = round(4.0 * info2["numbers_sent"] / (n1 + 2 * n2), 1)
+        except Exception as e:                                   # noqa: BLE001  (reported in the line, never fatal for the caller)
+            out["keyset"] = f"error: {e}"
+        finally:
+            for ext in (".meta", ".cache0"):
+                if os.path.exists(name + ext):
+                    os.remove(name + ext)
+        out["keyset_s"] = round(time.time() - t0, 1)
+    if rank == 0 and "partset" in legs:
+        t0 = time.time()
+        try:
+            import cpuref
+            if world == 1:
+                os.environ["MC_PARTSET_RCCL"] = "1"
+            gold = os.path.join(ROOT, "tests", "golden")
+            z = np.load(os.path.join(gold, "toy_reads.npz"))
+            off = z["single_off"]
+            treads = [z["single"][int(off[i]):int(off[i + 1])].tobytes() for i in range(min(1500, len(off) - 1))]
+            name = os.path.join(gold, "toy32p4")
+            odb = cpuref.oracle().open(name)
+            ps = api.PartSet(name, resident=min(4, max(2, len(devices))), devices=devices, max_candidates=K, slot_max_queries=500, slot_max_chars=1 << 17)
+            info = ps.info()
+            got = ps.classify(treads)
+            bad = 0
+            for i, s in enumerate(treads):
+                _, c = odb.query(s, b"", K, 0, 0, mode=1)
+                for j in range(K):
+                    e = (int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])) if j < len(c) else None
+                    g = got[i][j]
+                    bad += int((int(g["hits"]) != 0) if e is None else ((int(g["tgt"]), int(g["hits"]), int(g["beg"]), int(g["end"])) != e))
+            ps.close(); odb.close()
+            out["partset"] = bad
+            out["partset_devices"] = info["devices"]; out["partset_groups"] = info["groups"]
+        except Exception as e:                                   # noqa: BLE001
+            out["partset"] = f"error: {e}"
+        out["partset_s"] = round(time.time() - t0, 1)
+    dist.barrier()
+    ok = True
+    if rank == 0:
+        out["seconds"] = round(time.time() - t_start, 1)
+        for k in ("mode_P", "mode_K", "keyset", "partset"):
+            if (k if k in ("keyset", "partset") else k[-1]) in legs:
+                ok = ok and out.get(k) == 0
+        out["ok"] = ok
+        line = json.dumps(out)
+        if args.out:
+            with open(args.out, "w") as f:
+                f.write(line + "\n")
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
