@@ -265,6 +265,15 @@ int  mc_partset_info(const mc_partset* ps, uint64_t info[6]);
  * out[n][max_candidates] in HOST memory; insert_max as -insertsize (maxWindowsInRange, candidate_structs.hpp:143-145) */
 int  mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n,
                          int lowest_rank, uint64_t insert_max, mc_candidate* out);
+/* The same in the caller's hands, for reads that STREAM (mcq -resident-parts): mc_partset_select_group makes part group g resident (groups in
+ * order 0, 1, ...: group g + 1 loads behind group g's queries, every part by its own reader threads, one loading thread per device --
+ * database.cpp:203-226 reads every part in a thread of its own); mc_partset_classify_resident takes a batch of reads through the parts of
+ * the resident group only and merges their lists behind the list the earlier groups left in inout (has_prior != 0) -- the caller keeps
+ * 16 bytes x max_candidates per read between the groups, nothing else.  mc_partset_load_bytes: bytes of .cache files the group loads read. */
+int  mc_partset_select_group(mc_partset* ps, uint32_t group);
+int  mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n,
+                                  int lowest_rank, uint64_t insert_max, int has_prior, mc_candidate* inout);
+int  mc_partset_load_bytes(const mc_partset* ps, uint64_t* bytes);
 const char* mc_partset_last_error(const mc_partset* ps);
 
 /* Mode K.  Owner shard of a feature (independent of the table's own bucket hash). */

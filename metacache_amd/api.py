@@ -64,7 +64,7 @@ class McDeviceResults(C.Structure):
 
 
 EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
-           "mc_partset_info", "mc_partset_classify", "mc_partset_last_error",
+           "mc_partset_info", "mc_partset_classify", "mc_partset_last_error", "mc_partset_select_group", "mc_partset_classify_resident", "mc_partset_load_bytes",
            "mc_partial_numbers", "mc_candidates_from_partial_numbers", "mc_owner_stats", "mc_keyset_open", "mc_keyset_close", "mc_keyset_info", "mc_keyset_classify", "mc_keyset_last_error",
            "mc_open_database", "mc_open_metadata", "mc_load_stats", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
            "mc_batch_add", "mc_batch_add_bulk", "mc_batch_submit", "mc_batch_wait", "mc_batch_clear", "mc_query_device", "mc_query_finish", "mc_query_wait", "mc_synchronize",
@@ -418,7 +418,31 @@ class PartSet:
     def info(self) -> dict:
         a = (C.c_uint64 * 6)()
         lib().mc_partset_info(self.h, a)
-        return dict(parts=int(a[0]), resident=int(a[1]), groups=int(a[2]), devices=int(a[3]), load_s=a[4] / 1e9, wait_s=a[5] / 1e9)
+        nb = C.c_uint64()
+        lib().mc_partset_load_bytes(self.h, C.byref(nb))
+        return dict(parts=int(a[0]), resident=int(a[1]), groups=int(a[2]), devices=int(a[3]), load_s=a[4] / 1e9, wait_s=a[5] / 1e9, load_bytes=int(nb.value))
+
+    def select_group(self, g: int):
+        L = lib()
+        L.mc_partset_select_group.argtypes = [C.c_void_p, C.c_uint32]
+        rc = L.mc_partset_select_group(self.h, g)
+        if rc != 0:
+            raise McError(f"mc_partset_select_group: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
+
+    def classify_resident(self, reads, mates, out: np.ndarray, has_prior: bool, lowest: int = 0, insert_max: int = 0):
+        """one batch through the resident group's parts; out (cand_dtype [n, K]) holds the earlier groups' lists (has_prior) and receives the merged ones"""
+        def pack(rs):
+            offs = np.zeros(len(rs) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(r) for r in rs])
+            return np.frombuffer(b"".join(rs) + b"\0", dtype=np.uint8), offs
+        s1, o1 = pack(reads)
+        s2, o2 = pack(mates) if mates is not None else (None, None)
+        L = lib()
+        L.mc_partset_classify_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+        rc = L.mc_partset_classify_resident(self.h, s1.ctypes.data, o1.ctypes.data, s2.ctypes.data if s2 is not None else None,
+                                            o2.ctypes.data if o2 is not None else None, len(reads), lowest, insert_max, int(has_prior), out.ctypes.data)
+        if rc != 0:
+            raise McError(f"mc_partset_classify_resident: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
 
     def classify(self, reads, mates=None, lowest: int = 0, insert_max: int = 0) -> np.ndarray:
         """reads / mates: lists of bytes -> cand_dtype [n, max_candidates]"""

@@ -419,7 +419,8 @@ int mc_build_add_existing_target(mc_builder* b, const char* name, int64_t parent
 {
     if (!b) return MC_ERR_INVALID;
     if (b->finished) { b->err = "builder is finished"; return MC_ERR_STATE; }
-    if (!b->targets.empty() && !b->targets.back().existing) { b->err = "existing targets go in before new ones"; return MC_ERR_STATE; }
+    // (may stand between new targets: a target's number is its place in the order of the add calls -- one PART of a partitioned database
+    // names the other parts' targets this way; it is the existing LOCATION LISTS that must precede everything sketched, mc_build_add_locations)
     TargetRec r;
     r.name = name ? name : ""; r.filename = filename ? filename : ""; r.parent = parentTaxid < 1 ? 0 : parentTaxid;
     r.windows = windows; r.fileIndex = fileIndex; r.existing = true;

@@ -6,6 +6,9 @@
 // ~10^4 of its 3 x 10^4 locations; 2 Gbases/s are 2 x 10^9 keys per second, a tenth of what the sort delivers).
 #include "device_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -16,15 +19,54 @@ namespace mcamd {
 namespace {
 
 // segment i = the list of the i-th record of the sorted class (ws.sideList[3], longest list first: launch_gw_order)
+constexpr uint32_t kGwLdsSortMax = 16384;                 // longest list gw_lds_sort_kernel takes (64 KB of LDS)
 struct SegOffset {
-    const uint4* rec; const uint32_t* side; const uint32_t* midCount; uint32_t end;
+    const uint4* rec; const uint32_t* side; const uint32_t* midCount; uint32_t end, minLen;   // lists of up to minLen numbers are somebody else's: empty segments
     __device__ uint32_t operator()(uint32_t i) const
     {
         if (i >= midCount[13]) return 0u;
         const uint4 r = rec[side[i]];
-        return r.y + (end ? r.z : 0u);
+        return r.y + ((end && r.z > minLen) ? r.z : 0u);
     }
 };
+
+// ---- the library's place for everything but the longest lists: ONE block sorts ONE list in LDS -- the list comes in from HBM once and goes
+// out once (rocPRIM's segmented sort takes a block of 256 threads per list too, but lists beyond 4 352 numbers go through HBM radix pass
+// by radix pass: 5.2 of 17.3 ms per step on configs[4]'s reads in round 3).  A bitonic network on the next power of two (padded with
+// 0xFFFFFFFF, never a stored number): n log^2 n / 4 compare-exchanges with nothing but LDS and barriers in between -- for lists of
+// 10^3 .. 10^4 numbers about the instruction count of a block radix sort's eight 4-bit passes, without its scans and scatters.
+// The last strides of every merge stay inside a thread's own pair of elements' wave: the loop is the textbook one.
+template <uint32_t THREADS, uint32_t CAP>
+__global__ __launch_bounds__(THREADS) void gw_lds_sort_kernel(Workspace ws, uint32_t n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                              uint32_t minLen, uint32_t maxLen)
+{
+    __shared__ uint32_t s[CAP];
+    const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
+    const uint32_t* __restrict__ side = ws.sideList + (size_t)3 * n;
+    const uint32_t nseg = ws.midCount[13];
+    for (uint32_t i = blockIdx.x; i < nseg; i += gridDim.x) {
+        const uint4 r = rec[side[i]];
+        const uint32_t len = r.z;
+        if (len <= minLen || len > maxLen) continue;              // (block-uniform: another instance's list, or the library's)
+        uint32_t M = 64;
+        while (M < len) M <<= 1;
+        for (uint32_t t = threadIdx.x; t < M; t += THREADS) s[t] = t < len ? in[r.y + t] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t k = 2; k <= M; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < M / 2; t += THREADS) {
+                    const uint32_t lo = 2u * t - (t & (j - 1u));  // the pair (lo, lo + j): t with a zero bit put in at j's place
+                    const uint32_t a = s[lo], b = s[lo + j];
+                    const bool up = (lo & k) == 0u;
+                    if ((a > b) == up) { s[lo] = b; s[lo + j] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t t = threadIdx.x; t < len; t += THREADS) out[r.y + t] = s[t];
+        __syncthreads();
+    }
+}
 
 // keys of the ordering: the work a record stands for -- list 3 (sorted class): the numbers its filtered list holds; list 0 (reads of
 // gw_filter_stream_kernel): the read's locations.  Entries beyond the list's length (device-side count) get key 0 and end up last.
@@ -66,9 +108,17 @@ int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_
 {
     const uint4* rec = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
     const uint32_t* side = ws.sideList + (size_t)3 * n;
+    // lists up to kGwLdsSortMax numbers: our own block sort in LDS (two instances by length); the library keeps the longer ones -- its
+    // segments of the others are empty
+    static const bool own = [] { const char* e = std::getenv("MC_GW_OWN_SORT"); return !(e && e[0] == '0'); }();
+    const uint32_t libMin = own ? kGwLdsSortMax : 0u;
+    if (temp && own && nseg) {
+        hipLaunchKernelGGL((gw_lds_sort_kernel<256, 2048>), dim3(std::min<uint32_t>(nseg, 256u * 16u)), dim3(256), 0, st, ws, n, in, out, 0u, 2048u);
+        hipLaunchKernelGGL((gw_lds_sort_kernel<1024, kGwLdsSortMax>), dim3(std::min<uint32_t>(nseg, 256u * 4u)), dim3(1024), 0, st, ws, n, in, out, 2048u, kGwLdsSortMax);
+    }
     auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
-    auto beg = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u});
-    auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u});
+    auto beg = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u, libMin});
+    auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u, libMin});
     // (the library's default configuration: a block of 256 threads sorts up to 4 352 numbers in registers and LDS, longer lists in passes
     // through HBM.  Larger single-block limits measured worse on configs[4]'s reads at full scale: 1024 x 8: 6.0 ms, 256 x 32: 7.0 ms, default 5.2)
     return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull), nseg, beg, end, 0u, endBit, st);

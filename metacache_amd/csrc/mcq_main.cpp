@@ -812,72 +812,14 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             std::lock_guard<std::mutex> l(errMtx);
             collect(A);
         };
-        // -resident-parts / -gpus: the database's parts are queried group by group (mc_partset_classify loops groups outside, reads
-        // inside), so ALL reads are collected first, classified in one call, then classified / printed batch by batch as above
-        auto work_partset = [&]() {
-            struct Meta { uint64_t id; std::string header; bool empty; size_t batch; bool skipped; };
-            std::vector<Meta> metas;
-            std::string seq1, seq2, scratch1, scratch2;
-            std::vector<uint64_t> off1{0}, off2{0};
-            const bool paired = o.pairing != Options::unpaired;
-            for (size_t b = 0; b < batches.size(); ++b) {
-                const Batch& B = batches[b];
-                for (size_t q = B.qBeg; q < B.qEnd; ++q) {
-                    View h1, s1, h2, s2;
-                    const size_t qi = B.sel ? (size_t)(*B.sel)[q] : q;
-                    if (o.pairing == Options::sequences) {
-                        files[B.f1]->record(2 * qi, h1, s1, scratch1);
-                        if (!(B.halfLast && q + 1 == B.qEnd)) files[B.f1]->record(2 * qi + 1, h2, s2, scratch2);
-                    } else {
-                        files[B.f1]->record(qi, h1, s1, scratch1);
-                        if (o.pairing == Options::files) files[B.f2]->record(qi, h2, s2, scratch2);
-                    }
-                    const bool halfPair = B.halfLast && q + 1 == B.qEnd;
-                    const bool tooBig = s1.n + s2.n + 8 > cfg.slot_max_chars;
-                    if (tooBig) { std::cerr << "query batch is too small for a single read!\n"; continue; }
-                    metas.push_back(Meta{B.idBase + qi + (halfPair ? 0 : 1), std::string(h1.p, h1.n), h1.empty() || s1.empty(), b, false});
-                    seq1.append(s1.p, s1.n); off1.push_back(seq1.size());
-                    if (paired) { seq2.append(s2.p, s2.n); off2.push_back(seq2.size()); }
-                }
-            }
-            const size_t n = metas.size();
-            const uint32_t K = cfg.max_candidates;
-            std::vector<mc_candidate> all(n * K);
-            seq1.push_back('\0'); seq2.push_back('\0');
-            if (n && mc_partset_classify(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
-                                         o.insertMax, all.data()) != MC_OK)
-                throw std::runtime_error(mc_partset_last_error(S.partset));
-            Acc A;
-            std::vector<Cand> cands;
-            std::ostringstream out;
-            size_t i = 0;
-            for (size_t b = 0; b < batches.size(); ++b) {
-                out.str(std::string());
-                out << batches[b].prefix;
-                for (; i < n && metas[i].batch == b; ++i) {
-                    const Meta& m = metas[i];
-                    if (m.empty) continue;
-                    cands.clear();
-                    for (uint32_t j = 0; j < K; ++j) {
-                        const mc_candidate& c = all[i * K + j];
-                        if (c.hits == 0) break;
-                        Cand x{c.tgt, c.hits, c.beg, c.end, 0};
-                        if (c.tgt < tx.numTargets) {
-                            const uint32_t* lin = tx.targetLineages + (size_t)c.tgt * kNumRanks;
-                            if (o.lowest > 0) { for (int rk = o.lowest; rk < kNumRanks; ++rk) if (lin[rk]) { x.tax = lin[rk]; break; } }
-                            else x.tax = lin[0];
-                        }
-                        cands.push_back(x);
-                    }
-                    emit(A, out, m.id, View{m.header.data(), m.header.size()}, cands, nullptr, 0);
-                }
-                deliver(b, out.str());
-            }
-            collect(A);
-        };
-        // -shard keys: no loop over part groups, so the batches stream -- worker threads cut the records out of the files side by side,
-        // one at a time hands its batch to mc_keyset_classify (the key set takes one call at a time), then formats its lines
+        // -shard keys / -resident-parts / -gpus: the batches STREAM -- worker threads cut the records out of the files side by side, one at a
+        // time hands its batch to mc_keyset_classify / mc_partset_classify_resident (the sets take one call at a time), then formats
+        // its lines.  A partitioned database is gone through part group by part group (mc_partset_select_group: the next group loads
+        // behind this one's queries); between the groups a batch keeps nothing but its reads' candidate lists (`carried`), the last
+        // group's pass prints.  (Round 3 collected all reads on one thread first: 2.5 s per 10^7 reads.)
         std::mutex ksMtx;
+        std::deque<std::vector<mc_candidate>> carried;                          // [batch]; grown under batchMtx when a worker takes a batch
+        bool setHasPrior = false, setLastPass = true;                           // the part group pass the workers are in
         auto work_keyset = [&](unsigned) {
             struct Meta { uint64_t id; View header; bool empty; };
             std::vector<Meta> metas;
@@ -893,12 +835,14 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             for (;;) {
                 size_t b;
                 const Batch* Bp = nullptr;
+                std::vector<mc_candidate>* slot = nullptr;
                 {
                     std::unique_lock<std::mutex> l(batchMtx);
                     batchCv.wait(l, [&] { return failed || nextBatch < batches.size() || !producing; });
                     if (failed || nextBatch >= batches.size()) break;
                     b = nextBatch++;
                     Bp = &batches[b];
+                    if (S.partset) { if (carried.size() <= b) carried.resize(b + 1); slot = &carried[b]; }   // (a deque: the element stays where it is)
                 }
                 const Batch& B = *Bp;
                 metas.clear(); seq1.clear(); seq2.clear(); off1.assign(1, 0); off2.assign(1, 0);
@@ -919,13 +863,19 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     if (paired) { seq2.append(s2.p, s2.n); off2.push_back(seq2.size()); }
                 }
                 const size_t n = metas.size();
-                all.assign(n * K, mc_candidate{});
+                if (slot && setHasPrior) all.swap(*slot);              // what the earlier part groups left for this batch's reads
+                else all.assign(n * K, mc_candidate{});
+                if (all.size() != n * K) { fail("internal: a batch changed between two part groups"); break; }
                 seq1.push_back('\0'); seq2.push_back('\0');
                 if (n) {
                     std::lock_guard<std::mutex> l(ksMtx);
-                    if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
-                                           o.insertMax, all.data()) != MC_OK) { fail(mc_keyset_last_error(S.keyset)); break; }
+                    if (S.keyset) {
+                        if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                               o.insertMax, all.data()) != MC_OK) { fail(mc_keyset_last_error(S.keyset)); break; }
+                    } else if (mc_partset_classify_resident(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n,
+                                                            o.lowest, o.insertMax, setHasPrior ? 1 : 0, all.data()) != MC_OK) { fail(mc_partset_last_error(S.partset)); break; }
                 }
+                if (!setLastPass) { slot->swap(all); continue; }            // more part groups to come: nothing is printed yet
                 out.str(std::string());
                 out << B.prefix;
                 for (size_t i = 0; i < n; ++i) {
@@ -960,9 +910,22 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             batchCv.notify_all();
             producer.join();
         } else if (S.partset) {
-            produce();                                                           // (all batches known first: no overlap to win here)
-            if (!producerError.empty()) throw std::runtime_error(producerError);
-            work_partset();
+            uint64_t pinfo[6] = {0, 0, 1, 0, 0, 0};
+            mc_partset_info(S.partset, pinfo);
+            const uint32_t groups = (uint32_t)std::max<uint64_t>(pinfo[2], 1);
+            std::thread producer(produce);                                       // (the first pass streams behind the files' indexing)
+            for (uint32_t g = 0; g < groups && !failed; ++g) {
+                if (mc_partset_select_group(S.partset, g) != MC_OK) { std::lock_guard<std::mutex> l(errMtx); if (!failed.exchange(true)) firstError = mc_partset_last_error(S.partset); break; }
+                { std::lock_guard<std::mutex> l(batchMtx); nextBatch = 0; }
+                setHasPrior = g > 0; setLastPass = g + 1 == groups;
+                std::vector<std::thread> pool;
+                for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work_keyset, w);
+                work_keyset(0);
+                for (auto& t : pool) t.join();
+            }
+            { std::lock_guard<std::mutex> l(batchMtx); }
+            batchCv.notify_all();
+            producer.join();
         } else {
             std::thread producer(produce);
             std::vector<std::thread> pool;

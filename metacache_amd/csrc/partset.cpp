@@ -17,6 +17,7 @@
 #include "rccl_dl.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -54,7 +55,9 @@ struct mc_partset {
     int loaderRc = MC_OK;
     std::string loaderErr;
     size_t maxQ = 0, maxChars = 0;
+    std::vector<uint8_t> hseq; std::vector<uint32_t> hq, hmw;   // host staging of a batch
     uint64_t loadNs = 0, waitNs = 0;   // time the loader spent / the queries waited for it
+    std::atomic<uint64_t> loadBytes{0}; // bytes of .cache files read by the group loads
     bool rccl = false;                 // several devices (or MC_PARTSET_RCCL=1: the same calls with a single rank, tests): gather over RCCL
 };
 
@@ -66,19 +69,36 @@ uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint
 
 void close_group(std::vector<mc_ctx*>& g) { for (mc_ctx* c : g) if (c) mc_destroy(c); g.clear(); }
 
-// opens the parts [first, first + count) as one context each, part p on device devices[(p - first) % ndev]
+// opens the parts [first, first + count) as one context each, part p on device devices[(p - first) % ndev] -- one thread per DEVICE (its
+// parts one after the other; every load has its reader threads, its own copy stream and its device's PCIe link: dbload.cpp), as the
+// reference reads every part in a thread of its own (database.cpp:203-226)
 int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::string& err)
 {
     const uint32_t count = std::min(ps->resident, ps->nparts - first);
+    const uint32_t nd = (uint32_t)ps->devices.size();
     out.assign(count, nullptr);
-    for (uint32_t i = 0; i < count; ++i) {
-        mc_config c = ps->cfg;
-        c.single_part = (int32_t)(first + i);
-        c.device = ps->devices[i % ps->devices.size()];
-        c.num_slots = 1; c.copy_allhits = 0;
-        const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
-        if (rc != MC_OK) { err = mc_last_error(nullptr); close_group(out); return rc; }
+    std::vector<int> rcs(nd, MC_OK);
+    std::vector<std::string> errs(nd);
+    auto load_device = [&](uint32_t d) {
+        for (uint32_t i = d; i < count; i += nd) {
+            mc_config c = ps->cfg;
+            c.single_part = (int32_t)(first + i);
+            c.device = ps->devices[d];
+            c.num_slots = 1; c.copy_allhits = 0;
+            const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
+            if (rc != MC_OK) { rcs[d] = rc; errs[d] = mc_last_error(nullptr); return; }
+            uint64_t st[4] = {0, 0, 0, 0};
+            if (mc_load_stats(out[i], st) == MC_OK) ps->loadBytes += st[0];
+        }
+    };
+    if (std::min(nd, count) <= 1) load_device(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t d = 0; d < std::min(nd, count); ++d) th.emplace_back(load_device, d);
+        for (auto& t : th) t.join();
     }
+    for (uint32_t d = 0; d < nd; ++d)
+        if (rcs[d]) { err = errs[d]; close_group(out); return rcs[d]; }
     return MC_OK;
 }
 
@@ -157,7 +177,9 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     }
     if (!ok) { mc_partset_close(ps); return ps_fail(nullptr, MC_ERR_NOMEM, "mc_partset_open: cannot allocate the batch buffers"); }
     std::string err;
+    const uint64_t tl = now_ns();
     rc = open_group(ps, 0, ps->cur, err);
+    ps->loadNs += now_ns() - tl;
     if (rc) { mc_partset_close(ps); return ps_fail(nullptr, rc, err); }
     ps->curFirst = 0;
     *out = ps;
@@ -188,16 +210,57 @@ int mc_partset_info(const mc_partset* ps, uint64_t info[6])
     return MC_OK;
 }
 
-// All n reads (pairs: mate i = seqs2 + offs2[i] .. offs2[i + 1]; seqs2 == NULL: single reads) against every part of the database.
-// out: [n][max_candidates] in host memory.
-int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n, int lowestRank,
-                        uint64_t insertMax, mc_candidate* out)
+int mc_partset_load_bytes(const mc_partset* ps, uint64_t* bytes)
+{
+    if (!ps || !bytes) return MC_ERR_INVALID;
+    *bytes = ps->loadBytes.load();
+    return MC_OK;
+}
+
+// Makes part group g (parts g * resident ...) the resident one: waits for the loader if it is loading exactly that group, else opens it;
+// then starts loading group g + 1 behind the caller's queries.  Going through the groups in order 0, 1, ... is what overlaps every load
+// with the previous group's queries.
+int mc_partset_select_group(mc_partset* ps, uint32_t g)
+{
+    if (!ps) return MC_ERR_INVALID;
+    const uint32_t first = g * ps->resident;
+    if (first >= ps->nparts) return ps_fail(ps, MC_ERR_INVALID, "mc_partset_select_group: no such part group");
+    if (ps->curFirst != first || ps->cur.empty()) {
+        const uint64_t t0 = now_ns();
+        if (ps->loader.joinable()) ps->loader.join();
+        ps->waitNs += now_ns() - t0;
+        if (ps->nextFirst == first && !ps->next.empty() && ps->loaderRc == MC_OK) {
+            close_group(ps->cur);
+            ps->cur.swap(ps->next);
+        } else {
+            if (ps->nextFirst == first && ps->loaderRc != MC_OK) { close_group(ps->next); return ps_fail(ps, ps->loaderRc, ps->loaderErr); }
+            close_group(ps->next);
+            close_group(ps->cur);
+            std::string err;
+            const uint64_t t1 = now_ns();
+            const int rc = open_group(ps, first, ps->cur, err);
+            ps->loadNs += now_ns() - t1; ps->waitNs += now_ns() - t1;
+            if (rc) return ps_fail(ps, rc, err);
+        }
+        ps->curFirst = first;
+    }
+    // the next group loads behind this group's queries (a loader that is already at it is left alone)
+    const uint32_t nf = first + ps->resident;
+    if (nf < ps->nparts && !(ps->loader.joinable() && ps->nextFirst == nf) && !(ps->nextFirst == nf && !ps->next.empty())) start_loader(ps, nf);
+    return MC_OK;
+}
+
+// n reads (pairs: mate i = seqs2 + offs2[i] .. offs2[i + 1]; seqs2 == NULL: single reads) against the parts of the RESIDENT group only.
+// inout [n][max_candidates] (host): with hasPrior the list the earlier groups left for these reads -- it leads the merge, as if its parts had
+// been queried before this group's (candidate_generation.hpp:172-231) --, on return the merged list.  Callers stream their batches through
+// group after group and keep 16 bytes x max_candidates per read between groups (mcq -resident-parts; mc_partset_classify below).
+int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n, int lowestRank,
+                                 uint64_t insertMax, int hasPrior, mc_candidate* out)
 {
     if (!ps || !seqs || !offs || !out || (seqs2 && !offs2)) return MC_ERR_INVALID;
+    if (ps->cur.empty()) return ps_fail(ps, MC_ERR_STATE, "mc_partset_classify_resident: no part group is resident (mc_partset_select_group)");
     const uint32_t K = ps->K, nd = (uint32_t)ps->devices.size();
     const size_t listBytes = ps->maxQ * K * sizeof(mc_candidate);
-    std::memset(out, 0, n * K * sizeof(mc_candidate));
-    for (uint64_t i = 0; i < n * K; ++i) out[i].tgt = 0xFFFFFFFFu;
     // the batches: as many reads as fit the slot limits (a sequence starts 4-byte aligned, mc_batch_add)
     struct Batch { uint64_t first, count, chars; };
     std::vector<Batch> batches;
@@ -211,104 +274,100 @@ int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, 
         if (b.count == 0) return ps_fail(ps, MC_ERR_INVALID, "mc_partset_classify: a read is longer than slot_max_chars");
         batches.push_back(b);
     }
-    std::vector<uint8_t> hseq(ps->maxChars + 64);
-    std::vector<uint32_t> hq(ps->maxQ * 4), hmw(ps->maxQ);
-    // an earlier call that ended in an error may have left the loader running and a half-used group behind: settle that first
-    if (ps->loader.joinable()) ps->loader.join();
-    close_group(ps->next);
-    // back to the first group if an earlier call left another one resident
-    if (ps->curFirst != 0) {
-        close_group(ps->cur);
-        std::string err;
-        int rc = open_group(ps, 0, ps->cur, err);
-        if (rc) return ps_fail(ps, rc, err);
-        ps->curFirst = 0;
-    }
-    for (uint32_t first = 0; first < ps->nparts; first += ps->resident) {
-        if (first != ps->curFirst) {                                // the loader has had the whole previous group's queries to get here
-            const uint64_t t0 = now_ns();
-            if (ps->loader.joinable()) ps->loader.join();
-            ps->waitNs += now_ns() - t0;
-            if (ps->loaderRc) return ps_fail(ps, ps->loaderRc, ps->loaderErr);
-            close_group(ps->cur);
-            ps->cur.swap(ps->next);
-            ps->curFirst = first;
+    std::vector<uint8_t>& hseq = ps->hseq;
+    std::vector<uint32_t>& hq = ps->hq; std::vector<uint32_t>& hmw = ps->hmw;
+    hseq.resize(ps->maxChars + 64); hq.resize(ps->maxQ * 4); hmw.resize(ps->maxQ);
+    const uint32_t np = (uint32_t)ps->cur.size();
+    for (const Batch& B : batches) {
+        const uint32_t m = (uint32_t)B.count;
+        uint64_t at = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint64_t i = B.first + j, l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
+            hq[4 * j] = (uint32_t)at; hq[4 * j + 1] = (uint32_t)l1;
+            if (l1) std::memcpy(hseq.data() + at, seqs + offs[i], l1);
+            at += (l1 + 3) / 4 * 4;
+            hq[4 * j + 2] = (uint32_t)at; hq[4 * j + 3] = (uint32_t)l2;
+            if (l2) std::memcpy(hseq.data() + at, seqs2 + offs2[i], l2);
+            at += (l2 + 3) / 4 * 4;
+            hmw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ps->stride);   // candidate_structs.hpp:143-145
         }
-        if (first + ps->resident < ps->nparts) start_loader(ps, first + ps->resident);   // the next group loads behind this group's queries
-        const uint32_t np = (uint32_t)ps->cur.size();
-        for (const Batch& B : batches) {
-            const uint32_t m = (uint32_t)B.count;
-            uint64_t at = 0;
-            for (uint32_t j = 0; j < m; ++j) {
-                const uint64_t i = B.first + j, l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
-                hq[4 * j] = (uint32_t)at; hq[4 * j + 1] = (uint32_t)l1;
-                if (l1) std::memcpy(hseq.data() + at, seqs + offs[i], l1);
-                at += (l1 + 3) / 4 * 4;
-                hq[4 * j + 2] = (uint32_t)at; hq[4 * j + 3] = (uint32_t)l2;
-                if (l2) std::memcpy(hseq.data() + at, seqs2 + offs2[i], l2);
-                at += (l2 + 3) / 4 * 4;
-                hmw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ps->stride);   // candidate_structs.hpp:143-145
+        // every device: the batch, then its parts of the group, their top lists side by side in dmine
+        std::vector<int> rcs(nd, MC_OK);
+        std::vector<std::string> errs(nd);
+        auto run_device = [&](uint32_t d) {
+            DevState& D = ps->dev[d];
+            if (hipSetDevice(D.device) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipSetDevice"; return; }
+            (void)hipMemcpyAsync(D.dseq, hseq.data(), at + 16, hipMemcpyHostToDevice, D.stream);
+            (void)hipMemcpyAsync(D.dqinfo, hq.data(), (size_t)m * 16, hipMemcpyHostToDevice, D.stream);
+            (void)hipMemcpyAsync(D.dmaxwin, hmw.data(), (size_t)m * 4, hipMemcpyHostToDevice, D.stream);
+            (void)hipMemsetAsync(D.dmine, 0, ps->slotsPerDev * listBytes, D.stream);     // slots without a part: empty lists (hits = 0)
+            uint32_t slot = 0;
+            for (uint32_t p = d; p < np; p += nd, ++slot) {
+                mc_device_batch in{D.dseq, D.dqinfo, D.dmaxwin, 0, m, at};
+                mc_device_results res{};
+                int rc = mc_query_device(ps->cur[p], &in, lowestRank, 0, &res, D.stream);
+                if (!rc) rc = mc_copy_results_on(ps->cur[p], reinterpret_cast<char*>(D.dmine) + slot * listBytes, res.cands, (uint64_t)m * K * sizeof(mc_candidate), 0, D.stream);
+                if (rc) { rcs[d] = rc; errs[d] = mc_last_error(ps->cur[p]); return; }
             }
-            // every device: the batch, then its parts of the group, their top lists side by side in dmine
-            std::vector<int> rcs(nd, MC_OK);
-            std::vector<std::string> errs(nd);
-            auto run_device = [&](uint32_t d) {
-                DevState& D = ps->dev[d];
-                if (hipSetDevice(D.device) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipSetDevice"; return; }
-                (void)hipMemcpyAsync(D.dseq, hseq.data(), at + 16, hipMemcpyHostToDevice, D.stream);
-                (void)hipMemcpyAsync(D.dqinfo, hq.data(), (size_t)m * 16, hipMemcpyHostToDevice, D.stream);
-                (void)hipMemcpyAsync(D.dmaxwin, hmw.data(), (size_t)m * 4, hipMemcpyHostToDevice, D.stream);
-                (void)hipMemsetAsync(D.dmine, 0, ps->slotsPerDev * listBytes, D.stream);     // slots without a part: empty lists (hits = 0)
-                uint32_t slot = 0;
-                for (uint32_t p = d; p < np; p += nd, ++slot) {
-                    mc_device_batch in{D.dseq, D.dqinfo, D.dmaxwin, 0, m, at};
-                    mc_device_results res{};
-                    int rc = mc_query_device(ps->cur[p], &in, lowestRank, 0, &res, D.stream);
-                    if (!rc) rc = mc_copy_results_on(ps->cur[p], reinterpret_cast<char*>(D.dmine) + slot * listBytes, res.cands, (uint64_t)m * K * sizeof(mc_candidate), 0, D.stream);
-                    if (rc) { rcs[d] = rc; errs[d] = mc_last_error(ps->cur[p]); return; }
-                }
-            };
-            if (nd == 1) run_device(0);
-            else {
-                std::vector<std::thread> th;
-                for (uint32_t d = 0; d < nd; ++d) th.emplace_back(run_device, d);
-                for (auto& t : th) t.join();
-            }
-            for (uint32_t d = 0; d < nd; ++d) if (rcs[d]) return ps_fail(ps, rcs[d], errs[d]);
-            // per-rank partial lists gathered over RCCL: every rank's slotsPerDev lists -> dall[rank][slot] on every device
-            if (!ps->rccl) {
-                (void)hipSetDevice(ps->dev[0].device);
-                (void)hipMemcpyAsync(ps->dev[0].dall, ps->dev[0].dmine, ps->slotsPerDev * listBytes, hipMemcpyDeviceToDevice, ps->dev[0].stream);
-            } else {
+        };
+        if (nd == 1) run_device(0);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t d = 0; d < nd; ++d) th.emplace_back(run_device, d);
+            for (auto& t : th) t.join();
+        }
+        auto idle = [&](int code, const std::string& msg) {            // an error leaves nothing in flight
+            for (uint32_t d = 0; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
+            return ps_fail(ps, code, msg);
+        };
+        for (uint32_t d = 0; d < nd; ++d) if (rcs[d]) return idle(rcs[d], errs[d]);
+        // per-rank partial lists gathered over RCCL: every rank's slotsPerDev lists -> dall[rank][slot] on every device
+        if (!ps->rccl) {
+            (void)hipSetDevice(ps->dev[0].device);
+            (void)hipMemcpyAsync(ps->dev[0].dall, ps->dev[0].dmine, ps->slotsPerDev * listBytes, hipMemcpyDeviceToDevice, ps->dev[0].stream);
+        } else {
             g_rccl.GroupStart();
-            for (uint32_t d = 0; d < nd; ++d) {
+            int r = 0;
+            for (uint32_t d = 0; d < nd && !r; ++d) {
                 DevState& D = ps->dev[d];
                 (void)hipSetDevice(D.device);
-                if (int r = g_rccl.AllGather(D.dmine, D.dall, ps->slotsPerDev * listBytes, /*ncclChar*/ 0, D.comm, D.stream)) {
-                    g_rccl.GroupEnd();
-                    return ps_fail(ps, MC_ERR_HIP, std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
-                }
+                r = g_rccl.AllGather(D.dmine, D.dall, ps->slotsPerDev * listBytes, /*ncclChar*/ 0, D.comm, D.stream);
             }
-            if (int r = g_rccl.GroupEnd()) return ps_fail(ps, MC_ERR_HIP, std::string("ncclGroupEnd: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
-            }
-            // device 0: the earlier groups' list of these reads first, then this group's parts in part order (part p: rank p % nd, slot p / nd)
-            DevState& D0 = ps->dev[0];
-            if (hipSetDevice(D0.device) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipSetDevice");
-            std::vector<const mc_candidate*> lists;
-            if (first != 0) {
-                (void)hipMemcpyAsync(D0.dprior, out + B.first * K, (size_t)m * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D0.stream);
-                lists.push_back(D0.dprior);
-            }
-            for (uint32_t p = 0; p < np; ++p)
-                lists.push_back(reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(D0.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes));
-            int rc = mc_merge_part_candidates(ps->cur[0], lists.data(), (uint32_t)lists.size(), m, lowestRank, D0.dout, D0.stream);
-            if (rc) return ps_fail(ps, rc, mc_last_error(ps->cur[0]));
-            if (hipMemcpyAsync(out + B.first * K, D0.dout, (size_t)m * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, D0.stream) != hipSuccess ||
-                hipStreamSynchronize(D0.stream) != hipSuccess)
-                return ps_fail(ps, MC_ERR_HIP, "copy of the merged candidates failed");
-            for (uint32_t d = 1; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
+            const int e2 = g_rccl.GroupEnd();
+            if (r || e2) return idle(MC_ERR_HIP, std::string("ncclAllGather of the per-part candidates: ") + g_rccl.text(r ? r : e2));
         }
+        // device 0: the earlier groups' list of these reads first, then this group's parts in part order (part p: rank p % nd, slot p / nd)
+        DevState& D0 = ps->dev[0];
+        if (hipSetDevice(D0.device) != hipSuccess) return idle(MC_ERR_HIP, "hipSetDevice");
+        std::vector<const mc_candidate*> lists;
+        if (hasPrior) {
+            (void)hipMemcpyAsync(D0.dprior, out + B.first * K, (size_t)m * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D0.stream);
+            lists.push_back(D0.dprior);
+        }
+        for (uint32_t p = 0; p < np; ++p)
+            lists.push_back(reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(D0.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes));
+        int rc = mc_merge_part_candidates(ps->cur[0], lists.data(), (uint32_t)lists.size(), m, lowestRank, D0.dout, D0.stream);
+        if (rc) return idle(rc, mc_last_error(ps->cur[0]));
+        if (hipMemcpyAsync(out + B.first * K, D0.dout, (size_t)m * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, D0.stream) != hipSuccess ||
+            hipStreamSynchronize(D0.stream) != hipSuccess)
+            return idle(MC_ERR_HIP, "copy of the merged candidates failed");
+        for (uint32_t d = 1; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
     }
+    return MC_OK;
+}
+
+// All n reads against every part of the database, part group by part group.  out: [n][max_candidates] in host memory.
+int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n, int lowestRank,
+                        uint64_t insertMax, mc_candidate* out)
+{
+    if (!ps || !seqs || !offs || !out || (seqs2 && !offs2)) return MC_ERR_INVALID;
+    const uint32_t groups = (ps->nparts + ps->resident - 1) / ps->resident;
+    for (uint32_t g = 0; g < groups; ++g) {
+        int rc = mc_partset_select_group(ps, g);
+        if (!rc) rc = mc_partset_classify_resident(ps, seqs, offs, seqs2, offs2, n, lowestRank, insertMax, g > 0, out);
+        if (rc) return rc;
+    }
+    if (n == 0) return MC_OK;
     return MC_OK;
 }
 

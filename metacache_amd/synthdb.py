@@ -198,13 +198,16 @@ class GpuSynth:
             raise RuntimeError(f"mcs_reads -> {rc}")
 
 
-def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_bytes: int = 3 << 30, report=None, key_shard=(0, 1), write_to: str | None = None, **cfg):
+def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_bytes: int = 3 << 30, report=None, key_shard=(0, 1), write_to: str | None = None,
+                   only_targets: np.ndarray | None = None, **cfg):
     """The collection as a query table in HBM, built by the product's builder (mc_build_*) from targets that are generated on the
     device group by group: `shards` key-shard passes (every pass sketches all targets and keeps 1/shards of the features, sorts them
     and inserts them into the table: mc_build_table_*), so that neither the targets (150 Gbp) nor all (feature, location) pairs
     (2 x 10^10) ever exist at once.  key_shard = (i, n): only the features of key shard i of n (mc_key_owner) -- one rank's table in
     Mode K; its `shards` build passes are the sub-shards i * shards .. i * shards + shards - 1 of n * shards.
     write_to: also write the database as files <write_to>.meta / .cache0 in the reference's format, shard by shard (mc_build_write_*).
+    only_targets: ONE PART of a partitioned database -- all targets keep their numbers and stand in the metadata, but only these
+    (ascending) are sketched; the others go in as names and window counts (mc_build_add_existing_target).  tools/partgroup_bench.py.
     cfg: Builder / mc_config fields (max_candidates, max_load_factor, target_id_bytes, ...).
     -> (api.Database, info dict with seconds per phase)"""
     import time
@@ -233,6 +236,13 @@ def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_byte
     db = None
     writer = None
     L = api.lib()
+    mine = None
+    if only_targets is not None:
+        mine = np.zeros(n, dtype=bool); mine[np.asarray(only_targets, dtype=np.int64)] = True
+        est_pairs = int((lens[mine] // stride + 2).sum()) * sk
+        L.mc_build_add_existing_target.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_uint64, C.c_uint64]
+        kk = cfg.get("kmerlen", 16) or 16
+        wl = cfg.get("winlen", 127) or 127
     L.mc_build_add_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int64, C.c_char_p, C.c_uint64]
     t_all = time.time()
     for sh in range(shards):
@@ -249,7 +259,18 @@ def build_database(spec: Phylogeny, device: int = 0, shards: int = 1, chunk_byte
             base = buf.data_ptr()
             for i in range(c):
                 t = f + i
-                rc = L.mc_build_add_target_device(b.h, base + int(off[i]), int(lens[t]), names[t], 1000 + int(spec.species[t]), b"", 0)
+                if mine is not None and not mine[t]:
+                    # another part's target: its place in the numbering and its window count (hash_dna.hpp:54-75), no sequence
+                    ln = int(lens[t])
+                    if ln <= wl:
+                        nw = 1 if ln >= kk else 0
+                    else:
+                        nw = (ln - wl) // stride + 1
+                        if nw * stride < ln and ln - nw * stride >= kk:
+                            nw += 1
+                    rc = L.mc_build_add_existing_target(b.h, names[t], 1000 + int(spec.species[t]), b"", 0, nw)
+                else:
+                    rc = L.mc_build_add_target_device(b.h, base + int(off[i]), int(lens[t]), names[t], 1000 + int(spec.species[t]), b"", 0)
                 if rc < 0:
                     b._check(rc)
             b.flush()
