@@ -647,7 +647,7 @@ def main():
     # N > 1: the per-rank candidate lists go to rank 0 over RCCL (north_star: "per-rank partial hit lists gathered over RCCL/xGMI
     # before host-side taxonomy assignment").  Two buffers per rank: the gather of batch i runs while batch i+1 is computed.
     dist_path = world > 1 or args.force_dist
-    pipelined = mode == "R" and not args.long_reads and not args.no_pipeline
+    pipelined = mode == "R" and not args.no_pipeline
     nbuf = 2 if (dist_path or pipelined) else 1
     nout = B if mode in ("R", "K") else nloc                    # candidate rows this rank ends up with per step
     out_bufs = [torch.zeros((nout, K, 4), dtype=torch.int32, device=dev) for _ in range(nbuf)]
@@ -684,7 +684,12 @@ def main():
         finish(j)                                            # the gather that used this buffer two batches ago
         if pipelined:
             # batch i's main kernels go to pipe j WITHOUT any host synchronisation, then the tail and the hand-over of batch i - 1 (other pipe)
-            res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, second_pipe=bool(j), defer_tail=True)
+            if args.long_reads:
+                lb = long_batches[i % nb]
+                res = db.query_device(lb["seq"].data_ptr(), lb["qinfo"].data_ptr(), nloc, lb["nchars"], max_win_ptr=lb["maxwin"].data_ptr(), second_pipe=bool(j),
+                                      defer_tail=True)
+            else:
+                res = db.query_device(b.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, second_pipe=bool(j), defer_tail=True)
             pend[j] = res.cands
             finish_pipe(j ^ 1)
             return res
@@ -755,7 +760,11 @@ def main():
     if pipelined and rank == 0:
         db.timing(True); db.timing_reset()
         for i in range(min(3, args.steps)):
-            r = db.query_device(batches[i % nb].data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win)
+            if args.long_reads:
+                lb = long_batches[i % nb]
+                r = db.query_device(lb["seq"].data_ptr(), lb["qinfo"].data_ptr(), nloc, lb["nchars"], max_win_ptr=lb["maxwin"].data_ptr())
+            else:
+                r = db.query_device(batches[i % nb].data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win)
             db.copy_results(out_bufs[0].data_ptr(), r.cands, nloc * K * 16)
             db.synchronize()
         db.timing(False)

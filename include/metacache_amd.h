@@ -226,8 +226,9 @@ typedef struct {
                                  segments of the exact wave kernels' leftovers: a few reads per million) is left to mc_query_finish on the
                                  same pipe, which the caller issues AFTER it has enqueued the next batch on the other pipe -- the device
                                  never waits for the host.  out->cands is complete once mc_query_finish has returned (in stream order).
-                                 Honoured for batches of more than 2^20 reads on the lane path without MC_WANT_*; otherwise the call
-                                 does everything at once as without the flag (mc_query_finish is then a no-op).  A new mc_query_device
+                                 Honoured on the lane path without MC_WANT_* (small batches then skip their look at the work-list counters
+                                 too and launch every kernel); otherwise the call does everything at once as without the flag
+                                 (mc_query_finish is then a no-op).  A new mc_query_device
                                  on a pipe with a pending tail runs that tail first. */
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);

@@ -778,7 +778,8 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         uint32_t all[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         uint32_t none[16] = {0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};      // partial lists: no candidate kernels, the wave kernels for the rest
         uint32_t* hcnt = wantPartial ? none : all;
-        if (!wantPartial && n <= (1u << 20)) {
+        // (MC_DEFER_TAIL: no look at the counters either -- everything is launched, the caller has another batch to enqueue)
+        if (!wantPartial && n <= (1u << 20) && !(flags & MC_DEFER_TAIL)) {
             if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
             hcnt = reinterpret_cast<uint32_t*>(P.hTotal + 1);
             launch_flag_count(ws, n, st);
@@ -798,7 +799,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             launch_wave_rejoin(b, sp, tab, ws, st);
             waveDone = true;
         }
-        if (T.compact && !wantPartial && n <= (1u << 20) && hcnt != all && hcnt[10]) {
+        if (T.compact && !wantPartial && n <= (1u << 20) && (hcnt == all || hcnt[10])) {
             // reads beyond kGwSmallH locations (long reads): the stream filter takes them longest first (launch_gw_order)
             size_t ordBytes = 0;
             if (launch_gw_order(0, ws, n, n, nullptr, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the stream filter's reads: size query failed");

@@ -110,7 +110,10 @@ int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_
     const uint32_t* side = ws.sideList + (size_t)3 * n;
     // lists up to kGwLdsSortMax numbers: our own block sort in LDS (two instances by length); the library keeps the longer ones -- its
     // segments of the others are empty
-    static const bool own = [] { const char* e = std::getenv("MC_GW_OWN_SORT"); return !(e && e[0] == '0'); }();
+    // MEASURED SLOWER than the library on configs[4]'s reads at full scale (7.99 against 5.26 ms per 250 000 reads, profiles/r04_long_reads_own_sort.json:
+    // 330 .. 525 instructions and two LDS round trips per key and stage-pair against the block radix sort's ~400 with far fewer barriers), so it is
+    // OFF unless MC_GW_OWN_SORT=1 asks for it; kept as the measured baseline of the next attempt (a wave-ballot radix sort with the keys in registers)
+    static const bool own = [] { const char* e = std::getenv("MC_GW_OWN_SORT"); return e && e[0] == '1'; }();
     const uint32_t libMin = own ? kGwLdsSortMax : 0u;
     if (temp && own && nseg) {
         hipLaunchKernelGGL((gw_lds_sort_kernel<256, 2048>), dim3(std::min<uint32_t>(nseg, 256u * 16u)), dim3(256), 0, st, ws, n, in, out, 0u, 2048u);
