@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <memory>
 #include <unordered_map>
@@ -161,8 +162,12 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     *out = nullptr;
     Meta m{};
     std::string err;
+    const bool trace = std::getenv("MC_LOAD_TRACE") != nullptr;
+    auto now_s = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    const double tr0 = now_s();
     int rc = read_meta(name, m, err);
     if (rc) { set_global_error(err); return rc; }
+    const double tr1 = now_s();
     mc_config cfg = *cfgIn;
     cfg.kmerlen = m.k;                                      // k always comes from the DB (querying.cpp:232-243)
     if (!cfg.sketchlen) cfg.sketchlen = m.s;
@@ -183,8 +188,11 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     // window numbers, DeviceTable::values32); every target's window count comes from the target metadata (taxonomy.hpp:264-280
     // file_source::windows; targets carry the ids -(target) - 1, taxonomy.hpp:930).  Should a file hold a location outside of what
     // its own metadata says, the load is repeated with 8-byte locations.
+    double trCreate = 0, trBegin = 0, trLoad = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        const double tc0 = now_s();
         if ((rc = mc_create(&cfg, &ctx))) return rc;
+        trCreate += now_s() - tc0;
         ctx->targetSketch = SketchParams{m.k, m.s, m.w, m.stride};
         ctx->targetCount = m.targetCount;
         ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
@@ -204,13 +212,16 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
             if (tryCompact) rc = mc_load_target_windows(ctx, windows.data(), windows.size());
         }
         // every part is announced first (the merged table is sized for all of them), then loaded in part order
+        const double tb0 = now_s();
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
             PartHeader h;
             rc = read_part_header(ctx, std::string(name) + ".cache" + std::to_string(firstPart + p), h, m.targetBytes);
             if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
         }
+        const double tb1 = now_s();
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
             rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
+        trBegin += tb1 - tb0; trLoad += now_s() - tb1;
         if (rc && tryCompact && ctx->locRangeViolated) {
             m.taxa = std::move(ctx->taxa);
             mc_destroy(ctx); ctx = nullptr; rc = 0;
@@ -223,10 +234,13 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         mc_destroy(ctx);
         return rc;
     }
+    const double tr2 = now_s();
     Meta tmp{}; tmp.targetCount = ctx->targetCount; tmp.taxa = ctx->taxa;
     std::vector<uint32_t> lin;
     make_lineages(tmp, lin);
     if ((rc = mc_set_lineages(ctx, lin.data(), ctx->targetCount))) { set_global_error(ctx->err); mc_destroy(ctx); return rc; }
+    if (trace) std::fprintf(stderr, "mc_open_database %s part %d: metadata %.3f s, mc_create %.3f s, table allocation %.3f s, files %.3f s, lineages %.3f s\n", name, cfg.single_part, tr1 - tr0,
+                            trCreate, trBegin, trLoad, now_s() - tr2);
     *out = ctx;
     return MC_OK;
 }

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -187,6 +188,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
         s = pool().get(slabBytes);
         if (!s.p) { for (auto& t : slabs) pool().put(t); return fail(MC_ERR_NOMEM, "database load: cannot allocate pinned staging memory"); }
     }
+    const uint64_t tSlabs = now();
     std::mutex mtx;
     std::condition_variable cv;
     std::vector<uint8_t> ready(nbatches, 0);                  // 1 = in its slab, 2 = the read failed
@@ -310,5 +312,9 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     for (auto& s : slabs) pool().put(s);
     if (!synced) return fail(MC_ERR_HIP, "database load: table build failed");
     if (stats) { stats[0] = bytesIn; stats[1] = now() - t0; stats[2] = tIndex - t0; stats[3] = waitNs; }
+    if (std::getenv("MC_LOAD_TRACE"))
+        std::fprintf(stderr, "mc load %s: %.2f GB, %zu batches, %u threads, %u slabs of %.0f MB; index %.3f s, slabs %.3f s, total %.3f s (feeder waited %.3f s) = %.1f GB/s\n",
+                     fname.c_str(), bytesIn / 1e9, nbatches, nthreads, nslabs, slabBytes / 1e6, (tIndex - t0) / 1e9, (tSlabs - tIndex) / 1e9, (now() - t0) / 1e9, waitNs / 1e9,
+                     bytesIn / (double)(now() - t0));
     return MC_OK;
 }

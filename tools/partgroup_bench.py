@@ -62,6 +62,23 @@ def main():
         sizes = [os.path.getsize(f"{name}.cache{p}") for p in range(N)]
         res["part_file_GB"] = [round(s / 1e9, 2) for s in sizes]
         res["build_and_write_s"] = round(time.time() - t0, 1)
+        # one plain read of the files first: the FIRST read of tmpfs pages that were just written is slower than every later one (11 - 15 GB/s
+        # against 25 - 41 with the same eight threads, MC_LOAD_TRACE) -- the runs below then see files as a page cache holds them
+        from concurrent.futures import ThreadPoolExecutor
+
+        def slurp(fn):
+            n = 0
+            with open(fn, "rb", buffering=0) as f:
+                buf = bytearray(64 << 20)
+                while True:
+                    k = f.readinto(buf)
+                    if not k:
+                        return n
+                    n += k
+        tw = time.time()
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            total = sum(ex.map(slurp, [f"{name}.cache{p}" for p in range(N)]))
+        res["first_read_after_write"] = {"GB": round(total / 1e9, 2), "seconds": round(time.time() - tw, 2), "GB_per_s": round(total / 1e9 / (time.time() - tw), 2), "threads": 8}
         # the reads (host memory: mc_partset_classify_resident takes host buffers, as the command line does)
         P = synthdb.read_params(spec, 3100)
         rows = torch.zeros((args.reads, P.row_bytes), dtype=torch.uint8, device="cuda")
