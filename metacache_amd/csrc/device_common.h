@@ -57,6 +57,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
+// the same with max (values >= 0: the lanes a shift leaves empty read as 0)
+__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
 // orders this wave's LDS / global accesses (other lanes of the same wave read what this lane wrote).
 // Heavy: waits for every outstanding global load AND store of the wave.
 __device__ __forceinline__ void wave_mem_sync()

@@ -134,6 +134,31 @@ __device__ __forceinline__ void gw_fill_rounds(uint64_t* T, uint32_t lane, uint3
     const uint32_t jlo = r0 > start ? r0 - start : 0u, jhi = min(myR, r0 + kGwRounds > start ? r0 + kGwRounds - start : 0u);
     for (uint32_t j = jlo; j < jhi; ++j) T[start + j - r0] = (pay + 16ull * j) | ((uint64_t)min(16u, sz - 16u * j) << 40);
 }
+// The same table for a read whose rounds fit ONE batch (r0 = 0, Rc <= kGwRounds), in a fixed number of instructions: gw_fill_rounds has
+// every lane write its own rounds one after the other -- as many steps as the longest list has rounds (16 for the lists of 254
+// locations every read of a RefSeq-scale table meets): ~130 of the kernel's ~1 380 VALU instructions per read.  Here every lane leaves
+// its number at its FIRST round's slot, a max-scan over the slots (lane l: slots l and l + 64) tells every slot whose round it is, and
+// the entry's fields come over from that lane (ds_bpermute): ~40 instructions whatever the lists' lengths.  E: 128 words of LDS scratch.
+__device__ __forceinline__ void gw_fill_rounds_scan(uint64_t* T, uint32_t* E, uint32_t lane, uint32_t Rc, uint32_t start, uint32_t myR, uint32_t sz, uint64_t pay)
+{
+    E[lane] = 0u; E[lane + 64u] = 0u;
+    wave_lds_sync();
+    if (myR && start < kGwRounds) E[start] = lane + 1u;            // (entries' first rounds are distinct slots)
+    wave_lds_sync();
+    uint32_t lo = wave_incl_scan_max_u32(E[lane]);
+    uint32_t hi = max(wave_incl_scan_max_u32(E[lane + 64u]), rdlane(lo, 63));
+    const uint32_t payLo = (uint32_t)pay, payHi = (uint32_t)(pay >> 32);
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t slot = lane + 64u * h, who = h ? hi : lo;
+        const int src = (int)(who ? who - 1u : 0u);
+        const uint32_t eStart = (uint32_t)__shfl((int)start, src), eSz = (uint32_t)__shfl((int)sz, src);
+        const uint32_t eLo = (uint32_t)__shfl((int)payLo, src), eHi = (uint32_t)__shfl((int)payHi, src);
+        const uint32_t j = slot - eStart;
+        const uint64_t ep = ((uint64_t)eHi << 32) | eLo;
+        T[slot] = (who && slot < Rc) ? ((ep + 16ull * j) | ((uint64_t)min(16u, eSz - 16u * j) << 40)) : 0ull;
+    }
+}
 // the batch's numbers: 16 bytes per lane and load, four lanes per round; places without a round read as kGwNone
 template <bool ALIGN_TEST = false>
 __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads],
@@ -505,7 +530,6 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     const uint32_t* __restrict__ side = ws.sideList;
     for (uint32_t i = blockIdx.x; i < mine; i += gridDim.x) {
         const uint32_t w = side[i];
-        if (outRec[w].z != kGwDefer) continue;                     // (block-uniform) gw_filter_stream1_kernel took it
         const uint4 rec = work[w];
         const uint32_t q = rec.x, fbase = rec.y, recZ = rec.z, maxWin = rec.w;
         const uint32_t nent = recZ & 0xFFFu, H = recZ >> 12;
@@ -564,105 +588,6 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
         }
         if (!fallback && k >= 0) used[k] += n2;
         __syncthreads();                                           // (the counter and the filters are reset for the next read)
-    }
-}
-
-// The stream filter's reads whose numbers FIT THE BLOCK'S REGISTERS in ONE pass over the fabric (as gw_filter2_kernel does for pairs): a
-// block of WAVES waves per read, wave w takes the entries [32 w, 32 w + 32) -- 32 lists of 49 numbers are about 100 rounds, a register
-// batch holds 128 --, phase A (marks into the block's one pair of filters), barrier, phase B from the registers.  Takes the reads of up to
-// 32 x WAVES found features (eight waves: reads up to ~1 800 bp at the default windows) whose every wave's rounds fit; everything else
-// stays with gw_filter_stream_kernel (two passes, the second from the L2), which runs next and skips what has a result already.
-// Pool: the block owns WAVES of the filter kernels' slices (nSlices of them in all); their fill is read from and written back to
-// ws.sliceFill, so the kernels before and after share them.
-template <uint32_t WAVES, uint32_t T1LOG2, uint32_t T2LOG2>
-__global__ __launch_bounds__(WAVES * 64) void gw_filter_stream1_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t nSlices)
-{
-    using Bloom = GwBloom<T1LOG2, T2LOG2>;
-    __shared__ uint32_t bits[Bloom::kWords];
-    __shared__ uint64_t roundS[WAVES][kGwRounds];
-    __shared__ uint32_t n2S, fitS;
-    __shared__ unsigned long long ovfS;
-    const uint32_t mine = ws.midCount[12];
-    if (mine == 0) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint64_t* T = roundS[wave];
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
-    uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
-    const uint32_t w0 = blockIdx.x * WAVES;                        // the block's first slice
-    if (w0 >= nSlices) return;
-    const uint32_t nown = min(WAVES, nSlices - w0);
-    const uint64_t sliceCap = ws.bigPoolCap / nSlices;
-    uint64_t used[WAVES];                                          // block-uniform copies
-#pragma unroll
-    for (uint32_t k = 0; k < WAVES; ++k) used[k] = (ws.sliceFill && k < nown) ? ws.sliceFill[w0 + k] : sliceCap;   // (a slice that is not ours is full)
-    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    const uint32_t* __restrict__ side = ws.sideList;
-    for (uint32_t i = blockIdx.x; i < mine; i += gridDim.x) {
-        const uint32_t w = side[i];
-        const uint4 rec = work[w];
-        const uint32_t q = rec.x, fbase = rec.y, recZ = rec.z, maxWin = rec.w;
-        const uint32_t nent = recZ & 0xFFFu, H = recZ >> 12;
-        if (nent > 32u * WAVES || maxWin > tab.gwGap) continue;    // (block-uniform: the two-pass kernel's)
-        // this wave's 32 entries, one per lane of its lower half
-        const uint32_t e = wave * 32u + lane;
-        const bool have = lane < 32u && e < nent;
-        const uint32_t sz = have ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
-        const uint64_t pay = have ? ws.ppay[fbase + e] : 0ull;
-        const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
-        const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
-        __syncthreads();                                           // (everybody has read the previous read's flags)
-        if (threadIdx.x == 0) { fitS = 1u; n2S = 0u; }
-        {
-            uint4* z4 = reinterpret_cast<uint4*>(bits);
-            for (uint32_t j = threadIdx.x; j < Bloom::kWords / 4; j += WAVES * 64) z4[j] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();
-        if (Rc > kGwRounds && lane == 0) fitS = 0u;
-        __syncthreads();
-        if (!fitS) continue;                                       // a wave's rounds do not fit its registers: the two-pass kernel's
-        // where the list goes: the first of the block's slices that can take all H numbers, else H places of the overflow region
-        int k = -1;
-#pragma unroll
-        for (uint32_t kk = 0; kk < WAVES; ++kk) if (k < 0 && used[kk] < sliceCap && (uint64_t)H <= min((uint64_t)kGwMaxKept, sliceCap - used[kk])) k = (int)kk;
-        uint64_t listAt = 0; uint32_t room = 0;
-        if (k >= 0) { listAt = (uint64_t)(w0 + (uint32_t)k) * sliceCap + used[k]; room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - used[k]); }
-        else {
-            if (threadIdx.x == 0) ovfS = atomicAdd(reinterpret_cast<unsigned long long*>(ws.midCount + 16), (unsigned long long)H);
-            __syncthreads();
-            const unsigned long long at = ovfS;
-            if (at + H <= ws.bigOvfCap) { listAt = (uint64_t)ws.bigPoolCap + at; room = H; }
-            else continue;                                         // no room anywhere: left to the two-pass kernel (which hands it to the wave kernel if need be)
-        }
-        GwSink S{reinterpret_cast<uint32_t*>(ws.bigPool) + listAt, room, 0u, &n2S};
-        const GwFrame F(maxWin);
-        const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
-        const uint32_t nl = (Rc + 15u) >> 4;
-        // ---- A
-        gw_fill_rounds(T, lane, 0, Rc, incl - myR, myR, sz, pay);
-        wave_lds_sync();
-        uint4 x[kGwLoads];
-        gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
-        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
-        gw_mark_rounds<Bloom>(bits, x, F.A, nl);
-        __syncthreads();                                           // every wave's marks before anybody's tests
-        // ---- B, from the registers
-        gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-        gw_take_rounds<Bloom, true>(bits, T, F, S, grp, sub4, x, nl);
-        __syncthreads();                                           // every wave's numbers before the count is read
-        const uint32_t n2 = n2S;
-        const bool fallback = n2 > room;
-        if (threadIdx.x == 0) {
-            if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
-            else outRec[w] = make_uint4(q, (uint32_t)listAt, n2, maxWin);
-        }
-        if (!fallback && k >= 0) used[k] += n2;
-        __syncthreads();
-    }
-    if (ws.sliceFill && threadIdx.x < nown) {
-        uint64_t u = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < WAVES; ++k) if (k == threadIdx.x) u = used[k];
-        ws.sliceFill[w0 + threadIdx.x] = (uint32_t)u;
     }
 }
 
@@ -1196,7 +1121,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_simple_kernel
 #pragma unroll
             for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         }
-        gw_fill_rounds(T, lane, 0, Rc, incl - myR, myR, sz, pay);
+        gw_fill_rounds_scan(T, kept, lane, Rc, incl - myR, myR, sz, pay);   // (kept: free until phase B)
         wave_lds_sync();
         const GwFrame F(maxWin);
         const uint32_t nl = (Rc + 15u) >> 4;
@@ -1688,9 +1613,8 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
         if (ws.orderScratch) { size_t tb = ws.orderTemp; (void)launch_gw_order(0, ws, b.n, b.n, ws.orderScratch, tb, st); }   // longest reads first
         // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads)
-        // single pass for the reads whose numbers fit a block's registers (MC_GW_STREAM1=0: off), then the two-pass kernel for the rest
-        static const bool stream1 = [] { const char* e = std::getenv("MC_GW_STREAM1"); return !(e && e[0] == '0'); }();
-        if (stream1) hipLaunchKernelGGL((gw_filter_stream1_kernel<8, 17, 15>), dim3((4 * fgrid + 7) / 8), dim3(512), 0, st, b, tab, ws, 4u * fgrid);
+        // (a single-pass instance for reads whose numbers fit a block's registers -- eight waves of 32 entries each, phase B from the registers --
+        // was measured SLOWER in front of this kernel: 5.00 against 4.60 ms per 250 000 long reads, 125 registers and idle waves at barriers; dropped)
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1) {

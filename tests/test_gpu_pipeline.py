@@ -49,11 +49,12 @@ def test_deferred_tail_on_two_pipes_equals_the_synchronous_call(monkeypatch, K, 
         batches.append([reads[i] for i in rng.permutation(len(reads))])
     dev = torch.device("cuda", 0)
     dbatch = [_device_batch(r, dev) for r in batches]
+    torch.cuda.synchronize()
     # one batch at a time
     want = []
     for (seq, qi, mw, nch), reads in zip(dbatch, batches):
         r = db.query_device(seq.data_ptr(), qi.data_ptr(), len(reads), nch, max_win_ptr=mw.data_ptr(), lowest=lowest)
-        out = torch.zeros((len(reads), K, 4), dtype=torch.int32, device=dev)
+        out = torch.empty((len(reads), K, 4), dtype=torch.int32, device=dev)   # (empty: a fill kernel on torch's stream would race the copy on the context's)
         db.copy_results(out.data_ptr(), r.cands, len(reads) * K * 16); db.synchronize()
         want.append(out.cpu().numpy().view(np.uint32))
     # ... against the oracle (the long reads' sorted lists, the handed-back reads)
@@ -74,7 +75,7 @@ def test_deferred_tail_on_two_pipes_equals_the_synchronous_call(monkeypatch, K, 
         if j in pend:
             i, ptr, n = pend.pop(j)
             db.query_finish(second_pipe=bool(j))
-            out = torch.zeros((n, K, 4), dtype=torch.int32, device=dev)
+            out = torch.empty((n, K, 4), dtype=torch.int32, device=dev)
             db.copy_results(out.data_ptr(), ptr, n * K * 16, second_pipe=bool(j))
             db.query_wait(second_pipe=bool(j))
             got[i] = out.cpu().numpy().view(np.uint32)
@@ -95,7 +96,7 @@ def test_deferred_tail_on_two_pipes_equals_the_synchronous_call(monkeypatch, K, 
     seq, qi, mw, nch = dbatch[2]
     db.query_device(seq.data_ptr(), qi.data_ptr(), len(batches[2]), nch, max_win_ptr=mw.data_ptr(), lowest=lowest, defer_tail=True)
     r = db.query_device(seq.data_ptr(), qi.data_ptr(), len(batches[2]), nch, max_win_ptr=mw.data_ptr(), lowest=lowest)
-    out = torch.zeros((len(batches[2]), K, 4), dtype=torch.int32, device=dev)
+    out = torch.empty((len(batches[2]), K, 4), dtype=torch.int32, device=dev)
     db.copy_results(out.data_ptr(), r.cands, len(batches[2]) * K * 16); db.synchronize()
     o = out.cpu().numpy().view(np.uint32)
     live = (o[:, :, 1] > 0) | (want[2][:, :, 1] > 0)

@@ -146,7 +146,7 @@ def main():
         bad = 0
         for idx, (seq, qi, n, nch, mw) in enumerate(((singles, q1, n1, n1 * PAD_LEN, mw1), (pairs, q2, n2, 2 * n2 * PAD_LEN, mw2))):
             res = dbp.query_device(seq.data_ptr(), qi.data_ptr(), n, nch, max_win_uniform=mw)
-            c = torch.zeros((n, K, 4), dtype=torch.int32, device=dev)
+            c = torch.empty((n, K, 4), dtype=torch.int32, device=dev)     # (empty: a fill kernel on torch's stream would race the copy on the context's)
             dbp.copy_results(c.data_ptr(), res.cands, n * K * 16); dbp.synchronize()
             live = c[:, :, 1] > 0
             c[:, :, 0] = torch.where(live, sel_t[c[:, :, 0].clamp(min=0, max=sel_t.numel() - 1).long()], c[:, :, 0])
