@@ -769,12 +769,18 @@ def main():
             db.synchronize()
         db.timing(False)
         kt_solo = {k: db.timing_get(k) for k in KERNELS}
+    kstats = None
+    if mode == "K" and rank == 0 and world == 1:
+        # (the owner-side call resets the shard side's statistics: one more lookup pass for F and H of the line)
+        db.query_device(batches[0].data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, want_partial_hits=not numbers_wire, want_partial_numbers=numbers_wire)
+        db.synchronize()
+        kstats = db.last_batch_stats()
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         kt = kt_timed                                         # HIP events over THE timed region
-        st = db.last_batch_stats()                            # of the last batch that went through the first pipe
+        st = kstats or db.last_batch_stats()                  # of the last batch that went through the first pipe
         layout = db.table_layout()
         if cfg != 1:
             V = layout["location_bytes"]                       # SURVEY's V = bytes per location as the table holds them: 4 with the compact store

@@ -111,18 +111,20 @@ def test_part_groups_streamed_batch_by_batch_equal_classify(golden, resident, lo
     name = golden.db_path("toy32p4")
     K = 2
     ps = api.PartSet(name, resident=resident, max_candidates=K, slot_max_queries=400, slot_max_chars=1 << 17)
+    p1, p2 = p1[:600], p2[:600]
+    npairs = len(p1)
     want = ps.classify(single[:1500], lowest=lowest)
-    wantp = ps.classify(p1[:600], p2[:600], lowest=lowest, insert_max=700)
+    wantp = ps.classify(p1, p2, lowest=lowest, insert_max=700)
     groups = ps.info()["groups"]
     # group by group, the reads in batches of their own; between the groups a batch keeps nothing but its candidate lists
     cuts = [(0, 500), (500, 1100), (1100, 1500)]
     got = np.zeros((1500, K), dtype=api.cand_dtype)
-    gotp = np.zeros((600, K), dtype=api.cand_dtype)
+    gotp = np.zeros((npairs, K), dtype=api.cand_dtype)
     for g in range(groups):
         ps.select_group(g)
         for lo, hi in cuts:
             ps.classify_resident(single[lo:hi], None, got[lo:hi], has_prior=g > 0, lowest=lowest)
-        ps.classify_resident(p1[:600], p2[:600], gotp, has_prior=g > 0, lowest=lowest, insert_max=700)
+        ps.classify_resident(p1, p2, gotp, has_prior=g > 0, lowest=lowest, insert_max=700)
     info = ps.info()
     ps.close()
     for a, b in ((got, want), (gotp, wantp)):
