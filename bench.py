@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
 PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
-           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter_rest", "gw_count", "gw_count_1024",
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter_rest", "gw_count", "gw_count_1024", "gw_count_block",
            "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates")
 KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
 # timer (mc_timing_get) -> the kernel's own name as the rocprofv3 summaries carry it (scripts/summarize_profile.py): prefixes
@@ -61,7 +61,7 @@ KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cand
              "query_wave": ("query_kernel",), "sort_candidates": ("sort_candidates_kernel",),
              "gw_filter_count": ("gw_filter_count_kernel", "gw_filter_count_simple_kernel"), "gw_filter": ("gw_filter_kernel",),
              "gw_filter_rest": ("gw_filter_stream_kernel", "gw_filter2_kernel"), "gw_count": ("gw_count_kernel<9", "gw_count_kernel<10"),
-             "gw_count_1024": ("gw_count_kernel<11",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
+             "gw_count_1024": ("gw_count_kernel<11",), "gw_count_block": ("gw_count_block_kernel",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
              "big_count_2": ("big_count_kernel<11",), "hash_cands_256": ("hash_cands_kernel<9",), "hash_cands_512": ("hash_cands_kernel<10",),
              "hash_cands_1024": ("hash_cands_kernel<11",), "mid_cands_64": ("mid_cands_kernel",), "mid_cands_128": ("mid_cands_kernel",),
              "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("rocprim",), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
@@ -505,6 +505,7 @@ def main():
                     "pipes, mc_query_device(MC_DEFER_TAIL) + mc_query_finish)")
     ap.add_argument("--selfcheck-seconds", type=float, default=150.0, help="time limit of the multi-GPU self-check that follows the timed region "
                     "(tools/multi_gpu_selfcheck.py as its own job over the same N ranks; 0 = skip)")
+    ap.add_argument("--tune", default="", help="run-time tuning switches (mc_set_tuning) for experiments: name=value[,name=value ...], e.g. gw_block=0")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of the K steps: the first is the line's value, all of them its value_range")
     ap.add_argument("--long-reads", action="store_true", help="configs[2] table, BASELINE configs[4]'s reads: single reads of 200 .. 19 000 bp (log-normal, "
                     "median 480), 7.5 %% substitutions, seed 5100; --batch = reads per step (default 250 000)")
@@ -625,6 +626,8 @@ def main():
         pmc_tag = "r04" if (mode == "R" and not args.pairs and not args.long_reads and args.scale == 1.0 and B == 5_000_000) else "r04-none"
     build_s = time.time() - t0
     db_info = db.info()
+    for kv in filter(None, args.tune.split(",")):
+        db.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 
     mode = args.mode if cfg == 2 else "R"
     pairs = bool(args.pairs) and cfg == 2

@@ -604,6 +604,8 @@ static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const Ske
     if (second || compact) { ScopedTimer t(ctx, compact ? "gw_filter_rest" : "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count" : "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count_1024" : "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    // the sorted class' lists that fit a block's LDS table are counted as well (a block per read); what it cannot take joins the sorted ones
+    if (compact && ws.gwBlock) { ScopedTimer t(ctx, "gw_count_block", st); launch_big_cands(5, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     if (compact && !deferSorted) return run_sorted_tail(ctx, P, b, sp, tab, ws, K, taxkey, poolEntries, false, st);
     return MC_OK;
 }
@@ -716,7 +718,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     const uint64_t ovfCap = T0.compact ? std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20)) : 0;
     if (lanePath && (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
     if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * 4 + 64))) return rc;
-    if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4))) return rc;
+    if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)5 * std::max<uint32_t>(n, 1) * 4))) return rc;
     if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
     if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
@@ -724,7 +726,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -896,7 +898,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -944,7 +946,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -1046,11 +1048,11 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
         (rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1))) ||
         (rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16)) ||
         (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * 4)) || (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, true, ctx->filterBpc) * 4 * 4 + 64)) ||
-        (rc = ensure(ctx, P.bSide, (size_t)4 * std::max<uint32_t>(n, 1) * 4)) ||
+        (rc = ensure(ctx, P.bSide, (size_t)5 * std::max<uint32_t>(n, 1) * 4)) ||
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1141,6 +1143,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
     else if (n == "filter_lds_pad") ctx->filterLdsPad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 120 << 10));   // bytes of unused dynamic LDS per filter block
+    else if (n == "gw_block") ctx->gwBlock = value != 0;                       // gw_count_block_kernel for the sorted class' lists of up to kGwBlockMax numbers (default on)
     else if (n == "gw_fuse") ctx->gwFuse = (int)value;                         // counting of short filtered lists inside the filter kernel: 0 = apart, 1 (default) = fused, 2 = fused + software pipeline (four waves per SIMD: measured slower), 3 = the same compiled for five waves per SIMD (spills)
     else if (n == "gw_diag") {                                                 // timing experiments on gw_filter_kernel (WRONG results): only with MC_ALLOW_DIAG=1 in the environment
         const char* e = std::getenv("MC_ALLOW_DIAG");
@@ -1189,7 +1192,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     Pipe& P = ctx->pipe0;
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

@@ -451,46 +451,53 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
 {
     // a block takes a contiguous stretch of the records: it counts its members of every class first, reserves their places with ONE
     // atomic per class (78 000 atomics on one counter -- one per 64 records -- took 0.4 ms), then writes them in record order
-    __shared__ uint32_t cnt[4][4], base[4];
+    constexpr uint32_t kC = 5;                                     // classes = side lists; class kC: none
+    __shared__ uint32_t cnt[4][kC], base[kC];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ rec7 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((total + gridDim.x - 1) / gridDim.x + 255u) / 256u * 256u;          // records per block, whole 256-record steps
     const uint32_t lo = blockIdx.x * per, hi = min(total, lo + per);
+    const bool blockCount = ws.gwBlock != 0;
     auto class_of = [&](uint32_t i) -> uint32_t {
-        if (i >= hi) return 4u;
+        if (i >= hi) return kC;
         const uint4 r = rec7[i];
-        if (stage == 0) return r.z == kGwDefer ? 0u : 4u;
+        if (stage == 0) return r.z == kGwDefer ? 0u : kC;
+        if (blockCount && gw_block_class(r.z, r.w)) return 4u;     // sorted class, but a block's LDS table holds it: gw_count_block_kernel
         if (gw_sorted_class(r.z, r.w)) return 3u;
-        if (r.z <= kBigMaxFilteredCount && r.w <= kHashWin) return r.z > 512u ? 2u : r.z > 256u ? 1u : 4u;
-        return 4u;
+        if (r.z <= kBigMaxFilteredCount && r.w <= kHashWin) return r.z > 512u ? 2u : r.z > 256u ? 1u : kC;
+        return kC;
     };
-    uint32_t mine[4] = {0, 0, 0, 0};
+    uint32_t mine[kC];
+#pragma unroll
+    for (uint32_t k = 0; k < kC; ++k) mine[k] = 0;
     for (uint32_t i = lo + threadIdx.x; i < lo + per && lo < hi; i += 256) {
         const uint32_t c = class_of(i);
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) mine[k] += (uint32_t)__popcll(__ballot(c == k));       // (wave-uniform counts)
+        for (uint32_t k = 0; k < kC; ++k) mine[k] += (uint32_t)__popcll(__ballot(c == k));       // (wave-uniform counts)
     }
-    if (lane == 0) { for (uint32_t k = 0; k < 4; ++k) cnt[wave][k] = mine[k]; }
+    if (lane == 0) { for (uint32_t k = 0; k < kC; ++k) cnt[wave][k] = mine[k]; }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < kC) {
         const uint32_t k = threadIdx.x, tot = cnt[0][k] + cnt[1][k] + cnt[2][k] + cnt[3][k];
-        base[k] = tot ? atomicAdd(&ws.midCount[k == 0 ? 12u : k == 1 ? 14u : k == 2 ? 15u : 13u], tot) : 0u;
+        base[k] = tot ? atomicAdd(&ws.midCount[k == 0 ? 12u : k == 1 ? 14u : k == 2 ? 15u : k == 3 ? 13u : 19u], tot) : 0u;
     }
     __syncthreads();
     // second pass: step s of the block holds records lo + s * 256 .. ; within a step the waves' members follow each other
-    uint32_t run[4] = {base[0], base[1], base[2], base[3]};
+    uint32_t run[kC];
+#pragma unroll
+    for (uint32_t k = 0; k < kC; ++k) run[k] = base[k];
     for (uint32_t i0 = lo; i0 < lo + per && lo < hi; i0 += 256) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t c = class_of(i);
-        uint64_t m[4];
+        uint64_t m[kC];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) m[k] = __ballot(c == k);
+        for (uint32_t k = 0; k < kC; ++k) m[k] = __ballot(c == k);
         __syncthreads();
-        if (lane == 0) { for (uint32_t k = 0; k < 4; ++k) cnt[wave][k] = (uint32_t)__popcll(m[k]); }
+        if (lane == 0) { for (uint32_t k = 0; k < kC; ++k) cnt[wave][k] = (uint32_t)__popcll(m[k]); }
         __syncthreads();
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
+        for (uint32_t k = 0; k < kC; ++k) {
             uint32_t before = 0, all = 0;
             for (uint32_t w = 0; w < 4; ++w) { before += w < wave ? cnt[w][k] : 0u; all += cnt[w][k]; }
             if (c == k) ws.sideList[(size_t)k * n + run[k] + before + __popcll(m[k] & ((1ull << lane) - 1ull))] = i;
@@ -1571,6 +1578,202 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
 }
 
 
+// ================================================================================================
+// gw_count_block_kernel: rows 8-10 on a filtered list of the SORTED class -- more than 1 024 numbers, or window ranges wider than 8:
+// reads of 800 bp and more -- WITHOUT the sort, by gw_count_kernel's method and a BLOCK per read.  A filtered list holds every location
+// about four times (the read's features that hit one window of a target), and everything after the counting is per DISTINCT number:
+//   1. every number is counted in the block's LDS table of {number, count} slots (compare-and-swap claims a slot, linear probing);
+//   2. the occupied slots are listed (one 16-bit slot number each), one distinct number per thread and step from here on;
+//   3. the thread that holds number g adds the counts of g - 1 .. g - (maxWindowsInRange - 1): the hits of the window range that ENDS
+//      in g (candidate_generation.hpp:47-108 evaluates exactly these ranges; the first to reach a target's maximum has the smallest end) --
+//      D - 1 table lookups per distinct number where the sort moved every number through eight radix passes;
+//   4. K rounds over the block: maximum of the hits, the smallest number among its holders, its REGION (every number within the gap
+//      between two targets: it lies inside its target) or taxon struck -- gw_pick's rounds, and its exactness argument, on a block;
+//   5. the K winners' targets are looked up, two winners of one target or fewer than K winners with two hits send the read to the
+//      exact wave kernel (as the scan of the sorted lists does).
+// A list with more distinct numbers than half the table's slots (the neighbour lookups need free slots to end at) joins the sorted
+// class after all: one atomic on its counter.  Instances by list length: 2^11 slots (18 KB of LDS: eight blocks per CU), 2^12, 2^13.
+// ================================================================================================
+template <uint32_t LOG2S, uint32_t THREADS, bool TAX>
+__global__ __launch_bounds__(THREADS) void gw_count_block_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
+                                                                 mc_candidate_dev* __restrict__ cands, uint32_t minN2)
+{
+    constexpr uint32_t kSlots = 1u << LOG2S, kCap = kSlots / 2, kE = kCap / THREADS, kWaves = THREADS / 64;
+    constexpr uint32_t kByteMask = (kSlots - 1u) << 3;
+    static_assert(kE >= 1 && kE <= 16 && kSlots <= 65536, "one 16-bit slot number per distinct number, a few of them per thread");
+    __shared__ __attribute__((aligned(16))) uint2 slotS[kSlots];
+    __shared__ uint16_t ckS[kCap];
+    __shared__ uint32_t ctrS[2];                                   // distinct numbers claimed; occupied slots listed
+    __shared__ uint32_t redS[4][kWaves];
+    __shared__ uint32_t winS[kLaneK][4];                           // the rounds' winners: number, hits, end - begin, taxon
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* base = reinterpret_cast<char*>(slotS);
+    auto key_at = [&](uint32_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(base + off); };
+    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
+    const uint32_t* __restrict__ side = ws.sideList + (size_t)4 * b.n;
+    const uint32_t* __restrict__ pool = reinterpret_cast<const uint32_t*>(ws.bigPool);
+    const uint32_t nmine = ws.midCount[19];
+    // block-wide maximum / minimum: the waves' results meet in LDS, four buffers in turn (one barrier per reduction)
+    uint32_t red = 0;
+    auto block_max = [&](uint32_t x) -> uint32_t {
+        x = wave_max_u32(x);
+        if (lane == 0) redS[red][wave] = x;
+        __syncthreads();
+        uint32_t r = redS[red][0];
+#pragma unroll
+        for (uint32_t k = 1; k < kWaves; ++k) r = max(r, redS[red][k]);
+        red = (red + 1u) & 3u;
+        return r;
+    };
+    auto block_min = [&](uint32_t x) -> uint32_t {
+        x = wave_min_u32(x);
+        if (lane == 0) redS[red][wave] = x;
+        __syncthreads();
+        uint32_t r = redS[red][0];
+#pragma unroll
+        for (uint32_t k = 1; k < kWaves; ++k) r = min(r, redS[red][k]);
+        red = (red + 1u) & 3u;
+        return r;
+    };
+    for (uint32_t i = blockIdx.x; i < nmine; i += gridDim.x) {
+        const uint32_t w = side[i];
+        const uint4 rec = work[w];
+        const uint32_t q = rec.x, n2 = rec.z, maxWin = rec.w;
+        if (n2 <= minN2 || n2 > kSlots) continue;                  // (block-uniform) another instance's list
+        {
+            uint4* k4 = reinterpret_cast<uint4*>(slotS);
+            for (uint32_t j = tid; j < kSlots / 2; j += THREADS) k4[j] = make_uint4(kGwNone, 0u, kGwNone, 0u);
+        }
+        if (tid < 2) ctrS[tid] = 0u;
+        if (tid < kLaneK) { winS[tid][0] = kGwNone; winS[tid][1] = 0u; winS[tid][2] = 0u; winS[tid][3] = 0u; }
+        __syncthreads();
+        // ---- 1. counting
+        const uint32_t* __restrict__ src = pool + rec.y;
+        uint32_t claimed = 0;
+        for (uint32_t j = tid; j < n2; j += THREADS) {
+            const uint32_t g = src[j];
+            uint32_t off = gw_slot<LOG2S>(g), old;
+            for (;;) {
+                old = atomicCAS(key_at(off), kGwNone, g);
+                if (old == kGwNone || old == g) break;
+                off = (off + 8u) & kByteMask;
+            }
+            atomicAdd(key_at(off) + 1, 1u);
+            claimed += old == kGwNone ? 1u : 0u;
+        }
+        claimed = wave_sum_u32(claimed);
+        if (lane == 0 && claimed) atomicAdd(&ctrS[0], claimed);
+        __syncthreads();
+        const uint32_t C = ctrS[0];
+        if (C > kCap) {                                            // too many distinct numbers for this table: the sort takes the list
+            if (tid == 0) { const uint32_t at = atomicAdd(&ws.midCount[13], 1u); ws.sideList[(size_t)3 * b.n + at] = w; }
+            __syncthreads();                                       // (everybody has read C before the counters are reset)
+            continue;
+        }
+        // ---- 2. the occupied slots
+        for (uint32_t s0 = 0; s0 < kSlots; s0 += THREADS) {
+            const uint32_t sl = s0 + tid;
+            const bool occ = slotS[sl].x != kGwNone;
+            const uint64_t m = __ballot(occ);
+            uint32_t wb = 0;
+            if (lane == 0 && m) wb = atomicAdd(&ctrS[1], (uint32_t)__popcll(m));
+            wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+            if (occ) ckS[wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)sl;
+        }
+        __syncthreads();
+        // ---- 3. ranges that end in this thread's numbers: hits | (end - begin) << 16
+        uint32_t v[kE], R[kE];
+#pragma unroll
+        for (uint32_t e = 0; e < kE; ++e) {
+            const uint32_t j = e * THREADS + tid;
+            const uint2 c = j < C ? slotS[ckS[j]] : make_uint2(kGwNone, 0u);
+            v[e] = c.x; R[e] = c.y;
+        }
+        uint32_t tgt[TAX ? kE : 1], ptax[TAX ? kE : 1];
+        if constexpr (TAX) {
+#pragma unroll
+            for (uint32_t e = 0; e < kE; ++e) tgt[e] = v[e] != kGwNone ? tab.gwDir[v[e] >> tab.gwDirShift] : 0u;
+        }
+        for (uint32_t d = 1; d < maxWin; ++d) {
+            uint2 kc[kE]; uint32_t o[kE];
+            bool chain = false;
+#pragma unroll
+            for (uint32_t e = 0; e < kE; ++e) {
+                o[e] = gw_slot<LOG2S>(v[e] - d);                   // (v - d is never kGwNone: numbers start at gwGap >= maxWin)
+                kc[e] = *reinterpret_cast<const uint2*>(base + o[e]);
+                if (v[e] == kGwNone) kc[e].x = kGwNone;
+                chain = chain || (kc[e].x != v[e] - d && kc[e].x != kGwNone);
+            }
+            if (chain) {
+#pragma unroll
+                for (uint32_t e = 0; e < kE; ++e)
+                    while (kc[e].x != v[e] - d && kc[e].x != kGwNone) { o[e] = (o[e] + 8u) & kByteMask; kc[e] = *reinterpret_cast<const uint2*>(base + o[e]); }
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < kE; ++e)
+                if (kc[e].x == v[e] - d) R[e] = ((R[e] & 0xFFFFu) + kc[e].y) | (d << 16);
+        }
+        if constexpr (TAX) {
+            // (a directory entry names the target of its block's FIRST number: the few numbers behind a target boundary inside a block move on)
+#pragma unroll
+            for (uint32_t e = 0; e < kE; ++e) {
+                uint32_t thi = v[e] != kGwNone ? tab.gwBase[tgt[e] + 1] : 0u;
+                while (v[e] != kGwNone && v[e] >= thi) { ++tgt[e]; thi = tab.gwBase[tgt[e] + 1]; }
+                ptax[e] = v[e] != kGwNone ? taxkey[tgt[e]] : 0u;
+            }
+        }
+        // ---- 4. K rounds (gw_pick's, over the block)
+        uint32_t live = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < kE; ++e) {
+            bool ok = v[e] != kGwNone;
+            if constexpr (TAX) ok = ok && ptax[e] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
+            live |= ok ? (1u << e) : 0u;
+        }
+        uint32_t strong = 0;
+        for (uint32_t rnd = 0; rnd < K; ++rnd) {
+            uint32_t hh = 0, hv = kGwNone, hd = 0, hg = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < kE; ++e) {
+                const uint32_t h = R[e] & 0xFFFFu;
+                const bool take = ((live >> e) & 1u) && (h > hh || (h == hh && v[e] < hv));
+                if (take) { hh = h; hv = v[e]; hd = R[e] >> 16; if constexpr (TAX) hg = ptax[e]; }
+            }
+            const uint32_t mh = block_max(hh);
+            if (mh == 0) break;                                    // (block-uniform)
+            const uint32_t mv = block_min(hh == mh ? hv : kGwNone);
+            if (hh == mh && hv == mv) { winS[rnd][0] = mv; winS[rnd][1] = mh; winS[rnd][2] = hd; winS[rnd][3] = hg; }   // (distinct numbers: one thread)
+            if constexpr (TAX) {
+                __syncthreads();
+                const uint32_t g = winS[rnd][3];
+#pragma unroll
+                for (uint32_t e = 0; e < kE; ++e) if (ptax[e] == g) live &= ~(1u << e);
+            } else {
+                const uint32_t from = mv - tab.gwGap, span = 2u * tab.gwGap;
+#pragma unroll
+                for (uint32_t e = 0; e < kE; ++e) if (v[e] - from <= span) live &= ~(1u << e);
+            }
+            strong += mh >= 2 ? 1u : 0u;
+        }
+        __syncthreads();
+        // ---- 5. the winners' targets, the candidates (wave 0: lane i holds winner i)
+        if (wave == 0) {
+            const bool mineW = lane < kLaneK && lane < K;
+            const uint32_t wv = mineW ? winS[lane & (kLaneK - 1u)][0] : kGwNone, wh = mineW ? winS[lane & (kLaneK - 1u)][1] : 0u, wd = mineW ? winS[lane & (kLaneK - 1u)][2] : 0u;
+            uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
+            if (wv != kGwNone) tab.gw_target_bounds(wv, wt, wlo, whi);
+            uint32_t pickLo[kLaneK], pickHi[kLaneK];
+            const bool again = gw_winners_out<TAX>(lane, K, wv, wh, wd, wt, wlo, whi, cands + (size_t)q * K, pickLo, pickHi);
+            if (lane == 0) {
+                // two winners of one target, or places left for candidates with a single hit (filtered away): the exact wave kernel
+                if (again || strong < K) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+                else ws.qflag[q] = kFlagDone;
+            }
+        }
+        __syncthreads();                                           // (the winners and the table are the next read's from here)
+    }
+}
+
 static uint32_t gw_env(const char* name, uint32_t dflt)
 {
     const char* e = std::getenv(name);
@@ -1642,6 +1845,18 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             hipLaunchKernelGGL((gw_sorted_cands_kernel<false, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
             hipLaunchKernelGGL((gw_sorted_cands_kernel<false, true>), dim3(std::min<uint32_t>(grid, 512u)), dim3(1024), 0, st, b, tab, ws, maxCand, taxkey, c);
         }
+    } else if (stage == 5) {
+        // counting by a block per read for the sorted class' lists of up to kGwBlockMax numbers: three instances by list length, grids
+        // in shares of what a CU holds of each (18 / 36 / 72 KB of LDS per block)
+        auto blk = [&](auto log2s, auto threads, uint32_t perCu, uint32_t minN2) {
+            constexpr uint32_t L = decltype(log2s)::value, T = decltype(threads)::value;
+            const uint32_t grid = std::min<uint32_t>(256u * perCu, b.n);
+            if (taxkey) hipLaunchKernelGGL((gw_count_block_kernel<L, T, true>), dim3(grid), dim3(T), 0, st, b, tab, ws, maxCand, taxkey, c, minN2);
+            else        hipLaunchKernelGGL((gw_count_block_kernel<L, T, false>), dim3(grid), dim3(T), 0, st, b, tab, ws, maxCand, taxkey, c, minN2);
+        };
+        blk(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 256>{}, 16u, 0u);
+        blk(std::integral_constant<uint32_t, 12>{}, std::integral_constant<uint32_t, 256>{}, 8u, 2048u);
+        blk(std::integral_constant<uint32_t, 13>{}, std::integral_constant<uint32_t, 512>{}, 4u, 4096u);
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
         const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);

@@ -148,7 +148,7 @@ struct Workspace {           // device buffers sized by the host for this batch
                              // hands their filtered parts (bigPool, cursor midCount[11]) to big_count_kernel (midCount[10] / [12], lists 7 / 8)
     uint32_t* sliceFill;     // [waves of big_filter_kernel] entries each wave's pool slice holds after the first instance (nullptr: single instance)
     uint64_t* bigPool;       // [bigPoolCap] filtered locations of a batch
-    uint32_t* sideList;      // [4][n] compact store: record numbers (list 6 / 7) of the reads gw_filter_stream_kernel takes ([0], length midCount[12]), of the
+    uint32_t* sideList;      // [5][n] ([4]: the sorted class' lists gw_count_block_kernel takes, midCount[19]) compact store: record numbers (list 6 / 7) of the reads gw_filter_stream_kernel takes ([0], length midCount[12]), of the
                              // filtered lists of 257 .. 512 ([1], midCount[14]) and 513 .. 1024 numbers ([2], midCount[15]) and of the sorted ones ([3], midCount[13])
     uint32_t* bigPool2;      // [bigPoolCap] compact store: the filtered lists that are sorted (gw_sort.hip), at their pool offsets
     uint32_t* orderScratch;  // compact store, batches up to 2^20 reads: scratch of launch_gw_order for the stream filter's list (3 n words + orderTemp bytes); nullptr: no ordering
@@ -165,6 +165,7 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint64_t* stats;         // [8]        batch statistics (on demand)
     // host side only: the context's grid tuning switches (mc_set_tuning; 0 = default) -- per context, never process-wide
     int32_t   filterLdsPad = 0;
+    int32_t   gwBlock = 1;        // gw_count_block_kernel takes the sorted class' lists that fit a block's LDS table (0: all of them are sorted)
     int32_t   filterBpc = 0, countBpc = 0, gwDiag = 0, gwFuse = 1;   // gwFuse: gw_filter_count_kernel (1) or gw_filter_kernel + gw_count_kernel (0)
 };
 

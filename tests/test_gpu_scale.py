@@ -324,10 +324,17 @@ def test_long_reads_length_distribution_against_oracle(table33):
     cands, counts, _ = db.query(reads)
     db.timing(False)
     assert db.timing_get("gw_sort")[1] > 0 and db.timing_get("gw_sorted_cands")[1] > 0      # the sorted path ran
+    assert db.timing_get("gw_count_block")[1] > 0                                           # ... and the block counting before it
     assert counts.max() > 20_000, counts.max()
+    # once more with every list of the sorted class sorted (round 3's path): the same candidates
+    db.set_tuning("gw_block", 0)
+    cands0, counts0, _ = db.query(reads)
+    db.set_tuning("gw_block", 1)
+    assert np.array_equal(counts, counts0)
     for i in range(n):
         _, e = odb.query(reads[i], b"", K, 0, 0)
         _check(cands[i], e, K, (i, int(lens[i]), counts[i]))
+        _check(cands0[i], e, K, ("sorted", i, int(lens[i]), counts[i]))
     odb.close()
 
 
@@ -431,9 +438,11 @@ def test_sorted_path_strain_rich_long_reads_against_oracle(tmp_path, K, lowest, 
     bld.write(name, [(1, 1, 20, "root"), (500, 1, 6, "genus a"), (501, 1, 6, "genus b")] + [(1000 + i, 500 + i % 2, 4, f"sp{i}") for i in range(5)])
     bld.free()
     reads = []
-    for i in range(160):
+    for i in range(240):
         g = genomes[int(rng.integers(len(genomes)))]
-        L = int(min(g.size - 1, rng.choice([700, 1500, 3000, 6000, 12_000, 19_000])))
+        # (the last 80: reads of 7 .. 20 windows on the small strain groups -- lists gw_count_block_kernel's tables hold)
+        L = int(min(g.size - 1, rng.choice([700, 1500, 3000, 6000, 12_000, 19_000]) if i < 160 else rng.choice([700, 900, 1200, 1500, 2200])))
+        if i >= 160: g = genomes[int(rng.integers(85, len(genomes)))]
         p = int(rng.integers(0, g.size - L))
         r = synth.mutate(rng, g[p:p + L], float(rng.choice([0.0, 0.02, 0.075])))
         if i % 5 == 0:                                            # chimeras: two genomes' pieces in one read
@@ -447,8 +456,12 @@ def test_sorted_path_strain_rich_long_reads_against_oracle(tmp_path, K, lowest, 
     cands, counts, _ = db.query(reads, lowest=lowest)
     db.timing(False)
     assert db.timing_get("gw_sorted_cands")[1] > 0 and counts.max() > 30_000, counts.max()
+    assert db.timing_get("gw_count_block")[1] > 0
+    db.set_tuning("gw_block", 0)                                  # every list of the sorted class through the sort: the same candidates
+    cands0, _, _ = db.query(reads, lowest=lowest)
     db.close()
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, len(r), counts[i]))
+        _check(cands0[i], e, K, ("sorted", i, len(r), counts[i]))
     odb.close()
