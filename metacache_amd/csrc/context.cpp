@@ -568,6 +568,15 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
     uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
     if (!counterCopied) HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    {   // MC_GW_DIAG=1: the batch's work-list counters on stderr (the classes of the filtered path)
+        static const bool diag = [] { const char* e = std::getenv("MC_GW_DIAG"); return e && e[0] == '1'; }();
+        if (diag) {
+            uint32_t mc[32];
+            HIP_TRY(ctx, hipMemcpy(mc, ws.midCount, sizeof mc, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[gw diag] n %u filtered %u | stream filter %u | counted apart: 257..512 %u, 513..1024 %u | block-counted class %u | sorted %u\n",
+                         n, mc[9], mc[12], mc[14], mc[15], mc[19], mc[13]);
+        }
+    }
     if (!*nsorted) return MC_OK;
     if ((rc = ensure(ctx, P.bBigPool2, poolEntries * 4))) return rc;
     ws.bigPool2 = (uint32_t*)P.bBigPool2.p;
@@ -763,7 +772,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
         if (ctx->fuseLane) {
             ScopedTimer t(ctx, "sketch_probe", st);
-            launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, st);
+            launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st);
         } else {
             { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
             { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }

@@ -142,7 +142,7 @@ struct mc_ctx {
                                            // 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy), 7 % faster on
                                            // strain-rich tables -- off by default
 
-    int gwBlock = 1;          // mc_set_tuning "gw_block": counting by a block per read for the sorted class' shorter lists (0 = off: everything is sorted)
+    int gwBlock = 0;          // mc_set_tuning "gw_block": counting by a block per read for the sorted class' shorter lists (0 = off: everything is sorted)
     int filterBpc = 0, countBpc = 0, gwDiag = 0, gwFuse = 1, filterLdsPad = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), diagnostic variant of gw_filter_kernel -- this context only
 
     uint64_t loadStats[4] = {0, 0, 0, 0};  // mc_load_stats: bytes read from the database files, nanoseconds of the load, of its index pass, the feeder waited for the readers

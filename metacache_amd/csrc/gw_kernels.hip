@@ -829,7 +829,7 @@ struct GwPend {
 // LONG (first instance's table only): the list may hold up to 2^LOG2S numbers as long as no more than half of them are DISTINCT (a filtered
 // list of 400 numbers has about 100 distinct ones); a list with more goes to the exact wave kernel.
 template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, class GetV>
-__device__ __forceinline__ void gw_count_read(const uint32_t q, const uint32_t w, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
+__device__ __forceinline__ bool gw_count_read(const uint32_t q, const uint32_t w, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
                                               uint2* slots, uint32_t* ck, uint64_t* T, const uint32_t lane, const uint32_t grp, const uint32_t sub4,
                                               const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab, const Workspace& ws,
                                               mc_candidate_dev* __restrict__ cands, const uint4* __restrict__ work6, GwPend& P)
@@ -877,11 +877,10 @@ __device__ __forceinline__ void gw_count_read(const uint32_t q, const uint32_t w
     C = __builtin_amdgcn_readfirstlane(C);
     wave_lds_sync();
     if constexpr (LONG) {
-        if (C > kList) {                                           // more distinct numbers than the table is made for (the neighbour lookups need free slots): the exact wave kernel
-            if constexpr (DEFER) P.template finish<TAX>(lane, K, tab, ws, cands);
-            if (lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
+        if (C > kList) {                                           // more distinct numbers than the table is made for (the neighbour lookups need free slots):
+            if constexpr (DEFER) P.template finish<TAX>(lane, K, tab, ws, cands);   // the caller sends the list on (false)
             wave_lds_sync();
-            return;
+            return false;
         }
     }
     auto pick = [&](auto perc) {
@@ -902,7 +901,7 @@ __device__ __forceinline__ void gw_count_read(const uint32_t q, const uint32_t w
             P.pend = true; P.q = q; P.wv = wv; P.wh = wh; P.wd = wd;
             P.dir = wv != kGwNone ? tab.gwDir[wv >> tab.gwDirShift] : 0u;
             wave_lds_sync();
-            return;
+            return true;
         }
     }
     {
@@ -998,6 +997,7 @@ __device__ __forceinline__ void gw_count_read(const uint32_t q, const uint32_t w
     }
     if (done && lane == 0) ws.qflag[q] = kFlagDone;
     wave_lds_sync();
+    return true;
 }
 
 }  // namespace
@@ -1154,8 +1154,18 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_simple_kernel
         if (here && n2 <= kKeep) {
             if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
             wave_lds_sync();
-            gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
+            const bool counted = gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
                                         reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, work, P);
+            if (!counted) {
+                // more than 256 DISTINCT numbers among the kept ones (1 read in 60 at RefSeq scale): the list -- still in LDS -- goes through the
+                // pool to gw_count_kernel<10> like the lists of 257 .. 512 numbers round 3's filter left (the exact wave kernel took them: 0.5 ms
+                // per 5 x 10^6 reads).  (Room: the slice holds kGwRounds x 16 + 64 numbers more, checked above.)
+#pragma unroll
+                for (uint32_t r = 0; r < kKeep / 64; ++r) if (r * 64 + lane < n2) slice[sliceUsed + r * 64 + lane] = kept[r * 64 + lane];
+                if (lane == 0) outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin);
+                sliceUsed += n2;
+                wave_lds_sync();
+            }
             continue;
         }
         if (here) {
@@ -1345,8 +1355,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         if (here && n2 <= kKeep) {
             if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
             wave_lds_sync();                                       // every lane's tests of the filter bits before the slot table takes their place
-            gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
+            const bool counted = gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
                                         reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, work, P);
+            if (!counted && lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }   // (more than 256 distinct numbers: the exact wave kernel)
         } else {
             if (here) {                                            // the first 256 in front of the rest
 #pragma unroll
@@ -1583,7 +1594,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
 // reads of 800 bp and more -- WITHOUT the sort, by gw_count_kernel's method and a BLOCK per read.  A filtered list holds every location
 // about four times (the read's features that hit one window of a target), and everything after the counting is per DISTINCT number:
 //   1. every number is counted in the block's LDS table of {number, count} slots (compare-and-swap claims a slot, linear probing);
-//   2. the occupied slots are listed (one 16-bit slot number each), one distinct number per thread and step from here on;
+//   2. the thread that claimed a slot lists it (one 16-bit slot number each): one distinct number per thread and step from here on;
 //   3. the thread that holds number g adds the counts of g - 1 .. g - (maxWindowsInRange - 1): the hits of the window range that ENDS
 //      in g (candidate_generation.hpp:47-108 evaluates exactly these ranges; the first to reach a target's maximum has the smallest end) --
 //      D - 1 table lookups per distinct number where the sort moved every number through eight radix passes;
@@ -1591,8 +1602,9 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
 //      between two targets: it lies inside its target) or taxon struck -- gw_pick's rounds, and its exactness argument, on a block;
 //   5. the K winners' targets are looked up, two winners of one target or fewer than K winners with two hits send the read to the
 //      exact wave kernel (as the scan of the sorted lists does).
-// A list with more distinct numbers than half the table's slots (the neighbour lookups need free slots to end at) joins the sorted
-// class after all: one atomic on its counter.  Instances by list length: 2^11 slots (18 KB of LDS: eight blocks per CU), 2^12, 2^13.
+// An instance takes the lists of up to HALF its slots (the neighbour lookups need free slots to end at; configs[4]'s reads at 7.5 %
+// substitutions hold a number 1.5 times on average: a third of the slots are taken).  Instances: 2^11 slots (18 KB of LDS: eight blocks
+// per CU) for up to 1 024 numbers, 2^12, 2^13, 2^14 (144 KB: one block of sixteen waves per CU) for up to 8 192.
 // ================================================================================================
 template <uint32_t LOG2S, uint32_t THREADS, bool TAX>
 __global__ __launch_bounds__(THREADS) void gw_count_block_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
@@ -1603,7 +1615,7 @@ __global__ __launch_bounds__(THREADS) void gw_count_block_kernel(BatchView b, De
     static_assert(kE >= 1 && kE <= 16 && kSlots <= 65536, "one 16-bit slot number per distinct number, a few of them per thread");
     __shared__ __attribute__((aligned(16))) uint2 slotS[kSlots];
     __shared__ uint16_t ckS[kCap];
-    __shared__ uint32_t ctrS[2];                                   // distinct numbers claimed; occupied slots listed
+    __shared__ uint32_t ctrS[1];                                   // distinct numbers (slots claimed)
     __shared__ uint32_t redS[4][kWaves];
     __shared__ uint32_t winS[kLaneK][4];                           // the rounds' winners: number, hits, end - begin, taxon
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1635,52 +1647,48 @@ __global__ __launch_bounds__(THREADS) void gw_count_block_kernel(BatchView b, De
         red = (red + 1u) & 3u;
         return r;
     };
+    // (every instance walks the whole class list and takes the lists of its lengths: n2 in (minN2, kCap] -- at most half the slots are
+    // ever taken, whatever the list holds; the next record is on its way while this one is worked on)
+    auto load_rec = [&](uint32_t i) -> uint4 { return i < nmine ? work[side[i]] : make_uint4(0, 0, 0, 0); };
+    uint4 recNext = load_rec(blockIdx.x);
     for (uint32_t i = blockIdx.x; i < nmine; i += gridDim.x) {
-        const uint32_t w = side[i];
-        const uint4 rec = work[w];
+        const uint4 rec = recNext;
+        recNext = load_rec(i + gridDim.x);
         const uint32_t q = rec.x, n2 = rec.z, maxWin = rec.w;
-        if (n2 <= minN2 || n2 > kSlots) continue;                  // (block-uniform) another instance's list
+        if (n2 <= minN2 || n2 > kCap) continue;                    // (block-uniform) another instance's list
         {
             uint4* k4 = reinterpret_cast<uint4*>(slotS);
             for (uint32_t j = tid; j < kSlots / 2; j += THREADS) k4[j] = make_uint4(kGwNone, 0u, kGwNone, 0u);
         }
-        if (tid < 2) ctrS[tid] = 0u;
+        if (tid == 0) ctrS[0] = 0u;
         if (tid < kLaneK) { winS[tid][0] = kGwNone; winS[tid][1] = 0u; winS[tid][2] = 0u; winS[tid][3] = 0u; }
         __syncthreads();
-        // ---- 1. counting
+        // ---- 1. + 2. counting; the thread that claims a slot lists it (one LDS atomic per wave and step reserves the places)
         const uint32_t* __restrict__ src = pool + rec.y;
-        uint32_t claimed = 0;
-        for (uint32_t j = tid; j < n2; j += THREADS) {
-            const uint32_t g = src[j];
-            uint32_t off = gw_slot<LOG2S>(g), old;
-            for (;;) {
-                old = atomicCAS(key_at(off), kGwNone, g);
-                if (old == kGwNone || old == g) break;
-                off = (off + 8u) & kByteMask;
+        for (uint32_t j0 = 0; j0 < n2; j0 += THREADS) {
+            const uint32_t j = j0 + tid;
+            bool claimed = false;
+            uint32_t off = 0;
+            if (j < n2) {
+                const uint32_t g = src[j];
+                off = gw_slot<LOG2S>(g);
+                uint32_t old;
+                for (;;) {
+                    old = atomicCAS(key_at(off), kGwNone, g);
+                    if (old == kGwNone || old == g) break;
+                    off = (off + 8u) & kByteMask;
+                }
+                atomicAdd(key_at(off) + 1, 1u);
+                claimed = old == kGwNone;
             }
-            atomicAdd(key_at(off) + 1, 1u);
-            claimed += old == kGwNone ? 1u : 0u;
-        }
-        claimed = wave_sum_u32(claimed);
-        if (lane == 0 && claimed) atomicAdd(&ctrS[0], claimed);
-        __syncthreads();
-        const uint32_t C = ctrS[0];
-        if (C > kCap) {                                            // too many distinct numbers for this table: the sort takes the list
-            if (tid == 0) { const uint32_t at = atomicAdd(&ws.midCount[13], 1u); ws.sideList[(size_t)3 * b.n + at] = w; }
-            __syncthreads();                                       // (everybody has read C before the counters are reset)
-            continue;
-        }
-        // ---- 2. the occupied slots
-        for (uint32_t s0 = 0; s0 < kSlots; s0 += THREADS) {
-            const uint32_t sl = s0 + tid;
-            const bool occ = slotS[sl].x != kGwNone;
-            const uint64_t m = __ballot(occ);
+            const uint64_t m = __ballot(claimed);
             uint32_t wb = 0;
-            if (lane == 0 && m) wb = atomicAdd(&ctrS[1], (uint32_t)__popcll(m));
+            if (lane == 0 && m) wb = atomicAdd(&ctrS[0], (uint32_t)__popcll(m));
             wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
-            if (occ) ckS[wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)sl;
+            if (claimed) ckS[wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(off >> 3);
         }
         __syncthreads();
+        const uint32_t C = ctrS[0];                                // distinct numbers: <= n2 <= kCap
         // ---- 3. ranges that end in this thread's numbers: hits | (end - begin) << 16
         uint32_t v[kE], R[kE];
 #pragma unroll
@@ -1846,8 +1854,8 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             hipLaunchKernelGGL((gw_sorted_cands_kernel<false, true>), dim3(std::min<uint32_t>(grid, 512u)), dim3(1024), 0, st, b, tab, ws, maxCand, taxkey, c);
         }
     } else if (stage == 5) {
-        // counting by a block per read for the sorted class' lists of up to kGwBlockMax numbers: three instances by list length, grids
-        // in shares of what a CU holds of each (18 / 36 / 72 KB of LDS per block)
+        // counting by a block per read for the sorted class' lists of up to kGwBlockMax numbers: four instances by list length, grids
+        // in shares of what a CU holds of each (18 / 36 / 72 / 144 KB of LDS per block)
         auto blk = [&](auto log2s, auto threads, uint32_t perCu, uint32_t minN2) {
             constexpr uint32_t L = decltype(log2s)::value, T = decltype(threads)::value;
             const uint32_t grid = std::min<uint32_t>(256u * perCu, b.n);
@@ -1855,8 +1863,9 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             else        hipLaunchKernelGGL((gw_count_block_kernel<L, T, false>), dim3(grid), dim3(T), 0, st, b, tab, ws, maxCand, taxkey, c, minN2);
         };
         blk(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 256>{}, 16u, 0u);
-        blk(std::integral_constant<uint32_t, 12>{}, std::integral_constant<uint32_t, 256>{}, 8u, 2048u);
-        blk(std::integral_constant<uint32_t, 13>{}, std::integral_constant<uint32_t, 512>{}, 4u, 4096u);
+        blk(std::integral_constant<uint32_t, 12>{}, std::integral_constant<uint32_t, 256>{}, 8u, 1024u);
+        blk(std::integral_constant<uint32_t, 13>{}, std::integral_constant<uint32_t, 512>{}, 4u, 2048u);
+        blk(std::integral_constant<uint32_t, 14>{}, std::integral_constant<uint32_t, 1024>{}, 2u, 4096u);
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
         const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);

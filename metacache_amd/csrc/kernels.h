@@ -165,7 +165,7 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint64_t* stats;         // [8]        batch statistics (on demand)
     // host side only: the context's grid tuning switches (mc_set_tuning; 0 = default) -- per context, never process-wide
     int32_t   filterLdsPad = 0;
-    int32_t   gwBlock = 1;        // gw_count_block_kernel takes the sorted class' lists that fit a block's LDS table (0: all of them are sorted)
+    int32_t   gwBlock = 0;        // gw_count_block_kernel takes the sorted class' lists that fit a block's LDS table (0: all of them are sorted)
     int32_t   filterBpc = 0, countBpc = 0, gwDiag = 0, gwFuse = 1;   // gwFuse: gw_filter_count_kernel (1) or gw_filter_kernel + gw_count_kernel (0)
 };
 
@@ -201,7 +201,7 @@ void launch_table_values_compact(const uint32_t* keys, const uint8_t* sizes, uin
                                  const uint8_t* vals, uint32_t tb, uint64_t totalFileVals, uint32_t* dst32, GwLayout gw, unsigned int* rangeErr, hipStream_t st);
 void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, int quadMode, hipStream_t st);
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                              const uint32_t* taxkey, void* cands, hipStream_t st);
+                              const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st);
 // up to 16 candidate lists per read ([n][K] each, device), merged in list order through the CPU's top-list insert; K <= 4.  -1: not supported
 int launch_merge_parts(const void* const* lists, uint32_t nlists, uint32_t n, uint32_t K, const uint32_t* taxkey, void* out, hipStream_t st);
 void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st);

@@ -1864,6 +1864,7 @@ __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, ui
 // Both halves in one kernel: sketching is ALU work (rolling k-mers, hash, 16-entry insertion chain), probing is waiting for random
 // HBM lines; with waves of one CU in different phases the two overlap instead of running one after the other.  The window
 // sketches still go through ws.features (a lane reads back what it wrote itself; they are also the MC_WANT_FEATURES output).
+template <bool QUAD>
 __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, uint32_t K,
                                                                        const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
@@ -1872,15 +1873,18 @@ __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView
     uint32_t flag = kFlagDone;
     if (q < b.n) { flag = sketch_lane_one(b, sp, ws.winOff, ws.features, q); if (flag != kFlagProbe) ws.qflag[q] = flag; }
     __threadfence_block();                                        // own feature stores before own feature loads
-    probe_cands_one<false>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
+    probe_cands_one<QUAD>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
 }
 
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                              const uint32_t* taxkey, void* cands, hipStream_t st)
+                              const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st)
 {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(sketch_probe_lane_kernel, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
-                       taxkey, (mc_candidate_dev*)cands);
+    const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
+    if (quad) hipLaunchKernelGGL(sketch_probe_lane_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
+                                 taxkey, (mc_candidate_dev*)cands);
+    else      hipLaunchKernelGGL(sketch_probe_lane_kernel<false>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
+                                 taxkey, (mc_candidate_dev*)cands);
 }
 
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st)
