@@ -168,7 +168,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->loadFactor = (cfg->max_load_factor > 0.05f && cfg->max_load_factor <= 0.99f) ? cfg->max_load_factor : 0.3f;
     ctx->parts.resize(cfg->num_parts);
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
-    if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1';           // experiment switch
+    if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1' ? 1 : 0;   // (default: by table size)
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
     if (const char* e = std::getenv("MC_COMPACT_LOCATIONS")) ctx->compactAllowed = e[0] != '0';   // tests / tuning
     if (const char* e = std::getenv("MC_BIG_MIN")) ctx->bigMin = (uint32_t)std::max(0, std::atoi(e));   // tests / tuning
@@ -770,14 +770,22 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
         HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
-        if (ctx->fuseLane) {
-            ScopedTimer t(ctx, "sketch_probe", st);
-            launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st);
+        // sketching + probing in ONE kernel where the lookups wait for HBM (tables beyond the infinity cache: quad-cooperative fetches) -- the
+        // sketching of some waves runs under the waiting of others (5.27 -> 5.08 ms per 5 x 10^6 reads at full scale); small tables keep
+        // the two kernels (the ALU phase at the probe kernel's occupancy cost 5 % on configs[1]).  "lane_fusion" / MC_LANE_FUSION: 0 / 1 force it.
+        // (A key shard's side of Mode K masks the features it does not own between the two: not fused.)
+        const bool maskFeatures = wantPartial && !wantFeatures && ctx->cfg.key_shard_count > 1;
+        const bool quadTable = ctx->quadLookup >= 0 ? ctx->quadLookup != 0 : (uint64_t)tab.nbuckets * 64ull > (1ull << 30);
+        const bool fuseSketch = !maskFeatures && (ctx->fuseLane >= 0 ? ctx->fuseLane != 0 : quadTable);
+        if (fuseSketch) {
+            { ScopedTimer t(ctx, "sketch_probe", st); launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st); }
+            { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
+            { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, ctx->quadLookup, st); }
         } else {
             { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
             { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
             // a key shard's side of Mode K: only the features this shard owns are looked up (the others cannot be in its table)
-            if (wantPartial && !wantFeatures && ctx->cfg.key_shard_count > 1) {
+            if (maskFeatures) {
                 ScopedTimer t(ctx, "mask_features", st);
                 launch_mask_foreign_features(ws.features, ws.winOff + n, sp.s, nfeat, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count, st);
             }
@@ -1152,6 +1160,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
     else if (n == "filter_lds_pad") ctx->filterLdsPad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 120 << 10));   // bytes of unused dynamic LDS per filter block
+    else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_block") ctx->gwBlock = value != 0;                       // gw_count_block_kernel for the sorted class' lists of up to kGwBlockMax numbers (default on)
     else if (n == "gw_fuse") ctx->gwFuse = (int)value;                         // counting of short filtered lists inside the filter kernel: 0 = apart, 1 (default) = fused, 2 = fused + software pipeline (four waves per SIMD: measured slower), 3 = the same compiled for five waves per SIMD (spills)
     else if (n == "gw_diag") {                                                 // timing experiments on gw_filter_kernel (WRONG results): only with MC_ALLOW_DIAG=1 in the environment

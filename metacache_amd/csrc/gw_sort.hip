@@ -21,12 +21,12 @@ namespace {
 // segment i = the list of the i-th record of the sorted class (ws.sideList[3], longest list first: launch_gw_order)
 constexpr uint32_t kGwLdsSortMax = 16384;                 // longest list gw_lds_sort_kernel takes (64 KB of LDS)
 struct SegOffset {
-    const uint4* rec; const uint32_t* side; const uint32_t* midCount; uint32_t end, minLen, maxLen;   // lists outside (minLen, maxLen] are somebody else's: empty segments
+    const uint4* rec; const uint32_t* side; const uint32_t* midCount; uint32_t end, minLen;   // lists of up to minLen numbers are somebody else's: empty segments
     __device__ uint32_t operator()(uint32_t i) const
     {
         if (i >= midCount[13]) return 0u;
         const uint4 r = rec[side[i]];
-        return r.y + ((end && r.z > minLen && r.z <= maxLen) ? r.z : 0u);
+        return r.y + ((end && r.z > minLen) ? r.z : 0u);
     }
 };
 
@@ -120,37 +120,11 @@ int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_
         hipLaunchKernelGGL((gw_lds_sort_kernel<1024, kGwLdsSortMax>), dim3(std::min<uint32_t>(nseg, 256u * 4u)), dim3(1024), 0, st, ws, n, in, out, 2048u, kGwLdsSortMax);
     }
     auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
+    auto beg = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u, libMin});
+    auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u, libMin});
     // (the library's default configuration: a block of 256 threads sorts up to 4 352 numbers in registers and LDS, longer lists in passes
-    // through HBM.  Larger single-block limits FOR ALL LISTS measured worse on configs[4]'s reads at full scale: 1024 x 8: 6.0 ms, 256 x 32: 7.0 ms,
-    // default 5.2.)  The few LONGEST lists are what the call waits for -- 4 400 lists beyond 8 192 numbers (reads of 5 kbp and more: 90 of the
-    // 235 x 10^6 numbers of a batch) took 3.3 of its 5.3 ms, one block of 256 threads walking each through five passes -- so they get a call
-    // of their own: blocks of 1 024 threads, 8 bits per pass.  MC_GW_SORT_SPLIT=<numbers> moves the border (0: one call for all).
-    static const uint32_t split = [] { const char* e = std::getenv("MC_GW_SORT_SPLIT"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 8192u; }();
-    const unsigned int poolN = (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull);
-    if (split == 0) {
-        auto beg = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u, libMin, 0xFFFFFFFFu});
-        auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u, libMin, 0xFFFFFFFFu});
-        return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, poolN, nseg, beg, end, 0u, endBit, st);
-    }
-    using BigConfig = rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<1024, 8>, rocprim::DisabledWarpSortConfig, false>;
-    auto begS = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u, libMin, std::max(split, libMin)});
-    auto endS = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u, libMin, std::max(split, libMin)});
-    auto begB = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 0u, std::max(split, libMin), 0xFFFFFFFFu});
-    auto endB = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u, std::max(split, libMin), 0xFFFFFFFFu});
-    if (!temp) {                                               // size query: the larger of the two calls' needs
-        size_t a = 0, b2 = 0;
-        int rc = (int)rocprim::segmented_radix_sort_keys(nullptr, a, in, out, poolN, nseg, begS, endS, 0u, endBit, st);
-        if (rc) return rc;
-        rc = (int)rocprim::segmented_radix_sort_keys<BigConfig>(nullptr, b2, in, out, poolN, nseg, begB, endB, 0u, endBit, st);
-        tempBytes = std::max(a, b2);
-        return rc;
-    }
-    // the longest lists first (the work list is in descending order of length: they are its head), the many short ones fill the device behind them
-    size_t tb = tempBytes;
-    int rc = (int)rocprim::segmented_radix_sort_keys<BigConfig>(temp, tb, in, out, poolN, nseg, begB, endB, 0u, endBit, st);
-    if (rc) return rc;
-    tb = tempBytes;
-    return (int)rocprim::segmented_radix_sort_keys(temp, tb, in, out, poolN, nseg, begS, endS, 0u, endBit, st);
+    // through HBM.  Larger single-block limits measured worse on configs[4]'s reads at full scale: 1024 x 8: 6.0 ms, 256 x 32: 7.0 ms, default 5.2)
+    return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull), nseg, beg, end, 0u, endBit, st);
 }
 
 }  // namespace mcamd

@@ -1272,10 +1272,9 @@ constexpr uint32_t kChunkWins = MC_CHUNK_WINS;   // windows per chunk lane of a 
 // Long single reads (> kLaneMaxLen) are cut into chunks of kChunkWins windows; every chunk is sketched and probed by its own
 // lane (chunk_sketch_kernel / chunk_probe_kernel), so a 19 000 bp read keeps 43 lanes busy instead of one wave for 170 windows.
 // Here: the read's lane appends its chunk records {query, chunk} to the work list (one atomic per wave).
-__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, Workspace ws)
+// (the wave's lanes with long reads append their chunk records to the work list; returns this lane's number of chunks -- 0: a read of its own)
+__device__ __forceinline__ uint32_t lane_chunk_records(const BatchView& b, const SketchParams& sp, const Workspace& ws, const uint32_t q, const uint32_t lane)
 {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
     const bool chunkable = (sp.stride & 3u) == 0 && ws.chunkList != nullptr;    // chunk starts stay 4-byte aligned
     uint32_t nch = 0;
     if (q < b.n && chunkable) {
@@ -1304,6 +1303,13 @@ __global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchPar
             if (r < total) ws.chunkList[base + r] = make_uint2(oq, r - first);
         }
     }
+    return nch;
+}
+__global__ __launch_bounds__(256) void sketch_lane_kernel(BatchView b, SketchParams sp, Workspace ws)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nch = lane_chunk_records(b, sp, ws, q, lane);
     if (q >= b.n) return;
     if (nch) {
         ws.qflag[q] = kFlagChunks;
@@ -1871,7 +1877,11 @@ __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
     uint32_t flag = kFlagDone;
-    if (q < b.n) { flag = sketch_lane_one(b, sp, ws.winOff, ws.features, q); if (flag != kFlagProbe) ws.qflag[q] = flag; }
+    const uint32_t nch = lane_chunk_records(b, sp, ws, q, threadIdx.x & 63u);   // (long reads: the chunk lanes' kernels follow this one)
+    if (q < b.n) {
+        flag = nch ? kFlagChunks : sketch_lane_one(b, sp, ws.winOff, ws.features, q);
+        if (flag != kFlagProbe) ws.qflag[q] = flag;
+    }
     __threadfence_block();                                        // own feature stores before own feature loads
     probe_cands_one<QUAD>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
 }
