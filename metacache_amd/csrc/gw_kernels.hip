@@ -102,6 +102,11 @@ struct GwBloom {
         const uint32_t h = hash(key), m = mask_of(h);
         return (bits[twice_index(seen_index(h), h)] & m) == m;
     }
+    __device__ __forceinline__ static bool seen(const uint32_t* bits, uint32_t key)     // the key was marked at all (or its bits by others)
+    {
+        const uint32_t h = hash(key), m = mask_of(h);
+        return (bits[seen_index(h)] & m) == m;
+    }
 };
 
 // What both filter kernels share: the per-read frame (block size of the keys, edge test, the pool slice) and the two phases on a
@@ -109,9 +114,11 @@ struct GwBloom {
 struct GwFrame {
     uint32_t A, D, blockMask, inner;                           // keys = number >> A; (number & blockMask) - D >= inner: within D of a block boundary
     uint32_t shv, Dsh, twoDsh;                                 // the same test in two instructions: ((number + D) << (32 - A)) < (2 D << (32 - A))
-    __device__ __forceinline__ explicit GwFrame(uint32_t maxWin)
+    // fine = true: blocks of 2^A >= D numbers only (gw_filter_stream_kernel<.., FINE>: the neighbour blocks are asked as well, no edge rule)
+    __device__ __forceinline__ explicit GwFrame(uint32_t maxWin, bool fine = false)
     {
         A = gw_block_shift(maxWin); D = maxWin > 1 ? maxWin - 1 : 0u;
+        if (fine) { A = 32u - (uint32_t)__builtin_clz((D > 1u ? D : 2u) - 1u); A = A < 8u ? 8u : A; }   // 2^A >= D; keys below 2^24
         blockMask = (1u << A) - 1u; inner = (1u << A) - 2u * D;
         const uint32_t sh = 32u - A;                           // (A <= 16: 2 D < 2^A, nothing is shifted out of 2 D)
         asm volatile("v_mov_b32 %0, %1" : "=v"(shv) : "s"(sh));   // (kept in a vector register: a VOP3 instruction reads one scalar register at most)
@@ -194,10 +201,14 @@ __device__ __forceinline__ uint32_t gw_reserve(uint32_t* shared, uint32_t tot)
     if (tot && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) at = atomicAdd(shared, tot);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
 }
-template <class Bloom>
+// FINE: the filter's blocks hold 2^A >= D numbers only -- a neighbour lies in the same block (marked twice) or in one of the two next to
+// it (seen): three lookups instead of one and an edge rule, for reads whose tens of thousands of locations leave no block of 64 D
+// numbers without a second one (gw_filter_stream_kernel<.., FINE>)
+template <class Bloom, bool FINE = false>
 __device__ __forceinline__ void gw_take(const uint32_t* bits, const GwFrame& F, GwSink& S, uint32_t v, bool valid)
 {
-    const bool keep = valid & (Bloom::twice(bits, v >> F.A) | F.edge(v));
+    const uint32_t key = v >> F.A;
+    const bool keep = valid & (FINE ? (Bloom::twice(bits, key) | Bloom::seen(bits, key - 1u) | Bloom::seen(bits, key + 1u)) : (Bloom::twice(bits, key) | F.edge(v)));
     const uint64_t m = __ballot(keep);
     if (S.shared) S.n2 = gw_reserve(S.shared, (uint32_t)__popcll(m));
     if (keep) {
@@ -208,24 +219,38 @@ __device__ __forceinline__ void gw_take(const uint32_t* bits, const GwFrame& F, 
 }
 // four numbers at a time: the four filter words are read together (one LDS round trip), no branch but the ones around the stores.
 // CHECK = false: the caller has made sure that everything this read can keep fits the slice.
-template <class Bloom, bool CHECK>
+template <class Bloom, bool CHECK, bool FINE = false>
 __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F, GwSink& S, const uint4 x, const int32_t rem)
 {
     const uint32_t v[4] = {x.x, x.y, x.z, x.w};
     uint32_t m[4], wd[4];
+    uint32_t mlo[FINE ? 4 : 1], wlo[FINE ? 4 : 1], mhi[FINE ? 4 : 1], whi[FINE ? 4 : 1];   // FINE: the "seen" words of the blocks before and behind
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t h = Bloom::hash(v[j] >> F.A);
+        const uint32_t key = v[j] >> F.A;
+        const uint32_t h = Bloom::hash(key);
         m[j] = Bloom::mask_of(h);
         wd[j] = bits[Bloom::twice_index(Bloom::seen_index(h), h)];
+        if constexpr (FINE) {
+            const uint32_t h0 = Bloom::hash(key - 1u), h1 = Bloom::hash(key + 1u);
+            mlo[j] = Bloom::mask_of(h0); wlo[j] = bits[Bloom::seen_index(h0)];
+            mhi[j] = Bloom::mask_of(h1); whi[j] = bits[Bloom::seen_index(h1)];
+        }
     }
     // (ballots of the three compares, combined on the scalar unit: a ballot of the combined condition costs two VALU instructions more)
     uint64_t km[4]; bool kb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool valid = rem > j, hit = (wd[j] & m[j]) == m[j], edge = F.edge(v[j]);
-        kb[j] = valid & (hit | edge);
-        km[j] = __ballot(valid) & (__ballot(hit) | __ballot(edge));
+        const bool valid = rem > j, hit = (wd[j] & m[j]) == m[j];
+        if constexpr (FINE) {
+            const bool lo = (wlo[j] & mlo[j]) == mlo[j], hi = (whi[j] & mhi[j]) == mhi[j];
+            kb[j] = valid & (hit | lo | hi);
+            km[j] = __ballot(valid) & (__ballot(hit) | __ballot(lo) | __ballot(hi));
+        } else {
+            const bool edge = F.edge(v[j]);
+            kb[j] = valid & (hit | edge);
+            km[j] = __ballot(valid) & (__ballot(hit) | __ballot(edge));
+        }
     }
     if (S.shared) S.n2 = gw_reserve(S.shared, (uint32_t)(__popcll(km[0]) + __popcll(km[1]) + __popcll(km[2]) + __popcll(km[3])));
     uint32_t n2 = S.n2;
@@ -241,7 +266,7 @@ __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F,
     }
     S.n2 = n2;
 }
-template <class Bloom, bool CHECK>
+template <class Bloom, bool CHECK, bool FINE = false>
 __device__ __forceinline__ void gw_take_rounds(const uint32_t* bits, const uint64_t* T, const GwFrame& F, GwSink& S, uint32_t grp, uint32_t sub4,
                                                const uint4 (&x)[kGwLoads], uint32_t nl = kGwLoads)
 {
@@ -249,7 +274,7 @@ __device__ __forceinline__ void gw_take_rounds(const uint32_t* bits, const uint6
     for (uint32_t u = 0; u < kGwLoads; ++u) {
         if (u >= nl) continue;
         const int32_t rem = (int32_t)(uint32_t)(T[u * 16 + grp] >> 40) - (int32_t)sub4;     // numbers of the round from this lane's first on
-        gw_take4<Bloom, CHECK>(bits, F, S, x[u], rem);
+        gw_take4<Bloom, CHECK, FINE>(bits, F, S, x[u], rem);
     }
 }
 
@@ -510,8 +535,14 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
 // reads: thousands to tens of thousands).  Entries in chunks of 64, rounds in batches of kGwRounds, two passes over the lists (the
 // second one finds them in the L2 / infinity cache), filters sized for tens of thousands of keys.  Same waves, same pool slices
 // (ws.sliceFill) as gw_filter_kernel, after which it runs; returns at once when the batch has no such read (midCount[10]).
-template <uint32_t WAVES, uint32_t T1LOG2, uint32_t T2LOG2>
-__global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView b, DeviceTable tab, Workspace ws)
+// Two instances by the read's locations H in (hMin, hMax].  FINE (reads beyond kGwBigH locations -- 4 kbp and more: 1.7 % of configs[4]'s
+// reads with an eighth of its locations): with tens of thousands of locations in 1.4 x 10^9 numbers every block of 64 D numbers holds a
+// second location and the block filter keeps nearly all of them (a 19 kbp read kept 10^5 of its 1.6 x 10^5: these lists were 90 of the
+// 235 x 10^6 numbers a batch sorts and 3.3 of the sort's 5.3 ms).  Their instance asks blocks of 2^A >= D numbers -- the location's own
+// ("twice") and the two next to it ("seen") -- in filters of 2^19 + 2^17 bits, one BLOCK of sixteen waves per read and CU.
+constexpr uint32_t kGwBigH = 32768;
+template <uint32_t WAVES, uint32_t T1LOG2, uint32_t T2LOG2, bool FINE = false>
+__global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t hMin, uint32_t hMax)
 {
     // One BLOCK per read: its waves share ONE pair of filters (20 KB: with a pair per wave six waves fitted a CU) and take the read's
     // entry chunks in turn -- phase A of all chunks, barrier, phase B; the kept numbers of all waves go to one list, its places
@@ -540,12 +571,13 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
         const uint4 rec = work[w];
         const uint32_t q = rec.x, fbase = rec.y, recZ = rec.z, maxWin = rec.w;
         const uint32_t nent = recZ & 0xFFFu, H = recZ >> 12;
+        if (H <= hMin || H > hMax) continue;                       // (block-uniform) the other instance's read
         {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
             for (uint32_t j = threadIdx.x; j < Bloom::kWords / 4; j += WAVES * 64) z4[j] = make_uint4(0, 0, 0, 0);
         }
         if (threadIdx.x == 0) n2S = 0u;
-        const GwFrame F(maxWin);
+        const GwFrame F(maxWin, FINE);
         // where the list goes: the first of the block's slices that can take all H numbers, else H places of the overflow region
         // (the filter keeps H at most), else what is left of the first slice (a list that outgrows it goes to the wave kernel)
         int k = -1;
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
                     const uint32_t sz = e < nent ? (ws.psize[fbase + e] & 0xFFFFu) : 0u;
                     const uint64_t pay = e < nent ? ws.ppay[fbase + e] : 0ull;
                     const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
-                    if (pass == 0) { if (sv != kGwNone) Bloom::mark(bits, sv >> F.A); } else gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
+                    if (pass == 0) { if (sv != kGwNone) Bloom::mark(bits, sv >> F.A); } else gw_take<Bloom, FINE>(bits, F, S, sv, sv != kGwNone);
                     const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
                     const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
                     for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
@@ -580,7 +612,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
                         wave_lds_sync();
                         uint4 x[kGwLoads];
                         gw_load_rounds(T, tab.values32, grp, sub4, x);
-                        if (pass == 0) gw_mark_rounds<Bloom>(bits, x, F.A); else gw_take_rounds<Bloom, true>(bits, T, F, S, grp, sub4, x);
+                        if (pass == 0) gw_mark_rounds<Bloom>(bits, x, F.A); else gw_take_rounds<Bloom, true, FINE>(bits, T, F, S, grp, sub4, x);
                         wave_lds_sync();                           // the table is rewritten by the next batch
                     }
                 }
@@ -595,6 +627,10 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
         }
         if (!fallback && k >= 0) used[k] += n2;
         __syncthreads();                                           // (the counter and the filters are reset for the next read)
+    }
+    if (threadIdx.x == 0 && ws.sliceFill) {                        // (the next instance goes on in the same slices)
+#pragma unroll
+        for (uint32_t k = 0; k < WAVES; ++k) ws.sliceFill[w0 + k] = (uint32_t)used[k];
     }
 }
 
@@ -1826,7 +1862,13 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads)
         // (a single-pass instance for reads whose numbers fit a block's registers -- eight waves of 32 entries each, phase B from the registers --
         // was measured SLOWER in front of this kernel: 5.00 against 4.60 ms per 250 000 long reads, 125 registers and idle waves at barriers; dropped)
-        hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws);
+        {
+            // the reads beyond kGwBigH locations first (one block of sixteen waves per read: blocks x 16 = the same waves, the same pool slices)
+            static const bool bigOff = [] { const char* e = std::getenv("MC_GW_BIG_OFF"); return e && e[0] == '1'; }();   // (one instance for all reads, as round 3)
+            static const uint32_t bigH = bigOff ? 0xFFFFFFFFu : gw_env("MC_GW_BIG_H", kGwBigH);
+            if (!bigOff) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3(std::max(1u, fgrid / 4)), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu);
+            hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, bigH);
+        }
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1) {
         // filtered lists up to 256 (4 KB of LDS per wave), then 257 .. 512
