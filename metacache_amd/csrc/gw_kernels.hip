@@ -1447,10 +1447,13 @@ __device__ __forceinline__ void gw_sorted_scan(const uint32_t* __restrict__ g, c
     // the lane that holds its last element (per-lane lists in target order, merged by the K rounds).
     uint32_t cT = 0xFFFFFFFFu, cHits = 0, cBeg = 0, cEnd = 0, cLo = 0, cHi = 0;   // the open target, its best range so far, its numbers (wave-uniform)
     uint32_t lowFst = 0;
+    uint32_t gnext = first + lane < end ? g[first + lane] : 0xFFFFFFFFu;      // (the next chunk's numbers are on their way while this one is scanned,
+    uint32_t dnext = gnext != 0xFFFFFFFFu ? tab.gwDir[gnext >> tab.gwDirShift] : 0u;   //  their directory entries behind them)
     for (uint32_t base = first; base < end; base += 64) {
         const uint32_t cnt = min(64u, end - base), ei = base + lane;
         const bool valid = lane < cnt;
-        const uint32_t gi = valid ? g[ei] : 0xFFFFFFFFu;
+        const uint32_t gi = gnext, di = dnext;
+        gnext = ei + 64u < end ? g[ei + 64u] : 0xFFFFFFFFu;
         ring[ei & 127u] = gi;
         wave_lds_sync();
         const uint32_t want = gi - D;
@@ -1477,7 +1480,13 @@ __device__ __forceinline__ void gw_sorted_scan(const uint32_t* __restrict__ g, c
         const bool inCur = cT != 0xFFFFFFFFu && (gi - cLo) < (cHi - cLo);
         if (valid) {
             if (inCur) { t = cT; tlo = cLo; thi = cHi; }
-            else tab.gw_target_bounds(gi, t, tlo, thi);
+            else {                                                 // (DeviceTable::gw_target_bounds with the directory entry at hand)
+                t = di;
+                const uint32_t b0 = tab.gwBase[t], b1 = tab.gwBase[t + 1], b2 = tab.gwBase[min(t + 2, tab.gwTargets)];
+                tlo = b0; thi = b1;
+                if (gi >= b1) { ++t; tlo = b1; thi = b2; }
+                while (gi >= thi) { ++t; tlo = thi; thi = tab.gwBase[t + 1]; }
+            }
         }
         // the open target ended with the previous chunk: its candidate is due (lane 0: before anything of this chunk)
         if (cT != 0xFFFFFFFFu && rdlane(t, 0) != cT && lane == 0) {
@@ -1500,6 +1509,7 @@ __device__ __forceinline__ void gw_sorted_scan(const uint32_t* __restrict__ g, c
         if (tail && (last || lane + 1u < cnt)) top_insert(top, toptax, c, K, TAX ? taxkey : nullptr, 0xFFFFFFFFu);
         cT = rdlane(c.tgt, cnt - 1u); cHits = rdlane(c.hits, cnt - 1u); cBeg = rdlane(c.beg, cnt - 1u); cEnd = rdlane(c.end, cnt - 1u);
         cLo = rdlane(tlo, cnt - 1u); cHi = rdlane(thi, cnt - 1u);
+        dnext = gnext != 0xFFFFFFFFu ? tab.gwDir[gnext >> tab.gwDirShift] : 0u;
     }
     wave_lds_sync();
 }
@@ -1867,6 +1877,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             static const bool bigOff = [] { const char* e = std::getenv("MC_GW_BIG_OFF"); return e && e[0] == '1'; }();   // (one instance for all reads, as round 3)
             static const uint32_t bigH = bigOff ? 0xFFFFFFFFu : gw_env("MC_GW_BIG_H", kGwBigH);
             if (!bigOff) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3(std::max(1u, fgrid / 4)), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu);
+            // (four waves per block and pair of filters instead of two -- 24 waves per CU: 5.01 -> 4.87 ms per 250 000 long reads: left at two)
             hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, bigH);
         }
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
