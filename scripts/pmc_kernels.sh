@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch: kernel trace + two PMC passes of the long-read bench, counters for the kernels matching $1 only
+# Kernel trace + two PMC passes (separate runs) of bench.py --long-reads, counters for the kernels matching the regular expression $1 only:
+#   gpurun -- bash scripts/pmc_kernels.sh "gw_filter_stream|gw_sorted_cands"     -> gpurun_out/pmc_block/summary.txt
 set -u
 PAT=${1:-gw_count_block}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
