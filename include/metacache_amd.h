@@ -379,6 +379,7 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
  * target before they are counted, big_filter_kernel), "quad_lookup" (-1 by table size, 0 / 1), "lane_path" (0 / 1), "compact_locations" (0 / 1, before mc_load_begin),
  * "filter_bpc" / "count_bpc" (blocks per CU of the filter kernels' / the first counting instance's persistent grids, 0 = default; this context only),
  * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart, 2 / 3 = the software-pipelined variants), "filter_lds_pad" (bytes of unused LDS per filter block),
+ * "gw_big_h" (reads beyond this many locations take the fine-block instance of the stream filter; default 32 768, 0 = none),
  * "lane_fusion" (sketching + lookups of the lane path in one kernel: -1 = on tables beyond 1 GiB (default), 0 / 1 = never / always), "gw_block" (the sorted class' lists of
  * up to 8 192 numbers counted by a block per read instead of sorted: 0 = default, measured slower),
  * "gw_diag" (timing variants of gw_filter_kernel: wrong results by design -- refused unless MC_ALLOW_DIAG=1 is set in the environment). */

@@ -735,7 +735,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -915,7 +915,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -963,7 +963,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -1069,7 +1069,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1161,6 +1161,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "count_bpc") ctx->countBpc = (int)value;
     else if (n == "filter_lds_pad") ctx->filterLdsPad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 120 << 10));   // bytes of unused dynamic LDS per filter block
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
+    else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
     else if (n == "gw_block") ctx->gwBlock = value != 0;                       // gw_count_block_kernel for the sorted class' lists of up to kGwBlockMax numbers (default on)
     else if (n == "gw_fuse") ctx->gwFuse = (int)value;                         // counting of short filtered lists inside the filter kernel: 0 = apart, 1 (default) = fused, 2 = fused + software pipeline (four waves per SIMD: measured slower), 3 = the same compiled for five waves per SIMD (spills)
     else if (n == "gw_diag") {                                                 // timing experiments on gw_filter_kernel (WRONG results): only with MC_ALLOW_DIAG=1 in the environment
@@ -1210,7 +1211,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     Pipe& P = ctx->pipe0;
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

@@ -142,6 +142,7 @@ struct mc_ctx {
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)
 
+    uint32_t gwBigH = 32768;  // mc_set_tuning "gw_big_h": reads beyond this many locations take the fine-block instance of the stream filter (0 = none)
     int gwBlock = 0;          // mc_set_tuning "gw_block": counting by a block per read for the sorted class' shorter lists (0 = off: everything is sorted)
     int filterBpc = 0, countBpc = 0, gwDiag = 0, gwFuse = 1, filterLdsPad = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), diagnostic variant of gw_filter_kernel -- this context only
 

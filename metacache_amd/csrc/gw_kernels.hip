@@ -1874,9 +1874,8 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // was measured SLOWER in front of this kernel: 5.00 against 4.60 ms per 250 000 long reads, 125 registers and idle waves at barriers; dropped)
         {
             // the reads beyond kGwBigH locations first (one block of sixteen waves per read: blocks x 16 = the same waves, the same pool slices)
-            static const bool bigOff = [] { const char* e = std::getenv("MC_GW_BIG_OFF"); return e && e[0] == '1'; }();   // (one instance for all reads, as round 3)
-            static const uint32_t bigH = bigOff ? 0xFFFFFFFFu : gw_env("MC_GW_BIG_H", kGwBigH);
-            if (!bigOff) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3(std::max(1u, fgrid / 4)), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu);
+            const uint32_t bigH = ws.gwBigH;                       // (tuning switch "gw_big_h"; 0xFFFFFFFF: one instance for all reads, as round 3)
+            if (bigH != 0xFFFFFFFFu) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3(std::max(1u, fgrid / 4)), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu);
             // (four waves per block and pair of filters instead of two -- 24 waves per CU: 5.01 -> 4.87 ms per 250 000 long reads: left at two)
             hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, bigH);
         }

@@ -332,10 +332,14 @@ def test_long_reads_length_distribution_against_oracle(table33):
     db.timing(False)
     assert db.timing_get("gw_count_block")[1] > 0
     assert np.array_equal(counts, counts0)
+    db.set_tuning("gw_big_h", 4096)                               # the fine-block instance of the stream filter from 4 096 locations on (default: 32 768)
+    cands_fine, _, _ = db.query(reads)
+    db.set_tuning("gw_big_h", 32768)
     for i in range(n):
         _, e = odb.query(reads[i], b"", K, 0, 0)
         _check(cands[i], e, K, (i, int(lens[i]), counts[i]))
         _check(cands0[i], e, K, ("sorted", i, int(lens[i]), counts[i]))
+        _check(cands_fine[i], e, K, ("fine", i, int(lens[i]), counts[i]))
     odb.close()
 
 
@@ -460,9 +464,18 @@ def test_sorted_path_strain_rich_long_reads_against_oracle(tmp_path, K, lowest, 
     cands, _, _ = db.query(reads, lowest=lowest)
     db.timing(False)
     assert db.timing_get("gw_count_block")[1] > 0
+    # the stream filter's fine-block instance (blocks of 2^A >= D numbers, the neighbour blocks asked as well; by default for reads beyond
+    # 32 768 locations) for EVERY read of the stream filter, and none at all: the same candidates
+    db.set_tuning("gw_block", 0)
+    db.set_tuning("gw_big_h", 2048)
+    cands_fine, _, _ = db.query(reads, lowest=lowest)
+    db.set_tuning("gw_big_h", 0)
+    cands_coarse, _, _ = db.query(reads, lowest=lowest)
     db.close()
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, len(r), counts[i]))
         _check(cands0[i], e, K, ("sorted", i, len(r), counts[i]))
+        _check(cands_fine[i], e, K, ("fine", i, len(r), counts[i]))
+        _check(cands_coarse[i], e, K, ("coarse", i, len(r), counts[i]))
     odb.close()
