@@ -124,7 +124,15 @@ int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_
     auto end = rocprim::make_transform_iterator(cnt, SegOffset{rec, side, ws.midCount, 1u, libMin});
     // (the library's default configuration: a block of 256 threads sorts up to 4 352 numbers in registers and LDS, longer lists in passes
     // through HBM.  Larger single-block limits measured worse on configs[4]'s reads at full scale: 1024 x 8: 6.0 ms, 256 x 32: 7.0 ms, default 5.2)
-    return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull), nseg, beg, end, 0u, endBit, st);
+    // This rocPRIM has no configuration tuned for gfx950: its generic default takes 6 bits per pass -- six passes through HBM over the 31 bits of
+    // the lists a block cannot hold in LDS (beyond 4 352 numbers).  8 bits (the most a block of 256 threads ranks): four passes, the same block
+    // shape: 4.29 -> 3.77 ms per 250 000 long reads (7 bits: 4.00; profiles/r04_exp_v4_long_b*.json).  MC_GW_SORT_BITS=6 / 7: the others.
+    static const uint32_t bits = [] { const char* e = std::getenv("MC_GW_SORT_BITS"); return e ? (uint32_t)std::atoi(e) : 8u; }();
+    const unsigned int poolN = (unsigned int)std::min<uint64_t>(poolCap, 0xFFFFFFFFull);
+    using Warp = rocprim::WarpSortConfig<32, 4, 256, 3000, 32, 4, 256>;
+    if (bits == 6) return (int)rocprim::segmented_radix_sort_keys(temp, tempBytes, in, out, poolN, nseg, beg, end, 0u, endBit, st);
+    if (bits == 7) return (int)rocprim::segmented_radix_sort_keys<rocprim::segmented_radix_sort_config<7, rocprim::kernel_config<256, 17>, Warp, true>>(temp, tempBytes, in, out, poolN, nseg, beg, end, 0u, endBit, st);
+    return (int)rocprim::segmented_radix_sort_keys<rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<256, 17>, Warp, true>>(temp, tempBytes, in, out, poolN, nseg, beg, end, 0u, endBit, st);
 }
 
 }  // namespace mcamd
