@@ -17,8 +17,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmetacache_amd.so")
-SOURCES = ["kernels.hip", "gw_kernels.hip", "gw_sort.hip", "table_build.hip", "context.cpp", "dbfile.cpp", "dbload.cpp", "builder.hip", "partset.cpp", "keyshard.hip", "keyset.cpp"]
-HEADERS = ["kernels.h", "device_common.h", "context.h", "rccl_dl.h", os.path.join(ROOT, "include", "metacache_amd.h")]
+SOURCES = ["kernels.hip", "gw_kernels.hip", "gw_sort.hip", "table_build.hip", "context.cpp", "dbfile.cpp", "dbload.cpp", "builder.hip", "partset.cpp", "keyshard.hip", "keyset.cpp", "devcache.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "context.h", "rccl_dl.h", "devcache.h", os.path.join(ROOT, "include", "metacache_amd.h")]
 ARCH = "gfx950"
 BINDIR = os.path.join(PKG, "bin")
 MCQ = os.path.join(BINDIR, "mcq")

@@ -10,6 +10,7 @@
 
 #include "context.h"
 
+#include "devcache.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 
@@ -189,15 +190,15 @@ int grow_pairs(mc_builder* b, uint64_t need, bool exact = false)
     if (need <= b->cap) return MC_OK;
     uint64_t ncap = exact ? need : std::max<uint64_t>(need + need / 2, 1u << 20);
     uint32_t* nk = nullptr; uint64_t* nv = nullptr;
-    B_TRY(b, hipMalloc((void**)&nk, ncap * 4));
-    if (hipMalloc((void**)&nv, ncap * 8) != hipSuccess) { (void)hipFree(nk); b->err = "out of device memory for (feature, location) pairs"; return MC_ERR_NOMEM; }
+    B_TRY(b, big_malloc((void**)&nk, ncap * 4));
+    if (big_malloc((void**)&nv, ncap * 8) != hipSuccess) { (void)big_free(nk); b->err = "out of device memory for (feature, location) pairs"; return MC_ERR_NOMEM; }
     if (b->npairs) {
         B_TRY(b, hipMemcpyAsync(nk, b->dkeys, b->npairs * 4, hipMemcpyDeviceToDevice, b->st));
         B_TRY(b, hipMemcpyAsync(nv, b->dvals, b->npairs * 8, hipMemcpyDeviceToDevice, b->st));
         B_TRY(b, hipStreamSynchronize(b->st));
     }
-    if (b->dkeys) (void)hipFree(b->dkeys);
-    if (b->dvals) (void)hipFree(b->dvals);
+    if (b->dkeys) (void)big_free(b->dkeys);
+    if (b->dvals) (void)big_free(b->dvals);
     b->dkeys = nk; b->dvals = nv; b->cap = ncap;
     return MC_OK;
 }
@@ -205,9 +206,10 @@ int grow_pairs(mc_builder* b, uint64_t need, bool exact = false)
 // scratch of one flush: freed on every way out
 struct FlushBufs {
     std::vector<void*> p;
-    ~FlushBufs() { for (void* q : p) if (q) (void)hipFree(q); }
-    void drop(void* q) { for (auto& x : p) if (x == q && q) { (void)hipFree(q); x = nullptr; } }
-    template <class T> hipError_t get(T** out, size_t bytes) { void* q = nullptr; hipError_t e = hipMalloc(&q, bytes ? bytes : 16); if (e == hipSuccess) { p.push_back(q); *out = (T*)q; } return e; }
+    // (big_malloc / big_free: while a table is being built shard after shard the scratch of one shard's sort is the next one's, devcache.h)
+    ~FlushBufs() { for (void* q : p) if (q) (void)big_free(q); }
+    void drop(void* q) { for (auto& x : p) if (x == q && q) { (void)big_free(q); x = nullptr; } }
+    template <class T> hipError_t get(T** out, size_t bytes) { void* q = nullptr; hipError_t e = big_malloc(&q, bytes ? bytes : 16); if (e == hipSuccess) { p.push_back(q); *out = (T*)q; } return e; }
 };
 
 int flush(mc_builder* b)
@@ -474,7 +476,7 @@ static int finish_sorted(mc_builder* b)
     B_TRY(b, rocprim::radix_sort_pairs(tmp, tmpBytes, b->dkeys, k2, b->dvals, v2, n, 0, 32, st));
     B_TRY(b, hipStreamSynchronize(st));
     fb.drop(tmp); tmp = nullptr;
-    (void)hipFree(b->dkeys); (void)hipFree(b->dvals);
+    (void)big_free(b->dkeys); (void)big_free(b->dvals);
     b->dkeys = nullptr; b->dvals = nullptr; b->cap = 0; b->npairs = 0;
     b->failed = true;                      // from here on the pairs are gone: an error leaves a builder that cannot be finished again
     // runs of equal features, counted first so that the run arrays are as long as the runs (at RefSeq scale a feature has ~35 locations)
@@ -500,10 +502,10 @@ static int finish_sorted(mc_builder* b)
     if (nruns && lastKey == 0xFFFFFFFFu) --nruns;            // the padding feature can never be stored (hash_dna.hpp:233)
     fb.drop(tmp); fb.drop(k2); fb.drop(dnruns);
     uint32_t* keep32 = nullptr; uint64_t* runOff = nullptr; void* scanTmp = nullptr;
-    B_TRY(b, hipMalloc((void**)&b->rS, (size_t)nruns + 16));
+    B_TRY(b, big_malloc((void**)&b->rS, (size_t)nruns + 16));
     B_TRY(b, fb.get(&keep32, ((size_t)nruns + 1) * 4));
     B_TRY(b, fb.get(&runOff, ((size_t)nruns + 2) * 8));
-    B_TRY(b, hipMalloc((void**)&b->rVoff, ((size_t)nruns + 2) * 8));
+    B_TRY(b, big_malloc((void**)&b->rVoff, ((size_t)nruns + 2) * 8));
     B_TRY(b, fb.get(&scanTmp, scan_tmp_bytes(nruns + 1)));
     if (nruns) hipLaunchKernelGGL(keep_sizes_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, counts, nruns, b->maxLocs, b->rS, keep32);
     launch_scan_u32(counts, 1, nruns, nullptr, runOff, scanTmp, st);
@@ -511,11 +513,11 @@ static int finish_sorted(mc_builder* b)
     uint64_t nvals = 0;
     B_TRY(b, hipMemcpyAsync(&nvals, b->rVoff + nruns, 8, hipMemcpyDeviceToHost, st));
     B_TRY(b, hipStreamSynchronize(st));
-    B_TRY(b, hipMalloc((void**)&b->rV, (nvals + 2) * 8));
+    B_TRY(b, big_malloc((void**)&b->rV, (nvals + 2) * 8));
     if (nruns) hipLaunchKernelGGL(compact_values_kernel, dim3((nruns + 255) / 256), dim3(256), 0, st, v2, runOff, b->rVoff, b->rS, nruns, b->rV);
     B_TRY(b, hipGetLastError());
     B_TRY(b, hipStreamSynchronize(st));
-    B_TRY(b, hipMalloc((void**)&b->rK, ((size_t)nruns + 1) * 4));
+    B_TRY(b, big_malloc((void**)&b->rK, ((size_t)nruns + 1) * 4));
     B_TRY(b, hipMemcpy(b->rK, uniq, (size_t)nruns * 4, hipMemcpyDeviceToDevice));
     b->nkeys = nruns; b->nvals = nvals;
     b->failed = false;
@@ -579,6 +581,7 @@ int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValu
     rc = mc_load_begin(ctx, 0, expectKeys, expectValues);
     if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
     *outCtx = ctx;
+    big_cache_hold(+1);                                            // until mc_build_table_end: the builders freed meanwhile leave their large buffers to the next ones
     return MC_OK;
 }
 
@@ -605,6 +608,7 @@ int mc_build_table_add(mc_ctx* ctx, mc_builder* b)
 int mc_build_table_end(mc_ctx* ctx)
 {
     if (!ctx) return MC_ERR_INVALID;
+    big_cache_hold(-1);                                            // (the shards' scratch, kept since mc_build_table_begin, goes back to the device)
     return mc_load_end(ctx, 0);
 }
 
@@ -676,7 +680,7 @@ int mc_build_remove_ambiguous(mc_builder* b, const uint32_t* ancestorOfTarget, u
         hipLaunchKernelGGL(ambig_compact_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, b->rK, b->rS, b->rV, b->rVoff, nk, keep, kpos, nvoff, oK, oS, oV);
         B_TRY(b, hipGetLastError());
         B_TRY(b, hipStreamSynchronize(st));
-        (void)hipFree(b->rK); (void)hipFree(b->rS); (void)hipFree(b->rV);
+        (void)big_free(b->rK); (void)big_free(b->rS); (void)big_free(b->rV);
         b->rK = oK; b->rS = oS; b->rV = oV;
         // rVoff[j] for the kept features = nvoff at their old places, moved to the front
         uint64_t* oOff = nullptr;
@@ -684,7 +688,7 @@ int mc_build_remove_ambiguous(mc_builder* b, const uint32_t* ancestorOfTarget, u
         hipLaunchKernelGGL(ambig_offsets_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, keep, kpos, nvoff, nk, nvNew, nkNew, oOff);
         B_TRY(b, hipGetLastError());
         B_TRY(b, hipStreamSynchronize(st));
-        (void)hipFree(b->rVoff);
+        (void)big_free(b->rVoff);
         b->rVoff = oOff;
         if (removed) *removed = nk - nkNew;
         b->nkeys = nkNew; b->nvals = nvNew;
@@ -880,9 +884,9 @@ void mc_build_free(mc_builder* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->cfg.device);
-    if (b->dkeys) (void)hipFree(b->dkeys);
-    if (b->dvals) (void)hipFree(b->dvals);
-    for (void* p : {(void*)b->rK, (void*)b->rS, (void*)b->rV, (void*)b->rVoff}) if (p) (void)hipFree(p);
+    if (b->dkeys) (void)big_free(b->dkeys);
+    if (b->dvals) (void)big_free(b->dvals);
+    for (void* p : {(void*)b->rK, (void*)b->rS, (void*)b->rV, (void*)b->rVoff}) if (p) (void)big_free(p);
     if (b->st) (void)hipStreamDestroy(b->st);
     delete b;
 }

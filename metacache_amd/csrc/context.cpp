@@ -1,6 +1,7 @@
 // metacache_amd/csrc/context.cpp -- host side of the C ABI: context, table loading, the per-batch
 // pipeline, host slots, timing.  (Compiled with hipcc; the kernels live in kernels.hip.)
 #include "context.h"
+#include "devcache.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -208,7 +209,7 @@ void mc_destroy(mc_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto& p : ctx->parts) { if (p.dbuckets) (void)hipFree(p.dbuckets); if (p.dvalues) (void)hipFree(p.dvalues); }
+    for (auto& p : ctx->parts) { if (p.dbuckets) (void)big_free(p.dbuckets); if (p.dvalues) (void)big_free(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     if (ctx->dGwBase) (void)hipFree(ctx->dGwBase);
     if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
@@ -299,8 +300,9 @@ static int allocate_table(mc_ctx* ctx)
             }
         }
         // (+ 4 entries: the filter reads the compact lists 16 bytes at a time, a list's last load may reach 3 entries past its end)
-        HIP_TRY(ctx, hipMalloc((void**)&T.dvalues, (T.dvaluesCap + 4) * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
-        HIP_TRY(ctx, hipMalloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
+        // (big_malloc: the tables of a part group come back from the tables of the group before it, devcache.h)
+        HIP_TRY(ctx, big_malloc((void**)&T.dvalues, (T.dvaluesCap + 4) * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
+        HIP_TRY(ctx, big_malloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
         HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
         int rc = ensure(ctx, ctx->bLdCounters, 4 * sizeof(unsigned long long));
         if (rc) return rc;

@@ -1,0 +1,99 @@
+// metacache_amd/csrc/devcache.cpp -- see devcache.h
+#include "devcache.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace mcamd {
+
+namespace {
+
+constexpr size_t kMinCached = 64ull << 20;
+struct Block { void* p; size_t bytes; int dev; };
+std::mutex g_mu;
+std::unordered_map<void*, Block> g_live;           // blocks big_malloc handed out (kMinCached and more)
+std::vector<Block> g_kept;
+size_t g_keptBytes = 0;
+int g_hold = 0;
+
+size_t budget()
+{
+    static const size_t b = [] { const char* e = std::getenv("MC_DEVCACHE_GB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 64) << 30; }();
+    return b;
+}
+
+void trim_locked(std::vector<Block>& out) { out.swap(g_kept); g_keptBytes = 0; }
+
+void release(const std::vector<Block>& blocks)
+{
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const Block& b : blocks) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    if (!blocks.empty()) (void)hipSetDevice(cur);
+}
+
+}  // namespace
+
+hipError_t big_malloc(void** p, size_t bytes)
+{
+    if (bytes < kMinCached) return hipMalloc(p, bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        size_t best = g_kept.size();
+        for (size_t i = 0; i < g_kept.size(); ++i)              // the smallest kept block that holds it and is not a quarter larger
+            if (g_kept[i].dev == dev && g_kept[i].bytes >= bytes && g_kept[i].bytes <= bytes + bytes / 4 &&
+                (best == g_kept.size() || g_kept[i].bytes < g_kept[best].bytes)) best = i;
+        if (best != g_kept.size()) {
+            const Block b = g_kept[best];
+            g_kept.erase(g_kept.begin() + (std::ptrdiff_t)best);
+            g_keptBytes -= b.bytes;
+            g_live[b.p] = b;
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {                                       // what is kept may be what is missing
+        std::vector<Block> out;
+        { std::lock_guard<std::mutex> lk(g_mu); trim_locked(out); }
+        if (!out.empty()) { (void)hipGetLastError(); release(out); e = hipMalloc(p, bytes); }
+    }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_mu); g_live[*p] = Block{*p, bytes, dev}; }
+    return e;
+}
+
+hipError_t big_free(void* p)
+{
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) {
+            const Block b = it->second;
+            g_live.erase(it);
+            if (g_hold > 0 && g_keptBytes + b.bytes <= budget()) { g_kept.push_back(b); g_keptBytes += b.bytes; return hipSuccess; }
+        }
+    }
+    return hipFree(p);
+}
+
+void big_cache_trim()
+{
+    std::vector<Block> out;
+    { std::lock_guard<std::mutex> lk(g_mu); trim_locked(out); }
+    release(out);
+}
+
+void big_cache_hold(int delta)
+{
+    bool trim = false;
+    { std::lock_guard<std::mutex> lk(g_mu); g_hold = std::max(0, g_hold + delta); trim = g_hold == 0; }
+    if (trim) big_cache_trim();
+}
+
+}  // namespace mcamd

@@ -14,6 +14,7 @@
 //
 // RCCL is loaded at run time (rccl_dl.h).
 #include "context.h"
+#include "devcache.h"
 #include "rccl_dl.h"
 
 #include <algorithm>
@@ -132,6 +133,7 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     mc_db_info(meta, info);
     mc_destroy(meta);
     auto* ps = new mc_partset;
+    mcamd::big_cache_hold(+1);                                    // (the tables of a closed group are the next group's: devcache.h; released in mc_partset_close)
     ps->db = name; ps->cfg = *cfg;
     ps->nparts = (uint32_t)info[6];
     ps->stride = (uint32_t)(info[3] ? info[3] : 112);
@@ -200,6 +202,7 @@ void mc_partset_close(mc_partset* ps)
         if (D.stream) (void)hipStreamDestroy(D.stream);
     }
     delete ps;
+    mcamd::big_cache_hold(-1);
 }
 
 int mc_partset_info(const mc_partset* ps, uint64_t info[6])
