@@ -467,7 +467,11 @@ int  mc_build_finish_shards(mc_builder** builders, uint32_t n, mc_ctx** out_ctx)
  *                         (0 = estimate from the FINISHED builder b: its counts times its key_shard_count, plus a margin);
  *   mc_build_table_add    inserts one finished builder -- a whole one or one key shard, same targets -- from its device arrays;
  *                         the builder can be freed right after;
- *   mc_build_table_end    closes the load (mc_load_end).  More keys or locations than announced fail with MC_ERR_INVALID. */
+ *   mc_build_table_end    closes the load (mc_load_end).  More keys or locations than announced fail with MC_ERR_INVALID.
+ * Between _begin and _end (and between mc_partset_open and mc_partset_close) device blocks of 64 MB and more that the library frees are kept
+ * for its next allocation of that size instead of going back to the device -- hipMalloc hands out scrubbed memory at ~18 GB/s, which was
+ * most of a build's and of a part group's time --: at most MC_DEVCACHE_GB (environment, default 64) gigabytes, released by the closing
+ * call or when an allocation cannot be served. */
 int  mc_build_table_begin(mc_builder* b, uint64_t expect_keys, uint64_t expect_values, mc_ctx** out_ctx);
 int  mc_build_table_add(mc_ctx* ctx, mc_builder* shard);
 int  mc_build_table_end(mc_ctx* ctx);
