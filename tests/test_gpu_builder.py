@@ -161,3 +161,27 @@ def test_remove_ambiguous_features(tmp_path, shards, max_ambig):
     odb.close(); db.close()
     for b in bs:
         b.free()
+
+
+def test_streaming_build_reuses_and_releases_large_blocks():
+    """devcache.cpp: between mc_build_table_begin and _end the key shards' large scratch buffers (64 MB and more) are kept for the next
+    shard instead of going back through hipMalloc; afterwards nothing is kept -- the device's free memory after closing the database is
+    what it was before the build -- and the table answers like the one of a single-pass build."""
+    import torch
+    from metacache_amd import synthdb
+    spec = synthdb.phylogeny(12, 2, 2, 4_000_000, 5_000_000, seed=77)          # 48 targets, ~0.2 Gbp: shard buffers of several hundred MB
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    db4, info4 = synthdb.build_database(spec, shards=4, max_candidates=2)
+    db1, info1 = synthdb.build_database(spec, shards=1, max_candidates=2)
+    P = synthdb.read_params(spec, 78)
+    reads = [bytes(r[:150]) for r in synthdb.CpuSynth().reads(spec, P, 0, 3000)]
+    c4, n4, _ = db4.query(reads)
+    c1, n1, _ = db1.query(reads)
+    assert np.array_equal(n4, n1)
+    for f in ("tgt", "hits", "beg", "end"):
+        assert np.array_equal(c4[f], c1[f]), f
+    db4.close(); db1.close()
+    torch.cuda.empty_cache(); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < (512 << 20), (free0, free1)              # (nothing of the builds is still held: 64 GB could be, were the cache left open)
