@@ -476,6 +476,25 @@ def run_multi_gpu_selfcheck(world: int, budget_s: float) -> dict:
         return {"ranks_seen": world, "ok": False, "error": repr(e)}
 
 
+def self_launch_command(argv, gpus, port):
+    """the command `python bench.py --gpus N <args>` re-executes itself as when it is not already a rank of a process group"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = self_launch_command(argv, gpus, port)
+    print("[bench] " + " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -517,9 +536,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL) and hand on their exit code;
+        # rank 0's JSON line is the last line of stdout either way
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} inside a process group of {world} ranks: start one rank per GPU (--nproc-per-node = --gpus)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or args.force_dist:

@@ -37,3 +37,16 @@ def test_bench_line_and_parity(extra):
     if "--config" not in extra:
         assert res["config"]["workload"].startswith("configs[")
         assert res["config"]["mode"] == (extra[extra.index("--mode") + 1] if "--mode" in extra else "R")
+
+
+def test_self_launched_process_group():
+    """`python bench.py --gpus N` without a launcher starts its own ranks under torch.distributed.run (here N = 1 through --force-dist):
+    rank 0's JSON line is the last line of stdout, the exit code comes back"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--scale", "0.004", "--batch", "30000", "--steps", "2", "--warmup", "1",
+           "--gather-gib", "0", "--parity-reads", "3000", "--cpu-seconds", "2", "--calibrate-scale", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "torch.distributed.run" in r.stderr
+    res = json.loads(r.stdout.strip().split("\n")[-1])
+    assert res["n_gpus"] == 1 and res["parity"]["mismatches"] == 0 and res["value"] > 0
