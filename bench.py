@@ -524,7 +524,7 @@ def main():
                     "pipes, mc_query_device(MC_DEFER_TAIL) + mc_query_finish)")
     ap.add_argument("--selfcheck-seconds", type=float, default=150.0, help="time limit of the multi-GPU self-check that follows the timed region "
                     "(tools/multi_gpu_selfcheck.py as its own job over the same N ranks; 0 = skip)")
-    ap.add_argument("--tune", default="", help="run-time tuning switches (mc_set_tuning) for experiments: name=value[,name=value ...], e.g. gw_block=0")
+    ap.add_argument("--tune", default="", help="run-time tuning switches (mc_set_tuning) for experiments: name=value[,name=value ...], e.g. gw_fuse=0")
     ap.add_argument("--repeats", type=int, default=3, help="timed repeats of the K steps: the first is the line's value, all of them its value_range")
     ap.add_argument("--long-reads", action="store_true", help="configs[2] table, BASELINE configs[4]'s reads: single reads of 200 .. 19 000 bp (log-normal, "
                     "median 480), 7.5 %% substitutions, seed 5100; --batch = reads per step (default 250 000)")

@@ -228,8 +228,11 @@ typedef struct {
                                  never waits for the host.  out->cands is complete once mc_query_finish has returned (in stream order).
                                  Honoured on the lane path without MC_WANT_* (small batches then skip their look at the work-list counters
                                  too and launch every kernel); otherwise the call does everything at once as without the flag
-                                 (mc_query_finish is then a no-op).  A new mc_query_device
-                                 on a pipe with a pending tail runs that tail first. */
+                                 (mc_query_finish is then a no-op).  A new mc_query_device -- and every other call that uses the first
+                                 pipe's workspace: mc_candidates_from_*, mc_partial_numbers, mc_last_batch_stats -- runs a pending tail
+                                 first; mc_destroy drops it.  INPUT LIFETIME: the tail reads the batch again (in->seq, in->qinfo,
+                                 in->max_win): the caller's device buffers must stay valid and unchanged until mc_query_finish (or the
+                                 call that runs the tail in its place) has returned. */
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowest_rank, int flags,
                     mc_device_results* out, void* stream);
 /* the tail of the last mc_query_device(MC_DEFER_TAIL) call on the first (flags = 0) or second (flags = MC_SECOND_PIPE) pipe: waits for
@@ -378,17 +381,16 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
  * set at mc_create, on a live context with no batch in flight.  names: "big_min" (location lists longer than this are filtered by
  * target before they are counted, big_filter_kernel), "quad_lookup" (-1 by table size, 0 / 1), "lane_path" (0 / 1), "compact_locations" (0 / 1, before mc_load_begin),
  * "filter_bpc" / "count_bpc" (blocks per CU of the filter kernels' / the first counting instance's persistent grids, 0 = default; this context only),
- * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart, 2 / 3 = the software-pipelined variants), "filter_lds_pad" (bytes of unused LDS per filter block),
+ * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart),
  * "gw_big_h" (reads beyond this many locations take the fine-block instance of the stream filter; default 32 768, 0 = none),
- * "lane_fusion" (sketching + lookups of the lane path in one kernel: -1 = on tables beyond 1 GiB (default), 0 / 1 = never / always), "gw_block" (the sorted class' lists of
- * up to 8 192 numbers counted by a block per read instead of sorted: 0 = default, measured slower),
- * "gw_diag" (timing variants of gw_filter_kernel: wrong results by design -- refused unless MC_ALLOW_DIAG=1 is set in the environment). */
+ * "lane_fusion" (sketching + lookups of the lane path in one kernel: -1 = on tables beyond 1 GiB (default), 0 / 1 = never / always).
+ * Every value of every switch gives the same results (tests/test_gpu_variants.py runs them against the oracle). */
 int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256",
  * "hash_cands_256", "hash_cands_512", "hash_cands_1024", the filtered path -- compact location store: "gw_filter_count" (gw_filter_count_kernel; "gw_filter" with
- * the tuning switch "gw_fuse" 0), "gw_filter_rest" (gw_filter2 + gw_compact + gw_filter_stream), "gw_count" (gw_count_kernel<9> + <10>), "gw_count_1024" (<11>), "gw_count_block" (tuning switch "gw_block" 1); 8-byte store:
+ * the tuning switch "gw_fuse" 0), "gw_filter_rest" (gw_filter2 + gw_compact + gw_filter_stream), "gw_count" (gw_count_kernel<9> + <10>), "gw_count_1024" (<11>); 8-byte store:
  * "big_filter", "big_filter_2", "big_count", "big_count_2" --, "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates";
  * Mode K: "mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union"; "sketch_probe" (sketch_probe_lane_kernel: instead of "sketch_lane" + "probe_cands" where the two are one kernel, see "lane_fusion"); "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);

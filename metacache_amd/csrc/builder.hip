@@ -581,7 +581,8 @@ int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValu
     rc = mc_load_begin(ctx, 0, expectKeys, expectValues);
     if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
     *outCtx = ctx;
-    big_cache_hold(+1);                                            // until mc_build_table_end: the builders freed meanwhile leave their large buffers to the next ones
+    big_cache_hold(+1);                                            // until mc_build_table_end (or mc_destroy): the builders freed meanwhile leave their large buffers to the next ones
+    ctx->buildHold = true;
     return MC_OK;
 }
 
@@ -608,7 +609,7 @@ int mc_build_table_add(mc_ctx* ctx, mc_builder* b)
 int mc_build_table_end(mc_ctx* ctx)
 {
     if (!ctx) return MC_ERR_INVALID;
-    big_cache_hold(-1);                                            // (the shards' scratch, kept since mc_build_table_begin, goes back to the device)
+    if (ctx->buildHold) { big_cache_hold(-1); ctx->buildHold = false; }   // (the shards' scratch, kept since mc_build_table_begin, goes back to the device)
     return mc_load_end(ctx, 0);
 }
 

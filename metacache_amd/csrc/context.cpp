@@ -35,7 +35,7 @@ int ensure(mc_ctx* ctx, DevBuf& b, size_t bytes)
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     size_t want = bytes + bytes / 4 + 256;                 // head-room: fewer re-allocations
-    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    HIP_TRY(ctx, dev_malloc(&b.p, want));
     b.cap = want;
     return MC_OK;
 }
@@ -208,7 +208,13 @@ void mc_destroy(mc_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // every stream that may still run kernels on the tables: the context's, both pipes', the slots' (callers' own streams: theirs to wait for)
+    if (ctx->pipe0.tail.pending || ctx->pipe1.tail.pending) { ctx->pipe0.tail.pending = false; ctx->pipe1.tail.pending = false; }   // (a deferred tail nobody asked for is dropped)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pipe0.stream) (void)hipStreamSynchronize(ctx->pipe0.stream);
+    if (ctx->pipe1.stream) (void)hipStreamSynchronize(ctx->pipe1.stream);
+    for (Pipe* p : ctx->pipes) if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (ctx->buildHold) { big_cache_hold(-1); ctx->buildHold = false; }   // (a table build that was abandoned before mc_build_table_end)
     for (auto& p : ctx->parts) { if (p.dbuckets) (void)big_free(p.dbuckets); if (p.dvalues) (void)big_free(p.dvalues); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     if (ctx->dGwBase) (void)hipFree(ctx->dGwBase);
@@ -575,8 +581,8 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
         if (diag) {
             uint32_t mc[32];
             HIP_TRY(ctx, hipMemcpy(mc, ws.midCount, sizeof mc, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "[gw diag] n %u filtered %u | stream filter %u | counted apart: 257..512 %u, 513..1024 %u | block-counted class %u | sorted %u\n",
-                         n, mc[9], mc[12], mc[14], mc[15], mc[19], mc[13]);
+            std::fprintf(stderr, "[gw diag] n %u filtered %u | stream filter %u | counted apart: 257..512 %u, 513..1024 %u | sorted %u\n",
+                         n, mc[9], mc[12], mc[14], mc[15], mc[13]);
         }
     }
     if (!*nsorted) return MC_OK;
@@ -615,8 +621,6 @@ static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const Ske
     if (second || compact) { ScopedTimer t(ctx, compact ? "gw_filter_rest" : "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count" : "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count_1024" : "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-    // the sorted class' lists that fit a block's LDS table are counted as well (a block per read); what it cannot take joins the sorted ones
-    if (compact && ws.gwBlock) { ScopedTimer t(ctx, "gw_count_block", st); launch_big_cands(5, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     if (compact && !deferSorted) return run_sorted_tail(ctx, P, b, sp, tab, ws, K, taxkey, poolEntries, false, st);
     return MC_OK;
 }
@@ -737,7 +741,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -899,6 +903,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Pipe& P = ctx->pipe0;
+    if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
     const uint32_t n = in->num_queries;
     const uint32_t K = ctx->cfg.max_candidates;
@@ -917,7 +922,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -943,6 +948,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Pipe& P = ctx->pipe0;
+    if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
     const uint32_t n = in->num_queries, S = in->num_sources;
     const uint32_t K = ctx->cfg.max_candidates;
@@ -965,7 +971,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -1012,6 +1018,7 @@ int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t n, co
         return fail(ctx, MC_ERR_UNSUPPORTED, "mc_partial_numbers: the database has no global window numbers (compact location store)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Pipe& P = ctx->pipe0;
+    if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
     for (uint32_t i = 0; i < numCuts; ++i) {
         if (cutQueries[i] > n) return fail(ctx, MC_ERR_INVALID, "mc_partial_numbers: cut beyond the batch");
@@ -1054,6 +1061,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
     if (totalIn && !in->numbers) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Pipe& P = ctx->pipe0;
+    if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
     const uint32_t* taxkey = nullptr;
     int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
@@ -1071,7 +1079,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1161,16 +1169,9 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
-    else if (n == "filter_lds_pad") ctx->filterLdsPad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 120 << 10));   // bytes of unused dynamic LDS per filter block
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
-    else if (n == "gw_block") ctx->gwBlock = value != 0;                       // gw_count_block_kernel for the sorted class' lists of up to kGwBlockMax numbers (default on)
-    else if (n == "gw_fuse") ctx->gwFuse = (int)value;                         // counting of short filtered lists inside the filter kernel: 0 = apart, 1 (default) = fused, 2 = fused + software pipeline (four waves per SIMD: measured slower), 3 = the same compiled for five waves per SIMD (spills)
-    else if (n == "gw_diag") {                                                 // timing experiments on gw_filter_kernel (WRONG results): only with MC_ALLOW_DIAG=1 in the environment
-        const char* e = std::getenv("MC_ALLOW_DIAG");
-        if (!(e && e[0] == '1')) return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: gw_diag needs MC_ALLOW_DIAG=1 (its results are wrong by design)");
-        ctx->gwDiag = (int)value;
-    }
+    else if (n == "gw_fuse") ctx->gwFuse = value != 0;                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }
@@ -1211,9 +1212,10 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::memset(stats, 0, 64);
     Pipe& P = ctx->pipe0;
+    if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwDiag = ctx->gwDiag; ws.gwFuse = ctx->gwFuse; ws.filterLdsPad = ctx->filterLdsPad; ws.gwBlock = ctx->gwBlock; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

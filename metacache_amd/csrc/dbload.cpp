@@ -12,6 +12,7 @@
 // of (4 + target_id_bytes) bytes each: where batch i + 1 begins follows from batch i's sizes, so an INDEX PASS reads the sizes of all
 // batches first (1 byte per key: 1-2 % of the file) and the readers then know every batch's place.
 #include "context.h"
+#include "devcache.h"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -107,7 +108,7 @@ int mcamd::load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uin
         if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); }
         b.p = nullptr; b.cap = 0;
         const size_t want = bytes + bytes / 4 + 256;
-        if (hipMalloc(&b.p, want) != hipSuccess) return false;
+        if (mcamd::dev_malloc(&b.p, want) != hipSuccess) return false;
         b.cap = want;
         return true;
     };
@@ -269,7 +270,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
         if (bytes > stage[k].cap) {
             if (stage[k].p) (void)hipFree(stage[k].p);
             stage[k].p = nullptr; stage[k].cap = 0;
-            if (hipMalloc(&stage[k].p, slabBytes) != hipSuccess) { rc = MC_ERR_NOMEM; emsg = "database load: cannot allocate the device staging"; break; }
+            if (mcamd::dev_malloc(&stage[k].p, slabBytes) != hipSuccess) { rc = MC_ERR_NOMEM; emsg = "database load: cannot allocate the device staging"; break; }
             stage[k].cap = slabBytes;
         }
         const uint8_t* hbase = slabs[b % nslabs].p;

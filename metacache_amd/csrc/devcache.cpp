@@ -16,7 +16,7 @@ struct Block { void* p; size_t bytes; int dev; };
 std::mutex g_mu;
 std::unordered_map<void*, Block> g_live;           // blocks big_malloc handed out (kMinCached and more)
 std::vector<Block> g_kept;
-size_t g_keptBytes = 0;
+std::unordered_map<int, size_t> g_keptBytes;       // per device: MC_DEVCACHE_GB is a device's budget
 int g_hold = 0;
 
 size_t budget()
@@ -25,7 +25,7 @@ size_t budget()
     return b;
 }
 
-void trim_locked(std::vector<Block>& out) { out.swap(g_kept); g_keptBytes = 0; }
+void trim_locked(std::vector<Block>& out) { out.swap(g_kept); g_keptBytes.clear(); }
 
 void release(const std::vector<Block>& blocks)
 {
@@ -51,35 +51,53 @@ hipError_t big_malloc(void** p, size_t bytes)
         if (best != g_kept.size()) {
             const Block b = g_kept[best];
             g_kept.erase(g_kept.begin() + (std::ptrdiff_t)best);
-            g_keptBytes -= b.bytes;
+            g_keptBytes[b.dev] -= b.bytes;
             g_live[b.p] = b;
             *p = b.p;
             return hipSuccess;
         }
     }
+    const hipError_t e = dev_malloc(p, bytes);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_mu); g_live[*p] = Block{*p, bytes, dev}; }
+    return e;
+}
+
+hipError_t dev_malloc(void** p, size_t bytes)
+{
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {                                       // what is kept may be what is missing
         std::vector<Block> out;
         { std::lock_guard<std::mutex> lk(g_mu); trim_locked(out); }
         if (!out.empty()) { (void)hipGetLastError(); release(out); e = hipMalloc(p, bytes); }
     }
-    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_mu); g_live[*p] = Block{*p, bytes, dev}; }
     return e;
 }
 
 hipError_t big_free(void* p)
 {
     if (!p) return hipSuccess;
+    Block b{nullptr, 0, 0};
+    bool keep = false;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_live.find(p);
         if (it != g_live.end()) {
-            const Block b = it->second;
+            b = it->second;
             g_live.erase(it);
-            if (g_hold > 0 && g_keptBytes + b.bytes <= budget()) { g_kept.push_back(b); g_keptBytes += b.bytes; return hipSuccess; }
+            keep = g_hold > 0 && g_keptBytes[b.dev] + b.bytes <= budget();
+            if (keep) g_keptBytes[b.dev] += b.bytes;              // (the room is reserved; the block joins the list once the device is idle)
         }
     }
-    return hipFree(p);
+    if (!keep) return hipFree(p);
+    // hipFree waits for the device before the memory goes to anybody else; a kept block gets the same: whatever kernel or copy is still
+    // queued on ANY stream of its device (the caller's, a pipe's, a loader thread's) is done before another big_malloc can hand it out
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != b.dev) (void)hipSetDevice(b.dev);
+    const hipError_t e = hipDeviceSynchronize();
+    if (cur != b.dev) (void)hipSetDevice(cur);
+    { std::lock_guard<std::mutex> lk(g_mu); g_kept.push_back(b); }
+    return e;
 }
 
 void big_cache_trim()

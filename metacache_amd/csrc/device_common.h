@@ -158,10 +158,6 @@ constexpr uint32_t kGwSmallH = 2048;      // compact store: reads with more loca
 constexpr uint32_t kGwMaxKept = kMaxHitsPerQuery;   // longest filtered list handed on (gw_filter kernels)
 // a filtered list (n2 numbers, window range maxWin) that is sorted instead of counted
 __host__ __device__ inline bool gw_sorted_class(uint32_t n2, uint32_t maxWin) { return n2 <= kGwMaxKept && (n2 > kBigMaxFilteredCount || maxWin > kHashWin); }
-// ... of which gw_count_block_kernel takes the ones a block's LDS table holds: up to kGwBlockMax numbers (half as many DISTINCT ones: a list
-// with more goes on to the sort), window ranges up to kGwBlockWin -- reads of up to ~5 kbp at RefSeq scale; the sort keeps the rest
-constexpr uint32_t kGwBlockMax = 8192, kGwBlockWin = 64;
-__host__ __device__ inline bool gw_block_class(uint32_t n2, uint32_t maxWin) { return gw_sorted_class(n2, maxWin) && n2 <= kGwBlockMax && maxWin <= kGwBlockWin; }
 // (stage 4 of launch_gw_cands: candidates of the sorted lists; needs ws.bigPool2 filled by launch_gw_segsort, kernels.h)
 // gw_kernels.hip: the filtered path of tables with the compact location store (stages as launch_big_cands)
 void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,

@@ -167,7 +167,6 @@ __device__ __forceinline__ void gw_fill_rounds_scan(uint64_t* T, uint32_t* E, ui
     }
 }
 // the batch's numbers: 16 bytes per lane and load, four lanes per round; places without a round read as kGwNone
-template <bool ALIGN_TEST = false>
 __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads],
                                                uint32_t nl = kGwLoads)   // nl: loads of this batch that have rounds at all (wave-uniform: the others are skipped)
 {
@@ -177,7 +176,7 @@ __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t
         if (u >= nl) continue;
         const uint64_t rd = T[u * 16 + grp];
         if (sub4 < (uint32_t)(rd >> 40)) {
-            const U4 t = *reinterpret_cast<const U4*>(values32 + ((rd & 0xFFFFFFFFFFull) & (ALIGN_TEST ? ~3ull : ~0ull)) + sub4);
+            const U4 t = *reinterpret_cast<const U4*>(values32 + (rd & 0xFFFFFFFFFFull) + sub4);
             x[u] = make_uint4(t.x, t.y, t.z, t.w);
         }
     }
@@ -289,9 +288,7 @@ constexpr uint32_t kGwFallback = 0xFFFFFFFFu;              // ... handed to the 
 #ifndef MC_GW_FILTER_WPE
 #define MC_GW_FILTER_WPE 4
 #endif
-// DIAG != 0: timing experiments (tools/tune_gw.py; results are wrong): 1 = loads from 16-byte aligned addresses, 2 = loads only (no
-// filter phases), 3 = filter phases only (no loads)
-template <uint32_t WAVES, uint32_t TLOG2, int DIAG, uint32_t WPE = MC_GW_FILTER_WPE>
+template <uint32_t WAVES, uint32_t TLOG2, uint32_t WPE = MC_GW_FILTER_WPE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
     using Bloom = GwBloom<TLOG2, TLOG2>;
@@ -345,18 +342,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
         const GwFrame F(maxWin);
         const uint32_t nl = (Rc + 15u) >> 4;                        // (26 lists of 49 numbers: 104 rounds = 7 of the 8 loads)
         uint4 x[kGwLoads];
-        if constexpr (DIAG == 3) {
-#pragma unroll
-            for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = make_uint4(lane * 977u + u * 13u + w, lane * 7717u + u + q, (lane ^ u) * 40503u + w, lane * 31u + u * 5u + q * 3u);
-        } else gw_load_rounds<DIAG == 1>(T, tab.values32, grp, sub4, x, nl);
+        gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;     // single locations live in their buckets in the 8-byte form
         GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-        if constexpr (DIAG == 2) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (uint32_t u = 0; u < kGwLoads; ++u) acc |= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w;
-            S.n2 = (uint32_t)__popcll(__ballot(acc == 0x12345u));
-        } else {
         // ---- A
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
         gw_mark_rounds<Bloom>(bits, x, F.A, nl);
@@ -364,7 +352,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
         // ---- B
         gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
         gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
-        }
         const bool fallback = S.n2 > S.room;                       // longer than what is handed on, or the slice is full
         if (lane == 0) {
             if (fallback) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
@@ -476,19 +463,17 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
 {
     // a block takes a contiguous stretch of the records: it counts its members of every class first, reserves their places with ONE
     // atomic per class (78 000 atomics on one counter -- one per 64 records -- took 0.4 ms), then writes them in record order
-    constexpr uint32_t kC = 5;                                     // classes = side lists; class kC: none
+    constexpr uint32_t kC = 4;                                     // classes = side lists; class kC: none
     __shared__ uint32_t cnt[4][kC], base[kC];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ rec7 = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * n;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((total + gridDim.x - 1) / gridDim.x + 255u) / 256u * 256u;          // records per block, whole 256-record steps
     const uint32_t lo = blockIdx.x * per, hi = min(total, lo + per);
-    const bool blockCount = ws.gwBlock != 0;
     auto class_of = [&](uint32_t i) -> uint32_t {
         if (i >= hi) return kC;
         const uint4 r = rec7[i];
         if (stage == 0) return r.z == kGwDefer ? 0u : kC;
-        if (blockCount && gw_block_class(r.z, r.w)) return 4u;     // sorted class, but a block's LDS table holds it: gw_count_block_kernel
         if (gw_sorted_class(r.z, r.w)) return 3u;
         if (r.z <= kBigMaxFilteredCount && r.w <= kHashWin) return r.z > 512u ? 2u : r.z > 256u ? 1u : kC;
         return kC;
@@ -505,7 +490,7 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
     __syncthreads();
     if (threadIdx.x < kC) {
         const uint32_t k = threadIdx.x, tot = cnt[0][k] + cnt[1][k] + cnt[2][k] + cnt[3][k];
-        base[k] = tot ? atomicAdd(&ws.midCount[k == 0 ? 12u : k == 1 ? 14u : k == 2 ? 15u : k == 3 ? 13u : 19u], tot) : 0u;
+        base[k] = tot ? atomicAdd(&ws.midCount[k == 0 ? 12u : k == 1 ? 14u : k == 2 ? 15u : 13u], tot) : 0u;
     }
     __syncthreads();
     // second pass: step s of the block holds records lo + s * 256 .. ; within a step the waves' members follow each other
@@ -542,8 +527,11 @@ __global__ __launch_bounds__(256) void gw_compact_kernel(Workspace ws, uint32_t 
 // ("twice") and the two next to it ("seen") -- in filters of 2^19 + 2^17 bits, one BLOCK of sixteen waves per read and CU.
 constexpr uint32_t kGwBigH = 32768;
 template <uint32_t WAVES, uint32_t T1LOG2, uint32_t T2LOG2, bool FINE = false>
-__global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t hMin, uint32_t hMax)
+__global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t hMin, uint32_t hMax, uint32_t nSlices)
 {
+    // nSlices: the pool's slices = the waves of gw_filter_kernel's grid (4 x fgrid), whatever this instance's block size: a block owns
+    // slices [blockIdx.x * WAVES, min(.. + WAVES, nSlices)) -- the last block of the sixteen-wave instance may own fewer than sixteen
+    // (the slicing used to be derived from gridDim.x * WAVES, which is another slicing whenever fgrid is not a multiple of four)
     // One BLOCK per read: its waves share ONE pair of filters (20 KB: with a pair per wave six waves fitted a CU) and take the read's
     // entry chunks in turn -- phase A of all chunks, barrier, phase B; the kept numbers of all waves go to one list, its places
     // reserved with an LDS counter.  The pool: the slices of this block's waves as the filter kernels before left them.
@@ -557,12 +545,13 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     uint64_t* T = roundS[wave];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
-    const uint32_t nWaves = gridDim.x * WAVES;
-    const uint32_t w0 = blockIdx.x * WAVES;                        // the block's first wave (slice)
-    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint64_t used[WAVES];                                          // block-uniform copies
+    const uint32_t w0 = blockIdx.x * WAVES;                        // the block's first slice
+    const uint64_t sliceCap = ws.bigPoolCap / nSlices;
+    const uint32_t mySlices = w0 < nSlices ? min(WAVES, nSlices - w0) : 0u;
+    if (mySlices == 0) return;
+    uint64_t used[WAVES];                                          // block-uniform copies (a slice this block does not own: full)
 #pragma unroll
-    for (uint32_t k = 0; k < WAVES; ++k) used[k] = ws.sliceFill ? ws.sliceFill[w0 + k] : 0u;
+    for (uint32_t k = 0; k < WAVES; ++k) used[k] = k < mySlices ? (ws.sliceFill ? ws.sliceFill[w0 + k] : 0u) : sliceCap;
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
     const uint32_t mine = ws.midCount[12];
     const uint32_t* __restrict__ side = ws.sideList;
@@ -630,7 +619,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     }
     if (threadIdx.x == 0 && ws.sliceFill) {                        // (the next instance goes on in the same slices)
 #pragma unroll
-        for (uint32_t k = 0; k < WAVES; ++k) ws.sliceFill[w0 + k] = (uint32_t)used[k];
+        for (uint32_t k = 0; k < WAVES; ++k) if (k < mySlices) ws.sliceFill[w0 + k] = (uint32_t)used[k];
     }
 }
 
@@ -1109,11 +1098,16 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
 
 constexpr uint32_t kGwCounted = 0x80000000u;      // record of list 7: the read was counted inside the filter kernel (| kept numbers)
 
-// The fused kernel WITHOUT the software pipeline (tuning switch "gw_fuse" 1; kept for comparison: 90 registers, five waves per SIMD, but
-// every read waits for its own loads): see gw_filter_count_kernel below for what it does.  Lists that keep more than 256 numbers
-// repeat phase B into the pool (the numbers are still in registers).
+// FUSED filter + counting (the common case of a 150 bp read at RefSeq scale in ONE kernel): gw_filter_kernel's two phases on the read's
+// lists in registers, the kept numbers to LDS instead of the pool (up to 512), gw_count_read on them right there -- no round trip of
+// the kept numbers through HBM (4.3 GB written and read back per 5 x 10^6 reads), one kernel's launch and tail less.  The slot table of
+// the counting takes the place of the filter bits (4 KB, done with after phase B), the distinct numbers' slots that of the round table.
+// Lists that keep more than 512 numbers or have window ranges beyond kHashWin repeat phase B into the pool (the numbers are still in
+// registers) and go on to the other kernels as from gw_filter_kernel.  A record whose read was counted here is marked kGwCounted | n2.
+// 92 registers: five waves per SIMD.  (A software-pipelined form -- the next read's loads issued as phase B frees the registers -- needed
+// 127 registers = four waves per SIMD and was slower, 14.95 against 13.1 ms per 5 x 10^6 reads; removed in round 5, docs/LAB_NOTEBOOK_r04.md.)
 template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
-__global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_simple_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
+__global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
                                                                                  mc_candidate_dev* __restrict__ cands)
 {
     using Bloom = GwBloom<TLOG2, TLOG2>;
@@ -1169,7 +1163,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_simple_kernel
         const GwFrame F(maxWin);
         const uint32_t nl = (Rc + 15u) >> 4;
         uint4 x[kGwLoads];
-        gw_load_rounds<false>(T, tab.values32, grp, sub4, x, nl);
+        gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
         gw_mark_rounds<Bloom>(bits, x, F.A, nl);
@@ -1218,197 +1212,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_simple_kernel
         }
         if (!fallback) sliceUsed += n2;
         wave_lds_sync();
-    }
-    P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
-    if (lane == 0) {
-        if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
-        if (deferred) atomicAdd(&ws.midCount[10], deferred);
-    }
-}
-
-// FUSED filter + counting (the common case of a 150 bp read at RefSeq scale in ONE kernel): gw_filter_kernel's two phases on the read's
-// lists in registers, the kept numbers to LDS instead of the pool, gw_count_read on them right there -- no round trip of the kept
-// numbers through HBM (4.3 GB written and read back per 5 x 10^6 reads), one kernel's launch and tail less.
-// SOFTWARE PIPELINE over a wave's reads: the registers that hold read i's numbers are refilled with read i + 1's, load by load, as
-// phase B of read i is done with them (its round table is made before phase A, in a second table) -- the loads are in flight while
-// read i is counted and have landed when read i + 1's phase A wants them; its entries were fetched during read i - 1, its record
-// before that.  The kernel is bound by VALU issue; what this removes is the time all five waves of a SIMD spent waiting for
-// their lists at once (SQ_WAIT_ANY 50 % in gw_filter_kernel).
-// The slot table of the counting takes the place of the filter bits (4 KB, done with after phase B), the distinct numbers' slots that
-// of the current round table.  A list that keeps more than 256 numbers has its first 256 in LDS and the rest in the wave's pool slice
-// already (the sink switches where the running count passes 256: a scalar branch); the 256 are copied in front of them and the list
-// goes on to the other kernels as from gw_filter_kernel, as do lists with window ranges beyond kHashWin (pool from the start).
-// A record whose read was counted here is marked kGwCounted | n2.
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
-__global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
-                                                                          mc_candidate_dev* __restrict__ cands)
-{
-    using Bloom = GwBloom<TLOG2, TLOG2>;
-    constexpr uint32_t kKeep = 512;                                // numbers kept in LDS: the counting takes them when at most 256 are distinct
-    static_assert(Bloom::kWords * 4 >= 512 * 8, "the slot table of the counting takes the place of the filter bits");
-    static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
-    __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
-    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][2][kGwRounds];
-    __shared__ uint32_t keptS[WAVES][kKeep];
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* bits = bitS[wave];
-    uint32_t* kept = keptS[wave];
-    const uint32_t total = ws.midCount[9];
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
-    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
-    const uint32_t nWaves = gridDim.x * WAVES;
-    const uint32_t w0 = blockIdx.x * WAVES + wave;
-    auto load_rec = [&](uint32_t w) -> uint4 { return w < total ? work[w] : make_uint4(0, 0, 0, 0); };
-    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
-    uint64_t sliceUsed = 0;
-    uint32_t deferred = 0;
-    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    const uint32_t* __restrict__ values32 = tab.values32;
-
-    // a read on its way through the pipeline: its record, this lane's entry, the rounds of its lists
-    struct Read { uint32_t q, nent, H, maxWin, sz, Rc, nl; uint64_t pay; bool ok; };
-    uint32_t esz = 0; uint64_t epay = 0;                           // entries of the read whose record is `rec` (fetched one read ahead)
-    auto load_entries = [&](const uint4& r) {
-        const uint32_t ne = (r.z >> 12) <= kGwSmallH ? min(r.z & 0xFFFu, 64u) : 0u;
-        esz = lane < ne ? ws.psize[r.y + lane] : 0u;
-        epay = lane < ne ? ws.ppay[r.y + lane] : 0ull;
-    };
-    // record + entries -> the read, its round table in T (read by the loads after the next wave_lds_sync)
-    auto prepare = [&](const uint4& r, uint64_t* T) -> Read {
-        Read R;
-        R.q = r.x; R.nent = r.z & 0xFFFu; R.H = r.z >> 12; R.maxWin = r.w;
-        R.sz = esz & 0xFFFFu; R.pay = epay;
-        const uint32_t myR = R.sz > 1 ? (R.sz + 15u) >> 4 : 0u;
-        const uint32_t incl = wave_incl_scan_u32(myR, lane);
-        R.Rc = rdlane(incl, 63);
-        R.ok = !(R.H > kGwSmallH || R.nent > 64u || R.Rc > kGwRounds || R.maxWin > tab.gwGap);
-        R.nl = R.ok ? (R.Rc + 15u) >> 4 : 0u;
-        if (R.ok) gw_fill_rounds(T, lane, 0, R.Rc, incl - myR, myR, R.sz, R.pay);
-        return R;
-    };
-    auto load_one = [&](const uint64_t* T, uint32_t u, uint32_t nl) -> uint4 {
-        uint4 v = make_uint4(kGwNone, kGwNone, kGwNone, kGwNone);
-        if (u < nl) {
-            const uint64_t rd = T[u * 16 + grp];
-            if (sub4 < (uint32_t)(rd >> 40)) {
-                const U4 t = *reinterpret_cast<const U4*>(values32 + (rd & 0xFFFFFFFFFFull) + sub4);
-                v = make_uint4(t.x, t.y, t.z, t.w);
-            }
-        }
-        return v;
-    };
-
-    uint32_t c = 0;                                                // which of the two round tables is the current read's
-    uint4 x[kGwLoads];
-    uint4 recB = load_rec(w0);
-    load_entries(recB);
-    Read A = prepare(recB, roundS[wave][0]);
-    wave_lds_sync();
-#pragma unroll
-    for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = load_one(roundS[wave][0], u, A.nl);
-    recB = load_rec(w0 + nWaves);
-    load_entries(recB);
-    uint4 recC = load_rec(w0 + 2 * nWaves);
-    GwPend P;
-    for (uint32_t w = w0; w < total; w += nWaves) {
-        uint64_t* T = roundS[wave][c];
-        uint64_t* Tn = roundS[wave][c ^ 1u];
-        {
-            uint4* z4 = reinterpret_cast<uint4*>(bits);
-#pragma unroll
-            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        }
-        // the next read: its round table now, its loads as phase B frees the registers; the one after: its entries; the third: its record
-        const Read B = prepare(recB, Tn);
-        recB = recC;
-        load_entries(recB);
-        recC = load_rec(w + 3 * nWaves);
-        const uint32_t q = A.q, maxWin = A.maxWin;
-        if (!A.ok || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
-            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin);
-            ++deferred;
-            wave_lds_sync();
-#pragma unroll
-            for (uint32_t u = 0; u < kGwLoads; ++u) x[u] = load_one(Tn, u, B.nl);
-            A = B; c ^= 1u;
-            continue;
-        }
-        const GwFrame F(maxWin);
-        const uint32_t nl = A.nl;
-        const uint32_t sv = A.sz == 1 ? tab.gw_of(A.pay) : kGwNone;   // single locations live in their buckets in the 8-byte form
-        // ---- A
-        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
-        gw_mark_rounds<Bloom>(bits, x, F.A, nl);
-        wave_lds_sync();
-        // ---- B (+ the next read's loads): into LDS while the counting can follow here and the list is short, else into the pool
-        const bool here = maxWin <= kHashWin;
-        uint32_t* const dstPool = slice + sliceUsed;
-        uint32_t n2;
-        {
-            GwSink S{here ? kept : dstPool, here ? kKeep : 64u, 0u};          // (the single locations: 64 at most)
-            if (here) { GwSink SL{kept, kKeep, 0u}; gw_take<Bloom>(bits, F, SL, sv, sv != kGwNone); n2 = SL.n2; }
-            else { GwSink SG{dstPool, 64u, 0u}; gw_take<Bloom>(bits, F, SG, sv, sv != kGwNone); n2 = SG.n2; }
-            (void)S;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kGwLoads; ++u) {
-            if (u < nl) {
-                const int32_t rem = (int32_t)(uint32_t)(T[u * 16 + grp] >> 40) - (int32_t)sub4;
-                const uint32_t v[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-                uint32_t m[4], wd[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t h = Bloom::hash(v[j] >> F.A);
-                    m[j] = Bloom::mask_of(h);
-                    wd[j] = bits[Bloom::twice_index(Bloom::seen_index(h), h)];
-                }
-                uint64_t km[4]; bool kb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool valid = rem > j, hit = (wd[j] & m[j]) == m[j], edge = F.edge(v[j]);
-                    kb[j] = valid & (hit | edge);
-                    km[j] = __ballot(valid) & (__ballot(hit) | __ballot(edge));
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t cnt = (uint32_t)__popcll(km[j]);
-                    if (kb[j]) {
-                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(km[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km[j], n2));
-                        // (n2 and cnt are wave-uniform: the choice of the sink is a scalar branch)
-                        if (!here || n2 >= kKeep) dstPool[at] = v[j];
-                        else if (n2 + cnt <= kKeep) kept[at] = v[j];
-                        else { if (at < kKeep) kept[at] = v[j]; else dstPool[at] = v[j]; }
-                    }
-                    n2 += cnt;
-                }
-            }
-            // (the refill stays BEHIND this load's phase B: hoisted, the scheduler keeps both reads' numbers in registers -- 127 instead of 96)
-            __builtin_amdgcn_sched_barrier(0);
-            x[u] = load_one(Tn, u, B.nl);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (here && n2 <= kKeep) {
-            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
-            wave_lds_sync();                                       // every lane's tests of the filter bits before the slot table takes their place
-            const bool counted = gw_count_read<9, TAX, true, true>(q, w, n2, maxWin, [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
-                                        reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, work, P);
-            if (!counted && lane == 0) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }   // (more than 256 distinct numbers: the exact wave kernel)
-        } else {
-            if (here) {                                            // the first 256 in front of the rest
-#pragma unroll
-                for (uint32_t r = 0; r < kKeep / 64; ++r) dstPool[r * 64 + lane] = kept[r * 64 + lane];
-            }
-            const uint32_t room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed);
-            const bool fallback = n2 > room;                       // (cannot happen with the room checked above; kept for the invariant's sake)
-            if (lane == 0) {
-                if (fallback) { ws.hitScan[q] = A.H; ws.qflag[q] = kFlagCands; outRec[w] = make_uint4(q, 0u, kGwFallback, maxWin); }
-                else outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin);
-            }
-            if (!fallback) sliceUsed += n2;
-            wave_lds_sync();
-        }
-        A = B; c ^= 1u;
     }
     P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
     if (lane == 0) {
@@ -1635,199 +1438,6 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void gw_sorted_cands_kernel(Batch
 }
 
 
-// ================================================================================================
-// gw_count_block_kernel: rows 8-10 on a filtered list of the SORTED class -- more than 1 024 numbers, or window ranges wider than 8:
-// reads of 800 bp and more -- WITHOUT the sort, by gw_count_kernel's method and a BLOCK per read.  A filtered list holds every location
-// about four times (the read's features that hit one window of a target), and everything after the counting is per DISTINCT number:
-//   1. every number is counted in the block's LDS table of {number, count} slots (compare-and-swap claims a slot, linear probing);
-//   2. the thread that claimed a slot lists it (one 16-bit slot number each): one distinct number per thread and step from here on;
-//   3. the thread that holds number g adds the counts of g - 1 .. g - (maxWindowsInRange - 1): the hits of the window range that ENDS
-//      in g (candidate_generation.hpp:47-108 evaluates exactly these ranges; the first to reach a target's maximum has the smallest end) --
-//      D - 1 table lookups per distinct number where the sort moved every number through eight radix passes;
-//   4. K rounds over the block: maximum of the hits, the smallest number among its holders, its REGION (every number within the gap
-//      between two targets: it lies inside its target) or taxon struck -- gw_pick's rounds, and its exactness argument, on a block;
-//   5. the K winners' targets are looked up, two winners of one target or fewer than K winners with two hits send the read to the
-//      exact wave kernel (as the scan of the sorted lists does).
-// An instance takes the lists of up to HALF its slots (the neighbour lookups need free slots to end at; configs[4]'s reads at 7.5 %
-// substitutions hold a number 1.5 times on average: a third of the slots are taken).  Instances: 2^11 slots (18 KB of LDS: eight blocks
-// per CU) for up to 1 024 numbers, 2^12, 2^13, 2^14 (144 KB: one block of sixteen waves per CU) for up to 8 192.
-// ================================================================================================
-template <uint32_t LOG2S, uint32_t THREADS, bool TAX>
-__global__ __launch_bounds__(THREADS) void gw_count_block_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
-                                                                 mc_candidate_dev* __restrict__ cands, uint32_t minN2)
-{
-    constexpr uint32_t kSlots = 1u << LOG2S, kCap = kSlots / 2, kE = kCap / THREADS, kWaves = THREADS / 64;
-    constexpr uint32_t kByteMask = (kSlots - 1u) << 3;
-    static_assert(kE >= 1 && kE <= 16 && kSlots <= 65536, "one 16-bit slot number per distinct number, a few of them per thread");
-    __shared__ __attribute__((aligned(16))) uint2 slotS[kSlots];
-    __shared__ uint16_t ckS[kCap];
-    __shared__ uint32_t ctrS[1];                                   // distinct numbers (slots claimed)
-    __shared__ uint32_t redS[4][kWaves];
-    __shared__ uint32_t winS[kLaneK][4];                           // the rounds' winners: number, hits, end - begin, taxon
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* base = reinterpret_cast<char*>(slotS);
-    auto key_at = [&](uint32_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(base + off); };
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)7 * b.n;
-    const uint32_t* __restrict__ side = ws.sideList + (size_t)4 * b.n;
-    const uint32_t* __restrict__ pool = reinterpret_cast<const uint32_t*>(ws.bigPool);
-    const uint32_t nmine = ws.midCount[19];
-    // block-wide maximum / minimum: the waves' results meet in LDS, four buffers in turn (one barrier per reduction)
-    uint32_t red = 0;
-    auto block_max = [&](uint32_t x) -> uint32_t {
-        x = wave_max_u32(x);
-        if (lane == 0) redS[red][wave] = x;
-        __syncthreads();
-        uint32_t r = redS[red][0];
-#pragma unroll
-        for (uint32_t k = 1; k < kWaves; ++k) r = max(r, redS[red][k]);
-        red = (red + 1u) & 3u;
-        return r;
-    };
-    auto block_min = [&](uint32_t x) -> uint32_t {
-        x = wave_min_u32(x);
-        if (lane == 0) redS[red][wave] = x;
-        __syncthreads();
-        uint32_t r = redS[red][0];
-#pragma unroll
-        for (uint32_t k = 1; k < kWaves; ++k) r = min(r, redS[red][k]);
-        red = (red + 1u) & 3u;
-        return r;
-    };
-    // (every instance walks the whole class list and takes the lists of its lengths: n2 in (minN2, kCap] -- at most half the slots are
-    // ever taken, whatever the list holds; the next record is on its way while this one is worked on)
-    auto load_rec = [&](uint32_t i) -> uint4 { return i < nmine ? work[side[i]] : make_uint4(0, 0, 0, 0); };
-    uint4 recNext = load_rec(blockIdx.x);
-    for (uint32_t i = blockIdx.x; i < nmine; i += gridDim.x) {
-        const uint4 rec = recNext;
-        recNext = load_rec(i + gridDim.x);
-        const uint32_t q = rec.x, n2 = rec.z, maxWin = rec.w;
-        if (n2 <= minN2 || n2 > kCap) continue;                    // (block-uniform) another instance's list
-        {
-            uint4* k4 = reinterpret_cast<uint4*>(slotS);
-            for (uint32_t j = tid; j < kSlots / 2; j += THREADS) k4[j] = make_uint4(kGwNone, 0u, kGwNone, 0u);
-        }
-        if (tid == 0) ctrS[0] = 0u;
-        if (tid < kLaneK) { winS[tid][0] = kGwNone; winS[tid][1] = 0u; winS[tid][2] = 0u; winS[tid][3] = 0u; }
-        __syncthreads();
-        // ---- 1. + 2. counting; the thread that claims a slot lists it (one LDS atomic per wave and step reserves the places)
-        const uint32_t* __restrict__ src = pool + rec.y;
-        for (uint32_t j0 = 0; j0 < n2; j0 += THREADS) {
-            const uint32_t j = j0 + tid;
-            bool claimed = false;
-            uint32_t off = 0;
-            if (j < n2) {
-                const uint32_t g = src[j];
-                off = gw_slot<LOG2S>(g);
-                uint32_t old;
-                for (;;) {
-                    old = atomicCAS(key_at(off), kGwNone, g);
-                    if (old == kGwNone || old == g) break;
-                    off = (off + 8u) & kByteMask;
-                }
-                atomicAdd(key_at(off) + 1, 1u);
-                claimed = old == kGwNone;
-            }
-            const uint64_t m = __ballot(claimed);
-            uint32_t wb = 0;
-            if (lane == 0 && m) wb = atomicAdd(&ctrS[0], (uint32_t)__popcll(m));
-            wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
-            if (claimed) ckS[wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(off >> 3);
-        }
-        __syncthreads();
-        const uint32_t C = ctrS[0];                                // distinct numbers: <= n2 <= kCap
-        // ---- 3. ranges that end in this thread's numbers: hits | (end - begin) << 16
-        uint32_t v[kE], R[kE];
-#pragma unroll
-        for (uint32_t e = 0; e < kE; ++e) {
-            const uint32_t j = e * THREADS + tid;
-            const uint2 c = j < C ? slotS[ckS[j]] : make_uint2(kGwNone, 0u);
-            v[e] = c.x; R[e] = c.y;
-        }
-        uint32_t tgt[TAX ? kE : 1], ptax[TAX ? kE : 1];
-        if constexpr (TAX) {
-#pragma unroll
-            for (uint32_t e = 0; e < kE; ++e) tgt[e] = v[e] != kGwNone ? tab.gwDir[v[e] >> tab.gwDirShift] : 0u;
-        }
-        for (uint32_t d = 1; d < maxWin; ++d) {
-            uint2 kc[kE]; uint32_t o[kE];
-            bool chain = false;
-#pragma unroll
-            for (uint32_t e = 0; e < kE; ++e) {
-                o[e] = gw_slot<LOG2S>(v[e] - d);                   // (v - d is never kGwNone: numbers start at gwGap >= maxWin)
-                kc[e] = *reinterpret_cast<const uint2*>(base + o[e]);
-                if (v[e] == kGwNone) kc[e].x = kGwNone;
-                chain = chain || (kc[e].x != v[e] - d && kc[e].x != kGwNone);
-            }
-            if (chain) {
-#pragma unroll
-                for (uint32_t e = 0; e < kE; ++e)
-                    while (kc[e].x != v[e] - d && kc[e].x != kGwNone) { o[e] = (o[e] + 8u) & kByteMask; kc[e] = *reinterpret_cast<const uint2*>(base + o[e]); }
-            }
-#pragma unroll
-            for (uint32_t e = 0; e < kE; ++e)
-                if (kc[e].x == v[e] - d) R[e] = ((R[e] & 0xFFFFu) + kc[e].y) | (d << 16);
-        }
-        if constexpr (TAX) {
-            // (a directory entry names the target of its block's FIRST number: the few numbers behind a target boundary inside a block move on)
-#pragma unroll
-            for (uint32_t e = 0; e < kE; ++e) {
-                uint32_t thi = v[e] != kGwNone ? tab.gwBase[tgt[e] + 1] : 0u;
-                while (v[e] != kGwNone && v[e] >= thi) { ++tgt[e]; thi = tab.gwBase[tgt[e] + 1]; }
-                ptax[e] = v[e] != kGwNone ? taxkey[tgt[e]] : 0u;
-            }
-        }
-        // ---- 4. K rounds (gw_pick's, over the block)
-        uint32_t live = 0;
-#pragma unroll
-        for (uint32_t e = 0; e < kE; ++e) {
-            bool ok = v[e] != kGwNone;
-            if constexpr (TAX) ok = ok && ptax[e] != 0;            // no taxon at that rank: skipped (candidate_generation.hpp:185)
-            live |= ok ? (1u << e) : 0u;
-        }
-        uint32_t strong = 0;
-        for (uint32_t rnd = 0; rnd < K; ++rnd) {
-            uint32_t hh = 0, hv = kGwNone, hd = 0, hg = 0;
-#pragma unroll
-            for (uint32_t e = 0; e < kE; ++e) {
-                const uint32_t h = R[e] & 0xFFFFu;
-                const bool take = ((live >> e) & 1u) && (h > hh || (h == hh && v[e] < hv));
-                if (take) { hh = h; hv = v[e]; hd = R[e] >> 16; if constexpr (TAX) hg = ptax[e]; }
-            }
-            const uint32_t mh = block_max(hh);
-            if (mh == 0) break;                                    // (block-uniform)
-            const uint32_t mv = block_min(hh == mh ? hv : kGwNone);
-            if (hh == mh && hv == mv) { winS[rnd][0] = mv; winS[rnd][1] = mh; winS[rnd][2] = hd; winS[rnd][3] = hg; }   // (distinct numbers: one thread)
-            if constexpr (TAX) {
-                __syncthreads();
-                const uint32_t g = winS[rnd][3];
-#pragma unroll
-                for (uint32_t e = 0; e < kE; ++e) if (ptax[e] == g) live &= ~(1u << e);
-            } else {
-                const uint32_t from = mv - tab.gwGap, span = 2u * tab.gwGap;
-#pragma unroll
-                for (uint32_t e = 0; e < kE; ++e) if (v[e] - from <= span) live &= ~(1u << e);
-            }
-            strong += mh >= 2 ? 1u : 0u;
-        }
-        __syncthreads();
-        // ---- 5. the winners' targets, the candidates (wave 0: lane i holds winner i)
-        if (wave == 0) {
-            const bool mineW = lane < kLaneK && lane < K;
-            const uint32_t wv = mineW ? winS[lane & (kLaneK - 1u)][0] : kGwNone, wh = mineW ? winS[lane & (kLaneK - 1u)][1] : 0u, wd = mineW ? winS[lane & (kLaneK - 1u)][2] : 0u;
-            uint32_t wt = 0xFFFFFFFFu, wlo = 0, whi = 0;
-            if (wv != kGwNone) tab.gw_target_bounds(wv, wt, wlo, whi);
-            uint32_t pickLo[kLaneK], pickHi[kLaneK];
-            const bool again = gw_winners_out<TAX>(lane, K, wv, wh, wd, wt, wlo, whi, cands + (size_t)q * K, pickLo, pickHi);
-            if (lane == 0) {
-                // two winners of one target, or places left for candidates with a single hit (filtered away): the exact wave kernel
-                if (again || strong < K) { ws.hitScan[q] = ws.qstat[q].hits; ws.qflag[q] = kFlagCands; }
-                else ws.qflag[q] = kFlagDone;
-            }
-        }
-        __syncthreads();                                           // (the winners and the table are the next read's from here)
-    }
-}
-
 static uint32_t gw_env(const char* name, uint32_t dflt)
 {
     const char* e = std::getenv(name);
@@ -1841,28 +1451,10 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     mc_candidate_dev* c = (mc_candidate_dev*)cands;
     const uint32_t fgrid = big_filter_grid(b.n, true, ws.filterBpc);               // blocks of 4 waves: the pool is cut into one slice per wave
     if (stage == 0) {
-        switch (ws.gwDiag) {
-            case 1: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 1>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
-            case 2: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 2>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
-            case 3: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 3>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
-            case 4: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
-            case 5: hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws); break;
-            default:
-                // the filter with the counting of lists up to 256 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
-                // (filterLdsPad: dynamic LDS the kernel never touches -- fewer blocks per CU, room for another stream's kernel beside them)
-                if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 0, 5>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
-                else if (ws.gwFuse == 1) {
-                    if (taxkey) hipLaunchKernelGGL((gw_filter_count_simple_kernel<4, 14, true>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
-                    else hipLaunchKernelGGL((gw_filter_count_simple_kernel<4, 14, false>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
-                } else if (ws.gwFuse == 3) {
-                    if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 5>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
-                    else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 5>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
-                } else {
-                    if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 4>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
-                    else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), (size_t)ws.filterLdsPad, st, b, tab, ws, maxCand, taxkey, c);
-                }
-                break;
-        }
+        // the filter with the counting of lists up to 512 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
+        if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
+        else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
@@ -1875,9 +1467,10 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         {
             // the reads beyond kGwBigH locations first (one block of sixteen waves per read: blocks x 16 = the same waves, the same pool slices)
             const uint32_t bigH = ws.gwBigH;                       // (tuning switch "gw_big_h"; 0xFFFFFFFF: one instance for all reads, as round 3)
-            if (bigH != 0xFFFFFFFFu) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3(std::max(1u, fgrid / 4)), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu);
+            const uint32_t nSlices = 4u * fgrid;
+            if (bigH != 0xFFFFFFFFu) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3((nSlices + 15u) / 16u), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu, nSlices);
             // (four waves per block and pair of filters instead of two -- 24 waves per CU: 5.01 -> 4.87 ms per 250 000 long reads: left at two)
-            hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, bigH);
+            hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, bigH, nSlices);
         }
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1) {
@@ -1905,19 +1498,6 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
             hipLaunchKernelGGL((gw_sorted_cands_kernel<false, false>), dim3(grid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
             hipLaunchKernelGGL((gw_sorted_cands_kernel<false, true>), dim3(std::min<uint32_t>(grid, 512u)), dim3(1024), 0, st, b, tab, ws, maxCand, taxkey, c);
         }
-    } else if (stage == 5) {
-        // counting by a block per read for the sorted class' lists of up to kGwBlockMax numbers: four instances by list length, grids
-        // in shares of what a CU holds of each (18 / 36 / 72 / 144 KB of LDS per block)
-        auto blk = [&](auto log2s, auto threads, uint32_t perCu, uint32_t minN2) {
-            constexpr uint32_t L = decltype(log2s)::value, T = decltype(threads)::value;
-            const uint32_t grid = std::min<uint32_t>(256u * perCu, b.n);
-            if (taxkey) hipLaunchKernelGGL((gw_count_block_kernel<L, T, true>), dim3(grid), dim3(T), 0, st, b, tab, ws, maxCand, taxkey, c, minN2);
-            else        hipLaunchKernelGGL((gw_count_block_kernel<L, T, false>), dim3(grid), dim3(T), 0, st, b, tab, ws, maxCand, taxkey, c, minN2);
-        };
-        blk(std::integral_constant<uint32_t, 11>{}, std::integral_constant<uint32_t, 256>{}, 16u, 0u);
-        blk(std::integral_constant<uint32_t, 12>{}, std::integral_constant<uint32_t, 256>{}, 8u, 1024u);
-        blk(std::integral_constant<uint32_t, 13>{}, std::integral_constant<uint32_t, 512>{}, 4u, 2048u);
-        blk(std::integral_constant<uint32_t, 14>{}, std::integral_constant<uint32_t, 1024>{}, 2u, 4096u);
     } else if (stage == 2) {
         static const uint32_t bpc2 = gw_env("MC_BIG_COUNT2_BPC", 4u);  // 32 KB per block of two waves
         const uint32_t grid = std::min<uint32_t>(256 * bpc2, (b.n + 1) / 2);

@@ -18,6 +18,7 @@
 //   3. every owner: mc_candidates_from_partial_numbers on what it received (no union copy: the receive buffer is the location store),
 //      its reads' top candidates to the host.
 #include "context.h"
+#include "devcache.h"
 #include "rccl_dl.h"
 
 #include <algorithm>
@@ -132,9 +133,9 @@ int mc_keyset_open(const char* name, const mc_config* cfg, uint32_t numShards, c
         R.rc = mc_open_database(ks->db.c_str(), &c, &R.ctx);
         if (R.rc) { R.err = mc_last_error(nullptr); return; }
         const bool ok = hipSetDevice(R.device) == hipSuccess && hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) == hipSuccess &&
-                        hipMalloc((void**)&R.dseq, ks->maxChars + 64) == hipSuccess && hipMalloc((void**)&R.dqinfo, ks->maxQ * 16) == hipSuccess &&
-                        hipMalloc((void**)&R.dmaxwin, ks->maxQ * 4) == hipSuccess &&
-                        hipMalloc((void**)&R.drecvCounts, (size_t)ks->S * std::max<uint32_t>(mMax, 1) * 4) == hipSuccess;
+                        mcamd::dev_malloc((void**)&R.dseq, ks->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&R.dqinfo, ks->maxQ * 16) == hipSuccess &&
+                        mcamd::dev_malloc((void**)&R.dmaxwin, ks->maxQ * 4) == hipSuccess &&
+                        mcamd::dev_malloc((void**)&R.drecvCounts, (size_t)ks->S * std::max<uint32_t>(mMax, 1) * 4) == hipSuccess;
         if (!ok) { R.rc = MC_ERR_NOMEM; R.err = "mc_keyset_open: cannot allocate the batch buffers"; }
     });
     for (KsRank& R : ks->rank) if (R.rc) { const int rc = R.rc; const std::string e = R.err; mc_keyset_close(ks); return ks_fail(nullptr, rc, e); }
@@ -245,7 +246,7 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
                 if (hipSetDevice(O.device) != hipSuccess) return ks_fail_idle(ks, MC_ERR_HIP, "hipSetDevice");
                 if (O.drecvNumbers) { (void)hipStreamSynchronize(O.stream); (void)hipFree(O.drecvNumbers); O.drecvNumbers = nullptr; }
                 O.recvCap = O.srcOff[S] + O.srcOff[S] / 4 + 1024;
-                if (hipMalloc((void**)&O.drecvNumbers, O.recvCap * 4) != hipSuccess) { O.recvCap = 0; return ks_fail_idle(ks, MC_ERR_NOMEM, "mc_keyset_classify: receive buffer"); }
+                if (mcamd::dev_malloc((void**)&O.drecvNumbers, O.recvCap * 4) != hipSuccess) { O.recvCap = 0; return ks_fail_idle(ks, MC_ERR_NOMEM, "mc_keyset_classify: receive buffer"); }
             }
             ks->numbersSent += O.srcOff[S];
         }

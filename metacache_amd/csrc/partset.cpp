@@ -172,10 +172,10 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
         DevState& D = ps->dev[d];
         D.device = ps->devices[d]; D.comm = comms[d];
         ok = hipSetDevice(D.device) == hipSuccess && hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking) == hipSuccess &&
-             hipMalloc((void**)&D.dseq, ps->maxChars + 64) == hipSuccess && hipMalloc((void**)&D.dqinfo, ps->maxQ * 16) == hipSuccess &&
-             hipMalloc((void**)&D.dmaxwin, ps->maxQ * 4) == hipSuccess && hipMalloc((void**)&D.dmine, ps->slotsPerDev * listBytes) == hipSuccess &&
-             hipMalloc((void**)&D.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
-        if (ok && d == 0) ok = hipMalloc((void**)&D.dprior, listBytes) == hipSuccess && hipMalloc((void**)&D.dout, listBytes) == hipSuccess;
+             mcamd::dev_malloc((void**)&D.dseq, ps->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&D.dqinfo, ps->maxQ * 16) == hipSuccess &&
+             mcamd::dev_malloc((void**)&D.dmaxwin, ps->maxQ * 4) == hipSuccess && mcamd::dev_malloc((void**)&D.dmine, ps->slotsPerDev * listBytes) == hipSuccess &&
+             mcamd::dev_malloc((void**)&D.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
+        if (ok && d == 0) ok = mcamd::dev_malloc((void**)&D.dprior, listBytes) == hipSuccess && mcamd::dev_malloc((void**)&D.dout, listBytes) == hipSuccess;
     }
     if (!ok) { mc_partset_close(ps); return ps_fail(nullptr, MC_ERR_NOMEM, "mc_partset_open: cannot allocate the batch buffers"); }
     std::string err;
@@ -370,7 +370,6 @@ int mc_partset_classify(mc_partset* ps, const char* seqs, const uint64_t* offs, 
         if (!rc) rc = mc_partset_classify_resident(ps, seqs, offs, seqs2, offs2, n, lowestRank, insertMax, g > 0, out);
         if (rc) return rc;
     }
-    if (n == 0) return MC_OK;
     return MC_OK;
 }
 

@@ -324,14 +324,8 @@ def test_long_reads_length_distribution_against_oracle(table33):
     cands0, counts0, _ = db.query(reads)
     assert db.timing_get("gw_sort")[1] > 0 and db.timing_get("gw_sorted_cands")[1] > 0      # the sorted path ran
     assert counts0.max() > 20_000, counts0.max()
-    # once more with the sorted class' lists of up to 8 192 numbers counted by a block per read instead (gw_count_block_kernel; off by
-    # default: measured slower): the same candidates
-    db.set_tuning("gw_block", 1)
-    cands, counts, _ = db.query(reads)
-    db.set_tuning("gw_block", 0)
     db.timing(False)
-    assert db.timing_get("gw_count_block")[1] > 0
-    assert np.array_equal(counts, counts0)
+    cands, counts = cands0, counts0
     db.set_tuning("gw_big_h", 4096)                               # the fine-block instance of the stream filter from 4 096 locations on (default: 32 768)
     cands_fine, _, _ = db.query(reads)
     db.set_tuning("gw_big_h", 32768)
@@ -460,13 +454,10 @@ def test_sorted_path_strain_rich_long_reads_against_oracle(tmp_path, K, lowest, 
     db.timing(True); db.timing_reset()
     cands0, counts, _ = db.query(reads, lowest=lowest)
     assert db.timing_get("gw_sorted_cands")[1] > 0 and counts.max() > 30_000, counts.max()
-    db.set_tuning("gw_block", 1)                                  # the sorted class' shorter lists counted by a block per read (gw_count_block_kernel): the same candidates
-    cands, _, _ = db.query(reads, lowest=lowest)
     db.timing(False)
-    assert db.timing_get("gw_count_block")[1] > 0
+    cands = cands0
     # the stream filter's fine-block instance (blocks of 2^A >= D numbers, the neighbour blocks asked as well; by default for reads beyond
     # 32 768 locations) for EVERY read of the stream filter, and none at all: the same candidates
-    db.set_tuning("gw_block", 0)
     db.set_tuning("gw_big_h", 2048)
     cands_fine, _, _ = db.query(reads, lowest=lowest)
     db.set_tuning("gw_big_h", 0)

@@ -1,10 +1,9 @@
 """Builds the configs[2] table once (bench.py's collection at --scale) and times the hot path for settings of run-time tuning switches
-(mc_set_tuning), e.g. the diagnostic variants of gw_filter_kernel or the grids' blocks per CU:
-  python tools/tune_gw.py --scale 1 --set gw_diag=0,1,2,3      python tools/tune_gw.py --scale 1 --set filter_bpc=5,10,20      --set count_bpc=8,16,24"""
+(mc_set_tuning), e.g. the filter and the counting apart or the grids' blocks per CU:
+  python tools/tune_gw.py --scale 1 --set gw_fuse=0,1      python tools/tune_gw.py --scale 1 --set filter_bpc=5,10,20      --set count_bpc=8,16,24"""
 import argparse
 import json
 import os
-os.environ.setdefault("MC_ALLOW_DIAG", "1")   # the gw_diag variants (wrong results by design) are refused without it
 import sys
 import time
 
@@ -22,7 +21,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=5_000_000)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--set", default="gw_diag=0", help="name=v1,v2,...: one timed run per value")
+    ap.add_argument("--set", default="gw_fuse=1", help="name=v1,v2,...: one timed run per value")
     ap.add_argument("--load-factor", type=float, default=0.3)
     ap.add_argument("--out", default="")
     ap.add_argument("--pipes", default="1", help="1,2: batches in flight (2 = mc_query_device(MC_DEFER_TAIL) alternating between the two pipes)")
