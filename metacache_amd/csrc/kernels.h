@@ -182,8 +182,10 @@ void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable&
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
 // quadMode: -1 = by table size, 0 = lane-private bucket loads, 1 = quad-cooperative bucket loads
+// minFeat: only the reads with at least this many feature slots (0: all)
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st);
+                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st, uint32_t minFeat = 0);
+constexpr uint32_t kGwLookFeat = 32;      // gw_lookup_filter_count_kernel (gw_kernels.hip) looks up the features of reads with up to this many feature slots itself
 // table_build.hip: GPU-side table construction from the file's batch stream
 struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt; };   // load-time modifiers + key shard
 struct GwLayout { const uint32_t* base = nullptr; uint32_t targets = 0, gap = 0; };   // compact store: gwBase[targets + 1] (DeviceTable)

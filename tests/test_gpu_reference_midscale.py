@@ -53,8 +53,13 @@ def test_reference_witnesses_the_filtered_path(monkeypatch):
         assert np.mean(counts > 128) > 0.6, np.percentile(counts, [5, 50, 95])      # the filtered path's regime
         st = db.last_batch_stats()
         got["compact"] = (c, db.query(p1, p2)[0])
+        # every shipped variant of the lane path's kernels on the reference's reads (scale_util.VARIANTS)
+        for v in scale_util.each_variant(db):
+            got["compact, " + v] = (db.query(singles)[0], db.query(p1, p2)[0])
         db.set_tuning("big_min", 0)
         got["compact, big_min 0"] = (db.query(singles)[0], db.query(p1, p2)[0])
+        for v in scale_util.each_variant(db, ("lookup_fusion",)):
+            got["compact, big_min 0, " + v] = (db.query(singles)[0], db.query(p1, p2)[0])
         db.close()
         monkeypatch.setenv("MC_COMPACT_LOCATIONS", "0")
         db, _ = synthdb.build_database(spec, shards=2, max_candidates=K)

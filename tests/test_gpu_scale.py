@@ -115,6 +115,14 @@ def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K, store):
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, counts[i]))
+    # every shipped variant of the lane path's kernels (lookups inside the filter kernel, sketch + probe in one kernel or apart, both bucket
+    # fetch schemes, filter and counting apart): the same candidates
+    for v in scale_util.each_variant(db):
+        cv, cnt_v, _ = db.query(reads, lowest=lowest)
+        assert np.array_equal(cnt_v, counts), v
+        for f in ("tgt", "hits", "beg", "end"):
+            bad = np.nonzero((cv[f] != cands[f]).any(axis=1))[0]
+            assert len(bad) == 0, (v, f, bad[:5], cv[bad[:2]], cands[bad[:2]])
     # Mode K's two halves on the same lists: the shard side hands the lists over as they are (MC_WANT_PARTIAL_HITS, lane path), the
     # owner side unites them (one source here) and sends the long ones through the same filter with the union buffer as its table
     import torch
