@@ -746,7 +746,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
 
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.lookupWpe = ctx->lookupWpe; ws.gwPrefetch = ctx->gwPrefetch; ws.gwBigH = ctx->gwBigH;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -945,7 +945,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.lookupWpe = ctx->lookupWpe; ws.gwPrefetch = ctx->gwPrefetch; ws.gwBigH = ctx->gwBigH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -994,7 +994,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.lookupWpe = ctx->lookupWpe; ws.gwPrefetch = ctx->gwPrefetch; ws.gwBigH = ctx->gwBigH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -1102,7 +1102,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.lookupWpe = ctx->lookupWpe; ws.gwPrefetch = ctx->gwPrefetch; ws.gwBigH = ctx->gwBigH;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1192,6 +1192,8 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
+    else if (n == "gw_prefetch") ctx->gwPrefetch = (int)value;
+    else if (n == "lookup_wpe") ctx->lookupWpe = value == 4 ? 4 : 5;              // (experiment: gw_lookup_filter_count_kernel compiled for four / five waves per SIMD)
     else if (n == "lookup_fusion") ctx->fuseLookup = value < 0 ? -1 : (value != 0);   // lookups of 150 bp reads inside the kernel that filters and counts them (-1: on tables beyond 1 GiB)
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
@@ -1239,7 +1241,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.lookupWpe = ctx->lookupWpe; ws.gwPrefetch = ctx->gwPrefetch; ws.gwBigH = ctx->gwBigH;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

@@ -145,7 +145,7 @@ struct mc_ctx {
 
     uint32_t gwBigH = 32768;  // mc_set_tuning "gw_big_h": reads beyond this many locations take the fine-block instance of the stream filter (0 = none)
     bool buildHold = false;   // mc_build_table_begin took a hold on the block cache (devcache.h) that mc_build_table_end / mc_destroy gives back
-    int filterBpc = 0, countBpc = 0, gwFuse = 1;   // mc_set_tuning: grids' blocks per CU (0 = default), counting inside the filter kernel -- this context only
+    int filterBpc = 0, countBpc = 0, gwFuse = 1, lookupWpe = 5, gwPrefetch = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), counting inside the filter kernel -- this context only
 
     uint64_t loadStats[4] = {0, 0, 0, 0};  // mc_load_stats: bytes read from the database files, nanoseconds of the load, of its index pass, the feeder waited for the readers
     uint64_t ownerStats[4] = {0, 0, 0, 0}; // mc_owner_stats: reads, reads on the filtered path, numbers received, locations decoded for the sort

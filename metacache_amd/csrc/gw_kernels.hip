@@ -855,7 +855,8 @@ struct GwPend {
 // list of 400 numbers has about 100 distinct ones); a list with more goes to the exact wave kernel.
 // entf(): where step D finds the read's entries -- {first entry slot in ws.psize / ws.ppay, entries} (the record of work list 6 for the
 // kernels that run on records).  COH: the entries were written by THIS kernel (gw_lookup_filter_count_kernel): read past the L1.
-template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, bool COH = false, class GetV, class EntF>
+// BASES = false: the caller has issued P.bases itself (before loads of its own that must not be waited for with them).
+template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, bool COH = false, bool BASES = true, class GetV, class EntF>
 __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
                                               uint2* slots, uint32_t* ck, uint64_t* T, const uint32_t lane, const uint32_t grp, const uint32_t sub4,
                                               const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab, const Workspace& ws,
@@ -874,7 +875,7 @@ __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, con
     uint32_t strong = 0, wv = kGwNone, wh = 0, wd = 0;
     bool again = false;
     mc_candidate_dev* out = cands + (size_t)q * K;
-    if constexpr (DEFER) P.bases(tab);
+    if constexpr (DEFER && BASES) P.bases(tab);
     uint32_t C = 0;
     auto body = [&](auto perc) {
         constexpr uint32_t PER = decltype(perc)::value;
@@ -1105,6 +1106,22 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
 
 constexpr uint32_t kGwCounted = 0x80000000u;      // record of list 7: the read was counted inside the filter kernel (| kept numbers)
 
+// A load whose result nobody reads: brings the line into the L2 (and its translation into the TLBs) ahead of the loads that want the
+// data -- gfx950 has no prefetch instruction.  Written as inline asm so that the compiler neither removes it nor waits for it; `sink`
+// is the register the data lands in whenever it arrives: the caller keeps it alive (and unused) for as long as touches may be in flight.
+__device__ __forceinline__ void gw_touch(const void* p, uint32_t& sink)
+{
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
+}
+// the lines of this lane's entry's list (sz numbers from index pay of the location store)
+__device__ __forceinline__ void gw_touch_list(const uint32_t* __restrict__ values32, uint32_t sz, uint64_t pay, uint32_t& sink)
+{
+    if (sz > 1u) {
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(values32 + (pay & 0xFFFFFFFFFFull)), hi = lo + 4u * sz - 1u;
+        for (uintptr_t a = lo & ~(uintptr_t)127; a <= hi; a += 128) gw_touch(reinterpret_cast<const void*>(a), sink);
+    }
+}
+
 // FUSED filter + counting (the common case of a 150 bp read at RefSeq scale in ONE kernel): gw_filter_kernel's two phases on the read's
 // lists in registers, the kept numbers to LDS instead of the pool (up to 512), gw_count_read on them right there -- no round trip of
 // the kept numbers through HBM (4.3 GB written and read back per 5 x 10^6 reads), one kernel's launch and tail less.  The slot table of
@@ -1113,7 +1130,7 @@ constexpr uint32_t kGwCounted = 0x80000000u;      // record of list 7: the read 
 // registers) and go on to the other kernels as from gw_filter_kernel.  A record whose read was counted here is marked kGwCounted | n2.
 // 92 registers: five waves per SIMD.  (A software-pipelined form -- the next read's loads issued as phase B frees the registers -- needed
 // 127 registers = four waves per SIMD and was slower, 14.95 against 13.1 ms per 5 x 10^6 reads; removed in round 5, docs/LAB_NOTEBOOK_r04.md.)
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
+template <uint32_t WAVES, uint32_t TLOG2, bool TAX, bool PF = false, uint32_t WPE = MC_GW_FILTER_WPE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
                                                                                  mc_candidate_dev* __restrict__ cands)
 {
@@ -1146,6 +1163,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
     };
     load_entries(rec);
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
+    uint32_t pfSink = 0;
     GwPend P;
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
@@ -1174,6 +1192,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
         gw_mark_rounds<Bloom>(bits, x, F.A, nl);
+        // (PF: the NEXT read's lists on their way into the L2 -- its entries, requested at the top of this iteration, are older than the loads
+        // phase A has just waited for; the lists' own loads at the top of the next iteration then find them there or on their way)
+        if constexpr (PF) gw_touch_list(tab.values32, esz & 0xFFFFu, epay, pfSink);
         wave_lds_sync();
         const bool here = maxWin <= kHashWin;
         uint32_t n2;
@@ -1221,6 +1242,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         if (!fallback) sliceUsed += n2;
         wave_lds_sync();
     }
+    if constexpr (PF) asm volatile("s_waitcnt vmcnt(0)" :: "v"(pfSink));
     P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
     if (lane == 0) {
         if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
@@ -1254,7 +1276,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
 // mid_cands / hash_cands (launched behind this kernel) or to the exact wave kernel, as probe_cands_one sends them.
 // Runs behind gw_filter_count_kernel on the records the chunk and wave kernels left (same grid, same pool slices: ws.sliceFill).
 // ================================================================================================
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
+template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE, int PFB = 0>
 __global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                                  const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
@@ -1314,6 +1336,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel
             raw[r] = make_uint4(0, 0, 0, 0);
             if (h.valid && hq[r] != kGwNone)                       // (round r: feature 4 g + r of every group g)
                 raw[r] = *reinterpret_cast<const uint4*>(bucketBytes + (uint64_t)(hq[r] & ~1u) * 64u + lt * 16u);
+        }
+    };
+    // the table lines of the next read, touched one filter pass ahead: ONE load instruction, a dword per 64-byte half line (lane 8 g + t: the
+    // home bucket of feature 4 g + (t & 3) for t < 4, its sibling for t >= 4).  An ordinary load -- the compiler counts it when it waits
+    // for the read's lists, which are older -- whose result is "used" only when the lines themselves are wanted.
+    uint32_t pfSink = 0;
+    auto touch_lines = [&](const Head& h, uint32_t F) {
+        if (h.valid && F != 0xFFFFFFFFu) {
+            const uint32_t home = (uint32_t)(((uint64_t)mix32(F) * tab.nbuckets) >> 32);
+            pfSink = *reinterpret_cast<const volatile uint32_t*>(bucketBytes + (uint64_t)(home ^ (lt >> 2)) * 64u);
         }
     };
     // lines: LDS, 4 KB ([round][group][128 bytes]); the caller has made sure nobody needs what was there
@@ -1391,6 +1423,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel
     uint32_t nF = load_feat(nxt);
     // the next read's lookups are consumed at the end of every path through the loop body; then the window moves on
     auto advance = [&](bool issued) {
+        if constexpr (PFB != 0) asm volatile("" :: "v"(pfSink));   // (the touch has come back by now: its register is free again)
         if (!issued) issue(nxt, nF);
         consume(nxt, nF, reinterpret_cast<char*>(bits));
         cur = nxt; F = nF;
@@ -1471,6 +1504,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel
         const uint32_t nl = (Rc + 15u) >> 4;
         uint4 x[kGwLoads];
         gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
+        // (PFB: the next read's table lines on their way into the L2 behind this read's lists; the loads that want their bytes follow
+        // after phase B -- PFB 1 -- or after the counting -- PFB 2)
+        if constexpr (PFB != 0) touch_lines(nxt, nF);
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
         if (sv != kGwNone) Bloom::mark(bits, sv >> Fr.A);
         gw_mark_rounds<Bloom>(bits, x, Fr.A, nl);
@@ -1491,10 +1527,17 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel
         if (here && n2 <= kKeep) {
             // ---- the common case: the next read's lines are requested now (the registers of this read's numbers are free) and arrive
             //      while this read is counted
-            issue(nxt, nF);
+            // (the previous read's winners: their gwBase words are requested BEFORE the table lines -- loads come back in order, and the
+            // counting must not wait for the lines when it wants these)
+            P.bases(tab);
+            if constexpr (PFB != 2) {
+                __builtin_amdgcn_sched_barrier(0);                 // (not before phase B is over: the loads' registers are the ones it has just left)
+                issue(nxt, nF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             ++statReads; statKept += n2;
             wave_lds_sync();
-            const bool counted = gw_count_read<9, TAX, true, true, true>(q, [&]() -> uint2 { return make_uint2(fbase, nent); }, n2, maxWin,
+            const bool counted = gw_count_read<9, TAX, true, true, true, false>(q, [&]() -> uint2 { return make_uint2(fbase, nent); }, n2, maxWin,
                                         [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
                                         reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, P);
             if (!counted) {
@@ -1507,7 +1550,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel
                 --statReads; statKept -= n2;
                 wave_lds_sync();
             }
-            advance(true);
+            advance(PFB != 2);
             continue;
         }
         if (here) {
@@ -1770,11 +1813,18 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // the filter with the counting of lists up to 512 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
         else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwPrefetch) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 6) {
         // the reads of up to kGwLookFeat features that are still waiting for their lookups (kFlagProbe): lookups + filter + counting in one kernel
-        if (taxkey) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        const int wpe = ws.lookupWpe;
+        if (taxkey) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, true, 5>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        else if (wpe == 4) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwPrefetch == 1) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 5, 1>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwPrefetch == 2) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 5, 2>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwPrefetch == 3) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 4, 1>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwPrefetch == 4) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 4, 2>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
+        else hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 5>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);

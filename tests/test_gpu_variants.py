@@ -25,10 +25,16 @@ def test_golden_reads_every_variant(golden, name, big_min):
         if big_min is not None:
             db.set_tuning("big_min", big_min)
         exp = golden.expected(name, "single_" + rname)
+        db.timing(True)
         for v in scale_util.each_variant(db):
+            db.timing_reset()
             cands, counts, _ = db.query(single, lowest=low, insert_max=ins)
+            ran = {k: db.timing_get(k)[1] for k in ("gw_lookup_filter_count", "sketch_probe", "probe_cands", "sketch_lane", "gw_filter", "gw_filter_count")}
+            assert (ran["gw_lookup_filter_count"] > 0) == (v == "lookup_fusion") and (ran["sketch_probe"] > 0) == v.startswith("lane_fusion"), (v, ran)
+            assert (ran["gw_filter"] > 0) == (v == "apart_quad_unfused_count"), (v, ran)
             for i in range(len(single)):
                 assert cands_equal(cands[i], exp[i][:mc]), (v, rname, i, cands[i], exp[i])
+        db.timing(False)
         db.close()
     for rname, mc, low, ins in PAIR_RULES:
         db = api.Database.open(golden.db_path(name), max_candidates=mc, copy_allhits=0)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=5_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--set", default="gw_fuse=1", help="name=v1,v2,...: one timed run per value")
+    ap.add_argument("--fixed", default="", help="name=value[,name=value ...]: switches set once, before the runs")
     ap.add_argument("--load-factor", type=float, default=0.3)
     ap.add_argument("--out", default="")
     ap.add_argument("--pipes", default="1", help="1,2: batches in flight (2 = mc_query_device(MC_DEFER_TAIL) alternating between the two pipes)")
@@ -46,6 +47,8 @@ def main():
     qinfo[:, 1] = bench.READ_LEN; qinfo[:, 2] = qinfo[:, 0]
     out = torch.zeros((B, 2, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+    for kv in filter(None, args.fixed.split(",")):
+        db.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
     name, vals = args.set.split("=")
     res = {"build": info, "table": db.table_layout(), "runs": []}
     ref = None
