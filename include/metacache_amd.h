@@ -384,7 +384,8 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
  * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart),
  * "gw_big_h" (reads beyond this many locations take the fine-block instance of the stream filter; default 32 768, 0 = none),
  * "lane_fusion" (sketching + lookups of the lane path in one kernel: -1 = on tables beyond 1 GiB (default), 0 / 1 = never / always).
- * Every value of every switch gives the same results (tests/test_gpu_variants.py runs them against the oracle). */
+ * Every value of every switch gives the same results (tests/test_gpu_variants.py and the variant loops of test_gpu_scale.py /
+ * test_gpu_reference_midscale.py run them against the goldens, the oracle and the reference). */
 int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).

@@ -138,14 +138,13 @@ struct mc_ctx {
     uint32_t bigMin = 128;                 // location lists longer than this (and than 64) are filtered before they are counted (big_filter_kernel); MC_BIG_MIN.
                                            // 256 / 128 / 64 at 15 Gbp (195 locations per read): 3.92 / 3.53 / 3.48 ms per 10^6 reads; at 4.5 Gbp (100): 3.01 / 3.12 / 3.25
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
-    int fuseLookup = -1;                   // lookups of reads with up to kGwLookFeat feature slots inside gw_lookup_filter_count_kernel: -1 = on tables beyond 1 GiB, 0 / 1
     int fuseLane = -1;                     // sketching + probing of the lane path in ONE kernel: -1 = where the lookups are quad-cooperative (tables beyond 1 GiB: the
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)
 
     uint32_t gwBigH = 32768;  // mc_set_tuning "gw_big_h": reads beyond this many locations take the fine-block instance of the stream filter (0 = none)
     bool buildHold = false;   // mc_build_table_begin took a hold on the block cache (devcache.h) that mc_build_table_end / mc_destroy gives back
-    int filterBpc = 0, countBpc = 0, gwFuse = 1, lookupWpe = 5, gwPrefetch = 0;   // mc_set_tuning: grids' blocks per CU (0 = default), counting inside the filter kernel -- this context only
+    int filterBpc = 0, countBpc = 0, gwFuse = 1;   // mc_set_tuning: grids' blocks per CU (0 = default), counting inside the filter kernel -- this context only
 
     uint64_t loadStats[4] = {0, 0, 0, 0};  // mc_load_stats: bytes read from the database files, nanoseconds of the load, of its index pass, the feeder waited for the readers
     uint64_t ownerStats[4] = {0, 0, 0, 0}; // mc_owner_stats: reads, reads on the filtered path, numbers received, locations decoded for the sort

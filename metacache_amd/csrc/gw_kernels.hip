@@ -853,10 +853,8 @@ struct GwPend {
 // DEFER: the winners' target lookup waits in P for the caller's next read (see GwPend; the caller finishes the last one).
 // LONG (first instance's table only): the list may hold up to 2^LOG2S numbers as long as no more than half of them are DISTINCT (a filtered
 // list of 400 numbers has about 100 distinct ones); a list with more goes to the exact wave kernel.
-// entf(): where step D finds the read's entries -- {first entry slot in ws.psize / ws.ppay, entries} (the record of work list 6 for the
-// kernels that run on records).  COH: the entries were written by THIS kernel (gw_lookup_filter_count_kernel): read past the L1.
-// BASES = false: the caller has issued P.bases itself (before loads of its own that must not be waited for with them).
-template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, bool COH = false, bool BASES = true, class GetV, class EntF>
+// entf(): where step D finds the read's entries -- {first entry slot in ws.psize / ws.ppay, entries} (the record of work list 6)
+template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, class GetV, class EntF>
 __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
                                               uint2* slots, uint32_t* ck, uint64_t* T, const uint32_t lane, const uint32_t grp, const uint32_t sub4,
                                               const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab, const Workspace& ws,
@@ -875,7 +873,7 @@ __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, con
     uint32_t strong = 0, wv = kGwNone, wh = 0, wd = 0;
     bool again = false;
     mc_candidate_dev* out = cands + (size_t)q * K;
-    if constexpr (DEFER && BASES) P.bases(tab);
+    if constexpr (DEFER) P.bases(tab);
     uint32_t C = 0;
     auto body = [&](auto perc) {
         constexpr uint32_t PER = decltype(perc)::value;
@@ -953,13 +951,8 @@ __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, con
             // ---- D. the smallest numbers of targets that were not picked with >= 2 hits -- every such target's best range is a
             //      single location, and the first of them in (target, window) order are what the CPU's list keeps
             wave_lds_sync();
-            uint32_t sz = 0; uint64_t pay = 0;
-            if (lane < nent) {
-                if constexpr (COH) {
-                    sz = __hip_atomic_load(ws.psize + fbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu;
-                    pay = __hip_atomic_load(ws.ppay + fbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else { sz = ws.psize[fbase + lane] & 0xFFFFu; pay = ws.ppay[fbase + lane]; }
-            }
+            const uint32_t sz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
+            const uint64_t pay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
             const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
             const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
             // every lane keeps the kLaneK smallest numbers it sees (several may be one target's: the rounds below strike whole
@@ -1106,22 +1099,6 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
 
 constexpr uint32_t kGwCounted = 0x80000000u;      // record of list 7: the read was counted inside the filter kernel (| kept numbers)
 
-// A load whose result nobody reads: brings the line into the L2 (and its translation into the TLBs) ahead of the loads that want the
-// data -- gfx950 has no prefetch instruction.  Written as inline asm so that the compiler neither removes it nor waits for it; `sink`
-// is the register the data lands in whenever it arrives: the caller keeps it alive (and unused) for as long as touches may be in flight.
-__device__ __forceinline__ void gw_touch(const void* p, uint32_t& sink)
-{
-    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
-}
-// the lines of this lane's entry's list (sz numbers from index pay of the location store)
-__device__ __forceinline__ void gw_touch_list(const uint32_t* __restrict__ values32, uint32_t sz, uint64_t pay, uint32_t& sink)
-{
-    if (sz > 1u) {
-        const uintptr_t lo = reinterpret_cast<uintptr_t>(values32 + (pay & 0xFFFFFFFFFFull)), hi = lo + 4u * sz - 1u;
-        for (uintptr_t a = lo & ~(uintptr_t)127; a <= hi; a += 128) gw_touch(reinterpret_cast<const void*>(a), sink);
-    }
-}
-
 // FUSED filter + counting (the common case of a 150 bp read at RefSeq scale in ONE kernel): gw_filter_kernel's two phases on the read's
 // lists in registers, the kept numbers to LDS instead of the pool (up to 512), gw_count_read on them right there -- no round trip of
 // the kept numbers through HBM (4.3 GB written and read back per 5 x 10^6 reads), one kernel's launch and tail less.  The slot table of
@@ -1130,7 +1107,7 @@ __device__ __forceinline__ void gw_touch_list(const uint32_t* __restrict__ value
 // registers) and go on to the other kernels as from gw_filter_kernel.  A record whose read was counted here is marked kGwCounted | n2.
 // 92 registers: five waves per SIMD.  (A software-pipelined form -- the next read's loads issued as phase B frees the registers -- needed
 // 127 registers = four waves per SIMD and was slower, 14.95 against 13.1 ms per 5 x 10^6 reads; removed in round 5, docs/LAB_NOTEBOOK_r04.md.)
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX, bool PF = false, uint32_t WPE = MC_GW_FILTER_WPE>
+template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
                                                                                  mc_candidate_dev* __restrict__ cands)
 {
@@ -1163,7 +1140,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
     };
     load_entries(rec);
     const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    uint32_t pfSink = 0;
     GwPend P;
     for (uint32_t w = w0; w < total; w += nWaves) {
         const uint32_t q = rec.x, nent = rec.z & 0xFFFu, H = rec.z >> 12, maxWin = rec.w;
@@ -1192,9 +1168,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
         gw_mark_rounds<Bloom>(bits, x, F.A, nl);
-        // (PF: the NEXT read's lists on their way into the L2 -- its entries, requested at the top of this iteration, are older than the loads
-        // phase A has just waited for; the lists' own loads at the top of the next iteration then find them there or on their way)
-        if constexpr (PF) gw_touch_list(tab.values32, esz & 0xFFFFu, epay, pfSink);
         wave_lds_sync();
         const bool here = maxWin <= kHashWin;
         uint32_t n2;
@@ -1242,340 +1215,10 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         if (!fallback) sliceUsed += n2;
         wave_lds_sync();
     }
-    if constexpr (PF) asm volatile("s_waitcnt vmcnt(0)" :: "v"(pfSink));
     P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
     if (lane == 0) {
         if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
         if (deferred) atomicAdd(&ws.midCount[10], deferred);
-    }
-}
-
-// ================================================================================================
-// gw_lookup_filter_count_kernel (round 5): gw_filter_count_kernel that looks the read's features up ITSELF.
-// Round 4's step was 4.8 ms of waiting for random buckets (sketch_probe_lane_kernel: 74 % of its wave cycles in SQ_WAIT_ANY, the VALUs idle)
-// followed by 12.9 ms of instruction issue (this kernel's filter and counting: 83 % of the VALU issue peak, the memory system idle) --
-// one after the other even with two batches in flight, because five filter waves per SIMD leave no room for a lookup wave.  Here the
-// waves that filter and count also fetch the NEXT read's buckets: the loads are issued when phase B is done with the registers that
-// held the read's numbers (32 of the kernel's 92: nothing new is live across the filter phases) and are in flight while the read is
-// counted -- LDS work of 4 - 5 us, longer than a random access takes; what arrives is matched when the counting is over, in the LDS
-// the filter has just left.  sketch_lane_kernel stays a kernel of its own (ALU work, 0.75 ms); the lookup-only kernel is gone from the
-// step of a batch of 150 bp reads.  (src/gpu_hashmap_operations.cuh:847-942 is one kernel for sketch + lookup + copy as well.)
-//
-// Geometry of a read's lookups (up to kGwLookFeat = 32 features: two windows of sixteen): a GROUP of eight lanes fetches one whole
-// 128-byte table line -- the feature's home bucket AND its sibling, the first two stations of the probe sequence (kernels.h) -- sixteen
-// bytes per lane, one request per line (requests are what random access costs, tools/gather_width.hip); four rounds of eight features.
-// Lane 8 g + t (t < 4) OWNS feature 4 g + t: it keeps the feature one read ahead, computes the home bucket, and matches keys, sizes and
-// payload of its line from the LDS copy.  A lookup that needs a third bucket (both halves of its line full and the key in neither:
-// one feature in a thousand) goes on with plain loads on its owner lane.
-// Every read's entries are written to ws.psize / ws.ppay in probe_cands_one's hand-over format (found features only, single locations
-// first, list offsets a running sum; the rest of the read's slots zero): everything behind this kernel -- step D, gw_filter2 / stream,
-// the counting instances, the exact wave kernel -- reads them from there as before.
-// Records: a read that is counted here needs none.  Reads that go on through the pool (or are left to gw_filter2 / the stream filter)
-// get a record appended to work list 6 / 7 -- places reserved eight at a time per wave (never more than the wave has reads left), what
-// is left unused is filled with records every consumer skips.  Reads the filtered path does not take go to the work lists of
-// mid_cands / hash_cands (launched behind this kernel) or to the exact wave kernel, as probe_cands_one sends them.
-// Runs behind gw_filter_count_kernel on the records the chunk and wave kernels left (same grid, same pool slices: ws.sliceFill).
-// ================================================================================================
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE, int PFB = 0>
-__global__ __launch_bounds__(WAVES * 64, WPE) void gw_lookup_filter_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
-                                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
-{
-    using Bloom = GwBloom<TLOG2, TLOG2>;
-    constexpr uint32_t kKeep = 512;
-    static_assert(Bloom::kWords * 4 >= 4096, "the 32 lines of a read's lookups (4 KB) are matched in the filter's LDS");
-    static_assert(kKeep * 4 >= 64 * 12, "the entry table is put in order in the kept numbers' LDS");
-    __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
-    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][kGwRounds];
-    __shared__ __attribute__((aligned(16))) uint32_t keptS[WAVES][kKeep];
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* bits = bitS[wave];
-    uint64_t* T = roundS[wave];
-    uint32_t* kept = keptS[wave];
-    const uint32_t n = b.n;
-    uint4* __restrict__ work6 = reinterpret_cast<uint4*>(ws.midList) + (size_t)6 * n;
-    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * n;
-    const uint32_t nWaves = gridDim.x * WAVES;
-    const uint32_t w0 = blockIdx.x * WAVES + wave;
-    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
-    uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;   // (gw_filter_count_kernel ran before, on the chunk and wave kernels' records)
-    uint32_t deferred = 0, statReads = 0;
-    unsigned long long statKept = 0;
-    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    GwPend P;
-    // read-only views (scalar loads; qflag is read AHEAD of this wave's own writes only)
-    const uint32_t* __restrict__ flagIn = ws.qflag;
-    const uint32_t* __restrict__ winOff = ws.winOff;
-    const uint32_t* __restrict__ feats = ws.features;
-    const uint32_t* __restrict__ mwArr = b.maxWin;
-    const char* const bucketBytes = reinterpret_cast<const char*>(tab.buckets);
-    const uint32_t lt = lane & 7u;
-    const bool owner = lt < 4u;                                    // lane 8 g + t, t < 4: feature 4 g + t
-    const uint32_t myFeat = 4u * (lane >> 3) + (lane & 3u);        // (both quads of a group hold the group's four features: DPP quad broadcasts)
-
-    struct Head { uint32_t q, fbase, nf; bool valid; };
-    auto head = [&](uint32_t qq) -> Head {
-        Head h{qq, 0u, 0u, false};
-        if (qq < n) {
-            const uint32_t a = winOff[qq], e = winOff[qq + 1];
-            h.fbase = a * s; h.nf = (e - a) * s;
-            h.valid = flagIn[qq] == kFlagProbe && h.nf <= kGwLookFeat;     // (a read without a window: no features, no locations, done below)
-        }
-        return h;
-    };
-    auto load_feat = [&](const Head& h) -> uint32_t { return (h.valid && myFeat < h.nf) ? feats[h.fbase + myFeat] : 0xFFFFFFFFu; };
-
-    // ---- lookups of the read `nxt` (features nF): issue = four line loads, consume = match -> esz / epay / steps of the owner lanes
-    uint4 raw[4];
-    uint32_t esz = 0, steps = 0; uint64_t epay = 0;                // the CURRENT read's entries (owner lanes)
-    auto issue = [&](const Head& h, uint32_t F) {
-        const uint32_t home = F != 0xFFFFFFFFu ? (uint32_t)(((uint64_t)mix32(F) * tab.nbuckets) >> 32) : kGwNone;
-        const uint32_t hq[4] = {dpp_mov<0x00>(home), dpp_mov<0x55>(home), dpp_mov<0xAA>(home), dpp_mov<0xFF>(home)};   // the group's four features
-#pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            raw[r] = make_uint4(0, 0, 0, 0);
-            if (h.valid && hq[r] != kGwNone)                       // (round r: feature 4 g + r of every group g)
-                raw[r] = *reinterpret_cast<const uint4*>(bucketBytes + (uint64_t)(hq[r] & ~1u) * 64u + lt * 16u);
-        }
-    };
-    // the table lines of the next read, touched one filter pass ahead: ONE load instruction, a dword per 64-byte half line (lane 8 g + t: the
-    // home bucket of feature 4 g + (t & 3) for t < 4, its sibling for t >= 4).  An ordinary load -- the compiler counts it when it waits
-    // for the read's lists, which are older -- whose result is "used" only when the lines themselves are wanted.
-    uint32_t pfSink = 0;
-    auto touch_lines = [&](const Head& h, uint32_t F) {
-        if (h.valid && F != 0xFFFFFFFFu) {
-            const uint32_t home = (uint32_t)(((uint64_t)mix32(F) * tab.nbuckets) >> 32);
-            pfSink = *reinterpret_cast<const volatile uint32_t*>(bucketBytes + (uint64_t)(home ^ (lt >> 2)) * 64u);
-        }
-    };
-    // lines: LDS, 4 KB ([round][group][128 bytes]); the caller has made sure nobody needs what was there
-    auto consume = [&](const Head& h, uint32_t F, char* lines) {
-        esz = 0; steps = 0; epay = 0;
-        if (!h.valid) return;                                      // (wave-uniform)
-#pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) *reinterpret_cast<uint4*>(lines + r * 1024u + lane * 16u) = raw[r];
-        wave_lds_sync();
-        bool pending = false;
-        uint32_t home = 0, cur = 0;
-        if (owner && F != 0xFFFFFFFFu) {
-            home = (uint32_t)(((uint64_t)mix32(F) * tab.nbuckets) >> 32);
-            const char* line = lines + (lane & 3u) * 1024u + (lane >> 3) * 128u;      // round t, group g
-            cur = home;
-            for (uint32_t st = 1; st <= 2; ++st) {                 // home bucket, then its sibling in the line
-                const char* bk = line + (cur & 1u) * 64u;
-                const uint4 k4 = *reinterpret_cast<const uint4*>(bk);
-                const uint2 s2 = *reinterpret_cast<const uint2*>(bk + 16);
-                const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w};
-                const uint32_t sz[4] = {s2.x & 0xFFFFu, s2.x >> 16, s2.y & 0xFFFFu, s2.y >> 16};
-                bool anyFree = false; uint32_t slot = 4;
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) { anyFree = anyFree || sz[i] == 0u; if (sz[i] != 0u && keys[i] == F) slot = i; }
-                steps = st;
-                if (slot < 4u) { esz = sz[slot]; epay = *reinterpret_cast<const uint64_t*>(bk + 32 + 8 * slot); break; }
-                if (anyFree || st >= tab.maxProbe) break;          // a bucket with a free slot ends the chain
-                if (st == 2) { pending = true; break; }
-                cur = home ^ 1u;
-            }
-        }
-        // a third bucket and beyond: plain loads on the owner lane (probe_finish's loop)
-        if (__ballot(pending)) {
-            if (pending) {
-                uint32_t st = 2;
-                for (;;) {
-                    cur = next_bucket(home, cur, st, tab.nbuckets);
-                    ++st;
-                    const uint4* p = reinterpret_cast<const uint4*>(tab.buckets + cur);
-                    const uint4 k4 = p[0], s4 = p[1];
-                    const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w};
-                    const uint32_t sz[4] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16};
-                    bool anyFree = false; uint32_t slot = 4;
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; ++i) { anyFree = anyFree || sz[i] == 0u; if (sz[i] != 0u && keys[i] == F) slot = i; }
-                    steps = st;
-                    if (slot < 4u) { esz = sz[slot]; epay = tab.buckets[cur].payload[slot]; break; }
-                    if (anyFree || st >= tab.maxProbe) break;
-                }
-            }
-        }
-        wave_lds_sync();                                           // (the lines are done with: the caller's LDS is its own again)
-    };
-
-    // ---- records of work lists 6 / 7 for the reads that go on: places reserved in steps of up to eight
-    uint32_t recAt = 0, recLeft = 0;
-    auto take_record = [&](uint32_t q) -> uint32_t {
-        if (recLeft == 0) {
-            const uint32_t mine = (n - 1u - q) / nWaves + 1u;      // reads this wave has left, this one included
-            const uint32_t want = min(8u, mine);
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(&ws.midCount[9], want);
-            recAt = (uint32_t)__builtin_amdgcn_readfirstlane((int)at); recLeft = want;
-        }
-        --recLeft;
-        return recAt++;
-    };
-
-    // ---- prologue: the first read's lookups, the second read's head and features
-    Head cur = head(w0);
-    uint32_t F = load_feat(cur);
-    issue(cur, F);
-    consume(cur, F, reinterpret_cast<char*>(bits));
-    Head nxt = head(w0 + nWaves);
-    uint32_t nF = load_feat(nxt);
-    // the next read's lookups are consumed at the end of every path through the loop body; then the window moves on
-    auto advance = [&](bool issued) {
-        if constexpr (PFB != 0) asm volatile("" :: "v"(pfSink));   // (the touch has come back by now: its register is free again)
-        if (!issued) issue(nxt, nF);
-        consume(nxt, nF, reinterpret_cast<char*>(bits));
-        cur = nxt; F = nF;
-        nxt = head(cur.q + nWaves);
-        nF = load_feat(nxt);
-    };
-
-    for (; cur.q < n;) {
-        if (!cur.valid) { advance(false); continue; }
-        const uint32_t q = cur.q, fbase = cur.fbase, nf = cur.nf;
-        const uint32_t maxWin = mwArr ? mwArr[q] : b.maxWinUniform;
-        // ---- the read's entries: statistics, the entry table in hand-over order, its class
-        const uint64_t mFound = __ballot(esz != 0u), mSingle = __ballot(esz == 1u);
-        const uint32_t nent = (uint32_t)__popcll(mFound), nS = (uint32_t)__popcll(mSingle);
-        const uint32_t nfeat = (uint32_t)__popcll(__ballot(steps != 0u));
-        const uint32_t listSz = esz > 1u ? esz : 0u;
-        const uint32_t inclL = wave_incl_scan_u32(listSz, lane);
-        const uint32_t H = rdlane(inclL, 63) + nS;
-        const uint32_t nsteps = wave_sum_u32(steps);
-        {
-            uint32_t* psS = kept; uint64_t* ppS = reinterpret_cast<uint64_t*>(kept + 64);
-            const uint64_t mList = mFound & ~mSingle;
-            const uint32_t rank = esz == 1u ? __builtin_amdgcn_mbcnt_hi((uint32_t)(mSingle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mSingle, 0u))
-                                            : nS + __builtin_amdgcn_mbcnt_hi((uint32_t)(mList >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mList, 0u));
-            const uint32_t off = esz == 1u ? rank : nS + (inclL - listSz);
-            if (esz) { psS[rank] = esz | (off << 16); ppS[rank] = epay; }
-            wave_lds_sync();
-            if (lane < nf) ws.psize[fbase + lane] = lane < nent ? psS[lane] : 0u;
-            if (lane < nent) ws.ppay[fbase + lane] = ppS[lane];
-            wave_lds_sync();
-        }
-        const bool bigOK = H > ws.bigMin && H > 64u && maxWin <= tab.gwGap && H <= kMaxHitsPerQuery;
-        if (lane == 0) {
-            QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nent; qs.nsteps = nsteps;
-            ws.qstat[q] = qs;
-        }
-        if (!bigOK) {
-            // not the filtered path's read: the classes of probe_cands_one (mid_cands / hash_cands run behind this kernel; a read without
-            // any location is done)
-            if (H == 0u) {
-                if (lane < K) { mc_candidate_dev e; e.tgt = 0xFFFFFFFFu; e.hits = 0; e.beg = 0; e.end = 0; cands[(size_t)q * K + lane] = e; }
-                if (lane == 0) { ws.hitScan[q] = 0u; ws.qflag[q] = kFlagDone; }
-            } else {
-                const bool hashOK = nent <= kHashEnt && maxWin <= kHashWin;
-                const uint32_t cls = H <= 64u ? 0u : H <= 128u ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u)
-                                   : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
-                if (lane == 0) {
-                    ws.hitScan[q] = (cls == 6u || cls < 3u) ? ((H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u) : 0u;
-                    ws.qflag[q] = cls != 6u ? kFlagMid : kFlagCands;
-                    if (cls != 6u) {
-                        const uint32_t at = atomicAdd(&ws.midCount[cls < 5u ? cls : 8u], 1u);
-                        reinterpret_cast<uint4*>(ws.midList)[(size_t)cls * n + at] = make_uint4(q, fbase, nent | (H << 12), maxWin);
-                    }
-                }
-            }
-            advance(false);
-            continue;
-        }
-        if (lane == 0) { ws.hitScan[q] = 0u; ws.qflag[q] = kFlagMid; }
-        const uint32_t sz = esz & 0xFFFFu; const uint64_t pay = epay;
-        const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
-        const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
-        if (H > kGwSmallH || Rc > kGwRounds || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
-            const uint32_t w = take_record(q);                     // left to gw_filter2_kernel / gw_filter_stream_kernel
-            if (lane == 0) { work6[w] = make_uint4(q, fbase, nent | (H << 12), maxWin); outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin); }
-            ++deferred;
-            advance(false);
-            continue;
-        }
-        {
-            uint4* z4 = reinterpret_cast<uint4*>(bits);
-#pragma unroll
-            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        }
-        gw_fill_rounds_scan(T, kept, lane, Rc, incl - myR, myR, sz, pay);   // (kept: free until phase B)
-        wave_lds_sync();
-        const GwFrame Fr(maxWin);
-        const uint32_t nl = (Rc + 15u) >> 4;
-        uint4 x[kGwLoads];
-        gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
-        // (PFB: the next read's table lines on their way into the L2 behind this read's lists; the loads that want their bytes follow
-        // after phase B -- PFB 1 -- or after the counting -- PFB 2)
-        if constexpr (PFB != 0) touch_lines(nxt, nF);
-        const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
-        if (sv != kGwNone) Bloom::mark(bits, sv >> Fr.A);
-        gw_mark_rounds<Bloom>(bits, x, Fr.A, nl);
-        wave_lds_sync();
-        const bool here = maxWin <= kHashWin;
-        uint32_t n2;
-        if (here) {
-            GwSink S{kept, kKeep, 0u};
-            gw_take<Bloom>(bits, Fr, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, true>(bits, T, Fr, S, grp, sub4, x, nl);
-            n2 = S.n2;
-        } else {
-            GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-            gw_take<Bloom>(bits, Fr, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, false>(bits, T, Fr, S, grp, sub4, x, nl);
-            n2 = S.n2;
-        }
-        if (here && n2 <= kKeep) {
-            // ---- the common case: the next read's lines are requested now (the registers of this read's numbers are free) and arrive
-            //      while this read is counted
-            // (the previous read's winners: their gwBase words are requested BEFORE the table lines -- loads come back in order, and the
-            // counting must not wait for the lines when it wants these)
-            P.bases(tab);
-            if constexpr (PFB != 2) {
-                __builtin_amdgcn_sched_barrier(0);                 // (not before phase B is over: the loads' registers are the ones it has just left)
-                issue(nxt, nF);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            ++statReads; statKept += n2;
-            wave_lds_sync();
-            const bool counted = gw_count_read<9, TAX, true, true, true, false>(q, [&]() -> uint2 { return make_uint2(fbase, nent); }, n2, maxWin,
-                                        [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
-                                        reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, P);
-            if (!counted) {
-                // more than 256 DISTINCT numbers among the kept ones: the list -- still in LDS -- goes through the pool to gw_count_kernel<10>
-                const uint32_t w = take_record(q);
-#pragma unroll
-                for (uint32_t r = 0; r < kKeep / 64; ++r) if (r * 64 + lane < n2) slice[sliceUsed + r * 64 + lane] = kept[r * 64 + lane];
-                if (lane == 0) { work6[w] = make_uint4(q, fbase, nent | (H << 12), maxWin); outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin); }
-                sliceUsed += n2;
-                --statReads; statKept -= n2;
-                wave_lds_sync();
-            }
-            advance(PFB != 2);
-            continue;
-        }
-        if (here) {
-            GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-            gw_take<Bloom>(bits, Fr, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, false>(bits, T, Fr, S, grp, sub4, x, nl);
-            n2 = S.n2;
-        }
-        const uint32_t room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed);
-        const bool fallback = n2 > room;
-        if (fallback) { if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; } }
-        else {
-            const uint32_t w = take_record(q);
-            if (lane == 0) { work6[w] = make_uint4(q, fbase, nent | (H << 12), maxWin); outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin); }
-            sliceUsed += n2;
-        }
-        wave_lds_sync();
-        advance(false);
-    }
-    P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
-    if (lane == 0) {
-        for (; recLeft; --recLeft, ++recAt) { work6[recAt] = make_uint4(0, 0, 0, 0); outRec[recAt] = make_uint4(0, 0, kGwCounted, 0); }   // (skipped by everybody)
-        if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
-        if (deferred) atomicAdd(&ws.midCount[10], deferred);
-        if (statReads) { atomicAdd(&ws.midCount[20], statReads); atomicAdd(reinterpret_cast<unsigned long long*>(ws.midCount + 22), statKept); }
     }
 }
 
@@ -1813,18 +1456,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // the filter with the counting of lists up to 512 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
         else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwPrefetch) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-    } else if (stage == 6) {
-        // the reads of up to kGwLookFeat features that are still waiting for their lookups (kFlagProbe): lookups + filter + counting in one kernel
-        const int wpe = ws.lookupWpe;
-        if (taxkey) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, true, 5>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else if (wpe == 4) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwPrefetch == 1) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 5, 1>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwPrefetch == 2) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 5, 2>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwPrefetch == 3) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 4, 1>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwPrefetch == 4) hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 4, 2>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else hipLaunchKernelGGL((gw_lookup_filter_count_kernel<4, 14, false, 5>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);

@@ -165,7 +165,7 @@ struct Workspace {           // device buffers sized by the host for this batch
     uint64_t* stats;         // [8]        batch statistics (on demand)
     // host side only: the context's grid tuning switches (mc_set_tuning; 0 = default) -- per context, never process-wide
     uint32_t  gwBigH = 32768;     // reads beyond this many locations take the stream filter's fine-block instance (gw_kernels.hip kGwBigH; 0xFFFFFFFF: none)
-    int32_t   filterBpc = 0, countBpc = 0, gwFuse = 1, lookupWpe = 5, gwPrefetch = 0;   // gwFuse: gw_filter_count_kernel (1) or gw_filter_kernel + gw_count_kernel (0)
+    int32_t   filterBpc = 0, countBpc = 0, gwFuse = 1;   // gwFuse: gw_filter_count_kernel (1) or gw_filter_kernel + gw_count_kernel (0)
 };
 
 // launchers (all asynchronous on 'st')
@@ -182,10 +182,8 @@ void launch_query(const BatchView& b, const SketchParams& sp, const DeviceTable&
                   const Workspace& ws, uint32_t maxCand, void* cands, hipStream_t st);
 void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
 // quadMode: -1 = by table size, 0 = lane-private bucket loads, 1 = quad-cooperative bucket loads
-// minFeat: only the reads with at least this many feature slots (0: all)
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st, uint32_t minFeat = 0);
-constexpr uint32_t kGwLookFeat = 32;      // gw_lookup_filter_count_kernel (gw_kernels.hip) looks up the features of reads with up to this many feature slots itself
+                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st);
 // table_build.hip: GPU-side table construction from the file's batch stream
 struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt; };   // load-time modifiers + key shard
 struct GwLayout { const uint32_t* base = nullptr; uint32_t targets = 0, gap = 0; };   // compact store: gwBase[targets + 1] (DeviceTable)

@@ -1859,13 +1859,11 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
 
 template <bool QUAD>
 __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
-                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, uint32_t minFeat)
+                                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
-    // minFeat: only the reads with at least this many feature slots (the others are left to gw_lookup_filter_count_kernel, which looks
-    // its reads' features up itself; 0: all)
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
-    const bool valid = q < b.n && ws.qflag[q] == kFlagProbe && (minFeat == 0u || (ws.winOff[q + 1] - ws.winOff[q]) * s >= minFeat);
+    const bool valid = q < b.n && ws.qflag[q] == kFlagProbe;
     probe_cands_one<QUAD>(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, valid);
 }
 
@@ -1998,15 +1996,15 @@ void launch_gather_lists(const BatchView& b, const SketchParams& sp, const Devic
 }
 
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
-                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st, uint32_t minFeat)
+                        const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st)
 {
     if (b.n == 0) return;
     // tables that reach beyond the infinity cache and the TLBs: quad-cooperative bucket fetches (see quad_issue)
     const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
     if (quad) hipLaunchKernelGGL(probe_cands_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
-                                 taxkey, (mc_candidate_dev*)cands, minFeat);
+                                 taxkey, (mc_candidate_dev*)cands);
     else      hipLaunchKernelGGL(probe_cands_kernel<false>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
-                                 taxkey, (mc_candidate_dev*)cands, minFeat);
+                                 taxkey, (mc_candidate_dev*)cands);
 }
 // ================================================================================================
 // mid_cands_kernel<G>: location lists of 33 .. 16*G entries (G = 4, 8, 16 lanes per query; 64/G queries per wave).
@@ -3156,11 +3154,7 @@ __global__ __launch_bounds__(256) void big_stats_kernel(const uint32_t* __restri
     atomicAdd((unsigned long long*)&stats[5], kept);
     atomicAdd((unsigned long long*)&stats[6], (unsigned long long)over << 32);
     atomicAdd((unsigned long long*)&stats[7], (unsigned long long)fb << 32);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // ([20], [22..23]: the reads gw_lookup_filter_count_kernel counted without a record, and what its filter kept of them)
-        atomicAdd((unsigned long long*)&stats[6], (unsigned long long)total + midCount[20]); atomicAdd((unsigned long long*)&stats[7], (unsigned long long)midCount[10]);
-        atomicAdd((unsigned long long*)&stats[5], *reinterpret_cast<const unsigned long long*>(midCount + 22));
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd((unsigned long long*)&stats[6], (unsigned long long)total); atomicAdd((unsigned long long*)&stats[7], (unsigned long long)midCount[10]); }
 }
 
 void launch_batch_stats(const Workspace& ws, uint32_t n, hipStream_t st)

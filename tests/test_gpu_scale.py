@@ -115,7 +115,7 @@ def test_big_cands_filtered_lists_against_oracle(monkeypatch, lowest, K, store):
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, counts[i]))
-    # every shipped variant of the lane path's kernels (lookups inside the filter kernel, sketch + probe in one kernel or apart, both bucket
+    # every shipped variant of the lane path's kernels (sketch + probe in one kernel or apart, both bucket
     # fetch schemes, filter and counting apart): the same candidates
     for v in scale_util.each_variant(db):
         cv, cnt_v, _ = db.query(reads, lowest=lowest)
