@@ -94,6 +94,74 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 }
 
 
+__device__ __forceinline__ uint32_t home_group(uint32_t key, uint32_t nbuckets)
+{
+    return (uint32_t)(((uint64_t)mix32(key) * nbuckets) >> 32);
+}
+
+
+// ================================================================================================
+// lane-private table lookup: ONE lane looks one feature up with four 16-byte loads of one 64-byte bucket
+// (keys, sizes, payloads).  Split in two so that callers can have several lookups in flight per lane.
+// ================================================================================================
+struct BucketRegs { uint4 k, sz, p0, p1; };      // key[0..3] | size[0..3] (4 x u16) + spare | payload[0..1] | payload[2..3]
+
+__device__ __forceinline__ BucketRegs load_bucket(const DeviceTable& tab, uint32_t bi)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(tab.buckets + bi);
+    BucketRegs r; r.k = p[0]; r.sz = p[1]; r.p0 = p[2]; r.p1 = p[3];
+    return r;
+}
+// Quad-cooperative bucket fetch.  A lane that loads its own 64-byte bucket with four 16-byte loads touches 64 different lines per
+// load instruction; on tables far larger than the infinity cache every one of these accesses pays the full price (measured,
+// tools/gather_bench3.hip: 52 G buckets/s on a 366 MB table, 16 G/s on 16 GB), whereas four neighbouring lanes reading the four
+// quarters of ONE bucket stay at 48 G/s whatever the table size (tools/gather_bench.hip).  So the four lanes of a quad fetch the
+// buckets of its members one after the other (lane i of the quad always loads quarter i) and a 4 x 4 register transpose inside the
+// quad (DPP quad_perm, no LDS) gives every lane the four quarters of its own bucket.
+// Both calls must be made by all four lanes of a quad together; kNoBucket = this lane wants nothing.
+constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
+constexpr uint64_t kQuadTableBytes = 1ull << 30;               // tables larger than this are probed quad-cooperatively
+struct QuadRaw { uint4 v[4]; };                                 // v[t] = my quarter of the bucket wanted by lane t of my quad
+
+__device__ __forceinline__ void quad_issue(const DeviceTable& tab, uint32_t want, QuadRaw& raw)
+{
+    const uint32_t part = threadIdx.x & 3u;
+    const uint32_t w[4] = {dpp_mov<0x00>(want), dpp_mov<0x55>(want), dpp_mov<0xAA>(want), dpp_mov<0xFF>(want)};   // quad broadcasts
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t)
+        if (w[t] != kNoBucket) raw.v[t] = reinterpret_cast<const uint4*>(tab.buckets + w[t])[part];
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint4 dpp_mov4(uint4 v)
+{
+    return make_uint4(dpp_mov<CTRL>(v.x), dpp_mov<CTRL>(v.y), dpp_mov<CTRL>(v.z), dpp_mov<CTRL>(v.w));
+}
+__device__ __forceinline__ uint4 sel4(bool c, uint4 a, uint4 b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+
+__device__ __forceinline__ BucketRegs quad_collect(const QuadRaw& raw)
+{
+    // butterfly transpose: after the stage with distance d, register j of lane i holds what register j^d of lane i^d held wherever
+    // bit d of i and of j differ
+    const bool b0 = (threadIdx.x & 1u) != 0, b1 = (threadIdx.x & 2u) != 0;
+    uint4 m0 = raw.v[0], m1 = raw.v[1], m2 = raw.v[2], m3 = raw.v[3];
+    {
+        const uint4 ra = dpp_mov4<0xB1>(sel4(b0, m0, m1));      // quad_perm [1,0,3,2]
+        const uint4 rb = dpp_mov4<0xB1>(sel4(b0, m2, m3));
+        m0 = sel4(b0, ra, m0); m1 = sel4(b0, m1, ra);
+        m2 = sel4(b0, rb, m2); m3 = sel4(b0, m3, rb);
+    }
+    {
+        const uint4 ra = dpp_mov4<0x4E>(sel4(b1, m0, m2));      // quad_perm [2,3,0,1]
+        const uint4 rb = dpp_mov4<0x4E>(sel4(b1, m1, m3));
+        m0 = sel4(b1, ra, m0); m2 = sel4(b1, m2, ra);
+        m1 = sel4(b1, rb, m1); m3 = sel4(b1, m3, rb);
+    }
+    BucketRegs r; r.k = m0; r.sz = m1; r.p0 = m2; r.p1 = m3;
+    return r;
+}
+
+
 struct mc_candidate_dev { uint32_t tgt, hits, beg, end; };
 
 constexpr uint32_t kLaneK = 4;            // most candidates handled by one lane
