@@ -53,13 +53,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
 PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
-           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_probe_filter_count", "gw_filter", "gw_filter_rest", "gw_count", "gw_count_1024",
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter_rest", "gw_count", "gw_count_1024",
            "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates")
 KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
 # timer (mc_timing_get) -> the kernel's own name as the rocprofv3 summaries carry it (scripts/summarize_profile.py): prefixes
 KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cands_kernel",), "sketch_probe": ("sketch_probe_lane_kernel",),
              "query_wave": ("query_kernel",), "sort_candidates": ("sort_candidates_kernel",),
-             "gw_filter_count": ("gw_filter_count_kernel",), "gw_probe_filter_count": ("gw_probe_filter_count_kernel",), "gw_filter": ("gw_filter_kernel",),
+             "gw_filter_count": ("gw_filter_count_kernel",), "gw_filter": ("gw_filter_kernel",),
              "gw_filter_rest": ("gw_filter_stream_kernel", "gw_filter2_kernel"), "gw_count": ("gw_count_kernel<9", "gw_count_kernel<10"),
              "gw_count_1024": ("gw_count_kernel<11",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
              "big_count_2": ("big_count_kernel<11",), "hash_cands_256": ("hash_cands_kernel<9",), "hash_cands_512": ("hash_cands_kernel<10",),
@@ -190,7 +190,7 @@ def kernel_bytes_per_read(timer: str, L: float, F: float, H: float, K: int, V: i
     """the kernel's OWN share of SURVEY §8(d)'s bytes per read (ceil(L/4) + ceil(L/8) + 12 F + V H + 16 K): the read's characters belong to the
     sketching kernel, 12 F to the lookups, the V H bytes of the lists to the filter, the 16 K bytes of candidates to whoever writes them"""
     share = {"sketch_lane": (L + 3) // 4 + (L + 7) // 8, "sketch_probe": (L + 3) // 4 + (L + 7) // 8 + 12.0 * F, "probe_cands": 12.0 * F,
-             "gw_filter_count": V * H + 16.0 * K, "gw_probe_filter_count": 12.0 * F + V * H + 16.0 * K, "gw_filter": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
+             "gw_filter_count": V * H + 16.0 * K, "gw_filter": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
              "gather_lists": V * H}
     return share.get(timer)
 

@@ -170,7 +170,6 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->parts.resize(cfg->num_parts);
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1' ? 1 : 0;   // (default: by table size)
-    if (const char* e = std::getenv("MC_PROBE_FUSION")) ctx->fuseProbe = e[0] == '1' ? 1 : 0;   // (default: by table size)
     if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
     if (const char* e = std::getenv("MC_COMPACT_LOCATIONS")) ctx->compactAllowed = e[0] != '0';   // tests / tuning
@@ -613,14 +612,11 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
 // in list 6: filter -> counting -> [segmented sort -> scan of the sorted lists].  poolEntries: entries of ws.bigPool (slices + overflow).
 // deferSorted: the sorted class is left to the caller (mc_query_finish runs run_sorted_tail).
 static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
-                             const uint32_t* taxkey, bool compact, bool second, uint64_t poolEntries, hipStream_t st, bool deferSorted = false, bool probeFusion = false)
+                             const uint32_t* taxkey, bool compact, bool second, uint64_t poolEntries, hipStream_t st, bool deferSorted = false)
 {
     // timers carry the kernels' own names: compact store gw_filter_count_kernel (or gw_filter_kernel with "gw_fuse" 0), the rest of the
     // filters (gw_filter2 + compaction + gw_filter_stream), gw_count_kernel<9> + <10>, gw_count_kernel<11>; 8-byte store: big_*
     { ScopedTimer t(ctx, compact ? (ws.gwFuse ? "gw_filter_count" : "gw_filter") : "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
-    // probe fusion: the lane path's reads still wait for their lookups (kFlagProbe) -- lookups, filter and counting in one kernel, in the
-    // same pool slices behind the kernel above (which took the chunk and wave kernels' records)
-    if (probeFusion) { ScopedTimer t(ctx, "gw_probe_filter_count", st); launch_big_cands(6, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
     // host's look at the counters: always launched, returns at once with nothing to do)
     if (second || compact) { ScopedTimer t(ctx, compact ? "gw_filter_rest" : "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
@@ -787,16 +783,8 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         // (A key shard's side of Mode K masks the features it does not own between the two: not fused.)
         const bool maskFeatures = wantPartial && !wantFeatures && ctx->cfg.key_shard_count > 1;
         const bool quadTable = ctx->quadLookup >= 0 ? ctx->quadLookup != 0 : (uint64_t)tab.nbuckets * 64ull > (1ull << 30);
-        // PROBE FUSION (round 5; compact store): the lookups of the lane path's reads are done by the kernel that filters and counts them
-        // (gw_probe_filter_count_kernel: a lookup phase of one lane per read, then a filter phase of one wave per read, per chunk of 64 reads) --
-        // no lookup-only kernel whose waiting leaves the VALUs idle.  "probe_fusion" / MC_PROBE_FUSION: -1 = on tables beyond 1 GiB, 0 / 1.
-        const bool fuseProbe = T.compact && !wantPartial && ctx->gwFuse != 0 && (ctx->fuseProbe >= 0 ? ctx->fuseProbe != 0 : quadTable);
-        const bool fuseSketch = !fuseProbe && !maskFeatures && (ctx->fuseLane >= 0 ? ctx->fuseLane != 0 : quadTable);
-        if (fuseProbe) {
-            { ScopedTimer t(ctx, "sketch_lane", st); launch_sketch_lane(b, sp, ws, st); }
-            { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
-            { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, ctx->quadLookup, st); }
-        } else if (fuseSketch) {
+        const bool fuseSketch = !maskFeatures && (ctx->fuseLane >= 0 ? ctx->fuseLane != 0 : quadTable);
+        if (fuseSketch) {
             { ScopedTimer t(ctx, "sketch_probe", st); launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st); }
             { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
             { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, ctx->quadLookup, st); }
@@ -817,8 +805,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         uint32_t none[16] = {0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};      // partial lists: no candidate kernels, the wave kernels for the rest
         uint32_t* hcnt = wantPartial ? none : all;
         // (MC_DEFER_TAIL: no look at the counters either -- everything is launched, the caller has another batch to enqueue)
-        // (probe fusion: the work lists are complete only behind gw_probe_filter_count_kernel -- everything is launched)
-        if (!wantPartial && n <= (1u << 20) && !(flags & MC_DEFER_TAIL) && !fuseProbe) {
+        if (!wantPartial && n <= (1u << 20) && !(flags & MC_DEFER_TAIL)) {
             if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
             hcnt = reinterpret_cast<uint32_t*>(P.hTotal + 1);
             launch_flag_count(ws, n, st);
@@ -833,7 +820,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             if (hcnt[3]) { ScopedTimer t(ctx, "hash_cands_512", st); launch_hash_cands(3, b, tab, ws, K, taxkey, P.bCands.p, st); }
             if (hcnt[4]) { ScopedTimer t(ctx, "hash_cands_1024", st); launch_hash_cands(4, b, tab, ws, K, taxkey, P.bCands.p, st); }
         };
-        if (!fuseProbe) mid_and_hash();                        // (probe fusion: their work lists are filled by the filtered path's kernel: below)
+        mid_and_hash();
         bool waveDone = false;
         if (T.compact && !wantPartial && hcnt[6]) {
             // compact store: the wave kernel's sketching and probing first, so that its reads can join the filtered path
@@ -853,12 +840,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         // the main kernels enqueued and NO synchronisation, so that the caller can enqueue the next batch on the other pipe first
         const bool defer = (flags & MC_DEFER_TAIL) != 0 && hcnt == all && !wantFeatures;
         if (hcnt[9] || waveDone) {
-            // (probe fusion without MC_DEFER_TAIL: the sorted class waits until the lane kernels behind the filtered path are enqueued)
-            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st, defer || fuseProbe, fuseProbe))) return rc;
-        }
-        if (fuseProbe) {
-            mid_and_hash();
-            if (!defer && (rc = run_sorted_tail(ctx, P, b, sp, tab, ws, K, taxkey, poolCap + ovfCap, false, st))) return rc;
+            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st, defer))) return rc;
         }
         waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
         skipWaveSketch = waveDone;
@@ -1191,7 +1173,6 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
-    else if (n == "probe_fusion") ctx->fuseProbe = value < 0 ? -1 : (value != 0);   // lookups inside the kernel that filters and counts (-1: on tables beyond 1 GiB)
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
     else if (n == "gw_fuse") ctx->gwFuse = value != 0;                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart

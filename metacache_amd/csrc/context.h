@@ -138,7 +138,6 @@ struct mc_ctx {
     uint32_t bigMin = 128;                 // location lists longer than this (and than 64) are filtered before they are counted (big_filter_kernel); MC_BIG_MIN.
                                            // 256 / 128 / 64 at 15 Gbp (195 locations per read): 3.92 / 3.53 / 3.48 ms per 10^6 reads; at 4.5 Gbp (100): 3.01 / 3.12 / 3.25
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
-    int fuseProbe = -1;                    // lookups of the lane path inside gw_probe_filter_count_kernel: -1 = on tables beyond 1 GiB, 0 / 1
     int fuseLane = -1;                     // sketching + probing of the lane path in ONE kernel: -1 = where the lookups are quad-cooperative (tables beyond 1 GiB: the
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)

@@ -853,9 +853,8 @@ struct GwPend {
 // DEFER: the winners' target lookup waits in P for the caller's next read (see GwPend; the caller finishes the last one).
 // LONG (first instance's table only): the list may hold up to 2^LOG2S numbers as long as no more than half of them are DISTINCT (a filtered
 // list of 400 numbers has about 100 distinct ones); a list with more goes to the exact wave kernel.
-// entf(): where step D finds the read's entries -- {first entry slot in ws.psize / ws.ppay, entries} (the record of work list 6).
-// COH: the entries were written by THIS kernel (gw_probe_filter_count_kernel): read past the L1.
-template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, bool COH = false, class GetV, class EntF>
+// entf(): where step D finds the read's entries -- {first entry slot in ws.psize / ws.ppay, entries} (the record of work list 6)
+template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, class GetV, class EntF>
 __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
                                               uint2* slots, uint32_t* ck, uint64_t* T, const uint32_t lane, const uint32_t grp, const uint32_t sub4,
                                               const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab, const Workspace& ws,
@@ -952,13 +951,8 @@ __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, con
             // ---- D. the smallest numbers of targets that were not picked with >= 2 hits -- every such target's best range is a
             //      single location, and the first of them in (target, window) order are what the CPU's list keeps
             wave_lds_sync();
-            uint32_t sz = 0; uint64_t pay = 0;
-            if (lane < nent) {
-                if constexpr (COH) {
-                    sz = __hip_atomic_load(ws.psize + fbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu;
-                    pay = __hip_atomic_load(ws.ppay + fbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else { sz = ws.psize[fbase + lane] & 0xFFFFu; pay = ws.ppay[fbase + lane]; }
-            }
+            const uint32_t sz = lane < nent ? (ws.psize[fbase + lane] & 0xFFFFu) : 0u;
+            const uint64_t pay = lane < nent ? ws.ppay[fbase + lane] : 0ull;
             const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
             const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
             // every lane keeps the kLaneK smallest numbers it sees (several may be one target's: the rounds below strike whole
@@ -1229,305 +1223,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
 }
 
 // ================================================================================================
-// gw_probe_filter_count_kernel (round 5): the lookups of the lane path AND the filter + counting of its reads in one persistent kernel,
-// in alternating PHASES per wave.
-// Round 4's step ran sketch_probe_lane_kernel (4.9 ms per 5 x 10^6 reads: 74 % of its wave cycles waiting for random buckets, the VALUs
-// idle) and then gw_filter_count_kernel (12.9 ms: instruction issue and LDS round trips, the memory system idle); two batches in
-// flight hardly overlap them, because a CU full of filter waves has no slot for a lookup wave.  Here every wave of the filter
-// kernel's grid takes CHUNKS of 64 consecutive reads and alternates:
-//   lookup phase   one LANE per read -- probe_cands_one's state machine (two lookups in flight per lane, quad-cooperative bucket
-//                  fetches), ~100 VALU wave instructions per read because 64 reads share every instruction: the wave spends ~150 us
-//                  per chunk mostly waiting, and that waiting costs the SIMD's other four waves nothing (measured with a sleep of the
-//                  same length in the filter kernel: 160 us per 64 reads = +0.9 ms per launch);
-//   filter phase   one WAVE per read over the chunk's reads of the filtered class -- gw_filter_count_kernel's body; the entries
-//                  the lookup phase has just written are read back through the L2 (a read ahead).
-// (A wave per read for the LOOKUPS as well -- the form the round-4 verdict sketched -- was built first and measured slower: 344 VALU
-// instructions per read instead of 100 in a kernel bound by issue; docs/LAB_NOTEBOOK_r05.md.)
-// The lookup phase writes every read's entries (found features only, in the order they were found, list offsets a running sum; the rest
-// of the read's slots zero), its QueryStat and its class as probe_cands_one does, with two differences: reads of up to kLaneHits
-// locations, which that kernel finishes in its lane's LDS row, go to mid_cands_kernel's first work list (this kernel has no rows), and
-// the filtered class' reads are not appended to work list 6 -- the wave keeps them.  Records of lists 6 / 7 are appended only for the
-// reads that go on behind this kernel (left to gw_filter2 / the stream filter, or through the pool to the other counting instances):
-// places reserved up to eight at a time per wave, never more than the wave has reads left; unused places get records everybody skips.
-// Runs behind gw_filter_count_kernel on the records the chunk and wave kernels left (same grid, same pool slices: ws.sliceFill);
-// mid_cands / hash_cands are launched behind it.  (src/gpu_hashmap_operations.cuh:847-942 is one kernel for sketch + lookup + copy too.)
-// ================================================================================================
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
-__global__ __launch_bounds__(WAVES * 64, WPE) void gw_probe_filter_count_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
-                                                                                const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
-{
-    using Bloom = GwBloom<TLOG2, TLOG2>;
-    constexpr uint32_t kKeep = 512;
-    __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
-    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][kGwRounds];
-    __shared__ uint32_t keptS[WAVES][kKeep];
-    __shared__ uint32_t classS[WAVES][64];                         // the chunk's reads of the filtered class: entries | locations << 12
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* bits = bitS[wave];
-    uint64_t* T = roundS[wave];
-    uint32_t* kept = keptS[wave];
-    uint32_t* cls7 = classS[wave];
-    const uint32_t n = b.n;
-    uint4* __restrict__ work6 = reinterpret_cast<uint4*>(ws.midList) + (size_t)6 * n;
-    uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * n;
-    const uint32_t nWaves = gridDim.x * WAVES;
-    const uint32_t w0 = blockIdx.x * WAVES + wave;
-    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
-    uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;   // (gw_filter_count_kernel ran before, on the chunk and wave kernels' records)
-    uint32_t deferred = 0, statReads = 0;
-    unsigned long long statKept = 0;
-    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    const uint32_t* __restrict__ winOff = ws.winOff;
-    const uint32_t* __restrict__ mwArr = b.maxWin;
-    const uint32_t nChunks = (n + 63u) / 64u;
-    GwPend P;
-    uint32_t recAt = 0, recLeft = 0;
-
-    for (uint32_t c = w0; c < nChunks; c += nWaves) {
-        // =================================================================== lookup phase: lane = read 64 c + lane
-        uint64_t todo;
-        {
-            const uint32_t q = c * 64u + lane;
-            const bool valid = q < n && ws.qflag[q] == kFlagProbe;
-            const uint32_t fbase = valid ? winOff[q] * s : 0u, nf = valid ? (winOff[q + 1] - winOff[q]) * s : 0u;
-            const uint32_t* feats = ws.features + fbase;
-            uint32_t H = 0, nfeat = 0, nfound = 0, nsteps = 0, goff = 0;
-            // entries go out two at a time (8 + 16 bytes): every store of a lane is a request of its own
-            uint32_t heldSize = 0; uint64_t heldPay = 0;
-            const bool pairs = (fbase & 1u) == 0;
-            auto put_entry = [&](uint32_t ps, uint64_t pp) {
-                if (!pairs) { ws.psize[fbase + nfound] = ps; ws.ppay[fbase + nfound] = pp; }
-                else if ((nfound & 1u) == 0) { heldSize = ps; heldPay = pp; }
-                else {
-                    *reinterpret_cast<uint2*>(ws.psize + fbase + nfound - 1) = make_uint2(heldSize, ps);
-                    *reinterpret_cast<uint4*>(ws.ppay + fbase + nfound - 1) = make_uint4((uint32_t)heldPay, (uint32_t)(heldPay >> 32), (uint32_t)pp, (uint32_t)(pp >> 32));
-                }
-                ++nfound;
-            };
-            uint32_t e = 0;
-            uint4 fcache = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            const bool wide = (s & 3u) == 0;
-            auto next_feature = [&]() -> uint32_t {
-                if (!wide) return feats[e++];
-                if ((e & 3u) == 0) fcache = reinterpret_cast<const uint4*>(feats)[e >> 2];
-                const uint32_t i = e++ & 3u;
-                return i == 0 ? fcache.x : i == 1 ? fcache.y : i == 2 ? fcache.z : fcache.w;
-            };
-            // every round: resolve what was requested in the round before, hand idle slots their next feature, request what every busy slot
-            // needs now (quad-cooperative: the branches around the requests are wave-uniform; a lane that has run out idles along).
-            // A quad's four buckets arrive as four quarters per lane (quad_issue); they are put together in LDS -- the filter's, idle in this
-            // phase: lane L's bucket at byte 64 L -- and matched from there: keys, sizes, then the one payload that is wanted (the register
-            // transpose of probe_cands_one holds 32 registers more than this kernel has).
-            struct Slot { uint32_t f, cur, step; bool busy; QuadRaw raw; };
-            Slot S0, S1;
-            S0.busy = false; S1.busy = false;
-            char* const lines = reinterpret_cast<char*>(bits);
-            auto resolve = [&](Slot& S) {
-                if (!__ballot(S.busy)) return;
-                *reinterpret_cast<uint4*>(lines + ((lane & ~3u) + 0u) * 64u + (lane & 3u) * 16u) = S.raw.v[0];
-                *reinterpret_cast<uint4*>(lines + ((lane & ~3u) + 1u) * 64u + (lane & 3u) * 16u) = S.raw.v[1];
-                *reinterpret_cast<uint4*>(lines + ((lane & ~3u) + 2u) * 64u + (lane & 3u) * 16u) = S.raw.v[2];
-                *reinterpret_cast<uint4*>(lines + ((lane & ~3u) + 3u) * 64u + (lane & 3u) * 16u) = S.raw.v[3];
-                wave_lds_sync();
-                if (S.busy) {
-                    ++nsteps;
-                    const char* bk = lines + lane * 64u;
-                    const uint4 k4 = *reinterpret_cast<const uint4*>(bk);
-                    const uint2 s2 = *reinterpret_cast<const uint2*>(bk + 16);
-                    const uint32_t s0 = s2.x & 0xFFFFu, s1 = s2.x >> 16, s2v = s2.y & 0xFFFFu, s3 = s2.y >> 16;
-                    const bool anyFree = s0 == 0u || s1 == 0u || s2v == 0u || s3 == 0u;
-                    uint32_t size = 0, slot = 0;
-                    if (s0 != 0u && k4.x == S.f) { size = s0; slot = 0; }
-                    if (s1 != 0u && k4.y == S.f) { size = s1; slot = 1; }
-                    if (s2v != 0u && k4.z == S.f) { size = s2v; slot = 2; }
-                    if (s3 != 0u && k4.w == S.f) { size = s3; slot = 3; }
-                    if (size) {
-                        put_entry(size | (goff << 16), *reinterpret_cast<const uint64_t*>(bk + 32 + 8 * slot));
-                        goff += size; H += size;
-                        S.busy = false;
-                    } else if (anyFree || S.step >= tab.maxProbe) {
-                        S.busy = false;                                // a bucket with a free slot ends the chain
-                    } else {
-                        // (next_bucket from the bucket at hand: home ^ 1, then (home | 1) + 1 = (sibling | 1) + 1, then one by one)
-                        const uint32_t nx = S.step == 1 ? (S.cur ^ 1u) : ((S.step == 2 ? (S.cur | 1u) : S.cur) + 1u);
-                        S.cur = (S.step != 1 && nx >= tab.nbuckets) ? 0u : nx;
-                        ++S.step;
-                    }
-                }
-                wave_lds_sync();                                       // (the next slot's buckets take the same LDS)
-            };
-            auto refill = [&](Slot& S) {
-                while (!S.busy && e < nf) {
-                    S.f = next_feature();
-                    if (S.f != 0xFFFFFFFFu) {
-                        ++nfeat;
-                        S.cur = home_group(S.f, tab.nbuckets); S.step = 1;
-                        S.busy = true;
-                    }
-                }
-            };
-            for (bool first = true;; first = false) {
-                if (!first) { resolve(S0); resolve(S1); }
-                refill(S0); refill(S1);
-                if (!__ballot(S0.busy || S1.busy)) break;
-                if (__ballot(S0.busy)) quad_issue(tab, S0.busy ? S0.cur : kNoBucket, S0.raw);
-                if (__ballot(S1.busy)) quad_issue(tab, S1.busy ? S1.cur : kNoBucket, S1.raw);
-            }
-            if (pairs && (nfound & 1u)) { ws.psize[fbase + nfound - 1] = heldSize; ws.ppay[fbase + nfound - 1] = heldPay; }
-            uint32_t cls = 8;                                      // 8: not this kernel's read
-            const uint32_t mw = mwArr ? (q < n ? mwArr[q] : 0u) : b.maxWinUniform;
-            if (valid) {
-                for (uint32_t j = nfound; j < nf; ++j) ws.psize[fbase + j] = 0u;   // (the wave kernel reads all nf slots)
-                QueryStat qs; qs.hits = H; qs.nfeat = nfeat; qs.nfound = nfound; qs.nsteps = nsteps;
-                ws.qstat[q] = qs;
-                if (H == 0u) {
-                    for (uint32_t i = 0; i < K; ++i) { mc_candidate_dev z; z.tgt = 0xFFFFFFFFu; z.hits = 0; z.beg = 0; z.end = 0; cands[(size_t)q * K + i] = z; }
-                    ws.hitScan[q] = 0u; ws.qflag[q] = kFlagDone;
-                } else {
-                    const bool hashOK = nfound <= kHashEnt && mw <= kHashWin;
-                    const bool bigOK = H > ws.bigMin && H > 64u && nfound <= 0xFFFu && mw <= tab.gwGap && H <= kMaxHitsPerQuery;
-                    cls = bigOK ? 7u : H <= 64u ? 0u : H <= 128u ? (hashOK ? 5u : 1u) : H <= kMidMax ? (hashOK ? 5u : 2u)
-                        : (H <= kHashMax && hashOK) ? (H <= kHashMax / 2 ? 3u : 4u) : 6u;
-                    ws.hitScan[q] = (cls >= 3u && cls != 6u) ? 0u : ((H <= kMaxHitsPerQuery && H > kLdsCap) ? H : 0u);
-                    ws.qflag[q] = cls != 6u ? kFlagMid : kFlagCands;
-                }
-            }
-            // the work lists of mid_cands / hash_cands: one atomic per wave and class
-#pragma unroll
-            for (uint32_t k = 0; k < 6; ++k) {
-                const uint64_t mask = __ballot(cls == k);
-                if (cls == k) {
-                    const uint32_t leader = __ffsll((unsigned long long)mask) - 1;
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(&ws.midCount[k < 5 ? k : 8u], (uint32_t)__popcll(mask));
-                    base = __shfl(base, leader);
-                    reinterpret_cast<uint4*>(ws.midList)[(size_t)k * n + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint4(q, fbase, nfound | (H << 12), mw);
-                }
-            }
-            todo = __ballot(cls == 7u);
-            cls7[lane] = nfound | (H << 12);
-        }
-        if (!todo) continue;
-        // the entries are read back by other lanes of this wave: stores done, loads past the L1
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        wave_lds_sync();
-        // =================================================================== filter phase: wave = read
-        uint32_t esz = 0; uint64_t epay = 0;                       // the read's entries, fetched one read ahead
-        auto load_entries = [&](uint32_t j) {
-            const uint32_t qq = c * 64u + j;
-            const uint32_t z = (uint32_t)__builtin_amdgcn_readfirstlane((int)cls7[j]);
-            const uint32_t fb = winOff[qq] * s;
-            const uint32_t ne = (z >> 12) <= kGwSmallH ? min(z & 0xFFFu, 64u) : 0u;
-            esz = 0; epay = 0;
-            if (lane < ne) {
-                esz = __hip_atomic_load(ws.psize + fb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                epay = __hip_atomic_load(ws.ppay + fb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        auto take_record = [&](uint64_t left) -> uint32_t {       // left: this chunk's reads still to do, this one included
-            if (recLeft == 0) {
-                const uint32_t later = (nChunks - 1u - c) / nWaves;                   // chunks this wave still has after this one
-                const uint32_t mine = (uint32_t)__popcll(left) + (later ? 64u * (later - 1u) : 0u);
-                const uint32_t want = min(8u, mine);
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&ws.midCount[9], want);
-                recAt = (uint32_t)__builtin_amdgcn_readfirstlane((int)at); recLeft = want;
-            }
-            --recLeft;
-            return recAt++;
-        };
-        load_entries((uint32_t)__ffsll((unsigned long long)todo) - 1u);
-        while (todo) {
-            const uint64_t left = todo;
-            const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
-            todo &= todo - 1;
-            const uint32_t q = c * 64u + j;
-            const uint32_t z = (uint32_t)__builtin_amdgcn_readfirstlane((int)cls7[j]);
-            const uint32_t nent = z & 0xFFFu, H = z >> 12, fbase = winOff[q] * s;
-            const uint32_t maxWin = mwArr ? mwArr[q] : b.maxWinUniform;
-            const uint32_t sz = esz & 0xFFFFu; const uint64_t pay = epay;
-            if (todo) load_entries((uint32_t)__ffsll((unsigned long long)todo) - 1u);
-            const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
-            const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
-            if (H > kGwSmallH || nent > 64u || Rc > kGwRounds || sliceCap - sliceUsed < kGwRounds * 16u + 64u) {
-                const uint32_t w = take_record(left);              // left to gw_filter2_kernel / gw_filter_stream_kernel
-                if (lane == 0) { work6[w] = make_uint4(q, fbase, z, maxWin); outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin); }
-                ++deferred;
-                continue;
-            }
-            {
-                uint4* z4 = reinterpret_cast<uint4*>(bits);
-#pragma unroll
-                for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-            }
-            gw_fill_rounds_scan(T, kept, lane, Rc, incl - myR, myR, sz, pay);   // (kept: free until phase B)
-            wave_lds_sync();
-            const GwFrame F(maxWin);
-            const uint32_t nl = (Rc + 15u) >> 4;
-            uint4 x[kGwLoads];
-            gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
-            const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
-            if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
-            gw_mark_rounds<Bloom>(bits, x, F.A, nl);
-            wave_lds_sync();
-            const bool here = maxWin <= kHashWin;
-            uint32_t n2;
-            if (here) {
-                GwSink S{kept, kKeep, 0u};
-                gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-                gw_take_rounds<Bloom, true>(bits, T, F, S, grp, sub4, x, nl);
-                n2 = S.n2;
-            } else {
-                GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-                gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-                gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
-                n2 = S.n2;
-            }
-            if (here && n2 <= kKeep) {
-                wave_lds_sync();
-                const bool counted = gw_count_read<9, TAX, true, true, true>(q, [&]() -> uint2 { return make_uint2(fbase, nent); }, n2, maxWin,
-                                            [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
-                                            reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, P);
-                if (counted) { ++statReads; statKept += n2; }
-                else {
-                    // more than 256 DISTINCT numbers among the kept ones: the list -- still in LDS -- goes through the pool to gw_count_kernel<10>
-                    const uint32_t w = take_record(left);
-#pragma unroll
-                    for (uint32_t r = 0; r < kKeep / 64; ++r) if (r * 64 + lane < n2) slice[sliceUsed + r * 64 + lane] = kept[r * 64 + lane];
-                    if (lane == 0) { work6[w] = make_uint4(q, fbase, z, maxWin); outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin); }
-                    sliceUsed += n2;
-                    wave_lds_sync();
-                }
-                continue;
-            }
-            if (here) {
-                GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-                gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-                gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
-                n2 = S.n2;
-            }
-            const uint32_t room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed);
-            if (n2 > room) { if (lane == 0) { ws.hitScan[q] = H; ws.qflag[q] = kFlagCands; } }
-            else {
-                const uint32_t w = take_record(left);
-                if (lane == 0) { work6[w] = make_uint4(q, fbase, z, maxWin); outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin); }
-                sliceUsed += n2;
-            }
-            wave_lds_sync();
-        }
-        // (the winners of the chunk's last read are looked up before the next lookup phase: its loads would be waited for with theirs)
-        P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
-    }
-    if (lane == 0) {
-        for (; recLeft; --recLeft, ++recAt) { work6[recAt] = make_uint4(0, 0, 0, 0); outRec[recAt] = make_uint4(0, 0, kGwCounted, 0); }   // (skipped by everybody)
-        if (ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
-        if (deferred) atomicAdd(&ws.midCount[10], deferred);
-        if (statReads) { atomicAdd(&ws.midCount[20], statReads); atomicAdd(reinterpret_cast<unsigned long long*>(ws.midCount + 22), statKept); }
-    }
-}
-
-// ================================================================================================
 // gw_sorted_cands_kernel: rows 9-10 on a SORTED filtered list (gw_sort.hip) -- long reads (thousands of kept locations, window ranges
 // of tens to hundreds), pairs with large insert sizes.  One wave per read; the list is taken 64 numbers at a time, one per lane, each
 // finding the begin of the CPU's sliding window that ends in it (candidate_generation.hpp:47-108: numbers less than maxWindowsInRange
@@ -1762,12 +1457,6 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
         else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-    } else if (stage == 6) {
-        // the lane path's reads that still wait for their lookups (kFlagProbe): lookups, filter and counting in one kernel, in phases per wave
-        static const uint32_t wpe = gw_env("MC_PROBE_WPE", 5u);   // EXPERIMENT
-        if (taxkey) hipLaunchKernelGGL((gw_probe_filter_count_kernel<4, 14, true, 5>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else if (wpe == 4) hipLaunchKernelGGL((gw_probe_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
-        else hipLaunchKernelGGL((gw_probe_filter_count_kernel<4, 14, false, 5>), dim3(fgrid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);

@@ -3088,11 +3088,7 @@ __global__ __launch_bounds__(256) void big_stats_kernel(const uint32_t* __restri
     atomicAdd((unsigned long long*)&stats[5], kept);
     atomicAdd((unsigned long long*)&stats[6], (unsigned long long)over << 32);
     atomicAdd((unsigned long long*)&stats[7], (unsigned long long)fb << 32);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // ([20], [22..23]: the reads gw_probe_filter_count_kernel counted without a record, and what its filter kept of them)
-        atomicAdd((unsigned long long*)&stats[6], (unsigned long long)total + midCount[20]); atomicAdd((unsigned long long*)&stats[7], (unsigned long long)midCount[10]);
-        atomicAdd((unsigned long long*)&stats[5], *reinterpret_cast<const unsigned long long*>(midCount + 22));
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd((unsigned long long*)&stats[6], (unsigned long long)total); atomicAdd((unsigned long long*)&stats[7], (unsigned long long)midCount[10]); }
 }
 
 void launch_batch_stats(const Workspace& ws, uint32_t n, hipStream_t st)

@@ -54,13 +54,12 @@ def sample_features(reads: list[bytes]) -> np.ndarray:
 # Every shipped variant of the lane path's kernels (mc_set_tuning switches; include/metacache_amd.h): each must give the results the
 # default gives -- and those are compared with the oracle / the reference.  name -> switches set on top of the defaults.
 VARIANTS = {
-    "probe_fusion": {"probe_fusion": 1},                                                # gw_probe_filter_count_kernel (lookups inside the filter kernel)
-    "lane_fusion_quad": {"probe_fusion": 0, "lane_fusion": 1, "quad_lookup": 1},       # sketch_probe_lane_kernel<true>
-    "lane_fusion_private": {"probe_fusion": 0, "lane_fusion": 1, "quad_lookup": 0},    # sketch_probe_lane_kernel<false>
-    "apart": {"probe_fusion": 0, "lane_fusion": 0, "quad_lookup": 0},                  # sketch_lane + probe_cands<false> + gw_filter_count
-    "apart_quad_unfused_count": {"probe_fusion": 0, "lane_fusion": 0, "quad_lookup": 1, "gw_fuse": 0},   # ... probe_cands<true>, gw_filter + gw_count apart
+    "lane_fusion_quad": {"lane_fusion": 1, "quad_lookup": 1},       # sketch_probe_lane_kernel<true>
+    "lane_fusion_private": {"lane_fusion": 1, "quad_lookup": 0},    # sketch_probe_lane_kernel<false>
+    "apart": {"lane_fusion": 0, "quad_lookup": 0},                  # sketch_lane + probe_cands<false> + gw_filter_count
+    "apart_quad_unfused_count": {"lane_fusion": 0, "quad_lookup": 1, "gw_fuse": 0},   # ... probe_cands<true>, gw_filter + gw_count apart
 }
-_DEFAULTS = {"probe_fusion": -1, "lane_fusion": -1, "quad_lookup": -1, "gw_fuse": 1}
+_DEFAULTS = {"lane_fusion": -1, "quad_lookup": -1, "gw_fuse": 1}
 
 
 def each_variant(db, names=None):

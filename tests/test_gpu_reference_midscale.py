@@ -58,7 +58,7 @@ def test_reference_witnesses_the_filtered_path(monkeypatch):
             got["compact, " + v] = (db.query(singles)[0], db.query(p1, p2)[0])
         db.set_tuning("big_min", 0)
         got["compact, big_min 0"] = (db.query(singles)[0], db.query(p1, p2)[0])
-        for v in scale_util.each_variant(db, ("probe_fusion", "apart_quad_unfused_count")):
+        for v in scale_util.each_variant(db, ("apart_quad_unfused_count",)):
             got["compact, big_min 0, " + v] = (db.query(singles)[0], db.query(p1, p2)[0])
         db.close()
         monkeypatch.setenv("MC_COMPACT_LOCATIONS", "0")
