@@ -1222,134 +1222,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
     }
 }
 
-// The same fusion for reads of up to 2 x kGwRounds rounds and 2 x kGwSmallH locations (2 x 150 bp pairs at RefSeq scale: 52 lists, ~2 540
-// locations, ~400 of them kept): gw_filter2_kernel's two register batches, and the counting right behind phase B where the kept numbers
-// fit.  No LDS beyond the filter's own: phase B only asks the "twice" half of the filter bits, so the "seen" half -- 4 KB, dead once
-// phase A is over -- takes the kept numbers (up to 1 024) while phase B runs; after phase B the "twice" half is the counting's slot table
-// and the round table its list of distinct numbers.  (Round 4 read the kept numbers back from the pool instead: 16.6 + 1.9 ms against
-// 11.4 + 6.4 apart; a third LDS array would have cost a block per CU.)  Lists of 513 .. 1 024 kept numbers are copied from LDS to the pool
-// for gw_count_kernel<11>; longer ones (the sorted class) and window ranges beyond kHashWin repeat phase B into the pool.
-template <uint32_t WAVES, uint32_t TLOG2, bool TAX>
-__global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K,
-                                                                                        const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
-{
-    using Bloom = GwBloom<TLOG2, TLOG2>;
-    constexpr uint32_t kLdsKeep = Bloom::kW1;                      // numbers the "seen" half holds
-    constexpr uint32_t kCountMax = 512;                            // gw_count_read<9, .., LONG>: up to 512 numbers, 256 of them distinct
-    static_assert(Bloom::kW2 * 4 >= 512 * 8, "the slot table of the counting takes the place of the \"twice\" bits");
-    static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
-    __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
-    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][kGwRounds];
-    if (ws.midCount[10] == 0) return;                              // nothing was left
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* bits = bitS[wave];
-    uint32_t* kept = bits;                                         // the "seen" half, from phase B on
-    uint32_t* twiceBits = bits + Bloom::kW1;
-    uint64_t* T = roundS[wave];
-    const uint32_t total = ws.midCount[9];
-    const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
-    uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
-    const uint32_t nWaves = gridDim.x * WAVES;
-    const uint32_t w0 = blockIdx.x * WAVES + wave;
-    const uint64_t sliceCap = ws.bigPoolCap / nWaves;
-    uint32_t* const slice = reinterpret_cast<uint32_t*>(ws.bigPool) + (uint64_t)w0 * sliceCap;
-    uint64_t sliceUsed = ws.sliceFill ? ws.sliceFill[w0] : 0u;
-    const uint32_t grp = lane >> 2, sub4 = (lane & 3u) * 4u;
-    constexpr uint32_t kMaxRounds = 2 * kGwRounds, kMaxH = 2 * kGwSmallH;
-    uint32_t esz = 0; uint64_t epay = 0;
-    auto load_entries = [&](uint32_t fbase, uint32_t ne) {
-        esz = lane < ne ? ws.psize[fbase + lane] : 0u;
-        epay = lane < ne ? ws.ppay[fbase + lane] : 0ull;
-    };
-    GwPend P;
-    for (uint32_t chunk = w0 * 64u; chunk < total; chunk += nWaves * 64u) {
-      const bool inb = chunk + lane < total;
-      const uint4 myRec = inb ? work[chunk + lane] : make_uint4(0, 0, 0, 0);
-      const uint32_t myZ = inb ? outRec[chunk + lane].z : 0u;
-      uint64_t todo = __ballot(inb && myZ == kGwDefer && (myRec.z >> 12) <= kMaxH && (myRec.z & 0xFFFu) <= 64u && myRec.w <= tab.gwGap);
-      if (todo) { const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1; load_entries(rdlane(myRec.y, j), rdlane(myRec.z, j) & 0xFFFu); }
-      while (todo) {
-        const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t w = chunk + j, q = rdlane(myRec.x, j), maxWin = rdlane(myRec.w, j);
-        const uint32_t sz = esz & 0xFFFFu; const uint64_t pay = epay;
-        if (todo) { const uint32_t jn = (uint32_t)__ffsll((unsigned long long)todo) - 1; load_entries(rdlane(myRec.y, jn), rdlane(myRec.z, jn) & 0xFFFu); }
-        const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
-        const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63), start = incl - myR;
-        if (Rc > kMaxRounds || sliceCap - sliceUsed < kMaxRounds * 16u + 64u) continue;   // stays deferred: gw_filter_stream_kernel
-        {
-            uint4* z4 = reinterpret_cast<uint4*>(bits);
-#pragma unroll
-            for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        }
-        const GwFrame F(maxWin);
-        const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
-        uint4 x[kGwLoads];
-        // ---- A: batch 0, then batch 1 (stays in registers)
-        if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
-        gw_fill_rounds(T, lane, 0, Rc, start, myR, sz, pay);
-        wave_lds_sync();
-        gw_load_rounds(T, tab.values32, grp, sub4, x);
-        gw_mark_rounds<Bloom>(bits, x, F.A);
-        const bool two = Rc > kGwRounds;
-        if (two) {
-            wave_lds_sync();
-            gw_fill_rounds(T, lane, kGwRounds, Rc, start, myR, sz, pay);
-            wave_lds_sync();
-            gw_load_rounds(T, tab.values32, grp, sub4, x);
-            gw_mark_rounds<Bloom>(bits, x, F.A);
-        }
-        wave_lds_sync();
-        // ---- B: the batch in registers, then (two batches) batch 0 again; kept numbers to the "seen" half (phase B reads "twice" only)
-        //      or, window ranges the counting here does not take, to the pool
-        const bool here = maxWin <= kHashWin;
-        auto phase_b = [&](GwSink& S, auto check) {
-            constexpr bool CHECK = decltype(check)::value;
-            gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, CHECK>(bits, T, F, S, grp, sub4, x);
-            if (two) {
-                wave_lds_sync();
-                gw_fill_rounds(T, lane, 0, Rc, start, myR, sz, pay);
-                wave_lds_sync();
-                gw_load_rounds(T, tab.values32, grp, sub4, x);
-                gw_take_rounds<Bloom, CHECK>(bits, T, F, S, grp, sub4, x);
-            }
-        };
-        uint32_t n2;
-        if (here) { GwSink S{kept, kLdsKeep, 0u}; phase_b(S, std::true_type{}); n2 = S.n2; }
-        else { GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u}; phase_b(S, std::false_type{}); n2 = S.n2; }
-        if (here && n2 <= kCountMax) {
-            if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
-            wave_lds_sync();                                       // every lane's tests of the "twice" bits before the slot table takes their place
-            const bool counted = gw_count_read<9, TAX, true, true>(q, [&]() -> uint2 { const uint4 r6 = work[w]; return make_uint2(r6.y, r6.z & 0xFFFu); }, n2, maxWin,
-                                        [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
-                                        reinterpret_cast<uint2*>(twiceBits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, P);
-            if (counted) continue;
-        }
-        if (here && n2 <= kLdsKeep) {
-            // 513 .. 1 024 kept numbers (or more than 256 distinct ones): from LDS to the pool, for gw_count_kernel<10> / <11>
-            for (uint32_t r = lane; r < n2; r += 64) slice[sliceUsed + r] = kept[r];
-        } else if (here) {
-            // more than the "seen" half holds: phase B once more, into the pool (batch 1 is loaded again: phase B left batch 0 in the registers)
-            if (two) {
-                wave_lds_sync();
-                gw_fill_rounds(T, lane, kGwRounds, Rc, start, myR, sz, pay);
-                wave_lds_sync();
-                gw_load_rounds(T, tab.values32, grp, sub4, x);
-            }
-            GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
-            phase_b(S, std::false_type{});
-            n2 = S.n2;
-        }
-        if (lane == 0) outRec[w] = make_uint4(q, (uint32_t)((uint64_t)w0 * sliceCap + sliceUsed), n2, maxWin);
-        sliceUsed += n2;
-        wave_lds_sync();
-      }
-    }
-    P.bases(tab); P.template finish<TAX>(lane, K, tab, ws, cands);
-    if (lane == 0 && ws.sliceFill) ws.sliceFill[w0] = (uint32_t)sliceUsed;
-}
-
 // ================================================================================================
 // gw_sorted_cands_kernel: rows 9-10 on a SORTED filtered list (gw_sort.hip) -- long reads (thousands of kept locations, window ranges
 // of tens to hundreds), pairs with large insert sizes.  One wave per read; the list is taken 64 numbers at a time, one per lane, each
@@ -1588,10 +1460,7 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     } else if (stage == 3) {
         // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
-        // (read pairs: two register batches; "gw_fuse" 1: with the counting of up to 512 kept numbers behind phase B)
-        if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
-        else if (taxkey) hipLaunchKernelGGL((gw_filter2_count_kernel<4, 15, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else hipLaunchKernelGGL((gw_filter2_count_kernel<4, 15, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
         if (ws.orderScratch) { size_t tb = ws.orderTemp; (void)launch_gw_order(0, ws, b.n, b.n, ws.orderScratch, tb, st); }   // longest reads first
         // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads)
