@@ -53,14 +53,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
 PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
-           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter_rest", "gw_count", "gw_count_1024",
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter2", "gw_compact", "gw_filter_stream_fine", "gw_filter_stream", "gw_count", "gw_count_512", "gw_count_1024",
            "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates")
 KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
 # timer (mc_timing_get) -> the kernel's own name as the rocprofv3 summaries carry it (scripts/summarize_profile.py): prefixes
 KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cands_kernel",), "sketch_probe": ("sketch_probe_lane_kernel",),
              "query_wave": ("query_kernel",), "sort_candidates": ("sort_candidates_kernel",),
              "gw_filter_count": ("gw_filter_count_kernel",), "gw_filter": ("gw_filter_kernel",),
-             "gw_filter_rest": ("gw_filter_stream_kernel", "gw_filter2_kernel"), "gw_count": ("gw_count_kernel<9", "gw_count_kernel<10"),
+             "gw_filter2": ("gw_filter2_kernel",), "gw_compact": ("gw_compact_kernel",), "gw_filter_stream_fine": ("gw_filter_stream_kernel<16",),
+             "gw_filter_stream": ("gw_filter_stream_kernel<2",), "gw_count": ("gw_count_kernel<9",), "gw_count_512": ("gw_count_kernel<10",),
              "gw_count_1024": ("gw_count_kernel<11",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
              "big_count_2": ("big_count_kernel<11",), "hash_cands_256": ("hash_cands_kernel<9",), "hash_cands_512": ("hash_cands_kernel<10",),
              "hash_cands_1024": ("hash_cands_kernel<11",), "mid_cands_64": ("mid_cands_kernel",), "mid_cands_128": ("mid_cands_kernel",),
@@ -153,15 +154,25 @@ def _pmc_rows(kernel_timer_name: str, tag: str):
     return fn, vals
 
 
+LINE_BYTES = 128.0            # what one read request of the L2's memory side costs against the HBM roofline (profiles/r05_fetch_calibration.md)
+
+
 def measured_traffic(kernel_timer_name: str, tag: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
-    (profiles/<tag>_pmc_summary.csv: FETCH_SIZE / WRITE_SIZE in KB from separate --pmc passes; gfx950 caveat of
-    MI355X_MICROARCH.md calibrated in profiles/r01_fetch_calibration.md).  None if no summary of this configuration exists."""
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this workload
+    (profiles/<tag>_pmc_summary.csv, separate --pmc passes): READ REQUESTS x 128 bytes + WRITE_SIZE.
+    rocprofv3's FETCH_SIZE on gfx950 is TCC_EA0_RDREQ x 64 bytes whatever a request moves (MI355X_MICROARCH.md, HBM section); calibrated on this
+    path's own access shapes (profiles/r05_fetch_calibration.md, tools/gather_width.hip): a request is one 128-byte LINE touched -- a list of 196
+    bytes at a random 4-byte offset makes 2.6 requests for its 2.5 lines, not 4 for its 4 sectors -- and the memory system serves the same 47 x 10^9
+    random requests per second for units of 32, 64 and 128 bytes and half as many units of 256: every request costs a line of the roofline.
+    -> (bytes, file, detail) or (None, None, None) if no summary of this configuration exists."""
     fn, vals = _pmc_rows(kernel_timer_name, tag)
     for k, v in vals.items():
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            return (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
-    return None, None
+        if "TCC_EA0_RDREQ_sum" in v and "WRITE_SIZE" in v:
+            rd = v["TCC_EA0_RDREQ_sum"] * LINE_BYTES
+            return rd + v["WRITE_SIZE"] * 1024.0, os.path.basename(fn), {"read_requests": v["TCC_EA0_RDREQ_sum"], "bytes_per_request": LINE_BYTES,
+                                                                          "WRITE_SIZE_bytes": v["WRITE_SIZE"] * 1024.0,
+                                                                          "FETCH_SIZE_bytes_as_reported": v.get("FETCH_SIZE", 0.0) * 1024.0}
+    return None, None, None
 
 
 def gather_peak(gib: float):
@@ -190,7 +201,7 @@ def kernel_bytes_per_read(timer: str, L: float, F: float, H: float, K: int, V: i
     """the kernel's OWN share of SURVEY §8(d)'s bytes per read (ceil(L/4) + ceil(L/8) + 12 F + V H + 16 K): the read's characters belong to the
     sketching kernel, 12 F to the lookups, the V H bytes of the lists to the filter, the 16 K bytes of candidates to whoever writes them"""
     share = {"sketch_lane": (L + 3) // 4 + (L + 7) // 8, "sketch_probe": (L + 3) // 4 + (L + 7) // 8 + 12.0 * F, "probe_cands": 12.0 * F,
-             "gw_filter_count": V * H + 16.0 * K, "gw_filter": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
+             "gw_filter_count": V * H + 16.0 * K, "gw_filter": V * H, "gw_filter2": V * H, "gw_filter_stream": V * H, "gw_filter_stream_fine": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
              "gather_lists": V * H}
     return share.get(timer)
 
@@ -296,33 +307,22 @@ def cpu_leg_config2(spec, reads_host, gpu_cands, K, n_parity, budget_s, mates_ho
     odb = scale_util.oracle_database(spec, wanted, threads=threads)
     build_s = time.time() - t0
     if mates_host is not None:
-        # pairs: the oracle's per-query entry (its bulk entry takes single reads), `threads` host threads each with a contiguous share of
-        # the pairs (the C call releases the interpreter lock); the baseline value is then pairs x 2 per minute
-        from concurrent.futures import ThreadPoolExecutor
+        # pairs: the oracle's threaded bulk entry for pairs (mco_query_many_pairs: one query state per thread, a contiguous share of the pairs
+        # each -- the reference's thread model); a pair counts as 2 reads
+        def run_pairs(m, th):
+            s1 = np.ascontiguousarray(reads_host[:m, :READ_LEN]).reshape(-1)
+            s2 = np.ascontiguousarray(mates_host[:m, :READ_LEN]).reshape(-1)
+            offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+            return odb.query_many_pairs(s1, offs, s2, offs, max_cand=K, lowest=0, insert_max=0, threads=th)
 
-        def chunk(lo_hi):
-            lo, hi = lo_hi
-            bad = 0
-            hd = odb.new_handler()                             # (the oracle's query state: one per thread)
-            for i in range(lo, hi):
-                _, e = odb.query(sample[i], sample[n + i], K, 0, 0, handler=hd)
-                g = gpu_cands[i]
-                ok = all((g[j]["tgt"], g[j]["hits"], g[j]["beg"], g[j]["end"]) == (e[j]["tgt"], e[j]["hits"], e[j]["beg"], e[j]["end"]) if j < len(e)
-                         else g[j]["hits"] == 0 for j in range(K))
-                bad += 0 if ok else 1
-            odb.free_handler(hd)
-            return bad
-        t1 = time.time()
-        cuts = [(n * t // threads, n * (t + 1) // threads) for t in range(threads)]
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            mism = sum(ex.map(chunk, cuts))
-        el = time.time() - t1
+        t, cands = run_pairs(n, threads)
+        mism = count_mismatches(gpu_cands, cands)
+        best, bt, sweep = thread_sweep(run_pairs, n, budget_s, min(os.cpu_count() or 1, 4 * eff))
         info = odb.info()
         odb.close()
-        return ({"value": round(2 * n / el * 60 / 1e6, 3), "unit": "Mreads/min", "cores": threads, "kind": "port", "host_cpus_granted": eff,
-                 "sample": f"{n} pairs of the same workload (batch 0), {threads} host threads through the oracle's per-query entry (the box grants {eff} CPUs; "
-                           f"the Python loop around the C call is part of the figure); "
-                           f"buckets of the sample's {len(wanted)} features ({info[7]} locations) built by the oracle itself in {build_s:.0f} s"},
+        return ({"value": round(2 * best, 3), "unit": "Mreads/min", "cores": bt, "kind": "port", "thread_sweep_pairs_per_min": sweep, "host_cpus_granted": eff,
+                 "sample": f"{n} pairs of the same workload (batch 0); C oracle (mco_query_many_pairs) on {bt} host threads (best of the sweep; the box grants {eff} "
+                           f"CPUs); buckets of the sample's {len(wanted)} features ({info[7]} locations) built by the oracle itself in {build_s:.0f} s"},
                 {"checked": n, "mismatches": mism, "against": "port (oracle builds its own buckets)"})
 
     def run(m, th):
@@ -821,7 +821,7 @@ def main():
         L_mean = float(long_batches[(args.steps - 1) % nb]["lens"].mean()) if args.long_reads else float(READ_LEN)
         kshare = kernel_bytes_per_read(dom, L_mean, F, H, K, V)
         kbytes = None if kshare is None else kshare * nloc * per_read
-        traffic, traffic_src = measured_traffic(dom, pmc_tag)
+        traffic, traffic_src, traffic_detail = measured_traffic(dom, pmc_tag)
         total_reads = world * args.steps * B * per_read
         value = total_reads / elapsed * 60.0 / 1e6
         result = {
@@ -842,7 +842,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6),
                          # the same bytes over the WHOLE step (all kernels, launches, the copy of the candidates)
                          "step_frac": round(bytes_per_read * nloc * per_read / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                          # like for like with `traffic`: the dominant kernel's OWN share of the algorithmic bytes (kernel_bytes_per_read)
                          "kernel_name": "mcamd::" + KERNEL_OF.get(dom, (dom,))[0],
                          "kernel_algorithmic_bytes": None if kbytes is None else round(kbytes),

@@ -391,7 +391,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value);
 /* per-kernel timing with HIP events on the launching stream (for bench.py's roofline block).
  * names: "plan", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128", "mid_cands_256",
  * "hash_cands_256", "hash_cands_512", "hash_cands_1024", the filtered path -- compact location store: "gw_filter_count" (gw_filter_count_kernel; "gw_filter" with
- * the tuning switch "gw_fuse" 0), "gw_filter_rest" (gw_filter2 + gw_compact + gw_filter_stream), "gw_count" (gw_count_kernel<9> + <10>), "gw_count_1024" (<11>); 8-byte store:
+ * the tuning switch "gw_fuse" 0), "gw_filter2", "gw_compact" (+ the ordering of the stream filter's reads), "gw_filter_stream_fine" (the sixteen-wave instance), "gw_filter_stream" (+ the second gw_compact), "gw_count" (gw_count_kernel<9>), "gw_count_512" (<10>), "gw_count_1024" (<11>); 8-byte store:
  * "big_filter", "big_filter_2", "big_count", "big_count_2" --, "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates";
  * Mode K: "mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union"; "sketch_probe" (sketch_probe_lane_kernel: instead of "sketch_lane" + "probe_cands" where the two are one kernel, see "lane_fusion"); "cands_from_hits" (mc_candidates_from_hits).  Returns accumulated milliseconds and launch counts since the last reset. */
 int mc_timing_enable(mc_ctx* ctx, int on);

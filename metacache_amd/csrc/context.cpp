@@ -614,13 +614,20 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
 static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
                              const uint32_t* taxkey, bool compact, bool second, uint64_t poolEntries, hipStream_t st, bool deferSorted = false)
 {
-    // timers carry the kernels' own names: compact store gw_filter_count_kernel (or gw_filter_kernel with "gw_fuse" 0), the rest of the
-    // filters (gw_filter2 + compaction + gw_filter_stream), gw_count_kernel<9> + <10>, gw_count_kernel<11>; 8-byte store: big_*
+    // timers carry the kernels' own names, one kernel each: compact store gw_filter_count_kernel (or gw_filter_kernel with "gw_fuse" 0), gw_filter2,
+    // gw_compact (+ the ordering of the stream filter's reads), gw_filter_stream<fine>, gw_filter_stream (+ the second compaction),
+    // gw_count_kernel<9>, <10>, <11>; 8-byte store: big_*
     { ScopedTimer t(ctx, compact ? (ws.gwFuse ? "gw_filter_count" : "gw_filter") : "big_filter", st); launch_big_cands(0, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     // (compact store: gw_filter_kernel itself may leave reads to the second kernel -- it counts them on the device, after the
     // host's look at the counters: always launched, returns at once with nothing to do)
-    if (second || compact) { ScopedTimer t(ctx, compact ? "gw_filter_rest" : "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    if (compact) {                                             // (timers by kernel: a bench line's dominant "kernel" must be one)
+        { ScopedTimer t(ctx, "gw_filter2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "gw_compact", st); launch_big_cands(7, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "gw_filter_stream_fine", st); launch_big_cands(8, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "gw_filter_stream", st); launch_big_cands(9, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    } else if (second) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count" : "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+    if (compact) { ScopedTimer t(ctx, "gw_count_512", st); launch_big_cands(10, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count_1024" : "big_count_2", st); launch_big_cands(2, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     if (compact && !deferSorted) return run_sorted_tail(ctx, P, b, sp, tab, ws, K, taxkey, poolEntries, false, st);
     return MC_OK;

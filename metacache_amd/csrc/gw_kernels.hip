@@ -1458,25 +1458,29 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
-        // reads with more than kGwSmallH locations: 2^17 + 2^15 filter bits per wave (20 KB), two waves per block, twice the blocks
-        const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
+        // reads of up to 2 x kGwRounds rounds (read pairs): two register batches
         hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
+    } else if (stage == 7) {
+        // the records the register filters left -> the stream filter's list, longest reads first
+        const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 0u);
-        if (ws.orderScratch) { size_t tb = ws.orderTemp; (void)launch_gw_order(0, ws, b.n, b.n, ws.orderScratch, tb, st); }   // longest reads first
-        // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads)
-        // (a single-pass instance for reads whose numbers fit a block's registers -- eight waves of 32 entries each, phase B from the registers --
-        // was measured SLOWER in front of this kernel: 5.00 against 4.60 ms per 250 000 long reads, 125 registers and idle waves at barriers; dropped)
-        {
-            // the reads beyond kGwBigH locations first (one block of sixteen waves per read: blocks x 16 = the same waves, the same pool slices)
-            const uint32_t bigH = ws.gwBigH;                       // (tuning switch "gw_big_h"; 0xFFFFFFFF: one instance for all reads, as round 3)
-            const uint32_t nSlices = 4u * fgrid;
-            if (bigH != 0xFFFFFFFFu) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3((nSlices + 15u) / 16u), dim3(1024), 0, st, b, tab, ws, bigH, 0xFFFFFFFFu, nSlices);
-            // (four waves per block and pair of filters instead of two -- 24 waves per CU: 5.01 -> 4.87 ms per 250 000 long reads: left at two)
-            hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, bigH, nSlices);
-        }
+        if (ws.orderScratch) { size_t tb = ws.orderTemp; (void)launch_gw_order(0, ws, b.n, b.n, ws.orderScratch, tb, st); }
+    } else if (stage == 8) {
+        // reads with more than kGwSmallH locations: the ones beyond kGwBigH first (one block of sixteen waves per read, 2^19 + 2^17 filter bits:
+        // blocks x 16 = the same waves, the same pool slices; tuning switch "gw_big_h"; 0xFFFFFFFF: one instance for all reads, as round 3)
+        const uint32_t nSlices = 4u * fgrid;
+        if (ws.gwBigH != 0xFFFFFFFFu) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3((nSlices + 15u) / 16u), dim3(1024), 0, st, b, tab, ws, ws.gwBigH, 0xFFFFFFFFu, nSlices);
+    } else if (stage == 9) {
+        // ... the others: 2^17 + 2^15 filter bits per block of two waves (20 KB), twice the blocks
+        // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads;
+        // four waves per block and pair of filters -- 24 waves per CU: 5.01 -> 4.87 ms per 250 000 long reads: left at two; a single-pass
+        // instance in front of this kernel was measured slower: DESIGN section 10 of round 4)
+        const uint32_t nSlices = 4u * fgrid;
+        const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
+        hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, ws.gwBigH, nSlices);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
-    } else if (stage == 1) {
-        // filtered lists up to 256 (4 KB of LDS per wave), then 257 .. 512
+    } else if (stage == 1 || stage == 10) {
+        // filtered lists up to 256 (stage 1: 4 KB of LDS per wave), then 257 .. 512 (stage 10)
         // (eight blocks per CU are resident; a grid of exactly that many left the waves with 9 or 10 steps of 64 records each and the CU waiting
         // for the last one: 5.9 ms per 5 x 10^6 reads; 16 / 24 / 32 blocks per CU: 5.23 / 5.19 / 5.15)
         static const uint32_t bpcEnv = gw_env("MC_BIG_COUNT_BPC", 24u);
@@ -1484,12 +1488,12 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // (second instance: 40 KB of LDS per block = four blocks per CU at a time; its grid in whole rounds of four)
         static const uint32_t bpc1 = gw_env("MC_BIG_COUNT1_BPC", 16u);
         const uint32_t grid = std::min<uint32_t>(256 * bpc, (b.n + 3) / 4), grid1 = std::min<uint32_t>(256 * bpc1, (b.n + 3) / 4);
-        if (taxkey) {
-            hipLaunchKernelGGL((gw_count_kernel<9, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
-            hipLaunchKernelGGL((gw_count_kernel<10, 4, true>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
+        if (stage == 1) {
+            if (taxkey) hipLaunchKernelGGL((gw_count_kernel<9, 4, true>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
+            else        hipLaunchKernelGGL((gw_count_kernel<9, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
         } else {
-            hipLaunchKernelGGL((gw_count_kernel<9, 4, false>), dim3(grid), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 0u);
-            hipLaunchKernelGGL((gw_count_kernel<10, 4, false>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
+            if (taxkey) hipLaunchKernelGGL((gw_count_kernel<10, 4, true>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
+            else        hipLaunchKernelGGL((gw_count_kernel<10, 4, false>), dim3(grid1), dim3(256), 0, st, b, sp.s, tab, ws, maxCand, taxkey, c, 256u);
         }
     } else if (stage == 4) {                                   // candidates of the sorted lists (after launch_gw_segsort)
         const uint32_t grid = std::min<uint32_t>(256 * 8, (b.n + 3) / 4);

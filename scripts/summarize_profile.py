@@ -30,6 +30,18 @@ def short(k):
     return k.strip()
 
 
+def full(k):
+    """the name as rocprofv3 prints it, whole (template arguments and all -- they may hold commas and parentheses), without the argument list"""
+    k = k.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(k):
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0:
+            return k[:i].strip()
+    return k.strip()
+
+
 # 1. rocprofv3 --kernel-trace --stats summary, our kernels only (torch's synthetic-data kernels dropped)
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -37,7 +49,7 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
         if "mcamd" in r["Name"]:
-            w.writerow([r["Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+            w.writerow([full(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 # 2. PMC counters per kernel (mean per dispatch over the dispatches of each separate --pmc pass)
 res = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -64,6 +64,10 @@ class CpuRef:
         qm.restype = C.c_double
         qm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
         if self.is_oracle:
+            self.lib.mco_query_many_pairs.restype = C.c_double
+            self.lib.mco_query_many_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64,
+                                                      C.c_int, C.c_void_p]
+        if self.is_oracle:
             self.lib.mco_candidates.restype = C.c_uint64
             self.lib.mco_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int,
                                                 C.c_void_p, C.c_uint64]
@@ -233,6 +237,19 @@ class CpuDb:
         t = self.ref._f("query_many")(self.h, _ptr(seqs), _ptr(offs), n, max_cand, lowest, insert_max, threads,
                                       None if cands is None else _ptr(cands))
         return t, cands
+
+
+def _query_many_pairs(self, seqs, offs, seqs2, offs2, max_cand: int = 2, lowest: int = 0, insert_max: int = 0, threads: int = 1):
+    """read pairs through the oracle's threaded bulk entry (mco_query_many_pairs) -> (seconds, cands[n, max_cand])"""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8); seqs2 = np.ascontiguousarray(seqs2, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64); offs2 = np.ascontiguousarray(offs2, dtype=np.uint64)
+    n = len(offs) - 1
+    cands = np.zeros((n, max_cand), dtype=cand_dtype)
+    t = self.ref.lib.mco_query_many_pairs(self.h, _ptr(seqs), _ptr(offs), _ptr(seqs2), _ptr(offs2), n, max_cand, lowest, insert_max, threads, _ptr(cands))
+    return t, cands
+
+
+CpuDb.query_many_pairs = _query_many_pairs
 
 
 def build_oracle() -> str:

@@ -405,7 +405,7 @@ def test_filter_second_instance_reads_of_five_to_ten_windows(monkeypatch, lowest
     db.timing(True); db.timing_reset()
     cands, counts, _ = db.query(reads, lowest=lowest)
     if store == 4:
-        assert db.timing_get("gw_filter_rest")[1] > 0 and (db.timing_get("gw_filter_count")[1] > 0 or db.timing_get("gw_filter")[1] > 0)
+        assert db.timing_get("gw_filter_stream")[1] > 0 and (db.timing_get("gw_filter_count")[1] > 0 or db.timing_get("gw_filter")[1] > 0)
     else:
         assert db.timing_get("big_filter_2")[1] > 0 and db.timing_get("big_filter")[1] > 0
     assert np.mean(counts > 256) > 0.5, np.percentile(counts, [5, 50, 95])

@@ -141,3 +141,22 @@ def test_live_against_reference(orc, golden):
         f1 = ref.sketch(bytes(s), 16, 16, 127, 112); f2 = orc.sketch(bytes(s), 16, 16, 127, 112)
         assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
     rdb.close(); odb.close()
+
+
+def test_bulk_pair_entry_equals_the_goldens(orc, golden):
+    """mco_query_many_pairs (the threaded bulk entry bench.py's --pairs baseline runs through) against the reference's pair goldens"""
+    _, p1, p2 = golden.reads()
+    db = orc.open(golden.db_path("toy32"))
+    s1 = np.frombuffer(b"".join(p1), dtype=np.uint8); s2 = np.frombuffer(b"".join(p2), dtype=np.uint8)
+    o1 = np.zeros(len(p1) + 1, np.uint64); o1[1:] = np.cumsum([len(x) for x in p1])
+    o2 = np.zeros(len(p2) + 1, np.uint64); o2[1:] = np.cumsum([len(x) for x in p2])
+    for rname, mc, low, ins in PAIR_RULES:
+        exp = golden.expected("toy32", "pair_" + rname)
+        for threads in (1, 3):
+            _, c = db.query_many_pairs(s1, o1, s2, o2, max_cand=mc, lowest=low, insert_max=ins, threads=threads)
+            for i in range(len(p1)):
+                e = exp[i]
+                assert int((c[i]["hits"] > 0).sum()) == len(e), (rname, i)
+                for j in range(len(e)):
+                    assert tuple(c[i][j][f] for f in ("tgt", "hits", "beg", "end")) == tuple(e[j][f] for f in ("tgt", "hits", "beg", "end")), (rname, i, j)
+    db.close()
