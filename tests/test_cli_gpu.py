@@ -24,7 +24,8 @@ CASES = _cases()
 
 
 def _volatile(line: str) -> bool:
-    return re.match(r"^(# |%%)(time:    |speed:   )", line) is not None
+    # (times, speeds, and the number of hardware threads of the box the command ran on)
+    return re.match(r"^(# |%%)(time:    |speed:   |Using \d+ threads$)", line) is not None
 
 
 def _same(got, exp, tag, unordered=False):
