@@ -168,6 +168,21 @@ Options parse(const std::vector<std::string>& args, Options o)
     return o;
 }
 
+// host threads worth running: the cgroup's CPU quota where there is one (a box may show 256 CPUs and grant 16), else the hardware threads
+static unsigned granted_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0}; long long period = 0;
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = std::atoll(q);
+            if (quota > 0) n = std::max(1u, std::min(n, (unsigned)((quota + period / 2) / period)));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 // ---- output (printing.cpp:160-365) ----------------------------------------------------------------------------------
 // The mapping lines of a batch are put together by its worker thread in a plain byte buffer: the inserters the line formatters use,
 // without a stream's locale and sentry work per field (10^7 lines of `-tophits -queryids` took 5.7 s of CPU through std::ostringstream --
@@ -388,6 +403,7 @@ struct Session {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         threads = o.threads > 0 ? (unsigned)o.threads : hw;                     // options.hpp: numThreads defaults to all hardware threads
         workers = std::min(threads, 64u);                                      // one batch slot (pinned staging) per worker
+        if (o.threads <= 0) workers = std::min(workers, std::max(8u, 2u * granted_cpus()));   // (a container's CPU quota: more runnable threads than twice that only get the group throttled)
         const uint32_t nrep = built ? 1u : std::max(1u, o.replication);
         workers = std::max(workers, nrep);
         c.num_slots = (workers + nrep - 1) / nrep;                              // worker w: replica w % n, slot w / n
@@ -767,6 +783,11 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         // was a quarter of a second of a 0.3 s query phase.  (No file: std::cout, in order, as before.)
         int outFd = -1;
         uint64_t outOff = 0;
+        std::vector<std::string> bufPool;                                       // written batches' buffers, for the next batches (a fresh 7 MB buffer per batch is 1 700 page faults)
+        auto take_buffer = [&](std::string& into) {
+            std::lock_guard<std::mutex> lock(outMtx);
+            if (!bufPool.empty()) { into = std::move(bufPool.back()); bufPool.pop_back(); into.clear(); }
+        };
         if (!outfile.empty()) {
             fout.flush();
             const std::streamoff at = fout.tellp();
@@ -784,6 +805,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             }
             for (auto& m : mine) {
                 const char* p = m.second.data();
+                struct Recycle { std::string& s; std::mutex& mu; std::vector<std::string>& pool; ~Recycle() { s.clear(); std::lock_guard<std::mutex> l(mu); if (pool.size() < 256) pool.push_back(std::move(s)); } } recycle{m.second, outMtx, bufPool};
                 uint64_t left = m.second.size(), at = m.first;
                 while (left) {
                     const ssize_t w = ::pwrite(outFd, p, (size_t)std::min<uint64_t>(left, 1ull << 30), (off_t)at);
@@ -815,7 +837,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                     if (covMode) { while (deferred.size() <= b) deferred.emplace_back(); Dp = &deferred[b]; }
                 }
                 const Batch& B = *Bp;
-                out.str(std::string());
+                out.s.clear();
+                if (out.s.capacity() == 0) take_buffer(out.s);
                 out << B.prefix;
                 size_t q = B.qBeg;
                 while (q < B.qEnd && !failed) {
@@ -947,7 +970,8 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                                                             o.lowest, o.insertMax, setHasPrior ? 1 : 0, all.data()) != MC_OK) { fail(mc_partset_last_error(S.partset)); break; }
                 }
                 if (!setLastPass) { slot->swap(all); continue; }            // more part groups to come: nothing is printed yet
-                out.str(std::string());
+                out.s.clear();
+                if (out.s.capacity() == 0) take_buffer(out.s);
                 out << B.prefix;
                 for (size_t i = 0; i < n; ++i) {
                     const Meta& m = metas[i];
