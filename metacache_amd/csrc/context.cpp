@@ -226,6 +226,9 @@ void mc_destroy(mc_ctx* ctx)
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         if (P.tail.mainDone) (void)hipEventDestroy(P.tail.mainDone);
+        if (P.sortSide.stream) { (void)hipStreamSynchronize(P.sortSide.stream); (void)hipStreamDestroy(P.sortSide.stream); }
+        if (P.sortSide.fork) (void)hipEventDestroy(P.sortSide.fork);
+        if (P.sortSide.join) (void)hipEventDestroy(P.sortSide.join);
         for (auto* b : pb) if (b->p) (void)hipFree(b->p);
         if (ownStream && P.stream) (void)hipStreamDestroy(P.stream);
     };
@@ -601,7 +604,11 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
     {
         ScopedTimer t(ctx, "gw_sort", st);
         if (launch_gw_order(3, ws, n, nseg, (uint32_t*)P.bOrder.p, ordBytes, st) != 0) return fail(ctx, MC_ERR_HIP, "ordering of the sorted lists failed");
-        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st) != 0)
+        if (!P.sortSide.stream) {
+            if (hipStreamCreateWithFlags(&P.sortSide.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&P.sortSide.fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&P.sortSide.join, hipEventDisableTiming) != hipSuccess) P.sortSide = GwSortSide{};
+        }
+        if (launch_gw_segsort(P.bSortTmp.p, tmpBytes, (const uint32_t*)ws.bigPool, ws.bigPool2, poolEntries, ws, n, nseg, ctx->gwBits, st, &P.sortSide) != 0)
             return fail(ctx, MC_ERR_HIP, "segmented sort failed");
     }
     { ScopedTimer t(ctx, "gw_sorted_cands", st); launch_big_cands(4, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }

@@ -18,6 +18,7 @@ struct DevBuf {                 // grow-only device allocation
 };
 
 struct Pipe {                   // the device workspace of ONE batch in flight + the stream its work is enqueued on
+    GwSortSide sortSide;            // second stream + fork / join events of the sorted path (created on first use)
     hipStream_t stream = nullptr;
     DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
         bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide,

@@ -212,8 +212,9 @@ void launch_big_cands(uint32_t stage, const BatchView& b, const SketchParams& sp
 void launch_gather_lists(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t* numbers, hipStream_t st);
 // gw_sort.hip: the filtered lists that are sorted instead of counted (the first nseg records of ws.sideList[3]), pool -> out at the same
 // offsets; temp == nullptr: size query
+struct GwSortSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };   // a second stream for the sort's independent instances (the caller's: a Pipe's)
 int launch_gw_segsort(void* temp, size_t& tempBytes, const uint32_t* in, uint32_t* out, uint64_t poolCap, const Workspace& ws, uint32_t n, uint32_t nseg,
-                      uint32_t endBit, hipStream_t st);
+                      uint32_t endBit, hipStream_t st, const GwSortSide* side2 = nullptr);
 // ws.sideList[list] (list 0: the stream filter's reads, 3: the sorted class) in descending order of the records' work; scratch == nullptr: size query
 int launch_gw_order(uint32_t list, const Workspace& ws, uint32_t n, uint32_t count, uint32_t* scratch, size_t& tempBytes, hipStream_t st);
 uint32_t big_filter_grid(uint32_t n, bool compact, int bpcOverride = 0);     // (bpcOverride: mc_set_tuning "filter_bpc" of the context) blocks of 4 waves the filter kernels run with (compact: the gw kernels): the pool is cut into one slice per wave
