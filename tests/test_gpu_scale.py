@@ -471,6 +471,19 @@ def test_sorted_path_strain_rich_long_reads_against_oracle(tmp_path, K, lowest, 
     db.set_tuning("gw_big_h", 0)
     cands_coarse, _, _ = db.query(reads, lowest=lowest)
     db.close()
+    # batches whose filter grid is NOT a multiple of four blocks (the fine-block instance of sixteen waves owns the pool slices of four
+    # such blocks; its last block fewer) and batches of fewer than thirteen reads (fewer slices than one such block has waves): batch
+    # sizes 241 (61 blocks), 9 (3 blocks), 1 -- with the fine-block instance on every read of the stream filter
+    if K == 2:
+        for bs in (241, 9, 1):
+            dbs = api.Database.open(name, max_candidates=K, slot_max_queries=bs, slot_max_chars=1 << 23)
+            dbs.set_tuning("gw_big_h", 2048)
+            sub = reads if bs > 1 else reads[:40]
+            cs, _, _ = dbs.query(sub, lowest=lowest)
+            dbs.close()
+            for i, r in enumerate(sub):
+                _, e = odb.query(r, b"", K, lowest, 0)
+                _check(cs[i], e, K, ("batch size", bs, i, len(r)))
     for i, r in enumerate(reads):
         _, e = odb.query(r, b"", K, lowest, 0)
         _check(cands[i], e, K, (i, len(r), counts[i]))
