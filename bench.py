@@ -645,7 +645,7 @@ def main():
                        f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
                     + ("" if nb >= args.steps + args.warmup else f" ({world * nb * B * (2 if args.pairs else 1)} distinct, cycled)"))
         # the committed PMC passes (profiles/r04_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
-        pmc_tag = "r04" if (mode == "R" and not args.pairs and not args.long_reads and args.scale == 1.0 and B == 5_000_000) else "r04-none"
+        pmc_tag = ("r05" if (not args.pairs and not args.long_reads and B == 5_000_000) else "r05_long" if (args.long_reads and B == 250_000) else "r05_pairs" if (args.pairs and B == 2_500_000) else "r05-none") if (mode == "R" and args.scale == 1.0) else "r05-none"
     build_s = time.time() - t0
     db_info = db.info()
     for kv in filter(None, args.tune.split(",")):
