@@ -18,5 +18,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
 done
 # the raw traces are large: keep the per-kernel aggregates only
 python $REPO/scripts/summarize_profile.py $TAG $OUT
-find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "pmc_counter_collection.csv" -size +20M -delete
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "pmc_counter_collection.csv" -delete; find $OUT -name "*.log" -size +1M -delete
 du -sh $OUT

@@ -76,6 +76,41 @@ extern "C" int mcg_gather_peak(uint64_t bytes, double* requests)
     return 0;
 }
 
+// ---- co-residency experiment (round 5, tools/coresidency_probe.py): a lookup-shaped kernel small enough for what five waves of
+// gw_filter_count_kernel per SIMD leave of a CU (32 registers, no LDS), launched on a second stream while the filter runs.
+// LANES lanes share one random unit of LANES x 16 bytes (1: a bucket's keys; 4: a whole 64-byte bucket), U units in flight per lane.
+template <int LANES, int U>
+__attribute__((amdgpu_num_vgpr(32), amdgpu_flat_work_group_size(64, 64))) __global__ void side_gather_kernel(const uint4* __restrict__ tab, uint64_t nunits, uint32_t iters, uint32_t* __restrict__ out)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n32 = (uint32_t)nunits;                         // (units below 2^32: one multiply per place)
+    const char* const base = reinterpret_cast<const char*>(tab) + (LANES == 1 ? 0u : (tid % LANES) * 16u);
+    uint32_t acc = 0, h = (tid / LANES) * 0x9E3779B1u + 999u;
+#pragma unroll 1
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            h = mix32(h + 0x85EBCA77u);
+            v[u] = *reinterpret_cast<const uint4*>(base + (uint64_t)__umulhi(h, n32) * 64u);
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // (all U loads in flight before the first is waited for)
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (acc == 0x12345678u) out[tid] = acc;
+}
+// units = blocks x 64 x iters x U / LANES; shape 1 / 4 = LANES
+extern "C" int mcg_side_launch(const void* tab, uint64_t bytes, int lanes, uint32_t blocks, uint32_t iters, void* out, void* stream)
+{
+    const uint64_t nunits = bytes / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (lanes == 1) hipLaunchKernelGGL((side_gather_kernel<1, 4>), dim3(blocks), dim3(64), 0, st, (const uint4*)tab, nunits, iters, (uint32_t*)out);
+    else hipLaunchKernelGGL((side_gather_kernel<4, 4>), dim3(blocks), dim3(64), 0, st, (const uint4*)tab, nunits, iters, (uint32_t*)out);
+    return (int)hipGetLastError();
+}
+
 #ifdef GATHER_PEAK_MAIN
 int main(int argc, char** argv)
 {
