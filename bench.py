@@ -55,6 +55,7 @@ PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
            "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter2", "gw_compact", "gw_filter_stream_fine", "gw_filter_stream", "gw_count", "gw_count_512", "gw_count_1024",
            "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates")
+MULTI_KERNEL_TIMERS = ("plan", "scan", "gw_sort", "gw_compact", "gw_sorted_cands")   # timers over more than one kernel: never a line's `roofline.kernel`
 KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
 # timer (mc_timing_get) -> the kernel's own name as the rocprofv3 summaries carry it (scripts/summarize_profile.py): prefixes
 KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cands_kernel",), "sketch_probe": ("sketch_probe_lane_kernel",),
@@ -65,7 +66,7 @@ KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cand
              "gw_count_1024": ("gw_count_kernel<11",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
              "big_count_2": ("big_count_kernel<11",), "hash_cands_256": ("hash_cands_kernel<9",), "hash_cands_512": ("hash_cands_kernel<10",),
              "hash_cands_1024": ("hash_cands_kernel<11",), "mid_cands_64": ("mid_cands_kernel",), "mid_cands_128": ("mid_cands_kernel",),
-             "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("rocprim",), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
+             "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("gw_sort_chunk_kernel", "gw_sort_lists_kernel", "gw_merge_pass_kernel"), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
              "gather_lists": ("gather_lists_kernel",), "owner_entries": ("owner_entries_kernel",), "decode_union": ("decode_union_kernel",)}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
@@ -815,7 +816,8 @@ def main():
         if args.long_reads:                                    # SURVEY's formula with the reads' own lengths: ceil(L/4) + ceil(L/8) summed over the last timed batch
             lb = long_batches[(args.steps - 1) % nb]
             bytes_per_read = float(((lb["lens"] + 3) // 4 + (lb["lens"] + 7) // 8).sum()) / nloc + 12.0 * F + V * H + 16.0 * K
-        dom = max((k for k in kt if k not in ("plan", "scan")), key=lambda k: kt[k][0])      # (mode K: its own kernels are candidates too)
+        # the dominant KERNEL: timers that bracket several kernels (the sort's instances and merge passes, compaction + ordering, scans) are not candidates
+        dom = max((k for k in kt if k not in MULTI_KERNEL_TIMERS), key=lambda k: kt[k][0])      # (mode K: its own kernels are candidates too)
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * nloc * per_read / (dom_ms * 1e-3) / 1e9
         L_mean = float(long_batches[(args.steps - 1) % nb]["lens"].mean()) if args.long_reads else float(READ_LEN)
@@ -861,7 +863,7 @@ def main():
             # two batches in flight share the device: the events of the timed region bracket that sharing.  The same kernels one batch at a
             # time (3 steps after the timed region):
             sm = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt_solo.items()}
-            sdom = max((k for k in sm if k not in ("plan", "scan")), key=lambda k: sm[k])
+            sdom = max((k for k in sm if k not in MULTI_KERNEL_TIMERS), key=lambda k: sm[k])
             result["roofline"]["kernel_ms_solo"] = sm
             result["roofline"]["kernel_solo"] = sdom
             result["roofline"]["frac_solo"] = round(bytes_per_read * nloc * per_read / (sm[sdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)

@@ -67,6 +67,24 @@ struct GwBloom {
         asm("v_lshl_or_b32 %0, 1, %1, %2" : "=v"(m) : "v"(h >> 12), "v"(m1));
         return m;
     }
+    // "twice" holds ONE bit per key, the first of the two (round 5): a key enters it only when it is seen again -- a hundred keys of a
+    // read's 1 100 in 2^14 bits: one bit has a false-positive rate of 0.6 % there, and the test is two instructions shorter
+    // (only the register-batch kernels' filters, kSame: a long read's stream filter marks thousands of keys twice -- there both bits stay)
+    __device__ __forceinline__ static uint32_t mask1_of(uint32_t h)
+    {
+        if constexpr (!kSame) return mask_of(h);
+        uint32_t m1;
+        asm("v_lshlrev_b32_e64 %0, %1, 1" : "=v"(m1) : "v"(h));
+        return m1;
+    }
+    __device__ __forceinline__ static bool twice_hit(uint32_t word, uint32_t m) { if constexpr (kSame) return (word & m) != 0u; else return (word & m) == m; }
+    // the same test from the hash itself: bit h[4:0] of the word (v_bfe_u32 takes the low five bits of its offset operand by itself) --
+    // no mask to build
+    __device__ __forceinline__ static bool twice_hit_h(uint32_t word, uint32_t h)
+    {
+        if constexpr (kSame) { uint32_t t; asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(t) : "v"(word), "v"(h)); return t != 0u; }
+        else { const uint32_t m = mask_of(h); return (word & m) == m; }
+    }
     __device__ __forceinline__ static uint32_t seen_index(uint32_t h)                                            // the word: the product's top bits
     {
         uint32_t i;                                            // (as an instruction: the compiler would fold the shift into shift + and + add)
@@ -89,7 +107,7 @@ struct GwBloom {
 #pragma unroll
         for (int j = 0; j < 4; ++j) old[j] = atomicOr(&bits[i1[j]], m[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if ((old[j] & m[j]) == m[j]) atomicOr(&bits[i2[j]], m[j]);
+        for (int j = 0; j < 4; ++j) if ((old[j] & m[j]) == m[j]) atomicOr(&bits[i2[j]], m[j]);   // (both bits: the one bit asked for is among them)
     }
     __device__ __forceinline__ static void mark(uint32_t* bits, uint32_t key)
     {
@@ -99,8 +117,8 @@ struct GwBloom {
     }
     __device__ __forceinline__ static bool twice(const uint32_t* bits, uint32_t key)
     {
-        const uint32_t h = hash(key), m = mask_of(h);
-        return (bits[twice_index(seen_index(h), h)] & m) == m;
+        const uint32_t h = hash(key), m = mask1_of(h);
+        return twice_hit(bits[twice_index(seen_index(h), h)], m);
     }
     __device__ __forceinline__ static bool seen(const uint32_t* bits, uint32_t key)     // the key was marked at all (or its bits by others)
     {
@@ -228,7 +246,7 @@ __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F,
     for (int j = 0; j < 4; ++j) {
         const uint32_t key = v[j] >> F.A;
         const uint32_t h = Bloom::hash(key);
-        m[j] = Bloom::mask_of(h);
+        m[j] = h;                                                  // (the "twice" test works on the hash: twice_hit_h)
         wd[j] = bits[Bloom::twice_index(Bloom::seen_index(h), h)];
         if constexpr (FINE) {
             const uint32_t h0 = Bloom::hash(key - 1u), h1 = Bloom::hash(key + 1u);
@@ -240,7 +258,7 @@ __device__ __forceinline__ void gw_take4(const uint32_t* bits, const GwFrame& F,
     uint64_t km[4]; bool kb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool valid = rem > j, hit = (wd[j] & m[j]) == m[j];
+        const bool valid = rem > j, hit = Bloom::twice_hit_h(wd[j], m[j]);
         if constexpr (FINE) {
             const bool lo = (wlo[j] & mlo[j]) == mlo[j], hi = (whi[j] & mhi[j]) == mhi[j];
             kb[j] = valid & (hit | lo | hi);
