@@ -543,11 +543,38 @@ int mc_build_finish(mc_builder* b, mc_ctx** outCtx)
     return MC_OK;
 }
 
+// what a finished builder's lists take in the location store with every list on lines of its own (kernels.h list_alloc): one number per block
+__global__ __launch_bounds__(256) void padded_store_kernel(const uint8_t* __restrict__ sizes, uint64_t n, uint32_t rmOver, unsigned long long* __restrict__ out)
+{
+    unsigned long long sum = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        uint32_t e = sizes[i];
+        if (rmOver && e > rmOver) e = 0;
+        sum += list_alloc(e, kListAlign);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(out, sum);
+}
+static uint64_t padded_store_of(mc_builder* b, uint32_t rmOver)
+{
+    if (!b->finished || !b->rS || b->nkeys == 0) return 0;
+    unsigned long long* d = nullptr; unsigned long long h = 0;
+    if (hipMalloc((void**)&d, 8) != hipSuccess) return 0;
+    (void)hipMemset(d, 0, 8);
+    hipLaunchKernelGGL(padded_store_kernel, dim3(1024), dim3(256), 0, 0, b->rS, b->nkeys, rmOver, d);
+    if (hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) != hipSuccess) h = 0;
+    (void)hipFree(d);
+    return h;
+}
+
 // A query table filled from finished builders.  mc_build_table_begin creates the context (table sized for the expected totals),
 // mc_build_table_add inserts one finished builder (a whole one or one key shard) straight from its device arrays,
 // mc_build_table_end closes the load.  mc_build_finish_shards is the three in a row for builders that all fit next to the table;
 // the streaming form lets the caller free every shard's builder before the next one is sketched.
-int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValues, mc_ctx** outCtx)
+static int build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValues, uint64_t paddedTotalHint, mc_ctx** outCtx);
+int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValues, mc_ctx** outCtx) { return build_table_begin(b, expectKeys, expectValues, 0, outCtx); }
+// paddedTotalHint: the exact padded store of all builders that will be added (mc_build_finish_shards knows them all), 0: estimated from `b`
+static int build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValues, uint64_t paddedTotalHint, mc_ctx** outCtx)
 {
     if (!b || !outCtx) return MC_ERR_INVALID;
     *outCtx = nullptr;
@@ -580,6 +607,11 @@ int mc_build_table_begin(mc_builder* b, uint64_t expectKeys, uint64_t expectValu
     }
     rc = mc_load_begin(ctx, 0, expectKeys, expectValues);
     if (rc) { b->err = mc_last_error(ctx); mc_destroy(ctx); return rc; }
+    {
+        // list alignment: this builder's lists padded, scaled to the expected total (the shards' lists are alike: keys are dealt out by a hash)
+        const uint64_t mine = padded_store_of(b, qc.remove_overpopulated);
+        if (mine && b->nvals) mcamd::announce_store(ctx, paddedTotalHint ? paddedTotalHint : (uint64_t)((double)mine / (double)b->nvals * (double)expectValues * 1.02) + (1u << 20));
+    }
     *outCtx = ctx;
     big_cache_hold(+1);                                            // until mc_build_table_end (or mc_destroy): the builders freed meanwhile leave their large buffers to the next ones
     ctx->buildHold = true;
@@ -629,8 +661,10 @@ int mc_build_finish_shards(mc_builder** bs, uint32_t n, mc_ctx** outCtx)
             (n > 1 && bs[i]->cfg.key_shard_index != i)) { b->err = "mc_build_finish_shards: builders do not form one key-sharded set"; return MC_ERR_INVALID; }
         nkeys += bs[i]->nkeys; nvals += bs[i]->nvals;
     }
+    uint64_t paddedAll = 0;
+    for (uint32_t i = 0; i < n; ++i) paddedAll += padded_store_of(bs[i], b->rmOver ? b->maxLocs - 1 : 0);
     mc_ctx* ctx = nullptr;
-    int rc = mc_build_table_begin(b, std::max<uint64_t>(nkeys, 1), std::max<uint64_t>(nvals, 1), &ctx);
+    int rc = build_table_begin(b, std::max<uint64_t>(nkeys, 1), std::max<uint64_t>(nvals, 1), paddedAll + 64, &ctx);
     if (rc) return rc;
     for (uint32_t s = 0; !rc && s < n; ++s) { rc = mc_build_table_add(ctx, bs[s]); if (rc) b->err = bs[s]->err; }
     if (!rc) { rc = mc_build_table_end(ctx); if (rc) b->err = mc_last_error(ctx); }

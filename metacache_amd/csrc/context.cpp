@@ -78,6 +78,29 @@ void collect_timers(mc_ctx* ctx)
 
 void mcamd::set_global_error(const std::string& msg) { g_createError = msg; }
 
+// The loader knows what the lists would take with every list on a line of its own (kernels.h list_alloc): alignment is switched on where
+// that is wanted ("list_align"), the table has the compact store, and the padded store is affordable.  Before the first chunk.
+void mcamd::announce_store(mc_ctx* ctx, uint64_t paddedEntries)
+{
+    Part& T = ctx->parts[0];
+    if (T.dvalues || !T.compact || ctx->listAlignWant == 0 || paddedEntries == 0) return;
+    const uint64_t plain = T.dvaluesCap;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return;
+    const bool affordable = (paddedEntries + 4) * 4 + (4ull << 30) < freeB && (ctx->listAlignWant == 1 || paddedEntries <= plain + plain / 2 + (1u << 20));
+    if (!affordable) return;
+    T.listAlign = kListAlign; T.expectStore = paddedEntries; T.dvaluesCap = paddedEntries + 1;
+}
+// the location store, with the first chunk that is loaded
+int mcamd::allocate_values(mc_ctx* ctx)
+{
+    Part& T = ctx->parts[0];
+    if (T.dvalues) return MC_OK;
+    // (+ 4 entries: the filter reads the compact lists 16 bytes at a time, a list's last load may reach 3 entries past its end)
+    HIP_TRY(ctx, big_malloc((void**)&T.dvalues, (T.dvaluesCap + 4) * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
+    return MC_OK;
+}
+
 // One chunk of a single-part database whose batch arrays are already in device memory (keys u32 | sizes u8 | packed values).
 // counters: [0] keys stored, [1] locations kept, [2] (as two u32) longest probe sequence | table-full flag.
 int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nb, uint64_t fileVals)
@@ -87,7 +110,7 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     if (P.keysLoaded + nb > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
     if (fileVals >= (1ull << 32)) return fail(ctx, MC_ERR_INVALID, "load_chunk_device: chunk too large");
     const uint32_t tb = ctx->cfg.target_id_bytes;
-    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count};
+    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count, ctx->parts[0].listAlign};
     hipStream_t st = ctx->stream;
     int rc = 0;
     if ((rc = ensure(ctx, ctx->bLdFileSz, (size_t)nb * 4)) || (rc = ensure(ctx, ctx->bLdStoreSz, (size_t)nb * 4)) ||
@@ -103,6 +126,7 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     uint32_t stored = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if ((rc = allocate_values(ctx))) return rc;
     if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
     const GwLayout gwl = P.compact ? GwLayout{ctx->dGwBase, ctx->gwTargets, ctx->gwGap} : GwLayout{};
     launch_table_insert(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, P.valuesStored, P.dbuckets, P.nbuckets,
@@ -170,6 +194,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->parts.resize(cfg->num_parts);
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1' ? 1 : 0;   // (default: by table size)
+    if (const char* e = std::getenv("MC_LIST_ALIGN")) ctx->listAlignWant = e[0] == '1' ? 1 : 0;   // (default: where the padded store is affordable)
     if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
     if (const char* e = std::getenv("MC_COMPACT_LOCATIONS")) ctx->compactAllowed = e[0] != '0';   // tests / tuning
@@ -309,9 +334,9 @@ static int allocate_table(mc_ctx* ctx)
                 T.compact = true;
             }
         }
-        // (+ 4 entries: the filter reads the compact lists 16 bytes at a time, a list's last load may reach 3 entries past its end)
+        // (the location store is allocated with the first chunk -- allocate_values: a loader that knows the lists' sizes announces the
+        // padded total first, mcamd::announce_store)
         // (big_malloc: the tables of a part group come back from the tables of the group before it, devcache.h)
-        HIP_TRY(ctx, big_malloc((void**)&T.dvalues, (T.dvaluesCap + 4) * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
         HIP_TRY(ctx, big_malloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
         HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
         int rc = ensure(ctx, ctx->bLdCounters, 4 * sizeof(unsigned long long));
@@ -1187,6 +1212,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
+    else if (n == "list_align") ctx->listAlignWant = value < 0 ? -1 : (value != 0);   // before the table is loaded: lists of the compact store on lines of their own
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
     else if (n == "gw_fuse") ctx->gwFuse = value != 0;                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart

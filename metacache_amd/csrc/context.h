@@ -54,6 +54,8 @@ struct Part {
     uint64_t* dvalues = nullptr;    // compact: the same allocation holds uint32_t entries (global window numbers, kernels.h DeviceTable)
     uint64_t dvaluesCap = 0;
     bool compact = false;
+    uint32_t listAlign = 1;         // lists begin at multiples of this many entries (kernels.h list_alloc; kListAlign when the padded total was announced and fits)
+    uint64_t expectStore = 0;       // entries of the store with the padding (0: unknown -> no alignment)
 };
 
 struct Taxon {
@@ -83,6 +85,10 @@ struct Slot {
 int load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals);
 
 // the same without any synchronisation: what the chunk adds to the location store comes from the host (dbload.cpp)
+// list alignment of the compact store (kernels.h list_alloc): a loader that knows the lists' sizes announces what the store takes with
+// every list on lines of its own -- before the first chunk, with which the store is allocated
+void announce_store(mc_ctx* ctx, uint64_t paddedEntries);
+int allocate_values(mc_ctx* ctx);
 int load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals, uint64_t stored);
 // dbload.cpp: a whole .cache file of a single-part context through reader threads, pinned slabs and a copy stream (between mc_load_begin
 // and mc_load_end).  stats (may be NULL): bytes read, nanoseconds in all, of the index pass, the feeder waited for readers
@@ -139,6 +145,7 @@ struct mc_ctx {
     uint32_t bigMin = 128;                 // location lists longer than this (and than 64) are filtered before they are counted (big_filter_kernel); MC_BIG_MIN.
                                            // 256 / 128 / 64 at 15 Gbp (195 locations per read): 3.92 / 3.53 / 3.48 ms per 10^6 reads; at 4.5 Gbp (100): 3.01 / 3.12 / 3.25
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
+    int listAlignWant = -1;                // mc_set_tuning "list_align" / MC_LIST_ALIGN: -1 = where the padded store stays below 1.5 x the plain one and fits, 0 / 1
     int fuseLane = -1;                     // sketching + probing of the lane path in ONE kernel: -1 = where the lookups are quad-cooperative (tables beyond 1 GiB: the
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)

@@ -85,7 +85,7 @@ inline uint32_t stored_of(uint32_t key, uint32_t fileSize, const LoadFilter& lf)
     if (lf.rmOver && size > lf.rmOver) size = 0;
     if (lf.maxLocs && size > lf.maxLocs) size = lf.maxLocs;
     if (lf.shardCnt > 1 && key_owner(key, lf.shardCnt) != lf.shardIdx) size = 0;
-    return size > 1 ? size : 0;
+    return list_alloc(size, lf.align);
 }
 
 }  // namespace
@@ -98,9 +98,10 @@ int mcamd::load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uin
     auto fail = [&](int code, const char* msg) { ctx->err = msg; return code; };
     if (P.keysLoaded + nb > P.expectKeys) return fail(MC_ERR_INVALID, "database file: more keys than its header announces");
     if (fileVals >= (1ull << 32)) return fail(MC_ERR_INVALID, "database file: a chunk holds 2^32 or more locations");
+    if (mcamd::allocate_values(ctx) != MC_OK) return fail(MC_ERR_NOMEM, "database load: cannot allocate the location store");
     if (P.valuesStored + stored > P.dvaluesCap) return fail(MC_ERR_INVALID, "database file: more values than its header announces");
     const uint32_t tb = ctx->cfg.target_id_bytes;
-    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count};
+    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count, ctx->parts[0].listAlign};
     hipStream_t st = ctx->stream;
     auto ensure = [&](DevBuf& b, size_t bytes) -> bool {
         if (bytes <= b.cap) return true;
@@ -155,8 +156,11 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     const uint64_t t0 = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }();
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; };
 
-    // ---- index pass: every batch's place (its sizes are read to find the next one)
+    // ---- index pass: every batch's place (its sizes are read to find the next one), and what the store would take with every list on
+    //      lines of its own (announce_store)
     std::vector<BatchPlace> place;
+    uint64_t padded = 0;
+    const uint32_t rmOver0 = ctx->cfg.remove_overpopulated, maxLocs0 = ctx->cfg.max_locations_per_feature;
     {
         std::vector<uint8_t> sz((size_t)std::min<uint64_t>(batch, nkeys));
         uint64_t off = 24;
@@ -164,7 +168,13 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
             const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, nkeys - done);
             if (off + (uint64_t)nb * 5 > fileSize || !pread_all(fd, sz.data(), nb, off + (uint64_t)nb * 4)) return fail(MC_ERR_IO, "truncated " + fname);
             uint64_t bv = 0;
-            for (uint32_t i = 0; i < nb; ++i) bv += sz[i];
+            for (uint32_t i = 0; i < nb; ++i) {
+                bv += sz[i];
+                uint32_t e = sz[i];                                // (the load-time modifiers that look at the size alone: table_build.hip effective_size)
+                if (rmOver0 && e > rmOver0) e = 0;
+                if (maxLocs0 && e > maxLocs0) e = maxLocs0;
+                padded += list_alloc(e, kListAlign);
+            }
             if (off + (uint64_t)nb * 5 + bv * vb > fileSize) return fail(MC_ERR_IO, "truncated " + fname);
             place.push_back(BatchPlace{off, bv, nb});
             off += (uint64_t)nb * 5 + bv * vb;
@@ -174,6 +184,11 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     const uint64_t tIndex = now();
     const size_t nbatches = place.size();
     if (nbatches == 0) return MC_OK;
+    {
+        // (a key shard keeps about 1 / count of the lists: the margin of allocate_table's estimate for the plain store)
+        const uint64_t c = std::max<uint32_t>(ctx->cfg.key_shard_count, 1);
+        mcamd::announce_store(ctx, c > 1 ? padded / c + padded / (3 * c) + (1u << 16) : padded);
+    }
     auto batch_bytes = [&](const BatchPlace& b) { return align16((size_t)b.nkeys * 4) + align16(b.nkeys) + align16((size_t)b.fileVals * vb) + 16; };
     size_t slabBytes = 0;
     for (const auto& b : place) slabBytes = std::max(slabBytes, batch_bytes(b));
@@ -197,7 +212,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     size_t released = 0;                                      // batches whose slab the feeder has given back
     std::atomic<size_t> next{0};
     bool abort = false;
-    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count};
+    const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count, ctx->parts[0].listAlign};
     auto reader = [&] {
         for (;;) {
             const size_t b = next.fetch_add(1);
@@ -217,6 +232,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
             if (ok) {
                 const uint32_t* k = reinterpret_cast<const uint32_t*>(keys);
                 if (lf.shardCnt > 1 || lf.maxLocs || lf.rmOver) for (uint32_t i = 0; i < B.nkeys; ++i) st += stored_of(k[i], sizes[i], lf);
+                else if (lf.align > 1) for (uint32_t i = 0; i < B.nkeys; ++i) st += list_alloc(sizes[i], lf.align);
                 else for (uint32_t i = 0; i < B.nkeys; ++i) st += sizes[i] > 1 ? sizes[i] : 0u;
             }
             {

@@ -185,7 +185,13 @@ void launch_sketch_lane(const BatchView& b, const SketchParams& sp, const Worksp
 void launch_probe_cands(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                         const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st);
 // table_build.hip: GPU-side table construction from the file's batch stream
-struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt; };   // load-time modifiers + key shard
+struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt, align = 1; };   // load-time modifiers + key shard + list alignment (below)
+// LIST ALIGNMENT (round 5, compact store): a list of the location store may begin at a multiple of kListAlign numbers = 128 bytes.  The
+// memory system serves random reads line by line (47 x 10^9 requests of 128 bytes per second, whatever part of the line is wanted:
+// profiles/r05_fetch_calibration.md): a list of 196 bytes at an arbitrary 4-byte offset touches 2.6 lines, an aligned one 2.0 -- the
+// filter kernels of read pairs and long reads run at that request rate.  Space a list takes in the store: list_alloc(size, align).
+constexpr uint32_t kListAlign = 32;
+__host__ __device__ inline uint32_t list_alloc(uint32_t size, uint32_t align) { return size > 1 ? (size + align - 1) / align * align : 0; }
 struct GwLayout { const uint32_t* base = nullptr; uint32_t targets = 0, gap = 0; };   // compact store: gwBase[targets + 1] (DeviceTable)
 void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
                        unsigned long long* counters, hipStream_t st);

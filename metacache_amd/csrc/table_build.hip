@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void table_prep_kernel(const uint32_t* __restr
         const uint32_t fs = sizes[i];
         eff = effective_size(keys[i], fs, lf);
         fileSz[i] = fs;
-        storeSz[i] = eff > 1 ? eff : 0;
+        storeSz[i] = list_alloc(eff, lf.align);              // (what the list takes in the store: its length, or that rounded up to whole lines)
     }
     // counters[0] = keys stored, [1] = locations kept: one atomic per wave
     uint32_t nk = eff > 0 ? 1u : 0u, locs = eff;
