@@ -852,7 +852,7 @@ def main():
                          "traffic_over_kernel_bytes": None if (kbytes is None or traffic is None) else round(traffic / kbytes, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_read * nloc * per_read),
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3), "V": V,
-                         "table_location_bytes": layout["location_bytes"],
+                         "table_location_bytes": layout["location_bytes"], "table_list_align": layout.get("list_align", 1), "table_list_entries": layout["list_locations"],
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
         vals = [total_reads / e * 60.0 / 1e6 for e in repeats]

@@ -396,7 +396,7 @@ int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4])
 {
     if (!ctx || !layout || ctx->parts.empty()) return MC_ERR_INVALID;
     const Part& T = ctx->parts[0];
-    layout[0] = T.compact ? 4 : 8; layout[1] = T.compact ? ctx->gwGap : 0; layout[2] = T.nbuckets; layout[3] = T.valuesStored;
+    layout[0] = T.compact ? 4 : 8; layout[1] = (T.compact ? ctx->gwGap : 0) | ((uint64_t)T.listAlign << 32); layout[2] = T.nbuckets; layout[3] = T.valuesStored;
     return MC_OK;
 }
 

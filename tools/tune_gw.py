@@ -51,6 +51,7 @@ def main():
         db.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
     name, vals = args.set.split("=")
     res = {"build": info, "table": db.table_layout(), "runs": []}
+    print(json.dumps({"table": res["table"], "locations": int(db.info()[7])}), flush=True)
     ref = None
     nbt = args.nbatches
     outs = [out, torch.zeros_like(out)]
