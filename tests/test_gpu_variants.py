@@ -75,3 +75,26 @@ def test_random_reads_every_variant_against_oracle(golden, big_min):
                 assert cands_equal(cands[i], exp[i]), (v, s, w, st, i, reads[i], cands[i], exp[i])
         db.close()
     odb.close()
+
+
+@pytest.mark.parametrize("align", ["0", "1"])
+def test_list_alignment_on_and_off(golden, align, monkeypatch):
+    """the compact store with every list on a 128-byte line of its own (mc_table_layout: list_align 32) and without: the reference's golden
+    reads, singles and pairs, lane path and filtered path"""
+    monkeypatch.setenv("MC_LIST_ALIGN", align)
+    single, p1, p2 = golden.reads()
+    for big_min in (None, 0):
+        db = api.Database.open(golden.db_path("toy32"), max_candidates=2, copy_allhits=0, slot_max_queries=700, slot_max_chars=1 << 18)
+        lay = db.table_layout()
+        assert lay["location_bytes"] == 4 and lay["list_align"] == (32 if align == "1" else 1), lay
+        if big_min is not None:
+            db.set_tuning("big_min", big_min)
+        exp = golden.expected("toy32", "single_c2_seq")
+        cands, _, _ = db.query(single, lowest=0, insert_max=0)
+        for i in range(len(single)):
+            assert cands_equal(cands[i], exp[i][:2]), (align, big_min, i, cands[i], exp[i])
+        exp = golden.expected("toy32", "pair_c2_seq")
+        cands, _, _ = db.query(p1, p2, lowest=0, insert_max=0)
+        for i in range(len(p1)):
+            assert cands_equal(cands[i], exp[i]), (align, big_min, "pair", i)
+        db.close()
