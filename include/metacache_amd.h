@@ -93,6 +93,15 @@ typedef struct {
      * the PARTIAL location lists of its keys; the union of all shards goes through mc_candidates_from_hits. */
     uint32_t key_shard_index;
     uint32_t key_shard_count;
+    /* target-range sharding of ONE part over several GPUs ("Mode T"): mc_open_database keeps only the locations whose target lies in
+     * range `index` of `count` CONTIGUOUS target-id ranges (cut where the targets' window counts -- the metadata's -- split into
+     * equal shares: target t belongs to range floor(windows_before(t) * count / windows_total)); count <= 1 keeps everything.  The
+     * load-time rules above are applied to the file's full bucket first, as on the whole table.  Every range keeps the full target
+     * numbering and answers mc_query_* with the unchanged single-table path; the candidates of a read are disjoint between ranges,
+     * so mc_merge_part_candidates over the ranges' top lists IN RANGE ORDER equals the whole table's list (mc_partset_open does
+     * that when this count is > 1).  Not combinable with key shards or with several parts in one context. */
+    uint32_t target_shard_index;
+    uint32_t target_shard_count;
 } mc_config;
 
 void mc_config_default(mc_config* cfg);
@@ -125,6 +134,9 @@ int mc_load_location_range(mc_ctx* ctx, uint32_t max_target_id, uint32_t max_win
  * and fits the device; mc_set_tuning "list_align" 0 / 1 / -1, MC_LIST_ALIGN), [2] = number of 64-byte buckets, [3] = entries of the list
  * store (lists of >= 2 with their padding; single locations live in their bucket) */
 int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4]);
+/* the targets whose locations this context holds: range[0] <= target < range[1] (everything: 0 .. number of targets; a target-range
+ * shard, mc_config.target_shard_*: its contiguous range, possibly empty) */
+int mc_target_range(const mc_ctx* ctx, uint64_t range[2]);
 int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_t* sizes,
                   const void* values, uint64_t nkeys_in_batch);
 int mc_load_end(mc_ctx* ctx, uint32_t part);

@@ -26,7 +26,8 @@ class McConfig(C.Structure):
                 ("num_parts", C.c_uint32), ("max_locations_per_feature", C.c_uint32), ("remove_overpopulated", C.c_uint32),
                 ("max_load_factor", C.c_float), ("num_slots", C.c_uint32), ("slot_max_queries", C.c_uint32),
                 ("slot_max_chars", C.c_uint32), ("copy_allhits", C.c_uint32), ("single_part", C.c_int32),
-                ("key_shard_index", C.c_uint32), ("key_shard_count", C.c_uint32)]
+                ("key_shard_index", C.c_uint32), ("key_shard_count", C.c_uint32),
+                ("target_shard_index", C.c_uint32), ("target_shard_count", C.c_uint32)]
 
 
 class McResults(C.Structure):
@@ -63,7 +64,7 @@ class McDeviceResults(C.Structure):
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
 
 
-EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
+EXPORTS = ["mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_target_range", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
            "mc_partset_info", "mc_partset_classify", "mc_partset_last_error", "mc_partset_select_group", "mc_partset_classify_resident", "mc_partset_load_bytes",
            "mc_partial_numbers", "mc_candidates_from_partial_numbers", "mc_owner_stats", "mc_keyset_open", "mc_keyset_close", "mc_keyset_info", "mc_keyset_classify", "mc_keyset_last_error",
            "mc_open_database", "mc_open_metadata", "mc_load_stats", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",
@@ -102,6 +103,7 @@ def lib() -> C.CDLL:
         L.mc_load_location_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.mc_load_target_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_table_layout.argtypes = [C.c_void_p, C.c_void_p]
+        L.mc_target_range.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_set_lineages.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mc_db_info.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_db_num_taxa.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -369,6 +371,12 @@ class Database:
         self._check(lib().mc_table_layout(self.h, a))
         return {"location_bytes": int(a[0]), "window_gap": int(a[1]) & 0xFFFFFFFF, "list_align": int(a[1]) >> 32, "buckets": int(a[2]), "list_locations": int(a[3])}
 
+    def target_range(self) -> tuple:
+        """[lo, hi): the targets whose locations this context holds (mc_target_range)"""
+        a = (C.c_uint64 * 2)()
+        self._check(lib().mc_target_range(self.h, a))
+        return int(a[0]), int(a[1])
+
     def set_tuning(self, name: str, value: int):
         L = lib()
         L.mc_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -408,6 +416,7 @@ class PartSet:
         L.mc_partset_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
         L.mc_partset_last_error.argtypes = [C.c_void_p]
         L.mc_partset_last_error.restype = C.c_char_p
+        kw.setdefault("kmerlen", 0); kw.setdefault("sketchlen", 0); kw.setdefault("winlen", 0); kw.setdefault("winstride", 0)   # (the database's own, as Database.open)
         self.cfg = default_config(**kw)
         self.h = C.c_void_p()
         dv = np.asarray(devices if devices is not None else [], dtype=np.int32)

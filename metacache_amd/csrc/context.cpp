@@ -163,6 +163,7 @@ void mc_config_default(mc_config* c)
     c->copy_allhits = 0;
     c->single_part = -1;
     c->key_shard_index = 0; c->key_shard_count = 1;
+    c->target_shard_index = 0; c->target_shard_count = 1;
 }
 
 const char* mc_last_error(const mc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
@@ -179,6 +180,11 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (cfg->num_parts < 1 || cfg->num_parts > 255) return fail(nullptr, MC_ERR_UNSUPPORTED, "num_parts must be 1..255");
     if (cfg->max_candidates < 1) return fail(nullptr, MC_ERR_INVALID, "max_candidates must be >= 1");
     if (cfg->key_shard_count > 1 && cfg->key_shard_index >= cfg->key_shard_count) return fail(nullptr, MC_ERR_INVALID, "key_shard_index out of range");
+    if (cfg->target_shard_count > 1) {
+        if (cfg->target_shard_index >= cfg->target_shard_count) return fail(nullptr, MC_ERR_INVALID, "target_shard_index out of range");
+        if (cfg->key_shard_count > 1) return fail(nullptr, MC_ERR_UNSUPPORTED, "target shards and key shards cannot be combined");
+        if (cfg->num_parts > 1) return fail(nullptr, MC_ERR_UNSUPPORTED, "target shards need a single part per context (single_part)");
+    }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -400,12 +406,22 @@ int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4])
     return MC_OK;
 }
 
+int mc_target_range(const mc_ctx* ctx, uint64_t range[2])
+{
+    if (!ctx || !range) return MC_ERR_INVALID;
+    range[0] = ctx->tgtRangeSet ? ctx->tgtLo : 0;
+    range[1] = ctx->tgtRangeSet ? ctx->tgtHi : ctx->targetCount;
+    return MC_OK;
+}
+
 int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues)
 {
     if (!ctx) return MC_ERR_INVALID;
     if (part >= ctx->parts.size()) return fail(ctx, MC_ERR_INVALID, "mc_load_begin: part out of range");
     Part& P = ctx->parts[part];
     if (P.announced) return fail(ctx, MC_ERR_STATE, "mc_load_begin: part already announced");
+    if (ctx->cfg.target_shard_count > 1 && !ctx->tgtRangeSet)
+        return fail(ctx, MC_ERR_UNSUPPORTED, "target shards are cut from a database file (mc_open_database), not from mc_load_batch arrays");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     P.expectKeys = nkeys; P.expectValues = nvalues;
     P.announced = true; P.loading = true;

@@ -93,6 +93,9 @@ int load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* d
 // dbload.cpp: a whole .cache file of a single-part context through reader threads, pinned slabs and a copy stream (between mc_load_begin
 // and mc_load_end).  stats (may be NULL): bytes read, nanoseconds in all, of the index pass, the feeder waited for readers
 int load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t targetBytes, uint64_t stats[4]);
+// Mode T: one batch of the file in host memory (keys | sizes | packed values) cut IN PLACE to the locations of the context's target
+// range, after the load-time rules that look at a bucket's size; returns the number of values that stay (sizes[] updated)
+uint64_t cut_batch_to_target_range(const mc_ctx* ctx, uint8_t* sizes, uint8_t* vals, uint32_t nkeys, uint32_t targetBytes);
 
 // error text for failures that have no context yet (mc_last_error(NULL))
 void set_global_error(const std::string& msg);
@@ -117,6 +120,12 @@ struct mc_ctx {
     // (DeviceTable::values32 / gwBase / gwDir).
     bool compactAllowed = true, locRangeViolated = false;
     std::vector<uint32_t> targetWindows;   // empty: not announced
+    // cfg.target_shard_count > 1 ("Mode T", set by mc_open_database): only locations of the targets [tgtLo, tgtHi) are kept;
+    // tgtShare = this range's share of the database's windows (what the location store is sized by)
+    uint32_t tgtLo = 0, tgtHi = 0xFFFFFFFFu;
+    double tgtShare = 1.0;
+    bool tgtRangeSet = false, storeShort = false;      // storeShort: the estimate of the range's store was too small; tgtExact* hold what it takes
+    uint64_t tgtExactPlain = 0, tgtExactPadded = 0;
     uint32_t* dGwBase = nullptr;           // [targets + 1]
     uint32_t* dGwDir = nullptr;
     uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0, gwBits = 32;   // gwBits: bits of the largest window number

@@ -146,6 +146,7 @@ int load_part(mc_ctx* ctx, uint32_t part, const std::string& fname, uint32_t tar
         for (uint64_t i = 0; i < nb; ++i) bv += sizes[i];
         vals.resize(bv * vb + 8);
         if (bv && !f.rd(vals.data(), bv * vb)) { ctx->err = "truncated " + fname; return MC_ERR_IO; }
+        if (ctx->cfg.target_shard_count > 1) cut_batch_to_target_range(ctx, sizes.data(), vals.data(), (uint32_t)nb, targetBytes);
         if ((rc = mc_load_batch(ctx, part, keys.data(), sizes.data(), vals.data(), nb))) return rc;
         done += nb;
     }
@@ -189,7 +190,9 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     // file_source::windows; targets carry the ids -(target) - 1, taxonomy.hpp:930).  Should a file hold a location outside of what
     // its own metadata says, the load is repeated with 8-byte locations.
     double trCreate = 0, trBegin = 0, trLoad = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool compactRefused = false;
+    uint64_t exactPlain = 0, exactPadded = 0;                 // Mode T: a first load found its store too small and counted it
+    for (int attempt = 0; attempt < 3; ++attempt) {
         const double tc0 = now_s();
         if ((rc = mc_create(&cfg, &ctx))) return rc;
         trCreate += now_s() - tc0;
@@ -198,7 +201,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         ctx->maxLocs = cfg.max_locations_per_feature ? std::min<uint64_t>(m.maxLocs, cfg.max_locations_per_feature) : m.maxLocs;
         ctx->taxa = std::move(m.taxa);
         m.taxa.clear();
-        bool tryCompact = attempt == 0 && cfg.num_parts == 1 && m.targetCount > 0 && m.targetCount < 0xFFFFFFFFull;
+        bool tryCompact = !compactRefused && cfg.num_parts == 1 && m.targetCount > 0 && m.targetCount < 0xFFFFFFFFull;
         if (tryCompact) {
             std::vector<uint32_t> windows((size_t)m.targetCount, 0u);
             uint64_t seen = 0;
@@ -211,6 +214,27 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
             tryCompact = tryCompact && seen == m.targetCount;
             if (tryCompact) rc = mc_load_target_windows(ctx, windows.data(), windows.size());
         }
+        if (cfg.target_shard_count > 1) {
+            // Mode T: the contiguous target range of this context, cut where the windows split into equal shares (metacache_amd.h)
+            std::vector<uint64_t> win((size_t)m.targetCount, 1);
+            for (const auto& t : ctx->taxa)
+                if (t.id < 0 && (uint64_t)(-(t.id + 1)) < m.targetCount) win[(size_t)(-(t.id + 1))] = std::max<uint64_t>(t.windows, 1);
+            uint64_t total = 0;
+            for (uint64_t w : win) total += w;
+            const uint64_t R = cfg.target_shard_count, me = cfg.target_shard_index;
+            uint64_t before = 0, mine = 0;
+            uint32_t lo = (uint32_t)m.targetCount, hi = 0;
+            for (uint64_t t = 0; t < m.targetCount; ++t) {
+                const uint64_t r = (uint64_t)(((unsigned __int128)before * R) / std::max<uint64_t>(total, 1));
+                if (r == me) { lo = std::min<uint32_t>(lo, (uint32_t)t); hi = (uint32_t)t + 1; mine += win[(size_t)t]; }
+                before += win[(size_t)t];
+            }
+            if (hi == 0) lo = 0;                                // (more ranges than targets: an empty one)
+            ctx->tgtLo = lo; ctx->tgtHi = hi;
+            ctx->tgtShare = total ? (double)mine / (double)total : 1.0;
+            ctx->tgtRangeSet = true;
+            ctx->tgtExactPlain = exactPlain; ctx->tgtExactPadded = exactPadded;
+        }
         // every part is announced first (the merged table is sized for all of them), then loaded in part order
         const double tb0 = now_s();
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p) {
@@ -222,7 +246,14 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
             rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
         trBegin += tb1 - tb0; trLoad += now_s() - tb1;
-        if (rc && tryCompact && ctx->locRangeViolated) {
+        if (rc && tryCompact && ctx->locRangeViolated && attempt < 2) {
+            compactRefused = true;
+            m.taxa = std::move(ctx->taxa);
+            mc_destroy(ctx); ctx = nullptr; rc = 0;
+            continue;
+        }
+        if (rc && ctx->storeShort && !exactPlain && attempt < 2) {
+            exactPlain = ctx->tgtExactPlain; exactPadded = ctx->tgtExactPadded;
             m.taxa = std::move(ctx->taxa);
             mc_destroy(ctx); ctx = nullptr; rc = 0;
             continue;

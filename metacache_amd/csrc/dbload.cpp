@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -136,6 +137,40 @@ int mcamd::load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uin
     return MC_OK;
 }
 
+// Mode T (mc_config.target_shard_*): the values of a batch that lie in the context's target range move to the front of the batch's value
+// array, bucket after bucket; a bucket is first cut as the whole table would cut it (remove-overpopulated empties it, max-locations
+// keeps its first n values: host_hashmap.hpp:454-495), so that the device's own size rules find nothing more to do.  A bucket none
+// of whose locations are in range keeps its key with size 0 (the table build skips it).
+uint64_t mcamd::cut_batch_to_target_range(const mc_ctx* ctx, uint8_t* sizes, uint8_t* vals, uint32_t nkeys, uint32_t targetBytes)
+{
+    const uint32_t lo = ctx->tgtLo, hi = ctx->tgtHi;
+    const uint32_t rmOver = ctx->cfg.remove_overpopulated, maxLocs = ctx->cfg.max_locations_per_feature;
+    const size_t vb = 4 + targetBytes;
+    const uint8_t* src = vals;
+    uint8_t* dst = vals;
+    uint64_t kept = 0;
+    for (uint32_t i = 0; i < nkeys; ++i) {
+        const uint32_t fileSize = sizes[i];
+        uint32_t eff = fileSize;
+        if (rmOver && eff > rmOver) eff = 0;
+        if (maxLocs && eff > maxLocs) eff = maxLocs;
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < eff; ++j) {
+            const uint8_t* v = src + (size_t)j * vb;
+            uint32_t tgt = (uint32_t)v[4] | ((uint32_t)v[5] << 8);
+            if (targetBytes == 4) tgt |= ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+            if (tgt >= lo && tgt < hi) {
+                if (dst != v) std::memmove(dst, v, vb);
+                dst += vb; ++n;
+            }
+        }
+        src += (size_t)fileSize * vb;
+        sizes[i] = (uint8_t)n;
+        kept += n;
+    }
+    return kept;
+}
+
 // The whole .cache file of a single-part context (between mc_load_begin and mc_load_end, which the caller issues).
 int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t targetBytes, uint64_t stats[4])
 {
@@ -160,6 +195,16 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     //      lines of its own (announce_store)
     std::vector<BatchPlace> place;
     uint64_t padded = 0;
+    // Mode T: what this range's store takes is known only when the values have been read; the first estimate assumes a bucket's
+    // locations fall into the range independently with the range's share of the windows: a list of e locations leaves a piece of
+    // e * share entries, there at all with probability 1 - (1 - share)^e, and a piece on lines of its own wastes half a line
+    const bool targetCut = ctx->cfg.target_shard_count > 1;
+    double pieceEntries[256] = {0}, piecePadded[256] = {0}, estPlain = 0, estPadded = 0;
+    if (targetCut)
+        for (int e = 2; e < 256; ++e) {
+            const double sh = std::min(1.0, std::max(ctx->tgtShare, 0.0)), there = 1.0 - std::pow(1.0 - sh, e);
+            pieceEntries[e] = e * sh; piecePadded[e] = e * sh + 0.5 * kListAlign * there;
+        }
     const uint32_t rmOver0 = ctx->cfg.remove_overpopulated, maxLocs0 = ctx->cfg.max_locations_per_feature;
     {
         std::vector<uint8_t> sz((size_t)std::min<uint64_t>(batch, nkeys));
@@ -174,6 +219,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
                 if (rmOver0 && e > rmOver0) e = 0;
                 if (maxLocs0 && e > maxLocs0) e = maxLocs0;
                 padded += list_alloc(e, kListAlign);
+                estPlain += pieceEntries[e]; estPadded += piecePadded[e];
             }
             if (off + (uint64_t)nb * 5 + bv * vb > fileSize) return fail(MC_ERR_IO, "truncated " + fname);
             place.push_back(BatchPlace{off, bv, nb});
@@ -187,7 +233,24 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     {
         // (a key shard keeps about 1 / count of the lists: the margin of allocate_table's estimate for the plain store)
         const uint64_t c = std::max<uint32_t>(ctx->cfg.key_shard_count, 1);
-        mcamd::announce_store(ctx, c > 1 ? padded / c + padded / (3 * c) + (1u << 16) : padded);
+        uint64_t want = c > 1 ? padded / c + padded / (3 * c) + (1u << 16) : padded;
+        if (targetCut) {
+            // (40 % margin, everything for small files; a store that turns out too small is counted to its end and the load repeated
+            // with the exact numbers: mc_open_database)
+            Part& T = ctx->parts[0];
+            if (ctx->tgtExactPlain) { T.dvaluesCap = ctx->tgtExactPlain + 1; want = ctx->tgtExactPadded; }
+            else {
+                double margin = 1.4;
+                bool tiny = true;
+                if (const char* e = std::getenv("MC_TARGET_STORE_MARGIN")) { margin = std::atof(e); tiny = false; }   // tests: an estimate that is too small
+                auto roomy = [&](double est, uint64_t all) {
+                    return tiny && all <= (1ull << 24) ? all : std::min<uint64_t>(all, (uint64_t)(est * margin) + (tiny ? (1u << 20) : 0u));
+                };
+                T.dvaluesCap = roomy(estPlain, head[1]) + 1;
+                want = roomy(estPadded, padded);
+            }
+        }
+        mcamd::announce_store(ctx, want);
     }
     auto batch_bytes = [&](const BatchPlace& b) { return align16((size_t)b.nkeys * 4) + align16(b.nkeys) + align16((size_t)b.fileVals * vb) + 16; };
     size_t slabBytes = 0;
@@ -209,6 +272,8 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     std::condition_variable cv;
     std::vector<uint8_t> ready(nbatches, 0);                  // 1 = in its slab, 2 = the read failed
     std::vector<uint64_t> storedOf(nbatches, 0);
+    std::vector<uint64_t> keptOf(nbatches, 0);                // Mode T: the values of the batch that are in this context's target range,
+    std::vector<uint64_t> plainOf(targetCut ? nbatches : 0, 0), paddedOf(targetCut ? nbatches : 0, 0);   // what they take in the store (plain / on lines of their own)
     size_t released = 0;                                      // batches whose slab the feeder has given back
     std::atomic<size_t> next{0};
     bool abort = false;
@@ -229,6 +294,12 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
             bool ok = pread_all(fd, keys, (size_t)B.nkeys * 4, B.off) && pread_all(fd, sizes, B.nkeys, B.off + (uint64_t)B.nkeys * 4) &&
                       (B.fileVals == 0 || pread_all(fd, vals, (size_t)B.fileVals * vb, B.off + (uint64_t)B.nkeys * 5));
             uint64_t st = 0;
+            if (ok && targetCut) {                             // (only this reader touches the batch's entries before ready[b])
+                keptOf[b] = cut_batch_to_target_range(ctx, sizes, vals, B.nkeys, targetBytes);
+                uint64_t pl = 0, pd = 0;
+                for (uint32_t i = 0; i < B.nkeys; ++i) { pl += list_alloc(sizes[i], 1); pd += list_alloc(sizes[i], kListAlign); }
+                plainOf[b] = pl; paddedOf[b] = pd;
+            }
             if (ok) {
                 const uint32_t* k = reinterpret_cast<const uint32_t*>(keys);
                 if (lf.shardCnt > 1 || lf.maxLocs || lf.rmOver) for (uint32_t i = 0; i < B.nkeys; ++i) st += stored_of(k[i], sizes[i], lf);
@@ -269,6 +340,8 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     };
     if (!okInit) { const int code = stop(MC_ERR_HIP, "database load: cannot create the copy stream"); cleanup(); return code; }
     uint64_t waitNs = 0, bytesIn = 24;
+    uint64_t exactPlain = 0, exactPadded = 0;                 // Mode T: this range's store, known when the last batch is through
+    bool countOnly = false;
     int rc = MC_OK;
     std::string emsg;
     for (size_t b = 0; b < nbatches && !rc; ++b) {
@@ -280,7 +353,24 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
             waitNs += now() - w0;
             if (ready[b] == 2) { rc = MC_ERR_IO; emsg = "truncated " + fname; break; }
         }
-        const BatchPlace& B = place[b];
+        BatchPlace B = place[b];
+        const uint64_t fileBytes = (uint64_t)B.nkeys * 5 + B.fileVals * vb;
+        if (targetCut) {
+            B.fileVals = keptOf[b];                            // (the slab keeps the batch's places; its values end earlier)
+            exactPlain += plainOf[b]; exactPadded += paddedOf[b];
+            Part& T = ctx->parts[0];
+            if (!countOnly && T.valuesStored + storedOf[b] > T.dvaluesCap) {
+                // the estimate was too small: the rest of the file is only counted (no more device work)
+                countOnly = true;
+                (void)hipStreamSynchronize(copySt);
+            }
+            if (countOnly) {
+                bytesIn += fileBytes;
+                { std::lock_guard<std::mutex> l(mtx); released = b + 1; }
+                cv.notify_all();
+                continue;
+            }
+        }
         const size_t bytes = batch_bytes(B);
         if (b >= 2 && hipEventSynchronize(built[k]) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: table build failed"; break; }   // staging k is free again
         if (bytes > stage[k].cap) {
@@ -314,7 +404,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
         }
         if (rc) { emsg = ctx->err; break; }
         if (hipEventRecord(built[k], ctx->stream) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: event"; break; }
-        bytesIn += (uint64_t)B.nkeys * 5 + B.fileVals * vb;
+        bytesIn += fileBytes;
         // the slab goes back to the readers when its copy has left the host: the copy of the PREVIOUS batch has had a batch's time to finish
         if (b >= 1) {
             if (hipEventSynchronize(copied[k ^ 1]) != hipSuccess) { rc = MC_ERR_HIP; emsg = "database load: copy to the device failed"; break; }
@@ -328,6 +418,10 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     cleanup();
     for (auto& s : slabs) pool().put(s);
     if (!synced) return fail(MC_ERR_HIP, "database load: table build failed");
+    if (countOnly) {
+        ctx->tgtExactPlain = std::max<uint64_t>(exactPlain, 1); ctx->tgtExactPadded = exactPadded; ctx->storeShort = true;
+        return fail(MC_ERR_NOMEM, "database load: the target range holds more locations than estimated (" + std::to_string(exactPlain) + "); load again with the exact size");
+    }
     if (stats) { stats[0] = bytesIn; stats[1] = now() - t0; stats[2] = tIndex - t0; stats[3] = waitNs; }
     if (std::getenv("MC_LOAD_TRACE"))
         std::fprintf(stderr, "mc load %s: %.2f GB, %zu batches, %u threads, %u slabs of %.0f MB; index %.3f s, slabs %.3f s, total %.3f s (feeder waited %.3f s) = %.1f GB/s\n",

@@ -59,6 +59,7 @@ struct mc_partset {
     std::vector<uint8_t> hseq; std::vector<uint32_t> hq, hmw;   // host staging of a batch
     uint64_t loadNs = 0, waitNs = 0;   // time the loader spent / the queries waited for it
     std::atomic<uint64_t> loadBytes{0}; // bytes of .cache files read by the group loads
+    bool ranges = false;               // the parts are target ranges of one file (cfg.target_shard_count > 1)
     bool rccl = false;                 // several devices (or MC_PARTSET_RCCL=1: the same calls with a single rank, tests): gather over RCCL
 };
 
@@ -67,6 +68,8 @@ namespace {
 int ps_fail(mc_partset* ps, int code, const std::string& msg) { if (ps) ps->err = msg; else set_global_error(msg); return code; }
 
 uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+
+void drop(mc_partset* ps) { delete ps; mcamd::big_cache_hold(-1); }   // (mc_partset_open before any device state exists: the hold goes back too)
 
 void close_group(std::vector<mc_ctx*>& g) { for (mc_ctx* c : g) if (c) mc_destroy(c); g.clear(); }
 
@@ -83,7 +86,8 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
     auto load_device = [&](uint32_t d) {
         for (uint32_t i = d; i < count; i += nd) {
             mc_config c = ps->cfg;
-            c.single_part = (int32_t)(first + i);
+            if (ps->ranges) { c.single_part = std::max(ps->cfg.single_part, 0); c.target_shard_index = first + i; c.target_shard_count = ps->nparts; }
+            else c.single_part = (int32_t)(first + i);
             c.device = ps->devices[d];
             c.num_slots = 1; c.copy_allhits = 0;
             const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
@@ -136,17 +140,23 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     mcamd::big_cache_hold(+1);                                    // (the tables of a closed group are the next group's: devcache.h; released in mc_partset_close)
     ps->db = name; ps->cfg = *cfg;
     ps->nparts = (uint32_t)info[6];
+    // Mode T: the "parts" are the target ranges of ONE part file (cfg.single_part, or part 0), cut at load (metacache_amd.h mc_config)
+    ps->ranges = cfg->target_shard_count > 1;
+    if (ps->ranges) {
+        if (cfg->single_part >= (int32_t)ps->nparts) { drop(ps); return ps_fail(nullptr, MC_ERR_INVALID, "database part is not available"); }
+        ps->nparts = cfg->target_shard_count;
+    }
     ps->stride = (uint32_t)(info[3] ? info[3] : 112);
     ps->K = cfg->max_candidates;
     ps->resident = std::max<uint32_t>(1, std::min<uint32_t>(residentParts ? residentParts : ps->nparts, ps->nparts));
-    if (ps->K > 4) { delete ps; return ps_fail(nullptr, MC_ERR_UNSUPPORTED, "mc_partset_open: max_candidates above 4"); }
+    if (ps->K > 4) { drop(ps); return ps_fail(nullptr, MC_ERR_UNSUPPORTED, "mc_partset_open: max_candidates above 4"); }
     int ndevAvail = 0;
-    if (hipGetDeviceCount(&ndevAvail) != hipSuccess || ndevAvail < 1) { delete ps; return ps_fail(nullptr, MC_ERR_HIP, "no usable HIP device (this library has no CPU fallback)"); }
+    if (hipGetDeviceCount(&ndevAvail) != hipSuccess || ndevAvail < 1) { drop(ps); return ps_fail(nullptr, MC_ERR_HIP, "no usable HIP device (this library has no CPU fallback)"); }
     if (devices && numDevices) ps->devices.assign(devices, devices + numDevices); else ps->devices.assign(1, cfg->device);
     for (size_t i = 0; i < ps->devices.size(); ++i) {
-        if (ps->devices[i] < 0 || ps->devices[i] >= ndevAvail) { delete ps; return ps_fail(nullptr, MC_ERR_INVALID, "mc_partset_open: device ordinal out of range"); }
+        if (ps->devices[i] < 0 || ps->devices[i] >= ndevAvail) { drop(ps); return ps_fail(nullptr, MC_ERR_INVALID, "mc_partset_open: device ordinal out of range"); }
         for (size_t j = 0; j < i; ++j)
-            if (ps->devices[j] == ps->devices[i]) { delete ps; return ps_fail(nullptr, MC_ERR_INVALID, "mc_partset_open: a device is listed twice"); }
+            if (ps->devices[j] == ps->devices[i]) { drop(ps); return ps_fail(nullptr, MC_ERR_INVALID, "mc_partset_open: a device is listed twice"); }
     }
     const uint32_t nd = (uint32_t)ps->devices.size();
     ps->slotsPerDev = (ps->resident + nd - 1) / nd;
@@ -158,10 +168,10 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     ps->rccl = nd > 1 || (force && force[0] == '1');
     std::vector<void*> comms(nd, nullptr);
     if (ps->rccl) {
-        if (!g_rccl.load()) { const std::string e = g_rccl.err; delete ps; return ps_fail(nullptr, MC_ERR_UNSUPPORTED, e); }
+        if (!g_rccl.load()) { const std::string e = g_rccl.err; drop(ps); return ps_fail(nullptr, MC_ERR_UNSUPPORTED, e); }
         if (int r = g_rccl.CommInitAll(comms.data(), (int)nd, ps->devices.data())) {
             const std::string e = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
-            delete ps;
+            drop(ps);
             return ps_fail(nullptr, MC_ERR_HIP, e);
         }
     }
