@@ -135,8 +135,8 @@ int mc_load_location_range(mc_ctx* ctx, uint32_t max_target_id, uint32_t max_win
  * store (lists of >= 2 with their padding; single locations live in their bucket) */
 int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4]);
 /* the targets whose locations this context holds: range[0] <= target < range[1] (everything: 0 .. number of targets; a target-range
- * shard, mc_config.target_shard_*: its contiguous range, possibly empty) */
-int mc_target_range(const mc_ctx* ctx, uint64_t range[2]);
+ * shard, mc_config.target_shard_*: its contiguous range, possibly empty); range[2] = features stored in the table, range[3] = locations */
+int mc_target_range(const mc_ctx* ctx, uint64_t range[4]);
 int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_t* sizes,
                   const void* values, uint64_t nkeys_in_batch);
 int mc_load_end(mc_ctx* ctx, uint32_t part);

@@ -373,8 +373,9 @@ class Database:
 
     def target_range(self) -> tuple:
         """[lo, hi): the targets whose locations this context holds (mc_target_range)"""
-        a = (C.c_uint64 * 2)()
+        a = (C.c_uint64 * 4)()
         self._check(lib().mc_target_range(self.h, a))
+        self.n_features = int(a[2])                               # (features the table holds)
         return int(a[0]), int(a[1])
 
     def set_tuning(self, name: str, value: int):
@@ -453,6 +454,15 @@ class PartSet:
         if rc != 0:
             raise McError(f"mc_partset_classify_resident: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
 
+    def classify_resident_packed(self, seqs: np.ndarray, offs: np.ndarray, out: np.ndarray, has_prior: bool, lowest: int = 0):
+        """classify_resident for single-end reads given as one byte array + n + 1 offsets"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8); offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        L = lib()
+        L.mc_partset_classify_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+        rc = L.mc_partset_classify_resident(self.h, seqs.ctypes.data, offs.ctypes.data, None, None, len(offs) - 1, lowest, 0, int(has_prior), out.ctypes.data)
+        if rc != 0:
+            raise McError(f"mc_partset_classify_resident: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
+
     def classify(self, reads, mates=None, lowest: int = 0, insert_max: int = 0) -> np.ndarray:
         """reads / mates: lists of bytes -> cand_dtype [n, max_candidates]"""
         def pack(rs):
@@ -466,6 +476,17 @@ class PartSet:
         L = lib()
         rc = L.mc_partset_classify(self.h, s1.ctypes.data, o1.ctypes.data, s2.ctypes.data if s2 is not None else None,
                                    o2.ctypes.data if o2 is not None else None, n, lowest, insert_max, out.ctypes.data)
+        if rc != 0:
+            raise McError(f"mc_partset_classify: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
+        return out
+
+    def classify_packed(self, seqs: np.ndarray, offs: np.ndarray, lowest: int = 0, insert_max: int = 0) -> np.ndarray:
+        """single-end reads as one byte array + n + 1 offsets (what mc_partset_classify takes) -> cand_dtype [n, max_candidates]"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8); offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        out = np.zeros((n, self.cfg.max_candidates), dtype=cand_dtype)
+        L = lib()
+        rc = L.mc_partset_classify(self.h, seqs.ctypes.data, offs.ctypes.data, None, None, n, lowest, insert_max, out.ctypes.data)
         if rc != 0:
             raise McError(f"mc_partset_classify: {L.mc_partset_last_error(self.h).decode()} (rc {rc})")
         return out

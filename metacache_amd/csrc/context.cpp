@@ -91,6 +91,21 @@ void mcamd::announce_store(mc_ctx* ctx, uint64_t paddedEntries)
     if (!affordable) return;
     T.listAlign = kListAlign; T.expectStore = paddedEntries; T.dvaluesCap = paddedEntries + 1;
 }
+// the bucket table of a single-part context whose mc_load_begin left it open (Mode T), for `nkeys` keys at the context's load factor;
+// nkeys = 0: for all keys the part announced
+int mcamd::allocate_buckets(mc_ctx* ctx, uint64_t nkeys)
+{
+    Part& T = ctx->parts[0];
+    if (T.dbuckets) return MC_OK;
+    if (nkeys == 0 || nkeys > T.expectKeys) nkeys = T.expectKeys;
+    uint64_t nb = (uint64_t)((double)nkeys / (kSlotsPerBucket * (double)ctx->loadFactor)) + 2;
+    nb += nb & 1;
+    if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
+    T.nbuckets = (uint32_t)nb;
+    HIP_TRY(ctx, big_malloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
+    HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
+    return MC_OK;
+}
 // the location store, with the first chunk that is loaded
 int mcamd::allocate_values(mc_ctx* ctx)
 {
@@ -109,6 +124,7 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     Part& P = ctx->parts[0];
     if (P.keysLoaded + nb > P.expectKeys) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more keys than announced");
     if (fileVals >= (1ull << 32)) return fail(ctx, MC_ERR_INVALID, "load_chunk_device: chunk too large");
+    if (int rcB = mcamd::allocate_buckets(ctx, 0)) return rcB;
     const uint32_t tb = ctx->cfg.target_id_bytes;
     const LoadFilter lf{ctx->cfg.max_locations_per_feature, ctx->cfg.remove_overpopulated, ctx->cfg.key_shard_index, ctx->cfg.key_shard_count, ctx->parts[0].listAlign};
     hipStream_t st = ctx->stream;
@@ -303,6 +319,8 @@ static int allocate_table(mc_ctx* ctx)
         nkeys = std::min<uint64_t>(nkeys, nkeys / c + nkeys / (8 * c) + 4096);
         nvalues = std::min<uint64_t>(nvalues, nvalues / c + nvalues / (3 * c) + (1u << 16));
     }
+    // (Mode T: the buckets wait for the loader's estimate of the keys that have a location in the range, mcamd::allocate_buckets)
+    const bool bucketsLater = ctx->parts.size() == 1 && ctx->cfg.target_shard_count > 1;
     uint64_t nb = (uint64_t)((double)nkeys / (kSlotsPerBucket * (double)ctx->loadFactor)) + 2;
     nb += nb & 1;                                            // two buckets per line
     if (nb > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "table too large for 32-bit bucket index");
@@ -343,8 +361,10 @@ static int allocate_table(mc_ctx* ctx)
         // (the location store is allocated with the first chunk -- allocate_values: a loader that knows the lists' sizes announces the
         // padded total first, mcamd::announce_store)
         // (big_malloc: the tables of a part group come back from the tables of the group before it, devcache.h)
-        HIP_TRY(ctx, big_malloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
-        HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
+        if (!bucketsLater) {
+            HIP_TRY(ctx, big_malloc((void**)&T.dbuckets, (size_t)nb * sizeof(TableBucket)));
+            HIP_TRY(ctx, hipMemsetAsync(T.dbuckets, 0, (size_t)nb * sizeof(TableBucket), ctx->stream));
+        }
         int rc = ensure(ctx, ctx->bLdCounters, 4 * sizeof(unsigned long long));
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->bLdCounters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
@@ -406,11 +426,14 @@ int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4])
     return MC_OK;
 }
 
-int mc_target_range(const mc_ctx* ctx, uint64_t range[2])
+int mc_target_range(const mc_ctx* ctx, uint64_t range[4])
 {
     if (!ctx || !range) return MC_ERR_INVALID;
     range[0] = ctx->tgtRangeSet ? ctx->tgtLo : 0;
     range[1] = ctx->tgtRangeSet ? ctx->tgtHi : ctx->targetCount;
+    range[2] = ctx->parts.empty() ? 0 : ctx->parts[0].keysStored;
+    range[3] = 0;
+    for (const auto& p : ctx->parts) range[3] += p.locations;
     return MC_OK;
 }
 

@@ -89,6 +89,7 @@ int load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes,
 // every list on lines of its own -- before the first chunk, with which the store is allocated
 void announce_store(mc_ctx* ctx, uint64_t paddedEntries);
 int allocate_values(mc_ctx* ctx);
+int allocate_buckets(mc_ctx* ctx, uint64_t nkeys);
 int load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals, uint64_t stored);
 // dbload.cpp: a whole .cache file of a single-part context through reader threads, pinned slabs and a copy stream (between mc_load_begin
 // and mc_load_end).  stats (may be NULL): bytes read, nanoseconds in all, of the index pass, the feeder waited for readers
@@ -125,7 +126,7 @@ struct mc_ctx {
     uint32_t tgtLo = 0, tgtHi = 0xFFFFFFFFu;
     double tgtShare = 1.0;
     bool tgtRangeSet = false, storeShort = false;      // storeShort: the estimate of the range's store was too small; tgtExact* hold what it takes
-    uint64_t tgtExactPlain = 0, tgtExactPadded = 0;
+    uint64_t tgtExactPlain = 0, tgtExactPadded = 0, tgtExactKeys = 0;
     uint32_t* dGwBase = nullptr;           // [targets + 1]
     uint32_t* dGwDir = nullptr;
     uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0, gwBits = 32;   // gwBits: bits of the largest window number

@@ -191,7 +191,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
     // its own metadata says, the load is repeated with 8-byte locations.
     double trCreate = 0, trBegin = 0, trLoad = 0;
     bool compactRefused = false;
-    uint64_t exactPlain = 0, exactPadded = 0;                 // Mode T: a first load found its store too small and counted it
+    uint64_t exactPlain = 0, exactPadded = 0, exactKeys = 0;   // Mode T: a first load found its store or its table too small and counted them
     for (int attempt = 0; attempt < 3; ++attempt) {
         const double tc0 = now_s();
         if ((rc = mc_create(&cfg, &ctx))) return rc;
@@ -233,7 +233,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
             ctx->tgtLo = lo; ctx->tgtHi = hi;
             ctx->tgtShare = total ? (double)mine / (double)total : 1.0;
             ctx->tgtRangeSet = true;
-            ctx->tgtExactPlain = exactPlain; ctx->tgtExactPadded = exactPadded;
+            ctx->tgtExactPlain = exactPlain; ctx->tgtExactPadded = exactPadded; ctx->tgtExactKeys = exactKeys;
         }
         // every part is announced first (the merged table is sized for all of them), then loaded in part order
         const double tb0 = now_s();
@@ -253,7 +253,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
             continue;
         }
         if (rc && ctx->storeShort && !exactPlain && attempt < 2) {
-            exactPlain = ctx->tgtExactPlain; exactPadded = ctx->tgtExactPadded;
+            exactPlain = ctx->tgtExactPlain; exactPadded = ctx->tgtExactPadded; exactKeys = ctx->tgtExactKeys;
             m.taxa = std::move(ctx->taxa);
             mc_destroy(ctx); ctx = nullptr; rc = 0;
             continue;

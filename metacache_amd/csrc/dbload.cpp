@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -99,6 +100,7 @@ int mcamd::load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uin
     auto fail = [&](int code, const char* msg) { ctx->err = msg; return code; };
     if (P.keysLoaded + nb > P.expectKeys) return fail(MC_ERR_INVALID, "database file: more keys than its header announces");
     if (fileVals >= (1ull << 32)) return fail(MC_ERR_INVALID, "database file: a chunk holds 2^32 or more locations");
+    if (mcamd::allocate_buckets(ctx, 0) != MC_OK) return MC_ERR_NOMEM;
     if (mcamd::allocate_values(ctx) != MC_OK) return fail(MC_ERR_NOMEM, "database load: cannot allocate the location store");
     if (P.valuesStored + stored > P.dvaluesCap) return fail(MC_ERR_INVALID, "database file: more values than its header announces");
     const uint32_t tb = ctx->cfg.target_id_bytes;
@@ -199,11 +201,14 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     // locations fall into the range independently with the range's share of the windows: a list of e locations leaves a piece of
     // e * share entries, there at all with probability 1 - (1 - share)^e, and a piece on lines of its own wastes half a line
     const bool targetCut = ctx->cfg.target_shard_count > 1;
-    double pieceEntries[256] = {0}, piecePadded[256] = {0}, estPlain = 0, estPadded = 0;
+    double pieceEntries[256] = {0}, piecePadded[256] = {0}, pieceThere[256] = {0}, estPlain = 0, estPadded = 0, estKeys = 0;
+    struct ModelSums { double keys, plain, padded; };
+    std::vector<ModelSums> model;                             // the model's sums batch by batch (the sampled ones are compared with what is there)
     if (targetCut)
-        for (int e = 2; e < 256; ++e) {
+        for (int e = 1; e < 256; ++e) {
             const double sh = std::min(1.0, std::max(ctx->tgtShare, 0.0)), there = 1.0 - std::pow(1.0 - sh, e);
-            pieceEntries[e] = e * sh; piecePadded[e] = e * sh + 0.5 * kListAlign * there;
+            pieceThere[e] = there;                             // (the bucket table is sized by the keys that have a piece here)
+            if (e >= 2) { pieceEntries[e] = e * sh; piecePadded[e] = e * sh + 0.5 * kListAlign * there; }
         }
     const uint32_t rmOver0 = ctx->cfg.remove_overpopulated, maxLocs0 = ctx->cfg.max_locations_per_feature;
     {
@@ -213,16 +218,18 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
             const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, nkeys - done);
             if (off + (uint64_t)nb * 5 > fileSize || !pread_all(fd, sz.data(), nb, off + (uint64_t)nb * 4)) return fail(MC_ERR_IO, "truncated " + fname);
             uint64_t bv = 0;
+            const double mk0 = estKeys, mp0 = estPlain, md0 = estPadded;
             for (uint32_t i = 0; i < nb; ++i) {
                 bv += sz[i];
                 uint32_t e = sz[i];                                // (the load-time modifiers that look at the size alone: table_build.hip effective_size)
                 if (rmOver0 && e > rmOver0) e = 0;
                 if (maxLocs0 && e > maxLocs0) e = maxLocs0;
                 padded += list_alloc(e, kListAlign);
-                estPlain += pieceEntries[e]; estPadded += piecePadded[e];
+                estPlain += pieceEntries[e]; estPadded += piecePadded[e]; estKeys += pieceThere[e];
             }
             if (off + (uint64_t)nb * 5 + bv * vb > fileSize) return fail(MC_ERR_IO, "truncated " + fname);
             place.push_back(BatchPlace{off, bv, nb});
+            if (targetCut) model.push_back({estKeys - mk0, estPlain - mp0, estPadded - md0});
             off += (uint64_t)nb * 5 + bv * vb;
             done += nb;
         }
@@ -235,12 +242,44 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
         const uint64_t c = std::max<uint32_t>(ctx->cfg.key_shard_count, 1);
         uint64_t want = c > 1 ? padded / c + padded / (3 * c) + (1u << 16) : padded;
         if (targetCut) {
-            // (40 % margin, everything for small files; a store that turns out too small is counted to its end and the load repeated
-            // with the exact numbers: mc_open_database)
+            // (15 % margin on the corrected estimate, everything for small files; a store or a table that turns out too small is counted to
+            // its end and the load repeated with the exact numbers: mc_open_database)
             Part& T = ctx->parts[0];
-            if (ctx->tgtExactPlain) { T.dvaluesCap = ctx->tgtExactPlain + 1; want = ctx->tgtExactPadded; }
-            else {
-                double margin = 1.4;
+            if (ctx->tgtExactPlain) {
+                T.dvaluesCap = ctx->tgtExactPlain + 1; want = ctx->tgtExactPadded;
+                if (mcamd::allocate_buckets(ctx, std::max<uint64_t>(ctx->tgtExactKeys, 1)) != MC_OK) return MC_ERR_NOMEM;
+            } else {
+                // the model against the file: a few batches spread over the file are read and cut now; what they keep over what the model says they
+                // keep corrects the model's totals (locations of a feature cluster in neighbouring targets -- strains of one species: fewer
+                // features per range and longer pieces than independent draws give)
+                const size_t nsample = std::min<size_t>(nbatches, 4);
+                double got[3] = {0, 0, 0}, said[3] = {0, 0, 0};
+                {
+                    std::vector<std::thread> th;
+                    std::vector<std::array<double, 3>> part(nsample, {0, 0, 0});
+                    std::vector<char> okS(nsample, 1);
+                    for (size_t k = 0; k < nsample; ++k)
+                        th.emplace_back([&, k] {
+                            const BatchPlace& B = place[(2 * k + 1) * nbatches / (2 * nsample)];
+                            std::vector<uint8_t> sz(B.nkeys), vals((size_t)B.fileVals * vb + 8);
+                            if (!pread_all(fd, sz.data(), B.nkeys, B.off + (uint64_t)B.nkeys * 4) ||
+                                (B.fileVals && !pread_all(fd, vals.data(), (size_t)B.fileVals * vb, B.off + (uint64_t)B.nkeys * 5))) { okS[k] = 0; return; }
+                            cut_batch_to_target_range(ctx, sz.data(), vals.data(), B.nkeys, targetBytes);
+                            for (uint32_t i = 0; i < B.nkeys; ++i) {
+                                part[k][0] += sz[i] ? 1 : 0; part[k][1] += list_alloc(sz[i], 1); part[k][2] += list_alloc(sz[i], kListAlign);
+                            }
+                        });
+                    for (auto& t : th) t.join();
+                    for (size_t k = 0; k < nsample; ++k) {
+                        if (!okS[k]) return fail(MC_ERR_IO, "truncated " + fname);
+                        const ModelSums& M = model[(2 * k + 1) * nbatches / (2 * nsample)];
+                        for (int j = 0; j < 3; ++j) got[j] += part[k][j];
+                        said[0] += M.keys; said[1] += M.plain; said[2] += M.padded;
+                    }
+                }
+                auto corrected = [&](double total, int j) { return said[j] > 0 ? total * got[j] / said[j] : total; };
+                estKeys = corrected(estKeys, 0); estPlain = corrected(estPlain, 1); estPadded = corrected(estPadded, 2);
+                double margin = 1.15;
                 bool tiny = true;
                 if (const char* e = std::getenv("MC_TARGET_STORE_MARGIN")) { margin = std::atof(e); tiny = false; }   // tests: an estimate that is too small
                 auto roomy = [&](double est, uint64_t all) {
@@ -248,6 +287,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
                 };
                 T.dvaluesCap = roomy(estPlain, head[1]) + 1;
                 want = roomy(estPadded, padded);
+                if (mcamd::allocate_buckets(ctx, std::max<uint64_t>(roomy(estKeys, nkeys), 1)) != MC_OK) return MC_ERR_NOMEM;
             }
         }
         mcamd::announce_store(ctx, want);
@@ -273,6 +313,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     std::vector<uint8_t> ready(nbatches, 0);                  // 1 = in its slab, 2 = the read failed
     std::vector<uint64_t> storedOf(nbatches, 0);
     std::vector<uint64_t> keptOf(nbatches, 0);                // Mode T: the values of the batch that are in this context's target range,
+    std::vector<uint32_t> keysOf(targetCut ? nbatches : 0, 0);
     std::vector<uint64_t> plainOf(targetCut ? nbatches : 0, 0), paddedOf(targetCut ? nbatches : 0, 0);   // what they take in the store (plain / on lines of their own)
     size_t released = 0;                                      // batches whose slab the feeder has given back
     std::atomic<size_t> next{0};
@@ -297,8 +338,9 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
             if (ok && targetCut) {                             // (only this reader touches the batch's entries before ready[b])
                 keptOf[b] = cut_batch_to_target_range(ctx, sizes, vals, B.nkeys, targetBytes);
                 uint64_t pl = 0, pd = 0;
-                for (uint32_t i = 0; i < B.nkeys; ++i) { pl += list_alloc(sizes[i], 1); pd += list_alloc(sizes[i], kListAlign); }
-                plainOf[b] = pl; paddedOf[b] = pd;
+                uint32_t nk = 0;
+                for (uint32_t i = 0; i < B.nkeys; ++i) { pl += list_alloc(sizes[i], 1); pd += list_alloc(sizes[i], kListAlign); nk += sizes[i] ? 1u : 0u; }
+                plainOf[b] = pl; paddedOf[b] = pd; keysOf[b] = nk;
             }
             if (ok) {
                 const uint32_t* k = reinterpret_cast<const uint32_t*>(keys);
@@ -340,7 +382,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     };
     if (!okInit) { const int code = stop(MC_ERR_HIP, "database load: cannot create the copy stream"); cleanup(); return code; }
     uint64_t waitNs = 0, bytesIn = 24;
-    uint64_t exactPlain = 0, exactPadded = 0;                 // Mode T: this range's store, known when the last batch is through
+    uint64_t exactPlain = 0, exactPadded = 0, exactKeys = 0;   // Mode T: this range's store and keys, known when the last batch is through
     bool countOnly = false;
     int rc = MC_OK;
     std::string emsg;
@@ -357,9 +399,11 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
         const uint64_t fileBytes = (uint64_t)B.nkeys * 5 + B.fileVals * vb;
         if (targetCut) {
             B.fileVals = keptOf[b];                            // (the slab keeps the batch's places; its values end earlier)
-            exactPlain += plainOf[b]; exactPadded += paddedOf[b];
+            exactPlain += plainOf[b]; exactPadded += paddedOf[b]; exactKeys += keysOf[b];
             Part& T = ctx->parts[0];
-            if (!countOnly && T.valuesStored + storedOf[b] > T.dvaluesCap) {
+            // (a table for too few keys: twice the load factor it was sized for is where the load is given up)
+            const bool crowded = (double)exactKeys > (double)T.nbuckets * kSlotsPerBucket * std::min(0.9, 2.0 * (double)ctx->loadFactor);
+            if (!countOnly && (T.valuesStored + storedOf[b] > T.dvaluesCap || crowded)) {
                 // the estimate was too small: the rest of the file is only counted (no more device work)
                 countOnly = true;
                 (void)hipStreamSynchronize(copySt);
@@ -419,7 +463,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     for (auto& s : slabs) pool().put(s);
     if (!synced) return fail(MC_ERR_HIP, "database load: table build failed");
     if (countOnly) {
-        ctx->tgtExactPlain = std::max<uint64_t>(exactPlain, 1); ctx->tgtExactPadded = exactPadded; ctx->storeShort = true;
+        ctx->tgtExactPlain = std::max<uint64_t>(exactPlain, 1); ctx->tgtExactPadded = exactPadded; ctx->tgtExactKeys = exactKeys; ctx->storeShort = true;
         return fail(MC_ERR_NOMEM, "database load: the target range holds more locations than estimated (" + std::to_string(exactPlain) + "); load again with the exact size");
     }
     if (stats) { stats[0] = bytesIn; stats[1] = now() - t0; stats[2] = tIndex - t0; stats[3] = waitNs; }

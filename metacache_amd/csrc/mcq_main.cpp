@@ -49,6 +49,8 @@ struct Options {
     std::vector<int32_t> gpus;           // -gpus a,b,...: the resident parts dealt out over these GPUs, per-part candidates gathered over RCCL
     bool shardKeys = false;              // -shard keys: ONE database key-sharded over the GPUs of -gpus (mc_keyset_*: every GPU holds the features it owns, the partial
                                          // location lists travel over RCCL to the GPU that owns the read); -shard parts = the default of -gpus (parts over GPUs)
+    bool shardTargets = false;           // -shard targets: ONE database file cut into contiguous target ranges at load (mc_config.target_shard_*), a range per GPU of -gpus
+    uint32_t targetShards = 0;           // -target-shards n: number of ranges (default: one per GPU of -gpus); with -resident-parts m: m ranges in HBM at a time
     uint32_t keyShards = 0;              // -key-shards n: number of key shards (default: one per GPU of -gpus; more than one per GPU on a single device)
     uint32_t replication = 1;            // -replicate: copies of the table on GPUs 0 .. n-1, the workers are dealt out over them (options.cpp:1155-1163)
     uint32_t refBatchSize = 0;           // -batch-size as given (the reference's batches matter for -cov-percentile)
@@ -135,8 +137,10 @@ Options parse(const std::vector<std::string>& args, Options o)
         else if (a == "-resident-parts") o.residentParts = (uint32_t)std::max(1, std::stoi(need(i)));
         else if (a == "-shard") {
             const std::string v = need(i);
-            if (v == "keys") o.shardKeys = true; else if (v == "parts") o.shardKeys = false; else throw std::runtime_error("-shard parts|keys");
+            o.shardKeys = v == "keys"; o.shardTargets = v == "targets";
+            if (v != "keys" && v != "parts" && v != "targets") throw std::runtime_error("-shard parts|keys|targets");
         }
+        else if (a == "-target-shards") o.targetShards = (uint32_t)std::max(1, std::stoi(need(i)));
         else if (a == "-key-shards") o.keyShards = (uint32_t)std::max(1, std::stoi(need(i)));
         else if (a == "-gpus") {
             std::stringstream ss(need(i));
@@ -419,7 +423,8 @@ struct Session {
             c.max_locations_per_feature = o.maxLocs < 0 ? 0 : (uint32_t)std::max(1, o.maxLocs);
         } else if (o.maxLocs > 1) c.max_locations_per_feature = (uint32_t)o.maxLocs;
         const bool wantKeys = !built && o.shardKeys;
-        const bool wantSet = !built && (o.residentParts > 0 || !o.gpus.empty() || wantKeys);
+        const bool wantTargets = !built && o.shardTargets;
+        const bool wantSet = !built && (o.residentParts > 0 || !o.gpus.empty() || wantKeys || wantTargets);
         if (ctx && db == o.db && std::memcmp(&c, &cfg, sizeof(c)) == 0 && replication == nrep && !wantSet && !partset && !keyset) return;  // same table, same slots: keep it
         close_replicas();
         if (partset) { mc_partset_close(partset); partset = nullptr; }
@@ -433,6 +438,8 @@ struct Session {
             c.num_slots = 1;
             c.slot_max_queries = std::max<uint32_t>(o.batchSize, 1u << 16);
             c.slot_max_chars = std::max<uint32_t>(1u << 24, c.slot_max_queries * 320u);
+            // (-shard targets: the part set's "parts" are the target ranges of the one file, mc_config.target_shard_count)
+            if (wantTargets) c.target_shard_count = o.targetShards ? o.targetShards : (uint32_t)std::max<size_t>(o.gpus.size(), 1);
             if (wantKeys) {
                 if (mc_keyset_open(o.db.c_str(), &c, o.keyShards, o.gpus.empty() ? nullptr : o.gpus.data(), (uint32_t)o.gpus.size(), &keyset) != MC_OK)
                     throw std::runtime_error(mc_keyset_last_error(nullptr));

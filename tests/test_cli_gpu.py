@@ -236,6 +236,25 @@ def test_cli_key_shards_equal_reference(tmp_path, case, shards):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,ranges,resident", [("default", 3, 0), ("pairseq_insert", 2, 1), ("mapped_only_vote", 5, 2), ("two_files", 4, 0), ("hitdiff_percent", 40, 7)])
+def test_cli_target_ranges_equal_reference(tmp_path, case, ranges, resident):
+    """-shard targets (mc_config.target_shard_*: ONE database file cut into contiguous target ranges at load, every range a context of
+    its own, the ranges' candidates merged in range order): the output must be the reference's, line by line.  One GPU: the ranges share
+    it; -resident-parts: that many ranges in HBM at a time."""
+    build.build_library()
+    c = CASES[case]
+    out = tmp_path / "out.txt"
+    cmd = [build.MCQ, "query", "toy32"] + c["files"] + c["args"] + ["-shard", "targets", "-target-shards", str(ranges), "-gpus", "0", "-out", str(out)]
+    if resident:
+        cmd += ["-resident-parts", str(resident)]
+    r = subprocess.run(cmd, cwd=GOLD, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in out.read_text().split("\n") if not _volatile(l) and "threads" not in l]
+    exp = [l for l in c["lines"] if not _volatile(l) and "threads" not in l]
+    assert got == exp
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("resident", [1, 2, 3])
 def test_cli_resident_parts_equal_all_parts_resident(tmp_path, resident):
     """the four-part fixture, `resident` parts in HBM at a time: the same output as with every part in one table"""

@@ -44,7 +44,7 @@ def _run(world: int, tmp_path, extra=()):
 def test_sharded_modes_single_rank(tmp_path):
     res = _run(1, tmp_path, ("--reads", "6000", "--pairs", "1500"))
     assert res["ok"] and res["ranks_seen"] == 1, res
-    assert res["mode_P"] == 0 and res["mode_K"] == 0 and res["keyset"] == 0 and res["partset"] == 0, res
+    assert res["mode_P"] == 0 and res["mode_K"] == 0 and res["mode_T"] == 0 and res["keyset"] == 0 and res["partset"] == 0, res
     assert res["mode_K_wire"] == 4 and res["keyset_rccl"] and res["wire_bytes_per_read"] > 0, res
 
 
@@ -55,5 +55,5 @@ def test_sharded_modes_all_devices(tmp_path):
         pytest.skip("needs two or more GPUs (the driver's multi-GPU node; bench.py --gpus N runs the same job after its timed region)")
     res = _run(n, tmp_path, ("--reads", "6000", "--pairs", "1500"))
     assert res["ok"] and res["ranks_seen"] == n, res
-    assert res["mode_P"] == 0 and res["mode_K"] == 0 and res["keyset"] == 0 and res["partset"] == 0, res
+    assert res["mode_P"] == 0 and res["mode_K"] == 0 and res["mode_T"] == 0 and res["keyset"] == 0 and res["partset"] == 0, res
     assert res["keyset_devices"] == n and res["partset_devices"] == n and res["keyset_rccl"], res

@@ -141,3 +141,76 @@ def test_refusals(golden):
     ps = api.PartSet(golden.db_path("toy32p2"), resident=2, max_candidates=2, single_part=1, target_shard_count=2)
     assert ps.info()["parts"] == 2
     ps.close()
+
+
+def test_target_ranges_at_midscale_filtered_regime():
+    """A 15 Gbp cut of the bench collection (195 locations per 150 bp read: the filtered path's regime) written as ONE database file, then
+    opened as 4 target ranges: singles, pairs and long reads (window ranges up to 171, sorted lists), sequence level and species level,
+    against the single table holding everything -- whose results tests/test_gpu_reference_midscale.py holds against the reference itself
+    on the same collection.  The ranges' tables are sized by what the loader's sample of the file says they hold."""
+    import os
+    import torch
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    name = os.path.join(shm, f"mc_ranges_{os.getpid()}")
+    spec = synthdb.phylogeny(200, 4, 5, 2_500_000, 5_000_000, seed=3100)
+    K = 2
+    n1, n2, n3 = 40_000, 8_000, 600
+    try:
+        db, _ = synthdb.build_database(spec, shards=2, max_candidates=K, write_to=name)
+        assert db.table_layout()["location_bytes"] == 4
+        whole_layout = db.table_layout()
+        nloc = db.n_locations
+        gen = synthdb.GpuSynth(0)
+        P1 = synthdb.read_params(spec, 3100)
+        P2 = synthdb.read_params(spec, 4100, paired=True)
+        a = torch.zeros((n1, P1.row_bytes), dtype=torch.uint8, device="cuda:0")
+        m1 = torch.zeros((n2, P2.row_bytes), dtype=torch.uint8, device="cuda:0")
+        m2 = torch.zeros((n2, P2.row_bytes), dtype=torch.uint8, device="cuda:0")
+        gen.reads(spec, P1, 0, n1, a)
+        gen.reads(spec, P2, 0, n2, m1, m2)
+        Lmax = 19_000
+        rng = np.random.default_rng(5100)
+        lens = np.clip(np.exp(rng.normal(np.log(480.0), 0.95, n3)), 200, Lmax).astype(np.int64)
+        lens[:4] = (Lmax, 12_345, 200, 513)
+        P3 = synthdb.read_params(spec, 5100, read_len=Lmax, sub_rate=0.075)
+        rows = torch.zeros((n3, P3.row_bytes), dtype=torch.uint8, device="cuda:0")
+        gen.reads(spec, P3, 0, n3, rows)
+        torch.cuda.synchronize()
+        singles = [bytes(r[:150]) for r in a.cpu().numpy()]
+        p1 = [bytes(r[:150]) for r in m1.cpu().numpy()]
+        p2 = [bytes(r[:150]) for r in m2.cpu().numpy()]
+        hl = rows.cpu().numpy()
+        longs = [bytes(hl[i, :int(lens[i])]) for i in range(n3)]
+        e1, counts, _ = db.query(singles)
+        assert np.mean(counts > 128) > 0.6, np.percentile(counts, [5, 50, 95])
+        e2 = db.query(p1, p2)[0]
+        e3 = db.query(longs)[0]
+        db.set_lineages(spec.lineages())
+        e4 = db.query(singles[:10_000], lowest=4)[0]
+        e5 = db.query(longs[:200], lowest=4)[0]
+        db.close()
+        del a, m1, m2, rows
+        torch.cuda.empty_cache()
+        # one range by itself: a quarter of the locations in a table for the features that have one there
+        part = api.Database.open(name, max_candidates=K, target_shard_index=2, target_shard_count=4)
+        lay = part.table_layout()
+        lo, hi = part.target_range()
+        assert 0.2 * nloc < part.n_locations < 0.3 * nloc and 0 < lo < hi < len(spec.targets)
+        assert lay["buckets"] < 0.75 * whole_layout["buckets"] and 0.15 < part.n_features / (4.0 * lay["buckets"]) < 0.35
+        part.close()
+        ps = api.PartSet(name, resident=4, max_candidates=K, target_shard_count=4, slot_max_queries=16384, slot_max_chars=16 << 20)
+        g1 = ps.classify(singles)
+        g2 = ps.classify(p1, p2)
+        g3 = ps.classify(longs)
+        g4 = ps.classify(singles[:10_000], lowest=4)
+        g5 = ps.classify(longs[:200], lowest=4)
+        ps.close()
+        _same(g1, e1, "singles")
+        _same(g2, e2, "pairs")
+        _same(g3, e3, "long reads")
+        _same(g4, e4, "singles, species level")
+        _same(g5, e5, "long reads, species level")
+    finally:
+        for e in (".meta", ".cache0"):
+            if os.path.exists(name + e):
+                os.remove(name + e)

@@ -13,6 +13,9 @@ Legs (reference: gpu_hashmap.cu:1253-1292, query_batch.cu:464-527, :638-652 -- t
             RCCL all-gather of the per-part top lists + merge) against the per-part ORACLE lists merged in part order
   mode_K    ONE table key-sharded over the N ranks, 4-byte global window numbers on the wire (classify_key_sharded_device: RCCL
             all-to-all-v, owner-side filter + counting) against the oracle on the whole cut
+  mode_T    ONE database file cut into N contiguous target ranges at load (mc_config.target_shard_*), a range per rank, the unchanged
+            single-table path on every rank, RCCL all-gather of the per-range top lists + merge in range order (classify_partitioned)
+            against the oracle on the whole cut; then rank 0 alone: mc_partset_open(target_shard_count = N) over ALL N devices
   keyset    rank 0 alone: mc_keyset_open over ALL N devices of the node (C++: ncclCommInitAll, one thread per device, ncclSend /
             ncclRecv all-to-all-v) on the cut written as database files, same expectation as mode_K
   partset   rank 0 alone: mc_partset_open over ALL N devices on the 4-part fixture tests/golden/toy32p4 (ncclAllGather + device merge),
@@ -59,7 +62,7 @@ def main():
     ap.add_argument("--reads", type=int, default=20_000)
     ap.add_argument("--pairs", type=int, default=5_000)
     ap.add_argument("--maxcand", type=int, default=2)
-    ap.add_argument("--legs", default="P,K,keyset,partset")
+    ap.add_argument("--legs", default="P,K,T,keyset,partset")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -183,6 +186,54 @@ def main():
         out["wire_bytes_per_read"] = round((4 if numbers_wire else 8) * int(tsent.item()) / (n1 + 2 * n2), 1)
         out["mode_K_s"] = round(time.time() - t0, 1)
 
+    # ---- mode T: one file, a contiguous target range per rank
+    if "T" in legs:
+        t0 = time.time()
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        tname = os.path.join(shm, f"mcselfcheck_t_{os.environ.get('MASTER_PORT', '0')}")
+        try:
+            if rank == 0:
+                dbw, _ = synthdb.build_database(spec, device=local, shards=1, max_candidates=K, max_load_factor=0.3, write_to=tname)
+                dbw.close()
+            dist.barrier()
+            dbt = api.Database.open(tname, device=local, max_candidates=K, target_shard_index=rank, target_shard_count=world)
+            lo, hi = dbt.target_range()
+            bad = 0
+            for idx, (seq, qi, n, nch, mw) in enumerate(((singles, q1, n1, n1 * PAD_LEN, mw1), (pairs, q2, n2, 2 * n2 * PAD_LEN, mw2))):
+                res = dbt.query_device(seq.data_ptr(), qi.data_ptr(), n, nch, max_win_uniform=mw)
+                c = torch.empty((n, K, 4), dtype=torch.int32, device=dev)
+                dbt.copy_results(c.data_ptr(), res.cands, n * K * 16); dbt.synchronize()
+                merged = classify_partitioned(c)                 # RCCL all-gather of the per-range lists + merge in range (= rank) order
+                torch.cuda.synchronize()
+                if rank == 0:
+                    bad += mismatches(merged.cpu().numpy().view(np.uint32), exp["whole"][idx])
+            nloc = torch.tensor([dbt.n_locations], dtype=torch.int64, device=dev)
+            dbt.close()
+            dist.all_reduce(nloc)
+            out["mode_T"] = bad if rank == 0 else None
+            out["mode_T_range_of_rank0"] = [lo, hi]; out["mode_T_locations_all_ranges"] = int(nloc.item())
+            dist.barrier()
+            if rank == 0:
+                # the C++ driver: the ranges as contexts over ALL devices of the node, gathered with ncclAllGather, merged on device 0
+                if world == 1:
+                    os.environ["MC_PARTSET_RCCL"] = "1"
+                devs = list(range(torch.cuda.device_count())) if world > 1 else [local]
+                ps = api.PartSet(tname, resident=len(devs), devices=devs, max_candidates=K, target_shard_count=len(devs), slot_max_queries=8192, slot_max_chars=8192 * 320)
+                g1 = cands_array(ps.classify(sreads), K)
+                g2 = cands_array(ps.classify(areads, breads, insert_max=0), K)
+                ps.close()
+                out["mode_T_partset"] = mismatches(g1, exp["whole"][0]) + mismatches(g2, exp["whole"][1])
+                out["mode_T"] += out["mode_T_partset"]
+        except Exception as e:                                   # noqa: BLE001
+            out["mode_T"] = f"error: {e}"
+        finally:
+            dist.barrier()
+            if rank == 0:
+                for ext in (".meta", ".cache0"):
+                    if os.path.exists(tname + ext):
+                        os.remove(tname + ext)
+        out["mode_T_s"] = round(time.time() - t0, 1)
+
     dist.barrier()
     torch.cuda.synchronize()
     # ---- the C++ drivers over ALL devices of the node, from rank 0's process (the other ranks have released their tables)
@@ -245,7 +296,7 @@ def main():
     ok = True
     if rank == 0:
         out["seconds"] = round(time.time() - t_start, 1)
-        for k in ("mode_P", "mode_K", "keyset", "partset"):
+        for k in ("mode_P", "mode_K", "mode_T", "keyset", "partset"):
             if (k if k in ("keyset", "partset") else k[-1]) in legs:
                 ok = ok and out.get(k) == 0
         out["ok"] = ok
