@@ -273,7 +273,9 @@ int mc_merge_part_candidates(mc_ctx* ctx, const mc_candidate* const* lists, uint
  * HBM at a time -- one context each, part i of a group on devices[i % num_devices] -- and the NEXT group is loaded by a background
  * thread while the reads run against this one.  Per batch the per-part top lists are gathered with ncclAllGather (RCCL; one
  * communicator rank per device, ncclCommInitAll) and merged on devices[0] by mc_merge_part_candidates, together with the list the
- * earlier groups left.  devices == NULL: cfg->device alone.  cfg: as for mc_open_database (slot_max_queries / slot_max_chars = batch size). */
+ * earlier groups left.  devices == NULL: cfg->device alone.  cfg: as for mc_open_database (slot_max_queries / slot_max_chars = batch size).
+ * cfg->target_shard_count > 1: the "parts" are the contiguous target ranges of ONE part file (cfg->single_part, or part 0), cut at load
+ * (mc_config.target_shard_*); everything else -- groups, gather, merge in range order -- is the same. */
 typedef struct mc_partset mc_partset;
 int  mc_partset_open(const char* name, const mc_config* cfg, uint32_t resident_parts, const int32_t* devices, uint32_t num_devices, mc_partset** out);
 void mc_partset_close(mc_partset* ps);
