@@ -32,11 +32,20 @@ int fail(mc_ctx* ctx, int code, const std::string& msg)
 int ensure(mc_ctx* ctx, DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap) return MC_OK;
+    static const bool trace = std::getenv("MC_ALLOC_TRACE") != nullptr;      // allocations of 20 ms and more go to stderr
+    timespec t0{}, t1{}, t2{};
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &t1);
     b.p = nullptr; b.cap = 0;
     size_t want = bytes + bytes / 4 + 256;                 // head-room: fewer re-allocations
     HIP_TRY(ctx, dev_malloc(&b.p, want));
     b.cap = want;
+    if (trace) {
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        const double f = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6, m = (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) / 1e6;
+        if (f + m >= 20.0) std::fprintf(stderr, "mc ensure: %.1f MB: hipFree of the old buffer %.1f ms, hipMalloc %.1f ms\n", want / 1e6, f, m);
+    }
     return MC_OK;
 }
 

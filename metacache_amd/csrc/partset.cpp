@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -56,9 +57,20 @@ struct mc_partset {
     int loaderRc = MC_OK;
     std::string loaderErr;
     size_t maxQ = 0, maxChars = 0;
-    std::vector<uint8_t> hseq; std::vector<uint32_t> hq, hmw;   // host staging of a batch
+    // host staging of a batch, twice, in pinned memory: batch b + 1 is packed while the devices run batch b, the copies in both
+    // directions are asynchronous (pageable memory would make every hipMemcpyAsync a synchronous staged copy)
+    struct HostSlot {
+        uint8_t* seq = nullptr; uint32_t* q = nullptr; uint32_t* mw = nullptr;
+        mc_candidate* prior = nullptr; mc_candidate* out = nullptr;
+        std::vector<hipEvent_t> inDone;   // per device: the slot's input has left the host
+        hipEvent_t outDone = nullptr;     // device 0: the merged lists are in `out`
+        bool inFlight = false;
+        uint64_t chars = 0;               // characters of the batch in `seq`
+        uint64_t first = 0, count = 0;    // the batch whose result `out` will hold
+    } hs[2];
     uint64_t loadNs = 0, waitNs = 0;   // time the loader spent / the queries waited for it
     std::atomic<uint64_t> loadBytes{0}; // bytes of .cache files read by the group loads
+    uint32_t packThreads = 8;          // host threads that copy a batch's characters into the staging buffer (MC_PARTSET_PACK_THREADS)
     bool ranges = false;               // the parts are target ranges of one file (cfg.target_shard_count > 1)
     bool rccl = false;                 // several devices (or MC_PARTSET_RCCL=1: the same calls with a single rank, tests): gather over RCCL
 };
@@ -160,6 +172,8 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     }
     const uint32_t nd = (uint32_t)ps->devices.size();
     ps->slotsPerDev = (ps->resident + nd - 1) / nd;
+    if (const char* e = std::getenv("MC_PARTSET_PACK_THREADS")) ps->packThreads = (uint32_t)std::max(1, std::atoi(e));
+    ps->packThreads = std::min<uint32_t>(ps->packThreads, std::max(1u, std::thread::hardware_concurrency()));
     ps->maxQ = std::max<uint32_t>(cfg->slot_max_queries, 1);
     ps->maxChars = std::max<uint32_t>(cfg->slot_max_chars, 1u << 16);
     // RCCL: one communicator rank per device of this process (ncclCommInitAll).  A single device needs no gather (loading and
@@ -187,6 +201,16 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
              mcamd::dev_malloc((void**)&D.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
         if (ok && d == 0) ok = mcamd::dev_malloc((void**)&D.dprior, listBytes) == hipSuccess && mcamd::dev_malloc((void**)&D.dout, listBytes) == hipSuccess;
     }
+    for (auto& H : ps->hs) {
+        if (!ok) break;
+        ok = hipHostMalloc((void**)&H.seq, ps->maxChars + 64) == hipSuccess && hipHostMalloc((void**)&H.q, ps->maxQ * 16) == hipSuccess &&
+             hipHostMalloc((void**)&H.mw, ps->maxQ * 4) == hipSuccess && hipHostMalloc((void**)&H.prior, listBytes) == hipSuccess &&
+             hipHostMalloc((void**)&H.out, listBytes) == hipSuccess;
+        H.inDone.assign(nd, nullptr);
+        for (uint32_t d = 0; d < nd && ok; ++d)
+            ok = hipSetDevice(ps->devices[d]) == hipSuccess && hipEventCreateWithFlags(&H.inDone[d], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipSetDevice(ps->devices[0]) == hipSuccess && hipEventCreateWithFlags(&H.outDone, hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) { mc_partset_close(ps); return ps_fail(nullptr, MC_ERR_NOMEM, "mc_partset_open: cannot allocate the batch buffers"); }
     std::string err;
     const uint64_t tl = now_ns();
@@ -210,6 +234,12 @@ void mc_partset_close(mc_partset* ps)
         for (void* b : bufs) if (b) (void)hipFree(b);
         if (D.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(D.comm);
         if (D.stream) (void)hipStreamDestroy(D.stream);
+    }
+    for (auto& H : ps->hs) {
+        void* bufs[] = {H.seq, H.q, H.mw, H.prior, H.out};
+        for (void* b : bufs) if (b) (void)hipHostFree(b);
+        for (hipEvent_t e : H.inDone) if (e) (void)hipEventDestroy(e);
+        if (H.outDone) (void)hipEventDestroy(H.outDone);
     }
     delete ps;
     mcamd::big_cache_hold(-1);
@@ -287,32 +317,87 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         if (b.count == 0) return ps_fail(ps, MC_ERR_INVALID, "mc_partset_classify: a read is longer than slot_max_chars");
         batches.push_back(b);
     }
-    std::vector<uint8_t>& hseq = ps->hseq;
-    std::vector<uint32_t>& hq = ps->hq; std::vector<uint32_t>& hmw = ps->hmw;
-    hseq.resize(ps->maxChars + 64); hq.resize(ps->maxQ * 4); hmw.resize(ps->maxQ);
     const uint32_t np = (uint32_t)ps->cur.size();
-    for (const Batch& B : batches) {
+    auto idle = [&](int code, const std::string& msg) {            // an error leaves nothing in flight
+        for (uint32_t d = 0; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
+        for (auto& H : ps->hs) H.inFlight = false;
+        return ps_fail(ps, code, msg);
+    };
+    // the merged lists of a slot's batch -> the caller's array, once device 0 has written them
+    auto collect = [&](mc_partset::HostSlot& H) -> bool {
+        if (!H.inFlight) return true;
+        H.inFlight = false;
+        if (hipEventSynchronize(H.outDone) != hipSuccess) return false;
+        std::memcpy(out + H.first * K, H.out, (size_t)H.count * K * sizeof(mc_candidate));
+        return true;
+    };
+    static const bool trace = std::getenv("MC_PARTSET_TRACE") != nullptr;
+    uint64_t tCollect = 0, tPack = 0, tEnqueue = 0, tGather = 0;
+    // a batch into its slot's pinned buffers: where every read goes (a sequence starts 4-byte aligned), then the characters by a few
+    // threads (one thread packs 60 M reads of 150 bp a second: less than the devices take)
+    auto pack_batch = [&](size_t bi) {
+        const Batch& B = batches[bi];
+        mc_partset::HostSlot& H = ps->hs[bi & 1];
         const uint32_t m = (uint32_t)B.count;
         uint64_t at = 0;
         for (uint32_t j = 0; j < m; ++j) {
             const uint64_t i = B.first + j, l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
-            hq[4 * j] = (uint32_t)at; hq[4 * j + 1] = (uint32_t)l1;
-            if (l1) std::memcpy(hseq.data() + at, seqs + offs[i], l1);
+            H.q[4 * j] = (uint32_t)at; H.q[4 * j + 1] = (uint32_t)l1;
             at += (l1 + 3) / 4 * 4;
-            hq[4 * j + 2] = (uint32_t)at; hq[4 * j + 3] = (uint32_t)l2;
-            if (l2) std::memcpy(hseq.data() + at, seqs2 + offs2[i], l2);
+            H.q[4 * j + 2] = (uint32_t)at; H.q[4 * j + 3] = (uint32_t)l2;
             at += (l2 + 3) / 4 * 4;
-            hmw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ps->stride);   // candidate_structs.hpp:143-145
+            H.mw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ps->stride);   // candidate_structs.hpp:143-145
         }
-        // every device: the batch, then its parts of the group, their top lists side by side in dmine
+        H.chars = at;
+        auto pack = [&](uint32_t j0, uint32_t j1) {
+            for (uint32_t j = j0; j < j1; ++j) {
+                const uint64_t i = B.first + j;
+                if (H.q[4 * j + 1]) std::memcpy(H.seq + H.q[4 * j], seqs + offs[i], H.q[4 * j + 1]);
+                if (H.q[4 * j + 3]) std::memcpy(H.seq + H.q[4 * j + 2], seqs2 + offs2[i], H.q[4 * j + 3]);
+            }
+        };
+        const uint32_t nt = m >= (1u << 15) ? ps->packThreads : 1;
+        if (nt <= 1) pack(0, m);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t t = 1; t < nt; ++t) th.emplace_back(pack, (uint32_t)((uint64_t)m * t / nt), (uint32_t)((uint64_t)m * (t + 1) / nt));
+            pack(0, (uint32_t)((uint64_t)m / nt));
+            for (auto& t : th) t.join();
+        }
+        if (hasPrior) std::memcpy(H.prior, out + B.first * K, (size_t)m * K * sizeof(mc_candidate));
+    };
+    // mc_query_device comes back when a batch's kernels are nearly through (its lists' sizes make a host round trip): batch b + 1 is packed
+    // by a helper thread meanwhile
+    std::thread packer;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{packer};
+    if (!batches.empty()) pack_batch(0);
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
+        const Batch& B = batches[bi];
+        mc_partset::HostSlot& H = ps->hs[bi & 1];
+        const uint64_t tr0 = now_ns();
+        if (packer.joinable()) packer.join();                       // this batch is in its slot
+        const uint64_t tr1 = now_ns();
+        // the OTHER slot is packed next: its last batch (bi - 1) must have left the host on every device, and its result goes to the caller
+        mc_partset::HostSlot& O = ps->hs[(bi + 1) & 1];
+        if (O.inFlight)
+            for (uint32_t d = 0; d < nd; ++d) if (hipEventSynchronize(O.inDone[d]) != hipSuccess) return idle(MC_ERR_HIP, "copy of a batch to the device failed");
+        if (!collect(O)) return idle(MC_ERR_HIP, "copy of the merged candidates failed");
+        const uint64_t tr2 = now_ns();
+        if (bi + 1 < batches.size()) packer = std::thread(pack_batch, bi + 1);
+        const uint32_t m = (uint32_t)B.count;
+        const uint64_t at = H.chars;
+        // every device: the batch, then its parts of the group, their top lists side by side in dmine.  Everything of a device is in
+        // order on its one stream: batch b + 1's input overwrites the device buffers only after batch b's kernels have read them
         std::vector<int> rcs(nd, MC_OK);
         std::vector<std::string> errs(nd);
         auto run_device = [&](uint32_t d) {
             DevState& D = ps->dev[d];
             if (hipSetDevice(D.device) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipSetDevice"; return; }
-            (void)hipMemcpyAsync(D.dseq, hseq.data(), at + 16, hipMemcpyHostToDevice, D.stream);
-            (void)hipMemcpyAsync(D.dqinfo, hq.data(), (size_t)m * 16, hipMemcpyHostToDevice, D.stream);
-            (void)hipMemcpyAsync(D.dmaxwin, hmw.data(), (size_t)m * 4, hipMemcpyHostToDevice, D.stream);
+            (void)hipMemcpyAsync(D.dseq, H.seq, at + 16, hipMemcpyHostToDevice, D.stream);
+            (void)hipMemcpyAsync(D.dqinfo, H.q, (size_t)m * 16, hipMemcpyHostToDevice, D.stream);
+            (void)hipMemcpyAsync(D.dmaxwin, H.mw, (size_t)m * 4, hipMemcpyHostToDevice, D.stream);
+            if (d == 0 && hasPrior) (void)hipMemcpyAsync(D.dprior, H.prior, (size_t)m * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D.stream);
+            (void)hipEventRecord(H.inDone[d], D.stream);
             (void)hipMemsetAsync(D.dmine, 0, ps->slotsPerDev * listBytes, D.stream);     // slots without a part: empty lists (hits = 0)
             uint32_t slot = 0;
             for (uint32_t p = d; p < np; p += nd, ++slot) {
@@ -329,11 +414,8 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
             for (uint32_t d = 0; d < nd; ++d) th.emplace_back(run_device, d);
             for (auto& t : th) t.join();
         }
-        auto idle = [&](int code, const std::string& msg) {            // an error leaves nothing in flight
-            for (uint32_t d = 0; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
-            return ps_fail(ps, code, msg);
-        };
         for (uint32_t d = 0; d < nd; ++d) if (rcs[d]) return idle(rcs[d], errs[d]);
+        const uint64_t tr3 = now_ns();
         // per-rank partial lists gathered over RCCL: every rank's slotsPerDev lists -> dall[rank][slot] on every device
         if (!ps->rccl) {
             (void)hipSetDevice(ps->dev[0].device);
@@ -353,19 +435,26 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         DevState& D0 = ps->dev[0];
         if (hipSetDevice(D0.device) != hipSuccess) return idle(MC_ERR_HIP, "hipSetDevice");
         std::vector<const mc_candidate*> lists;
-        if (hasPrior) {
-            (void)hipMemcpyAsync(D0.dprior, out + B.first * K, (size_t)m * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D0.stream);
-            lists.push_back(D0.dprior);
-        }
+        if (hasPrior) lists.push_back(D0.dprior);
         for (uint32_t p = 0; p < np; ++p)
             lists.push_back(reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(D0.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes));
         int rc = mc_merge_part_candidates(ps->cur[0], lists.data(), (uint32_t)lists.size(), m, lowestRank, D0.dout, D0.stream);
         if (rc) return idle(rc, mc_last_error(ps->cur[0]));
-        if (hipMemcpyAsync(out + B.first * K, D0.dout, (size_t)m * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, D0.stream) != hipSuccess ||
-            hipStreamSynchronize(D0.stream) != hipSuccess)
+        if (hipMemcpyAsync(H.out, D0.dout, (size_t)m * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, D0.stream) != hipSuccess ||
+            hipEventRecord(H.outDone, D0.stream) != hipSuccess)
             return idle(MC_ERR_HIP, "copy of the merged candidates failed");
-        for (uint32_t d = 1; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
+        H.inFlight = true; H.first = B.first; H.count = m;
+        const uint64_t tr4 = now_ns();
+        tPack += tr1 - tr0; tCollect += tr2 - tr1; tEnqueue += tr3 - tr2; tGather += tr4 - tr3;
     }
+    if (trace)
+        std::fprintf(stderr, "mc_partset_classify_resident: %zu batches, %u parts; host ms: waiting for the packer %.2f, collect %.2f, enqueue %.2f, gather+merge %.2f\n",
+                     batches.size(), np, tPack / 1e6, tCollect / 1e6, tEnqueue / 1e6, tGather / 1e6);
+    // the last two batches; then nothing is left in flight (the callers' next call may come from another thread or select another group)
+    const size_t nbt = batches.size();
+    for (size_t k = nbt >= 2 ? nbt - 2 : 0; k < nbt; ++k)
+        if (!collect(ps->hs[k & 1])) return idle(MC_ERR_HIP, "copy of the merged candidates failed");
+    for (uint32_t d = 0; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
     return MC_OK;
 }
 
