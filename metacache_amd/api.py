@@ -539,6 +539,17 @@ class KeySet:
             raise McError(f"mc_keyset_classify: {L.mc_keyset_last_error(self.h).decode()} (rc {rc})")
         return out
 
+    def classify_packed(self, seqs: np.ndarray, offs: np.ndarray, lowest: int = 0, insert_max: int = 0) -> np.ndarray:
+        """single-end reads as one byte array + n + 1 offsets (what mc_keyset_classify takes) -> cand_dtype [n, max_candidates]"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8); offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        out = np.zeros((n, self.cfg.max_candidates), dtype=cand_dtype)
+        L = lib()
+        rc = L.mc_keyset_classify(self.h, seqs.ctypes.data, offs.ctypes.data, None, None, n, lowest, insert_max, out.ctypes.data)
+        if rc != 0:
+            raise McError(f"mc_keyset_classify: {L.mc_keyset_last_error(self.h).decode()} (rc {rc})")
+        return out
+
     def close(self):
         if self.h:
             lib().mc_keyset_close(self.h)

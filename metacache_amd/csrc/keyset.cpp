@@ -58,7 +58,10 @@ struct mc_keyset {
     size_t maxQ = 0, maxChars = 0;
     bool rccl = false;
     uint64_t locations = 0, numbersSent = 0, batches = 0;
-    uint8_t* hseq = nullptr; uint32_t* hq = nullptr; uint32_t* hmw = nullptr;   // pinned staging of a batch (pageable memory: 120 ms per 10^6 reads and shard)
+    // pinned staging of a batch (pageable memory: 120 ms per 10^6 reads and shard), twice: batch b + 1 is packed by a helper thread while
+    // the shards work on batch b (every batch ends with all streams idle: a slot's last batch is long through when it is packed again)
+    struct HostSlot { uint8_t* seq = nullptr; uint32_t* q = nullptr; uint32_t* mw = nullptr; uint64_t chars = 0; } hs[2];
+    uint32_t packThreads = 8;          // threads that copy a batch's characters (MC_KEYSET_PACK_THREADS)
 };
 
 namespace {
@@ -139,9 +142,12 @@ int mc_keyset_open(const char* name, const mc_config* cfg, uint32_t numShards, c
         if (!ok) { R.rc = MC_ERR_NOMEM; R.err = "mc_keyset_open: cannot allocate the batch buffers"; }
     });
     for (KsRank& R : ks->rank) if (R.rc) { const int rc = R.rc; const std::string e = R.err; mc_keyset_close(ks); return ks_fail(nullptr, rc, e); }
-    if (hipHostMalloc((void**)&ks->hseq, ks->maxChars + 64) != hipSuccess || hipHostMalloc((void**)&ks->hq, ks->maxQ * 16) != hipSuccess ||
-        hipHostMalloc((void**)&ks->hmw, ks->maxQ * 4) != hipSuccess)
-        return bail(MC_ERR_NOMEM, "mc_keyset_open: cannot allocate the pinned batch staging");
+    for (auto& H : ks->hs)
+        if (hipHostMalloc((void**)&H.seq, ks->maxChars + 64) != hipSuccess || hipHostMalloc((void**)&H.q, ks->maxQ * 16) != hipSuccess ||
+            hipHostMalloc((void**)&H.mw, ks->maxQ * 4) != hipSuccess)
+            return bail(MC_ERR_NOMEM, "mc_keyset_open: cannot allocate the pinned batch staging");
+    if (const char* e = std::getenv("MC_KEYSET_PACK_THREADS")) ks->packThreads = (uint32_t)std::max(1, std::atoi(e));
+    ks->packThreads = std::min<uint32_t>(ks->packThreads, std::max(1u, std::thread::hardware_concurrency()));
     uint64_t info[8];
     for (KsRank& R : ks->rank) {
         mc_db_info(R.ctx, info); ks->locations += info[7]; ks->stride = (uint32_t)(info[3] ? info[3] : 112);
@@ -168,9 +174,11 @@ void mc_keyset_close(mc_keyset* ks)
         if (R.comm && std::find(destroyed.begin(), destroyed.end(), R.comm) == destroyed.end()) { rccl().CommDestroy(R.comm); destroyed.push_back(R.comm); }
         if (R.stream) (void)hipStreamDestroy(R.stream);
     }
-    if (ks->hseq) (void)hipHostFree(ks->hseq);
-    if (ks->hq) (void)hipHostFree(ks->hq);
-    if (ks->hmw) (void)hipHostFree(ks->hmw);
+    for (auto& H : ks->hs) {
+        if (H.seq) (void)hipHostFree(H.seq);
+        if (H.q) (void)hipHostFree(H.q);
+        if (H.mw) (void)hipHostFree(H.mw);
+    }
     delete ks;
 }
 
@@ -203,22 +211,50 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
         if (b.count == 0) return ks_fail(ks, MC_ERR_INVALID, "mc_keyset_classify: a read is longer than slot_max_chars");
         batches.push_back(b);
     }
-    uint8_t* const hseq = ks->hseq; uint32_t* const hq = ks->hq; uint32_t* const hmw = ks->hmw;
     std::vector<uint32_t> bounds(S + 1);
     Rccl& R = rccl();
-    for (const Batch& B : batches) {
+    // a batch into its slot's pinned buffers: where every read goes (a sequence starts 4-byte aligned), then the characters by a few threads
+    auto pack_batch = [&](size_t bi) {
+        const Batch& B = batches[bi];
+        mc_keyset::HostSlot& H = ks->hs[bi & 1];
         const uint32_t m = (uint32_t)B.count;
         uint64_t at = 0;
         for (uint32_t j = 0; j < m; ++j) {
             const uint64_t i = B.first + j, l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
-            hq[4 * j] = (uint32_t)at; hq[4 * j + 1] = (uint32_t)l1;
-            if (l1) std::memcpy(hseq + at, seqs + offs[i], l1);
+            H.q[4 * j] = (uint32_t)at; H.q[4 * j + 1] = (uint32_t)l1;
             at += (l1 + 3) / 4 * 4;
-            hq[4 * j + 2] = (uint32_t)at; hq[4 * j + 3] = (uint32_t)l2;
-            if (l2) std::memcpy(hseq + at, seqs2 + offs2[i], l2);
+            H.q[4 * j + 2] = (uint32_t)at; H.q[4 * j + 3] = (uint32_t)l2;
             at += (l2 + 3) / 4 * 4;
-            hmw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ks->stride);   // candidate_structs.hpp:143-145
+            H.mw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ks->stride);   // candidate_structs.hpp:143-145
         }
+        H.chars = at;
+        auto pack = [&](uint32_t j0, uint32_t j1) {
+            for (uint32_t j = j0; j < j1; ++j) {
+                const uint64_t i = B.first + j;
+                if (H.q[4 * j + 1]) std::memcpy(H.seq + H.q[4 * j], seqs + offs[i], H.q[4 * j + 1]);
+                if (H.q[4 * j + 3]) std::memcpy(H.seq + H.q[4 * j + 2], seqs2 + offs2[i], H.q[4 * j + 3]);
+            }
+        };
+        const uint32_t nt = m >= (1u << 15) ? ks->packThreads : 1;
+        if (nt <= 1) pack(0, m);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t t = 1; t < nt; ++t) th.emplace_back(pack, (uint32_t)((uint64_t)m * t / nt), (uint32_t)((uint64_t)m * (t + 1) / nt));
+            pack(0, (uint32_t)((uint64_t)m / nt));
+            for (auto& t : th) t.join();
+        }
+    };
+    std::thread packer;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{packer};
+    if (!batches.empty()) pack_batch(0);
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
+        const Batch& B = batches[bi];
+        if (packer.joinable()) packer.join();                       // this batch is in its slot
+        if (bi + 1 < batches.size()) packer = std::thread(pack_batch, bi + 1);   // (the other slot's batch ended with all streams idle)
+        const mc_keyset::HostSlot& H = ks->hs[bi & 1];
+        uint8_t* const hseq = H.seq; uint32_t* const hq = H.q; uint32_t* const hmw = H.mw;
+        const uint32_t m = (uint32_t)B.count;
+        const uint64_t at = H.chars;
         for (uint32_t o = 0; o <= S; ++o) bounds[o] = o < S ? shard_lo(m, o, S) : m;
         // ---- 1. every shard: its features' locations for ALL reads, as numbers
         for_each_rank(ks, [&](uint32_t r) {

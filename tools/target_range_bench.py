@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=250_000)
     ap.add_argument("--resident", type=int, default=0, help="ranges in HBM at a time (0 = all; fewer: range groups, loaded one after the other)")
+    ap.add_argument("--key-shards", type=int, default=0, help="also: the same file as this many key shards through mc_keyset_*")
     ap.add_argument("--skip-whole", action="store_true", help="no run of the whole table through the part set driver")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -109,6 +110,22 @@ def main():
         bad = 0
         for f in (("tgt", "hits", "beg", "end") if ref is not None else ()):
             bad += int((((got[f] != ref[f]) & ((got["hits"] > 0) | (ref["hits"] > 0))).any(axis=1)).sum())
+        if args.key_shards:
+            # mode K through ITS driver on the same file and reads (mc_keyset_*: the shards on the one GPU, the exchange as device copies)
+            ks = api.KeySet(name, shards=args.key_shards, devices=[0], max_candidates=K, slot_max_queries=args.batch, slot_max_chars=args.batch * 160)
+            ks.classify_packed(seqs[:150 * 10_000], offs[:10_001])
+            tk = []
+            for _ in range(3):
+                t1 = time.time()
+                gk = ks.classify_packed(seqs, offs)
+                tk.append(time.time() - t1)
+            ks.close()
+            badk = 0
+            for f in (("tgt", "hits", "beg", "end") if ref is not None else ()):
+                badk += int((((gk[f] != ref[f]) & ((gk["hits"] > 0) | (ref["hits"] > 0))).any(axis=1)).sum())
+            res["key_shards"] = {"shards": args.key_shards, "ms_per_1e6_reads_all_shards": round(min(tk) / args.reads * 1e9, 2), "runs_ms": [round(x * 1e3, 1) for x in tk],
+                                 "reads_with_different_candidates": badk}
+            print(json.dumps(res["key_shards"]), flush=True)
         res["whole_table"] = r1
         res["target_ranges"] = r2
         res["reads_with_different_candidates"] = bad
