@@ -212,27 +212,79 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
         }
     const uint32_t rmOver0 = ctx->cfg.remove_overpopulated, maxLocs0 = ctx->cfg.max_locations_per_feature;
     {
-        std::vector<uint8_t> sz((size_t)std::min<uint64_t>(batch, nkeys));
-        uint64_t off = 24;
-        for (uint64_t done = 0; done < nkeys;) {
-            const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, nkeys - done);
-            if (off + (uint64_t)nb * 5 > fileSize || !pread_all(fd, sz.data(), nb, off + (uint64_t)nb * 4)) return fail(MC_ERR_IO, "truncated " + fname);
-            uint64_t bv = 0;
-            const double mk0 = estKeys, mp0 = estPlain, md0 = estPadded;
-            for (uint32_t i = 0; i < nb; ++i) {
-                bv += sz[i];
-                uint32_t e = sz[i];                                // (the load-time modifiers that look at the size alone: table_build.hip effective_size)
-                if (rmOver0 && e > rmOver0) e = 0;
-                if (maxLocs0 && e > maxLocs0) e = maxLocs0;
-                padded += list_alloc(e, kListAlign);
-                estPlain += pieceEntries[e]; estPadded += piecePadded[e]; estKeys += pieceThere[e];
+        // The places are a chain (a batch's sizes say where the next batch begins): this thread reads the sizes and sums them; what else
+        // is wanted of them -- the padded total, Mode T's model sums -- are functions of the batch's HISTOGRAM of sizes, taken by helper
+        // threads from a ring of buffers (one thread doing both: 0.36 s per 4 x 10^8 keys, 40 % of a 19 GB part's load)
+        uint32_t effOf[256];                                   // (the load-time modifiers that look at the size alone: table_build.hip effective_size)
+        for (uint32_t v = 0; v < 256; ++v) {
+            uint32_t e = v;
+            if (rmOver0 && e > rmOver0) e = 0;
+            if (maxLocs0 && e > maxLocs0) e = maxLocs0;
+            effOf[v] = e;
+        }
+        const size_t expectBatches = (size_t)((nkeys + batch - 1) / std::max<uint64_t>(batch, 1));
+        if (targetCut) model.assign(expectBatches, ModelSums{0, 0, 0});
+        constexpr uint32_t kRing = 8;
+        const size_t bufBytes = (size_t)std::min<uint64_t>(batch, nkeys);
+        std::vector<std::vector<uint8_t>> ring(kRing, std::vector<uint8_t>(bufBytes));
+        struct Slot { int state = 0; uint32_t nb = 0; size_t b = 0; } slot[kRing];   // 0 free, 1 filled, 2 taken
+        std::mutex im; std::condition_variable icv;
+        bool idone = false;
+        struct Sums { uint64_t padded = 0; double keys = 0, plain = 0, pad = 0; };
+        const uint32_t nhelp = 3;
+        std::vector<Sums> sums(nhelp);
+        auto helper = [&](uint32_t id) {
+            for (;;) {
+                uint32_t k = kRing;
+                {
+                    std::unique_lock<std::mutex> l(im);
+                    icv.wait(l, [&] { for (uint32_t i = 0; i < kRing; ++i) if (slot[i].state == 1) { k = i; return true; } return idone; });
+                    if (k == kRing) return;
+                    slot[k].state = 2;
+                }
+                const uint8_t* sz = ring[k].data();
+                const uint32_t nb = slot[k].nb;
+                uint32_t h[4][256] = {};
+                uint32_t i = 0;
+                for (; i + 4 <= nb; i += 4) { ++h[0][sz[i]]; ++h[1][sz[i + 1]]; ++h[2][sz[i + 2]]; ++h[3][sz[i + 3]]; }
+                for (; i < nb; ++i) ++h[0][sz[i]];
+                Sums S;
+                for (uint32_t v = 0; v < 256; ++v) {
+                    const uint64_t c = (uint64_t)h[0][v] + h[1][v] + h[2][v] + h[3][v];
+                    if (!c) continue;
+                    const uint32_t e = effOf[v];
+                    S.padded += c * list_alloc(e, kListAlign);
+                    S.keys += c * pieceThere[e]; S.plain += c * pieceEntries[e]; S.pad += c * piecePadded[e];
+                }
+                if (targetCut) model[slot[k].b] = ModelSums{S.keys, S.plain, S.pad};
+                sums[id].padded += S.padded; sums[id].keys += S.keys; sums[id].plain += S.plain; sums[id].pad += S.pad;
+                { std::lock_guard<std::mutex> l(im); slot[k].state = 0; }
+                icv.notify_all();
             }
-            if (off + (uint64_t)nb * 5 + bv * vb > fileSize) return fail(MC_ERR_IO, "truncated " + fname);
+        };
+        std::vector<std::thread> helpers;
+        for (uint32_t t = 0; t < nhelp; ++t) helpers.emplace_back(helper, t);
+        auto finish = [&] { { std::lock_guard<std::mutex> l(im); idone = true; } icv.notify_all(); for (auto& t : helpers) t.join(); };
+        uint64_t off = 24;
+        size_t bidx = 0;
+        for (uint64_t done = 0; done < nkeys; ++bidx) {
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, nkeys - done);
+            const uint32_t k = (uint32_t)(bidx % kRing);
+            { std::unique_lock<std::mutex> l(im); icv.wait(l, [&] { return slot[k].state == 0; }); }
+            uint8_t* sz = ring[k].data();
+            if (off + (uint64_t)nb * 5 > fileSize || !pread_all(fd, sz, nb, off + (uint64_t)nb * 4)) { finish(); return fail(MC_ERR_IO, "truncated " + fname); }
+            uint64_t bv = 0;
+            for (uint32_t i = 0; i < nb; ++i) bv += sz[i];
+            if (off + (uint64_t)nb * 5 + bv * vb > fileSize) { finish(); return fail(MC_ERR_IO, "truncated " + fname); }
             place.push_back(BatchPlace{off, bv, nb});
-            if (targetCut) model.push_back({estKeys - mk0, estPlain - mp0, estPadded - md0});
+            { std::lock_guard<std::mutex> l(im); slot[k].nb = nb; slot[k].b = bidx; slot[k].state = 1; }
+            icv.notify_all();
             off += (uint64_t)nb * 5 + bv * vb;
             done += nb;
         }
+        finish();
+        for (const Sums& S : sums) { padded += S.padded; estKeys += S.keys; estPlain += S.plain; estPadded += S.pad; }
+        if (targetCut) model.resize(place.size());
     }
     const uint64_t tIndex = now();
     const size_t nbatches = place.size();

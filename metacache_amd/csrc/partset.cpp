@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -85,9 +86,9 @@ void drop(mc_partset* ps) { delete ps; mcamd::big_cache_hold(-1); }   // (mc_par
 
 void close_group(std::vector<mc_ctx*>& g) { for (mc_ctx* c : g) if (c) mc_destroy(c); g.clear(); }
 
-// opens the parts [first, first + count) as one context each, part p on device devices[(p - first) % ndev] -- one thread per DEVICE (its
-// parts one after the other; every load has its reader threads, its own copy stream and its device's PCIe link: dbload.cpp), as the
-// reference reads every part in a thread of its own (database.cpp:203-226)
+// opens the parts [first, first + count) as one context each, part p on device devices[(p - first) % ndev] -- two loading threads per
+// DEVICE (every load has its reader threads, its own copy stream and its device's PCIe link: dbload.cpp), as the reference reads every
+// part in a thread of its own (database.cpp:203-226)
 int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::string& err)
 {
     const uint32_t count = std::min(ps->resident, ps->nparts - first);
@@ -95,23 +96,34 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
     out.assign(count, nullptr);
     std::vector<int> rcs(nd, MC_OK);
     std::vector<std::string> errs(nd);
+    std::mutex errMu;
+    // a device's parts: two at a time (one part's index pass, table allocation and first batches run under the other's copies; more
+    // than two only share the one PCIe link) -- MC_PARTSET_LOADS_PER_DEVICE
+    const uint32_t perDevice = [] { const char* e = std::getenv("MC_PARTSET_LOADS_PER_DEVICE"); return (uint32_t)std::max(1, e ? std::atoi(e) : 2); }();
+    std::vector<std::atomic<uint32_t>> nextOf(nd);
+    for (uint32_t d = 0; d < nd; ++d) nextOf[d] = d;
     auto load_device = [&](uint32_t d) {
-        for (uint32_t i = d; i < count; i += nd) {
+        for (;;) {
+            const uint32_t i = nextOf[d].fetch_add(nd);
+            if (i >= count) return;
+            { std::lock_guard<std::mutex> l(errMu); if (rcs[d] != MC_OK) return; }
             mc_config c = ps->cfg;
             if (ps->ranges) { c.single_part = std::max(ps->cfg.single_part, 0); c.target_shard_index = first + i; c.target_shard_count = ps->nparts; }
             else c.single_part = (int32_t)(first + i);
             c.device = ps->devices[d];
             c.num_slots = 1; c.copy_allhits = 0;
             const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
-            if (rc != MC_OK) { rcs[d] = rc; errs[d] = mc_last_error(nullptr); return; }
+            if (rc != MC_OK) { std::lock_guard<std::mutex> l(errMu); rcs[d] = rc; errs[d] = mc_last_error(nullptr); return; }
             uint64_t st[4] = {0, 0, 0, 0};
             if (mc_load_stats(out[i], st) == MC_OK) ps->loadBytes += st[0];
         }
     };
-    if (std::min(nd, count) <= 1) load_device(0);
-    else {
+    {
         std::vector<std::thread> th;
-        for (uint32_t d = 0; d < std::min(nd, count); ++d) th.emplace_back(load_device, d);
+        for (uint32_t d = 0; d < std::min(nd, count); ++d) {
+            const uint32_t mine = (count - d + nd - 1) / nd;       // parts of the group on this device
+            for (uint32_t k = 0; k < std::min(perDevice, mine); ++k) th.emplace_back(load_device, d);
+        }
         for (auto& t : th) t.join();
     }
     for (uint32_t d = 0; d < nd; ++d)

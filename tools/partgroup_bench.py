@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--resident", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=250_000)
+    ap.add_argument("--env-variants", default="", help="'A=1,B=2;A=3': the part-group run once more per combination of environment switches (MC_LOAD_THREADS, MC_PARTSET_LOADS_PER_DEVICE)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
@@ -114,6 +115,18 @@ def main():
                          "loader_s": round(info["load_s"], 3), "waited_for_loader_s": round(info["wait_s"], 3), "loaded_GB": round(info["load_bytes"] / 1e9, 2),
                          "load_GB_per_s": round(info["load_bytes"] / 1e9 / max(info["load_s"], 1e-9), 2),
                          "ms_per_batch_per_group": round(sum(g["query_s"] for g in per_group) / (groups * nb) * 1e3, 2)}
+        variants = []
+        for combo in filter(None, args.env_variants.split(";")):
+            kv = dict(x.split("=") for x in combo.split(","))
+            os.environ.update(kv)
+            _, rv = run(args.resident)
+            rv["env"] = kv
+            variants.append(rv)
+            print(json.dumps(rv), flush=True)
+            for k in kv:
+                os.environ.pop(k, None)
+        if variants:
+            res["part_groups_by_env"] = variants
         got, r1 = run(args.resident)
         print(json.dumps(r1), flush=True)
         ref, r2 = run(N)
