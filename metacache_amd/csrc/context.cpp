@@ -4,6 +4,7 @@
 #include "devcache.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,7 +33,8 @@ int fail(mc_ctx* ctx, int code, const std::string& msg)
 int ensure(mc_ctx* ctx, DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap) return MC_OK;
-    static const bool trace = std::getenv("MC_ALLOC_TRACE") != nullptr;      // allocations of 20 ms and more go to stderr
+    static const bool trace = std::getenv("MC_ALLOC_TRACE") != nullptr;      // allocations of 20 ms (MC_ALLOC_TRACE=<ms>) and more go to stderr
+    static const double traceMs = [] { const char* e = std::getenv("MC_ALLOC_TRACE"); const double v = e ? std::atof(e) : 0; return v > 1.0 ? v : (e && e[0] == '0' ? 0.0 : 20.0); }();
     timespec t0{}, t1{}, t2{};
     if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
@@ -44,9 +46,23 @@ int ensure(mc_ctx* ctx, DevBuf& b, size_t bytes)
     if (trace) {
         clock_gettime(CLOCK_MONOTONIC, &t2);
         const double f = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6, m = (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) / 1e6;
-        if (f + m >= 20.0) std::fprintf(stderr, "mc ensure: %.1f MB: hipFree of the old buffer %.1f ms, hipMalloc %.1f ms\n", want / 1e6, f, m);
+        if (f + m >= traceMs) std::fprintf(stderr, "mc ensure: %.1f MB: hipFree of the old buffer %.1f ms, hipMalloc %.1f ms\n", want / 1e6, f, m);
     }
     return MC_OK;
+}
+
+// ---- MC_SUBMIT_TRACE=1: where the host spends a slot batch (sums over all threads, printed by mc_destroy) -----------------------
+static const bool g_submitTrace = std::getenv("MC_SUBMIT_TRACE") != nullptr;
+static std::atomic<uint64_t> g_trace[8];   // ns: [0] waiting for a free pipe, [1] enqueueing H2D, [2] query_on_pipe in all, [3] of it inside hipStreamSynchronize,
+                                           //     [4] enqueueing D2H; [5] batches, [6] hipStreamSynchronize calls
+static inline uint64_t trace_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+static hipError_t traced_sync(hipStream_t st)
+{
+    if (!g_submitTrace) return hipStreamSynchronize(st);
+    const uint64_t t0 = trace_now();
+    const hipError_t e = hipStreamSynchronize(st);
+    g_trace[3] += trace_now() - t0; ++g_trace[6];
+    return e;
 }
 
 // ---- timing ------------------------------------------------------------------------------
@@ -150,7 +166,7 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     launch_scan_u32(storeSz, 1, nb, storeOff, nullptr, ctx->bLdScan.p, st);
     uint32_t stored = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&stored, storeOff + nb, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, traced_sync(st));
     if ((rc = allocate_values(ctx))) return rc;
     if (P.valuesStored + stored > P.dvaluesCap) return fail(ctx, MC_ERR_INVALID, "mc_load_batch: more values than announced");
     const GwLayout gwl = P.compact ? GwLayout{ctx->dGwBase, ctx->gwTargets, ctx->gwGap} : GwLayout{};
@@ -162,7 +178,7 @@ int mcamd::load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* 
     else
         launch_table_values(dkeys, dsizes, nb, lf, fileOff, storeOff, dvals, tb, fileVals, P.dvalues + P.valuesStored, st);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(st));                   // staging buffers are reused by the next chunk
+    HIP_TRY(ctx, traced_sync(st));                   // staging buffers are reused by the next chunk
     P.valuesStored += stored;
     P.keysLoaded += nb;
     return MC_OK;
@@ -263,6 +279,9 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
 
 void mc_destroy(mc_ctx* ctx)
 {
+    if (g_submitTrace && ctx && g_trace[5].load())
+        std::fprintf(stderr, "mc submit trace: %llu batches; ms summed over the submitting threads: waiting for a pipe %.1f, H2D enqueue %.1f, query %.1f (of it %.1f in %llu hipStreamSynchronize calls), D2H enqueue %.1f\n",
+                     (unsigned long long)g_trace[5].load(), g_trace[0] / 1e6, g_trace[1] / 1e6, g_trace[2] / 1e6, g_trace[3] / 1e6, (unsigned long long)g_trace[6].load(), g_trace[4] / 1e6);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     // every stream that may still run kernels on the tables: the context's, both pipes', the slots' (callers' own streams: theirs to wait for)
@@ -652,7 +671,7 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
     if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
     uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
     if (!counterCopied) HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, traced_sync(st));
     {   // MC_GW_DIAG=1: the batch's work-list counters on stderr (the classes of the filtered path)
         static const bool diag = [] { const char* e = std::getenv("MC_GW_DIAG"); return e && e[0] == '1'; }();
         if (diag) {
@@ -731,7 +750,7 @@ static int run_wave_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchP
     // how many locations need a segment in HBM
     if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
     HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, traced_sync(st));
     const uint64_t totalHits = *P.hTotal;
     const size_t hb = (size_t)(totalHits + 1) * 8;
     if ((rc = ensure(ctx, P.bHits, hb))) return rc;
@@ -769,6 +788,74 @@ int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int 
     return query_on_pipe(ctx, ctx->pipe0, in, lowestRank, flags, out, streamv ? (hipStream_t)streamv : ctx->stream);
 }
 
+// A pipe's buffers whose sizes follow from the batch's size (n queries, numChars characters) and the table's mean list length alone --
+// everything mc_query_device needs before its first host round trip.  mc_open_database calls this for every slot pipe WHILE the file
+// loads (reserve_slot_pipes): a hipMalloc of memory another process has just given back takes 100-200 ms per 600 MB, and eight pipes
+// growing their pools inside the first batches made the same `mcq query` run take 81 or 390 ms per 10^7 reads.
+struct PipeSizes { uint64_t maxWindows = 0, poolCap = 0, ovfCap = 0; size_t nfeat = 0; };
+static int size_pipe(mc_ctx* ctx, Pipe& P, uint32_t n, uint64_t numChars, bool wantFeatures, bool lanePath, uint64_t locs, uint64_t keys, PipeSizes& out)
+{
+    int rc = MC_OK;
+    const SketchParams sp = ctx->querySketch;
+    const uint32_t K = ctx->cfg.max_candidates;
+    // windows <= chars/stride + 2 per sequence (row 1), so the sketch buffers can be sized without a sync
+    const uint64_t maxWindows = numChars / sp.stride + 4ull * n + 1;
+    if (maxWindows * sp.s > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "batch too large (feature index exceeds 32 bits)");
+    const size_t nfeat = (size_t)maxWindows * sp.s;
+    if ((rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4))) return rc;
+    // (the lane path delivers top candidates only: -allhits and K > 4 go through the wave kernels)
+    if ((wantFeatures || lanePath) && (rc = ensure(ctx, P.bFeatures, nfeat * 4))) return rc;
+    if ((rc = ensure(ctx, P.bPsize, nfeat * 4))) return rc;
+    if ((rc = ensure(ctx, P.bPpay, nfeat * 8))) return rc;
+    if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
+    if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
+    // pool of the filtered location lists (big_filter_kernel -> big_count_kernel): 384 per query on average, at least 4 MB
+    // (tables whose features have few locations each never produce such lists: a token pool; a full pool sends lists to the wave kernel)
+    const Part& T0 = ctx->parts[0];
+    const bool longLists = (double)locs / (double)std::max<uint64_t>(keys, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
+    // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
+    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, numChars * 3) : (uint64_t)n * 8,
+                                                                                  (uint64_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (numChars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
+    // compact store: behind the waves' slices an OVERFLOW region for filtered lists that may not fit their wave's slice (the longest
+    // reads of a batch keep 10^5 numbers): reserved with one atomic per such read (midCount[16..17])
+    const uint64_t ovfCap = T0.compact ? std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20)) : 0;
+    if (lanePath && (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
+    if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * 4 + 64))) return rc;
+    if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)5 * std::max<uint32_t>(n, 1) * 4))) return rc;
+    if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
+    if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
+    if ((rc = ensure(ctx, P.bStats, 64))) return rc;
+    if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
+    out.maxWindows = maxWindows; out.poolCap = poolCap; out.ovfCap = ovfCap; out.nfeat = nfeat;
+    return MC_OK;
+}
+
+// every slot pipe sized for a full slot of reads of the usual length (see size_pipe): called by mc_open_database from a thread of its own
+// once the table is announced; `locs` / `keys`: the part headers' counts
+}  // extern "C" (the loader's helper below has C++ linkage)
+int mcamd::reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys)
+{
+    if (!ctx || ctx->pipes.empty() || ctx->parts.empty()) return MC_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MC_ERR_HIP;
+    const SketchParams sp = ctx->querySketch;
+    const uint32_t K = ctx->cfg.max_candidates, n = ctx->cfg.slot_max_queries;
+    const bool wantAll = ctx->cfg.copy_allhits != 0;
+    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAll && lane_candidates_supported(K);
+    // (a slot of short reads: 152 characters each -- a slot filled with longer reads has fewer of them and grows its buffers as before)
+    const uint64_t chars = std::min<uint64_t>(ctx->cfg.slot_max_chars, (uint64_t)n * 152);
+    for (Pipe* P : ctx->pipes) {
+        PipeSizes sz{};
+        const int rc = size_pipe(ctx, *P, n, chars, false, lanePath, locs, keys, sz);
+        if (rc) return rc;
+    }
+    return MC_OK;
+}
+extern "C" {
+
 static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st)
 {
     // MC_WANT_PARTIAL_HITS: the location lists as they are (unsorted), lane path allowed -- a key shard's side of Mode K; the queries the
@@ -792,41 +879,16 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
     if (rc) return rc;
 
-    // windows <= chars/stride + 2 per sequence (row 1), so the sketch buffers can be sized without a sync
-    const uint64_t maxWindows = in->num_chars / sp.stride + 4ull * n + 1;
-    if (maxWindows * sp.s > 0xFFFFFFF0ull) return fail(ctx, MC_ERR_UNSUPPORTED, "batch too large (feature index exceeds 32 bits)");
-    const size_t nfeat = (size_t)maxWindows * sp.s;
-    if ((rc = ensure(ctx, P.bWinCount, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, P.bWinOff, (size_t)(n + 2) * 4))) return rc;
-    // the lane path delivers top candidates only: -allhits and K > 4 go through the wave kernels
+    // the pipe's buffers that depend on the batch's size alone (size_pipe; mc_open_database reserves them beside the file load)
     const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && (!wantAllhits || wantPartial) && lane_candidates_supported(K);
-    if ((wantFeatures || lanePath) && (rc = ensure(ctx, P.bFeatures, nfeat * 4))) return rc;
-    if ((rc = ensure(ctx, P.bPsize, nfeat * 4))) return rc;
-    if ((rc = ensure(ctx, P.bPpay, nfeat * 8))) return rc;
-    if ((rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat)))) return rc;
-    if ((rc = ensure(ctx, P.bScanIn, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, P.bQflag, (size_t)(n + 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bMid, 128 + (size_t)8 * std::max<uint32_t>(n, 1) * 16))) return rc;
-    // pool of the filtered location lists (big_filter_kernel -> big_count_kernel): 384 per query on average, at least 4 MB
-    // (tables whose features have few locations each never produce such lists: a token pool; a full pool sends lists to the wave kernel)
     const Part& T0 = ctx->parts[0];
     uint64_t locs = 0;
     for (auto& p : ctx->parts) locs += p.locations;
-    const bool longLists = (double)locs / (double)std::max<uint64_t>(T0.keysStored, 1) * 2.0 * sp.s > 64.0;   // mean list of a 2-window read
-    // (448 per 150 bp read = 3 per base: longer reads collect -- and keep -- in proportion)
-    const uint64_t poolCap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(longLists ? std::max<uint64_t>((uint64_t)n * 448, in->num_chars * 3) : (uint64_t)n * 8,
-                                                                                  (uint64_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * std::min<uint64_t>(131072, std::max<uint64_t>(4096, 64 * (in->num_chars / std::max<uint32_t>(n, 1))))));   // per wave: one full batch of gw_filter_kernel (2 112 numbers); long reads keep up to 65 535
-    // compact store: behind the waves' slices an OVERFLOW region for filtered lists that may not fit their wave's slice (the longest
-    // reads of a batch keep 10^5 numbers): reserved with one atomic per such read (midCount[16..17])
-    const uint64_t ovfCap = T0.compact ? std::min<uint64_t>(0xFFFFFFF0ull - poolCap, std::max<uint64_t>(poolCap / 4, 8ull << 20)) : 0;
-    if (lanePath && (rc = ensure(ctx, P.bBigPool, (poolCap + ovfCap) * (T0.compact ? 4 : 8)))) return rc;   // the pool holds the table's location form
-    if (lanePath && (rc = ensure(ctx, P.bSliceFill, (size_t)big_filter_grid(n, T0.compact, ctx->filterBpc) * 4 * 4 + 64))) return rc;
-    if (lanePath && T0.compact && (rc = ensure(ctx, P.bSide, (size_t)5 * std::max<uint32_t>(n, 1) * 4))) return rc;
-    if (lanePath && (rc = ensure(ctx, P.bChunkList, (size_t)(maxWindows + n + 1) * 8))) return rc;
-    if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8))) return rc;
-    if ((rc = ensure(ctx, P.bScan, scan_tmp_bytes(n + 1)))) return rc;
-    if ((rc = ensure(ctx, P.bStats, 64))) return rc;
-    if ((rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate)))) return rc;
+    PipeSizes sz{};
+    if ((rc = size_pipe(ctx, P, n, in->num_chars, wantFeatures, lanePath, locs, T0.keysStored, sz))) return rc;
+    const uint64_t maxWindows = sz.maxWindows, poolCap = sz.poolCap, ovfCap = sz.ovfCap;
+    const size_t nfeat = sz.nfeat;
+    (void)maxWindows;
 
     Workspace ws{};
     ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
@@ -897,7 +959,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
             hcnt = reinterpret_cast<uint32_t*>(P.hTotal + 1);
             launch_flag_count(ws, n, st);
             HIP_TRY(ctx, hipMemcpyAsync(hcnt, ws.midCount, 64, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+            HIP_TRY(ctx, traced_sync(st));
         }
         auto mid_and_hash = [&]() {
             if (hcnt[0]) { ScopedTimer t(ctx, "mid_cands_64", st); launch_mid_cands(0, b, tab, ws, K, taxkey, P.bCands.p, st); }
@@ -1003,7 +1065,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (rc) return rc;
     uint64_t total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, in->hit_offsets + n, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, traced_sync(st));
     const size_t hb = (size_t)(total + 1) * 8;
     if ((rc = ensure(ctx, P.bHits, hb)) || (rc = ensure(ctx, P.bCscr, hb)) || (taxkey && (rc = ensure(ctx, P.bCscr2, hb)))) return rc;
     if ((rc = ensure(ctx, P.bHitOff, (size_t)(n + 2) * 8)) || (rc = ensure(ctx, P.bQstat, (size_t)(n + 1) * sizeof(QueryStat))) ||
@@ -1117,7 +1179,7 @@ int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t n, co
     }
     uint64_t total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, res->hit_offsets + n, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));                    // the one host round trip of the exchange: its split sizes
+    HIP_TRY(ctx, traced_sync(st));                    // the one host round trip of the exchange: its split sizes
     int rc;
     if (P.numbersN == n && P.numbersTotal == total && res->hit_offsets == (const uint64_t*)P.bHitOff.p) {
         // mc_query_device(MC_WANT_PARTIAL_NUMBERS) left the numbers and the counts where they belong
@@ -1199,7 +1261,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
     if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
     HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.hTotal + 10, ws.midCount + 9, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, traced_sync(st));
     ctx->ownerStats[0] += n; ctx->ownerStats[1] += *reinterpret_cast<const uint32_t*>(P.hTotal + 10); ctx->ownerStats[2] += totalIn; ctx->ownerStats[3] += *P.hTotal;
     const size_t hb = (size_t)(*P.hTotal + 1) * 8;
     if ((rc = ensure(ctx, P.bHits, hb)) || (rc = ensure(ctx, P.bCscr, hb)) || (taxkey && (rc = ensure(ctx, P.bCscr2, hb)))) return rc;
@@ -1282,7 +1344,7 @@ int mc_query_wait(mc_ctx* ctx, int flags)
     if (!ctx) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (flags & MC_SECOND_PIPE) ? ctx->pipe1.stream : ctx->stream;
-    if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (st) HIP_TRY(ctx, traced_sync(st));
     return MC_OK;
 }
 
@@ -1382,12 +1444,14 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     // every slot has its own stream and device workspace: batches of different slots overlap on the device (the reference orders
     // submissions with a mutex and overlaps through per-batch CUDA streams, database_query.hpp:110-113, query_batch.cu)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t tt0 = g_submitTrace ? trace_now() : 0;
     {
         std::unique_lock<std::mutex> lk(ctx->pipeMtx);
         ctx->pipeCv.wait(lk, [&] { return !ctx->freePipes.empty(); });
         S.pipe = ctx->freePipes.back();
         ctx->freePipes.pop_back();
     }
+    const uint64_t tt1 = g_submitTrace ? trace_now() : 0;
     struct Giveback {                                           // an error on the way returns the pipe at once
         mc_ctx* c; Slot& s; bool armed = true;
         ~Giveback() { if (armed && s.pipe) { (void)hipStreamSynchronize(s.pipe->stream); std::lock_guard<std::mutex> l(c->pipeMtx); c->freePipes.push_back(s.pipe); s.pipe = nullptr; c->pipeCv.notify_one(); } }
@@ -1403,14 +1467,16 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     mc_device_batch in{S.dseq, S.dqinfo, S.dmaxwin, 0, n, S.nchars};
     mc_device_results res{};
     const int wantAll = ctx->cfg.copy_allhits ? 1 : 0;
+    const uint64_t tt2 = g_submitTrace ? trace_now() : 0;
     int rc = query_on_pipe(ctx, P, &in, lowestRank, wantAll, &res, st);
     if (rc) return rc;
+    const uint64_t tt3 = g_submitTrace ? trace_now() : 0;
     const size_t K = ctx->cfg.max_candidates;
     HIP_TRY(ctx, hipMemcpyAsync(S.hcands, res.cands, (size_t)n * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S.hqstat, P.bQstat.p, (size_t)n * sizeof(QueryStat), hipMemcpyDeviceToHost, st));
     if (wantAll) {
         HIP_TRY(ctx, hipMemcpyAsync(S.hhitoff, res.hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, traced_sync(st));
         const uint64_t total = S.hhitoff[n];
         if (total > S.hhitsCap) {
             if (S.hhits) HIP_TRY(ctx, hipHostFree(S.hhits));
@@ -1421,6 +1487,7 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
         if (total) HIP_TRY(ctx, hipMemcpyAsync(S.hhits, res.hits, total * sizeof(mc_location), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipEventRecord(S.done, st));
+    if (g_submitTrace) { const uint64_t tt4 = trace_now(); g_trace[0] += tt1 - tt0; g_trace[1] += tt2 - tt1; g_trace[2] += tt3 - tt2; g_trace[4] += tt4 - tt3; ++g_trace[5]; }
     S.submitted = true;
     giveback.armed = false;                                     // mc_batch_wait returns the pipe
     return MC_OK;

@@ -10,6 +10,7 @@
 #include <ctime>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 
 using namespace mcamd;
@@ -243,8 +244,17 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
             if (!rc) rc = mc_load_begin(ctx, p, h.nkeys, h.nvalues);
         }
         const double tb1 = now_s();
+        // the slot pipes' workspaces are allocated beside the file load (context.cpp size_pipe: allocations of memory that another process
+        // has just given back take 0.1-0.2 s apiece; inside the first batches they stall every stream)
+        std::thread reserve;
+        if (!rc && cfg.num_slots > 0 && !std::getenv("MC_NO_RESERVE")) {
+            uint64_t locs = 0, keys = 0;
+            for (const auto& P : ctx->parts) { locs += P.expectValues; keys += P.expectKeys; }
+            reserve = std::thread([ctx, locs, keys] { (void)reserve_slot_pipes(ctx, locs, keys); });   // (a failure here is not one: the first batch asks again)
+        }
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
             rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
+        if (reserve.joinable()) reserve.join();
         trBegin += tb1 - tb0; trLoad += now_s() - tb1;
         if (rc && tryCompact && ctx->locRangeViolated && attempt < 2) {
             compactRefused = true;

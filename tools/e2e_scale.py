@@ -22,12 +22,28 @@ import e2e_bench  # noqa: E402
 from metacache_amd import build, synthdb  # noqa: E402
 
 
+def cpu_stat():
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+    except Exception:
+        return {}
+
+
 def timed(cmd, env=None):
     t0 = time.perf_counter()
+    c0 = cpu_stat()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    c1 = cpu_stat()
     if r.returncode != 0:
         raise RuntimeError(" ".join(cmd) + "\n" + r.stderr[-2000:])
-    prof = [l for l in r.stderr.splitlines() if l.startswith("mcq profile")]
+    prof = [l for l in r.stderr.splitlines() if l.startswith("mcq profile") or l.startswith("mc submit trace")]
+    ens = [l for l in r.stderr.splitlines() if l.startswith("mc ensure")]        # (MC_ALLOC_TRACE=1: allocations of 20 ms and more)
+    if ens:
+        import re
+        ms = [sum(float(x) for x in re.findall(r"([0-9.]+) ms", l)) for l in ens]
+        prof.append(f"{len(ens)} workspace allocations traced, {sum(ms):.0f} ms in all; the largest: " + "; ".join(sorted(ens, key=lambda l: -sum(float(x) for x in re.findall(r"([0-9.]+) ms", l)))[:6]))
+    if c0 and c1:
+        prof.append("cgroup: " + ", ".join(f"{k} +{c1[k] - c0[k]}" for k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec") if k in c0))
     return time.perf_counter() - t0, prof
 
 
@@ -38,6 +54,13 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=400_000)
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--key-shards", type=int, default=0, help="also run `mcq query -shard keys -key-shards n` (the database as n key shards on this GPU, mc_keyset_*)")
+    ap.add_argument("--batch-sizes", default="", help="comma list: the three mcq runs once more per -batch-size value (default run: mcq's own 65 536)")
+    ap.add_argument("--pipes", default="", help="comma list: the -no-map and the -tophits run once more per MC_PIPES value (batches in flight on the device; default 8)")
+    ap.add_argument("--repeat-nomap", type=int, default=0, help="the -no-map run this many times back to back, then as often with --sleep seconds before each (is the query phase's rate a property of the process' memory?)")
+    ap.add_argument("--sleep", type=float, default=20.0)
+    ap.add_argument("--profile-nomap", type=int, default=0, help="the -no-map run this many times under rocprofv3 --kernel-trace --stats: the kernels' total time beside the query phase's")
+    ap.add_argument("--repeat-prefix", default="", help="';'-separated command prefixes (e.g. 'taskset -c 0-31;taskset -c 64-95'): the repeated -no-map runs once per prefix")
+    ap.add_argument("--repeat-threads", default="", help="comma list: the repeated -no-map runs once per -threads value instead of pauses")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     build.build_library()
@@ -84,6 +107,52 @@ def main():
             res[name] = {"wall_s": round(wall, 2), "query_ms": ms, "database_load_and_startup_s": round(wall - ms / 1e3, 2),
                          "Mreads_per_min_query_phase": round(q / (ms / 1e3) * 60 / 1e6, 1), "Mreads_per_min_wall": round(q / wall * 60 / 1e6, 1), "profile": prof}
             print(name, res[name], flush=True)
+        for bs in filter(None, args.batch_sizes.split(",")):
+            for name, extra in (("mcq_nomap", ["-no-map"]), ("mcq_map", []), ("mcq_tophits_ids", ["-tophits", "-queryids"])):
+                wall, prof = timed([mcq, "query", db, fa] + extra + ["-batch-size", bs, "-out", o], env=env)
+                q, ms = e2e_bench.speed_of(o)
+                res[f"{name}_batch_{bs}"] = {"wall_s": round(wall, 2), "query_ms": ms, "profile": prof}
+                print(name, bs, res[f"{name}_batch_{bs}"], flush=True)
+        for np_ in filter(None, args.pipes.split(",")):
+            for name, extra in (("mcq_nomap", ["-no-map"]), ("mcq_tophits_ids", ["-tophits", "-queryids"])):
+                wall, prof = timed([mcq, "query", db, fa] + extra + ["-out", o], env=dict(env, MC_PIPES=np_))
+                q, ms = e2e_bench.speed_of(o)
+                res[f"{name}_pipes_{np_}"] = {"wall_s": round(wall, 2), "query_ms": ms, "profile": prof}
+                print(name, "pipes", np_, res[f"{name}_pipes_{np_}"], flush=True)
+        if args.repeat_nomap:
+            runs = []
+            plan = [(0.0, [])] * args.repeat_nomap + [(args.sleep, [])] * args.repeat_nomap
+            if args.repeat_threads:
+                plan = [(0.0, ["-threads", t]) for t in args.repeat_threads.split(",") for _ in range(args.repeat_nomap)]
+            prefixes = [p.split() for p in args.repeat_prefix.split(";")] if args.repeat_prefix else [[]]
+            if args.repeat_prefix:
+                plan = [(0.0, [])] * args.repeat_nomap
+            for prefix in prefixes:
+              for pause, extra in plan:
+                time.sleep(pause)
+                wall, prof = timed(prefix + [mcq, "query", db, fa, "-no-map"] + extra + ["-out", o], env=env)
+                q, ms = e2e_bench.speed_of(o)
+                runs.append({"prefix": " ".join(prefix), "slept_s": pause, "args": extra, "wall_s": round(wall, 2), "query_ms": ms, "profile": prof})
+                print("mcq_nomap again", runs[-1], flush=True)
+            res["mcq_nomap_repeats"] = runs
+        if args.profile_nomap:
+            import csv, glob, shutil
+            runs = []
+            for i in range(args.profile_nomap):
+                pd = os.path.join(shm, f"mc_prof_{os.getpid()}_{i}")
+                wall, prof = timed(["rocprofv3", "--kernel-trace", "--stats", "-d", pd, "-o", "p", "--output-format", "csv", "--", mcq, "query", db, fa, "-no-map", "-out", o],
+                                   env=dict(env, TMPDIR="/tmp"))
+                q, ms = e2e_bench.speed_of(o)
+                kern = {}
+                for fn in glob.glob(os.path.join(pd, "**", "*kernel_stats.csv"), recursive=True):
+                    for row in csv.DictReader(open(fn)):
+                        kern[row["Name"]] = kern.get(row["Name"], 0.0) + float(row["TotalDurationNs"]) / 1e6
+                top = sorted(kern.items(), key=lambda kv: -kv[1])[:8]
+                query_kernels = {k: round(v, 1) for k, v in top if "table_" not in k}
+                runs.append({"wall_s": round(wall, 2), "query_ms": ms, "profile": prof, "kernel_total_ms_top": query_kernels})
+                print("mcq_nomap profiled", runs[-1], flush=True)
+                shutil.rmtree(pd, ignore_errors=True)
+            res["mcq_nomap_profiled"] = runs
         if args.key_shards:
             ks = ["-shard", "keys", "-key-shards", str(args.key_shards), "-batch-size", "1000000"]
             wall, prof = timed([mcq, "query", db, fa, "-no-map"] + ks + ["-out", o], env=env)
