@@ -502,7 +502,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=(1, 2), help="BASELINE.json configs[i]")
-    ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: 5 M for configs[2], 10 M for configs[1])")
+    ap.add_argument("--batch", type=int, default=0, help="reads (pairs) per step per GPU (default: configs[2] 5 M reads, 2.5 M pairs, 250 000 long reads; configs[1] 10 M)")
     ap.add_argument("--scale", type=float, default=1.0, help="configs[2]: fraction of the 2000 genera (quick runs)")
     ap.add_argument("--build-shards", type=int, default=0, help="configs[2]: key-shard passes of the build (0 = by size)")
     ap.add_argument("--shape", default="default", choices=("default", "refseq72k"), help="configs[2]: the collection's shape (refseq72k: 72 000 targets, "
@@ -555,7 +555,7 @@ def main():
     peak = gather_peak(args.gather_gib) if rank == 0 and args.gather_gib > 0 else None
     K = args.maxcand
     cfg = args.config
-    B = args.batch or ((250_000 if args.long_reads else 5_000_000) if cfg == 2 else 10_000_000)
+    B = args.batch or ((250_000 if args.long_reads else 2_500_000 if args.pairs else 5_000_000) if cfg == 2 else 10_000_000)   # (5 M PAIRS ask for 2^32 pool entries per pipe: beyond the device)
     if args.long_reads and (cfg != 2 or args.mode != "R" or args.pairs):
         sys.exit("--long-reads: configs[2] table, mode R, single reads")
     lf = args.load_factor or 0.3                             # configs[2]: 0.5 -> 0.3 is 5.15 -> 4.55 ms of probing per 5 M reads for 10 GB more buckets

@@ -40,7 +40,7 @@ int ensure(mc_ctx* ctx, DevBuf& b, size_t bytes)
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
     if (trace) clock_gettime(CLOCK_MONOTONIC, &t1);
     b.p = nullptr; b.cap = 0;
-    size_t want = bytes + bytes / 4 + 256;                 // head-room: fewer re-allocations
+    size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)512 << 20) + 256;   // head-room: fewer re-allocations (a quarter, at most 512 MB: the pools of a 2.5 M-pair batch are 11 GB each)
     HIP_TRY(ctx, dev_malloc(&b.p, want));
     b.cap = want;
     if (trace) {
