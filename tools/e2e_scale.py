@@ -36,7 +36,7 @@ def timed(cmd, env=None):
     c1 = cpu_stat()
     if r.returncode != 0:
         raise RuntimeError(" ".join(cmd) + "\n" + r.stderr[-2000:])
-    prof = [l for l in r.stderr.splitlines() if l.startswith("mcq profile") or l.startswith("mc submit trace")]
+    prof = [l for l in r.stderr.splitlines() if l.startswith("mcq profile") or l.startswith("mc submit trace") or l.startswith("mc slot warm-up")]
     ens = [l for l in r.stderr.splitlines() if l.startswith("mc ensure")]        # (MC_ALLOC_TRACE=1: allocations of 20 ms and more)
     if ens:
         import re
