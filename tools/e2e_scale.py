@@ -23,10 +23,13 @@ from metacache_amd import build, synthdb  # noqa: E402
 
 
 def cpu_stat():
-    try:
-        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
-    except Exception:
-        return {}
+    out = {}
+    for fn in ("cpu.stat", "memory.stat", "memory.events"):
+        try:
+            out.update({k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/" + fn))})
+        except Exception:
+            pass
+    return out
 
 
 def timed(cmd, env=None):
@@ -43,7 +46,7 @@ def timed(cmd, env=None):
         ms = [sum(float(x) for x in re.findall(r"([0-9.]+) ms", l)) for l in ens]
         prof.append(f"{len(ens)} workspace allocations traced, {sum(ms):.0f} ms in all; the largest: " + "; ".join(sorted(ens, key=lambda l: -sum(float(x) for x in re.findall(r"([0-9.]+) ms", l)))[:6]))
     if c0 and c1:
-        prof.append("cgroup: " + ", ".join(f"{k} +{c1[k] - c0[k]}" for k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec") if k in c0))
+        prof.append("cgroup: " + ", ".join(f"{k} +{c1[k] - c0[k]}" for k in ("usage_usec", "nr_throttled", "pgfault", "pgmajfault", "pgscan", "pgsteal", "high", "max", "oom") if k in c0 and k in c1))
     return time.perf_counter() - t0, prof
 
 
