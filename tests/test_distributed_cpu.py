@@ -137,6 +137,64 @@ def test_mode_p_one_part_per_rank_matches_intended_multipart(golden):
     db.close()
 
 
+def _worker_ranges(rank, world, port, n, K, lowest, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import cpuref
+    from metacache_amd.distributed import classify_partitioned
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gold = os.path.join(here, "golden")
+    z = np.load(os.path.join(gold, "toy_reads.npz"))
+    off = z["single_off"]
+    reads = [z["single"][int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+    db = cpuref.oracle().open(os.path.join(gold, "toy32"))
+    nt = db.n_targets
+    lo, hi = rank * nt // world, (rank + 1) * nt // world      # this rank's contiguous target range
+    local = torch.zeros((n, K, 4), dtype=torch.int32)
+    local[:, :, 0] = -1
+    for i, r in enumerate(reads):
+        # what a context holding only the range's locations answers: the whole table's candidates of the range's targets, in their order
+        # (a candidate never spans two targets, candidate_generation.hpp:96-150), the first K of them
+        _, c = db.query(r, b"", 64, lowest, 0)
+        mine = [x for x in c if lo <= int(x["tgt"]) < hi][:K]
+        for j, x in enumerate(mine):
+            local[i, j] = torch.tensor([int(x["tgt"]), int(x["hits"]), int(x["beg"]), int(x["end"])], dtype=torch.int64).to(torch.int32)
+    merged = classify_partitioned(local)                       # all-gather + merge in rank order = range order
+    if rank == 0:
+        q.put(merged.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mode_t_contiguous_target_ranges_merge_to_the_whole_table(golden):
+    """Mode T (mc_config.target_shard_*; the GPU side: tests/test_gpu_target_ranges.py): rank r answers for a contiguous range of the
+    targets; the ranks' top lists merged in rank order are the whole table's top list (sequence level: the merge this mode rests on)."""
+    import cpuref
+    n, K, world = 300, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ranges, args=(r, world, port, n, K, 0, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, _, _ = golden.reads()
+    db = cpuref.oracle().open(golden.db_path("toy32"))
+    for i in range(n):
+        _, c = db.query(single[i], b"", K, 0, 0)
+        for j in range(K):
+            if j < len(c):
+                assert [int(x) for x in got[i, j].view(np.uint32)] == [int(c[j]["tgt"]), int(c[j]["hits"]), int(c[j]["beg"]), int(c[j]["end"])], (i, j)
+            else:
+                assert got[i, j, 1] == 0
+    db.close()
+
+
 # ---- Mode K: features key-sharded over the ranks, partial location lists exchanged to the read's owner -------------------
 def _worker_mode_k(rank, world, port, n, K, q):
     import sys
