@@ -1597,6 +1597,17 @@ int query_main(Session& S, const Options& init)
 
 int main(int argc, char** argv)
 {
+    // The HIP runtime's "direct dispatch" (the calling thread writes the queue packets itself) made the query phase of this program -- many
+    // worker threads, eight streams -- run at one of two speeds from process to process: hipMemcpyAsync and the kernel launches of a batch
+    // took 0.2 or 3-10 ms (150 Gbp: 81-130 or 300-480 ms per 10^7 reads, the kernels' time the same).  With the runtime's own
+    // submission threads every run is the fast kind.  The runtime reads the switch when it starts, i.e. before main: the program starts
+    // itself again with it set (once; a value the user has set is left alone).
+    if (!std::getenv("AMD_DIRECT_DISPATCH") && !std::getenv("MCQ_NO_REEXEC")) {
+        setenv("AMD_DIRECT_DISPATCH", "0", 0);
+        setenv("MCQ_NO_REEXEC", "1", 1);
+        execv("/proc/self/exe", argv);
+        // (no /proc: go on as we are)
+    }
     try {
         const std::string mode = argc > 1 ? argv[1] : "";
         const std::vector<std::string> args(argv + std::min(argc, 2), argv + argc);
