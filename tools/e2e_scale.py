@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--sleep", type=float, default=20.0)
     ap.add_argument("--profile-nomap", type=int, default=0, help="the -no-map run this many times under rocprofv3 --kernel-trace --stats: the kernels' total time beside the query phase's")
     ap.add_argument("--repeat-prefix", default="", help="';'-separated command prefixes (e.g. 'taskset -c 0-31;taskset -c 64-95'): the repeated -no-map runs once per prefix")
+    ap.add_argument("--repeat-lines", action="store_true", help="the repeated runs write mapping lines (-tophits -queryids) instead of -no-map")
     ap.add_argument("--repeat-extra", default="", help="arguments appended to every repeated run (e.g. '-shard keys -key-shards 4 -batch-size 1000000')")
     ap.add_argument("--repeat-threads", default="", help="comma list: the repeated -no-map runs once per -threads value instead of pauses")
     ap.add_argument("--out", default="")
@@ -134,7 +135,7 @@ def main():
             for prefix in prefixes:
               for pause, extra in plan:
                 time.sleep(pause)
-                wall, prof = timed(prefix + [mcq, "query", db, fa, "-no-map"] + extra + args.repeat_extra.split() + ["-out", o], env=env)
+                wall, prof = timed(prefix + [mcq, "query", db, fa] + (["-tophits", "-queryids"] if args.repeat_lines else ["-no-map"]) + extra + args.repeat_extra.split() + ["-out", o], env=env)
                 q, ms = e2e_bench.speed_of(o)
                 runs.append({"prefix": " ".join(prefix), "slept_s": pause, "args": extra, "wall_s": round(wall, 2), "query_ms": ms, "profile": prof})
                 print("mcq_nomap again", runs[-1], flush=True)
