@@ -68,6 +68,9 @@ KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cand
              "hash_cands_1024": ("hash_cands_kernel<11",), "mid_cands_64": ("mid_cands_kernel",), "mid_cands_128": ("mid_cands_kernel",),
              "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("gw_sort_chunk_kernel", "gw_sort_lists_kernel", "gw_merge_pass_kernel"), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
              "gather_lists": ("gather_lists_kernel",), "owner_entries": ("owner_entries_kernel",), "decode_union": ("decode_union_kernel",)}
+# ... and whole, for the kernels a line may name as its dominant one (profiles/r06*_kernel_stats.csv)
+KERNEL_FULL = {"gw_filter_count": "gw_filter_count_kernel<4u, 14u, false, 4u>", "gw_filter2": "gw_filter2_kernel<4u, 14u>", "gw_filter_stream": "gw_filter_stream_kernel<2u, 17u, 15u, false>",
+               "gw_filter_stream_fine": "gw_filter_stream_kernel<16u, 19u, 17u, true>", "sketch_probe": "sketch_probe_lane_kernel<true>"}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
 # --shape refseq72k: the same 150 Gbp as a collection shaped like a real bacterial RefSeq -- 72 000 targets, most of 0.5 .. 3 Mbp, 3 % of
@@ -156,6 +159,20 @@ def _pmc_rows(kernel_timer_name: str, tag: str):
 
 
 LINE_BYTES = 128.0            # what one read request of the L2's memory side costs against the HBM roofline (profiles/r05_fetch_calibration.md)
+
+
+def pmc_layout_matches(tag: str, layout: dict):
+    """profiles/<tag>_layout.json (scripts/summarize_profile.py: the table layout the PMC passes of that tag ran on, from the bench line of
+    the same command) against the table of THIS run: a request count taken on another layout (lists on lines of their own or not, 4- or
+    8-byte locations) says nothing about this one.  -> (ok, reason)"""
+    fn = os.path.join(ROOT, "profiles", f"{tag}_layout.json")
+    if not os.path.exists(fn):
+        return False, f"profiles/{tag}_layout.json missing: the summary does not say which table layout it saw"
+    rec = json.load(open(fn))
+    for key, mine in (("table_location_bytes", layout["location_bytes"]), ("table_list_align", layout.get("list_align", 1))):
+        if rec.get(key) != mine:
+            return False, f"profiles/{tag}_pmc_summary.csv was taken with {key} = {rec.get(key)}, this table has {mine}"
+    return True, None
 
 
 def measured_traffic(kernel_timer_name: str, tag: str):
@@ -436,6 +453,129 @@ def reference_calibration(scale: float, K: int, lf: float, device: int, budget_s
                 os.remove(name + e)
 
 
+def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, steps, warmup, nb, per_read, kernel_only_s):
+    """SURVEY 8(d) row 1, the host-fed form: the timed region's K batches once more, this time starting in PINNED HOST memory -- the upload
+    of batch i + 1 (mc_copy_results_on kind 2, on the pipe it will run on) under the kernels of batch i on the other pipe, the candidates
+    copied back to pinned host memory (kind 1) inside the clock.  What a host application that parses reads itself can reach at most:
+    never `value`."""
+    dev = qinfo.device
+    srcs = [(long_batches[(warmup + i) % nb] if long_batches is not None else batches[(warmup + i) % nb]) for i in range(steps)]
+    t0 = time.perf_counter()
+    host_in = []
+    for sidx in range(steps):
+        t = srcs[sidx]["seq"] if long_batches is not None else srcs[sidx]
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t)
+        host_in.append(h)
+    nbytes_in = [int(h.numel()) for h in host_in]
+    dev_in = [torch.zeros(max(nbytes_in) + 16, dtype=torch.uint8, device=dev) for _ in range(2)]
+    host_out = [torch.zeros((nloc, K, 4), dtype=torch.int32).pin_memory() for _ in range(2)]
+    torch.cuda.synchronize()
+    stage_s = time.perf_counter() - t0
+    pend = {}
+
+    def finish_pipe(j):
+        if j not in pend:
+            return
+        ptr = pend.pop(j)
+        db.query_finish(second_pipe=bool(j))
+        db.copy_results(host_out[j].data_ptr(), ptr, nloc * K * 16, to_host=True, second_pipe=bool(j))
+
+    def run():
+        db.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            j = i & 1
+            db.copy_results(dev_in[j].data_ptr(), host_in[i].data_ptr(), nbytes_in[i], from_host=True, second_pipe=bool(j))
+            if long_batches is not None:
+                lb = srcs[i]
+                res = db.query_device(dev_in[j].data_ptr(), lb["qinfo"].data_ptr(), nloc, lb["nchars"], max_win_ptr=lb["maxwin"].data_ptr(), second_pipe=bool(j), defer_tail=True)
+            else:
+                res = db.query_device(dev_in[j].data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, second_pipe=bool(j), defer_tail=True)
+            pend[j] = res.cands
+            finish_pipe(j ^ 1)
+        finish_pipe(0); finish_pipe(1)
+        db.synchronize()
+        return time.perf_counter() - t0
+
+    run()                                                    # (first touch of the pinned buffers by the device)
+    el = min(run(), run())
+    up = sum(nbytes_in) / 1e9
+    down = steps * nloc * K * 16 / 1e9
+    # the link alone: the same uploads back to back, nothing else on the device
+    db.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        db.copy_results(dev_in[i & 1].data_ptr(), host_in[i].data_ptr(), nbytes_in[i], from_host=True, second_pipe=bool(i & 1))
+    db.synchronize()
+    link_s = time.perf_counter() - t0
+    # the last batch's candidates as they arrived on the host against the device's own copy
+    last = (steps - 1) & 1
+    ms = el / steps * 1e3
+    ratio = kernel_only_s / (el / steps)
+    out = {"ms_per_step": round(ms, 3), "Mreads_min": round(steps * nloc * per_read / el * 60 / 1e6, 1), "h2d_GBps": round(up / link_s, 1),
+           "h2d_GB_per_step": round(up / steps, 3), "d2h_GB_per_step": round(down / steps, 4), "over_kernel_only": round(ratio, 3),
+           "staging_s": round(stage_s, 1),
+           "what": "the timed region's batches from pinned host memory: H2D of batch i+1 on its pipe under batch i's kernels, candidates D2H to pinned memory, all inside the clock; best of 2"}
+    if ratio < 0.8:
+        h2d_ms = up / steps / (up / link_s) * 1e3
+        out["bound"] = (f"PCIe: the upload alone takes {h2d_ms:.1f} ms per step at {up / link_s:.0f} GB/s" if h2d_ms > 0.8 * ms else
+                        f"neither the link ({h2d_ms:.1f} ms per step) nor the kernels ({kernel_only_s * 1e3:.1f}): the copies and the kernels do not overlap fully")
+    del host_in, dev_in, host_out
+    return out
+
+
+def e2e_leg(scale: float, budget_s: float) -> dict:
+    """end-to-end `mcq query` wall time on database FILES -- tools/e2e_scale.py as its own process once this one has
+    given the device back: the collection written to /dev/shm by the streaming writer, 10^7 reads in a FASTA file, `mcq query -no-map`
+    and `-tophits -queryids`.  File reading, parsing, PCIe, classification and printing included: never `value`."""
+    import shutil
+    import signal
+    import subprocess
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        lim = float("inf") if lim == "max" else float(lim)
+        cur = float(open("/sys/fs/cgroup/memory.current").read().strip())
+    except (OSError, ValueError):
+        lim, cur = float("inf"), 0.0
+    spec_bytes = lambda sc: 150.5e9 * sc / 112 * 16 * 8.2 + 2.0e9          # noqa: E731  (8 bytes per location + keys and sizes; + the FASTA file)
+    note = None
+    for sc in ([scale] + ([0.2] if scale > 0.2 else [])):
+        need = spec_bytes(sc)
+        if need * 1.25 + 30e9 < min(lim - cur, shutil.disk_usage(shm).free):
+            scale = sc
+            break
+        note = f"scale {sc}: {need / 1e9:.0f} GB of files do not fit this box's memory allowance ({(lim - cur) / 1e9:.0f} GB left, {shutil.disk_usage(shm).free / 1e9:.0f} GB of {shm})"
+    else:
+        return {"skipped": note}
+    out = os.path.join(tempfile.gettempdir(), f"mc_e2e_{os.getpid()}.json")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_scale.py"), "--scale", str(scale), "--no-ref", "--runs", "mcq_nomap,mcq_tophits_ids", "--out", out]
+    t0 = time.time()
+    p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True, cwd=ROOT)
+    try:
+        _, err = p.communicate(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)                       # exactly the process group started above
+        p.communicate()
+        for f in os.listdir(shm):
+            if f.startswith(f"mc_e2e_{p.pid}"):
+                os.remove(os.path.join(shm, f))
+        return {"skipped": f"time limit of {budget_s:.0f} s reached", "scale": scale}
+    if p.returncode != 0 or not os.path.exists(out):
+        return {"skipped": f"exit code {p.returncode}: " + (err or b"").decode(errors="replace")[-300:], "scale": scale}
+    r = json.load(open(out))
+    os.remove(out)
+    res = {"scale": scale, "reads": r["reads"], "database_file_GB": round(r["collection"]["database_file_bytes"] / 1e9, 1), "seconds": round(time.time() - t0, 1)}
+    for k in ("mcq_nomap", "mcq_tophits_ids"):
+        if k in r:
+            res[k] = {"query_ms": r[k]["query_ms"], "Mreads_min": r[k]["Mreads_per_min_query_phase"], "database_load_and_startup_s": r[k]["database_load_and_startup_s"],
+                      "wall_s": r[k]["wall_s"]}
+    if note:
+        res["note"] = note
+    return res
+
+
 def run_multi_gpu_selfcheck(world: int, budget_s: float) -> dict:
     """After the timed region: tools/multi_gpu_selfcheck.py as its OWN job over the same N GPUs (its own rendezvous, its own processes, a
     hard time limit: nothing in it can hang or fail this run) -- modes P and K across N real ranks and the C++ mc_keyset / mc_partset
@@ -532,6 +672,12 @@ def main():
     ap.add_argument("--calibrate-scale", type=float, default=0.1, help="configs[2], N = 1: after the run, the same collection at this scale is built, written "
                     "as database files and classified by the REFERENCE (oracle/_ref) and by the port on the same reads: cpu_baseline.reference_calibration "
                     "(0 = skip)")
+    ap.add_argument("--host-fed", type=int, default=1, help="N = 1, mode R: after the timed region the same K batches once more from PINNED HOST memory through the "
+                    "two pipes, H2D of the reads and D2H of the candidates inside the clock (`host_fed` in the line; SURVEY 8d: reads pre-staged in pinned host memory); 0 = skip")
+    ap.add_argument("--e2e-scale", type=float, default=1.0, help="N = 1, default workload: after everything else tools/e2e_scale.py as its own process -- the collection at this "
+                    "scale as database FILES in /dev/shm, 10^7 reads as a FASTA file, `mcq query -no-map` and `-tophits -queryids` (`e2e` in the line); falls back to 0.2 "
+                    "where the box's memory allowance does not hold the full-scale file set; 0 = skip")
+    ap.add_argument("--e2e-seconds", type=float, default=420.0, help="time limit of that process")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -646,7 +792,8 @@ def main():
                        f"{world * args.steps * B * (2 if args.pairs else 1)} synthetic {shape}")
                     + ("" if nb >= args.steps + args.warmup else f" ({world * nb * B * (2 if args.pairs else 1)} distinct, cycled)"))
         # the committed PMC passes (profiles/r04_pmc_summary.csv) ran the default command: full scale, 5 M reads per step, mode R
-        pmc_tag = ("r05" if (not args.pairs and not args.long_reads and B == 5_000_000) else "r05_long" if (args.long_reads and B == 250_000) else "r05_pairs" if (args.pairs and B == 2_500_000) else "r05-none") if (mode == "R" and args.scale == 1.0) else "r05-none"
+        # the committed PMC passes (scripts/profile.sh; profiles/r06*_pmc_summary.csv + _layout.json) ran these commands: full scale, mode R, default batch sizes
+        pmc_tag = ("r06" if (not args.pairs and not args.long_reads and B == 5_000_000) else "r06_long" if (args.long_reads and B == 250_000) else "r06_pairs" if (args.pairs and B == 2_500_000) else "r06-none") if (mode == "R" and args.scale == 1.0) else "r06-none"
     build_s = time.time() - t0
     db_info = db.info()
     for kv in filter(None, args.tune.split(",")):
@@ -704,7 +851,10 @@ def main():
             db.query_wait(second_pipe=bool(j))               # RCCL reads the buffer on torch's stream
             works[j] = gather_candidates_async(out_bufs[j], recv[j] if recv is not None else None, dst=0)
 
+    first_batch = [0]                                        # warm-up takes batches 0 .. W-1, the timed region W .. W+K-1: no timed batch has been through the path before
+
     def step(i: int):
+        i += first_batch[0]
         b = batches[i % nb] if batches else None
         j = i % nbuf
         finish(j)                                            # the gather that used this buffer two batches ago
@@ -754,6 +904,7 @@ def main():
         step(i)
     drain()
     torch.cuda.synchronize()
+    first_batch[0] = args.warmup
     db.timing(True)
     db.timing_reset()
 
@@ -795,6 +946,10 @@ def main():
             db.synchronize()
         db.timing(False)
         kt_solo = {k: db.timing_get(k) for k in KERNELS}
+    host_fed = None
+    if pipelined and world == 1 and args.host_fed and not args.force_dist:
+        host_fed = host_fed_leg(db, batches if not args.long_reads else None, long_batches if args.long_reads else None, qinfo, nloc, nchars, max_win, K, args.steps, args.warmup, nb,
+                                2 if pairs else 1, elapsed / args.steps)
     kstats = None
     if mode == "K" and rank == 0 and world == 1:
         # (the owner-side call resets the shard side's statistics: one more lookup pass for F and H of the line)
@@ -814,16 +969,23 @@ def main():
         F, H = st["features"] / (nloc * per_read), st["locations"] / (nloc * per_read)
         bytes_per_read = algorithmic_bytes_per_read(F, H, K, V)
         if args.long_reads:                                    # SURVEY's formula with the reads' own lengths: ceil(L/4) + ceil(L/8) summed over the last timed batch
-            lb = long_batches[(args.steps - 1) % nb]
+            lb = long_batches[(args.warmup + args.steps - 1) % nb]
             bytes_per_read = float(((lb["lens"] + 3) // 4 + (lb["lens"] + 7) // 8).sum()) / nloc + 12.0 * F + V * H + 16.0 * K
         # the dominant KERNEL: timers that bracket several kernels (the sort's instances and merge passes, compaction + ordering, scans) are not candidates
         dom = max((k for k in kt if k not in MULTI_KERNEL_TIMERS), key=lambda k: kt[k][0])      # (mode K: its own kernels are candidates too)
         dom_ms = kt[dom][0] / max(kt[dom][1], 1)
         achieved = bytes_per_read * nloc * per_read / (dom_ms * 1e-3) / 1e9
-        L_mean = float(long_batches[(args.steps - 1) % nb]["lens"].mean()) if args.long_reads else float(READ_LEN)
+        L_mean = float(long_batches[(args.warmup + args.steps - 1) % nb]["lens"].mean()) if args.long_reads else float(READ_LEN)
         kshare = kernel_bytes_per_read(dom, L_mean, F, H, K, V)
         kbytes = None if kshare is None else kshare * nloc * per_read
+        if cfg == 2 and layout.get("list_align", 1) <= 1 and layout["location_bytes"] == 4:
+            pmc_tag += "_plain"                                # (the passes with MC_LIST_ALIGN=0: lists at arbitrary 4-byte offsets)
         traffic, traffic_src, traffic_detail = measured_traffic(dom, pmc_tag)
+        if traffic is not None:
+            same, why = pmc_layout_matches(pmc_tag, layout)
+            if not same:                                       # a request count of another table layout is not this run's traffic
+                traffic, traffic_src, traffic_detail = None, None, {"refused": why}
+        _, pmc_kernels = _pmc_rows(dom, pmc_tag)
         total_reads = world * args.steps * B * per_read
         value = total_reads / elapsed * 60.0 / 1e6
         result = {
@@ -846,7 +1008,8 @@ def main():
                          "step_frac": round(bytes_per_read * nloc * per_read / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                          # like for like with `traffic`: the dominant kernel's OWN share of the algorithmic bytes (kernel_bytes_per_read)
-                         "kernel_name": "mcamd::" + KERNEL_OF.get(dom, (dom,))[0],
+                         # the kernel's whole name as the rocprofv3 summaries carry it (template arguments and all), where a summary of this workload exists
+                         "kernel_name": "mcamd::" + (sorted(pmc_kernels)[0] if pmc_kernels else KERNEL_FULL.get(dom, KERNEL_OF.get(dom, (dom,))[0])),
                          "kernel_algorithmic_bytes": None if kbytes is None else round(kbytes),
                          "kernel_frac": None if kbytes is None else round(kbytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic_over_kernel_bytes": None if (kbytes is None or traffic is None) else round(traffic / kbytes, 3),
@@ -859,6 +1022,8 @@ def main():
         result["value_range"] = [round(min(vals), 1), round(max(vals), 1)]
         result["repeats_ms_per_step"] = [round(e / args.steps * 1e3, 3) for e in repeats]
         result["config"]["batches_in_flight"] = 2 if pipelined else 1
+        if host_fed is not None:
+            result["host_fed"] = host_fed
         if kt_solo is not None:
             # two batches in flight share the device: the events of the timed region bracket that sharing.  The same kernels one batch at a
             # time (3 steps after the timed region):
@@ -870,7 +1035,7 @@ def main():
             result["roofline"]["step_ms_solo"] = round(sum(sm.values()), 3)
         # second roofline: 64-byte read requests per second of the dominant kernel against the box's measured random-access
         # peak for that kernel's access shape.  Requests per launch: TCC_EA0_RDREQ of the committed PMC pass (same batch size only).
-        req = measured_requests(dom, pmc_tag)
+        req = measured_requests(dom, pmc_tag) if pmc_layout_matches(pmc_tag, layout)[0] else None
         shape = "wave_512B_list" if dom.startswith(("big_", "gw_", "hash_", "mid_")) else \
                 ("quad_64B" if db_info[7] > 2_000_000_000 else "lane_private_64B")
         if peak is not None:
@@ -883,9 +1048,10 @@ def main():
                 ra["requests_per_s"] = None; ra["frac"] = None
             result["roofline"]["random_access"] = ra
         if args.long_reads:
-            tot_bases = sum(long_batches[i % nb]["bases"] for i in range(args.steps))
+            tot_bases = sum(long_batches[(args.warmup + i) % nb]["bases"] for i in range(args.steps))
             result["config"]["Gbases_per_s"] = round(world * tot_bases / elapsed / 1e9, 3)
             result["config"]["mean_read_len"] = round(tot_bases / (args.steps * B), 1)
+        first_batch[0] = 0                                    # the checker legs look at batch 0
         if world == 1 and args.cpu_seconds > 0 and args.long_reads:
             cb, par = cpu_leg_long_reads(spec, db, long_batches[0], K, args.parity_reads, args.cpu_seconds, lambda: (step(0), drain(), db.synchronize()), out_cands)
             result["cpu_baseline"] = cb
@@ -920,7 +1086,7 @@ def main():
     # ---- the sharded forms of the path on THESE N GPUs, checked against the oracle (outside every timing): its own job, rank 0 starts it
     # and the other ranks wait for it at the rendezvous store -- on the host, their GPUs are free for the job's ranks
     if cfg == 2 and mode == "R" and args.selfcheck_seconds > 0 and (world > 1 or args.cpu_seconds > 0):
-        del batches, out_bufs
+        batches = out_bufs = None
         torch.cuda.empty_cache()
         store = dist.distributed_c10d._get_default_store() if dist.is_initialized() else None
         if rank == 0:
@@ -933,6 +1099,11 @@ def main():
                 store.wait(["mc_selfcheck_done"], timedelta(seconds=args.selfcheck_seconds + 120))
             except Exception:                                   # noqa: BLE001
                 pass
+    if rank == 0 and world == 1 and cfg == 2 and mode == "R" and not pairs and not args.long_reads and args.scale == 1.0 and args.shape == "default" \
+            and args.cpu_seconds > 0 and args.e2e_scale > 0:
+        batches = out_bufs = mates = None                       # (the device belongs to the mcq processes now)
+        torch.cuda.empty_cache()
+        result["e2e"] = e2e_leg(args.e2e_scale, args.e2e_seconds)
     # the JSON line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which every rank
     # flushes here, before the barrier and the line, instead of at process exit after it
     import ctypes

@@ -390,7 +390,9 @@ const char* mc_keyset_last_error(const mc_keyset* ks);
  * (kind: 0 = device -> device, 1 = device -> host); mc_synchronize waits for both pipes' streams */
 int mc_copy_results(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
 /* the same on the caller's stream (the one its mc_query_device call ran on; NULL = the context's, or with kind | MC_SECOND_PIPE the
- * second pipe's own stream: results of a mc_query_device(MC_SECOND_PIPE) call that was given no stream) */
+ * second pipe's own stream: results of a mc_query_device(MC_SECOND_PIPE) call that was given no stream).
+ * kind 2 = host -> device: a caller whose reads lie in pinned host memory uploads batch i + 1 on the pipe it will run on while batch i's
+ * kernels run on the other pipe (cudaMemcpyAsync of query_batch's host buffers, query_batch.cu:330-360) */
 int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind, void* stream);
 
 /* tuning / test hook (not needed for normal use): the switches the MC_BIG_MIN / MC_QUAD_LOOKUP / MC_NO_LANE_PATH environment variables

@@ -351,10 +351,10 @@ class Database:
         self._check(L.mc_candidates_from_partial_numbers(self.h, C.byref(h), lowest, C.byref(r), stream or None))
         return r
 
-    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False, stream: int = 0, second_pipe: bool = False):
+    def copy_results(self, dst_ptr: int, src_ptr: int, nbytes: int, to_host: bool = False, stream: int = 0, second_pipe: bool = False, from_host: bool = False):
         L = lib()
         L.mc_copy_results_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
-        self._check(L.mc_copy_results_on(self.h, dst_ptr, src_ptr, nbytes, (1 if to_host else 0) | (8 if second_pipe else 0), stream or None))
+        self._check(L.mc_copy_results_on(self.h, dst_ptr, src_ptr, nbytes, (1 if to_host else 0) | (2 if from_host else 0) | (8 if second_pipe else 0), stream or None))
 
     def load_stats(self) -> dict:
         """how mc_open_database read the database files (mc_load_stats)"""

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
 
 using namespace mcamd;
 
@@ -18,14 +20,15 @@ thread_local std::string g_createError;
 #define HIP_TRY(ctx, expr)                                                                          \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess) {                                                                     \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
-            return MC_ERR_HIP;                                                                      \
-        }                                                                                           \
+        if (e_ != hipSuccess)                                                                       \
+            return fail((ctx), MC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                                                                                           \
     } while (0)
 
+// a helper thread that works on a context beside its owner (reserve_slot_pipes) must not write ctx->err: its failures stay its own
+static thread_local bool t_quietErrors = false;
 int fail(mc_ctx* ctx, int code, const std::string& msg)
 {
+    if (t_quietErrors) return code;
     if (ctx) ctx->err = msg; else g_createError = msg;
     return code;
 }
@@ -102,6 +105,7 @@ void collect_timers(mc_ctx* ctx)
 }  // namespace
 
 void mcamd::set_global_error(const std::string& msg) { g_createError = msg; }
+mcamd::OpenHints& mcamd::open_hints() { static thread_local OpenHints h; return h; }
 
 // The loader knows what the lists would take with every list on a line of its own (kernels.h list_alloc): alignment is switched on where
 // that is wanted ("list_align"), the table has the compact store, and the padded store is affordable.  Before the first chunk.
@@ -110,11 +114,24 @@ void mcamd::announce_store(mc_ctx* ctx, uint64_t paddedEntries)
     Part& T = ctx->parts[0];
     if (T.dvalues || !T.compact || ctx->listAlignWant == 0 || paddedEntries == 0) return;
     const uint64_t plain = T.dvaluesCap;
+    if (ctx->listAlignWant != 1 && paddedEntries > plain + plain / 2 + (1u << 20)) return;
+    // Decision and allocation are ONE step per process: several loads run side by side on a device (a part group loads two parts at a
+    // time while the previous group is still resident), and each would judge the padded store affordable against the same free memory.
+    // A padded store that cannot be had is not an error -- the table falls back to the plain one.
+    static std::mutex decide;
+    std::lock_guard<std::mutex> lk(decide);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return;
-    const bool affordable = (paddedEntries + 4) * 4 + (4ull << 30) < freeB && (ctx->listAlignWant == 1 || paddedEntries <= plain + plain / 2 + (1u << 20));
+    // (inside a part group the other parts of the group still have to fit: only the padding beyond the plain store counts against a
+    // share of what is free: listAlignShare, 1 outside part sets -- partset.cpp sets it through open_hints)
+    const uint64_t extra = paddedEntries > plain ? (paddedEntries - plain) * 4 : 0;
+    const bool affordable = (paddedEntries + 4) * 4 + (4ull << 30) < freeB && extra <= (uint64_t)((double)freeB * ctx->listAlignShare);
     if (!affordable) return;
+    void* p = nullptr;
+    if (big_malloc(&p, (paddedEntries + 1 + 4) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return; }
+    T.dvalues = reinterpret_cast<uint64_t*>(p);
     T.listAlign = kListAlign; T.expectStore = paddedEntries; T.dvaluesCap = paddedEntries + 1;
+    ctx->storesPlaced.fetch_add(1, std::memory_order_release);
 }
 // the bucket table of a single-part context whose mc_load_begin left it open (Mode T), for `nkeys` keys at the context's load factor;
 // nkeys = 0: for all keys the part announced
@@ -138,6 +155,7 @@ int mcamd::allocate_values(mc_ctx* ctx)
     if (T.dvalues) return MC_OK;
     // (+ 4 entries: the filter reads the compact lists 16 bytes at a time, a list's last load may reach 3 entries past its end)
     HIP_TRY(ctx, big_malloc((void**)&T.dvalues, (T.dvaluesCap + 4) * (T.compact ? sizeof(uint32_t) : sizeof(uint64_t))));
+    ctx->storesPlaced.fetch_add(1, std::memory_order_release);
     return MC_OK;
 }
 
@@ -241,6 +259,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->parts.resize(cfg->num_parts);
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1' ? 1 : 0;   // (default: by table size)
+    ctx->listAlignWant = mcamd::open_hints().listAlign; ctx->listAlignShare = mcamd::open_hints().listAlignShare;
     if (const char* e = std::getenv("MC_LIST_ALIGN")) ctx->listAlignWant = e[0] == '1' ? 1 : 0;   // (default: where the padded store is affordable)
     if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
@@ -841,18 +860,27 @@ int mcamd::reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys)
 {
     if (!ctx || ctx->pipes.empty() || ctx->parts.empty()) return MC_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return MC_ERR_HIP;
+    t_quietErrors = true;                                        // (the loader thread owns ctx->err)
+    // The table comes first: a single-part table's location store is allocated when the index pass is through (announce_store /
+    // allocate_values), and on a device the table nearly fills the pipes must not have taken its memory by then.
+    for (;;) {
+        if (ctx->loadSettled.load(std::memory_order_acquire)) break;
+        if (ctx->storesPlaced.load(std::memory_order_acquire) >= ctx->parts.size()) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(500));
+    }
     const SketchParams sp = ctx->querySketch;
     const uint32_t K = ctx->cfg.max_candidates, n = ctx->cfg.slot_max_queries;
     const bool wantAll = ctx->cfg.copy_allhits != 0;
     const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAll && lane_candidates_supported(K);
     // (a slot of short reads: 152 characters each -- a slot filled with longer reads has fewer of them and grows its buffers as before)
     const uint64_t chars = std::min<uint64_t>(ctx->cfg.slot_max_chars, (uint64_t)n * 152);
+    int rc = MC_OK;
     for (Pipe* P : ctx->pipes) {
         PipeSizes sz{};
-        const int rc = size_pipe(ctx, *P, n, chars, false, lanePath, locs, keys, sz);
-        if (rc) return rc;
+        if ((rc = size_pipe(ctx, *P, n, chars, false, lanePath, locs, keys, sz))) break;
     }
-    return MC_OK;
+    t_quietErrors = false;
+    return rc;
 }
 extern "C" {
 
@@ -1354,9 +1382,11 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
 {
     if (!ctx || !dst || !src) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // kind: bit 0 = device -> host (else device -> device); MC_SECOND_PIPE: on the second pipe's stream when no stream is given
-    hipStream_t st = stream ? (hipStream_t)stream : ((kind & MC_SECOND_PIPE) && ctx->pipe1.stream) ? ctx->pipe1.stream : ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, (kind & 1) == 0 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    // kind: bit 0 = device -> host, bit 1 = host -> device (else device -> device); MC_SECOND_PIPE: on the second pipe's stream when no stream is given
+    if ((kind & MC_SECOND_PIPE) && !stream && !ctx->pipe1.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe1.stream, hipStreamNonBlocking));
+    hipStream_t st = stream ? (hipStream_t)stream : (kind & MC_SECOND_PIPE) ? ctx->pipe1.stream : ctx->stream;
+    const hipMemcpyKind how = (kind & 1) ? hipMemcpyDeviceToHost : (kind & 2) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, how, st));
     return MC_OK;
 }
 

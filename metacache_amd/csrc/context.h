@@ -4,6 +4,7 @@
 #include "../../include/metacache_amd.h"
 #include "kernels.h"
 
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -88,6 +89,10 @@ int load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes,
 // list alignment of the compact store (kernels.h list_alloc): a loader that knows the lists' sizes announces what the store takes with
 // every list on lines of its own -- before the first chunk, with which the store is allocated
 void announce_store(mc_ctx* ctx, uint64_t paddedEntries);
+// what the caller of mc_open_database / mc_create on THIS thread knows about the device's other tenants (partset.cpp): list alignment
+// default (-1 / 0 / 1, only where neither MC_LIST_ALIGN nor mc_set_tuning says otherwise) and the share of free memory its padding may take
+struct OpenHints { int listAlign = -1; double listAlignShare = 1.0; };
+OpenHints& open_hints();
 int allocate_values(mc_ctx* ctx);
 int allocate_buckets(mc_ctx* ctx, uint64_t nkeys);
 int reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys);
@@ -157,6 +162,10 @@ struct mc_ctx {
                                            // 256 / 128 / 64 at 15 Gbp (195 locations per read): 3.92 / 3.53 / 3.48 ms per 10^6 reads; at 4.5 Gbp (100): 3.01 / 3.12 / 3.25
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
     int listAlignWant = -1;                // mc_set_tuning "list_align" / MC_LIST_ALIGN: -1 = where the padded store stays below 1.5 x the plain one and fits, 0 / 1
+    std::atomic<uint32_t> storesPlaced{0}; // single-part loads: location stores allocated (reserve_slot_pipes waits for the table before it takes memory)
+    std::atomic<bool> loadSettled{false};  // mc_open_database: the files are through (or the load failed)
+    double listAlignShare = 1.0;           // announce_store: the padding (padded - plain store) may take this share of the device's free memory; the part set driver
+                                           // lowers it to 1 / (parts it still has to place on the device) -- mcamd::open_hints
     int fuseLane = -1;                     // sketching + probing of the lane path in ONE kernel: -1 = where the lookups are quad-cooperative (tables beyond 1 GiB: the
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)

@@ -254,6 +254,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         }
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
             rc = load_part(ctx, p, std::string(name) + ".cache" + std::to_string(firstPart + p), m.targetBytes);
+        ctx->loadSettled.store(true, std::memory_order_release);
         if (reserve.joinable()) reserve.join();
         trBegin += tb1 - tb0; trLoad += now_s() - tb1;
         if (rc && tryCompact && ctx->locRangeViolated && attempt < 2) {

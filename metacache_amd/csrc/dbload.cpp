@@ -288,7 +288,7 @@ int mcamd::load_file_pipelined(mc_ctx* ctx, const std::string& fname, uint32_t t
     }
     const uint64_t tIndex = now();
     const size_t nbatches = place.size();
-    if (nbatches == 0) return MC_OK;
+    if (nbatches == 0) return mcamd::allocate_buckets(ctx, 1);   // (an empty part file: mc_load_begin may have left the bucket table to the loader -- target ranges)
     {
         // (a key shard keeps about 1 / count of the lists: the margin of allocate_table's estimate for the plain store)
         const uint64_t c = std::max<uint32_t>(ctx->cfg.key_shard_count, 1);

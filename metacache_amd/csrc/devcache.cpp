@@ -18,6 +18,7 @@ std::unordered_map<void*, Block> g_live;           // blocks big_malloc handed o
 std::vector<Block> g_kept;
 std::unordered_map<int, size_t> g_keptBytes;       // per device: MC_DEVCACHE_GB is a device's budget
 int g_hold = 0;
+uint64_t g_trims = 0;                               // generation of g_kept: big_free parks a block only into the generation it reserved room in
 
 size_t budget()
 {
@@ -25,7 +26,7 @@ size_t budget()
     return b;
 }
 
-void trim_locked(std::vector<Block>& out) { out.swap(g_kept); g_keptBytes.clear(); }
+void trim_locked(std::vector<Block>& out) { out.swap(g_kept); g_keptBytes.clear(); ++g_trims; }
 
 void release(const std::vector<Block>& blocks)
 {
@@ -78,8 +79,10 @@ hipError_t big_free(void* p)
     if (!p) return hipSuccess;
     Block b{nullptr, 0, 0};
     bool keep = false;
+    uint64_t gen = 0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
+        gen = g_trims;
         auto it = g_live.find(p);
         if (it != g_live.end()) {
             b = it->second;
@@ -96,7 +99,16 @@ hipError_t big_free(void* p)
     if (cur != b.dev) (void)hipSetDevice(b.dev);
     const hipError_t e = hipDeviceSynchronize();
     if (cur != b.dev) (void)hipSetDevice(cur);
-    { std::lock_guard<std::mutex> lk(g_mu); g_kept.push_back(b); }
+    // the lock was dropped for the wait: a trim (a failing allocation, the last holder letting go) may have emptied the cache meanwhile --
+    // then the reservation is gone with it and the block goes back to the device instead of being parked uncounted
+    bool park = false;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        park = g_hold > 0 && g_trims == gen;
+        if (park) g_kept.push_back(b);
+        else if (g_trims == gen) g_keptBytes[b.dev] -= b.bytes;
+    }
+    if (!park) { const hipError_t f = hipFree(p); return e != hipSuccess ? e : f; }
     return e;
 }
 

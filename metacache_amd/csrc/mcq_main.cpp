@@ -812,7 +812,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
             }
             for (auto& m : mine) {
                 const char* p = m.second.data();
-                struct Recycle { std::string& s; std::mutex& mu; std::vector<std::string>& pool; ~Recycle() { s.clear(); std::lock_guard<std::mutex> l(mu); if (pool.size() < 256) pool.push_back(std::move(s)); } } recycle{m.second, outMtx, bufPool};
+                struct Recycle { std::string& s; std::mutex& mu; std::vector<std::string>& pool; ~Recycle() { s.clear(); std::lock_guard<std::mutex> l(mu); if (pool.size() < 64) pool.push_back(std::move(s)); } } recycle{m.second, outMtx, bufPool};
                 uint64_t left = m.second.size(), at = m.first;
                 while (left) {
                     const ssize_t w = ::pwrite(outFd, p, (size_t)std::min<uint64_t>(left, 1ull << 30), (off_t)at);
@@ -845,7 +845,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 }
                 const Batch& B = *Bp;
                 out.s.clear();
-                if (out.s.capacity() == 0) take_buffer(out.s);
+                if (out.s.capacity() < 64) take_buffer(out.s);                     // (a moved-from string keeps its 15-character SSO capacity, never 0)
                 out << B.prefix;
                 size_t q = B.qBeg;
                 while (q < B.qEnd && !failed) {
@@ -978,7 +978,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 }
                 if (!setLastPass) { slot->swap(all); continue; }            // more part groups to come: nothing is printed yet
                 out.s.clear();
-                if (out.s.capacity() == 0) take_buffer(out.s);
+                if (out.s.capacity() < 64) take_buffer(out.s);                     // (a moved-from string keeps its 15-character SSO capacity, never 0)
                 out << B.prefix;
                 for (size_t i = 0; i < n; ++i) {
                     const Meta& m = metas[i];

@@ -112,7 +112,14 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
             else c.single_part = (int32_t)(first + i);
             c.device = ps->devices[d];
             c.num_slots = 1; c.copy_allhits = 0;
+            // list alignment (up to 1.5 x the plain store) is a table's own decision against the device's free memory: with several tenants
+            // per device it would be made against memory the group's later parts need.  Groups that stream (the next one loads beside the
+            // resident one): plain stores; all parts resident: the padding may take its share of what is free.
+            const uint32_t mine = (count - d + nd - 1) / nd, placed = i / nd;
+            mcamd::open_hints().listAlign = ps->resident < ps->nparts ? 0 : -1;
+            mcamd::open_hints().listAlignShare = 1.0 / (double)std::max<uint32_t>(1, mine - std::min(placed, mine - 1));
             const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
+            mcamd::open_hints() = mcamd::OpenHints{};
             if (rc != MC_OK) { std::lock_guard<std::mutex> l(errMu); rcs[d] = rc; errs[d] = mc_last_error(nullptr); return; }
             uint64_t st[4] = {0, 0, 0, 0};
             if (mc_load_stats(out[i], st) == MC_OK) ps->loadBytes += st[0];

@@ -65,4 +65,26 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
         for c in sorted(res[k]):
             v = res[k][c]
             w.writerow([k, c, len(v), f"{sum(v) / len(v):.6g}"])
+
+# 3. which table the passes saw: the bench line of the trace pass (every pass runs the same command) -- bench.py refuses a request count
+# that was taken on another layout (pmc_layout_matches)
+import json
+import subprocess
+line = None
+log = os.path.join(src, "trace.log")
+if os.path.exists(log):
+    for l in open(log, errors="replace"):
+        if l.startswith('{"metric"'):
+            line = json.loads(l)
+if line:
+    rf = line["roofline"]
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        head = None
+    with open(os.path.join(dst, f"{tag}_layout.json"), "w") as f:
+        json.dump({"table_location_bytes": rf["table_location_bytes"], "table_list_align": rf["table_list_align"], "table_list_entries": rf["table_list_entries"],
+                   "workload": line["config"]["workload"], "reads_per_step_per_gpu": line["config"]["reads_per_step_per_gpu"], "pairs": line["config"]["pairs"],
+                   "ms_per_step_under_the_tracer": line["ms_per_step"], "kernel_ms_under_the_tracer": rf["kernel_ms"], "head": head,
+                   "command": "scripts/profile.sh " + tag + " (bench.py --steps 4 --warmup 2 --cpu-seconds 0 --repeats 1 ...)"}, f, indent=1)
 print("wrote", dst)

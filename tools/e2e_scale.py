@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--repeat-lines", action="store_true", help="the repeated runs write mapping lines (-tophits -queryids) instead of -no-map")
     ap.add_argument("--repeat-extra", default="", help="arguments appended to every repeated run (e.g. '-shard keys -key-shards 4 -batch-size 1000000')")
     ap.add_argument("--repeat-threads", default="", help="comma list: the repeated -no-map runs once per -threads value instead of pauses")
+    ap.add_argument("--runs", default="mcq_nomap,mcq_map,mcq_tophits_ids", help="which of the three mcq runs (bench.py's e2e leg: mcq_nomap,mcq_tophits_ids)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     build.build_library()
@@ -107,6 +108,8 @@ def main():
         mcq = build.MCQ
         env = dict(os.environ, MCQ_PROFILE="1")
         for name, extra in (("mcq_nomap", ["-no-map"]), ("mcq_map", []), ("mcq_tophits_ids", ["-tophits", "-queryids"])):
+            if name not in args.runs.split(","):
+                continue
             wall, prof = timed([mcq, "query", db, fa] + extra + ["-out", o], env=env)
             q, ms = e2e_bench.speed_of(o)
             res[name] = {"wall_s": round(wall, 2), "query_ms": ms, "database_load_and_startup_s": round(wall - ms / 1e3, 2),
