@@ -882,6 +882,23 @@ int mcamd::reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys)
     t_quietErrors = false;
     return rc;
 }
+// the same for the context's own two pipes (mc_query_device with and without MC_SECOND_PIPE): the part set driver sizes them for its batches
+// right after a part has loaded -- on the group loader's thread, beside the other parts' loads -- instead of inside the first batches
+int mcamd::reserve_query_pipes(mc_ctx* ctx, uint32_t n, uint64_t chars)
+{
+    if (!ctx || ctx->parts.empty() || !ctx->tableReady) return MC_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MC_ERR_HIP;
+    const SketchParams sp = ctx->querySketch;
+    const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && lane_candidates_supported(ctx->cfg.max_candidates);
+    uint64_t locs = 0;
+    for (auto& p : ctx->parts) locs += p.locations;
+    if (!ctx->pipe1.stream && hipStreamCreateWithFlags(&ctx->pipe1.stream, hipStreamNonBlocking) != hipSuccess) return MC_ERR_HIP;
+    for (Pipe* P : {&ctx->pipe0, &ctx->pipe1}) {
+        PipeSizes sz{};
+        if (const int rc = size_pipe(ctx, *P, n, chars, false, lanePath, locs, ctx->parts[0].keysStored, sz)) return rc;
+    }
+    return MC_OK;
+}
 extern "C" {
 
 static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, hipStream_t st)

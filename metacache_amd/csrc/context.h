@@ -96,6 +96,7 @@ OpenHints& open_hints();
 int allocate_values(mc_ctx* ctx);
 int allocate_buckets(mc_ctx* ctx, uint64_t nkeys);
 int reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys);
+int reserve_query_pipes(mc_ctx* ctx, uint32_t n, uint64_t chars);
 int load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals, uint64_t stored);
 // dbload.cpp: a whole .cache file of a single-part context through reader threads, pinned slabs and a copy stream (between mc_load_begin
 // and mc_load_end).  stats (may be NULL): bytes read, nanoseconds in all, of the index pass, the feeder waited for readers

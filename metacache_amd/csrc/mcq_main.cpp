@@ -968,13 +968,15 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 else all.assign(n * K, mc_candidate{});
                 if (all.size() != n * K) { fail("internal: a batch changed between two part groups"); break; }
                 seq1.push_back('\0'); seq2.push_back('\0');
-                if (n) {
-                    std::lock_guard<std::mutex> l(ksMtx);
-                    if (S.keyset) {
-                        if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
-                                               o.insertMax, all.data()) != MC_OK) { fail(mc_keyset_last_error(S.keyset)); break; }
-                    } else if (mc_partset_classify_resident(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n,
-                                                            o.lowest, o.insertMax, setHasPrior ? 1 : 0, all.data()) != MC_OK) { fail(mc_partset_last_error(S.partset)); break; }
+                if (n && S.keyset) {
+                    std::lock_guard<std::mutex> l(ksMtx);                  // (the key set takes one call at a time)
+                    if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
+                                           o.insertMax, all.data()) != MC_OK) { fail(mc_keyset_last_error(S.keyset)); break; }
+                } else if (n) {
+                    // (the part set shares its two device lanes among the callers: this worker's batch runs beside another worker's,
+                    // its upload under the other's kernels)
+                    if (mc_partset_classify_resident(S.partset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n,
+                                                     o.lowest, o.insertMax, setHasPrior ? 1 : 0, all.data()) != MC_OK) { fail(mc_partset_last_error(S.partset)); break; }
                 }
                 if (!setLastPass) { slot->swap(all); continue; }            // more part groups to come: nothing is printed yet
                 out.s.clear();

@@ -6,11 +6,21 @@
 // fit the node (docs/partitioning.md:116-153: `query` one part at a time, `merge` the result files, mode_merge.cpp:247-296).
 // Here: `resident` parts are in HBM at a time, one context each (mc_open_database with single_part), dealt out round-robin over the
 // devices; while the reads run against group g a loader thread opens the parts of group g + 1 (their H2D copies and insert kernels
-// run on those contexts' own streams: two table slots, copy behind compute).  Per batch every device queries its parts, the
-// per-part top lists are gathered on device 0 with ncclAllGather (RCCL, one communicator rank per device; over xGMI between GPUs)
-// and merged IN PART ORDER by merge_parts_kernel -- the CPU's list insert, candidate_generation.hpp:172-231 -- together with the
-// list the earlier groups left for the read.  The result is what one candidate list fed by all parts in order holds: the intended
-// semantics of host_hashmap.hpp:695-723 (the in-process reference itself is history dependent for more than one part).
+// run on those contexts' own streams: two table slots, copy behind compute).  Per batch every device queries its parts; the reads
+// are dealt out to the devices as OWNERS (read i of a batch of m belongs to device i * owners / m), every device sends every owner
+// its parts' top lists of that owner's reads (one grouped ncclSend / ncclRecv round: RCCL, one communicator rank per device, xGMI
+// between GPUs -- 1 / owners of what an all-gather moves) and every owner merges its reads' lists IN PART ORDER (merge_parts_kernel
+// -- the CPU's list insert, candidate_generation.hpp:172-231 -- behind the list the earlier groups left for the read) and copies its
+// share to the host: the reference forwards the running top candidates GPU -> GPU (query_batch.cu:638-652); here the merge is spread
+// over the devices instead of chained through them.  The result is what one candidate list fed by all parts in order holds: the
+// intended semantics of host_hashmap.hpp:695-723 (the in-process reference itself is history dependent for more than one part,
+// SURVEY 8a row 8).
+//
+// Two batches are in flight (round 6): a batch takes one of four pinned STAGING slots on the host and one of two LANES on the devices
+// (a lane = per device a stream, the batch's input, the parts' lists, the exchanged lists -- and pipe 0 / 1 of every part's context).
+// Its upload and main kernels are enqueued without any host synchronisation (mc_query_device MC_DEFER_TAIL); what needs the host --
+// the tails of the parts' queries, exchange, merge, copy back -- is enqueued one batch later, when the next batch's upload and kernels
+// are already queued behind it on the other lane.  Callers may be several threads (mcq's workers: a batch each): they share the lanes.
 //
 // RCCL is loaded at run time (rccl_dl.h).
 #include "context.h"
@@ -19,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,14 +44,20 @@ namespace {
 
 Rccl& g_rccl = rccl();                 // rccl_dl.h
 
-struct DevState {                      // per device: the batch's input, the parts' candidate lists, the gathered lists
-    int device = 0;
+constexpr uint32_t kLanes = 2, kStaging = 4;
+
+struct DevLane {                       // one device's side of a lane
     hipStream_t stream = nullptr;
     uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;
-    mc_candidate* dmine = nullptr;     // [slotsPerDev][maxQ][K]: this device's parts of the resident group
-    mc_candidate* dall = nullptr;      // [ndev][slotsPerDev][maxQ][K]: everybody's (device 0 merges)
-    mc_candidate* dprior = nullptr, *dout = nullptr;   // device 0: the earlier groups' list of the batch's reads, the merged one
+    mc_candidate* dmine = nullptr;     // [slotsPerDev][maxQ][K]: this device's parts of the resident group, all reads of the batch
+    mc_candidate* dall = nullptr;      // [ndev][slotsPerDev][maxQ][K]: every part's lists of the reads this device OWNS (rows 0 .. its share)
+    mc_candidate* dprior = nullptr, *dout = nullptr;   // the earlier groups' list of the owned reads, the merged one
+    std::vector<const mc_candidate*> cands;              // [slot]: where the part's context leaves the batch's top lists (its pipe's result buffer)
+};
+struct DevState {
+    int device = 0;
     void* comm = nullptr;
+    DevLane lane[kLanes];
 };
 
 }  // namespace
@@ -58,27 +75,37 @@ struct mc_partset {
     int loaderRc = MC_OK;
     std::string loaderErr;
     size_t maxQ = 0, maxChars = 0;
-    // host staging of a batch, twice, in pinned memory: batch b + 1 is packed while the devices run batch b, the copies in both
-    // directions are asynchronous (pageable memory would make every hipMemcpyAsync a synchronous staged copy)
-    struct HostSlot {
+    // host staging of a batch in pinned memory (pageable memory would make every hipMemcpyAsync a synchronous staged copy): a batch is
+    // packed into a free slot while earlier ones are on the devices, its merged lists come back into the same slot
+    struct Staging {
         uint8_t* seq = nullptr; uint32_t* q = nullptr; uint32_t* mw = nullptr;
         mc_candidate* prior = nullptr; mc_candidate* out = nullptr;
-        std::vector<hipEvent_t> inDone;   // per device: the slot's input has left the host
-        hipEvent_t outDone = nullptr;     // device 0: the merged lists are in `out`
-        bool inFlight = false;
+        std::vector<hipEvent_t> outDone;  // per device: the owner's share of the merged lists is in `out`
         uint64_t chars = 0;               // characters of the batch in `seq`
-        uint64_t first = 0, count = 0;    // the batch whose result `out` will hold
-    } hs[2];
+        uint32_t count = 0, owners = 0;   // reads of the batch, devices that own a share of them
+        bool hasPrior = false;
+        bool busy = false;
+    } stg[kStaging];
+    bool laneBusy[kLanes] = {false, false};
+    std::mutex poolMu;                 // staging slots and lanes
+    std::condition_variable poolCv;
+    std::mutex orderMu;                // the exchange's RCCL calls: one group at a time, the same order on every device
     uint64_t loadNs = 0, waitNs = 0;   // time the loader spent / the queries waited for it
     std::atomic<uint64_t> loadBytes{0}; // bytes of .cache files read by the group loads
     uint32_t packThreads = 8;          // host threads that copy a batch's characters into the staging buffer (MC_PARTSET_PACK_THREADS)
     bool ranges = false;               // the parts are target ranges of one file (cfg.target_shard_count > 1)
-    bool rccl = false;                 // several devices (or MC_PARTSET_RCCL=1: the same calls with a single rank, tests): gather over RCCL
+    bool rccl = false;                 // several devices (or MC_PARTSET_RCCL=1: the same calls with a single rank, tests): exchange over RCCL
 };
 
 namespace {
 
-int ps_fail(mc_partset* ps, int code, const std::string& msg) { if (ps) ps->err = msg; else set_global_error(msg); return code; }
+int ps_fail(mc_partset* ps, int code, const std::string& msg)
+{
+    static std::mutex mu;                                          // (several callers may fail at once: the last one's text stays)
+    std::lock_guard<std::mutex> l(mu);
+    if (ps) ps->err = msg; else set_global_error(msg);
+    return code;
+}
 
 uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
 
@@ -111,7 +138,7 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
             if (ps->ranges) { c.single_part = std::max(ps->cfg.single_part, 0); c.target_shard_index = first + i; c.target_shard_count = ps->nparts; }
             else c.single_part = (int32_t)(first + i);
             c.device = ps->devices[d];
-            c.num_slots = 1; c.copy_allhits = 0;
+            c.num_slots = 0; c.copy_allhits = 0;                   // (no host slots: the set has its own staging; the contexts' two pipes are sized below)
             // list alignment (up to 1.5 x the plain store) is a table's own decision against the device's free memory: with several tenants
             // per device it would be made against memory the group's later parts need.  Groups that stream (the next one loads beside the
             // resident one): plain stores; all parts resident: the padding may take its share of what is free.
@@ -121,6 +148,7 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
             const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
             mcamd::open_hints() = mcamd::OpenHints{};
             if (rc != MC_OK) { std::lock_guard<std::mutex> l(errMu); rcs[d] = rc; errs[d] = mc_last_error(nullptr); return; }
+            (void)mcamd::reserve_query_pipes(out[i], (uint32_t)ps->maxQ, std::min<uint64_t>(ps->maxChars, (uint64_t)ps->maxQ * 152));   // (a failure here is not one: the first batch asks again)
             uint64_t st[4] = {0, 0, 0, 0};
             if (mc_load_stats(out[i], st) == MC_OK) ps->loadBytes += st[0];
         }
@@ -214,21 +242,25 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     for (uint32_t d = 0; d < nd && ok; ++d) {
         DevState& D = ps->dev[d];
         D.device = ps->devices[d]; D.comm = comms[d];
-        ok = hipSetDevice(D.device) == hipSuccess && hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking) == hipSuccess &&
-             mcamd::dev_malloc((void**)&D.dseq, ps->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&D.dqinfo, ps->maxQ * 16) == hipSuccess &&
-             mcamd::dev_malloc((void**)&D.dmaxwin, ps->maxQ * 4) == hipSuccess && mcamd::dev_malloc((void**)&D.dmine, ps->slotsPerDev * listBytes) == hipSuccess &&
-             mcamd::dev_malloc((void**)&D.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
-        if (ok && d == 0) ok = mcamd::dev_malloc((void**)&D.dprior, listBytes) == hipSuccess && mcamd::dev_malloc((void**)&D.dout, listBytes) == hipSuccess;
+        ok = hipSetDevice(D.device) == hipSuccess;
+        for (DevLane& L : D.lane) {
+            if (!ok) break;
+            ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
+                 mcamd::dev_malloc((void**)&L.dseq, ps->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&L.dqinfo, ps->maxQ * 16) == hipSuccess &&
+                 mcamd::dev_malloc((void**)&L.dmaxwin, ps->maxQ * 4) == hipSuccess && mcamd::dev_malloc((void**)&L.dmine, ps->slotsPerDev * listBytes) == hipSuccess &&
+                 mcamd::dev_malloc((void**)&L.dprior, listBytes) == hipSuccess && mcamd::dev_malloc((void**)&L.dout, listBytes) == hipSuccess;
+            // (without RCCL -- one device -- the exchanged lists ARE the device's own)
+            if (ok && ps->rccl) ok = mcamd::dev_malloc((void**)&L.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
+        }
     }
-    for (auto& H : ps->hs) {
+    for (auto& H : ps->stg) {
         if (!ok) break;
         ok = hipHostMalloc((void**)&H.seq, ps->maxChars + 64) == hipSuccess && hipHostMalloc((void**)&H.q, ps->maxQ * 16) == hipSuccess &&
              hipHostMalloc((void**)&H.mw, ps->maxQ * 4) == hipSuccess && hipHostMalloc((void**)&H.prior, listBytes) == hipSuccess &&
              hipHostMalloc((void**)&H.out, listBytes) == hipSuccess;
-        H.inDone.assign(nd, nullptr);
+        H.outDone.assign(nd, nullptr);
         for (uint32_t d = 0; d < nd && ok; ++d)
-            ok = hipSetDevice(ps->devices[d]) == hipSuccess && hipEventCreateWithFlags(&H.inDone[d], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipSetDevice(ps->devices[0]) == hipSuccess && hipEventCreateWithFlags(&H.outDone, hipEventDisableTiming) == hipSuccess;
+            ok = hipSetDevice(ps->devices[d]) == hipSuccess && hipEventCreateWithFlags(&H.outDone[d], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { mc_partset_close(ps); return ps_fail(nullptr, MC_ERR_NOMEM, "mc_partset_open: cannot allocate the batch buffers"); }
     std::string err;
@@ -248,17 +280,18 @@ void mc_partset_close(mc_partset* ps)
     close_group(ps->cur); close_group(ps->next);
     for (DevState& D : ps->dev) {
         (void)hipSetDevice(D.device);
-        if (D.stream) (void)hipStreamSynchronize(D.stream);
-        void* bufs[] = {D.dseq, D.dqinfo, D.dmaxwin, D.dmine, D.dall, D.dprior, D.dout};
-        for (void* b : bufs) if (b) (void)hipFree(b);
+        for (DevLane& L : D.lane) {
+            if (L.stream) (void)hipStreamSynchronize(L.stream);
+            void* bufs[] = {L.dseq, L.dqinfo, L.dmaxwin, L.dmine, L.dall, L.dprior, L.dout};
+            for (void* b : bufs) if (b) (void)hipFree(b);
+        }
         if (D.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(D.comm);
-        if (D.stream) (void)hipStreamDestroy(D.stream);
+        for (DevLane& L : D.lane) if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    for (auto& H : ps->hs) {
+    for (auto& H : ps->stg) {
         void* bufs[] = {H.seq, H.q, H.mw, H.prior, H.out};
         for (void* b : bufs) if (b) (void)hipHostFree(b);
-        for (hipEvent_t e : H.inDone) if (e) (void)hipEventDestroy(e);
-        if (H.outDone) (void)hipEventDestroy(H.outDone);
+        for (hipEvent_t e : H.outDone) if (e) (void)hipEventDestroy(e);
     }
     delete ps;
     mcamd::big_cache_hold(-1);
@@ -312,169 +345,318 @@ int mc_partset_select_group(mc_partset* ps, uint32_t g)
     return MC_OK;
 }
 
+}  // extern "C"
+
+// ---- a batch's way through the set ----------------------------------------------------------------------------------------------------
+namespace {
+
+struct BatchRef { uint64_t first = 0, count = 0, chars = 0; };
+struct CallArgs { const char* seqs; const uint64_t* offs; const char* seqs2; const uint64_t* offs2; int lowestRank; uint64_t insertMax; bool hasPrior; mc_candidate* out; };
+
+int take_staging(mc_partset* ps)
+{
+    std::unique_lock<std::mutex> l(ps->poolMu);
+    int got = -1;
+    ps->poolCv.wait(l, [&] { for (uint32_t i = 0; i < kStaging; ++i) if (!ps->stg[i].busy) { got = (int)i; return true; } return false; });
+    ps->stg[got].busy = true;
+    return got;
+}
+void give_staging(mc_partset* ps, int i) { { std::lock_guard<std::mutex> l(ps->poolMu); ps->stg[i].busy = false; } ps->poolCv.notify_all(); }
+// block = false: -1 when both lanes are taken (a caller that holds one finishes its own batch first: no two callers ever wait for each other)
+int take_lane(mc_partset* ps, bool block)
+{
+    std::unique_lock<std::mutex> l(ps->poolMu);
+    for (;;) {
+        for (uint32_t i = 0; i < kLanes; ++i) if (!ps->laneBusy[i]) { ps->laneBusy[i] = true; return (int)i; }
+        if (!block) return -1;
+        ps->poolCv.wait(l);
+    }
+}
+void give_lane(mc_partset* ps, int i) { { std::lock_guard<std::mutex> l(ps->poolMu); ps->laneBusy[i] = false; } ps->poolCv.notify_all(); }
+
+template <class F>
+void on_threads(uint32_t nt, F&& f)                                 // f(t) for t in [0, nt): t = 0 on the caller's thread
+{
+    if (nt <= 1) { f(0u); return; }
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nt; ++t) th.emplace_back(f, t);
+    f(0u);
+    for (auto& t : th) t.join();
+}
+
+// the batch into a staging slot: where every read goes (a sequence starts 4-byte aligned, mc_batch_add), then the characters by a few
+// threads (one thread packs 60 M reads of 150 bp a second: less than the devices take)
+void pack_batch(mc_partset* ps, const CallArgs& A, const BatchRef& B, mc_partset::Staging& H)
+{
+    const uint32_t m = (uint32_t)B.count, K = ps->K;
+    uint64_t at = 0;
+    for (uint32_t j = 0; j < m; ++j) {
+        const uint64_t i = B.first + j, l1 = A.offs[i + 1] - A.offs[i], l2 = A.seqs2 ? A.offs2[i + 1] - A.offs2[i] : 0;
+        H.q[4 * j] = (uint32_t)at; H.q[4 * j + 1] = (uint32_t)l1;
+        at += (l1 + 3) / 4 * 4;
+        H.q[4 * j + 2] = (uint32_t)at; H.q[4 * j + 3] = (uint32_t)l2;
+        at += (l2 + 3) / 4 * 4;
+        H.mw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, A.insertMax) / ps->stride);   // candidate_structs.hpp:143-145
+    }
+    H.chars = at; H.count = m; H.hasPrior = A.hasPrior;
+    const uint32_t nt = m >= (1u << 15) ? ps->packThreads : 1;
+    on_threads(nt, [&](uint32_t t) {
+        for (uint32_t j = (uint32_t)((uint64_t)m * t / nt), j1 = (uint32_t)((uint64_t)m * (t + 1) / nt); j < j1; ++j) {
+            const uint64_t i = B.first + j;
+            if (H.q[4 * j + 1]) std::memcpy(H.seq + H.q[4 * j], A.seqs + A.offs[i], H.q[4 * j + 1]);
+            if (H.q[4 * j + 3]) std::memcpy(H.seq + H.q[4 * j + 2], A.seqs2 + A.offs2[i], H.q[4 * j + 3]);
+        }
+    });
+    if (A.hasPrior) std::memcpy(H.prior, A.out + B.first * K, (size_t)m * K * sizeof(mc_candidate));
+}
+
+// rows [lo, hi) of a batch of m reads belong to owner o of `owners`
+inline uint32_t share_lo(uint32_t m, uint32_t o, uint32_t owners) { return (uint32_t)((uint64_t)m * o / owners); }
+
+// Upload + main kernels of the batch in staging slot H on lane ln: every device that holds a part of the resident group gets the batch and
+// runs its parts on it, all on the lane's stream of that device -- nothing here waits for a device (MC_DEFER_TAIL).
+int submit_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
+{
+    const uint32_t nd = (uint32_t)ps->devices.size(), np = (uint32_t)ps->cur.size(), K = ps->K, m = H.count;
+    const uint32_t owners = std::min(nd, np);                     // the devices with parts: they are the owners of the reads, too
+    H.owners = owners;
+    std::vector<int> rcs(owners, MC_OK);
+    std::vector<std::string> errs(owners);
+    on_threads(owners, [&](uint32_t d) {
+        DevState& D = ps->dev[d];
+        DevLane& L = D.lane[ln];
+        auto bad = [&](const char* what) { rcs[d] = MC_ERR_HIP; errs[d] = what; };
+        if (hipSetDevice(D.device) != hipSuccess) return bad("hipSetDevice");
+        if (hipMemcpyAsync(L.dseq, H.seq, H.chars + 16, hipMemcpyHostToDevice, L.stream) != hipSuccess ||
+            hipMemcpyAsync(L.dqinfo, H.q, (size_t)m * 16, hipMemcpyHostToDevice, L.stream) != hipSuccess ||
+            hipMemcpyAsync(L.dmaxwin, H.mw, (size_t)m * 4, hipMemcpyHostToDevice, L.stream) != hipSuccess) return bad("copy of a batch to the device failed");
+        const uint32_t lo = share_lo(m, d, owners), hi = share_lo(m, d + 1, owners);
+        if (H.hasPrior && hi > lo &&
+            hipMemcpyAsync(L.dprior, H.prior + (size_t)lo * K, (size_t)(hi - lo) * K * sizeof(mc_candidate), hipMemcpyHostToDevice, L.stream) != hipSuccess)
+            return bad("copy of the earlier groups' lists to the device failed");
+        L.cands.clear();
+        for (uint32_t p = d; p < np; p += nd) {
+            mc_device_batch in{L.dseq, L.dqinfo, L.dmaxwin, 0, m, H.chars};
+            mc_device_results res{};
+            const int rc = mc_query_device(ps->cur[p], &in, lowestRank, MC_DEFER_TAIL | (ln ? MC_SECOND_PIPE : 0), &res, L.stream);
+            if (rc) { rcs[d] = rc; errs[d] = mc_last_error(ps->cur[p]); return; }
+            L.cands.push_back(res.cands);
+        }
+    });
+    for (uint32_t d = 0; d < owners; ++d) if (rcs[d]) return ps_fail(ps, rcs[d], errs[d]);
+    return MC_OK;
+}
+
+// The rest of the batch on lane ln, enqueued once its main kernels are through (mc_query_finish waits for them; the NEXT batch is
+// queued on the other lane by then): tails of the parts' queries, their top lists side by side in dmine, the exchange, the owners'
+// merges, every owner's share to the staging slot.
+int finish_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
+{
+    const uint32_t nd = (uint32_t)ps->devices.size(), np = (uint32_t)ps->cur.size(), K = ps->K, m = H.count, owners = H.owners;
+    const size_t listBytes = ps->maxQ * K * sizeof(mc_candidate), row = K * sizeof(mc_candidate);
+    std::vector<int> rcs(owners, MC_OK);
+    std::vector<std::string> errs(owners);
+    on_threads(owners, [&](uint32_t d) {
+        DevState& D = ps->dev[d];
+        DevLane& L = D.lane[ln];
+        if (hipSetDevice(D.device) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipSetDevice"; return; }
+        uint32_t slot = 0;
+        for (uint32_t p = d; p < np; p += nd, ++slot) {
+            mc_ctx* c = ps->cur[p];
+            int rc = mc_query_finish(c, ln ? MC_SECOND_PIPE : 0);
+            if (!rc) rc = mc_copy_results_on(c, reinterpret_cast<char*>(L.dmine) + slot * listBytes, L.cands[slot], (uint64_t)m * row, 0, L.stream);
+            if (rc) { rcs[d] = rc; errs[d] = mc_last_error(c); return; }
+        }
+    });
+    for (uint32_t d = 0; d < owners; ++d) if (rcs[d]) return ps_fail(ps, rcs[d], errs[d]);
+    // every device's lists of owner o's reads -> o: dall[source device][slot], rows 0 .. o's share
+    if (ps->rccl) {
+        std::lock_guard<std::mutex> order(ps->orderMu);
+        g_rccl.GroupStart();
+        int r = 0;
+        for (uint32_t d = 0; d < owners && !r; ++d) {
+            DevState& D = ps->dev[d];
+            DevLane& L = D.lane[ln];
+            (void)hipSetDevice(D.device);
+            const uint32_t myLo = share_lo(m, d, owners), myN = share_lo(m, d + 1, owners) - myLo;
+            for (uint32_t o = 0; o < owners && !r; ++o) {
+                const uint32_t lo = share_lo(m, o, owners), cnt = share_lo(m, o + 1, owners) - lo;
+                uint32_t slot = 0;
+                for (uint32_t pp = d; pp < np && !r; pp += nd, ++slot)          // my parts' lists of o's reads
+                    if (cnt) r = g_rccl.Send(reinterpret_cast<const char*>(L.dmine) + slot * listBytes + (size_t)lo * row, (size_t)cnt * row, Rccl::kChar, (int)o, D.comm, L.stream);
+                slot = 0;
+                for (uint32_t pp = o; pp < np && !r; pp += nd, ++slot)          // o's parts' lists of my reads
+                    if (myN) r = g_rccl.Recv(reinterpret_cast<char*>(L.dall) + ((size_t)o * ps->slotsPerDev + slot) * listBytes, (size_t)myN * row, Rccl::kChar, (int)o, D.comm, L.stream);
+            }
+        }
+        const int e2 = g_rccl.GroupEnd();
+        if (r || e2) return ps_fail(ps, MC_ERR_HIP, std::string("ncclSend / ncclRecv of the per-part candidates: ") + g_rccl.text(r ? r : e2));
+    }
+    // every owner: the earlier groups' list of its reads first, then this group's parts in part order (part p: device p % nd, slot p / nd)
+    for (uint32_t d = 0; d < owners; ++d) {
+        DevState& D = ps->dev[d];
+        DevLane& L = D.lane[ln];
+        const uint32_t lo = share_lo(m, d, owners), cnt = share_lo(m, d + 1, owners) - lo;
+        if (hipSetDevice(D.device) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipSetDevice");
+        if (cnt) {
+            std::vector<const mc_candidate*> lists;
+            if (H.hasPrior) lists.push_back(L.dprior);
+            for (uint32_t p = 0; p < np; ++p)
+                lists.push_back(ps->rccl ? reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(L.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes)
+                                         : reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(L.dmine) + (size_t)(p / nd) * listBytes + (size_t)lo * row));
+            const int rc = mc_merge_part_candidates(ps->cur[d], lists.data(), (uint32_t)lists.size(), cnt, lowestRank, L.dout, L.stream);
+            if (rc) return ps_fail(ps, rc, mc_last_error(ps->cur[d]));
+            if (hipMemcpyAsync(H.out + (size_t)lo * K, L.dout, (size_t)cnt * row, hipMemcpyDeviceToHost, L.stream) != hipSuccess)
+                return ps_fail(ps, MC_ERR_HIP, "copy of the merged candidates failed");
+        }
+        if (hipEventRecord(H.outDone[d], L.stream) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipEventRecord");
+    }
+    return MC_OK;
+}
+
+// the merged lists of the batch in slot H -> the caller's array, once every owner has delivered its share
+int collect_batch(mc_partset* ps, mc_partset::Staging& H, const CallArgs& A, const BatchRef& B)
+{
+    for (uint32_t d = 0; d < H.owners; ++d)
+        if (hipEventSynchronize(H.outDone[d]) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "copy of the merged candidates failed");
+    const size_t bytes = (size_t)B.count * ps->K * sizeof(mc_candidate);
+    char* dst = reinterpret_cast<char*>(A.out + B.first * ps->K);
+    const char* src = reinterpret_cast<const char*>(H.out);
+    const uint32_t nt = bytes >= (4u << 20) ? std::min<uint32_t>(ps->packThreads, 4) : 1;
+    on_threads(nt, [&](uint32_t t) { const size_t a = bytes * t / nt, b = bytes * (t + 1) / nt; std::memcpy(dst + a, src + a, b - a); });
+    return MC_OK;
+}
+
+void idle_devices(mc_partset* ps)
+{
+    for (DevState& D : ps->dev) { (void)hipSetDevice(D.device); for (DevLane& L : D.lane) (void)hipStreamSynchronize(L.stream); }
+}
+
+}  // namespace
+
+extern "C" {
+
 // n reads (pairs: mate i = seqs2 + offs2[i] .. offs2[i + 1]; seqs2 == NULL: single reads) against the parts of the RESIDENT group only.
 // inout [n][max_candidates] (host): with hasPrior the list the earlier groups left for these reads -- it leads the merge, as if its parts had
 // been queried before this group's (candidate_generation.hpp:172-231) --, on return the merged list.  Callers stream their batches through
 // group after group and keep 16 bytes x max_candidates per read between groups (mcq -resident-parts; mc_partset_classify below).
+// Thread-safe: several callers (a batch each) share the set's two lanes; ONE caller with several batches keeps two of them in flight itself.
 int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_t* offs, const char* seqs2, const uint64_t* offs2, uint64_t n, int lowestRank,
                                  uint64_t insertMax, int hasPrior, mc_candidate* out)
 {
     if (!ps || !seqs || !offs || !out || (seqs2 && !offs2)) return MC_ERR_INVALID;
     if (ps->cur.empty()) return ps_fail(ps, MC_ERR_STATE, "mc_partset_classify_resident: no part group is resident (mc_partset_select_group)");
-    const uint32_t K = ps->K, nd = (uint32_t)ps->devices.size();
-    const size_t listBytes = ps->maxQ * K * sizeof(mc_candidate);
+    const CallArgs A{seqs, offs, seqs2, offs2, lowestRank, insertMax, hasPrior != 0, out};
     // the batches: as many reads as fit the slot limits (a sequence starts 4-byte aligned, mc_batch_add)
-    struct Batch { uint64_t first, count, chars; };
-    std::vector<Batch> batches;
+    std::vector<BatchRef> batches;
     auto need = [&](uint64_t i) {
         const uint64_t l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
         return (l1 + 3) / 4 * 4 + (l2 + 3) / 4 * 4;
     };
     for (uint64_t i = 0; i < n;) {
-        Batch b{i, 0, 0};
+        BatchRef b{i, 0, 0};
         while (i < n && b.count < ps->maxQ && b.chars + need(i) <= ps->maxChars) { b.chars += need(i); ++b.count; ++i; }
         if (b.count == 0) return ps_fail(ps, MC_ERR_INVALID, "mc_partset_classify: a read is longer than slot_max_chars");
         batches.push_back(b);
     }
-    const uint32_t np = (uint32_t)ps->cur.size();
-    auto idle = [&](int code, const std::string& msg) {            // an error leaves nothing in flight
-        for (uint32_t d = 0; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
-        for (auto& H : ps->hs) H.inFlight = false;
-        return ps_fail(ps, code, msg);
-    };
-    // the merged lists of a slot's batch -> the caller's array, once device 0 has written them
-    auto collect = [&](mc_partset::HostSlot& H) -> bool {
-        if (!H.inFlight) return true;
-        H.inFlight = false;
-        if (hipEventSynchronize(H.outDone) != hipSuccess) return false;
-        std::memcpy(out + H.first * K, H.out, (size_t)H.count * K * sizeof(mc_candidate));
-        return true;
-    };
+    const size_t nbt = batches.size();
+    if (nbt == 0) return MC_OK;
     static const bool trace = std::getenv("MC_PARTSET_TRACE") != nullptr;
-    uint64_t tCollect = 0, tPack = 0, tEnqueue = 0, tGather = 0;
-    // a batch into its slot's pinned buffers: where every read goes (a sequence starts 4-byte aligned), then the characters by a few
-    // threads (one thread packs 60 M reads of 150 bp a second: less than the devices take)
-    auto pack_batch = [&](size_t bi) {
-        const Batch& B = batches[bi];
-        mc_partset::HostSlot& H = ps->hs[bi & 1];
-        const uint32_t m = (uint32_t)B.count;
-        uint64_t at = 0;
-        for (uint32_t j = 0; j < m; ++j) {
-            const uint64_t i = B.first + j, l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
-            H.q[4 * j] = (uint32_t)at; H.q[4 * j + 1] = (uint32_t)l1;
-            at += (l1 + 3) / 4 * 4;
-            H.q[4 * j + 2] = (uint32_t)at; H.q[4 * j + 3] = (uint32_t)l2;
-            at += (l2 + 3) / 4 * 4;
-            H.mw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, insertMax) / ps->stride);   // candidate_structs.hpp:143-145
-        }
-        H.chars = at;
-        auto pack = [&](uint32_t j0, uint32_t j1) {
-            for (uint32_t j = j0; j < j1; ++j) {
-                const uint64_t i = B.first + j;
-                if (H.q[4 * j + 1]) std::memcpy(H.seq + H.q[4 * j], seqs + offs[i], H.q[4 * j + 1]);
-                if (H.q[4 * j + 3]) std::memcpy(H.seq + H.q[4 * j + 2], seqs2 + offs2[i], H.q[4 * j + 3]);
-            }
-        };
-        const uint32_t nt = m >= (1u << 15) ? ps->packThreads : 1;
-        if (nt <= 1) pack(0, m);
-        else {
-            std::vector<std::thread> th;
-            for (uint32_t t = 1; t < nt; ++t) th.emplace_back(pack, (uint32_t)((uint64_t)m * t / nt), (uint32_t)((uint64_t)m * (t + 1) / nt));
-            pack(0, (uint32_t)((uint64_t)m / nt));
-            for (auto& t : th) t.join();
-        }
-        if (hasPrior) std::memcpy(H.prior, out + B.first * K, (size_t)m * K * sizeof(mc_candidate));
-    };
-    // mc_query_device comes back when a batch's kernels are nearly through (its lists' sizes make a host round trip): batch b + 1 is packed
-    // by a helper thread meanwhile
+    uint64_t tPackWait = 0, tSubmit = 0, tFinish = 0, tCollect = 0;
+    // the packer runs ahead of the devices: batch b + 1 (b + 2) is in its staging slot when batch b is submitted
+    std::vector<int> slotOf(nbt, -1);
+    std::mutex qMu;
+    std::condition_variable qCv;
+    size_t packed = 0;                                             // batches [0, packed) are in their slots
+    bool stop = false;
     std::thread packer;
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{packer};
-    if (!batches.empty()) pack_batch(0);
-    for (size_t bi = 0; bi < batches.size(); ++bi) {
-        const Batch& B = batches[bi];
-        mc_partset::HostSlot& H = ps->hs[bi & 1];
-        const uint64_t tr0 = now_ns();
-        if (packer.joinable()) packer.join();                       // this batch is in its slot
-        const uint64_t tr1 = now_ns();
-        // the OTHER slot is packed next: its last batch (bi - 1) must have left the host on every device, and its result goes to the caller
-        mc_partset::HostSlot& O = ps->hs[(bi + 1) & 1];
-        if (O.inFlight)
-            for (uint32_t d = 0; d < nd; ++d) if (hipEventSynchronize(O.inDone[d]) != hipSuccess) return idle(MC_ERR_HIP, "copy of a batch to the device failed");
-        if (!collect(O)) return idle(MC_ERR_HIP, "copy of the merged candidates failed");
-        const uint64_t tr2 = now_ns();
-        if (bi + 1 < batches.size()) packer = std::thread(pack_batch, bi + 1);
-        const uint32_t m = (uint32_t)B.count;
-        const uint64_t at = H.chars;
-        // every device: the batch, then its parts of the group, their top lists side by side in dmine.  Everything of a device is in
-        // order on its one stream: batch b + 1's input overwrites the device buffers only after batch b's kernels have read them
-        std::vector<int> rcs(nd, MC_OK);
-        std::vector<std::string> errs(nd);
-        auto run_device = [&](uint32_t d) {
-            DevState& D = ps->dev[d];
-            if (hipSetDevice(D.device) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipSetDevice"; return; }
-            (void)hipMemcpyAsync(D.dseq, H.seq, at + 16, hipMemcpyHostToDevice, D.stream);
-            (void)hipMemcpyAsync(D.dqinfo, H.q, (size_t)m * 16, hipMemcpyHostToDevice, D.stream);
-            (void)hipMemcpyAsync(D.dmaxwin, H.mw, (size_t)m * 4, hipMemcpyHostToDevice, D.stream);
-            if (d == 0 && hasPrior) (void)hipMemcpyAsync(D.dprior, H.prior, (size_t)m * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D.stream);
-            (void)hipEventRecord(H.inDone[d], D.stream);
-            (void)hipMemsetAsync(D.dmine, 0, ps->slotsPerDev * listBytes, D.stream);     // slots without a part: empty lists (hits = 0)
-            uint32_t slot = 0;
-            for (uint32_t p = d; p < np; p += nd, ++slot) {
-                mc_device_batch in{D.dseq, D.dqinfo, D.dmaxwin, 0, m, at};
-                mc_device_results res{};
-                int rc = mc_query_device(ps->cur[p], &in, lowestRank, 0, &res, D.stream);
-                if (!rc) rc = mc_copy_results_on(ps->cur[p], reinterpret_cast<char*>(D.dmine) + slot * listBytes, res.cands, (uint64_t)m * K * sizeof(mc_candidate), 0, D.stream);
-                if (rc) { rcs[d] = rc; errs[d] = mc_last_error(ps->cur[p]); return; }
+    if (nbt > 1)
+        packer = std::thread([&] {
+            for (size_t b = 0; b < nbt; ++b) {
+                { std::lock_guard<std::mutex> l(qMu); if (stop) return; }
+                const int s = take_staging(ps);
+                pack_batch(ps, A, batches[b], ps->stg[s]);
+                { std::lock_guard<std::mutex> l(qMu); slotOf[b] = s; packed = b + 1; }
+                qCv.notify_all();
             }
+        });
+    else { slotOf[0] = take_staging(ps); pack_batch(ps, A, batches[0], ps->stg[slotOf[0]]); packed = 1; }
+    // collecting (event wait + copy into the caller's array) by a helper of its own: the submitting thread only enqueues
+    std::vector<int> rcOf(nbt, MC_OK);
+    size_t finished = 0, collected = 0;                            // batches [0, finished) have their copy back enqueued
+    std::thread collector;
+    if (nbt > 1)
+        collector = std::thread([&] {
+            for (size_t b = 0; b < nbt; ++b) {
+                { std::unique_lock<std::mutex> l(qMu); qCv.wait(l, [&] { return stop || finished > b; }); if (finished <= b) return; }
+                rcOf[b] = collect_batch(ps, ps->stg[slotOf[b]], A, batches[b]);
+                give_staging(ps, slotOf[b]);
+                { std::lock_guard<std::mutex> l(qMu); collected = b + 1; }
+                qCv.notify_all();
+            }
+        });
+    int rc = MC_OK;
+    int laneOf[2] = {-1, -1};                                      // lanes of the batches in flight: [b & 1]
+    auto finish = [&](size_t b) -> int {                          // tail, exchange, merge, copy back of batch b; its lane goes back
+        const uint64_t t0 = now_ns();
+        const int r = finish_batch(ps, ps->stg[slotOf[b]], laneOf[b & 1], lowestRank);
+        give_lane(ps, laneOf[b & 1]); laneOf[b & 1] = -1;
+        tFinish += now_ns() - t0;
+        if (!r) { { std::lock_guard<std::mutex> l(qMu); finished = b + 1; } qCv.notify_all(); }
+        return r;
+    };
+    size_t inFlightFrom = 0;                                       // batches [inFlightFrom, b) are submitted and not finished
+    for (size_t b = 0; b < nbt && !rc; ++b) {
+        const uint64_t t0 = now_ns();
+        { std::unique_lock<std::mutex> l(qMu); qCv.wait(l, [&] { return packed > b; }); }
+        const uint64_t t1 = now_ns();
+        int ln = take_lane(ps, false);
+        while (ln < 0 && !rc) {                                     // no free lane: my own oldest batch gives one back, else another caller will
+            if (inFlightFrom < b) { rc = finish(inFlightFrom++); if (!rc) ln = take_lane(ps, false); }
+            else ln = take_lane(ps, true);
+        }
+        if (rc) break;
+        laneOf[b & 1] = ln;
+        rc = submit_batch(ps, ps->stg[slotOf[b]], ln, lowestRank);
+        tPackWait += t1 - t0; tSubmit += now_ns() - t1;
+        if (rc) { give_lane(ps, ln); laneOf[b & 1] = -1; break; }
+        if (inFlightFrom < b) rc = finish(inFlightFrom++);          // the batch before this one: its kernels ran while this one was enqueued
+    }
+    const size_t submitted = rc ? inFlightFrom : nbt;
+    while (!rc && inFlightFrom < submitted) rc = finish(inFlightFrom++);
+    if (nbt > 1) {
+        const uint64_t t0 = now_ns();
+        { std::lock_guard<std::mutex> l(qMu); stop = true; }
+        qCv.notify_all();
+        if (rc) {                                                   // an error leaves nothing in flight and no slot taken
+            idle_devices(ps);
+            for (int& l : laneOf) if (l >= 0) { give_lane(ps, l); l = -1; }
+        }
+        collector.join();
+        // (an error: the packer may be waiting for a slot -- the ones nobody will collect go back first; it packs one batch more at most)
+        std::vector<char> given(nbt, 0);
+        auto give_uncollected = [&] {
+            size_t upTo;
+            { std::lock_guard<std::mutex> l(qMu); upTo = packed; }
+            for (size_t b = collected; b < upTo; ++b) if (!given[b] && slotOf[b] >= 0) { given[b] = 1; give_staging(ps, slotOf[b]); }
         };
-        if (nd == 1) run_device(0);
-        else {
-            std::vector<std::thread> th;
-            for (uint32_t d = 0; d < nd; ++d) th.emplace_back(run_device, d);
-            for (auto& t : th) t.join();
-        }
-        for (uint32_t d = 0; d < nd; ++d) if (rcs[d]) return idle(rcs[d], errs[d]);
-        const uint64_t tr3 = now_ns();
-        // per-rank partial lists gathered over RCCL: every rank's slotsPerDev lists -> dall[rank][slot] on every device
-        if (!ps->rccl) {
-            (void)hipSetDevice(ps->dev[0].device);
-            (void)hipMemcpyAsync(ps->dev[0].dall, ps->dev[0].dmine, ps->slotsPerDev * listBytes, hipMemcpyDeviceToDevice, ps->dev[0].stream);
-        } else {
-            g_rccl.GroupStart();
-            int r = 0;
-            for (uint32_t d = 0; d < nd && !r; ++d) {
-                DevState& D = ps->dev[d];
-                (void)hipSetDevice(D.device);
-                r = g_rccl.AllGather(D.dmine, D.dall, ps->slotsPerDev * listBytes, /*ncclChar*/ 0, D.comm, D.stream);
-            }
-            const int e2 = g_rccl.GroupEnd();
-            if (r || e2) return idle(MC_ERR_HIP, std::string("ncclAllGather of the per-part candidates: ") + g_rccl.text(r ? r : e2));
-        }
-        // device 0: the earlier groups' list of these reads first, then this group's parts in part order (part p: rank p % nd, slot p / nd)
-        DevState& D0 = ps->dev[0];
-        if (hipSetDevice(D0.device) != hipSuccess) return idle(MC_ERR_HIP, "hipSetDevice");
-        std::vector<const mc_candidate*> lists;
-        if (hasPrior) lists.push_back(D0.dprior);
-        for (uint32_t p = 0; p < np; ++p)
-            lists.push_back(reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(D0.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes));
-        int rc = mc_merge_part_candidates(ps->cur[0], lists.data(), (uint32_t)lists.size(), m, lowestRank, D0.dout, D0.stream);
-        if (rc) return idle(rc, mc_last_error(ps->cur[0]));
-        if (hipMemcpyAsync(H.out, D0.dout, (size_t)m * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, D0.stream) != hipSuccess ||
-            hipEventRecord(H.outDone, D0.stream) != hipSuccess)
-            return idle(MC_ERR_HIP, "copy of the merged candidates failed");
-        H.inFlight = true; H.first = B.first; H.count = m;
-        const uint64_t tr4 = now_ns();
-        tPack += tr1 - tr0; tCollect += tr2 - tr1; tEnqueue += tr3 - tr2; tGather += tr4 - tr3;
+        give_uncollected();
+        packer.join();
+        give_uncollected();
+        for (size_t b = 0; b < nbt; ++b) if (!rc && rcOf[b]) rc = rcOf[b];
+        if (!rc && collected < nbt) rc = ps_fail(ps, MC_ERR_STATE, "mc_partset_classify_resident: internal: a batch was not collected");
+        tCollect += now_ns() - t0;
+    } else {
+        const uint64_t t0 = now_ns();
+        if (!rc) rc = collect_batch(ps, ps->stg[slotOf[0]], A, batches[0]);
+        else { idle_devices(ps); for (int& l : laneOf) if (l >= 0) { give_lane(ps, l); l = -1; } }
+        give_staging(ps, slotOf[0]);
+        tCollect += now_ns() - t0;
     }
     if (trace)
-        std::fprintf(stderr, "mc_partset_classify_resident: %zu batches, %u parts; host ms: waiting for the packer %.2f, collect %.2f, enqueue %.2f, gather+merge %.2f\n",
-                     batches.size(), np, tPack / 1e6, tCollect / 1e6, tEnqueue / 1e6, tGather / 1e6);
-    // the last two batches; then nothing is left in flight (the callers' next call may come from another thread or select another group)
-    const size_t nbt = batches.size();
-    for (size_t k = nbt >= 2 ? nbt - 2 : 0; k < nbt; ++k)
-        if (!collect(ps->hs[k & 1])) return idle(MC_ERR_HIP, "copy of the merged candidates failed");
-    for (uint32_t d = 0; d < nd; ++d) { (void)hipSetDevice(ps->dev[d].device); (void)hipStreamSynchronize(ps->dev[d].stream); }
-    return MC_OK;
+        std::fprintf(stderr, "mc_partset_classify_resident: %zu batches, %zu parts; host ms: waiting for the packer %.2f, submit %.2f, finish %.2f, waiting for the last copies %.2f\n",
+                     nbt, ps->cur.size(), tPackWait / 1e6, tSubmit / 1e6, tFinish / 1e6, tCollect / 1e6);
+    return rc;
 }
 
 // All n reads against every part of the database, part group by part group.  out: [n][max_candidates] in host memory.
