@@ -455,8 +455,8 @@ def reference_calibration(scale: float, K: int, lf: float, device: int, budget_s
 
 def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, steps, warmup, nb, per_read, kernel_only_s):
     """SURVEY 8(d) row 1, the host-fed form: the timed region's K batches once more, this time starting in PINNED HOST memory -- the upload
-    of batch i + 1 (mc_copy_results_on kind 2, on the pipe it will run on) under the kernels of batch i on the other pipe, the candidates
-    copied back to pinned host memory (kind 1) inside the clock.  What a host application that parses reads itself can reach at most:
+    of batch i + 1 on an upload stream of its own under the kernels of batch i, the candidates copied back to pinned host memory
+    (mc_copy_results_on kind 1) inside the clock.  What a host application that parses reads itself can reach at most:
     never `value`."""
     dev = qinfo.device
     srcs = [(long_batches[(warmup + i) % nb] if long_batches is not None else batches[(warmup + i) % nb]) for i in range(steps)]
@@ -468,12 +468,18 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
         h.copy_(t)
         host_in.append(h)
     nbytes_in = [int(h.numel()) for h in host_in]
-    dev_in = [torch.zeros(max(nbytes_in) + 16, dtype=torch.uint8, device=dev) for _ in range(2)]
+    # THREE input buffers on the device and an upload stream of its own: the upload of batch i + 1 is enqueued as soon as batch i's kernels are
+    # -- it must not sit behind the tail of batch i - 1 on that batch's stream (a few small kernels that wait for CUs while batch i's
+    # kernels fill the device: behind them the upload started a batch late, 30 ms per step instead of 18)
+    dev_in = [torch.zeros(max(nbytes_in) + 16, dtype=torch.uint8, device=dev) for _ in range(3)]
     host_out = [torch.zeros((nloc, K, 4), dtype=torch.int32).pin_memory() for _ in range(2)]
+    up = torch.cuda.Stream(device=dev)
+    pipes = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    up_done = [torch.cuda.Event() for _ in range(3)]
+    in_free = [torch.cuda.Event() for _ in range(3)]
     torch.cuda.synchronize()
     stage_s = time.perf_counter() - t0
     pend = {}
-
     trace = {"h2d_call": 0.0, "query_call": 0.0, "finish_call": 0.0, "d2h_call": 0.0}
 
     def clocked(key, f, *a, **kw):
@@ -482,30 +488,45 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
         trace[key] += time.perf_counter() - t
         return r
 
+    def upload(i):
+        k = i % 3
+        with torch.cuda.stream(up):
+            if i >= 3:
+                up.wait_event(in_free[k])                    # batch i - 3 has read this buffer to its end (main kernels and tail)
+            dev_in[k][: nbytes_in[i]].copy_(host_in[i], non_blocking=True)
+            up_done[k].record(up)
+
     def finish_pipe(j):
         if j not in pend:
             return
-        ptr = pend.pop(j)
+        ptr, i = pend.pop(j)
         clocked("finish_call", db.query_finish, second_pipe=bool(j))
-        clocked("d2h_call", db.copy_results, host_out[j].data_ptr(), ptr, nloc * K * 16, to_host=True, second_pipe=bool(j))
+        in_free[i % 3].record(pipes[j])
+        clocked("d2h_call", db.copy_results, host_out[j].data_ptr(), ptr, nloc * K * 16, to_host=True, second_pipe=bool(j), stream=pipes[j].cuda_stream)
 
     def run():
         db.synchronize(); torch.cuda.synchronize()
         for k in trace:
             trace[k] = 0.0
         t0 = time.perf_counter()
+        clocked("h2d_call", upload, 0)
         for i in range(steps):
             j = i & 1
-            clocked("h2d_call", db.copy_results, dev_in[j].data_ptr(), host_in[i].data_ptr(), nbytes_in[i], from_host=True, second_pipe=bool(j))
+            if i + 1 < steps:
+                clocked("h2d_call", upload, i + 1)
+            pipes[j].wait_event(up_done[i % 3])
+            src = dev_in[i % 3]
             if long_batches is not None:
                 lb = srcs[i]
-                res = clocked("query_call", db.query_device, dev_in[j].data_ptr(), lb["qinfo"].data_ptr(), nloc, lb["nchars"], max_win_ptr=lb["maxwin"].data_ptr(), second_pipe=bool(j),
-                              defer_tail=True)
+                res = clocked("query_call", db.query_device, src.data_ptr(), lb["qinfo"].data_ptr(), nloc, lb["nchars"], max_win_ptr=lb["maxwin"].data_ptr(), second_pipe=bool(j),
+                              defer_tail=True, stream=pipes[j].cuda_stream)
             else:
-                res = clocked("query_call", db.query_device, dev_in[j].data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, second_pipe=bool(j), defer_tail=True)
-            pend[j] = res.cands
+                res = clocked("query_call", db.query_device, src.data_ptr(), qinfo.data_ptr(), nloc, nchars, max_win_uniform=max_win, second_pipe=bool(j), defer_tail=True,
+                              stream=pipes[j].cuda_stream)
+            pend[j] = (res.cands, i)
             finish_pipe(j ^ 1)
         finish_pipe(0); finish_pipe(1)
+        torch.cuda.synchronize()
         db.synchronize()
         return time.perf_counter() - t0
 
@@ -517,8 +538,9 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
     db.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        db.copy_results(dev_in[i & 1].data_ptr(), host_in[i].data_ptr(), nbytes_in[i], from_host=True, second_pipe=bool(i & 1))
-    db.synchronize()
+        with torch.cuda.stream(up):
+            dev_in[i % 3][: nbytes_in[i]].copy_(host_in[i], non_blocking=True)
+    torch.cuda.synchronize()
     link_s = time.perf_counter() - t0
     # the last batch's candidates as they arrived on the host against the device's own copy
     last = (steps - 1) & 1
@@ -527,7 +549,7 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
     out = {"ms_per_step": round(ms, 3), "Mreads_min": round(steps * nloc * per_read / el * 60 / 1e6, 1), "h2d_GBps": round(up / link_s, 1),
            "h2d_GB_per_step": round(up / steps, 3), "d2h_GB_per_step": round(down / steps, 4), "over_kernel_only": round(ratio, 3),
            "staging_s": round(stage_s, 1), "host_ms_per_step_inside_the_calls": {k: round(v / steps * 1e3, 3) for k, v in trace.items()},
-           "what": "the timed region's batches from pinned host memory: H2D of batch i+1 on its pipe under batch i's kernels, candidates D2H to pinned memory, all inside the clock; best of 2"}
+           "what": "the timed region's batches from pinned host memory: H2D of batch i+1 on an upload stream under batch i's kernels, candidates D2H to pinned memory, all inside the clock; best of 2"}
     if ratio < 0.8:
         h2d_ms = up / steps / (up / link_s) * 1e3
         out["bound"] = (f"PCIe: the upload alone takes {h2d_ms:.1f} ms per step at {up / link_s:.0f} GB/s" if h2d_ms > 0.8 * ms else

@@ -44,19 +44,27 @@ namespace {
 
 Rccl& g_rccl = rccl();                 // rccl_dl.h
 
-constexpr uint32_t kLanes = 2, kStaging = 4;
+constexpr uint32_t kLanes = 2, kStaging = 4, kInputs = 3;
 
+struct DevInput {                      // one device's copy of a batch's input: uploaded on the device's upload stream, read by a lane
+    uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;
+    mc_candidate* dprior = nullptr;    // the earlier groups' list of the reads this device owns
+    hipEvent_t upDone = nullptr;       // upload stream: the batch is here
+    hipEvent_t inFree = nullptr;       // lane stream: the batch that used this input has read it to its end (main kernels, tails, merge)
+    bool used = false;
+};
 struct DevLane {                       // one device's side of a lane
     hipStream_t stream = nullptr;
-    uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;
     mc_candidate* dmine = nullptr;     // [slotsPerDev][maxQ][K]: this device's parts of the resident group, all reads of the batch
     mc_candidate* dall = nullptr;      // [ndev][slotsPerDev][maxQ][K]: every part's lists of the reads this device OWNS (rows 0 .. its share)
-    mc_candidate* dprior = nullptr, *dout = nullptr;   // the earlier groups' list of the owned reads, the merged one
+    mc_candidate* dout = nullptr;      // the merged lists of the owned reads
     std::vector<const mc_candidate*> cands;              // [slot]: where the part's context leaves the batch's top lists (its pipe's result buffer)
 };
 struct DevState {
     int device = 0;
     void* comm = nullptr;
+    hipStream_t up = nullptr;          // uploads: never behind a lane's small kernels, which wait for CUs while the other lane's batch fills the device
+    DevInput in[kInputs];
     DevLane lane[kLanes];
 };
 
@@ -87,6 +95,7 @@ struct mc_partset {
         bool busy = false;
     } stg[kStaging];
     bool laneBusy[kLanes] = {false, false};
+    bool inputBusy[kInputs] = {false, false, false};
     std::mutex poolMu;                 // staging slots and lanes
     std::condition_variable poolCv;
     std::mutex orderMu;                // the exchange's RCCL calls: one group at a time, the same order on every device
@@ -242,13 +251,17 @@ int mc_partset_open(const char* name, const mc_config* cfg, uint32_t residentPar
     for (uint32_t d = 0; d < nd && ok; ++d) {
         DevState& D = ps->dev[d];
         D.device = ps->devices[d]; D.comm = comms[d];
-        ok = hipSetDevice(D.device) == hipSuccess;
+        ok = hipSetDevice(D.device) == hipSuccess && hipStreamCreateWithFlags(&D.up, hipStreamNonBlocking) == hipSuccess;
+        for (DevInput& I : D.in) {
+            if (!ok) break;
+            ok = mcamd::dev_malloc((void**)&I.dseq, ps->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&I.dqinfo, ps->maxQ * 16) == hipSuccess &&
+                 mcamd::dev_malloc((void**)&I.dmaxwin, ps->maxQ * 4) == hipSuccess && mcamd::dev_malloc((void**)&I.dprior, listBytes) == hipSuccess &&
+                 hipEventCreateWithFlags(&I.upDone, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&I.inFree, hipEventDisableTiming) == hipSuccess;
+        }
         for (DevLane& L : D.lane) {
             if (!ok) break;
             ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
-                 mcamd::dev_malloc((void**)&L.dseq, ps->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&L.dqinfo, ps->maxQ * 16) == hipSuccess &&
-                 mcamd::dev_malloc((void**)&L.dmaxwin, ps->maxQ * 4) == hipSuccess && mcamd::dev_malloc((void**)&L.dmine, ps->slotsPerDev * listBytes) == hipSuccess &&
-                 mcamd::dev_malloc((void**)&L.dprior, listBytes) == hipSuccess && mcamd::dev_malloc((void**)&L.dout, listBytes) == hipSuccess;
+                 mcamd::dev_malloc((void**)&L.dmine, ps->slotsPerDev * listBytes) == hipSuccess && mcamd::dev_malloc((void**)&L.dout, listBytes) == hipSuccess;
             // (without RCCL -- one device -- the exchanged lists ARE the device's own)
             if (ok && ps->rccl) ok = mcamd::dev_malloc((void**)&L.dall, (size_t)nd * ps->slotsPerDev * listBytes) == hipSuccess;
         }
@@ -280,13 +293,21 @@ void mc_partset_close(mc_partset* ps)
     close_group(ps->cur); close_group(ps->next);
     for (DevState& D : ps->dev) {
         (void)hipSetDevice(D.device);
+        if (D.up) (void)hipStreamSynchronize(D.up);
         for (DevLane& L : D.lane) {
             if (L.stream) (void)hipStreamSynchronize(L.stream);
-            void* bufs[] = {L.dseq, L.dqinfo, L.dmaxwin, L.dmine, L.dall, L.dprior, L.dout};
+            void* bufs[] = {L.dmine, L.dall, L.dout};
             for (void* b : bufs) if (b) (void)hipFree(b);
+        }
+        for (DevInput& I : D.in) {
+            void* bufs[] = {I.dseq, I.dqinfo, I.dmaxwin, I.dprior};
+            for (void* b : bufs) if (b) (void)hipFree(b);
+            if (I.upDone) (void)hipEventDestroy(I.upDone);
+            if (I.inFree) (void)hipEventDestroy(I.inFree);
         }
         if (D.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(D.comm);
         for (DevLane& L : D.lane) if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (D.up) (void)hipStreamDestroy(D.up);
     }
     for (auto& H : ps->stg) {
         void* bufs[] = {H.seq, H.q, H.mw, H.prior, H.out};
@@ -372,6 +393,16 @@ int take_lane(mc_partset* ps, bool block)
         ps->poolCv.wait(l);
     }
 }
+int take_input(mc_partset* ps, bool block)
+{
+    std::unique_lock<std::mutex> l(ps->poolMu);
+    for (;;) {
+        for (uint32_t i = 0; i < kInputs; ++i) if (!ps->inputBusy[i]) { ps->inputBusy[i] = true; return (int)i; }
+        if (!block) return -1;
+        ps->poolCv.wait(l);
+    }
+}
+void give_input(mc_partset* ps, int i) { { std::lock_guard<std::mutex> l(ps->poolMu); ps->inputBusy[i] = false; } ps->poolCv.notify_all(); }
 void give_lane(mc_partset* ps, int i) { { std::lock_guard<std::mutex> l(ps->poolMu); ps->laneBusy[i] = false; } ps->poolCv.notify_all(); }
 
 template <class F>
@@ -389,54 +420,81 @@ void on_threads(uint32_t nt, F&& f)                                 // f(t) for 
 void pack_batch(mc_partset* ps, const CallArgs& A, const BatchRef& B, mc_partset::Staging& H)
 {
     const uint32_t m = (uint32_t)B.count, K = ps->K;
-    uint64_t at = 0;
-    for (uint32_t j = 0; j < m; ++j) {
-        const uint64_t i = B.first + j, l1 = A.offs[i + 1] - A.offs[i], l2 = A.seqs2 ? A.offs2[i + 1] - A.offs2[i] : 0;
-        H.q[4 * j] = (uint32_t)at; H.q[4 * j + 1] = (uint32_t)l1;
-        at += (l1 + 3) / 4 * 4;
-        H.q[4 * j + 2] = (uint32_t)at; H.q[4 * j + 3] = (uint32_t)l2;
-        at += (l2 + 3) / 4 * 4;
-        H.mw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, A.insertMax) / ps->stride);   // candidate_structs.hpp:143-145
-    }
-    H.chars = at; H.count = m; H.hasPrior = A.hasPrior;
     const uint32_t nt = m >= (1u << 15) ? ps->packThreads : 1;
+    // every thread a contiguous share of the reads: what its share takes, then (the shares' offsets known) places, window ranges, characters
+    std::vector<uint64_t> base(nt + 1, 0);
+    auto padded = [&](uint64_t i) { return (A.offs[i + 1] - A.offs[i] + 3) / 4 * 4 + (A.seqs2 ? (A.offs2[i + 1] - A.offs2[i] + 3) / 4 * 4 : 0); };
+    if (nt > 1)
+        on_threads(nt, [&](uint32_t t) {
+            uint64_t sum = 0;
+            for (uint64_t i = B.first + (uint64_t)m * t / nt, e = B.first + (uint64_t)m * (t + 1) / nt; i < e; ++i) sum += padded(i);
+            base[t + 1] = sum;
+        });
+    for (uint32_t t = 0; t < nt; ++t) base[t + 1] += base[t];
     on_threads(nt, [&](uint32_t t) {
+        uint64_t at = base[t];
         for (uint32_t j = (uint32_t)((uint64_t)m * t / nt), j1 = (uint32_t)((uint64_t)m * (t + 1) / nt); j < j1; ++j) {
-            const uint64_t i = B.first + j;
-            if (H.q[4 * j + 1]) std::memcpy(H.seq + H.q[4 * j], A.seqs + A.offs[i], H.q[4 * j + 1]);
-            if (H.q[4 * j + 3]) std::memcpy(H.seq + H.q[4 * j + 2], A.seqs2 + A.offs2[i], H.q[4 * j + 3]);
+            const uint64_t i = B.first + j, l1 = A.offs[i + 1] - A.offs[i], l2 = A.seqs2 ? A.offs2[i + 1] - A.offs2[i] : 0;
+            H.q[4 * j] = (uint32_t)at; H.q[4 * j + 1] = (uint32_t)l1;
+            if (l1) std::memcpy(H.seq + at, A.seqs + A.offs[i], l1);
+            at += (l1 + 3) / 4 * 4;
+            H.q[4 * j + 2] = (uint32_t)at; H.q[4 * j + 3] = (uint32_t)l2;
+            if (l2) std::memcpy(H.seq + at, A.seqs2 + A.offs2[i], l2);
+            at += (l2 + 3) / 4 * 4;
+            H.mw[j] = (uint32_t)(2 + std::max<uint64_t>(l1 + l2, A.insertMax) / ps->stride);   // candidate_structs.hpp:143-145
+        }
+        if (t + 1 == nt) H.chars = at;
+        if (A.hasPrior) {                                           // the earlier groups' lists of the share
+            const uint32_t j0 = (uint32_t)((uint64_t)m * t / nt), j1 = (uint32_t)((uint64_t)m * (t + 1) / nt);
+            std::memcpy(H.prior + (size_t)j0 * K, A.out + (B.first + j0) * K, (size_t)(j1 - j0) * K * sizeof(mc_candidate));
         }
     });
-    if (A.hasPrior) std::memcpy(H.prior, A.out + B.first * K, (size_t)m * K * sizeof(mc_candidate));
+    H.count = m; H.hasPrior = A.hasPrior;
 }
 
 // rows [lo, hi) of a batch of m reads belong to owner o of `owners`
 inline uint32_t share_lo(uint32_t m, uint32_t o, uint32_t owners) { return (uint32_t)((uint64_t)m * o / owners); }
 
-// Upload + main kernels of the batch in staging slot H on lane ln: every device that holds a part of the resident group gets the batch and
-// runs its parts on it, all on the lane's stream of that device -- nothing here waits for a device (MC_DEFER_TAIL).
-int submit_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
+// The batch in staging slot H to device input k of every device that holds a part of the resident group (they are the owners of the
+// reads, too), on the devices' upload streams; an input's last batch must have read it to its end (a device-side wait).
+int upload_batch(mc_partset* ps, mc_partset::Staging& H, int k)
 {
     const uint32_t nd = (uint32_t)ps->devices.size(), np = (uint32_t)ps->cur.size(), K = ps->K, m = H.count;
-    const uint32_t owners = std::min(nd, np);                     // the devices with parts: they are the owners of the reads, too
+    const uint32_t owners = std::min(nd, np);
     H.owners = owners;
+    for (uint32_t d = 0; d < owners; ++d) {
+        DevState& D = ps->dev[d];
+        DevInput& I = D.in[k];
+        if (hipSetDevice(D.device) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipSetDevice");
+        if (I.used && hipStreamWaitEvent(D.up, I.inFree, 0) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipStreamWaitEvent");
+        I.used = true;
+        const uint32_t lo = share_lo(m, d, owners), hi = share_lo(m, d + 1, owners);
+        if (hipMemcpyAsync(I.dseq, H.seq, H.chars + 16, hipMemcpyHostToDevice, D.up) != hipSuccess ||
+            hipMemcpyAsync(I.dqinfo, H.q, (size_t)m * 16, hipMemcpyHostToDevice, D.up) != hipSuccess ||
+            hipMemcpyAsync(I.dmaxwin, H.mw, (size_t)m * 4, hipMemcpyHostToDevice, D.up) != hipSuccess ||
+            (H.hasPrior && hi > lo &&
+             hipMemcpyAsync(I.dprior, H.prior + (size_t)lo * K, (size_t)(hi - lo) * K * sizeof(mc_candidate), hipMemcpyHostToDevice, D.up) != hipSuccess) ||
+            hipEventRecord(I.upDone, D.up) != hipSuccess)
+            return ps_fail(ps, MC_ERR_HIP, "copy of a batch to the device failed");
+    }
+    return MC_OK;
+}
+
+// Main kernels of the batch (input k) on lane ln: every owner device runs its parts on it, all on the lane's stream of that device --
+// nothing here waits for a device (MC_DEFER_TAIL).
+int submit_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int k, int lowestRank)
+{
+    const uint32_t nd = (uint32_t)ps->devices.size(), np = (uint32_t)ps->cur.size(), m = H.count, owners = H.owners;
     std::vector<int> rcs(owners, MC_OK);
     std::vector<std::string> errs(owners);
     on_threads(owners, [&](uint32_t d) {
         DevState& D = ps->dev[d];
         DevLane& L = D.lane[ln];
-        auto bad = [&](const char* what) { rcs[d] = MC_ERR_HIP; errs[d] = what; };
-        if (hipSetDevice(D.device) != hipSuccess) return bad("hipSetDevice");
-        if (hipMemcpyAsync(L.dseq, H.seq, H.chars + 16, hipMemcpyHostToDevice, L.stream) != hipSuccess ||
-            hipMemcpyAsync(L.dqinfo, H.q, (size_t)m * 16, hipMemcpyHostToDevice, L.stream) != hipSuccess ||
-            hipMemcpyAsync(L.dmaxwin, H.mw, (size_t)m * 4, hipMemcpyHostToDevice, L.stream) != hipSuccess) return bad("copy of a batch to the device failed");
-        const uint32_t lo = share_lo(m, d, owners), hi = share_lo(m, d + 1, owners);
-        if (H.hasPrior && hi > lo &&
-            hipMemcpyAsync(L.dprior, H.prior + (size_t)lo * K, (size_t)(hi - lo) * K * sizeof(mc_candidate), hipMemcpyHostToDevice, L.stream) != hipSuccess)
-            return bad("copy of the earlier groups' lists to the device failed");
+        DevInput& I = D.in[k];
+        if (hipSetDevice(D.device) != hipSuccess || hipStreamWaitEvent(L.stream, I.upDone, 0) != hipSuccess) { rcs[d] = MC_ERR_HIP; errs[d] = "hipStreamWaitEvent"; return; }
         L.cands.clear();
         for (uint32_t p = d; p < np; p += nd) {
-            mc_device_batch in{L.dseq, L.dqinfo, L.dmaxwin, 0, m, H.chars};
+            mc_device_batch in{I.dseq, I.dqinfo, I.dmaxwin, 0, m, H.chars};
             mc_device_results res{};
             const int rc = mc_query_device(ps->cur[p], &in, lowestRank, MC_DEFER_TAIL | (ln ? MC_SECOND_PIPE : 0), &res, L.stream);
             if (rc) { rcs[d] = rc; errs[d] = mc_last_error(ps->cur[p]); return; }
@@ -450,7 +508,7 @@ int submit_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
 // The rest of the batch on lane ln, enqueued once its main kernels are through (mc_query_finish waits for them; the NEXT batch is
 // queued on the other lane by then): tails of the parts' queries, their top lists side by side in dmine, the exchange, the owners'
 // merges, every owner's share to the staging slot.
-int finish_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
+int finish_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int k, int lowestRank)
 {
     const uint32_t nd = (uint32_t)ps->devices.size(), np = (uint32_t)ps->cur.size(), K = ps->K, m = H.count, owners = H.owners;
     const size_t listBytes = ps->maxQ * K * sizeof(mc_candidate), row = K * sizeof(mc_candidate);
@@ -500,7 +558,7 @@ int finish_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
         if (hipSetDevice(D.device) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipSetDevice");
         if (cnt) {
             std::vector<const mc_candidate*> lists;
-            if (H.hasPrior) lists.push_back(L.dprior);
+            if (H.hasPrior) lists.push_back(D.in[k].dprior);
             for (uint32_t p = 0; p < np; ++p)
                 lists.push_back(ps->rccl ? reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(L.dall) + ((size_t)(p % nd) * ps->slotsPerDev + p / nd) * listBytes)
                                          : reinterpret_cast<const mc_candidate*>(reinterpret_cast<const char*>(L.dmine) + (size_t)(p / nd) * listBytes + (size_t)lo * row));
@@ -509,7 +567,7 @@ int finish_batch(mc_partset* ps, mc_partset::Staging& H, int ln, int lowestRank)
             if (hipMemcpyAsync(H.out + (size_t)lo * K, L.dout, (size_t)cnt * row, hipMemcpyDeviceToHost, L.stream) != hipSuccess)
                 return ps_fail(ps, MC_ERR_HIP, "copy of the merged candidates failed");
         }
-        if (hipEventRecord(H.outDone[d], L.stream) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipEventRecord");
+        if (hipEventRecord(H.outDone[d], L.stream) != hipSuccess || hipEventRecord(D.in[k].inFree, L.stream) != hipSuccess) return ps_fail(ps, MC_ERR_HIP, "hipEventRecord");
     }
     return MC_OK;
 }
@@ -529,7 +587,7 @@ int collect_batch(mc_partset* ps, mc_partset::Staging& H, const CallArgs& A, con
 
 void idle_devices(mc_partset* ps)
 {
-    for (DevState& D : ps->dev) { (void)hipSetDevice(D.device); for (DevLane& L : D.lane) (void)hipStreamSynchronize(L.stream); }
+    for (DevState& D : ps->dev) { (void)hipSetDevice(D.device); (void)hipStreamSynchronize(D.up); for (DevLane& L : D.lane) (void)hipStreamSynchronize(L.stream); }
 }
 
 }  // namespace
@@ -553,9 +611,13 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         const uint64_t l1 = offs[i + 1] - offs[i], l2 = seqs2 ? offs2[i + 1] - offs2[i] : 0;
         return (l1 + 3) / 4 * 4 + (l2 + 3) / 4 * 4;
     };
+    // (a call of several batches starts with a quarter and a half batch: the devices begin after a quarter of a batch's packing, and the
+    // first full batch is packed under work that is already there)
+    const bool ramp = n >= 3 * ps->maxQ;
     for (uint64_t i = 0; i < n;) {
         BatchRef b{i, 0, 0};
-        while (i < n && b.count < ps->maxQ && b.chars + need(i) <= ps->maxChars) { b.chars += need(i); ++b.count; ++i; }
+        const uint64_t cap = ramp && batches.size() < 2 ? std::max<uint64_t>(ps->maxQ >> (2 - batches.size()), 1) : ps->maxQ;
+        while (i < n && b.count < cap && b.chars + need(i) <= ps->maxChars) { b.chars += need(i); ++b.count; ++i; }
         if (b.count == 0) return ps_fail(ps, MC_ERR_INVALID, "mc_partset_classify: a read is longer than slot_max_chars");
         batches.push_back(b);
     }
@@ -596,11 +658,12 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
             }
         });
     int rc = MC_OK;
-    int laneOf[2] = {-1, -1};                                      // lanes of the batches in flight: [b & 1]
-    auto finish = [&](size_t b) -> int {                          // tail, exchange, merge, copy back of batch b; its lane goes back
+    int laneOf[2] = {-1, -1}, inputOf[2] = {-1, -1};               // lane and device input of the batches in flight: [b & 1]
+    auto finish = [&](size_t b) -> int {                          // tail, exchange, merge, copy back of batch b; its lane and input go back
         const uint64_t t0 = now_ns();
-        const int r = finish_batch(ps, ps->stg[slotOf[b]], laneOf[b & 1], lowestRank);
+        const int r = finish_batch(ps, ps->stg[slotOf[b]], laneOf[b & 1], inputOf[b & 1], lowestRank);
         give_lane(ps, laneOf[b & 1]); laneOf[b & 1] = -1;
+        give_input(ps, inputOf[b & 1]); inputOf[b & 1] = -1;      // (its next batch's upload waits for this one's reads on the device: inFree)
         tFinish += now_ns() - t0;
         if (!r) { { std::lock_guard<std::mutex> l(qMu); finished = b + 1; } qCv.notify_all(); }
         return r;
@@ -610,16 +673,24 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         const uint64_t t0 = now_ns();
         { std::unique_lock<std::mutex> l(qMu); qCv.wait(l, [&] { return packed > b; }); }
         const uint64_t t1 = now_ns();
-        int ln = take_lane(ps, false);
-        while (ln < 0 && !rc) {                                     // no free lane: my own oldest batch gives one back, else another caller will
+        // nothing is waited for while this caller holds a lane: its own oldest batch gives a lane and an input back, else another caller will
+        int k = take_input(ps, false);
+        while (k < 0 && !rc) {
+            if (inFlightFrom < b) { rc = finish(inFlightFrom++); if (!rc) k = take_input(ps, false); }
+            else k = take_input(ps, true);
+        }
+        if (rc) break;
+        rc = upload_batch(ps, ps->stg[slotOf[b]], k);              // (enqueued before anything below waits: it runs under the batch before)
+        int ln = rc ? -1 : take_lane(ps, false);
+        while (ln < 0 && !rc) {
             if (inFlightFrom < b) { rc = finish(inFlightFrom++); if (!rc) ln = take_lane(ps, false); }
             else ln = take_lane(ps, true);
         }
-        if (rc) break;
-        laneOf[b & 1] = ln;
-        rc = submit_batch(ps, ps->stg[slotOf[b]], ln, lowestRank);
+        if (rc) { give_input(ps, k); if (ln >= 0) give_lane(ps, ln); break; }
+        laneOf[b & 1] = ln; inputOf[b & 1] = k;
+        rc = submit_batch(ps, ps->stg[slotOf[b]], ln, k, lowestRank);
         tPackWait += t1 - t0; tSubmit += now_ns() - t1;
-        if (rc) { give_lane(ps, ln); laneOf[b & 1] = -1; break; }
+        if (rc) { give_lane(ps, ln); laneOf[b & 1] = -1; give_input(ps, k); inputOf[b & 1] = -1; break; }
         if (inFlightFrom < b) rc = finish(inFlightFrom++);          // the batch before this one: its kernels ran while this one was enqueued
     }
     const size_t submitted = rc ? inFlightFrom : nbt;
@@ -631,6 +702,7 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         if (rc) {                                                   // an error leaves nothing in flight and no slot taken
             idle_devices(ps);
             for (int& l : laneOf) if (l >= 0) { give_lane(ps, l); l = -1; }
+            for (int& k : inputOf) if (k >= 0) { give_input(ps, k); k = -1; }
         }
         collector.join();
         // (an error: the packer may be waiting for a slot -- the ones nobody will collect go back first; it packs one batch more at most)
@@ -649,7 +721,7 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
     } else {
         const uint64_t t0 = now_ns();
         if (!rc) rc = collect_batch(ps, ps->stg[slotOf[0]], A, batches[0]);
-        else { idle_devices(ps); for (int& l : laneOf) if (l >= 0) { give_lane(ps, l); l = -1; } }
+        else { idle_devices(ps); for (int& l : laneOf) if (l >= 0) { give_lane(ps, l); l = -1; } for (int& k : inputOf) if (k >= 0) { give_input(ps, k); k = -1; } }
         give_staging(ps, slotOf[0]);
         tCollect += now_ns() - t0;
     }

@@ -56,6 +56,40 @@ __global__ __launch_bounds__(256) void klist(const uint32_t* __restrict__ tab, u
     if (acc == 0x12345678u) out[tid] = acc;
     if (l16 == 0) { atomicAdd(touched, lines); atomicAdd(touched + 1, sectors); }
 }
+// Round 6: the DIRECT-ADDRESS index of SURVEY 7 as a benchmark -- 2^32 entries of 8 bytes (size | list index: 32 GiB), the feature IS the
+// index: one 8-byte load per lookup by ONE lane, no key compare, no chain; U lookups in flight per lane.  What the hash table's 40
+// requests per read (32 buckets + chains + the features' own lines) would become: 32.
+template <int U>
+__global__ __launch_bounds__(256) void kdirect(const uint2* __restrict__ tab, uint64_t nentries, uint32_t iters, uint32_t* __restrict__ out)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t h1 = mix32(tid * 0x9E3779B1u + (it * U + u) * 0x85EBCA77u + 999u), h2 = mix32(h1 ^ 0x5bd1e995u);
+            v[u] = tab[__umul64hi(((uint64_t)h1 << 32) | h2, nentries)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x ^ v[u].y;
+    }
+    if (acc == 0x12345678u) out[tid] = acc;
+}
+template <int U>
+double measure_direct(const uint4* tab, size_t bytes, uint32_t* out, int bpc)
+{
+    const uint32_t blocks = 256 * bpc, iters = 256 / U;
+    const uint64_t nentries = bytes / 8;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((kdirect<U>), dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const uint2*>(tab), nentries, 2u, out);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL((kdirect<U>), dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const uint2*>(tab), nentries, iters, out);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    return (double)blocks * 256 * iters * U / (ms * 1e-3);
+}
 template <int LANES, int U>
 double measure(const uint4* tab, size_t bytes, uint32_t* out, int bpc)
 {
@@ -95,6 +129,9 @@ int main(int argc, char** argv)
         printf("256B x16 lanes: U4 %.1f G units/s  (128B x8: %.1f; x 128 B / x 256 B = %.2f / %.2f TB/s)\n", measure<16, 4>(tab, bytes, out, 16) / 1e9,
                measure<8, 4>(tab, bytes, out, 16) / 1e9, measure<8, 4>(tab, bytes, out, 16) * 128 / 1e12, measure<16, 4>(tab, bytes, out, 16) * 256 / 1e12);
     }
+    for (int bpc : {8, 16, 32})
+        printf("direct-address index, 8-byte entries by one lane (bpc %d): U4 %.1f U8 %.1f U16 %.1f G lookups/s\n", bpc,
+               measure_direct<4>(tab, bytes, out, bpc) / 1e9, measure_direct<8>(tab, bytes, out, bpc) / 1e9, measure_direct<16>(tab, bytes, out, bpc) / 1e9);
     for (int bpc : {8, 16}) {
         printf("bpc %d: 16B x1 lane: U4 %.1f U8 %.1f | 32B x2 lanes: U4 %.1f U8 %.1f | 64B x4 lanes: U4 %.1f U8 %.1f | 128B x8 lanes: U4 %.1f U8 %.1f  (G units/s)\n", bpc,
                measure<1, 4>(tab, bytes, out, bpc) / 1e9, measure<1, 8>(tab, bytes, out, bpc) / 1e9,
