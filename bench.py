@@ -532,7 +532,7 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
 
     run()                                                    # (first touch of the pinned buffers by the device)
     el = min(run(), run())
-    up = sum(nbytes_in) / 1e9
+    up_gb = sum(nbytes_in) / 1e9
     down = steps * nloc * K * 16 / 1e9
     # the link alone: the same uploads back to back, nothing else on the device
     db.synchronize()
@@ -542,17 +542,15 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
             dev_in[i % 3][: nbytes_in[i]].copy_(host_in[i], non_blocking=True)
     torch.cuda.synchronize()
     link_s = time.perf_counter() - t0
-    # the last batch's candidates as they arrived on the host against the device's own copy
-    last = (steps - 1) & 1
     ms = el / steps * 1e3
     ratio = kernel_only_s / (el / steps)
-    out = {"ms_per_step": round(ms, 3), "Mreads_min": round(steps * nloc * per_read / el * 60 / 1e6, 1), "h2d_GBps": round(up / link_s, 1),
-           "h2d_GB_per_step": round(up / steps, 3), "d2h_GB_per_step": round(down / steps, 4), "over_kernel_only": round(ratio, 3),
+    out = {"ms_per_step": round(ms, 3), "Mreads_min": round(steps * nloc * per_read / el * 60 / 1e6, 1), "h2d_GBps": round(up_gb / link_s, 1),
+           "h2d_GB_per_step": round(up_gb / steps, 3), "d2h_GB_per_step": round(down / steps, 4), "over_kernel_only": round(ratio, 3),
            "staging_s": round(stage_s, 1), "host_ms_per_step_inside_the_calls": {k: round(v / steps * 1e3, 3) for k, v in trace.items()},
            "what": "the timed region's batches from pinned host memory: H2D of batch i+1 on an upload stream under batch i's kernels, candidates D2H to pinned memory, all inside the clock; best of 2"}
     if ratio < 0.8:
-        h2d_ms = up / steps / (up / link_s) * 1e3
-        out["bound"] = (f"PCIe: the upload alone takes {h2d_ms:.1f} ms per step at {up / link_s:.0f} GB/s" if h2d_ms > 0.8 * ms else
+        h2d_ms = link_s / steps * 1e3
+        out["bound"] = (f"PCIe: the upload alone takes {h2d_ms:.1f} ms per step at {up_gb / link_s:.0f} GB/s" if h2d_ms > 0.8 * ms else
                         f"neither the link ({h2d_ms:.1f} ms per step) nor the kernels ({kernel_only_s * 1e3:.1f}): the copies and the kernels do not overlap fully")
     del host_in, dev_in, host_out
     return out

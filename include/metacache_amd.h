@@ -182,6 +182,12 @@ int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* seq1, uint32_t len1, co
  * from the database's window stride (candidate_structs.hpp:143-145) and insert_size_max.  Returns the number of reads
  * added (< n when the slot is full: submit, wait, clear, continue with the rest) or a negative error. */
 int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const uint64_t* offsets, uint64_t n, uint64_t insert_size_max);
+/* How the slots reach the device.  With two or more slots (and top candidates only: copy_allhits = 0) submissions are QUEUED and a few
+ * dispatcher threads of the library take whatever is waiting as ONE device batch (slots of the reference's size -- 4 096 reads,
+ * options.hpp:229-232 -- are ~30 kernel launches and three host round trips for 0.1 ms of device work each; database_query.hpp:110-113
+ * orders the submissions with a mutex instead); MC_SLOT_COALESCE=0: every slot its own batch.  stats[0] = 1 if slots are united,
+ * [1] = united batches sent so far, [2] = slots they carried, [3] = dispatcher threads. */
+int mc_slot_stats(mc_ctx* ctx, uint64_t stats[4]);
 int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowest_rank);
 
 typedef struct {

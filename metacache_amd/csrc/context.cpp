@@ -26,8 +26,10 @@ thread_local std::string g_createError;
 
 // a helper thread that works on a context beside its owner (reserve_slot_pipes) must not write ctx->err: its failures stay its own
 static thread_local bool t_quietErrors = false;
+static thread_local std::string* t_errSink = nullptr;         // a dispatcher thread of the slot coalescer keeps its errors for the slots it carries
 int fail(mc_ctx* ctx, int code, const std::string& msg)
 {
+    if (t_errSink) { *t_errSink = msg; return code; }
     if (t_quietErrors) return code;
     if (ctx) ctx->err = msg; else g_createError = msg;
     return code;
@@ -227,6 +229,8 @@ void mc_config_default(mc_config* c)
 
 const char* mc_last_error(const mc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
 
+static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D);
+
 int mc_create(const mc_config* cfg, mc_ctx** out)
 {
     if (!cfg || !out) return fail(nullptr, MC_ERR_INVALID, "mc_create: null argument");
@@ -286,11 +290,35 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     }
     uint32_t npipes = std::min<uint32_t>(cfg->num_slots, 8);
     if (const char* e = std::getenv("MC_PIPES")) npipes = std::max(1, std::atoi(e));
+    // Slots that are submitted side by side go to the device as ONE batch (slot coalescer, below): several slots, top candidates only.
+    // MC_SLOT_COALESCE=0: every slot its own batch on a pipe it borrows, as before round 6.
+    ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits;
+    if (const char* e = std::getenv("MC_SLOT_COALESCE")) ctx->coalesce = ctx->coalesce && e[0] != '0';
+    if (ctx->coalesce) {
+        npipes = std::min<uint32_t>(npipes, 3);                    // dispatchers: one united batch each in flight
+        if (const char* e = std::getenv("MC_SLOT_DISPATCHERS")) npipes = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+        // what a united batch may hold: up to 2^18 reads (beyond that the kernels run at their large-batch rate anyway), character offsets are 32 bits
+        ctx->coMaxQueries = (uint32_t)std::max<uint64_t>(cfg->slot_max_queries, std::min<uint64_t>(1u << 18, (uint64_t)cfg->num_slots * cfg->slot_max_queries));
+        ctx->coMaxChars = std::max<uint64_t>(cfg->slot_max_chars, std::min<uint64_t>(1ull << 30, (uint64_t)cfg->num_slots * cfg->slot_max_chars));
+    }
     for (uint32_t i = 0; i < npipes && i < cfg->num_slots; ++i) {
         Pipe* p = new Pipe;
         ctx->pipes.push_back(p);
         if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { mc_destroy(ctx); return fail(nullptr, MC_ERR_HIP, "cannot create HIP stream"); }
-        ctx->freePipes.push_back(p);
+        if (!ctx->coalesce) ctx->freePipes.push_back(p);
+    }
+    if (ctx->coalesce) {
+        for (Pipe* p : ctx->pipes) {
+            auto* d = new mcamd::CoDispatcher;
+            d->pipe = p;
+            bool ok = true;
+            for (int k = 0; k < 2 && ok; ++k)
+                ok = hipHostMalloc((void**)&d->hq[k], (size_t)ctx->coMaxQueries * 16) == hipSuccess && hipHostMalloc((void**)&d->hmw[k], (size_t)ctx->coMaxQueries * 4) == hipSuccess &&
+                     hipEventCreateWithFlags(&d->staged[k], hipEventDisableTiming) == hipSuccess;
+            ctx->coDisp.push_back(d);
+            if (!ok) { mc_destroy(ctx); return fail(nullptr, MC_ERR_NOMEM, "cannot allocate the slot coalescer's staging"); }
+        }
+        for (auto* d : ctx->coDisp) d->th = std::thread(co_dispatch, ctx, d);
     }
     *out = ctx;
     return MC_OK;
@@ -303,6 +331,18 @@ void mc_destroy(mc_ctx* ctx)
                      (unsigned long long)g_trace[5].load(), g_trace[0] / 1e6, g_trace[1] / 1e6, g_trace[2] / 1e6, g_trace[3] / 1e6, (unsigned long long)g_trace[6].load(), g_trace[4] / 1e6);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (!ctx->coDisp.empty()) {                                     // the slot coalescer's dispatchers: let them finish what they carry, then go
+        { std::lock_guard<std::mutex> l(ctx->coMu); ctx->coStop = true; }
+        ctx->coCv.notify_all();
+        for (auto* d : ctx->coDisp) if (d->th.joinable()) d->th.join();
+        for (auto* d : ctx->coDisp) {
+            if (d->pipe && d->pipe->stream) (void)hipStreamSynchronize(d->pipe->stream);
+            for (int k = 0; k < 2; ++k) { if (d->hq[k]) (void)hipHostFree(d->hq[k]); if (d->hmw[k]) (void)hipHostFree(d->hmw[k]); if (d->staged[k]) (void)hipEventDestroy(d->staged[k]); }
+            for (DevBuf* b : {&d->dseq, &d->dqinfo, &d->dmaxwin}) if (b->p) (void)hipFree(b->p);
+            delete d;
+        }
+        ctx->coDisp.clear();
+    }
     // every stream that may still run kernels on the tables: the context's, both pipes', the slots' (callers' own streams: theirs to wait for)
     if (ctx->pipe0.tail.pending || ctx->pipe1.tail.pending) { ctx->pipe0.tail.pending = false; ctx->pipe1.tail.pending = false; }   // (a deferred tail nobody asked for is dropped)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -869,11 +909,11 @@ int mcamd::reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys)
         std::this_thread::sleep_for(std::chrono::microseconds(500));
     }
     const SketchParams sp = ctx->querySketch;
-    const uint32_t K = ctx->cfg.max_candidates, n = ctx->cfg.slot_max_queries;
+    const uint32_t K = ctx->cfg.max_candidates, n = ctx->coalesce ? ctx->coMaxQueries : ctx->cfg.slot_max_queries;   // (coalescer: a dispatcher's pipe takes a united batch)
     const bool wantAll = ctx->cfg.copy_allhits != 0;
     const bool lanePath = lane_path_supported(sp) && ctx->useLanePath && !wantAll && lane_candidates_supported(K);
     // (a slot of short reads: 152 characters each -- a slot filled with longer reads has fewer of them and grows its buffers as before)
-    const uint64_t chars = std::min<uint64_t>(ctx->cfg.slot_max_chars, (uint64_t)n * 152);
+    const uint64_t chars = std::min<uint64_t>(ctx->coalesce ? ctx->coMaxChars : ctx->cfg.slot_max_chars, (uint64_t)n * 152);
     int rc = MC_OK;
     for (Pipe* P : ctx->pipes) {
         PipeSizes sz{};
@@ -1491,6 +1531,18 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     // every slot has its own stream and device workspace: batches of different slots overlap on the device (the reference orders
     // submissions with a mutex and overlaps through per-batch CUDA streams, database_query.hpp:110-113, query_batch.cu)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->coalesce) {
+        // hand the slot to the dispatchers: whatever is waiting when one of them comes free goes to the device as ONE batch
+        S.submittedQueries = S.nq; S.coLowest = lowestRank; S.coRc = MC_OK; S.coEvent = false; S.coErr.clear();
+        S.submitted = true;
+        {
+            std::lock_guard<std::mutex> l(ctx->coMu);
+            if (S.nq == 0) S.coState = 3;
+            else { S.coState = 1; ctx->coPending.push_back(slot); }
+        }
+        if (S.nq) ctx->coCv.notify_one();
+        return MC_OK;
+    }
     const uint64_t tt0 = g_submitTrace ? trace_now() : 0;
     {
         std::unique_lock<std::mutex> lk(ctx->pipeMtx);
@@ -1540,6 +1592,97 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     return MC_OK;
 }
 
+// ---- slot coalescer -----------------------------------------------------------------------------------------------------------------
+// The reference's consumer threads submit batches of 4 096 reads (options.hpp:229-232) and order their submissions with a mutex
+// (database_query.hpp:110-113).  Here a batch of that size is ~30 kernel launches and three host round trips for ~0.1 ms of device
+// work: one batch per slot keeps the device waiting for the host.  So submissions are QUEUED, and a few dispatcher threads -- a pipe
+// each -- take whatever is waiting (same lowest rank, up to coMaxQueries reads) as ONE device batch: every slot's characters go to
+// their place in the united input (an H2D each, out of the slot's pinned buffer), the qinfo rows are rebased on the host, one
+// query_on_pipe, and every slot's candidates and statistics come back into its own pinned buffers (`done` behind them).  Under load
+// the united batches grow by themselves; a lone submitter pays a thread hand-over (~20 us).  Only these threads make HIP calls for
+// the slots -- dozens of host threads enqueueing on eight streams is what sends the runtime's direct dispatch into its slow state.
+static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D)
+{
+    (void)hipSetDevice(ctx->device);
+    std::string err;
+    t_errSink = &err;
+    Pipe& P = *D->pipe;
+    hipStream_t st = P.stream;
+    std::vector<uint32_t> mine;
+    const size_t K = ctx->cfg.max_candidates;
+    for (;;) {
+        mine.clear();
+        int lowest = 0;
+        {
+            std::unique_lock<std::mutex> l(ctx->coMu);
+            ctx->coCv.wait(l, [&] { return ctx->coStop || !ctx->coPending.empty(); });
+            if (ctx->coPending.empty()) return;                    // (stop: nothing is waiting any more)
+            uint64_t nq = 0, nc = 0;
+            lowest = ctx->slots[ctx->coPending.front()].coLowest;
+            while (!ctx->coPending.empty()) {
+                Slot& S = ctx->slots[ctx->coPending.front()];
+                if (!mine.empty() && (S.coLowest != lowest || nq + S.nq > ctx->coMaxQueries || nc + S.nchars + 16 > ctx->coMaxChars)) break;
+                nq += S.nq; nc += S.nchars;
+                S.coState = 2;
+                mine.push_back(ctx->coPending.front());
+                ctx->coPending.pop_front();
+            }
+            ctx->coBatches++; ctx->coSlots += mine.size();
+        }
+        uint64_t nq = 0, nc = 0;
+        for (uint32_t s : mine) { nq += ctx->slots[s].nq; nc += ctx->slots[s].nchars; }
+        int rc = MC_OK;
+        err.clear();
+        const uint32_t k = D->turn++ & 1u;
+        auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) { rc = MC_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
+        if (D->stagedUsed[k]) hip(hipEventSynchronize(D->staged[k]), "hipEventSynchronize");   // (two united batches ago: long through)
+        if (!rc) rc = ensure(ctx, D->dseq, nc + 64);
+        if (!rc) rc = ensure(ctx, D->dqinfo, nq * 16);
+        if (!rc) rc = ensure(ctx, D->dmaxwin, nq * 4);
+        if (!rc) {
+            uint64_t qb = 0, cb = 0;
+            uint32_t* hq = D->hq[k]; uint32_t* hmw = D->hmw[k];
+            for (uint32_t s : mine) {
+                Slot& S = ctx->slots[s];
+                hip(hipMemcpyAsync((uint8_t*)D->dseq.p + cb, S.hseq, S.nchars, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+                for (uint32_t j = 0; j < S.nq; ++j) {
+                    const uint32_t* q = S.hqinfo + (size_t)j * 4;
+                    uint32_t* o = hq + (qb + j) * 4;
+                    o[0] = q[0] + (uint32_t)cb; o[1] = q[1]; o[2] = q[2] + (uint32_t)cb; o[3] = q[3];
+                }
+                std::memcpy(hmw + qb, S.hmaxwin, (size_t)S.nq * 4);
+                qb += S.nq; cb += S.nchars;
+            }
+            hip(hipMemsetAsync((uint8_t*)D->dseq.p + cb, 0, 16, st), "hipMemsetAsync");
+            hip(hipMemcpyAsync(D->dqinfo.p, hq, nq * 16, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+            hip(hipMemcpyAsync(D->dmaxwin.p, hmw, nq * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+            hip(hipEventRecord(D->staged[k], st), "hipEventRecord");
+            D->stagedUsed[k] = true;
+        }
+        mc_device_results res{};
+        if (!rc) {
+            mc_device_batch in{(const uint8_t*)D->dseq.p, (const uint32_t*)D->dqinfo.p, (const uint32_t*)D->dmaxwin.p, 0, (uint32_t)nq, nc};
+            rc = query_on_pipe(ctx, P, &in, lowest, 0, &res, st);
+        }
+        if (!rc) {
+            uint64_t qb = 0;
+            for (uint32_t s : mine) {
+                Slot& S = ctx->slots[s];
+                hip(hipMemcpyAsync(S.hcands, (const mc_candidate*)res.cands + qb * K, (size_t)S.nq * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+                hip(hipMemcpyAsync(S.hqstat, (const QueryStat*)P.bQstat.p + qb, (size_t)S.nq * sizeof(QueryStat), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+                hip(hipEventRecord(S.done, st), "hipEventRecord");
+                qb += S.nq;
+            }
+        }
+        if (rc) (void)hipStreamSynchronize(st);                     // (whatever was enqueued is through before the slots' buffers go back to their owners)
+        {
+            std::lock_guard<std::mutex> l(ctx->coMu);
+            for (uint32_t s : mine) { Slot& S = ctx->slots[s]; S.coRc = rc; S.coErr = err; S.coEvent = rc == MC_OK; S.coState = 3; }
+        }
+        ctx->coDoneCv.notify_all();
+    }
+}
+
 static void release_pipe(mc_ctx* ctx, Slot& S)
 {
     if (!S.pipe) return;
@@ -1554,6 +1697,11 @@ int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
     if (!ctx || slot >= ctx->slots.size() || !out) return MC_ERR_INVALID;
     Slot& S = ctx->slots[slot];
     if (!S.submitted) return fail(ctx, MC_ERR_STATE, "mc_batch_wait: slot not submitted");
+    if (ctx->coalesce) {
+        { std::unique_lock<std::mutex> l(ctx->coMu); ctx->coDoneCv.wait(l, [&] { return S.coState == 3; }); }
+        if (S.coRc) return fail(ctx, S.coRc, S.coErr);
+        if (S.coEvent) HIP_TRY(ctx, hipEventSynchronize(S.done));
+    } else
     HIP_TRY(ctx, hipEventSynchronize(S.done));
     release_pipe(ctx, S);                                       // the results are in the slot's pinned buffers
     const uint32_t n = S.submittedQueries;
@@ -1572,11 +1720,23 @@ int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
     return MC_OK;
 }
 
+int mc_slot_stats(mc_ctx* ctx, uint64_t stats[4])
+{
+    if (!ctx || !stats) return MC_ERR_INVALID;
+    std::lock_guard<std::mutex> l(ctx->coMu);
+    stats[0] = ctx->coalesce ? 1 : 0; stats[1] = ctx->coBatches; stats[2] = ctx->coSlots; stats[3] = ctx->coDisp.size();
+    return MC_OK;
+}
+
 int mc_batch_clear(mc_ctx* ctx, uint32_t slot)
 {
     if (!ctx || slot >= ctx->slots.size()) return MC_ERR_INVALID;
     Slot& S = ctx->slots[slot];
-    if (S.submitted) (void)hipEventSynchronize(S.done);
+    if (S.submitted && ctx->coalesce) {
+        { std::unique_lock<std::mutex> l(ctx->coMu); ctx->coDoneCv.wait(l, [&] { return S.coState == 3; }); }
+        if (S.coEvent) (void)hipEventSynchronize(S.done);
+        S.coState = 0; S.coEvent = false;
+    } else if (S.submitted) (void)hipEventSynchronize(S.done);
     release_pipe(ctx, S);
     S.submitted = false; S.nq = 0; S.nchars = 0;
     return MC_OK;

@@ -6,6 +6,8 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <string>
@@ -79,6 +81,22 @@ struct Slot {
     bool submitted = false;
     uint32_t submittedQueries = 0;
     Pipe* pipe = nullptr;
+    // coalesced submission (context.cpp "slot coalescer"): 0 = not queued, 1 = waiting for a dispatcher, 2 = in a dispatcher's hands,
+    // 3 = enqueued on the device (`done` is recorded behind its copies back) or failed (coRc)
+    int coState = 0, coRc = 0, coLowest = 0;
+    bool coEvent = false;
+    std::string coErr;
+};
+
+// one dispatcher thread of the slot coalescer: a pipe of its own, the united batch's device input, pinned staging (twice) for the rebased qinfo rows
+struct CoDispatcher {
+    std::thread th;
+    Pipe* pipe = nullptr;
+    DevBuf dseq, dqinfo, dmaxwin;
+    uint32_t* hq[2] = {nullptr, nullptr}; uint32_t* hmw[2] = {nullptr, nullptr};
+    hipEvent_t staged[2] = {nullptr, nullptr};   // the staging set has left the host
+    bool stagedUsed[2] = {false, false};
+    uint32_t turn = 0;
 };
 
 // table_build: insert one chunk of a single-part database whose batch arrays already live in device memory
@@ -185,4 +203,14 @@ struct mc_ctx {
 
     // slots
     std::vector<mcamd::Slot> slots;
+    // slot coalescer: slots that are submitted while the dispatchers are busy go to the device TOGETHER, as one batch (a batch of the
+    // reference's size -- 4 096 reads -- is ~30 kernel launches and three host round trips for 0.1 ms of device work)
+    bool coalesce = false;
+    std::mutex coMu;
+    std::condition_variable coCv, coDoneCv;
+    std::deque<uint32_t> coPending;
+    std::vector<mcamd::CoDispatcher*> coDisp;
+    bool coStop = false;
+    uint32_t coMaxQueries = 0; uint64_t coMaxChars = 0;
+    uint64_t coBatches = 0, coSlots = 0;   // united batches sent, slots they held (mc_slot_stats)
 };

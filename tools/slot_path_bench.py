@@ -1,0 +1,104 @@
+"""The host slot API (mc_batch_add / submit / wait / clear: what the reference's consumer threads call, database_query.hpp:185-252) at the
+REFERENCE's batch size: 4 096 reads per batch (options.hpp:229-232: 8 192 windows), T threads with a slot each, on bench.py's collection.
+Reads start in ordinary host memory (mc_batch_add_bulk copies them into the slot's pinned buffer), every batch is H2D + kernels + D2H
+of its candidates.  Reported per (threads, batch size): Mreads/min, batches per second, and -- once -- that the candidates are the
+device path's.  Never bench.py's `value`.
+
+    python tools/slot_path_bench.py --scale 1 --threads 8,16,32 --batch 4096,65536 --out gpurun_out/r06_slot_path.json"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--reads", type=int, default=4_000_000)
+    ap.add_argument("--threads", default="8,16,32")
+    ap.add_argument("--batch", default="4096")
+    ap.add_argument("--seconds", type=float, default=3.0, help="per configuration")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    import torch
+    import bench
+    from metacache_amd import api, synthdb
+    c2 = dict(bench.CFG2); c2["genera"] = max(2, int(round(c2["genera"] * args.scale)))
+    spec = synthdb.phylogeny(**c2)
+    shards = max(1, int(np.ceil(spec.total_bases // 112 * 16 / 1.4e9)))
+    threads = [int(t) for t in args.threads.split(",")]
+    batches = [int(b) for b in args.batch.split(",")]
+    P = synthdb.read_params(spec, 3100)
+    rows = torch.zeros((args.reads, P.row_bytes), dtype=torch.uint8, device="cuda")
+    synthdb.GpuSynth(0).reads(spec, P, 0, args.reads, rows)
+    seqs = np.ascontiguousarray(rows[:, :150].cpu().numpy()).reshape(-1)
+    del rows
+    res = {"scale": args.scale, "Gbp": round(spec.total_bases / 1e9, 1), "reads_resident_on_the_host": args.reads, "runs": [],
+           "dispatch": os.environ.get("AMD_DIRECT_DISPATCH", "default"), "coalesce": os.environ.get("MC_SLOT_COALESCE", "default")}
+    L = api.lib()
+    db, _ = synthdb.build_database(spec, shards=shards, max_candidates=2, max_load_factor=0.3, num_slots=max(threads), slot_max_queries=max(batches),
+                                   slot_max_chars=max(batches) * 152 + 64, report=lambda m: print(m, file=sys.stderr, flush=True))
+    for B in batches:
+        offs = np.arange(B + 1, dtype=np.uint64) * np.uint64(150)
+        nb = args.reads // B
+        # the device path's candidates of the first batches: what every slot must deliver
+        want = db.query_bulk(seqs[: 150 * B * min(nb, 8)], np.arange(B * min(nb, 8) + 1, dtype=np.uint64) * np.uint64(150))
+        for T in threads:
+            stop = time.perf_counter() + args.seconds
+            done = [0] * T
+            bad = [0] * T
+            errs = []
+
+            def work(t):
+                out = api.McResults()
+                i = t
+                K = 2
+                try:
+                    while time.perf_counter() < stop:
+                        b = i % nb
+                        added = L.mc_batch_add_bulk(db.h, t, seqs[150 * B * b:].ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), B, 0)
+                        if added != B:
+                            raise RuntimeError(f"mc_batch_add_bulk: {added}")
+                        db._check(L.mc_batch_submit(db.h, t, 0))
+                        db._check(L.mc_batch_wait(db.h, t, C.byref(out)))
+                        if b < 8 and done[t] < 16:                 # (a few batches per thread are compared)
+                            got = api._view(out.cands, B * K, api.cand_dtype).reshape(B, K)
+                            bad[t] += int((got != want[b * B:(b + 1) * B]).any(axis=1).sum())
+                        db._check(L.mc_batch_clear(db.h, t))
+                        done[t] += 1
+                        i += T
+                except Exception as e:                             # noqa: BLE001
+                    errs.append(repr(e))
+
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            el = time.perf_counter() - t0
+            n = sum(done) * B
+            st = (C.c_uint64 * 4)()
+            L.mc_slot_stats.argtypes = [C.c_void_p, C.c_void_p]
+            L.mc_slot_stats(db.h, st)
+            run = {"slots_united": bool(st[0]), "united_batches_so_far": int(st[1]), "slots_carried_so_far": int(st[2]), "threads": T, "batch": B, "batches": sum(done), "seconds": round(el, 2), "Mreads_min": round(n / el * 60 / 1e6, 1),
+                   "batches_per_s": round(sum(done) / el), "us_per_batch_and_thread": round(el / max(1, max(done)) * 1e6), "reads_with_other_candidates": sum(bad), "errors": errs[:2]}
+            print(run, flush=True)
+            res["runs"].append(run)
+    db.close()
+    print(json.dumps(res))
+    if args.out:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
