@@ -169,7 +169,8 @@ def pmc_layout_matches(tag: str, layout: dict):
     if not os.path.exists(fn):
         return False, f"profiles/{tag}_layout.json missing: the summary does not say which table layout it saw"
     rec = json.load(open(fn))
-    for key, mine in (("table_location_bytes", layout["location_bytes"]), ("table_list_align", layout.get("list_align", 1))):
+    for key, mine in (("table_location_bytes", layout["location_bytes"]), ("table_list_align", layout.get("list_align", 1)),
+                      ("table_direct_index", bool(layout.get("direct_index", False)))):
         if rec.get(key) != mine:
             return False, f"profiles/{tag}_pmc_summary.csv was taken with {key} = {rec.get(key)}, this table has {mine}"
     return True, None
@@ -1047,6 +1048,7 @@ def main():
                          "algorithmic_bytes_per_launch": round(bytes_per_read * nloc * per_read),
                          "bytes_per_read": round(bytes_per_read, 1), "F": round(F, 3), "H": round(H, 3), "V": V,
                          "table_location_bytes": layout["location_bytes"], "table_list_align": layout.get("list_align", 1), "table_list_entries": layout["list_locations"],
+                         "table_direct_index": bool(layout.get("direct_index", False)),
                          "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}},
         }
         vals = [total_reads / e * 60.0 / 1e6 for e in repeats]

@@ -128,7 +128,10 @@ int mc_load_begin(mc_ctx* ctx, uint32_t part, uint64_t nkeys, uint64_t nvalues);
 int mc_load_target_windows(mc_ctx* ctx, const uint32_t* windows_per_target, uint64_t num_targets);
 /* the same announcement from bounds alone: targets 0 .. max_target_id with max_window_id + 1 windows each */
 int mc_load_location_range(mc_ctx* ctx, uint32_t max_target_id, uint32_t max_window_id);
-/* how the loaded table lies in HBM: layout[0] = bytes per stored location (8, or 4 with the compact store), [1] low 32 bits = the gap
+/* how the loaded table lies in HBM: layout[0] low 32 bits = bytes per stored location (8, or 4 with the compact store), bit 32 = 1 if the
+ * table has its DIRECT-ADDRESS INDEX (2^32 entries of 8 bytes beside the buckets -- the feature is the index, one request per lookup
+ * of the lane path instead of the buckets' 1.25; built at mc_load_end for single-part tables whose buckets take 8 GiB and more where
+ * 34 GB + head-room are free; mc_set_tuning "direct_index" 0 / 1 / -1, MC_DIRECT_INDEX), [1] low 32 bits = the gap
  * between two targets' window numbers in the compact form (0 otherwise), high 32 bits = the list alignment in entries (1, or 32 = every
  * list of the compact store begins on a 128-byte line: the loaders switch it on where the padded store stays below 1.5 x the plain one
  * and fits the device; mc_set_tuning "list_align" 0 / 1 / -1, MC_LIST_ALIGN), [2] = number of 64-byte buckets, [3] = entries of the list
@@ -408,6 +411,7 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
  * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart),
  * "gw_big_h" (reads beyond this many locations take the fine-block instance of the stream filter; default 32 768, 0 = none),
  * "lane_fusion" (sketching + lookups of the lane path in one kernel: -1 = on tables beyond 1 GiB (default), 0 / 1 = never / always),
+ * "direct_index" (-1 by table size, 0 / 1; on a loaded table the index is built or dropped at once: mc_table_layout),
  * "list_align" (before the table is loaded: the compact store's lists on 128-byte lines of their own, mc_table_layout).
  * Every value of every switch gives the same results (tests/test_gpu_variants.py and the variant loops of test_gpu_scale.py /
  * test_gpu_reference_midscale.py run them against the goldens, the oracle and the reference). */

@@ -369,7 +369,7 @@ class Database:
         """bytes per stored location (4 = compact store: global window numbers), gap between two targets' numbers, buckets, stored list locations (mc_table_layout)"""
         a = (C.c_uint64 * 4)()
         self._check(lib().mc_table_layout(self.h, a))
-        return {"location_bytes": int(a[0]), "window_gap": int(a[1]) & 0xFFFFFFFF, "list_align": int(a[1]) >> 32, "buckets": int(a[2]), "list_locations": int(a[3])}
+        return {"location_bytes": int(a[0]) & 0xFF, "direct_index": bool(int(a[0]) >> 32), "window_gap": int(a[1]) & 0xFFFFFFFF, "list_align": int(a[1]) >> 32, "buckets": int(a[2]), "list_locations": int(a[3])}
 
     def target_range(self) -> tuple:
         """[lo, hi): the targets whose locations this context holds (mc_target_range)"""

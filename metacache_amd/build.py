@@ -66,6 +66,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     build_cli(force=force, verbose=verbose)
     build_synth(force=force, verbose=verbose)
     build_gather_peak(force=force, verbose=verbose)
+    build_slot_driver(force=force, verbose=verbose)
     return LIB
 
 
@@ -107,6 +108,21 @@ def build_gather_peak(force: bool = False, verbose: bool = False) -> str:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return GATHER_LIB
+
+
+SLOTDRV_LIB = os.path.join(LIBDIR, "libmcslotdrv.so")
+
+
+def build_slot_driver(force: bool = False, verbose: bool = False) -> str:
+    """tools/slot_driver.cpp -> libmcslotdrv.so: host threads driving the slot API without an interpreter (measurement tool, tools/slot_path_bench.py)"""
+    src = os.path.join(ROOT, "tools", "slot_driver.cpp")
+    if force or _stale(SLOTDRV_LIB, [src, LIB, os.path.join(ROOT, "include", "metacache_amd.h")]):
+        cmd = ["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), src, "-o", SLOTDRV_LIB,
+               "-L", LIBDIR, "-lmetacache_amd", "-Wl,-rpath,$ORIGIN", "-pthread"]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SLOTDRV_LIB
 
 
 def build_cli(force: bool = False, verbose: bool = False) -> str:

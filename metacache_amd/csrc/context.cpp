@@ -264,6 +264,8 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (const char* e = std::getenv("MC_NO_LANE_PATH")) ctx->useLanePath = !(e[0] == '1');   // debugging aid
     if (const char* e = std::getenv("MC_LANE_FUSION")) ctx->fuseLane = e[0] == '1' ? 1 : 0;   // (default: by table size)
     ctx->listAlignWant = mcamd::open_hints().listAlign; ctx->listAlignShare = mcamd::open_hints().listAlignShare;
+    ctx->directWant = mcamd::open_hints().directIndex;
+    if (const char* e = std::getenv("MC_DIRECT_INDEX")) ctx->directWant = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_LIST_ALIGN")) ctx->listAlignWant = e[0] == '1' ? 1 : 0;   // (default: where the padded store is affordable)
     if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
@@ -350,7 +352,7 @@ void mc_destroy(mc_ctx* ctx)
     if (ctx->pipe1.stream) (void)hipStreamSynchronize(ctx->pipe1.stream);
     for (Pipe* p : ctx->pipes) if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (ctx->buildHold) { big_cache_hold(-1); ctx->buildHold = false; }   // (a table build that was abandoned before mc_build_table_end)
-    for (auto& p : ctx->parts) { if (p.dbuckets) (void)big_free(p.dbuckets); if (p.dvalues) (void)big_free(p.dvalues); }
+    for (auto& p : ctx->parts) { if (p.dbuckets) (void)big_free(p.dbuckets); if (p.dvalues) (void)big_free(p.dvalues); if (p.ddirect) (void)big_free(p.ddirect); }
     for (auto& kv : ctx->taxkeyDev) (void)hipFree(kv.second);
     if (ctx->dGwBase) (void)hipFree(ctx->dGwBase);
     if (ctx->dGwDir) (void)hipFree(ctx->dGwDir);
@@ -509,7 +511,7 @@ int mc_table_layout(const mc_ctx* ctx, uint64_t layout[4])
 {
     if (!ctx || !layout || ctx->parts.empty()) return MC_ERR_INVALID;
     const Part& T = ctx->parts[0];
-    layout[0] = T.compact ? 4 : 8; layout[1] = (T.compact ? ctx->gwGap : 0) | ((uint64_t)T.listAlign << 32); layout[2] = T.nbuckets; layout[3] = T.valuesStored;
+    layout[0] = (T.compact ? 4 : 8) | (T.ddirect ? 1ull << 32 : 0); layout[1] = (T.compact ? ctx->gwGap : 0) | ((uint64_t)T.listAlign << 32); layout[2] = T.nbuckets; layout[3] = T.valuesStored;
     return MC_OK;
 }
 
@@ -629,6 +631,34 @@ int mc_load_batch(mc_ctx* ctx, uint32_t part, const uint32_t* keys, const uint8_
     return MC_OK;
 }
 
+// The direct-address index of a finished single-part table (kernels.h DeviceTable::direct): 2^32 entries of 8 bytes = 32 GiB beside the
+// buckets.  Built where the lookups are bound by random requests -- bucket tables of 8 GiB and more -- and the device has the room
+// (the index, and 40 GB more for the batches' workspaces); "direct_index" 1 / MC_DIRECT_INDEX=1 asks for it whatever the table's
+// size, 0 never.  A payload that does not fit its 48 bits (targets or windows beyond 2^24 in a single location) drops it again.
+static int build_direct_index(mc_ctx* ctx)
+{
+    Part& T = ctx->parts[0];
+    if (T.ddirect || !T.dbuckets || ctx->directWant == 0) return MC_OK;
+    if (ctx->directWant < 0 && (uint64_t)T.nbuckets * sizeof(TableBucket) < (8ull << 30)) return MC_OK;
+    const size_t bytes = kDirectEntries * 8;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return MC_OK;
+    if (freeB < bytes + (ctx->directWant > 0 ? (4ull << 30) : (40ull << 30))) return MC_OK;
+    void* p = nullptr;
+    if (big_malloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return MC_OK; }
+    unsigned int* dflag = nullptr;
+    unsigned int flag = 1;
+    hipStream_t st = ctx->stream;
+    if (hipMalloc((void**)&dflag, 4) == hipSuccess && hipMemsetAsync(dflag, 0, 4, st) == hipSuccess && hipMemsetAsync(p, 0, bytes, st) == hipSuccess) {
+        launch_direct_index(T.dbuckets, T.nbuckets, (uint64_t*)p, dflag, st);
+        if (hipMemcpyAsync(&flag, dflag, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) flag = 1;
+    }
+    if (dflag) (void)hipFree(dflag);
+    if (flag) { (void)hipGetLastError(); (void)big_free(p); return MC_OK; }
+    T.ddirect = (uint64_t*)p;
+    return MC_OK;
+}
+
 int mc_load_end(mc_ctx* ctx, uint32_t part)
 {
     if (!ctx) return MC_ERR_INVALID;
@@ -651,6 +681,7 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
         if (c[3]) ctx->locRangeViolated = true;
         if (c[3]) return fail(ctx, MC_ERR_INVALID, "a location lies outside the range announced with mc_load_target_windows / mc_load_location_range");
         ctx->tableReady = true;
+        (void)build_direct_index(ctx);                            // (a lookup structure beside the buckets: not having it is not an error)
         return MC_OK;
     }
     if (T.hbuckets.empty()) { int rc = allocate_table(ctx); if (rc) return rc; }
@@ -999,6 +1030,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         tab.values = nullptr; tab.values32 = reinterpret_cast<const uint32_t*>(T.dvalues);
         tab.gwBase = ctx->dGwBase; tab.gwDir = ctx->dGwDir; tab.gwDirShift = ctx->gwDirShift; tab.gwGap = ctx->gwGap; tab.gwTargets = ctx->gwTargets;
     }
+    tab.direct = T.ddirect;                                       // (the lane path's lookups; every other kernel goes through the buckets)
 
     {
         ScopedTimer t(ctx, "plan", st);
@@ -1407,6 +1439,16 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
+    else if (n == "direct_index") {                                // before the table is loaded; on a loaded table: 0 drops the index, 1 / -1 builds it now (by the rules above)
+        ctx->directWant = value < 0 ? -1 : (value != 0);
+        if (ctx->tableReady && ctx->parts.size() == 1) {
+            Part& T = ctx->parts[0];
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            const bool wanted = value > 0 || (value < 0 && (uint64_t)T.nbuckets * sizeof(TableBucket) >= (8ull << 30));
+            if (!wanted && T.ddirect) { HIP_TRY(ctx, hipDeviceSynchronize()); (void)big_free(T.ddirect); T.ddirect = nullptr; }
+            else if (wanted) (void)build_direct_index(ctx);
+        }
+    }
     else if (n == "list_align") ctx->listAlignWant = value < 0 ? -1 : (value != 0);   // before the table is loaded: lists of the compact store on lines of their own
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)

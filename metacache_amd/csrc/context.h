@@ -56,6 +56,7 @@ struct Part {
     TableBucket* dbuckets = nullptr;
     uint64_t* dvalues = nullptr;    // compact: the same allocation holds uint32_t entries (global window numbers, kernels.h DeviceTable)
     uint64_t dvaluesCap = 0;
+    uint64_t* ddirect = nullptr;    // direct-address index (kernels.h DeviceTable::direct), built at mc_load_end where it pays and fits
     bool compact = false;
     uint32_t listAlign = 1;         // lists begin at multiples of this many entries (kernels.h list_alloc; kListAlign when the padded total was announced and fits)
     uint64_t expectStore = 0;       // entries of the store with the padding (0: unknown -> no alignment)
@@ -109,7 +110,7 @@ int load_chunk_device(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes,
 void announce_store(mc_ctx* ctx, uint64_t paddedEntries);
 // what the caller of mc_open_database / mc_create on THIS thread knows about the device's other tenants (partset.cpp): list alignment
 // default (-1 / 0 / 1, only where neither MC_LIST_ALIGN nor mc_set_tuning says otherwise) and the share of free memory its padding may take
-struct OpenHints { int listAlign = -1; double listAlignShare = 1.0; };
+struct OpenHints { int listAlign = -1; double listAlignShare = 1.0; int directIndex = -1; };
 OpenHints& open_hints();
 int allocate_values(mc_ctx* ctx);
 int allocate_buckets(mc_ctx* ctx, uint64_t nkeys);
@@ -185,6 +186,8 @@ struct mc_ctx {
     std::atomic<bool> loadSettled{false};  // mc_open_database: the files are through (or the load failed)
     double listAlignShare = 1.0;           // announce_store: the padding (padded - plain store) may take this share of the device's free memory; the part set driver
                                            // lowers it to 1 / (parts it still has to place on the device) -- mcamd::open_hints
+    int directWant = -1;                   // direct-address index beside the buckets: -1 = for tables whose buckets take 8 GiB and more, where 34 GB + head-room are free;
+                                           // 0 / 1 (mc_set_tuning "direct_index" before the table is loaded, MC_DIRECT_INDEX)
     int fuseLane = -1;                     // sketching + probing of the lane path in ONE kernel: -1 = where the lookups are quad-cooperative (tables beyond 1 GiB: the
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)

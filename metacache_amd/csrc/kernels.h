@@ -75,6 +75,11 @@ struct DeviceTable {
     // never another target's window.  values32 != nullptr selects the store (values is unused then); the inline singleton payloads of
     // the buckets keep the 8-byte form.  0xFFFFFFFF is never a stored number.
     const uint32_t* values32 = nullptr;
+    // DIRECT-ADDRESS INDEX (round 6): 2^32 entries of 8 bytes, the feature IS the index -- size (16 bits) | payload (48 bits:
+    // a list's first place in the store, or a single location as target (24) | window (24)); 0 = the feature is not in the table.
+    // One 8-byte request per lookup, no key compare, no chain (the buckets take 40 requests for a 150 bp read's 32 features; the box
+    // serves 47 x 10^9 requests a second whatever their width: tools/gather_width.hip).  Beside the buckets, which every other kernel keeps using.
+    const uint64_t* direct = nullptr;
     const uint32_t* gwBase = nullptr;     // [targets + 1]
     const uint32_t* gwDir = nullptr;      // [(gwBase[targets] >> gwDirShift) + 1]: the target whose numbers (gap included) hold block << gwDirShift
     uint32_t gwDirShift = 0, gwGap = 0, gwTargets = 0;
@@ -193,6 +198,11 @@ struct LoadFilter { uint32_t maxLocs, rmOver, shardIdx, shardCnt, align = 1; }; 
 constexpr uint32_t kListAlign = 32;
 __host__ __device__ inline uint32_t list_alloc(uint32_t size, uint32_t align) { return size > 1 ? (size + align - 1) / align * align : 0; }
 struct GwLayout { const uint32_t* base = nullptr; uint32_t targets = 0, gap = 0; };   // compact store: gwBase[targets + 1] (DeviceTable)
+// the direct-address index of a finished bucket table (DeviceTable::direct): every stored key's entry; *flag != 0: a payload does not fit 48 bits
+void launch_direct_index(const TableBucket* buckets, uint32_t nbuckets, uint64_t* direct, unsigned int* flag, hipStream_t st);
+constexpr uint64_t kDirectEntries = 1ull << 32;
+__host__ __device__ inline uint64_t direct_pack(uint32_t size, uint64_t pay) { return size == 1 ? (uint64_t)size | ((((pay >> 32) << 24) | (pay & 0xFFFFFFu)) << 16) : (uint64_t)size | (pay << 16); }
+__host__ __device__ inline uint64_t direct_payload(uint64_t e) { const uint64_t p = e >> 16; return (e & 0xFFFFu) == 1 ? ((p >> 24) << 32) | (p & 0xFFFFFFu) : p; }
 void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
                        unsigned long long* counters, hipStream_t st);
 void launch_table_insert(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, const uint32_t* fileOff,

@@ -1470,7 +1470,8 @@ constexpr uint32_t kLaneRow = kLaneHits + 1;                  // odd stride (in 
 constexpr uint32_t kLaneBlock = 128;
 
 // QUAD: quad-cooperative bucket fetches (tables beyond the reach of the infinity cache / TLBs), else lane-private 4 x 16-byte loads
-template <bool QUAD>
+// DIRECT: the lookups go to the direct-address index (DeviceTable::direct): one 8-byte load per feature, eight in flight per lane
+template <bool QUAD, bool DIRECT = false>
 __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32_t s, const DeviceTable& tab, const Workspace& ws, const uint32_t K,
                                                 const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands, const uint32_t q,
                                                 uint64_t* L, const bool valid)
@@ -1523,7 +1524,32 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
         const uint32_t i = e++ & 3u;
         return i == 0 ? fcache.x : i == 1 ? fcache.y : i == 2 ? fcache.z : fcache.w;
     };
-    if constexpr (QUAD) {
+    if constexpr (DIRECT) {
+        constexpr uint32_t kDirectU = 8;
+        while (e < nf) {
+            uint32_t f[kDirectU]; uint64_t ent[kDirectU];
+    #pragma unroll
+            for (uint32_t u = 0; u < kDirectU; ++u) {
+                f[u] = 0xFFFFFFFFu; ent[u] = 0;
+                if (e < nf) f[u] = next_feature();
+                if (f[u] != 0xFFFFFFFFu) { ++nfeat; ent[u] = tab.direct[f[u]]; }
+            }
+    #pragma unroll
+            for (uint32_t u = 0; u < kDirectU; ++u) {
+                if (f[u] == 0xFFFFFFFFu) continue;
+                ++nsteps;
+                const uint32_t size = (uint32_t)ent[u] & 0xFFFFu;
+                if (!size) continue;
+                const uint64_t pay = direct_payload(ent[u]);
+                ++nfound;
+                H += size;
+                if (!over && n + m >= kLaneHits) { dump_row(); over = true; }      // (as below: the row moves to the hand-over area)
+                if (over) { put_entry(size | (goff << 16), pay); goff += size; }
+                else if (size == 1) L[n++] = pay;
+                else { L[kLaneHits - m] = pay | ((uint64_t)size << 48); ++m; }
+            }
+        }
+    } else if constexpr (QUAD) {
         uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU];
         QuadRaw raw[kLaneU];
         bool busy[kLaneU];
@@ -1791,20 +1817,20 @@ __device__ __forceinline__ void probe_cands_one(const BatchView& b, const uint32
     ws.qflag[q] = kFlagDone;
 }
 
-template <bool QUAD>
+template <bool QUAD, bool DIRECT = false>
 __global__ __launch_bounds__(kLaneBlock) void probe_cands_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws, uint32_t K,
                                                                  const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
     __shared__ uint64_t lst[kLaneBlock * kLaneRow];
     const uint32_t q = blockIdx.x * kLaneBlock + threadIdx.x;
     const bool valid = q < b.n && ws.qflag[q] == kFlagProbe;
-    probe_cands_one<QUAD>(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, valid);
+    probe_cands_one<QUAD, DIRECT>(b, s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, valid);
 }
 
 // Both halves in one kernel: sketching is ALU work (rolling k-mers, hash, 16-entry insertion chain), probing is waiting for random
 // HBM lines; with waves of one CU in different phases the two overlap instead of running one after the other.  The window
 // sketches still go through ws.features (a lane reads back what it wrote itself; they are also the MC_WANT_FEATURES output).
-template <bool QUAD>
+template <bool QUAD, bool DIRECT = false>
 __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView b, SketchParams sp, DeviceTable tab, Workspace ws, uint32_t K,
                                                                        const uint32_t* __restrict__ taxkey, mc_candidate_dev* __restrict__ cands)
 {
@@ -1817,7 +1843,7 @@ __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView
         if (flag != kFlagProbe) ws.qflag[q] = flag;
     }
     __threadfence_block();                                        // own feature stores before own feature loads
-    probe_cands_one<QUAD>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
+    probe_cands_one<QUAD, DIRECT>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
 }
 
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
@@ -1825,7 +1851,9 @@ void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const 
 {
     if (b.n == 0) return;
     const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
-    if (quad) hipLaunchKernelGGL(sketch_probe_lane_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
+    if (tab.direct) hipLaunchKernelGGL((sketch_probe_lane_kernel<false, true>), dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
+                                       taxkey, (mc_candidate_dev*)cands);
+    else if (quad) hipLaunchKernelGGL(sketch_probe_lane_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
                                  taxkey, (mc_candidate_dev*)cands);
     else      hipLaunchKernelGGL(sketch_probe_lane_kernel<false>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp, tab, ws, maxCand,
                                  taxkey, (mc_candidate_dev*)cands);
@@ -1935,7 +1963,9 @@ void launch_probe_cands(const BatchView& b, const SketchParams& sp, const Device
     if (b.n == 0) return;
     // tables that reach beyond the infinity cache and the TLBs: quad-cooperative bucket fetches (see quad_issue)
     const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
-    if (quad) hipLaunchKernelGGL(probe_cands_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
+    if (tab.direct) hipLaunchKernelGGL((probe_cands_kernel<false, true>), dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
+                                       taxkey, (mc_candidate_dev*)cands);
+    else if (quad) hipLaunchKernelGGL(probe_cands_kernel<true>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
                                  taxkey, (mc_candidate_dev*)cands);
     else      hipLaunchKernelGGL(probe_cands_kernel<false>, dim3((b.n + kLaneBlock - 1) / kLaneBlock), dim3(kLaneBlock), 0, st, b, sp.s, tab, ws, maxCand,
                                  taxkey, (mc_candidate_dev*)cands);

@@ -153,6 +153,7 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
             // resident one): plain stores; all parts resident: the padding may take its share of what is free.
             const uint32_t mine = (count - d + nd - 1) / nd, placed = i / nd;
             mcamd::open_hints().listAlign = ps->resident < ps->nparts ? 0 : -1;
+            mcamd::open_hints().directIndex = 0;                     // (32 GiB per table: not beside other tenants)
             mcamd::open_hints().listAlignShare = 1.0 / (double)std::max<uint32_t>(1, mine - std::min(placed, mine - 1));
             const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
             mcamd::open_hints() = mcamd::OpenHints{};

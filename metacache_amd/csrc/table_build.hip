@@ -131,6 +131,25 @@ __global__ __launch_bounds__(256) void table_values_kernel(const uint32_t* __res
 
 }  // namespace
 
+// direct-address index: one thread per bucket slot, a scattered 8-byte store per stored key
+__global__ __launch_bounds__(256) void direct_index_kernel(const TableBucket* __restrict__ buckets, uint32_t nbuckets, uint64_t* __restrict__ direct, unsigned int* flag)
+{
+    const uint64_t total = (uint64_t)nbuckets * kSlotsPerBucket;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const TableBucket& B = buckets[i >> 2];
+        const uint32_t slot = (uint32_t)i & 3u, size = B.size[slot];
+        if (size == 0) continue;
+        const uint64_t pay = B.payload[slot];
+        const bool fits = size == 1 ? ((pay >> 32) < (1u << 24) && (uint32_t)pay < (1u << 24)) : (pay >> 48) == 0;
+        if (!fits) { atomicOr(flag, 1u); continue; }
+        direct[B.key[slot]] = direct_pack(size, pay);
+    }
+}
+void launch_direct_index(const TableBucket* buckets, uint32_t nbuckets, uint64_t* direct, unsigned int* flag, hipStream_t st)
+{
+    if (nbuckets) hipLaunchKernelGGL(direct_index_kernel, dim3(256 * 32), dim3(256), 0, st, buckets, nbuckets, direct, flag);
+}
+
 void launch_table_prep(const uint32_t* keys, const uint8_t* sizes, uint32_t n, LoadFilter lf, uint32_t* fileSz, uint32_t* storeSz,
                        unsigned long long* counters, hipStream_t st)
 {

@@ -83,7 +83,7 @@ if line:
     except Exception:
         head = None
     with open(os.path.join(dst, f"{tag}_layout.json"), "w") as f:
-        json.dump({"table_location_bytes": rf["table_location_bytes"], "table_list_align": rf["table_list_align"], "table_list_entries": rf["table_list_entries"],
+        json.dump({"table_location_bytes": rf["table_location_bytes"], "table_list_align": rf["table_list_align"], "table_list_entries": rf["table_list_entries"], "table_direct_index": rf.get("table_direct_index", False),
                    "workload": line["config"]["workload"], "reads_per_step_per_gpu": line["config"]["reads_per_step_per_gpu"], "pairs": line["config"]["pairs"],
                    "ms_per_step_under_the_tracer": line["ms_per_step"], "kernel_ms_under_the_tracer": rf["kernel_ms"], "head": head,
                    "command": "scripts/profile.sh " + tag + " (bench.py --steps 4 --warmup 2 --cpu-seconds 0 --repeats 1 ...)"}, f, indent=1)

@@ -58,8 +58,10 @@ VARIANTS = {
     "lane_fusion_private": {"lane_fusion": 1, "quad_lookup": 0},    # sketch_probe_lane_kernel<false>
     "apart": {"lane_fusion": 0, "quad_lookup": 0},                  # sketch_lane + probe_cands<false> + gw_filter_count
     "apart_quad_unfused_count": {"lane_fusion": 0, "quad_lookup": 1, "gw_fuse": 0},   # ... probe_cands<true>, gw_filter + gw_count apart
+    "direct_index_fused": {"direct_index": 1, "lane_fusion": 1},    # sketch_probe_lane_kernel<false, true>: lookups in the direct-address index (32 GiB beside the buckets)
+    "direct_index_apart": {"direct_index": 1, "lane_fusion": 0},    # sketch_lane + probe_cands<false, true>
 }
-_DEFAULTS = {"lane_fusion": -1, "quad_lookup": -1, "gw_fuse": 1}
+_DEFAULTS = {"lane_fusion": -1, "quad_lookup": -1, "gw_fuse": 1, "direct_index": -1}
 
 
 def each_variant(db, names=None):

@@ -10,7 +10,6 @@ import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -44,6 +43,9 @@ def main():
     res = {"scale": args.scale, "Gbp": round(spec.total_bases / 1e9, 1), "reads_resident_on_the_host": args.reads, "runs": [],
            "dispatch": os.environ.get("AMD_DIRECT_DISPATCH", "default"), "coalesce": os.environ.get("MC_SLOT_COALESCE", "default")}
     L = api.lib()
+    from metacache_amd import build
+    drv = C.CDLL(build.build_slot_driver())
+    drv.mc_slot_drive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p, C.c_uint64, C.c_void_p]
     db, _ = synthdb.build_database(spec, shards=shards, max_candidates=2, max_load_factor=0.3, num_slots=max(threads), slot_max_queries=max(batches),
                                    slot_max_chars=max(batches) * 152 + 64, report=lambda m: print(m, file=sys.stderr, flush=True))
     for B in batches:
@@ -52,45 +54,16 @@ def main():
         # the device path's candidates of the first batches: what every slot must deliver
         want = db.query_bulk(seqs[: 150 * B * min(nb, 8)], np.arange(B * min(nb, 8) + 1, dtype=np.uint64) * np.uint64(150))
         for T in threads:
-            stop = time.perf_counter() + args.seconds
-            done = [0] * T
-            bad = [0] * T
-            errs = []
-
-            def work(t):
-                out = api.McResults()
-                i = t
-                K = 2
-                try:
-                    while time.perf_counter() < stop:
-                        b = i % nb
-                        added = L.mc_batch_add_bulk(db.h, t, seqs[150 * B * b:].ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), B, 0)
-                        if added != B:
-                            raise RuntimeError(f"mc_batch_add_bulk: {added}")
-                        db._check(L.mc_batch_submit(db.h, t, 0))
-                        db._check(L.mc_batch_wait(db.h, t, C.byref(out)))
-                        if b < 8 and done[t] < 16:                 # (a few batches per thread are compared)
-                            got = api._view(out.cands, B * K, api.cand_dtype).reshape(B, K)
-                            bad[t] += int((got != want[b * B:(b + 1) * B]).any(axis=1).sum())
-                        db._check(L.mc_batch_clear(db.h, t))
-                        done[t] += 1
-                        i += T
-                except Exception as e:                             # noqa: BLE001
-                    errs.append(repr(e))
-
-            t0 = time.perf_counter()
-            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            el = time.perf_counter() - t0
+            o = (C.c_uint64 * 4)()
+            wantc = np.ascontiguousarray(want)
+            rc = drv.mc_slot_drive(db.h, seqs.ctypes.data_as(C.c_void_p), args.reads, 150, B, T, C.c_double(args.seconds), wantc.ctypes.data_as(C.c_void_p), len(wantc), o)
+            done, bad, errs, el = [int(o[0])], [int(o[1])], ([f"rc {rc}, {int(o[2])} threads failed: " + L.mc_last_error(db.h).decode()] if rc else []), o[3] / 1e6
             n = sum(done) * B
             st = (C.c_uint64 * 4)()
             L.mc_slot_stats.argtypes = [C.c_void_p, C.c_void_p]
             L.mc_slot_stats(db.h, st)
             run = {"slots_united": bool(st[0]), "united_batches_so_far": int(st[1]), "slots_carried_so_far": int(st[2]), "threads": T, "batch": B, "batches": sum(done), "seconds": round(el, 2), "Mreads_min": round(n / el * 60 / 1e6, 1),
-                   "batches_per_s": round(sum(done) / el), "us_per_batch_and_thread": round(el / max(1, max(done)) * 1e6), "reads_with_other_candidates": sum(bad), "errors": errs[:2]}
+                   "batches_per_s": round(sum(done) / el), "us_per_batch_and_thread": round(el / max(1, sum(done)) * T * 1e6), "reads_with_other_candidates": sum(bad), "errors": errs[:2]}
             print(run, flush=True)
             res["runs"].append(run)
     db.close()
