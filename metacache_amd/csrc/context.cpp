@@ -297,7 +297,8 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits;
     if (const char* e = std::getenv("MC_SLOT_COALESCE")) ctx->coalesce = ctx->coalesce && e[0] != '0';
     if (ctx->coalesce) {
-        npipes = std::min<uint32_t>(npipes, 3);                    // dispatchers: one united batch each in flight
+        // dispatchers: one united batch each in flight -- as many as there were pipes (up to 8): few submitters find a free one at once
+        // (their slots go alone, as before), many find them busy and their slots wait together
         if (const char* e = std::getenv("MC_SLOT_DISPATCHERS")) npipes = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
         // what a united batch may hold: up to 2^18 reads (beyond that the kernels run at their large-batch rate anyway), character offsets are 32 bits
         ctx->coMaxQueries = (uint32_t)std::max<uint64_t>(cfg->slot_max_queries, std::min<uint64_t>(1u << 18, (uint64_t)cfg->num_slots * cfg->slot_max_queries));
@@ -1704,7 +1705,11 @@ static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D)
         mc_device_results res{};
         if (!rc) {
             mc_device_batch in{(const uint8_t*)D->dseq.p, (const uint32_t*)D->dqinfo.p, (const uint32_t*)D->dmaxwin.p, 0, (uint32_t)nq, nc};
-            rc = query_on_pipe(ctx, P, &in, lowest, 0, &res, st);
+            // (deferred tail, finished at once: the main kernels go out without a look at the work lists' counters -- two host round
+            // trips less per united batch, a few empty launches more; MC_SLOT_DEFER=0: the synchronous call)
+            static const bool defer = [] { const char* e = std::getenv("MC_SLOT_DEFER"); return !e || e[0] != '0'; }();
+            rc = query_on_pipe(ctx, P, &in, lowest, defer ? MC_DEFER_TAIL : 0, &res, st);
+            if (!rc && defer) rc = finish_on_pipe(ctx, P);
         }
         if (!rc) {
             uint64_t qb = 0;

@@ -30,7 +30,9 @@ def test_golden_reads_every_variant(golden, name, big_min):
             db.timing_reset()
             cands, counts, _ = db.query(single, lowest=low, insert_max=ins)
             ran = {k: db.timing_get(k)[1] for k in ("sketch_probe", "probe_cands", "sketch_lane", "gw_filter", "gw_filter_count")}
-            assert (ran["sketch_probe"] > 0) == v.startswith("lane_fusion") and (ran["probe_cands"] > 0) == v.startswith("apart"), (v, ran)
+            fused, apart = v.startswith("lane_fusion") or v.endswith("_fused"), v.startswith("apart") or v.endswith("_apart")
+            assert (ran["sketch_probe"] > 0) == fused and (ran["probe_cands"] > 0) == apart, (v, ran)
+            assert db.table_layout()["direct_index"] == v.startswith("direct_index"), v
             assert (ran["gw_filter"] > 0) == (v == "apart_quad_unfused_count"), (v, ran)
             for i in range(len(single)):
                 assert cands_equal(cands[i], exp[i][:mc]), (v, rname, i, cands[i], exp[i])
