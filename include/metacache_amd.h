@@ -191,6 +191,10 @@ int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const ui
  * orders the submissions with a mutex instead); MC_SLOT_COALESCE=0: every slot its own batch.  stats[0] = 1 if slots are united,
  * [1] = united batches sent so far, [2] = slots they carried, [3] = dispatcher threads. */
 int mc_slot_stats(mc_ctx* ctx, uint64_t stats[4]);
+/* "" or what the library has noticed about the HIP runtime in this process: the slot paths time their enqueue-only calls, and when these
+ * take milliseconds apiece (the runtime's direct dispatch under many submitting threads: 3-4 x slower query phases at 150 Gbp)
+ * the text names the remedy -- AMD_DIRECT_DISPATCH=0 in the process' environment before it starts.  Also printed once to stderr. */
+const char* mc_runtime_warning(void);
 int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowest_rank);
 
 typedef struct {

@@ -61,6 +61,31 @@ static const bool g_submitTrace = std::getenv("MC_SUBMIT_TRACE") != nullptr;
 static std::atomic<uint64_t> g_trace[8];   // ns: [0] waiting for a free pipe, [1] enqueueing H2D, [2] query_on_pipe in all, [3] of it inside hipStreamSynchronize,
                                            //     [4] enqueueing D2H; [5] batches, [6] hipStreamSynchronize calls
 static inline uint64_t trace_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+
+// ---- the runtime's slow submission state: calls that only ENQUEUE -- hipMemcpyAsync of a pinned buffer -- take milliseconds
+// apiece once the HIP runtime's direct dispatch (AMD_DIRECT_DISPATCH, on by default) has gone into it, process by process, under many
+// submitting threads.  The slot paths time exactly these calls (two clock reads per batch); a window of 32 batches whose enqueues
+// averaged more than 0.5 ms each leaves a warning that names the switch: mc_runtime_warning(), and one line on stderr.
+static std::atomic<uint64_t> g_enqNs{0}, g_enqCalls{0}, g_enqBatches{0};
+static std::atomic<bool> g_enqWarned{false};
+static std::mutex g_warnMu;
+static std::string g_warning;
+static void note_enqueues(uint64_t ns, uint32_t calls)
+{
+    if (g_enqWarned.load(std::memory_order_relaxed)) return;
+    const uint64_t n = g_enqNs.fetch_add(ns) + ns, c = g_enqCalls.fetch_add(calls) + calls, b = g_enqBatches.fetch_add(1) + 1;
+    if (b < 32) return;
+    g_enqNs = 0; g_enqCalls = 0; g_enqBatches = 0;                 // (windows: racing updates only blur a window's edge)
+    if (c == 0 || n / c < 500000ull) return;
+    const char* dd = std::getenv("AMD_DIRECT_DISPATCH");
+    if (dd && dd[0] == '0') return;                               // (already off: something else is slow)
+    if (g_enqWarned.exchange(true)) return;
+    char msg[400];
+    std::snprintf(msg, sizeof msg, "metacache_amd: HIP calls that only enqueue (hipMemcpyAsync of pinned batches) take %.1f ms each in this process -- the HIP runtime's direct "
+                  "dispatch does this under many submitting threads; start the process with AMD_DIRECT_DISPATCH=0 (the runtime reads it before main)", (double)(n / c) / 1e6);
+    { std::lock_guard<std::mutex> l(g_warnMu); g_warning = msg; }
+    std::fprintf(stderr, "%s\n", msg);
+}
 static hipError_t traced_sync(hipStream_t st)
 {
     if (!g_submitTrace) return hipStreamSynchronize(st);
@@ -230,6 +255,7 @@ void mc_config_default(mc_config* c)
 const char* mc_last_error(const mc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
 
 static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D);
+static void co_run(mc_ctx* ctx, mcamd::CoDispatcher* D, const std::vector<uint32_t>& mine, int lowest);
 
 int mc_create(const mc_config* cfg, mc_ctx** out)
 {
@@ -321,6 +347,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
             ctx->coDisp.push_back(d);
             if (!ok) { mc_destroy(ctx); return fail(nullptr, MC_ERR_NOMEM, "cannot allocate the slot coalescer's staging"); }
         }
+        ctx->coFree = ctx->coDisp;
         for (auto* d : ctx->coDisp) d->th = std::thread(co_dispatch, ctx, d);
     }
     *out = ctx;
@@ -1578,12 +1605,24 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
         // hand the slot to the dispatchers: whatever is waiting when one of them comes free goes to the device as ONE batch
         S.submittedQueries = S.nq; S.coLowest = lowestRank; S.coRc = MC_OK; S.coEvent = false; S.coErr.clear();
         S.submitted = true;
+        mcamd::CoDispatcher* D = nullptr;
         {
             std::lock_guard<std::mutex> l(ctx->coMu);
             if (S.nq == 0) S.coState = 3;
+            else if (ctx->coPending.empty() && !ctx->coFree.empty()) {
+                // nothing is waiting and a pipe is free: this slot goes out now, on the submitter's own thread -- no hand-over (a lone
+                // submitter's batch takes what it took before there was a coalescer)
+                D = ctx->coFree.back(); ctx->coFree.pop_back();
+                S.coState = 2;
+                ctx->coBatches++; ctx->coSlots++;
+            }
             else { S.coState = 1; ctx->coPending.push_back(slot); }
         }
-        if (S.nq) ctx->coCv.notify_one();
+        if (D) {
+            co_run(ctx, D, std::vector<uint32_t>{slot}, lowestRank);
+            { std::lock_guard<std::mutex> l(ctx->coMu); ctx->coFree.push_back(D); }
+            ctx->coCv.notify_one();
+        } else if (S.nq) ctx->coCv.notify_one();
         return MC_OK;
     }
     const uint64_t tt0 = g_submitTrace ? trace_now() : 0;
@@ -1603,9 +1642,11 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     const uint32_t n = S.nq;
     S.submittedQueries = n;
     if (n == 0) { HIP_TRY(ctx, hipEventRecord(S.done, st)); S.submitted = true; return MC_OK; }
+    const uint64_t te0 = trace_now();
     HIP_TRY(ctx, hipMemcpyAsync(S.dseq, S.hseq, S.nchars + 16, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(S.dqinfo, S.hqinfo, (size_t)n * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(S.dmaxwin, S.hmaxwin, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    note_enqueues(trace_now() - te0, 3);
     mc_device_batch in{S.dseq, S.dqinfo, S.dmaxwin, 0, n, S.nchars};
     mc_device_results res{};
     const int wantAll = ctx->cfg.copy_allhits ? 1 : 0;
@@ -1644,34 +1685,54 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
 // query_on_pipe, and every slot's candidates and statistics come back into its own pinned buffers (`done` behind them).  Under load
 // the united batches grow by themselves; a lone submitter pays a thread hand-over (~20 us).  Only these threads make HIP calls for
 // the slots -- dozens of host threads enqueueing on eight streams is what sends the runtime's direct dispatch into its slow state.
-static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D)
+// takes what is waiting (front of the queue, one lowest rank, up to the united batch's limits); coMu held
+static void co_take(mc_ctx* ctx, std::vector<uint32_t>& mine, int& lowest)
+{
+    uint64_t nq = 0, nc = 0;
+    lowest = ctx->slots[ctx->coPending.front()].coLowest;
+    while (!ctx->coPending.empty()) {
+        Slot& S = ctx->slots[ctx->coPending.front()];
+        if (!mine.empty() && (S.coLowest != lowest || nq + S.nq > ctx->coMaxQueries || nc + S.nchars + 16 > ctx->coMaxChars)) break;
+        nq += S.nq; nc += S.nchars;
+        S.coState = 2;
+        mine.push_back(ctx->coPending.front());
+        ctx->coPending.pop_front();
+    }
+    ctx->coBatches++; ctx->coSlots += mine.size();
+}
+static void co_run(mc_ctx* ctx, mcamd::CoDispatcher* D, const std::vector<uint32_t>& mine, int lowest);
+
+static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher*)
 {
     (void)hipSetDevice(ctx->device);
-    std::string err;
-    t_errSink = &err;
-    Pipe& P = *D->pipe;
-    hipStream_t st = P.stream;
     std::vector<uint32_t> mine;
-    const size_t K = ctx->cfg.max_candidates;
     for (;;) {
         mine.clear();
         int lowest = 0;
+        mcamd::CoDispatcher* D = nullptr;
         {
             std::unique_lock<std::mutex> l(ctx->coMu);
-            ctx->coCv.wait(l, [&] { return ctx->coStop || !ctx->coPending.empty(); });
+            ctx->coCv.wait(l, [&] { return (ctx->coStop && ctx->coPending.empty()) || (!ctx->coPending.empty() && !ctx->coFree.empty()); });
             if (ctx->coPending.empty()) return;                    // (stop: nothing is waiting any more)
-            uint64_t nq = 0, nc = 0;
-            lowest = ctx->slots[ctx->coPending.front()].coLowest;
-            while (!ctx->coPending.empty()) {
-                Slot& S = ctx->slots[ctx->coPending.front()];
-                if (!mine.empty() && (S.coLowest != lowest || nq + S.nq > ctx->coMaxQueries || nc + S.nchars + 16 > ctx->coMaxChars)) break;
-                nq += S.nq; nc += S.nchars;
-                S.coState = 2;
-                mine.push_back(ctx->coPending.front());
-                ctx->coPending.pop_front();
-            }
-            ctx->coBatches++; ctx->coSlots += mine.size();
+            D = ctx->coFree.back(); ctx->coFree.pop_back();
+            co_take(ctx, mine, lowest);
         }
+        co_run(ctx, D, mine, lowest);
+        { std::lock_guard<std::mutex> l(ctx->coMu); ctx->coFree.push_back(D); }
+        ctx->coCv.notify_one();                                     // (a pipe is free again: whoever waits for one)
+    }
+}
+
+// one united batch on D's pipe, by the calling thread: a dispatcher, or the submitter itself when nothing was waiting and a pipe was free
+static void co_run(mc_ctx* ctx, mcamd::CoDispatcher* D, const std::vector<uint32_t>& mine, int lowest)
+{
+    std::string err;
+    std::string* const sinkBefore = t_errSink;
+    t_errSink = &err;
+    Pipe& P = *D->pipe;
+    hipStream_t st = P.stream;
+    const size_t K = ctx->cfg.max_candidates;
+    {
         uint64_t nq = 0, nc = 0;
         for (uint32_t s : mine) { nq += ctx->slots[s].nq; nc += ctx->slots[s].nchars; }
         int rc = MC_OK;
@@ -1683,11 +1744,13 @@ static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D)
         if (!rc) rc = ensure(ctx, D->dqinfo, nq * 16);
         if (!rc) rc = ensure(ctx, D->dmaxwin, nq * 4);
         if (!rc) {
-            uint64_t qb = 0, cb = 0;
+            uint64_t qb = 0, cb = 0, enq = 0;
             uint32_t* hq = D->hq[k]; uint32_t* hmw = D->hmw[k];
             for (uint32_t s : mine) {
                 Slot& S = ctx->slots[s];
+                const uint64_t te0 = trace_now();
                 hip(hipMemcpyAsync((uint8_t*)D->dseq.p + cb, S.hseq, S.nchars, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+                enq += trace_now() - te0;
                 for (uint32_t j = 0; j < S.nq; ++j) {
                     const uint32_t* q = S.hqinfo + (size_t)j * 4;
                     uint32_t* o = hq + (qb + j) * 4;
@@ -1701,13 +1764,15 @@ static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D)
             hip(hipMemcpyAsync(D->dmaxwin.p, hmw, nq * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
             hip(hipEventRecord(D->staged[k], st), "hipEventRecord");
             D->stagedUsed[k] = true;
+            note_enqueues(enq, (uint32_t)mine.size());
         }
         mc_device_results res{};
         if (!rc) {
             mc_device_batch in{(const uint8_t*)D->dseq.p, (const uint32_t*)D->dqinfo.p, (const uint32_t*)D->dmaxwin.p, 0, (uint32_t)nq, nc};
-            // (deferred tail, finished at once: the main kernels go out without a look at the work lists' counters -- two host round
-            // trips less per united batch, a few empty launches more; MC_SLOT_DEFER=0: the synchronous call)
-            static const bool defer = [] { const char* e = std::getenv("MC_SLOT_DEFER"); return !e || e[0] != '0'; }();
+            // (MC_SLOT_DEFER=1: deferred tail, finished at once -- the main kernels go out without a look at the work lists' counters: two
+            // host round trips less per united batch, every kernel of the path launched whether it has work or not.  Measured at 4 096
+            // reads per slot, 32 threads: 4 019 against 4 189 Mreads/min for the synchronous call, profiles/r06_slot_path.json: off)
+            static const bool defer = [] { const char* e = std::getenv("MC_SLOT_DEFER"); return e && e[0] == '1'; }();
             rc = query_on_pipe(ctx, P, &in, lowest, defer ? MC_DEFER_TAIL : 0, &res, st);
             if (!rc && defer) rc = finish_on_pipe(ctx, P);
         }
@@ -1728,6 +1793,7 @@ static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher* D)
         }
         ctx->coDoneCv.notify_all();
     }
+    t_errSink = sinkBefore;
 }
 
 static void release_pipe(mc_ctx* ctx, Slot& S)
@@ -1765,6 +1831,13 @@ int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
     out->hits = ctx->cfg.copy_allhits ? S.hhits : nullptr;
     if (status) return fail(ctx, status, "a query produced more than 2^20-1 location hits (unsupported)");
     return MC_OK;
+}
+
+const char* mc_runtime_warning(void)
+{
+    static thread_local std::string copy;
+    { std::lock_guard<std::mutex> l(g_warnMu); copy = g_warning; }
+    return copy.c_str();
 }
 
 int mc_slot_stats(mc_ctx* ctx, uint64_t stats[4])

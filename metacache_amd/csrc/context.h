@@ -212,7 +212,7 @@ struct mc_ctx {
     std::mutex coMu;
     std::condition_variable coCv, coDoneCv;
     std::deque<uint32_t> coPending;
-    std::vector<mcamd::CoDispatcher*> coDisp;
+    std::vector<mcamd::CoDispatcher*> coDisp, coFree;   // all dispatchers' state (a pipe + staging each) / those nobody is using
     bool coStop = false;
     uint32_t coMaxQueries = 0; uint64_t coMaxChars = 0;
     uint64_t coBatches = 0, coSlots = 0;   // united batches sent, slots they held (mc_slot_stats)

@@ -37,7 +37,11 @@ struct KsRank {
     mc_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
     void* comm = nullptr;
-    uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;   // the batch (all reads)
+    uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;   // the batch (all reads): ONE copy per device -- the first shard of a device
+                                                                                        // owns the buffers and uploads, the others (tests: several shards on one GPU) read them
+    bool ownsInput = false;
+    hipEvent_t upDone = nullptr;                     // owner: the batch is on the device
+    mc_candidate* hout = nullptr;                    // pinned: this owner's candidates come back here (a pageable target makes the copy a blocking staged one)
     uint32_t* drecvCounts = nullptr;                 // [S][mMax]
     uint32_t* drecvNumbers = nullptr; uint64_t recvCap = 0;
     // of the batch in flight
@@ -135,12 +139,16 @@ int mc_keyset_open(const char* name, const mc_config* cfg, uint32_t numShards, c
         c.device = R.device; c.key_shard_index = r; c.key_shard_count = ks->S; c.num_slots = 1; c.copy_allhits = 0;
         R.rc = mc_open_database(ks->db.c_str(), &c, &R.ctx);
         if (R.rc) { R.err = mc_last_error(nullptr); return; }
-        const bool ok = hipSetDevice(R.device) == hipSuccess && hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) == hipSuccess &&
-                        mcamd::dev_malloc((void**)&R.dseq, ks->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&R.dqinfo, ks->maxQ * 16) == hipSuccess &&
-                        mcamd::dev_malloc((void**)&R.dmaxwin, ks->maxQ * 4) == hipSuccess &&
-                        mcamd::dev_malloc((void**)&R.drecvCounts, (size_t)ks->S * std::max<uint32_t>(mMax, 1) * 4) == hipSuccess;
+        R.ownsInput = r < nd;
+        bool ok = hipSetDevice(R.device) == hipSuccess && hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) == hipSuccess &&
+                  mcamd::dev_malloc((void**)&R.drecvCounts, (size_t)ks->S * std::max<uint32_t>(mMax, 1) * 4) == hipSuccess &&
+                  hipHostMalloc((void**)&R.hout, (size_t)std::max<uint32_t>(mMax, 1) * ks->K * sizeof(mc_candidate)) == hipSuccess;
+        if (ok && R.ownsInput)
+            ok = mcamd::dev_malloc((void**)&R.dseq, ks->maxChars + 64) == hipSuccess && mcamd::dev_malloc((void**)&R.dqinfo, ks->maxQ * 16) == hipSuccess &&
+                 mcamd::dev_malloc((void**)&R.dmaxwin, ks->maxQ * 4) == hipSuccess && hipEventCreateWithFlags(&R.upDone, hipEventDisableTiming) == hipSuccess;
         if (!ok) { R.rc = MC_ERR_NOMEM; R.err = "mc_keyset_open: cannot allocate the batch buffers"; }
     });
+    for (uint32_t r = nd; r < ks->S; ++r) { KsRank& O = ks->rank[r % nd]; ks->rank[r].dseq = O.dseq; ks->rank[r].dqinfo = O.dqinfo; ks->rank[r].dmaxwin = O.dmaxwin; }
     for (KsRank& R : ks->rank) if (R.rc) { const int rc = R.rc; const std::string e = R.err; mc_keyset_close(ks); return ks_fail(nullptr, rc, e); }
     for (auto& H : ks->hs)
         if (hipHostMalloc((void**)&H.seq, ks->maxChars + 64) != hipSuccess || hipHostMalloc((void**)&H.q, ks->maxQ * 16) != hipSuccess ||
@@ -169,8 +177,10 @@ void mc_keyset_close(mc_keyset* ks)
         (void)hipSetDevice(R.device);
         if (R.stream) (void)hipStreamSynchronize(R.stream);
         if (R.ctx) mc_destroy(R.ctx);
-        void* bufs[] = {R.dseq, R.dqinfo, R.dmaxwin, R.drecvCounts, R.drecvNumbers};
+        void* bufs[] = {R.ownsInput ? R.dseq : nullptr, R.ownsInput ? (void*)R.dqinfo : nullptr, R.ownsInput ? (void*)R.dmaxwin : nullptr, R.drecvCounts, R.drecvNumbers};
         for (void* b : bufs) if (b) (void)hipFree(b);
+        if (R.hout) (void)hipHostFree(R.hout);
+        if (R.upDone) (void)hipEventDestroy(R.upDone);
         if (R.comm && std::find(destroyed.begin(), destroyed.end(), R.comm) == destroyed.end()) { rccl().CommDestroy(R.comm); destroyed.push_back(R.comm); }
         if (R.stream) (void)hipStreamDestroy(R.stream);
     }
@@ -256,14 +266,23 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
         const uint32_t m = (uint32_t)B.count;
         const uint64_t at = H.chars;
         for (uint32_t o = 0; o <= S; ++o) bounds[o] = o < S ? shard_lo(m, o, S) : m;
-        // ---- 1. every shard: its features' locations for ALL reads, as numbers
+        // ---- 1. every shard: its features' locations for ALL reads, as numbers.  The batch crosses the link once per DEVICE
+        // (the last batch ended with every stream idle: the buffers are free)
+        const uint32_t nd = (uint32_t)ks->devices.size();
+        for (uint32_t d = 0; d < std::min(nd, S); ++d) {
+            KsRank& O = ks->rank[d];
+            if (hipSetDevice(O.device) != hipSuccess) return ks_fail_idle(ks, MC_ERR_HIP, "hipSetDevice");
+            if (hipMemcpyAsync(O.dseq, hseq, at + 16, hipMemcpyHostToDevice, O.stream) != hipSuccess ||
+                hipMemcpyAsync(O.dqinfo, hq, (size_t)m * 16, hipMemcpyHostToDevice, O.stream) != hipSuccess ||
+                hipMemcpyAsync(O.dmaxwin, hmw, (size_t)m * 4, hipMemcpyHostToDevice, O.stream) != hipSuccess ||
+                hipEventRecord(O.upDone, O.stream) != hipSuccess)
+                return ks_fail_idle(ks, MC_ERR_HIP, "copy of a batch to the device failed");
+        }
         for_each_rank(ks, [&](uint32_t r) {
             KsRank& Rk = ks->rank[r];
             Rk.rc = MC_OK;
             if (hipSetDevice(Rk.device) != hipSuccess) { Rk.rc = MC_ERR_HIP; Rk.err = "hipSetDevice"; return; }
-            (void)hipMemcpyAsync(Rk.dseq, hseq, at + 16, hipMemcpyHostToDevice, Rk.stream);
-            (void)hipMemcpyAsync(Rk.dqinfo, hq, (size_t)m * 16, hipMemcpyHostToDevice, Rk.stream);
-            (void)hipMemcpyAsync(Rk.dmaxwin, hmw, (size_t)m * 4, hipMemcpyHostToDevice, Rk.stream);
+            if (!Rk.ownsInput && hipStreamWaitEvent(Rk.stream, ks->rank[r % nd].upDone, 0) != hipSuccess) { Rk.rc = MC_ERR_HIP; Rk.err = "hipStreamWaitEvent"; return; }
             mc_device_batch in{Rk.dseq, Rk.dqinfo, Rk.dmaxwin, 0, m, at};
             mc_device_results res{};
             Rk.cuts.assign(S + 1, 0);
@@ -325,9 +344,10 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
             mc_device_partial_numbers_in in{O.drecvCounts, O.drecvNumbers, O.srcOff.data(), O.dmaxwin + bounds[o], 0, mo, S};
             mc_device_results res{};
             int rc = mc_candidates_from_partial_numbers(O.ctx, &in, lowestRank, &res, O.stream);
-            if (!rc) rc = mc_copy_results_on(O.ctx, out + (B.first + bounds[o]) * K, res.cands, (uint64_t)mo * K * sizeof(mc_candidate), 1, O.stream);
+            if (!rc) rc = mc_copy_results_on(O.ctx, O.hout, res.cands, (uint64_t)mo * K * sizeof(mc_candidate), 1, O.stream);
             if (rc) { O.rc = rc; O.err = mc_last_error(O.ctx); return; }
-            if (hipStreamSynchronize(O.stream) != hipSuccess) { O.rc = MC_ERR_HIP; O.err = "copy of the candidates failed"; }
+            if (hipStreamSynchronize(O.stream) != hipSuccess) { O.rc = MC_ERR_HIP; O.err = "copy of the candidates failed"; return; }
+            std::memcpy(out + (B.first + bounds[o]) * K, O.hout, (size_t)mo * K * sizeof(mc_candidate));
         });
         for (KsRank& Rk : ks->rank) if (Rk.rc) return ks_fail_idle(ks, Rk.rc, Rk.err);
         // (a rank without reads of its own still took part in the exchange: its sends must be done before its buffers are reused)
