@@ -368,7 +368,7 @@ def cpu_leg_long_reads(spec, db, lb, K, n_parity, budget_s, rerun, out_cands):
     eff = scale_util.effective_cpus()
     threads = min(os.cpu_count() or 1, 2 * eff)
     rerun()
-    n = int(min(len(lb["lens"]), n_parity, max(200, np.searchsorted(np.cumsum(lb["lens"]), 4_000_000))))
+    n = int(min(len(lb["lens"]), n_parity, max(200, np.searchsorted(np.cumsum(lb["lens"]), 16_000_000))))      # (round 6: 16 Mbases = 20 000 reads and more; 4 Mbases = 5 231 before)
     host = lb["seq"][: int(lb["offs"][n])].cpu().numpy()
     sample = [host[int(lb["offs"][i]): int(lb["offs"][i]) + int(lb["lens"][i])].tobytes() for i in range(n)]
     t0 = time.time()

@@ -1616,7 +1616,7 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
                 S.coState = 2;
                 ctx->coBatches++; ctx->coSlots++;
             }
-            else { S.coState = 1; S.coQueuedNs = trace_now(); ctx->coPending.push_back(slot); }
+            else { S.coState = 1; ctx->coPending.push_back(slot); }
         }
         if (D) {
             co_run(ctx, D, std::vector<uint32_t>{slot}, lowestRank);
@@ -1714,16 +1714,6 @@ static void co_dispatch(mc_ctx* ctx, mcamd::CoDispatcher*)
             std::unique_lock<std::mutex> l(ctx->coMu);
             ctx->coCv.wait(l, [&] { return (ctx->coStop && ctx->coPending.empty()) || (!ctx->coPending.empty() && !ctx->coFree.empty()); });
             if (ctx->coPending.empty()) return;                    // (stop: nothing is waiting any more)
-            // a short wait for company: fewer than four slots waiting and the oldest of them younger than the linger time -- under load the
-            // united batches grow (the launches and round trips of a batch are shared by more reads), a lone slot loses at most that time
-            static const uint64_t lingerNs = [] { const char* e = std::getenv("MC_SLOT_LINGER_US"); return (uint64_t)(e ? std::max(0, std::atoi(e)) : 0) * 1000ull; }();
-            while (lingerNs && !ctx->coStop && ctx->coPending.size() < 4) {
-                const uint64_t age = trace_now() - ctx->slots[ctx->coPending.front()].coQueuedNs;
-                if (age >= lingerNs) break;
-                ctx->coCv.wait_for(l, std::chrono::nanoseconds(lingerNs - age));
-                if (ctx->coPending.empty() || ctx->coFree.empty()) break;
-            }
-            if (ctx->coPending.empty() || ctx->coFree.empty()) continue;
             D = ctx->coFree.back(); ctx->coFree.pop_back();
             co_take(ctx, mine, lowest);
         }

@@ -85,7 +85,6 @@ struct Slot {
     // coalesced submission (context.cpp "slot coalescer"): 0 = not queued, 1 = waiting for a dispatcher, 2 = in a dispatcher's hands,
     // 3 = enqueued on the device (`done` is recorded behind its copies back) or failed (coRc)
     int coState = 0, coRc = 0, coLowest = 0;
-    uint64_t coQueuedNs = 0;
     bool coEvent = false;
     std::string coErr;
 };

@@ -184,6 +184,28 @@ __device__ __forceinline__ void gw_fill_rounds_scan(uint64_t* T, uint32_t* E, ui
         T[slot] = (who && slot < Rc) ? ((ep + 16ull * j) | ((uint64_t)min(16u, eSz - 16u * j) << 40)) : 0ull;
     }
 }
+// ... and for the batch [r0, r0 + kGwRounds) of a read whose rounds take several batches (r0 = 0: the function above): the entry that
+// reaches into the batch from before r0 leaves its number at slot 0
+__device__ __forceinline__ void gw_fill_rounds_scan_at(uint64_t* T, uint32_t* E, uint32_t lane, uint32_t r0, uint32_t Rc, uint32_t start, uint32_t myR, uint32_t sz, uint64_t pay)
+{
+    E[lane] = 0u; E[lane + 64u] = 0u;
+    wave_lds_sync();
+    if (myR && start < r0 + kGwRounds && start + myR > r0) E[start > r0 ? start - r0 : 0u] = lane + 1u;   // (the entries' rounds are disjoint: distinct slots)
+    wave_lds_sync();
+    uint32_t lo = wave_incl_scan_max_u32(E[lane]);
+    uint32_t hi = max(wave_incl_scan_max_u32(E[lane + 64u]), rdlane(lo, 63));
+    const uint32_t payLo = (uint32_t)pay, payHi = (uint32_t)(pay >> 32);
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t slot = lane + 64u * h, who = h ? hi : lo;
+        const int src = (int)(who ? who - 1u : 0u);
+        const uint32_t eStart = (uint32_t)__shfl((int)start, src), eSz = (uint32_t)__shfl((int)sz, src);
+        const uint32_t eLo = (uint32_t)__shfl((int)payLo, src), eHi = (uint32_t)__shfl((int)payHi, src);
+        const uint32_t j = r0 + slot - eStart;
+        const uint64_t ep = ((uint64_t)eHi << 32) | eLo;
+        T[slot] = (who && r0 + slot < Rc) ? ((ep + 16ull * j) | ((uint64_t)min(16u, eSz - 16u * j) << 40)) : 0ull;
+    }
+}
 // the batch's numbers: 16 bytes per lane and load, four lanes per round; places without a round read as kGwNone
 __device__ __forceinline__ void gw_load_rounds(const uint64_t* T, const uint32_t* __restrict__ values32, uint32_t grp, uint32_t sub4, uint4 (&x)[kGwLoads],
                                                uint32_t nl = kGwLoads)   // nl: loads of this batch that have rounds at all (wave-uniform: the others are skipped)
@@ -396,10 +418,12 @@ __global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_kerne
     using Bloom = GwBloom<TLOG2, TLOG2>;
     __shared__ uint32_t bitS[WAVES][Bloom::kWords];
     __shared__ uint64_t roundS[WAVES][kGwRounds];
+    __shared__ uint32_t scanS[WAVES][kGwRounds];                   // scratch of the round tables' max-scan
     if (ws.midCount[10] == 0) return;                              // nothing was left
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* bits = bitS[wave];
     uint64_t* T = roundS[wave];
+    uint32_t* E = scanS[wave];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
@@ -439,16 +463,20 @@ __global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_kerne
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
         GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
         uint4 x[kGwLoads];
+        // Round 6: the round tables by the max-scan (gw_fill_rounds_scan_at: ~40 instructions whatever the lists' lengths) instead of the
+        // lanes' loops (~130 for lists of 254 numbers, three times per pair).  Measured and left (lab notebook r06 section 7): BOTH batches in
+        // registers, no second read of the first -- the kernel runs at four waves per SIMD for its LDS anyway, but it needed 143 registers
+        // of the 128 there are: 15 spilled, 12.3 against 10.3 ms per 2.5 x 10^6 pairs.
         // ---- A: batch 0, then batch 1 (stays in registers)
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
-        gw_fill_rounds(T, lane, 0, Rc, start, myR, sz, pay);
+        gw_fill_rounds_scan_at(T, E, lane, 0, Rc, start, myR, sz, pay);
         wave_lds_sync();
         gw_load_rounds(T, tab.values32, grp, sub4, x);
         gw_mark_rounds<Bloom>(bits, x, F.A);
         const bool two = Rc > kGwRounds;
         if (two) {
             wave_lds_sync();
-            gw_fill_rounds(T, lane, kGwRounds, Rc, start, myR, sz, pay);
+            gw_fill_rounds_scan_at(T, E, lane, kGwRounds, Rc, start, myR, sz, pay);
             wave_lds_sync();
             gw_load_rounds(T, tab.values32, grp, sub4, x);
             gw_mark_rounds<Bloom>(bits, x, F.A);
@@ -459,7 +487,7 @@ __global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_kerne
         gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
         if (two) {
             wave_lds_sync();
-            gw_fill_rounds(T, lane, 0, Rc, start, myR, sz, pay);
+            gw_fill_rounds_scan_at(T, E, lane, 0, Rc, start, myR, sz, pay);
             wave_lds_sync();
             gw_load_rounds(T, tab.values32, grp, sub4, x);
             gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x);
@@ -556,11 +584,13 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
     using Bloom = GwBloom<T1LOG2, T2LOG2>;
     __shared__ uint32_t bits[Bloom::kWords];
     __shared__ uint64_t roundS[WAVES][kGwRounds];
+    __shared__ uint32_t scanS[WAVES][kGwRounds];                   // scratch of the round tables' max-scan (round 6: gw_fill_rounds_scan_at)
     __shared__ uint32_t n2S;
     __shared__ unsigned long long ovfS;
     if (ws.midCount[12] == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t* T = roundS[wave];
+    uint32_t* E = scanS[wave];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
     const uint32_t w0 = blockIdx.x * WAVES;                        // the block's first slice
@@ -615,7 +645,7 @@ __global__ __launch_bounds__(WAVES * 64) void gw_filter_stream_kernel(BatchView 
                     const uint32_t myR = sz > 1 ? (sz + 15u) >> 4 : 0u;
                     const uint32_t incl = wave_incl_scan_u32(myR, lane), Rc = rdlane(incl, 63);
                     for (uint32_t r0 = 0; r0 < Rc; r0 += kGwRounds) {
-                        gw_fill_rounds(T, lane, r0, Rc, incl - myR, myR, sz, pay);
+                        gw_fill_rounds_scan_at(T, E, lane, r0, Rc, incl - myR, myR, sz, pay);
                         wave_lds_sync();
                         uint4 x[kGwLoads];
                         gw_load_rounds(T, tab.values32, grp, sub4, x);
