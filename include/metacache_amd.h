@@ -129,8 +129,8 @@ int mc_load_target_windows(mc_ctx* ctx, const uint32_t* windows_per_target, uint
 /* the same announcement from bounds alone: targets 0 .. max_target_id with max_window_id + 1 windows each */
 int mc_load_location_range(mc_ctx* ctx, uint32_t max_target_id, uint32_t max_window_id);
 /* how the loaded table lies in HBM: layout[0] low 32 bits = bytes per stored location (8, or 4 with the compact store), bit 32 = 1 if the
- * table has its DIRECT-ADDRESS INDEX (2^32 entries of 8 bytes beside the buckets -- the feature is the index, one request per lookup
- * of the lane path instead of the buckets' 1.25; built at mc_load_end for single-part tables whose buckets take 8 GiB and more where
+ * table has its DIRECT-ADDRESS INDEX (2^32 entries of 8 bytes beside the buckets -- the feature is the index: one independent 8-byte
+ * load per lookup of the lane path; built at mc_load_end for single-part tables whose buckets take 8 GiB and more where
  * 34 GB + head-room are free; mc_set_tuning "direct_index" 0 / 1 / -1, MC_DIRECT_INDEX), [1] low 32 bits = the gap
  * between two targets' window numbers in the compact form (0 otherwise), high 32 bits = the list alignment in entries (1, or 32 = every
  * list of the compact store begins on a 128-byte line: the loaders switch it on where the padded store stays below 1.5 x the plain one
@@ -185,10 +185,11 @@ int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* seq1, uint32_t len1, co
  * from the database's window stride (candidate_structs.hpp:143-145) and insert_size_max.  Returns the number of reads
  * added (< n when the slot is full: submit, wait, clear, continue with the rest) or a negative error. */
 int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const uint64_t* offsets, uint64_t n, uint64_t insert_size_max);
-/* How the slots reach the device.  With two or more slots (and top candidates only: copy_allhits = 0) submissions are QUEUED and a few
- * dispatcher threads of the library take whatever is waiting as ONE device batch (slots of the reference's size -- 4 096 reads,
+/* How the slots reach the device.  With two or more slots of up to 16 384 reads (and top candidates only: copy_allhits = 0) submissions
+ * are QUEUED: a slot that finds a pipe free and nothing waiting goes out at once, everything else is taken by dispatcher threads of the
+ * library -- whatever is waiting when a pipe comes free goes to the device as ONE batch (slots of the reference's size -- 4 096 reads,
  * options.hpp:229-232 -- are ~30 kernel launches and three host round trips for 0.1 ms of device work each; database_query.hpp:110-113
- * orders the submissions with a mutex instead); MC_SLOT_COALESCE=0: every slot its own batch.  stats[0] = 1 if slots are united,
+ * orders the submissions with a mutex instead); larger slots and MC_SLOT_COALESCE=0: every slot its own batch (MC_SLOT_COALESCE=1: united whatever their size).  stats[0] = 1 if slots are united,
  * [1] = united batches sent so far, [2] = slots they carried, [3] = dispatcher threads. */
 int mc_slot_stats(mc_ctx* ctx, uint64_t stats[4]);
 /* "" or what the library has noticed about the HIP runtime in this process: the slot paths time their enqueue-only calls, and when these

@@ -320,8 +320,12 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (const char* e = std::getenv("MC_PIPES")) npipes = std::max(1, std::atoi(e));
     // Slots that are submitted side by side go to the device as ONE batch (slot coalescer, below): several slots, top candidates only.
     // MC_SLOT_COALESCE=0: every slot its own batch on a pipe it borrows, as before round 6.
-    ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits;
-    if (const char* e = std::getenv("MC_SLOT_COALESCE")) ctx->coalesce = ctx->coalesce && e[0] != '0';
+    // Slots of 16 384 reads and fewer (the reference's 4 096): there a batch per slot is bound by its launches.  Larger slots keep a batch
+    // each on a pipe they borrow -- united they gain nothing (10 554 against 10 618 Mreads/min at 65 536 reads per slot) and `mcq`, whose 32
+    // workers run under AMD_DIRECT_DISPATCH=0, lost a third of its query phase (97 against 68 ms per 10^7 reads at 30 Gbp, profiles/r06_e2e_matrix02.json).
+    // MC_SLOT_COALESCE=1 / 0 forces either.
+    ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && cfg->slot_max_queries <= 16384;
+    if (const char* e = std::getenv("MC_SLOT_COALESCE")) ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && e[0] != '0';
     if (ctx->coalesce) {
         // dispatchers: one united batch each in flight -- as many as there were pipes (up to 8): few submitters find a free one at once
         // (their slots go alone, as before), many find them busy and their slots wait together

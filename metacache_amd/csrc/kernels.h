@@ -77,8 +77,9 @@ struct DeviceTable {
     const uint32_t* values32 = nullptr;
     // DIRECT-ADDRESS INDEX (round 6): 2^32 entries of 8 bytes, the feature IS the index -- size (16 bits) | payload (48 bits:
     // a list's first place in the store, or a single location as target (24) | window (24)); 0 = the feature is not in the table.
-    // One 8-byte request per lookup, no key compare, no chain (the buckets take 40 requests for a 150 bp read's 32 features; the box
-    // serves 47 x 10^9 requests a second whatever their width: tools/gather_width.hip).  Beside the buckets, which every other kernel keeps using.
+    // One 8-byte load per lookup by ONE lane, no key compare, no chain, no cooperation between lanes (the box serves 47 x 10^9 requests a
+    // second whatever their width: tools/gather_width.hip; against the quad-cooperative bucket fetch -- also one request per lookup -- it
+    // saves 40 % of the lookup kernel's instructions).  Beside the buckets, which every other kernel keeps using.
     const uint64_t* direct = nullptr;
     const uint32_t* gwBase = nullptr;     // [targets + 1]
     const uint32_t* gwDir = nullptr;      // [(gwBase[targets] >> gwDirShift) + 1]: the target whose numbers (gap included) hold block << gwDirShift

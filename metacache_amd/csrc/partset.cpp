@@ -158,7 +158,11 @@ int open_group(mc_partset* ps, uint32_t first, std::vector<mc_ctx*>& out, std::s
             const int rc = mc_open_database(ps->db.c_str(), &c, &out[i]);
             mcamd::open_hints() = mcamd::OpenHints{};
             if (rc != MC_OK) { std::lock_guard<std::mutex> l(errMu); rcs[d] = rc; errs[d] = mc_last_error(nullptr); return; }
-            (void)mcamd::reserve_query_pipes(out[i], (uint32_t)ps->maxQ, std::min<uint64_t>(ps->maxChars, (uint64_t)ps->maxQ * 152));   // (a failure here is not one: the first batch asks again)
+            // the contexts' two pipes sized here, beside the other parts' loads -- where the device has room to spare (a group that fills it
+            // leaves the workspaces to the first batches: they grow on demand)
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > (24ull << 30))
+                (void)mcamd::reserve_query_pipes(out[i], (uint32_t)ps->maxQ, std::min<uint64_t>(ps->maxChars, (uint64_t)ps->maxQ * 152));   // (a failure here is not one: the first batch asks again)
             uint64_t st[4] = {0, 0, 0, 0};
             if (mc_load_stats(out[i], st) == MC_OK) ps->loadBytes += st[0];
         }
@@ -350,9 +354,13 @@ int mc_partset_select_group(mc_partset* ps, uint32_t g)
             close_group(ps->cur);
             ps->cur.swap(ps->next);
         } else {
-            if (ps->nextFirst == first && ps->loaderRc != MC_OK) { close_group(ps->next); return ps_fail(ps, ps->loaderRc, ps->loaderErr); }
+            // (a group that could not be loaded BESIDE the resident one -- the two did not fit the devices together -- is loaded in its place:
+            // the caller is through with the resident group when it selects the next)
+            const bool retry = ps->nextFirst == first && (ps->loaderRc == MC_ERR_NOMEM || (ps->loaderRc == MC_ERR_HIP && ps->loaderErr.find("out of memory") != std::string::npos));
+            if (ps->nextFirst == first && ps->loaderRc != MC_OK && !retry) { close_group(ps->next); return ps_fail(ps, ps->loaderRc, ps->loaderErr); }
             close_group(ps->next);
             close_group(ps->cur);
+            if (retry) { for (DevState& D : ps->dev) { (void)hipSetDevice(D.device); (void)hipDeviceSynchronize(); } mcamd::big_cache_trim(); }
             std::string err;
             const uint64_t t1 = now_ns();
             const int rc = open_group(ps, first, ps->cur, err);

@@ -78,7 +78,7 @@ def test_slots_from_many_threads_get_their_own_candidates(golden, monkeypatch, c
         got = _drive(db, work, lowest)
         st = (C.c_uint64 * 4)()
         assert L.mc_slot_stats(db.h, st) == 0
-        assert bool(st[0]) == (coalesce == "1")
+        assert bool(st[0]) == (coalesce == "1")                  # (slots of 96 reads: united by default as well)
         if coalesce == "1":
             assert st[2] == sum(1 for w in work for (r, _) in w if len(r)) and 1 <= st[1] <= st[2] and st[3] >= 1
         for t in range(T):
