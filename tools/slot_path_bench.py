@@ -46,9 +46,10 @@ def main():
     from metacache_amd import build
     drv = C.CDLL(build.build_slot_driver())
     drv.mc_slot_drive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p, C.c_uint64, C.c_void_p]
-    db, _ = synthdb.build_database(spec, shards=shards, max_candidates=2, max_load_factor=0.3, num_slots=max(threads), slot_max_queries=max(batches),
-                                   slot_max_chars=max(batches) * 152 + 64, report=lambda m: print(m, file=sys.stderr, flush=True))
     for B in batches:
+        # (a table per slot size: the slots' capacity decides whether the library unites them -- mc_slot_stats, include/metacache_amd.h)
+        db, _ = synthdb.build_database(spec, shards=shards, max_candidates=2, max_load_factor=0.3, num_slots=max(threads), slot_max_queries=B,
+                                       slot_max_chars=B * 152 + 64, report=lambda m: print(m, file=sys.stderr, flush=True))
         offs = np.arange(B + 1, dtype=np.uint64) * np.uint64(150)
         nb = args.reads // B
         # the device path's candidates of the first batches: what every slot must deliver
@@ -66,7 +67,7 @@ def main():
                    "batches_per_s": round(sum(done) / el), "us_per_batch_and_thread": round(el / max(1, sum(done)) * T * 1e6), "reads_with_other_candidates": sum(bad), "errors": errs[:2]}
             print(run, flush=True)
             res["runs"].append(run)
-    db.close()
+        db.close()
     print(json.dumps(res))
     if args.out:
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
