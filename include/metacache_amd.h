@@ -185,7 +185,7 @@ int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* seq1, uint32_t len1, co
  * from the database's window stride (candidate_structs.hpp:143-145) and insert_size_max.  Returns the number of reads
  * added (< n when the slot is full: submit, wait, clear, continue with the rest) or a negative error. */
 int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const uint64_t* offsets, uint64_t n, uint64_t insert_size_max);
-/* How the slots reach the device.  With two or more slots of up to 16 384 reads (and top candidates only: copy_allhits = 0) submissions
+/* How the slots reach the device.  With two or more slots of up to 8 192 reads (and top candidates only: copy_allhits = 0) submissions
  * are QUEUED: a slot that finds a pipe free and nothing waiting goes out at once, everything else is taken by dispatcher threads of the
  * library -- whatever is waiting when a pipe comes free goes to the device as ONE batch (slots of the reference's size -- 4 096 reads,
  * options.hpp:229-232 -- are ~30 kernel launches and three host round trips for 0.1 ms of device work each; database_query.hpp:110-113

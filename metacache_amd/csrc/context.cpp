@@ -293,7 +293,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->directWant = mcamd::open_hints().directIndex;
     if (const char* e = std::getenv("MC_DIRECT_INDEX")) ctx->directWant = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_LIST_ALIGN")) ctx->listAlignWant = e[0] == '1' ? 1 : 0;   // (default: where the padded store is affordable)
-    if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '1' ? 1 : 0;
+    if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '4' ? 4 : e[0] == '1' ? 1 : 0;   // (4: the fused kernel's six-waves-per-SIMD instance)
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
     if (const char* e = std::getenv("MC_COMPACT_LOCATIONS")) ctx->compactAllowed = e[0] != '0';   // tests / tuning
     if (const char* e = std::getenv("MC_BIG_MIN")) ctx->bigMin = (uint32_t)std::max(0, std::atoi(e));   // tests / tuning
@@ -320,11 +320,12 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     if (const char* e = std::getenv("MC_PIPES")) npipes = std::max(1, std::atoi(e));
     // Slots that are submitted side by side go to the device as ONE batch (slot coalescer, below): several slots, top candidates only.
     // MC_SLOT_COALESCE=0: every slot its own batch on a pipe it borrows, as before round 6.
-    // Slots of 16 384 reads and fewer (the reference's 4 096): there a batch per slot is bound by its launches.  Larger slots keep a batch
+    // Slots of 8 192 reads and fewer (the reference's 4 096): there a batch per slot is bound by its launches (at 16 384 reads per slot united and
+    // apart are level: 4 133 / 5 402 / 6 136 / 7 279 against 3 479 / 6 000 / 6 537 / 6 535 Mreads/min with 4 / 8 / 16 / 32 threads).  Larger slots keep a batch
     // each on a pipe they borrow -- united they gain nothing (10 554 against 10 618 Mreads/min at 65 536 reads per slot) and `mcq`, whose 32
     // workers run under AMD_DIRECT_DISPATCH=0, lost a third of its query phase (97 against 68 ms per 10^7 reads at 30 Gbp, profiles/r06_e2e_matrix02.json).
     // MC_SLOT_COALESCE=1 / 0 forces either.
-    ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && cfg->slot_max_queries <= 16384;
+    ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && cfg->slot_max_queries <= 8192;
     if (const char* e = std::getenv("MC_SLOT_COALESCE")) ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && e[0] != '0';
     if (ctx->coalesce) {
         // dispatchers: one united batch each in flight -- as many as there were pipes (up to 8): few submitters find a free one at once
@@ -1484,7 +1485,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "list_align") ctx->listAlignWant = value < 0 ? -1 : (value != 0);   // before the table is loaded: lists of the compact store on lines of their own
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
-    else if (n == "gw_fuse") ctx->gwFuse = value != 0;                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
+    else if (n == "gw_fuse") ctx->gwFuse = value == 4 ? 4 : (value != 0);                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }

@@ -1160,7 +1160,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
                                                                                  mc_candidate_dev* __restrict__ cands)
 {
     using Bloom = GwBloom<TLOG2, TLOG2>;
-    constexpr uint32_t kKeep = 512;                                // numbers kept in LDS: the counting takes them when at most 256 are distinct
+    constexpr uint32_t kKeep = WPE >= 6 ? 384 : 512;               // numbers kept in LDS: the counting takes them when at most 256 are distinct
+                                                                   // (WPE = 6, "gw_fuse" 4: 26 KB of LDS per block -- six blocks per CU -- and 80 registers: six waves per SIMD)
     static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
     __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
     __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][kGwRounds];
@@ -1503,6 +1504,8 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     if (stage == 0) {
         // the filter with the counting of lists up to 512 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
+        else if (ws.gwFuse == 4 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwFuse == 4) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {

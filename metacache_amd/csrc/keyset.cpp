@@ -22,7 +22,9 @@
 #include "rccl_dl.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -256,10 +258,18 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
     };
     std::thread packer;
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{packer};
+    static const bool trace = std::getenv("MC_KEYSET_TRACE") != nullptr;
+    auto now_ns = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; };
+    uint64_t tPack = 0, tShards = 0, tExchange = 0, tOwners = 0;
+    const uint64_t tp0 = now_ns();
     if (!batches.empty()) pack_batch(0);
+    tPack += now_ns() - tp0;
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         const Batch& B = batches[bi];
+        const uint64_t tb0 = now_ns();
         if (packer.joinable()) packer.join();                       // this batch is in its slot
+        tPack += now_ns() - tb0;
+        const uint64_t tb1 = now_ns();
         if (bi + 1 < batches.size()) packer = std::thread(pack_batch, bi + 1);   // (the other slot's batch ended with all streams idle)
         const mc_keyset::HostSlot& H = ks->hs[bi & 1];
         uint8_t* const hseq = H.seq; uint32_t* const hq = H.q; uint32_t* const hmw = H.mw;
@@ -292,6 +302,7 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
             if (rc) { Rk.rc = rc; Rk.err = rc == MC_ERR_HIP && Rk.err.empty() ? "HIP error" : mc_last_error(Rk.ctx); }
         });
         for (KsRank& Rk : ks->rank) if (Rk.rc) return ks_fail_idle(ks, Rk.rc, Rk.err);
+        const uint64_t tb2 = now_ns();
         // ---- 2. the exchange.  Owner o receives from source s the numbers [cuts_s[o], cuts_s[o + 1]) and the counts of its reads
         for (uint32_t o = 0; o < S; ++o) {
             KsRank& O = ks->rank[o];
@@ -335,6 +346,7 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
                 }
             }
         }
+        const uint64_t tb3 = now_ns();
         // ---- 3. every owner: rows 8-10 on what it received, its reads' candidates to the host
         for_each_rank(ks, [&](uint32_t o) {
             KsRank& O = ks->rank[o];
@@ -353,7 +365,12 @@ int mc_keyset_classify(mc_keyset* ks, const char* seqs, const uint64_t* offs, co
         // (a rank without reads of its own still took part in the exchange: its sends must be done before its buffers are reused)
         for (KsRank& Rk : ks->rank) { (void)hipSetDevice(Rk.device); (void)hipStreamSynchronize(Rk.stream); }
         ++ks->batches;
+        const uint64_t tb4 = now_ns();
+        tShards += tb2 - tb1; tExchange += tb3 - tb2; tOwners += tb4 - tb3;
     }
+    if (trace)
+        std::fprintf(stderr, "mc_keyset_classify: %zu batches, %u shards; host ms: packing not hidden %.2f, upload + shards' lookups + split sizes %.2f, exchange enqueued %.2f, owners' candidates + copy back %.2f\n",
+                     batches.size(), S, tPack / 1e6, tShards / 1e6, tExchange / 1e6, tOwners / 1e6);
     return MC_OK;
 }
 
