@@ -293,7 +293,7 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->directWant = mcamd::open_hints().directIndex;
     if (const char* e = std::getenv("MC_DIRECT_INDEX")) ctx->directWant = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("MC_LIST_ALIGN")) ctx->listAlignWant = e[0] == '1' ? 1 : 0;   // (default: where the padded store is affordable)
-    if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '4' ? 4 : e[0] == '1' ? 1 : 0;   // (4: the fused kernel's six-waves-per-SIMD instance)
+    if (const char* e = std::getenv("MC_GW_FUSE")) ctx->gwFuse = e[0] == '5' ? 5 : e[0] == '1' ? 1 : 0;   // (5: the fused kernel's five-waves-per-SIMD instance of rounds 4-5)
     if (const char* e = std::getenv("MC_QUAD_LOOKUP")) ctx->quadLookup = e[0] == '1' ? 1 : 0;   // tests
     if (const char* e = std::getenv("MC_COMPACT_LOCATIONS")) ctx->compactAllowed = e[0] != '0';   // tests / tuning
     if (const char* e = std::getenv("MC_BIG_MIN")) ctx->bigMin = (uint32_t)std::max(0, std::atoi(e));   // tests / tuning
@@ -1485,7 +1485,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "list_align") ctx->listAlignWant = value < 0 ? -1 : (value != 0);   // before the table is loaded: lists of the compact store on lines of their own
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
-    else if (n == "gw_fuse") ctx->gwFuse = value == 4 ? 4 : (value != 0);                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
+    else if (n == "gw_fuse") ctx->gwFuse = value == 5 ? 5 : (value != 0);                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }

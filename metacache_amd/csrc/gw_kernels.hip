@@ -412,10 +412,10 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_kernel(BatchView b,
 // numbers = 208 rounds): TWO batches.  The second one stays in registers for phase B, the first one is read again (from the L2): one
 // and a half passes over the fabric instead of the streaming kernel's two, and its occupancy (8 KB of filter bits per wave).
 // Takes the records gw_filter_kernel left (kGwDefer), 64 at a time; leaves what does not fit either to gw_filter_stream_kernel.
-template <uint32_t WAVES, uint32_t TLOG2>
-__global__ __launch_bounds__(WAVES * 64, MC_GW_FILTER_WPE) void gw_filter2_kernel(BatchView b, DeviceTable tab, Workspace ws)
+template <uint32_t WAVES, uint32_t TLOG2, uint32_t T2LOG2 = TLOG2>
+__global__ __launch_bounds__(WAVES * 64, T2LOG2 == TLOG2 ? MC_GW_FILTER_WPE : 6) void gw_filter2_kernel(BatchView b, DeviceTable tab, Workspace ws)
 {
-    using Bloom = GwBloom<TLOG2, TLOG2>;
+    using Bloom = GwBloom<TLOG2, T2LOG2>;
     __shared__ uint32_t bitS[WAVES][Bloom::kWords];
     __shared__ uint64_t roundS[WAVES][kGwRounds];
     __shared__ uint32_t scanS[WAVES][kGwRounds];                   // scratch of the round tables' max-scan
@@ -1153,7 +1153,10 @@ constexpr uint32_t kGwCounted = 0x80000000u;      // record of list 7: the read 
 // the counting takes the place of the filter bits (4 KB, done with after phase B), the distinct numbers' slots that of the round table.
 // Lists that keep more than 512 numbers or have window ranges beyond kHashWin repeat phase B into the pool (the numbers are still in
 // registers) and go on to the other kernels as from gw_filter_kernel.  A record whose read was counted here is marked kGwCounted | n2.
-// 92 registers: five waves per SIMD.  (A software-pipelined form -- the next read's loads issued as phase B frees the registers -- needed
+// 92 registers: five waves per SIMD -- until round 6: with 384 instead of 512 kept numbers in LDS the block takes 26 KB, six fit a CU, and the
+// compiler, which sizes the register budget by the occupancy the LDS allows, brings the kernel to 80 registers (three spilled): SIX waves
+// per SIMD, 13.3 -> 12.0 ms per 5 x 10^6 reads (WPE = 6; the kernel waits for its LDS round trips and its lists 45 % of its wave cycles:
+// a sixth wave fills them).  (A software-pipelined form -- the next read's loads issued as phase B frees the registers -- needed
 // 127 registers = four waves per SIMD and was slower, 14.95 against 13.1 ms per 5 x 10^6 reads; removed in round 5, docs/LAB_NOTEBOOK_r04.md.)
 template <uint32_t WAVES, uint32_t TLOG2, bool TAX, uint32_t WPE = MC_GW_FILTER_WPE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchView b, DeviceTable tab, Workspace ws, uint32_t K, const uint32_t* __restrict__ taxkey,
@@ -1504,13 +1507,17 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     if (stage == 0) {
         // the filter with the counting of lists up to 512 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
-        else if (ws.gwFuse == 4 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwFuse == 4) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        // (round 6: the SIX-waves-per-SIMD instance -- 384 kept numbers in LDS instead of 512: 26 KB per block, six blocks per CU, 80 registers
+        // with three spilled -- 13.3 -> 12.0 ms per 5 x 10^6 reads, the step 17.9 -> 16.6 ms; "gw_fuse" 5: the five-wave instance of rounds 4-5)
+        else if (ws.gwFuse == 5 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwFuse == 5) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
         // reads of up to 2 x kGwRounds rounds (read pairs): two register batches
-        hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
+        // ("gw_fuse" 5 also brings back the pair filter of rounds 3-5: both filter halves of 2^15 bits, 38 KB per block, four waves per SIMD)
+        if (ws.gwFuse == 5) hipLaunchKernelGGL((gw_filter2_kernel<4, 15>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
+        else hipLaunchKernelGGL((gw_filter2_kernel<4, 15, 13>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);
     } else if (stage == 7) {
         // the records the register filters left -> the stream filter's list, longest reads first
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);

@@ -2967,7 +2967,8 @@ uint32_t big_filter_grid(uint32_t n, bool compact, int bpcOverride)
 {
     if (bpcOverride > 0) return std::min<uint32_t>(256u * (uint32_t)bpcOverride, (n + 3) / 4);
     static const uint32_t env = [] { const char* e = std::getenv("MC_BIG_FILTER_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 0u; }();
-    const uint32_t bpc = env ? env : compact ? 40u : 7u;   // (compact: 20 -> 40 -> 80 blocks per CU with two batches in flight: 19.05 / 18.56 / 18.55 ms per step -- finer shares let the other pipe's kernels in sooner)
+    const uint32_t bpc = env ? env : compact ? 48u : 7u;   // (compact: 20 -> 40 -> 80 blocks per CU with two batches in flight: 19.05 / 18.56 / 18.55 ms per step -- finer shares let the other pipe's kernels in sooner;
+                                                           // round 6: 48 = whole rounds of the six blocks a CU holds of the fused kernel, and of the four of the pair filter: 36 / 40 / 48 / 60: 16.88 / 16.95 / 16.67 / 16.71 ms)
     return std::min<uint32_t>(256 * bpc, (n + 3) / 4);
 }
 
