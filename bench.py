@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 READ_LEN = 150
 PAD_LEN = 152                  # every read starts 4-byte aligned
 KERNELS = ("plan", "sketch_probe", "sketch_lane", "chunk_sketch", "chunk_probe", "probe_cands", "mid_cands_64", "mid_cands_128",
-           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter2", "gw_compact", "gw_filter_stream_fine", "gw_filter_stream", "gw_count", "gw_count_512", "gw_count_1024",
+           "mid_cands_256", "hash_cands_256", "hash_cands_512", "hash_cands_1024", "gw_filter_count", "gw_filter", "gw_filter2", "gw_compact", "gw_filter_stream_fine", "gw_filter_stream_mid", "gw_filter_stream", "gw_count", "gw_count_512", "gw_count_1024",
            "big_filter", "big_filter_2", "big_count", "big_count_2", "gw_sort", "gw_sorted_cands", "query_wave", "scan", "sort_candidates")
 MULTI_KERNEL_TIMERS = ("plan", "scan", "gw_sort", "gw_compact", "gw_sorted_cands")   # timers over more than one kernel: never a line's `roofline.kernel`
 KERNELS_MODE_K = ("mask_features", "gather_lists", "pack_numbers", "owner_entries", "decode_union", "cands_from_hits")   # shard / owner side of --mode K
@@ -62,14 +62,14 @@ KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cand
              "query_wave": ("query_kernel",), "sort_candidates": ("sort_candidates_kernel",),
              "gw_filter_count": ("gw_filter_count_kernel",), "gw_filter": ("gw_filter_kernel",),
              "gw_filter2": ("gw_filter2_kernel",), "gw_compact": ("gw_compact_kernel",), "gw_filter_stream_fine": ("gw_filter_stream_kernel<16",),
-             "gw_filter_stream": ("gw_filter_stream_kernel<2",), "gw_count": ("gw_count_kernel<9",), "gw_count_512": ("gw_count_kernel<10",),
+             "gw_filter_stream": ("gw_filter_stream_kernel<2u, 17",), "gw_filter_stream_mid": ("gw_filter_stream_kernel<2u, 16",), "gw_count": ("gw_count_kernel<9",), "gw_count_512": ("gw_count_kernel<10",),
              "gw_count_1024": ("gw_count_kernel<11",), "big_filter": ("big_filter_kernel",), "big_count": ("big_count_kernel<10",),
              "big_count_2": ("big_count_kernel<11",), "hash_cands_256": ("hash_cands_kernel<9",), "hash_cands_512": ("hash_cands_kernel<10",),
              "hash_cands_1024": ("hash_cands_kernel<11",), "mid_cands_64": ("mid_cands_kernel",), "mid_cands_128": ("mid_cands_kernel",),
              "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("gw_sort_chunk_kernel", "gw_sort_lists_kernel", "gw_merge_pass_kernel"), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
              "gather_lists": ("gather_lists_kernel",), "owner_entries": ("owner_entries_kernel",), "decode_union": ("decode_union_kernel",)}
 # ... and whole, for the kernels a line may name as its dominant one (profiles/r06*_kernel_stats.csv)
-KERNEL_FULL = {"gw_filter_count": "gw_filter_count_kernel<4u, 14u, false, 6u>", "gw_filter2": "gw_filter2_kernel<4u, 14u>", "gw_filter_stream": "gw_filter_stream_kernel<2u, 17u, 15u, false>",
+KERNEL_FULL = {"gw_filter_count": "gw_filter_count_kernel<4u, 14u, false, 6u>", "gw_filter2": "gw_filter2_kernel<4u, 14u>", "gw_filter_stream": "gw_filter_stream_kernel<2u, 17u, 15u, false>", "gw_filter_stream_mid": "gw_filter_stream_kernel<2u, 16u, 13u, false>",
                "gw_filter_stream_fine": "gw_filter_stream_kernel<16u, 19u, 17u, true>", "sketch_probe": "sketch_probe_lane_kernel<true>"}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)
@@ -220,7 +220,7 @@ def kernel_bytes_per_read(timer: str, L: float, F: float, H: float, K: int, V: i
     """the kernel's OWN share of SURVEY §8(d)'s bytes per read (ceil(L/4) + ceil(L/8) + 12 F + V H + 16 K): the read's characters belong to the
     sketching kernel, 12 F to the lookups, the V H bytes of the lists to the filter, the 16 K bytes of candidates to whoever writes them"""
     share = {"sketch_lane": (L + 3) // 4 + (L + 7) // 8, "sketch_probe": (L + 3) // 4 + (L + 7) // 8 + 12.0 * F, "probe_cands": 12.0 * F,
-             "gw_filter_count": V * H + 16.0 * K, "gw_filter": V * H, "gw_filter2": V * H, "gw_filter_stream": V * H, "gw_filter_stream_fine": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
+             "gw_filter_count": V * H + 16.0 * K, "gw_filter": V * H, "gw_filter2": V * H, "gw_filter_stream": V * H, "gw_filter_stream_fine": V * H, "gw_filter_stream_mid": V * H, "big_filter": V * H, "gw_count": 16.0 * K, "big_count": 16.0 * K,
              "gather_lists": V * H}
     return share.get(timer)
 

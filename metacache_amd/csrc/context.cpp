@@ -846,6 +846,7 @@ static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const Ske
         { ScopedTimer t(ctx, "gw_filter2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "gw_compact", st); launch_big_cands(7, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "gw_filter_stream_fine", st); launch_big_cands(8, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
+        { ScopedTimer t(ctx, "gw_filter_stream_mid", st); launch_big_cands(11, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
         { ScopedTimer t(ctx, "gw_filter_stream", st); launch_big_cands(9, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     } else if (second) { ScopedTimer t(ctx, "big_filter_2", st); launch_big_cands(3, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
     { ScopedTimer t(ctx, compact ? "gw_count" : "big_count", st); launch_big_cands(1, b, sp, tab, ws, K, taxkey, P.bCands.p, st); }
@@ -1040,7 +1041,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     (void)maxWindows;
 
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH; ws.gwMidH = ctx->gwMidH;
     ws.winCount = (uint32_t*)P.bWinCount.p; ws.winOff = (uint32_t*)P.bWinOff.p;
     ws.features = (wantFeatures || lanePath) ? (uint32_t*)P.bFeatures.p : nullptr; ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1225,7 +1226,7 @@ int mc_candidates_from_hits(mc_ctx* ctx, const mc_device_hits* in, int lowestRan
     if (total) HIP_TRY(ctx, hipMemcpyAsync(P.bHits.p, in->hits, total * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(P.bHitOff.p, in->hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH; ws.gwMidH = ctx->gwMidH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -1274,7 +1275,7 @@ int mc_candidates_from_partial_hits(mc_ctx* ctx, const mc_device_partial_hits* i
     launch_union_partial(in->counts, S, n, reinterpret_cast<const uint64_t*>(in->hits), (uint32_t*)P.bScanIn.p, srcStart, (uint64_t*)P.bHitOff.p,
                          (uint64_t*)P.bHits.p, P.bScan.p, st);
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH; ws.gwMidH = ctx->gwMidH;
     ws.hits = (uint64_t*)P.bHits.p; ws.cscr = (uint64_t*)P.bCscr.p; ws.cscr2 = (uint64_t*)P.bCscr2.p;
     ws.hitOff = (uint64_t*)P.bHitOff.p; ws.qstat = (QueryStat*)P.bQstat.p;
     BatchView b{nullptr, nullptr, in->max_win, in->max_win_uniform, n};
@@ -1382,7 +1383,7 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
         (rc = ensure(ctx, P.bCands, (size_t)std::max<uint32_t>(n, 1) * K * sizeof(mc_candidate))))
         return rc;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH; ws.gwMidH = ctx->gwMidH;
     ws.psize = (uint32_t*)P.bPsize.p; ws.ppay = (uint64_t*)P.bPpay.p;
     uint64_t* srcStart = ws.ppay + (size_t)n * S + 2;                 // [S][n + 1] exclusive scans of the sources' counts
     ws.qstat = (QueryStat*)P.bQstat.p; ws.qflag = (uint32_t*)P.bQflag.p; ws.hitScan = (uint32_t*)P.bScanIn.p; ws.hitOff = (uint64_t*)P.bHitOff.p;
@@ -1484,6 +1485,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     }
     else if (n == "list_align") ctx->listAlignWant = value < 0 ? -1 : (value != 0);   // before the table is loaded: lists of the compact store on lines of their own
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
+    else if (n == "gw_mid_h") ctx->gwMidH = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 32768));   // reads up to this many locations: the stream filter's small-filter instance (0 = none; default 8 192)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
     else if (n == "gw_fuse") ctx->gwFuse = value == 5 ? 5 : (value != 0);                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
@@ -1531,7 +1533,7 @@ int mc_last_batch_stats(mc_ctx* ctx, uint64_t stats[8])
     if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
     if (!P.bStats.p || !P.bQstat.p) return MC_OK;
     Workspace ws{};
-    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH;
+    ws.filterBpc = ctx->filterBpc; ws.countBpc = ctx->countBpc; ws.gwFuse = ctx->gwFuse; ws.gwBigH = ctx->gwBigH; ws.gwMidH = ctx->gwMidH;
     ws.qstat = (QueryStat*)P.bQstat.p; ws.winOff = (uint32_t*)P.bWinOff.p; ws.stats = (uint64_t*)P.bStats.p;
     if (P.bMid.p) { ws.midCount = (uint32_t*)P.bMid.p; ws.midList = ws.midCount + 32; }
     launch_batch_stats(ws, P.lastN, ctx->stream);

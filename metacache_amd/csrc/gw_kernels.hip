@@ -1528,6 +1528,10 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // blocks x 16 = the same waves, the same pool slices; tuning switch "gw_big_h"; 0xFFFFFFFF: one instance for all reads, as round 3)
         const uint32_t nSlices = 4u * fgrid;
         if (ws.gwBigH != 0xFFFFFFFFu) hipLaunchKernelGGL((gw_filter_stream_kernel<16, 19, 17, true>), dim3((nSlices + 15u) / 16u), dim3(1024), 0, st, b, tab, ws, ws.gwBigH, 0xFFFFFFFFu, nSlices);
+    } else if (stage == 11) {
+        const uint32_t nSlices = 4u * fgrid;
+        const uint32_t midH = std::min(ws.gwMidH, ws.gwBigH);
+        if (midH) hipLaunchKernelGGL((gw_filter_stream_kernel<2, 16, 13>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, midH, nSlices);
     } else if (stage == 9) {
         // ... the others: 2^17 + 2^15 filter bits per block of two waves (20 KB), twice the blocks
         // (2^16 + 2^15 bits instead: more waves per CU, but more false positives to sort -- 612 against 676 Mreads/min on configs[4]'s reads;
@@ -1535,7 +1539,11 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // instance in front of this kernel was measured slower: DESIGN section 10 of round 4)
         const uint32_t nSlices = 4u * fgrid;
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
-        hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, 0u, ws.gwBigH, nSlices);
+        // Round 6: the reads of up to gwMidH locations (8 192: most of configs[4]'s reads) through an instance with 2^16 + 2^13 filter bits --
+        // 9 KB instead of 20 per block: thirteen blocks per CU by the LDS, six waves per SIMD by the registers, where the instance above
+        // runs at three; at these lengths the smaller filters keep one per cent more ("gw_mid_h", 0 = one instance for all)
+        const uint32_t midH = std::min(ws.gwMidH, ws.gwBigH);      // (stage 11, before this one)
+        hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, midH, ws.gwBigH, nSlices);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
     } else if (stage == 1 || stage == 10) {
         // filtered lists up to 256 (stage 1: 4 KB of LDS per wave), then 257 .. 512 (stage 10)

@@ -170,6 +170,7 @@ struct Workspace {           // device buffers sized by the host for this batch
     void*     scanTmp;       // block sums for the scans
     uint64_t* stats;         // [8]        batch statistics (on demand)
     // host side only: the context's grid tuning switches (mc_set_tuning; 0 = default) -- per context, never process-wide
+    uint32_t  gwMidH = 0;         // reads up to this many locations take the stream filter's small-filter instance (2^16 + 2^13 bits: six waves per SIMD; 0: none)
     uint32_t  gwBigH = 32768;     // reads beyond this many locations take the stream filter's fine-block instance (gw_kernels.hip kGwBigH; 0xFFFFFFFF: none)
     int32_t   filterBpc = 0, countBpc = 0, gwFuse = 1;   // gwFuse: gw_filter_count_kernel (1) or gw_filter_kernel + gw_count_kernel (0)
 };
