@@ -192,7 +192,8 @@ struct mc_ctx {
                                            // probing waits for HBM and the sketching runs under it: 5.27 -> 5.08 ms per 5 x 10^6 reads at full scale), 0 / 1 = never / always
                                            // (MC_LANE_FUSION, mc_set_tuning "lane_fusion"); small tables: 5 % slower on configs[1] (ALU phase at the probe kernel's occupancy)
 
-    uint32_t gwMidH = 8192;   // mc_set_tuning "gw_mid_h": reads up to this many locations take the small-filter instance of the stream filter (0 = none)
+    uint32_t gwMidH = 0;      // mc_set_tuning "gw_mid_h": reads up to this many locations take the small-filter instance of the stream filter (0 = none: the default --
+                              // 8 192: the filters' 3.35 -> 3.0 ms per 250 000 long reads, the false keeps' sort and counting +0.35: lab notebook r06 section 6)
     uint32_t gwBigH = 32768;  // mc_set_tuning "gw_big_h": reads beyond this many locations take the fine-block instance of the stream filter (0 = none)
     bool buildHold = false;   // mc_build_table_begin took a hold on the block cache (devcache.h) that mc_build_table_end / mc_destroy gives back
     int filterBpc = 0, countBpc = 0, gwFuse = 1;   // mc_set_tuning: grids' blocks per CU (0 = default), counting inside the filter kernel -- this context only

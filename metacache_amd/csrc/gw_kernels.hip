@@ -1539,9 +1539,9 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // instance in front of this kernel was measured slower: DESIGN section 10 of round 4)
         const uint32_t nSlices = 4u * fgrid;
         const uint32_t cgrid = std::min<uint32_t>((b.n + 255) / 256, 2048u);
-        // Round 6: the reads of up to gwMidH locations (8 192: most of configs[4]'s reads) through an instance with 2^16 + 2^13 filter bits --
-        // 9 KB instead of 20 per block: thirteen blocks per CU by the LDS, six waves per SIMD by the registers, where the instance above
-        // runs at three; at these lengths the smaller filters keep one per cent more ("gw_mid_h", 0 = one instance for all)
+        // (stage 11, "gw_mid_h" > 0: the reads of up to that many locations through an instance with 2^16 + 2^13 filter bits -- 9 KB instead of
+        // 20 per block, six waves per SIMD where this instance runs at three.  Measured at 8 192: filters 3.35 -> 3.0 ms per 250 000 long reads,
+        // and the sort, the scan and the counting of what the smaller filters keep too much +0.35: off by default)
         const uint32_t midH = std::min(ws.gwMidH, ws.gwBigH);      // (stage 11, before this one)
         hipLaunchKernelGGL((gw_filter_stream_kernel<2, 17, 15>), dim3(2 * fgrid), dim3(128), 0, st, b, tab, ws, midH, ws.gwBigH, nSlices);
         hipLaunchKernelGGL(gw_compact_kernel, dim3(cgrid), dim3(256), 0, st, ws, b.n, 1u);
