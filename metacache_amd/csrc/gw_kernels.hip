@@ -317,6 +317,26 @@ __device__ __forceinline__ void gw_take_rounds(const uint32_t* bits, const uint6
     }
 }
 
+// how many of a lane's four places per load hold numbers (0 .. 4), three bits per load: all that phase B needs of the round table -- the
+// table's place can go to something else once the loads are issued (gw_filter_count_kernel's seven-wave instance)
+__device__ __forceinline__ uint32_t gw_pack_rems(const uint64_t* T, uint32_t grp, uint32_t sub4, uint32_t nl)
+{
+    uint32_t packed = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < kGwLoads; ++u) {
+        if (u >= nl) continue;
+        const uint32_t cnt = (uint32_t)(T[u * 16 + grp] >> 40);
+        packed |= (cnt > sub4 ? min(cnt - sub4, 4u) : 0u) << (3u * u);
+    }
+    return packed;
+}
+template <class Bloom, bool CHECK>
+__device__ __forceinline__ void gw_take_rounds_packed(const uint32_t* bits, const uint32_t packed, const GwFrame& F, GwSink& S, const uint4 (&x)[kGwLoads], uint32_t nl)
+{
+#pragma unroll
+    for (uint32_t u = 0; u < kGwLoads; ++u) if (u < nl) gw_take4<Bloom, CHECK>(bits, F, S, x[u], (int32_t)((packed >> (3u * u)) & 7u));
+}
+
 constexpr uint32_t kGwDefer = 0xFFFFFFFEu;                 // record of list 7: left to gw_filter_stream_kernel
 constexpr uint32_t kGwFallback = 0xFFFFFFFFu;              // ... handed to the wave kernel
 
@@ -1166,12 +1186,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
     constexpr uint32_t kKeep = WPE >= 6 ? 384 : 512;               // numbers kept in LDS: the counting takes them when at most 256 are distinct
                                                                    // (WPE = 6, "gw_fuse" 4: 26 KB of LDS per block -- six blocks per CU -- and 80 registers: six waves per SIMD)
     static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
+    // WPE = 7 (experiment, "gw_fuse" 7): 22 KB per block -- the round table lies in the filter bits' place until the loads are issued (phase B
+    // needs three bits per load of it: gw_pack_rems; the bits are cleared behind the loads), the distinct numbers' slots of the counting in the
+    // kept numbers' (which are in registers by then): seven blocks per CU
+    constexpr bool kSeven = WPE >= 7;
     __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
-    __shared__ __attribute__((aligned(16))) uint64_t roundS[WAVES][kGwRounds];
-    __shared__ uint32_t keptS[WAVES][kKeep];
+    __shared__ __attribute__((aligned(16))) uint64_t roundS[kSeven ? 1 : WAVES][kSeven ? 1 : kGwRounds];
+    __shared__ __attribute__((aligned(16))) uint32_t keptS[WAVES][kKeep];
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* bits = bitS[wave];
-    uint64_t* T = roundS[wave];
+    uint64_t* T = kSeven ? reinterpret_cast<uint64_t*>(bits) : roundS[kSeven ? 0 : wave];
     uint32_t* kept = keptS[wave];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
@@ -1206,17 +1230,30 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
             ++deferred;
             continue;
         }
-        {
+        auto clear_bits = [&]() {
             uint4* z4 = reinterpret_cast<uint4*>(bits);
 #pragma unroll
             for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        }
+        };
+        if constexpr (!kSeven) clear_bits();
         gw_fill_rounds_scan(T, kept, lane, Rc, incl - myR, myR, sz, pay);   // (kept: free until phase B)
         wave_lds_sync();
         const GwFrame F(maxWin);
         const uint32_t nl = (Rc + 15u) >> 4;
         uint4 x[kGwLoads];
         gw_load_rounds(T, tab.values32, grp, sub4, x, nl);
+        uint32_t rems = 0;
+        if constexpr (kSeven) {                                    // the table has been read: its place is the filter's now
+            rems = gw_pack_rems(T, grp, sub4, nl);
+            wave_lds_sync();
+            clear_bits();
+            wave_lds_sync();
+        }
+        auto take_rounds = [&](auto check, GwSink& S) {
+            constexpr bool CHECK = decltype(check)::value;
+            if constexpr (kSeven) gw_take_rounds_packed<Bloom, CHECK>(bits, rems, F, S, x, nl);
+            else gw_take_rounds<Bloom, CHECK>(bits, T, F, S, grp, sub4, x, nl);
+        };
         const uint32_t sv = sz == 1 ? tab.gw_of(pay) : kGwNone;
         if (sv != kGwNone) Bloom::mark(bits, sv >> F.A);
         gw_mark_rounds<Bloom>(bits, x, F.A, nl);
@@ -1226,12 +1263,12 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         if (here) {
             GwSink S{kept, kKeep, 0u};
             gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, true>(bits, T, F, S, grp, sub4, x, nl);
+            take_rounds(std::true_type{}, S);
             n2 = S.n2;
         } else {
             GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
             gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
+            take_rounds(std::false_type{}, S);
             n2 = S.n2;
         }
         if (here && n2 <= kKeep) {
@@ -1239,8 +1276,14 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
             wave_lds_sync();
             const bool counted = gw_count_read<9, TAX, true, true>(q, [&]() -> uint2 { const uint4 r6 = work[w]; return make_uint2(r6.y, r6.z & 0xFFFu); }, n2, maxWin,
                                         [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
-                                        reinterpret_cast<uint2*>(bits), reinterpret_cast<uint32_t*>(T), T, lane, grp, sub4, K, taxkey, tab, ws, cands, P);
-            if (!counted) {
+                                        reinterpret_cast<uint2*>(bits), kSeven ? kept : reinterpret_cast<uint32_t*>(T), kSeven ? reinterpret_cast<uint64_t*>(kept) : T,
+                                        lane, grp, sub4, K, taxkey, tab, ws, cands, P);
+            if (!counted && kSeven) {
+                // (the kept numbers' place went to the counting: the read is filtered again by gw_filter2_kernel, 1 read in 60)
+                if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwDefer, maxWin);
+                ++deferred;
+                wave_lds_sync();
+            } else if (!counted) {
                 // more than 256 DISTINCT numbers among the kept ones (1 read in 60 at RefSeq scale): the list -- still in LDS -- goes through the
                 // pool to gw_count_kernel<10> like the lists of 257 .. 512 numbers round 3's filter left (the exact wave kernel took them: 0.5 ms
                 // per 5 x 10^6 reads).  (Room: the slice holds kGwRounds x 16 + 64 numbers more, checked above.)
@@ -1255,7 +1298,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         if (here) {
             GwSink S{slice + sliceUsed, (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed), 0u};
             gw_take<Bloom>(bits, F, S, sv, sv != kGwNone);
-            gw_take_rounds<Bloom, false>(bits, T, F, S, grp, sub4, x, nl);
+            take_rounds(std::false_type{}, S);
             n2 = S.n2;
         }
         const uint32_t room = (uint32_t)min((uint64_t)kGwMaxKept, sliceCap - sliceUsed);
@@ -1509,6 +1552,8 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
         // (round 6: the SIX-waves-per-SIMD instance -- 384 kept numbers in LDS instead of 512: 26 KB per block, six blocks per CU, 80 registers
         // with three spilled -- 13.3 -> 12.0 ms per 5 x 10^6 reads, the step 17.9 -> 16.6 ms; "gw_fuse" 5: the five-wave instance of rounds 4-5)
+        else if (ws.gwFuse == 7 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 7>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwFuse == 7) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 7>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 5 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 5) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
