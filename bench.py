@@ -69,7 +69,7 @@ KERNEL_OF = {"sketch_lane": ("sketch_lane_kernel",), "probe_cands": ("probe_cand
              "mid_cands_256": ("mid_cands_kernel",), "gw_sort": ("gw_sort_chunk_kernel", "gw_sort_lists_kernel", "gw_merge_pass_kernel"), "gw_sorted_cands": ("gw_sorted_cands_kernel",),
              "gather_lists": ("gather_lists_kernel",), "owner_entries": ("owner_entries_kernel",), "decode_union": ("decode_union_kernel",)}
 # ... and whole, for the kernels a line may name as its dominant one (profiles/r06*_kernel_stats.csv)
-KERNEL_FULL = {"gw_filter_count": "gw_filter_count_kernel<4u, 14u, false, 6u>", "gw_filter2": "gw_filter2_kernel<4u, 14u>", "gw_filter_stream": "gw_filter_stream_kernel<2u, 17u, 15u, false>", "gw_filter_stream_mid": "gw_filter_stream_kernel<2u, 16u, 13u, false>",
+KERNEL_FULL = {"gw_filter_count": "gw_filter_count_kernel<4u, 14u, false, 7u>", "gw_filter2": "gw_filter2_kernel<4u, 14u>", "gw_filter_stream": "gw_filter_stream_kernel<2u, 17u, 15u, false>", "gw_filter_stream_mid": "gw_filter_stream_kernel<2u, 16u, 13u, false>",
                "gw_filter_stream_fine": "gw_filter_stream_kernel<16u, 19u, 17u, true>", "sketch_probe": "sketch_probe_lane_kernel<true>"}
 # configs[2] at scale 1 (SURVEY §8d Config 3): 2000 genera x 4 species x 5 strains = 40 000 targets, 2.5 .. 5 Mbp each = 150 Gbp
 CFG2 = dict(genera=2000, species_per_genus=4, strains_per_species=5, len_min=2_500_000, len_max=5_000_000, seed=3100)

@@ -413,7 +413,7 @@ int mc_copy_results_on(mc_ctx* ctx, void* dst, const void* src, uint64_t bytes, 
  * set at mc_create, on a live context with no batch in flight.  names: "big_min" (location lists longer than this are filtered by
  * target before they are counted, big_filter_kernel), "quad_lookup" (-1 by table size, 0 / 1), "lane_path" (0 / 1), "compact_locations" (0 / 1, before mc_load_begin),
  * "filter_bpc" / "count_bpc" (blocks per CU of the filter kernels' / the first counting instance's persistent grids, 0 = default; this context only),
- * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart, 5 = the fused kernel's five-waves-per-SIMD instance),
+ * "gw_fuse" (counting inside the filter kernel: 1 = default, 0 = the two kernels apart, 5 / 6 = the fused kernel's five- / six-waves-per-SIMD instances; the default runs at seven),
  * "gw_big_h" (reads beyond this many locations take the fine-block instance of the stream filter; default 32 768, 0 = none),
  * "lane_fusion" (sketching + lookups of the lane path in one kernel: -1 = on tables beyond 1 GiB (default), 0 / 1 = never / always),
  * "direct_index" (-1 by table size, 0 / 1; on a loaded table the index is built or dropped at once: mc_table_layout),

@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
     constexpr uint32_t kKeep = WPE >= 6 ? 384 : 512;               // numbers kept in LDS: the counting takes them when at most 256 are distinct
                                                                    // (WPE = 6, "gw_fuse" 4: 26 KB of LDS per block -- six blocks per CU -- and 80 registers: six waves per SIMD)
     static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
-    // WPE = 7 (experiment, "gw_fuse" 7): 22 KB per block -- the round table lies in the filter bits' place until the loads are issued (phase B
+    // WPE = 7 (the default): 22 KB per block -- the round table lies in the filter bits' place until the loads are issued (phase B
     // needs three bits per load of it: gw_pack_rems; the bits are cleared behind the loads), the distinct numbers' slots of the counting in the
     // kept numbers' (which are in registers by then): seven blocks per CU
     constexpr bool kSeven = WPE >= 7;
@@ -1550,14 +1550,16 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
     if (stage == 0) {
         // the filter with the counting of lists up to 512 numbers fused in (gw_filter_count_kernel); "gw_fuse" 0: the two kernels apart
         if (ws.gwFuse == 0) hipLaunchKernelGGL((gw_filter_kernel<4, 14, 5>), dim3(fgrid), dim3(256), 0, st, b, tab, ws);   // (compiled for five waves per SIMD: 96 registers)
-        // (round 6: the SIX-waves-per-SIMD instance -- 384 kept numbers in LDS instead of 512: 26 KB per block, six blocks per CU, 80 registers
-        // with three spilled -- 13.3 -> 12.0 ms per 5 x 10^6 reads, the step 17.9 -> 16.6 ms; "gw_fuse" 5: the five-wave instance of rounds 4-5)
-        else if (ws.gwFuse == 7 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 7>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwFuse == 7) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 7>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        // (round 6: occupancy is what this kernel answers to -- the compiler sizes its registers by what the LDS allows, so the LDS was cut:
+        // SIX waves per SIMD with 384 instead of 512 kept numbers in LDS (26 KB per block, 80 registers, three spilled): 13.3 -> 12.0 ms per
+        // 5 x 10^6 reads; SEVEN with the round table in the filter bits' place until the loads are out and the counting's distinct slots in the
+        // kept numbers' (22 KB, 72 registers, five spilled): 11.65 ms, the step 17.9 -> 16.4 ms.  "gw_fuse" 6 / 5: the six- / five-wave instances)
+        else if (ws.gwFuse == 6 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (ws.gwFuse == 6) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 5 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 5) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else if (taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 7>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
+        else hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 7>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
     } else if (stage == 3) {
         // reads of up to 2 x kGwRounds rounds (read pairs): two register batches
         // ("gw_fuse" 5 also brings back the pair filter of rounds 3-5: both filter halves of 2^15 bits, 38 KB per block, four waves per SIMD)
