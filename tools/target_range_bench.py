@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--resident", type=int, default=0, help="ranges in HBM at a time (0 = all; fewer: range groups, loaded one after the other)")
     ap.add_argument("--key-shards", type=int, default=0, help="also: the same file as this many key shards through mc_keyset_*")
     ap.add_argument("--skip-whole", action="store_true", help="no run of the whole table through the part set driver")
+    ap.add_argument("--whole-only", action="store_true", help="only the whole table through the part set driver (e.g. with --reads 4000000: the driver's steady state)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
@@ -105,6 +106,12 @@ def main():
 
         ref, r1 = run(1) if not args.skip_whole else (None, {})
         print(json.dumps(r1), flush=True)
+        if args.whole_only:
+            res["whole_table"] = r1
+            if args.out:
+                os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+                json.dump(res, open(args.out, "w"), indent=1)
+            return
         got, r2 = run(args.ranges)
         print(json.dumps(r2), flush=True)
         bad = 0
