@@ -377,6 +377,9 @@ typedef struct {
     uint32_t        num_sources;
 } mc_device_partial_numbers_in;
 int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numbers_in* in, int lowest_rank, mc_device_results* out, void* stream);
+/* the same on the context's first (flags = 0) or second (flags = MC_SECOND_PIPE) pipe: a caller that keeps two batches in flight (keyset.cpp's
+ * lanes) runs a batch's shard side -- mc_query_device(MC_WANT_PARTIAL_NUMBERS | pipe), mc_partial_numbers -- and its owner side on the same pipe */
+int mc_candidates_from_partial_numbers_on(mc_ctx* ctx, const mc_device_partial_numbers_in* in, int lowest_rank, int flags, mc_device_results* out, void* stream);
 /* what mc_candidates_from_partial_numbers has done on this context so far: stats[0..3] = reads, reads whose pieces took the filtered path,
  * numbers received, locations decoded for the sort (short lists + what the filtered path handed back) */
 int mc_owner_stats(const mc_ctx* ctx, uint64_t stats[4]);

@@ -64,7 +64,7 @@ class McDeviceResults(C.Structure):
                 ("features", C.c_void_p), ("win_offsets", C.c_void_p)]
 
 
-EXPORTS = ["mc_runtime_warning", "mc_slot_stats", "mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_target_range", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
+EXPORTS = ["mc_candidates_from_partial_numbers_on", "mc_runtime_warning", "mc_slot_stats", "mc_config_default", "mc_create", "mc_destroy", "mc_last_error", "mc_load_begin", "mc_load_batch", "mc_load_end", "mc_load_location_range", "mc_load_target_windows", "mc_table_layout", "mc_target_range", "mc_merge_part_candidates", "mc_partset_open", "mc_partset_close",
            "mc_partset_info", "mc_partset_classify", "mc_partset_last_error", "mc_partset_select_group", "mc_partset_classify_resident", "mc_partset_load_bytes",
            "mc_partial_numbers", "mc_candidates_from_partial_numbers", "mc_owner_stats", "mc_keyset_open", "mc_keyset_close", "mc_keyset_info", "mc_keyset_classify", "mc_keyset_last_error",
            "mc_open_database", "mc_open_metadata", "mc_load_stats", "mc_set_lineages", "mc_db_info", "mc_db_num_taxa", "mc_db_taxon", "mc_db_taxon_source", "mc_db_lineages",

@@ -1321,9 +1321,10 @@ int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t n, co
     if (ctx->parts.size() != 1 || !ctx->parts[0].compact || !ctx->dGwBase)
         return fail(ctx, MC_ERR_UNSUPPORTED, "mc_partial_numbers: the database has no global window numbers (compact location store)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    Pipe& P = ctx->pipe0;
+    // (the pipe whose batch these results are: a caller with two batches in flight -- keyset.cpp's lanes -- runs the shards' lookups on either)
+    Pipe& P = (ctx->pipe1.bHitOff.p && res->hit_offsets == (const uint64_t*)ctx->pipe1.bHitOff.p) ? ctx->pipe1 : ctx->pipe0;
     if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
-    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    hipStream_t st = streamv ? (hipStream_t)streamv : (&P == &ctx->pipe1 && ctx->pipe1.stream) ? ctx->pipe1.stream : ctx->stream;
     for (uint32_t i = 0; i < numCuts; ++i) {
         if (cutQueries[i] > n) return fail(ctx, MC_ERR_INVALID, "mc_partial_numbers: cut beyond the batch");
         HIP_TRY(ctx, hipMemcpyAsync(&cutOffsets[i], res->hit_offsets + cutQueries[i], 8, hipMemcpyDeviceToHost, st));
@@ -1353,6 +1354,11 @@ int mc_partial_numbers(mc_ctx* ctx, const mc_device_results* res, uint32_t n, co
 // owner side: rows 8-10 on the pieces the key shards sent for this rank's reads, where they lie in the receive buffer
 int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numbers_in* in, int lowestRank, mc_device_results* out, void* streamv)
 {
+    return mc_candidates_from_partial_numbers_on(ctx, in, lowestRank, 0, out, streamv);
+}
+
+int mc_candidates_from_partial_numbers_on(mc_ctx* ctx, const mc_device_partial_numbers_in* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
+{
     if (!ctx || !in || !out || !in->counts || !in->source_offsets || in->num_sources < 1 || in->num_sources > 64) return MC_ERR_INVALID;
     if (!in->max_win && in->max_win_uniform < 1) return fail(ctx, MC_ERR_INVALID, "max_win or max_win_uniform required");
     if (ctx->parts.size() != 1 || !ctx->parts[0].compact || !ctx->dGwBase)
@@ -1364,9 +1370,10 @@ int mc_candidates_from_partial_numbers(mc_ctx* ctx, const mc_device_partial_numb
     const uint64_t totalIn = in->source_offsets[S];
     if (totalIn && !in->numbers) return MC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    Pipe& P = ctx->pipe0;
+    if ((flags & MC_SECOND_PIPE) && !ctx->pipe1.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe1.stream, hipStreamNonBlocking));
+    Pipe& P = (flags & MC_SECOND_PIPE) ? ctx->pipe1 : ctx->pipe0;
     if (P.tail.pending) { const int rcf = finish_on_pipe(ctx, P); if (rcf) return rcf; }   // (a deferred tail still owns the workspace this call is about to reuse)
-    hipStream_t st = streamv ? (hipStream_t)streamv : ctx->stream;
+    hipStream_t st = streamv ? (hipStream_t)streamv : (flags & MC_SECOND_PIPE) ? ctx->pipe1.stream : ctx->stream;
     const uint32_t* taxkey = nullptr;
     int rc = taxkey_for_rank(ctx, lowestRank, &taxkey);
     if (rc) return rc;

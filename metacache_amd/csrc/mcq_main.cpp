@@ -918,7 +918,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
         // its lines.  A partitioned database is gone through part group by part group (mc_partset_select_group: the next group loads
         // behind this one's queries); between the groups a batch keeps nothing but its reads' candidate lists (`carried`), the last
         // group's pass prints.  (Round 3 collected all reads on one thread first: 2.5 s per 10^7 reads.)
-        std::mutex ksMtx;
+
         std::deque<std::vector<mc_candidate>> carried;                          // [batch]; grown under batchMtx when a worker takes a batch
         bool setHasPrior = false, setLastPass = true;                           // the part group pass the workers are in
         auto work_keyset = [&](unsigned) {
@@ -969,7 +969,7 @@ void run_job(Session& S, Options o, const std::vector<std::string>& infiles, con
                 if (all.size() != n * K) { fail("internal: a batch changed between two part groups"); break; }
                 seq1.push_back('\0'); seq2.push_back('\0');
                 if (n && S.keyset) {
-                    std::lock_guard<std::mutex> l(ksMtx);                  // (the key set takes one call at a time)
+                    // (the key set shares its two lanes among the callers, as the part set does: this worker's batch runs beside another worker's)
                     if (mc_keyset_classify(S.keyset, seq1.data(), off1.data(), paired ? seq2.data() : nullptr, paired ? off2.data() : nullptr, n, o.lowest,
                                            o.insertMax, all.data()) != MC_OK) { fail(mc_keyset_last_error(S.keyset)); break; }
                 } else if (n) {
