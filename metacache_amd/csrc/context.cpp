@@ -1494,7 +1494,7 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "lane_fusion") ctx->fuseLane = value < 0 ? -1 : (value != 0);   // sketch + probe of the lane path in one kernel (-1: where the lookups are quad-cooperative)
     else if (n == "gw_mid_h") ctx->gwMidH = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 32768));   // reads up to this many locations: the stream filter's small-filter instance (0 = none; default 8 192)
     else if (n == "gw_big_h") ctx->gwBigH = value <= 0 ? 0xFFFFFFFFu : (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll);   // reads beyond this many locations: the stream filter's fine-block instance (0 = none; default 32 768)
-    else if (n == "gw_fuse") ctx->gwFuse = (value == 5 || value == 6 || value == 8) ? (int)value : (value != 0);                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
+    else if (n == "gw_fuse") ctx->gwFuse = (value == 5 || value == 6) ? (int)value : (value != 0);                         // counting of short filtered lists inside the filter kernel: 1 (default) = fused, 0 = the two kernels apart
     else return fail(ctx, MC_ERR_INVALID, "mc_set_tuning: unknown switch '" + n + "'");
     return MC_OK;
 }

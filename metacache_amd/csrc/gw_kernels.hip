@@ -922,21 +922,19 @@ struct GwPend {
 // LONG (first instance's table only): the list may hold up to 2^LOG2S numbers as long as no more than half of them are DISTINCT (a filtered
 // list of 400 numbers has about 100 distinct ones); a list with more goes to the exact wave kernel.
 // entf(): where step D finds the read's entries -- {first entry slot in ws.psize / ws.ppay, entries} (the record of work list 6)
-// LOADFIRST: the list's numbers lie where the slot table will (gw_filter_count_kernel's eight-wave instance keeps them in the dead half of the
-// filter bits): they are taken into registers before the table is cleared
-template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, bool LOADFIRST = false, class GetV, class EntF>
+template <uint32_t LOG2S, bool TAX, bool DEFER, bool LONG = false, class GetV, class EntF>
 __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, const uint32_t n2, const uint32_t maxWin, GetV&& getv,
                                               uint2* slots, uint32_t* ck, uint64_t* T, const uint32_t lane, const uint32_t grp, const uint32_t sub4,
                                               const uint32_t K, const uint32_t* __restrict__ taxkey, const DeviceTable& tab, const Workspace& ws,
                                               mc_candidate_dev* __restrict__ cands, GwPend& P)
 {
     constexpr uint32_t kSlots = 1u << LOG2S, kList = kSlots / 2;
-    auto clear_slots = [&]() {
+    {
         uint4* k4 = reinterpret_cast<uint4*>(slots);
 #pragma unroll
         for (uint32_t i = 0; i < kSlots * 8 / 16 / 64; ++i) k4[i * 64 + lane] = make_uint4(kGwNone, 0u, kGwNone, 0u);
-    };
-    if constexpr (!LOADFIRST) { clear_slots(); wave_lds_sync(); }
+    }
+    wave_lds_sync();
     uint32_t pickLo[kLaneK], pickHi[kLaneK];
 #pragma unroll
     for (uint32_t i = 0; i < kLaneK; ++i) { pickLo[i] = 0; pickHi[i] = 0; }
@@ -950,7 +948,6 @@ __device__ __forceinline__ bool gw_count_read(const uint32_t q, EntF&& entf, con
         uint32_t v[PER];
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) v[r] = getv(r);
-        if constexpr (LOADFIRST) { wave_lds_sync(); clear_slots(); wave_lds_sync(); }
         C = gw_count_numbers<LOG2S, PER, LONG ? kList : 0xFFFFFFFFu>(v, slots, ck, lane);
     };
     const uint32_t per = (n2 + 63u) / 64u;
@@ -1186,9 +1183,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
                                                                                  mc_candidate_dev* __restrict__ cands)
 {
     using Bloom = GwBloom<TLOG2, TLOG2>;
-    constexpr bool kEight = WPE >= 8;                              // (experiment, "gw_fuse" 8) the kept numbers in the dead "seen" half of the filter bits during phase B
-                                                                   // (phase B asks only the "twice" half): 4 KB of bits + 1 KB of scratch per wave = 20 KB per block
-    constexpr uint32_t kKeep = kEight ? 512 : WPE >= 6 ? 384 : 512;   // numbers kept in LDS: the counting takes them when at most 256 are distinct
+    constexpr uint32_t kKeep = WPE >= 6 ? 384 : 512;               // numbers kept in LDS: the counting takes them when at most 256 are distinct
                                                                    // (WPE = 6, "gw_fuse" 4: 26 KB of LDS per block -- six blocks per CU -- and 80 registers: six waves per SIMD)
     static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
     // WPE = 7 (the default): 22 KB per block -- the round table lies in the filter bits' place until the loads are issued (phase B
@@ -1197,12 +1192,11 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
     constexpr bool kSeven = WPE >= 7;
     __shared__ __attribute__((aligned(16))) uint32_t bitS[WAVES][Bloom::kWords];
     __shared__ __attribute__((aligned(16))) uint64_t roundS[kSeven ? 1 : WAVES][kSeven ? 1 : kGwRounds];
-    __shared__ __attribute__((aligned(16))) uint32_t keptS[WAVES][kEight ? 256 : kKeep];
+    __shared__ __attribute__((aligned(16))) uint32_t keptS[WAVES][kKeep];
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* bits = bitS[wave];
     uint64_t* T = kSeven ? reinterpret_cast<uint64_t*>(bits) : roundS[kSeven ? 0 : wave];
-    uint32_t* aux = keptS[wave];                                   // scratch of the round table's scan, then (seven / eight waves) the counting's distinct slots
-    uint32_t* kept = kEight ? bits : keptS[wave];
+    uint32_t* kept = keptS[wave];
     const uint32_t total = ws.midCount[9];
     const uint4* __restrict__ work = reinterpret_cast<const uint4*>(ws.midList) + (size_t)6 * b.n;
     uint4* __restrict__ outRec = reinterpret_cast<uint4*>(ws.midList) + (size_t)7 * b.n;
@@ -1242,7 +1236,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
             for (uint32_t i = 0; i < Bloom::kWords / 4 / 64; ++i) z4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         };
         if constexpr (!kSeven) clear_bits();
-        gw_fill_rounds_scan(T, aux, lane, Rc, incl - myR, myR, sz, pay);   // (aux / kept: free until phase B)
+        gw_fill_rounds_scan(T, kept, lane, Rc, incl - myR, myR, sz, pay);   // (kept: free until phase B)
         wave_lds_sync();
         const GwFrame F(maxWin);
         const uint32_t nl = (Rc + 15u) >> 4;
@@ -1280,9 +1274,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
         if (here && n2 <= kKeep) {
             if (lane == 0) outRec[w] = make_uint4(q, 0u, kGwCounted | n2, maxWin);
             wave_lds_sync();
-            const bool counted = gw_count_read<9, TAX, true, true, kEight>(q, [&]() -> uint2 { const uint4 r6 = work[w]; return make_uint2(r6.y, r6.z & 0xFFFu); }, n2, maxWin,
+            const bool counted = gw_count_read<9, TAX, true, true>(q, [&]() -> uint2 { const uint4 r6 = work[w]; return make_uint2(r6.y, r6.z & 0xFFFu); }, n2, maxWin,
                                         [&](uint32_t r) -> uint32_t { return r * 64 + lane < n2 ? kept[r * 64 + lane] : kGwNone; },
-                                        reinterpret_cast<uint2*>(bits), kSeven ? aux : reinterpret_cast<uint32_t*>(T), kSeven ? reinterpret_cast<uint64_t*>(aux) : T,
+                                        reinterpret_cast<uint2*>(bits), kSeven ? kept : reinterpret_cast<uint32_t*>(T), kSeven ? reinterpret_cast<uint64_t*>(kept) : T,
                                         lane, grp, sub4, K, taxkey, tab, ws, cands, P);
             if (!counted && kSeven) {
                 // (the kept numbers' place went to the counting: the read is filtered again by gw_filter2_kernel, 1 read in 60)
@@ -1560,8 +1554,6 @@ void launch_gw_cands(uint32_t stage, const BatchView& b, const SketchParams& sp,
         // SIX waves per SIMD with 384 instead of 512 kept numbers in LDS (26 KB per block, 80 registers, three spilled): 13.3 -> 12.0 ms per
         // 5 x 10^6 reads; SEVEN with the round table in the filter bits' place until the loads are out and the counting's distinct slots in the
         // kept numbers' (22 KB, 72 registers, five spilled): 11.65 ms, the step 17.9 -> 16.4 ms.  "gw_fuse" 6 / 5: the six- / five-wave instances)
-        else if (ws.gwFuse == 8 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 8>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
-        else if (ws.gwFuse == 8) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 8>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 6 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 6) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, false, 6>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);
         else if (ws.gwFuse == 5 && taxkey) hipLaunchKernelGGL((gw_filter_count_kernel<4, 14, true, 4>), dim3(fgrid), dim3(256), 0, st, b, tab, ws, maxCand, taxkey, c);

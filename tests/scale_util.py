@@ -60,7 +60,6 @@ VARIANTS = {
     "apart_quad_unfused_count": {"lane_fusion": 0, "quad_lookup": 1, "gw_fuse": 0},   # ... probe_cands<true>, gw_filter + gw_count apart
     "lane_fusion_five_waves": {"lane_fusion": 1, "gw_fuse": 5},      # gw_filter_count_kernel<.., 4>: 512 kept numbers in LDS, five waves per SIMD (rounds 4-5)
     "lane_fusion_six_waves": {"lane_fusion": 1, "gw_fuse": 6},       # gw_filter_count_kernel<.., 6>: 384 kept numbers, round table and distinct slots in LDS of their own (the default is <.., 7>)
-    "lane_fusion_eight_waves": {"lane_fusion": 1, "gw_fuse": 8},     # gw_filter_count_kernel<.., 8>: kept numbers in the dead half of the filter bits
     "direct_index_fused": {"direct_index": 1, "lane_fusion": 1},    # sketch_probe_lane_kernel<false, true>: lookups in the direct-address index (32 GiB beside the buckets)
     "direct_index_apart": {"direct_index": 1, "lane_fusion": 0},    # sketch_lane + probe_cands<false, true>
 }
