@@ -285,9 +285,11 @@ int mc_merge_part_candidates(mc_ctx* ctx, const mc_candidate* const* lists, uint
 /* A partitioned database queried part group by part group (docs/partitioning.md:116-153, for databases beyond the node's HBM), the
  * parts of a group spread over GPUs (options.cpp:1155-1163 lists the reference's multi-GPU switches): `resident_parts` parts are in
  * HBM at a time -- one context each, part i of a group on devices[i % num_devices] -- and the NEXT group is loaded by a background
- * thread while the reads run against this one.  Per batch the per-part top lists are gathered with ncclAllGather (RCCL; one
- * communicator rank per device, ncclCommInitAll) and merged on devices[0] by mc_merge_part_candidates, together with the list the
- * earlier groups left.  devices == NULL: cfg->device alone.  cfg: as for mc_open_database (slot_max_queries / slot_max_chars = batch size).
+ * thread while the reads run against this one.  Per batch the reads are dealt out to the devices as owners; every device sends every
+ * owner its parts' top lists of that owner's reads (one grouped ncclSend / ncclRecv round: RCCL, one communicator rank per device,
+ * ncclCommInitAll) and every owner merges its reads' lists in part order (mc_merge_part_candidates), together with the list the earlier
+ * groups left, and copies its share to the host (the reference forwards running top candidates GPU -> GPU, query_batch.cu:638-652).  Two
+ * batches are in flight; mc_partset_classify_resident may be called from several threads at once.  devices == NULL: cfg->device alone.  cfg: as for mc_open_database (slot_max_queries / slot_max_chars = batch size).
  * cfg->target_shard_count > 1: the "parts" are the contiguous target ranges of ONE part file (cfg->single_part, or part 0), cut at load
  * (mc_config.target_shard_*); everything else -- groups, gather, merge in range order -- is the same. */
 typedef struct mc_partset mc_partset;
