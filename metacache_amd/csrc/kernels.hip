@@ -1316,8 +1316,7 @@ uint32_t build_record_windows() { return kBuildRecWins; }
 
 // one lane per chunk: lookups of its <= kChunkWins * s features (kLaneU in flight), (size, payload) of the found features for the wave
 // kernel.  QUAD as in probe_cands_one.
-// DIRECT: the lookups in the direct-address index (DeviceTable::direct), eight 8-byte loads in flight per lane
-template <bool QUAD, bool DIRECT = false>
+template <bool QUAD>
 __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t s, DeviceTable tab, Workspace ws)
 {
     const uint32_t total = ws.midCount[5];
@@ -1333,30 +1332,6 @@ __global__ __launch_bounds__(128) void chunk_probe_kernel(BatchView b, uint32_t 
         uint32_t e = 0;
         uint4 fcache = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         const bool wide = (s & 3u) == 0;
-        if constexpr (DIRECT) {
-            constexpr uint32_t kDirectU = 8;
-            while (e < nf) {
-                uint32_t f[kDirectU], at[kDirectU]; uint64_t ent[kDirectU];
-#pragma unroll
-                for (uint32_t u = 0; u < kDirectU; ++u) {
-                    f[u] = 0xFFFFFFFFu; ent[u] = 0; at[u] = e;
-                    if (e < nf) {
-                        if (wide) {
-                            if ((e & 3u) == 0) fcache = reinterpret_cast<const uint4*>(feats)[e >> 2];
-                            const uint32_t i4 = e++ & 3u;
-                            f[u] = i4 == 0 ? fcache.x : i4 == 1 ? fcache.y : i4 == 2 ? fcache.z : fcache.w;
-                        } else f[u] = feats[e++];
-                    }
-                    if (f[u] != 0xFFFFFFFFu) ent[u] = tab.direct[f[u]];
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kDirectU; ++u) {
-                    const uint32_t size = (uint32_t)ent[u] & 0xFFFFu;
-                    if (f[u] != 0xFFFFFFFFu && size) { ws.psize[fbase + at[u]] = size; ws.ppay[fbase + at[u]] = direct_payload(ent[u]); }
-                }
-            }
-            continue;
-        }
         uint32_t f[kLaneU], home[kLaneU], cur[kLaneU], step[kLaneU], slot[kLaneU];
         QuadRaw raw[kLaneU];
         bool busy[kLaneU];
@@ -1896,8 +1871,7 @@ void launch_chunk_lanes(int stage, const BatchView& b, const SketchParams& sp, c
     if (stage == 0) hipLaunchKernelGGL(chunk_sketch_kernel, dim3(2048), dim3(128), 0, st, b, sp, ws);
     else {
         const bool quad = quadMode >= 0 ? quadMode != 0 : (uint64_t)tab.nbuckets * sizeof(TableBucket) > kQuadTableBytes;
-        if (tab.direct) hipLaunchKernelGGL((chunk_probe_kernel<false, true>), dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
-        else if (quad) hipLaunchKernelGGL(chunk_probe_kernel<true>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
+        if (quad) hipLaunchKernelGGL(chunk_probe_kernel<true>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
         else      hipLaunchKernelGGL(chunk_probe_kernel<false>, dim3(2048), dim3(128), 0, st, b, sp.s, tab, ws);
         hipLaunchKernelGGL(chunk_finish_kernel, dim3(1024), dim3(256), 0, st, sp.s, ws, b, tab);
     }
