@@ -709,7 +709,8 @@ def main():
     ap.add_argument("--e2e-scale", type=float, default=1.0, help="N = 1, default workload: after everything else tools/e2e_scale.py as its own process -- the collection at this "
                     "scale as database FILES in /dev/shm, 10^7 reads as a FASTA file, `mcq query -no-map` and `-tophits -queryids` (`e2e` in the line); falls back to 0.2 "
                     "where the box's memory allowance does not hold the full-scale file set; 0 = skip")
-    ap.add_argument("--e2e-seconds", type=float, default=420.0, help="time limit of that process")
+    ap.add_argument("--e2e-seconds", type=float, default=330.0, help="time limit of that process (it takes 140-200 s at full scale: 100 s to build and write the 174 GB file set, "
+                    "20 + 10 s of loading for the two mcq runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
