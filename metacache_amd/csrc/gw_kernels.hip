@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void gw_filter_count_kernel(BatchV
 {
     using Bloom = GwBloom<TLOG2, TLOG2>;
     constexpr uint32_t kKeep = WPE >= 6 ? 384 : 512;               // numbers kept in LDS: the counting takes them when at most 256 are distinct
-                                                                   // (WPE = 6, "gw_fuse" 4: 26 KB of LDS per block -- six blocks per CU -- and 80 registers: six waves per SIMD)
+                                                                   // (WPE >= 6: 384 -- 26 KB of LDS per block, six blocks per CU, 80 registers: six waves per SIMD, "gw_fuse" 6)
     static_assert(kGwRounds * 8 >= 256 * 4, "the distinct numbers' slots take the place of the round table");
     // WPE = 7 (the default): 22 KB per block -- the round table lies in the filter bits' place until the loads are issued (phase B
     // needs three bits per load of it: gw_pack_rems; the bits are cleared behind the loads), the distinct numbers' slots of the counting in the
