@@ -395,9 +395,6 @@ void mc_destroy(mc_ctx* ctx)
         if (P.stream) (void)hipStreamSynchronize(P.stream);
         if (P.hTotal) (void)hipHostFree(P.hTotal);
         if (P.tail.mainDone) (void)hipEventDestroy(P.tail.mainDone);
-        if (P.front) { (void)hipStreamSynchronize(P.front); (void)hipStreamDestroy(P.front); }
-        if (P.frontGo) (void)hipEventDestroy(P.frontGo);
-        if (P.frontDone) (void)hipEventDestroy(P.frontDone);
         if (P.sortSide.stream) { (void)hipStreamSynchronize(P.sortSide.stream); (void)hipStreamDestroy(P.sortSide.stream); }
         if (P.sortSide.fork) (void)hipEventDestroy(P.sortSide.fork);
         if (P.sortSide.join) (void)hipEventDestroy(P.sortSide.join);
@@ -1088,14 +1085,6 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         const bool quadTable = ctx->quadLookup >= 0 ? ctx->quadLookup != 0 : (uint64_t)tab.nbuckets * 64ull > (1ull << 30);
         const bool fuseSketch = !maskFeatures && (ctx->fuseLane >= 0 ? ctx->fuseLane != 0 : quadTable);
         if (fuseSketch) {
-            if (ctx->cuSplit && P.front && st == P.stream) {
-                // (cu_split: the lookups on the pipe's front stream -- a few CUs of their own --, the rest of the batch waits for them)
-                HIP_TRY(ctx, hipEventRecord(P.frontGo, st));
-                HIP_TRY(ctx, hipStreamWaitEvent(P.front, P.frontGo, 0));
-                { ScopedTimer t(ctx, "sketch_probe", P.front); launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, P.front); }
-                HIP_TRY(ctx, hipEventRecord(P.frontDone, P.front));
-                HIP_TRY(ctx, hipStreamWaitEvent(st, P.frontDone, 0));
-            } else
             { ScopedTimer t(ctx, "sketch_probe", st); launch_sketch_probe_lane(b, sp, tab, ws, K, taxkey, P.bCands.p, ctx->quadLookup, st); }
             { ScopedTimer t(ctx, "chunk_sketch", st); launch_chunk_lanes(0, b, sp, tab, ws, ctx->quadLookup, st); }
             { ScopedTimer t(ctx, "chunk_probe", st); launch_chunk_lanes(1, b, sp, tab, ws, ctx->quadLookup, st); }
@@ -1491,36 +1480,6 @@ int mc_set_tuning(mc_ctx* ctx, const char* name, int64_t value)
     else if (n == "compact_locations") ctx->compactAllowed = value != 0;      // before mc_load_begin
     else if (n == "filter_bpc") ctx->filterBpc = (int)value;                  // blocks per CU of the filter kernels' persistent grids (0 = default); this context only
     else if (n == "count_bpc") ctx->countBpc = (int)value;
-    else if (n == "cu_split") {
-        // experiment: both pipes' streams are made anew with CU masks -- the lookup kernel's (front) streams on `value` CUs (every (256 / value)-th:
-        // the same number from every XCD if the mask's bits go round the XCDs; value < 0: the first |value|), the pipes' own streams on the others
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        hipDeviceProp_t prop{};
-        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        const uint32_t ncu = (uint32_t)prop.multiProcessorCount, want = (uint32_t)std::min<int64_t>(std::llabs(value), ncu / 2);
-        std::vector<uint32_t> fm((ncu + 31) / 32, 0u), mm((ncu + 31) / 32, 0u);
-        for (uint32_t i = 0; i < ncu; ++i) {
-            const bool front = want && (value > 0 ? (i % (ncu / want) == 0 && i / (ncu / want) < want) : i < want);
-            (front ? fm : mm)[i / 32] |= 1u << (i % 32);
-        }
-        auto remake = [&](hipStream_t& s, const std::vector<uint32_t>& mask) -> hipError_t {
-            if (s) { (void)hipStreamDestroy(s); s = nullptr; }
-            return want ? hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-        };
-        HIP_TRY(ctx, remake(ctx->stream, mm));
-        ctx->pipe0.stream = ctx->stream;
-        HIP_TRY(ctx, remake(ctx->pipe1.stream, mm));
-        for (Pipe* Pp : {&ctx->pipe0, &ctx->pipe1}) {
-            if (Pp->front) { (void)hipStreamDestroy(Pp->front); Pp->front = nullptr; }
-            if (want) {
-                HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&Pp->front, (uint32_t)fm.size(), fm.data()));
-                if (!Pp->frontGo) HIP_TRY(ctx, hipEventCreateWithFlags(&Pp->frontGo, hipEventDisableTiming));
-                if (!Pp->frontDone) HIP_TRY(ctx, hipEventCreateWithFlags(&Pp->frontDone, hipEventDisableTiming));
-            }
-        }
-        ctx->cuSplit = want ? (int)value : 0;
-    }
     else if (n == "direct_index") {                                // before the table is loaded; on a loaded table: 0 drops the index, 1 / -1 builds it now (by the rules above)
         ctx->directWant = value < 0 ? -1 : (value != 0);
         if (ctx->tableReady && ctx->parts.size() == 1) {

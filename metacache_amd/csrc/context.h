@@ -23,9 +23,6 @@ struct DevBuf {                 // grow-only device allocation
 struct Pipe {                   // the device workspace of ONE batch in flight + the stream its work is enqueued on
     GwSortSide sortSide;            // second stream + fork / join events of the sorted path (created on first use)
     hipStream_t stream = nullptr;
-    // "cu_split" (experiment, round 6): the sketch + lookup kernel of this pipe's batches on a stream that is masked to a FEW CUs, everything
-    // else on the pipe's stream masked to the others: the next batch's lookups run BESIDE this batch's filter instead of before it
-    hipStream_t front = nullptr; hipEvent_t frontGo = nullptr, frontDone = nullptr;
     DevBuf bWinCount, bWinOff, bFeatures, bPsize, bPpay, bQstat, bHitOff, bHits, bCscr, bCscr2, bScan, bStats,
         bCands, bScanIn, bQflag, bMid, bChunkList, bBigPool, bSliceFill, bBigPool2, bSortTmp, bSide,
         bOrder,              // scratch of launch_gw_order (work lists longest first)
@@ -189,7 +186,6 @@ struct mc_ctx {
     std::atomic<bool> loadSettled{false};  // mc_open_database: the files are through (or the load failed)
     double listAlignShare = 1.0;           // announce_store: the padding (padded - plain store) may take this share of the device's free memory; the part set driver
                                            // lowers it to 1 / (parts it still has to place on the device) -- mcamd::open_hints
-    int cuSplit = 0;                       // mc_set_tuning "cu_split": CUs of the lookup kernel's own stream (0 = off; < 0: the first |n| CUs instead of every (256 / n)-th)
     int directWant = -1;                   // direct-address index beside the buckets: -1 = for tables whose buckets take 8 GiB and more, where 34 GB + head-room are free;
                                            // 0 / 1 (mc_set_tuning "direct_index" before the table is loaded, MC_DIRECT_INDEX)
     int fuseLane = -1;                     // sketching + probing of the lane path in ONE kernel: -1 = where the lookups are quad-cooperative (tables beyond 1 GiB: the
