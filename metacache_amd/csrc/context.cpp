@@ -86,11 +86,24 @@ static void note_enqueues(uint64_t ns, uint32_t calls)
     { std::lock_guard<std::mutex> l(g_warnMu); g_warning = msg; }
     std::fprintf(stderr, "%s\n", msg);
 }
+// MC_SPIN_SYNC (experiment): the host's waits inside a small batch by polling the stream instead of hipStreamSynchronize
+static const int g_spinSync = [] { const char* e = std::getenv("MC_SPIN_SYNC"); return e ? std::atoi(e) : 0; }();
+static hipError_t stream_wait(hipStream_t st)
+{
+    if (g_spinSync > 0) {
+        for (int i = 0; i < g_spinSync; ++i) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipErrorNotReady) return e;
+            for (int k = 0; k < 16; ++k) __builtin_ia32_pause();
+        }
+    }
+    return hipStreamSynchronize(st);
+}
 static hipError_t traced_sync(hipStream_t st)
 {
-    if (!g_submitTrace) return hipStreamSynchronize(st);
+    if (!g_submitTrace) return stream_wait(st);
     const uint64_t t0 = trace_now();
-    const hipError_t e = hipStreamSynchronize(st);
+    const hipError_t e = stream_wait(st);
     g_trace[3] += trace_now() - t0; ++g_trace[6];
     return e;
 }
@@ -347,8 +360,9 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
             d->pipe = p;
             bool ok = true;
             for (int k = 0; k < 2 && ok; ++k)
-                ok = hipHostMalloc((void**)&d->hq[k], (size_t)ctx->coMaxQueries * 16) == hipSuccess && hipHostMalloc((void**)&d->hmw[k], (size_t)ctx->coMaxQueries * 4) == hipSuccess &&
+                ok = hipHostMalloc((void**)&d->hq[k], (size_t)ctx->coMaxQueries * 20) == hipSuccess &&
                      hipEventCreateWithFlags(&d->staged[k], hipEventDisableTiming) == hipSuccess;
+            for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(&d->done[k], hipEventDisableTiming) == hipSuccess;
             ctx->coDisp.push_back(d);
             if (!ok) { mc_destroy(ctx); return fail(nullptr, MC_ERR_NOMEM, "cannot allocate the slot coalescer's staging"); }
         }
@@ -373,6 +387,7 @@ void mc_destroy(mc_ctx* ctx)
         for (auto* d : ctx->coDisp) {
             if (d->pipe && d->pipe->stream) (void)hipStreamSynchronize(d->pipe->stream);
             for (int k = 0; k < 2; ++k) { if (d->hq[k]) (void)hipHostFree(d->hq[k]); if (d->hmw[k]) (void)hipHostFree(d->hmw[k]); if (d->staged[k]) (void)hipEventDestroy(d->staged[k]); }
+            for (int k = 0; k < 4; ++k) if (d->done[k]) (void)hipEventDestroy(d->done[k]);
             for (DevBuf* b : {&d->dseq, &d->dqinfo, &d->dmaxwin}) if (b->p) (void)hipFree(b->p);
             delete d;
         }
@@ -793,7 +808,7 @@ static int run_sorted_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const Sketc
     const uint32_t n = b.n;
     if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
     uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
-    if (!counterCopied) HIP_TRY(ctx, hipMemcpyAsync(nsorted, ws.midCount + 13, 4, hipMemcpyDeviceToHost, st));
+    if (!counterCopied) launch_words_to_host(nsorted, ws.midCount + 13, 1, st);
     HIP_TRY(ctx, traced_sync(st));
     {   // MC_GW_DIAG=1: the batch's work-list counters on stderr (the classes of the filtered path)
         static const bool diag = [] { const char* e = std::getenv("MC_GW_DIAG"); return e && e[0] == '1'; }();
@@ -858,23 +873,34 @@ static int run_filtered_path(mc_ctx* ctx, Pipe& P, const BatchView& b, const Ske
 
 // What the lane path did not finish goes through the exact wave kernels (long reads, duplicate hashes, reads the filtered path handed
 // back, -allhits, ...): sketch + probe unless done, segments for their location lists (the host sizes them: one round trip), sort + candidates.
+// sortedPool (small batches whose filtered path left its sorted class to this call): the host's look at that class's counter shares this
+// call's one round trip -- the wave kernels' sketching and the scan go out first; in the rare batch that has sorted lists they run again
+// behind run_sorted_tail (query_kernel takes the reads still flagged for it: a second pass finds only what the sorted class handed back).
 static int run_wave_tail(mc_ctx* ctx, Pipe& P, const BatchView& b, const SketchParams& sp, const DeviceTable& tab, Workspace& ws, uint32_t K,
-                         const uint32_t* taxkey, bool fuse, bool skipWaveSketch, bool wantAllhits, bool wantPartial, bool wantNumbers, bool lanePath, hipStream_t st)
+                         const uint32_t* taxkey, bool fuse, bool skipWaveSketch, bool wantAllhits, bool wantPartial, bool wantNumbers, bool lanePath, hipStream_t st,
+                         const uint64_t* sortedPool = nullptr)
 {
     int rc = MC_OK;
     const uint32_t n = b.n;
-    if (!skipWaveSketch) {
-        ScopedTimer t(ctx, "query_wave", st);
-        launch_query(b, sp, tab, fuse, wantAllhits, ws, K, P.bCands.p, st);
-    }
-    {
-        ScopedTimer t(ctx, "scan", st);
-        launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st);
-    }
-    // how many locations need a segment in HBM
     if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
-    HIP_TRY(ctx, hipMemcpyAsync(P.hTotal, ws.hitOff + n, 8, hipMemcpyDeviceToHost, st));
+    auto sketch_and_scan = [&]() {
+        if (!skipWaveSketch) {
+            ScopedTimer t(ctx, "query_wave", st);
+            launch_query(b, sp, tab, fuse, wantAllhits, ws, K, P.bCands.p, st);
+        }
+        ScopedTimer t(ctx, "scan", st);
+        // (how many locations need a segment in HBM: the total goes to pinned host memory with the scan)
+        launch_scan_u32(ws.hitScan, 1, n, nullptr, ws.hitOff, ws.scanTmp, st, P.hTotal);
+    };
+    sketch_and_scan();
+    uint32_t* nsorted = reinterpret_cast<uint32_t*>(P.hTotal + 9);
+    if (sortedPool) launch_words_to_host(nsorted, ws.midCount + 13, 1, st);
     HIP_TRY(ctx, traced_sync(st));
+    if (sortedPool && *nsorted) {
+        if ((rc = run_sorted_tail(ctx, P, b, sp, tab, ws, K, taxkey, *sortedPool, true, st))) return rc;
+        sketch_and_scan();
+        HIP_TRY(ctx, traced_sync(st));
+    }
     const uint64_t totalHits = *P.hTotal;
     const size_t hb = (size_t)(totalHits + 1) * 8;
     if ((rc = ensure(ctx, P.bHits, hb))) return rc;
@@ -902,6 +928,7 @@ static int finish_on_pipe(mc_ctx* ctx, Pipe& P);
 int mc_query_device(mc_ctx* ctx, const mc_device_batch* in, int lowestRank, int flags, mc_device_results* out, void* streamv)
 {
     if (!ctx || !in || !out) return MC_ERR_INVALID;
+    flags &= ~mcamd::kQueryNoLongReads;                           // (internal: the caller of this entry point has not seen the reads)
     if (flags & MC_SECOND_PIPE) {
         if (!ctx->pipe1.stream) {
             HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1053,7 +1080,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         ws.bigPool = (uint64_t*)P.bBigPool.p; ws.bigPoolCap = (uint32_t)poolCap; ws.bigOvfCap = (uint32_t)ovfCap;
         ws.sliceFill = (uint32_t*)P.bSliceFill.p;
         ws.sideList = (uint32_t*)P.bSide.p;
-        ws.chunkList = (uint2*)P.bChunkList.p;
+        ws.chunkList = (flags & kQueryNoLongReads) ? nullptr : (uint2*)P.bChunkList.p;   // (null: no read is cut into chunks, launch_chunk_lanes launches nothing)
     }
 
     BatchView b{in->seq, in->qinfo, in->max_win, in->max_win_uniform, n};
@@ -1066,17 +1093,22 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     }
     tab.direct = T.ddirect;                                       // (the lane path's lookups; every other kernel goes through the buckets)
 
+    bool planSmall = false;                                      // small batches: plan + scan + the work-list counters' clearing in one launch
     {
         ScopedTimer t(ctx, "plan", st);
-        launch_plan(b, sp, ws.winCount, st);
-        launch_scan_u32(ws.winCount, 1, n, ws.winOff, nullptr, ws.scanTmp, st);
+        planSmall = launch_plan_scan_small(b, sp, ws.winCount, ws.winOff, lanePath ? ws.midCount : nullptr, st);
+        if (!planSmall) {
+            launch_plan(b, sp, ws.winCount, st);
+            launch_scan_u32(ws.winCount, 1, n, ws.winOff, nullptr, ws.scanTmp, st);
+        }
     }
     const bool fuse = !wantAllhits && !taxkey;
     bool waveWork = true;                                        // wave kernels needed (always without the lane path)
     bool skipWaveSketch = false;                                 // ... their sketching and probing has run already
+    bool sortedInTail = false;                                   // the filtered path's sorted class is run_wave_tail's to look at
     if (lanePath) {
         // short reads: one lane per query for sketching and candidates, cooperative probing in between
-        HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
+        if (!planSmall) HIP_TRY(ctx, hipMemsetAsync(ws.midCount, 0, 128, st));
         // sketching + probing in ONE kernel where the lookups wait for HBM (tables beyond the infinity cache: quad-cooperative fetches) -- the
         // sketching of some waves runs under the waiting of others (5.27 -> 5.08 ms per 5 x 10^6 reads at full scale); small tables keep
         // the two kernels (the ALU phase at the probe kernel's occupancy cost 5 % on configs[1]).  "lane_fusion" / MC_LANE_FUSION: 0 / 1 force it.
@@ -1108,8 +1140,7 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         if (!wantPartial && n <= (1u << 20) && !(flags & MC_DEFER_TAIL)) {
             if (!P.hTotal) HIP_TRY(ctx, hipHostMalloc((void**)&P.hTotal, 128));
             hcnt = reinterpret_cast<uint32_t*>(P.hTotal + 1);
-            launch_flag_count(ws, n, st);
-            HIP_TRY(ctx, hipMemcpyAsync(hcnt, ws.midCount, 64, hipMemcpyDeviceToHost, st));
+            launch_flag_count_host(ws, n, hcnt, st);
             HIP_TRY(ctx, traced_sync(st));
         }
         auto mid_and_hash = [&]() {
@@ -1139,10 +1170,12 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
         // filtered path, the segment sizes of the exact wave kernels' leftovers -- waits for mc_query_finish; this call returns with
         // the main kernels enqueued and NO synchronisation, so that the caller can enqueue the next batch on the other pipe first
         const bool defer = (flags & MC_DEFER_TAIL) != 0 && hcnt == all && !wantFeatures;
-        if (hcnt[9] || waveDone) {
-            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st, defer))) return rc;
-        }
         waveWork = wantPartial || hcnt[6] != 0 || hcnt[7] != 0 || hcnt[9] != 0;   // big_cands hands a few queries on to the wave kernels
+        // small batches: the sorted class's counter is looked at together with the wave tail's total (run_wave_tail: one round trip for both)
+        sortedInTail = hcnt != all && !defer && T.compact && waveWork && (hcnt[9] || waveDone);
+        if (hcnt[9] || waveDone) {
+            if ((rc = run_filtered_path(ctx, P, b, sp, tab, ws, K, taxkey, T.compact, hcnt[10] != 0, poolCap + ovfCap, st, defer || sortedInTail))) return rc;
+        }
         skipWaveSketch = waveDone;
         if (defer) {
             Pipe::Tail& tl = P.tail;
@@ -1166,7 +1199,9 @@ static int query_on_pipe(mc_ctx* ctx, Pipe& P, const mc_device_batch* in, int lo
     } else {
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ws.qflag, 1, n, st));     // every query: needs sketch + probe
     }
-    if (waveWork && (rc = run_wave_tail(ctx, P, b, sp, tab, ws, K, taxkey, fuse, skipWaveSketch, wantAllhits != 0, wantPartial, wantNumbers, lanePath, st))) return rc;
+    const uint64_t sortedPoolEntries = poolCap + ovfCap;
+    if (waveWork && (rc = run_wave_tail(ctx, P, b, sp, tab, ws, K, taxkey, fuse, skipWaveSketch, wantAllhits != 0, wantPartial, wantNumbers, lanePath, st,
+                                        sortedInTail ? &sortedPoolEntries : nullptr))) return rc;
     HIP_TRY(ctx, hipGetLastError());
     P.lastN = n;
     out->cands = (const mc_candidate*)P.bCands.p;
@@ -1587,6 +1622,7 @@ int mc_batch_add(mc_ctx* ctx, uint32_t slot, const char* s1, uint32_t l1, const 
     if (l2) std::memcpy(S.hseq + S.nchars, s2, l2);
     S.nchars += ((uint64_t)l2 + 3) / 4 * 4;
     S.hmaxwin[S.nq] = maxWin;
+    if (l2 == 0 && l1 > S.maxSingle) S.maxSingle = l1;
     S.nq++;
     return MC_OK;
 }
@@ -1665,12 +1701,15 @@ int mc_batch_submit(mc_ctx* ctx, uint32_t slot, int lowestRank)
     mc_device_results res{};
     const int wantAll = ctx->cfg.copy_allhits ? 1 : 0;
     const uint64_t tt2 = g_submitTrace ? trace_now() : 0;
-    int rc = query_on_pipe(ctx, P, &in, lowestRank, wantAll, &res, st);
+    int rc = query_on_pipe(ctx, P, &in, lowestRank, wantAll | (S.maxSingle <= mcamd::lane_max_len() ? mcamd::kQueryNoLongReads : 0), &res, st);
     if (rc) return rc;
     const uint64_t tt3 = g_submitTrace ? trace_now() : 0;
     const size_t K = ctx->cfg.max_candidates;
-    HIP_TRY(ctx, hipMemcpyAsync(S.hcands, res.cands, (size_t)n * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(S.hqstat, P.bQstat.p, (size_t)n * sizeof(QueryStat), hipMemcpyDeviceToHost, st));
+    {   // candidates and statistics to the slot's pinned buffers by one kernel (launch_deliver) instead of two copies
+        DeliverTable dt{};
+        dt.e[0] = DeliverEntry{S.hcands, S.hqstat, 0u, n}; dt.n = 1;
+        launch_deliver(dt, res.cands, P.bQstat.p, (uint32_t)K, st);
+    }
     if (wantAll) {
         HIP_TRY(ctx, hipMemcpyAsync(S.hhitoff, res.hit_offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, traced_sync(st));
@@ -1748,6 +1787,7 @@ static void co_run(mc_ctx* ctx, mcamd::CoDispatcher* D, const std::vector<uint32
     const size_t K = ctx->cfg.max_candidates;
     {
         uint64_t nq = 0, nc = 0;
+        uint32_t maxSingle = 0;
         for (uint32_t s : mine) { nq += ctx->slots[s].nq; nc += ctx->slots[s].nchars; }
         int rc = MC_OK;
         err.clear();
@@ -1755,16 +1795,20 @@ static void co_run(mc_ctx* ctx, mcamd::CoDispatcher* D, const std::vector<uint32
         auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) { rc = MC_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
         if (D->stagedUsed[k]) hip(hipEventSynchronize(D->staged[k]), "hipEventSynchronize");   // (two united batches ago: long through)
         if (!rc) rc = ensure(ctx, D->dseq, nc + 64);
-        if (!rc) rc = ensure(ctx, D->dqinfo, nq * 16);
-        if (!rc) rc = ensure(ctx, D->dmaxwin, nq * 4);
+        if (!rc) rc = ensure(ctx, D->dqinfo, nq * 20);
         if (!rc) {
+            const uint64_t ttA = g_submitTrace ? trace_now() : 0;
             uint64_t qb = 0, cb = 0, enq = 0;
-            uint32_t* hq = D->hq[k]; uint32_t* hmw = D->hmw[k];
+            // the rows of the queries and their window limits in ONE pinned buffer and one copy: [nq x 16 bytes | nq x 4 bytes]
+            uint32_t* hq = D->hq[k]; uint32_t* hmw = hq + nq * 4;
             for (uint32_t s : mine) {
                 Slot& S = ctx->slots[s];
+                const bool last = s == mine.back();
+                if (last) std::memset(S.hseq + S.nchars, 0, 16);   // (the united input ends with 16 zero bytes: they travel with the last slot's characters)
                 const uint64_t te0 = trace_now();
-                hip(hipMemcpyAsync((uint8_t*)D->dseq.p + cb, S.hseq, S.nchars, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+                hip(hipMemcpyAsync((uint8_t*)D->dseq.p + cb, S.hseq, S.nchars + (last ? 16 : 0), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
                 enq += trace_now() - te0;
+                if (S.maxSingle > maxSingle) maxSingle = S.maxSingle;
                 for (uint32_t j = 0; j < S.nq; ++j) {
                     const uint32_t* q = S.hqinfo + (size_t)j * 4;
                     uint32_t* o = hq + (qb + j) * 4;
@@ -1773,32 +1817,42 @@ static void co_run(mc_ctx* ctx, mcamd::CoDispatcher* D, const std::vector<uint32
                 std::memcpy(hmw + qb, S.hmaxwin, (size_t)S.nq * 4);
                 qb += S.nq; cb += S.nchars;
             }
-            hip(hipMemsetAsync((uint8_t*)D->dseq.p + cb, 0, 16, st), "hipMemsetAsync");
-            hip(hipMemcpyAsync(D->dqinfo.p, hq, nq * 16, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
-            hip(hipMemcpyAsync(D->dmaxwin.p, hmw, nq * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+            hip(hipMemcpyAsync(D->dqinfo.p, hq, nq * 20, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
             hip(hipEventRecord(D->staged[k], st), "hipEventRecord");
             D->stagedUsed[k] = true;
             note_enqueues(enq, (uint32_t)mine.size());
+            if (g_submitTrace) g_trace[1] += trace_now() - ttA;
         }
         mc_device_results res{};
         if (!rc) {
-            mc_device_batch in{(const uint8_t*)D->dseq.p, (const uint32_t*)D->dqinfo.p, (const uint32_t*)D->dmaxwin.p, 0, (uint32_t)nq, nc};
+            mc_device_batch in{(const uint8_t*)D->dseq.p, (const uint32_t*)D->dqinfo.p, (const uint32_t*)D->dqinfo.p + nq * 4, 0, (uint32_t)nq, nc};
             // (MC_SLOT_DEFER=1: deferred tail, finished at once -- the main kernels go out without a look at the work lists' counters: two
             // host round trips less per united batch, every kernel of the path launched whether it has work or not.  Measured at 4 096
             // reads per slot, 32 threads: 4 019 against 4 189 Mreads/min for the synchronous call, profiles/r06_slot_path.json: off)
             static const bool defer = [] { const char* e = std::getenv("MC_SLOT_DEFER"); return e && e[0] == '1'; }();
-            rc = query_on_pipe(ctx, P, &in, lowest, defer ? MC_DEFER_TAIL : 0, &res, st);
+            const uint64_t ttB = g_submitTrace ? trace_now() : 0;
+            rc = query_on_pipe(ctx, P, &in, lowest, (defer ? MC_DEFER_TAIL : 0) | (maxSingle <= mcamd::lane_max_len() ? mcamd::kQueryNoLongReads : 0), &res, st);
             if (!rc && defer) rc = finish_on_pipe(ctx, P);
+            if (g_submitTrace) { g_trace[2] += trace_now() - ttB; ++g_trace[5]; }
         }
         if (!rc) {
+            const uint64_t ttC = g_submitTrace ? trace_now() : 0;
+            // every slot's candidates and statistics into its own pinned buffers: one kernel per sixteen slots (launch_deliver) -- two copies
+            // per slot at ~15 us each were half a united batch's time on the stream --, then the slots' events behind it
             uint64_t qb = 0;
+            DeliverTable dt{};
             for (uint32_t s : mine) {
                 Slot& S = ctx->slots[s];
-                hip(hipMemcpyAsync(S.hcands, (const mc_candidate*)res.cands + qb * K, (size_t)S.nq * K * sizeof(mc_candidate), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
-                hip(hipMemcpyAsync(S.hqstat, (const QueryStat*)P.bQstat.p + qb, (size_t)S.nq * sizeof(QueryStat), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
-                hip(hipEventRecord(S.done, st), "hipEventRecord");
+                dt.e[dt.n++] = DeliverEntry{S.hcands, S.hqstat, (uint32_t)qb, S.nq};
+                if (dt.n == kDeliverMax) { launch_deliver(dt, res.cands, P.bQstat.p, (uint32_t)K, st); dt.n = 0; }
                 qb += S.nq;
             }
+            launch_deliver(dt, res.cands, P.bQstat.p, (uint32_t)K, st);
+            hip(hipGetLastError(), "deliver_kernel");
+            hipEvent_t ev = D->done[D->doneTurn++ & 3u];
+            hip(hipEventRecord(ev, st), "hipEventRecord");
+            for (uint32_t s : mine) ctx->slots[s].coDoneEv = ev;
+            if (g_submitTrace) g_trace[4] += trace_now() - ttC;
         }
         if (rc) (void)hipStreamSynchronize(st);                     // (whatever was enqueued is through before the slots' buffers go back to their owners)
         {
@@ -1827,7 +1881,7 @@ int mc_batch_wait(mc_ctx* ctx, uint32_t slot, mc_results* out)
     if (ctx->coalesce) {
         { std::unique_lock<std::mutex> l(ctx->coMu); ctx->coDoneCv.wait(l, [&] { return S.coState == 3; }); }
         if (S.coRc) return fail(ctx, S.coRc, S.coErr);
-        if (S.coEvent) HIP_TRY(ctx, hipEventSynchronize(S.done));
+        if (S.coEvent) HIP_TRY(ctx, hipEventSynchronize(S.coDoneEv));
     } else
     HIP_TRY(ctx, hipEventSynchronize(S.done));
     release_pipe(ctx, S);                                       // the results are in the slot's pinned buffers
@@ -1868,11 +1922,11 @@ int mc_batch_clear(mc_ctx* ctx, uint32_t slot)
     Slot& S = ctx->slots[slot];
     if (S.submitted && ctx->coalesce) {
         { std::unique_lock<std::mutex> l(ctx->coMu); ctx->coDoneCv.wait(l, [&] { return S.coState == 3; }); }
-        if (S.coEvent) (void)hipEventSynchronize(S.done);
+        if (S.coEvent) (void)hipEventSynchronize(S.coDoneEv);
         S.coState = 0; S.coEvent = false;
     } else if (S.submitted) (void)hipEventSynchronize(S.done);
     release_pipe(ctx, S);
-    S.submitted = false; S.nq = 0; S.nchars = 0;
+    S.submitted = false; S.nq = 0; S.nchars = 0; S.maxSingle = 0;
     return MC_OK;
 }
 

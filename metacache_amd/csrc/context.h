@@ -73,6 +73,7 @@ struct Slot {
     // pinned host staging
     uint8_t* hseq = nullptr; uint32_t* hqinfo = nullptr; uint32_t* hmaxwin = nullptr;
     uint32_t nq = 0; uint64_t nchars = 0;
+    uint32_t maxSingle = 0;         // longest single read of the batch (mc_batch_add): none beyond a lane's reach -> the chunk lanes' three launches are left out
     // device input
     uint8_t* dseq = nullptr; uint32_t* dqinfo = nullptr; uint32_t* dmaxwin = nullptr;
     // pinned results
@@ -86,16 +87,23 @@ struct Slot {
     // 3 = enqueued on the device (`done` is recorded behind its copies back) or failed (coRc)
     int coState = 0, coRc = 0, coLowest = 0;
     bool coEvent = false;
+    hipEvent_t coDoneEv = nullptr;  // the united batch's event (the dispatcher's, one of four in turn): recorded behind the kernel that delivered the results
     std::string coErr;
 };
 
 // one dispatcher thread of the slot coalescer: a pipe of its own, the united batch's device input, pinned staging (twice) for the rebased qinfo rows
+// query_on_pipe, internal (the slots, which see every read on the host): no single read is longer than one lane takes -- the chunk lanes'
+// kernels (launched for their work list, which would be empty) are left out.  Masked out of mc_query_device's flags.
+constexpr int kQueryNoLongReads = 1 << 24;
+
 struct CoDispatcher {
     std::thread th;
     Pipe* pipe = nullptr;
     DevBuf dseq, dqinfo, dmaxwin;
     uint32_t* hq[2] = {nullptr, nullptr}; uint32_t* hmw[2] = {nullptr, nullptr};
     hipEvent_t staged[2] = {nullptr, nullptr};   // the staging set has left the host
+    hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};   // a united batch's results are in its slots' pinned buffers (ONE event for all its slots, four in turn)
+    uint32_t doneTurn = 0;
     bool stagedUsed[2] = {false, false};
     uint32_t turn = 0;
 };

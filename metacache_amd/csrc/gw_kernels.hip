@@ -1137,8 +1137,10 @@ __global__ __launch_bounds__(WAVES * 64, LOG2S == 9 ? MC_GW_COUNT_WPE : LOG2S ==
     // winners' target lookup behind the next read's counting (GwPend).
     constexpr bool kDefer = LOG2S <= 10;
     GwPend P;
-    constexpr uint32_t kStep = LOG2S == 9 ? 64u : 8u;
     const uint32_t nmine = LOG2S == 9 ? total : ws.midCount[LOG2S == 10 ? 14 : 15];
+    // (few records -- the small batches of the host slots --: fewer per step, so that every wave of the grid has one before any wave has two;
+    // eight reads of ~25 us each one after the other on five waves were the longest kernel of a 4 096-read batch)
+    const uint32_t kStep = LOG2S == 9 ? 64u : min(8u, max(1u, (nmine + nWaves - 1) / nWaves));
     const uint32_t* __restrict__ side = ws.sideList + (size_t)(LOG2S == 10 ? 1 : 2) * b.n;
     for (uint32_t chunk = w0 * kStep; chunk < nmine; chunk += nWaves * kStep) {
       const bool inb = lane < kStep && chunk + lane < nmine;

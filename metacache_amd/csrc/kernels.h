@@ -176,9 +176,21 @@ struct Workspace {           // device buffers sized by the host for this batch
 };
 
 // launchers (all asynchronous on 'st')
+// Results of a batch of the host slots to the slots' own PINNED host buffers by ONE kernel (uint4 stores over the host link): every
+// hipMemcpyAsync D2H costs the stream ~15 us whatever its size, and a united batch has two per slot.  entry i: queries [first, first + count)
+// of the batch -> its candidates (count x K x 16 bytes) and statistics (count x 16 bytes).
+struct DeliverEntry { void* cands; void* qstat; uint32_t first, count; };
+constexpr uint32_t kDeliverMax = 16;
+struct DeliverTable { DeliverEntry e[kDeliverMax]; uint32_t n; };
+void launch_deliver(const DeliverTable& t, const void* cands, const void* qstat, uint32_t K, hipStream_t st);
+void launch_flag_count_host(const Workspace& ws, uint32_t n, uint32_t* hostCounts, hipStream_t st);   // launch_flag_count + the sixteen counters to pinned host memory
+void launch_words_to_host(uint32_t* hostDst, const uint32_t* src, uint32_t nwords, hipStream_t st);   // device words -> pinned host memory by a kernel on `st` (no copy engine)
+uint32_t lane_max_len();   // longest single read one lane sketches (longer ones are cut into chunk lanes' records)
 void launch_plan(const BatchView& b, const SketchParams& sp, uint32_t* winCount, hipStream_t st);
+// small batches (up to 65 536 reads): plan + scan of the windows + the lane path's 32 work-list counters cleared (zero32, may be null) in ONE launch; false: too large, nothing launched
+bool launch_plan_scan_small(const BatchView& b, const SketchParams& sp, uint32_t* winCount, uint32_t* winOff, uint32_t* zero32, hipStream_t st);
 void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64,
-                     void* tmp, hipStream_t st);
+                     void* tmp, hipStream_t st, uint64_t* hostTotal = nullptr);   // hostTotal: the grand total also to pinned host memory, by the kernels themselves
 size_t scan_tmp_bytes(uint32_t n);
 void launch_sketch_only(const BatchView& b, const SketchParams& sp, const Workspace& ws, hipStream_t st);
 // database builder: window sketches of window-aligned chunk records (<= build_record_windows() windows each); lanes where the

@@ -161,8 +161,86 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply(const uint32_t* __restr
 
 size_t scan_tmp_bytes(uint32_t n) { return ((size_t)(n + kScanTile - 1) / kScanTile + 2) * sizeof(uint64_t); }
 
-void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64, void* tmp, hipStream_t st)
+// Small inputs (the batches of the host slots: 4 096 reads each, a few of them united): ONE block of 1 024 threads walks the input in
+// tiles of 4 096 with a running carry -- one launch instead of three.  A launch costs the host ~5 us and the stream a dependent
+// dispatch; at 30 launches for 0.1 ms of device work per batch the slot path is bound by them (docs/LAB_NOTEBOOK_r06.md section 5).
+constexpr uint32_t kSmallScan = 65536, kSmallScanBlock = 1024, kSmallScanItems = 4;
+template <typename Value>
+__device__ __forceinline__ void scan_one_block(const uint32_t n, Value value, uint32_t* __restrict__ out32, uint64_t* __restrict__ out64, uint64_t* hostTotal = nullptr)
 {
+    __shared__ uint64_t waveSum[kSmallScanBlock / 64 + 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kSmallScanBlock * kSmallScanItems) {
+        const uint32_t i0 = base + threadIdx.x * kSmallScanItems;
+        uint32_t v[kSmallScanItems];
+        uint64_t local = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kSmallScanItems; ++j) { v[j] = i0 + j < n ? value(i0 + j) : 0u; local += v[j]; }
+        uint64_t incl = local;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint64_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) waveSum[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t run = 0;
+            for (uint32_t w = 0; w < kSmallScanBlock / 64; ++w) { const uint64_t t = waveSum[w]; waveSum[w] = run; run += t; }
+            waveSum[kSmallScanBlock / 64] = run;
+        }
+        __syncthreads();
+        uint64_t run = carry + waveSum[wave] + incl - local;
+        carry += waveSum[kSmallScanBlock / 64];
+#pragma unroll
+        for (uint32_t j = 0; j < kSmallScanItems; ++j) {
+            if (i0 + j < n) {
+                if (out32) out32[i0 + j] = (uint32_t)run;
+                if (out64) out64[i0 + j] = run;
+            }
+            run += v[j];
+        }
+        __syncthreads();                                           // (waveSum is written again in the next tile)
+    }
+    if (threadIdx.x == 0) {
+        if (out32) out32[n] = (uint32_t)carry;
+        if (out64) out64[n] = carry;
+        if (hostTotal) { *hostTotal = carry; __threadfence_system(); }   // (pinned host memory: the host sizes its segments by it)
+    }
+}
+__global__ __launch_bounds__(kSmallScanBlock) void scan_small_kernel(const uint32_t* __restrict__ in, uint32_t stride, uint32_t n,
+                                                                     uint32_t* __restrict__ out32, uint64_t* __restrict__ out64, uint64_t* hostTotal)
+{
+    scan_one_block(n, [&](uint32_t i) { return in[(size_t)i * stride]; }, out32, out64, hostTotal);
+}
+// ... and the window arithmetic of plan_kernel in the same block: winCount, its scan, and the lane path's work-list counters cleared
+// (`zero32`: 32 words, or null) -- one launch for what were five
+__global__ __launch_bounds__(kSmallScanBlock) void plan_scan_small_kernel(BatchView b, SketchParams sp, uint32_t* __restrict__ winCount, uint32_t* __restrict__ winOff,
+                                                                          uint32_t* __restrict__ zero32)
+{
+    if (zero32 && threadIdx.x < 32) zero32[threadIdx.x] = 0u;
+    scan_one_block(b.n, [&](uint32_t q) {
+        const uint4 qi = reinterpret_cast<const uint4*>(b.qinfo)[q];
+        const bool noTail = qi.w == kNoTail;
+        uint32_t c = windows_of(qi.y, sp, noTail);
+        if (!noTail) c += windows_of(qi.w, sp, false);
+        winCount[q] = c;
+        return c;
+    }, winOff, nullptr);
+}
+bool launch_plan_scan_small(const BatchView& b, const SketchParams& sp, uint32_t* winCount, uint32_t* winOff, uint32_t* zero32, hipStream_t st)
+{
+    if (b.n == 0 || b.n > kSmallScan) return false;                // (the caller takes the three-kernel way)
+    hipLaunchKernelGGL(plan_scan_small_kernel, dim3(1), dim3(kSmallScanBlock), 0, st, b, sp, winCount, winOff, zero32);
+    return true;
+}
+
+void launch_words_to_host(uint32_t* hostDst, const uint32_t* src, uint32_t nwords, hipStream_t st);
+void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64, void* tmp, hipStream_t st, uint64_t* hostTotal)
+{
+    if (n <= kSmallScan) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kSmallScanBlock), 0, st, in, stride, n, out32, out64, hostTotal);
+        return;
+    }
+    struct TotalOut { uint64_t* host; uint64_t* out64; uint32_t n; hipStream_t st; ~TotalOut() { if (host && out64) launch_words_to_host(reinterpret_cast<uint32_t*>(host), reinterpret_cast<const uint32_t*>(out64 + n), 2, st); } } totalOut{hostTotal, out64, n, st};
     uint32_t nblocks = (n + kScanTile - 1) / kScanTile;
     if (nblocks == 0) nblocks = 1;
     uint64_t* sums = (uint64_t*)tmp;
@@ -1846,6 +1924,8 @@ __global__ __launch_bounds__(kLaneBlock) void sketch_probe_lane_kernel(BatchView
     probe_cands_one<QUAD, DIRECT>(b, sp.s, tab, ws, K, taxkey, cands, q, lst + threadIdx.x * kLaneRow, q < b.n && flag == kFlagProbe);
 }
 
+uint32_t lane_max_len() { return kLaneMaxLen; }
+
 void launch_sketch_probe_lane(const BatchView& b, const SketchParams& sp, const DeviceTable& tab, const Workspace& ws, uint32_t maxCand,
                               const uint32_t* taxkey, void* cands, int quadMode, hipStream_t st)
 {
@@ -3078,6 +3158,61 @@ __global__ __launch_bounds__(256) void flag_count_kernel(const uint32_t* __restr
 void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st)
 {
     if (n) hipLaunchKernelGGL(flag_count_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), dim3(256), 0, st, ws.qflag, n, ws.midCount);
+}
+// small batches: ONE block counts, and hands the sixteen work-list counters to the host (pinned memory) itself
+__global__ __launch_bounds__(1024) void flag_count_small_kernel(const uint32_t* __restrict__ qflag, uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ hostCounts)
+{
+    uint32_t a = 0, c = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t f = qflag[i];
+        a += f == kFlagSketch; c += f == kFlagCands;
+    }
+    const uint64_t ma = __ballot(a != 0), mc = __ballot(c != 0);
+    if (ma) { for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off); if ((threadIdx.x & 63) == 0) atomicAdd(&counts[6], a); }
+    if (mc) { for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off); if ((threadIdx.x & 63) == 0) atomicAdd(&counts[7], c); }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x < 16) { hostCounts[threadIdx.x] = __hip_atomic_load(&counts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __threadfence_system(); }
+}
+void launch_flag_count_host(const Workspace& ws, uint32_t n, uint32_t* hostCounts, hipStream_t st)
+{
+    if (n && n <= kSmallScan) { hipLaunchKernelGGL(flag_count_small_kernel, dim3(1), dim3(1024), 0, st, ws.qflag, n, ws.midCount, hostCounts); return; }
+    launch_flag_count(ws, n, st);
+    launch_words_to_host(hostCounts, ws.midCount, 16, st);
+}
+
+// A few words of device memory to PINNED HOST memory by a one-wave kernel on the batch's own stream: what the host looks at inside a
+// batch (work-list counters, segment totals).  hipMemcpyAsync would take them through a copy engine -- a hop to another queue and back
+// for 64 bytes, which is most of a small batch's latency (docs/LAB_NOTEBOOK_r06.md section 5).
+__global__ __launch_bounds__(64) void words_to_host_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ hostDst, uint32_t nwords)
+{
+    for (uint32_t i = threadIdx.x; i < nwords; i += 64) hostDst[i] = src[i];
+    __threadfence_system();
+}
+void launch_words_to_host(uint32_t* hostDst, const uint32_t* src, uint32_t nwords, hipStream_t st)
+{
+    hipLaunchKernelGGL(words_to_host_kernel, dim3(1), dim3(64), 0, st, src, hostDst, nwords);
+}
+
+__global__ __launch_bounds__(256) void deliver_kernel(DeliverTable t, const uint4* __restrict__ cands, const uint4* __restrict__ qstat, uint32_t K)
+{
+    const DeliverEntry e = t.e[blockIdx.y];
+    uint4* __restrict__ dc = reinterpret_cast<uint4*>(e.cands);
+    uint4* __restrict__ dq = reinterpret_cast<uint4*>(e.qstat);
+    const uint32_t nc = e.count * K;
+    const uint4* __restrict__ sc = cands + (size_t)e.first * K;
+    const uint4* __restrict__ sq = qstat + e.first;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) dc[i] = sc[i];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < e.count; i += gridDim.x * 256) dq[i] = sq[i];
+    __threadfence_system();
+}
+void launch_deliver(const DeliverTable& t, const void* cands, const void* qstat, uint32_t K, hipStream_t st)
+{
+    static_assert(sizeof(mc_candidate_dev) == 16 && sizeof(QueryStat) == 16, "whole uint4 records");
+    if (!t.n) return;
+    uint32_t most = 0;
+    for (uint32_t i = 0; i < t.n; ++i) most = std::max(most, t.e[i].count * K);
+    hipLaunchKernelGGL(deliver_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>(64, (most + 1023) / 1024)), t.n), dim3(256), 0, st, t, (const uint4*)cands, (const uint4*)qstat, K);
 }
 
 bool lane_path_supported(const SketchParams& sp) { return sp.s <= kLaneS && sp.stride == sp.w - sp.k + 1 && sp.k <= 16; }
