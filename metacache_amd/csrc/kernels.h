@@ -187,7 +187,7 @@ void launch_flag_count_host(const Workspace& ws, uint32_t n, uint32_t* hostCount
 void launch_words_to_host(uint32_t* hostDst, const uint32_t* src, uint32_t nwords, hipStream_t st);   // device words -> pinned host memory by a kernel on `st` (no copy engine)
 uint32_t lane_max_len();   // longest single read one lane sketches (longer ones are cut into chunk lanes' records)
 void launch_plan(const BatchView& b, const SketchParams& sp, uint32_t* winCount, hipStream_t st);
-// small batches (up to 65 536 reads): plan + scan of the windows + the lane path's 32 work-list counters cleared (zero32, may be null) in ONE launch; false: too large, nothing launched
+// small batches (up to 32 768 reads): plan + scan of the windows + the lane path's 32 work-list counters cleared (zero32, may be null) in ONE launch; false: too large, nothing launched
 bool launch_plan_scan_small(const BatchView& b, const SketchParams& sp, uint32_t* winCount, uint32_t* winOff, uint32_t* zero32, hipStream_t st);
 void launch_scan_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out32, uint64_t* out64,
                      void* tmp, hipStream_t st, uint64_t* hostTotal = nullptr);   // hostTotal: the grand total also to pinned host memory, by the kernels themselves

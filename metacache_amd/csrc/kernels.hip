@@ -164,14 +164,18 @@ size_t scan_tmp_bytes(uint32_t n) { return ((size_t)(n + kScanTile - 1) / kScanT
 // Small inputs (the batches of the host slots: 4 096 reads each, a few of them united): ONE block of 1 024 threads walks the input in
 // tiles of 4 096 with a running carry -- one launch instead of three.  A launch costs the host ~5 us and the stream a dependent
 // dispatch; at 30 launches for 0.1 ms of device work per batch the slot path is bound by them (docs/LAB_NOTEBOOK_r06.md section 5).
-constexpr uint32_t kSmallScan = 65536, kSmallScanBlock = 1024, kSmallScanItems = 4;
+constexpr uint32_t kSmallScan = 32768, kSmallScanBlock = 256, kSmallScanItems = 8;
+// (256 threads: a block of 1 024 has to find sixteen free wave slots on ONE CU, which on a device busy with other pipes' kernels took
+// longer than its work; a tile of 2 048 elements costs one barrier: the waves' sums are double-buffered and every thread adds up the ones before its wave)
 template <typename Value>
 __device__ __forceinline__ void scan_one_block(const uint32_t n, Value value, uint32_t* __restrict__ out32, uint64_t* __restrict__ out64, uint64_t* hostTotal = nullptr)
 {
-    __shared__ uint64_t waveSum[kSmallScanBlock / 64 + 1];
+    constexpr uint32_t kWaves = kSmallScanBlock / 64;
+    __shared__ uint64_t waveSum[2][kWaves];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < n; base += kSmallScanBlock * kSmallScanItems) {
+    uint32_t buf = 0;
+    for (uint32_t base = 0; base < n; base += kSmallScanBlock * kSmallScanItems, buf ^= 1u) {
         const uint32_t i0 = base + threadIdx.x * kSmallScanItems;
         uint32_t v[kSmallScanItems];
         uint64_t local = 0;
@@ -180,16 +184,13 @@ __device__ __forceinline__ void scan_one_block(const uint32_t n, Value value, ui
         uint64_t incl = local;
 #pragma unroll
         for (uint32_t d = 1; d < 64; d <<= 1) { const uint64_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-        if (lane == 63) waveSum[wave] = incl;
+        if (lane == 63) waveSum[buf][wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t run = 0;
-            for (uint32_t w = 0; w < kSmallScanBlock / 64; ++w) { const uint64_t t = waveSum[w]; waveSum[w] = run; run += t; }
-            waveSum[kSmallScanBlock / 64] = run;
-        }
-        __syncthreads();
-        uint64_t run = carry + waveSum[wave] + incl - local;
-        carry += waveSum[kSmallScanBlock / 64];
+        uint64_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) { const uint64_t t = waveSum[buf][w]; all += t; if (w < wave) before += t; }
+        uint64_t run = carry + before + incl - local;
+        carry += all;
 #pragma unroll
         for (uint32_t j = 0; j < kSmallScanItems; ++j) {
             if (i0 + j < n) {
@@ -198,7 +199,6 @@ __device__ __forceinline__ void scan_one_block(const uint32_t n, Value value, ui
             }
             run += v[j];
         }
-        __syncthreads();                                           // (waveSum is written again in the next tile)
     }
     if (threadIdx.x == 0) {
         if (out32) out32[n] = (uint32_t)carry;
@@ -3160,10 +3160,10 @@ void launch_flag_count(const Workspace& ws, uint32_t n, hipStream_t st)
     if (n) hipLaunchKernelGGL(flag_count_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), dim3(256), 0, st, ws.qflag, n, ws.midCount);
 }
 // small batches: ONE block counts, and hands the sixteen work-list counters to the host (pinned memory) itself
-__global__ __launch_bounds__(1024) void flag_count_small_kernel(const uint32_t* __restrict__ qflag, uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ hostCounts)
+__global__ __launch_bounds__(256) void flag_count_small_kernel(const uint32_t* __restrict__ qflag, uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ hostCounts)
 {
     uint32_t a = 0, c = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t f = qflag[i];
         a += f == kFlagSketch; c += f == kFlagCands;
     }
@@ -3176,7 +3176,7 @@ __global__ __launch_bounds__(1024) void flag_count_small_kernel(const uint32_t* 
 }
 void launch_flag_count_host(const Workspace& ws, uint32_t n, uint32_t* hostCounts, hipStream_t st)
 {
-    if (n && n <= kSmallScan) { hipLaunchKernelGGL(flag_count_small_kernel, dim3(1), dim3(1024), 0, st, ws.qflag, n, ws.midCount, hostCounts); return; }
+    if (n && n <= kSmallScan) { hipLaunchKernelGGL(flag_count_small_kernel, dim3(1), dim3(256), 0, st, ws.qflag, n, ws.midCount, hostCounts); return; }
     launch_flag_count(ws, n, st);
     launch_words_to_host(hostCounts, ws.midCount, 16, st);
 }
