@@ -341,8 +341,12 @@ int mc_create(const mc_config* cfg, mc_ctx** out)
     ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && cfg->slot_max_queries <= 8192;
     if (const char* e = std::getenv("MC_SLOT_COALESCE")) ctx->coalesce = cfg->num_slots >= 2 && !cfg->copy_allhits && e[0] != '0';
     if (ctx->coalesce) {
-        // dispatchers: one united batch each in flight -- as many as there were pipes (up to 8): few submitters find a free one at once
-        // (their slots go alone, as before), many find them busy and their slots wait together
+        // dispatchers: one united batch each in flight: few submitters find a free one at once (their slots go alone), many find them busy and
+        // their slots wait together.  FIVE: the runtime runs a process' streams on four hardware queues, and pipes that share one take turns
+        // (a united batch's chain of ~25 steps: 715 / 770 / 1 014 us with 4 / 6 / 8 pipes).  Same box, 4 096-read slots, 8 / 16 / 32 threads:
+        // 4 pipes 2 960 / 4 010-4 070 / 5 400-5 470, five 3 350 / 4 530-4 550 / 5 790-5 920, six 3 070-3 140 / 3 940-4 120 / 5 380-5 490,
+        // eight 3 030-3 060 / 3 930-3 960 / 5 320-5 400 Mreads/min (docs/LAB_NOTEBOOK_r06.md section 5b).  MC_PIPES / MC_SLOT_DISPATCHERS override.
+        if (!std::getenv("MC_PIPES")) npipes = std::min<uint32_t>(npipes, 5);
         if (const char* e = std::getenv("MC_SLOT_DISPATCHERS")) npipes = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
         // what a united batch may hold: up to 2^18 reads (beyond that the kernels run at their large-batch rate anyway), character offsets are 32 bits
         ctx->coMaxQueries = (uint32_t)std::max<uint64_t>(cfg->slot_max_queries, std::min<uint64_t>(1u << 18, (uint64_t)cfg->num_slots * cfg->slot_max_queries));
@@ -707,6 +711,21 @@ static int build_direct_index(mc_ctx* ctx)
     return MC_OK;
 }
 
+// A table that came through mc_load_* (not mc_open_database, whose loader reserves beside the file load): the slot pipes' workspaces are
+// sized now, once, for full (united) batches.  Left to the first batches every pipe grew its ~25 buffers batch by batch -- a hipFree (which waits
+// for the whole device) and a hipMalloc each: the first seconds of 32 threads on a fresh context ran at 3-100 Mreads/min instead of 5 000.
+// (A failure here is not one: the first batch asks again.)
+static void reserve_pipes_after_load(mc_ctx* ctx)
+{
+    if (ctx->pipes.empty() || ctx->reserveByLoader.load(std::memory_order_acquire) || std::getenv("MC_NO_RESERVE")) return;
+    uint64_t locs = 0;
+    for (auto& p : ctx->parts) locs += p.locations;
+    std::string keep = ctx->err;
+    (void)mcamd::reserve_slot_pipes(ctx, locs, ctx->parts[0].keysStored, false);
+    (void)hipGetLastError();
+    ctx->err = keep;
+}
+
 int mc_load_end(mc_ctx* ctx, uint32_t part)
 {
     if (!ctx) return MC_ERR_INVALID;
@@ -730,6 +749,7 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
         if (c[3]) return fail(ctx, MC_ERR_INVALID, "a location lies outside the range announced with mc_load_target_windows / mc_load_location_range");
         ctx->tableReady = true;
         (void)build_direct_index(ctx);                            // (a lookup structure beside the buckets: not having it is not an error)
+        reserve_pipes_after_load(ctx);
         return MC_OK;
     }
     if (T.hbuckets.empty()) { int rc = allocate_table(ctx); if (rc) return rc; }
@@ -746,6 +766,7 @@ int mc_load_end(mc_ctx* ctx, uint32_t part)
     HIP_TRY(ctx, hipMemcpy(T.dbuckets, T.hbuckets.data(), bytes, hipMemcpyHostToDevice));
     std::vector<TableBucket>().swap(T.hbuckets);
     ctx->tableReady = true;
+    reserve_pipes_after_load(ctx);
     return MC_OK;
 }
 
@@ -988,14 +1009,14 @@ static int size_pipe(mc_ctx* ctx, Pipe& P, uint32_t n, uint64_t numChars, bool w
 // every slot pipe sized for a full slot of reads of the usual length (see size_pipe): called by mc_open_database from a thread of its own
 // once the table is announced; `locs` / `keys`: the part headers' counts
 }  // extern "C" (the loader's helper below has C++ linkage)
-int mcamd::reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys)
+int mcamd::reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys, bool waitForStores)
 {
     if (!ctx || ctx->pipes.empty() || ctx->parts.empty()) return MC_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return MC_ERR_HIP;
     t_quietErrors = true;                                        // (the loader thread owns ctx->err)
     // The table comes first: a single-part table's location store is allocated when the index pass is through (announce_store /
     // allocate_values), and on a device the table nearly fills the pipes must not have taken its memory by then.
-    for (;;) {
+    for (; waitForStores;) {
         if (ctx->loadSettled.load(std::memory_order_acquire)) break;
         if (ctx->storesPlaced.load(std::memory_order_acquire) >= ctx->parts.size()) break;
         std::this_thread::sleep_for(std::chrono::microseconds(500));

@@ -122,7 +122,7 @@ struct OpenHints { int listAlign = -1; double listAlignShare = 1.0; int directIn
 OpenHints& open_hints();
 int allocate_values(mc_ctx* ctx);
 int allocate_buckets(mc_ctx* ctx, uint64_t nkeys);
-int reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys);
+int reserve_slot_pipes(mc_ctx* ctx, uint64_t locs, uint64_t keys, bool waitForStores = true);
 int reserve_query_pipes(mc_ctx* ctx, uint32_t n, uint64_t chars);
 int load_chunk_device_async(mc_ctx* ctx, const uint32_t* dkeys, const uint8_t* dsizes, const uint8_t* dvals, uint32_t nkeys, uint64_t fileVals, uint64_t stored);
 // dbload.cpp: a whole .cache file of a single-part context through reader threads, pinned slabs and a copy stream (between mc_load_begin
@@ -191,6 +191,7 @@ struct mc_ctx {
     int quadLookup = -1;                   // MC_QUAD_LOOKUP=0/1 forces the bucket fetch scheme of probe_cands (tests); -1 = by table size
     int listAlignWant = -1;                // mc_set_tuning "list_align" / MC_LIST_ALIGN: -1 = where the padded store stays below 1.5 x the plain one and fits, 0 / 1
     std::atomic<uint32_t> storesPlaced{0}; // single-part loads: location stores allocated (reserve_slot_pipes waits for the table before it takes memory)
+    std::atomic<bool> reserveByLoader{false};  // mc_open_database reserves the slot pipes on a thread of its own beside the file load; otherwise mc_load_end does (tables built through mc_load_*)
     std::atomic<bool> loadSettled{false};  // mc_open_database: the files are through (or the load failed)
     double listAlignShare = 1.0;           // announce_store: the padding (padded - plain store) may take this share of the device's free memory; the part set driver
                                            // lowers it to 1 / (parts it still has to place on the device) -- mcamd::open_hints

@@ -250,6 +250,7 @@ int mc_open_database(const char* name, const mc_config* cfgIn, mc_ctx** out)
         if (!rc && cfg.num_slots > 0 && !std::getenv("MC_NO_RESERVE")) {
             uint64_t locs = 0, keys = 0;
             for (const auto& P : ctx->parts) { locs += P.expectValues; keys += P.expectKeys; }
+            ctx->reserveByLoader.store(true, std::memory_order_release);
             reserve = std::thread([ctx, locs, keys] { (void)reserve_slot_pipes(ctx, locs, keys); });   // (a failure here is not one: the first batch asks again)
         }
         for (uint32_t p = 0; p < cfg.num_parts && !rc; ++p)
