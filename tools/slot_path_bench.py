@@ -54,9 +54,11 @@ def main():
         nb = args.reads // B
         # the device path's candidates of the first batches: what every slot must deliver
         want = db.query_bulk(seqs[: 150 * B * min(nb, 8)], np.arange(B * min(nb, 8) + 1, dtype=np.uint64) * np.uint64(150))
+        wantc = np.ascontiguousarray(want)
+        # (half a second untimed: the first enqueues of a process may fall into the runtime's slow submission state -- DESIGN 9 -- for a second or two)
+        drv.mc_slot_drive(db.h, seqs.ctypes.data_as(C.c_void_p), args.reads, 150, B, max(threads), C.c_double(0.5), wantc.ctypes.data_as(C.c_void_p), len(wantc), (C.c_uint64 * 4)())
         for T in threads:
             o = (C.c_uint64 * 4)()
-            wantc = np.ascontiguousarray(want)
             rc = drv.mc_slot_drive(db.h, seqs.ctypes.data_as(C.c_void_p), args.reads, 150, B, T, C.c_double(args.seconds), wantc.ctypes.data_as(C.c_void_p), len(wantc), o)
             done, bad, errs, el = [int(o[0])], [int(o[1])], ([f"rc {rc}, {int(o[2])} threads failed: " + L.mc_last_error(db.h).decode()] if rc else []), o[3] / 1e6
             n = sum(done) * B
