@@ -89,7 +89,7 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-        path = _build.build_library()
+        path = os.environ.get("MC_AMD_LIB") or _build.build_library()   # (MC_AMD_LIB: another build of the library, for A/B measurements)
         L = C.CDLL(path)
         L.mc_last_error.restype = C.c_char_p
         L.mc_last_error.argtypes = [C.c_void_p]

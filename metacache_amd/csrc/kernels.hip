@@ -164,9 +164,9 @@ size_t scan_tmp_bytes(uint32_t n) { return ((size_t)(n + kScanTile - 1) / kScanT
 // Small inputs (the batches of the host slots: 4 096 reads each, a few of them united): ONE block of 1 024 threads walks the input in
 // tiles of 4 096 with a running carry -- one launch instead of three.  A launch costs the host ~5 us and the stream a dependent
 // dispatch; at 30 launches for 0.1 ms of device work per batch the slot path is bound by them (docs/LAB_NOTEBOOK_r06.md section 5).
-constexpr uint32_t kSmallScan = 32768, kSmallScanBlock = 256, kSmallScanItems = 8;
+constexpr uint32_t kSmallScan = 16384, kSmallPlan = 32768, kSmallScanBlock = 256, kSmallScanItems = 16;   // (a tile of 4 096: plain scans up to four tiles -- beyond that three parallel kernels are shorter --, the fused plan, which stands for five steps, up to eight)
 // (256 threads: a block of 1 024 has to find sixteen free wave slots on ONE CU, which on a device busy with other pipes' kernels took
-// longer than its work; a tile of 2 048 elements costs one barrier: the waves' sums are double-buffered and every thread adds up the ones before its wave)
+// longer than its work; a tile of 4 096 elements costs one barrier: the waves' sums are double-buffered and every thread adds up the ones before its wave)
 template <typename Value>
 __device__ __forceinline__ void scan_one_block(const uint32_t n, Value value, uint32_t* __restrict__ out32, uint64_t* __restrict__ out64, uint64_t* hostTotal = nullptr)
 {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kSmallScanBlock) void plan_scan_small_kernel(BatchV
 }
 bool launch_plan_scan_small(const BatchView& b, const SketchParams& sp, uint32_t* winCount, uint32_t* winOff, uint32_t* zero32, hipStream_t st)
 {
-    if (b.n == 0 || b.n > kSmallScan) return false;                // (the caller takes the three-kernel way)
+    if (b.n == 0 || b.n > kSmallPlan) return false;                // (the caller takes the three-kernel way)
     hipLaunchKernelGGL(plan_scan_small_kernel, dim3(1), dim3(kSmallScanBlock), 0, st, b, sp, winCount, winOff, zero32);
     return true;
 }
@@ -3176,7 +3176,7 @@ __global__ __launch_bounds__(256) void flag_count_small_kernel(const uint32_t* _
 }
 void launch_flag_count_host(const Workspace& ws, uint32_t n, uint32_t* hostCounts, hipStream_t st)
 {
-    if (n && n <= kSmallScan) { hipLaunchKernelGGL(flag_count_small_kernel, dim3(1), dim3(256), 0, st, ws.qflag, n, ws.midCount, hostCounts); return; }
+    if (n && n <= kSmallPlan) { hipLaunchKernelGGL(flag_count_small_kernel, dim3(1), dim3(256), 0, st, ws.qflag, n, ws.midCount, hostCounts); return; }
     launch_flag_count(ws, n, st);
     launch_words_to_host(hostCounts, ws.midCount, 16, st);
 }
