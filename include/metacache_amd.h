@@ -188,8 +188,8 @@ int64_t mc_batch_add_bulk(mc_ctx* ctx, uint32_t slot, const char* seqs, const ui
 /* How the slots reach the device.  With two or more slots of up to 8 192 reads (and top candidates only: copy_allhits = 0) submissions
  * are QUEUED: a slot that finds a pipe free and nothing waiting goes out at once, everything else is taken by dispatcher threads of the
  * library -- whatever is waiting when a pipe comes free goes to the device as ONE batch (slots of the reference's size -- 4 096 reads,
- * options.hpp:229-232 -- are ~30 kernel launches and three host round trips for 0.1 ms of device work each; database_query.hpp:110-113
- * orders the submissions with a mutex instead); larger slots and MC_SLOT_COALESCE=0: every slot its own batch (MC_SLOT_COALESCE=1: united whatever their size).  stats[0] = 1 if slots are united,
+ * options.hpp:229-232 -- are a chain of ~25 dependent steps and two host round trips for 0.1 ms of device work each; database_query.hpp:110-113
+ * orders the submissions with a mutex instead; up to five dispatchers: the runtime's four hardware queues); larger slots and MC_SLOT_COALESCE=0: every slot its own batch (MC_SLOT_COALESCE=1: united whatever their size).  stats[0] = 1 if slots are united,
  * [1] = united batches sent so far, [2] = slots they carried, [3] = dispatcher threads. */
 int mc_slot_stats(mc_ctx* ctx, uint64_t stats[4]);
 /* "" or what the library has noticed about the HIP runtime in this process: the slot paths time their enqueue-only calls, and when these
