@@ -143,3 +143,38 @@ def test_part_groups_streamed_batch_by_batch_equal_classify(golden, resident, lo
             else:
                 assert got[i][j]["hits"] == 0
     odb.close()
+
+
+@pytest.mark.parametrize("big_min", [None, 0])
+def test_batch_sizes_around_the_small_batch_kernels_limits(golden, big_min):
+    """Batches of up to 16 384 / 32 768 reads take other steps on the stream than larger ones (kernels.hip: scan_small_kernel, plan_scan_small_kernel,
+    flag_count_small_kernel; context.cpp: one host round trip for the sorted class and the wave tail): a read's candidates must not depend on
+    the size of the batch it came in.  big_min = 0 sends the toy table's lists through the filtered path and its counting kernels."""
+    single, _, _ = golden.reads()
+    rng = np.random.default_rng(4096)
+    reads = [single[k] for k in rng.integers(0, len(single), 40000)]
+    chars = sum((len(r) + 3) // 4 * 4 for r in reads) + 64
+
+    def run(n_batch, n_reads):
+        db = api.Database.open(golden.db_path("toy32"), max_candidates=2, copy_allhits=0, slot_max_queries=n_batch, slot_max_chars=chars)
+        try:
+            if big_min is not None:
+                db.set_tuning("big_min", big_min)
+            c, _, _ = db.query(reads[:n_reads], lowest=0)
+            return c
+        finally:
+            db.close()
+
+    whole = run(40000, 40000)                                    # one batch beyond every limit
+    for n in (1, 4095, 4096, 4097, 16383, 16384, 16385, 32767, 32768, 32769):
+        got = run(n, n)
+        assert np.array_equal(got, whole[:n]), n
+    # ... nor on the batches before it on the same pipe (sizes going up and down: the pinned counters and the workspaces are reused)
+    db = api.Database.open(golden.db_path("toy32"), max_candidates=2, copy_allhits=0, slot_max_queries=5000, slot_max_chars=chars)
+    try:
+        if big_min is not None:
+            db.set_tuning("big_min", big_min)
+        c, _, _ = db.query(reads[:23000], lowest=0)              # 5 000, 5 000, 5 000, 5 000, 3 000
+        assert np.array_equal(c, whole[:23000])
+    finally:
+        db.close()
