@@ -86,24 +86,11 @@ static void note_enqueues(uint64_t ns, uint32_t calls)
     { std::lock_guard<std::mutex> l(g_warnMu); g_warning = msg; }
     std::fprintf(stderr, "%s\n", msg);
 }
-// MC_SPIN_SYNC (experiment): the host's waits inside a small batch by polling the stream instead of hipStreamSynchronize
-static const int g_spinSync = [] { const char* e = std::getenv("MC_SPIN_SYNC"); return e ? std::atoi(e) : 0; }();
-static hipError_t stream_wait(hipStream_t st)
-{
-    if (g_spinSync > 0) {
-        for (int i = 0; i < g_spinSync; ++i) {
-            const hipError_t e = hipStreamQuery(st);
-            if (e != hipErrorNotReady) return e;
-            for (int k = 0; k < 16; ++k) __builtin_ia32_pause();
-        }
-    }
-    return hipStreamSynchronize(st);
-}
 static hipError_t traced_sync(hipStream_t st)
 {
-    if (!g_submitTrace) return stream_wait(st);
+    if (!g_submitTrace) return hipStreamSynchronize(st);
     const uint64_t t0 = trace_now();
-    const hipError_t e = stream_wait(st);
+    const hipError_t e = hipStreamSynchronize(st);
     g_trace[3] += trace_now() - t0; ++g_trace[6];
     return e;
 }
