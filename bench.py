@@ -456,8 +456,8 @@ def reference_calibration(scale: float, K: int, lf: float, device: int, budget_s
 
 def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, steps, warmup, nb, per_read, kernel_only_s):
     """SURVEY 8(d) row 1, the host-fed form: the timed region's K batches once more, this time starting in PINNED HOST memory -- the upload
-    of batch i + 1 on an upload stream of its own under the kernels of batch i, the candidates copied back to pinned host memory
-    (mc_copy_results_on kind 1) inside the clock.  What a host application that parses reads itself can reach at most:
+    of batch i + 1 on an upload stream of its own under the kernels of batch i, the candidates copied out of the pipe's buffer on the device
+    and back to pinned host memory on a download stream (mc_copy_results_on kind 0, then kind 1) inside the clock.  What a host application that parses reads itself can reach at most:
     never `value`."""
     dev = qinfo.device
     srcs = [(long_batches[(warmup + i) % nb] if long_batches is not None else batches[(warmup + i) % nb]) for i in range(steps)]
@@ -474,10 +474,22 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
     # kernels fill the device: behind them the upload started a batch late, 30 ms per step instead of 18)
     dev_in = [torch.zeros(max(nbytes_in) + 16, dtype=torch.uint8, device=dev) for _ in range(3)]
     host_out = [torch.zeros((nloc, K, 4), dtype=torch.int32).pin_memory() for _ in range(2)]
-    up = torch.cuda.Stream(device=dev)
+    # the candidates leave the pipe's own buffer by a copy on the device (0.1 ms) and go to the host on a DOWNLOAD stream: 0.16 GB at the
+    # link's rate are 3 ms, which on the pipe's stream stood in front of the pipe's next batch
+    dev_out = [torch.zeros((nloc, K, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+    down = torch.cuda.Stream(device=dev)
+    out_ready = [torch.cuda.Event() for _ in range(2)]
+    out_free = [torch.cuda.Event() for _ in range(2)]
+    out_used = [False, False]
+    # the upload in NUP shares on as many streams (copy engines): MC_BENCH_UP_STREAMS, default 2
+    NUP = max(1, int(os.environ.get("MC_BENCH_UP_STREAMS", "1")))   # (measured: 1 -> 21.0, 2 -> 22.1, 3 -> 26.1 ms per step; one share runs at the link's 57 GB/s under the kernels)
+    ups = [torch.cuda.Stream(device=dev) for _ in range(NUP)]
+    up = ups[0]
     pipes = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    up_done = [torch.cuda.Event() for _ in range(3)]
+    up_done = [[torch.cuda.Event() for _ in range(NUP)] for _ in range(3)]
     in_free = [torch.cuda.Event() for _ in range(3)]
+    up_t0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]     # how long an upload takes UNDER the kernels (share 0's stream)
+    up_t1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     torch.cuda.synchronize()
     stage_s = time.perf_counter() - t0
     pend = {}
@@ -491,11 +503,19 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
 
     def upload(i):
         k = i % 3
-        with torch.cuda.stream(up):
-            if i >= 3:
-                up.wait_event(in_free[k])                    # batch i - 3 has read this buffer to its end (main kernels and tail)
-            dev_in[k][: nbytes_in[i]].copy_(host_in[i], non_blocking=True)
-            up_done[k].record(up)
+        share = (nbytes_in[i] + NUP - 1) // NUP // 256 * 256 + 256
+        for u, st in enumerate(ups):
+            lo, hi = min(nbytes_in[i], u * share), min(nbytes_in[i], (u + 1) * share)
+            with torch.cuda.stream(st):
+                if i >= 3:
+                    st.wait_event(in_free[k])                # batch i - 3 has read this buffer to its end (main kernels and tail)
+                if u == 0:
+                    up_t0[i].record(st)
+                if hi > lo:
+                    dev_in[k][lo:hi].copy_(host_in[i][lo:hi], non_blocking=True)
+                if u == 0:
+                    up_t1[i].record(st)
+                up_done[k][u].record(st)
 
     def finish_pipe(j):
         if j not in pend:
@@ -503,7 +523,14 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
         ptr, i = pend.pop(j)
         clocked("finish_call", db.query_finish, second_pipe=bool(j))
         in_free[i % 3].record(pipes[j])
-        clocked("d2h_call", db.copy_results, host_out[j].data_ptr(), ptr, nloc * K * 16, to_host=True, second_pipe=bool(j), stream=pipes[j].cuda_stream)
+        if out_used[j]:
+            pipes[j].wait_event(out_free[j])                 # (the download of this pipe's batch before last has left dev_out[j])
+        clocked("d2h_call", db.copy_results, dev_out[j].data_ptr(), ptr, nloc * K * 16, second_pipe=bool(j), stream=pipes[j].cuda_stream)
+        out_ready[j].record(pipes[j])
+        down.wait_event(out_ready[j])
+        clocked("d2h_call", db.copy_results, host_out[j].data_ptr(), dev_out[j].data_ptr(), nloc * K * 16, to_host=True, second_pipe=bool(j), stream=down.cuda_stream)
+        out_free[j].record(down)
+        out_used[j] = True
 
     def run():
         db.synchronize(); torch.cuda.synchronize()
@@ -515,7 +542,8 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
             j = i & 1
             if i + 1 < steps:
                 clocked("h2d_call", upload, i + 1)
-            pipes[j].wait_event(up_done[i % 3])
+            for e in up_done[i % 3]:
+                pipes[j].wait_event(e)
             src = dev_in[i % 3]
             if long_batches is not None:
                 lb = srcs[i]
@@ -533,6 +561,7 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
 
     run()                                                    # (first touch of the pinned buffers by the device)
     el = min(run(), run())
+    up_ms = sorted(up_t0[i].elapsed_time(up_t1[i]) for i in range(1, steps))   # (the last run's; share 0 of NUP)
     up_gb = sum(nbytes_in) / 1e9
     down = steps * nloc * K * 16 / 1e9
     # the link alone: the same uploads back to back, nothing else on the device
@@ -547,13 +576,15 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
     ratio = kernel_only_s / (el / steps)
     out = {"ms_per_step": round(ms, 3), "Mreads_min": round(steps * nloc * per_read / el * 60 / 1e6, 1), "h2d_GBps": round(up_gb / link_s, 1),
            "h2d_GB_per_step": round(up_gb / steps, 3), "d2h_GB_per_step": round(down / steps, 4), "over_kernel_only": round(ratio, 3),
+           "upload_streams": NUP, "h2d_ms_of_one_share_under_the_kernels_median": round(up_ms[len(up_ms) // 2], 2),
+           "h2d_GBps_under_the_kernels": round(up_gb / steps / NUP / (up_ms[len(up_ms) // 2] / 1e3), 1),
            "staging_s": round(stage_s, 1), "host_ms_per_step_inside_the_calls": {k: round(v / steps * 1e3, 3) for k, v in trace.items()},
-           "what": "the timed region's batches from pinned host memory: H2D of batch i+1 on an upload stream under batch i's kernels, candidates D2H to pinned memory, all inside the clock; best of 2"}
+           "what": "the timed region's batches from pinned host memory: H2D of batch i+1 on an upload stream under batch i's kernels, candidates copied out of the pipe's buffer on the device and D2H to pinned memory on a download stream, all inside the clock; best of 2"}
     if ratio < 0.8:
         h2d_ms = link_s / steps * 1e3
         out["bound"] = (f"PCIe: the upload alone takes {h2d_ms:.1f} ms per step at {up_gb / link_s:.0f} GB/s" if h2d_ms > 0.8 * ms else
                         f"neither the link ({h2d_ms:.1f} ms per step) nor the kernels ({kernel_only_s * 1e3:.1f}): the copies and the kernels do not overlap fully")
-    del host_in, dev_in, host_out
+    del host_in, dev_in, host_out, dev_out
     return out
 
 
