@@ -678,18 +678,28 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         return r;
     };
     size_t inFlightFrom = 0;                                       // batches [inFlightFrom, b) are submitted and not finished
+    // The upload of batch b + 1 is ENQUEUED right behind the submission of batch b, before this thread goes into finish(b - 1): that call
+    // waits for batch b - 1's tail, whose few small kernels get their CUs only when batch b's persistent kernels end -- an upload enqueued
+    // after it started when the device had nothing left to run beside it, and a batch took upload + kernels (the stream's timeline at
+    // 15 Gbp: 1.06 + 1.1 ms per 250 000 reads; lab notebook r06 section 2c).  preInput: the device input that upload went to.
+    int preInput = -1;
+    size_t preFor = (size_t)-1;
     for (size_t b = 0; b < nbt && !rc; ++b) {
         const uint64_t t0 = now_ns();
         { std::unique_lock<std::mutex> l(qMu); qCv.wait(l, [&] { return packed > b; }); }
         const uint64_t t1 = now_ns();
         // nothing is waited for while this caller holds a lane: its own oldest batch gives a lane and an input back, else another caller will
-        int k = take_input(ps, false);
-        while (k < 0 && !rc) {
-            if (inFlightFrom < b) { rc = finish(inFlightFrom++); if (!rc) k = take_input(ps, false); }
-            else k = take_input(ps, true);
+        int k = -1;
+        if (preFor == b) { k = preInput; preInput = -1; preFor = (size_t)-1; }
+        else {
+            k = take_input(ps, false);
+            while (k < 0 && !rc) {
+                if (inFlightFrom < b) { rc = finish(inFlightFrom++); if (!rc) k = take_input(ps, false); }
+                else k = take_input(ps, true);
+            }
+            if (rc) break;
+            rc = upload_batch(ps, ps->stg[slotOf[b]], k);          // (enqueued before anything below waits: it runs under the batch before)
         }
-        if (rc) break;
-        rc = upload_batch(ps, ps->stg[slotOf[b]], k);              // (enqueued before anything below waits: it runs under the batch before)
         int ln = rc ? -1 : take_lane(ps, false);
         while (ln < 0 && !rc) {
             if (inFlightFrom < b) { rc = finish(inFlightFrom++); if (!rc) ln = take_lane(ps, false); }
@@ -700,8 +710,19 @@ int mc_partset_classify_resident(mc_partset* ps, const char* seqs, const uint64_
         rc = submit_batch(ps, ps->stg[slotOf[b]], ln, k, lowestRank);
         tPackWait += t1 - t0; tSubmit += now_ns() - t1;
         if (rc) { give_lane(ps, ln); laneOf[b & 1] = -1; give_input(ps, k); inputOf[b & 1] = -1; break; }
+        if (b + 1 < nbt) {                                          // the next batch's upload, if it is packed and an input is free -- no waiting here
+            bool ready;
+            { std::lock_guard<std::mutex> l(qMu); ready = packed > b + 1; }
+            const int k2 = ready ? take_input(ps, false) : -1;
+            if (k2 >= 0) {
+                rc = upload_batch(ps, ps->stg[slotOf[b + 1]], k2);
+                if (rc) { give_input(ps, k2); break; }
+                preInput = k2; preFor = b + 1;
+            }
+        }
         if (inFlightFrom < b) rc = finish(inFlightFrom++);          // the batch before this one: its kernels ran while this one was enqueued
     }
+    if (preInput >= 0) { idle_devices(ps); give_input(ps, preInput); preInput = -1; }   // (an error after an upload ahead: the copy is through before its input goes back)
     const size_t submitted = rc ? inFlightFrom : nbt;
     while (!rc && inFlightFrom < submitted) rc = finish(inFlightFrom++);
     if (nbt > 1) {
