@@ -561,7 +561,7 @@ def host_fed_leg(db, batches, long_batches, qinfo, nloc, nchars, max_win, K, ste
 
     run()                                                    # (first touch of the pinned buffers by the device)
     el = min(run(), run())
-    up_ms = sorted(up_t0[i].elapsed_time(up_t1[i]) for i in range(1, steps))   # (the last run's; share 0 of NUP)
+    up_ms = sorted(up_t0[i].elapsed_time(up_t1[i]) for i in range(min(1, steps - 1), steps))   # (the last run's; share 0 of NUP; without the first, which has nothing beside it)
     up_gb = sum(nbytes_in) / 1e9
     down = steps * nloc * K * 16 / 1e9
     # the link alone: the same uploads back to back, nothing else on the device
